@@ -1,0 +1,140 @@
+"""ctypes view of include/dartray_hip.h and the loader of libdartray_hip.so.
+
+The product path never falls back to a CPU implementation: if the HIP library
+is missing, loading raises and every operator fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdartray_hip.so")
+
+DR_OK = 0
+DR_INTEGRATOR_DIRECT_ALL = 0
+DR_INTEGRATOR_PATH = 1
+DR_SAMPLER_HOST_BUFFER = 0
+DR_SAMPLER_COUNTER = 1
+
+
+class DrBvhNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("offset", C.c_uint32),
+                ("nprims", C.c_uint16), ("axis", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class DrMaterial(C.Structure):
+    _fields_ = [("kd", C.c_float * 3), ("sigma", C.c_float)]
+
+
+class DrAreaLight(C.Structure):
+    _fields_ = [("L", C.c_float * 3), ("nsamples", C.c_int32), ("first_tri", C.c_uint32), ("ntris", C.c_uint32)]
+
+
+class DrLightTri(C.Structure):
+    _fields_ = [("v", C.c_uint32 * 3), ("reverse_orientation", C.c_uint32)]
+
+
+class DrSceneDesc(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("nnodes", C.c_uint64),
+                ("verts", C.c_void_p), ("nverts", C.c_uint64),
+                ("tri_idx", C.c_void_p), ("ntris", C.c_uint64),
+                ("tri_material", C.c_void_p), ("tri_light", C.c_void_p), ("tri_reverse", C.c_void_p),
+                ("materials", C.c_void_p), ("nmaterials", C.c_uint32),
+                ("lights", C.c_void_p), ("nlights", C.c_uint32),
+                ("light_tris", C.c_void_p), ("nlight_tris", C.c_uint32),
+                ("bvh_depth", C.c_uint32)]
+
+
+class DrRay(C.Structure):
+    _fields_ = [("o", C.c_float * 3), ("d", C.c_float * 3), ("tmin", C.c_double), ("tmax", C.c_double)]
+
+
+class DrHit(C.Structure):
+    _fields_ = [("prim", C.c_int32), ("pad", C.c_int32), ("t", C.c_double), ("b1", C.c_double), ("b2", C.c_double)]
+
+
+class DrCamera(C.Structure):
+    _fields_ = [("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float)]
+
+
+class DrFilm(C.Structure):
+    _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_float * 4),
+                ("filter_xw", C.c_float), ("filter_yw", C.c_float), ("filter_table", C.c_float * 256)]
+
+
+class DrRenderDesc(C.Structure):
+    _fields_ = [("camera", DrCamera), ("film", DrFilm),
+                ("integrator", C.c_int32), ("max_depth", C.c_int32), ("spp", C.c_int32), ("sampler_mode", C.c_int32),
+                ("seed", C.c_int64),
+                ("task_num", C.c_int32), ("task_count", C.c_int32),
+                ("tile_rank", C.c_int32), ("tile_count", C.c_int32), ("tile_size", C.c_int32),
+                ("nsamples", C.c_int64),
+                ("pixel_xy", C.c_void_p), ("sample_vec", C.c_void_p), ("sample_stride", C.c_int32),
+                ("tail", C.c_void_p), ("max_tail", C.c_int32)]
+
+
+class DrRenderStats(C.Structure):
+    _fields_ = [("camera_samples", C.c_uint64), ("film_samples", C.c_uint64),
+                ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64),
+                ("closest_nodes", C.c_uint64), ("any_nodes", C.c_uint64),
+                ("closest_tris", C.c_uint64), ("any_tris", C.c_uint64),
+                ("trace_launches", C.c_uint64), ("trace_ms", C.c_double), ("total_ms", C.c_double),
+                ("batches", C.c_uint64)]
+
+
+# name -> (restype, argtypes): every symbol include/dartray_hip.h declares.
+EXPORTS = {
+    "dr_init": (C.c_int, [C.c_int]),
+    "dr_bvh_build": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
+                               C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint32)]),
+    "dr_scene_create": (C.c_int, [C.POINTER(DrSceneDesc), C.POINTER(C.c_void_p)]),
+    "dr_scene_destroy": (None, [C.c_void_p]),
+    "dr_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
+    "dr_sample_floats": (C.c_int32, [C.c_int32, C.c_uint32]),
+    "dr_render": (C.c_int, [C.c_void_p, C.POINTER(DrRenderDesc), C.c_void_p, C.c_void_p]),
+    "dr_render_device": (C.c_int, [C.c_void_p, C.POINTER(DrRenderDesc), C.c_void_p, C.c_void_p]),
+    "dr_film_resolve_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(DrRenderStats)]),
+    "dr_copy_bandwidth": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
+    "dr_last_error": (C.c_char_p, []),
+    "dr_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class DartRayHipError(RuntimeError):
+    """Raised for every non-zero return code of the C ABI (the Dart shim maps
+    it to LogSevere -> Exception, lib/core/log.dart:42-47)."""
+
+
+def lib():
+    """Load libdartray_hip.so (built in-tree by __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DartRayHipError(
+                "HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != DR_OK:
+        raise DartRayHipError("dartray_hip error %d: %s" % (rc, lib().dr_last_error().decode()))
+
+
+_initialised = None
+
+
+def init(device=0):
+    global _initialised
+    if _initialised != device:
+        check(lib().dr_init(device))
+        _initialised = device

@@ -1,0 +1,620 @@
+"""Host-side mirror of the reference's plugin interface for the hot path.
+
+The reference is Dart; no Dart SDK exists in this image, so the host code above
+the C ABI is written in Python with the reference's class names, constructor
+arguments and error behaviour (a failing native call raises, like LogSevere,
+lib/core/log.dart:42-47).  Each class cites the Dart class it mirrors; the
+compute itself happens in libdartray_hip.so.
+
+    prims   = [GeometricPrimitive(TriangleMesh(...), MatteMaterial(Kd), DiffuseAreaLight(L) or None), ...]
+    accel   = BVHAccel(prims)                               # lib/accelerators/bvh_accel.dart
+    scene   = Scene(accel, lights)                          # lib/core/scene.dart
+    film    = ImageFilm(64, 64, BoxFilter(0.5, 0.5))        # lib/film/image_film.dart
+    camera  = PerspectiveCamera.lookAt(pos, look, up, fov, film)
+    sampler = LowDiscrepancySampler(camera, 4)
+    out     = SamplerRenderer(sampler, camera, PathIntegrator(5), EmissionIntegrator()).render(scene)
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi
+from ._abi import DartRayHipError  # noqa: F401  (re-export)
+
+
+# ---------------------------------------------------------------------------
+# shapes, materials, lights (lib/shapes/triangle_mesh.dart, lib/materials/matte_material.dart,
+# lib/lights/diffuse_area_light.dart, lib/core/primitive/geometric_primitive.dart)
+# ---------------------------------------------------------------------------
+class TriangleMesh:
+    """shapes/triangle_mesh.dart:23-36.  P is already in world space (the
+    reference pre-transforms vertices to world space, f32)."""
+
+    def __init__(self, vertexIndex, P, reverseOrientation=False):
+        self.vertexIndex = np.ascontiguousarray(vertexIndex, dtype=np.uint32).reshape(-1, 3)
+        self.P = np.ascontiguousarray(P, dtype=np.float32).reshape(-1, 3)
+        self.reverseOrientation = bool(reverseOrientation)
+        if self.vertexIndex.size and int(self.vertexIndex.max()) >= len(self.P):
+            raise ValueError("TriangleMesh has out of-bounds vertex index")  # triangle_mesh.dart:160-166
+
+    @property
+    def ntris(self):
+        return len(self.vertexIndex)
+
+    def canIntersect(self):
+        return False  # triangle_mesh.dart:79-81
+
+    def refine(self):
+        """Triangle order after Primitive.fullyRefine / ShapeSet: the todo list
+        is a LIFO stack, so triangles come out reversed (primitive.dart:71-84,
+        shape_set.dart:25-35)."""
+        return np.arange(self.ntris - 1, -1, -1, dtype=np.int64)
+
+
+class MatteMaterial:
+    """materials/matte_material.dart:37-77 with constant textures."""
+
+    def __init__(self, Kd=(0.5, 0.5, 0.5), sigma=0.0):
+        self.Kd = np.asarray(Kd, dtype=np.float32).reshape(3)
+        self.sigma = float(sigma)
+
+
+class DiffuseAreaLight:
+    """lights/diffuse_area_light.dart:36-43."""
+
+    def __init__(self, L=(1.0, 1.0, 1.0), nSamples=1, shape=None):
+        self.Lemit = np.asarray(L, dtype=np.float32).reshape(3)
+        self.nSamples = max(1, int(nSamples))
+        self.shape = shape
+
+
+class GeometricPrimitive:
+    """core/primitive/geometric_primitive.dart:27-29."""
+
+    def __init__(self, shape, material, areaLight=None):
+        self.shape = shape
+        self.material = material
+        self.areaLight = areaLight
+        if areaLight is not None and areaLight.shape is None:
+            areaLight.shape = shape
+
+    def getAreaLight(self):
+        return self.areaLight
+
+
+class Ray:
+    """Batch of core/ray.dart rays (o, d f32; minDistance/maxDistance f64)."""
+
+    def __init__(self, origin, direction, minDistance=0.0, maxDistance=math.inf):
+        self.origin = np.ascontiguousarray(origin, dtype=np.float32).reshape(-1, 3)
+        self.direction = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)
+        n = len(self.origin)
+        self.minDistance = np.broadcast_to(np.asarray(minDistance, dtype=np.float64), (n,)).copy()
+        self.maxDistance = np.broadcast_to(np.asarray(maxDistance, dtype=np.float64), (n,)).copy()
+
+    def __len__(self):
+        return len(self.origin)
+
+    def to_abi(self):
+        arr = (_abi.DrRay * len(self))()
+        buf = np.frombuffer(arr, dtype=np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("tmin", "<f8"), ("tmax", "<f8")]))
+        buf["o"] = self.origin
+        buf["d"] = self.direction
+        buf["tmin"] = self.minDistance
+        buf["tmax"] = self.maxDistance
+        return arr
+
+
+HIT_DTYPE = np.dtype([("prim", "<i4"), ("pad", "<i4"), ("t", "<f8"), ("b1", "<f8"), ("b2", "<f8")])
+NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<u4"), ("nprims", "<u2"),
+                       ("axis", "u1"), ("pad", "u1")])
+
+
+# ---------------------------------------------------------------------------
+# BVHAccel (lib/accelerators/bvh_accel.dart) -- the Aggregate of the scene
+# ---------------------------------------------------------------------------
+class BVHAccel:
+    """Aggregate 'bvh' (accelerators/bvh_accel.dart:36-91).
+
+    The constructor refines the primitives, runs the SAH build (host C++ behind
+    dr_bvh_build) and keeps the flattened arrays a Dart-side shim would marshal:
+    `nodes` (32-byte _LinearBVHNode records) and the per-primitive tables in
+    `primitives` order."""
+
+    def __init__(self, p, maxPrims=4, splitMethod="sah"):
+        if splitMethod != "sah":
+            raise NotImplementedError("only the default 'sah' split method is on the path")
+        self.maxPrimsInNode = min(255, int(maxPrims))
+        self.prims_in = list(p)
+        verts, tri, mat, lightOf, rev = [], [], [], [], []
+        base = 0
+        self.materials = []
+        self._lights = []  # DiffuseAreaLight objects in first-seen order
+        for gp in self.prims_in:
+            mesh = gp.shape
+            order = mesh.refine()
+            verts.append(mesh.P)
+            tri.append(mesh.vertexIndex[order].astype(np.uint32) + np.uint32(base))
+            mid = len(self.materials)
+            self.materials.append(gp.material)
+            mat.append(np.full(len(order), mid, dtype=np.uint32))
+            li = -1
+            if gp.areaLight is not None:
+                if gp.areaLight not in self._lights:
+                    self._lights.append(gp.areaLight)
+                li = self._lights.index(gp.areaLight)
+            lightOf.append(np.full(len(order), li, dtype=np.int32))
+            rev.append(np.full(len(order), 1 if mesh.reverseOrientation else 0, dtype=np.uint8))
+            base += len(mesh.P)
+        self.verts = np.ascontiguousarray(np.concatenate(verts) if verts else np.zeros((0, 3), np.float32))
+        refined = np.ascontiguousarray(np.concatenate(tri) if tri else np.zeros((0, 3), np.uint32))
+        mat = np.concatenate(mat) if mat else np.zeros(0, np.uint32)
+        lightOf = np.concatenate(lightOf) if lightOf else np.zeros(0, np.int32)
+        rev = np.concatenate(rev) if rev else np.zeros(0, np.uint8)
+        n = len(refined)
+        lib = _abi.lib()
+        nodes = np.zeros(max(2 * n - 1, 1), dtype=NODE_DTYPE)
+        order = np.zeros(max(n, 1), dtype=np.uint32)
+        nn = C.c_uint64(0)
+        depth = C.c_uint32(0)
+        _abi.check(lib.dr_bvh_build(self.verts.ctypes.data, len(self.verts), refined.ctypes.data, n,
+                                    self.maxPrimsInNode, nodes.ctypes.data, C.byref(nn), order.ctypes.data,
+                                    C.byref(depth)))
+        order = order[:n]
+        self.nodes = nodes[:nn.value] if n else None  # bvh_accel.dart:50-53
+        self.depth = int(depth.value)
+        self.order = order
+        # BVHAccel.primitives (orderedPrims, bvh_accel.dart:69-76)
+        self.tri_idx = np.ascontiguousarray(refined[order])
+        self.tri_material = np.ascontiguousarray(mat[order])
+        self.tri_light = np.ascontiguousarray(lightOf[order])
+        self.tri_reverse = np.ascontiguousarray(rev[order])
+        self._scene = None
+
+    @staticmethod
+    def Create(prims, ps=None):  # bvh_accel.dart:474-482
+        ps = ps or {}
+        return BVHAccel(prims, ps.get("maxnodeprims", 4), ps.get("splitmethod", "sah"))
+
+    @property
+    def primitives(self):
+        return self.tri_idx
+
+    def canIntersect(self):
+        return True
+
+    def worldBound(self):  # bvh_accel.dart:93-95
+        if self.nodes is None:
+            return (np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32))
+        return (self.nodes[0]["bmin"].copy(), self.nodes[0]["bmax"].copy())
+
+    def lights(self):
+        """One DiffuseAreaLight per emissive shape (dartray.dart:398-401)."""
+        return list(self._lights)
+
+    # --- device scene (created lazily, shared with Scene) ---
+    def _device_scene(self, lights=None):
+        if self._scene is None:
+            self._scene = _DeviceScene(self, self._lights if lights is None else lights)
+        return self._scene
+
+    def intersect(self, ray):
+        """Aggregate.intersect (bvh_accel.dart:101-165) on a batch: returns a
+        structured array (prim, t, b1, b2); prim == -1 is a miss."""
+        return self._device_scene().intersect(ray, any_hit=False)
+
+    def intersectP(self, ray):
+        """Aggregate.intersectP (bvh_accel.dart:167-226): bool per ray."""
+        return self._device_scene().intersect(ray, any_hit=True)["prim"] >= 0
+
+    def stats(self):
+        return self._device_scene().stats()
+
+
+class _DeviceScene:
+    """Owns the DrScene handle (scene arrays resident in HBM)."""
+
+    def __init__(self, accel, lights):
+        _abi.init(_abi._initialised if _abi._initialised is not None else 0)
+        lib = _abi.lib()
+        self.accel = accel
+        self.lights = list(lights)
+        mats = (_abi.DrMaterial * max(len(accel.materials), 1))()
+        for i, m in enumerate(accel.materials):
+            mats[i].kd[:] = [float(x) for x in m.Kd]
+            mats[i].sigma = m.sigma
+        # lights: ShapeSet triangle lists in refine (reversed) order (shape_set.dart:25-35)
+        dl = (_abi.DrAreaLight * max(len(self.lights), 1))()
+        ltris = []
+        base_of = {}
+        base = 0
+        for gp in accel.prims_in:
+            base_of[id(gp.shape)] = base
+            base += len(gp.shape.P)
+        for i, L in enumerate(self.lights):
+            mesh = L.shape
+            first = len(ltris)
+            for t in mesh.refine():
+                v = mesh.vertexIndex[t] + base_of[id(mesh)]
+                ltris.append((int(v[0]), int(v[1]), int(v[2]), 1 if mesh.reverseOrientation else 0))
+            dl[i].L[:] = [float(x) for x in L.Lemit]
+            dl[i].nsamples = L.nSamples
+            dl[i].first_tri = first
+            dl[i].ntris = len(ltris) - first
+        lt = (_abi.DrLightTri * max(len(ltris), 1))()
+        for i, t in enumerate(ltris):
+            lt[i].v[:] = t[:3]
+            lt[i].reverse_orientation = t[3]
+        d = _abi.DrSceneDesc()
+        n = len(accel.tri_idx)
+        self._keep = (mats, dl, lt)
+        d.nodes = accel.nodes.ctypes.data if accel.nodes is not None else None
+        d.nnodes = len(accel.nodes) if accel.nodes is not None else 0
+        d.verts = accel.verts.ctypes.data
+        d.nverts = len(accel.verts)
+        d.tri_idx = accel.tri_idx.ctypes.data
+        d.ntris = n
+        d.tri_material = accel.tri_material.ctypes.data
+        d.tri_light = accel.tri_light.ctypes.data
+        d.tri_reverse = accel.tri_reverse.ctypes.data
+        d.materials = C.cast(mats, C.c_void_p)
+        d.nmaterials = len(accel.materials)
+        d.lights = C.cast(dl, C.c_void_p)
+        d.nlights = len(self.lights)
+        d.light_tris = C.cast(lt, C.c_void_p)
+        d.nlight_tris = len(ltris)
+        d.bvh_depth = accel.depth
+        h = C.c_void_p()
+        _abi.check(lib.dr_scene_create(C.byref(d), C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _abi.lib().dr_scene_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def intersect(self, ray, any_hit):
+        n = len(ray)
+        out = np.zeros(n, dtype=HIT_DTYPE)
+        if n:
+            arr = ray.to_abi()
+            _abi.check(_abi.lib().dr_intersect(self.handle, C.cast(arr, C.c_void_p), n, out.ctypes.data, 1 if any_hit else 0))
+        return out
+
+    def stats(self):
+        s = _abi.DrRenderStats()
+        _abi.check(_abi.lib().dr_get_stats(self.handle, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _abi.DrRenderStats._fields_}
+
+
+class Scene:
+    """core/scene.dart:26-45."""
+
+    def __init__(self, aggregate, lights, volumeRegion=None):
+        if volumeRegion is not None:
+            raise NotImplementedError("participating media are not on the path")
+        self.aggregate = aggregate
+        self.lights = list(lights)
+        self.volumeRegion = None
+        self.worldBound = aggregate.worldBound()
+
+    def _device(self):
+        return self.aggregate._device_scene(self.lights)
+
+    def intersect(self, ray):  # scene.dart:51-56
+        return self.aggregate.intersect(ray)
+
+    def intersectP(self, ray):  # scene.dart:63-68
+        return self.aggregate.intersectP(ray)
+
+
+# ---------------------------------------------------------------------------
+# filter, film, camera (lib/filters/box_filter.dart, lib/film/image_film.dart,
+# lib/cameras/perspective_camera.dart, lib/core/projective_camera.dart)
+# ---------------------------------------------------------------------------
+class BoxFilter:
+    def __init__(self, xw=0.5, yw=0.5):  # box_filter.dart:33-46
+        self.xWidth = float(xw)
+        self.yWidth = float(yw)
+
+    def evaluate(self, x, y):
+        return 1.0
+
+
+FILTER_TABLE_SIZE = 16  # image_film.dart:307
+
+
+class ImageFilm:
+    def __init__(self, xres, yres, filter=None, cropWindow=(0.0, 1.0, 0.0, 1.0)):
+        self.xResolution = int(xres)
+        self.yResolution = int(yres)
+        self.filter = filter or BoxFilter()
+        self.cropWindow = tuple(float(c) for c in cropWindow)
+        # image_film.dart:61-65
+        self.left = math.ceil(self.xResolution * self.cropWindow[0])
+        self.width = max(1, math.ceil(self.xResolution * self.cropWindow[1]) - self.left)
+        self.top = math.ceil(self.yResolution * self.cropWindow[2])
+        self.height = max(1, math.ceil(self.yResolution * self.cropWindow[3]) - self.top)
+        # image_film.dart:74-82
+        t = np.zeros(FILTER_TABLE_SIZE * FILTER_TABLE_SIZE, dtype=np.float32)
+        fi = 0
+        for y in range(FILTER_TABLE_SIZE):
+            fy = (y + 0.5) * self.filter.yWidth / FILTER_TABLE_SIZE
+            for x in range(FILTER_TABLE_SIZE):
+                fx = (x + 0.5) * self.filter.xWidth / FILTER_TABLE_SIZE
+                t[fi] = self.filter.evaluate(fx, fy)
+                fi += 1
+        self.filterTable = t
+
+    def getSampleExtent(self):  # image_film.dart:247-252
+        return (math.floor(self.left + 0.5 - self.filter.xWidth),
+                math.ceil(self.left + 0.5 + self.width + self.filter.xWidth),
+                math.floor(self.top + 0.5 - self.filter.yWidth),
+                math.ceil(self.top + 0.5 + self.height + self.filter.yWidth))
+
+    def to_abi(self, f):
+        f.xres, f.yres = self.xResolution, self.yResolution
+        f.crop[:] = self.cropWindow
+        f.filter_xw, f.filter_yw = self.filter.xWidth, self.filter.yWidth
+        f.filter_table[:] = [float(v) for v in self.filterTable]
+
+
+def _m4(a):
+    return np.asarray(a, dtype=np.float64).astype(np.float32).reshape(4, 4)
+
+
+def _mul(a, b):  # Matrix4x4.Mul: f64 expression, f32 store (matrix4x4.dart:193-206)
+    return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+
+
+def _inv(a):  # Matrix4x4.Inverse (matrix4x4.dart:208-343) -- host logic, evaluated in f64, stored f32
+    return np.linalg.inv(a.astype(np.float64)).astype(np.float32)
+
+
+def _normalize(v):
+    v = np.asarray(v, dtype=np.float32).astype(np.float64)
+    return (v / math.sqrt(float(v @ v))).astype(np.float32)
+
+
+def look_at(pos, look, up):
+    """Transform.LookAt (transform.dart:301-329): returns camera-to-world."""
+    pos = np.asarray(pos, np.float32)
+    look = np.asarray(look, np.float32)
+    d = _normalize((look.astype(np.float64) - pos.astype(np.float64)).astype(np.float32))
+    upn = _normalize(up)
+    left = _normalize(np.cross(upn.astype(np.float64), d.astype(np.float64)).astype(np.float32))
+    new_up = np.cross(d.astype(np.float64), left.astype(np.float64)).astype(np.float32)
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 0] = left
+    m[:3, 1] = new_up
+    m[:3, 2] = d
+    m[:3, 3] = pos
+    return m
+
+
+class PerspectiveCamera:
+    """cameras/perspective_camera.dart:46-57 + core/projective_camera.dart:34-53."""
+
+    def __init__(self, cam2world, screenWindow, sopen, sclose, lensr, focald, fov, film):
+        self.cameraToWorld = _m4(cam2world)
+        self.shutterOpen, self.shutterClose = float(sopen), float(sclose)
+        self.lensRadius, self.focalDistance = float(lensr), float(focald)
+        self.film = film
+        znear, zfar = 1.0e-2, 1000.0
+        persp = _m4([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, zfar / (zfar - znear), -zfar * znear / (zfar - znear)], [0, 0, 1, 0]])
+        inv_tan = 1.0 / math.tan(((math.pi / 180.0) * fov) / 2.0)  # transform.dart:338-349
+        scale = _m4(np.diag([inv_tan, inv_tan, 1.0, 1.0]))
+        scale_inv = _m4(np.diag([1.0 / inv_tan, 1.0 / inv_tan, 1.0, 1.0]))
+        c2s = _mul(scale, persp)
+        c2s_inv = _mul(_inv(persp), scale_inv)
+        sw = [float(s) for s in screenWindow]
+        s1 = _m4(np.diag([float(film.xResolution), float(film.yResolution), 1.0, 1.0]))
+        s1i = _m4(np.diag([1.0 / film.xResolution, 1.0 / film.yResolution, 1.0, 1.0]))
+        s2 = _m4(np.diag([1.0 / (sw[1] - sw[0]), 1.0 / (sw[2] - sw[3]), 1.0, 1.0]))
+        s2i = _m4(np.diag([1.0 / (1.0 / (sw[1] - sw[0])), 1.0 / (1.0 / (sw[2] - sw[3])), 1.0, 1.0]))
+        tr = np.eye(4, dtype=np.float32)
+        tr[0, 3], tr[1, 3] = np.float32(-sw[0]), np.float32(-sw[3])
+        tri = np.eye(4, dtype=np.float32)
+        tri[0, 3], tri[1, 3] = -tr[0, 3], -tr[1, 3]
+        # screenToRaster = Scale * Scale * Translate; its inverse multiplies the inverses in reverse order
+        r2s = _mul(tri, _mul(s2i, s1i))
+        self.rasterToCamera = _mul(c2s_inv, r2s)
+        self.cameraToScreen = c2s
+        del s1, s2  # forward matrices are not needed on the path
+
+    @staticmethod
+    def lookAt(pos, look, up, fov, film, lensradius=0.0, focaldistance=1.0e30, shutteropen=0.0, shutterclose=1.0):
+        """'LookAt' + Camera "perspective" defaults (perspective_camera.dart:134-183)."""
+        frame = film.xResolution / film.yResolution
+        if frame > 1.0:
+            screen = [-frame, frame, -1.0, 1.0]
+        else:
+            screen = [-1.0, 1.0, -1.0 / frame, 1.0 / frame]
+        return PerspectiveCamera(look_at(pos, look, up), screen, shutteropen, shutterclose, lensradius, focaldistance,
+                                 fov, film)
+
+    def to_abi(self, c):
+        c.raster_to_camera[:] = [float(v) for v in self.rasterToCamera.reshape(-1)]
+        c.camera_to_world[:] = [float(v) for v in self.cameraToWorld.reshape(-1)]
+        c.lens_radius, c.focal_distance = self.lensRadius, self.focalDistance
+        c.shutter_open, c.shutter_close = self.shutterOpen, self.shutterClose
+
+
+# ---------------------------------------------------------------------------
+# samplers and integrators
+# ---------------------------------------------------------------------------
+def RoundUpPow2(v):  # common.dart:113-123
+    v -= 1
+    v |= v >> 1
+    v |= v >> 2
+    v |= v >> 4
+    v |= v >> 8
+    v |= v >> 16
+    return v + 1
+
+
+class LowDiscrepancySampler:
+    """samplers/low_discrepancy_sampler.dart:32-88.  The reference threads ONE
+    serial RNG through sampler and integrator (sampler_renderer.dart:137); on
+    the device every (pixel, LD block) owns a keyed stream instead
+    (DR_SAMPLER_COUNTER), or the caller supplies recorded sample vectors
+    (HostBufferSampler)."""
+
+    def __init__(self, camera, nsamp=4, seed=5489):
+        self.camera = camera
+        self.samplesPerPixel = RoundUpPow2(int(nsamp))
+        self.seed = int(seed)
+
+    def roundSize(self, size):
+        return RoundUpPow2(size)
+
+
+class HostBufferSampler:
+    """Explicit camera samples: pixel_xy [npix,2] int32, sample_vec [npix*spp, nfloats] f32
+    (imageU, imageV, lensU, lensV, time, oneD..., twoD...), tail [npix*spp, max_tail] f64 =
+    the RNG.randomFloat() values PathIntegrator.Li draws for bounces >= 3."""
+
+    def __init__(self, camera, spp, pixel_xy, sample_vec, tail=None):
+        self.camera = camera
+        self.samplesPerPixel = int(spp)
+        self.pixel_xy = np.ascontiguousarray(pixel_xy, dtype=np.int32).reshape(-1, 2)
+        self.sample_vec = np.ascontiguousarray(sample_vec, dtype=np.float32)
+        self.tail = None if tail is None else np.ascontiguousarray(tail, dtype=np.float64)
+        if len(self.sample_vec) != len(self.pixel_xy) * self.samplesPerPixel:
+            raise ValueError("sample_vec must hold spp vectors per pixel")
+
+
+class PathIntegrator:
+    """surface_integrators/path_integrator.dart:26-27,133-136."""
+
+    def __init__(self, maxDepth=5):
+        self.maxDepth = int(maxDepth)
+
+    kind = _abi.DR_INTEGRATOR_PATH
+
+
+class DirectLightingIntegrator:
+    """surface_integrators/direct_lighting_integrator.dart:23-28 (strategy 'all')."""
+    SAMPLE_ALL_UNIFORM = 0
+    SAMPLE_ONE_UNIFORM = 1
+
+    def __init__(self, strategy=0, maxDepth=5):
+        if strategy != self.SAMPLE_ALL_UNIFORM:
+            raise NotImplementedError("only strategy 'all' (the default) is on the path")
+        self.strategy = strategy
+        self.maxDepth = int(maxDepth)
+
+    kind = _abi.DR_INTEGRATOR_DIRECT_ALL
+
+
+class EmissionIntegrator:
+    """volume_integrators/emission_integrator.dart with no VolumeRegion: T = 1,
+    Lv = 0; its only effect on the path is the two 1-D sample slots it requests."""
+
+    def __init__(self, stepSize=1.0):
+        self.stepSize = stepSize
+
+
+class OutputImage:
+    """core/output_image.dart:35-55."""
+
+    def __init__(self, xOffset, yOffset, width, height, rgb, film=None):
+        self.xOffset, self.yOffset, self.width, self.height = xOffset, yOffset, width, height
+        self.imageWidth, self.imageHeight = width, height
+        self.rgb = rgb
+        self.film = film  # (X, Y, Z, weightSum) per pixel: ImageFilm._Lxyz/_weightSum
+
+
+class SamplerRenderer:
+    """renderers/sampler_renderer.dart:28-31: Renderer.render(Scene) -> OutputImage."""
+
+    def __init__(self, sampler, camera, surfaceIntegrator, volumeIntegrator=None, taskNum=0, taskCount=1,
+                 tileRank=0, tileCount=1, tileSize=32):
+        self.sampler = sampler
+        self.camera = camera
+        self.surfaceIntegrator = surfaceIntegrator
+        self.volumeIntegrator = volumeIntegrator
+        self.taskNum, self.taskCount = int(taskNum), int(taskCount)
+        self.tileRank, self.tileCount, self.tileSize = int(tileRank), int(tileCount), int(tileSize)
+        self.last_stats = None
+
+    def describe(self):
+        """DrRenderDesc for this renderer (plus the arrays it points into)."""
+        d = _abi.DrRenderDesc()
+        self.camera.to_abi(d.camera)
+        self.camera.film.to_abi(d.film)
+        d.integrator = self.surfaceIntegrator.kind
+        d.max_depth = self.surfaceIntegrator.maxDepth
+        d.spp = self.sampler.samplesPerPixel
+        d.task_num, d.task_count = self.taskNum, self.taskCount
+        d.tile_rank, d.tile_count, d.tile_size = self.tileRank, self.tileCount, self.tileSize
+        keep = []
+        if isinstance(self.sampler, HostBufferSampler):
+            s = self.sampler
+            d.sampler_mode = _abi.DR_SAMPLER_HOST_BUFFER
+            d.nsamples = len(s.sample_vec)
+            d.pixel_xy = s.pixel_xy.ctypes.data
+            d.sample_vec = s.sample_vec.ctypes.data
+            d.sample_stride = s.sample_vec.shape[1]
+            if s.tail is not None:
+                d.tail = s.tail.ctypes.data
+                d.max_tail = s.tail.shape[1]
+            keep = [s.pixel_xy, s.sample_vec, s.tail]
+        else:
+            d.sampler_mode = _abi.DR_SAMPLER_COUNTER
+            d.seed = self.sampler.seed
+        return d, keep
+
+    def render(self, scene):
+        film = self.camera.film
+        d, keep = self.describe()
+        out_film = np.zeros((film.height, film.width, 4), dtype=np.float32)
+        out_rgb = np.zeros((film.height, film.width, 3), dtype=np.float32)
+        dev = scene._device()
+        _abi.check(_abi.lib().dr_render(dev.handle, C.byref(d), out_film.ctypes.data, out_rgb.ctypes.data))
+        del keep
+        self.last_stats = dev.stats()
+        return OutputImage(film.left, film.top, film.width, film.height, out_rgb, out_film)
+
+    def Li(self, *a, **k):  # a per-ray FFI seam is far too fine grained
+        raise NotImplementedError("SamplerRenderer.Li is evaluated on the device inside render()")
+
+
+# ---------------------------------------------------------------------------
+# Plugin registry (lib/core/plugin.dart:23-180): names the reference registers
+# in RegisterStandardPlugins (render_manager_interface.dart:37-157) for the path.
+# ---------------------------------------------------------------------------
+class Plugin:
+    _reg = {"accelerator": {}, "surfaceIntegrator": {}, "renderer": {}, "sampler": {}, "film": {}, "filter": {},
+            "camera": {}, "material": {}, "shape": {}, "areaLight": {}, "volumeIntegrator": {}}
+
+    @classmethod
+    def register(cls, kind, name, creator):
+        cls._reg[kind][name] = creator
+
+    @classmethod
+    def get(cls, kind, name):
+        return cls._reg[kind].get(name)
+
+
+def RegisterStandardPlugins():
+    Plugin.register("accelerator", "bvh", BVHAccel.Create)
+    Plugin.register("surfaceIntegrator", "path", lambda ps=None: PathIntegrator((ps or {}).get("maxdepth", 5)))
+    Plugin.register("surfaceIntegrator", "directlighting",
+                    lambda ps=None: DirectLightingIntegrator(0, (ps or {}).get("maxdepth", 5)))
+    Plugin.register("volumeIntegrator", "emission", lambda ps=None: EmissionIntegrator((ps or {}).get("stepsize", 1.0)))
+    Plugin.register("renderer", "sampler", SamplerRenderer)
+    Plugin.register("sampler", "lowdiscrepancy", LowDiscrepancySampler)
+    Plugin.register("film", "image", ImageFilm)
+    Plugin.register("filter", "box", lambda ps=None: BoxFilter((ps or {}).get("xwidth", 0.5), (ps or {}).get("ywidth", 0.5)))
+    Plugin.register("camera", "perspective", PerspectiveCamera)
+    Plugin.register("material", "matte", MatteMaterial)
+    Plugin.register("shape", "trianglemesh", TriangleMesh)
+    Plugin.register("areaLight", "diffuse", DiffuseAreaLight)
+
+
+RegisterStandardPlugins()

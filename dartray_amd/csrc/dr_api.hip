@@ -1,0 +1,673 @@
+// dr_api.hip -- the C ABI of include/dartray_hip.h: scene upload, batch
+// driver of the wavefront path tracer, film, statistics.
+//
+// Host logic restated from the reference where it decides WHAT is traced:
+//   sampler window       ImageFilm.getSampleExtent (film/image_film.dart:247-252),
+//                        GetSubWindow (core/common.dart:52-73), dartray.dart:1009-1023
+//   pixel order          LinearPixelSampler (pixel_samplers/linear_pixel_sampler.dart:29-40)
+//   light tables         ShapeSet ctor (core/light/shape_set.dart:24-51), Distribution1D (core/montecarlo.dart:25-52)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dr_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int g_device = -1;
+int g_numCU = 256;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(DR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+struct Workspace {
+  uint32_t cap = 0;
+  int nFloats = 0, maxTail = 0;
+  DevBuf<float> sv, ro, rd, beta, L, betaNee, shD, Ld1, misD, Ld2;
+  DevBuf<double> rtmin, ht, shTmax, tail;
+  DevBuf<int32_t> hprim, shOcc, misLight, misPrim;
+  DevBuf<uint32_t> flags, activeA, activeB, closestQ, anyQ, counters, spill;
+  DevBuf<int2> pix;
+  DevBuf<float> filterTable, aosSamples;
+  int spillGrid = 0;
+};
+
+#define N_COUNTERS 1024
+
+}  // namespace
+
+struct DrScene {
+  DScene d;
+  DevBuf<uint4> nodes;
+  DevBuf<float4> tris, mats;
+  DevBuf<DLight> lights;
+  DevBuf<DLightTri> ltris;
+  DevBuf<float> lcdf;
+  DevBuf<TraceCounters> ctr;
+  uint32_t bvhDepth = 0;
+  std::vector<int32_t> lightNSamples;
+  Workspace ws;
+  // stats of the last render
+  DrRenderStats stats;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> traceEvents;
+  std::vector<hipEvent_t> eventPool;
+  size_t eventsUsed = 0;
+  hipEvent_t evStart = nullptr, evStop = nullptr;
+  bool statsPending = false;
+  hipEvent_t getEvent() {
+    if (eventsUsed == eventPool.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      eventPool.push_back(e);
+    }
+    return eventPool[eventsUsed++];
+  }
+  ~DrScene() {
+    for (auto e : eventPool) (void)hipEventDestroy(e);
+    if (evStart) (void)hipEventDestroy(evStart);
+    if (evStop) (void)hipEventDestroy(evStop);
+  }
+};
+
+namespace {
+
+inline double r32(double x) { return (double)(float)x; }
+
+// Triangle.area (shapes/triangle.dart:265-269): Vector temporaries are f32.
+double host_tri_area(const float* a, const float* b, const float* c) {
+  double e1[3], e2[3];
+  for (int k = 0; k < 3; ++k) {
+    e1[k] = r32((double)b[k] - (double)a[k]);
+    e2[k] = r32((double)c[k] - (double)a[k]);
+  }
+  double cx = r32(e1[1] * e2[2] - e1[2] * e2[1]);
+  double cy = r32(e1[2] * e2[0] - e1[0] * e2[2]);
+  double cz = r32(e1[0] * e2[1] - e1[1] * e2[0]);
+  return 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+}
+
+int traceGrid() {
+  // DR_LDS_STACK*256*4 = 32 KiB of LDS per workgroup => 5 workgroups (20 waves) per CU.
+  return g_numCU * 5;
+}
+
+int ensureSpill(DrScene* sc, int grid) {
+  if (sc->bvhDepth != 0 && sc->bvhDepth <= DR_LDS_STACK) return DR_OK;
+  size_t need = (size_t)grid * DR_TRACE_BLOCK * (DR_MAX_STACK - DR_LDS_STACK);
+  HIP_TRY(sc->ws.spill.alloc(need));
+  sc->ws.spillGrid = grid;
+  return DR_OK;
+}
+
+void rp_film(RenderParams& rp, const DrFilm& f) {
+  rp.xres = f.xres;
+  rp.yres = f.yres;
+  // image_film.dart:61-65
+  rp.left = (int)std::ceil(f.xres * (double)f.crop[0]);
+  rp.width = std::max(1, (int)std::ceil(f.xres * (double)f.crop[1]) - rp.left);
+  rp.top = (int)std::ceil(f.yres * (double)f.crop[2]);
+  rp.height = std::max(1, (int)std::ceil(f.yres * (double)f.crop[3]) - rp.top);
+  rp.fxw = f.filter_xw;
+  rp.fyw = f.filter_yw;
+  rp.invX = 1.0 / (double)f.filter_xw;  // filter.dart:33-37
+  rp.invY = 1.0 / (double)f.filter_yw;
+  // ImageFilm.getSampleExtent (image_film.dart:247-252)
+  int e0 = (int)std::floor(rp.left + 0.5 - rp.fxw);
+  int e1 = (int)std::ceil(rp.left + 0.5 + rp.width + rp.fxw);
+  int e2 = (int)std::floor(rp.top + 0.5 - rp.fyw);
+  int e3 = (int)std::ceil(rp.top + 0.5 + rp.height + rp.fyw);
+  rp.extX0 = e0;
+  rp.extY0 = e2;
+  rp.extW = e1 - e0;
+  rp.extH = e3 - e2;
+}
+
+// GetSubWindow (core/common.dart:52-73)
+void getSubWindow(int w, int h, int num, int count, int ext[4]) {
+  int nx = count, ny = 1;
+  while ((nx & 0x1) == 0 && 2 * w * ny < h * nx) {
+    nx >>= 1;
+    ny <<= 1;
+  }
+  int xo = num % nx, yo = num / nx;
+  double tx0 = (double)xo / nx, tx1 = (double)(xo + 1) / nx;
+  double ty0 = (double)yo / ny, ty1 = (double)(yo + 1) / ny;
+  auto lerp = [](double t, double v1, double v2) { return v1 * (1.0 - t) + v2 * t; };
+  ext[0] = (int)std::floor(lerp(tx0, 0, w));
+  ext[1] = std::min((int)std::floor(lerp(tx1, 0, w)), w);
+  ext[2] = (int)std::floor(lerp(ty0, 0, h));
+  ext[3] = std::min((int)std::floor(lerp(ty1, 0, h)), h);
+}
+
+int allocWorkspace(DrScene* sc, uint32_t cap, int nFloats, int maxTail, bool needTail) {
+  Workspace& w = sc->ws;
+  if (cap > w.cap || nFloats > w.nFloats) {
+    uint32_t c = std::max(cap, w.cap);
+    int nf = std::max(nFloats, w.nFloats);
+    HIP_TRY(w.sv.alloc((size_t)nf * c));
+    HIP_TRY(w.ro.alloc(3 * (size_t)c));
+    HIP_TRY(w.rd.alloc(3 * (size_t)c));
+    HIP_TRY(w.beta.alloc(3 * (size_t)c));
+    HIP_TRY(w.L.alloc(3 * (size_t)c));
+    HIP_TRY(w.betaNee.alloc(3 * (size_t)c));
+    HIP_TRY(w.shD.alloc(3 * (size_t)c));
+    HIP_TRY(w.Ld1.alloc(3 * (size_t)c));
+    HIP_TRY(w.misD.alloc(3 * (size_t)c));
+    HIP_TRY(w.Ld2.alloc(3 * (size_t)c));
+    HIP_TRY(w.rtmin.alloc(c));
+    HIP_TRY(w.ht.alloc(c));
+    HIP_TRY(w.shTmax.alloc(c));
+    HIP_TRY(w.hprim.alloc(c));
+    HIP_TRY(w.shOcc.alloc(c));
+    HIP_TRY(w.misLight.alloc(c));
+    HIP_TRY(w.misPrim.alloc(c));
+    HIP_TRY(w.flags.alloc(c));
+    HIP_TRY(w.activeA.alloc(c));
+    HIP_TRY(w.activeB.alloc(c));
+    HIP_TRY(w.closestQ.alloc(2 * (size_t)c));
+    HIP_TRY(w.anyQ.alloc(c));
+    w.cap = c;
+    w.nFloats = nf;
+  }
+  if (needTail && ((size_t)w.cap * maxTail > w.tail.n)) HIP_TRY(w.tail.alloc((size_t)w.cap * maxTail));
+  w.maxTail = maxTail;
+  HIP_TRY(w.counters.alloc(N_COUNTERS));
+  HIP_TRY(w.filterTable.alloc(256));
+  return DR_OK;
+}
+
+BatchState makeState(Workspace& w, const int2* pix, uint32_t nslots, bool useTail) {
+  BatchState st;
+  st.cap = w.cap;
+  st.nslots = nslots;
+  st.pix = pix;
+  st.sv = w.sv.p;
+  st.tail = useTail ? w.tail.p : nullptr;
+  st.ro = w.ro.p;
+  st.rd = w.rd.p;
+  st.rtmin = w.rtmin.p;
+  st.hprim = w.hprim.p;
+  st.ht = w.ht.p;
+  st.beta = w.beta.p;
+  st.L = w.L.p;
+  st.betaNee = w.betaNee.p;
+  st.shD = w.shD.p;
+  st.shTmax = w.shTmax.p;
+  st.Ld1 = w.Ld1.p;
+  st.shOcc = w.shOcc.p;
+  st.misD = w.misD.p;
+  st.Ld2 = w.Ld2.p;
+  st.misLight = w.misLight.p;
+  st.misPrim = w.misPrim.p;
+  st.flags = w.flags.p;
+  return st;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dr_last_error(void) { return g_err.c_str(); }
+const char* dr_version(void) { return "dartray_amd 0.1 (gfx950)"; }
+
+int dr_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return fail(DR_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n) return fail(DR_ERR_INVALID, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  g_numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  g_device = device;
+  return DR_OK;
+}
+
+int32_t dr_sample_floats(int32_t integrator, uint32_t nlights) {
+  // SURVEY.md Appendix B.  Path: 3 x (light 1D+2D, lightNum 1D, bsdf 1D+2D, path 1D+2D) + tau + scatter.
+  if (integrator == DR_INTEGRATOR_PATH) return 5 + 14 + 18;
+  return 5 + (2 * (int)nlights + 2) + 4 * (int)nlights;
+}
+
+int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
+  if (g_device < 0) return fail(DR_ERR_NO_DEVICE, "dr_init has not been called");
+  if (!desc || !out) return fail(DR_ERR_INVALID, "null argument");
+  if (desc->ntris > 0 && (!desc->nodes || !desc->verts || !desc->tri_idx || !desc->tri_material || !desc->tri_light ||
+                          !desc->tri_reverse || !desc->materials))
+    return fail(DR_ERR_INVALID, "scene arrays missing");
+  if (desc->ntris >= (1ull << 31) || desc->nnodes >= (1ull << 31)) return fail(DR_ERR_INVALID, "scene too large");
+  for (uint32_t i = 0; i < desc->nmaterials; ++i)
+    if (desc->materials[i].sigma != 0.0f) return fail(DR_ERR_UNSUPPORTED, "matte sigma != 0 (Oren-Nayar) is not on the path");
+  if (desc->bvh_depth > DR_MAX_STACK) return fail(DR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+  DrScene* sc = new DrScene();
+  memset(&sc->stats, 0, sizeof(sc->stats));
+  auto bail = [&](int code, const std::string& m) {
+    delete sc;
+    return fail(code, m);
+  };
+#define TRY_SC(expr)                                                             \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) return bail(DR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+  sc->bvhDepth = desc->bvh_depth;
+  // nodes: the 32-byte marshalled node is consumed as two 16-byte loads
+  TRY_SC(sc->nodes.alloc(2 * desc->nnodes));
+  if (desc->nnodes) TRY_SC(hipMemcpy(sc->nodes.p, desc->nodes, desc->nnodes * sizeof(DrBvhNode), hipMemcpyHostToDevice));
+  // primitives: gather vertices on the device
+  TRY_SC(sc->tris.alloc(3 * desc->ntris));
+  if (desc->ntris) {
+    DevBuf<float> dV;
+    DevBuf<uint32_t> dI, dM;
+    DevBuf<int32_t> dL;
+    DevBuf<uint8_t> dR;
+    TRY_SC(dV.alloc(3 * desc->nverts));
+    TRY_SC(dI.alloc(3 * desc->ntris));
+    TRY_SC(dM.alloc(desc->ntris));
+    TRY_SC(dL.alloc(desc->ntris));
+    TRY_SC(dR.alloc(desc->ntris));
+    for (uint64_t i = 0; i < 3 * desc->ntris; ++i)
+      if (desc->tri_idx[i] >= desc->nverts) return bail(DR_ERR_INVALID, "vertex index out of range");
+    for (uint64_t i = 0; i < desc->ntris; ++i) {
+      if (desc->tri_material[i] >= desc->nmaterials) return bail(DR_ERR_INVALID, "material index out of range");
+      if (desc->tri_light[i] >= (int32_t)desc->nlights) return bail(DR_ERR_INVALID, "light index out of range");
+    }
+    TRY_SC(hipMemcpy(dV.p, desc->verts, 3 * desc->nverts * sizeof(float), hipMemcpyHostToDevice));
+    TRY_SC(hipMemcpy(dI.p, desc->tri_idx, 3 * desc->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
+    TRY_SC(hipMemcpy(dM.p, desc->tri_material, desc->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
+    TRY_SC(hipMemcpy(dL.p, desc->tri_light, desc->ntris * sizeof(int32_t), hipMemcpyHostToDevice));
+    TRY_SC(hipMemcpy(dR.p, desc->tri_reverse, desc->ntris, hipMemcpyHostToDevice));
+    launch_gather_tris(dV.p, dI.p, dM.p, dL.p, dR.p, sc->tris.p, desc->ntris, 0);
+    TRY_SC(hipDeviceSynchronize());
+  }
+  // materials
+  {
+    std::vector<float4> m(std::max<uint32_t>(desc->nmaterials, 1));
+    for (uint32_t i = 0; i < desc->nmaterials; ++i)
+      m[i] = make_float4(desc->materials[i].kd[0], desc->materials[i].kd[1], desc->materials[i].kd[2], desc->materials[i].sigma);
+    TRY_SC(sc->mats.alloc(m.size()));
+    TRY_SC(hipMemcpy(sc->mats.p, m.data(), m.size() * sizeof(float4), hipMemcpyHostToDevice));
+  }
+  // lights: ShapeSet areas + Distribution1D (shape_set.dart:40-50; montecarlo.dart:25-52)
+  {
+    std::vector<DLight> L(std::max<uint32_t>(desc->nlights, 1));
+    std::vector<DLightTri> LT(std::max<uint32_t>(desc->nlight_tris, 1));
+    std::vector<float> cdf;
+    for (uint32_t i = 0; i < desc->nlights; ++i) {
+      const DrAreaLight& a = desc->lights[i];
+      if (a.ntris == 0 || (uint64_t)a.first_tri + a.ntris > desc->nlight_tris) return bail(DR_ERR_INVALID, "light triangle range");
+      DLight& d = L[i];
+      d.L[0] = a.L[0]; d.L[1] = a.L[1]; d.L[2] = a.L[2];
+      d.nsamples = std::max(1, a.nsamples);
+      d.first_tri = a.first_tri;
+      d.ntris = a.ntris;
+      d.pad = 0;
+      sc->lightNSamples.push_back(d.nsamples);
+      double area = 0.0;
+      std::vector<double> areas(a.ntris);
+      for (uint32_t t = 0; t < a.ntris; ++t) {
+        const DrLightTri& lt = desc->light_tris[a.first_tri + t];
+        DLightTri& o = LT[a.first_tri + t];
+        for (int k = 0; k < 3; ++k) {
+          if (lt.v[k] >= desc->nverts) return bail(DR_ERR_INVALID, "light vertex index out of range");
+          for (int c = 0; c < 3; ++c) o.p[3 * k + c] = desc->verts[3 * (size_t)lt.v[k] + c];
+        }
+        o.reverse = lt.reverse_orientation;
+        o.area = host_tri_area(o.p, o.p + 3, o.p + 6);
+        areas[t] = o.area;
+        area += o.area;
+      }
+      d.area = area;
+      // Distribution1D(areas, n)
+      int count = (int)a.ntris;
+      std::vector<float> func(count), c(count + 1);
+      for (int k = 0; k < count; ++k) func[k] = (float)areas[k];
+      c[0] = 0.0f;
+      for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)c[k - 1] + (double)func[k - 1] / (double)count);
+      double funcInt = c[count];
+      if (funcInt == 0.0) {
+        for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)k / (double)count);
+      } else {
+        for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)c[k] / funcInt);
+      }
+      d.cdf_off = (uint32_t)cdf.size();
+      cdf.insert(cdf.end(), c.begin(), c.end());
+    }
+    if (cdf.empty()) cdf.push_back(0.f);
+    TRY_SC(sc->lights.alloc(L.size()));
+    TRY_SC(hipMemcpy(sc->lights.p, L.data(), L.size() * sizeof(DLight), hipMemcpyHostToDevice));
+    TRY_SC(sc->ltris.alloc(LT.size()));
+    TRY_SC(hipMemcpy(sc->ltris.p, LT.data(), LT.size() * sizeof(DLightTri), hipMemcpyHostToDevice));
+    TRY_SC(sc->lcdf.alloc(cdf.size()));
+    TRY_SC(hipMemcpy(sc->lcdf.p, cdf.data(), cdf.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  TRY_SC(sc->ctr.alloc(1));
+  TRY_SC(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
+  sc->d.nodes = sc->nodes.p;
+  sc->d.tris = sc->tris.p;
+  sc->d.mats = sc->mats.p;
+  sc->d.lights = sc->lights.p;
+  sc->d.ltris = sc->ltris.p;
+  sc->d.lcdf = sc->lcdf.p;
+  sc->d.nnodes = (uint32_t)desc->nnodes;
+  sc->d.ntris = (uint32_t)desc->ntris;
+  sc->d.nlights = desc->nlights;
+  sc->d.nmats = desc->nmaterials;
+  TRY_SC(hipEventCreate(&sc->evStart));
+  TRY_SC(hipEventCreate(&sc->evStop));
+  *out = sc;
+  return DR_OK;
+#undef TRY_SC
+}
+
+void dr_scene_destroy(DrScene* scene) { delete scene; }
+
+int dr_intersect(DrScene* sc, const DrRay* rays, int64_t n, DrHit* out, int32_t any_hit) {
+  if (!sc || (n > 0 && (!rays || !out))) return fail(DR_ERR_INVALID, "null argument");
+  if (n <= 0) return DR_OK;
+  if (n >= (1ll << 31)) return fail(DR_ERR_INVALID, "too many rays in one call");
+  int grid = std::min<int64_t>(traceGrid(), (n + DR_TRACE_BLOCK - 1) / DR_TRACE_BLOCK);
+  int rc = ensureSpill(sc, traceGrid());
+  if (rc) return rc;
+  DevBuf<DrRay> dR;
+  DevBuf<DrHit> dH;
+  DevBuf<uint32_t> work;
+  HIP_TRY(dR.alloc(n));
+  HIP_TRY(dH.alloc(n));
+  HIP_TRY(work.alloc(1));
+  HIP_TRY(hipMemcpy(dR.p, rays, n * sizeof(DrRay), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(work.p, 0, sizeof(uint32_t)));
+  HIP_TRY(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
+  launch_intersect(sc->d, dR.p, n, dH.p, any_hit, sc->ws.spill.p, work.p, sc->ctr.p, grid, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, dH.p, n * sizeof(DrHit), hipMemcpyDeviceToHost));
+  TraceCounters c;
+  HIP_TRY(hipMemcpy(&c, sc->ctr.p, sizeof(c), hipMemcpyDeviceToHost));
+  memset(&sc->stats, 0, sizeof(sc->stats));
+  sc->stats.closest_rays = c.closest_rays; sc->stats.any_rays = c.any_rays;
+  sc->stats.closest_nodes = c.closest_nodes; sc->stats.any_nodes = c.any_nodes;
+  sc->stats.closest_tris = c.closest_tris; sc->stats.any_tris = c.any_tris;
+  sc->statsPending = false;
+  return DR_OK;
+}
+
+int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* hip_stream) {
+  if (!sc || !rd || !film_dev) return fail(DR_ERR_INVALID, "null argument");
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int spp = rd->spp;
+  if (spp <= 0 || (spp & (spp - 1)) != 0) return fail(DR_ERR_INVALID, "spp must be a power of two (low_discrepancy_sampler.dart:43-49)");
+  if (spp > 1024) return fail(DR_ERR_UNSUPPORTED, "spp > 1024");
+  if (rd->integrator != DR_INTEGRATOR_PATH && rd->integrator != DR_INTEGRATOR_DIRECT_ALL)
+    return fail(DR_ERR_INVALID, "unknown integrator");
+  if (rd->integrator == DR_INTEGRATOR_DIRECT_ALL)
+    for (int32_t ns : sc->lightNSamples)
+      if (ns != 1) return fail(DR_ERR_UNSUPPORTED, "DirectLighting on the device needs light nsamples == 1");
+  if (rd->max_depth < 0 || rd->max_depth > 64) return fail(DR_ERR_INVALID, "max_depth out of range");
+
+  RenderParams rp;
+  memset(&rp, 0, sizeof(rp));
+  memcpy(rp.r2c, rd->camera.raster_to_camera, sizeof(rp.r2c));
+  memcpy(rp.c2w, rd->camera.camera_to_world, sizeof(rp.c2w));
+  rp.lensRadius = rd->camera.lens_radius;
+  rp.focalDistance = rd->camera.focal_distance;
+  rp.shutterOpen = rd->camera.shutter_open;
+  rp.shutterClose = rd->camera.shutter_close;
+  rp_film(rp, rd->film);
+  rp.integrator = rd->integrator;
+  rp.maxDepth = rd->max_depth;
+  rp.spp = spp;
+  rp.sppShift = 0;
+  while ((1 << rp.sppShift) < spp) ++rp.sppShift;
+  rp.nLights = (int)sc->d.nlights;
+  rp.nFloats = dr_sample_floats(rd->integrator, sc->d.nlights);
+  rp.n1D = rd->integrator == DR_INTEGRATOR_PATH ? 14 : 2 * rp.nLights + 2;
+  rp.samplerMode = rd->sampler_mode;
+  rp.seed = (uint64_t)rd->seed;
+  const int perNee = rp.nLights > 0 ? 7 : 0;
+  const int needTail = rd->integrator == DR_INTEGRATOR_PATH && rd->max_depth >= 3
+                           ? (rd->max_depth - 2) * (perNee + 3) + std::max(0, rd->max_depth - 3)
+                           : 0;
+  rp.maxTail = rd->max_tail;
+
+  // ---- which pixels does this call trace? ----
+  std::vector<int2> pixels;
+  const bool hostBuf = rd->sampler_mode == DR_SAMPLER_HOST_BUFFER;
+  if (hostBuf) {
+    if (rd->nsamples <= 0 || rd->nsamples % spp != 0 || !rd->pixel_xy || !rd->sample_vec)
+      return fail(DR_ERR_INVALID, "host-buffer sampler: nsamples must be a positive multiple of spp with pixel_xy and sample_vec set");
+    if (rd->sample_stride < rp.nFloats) return fail(DR_ERR_INVALID, "sample_stride smaller than the sample vector");
+    if (needTail > 0 && (!rd->tail || rd->max_tail < needTail))
+      return fail(DR_ERR_INVALID, "host-buffer sampler: tail buffer missing or max_tail too small for max_depth");
+    int64_t np = rd->nsamples / spp;
+    pixels.resize(np);
+    for (int64_t i = 0; i < np; ++i) pixels[i] = make_int2(rd->pixel_xy[2 * i], rd->pixel_xy[2 * i + 1]);
+  } else if (rd->sampler_mode == DR_SAMPLER_COUNTER) {
+    int ext[4];
+    getSubWindow(rp.extW, rp.extH, rd->task_num, std::max(1, rd->task_count), ext);
+    const int ts = rd->tile_size > 0 ? rd->tile_size : 32;
+    const int ntx = (rp.extW + ts - 1) / ts;
+    const bool tiled = rd->tile_count > 1;
+    // The dead border row/column of the sampler window (W+1 x H+1 for the box filter) is traced as the
+    // reference does; a border sample only reaches the film when imageX/Y is exactly integral.
+    pixels.reserve((size_t)(ext[1] - ext[0]) * (ext[3] - ext[2]) / (tiled ? rd->tile_count : 1) + 1024);
+    if (!tiled) {
+      for (int y = ext[2]; y < ext[3]; ++y)
+        for (int x = ext[0]; x < ext[1]; ++x) pixels.push_back(make_int2(rp.extX0 + x, rp.extY0 + y));
+    } else {
+      // tile-major so that a batch covers whole tiles (coherent camera rays)
+      const int nty = (rp.extH + ts - 1) / ts;
+      for (int ty = 0; ty < nty; ++ty)
+        for (int tx = 0; tx < ntx; ++tx) {
+          if ((ty * ntx + tx) % rd->tile_count != rd->tile_rank) continue;
+          for (int y = std::max(ty * ts, ext[2]); y < std::min((ty + 1) * ts, ext[3]); ++y)
+            for (int x = std::max(tx * ts, ext[0]); x < std::min((tx + 1) * ts, ext[1]); ++x)
+              pixels.push_back(make_int2(rp.extX0 + x, rp.extY0 + y));
+        }
+    }
+  } else {
+    return fail(DR_ERR_INVALID, "unknown sampler mode");
+  }
+  const size_t npixTotal = pixels.size();
+  memset(&sc->stats, 0, sizeof(sc->stats));
+  sc->traceEvents.clear();
+  sc->eventsUsed = 0;
+  sc->statsPending = true;
+  HIP_TRY(hipMemsetAsync(sc->ctr.p, 0, sizeof(TraceCounters), s));
+  HIP_TRY(hipEventRecord(sc->evStart, s));
+  if (npixTotal == 0) {
+    HIP_TRY(hipEventRecord(sc->evStop, s));
+    return DR_OK;
+  }
+  uint64_t filmSamples = 0;
+  for (const int2& p : pixels)
+    if (p.x >= rp.left && p.x < rp.left + rp.width && p.y >= rp.top && p.y < rp.top + rp.height) filmSamples += spp;
+
+  // ---- workspace ----
+  const uint64_t maxSlots = 1ull << 24;
+  const uint64_t totalSlots = (uint64_t)npixTotal * spp;
+  const uint32_t pixPerBatch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(npixTotal, maxSlots / spp));
+  const uint32_t cap = pixPerBatch * (uint32_t)spp;
+  (void)totalSlots;
+  int rc = allocWorkspace(sc, cap, rp.nFloats, rd->max_tail, hostBuf && needTail > 0);
+  if (rc) return rc;
+  const int tgrid = traceGrid();
+  rc = ensureSpill(sc, tgrid);
+  if (rc) return rc;
+  Workspace& w = sc->ws;
+  HIP_TRY(w.pix.alloc(npixTotal));
+  HIP_TRY(hipMemcpyAsync(w.pix.p, pixels.data(), npixTotal * sizeof(int2), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(w.filterTable.p, rd->film.filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s));
+  // pixels is a local: the async copy above must complete before it goes out of scope
+  HIP_TRY(hipStreamSynchronize(s));
+  const int sgrid = g_numCU * 8;
+  const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : rp.nLights + 1;
+  if (4 * nStages + 8 > N_COUNTERS) return fail(DR_ERR_UNSUPPORTED, "too many stages");
+
+  for (size_t p0 = 0; p0 < npixTotal; p0 += pixPerBatch) {
+    const uint32_t np = (uint32_t)std::min<size_t>(pixPerBatch, npixTotal - p0);
+    const uint32_t nslots = np * (uint32_t)spp;
+    BatchState st = makeState(w, w.pix.p + p0, nslots, hostBuf && needTail > 0);
+    HIP_TRY(hipMemsetAsync(w.counters.p, 0, N_COUNTERS * sizeof(uint32_t), s));
+    if (hostBuf) {
+      HIP_TRY(w.aosSamples.alloc((size_t)w.cap * rd->sample_stride));
+      HIP_TRY(hipMemcpyAsync(w.aosSamples.p, rd->sample_vec + (size_t)p0 * spp * rd->sample_stride,
+                             (size_t)nslots * rd->sample_stride * sizeof(float), hipMemcpyHostToDevice, s));
+      launch_transpose_samples(w.aosSamples.p, rd->sample_stride, st, rp.nFloats, s);
+      if (needTail > 0)
+        HIP_TRY(hipMemcpyAsync(w.tail.p, rd->tail + (size_t)p0 * spp * rd->max_tail,
+                               (size_t)nslots * rd->max_tail * sizeof(double), hipMemcpyHostToDevice, s));
+    } else {
+      launch_gen_samples(rp, st, np, s);
+    }
+    launch_raygen(rp, st, s);
+    uint32_t* C = w.counters.p;
+    int wc = 0;  // work counters live at C[512..]
+    auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any) {
+      hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
+      (void)hipEventRecord(e0, s);
+      launch_trace(sc->d, st, queue, nQ, any, w.spill.p, C + 512 + (wc++), sc->ctr.p, tgrid, s);
+      (void)hipEventRecord(e1, s);
+      sc->traceEvents.push_back({e0, e1});
+    };
+    trace(nullptr, nullptr, 0);  // camera rays
+    for (int b = 0; b < nStages; ++b) {
+      StageQueues q;
+      q.activeIn = b == 0 ? nullptr : ((b - 1) & 1 ? w.activeB.p : w.activeA.p);
+      q.nActiveIn = b == 0 ? nullptr : C + 4 * (b - 1);
+      q.activeOut = (b & 1) ? w.activeB.p : w.activeA.p;
+      q.nActiveOut = C + 4 * b;
+      q.closestQ = w.closestQ.p;
+      q.nClosest = C + 4 * b + 1;
+      q.anyQ = w.anyQ.p;
+      q.nAny = C + 4 * b + 2;
+      if (rd->integrator == DR_INTEGRATOR_PATH) launch_shade_path(sc->d, rp, st, q, b, sgrid, s);
+      else launch_shade_direct(sc->d, rp, st, q, b, sgrid, s);
+      if (b + 1 < nStages) {
+        trace(q.closestQ, q.nClosest, 0);
+        trace(q.anyQ, q.nAny, 1);
+      }
+    }
+    launch_film(rp, st, w.filterTable.p, np, (float*)film_dev, s);
+    HIP_TRY(hipGetLastError());
+    sc->stats.batches++;
+    if (hostBuf) HIP_TRY(hipStreamSynchronize(s));  // host buffers of the next batch reuse the staging area
+  }
+  HIP_TRY(hipEventRecord(sc->evStop, s));
+  sc->stats.camera_samples = (uint64_t)npixTotal * spp;
+  sc->stats.film_samples = filmSamples;
+  return DR_OK;
+}
+
+int dr_get_stats(DrScene* sc, DrRenderStats* out) {
+  if (!sc || !out) return fail(DR_ERR_INVALID, "null argument");
+  if (sc->statsPending) {
+    HIP_TRY(hipEventSynchronize(sc->evStop));
+    TraceCounters c;
+    HIP_TRY(hipMemcpy(&c, sc->ctr.p, sizeof(c), hipMemcpyDeviceToHost));
+    sc->stats.closest_rays = c.closest_rays; sc->stats.any_rays = c.any_rays;
+    sc->stats.closest_nodes = c.closest_nodes; sc->stats.any_nodes = c.any_nodes;
+    sc->stats.closest_tris = c.closest_tris; sc->stats.any_tris = c.any_tris;
+    double ms = 0.0;
+    for (auto& ev : sc->traceEvents) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) ms += t;
+    }
+    sc->stats.trace_ms = ms;
+    sc->stats.trace_launches = sc->traceEvents.size();
+    float tot = 0.f;
+    if (hipEventElapsedTime(&tot, sc->evStart, sc->evStop) == hipSuccess) sc->stats.total_ms = tot;
+    sc->statsPending = false;
+  }
+  *out = sc->stats;
+  return DR_OK;
+}
+
+int dr_film_resolve_device(const void* film_dev, int64_t npixels, void* rgb_dev, void* hip_stream) {
+  if (!film_dev || !rgb_dev || npixels < 0) return fail(DR_ERR_INVALID, "null argument");
+  if (npixels == 0) return DR_OK;
+  launch_film_resolve((const float*)film_dev, npixels, (float*)rgb_dev, (hipStream_t)hip_stream);
+  HIP_TRY(hipGetLastError());
+  return DR_OK;
+}
+
+int dr_render(DrScene* sc, const DrRenderDesc* rd, float* film_out, float* rgb_out) {
+  if (!sc || !rd || !film_out) return fail(DR_ERR_INVALID, "null argument");
+  RenderParams rp;
+  memset(&rp, 0, sizeof(rp));
+  rp_film(rp, rd->film);
+  const int64_t npix = (int64_t)rp.width * rp.height;
+  DevBuf<float> film, rgb;
+  HIP_TRY(film.alloc(4 * npix));
+  HIP_TRY(hipMemset(film.p, 0, 4 * npix * sizeof(float)));
+  int rc = dr_render_device(sc, rd, film.p, nullptr);
+  if (rc) return rc;
+  if (rgb_out) {
+    HIP_TRY(rgb.alloc(3 * npix));
+    rc = dr_film_resolve_device(film.p, npix, rgb.p, nullptr);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(film_out, film.p, 4 * npix * sizeof(float), hipMemcpyDeviceToHost));
+  if (rgb_out) HIP_TRY(hipMemcpy(rgb_out, rgb.p, 3 * npix * sizeof(float), hipMemcpyDeviceToHost));
+  return DR_OK;
+}
+
+int dr_copy_bandwidth(uint64_t bytes, int32_t iters, double* gbps_out) {
+  if (g_device < 0) return fail(DR_ERR_NO_DEVICE, "dr_init has not been called");
+  if (!gbps_out || bytes < 16 || iters <= 0) return fail(DR_ERR_INVALID, "bad argument");
+  uint64_t n4 = bytes / 16;
+  DevBuf<float4> a, b;
+  HIP_TRY(a.alloc(n4));
+  HIP_TRY(b.alloc(n4));
+  HIP_TRY(hipMemset(a.p, 1, n4 * 16));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  launch_copy(a.p, b.p, n4, 0);
+  HIP_TRY(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) launch_copy(a.p, b.p, n4, 0);
+  HIP_TRY(hipEventRecord(e1, 0));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *gbps_out = (2.0 * (double)n4 * 16.0 * iters) / ((double)ms * 1.0e-3) / 1.0e9;
+  return DR_OK;
+}
+
+}  // extern "C"

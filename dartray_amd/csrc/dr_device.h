@@ -1,0 +1,378 @@
+// dr_device.h -- device-side numerics and geometry/shading functions.
+//
+// Numerics contract of the reference: every arithmetic
+// expression is an f64 expression; constructing a Vector/Point/Normal/Spectrum
+// or storing into a Float32List rounds to f32.  The device code keeps that
+// contract literally: values that live in a Dart Float32List are held as
+// `float`, every expression is evaluated in `double`, and this translation unit
+// is compiled with -ffp-contract=off.  (A single + - * / of two f32 operands
+// done in f32 equals the f64 result rounded to f32 because 53 >= 2*24+2, so
+// those are written directly in f32.)
+//
+// Citations are relative to /root/reference/lib/.
+#ifndef DR_DEVICE_H
+#define DR_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DR_DEV __device__ __forceinline__
+
+#define DR_INV_PI 0.31830988618379067154  // core/common.dart:23
+#define DR_PI 3.141592653589793
+#define DR_INF __longlong_as_double(0x7ff0000000000000LL)
+
+// ---- Vector / Point / Normal (core/vector.dart) ---------------------------
+struct F3 {
+  float x, y, z;
+};
+DR_DEV F3 f3(double x, double y, double z) { return F3{(float)x, (float)y, (float)z}; }  // vector.dart:29-34
+DR_DEV F3 vadd(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }              // :57-60
+DR_DEV F3 vsub(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }              // :62-65
+DR_DEV F3 vmul(F3 a, double f) { return f3((double)a.x * f, (double)a.y * f, (double)a.z * f); }  // :67-68
+DR_DEV F3 vdiv(F3 a, double f) { return f3((double)a.x / f, (double)a.y / f, (double)a.z / f); }  // :70-71
+DR_DEV F3 vneg(F3 a) { return F3{-a.x, -a.y, -a.z}; }
+DR_DEV double vdot(F3 a, F3 b) {  // :153-155
+  return (double)a.x * (double)b.x + (double)a.y * (double)b.y + (double)a.z * (double)b.z;
+}
+DR_DEV double vlen2(F3 a) { return vdot(a, a); }
+DR_DEV double vlen(F3 a) { return sqrt(vlen2(a)); }
+DR_DEV F3 vcross(F3 a, F3 b) {  // :161-171
+  double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+  return f3((ay * bz) - (az * by), (az * bx) - (ax * bz), (ax * by) - (ay * bx));
+}
+DR_DEV F3 vnormalize(F3 v) { return vdiv(v, vlen(v)); }  // :173
+
+// ---- Spectrum == RGBColor (core/rgb_color.dart:136-176) --------------------
+struct C3 {
+  float r, g, b;
+};
+DR_DEV C3 c3(double r, double g, double b) { return C3{(float)r, (float)g, (float)b}; }
+DR_DEV C3 cadd(C3 a, C3 b) { return C3{a.r + b.r, a.g + b.g, a.b + b.b}; }
+DR_DEV C3 cmul(C3 a, C3 b) { return C3{a.r * b.r, a.g * b.g, a.b * b.b}; }
+DR_DEV C3 cmulD(C3 a, double s) { return c3((double)a.r * s, (double)a.g * s, (double)a.b * s); }
+DR_DEV C3 cdivD(C3 a, double s) { return c3((double)a.r / s, (double)a.g / s, (double)a.b / s); }
+DR_DEV bool cblack(C3 a) { return !(a.r != 0.0f || a.g != 0.0f || a.b != 0.0f); }
+DR_DEV double clum(C3 a) { return 0.212671 * (double)a.r + 0.715160 * (double)a.g + 0.072169 * (double)a.b; }
+
+// ---- device scene ----------------------------------------------------------
+// Triangle record, 48 B: the primitive's three world-space vertices gathered
+// at upload (12 B of indices + 36 B of vertices per test in the reference,
+// triangle_mesh.dart:46-60) plus its GeometricPrimitive attributes.
+//   q0 = (p1.x, p1.y, p1.z, p2.x)  q1 = (p2.y, p2.z, p3.x, p3.y)
+//   q2 = (p3.z, material, light(int), reverse)
+struct DLight {
+  float L[3];
+  int32_t nsamples;
+  uint32_t first_tri, ntris;
+  uint32_t cdf_off;  // into lcdf: ntris+1 floats
+  uint32_t pad;
+  double area;
+};
+struct DLightTri {  // 48 B
+  float p[9];
+  uint32_t reverse;
+  double area;
+};
+struct DScene {
+  const uint4* nodes;   // 2 x uint4 per node (DrBvhNode)
+  const float4* tris;   // 3 x float4 per primitive
+  const float4* mats;   // kd.rgb, sigma
+  const DLight* lights;
+  const DLightTri* ltris;
+  const float* lcdf;
+  uint32_t nnodes, ntris, nlights, nmats;
+};
+
+struct Tri {
+  F3 p1, p2, p3;
+  uint32_t mat;
+  int32_t light;
+  uint32_t reverse;
+};
+DR_DEV Tri load_tri(const DScene& sc, uint32_t prim) {
+  const float4* tp = sc.tris + 3 * (size_t)prim;
+  float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+  Tri t;
+  t.p1 = F3{q0.x, q0.y, q0.z};
+  t.p2 = F3{q0.w, q1.x, q1.y};
+  t.p3 = F3{q1.z, q1.w, q2.x};
+  t.mat = __float_as_uint(q2.y);
+  t.light = (int32_t)__float_as_uint(q2.z);
+  t.reverse = __float_as_uint(q2.w);
+  return t;
+}
+
+// ---- Triangle (shapes/triangle.dart) ----------------------------------------
+// Triangle.intersect's hit test (triangle.dart:52-98): f64 scalars on f32 inputs.
+DR_DEV bool tri_hit(F3 p1, F3 p2, F3 p3, F3 o, F3 d, double tmin, double tmax, double* tOut, double* b1Out,
+                    double* b2Out) {
+  double e1x = (double)p2.x - (double)p1.x, e1y = (double)p2.y - (double)p1.y, e1z = (double)p2.z - (double)p1.z;
+  double e2x = (double)p3.x - (double)p1.x, e2y = (double)p3.y - (double)p1.y, e2z = (double)p3.z - (double)p1.z;
+  double dx = d.x, dy = d.y, dz = d.z;
+  double s1x = (dy * e2z) - (dz * e2y);
+  double s1y = (dz * e2x) - (dx * e2z);
+  double s1z = (dx * e2y) - (dy * e2x);
+  double divisor = (s1x * e1x) + (s1y * e1y) + (s1z * e1z);
+  if (divisor == 0.0) return false;
+  double invDivisor = 1.0 / divisor;
+  double sx = (double)o.x - (double)p1.x, sy = (double)o.y - (double)p1.y, sz = (double)o.z - (double)p1.z;
+  double b1 = (sx * s1x + sy * s1y + sz * s1z) * invDivisor;
+  if (b1 < 0.0 || b1 > 1.0) return false;
+  double s2x = (sy * e1z) - (sz * e1y);
+  double s2y = (sz * e1x) - (sx * e1z);
+  double s2z = (sx * e1y) - (sy * e1x);
+  double b2 = ((dx * s2x) + (dy * s2y) + (dz * s2z)) * invDivisor;
+  if (b2 < 0.0 || b1 + b2 > 1.0) return false;
+  double t = (e2x * s2x + e2y * s2y + e2z * s2z) * invDivisor;
+  if (t < tmin || t > tmax) return false;
+  *tOut = t;
+  *b1Out = b1;
+  *b2Out = b2;
+  return true;
+}
+// Triangle.intersectP (triangle.dart:162-194): Vector temporaries rounded to f32.
+DR_DEV bool tri_hitP(F3 p1, F3 p2, F3 p3, F3 o, F3 d, double tmin, double tmax) {
+  F3 e1 = vsub(p2, p1);
+  F3 e2 = vsub(p3, p1);
+  F3 s1 = vcross(d, e2);
+  double divisor = vdot(s1, e1);
+  if (divisor == 0.0) return false;
+  double invDivisor = 1.0 / divisor;
+  F3 s = vsub(o, p1);
+  double b1 = vdot(s, s1) * invDivisor;
+  if (b1 < 0.0 || b1 > 1.0) return false;
+  F3 s2 = vcross(s, e1);
+  double b2 = vdot(d, s2) * invDivisor;
+  if (b2 < 0.0 || b1 + b2 > 1.0) return false;
+  double t = vdot(e2, s2) * invDivisor;
+  if (t < tmin || t > tmax) return false;
+  return true;
+}
+
+// DifferentialGeometry of a triangle hit (triangle.dart:100-132,154 with the
+// default UVs (0,0),(1,0),(1,1) of :255-262; differential_geometry.dart:77-102).
+struct DGeo {
+  F3 p, dpdu, dpdv, nn;
+};
+DR_DEV void tri_dg(F3 p1, F3 p2, F3 p3, uint32_t reverse, F3 o, F3 d, double t, DGeo* dg) {
+  // du1 = -1, du2 = 0, dv1 = -1, dv2 = -1  =>  determinant = 1, invdet = 1
+  const double du1 = 0.0 - 1.0, du2 = 1.0 - 1.0, dv1 = 0.0 - 1.0, dv2 = 0.0 - 1.0;
+  F3 dp1 = vsub(p1, p3);
+  F3 dp2 = vsub(p2, p3);
+  const double invdet = 1.0 / (du1 * dv2 - dv1 * du2);
+  dg->dpdu = vmul(vsub(vmul(dp1, dv2), vmul(dp2, dv1)), invdet);
+  dg->dpdv = vmul(vadd(vmul(dp1, -du2), vmul(dp2, du1)), invdet);
+  dg->p = vadd(o, vmul(d, t));  // Ray.pointAt ray.dart:66-67
+  F3 nn = vnormalize(vcross(dg->dpdu, dg->dpdv));
+  if (reverse) nn = vmul(nn, -1.0);
+  dg->nn = nn;
+}
+DR_DEV double tri_area(F3 p1, F3 p2, F3 p3) {  // triangle.dart:265-269
+  return 0.5 * vlen(vcross(vsub(p2, p1), vsub(p3, p1)));
+}
+
+// ---- montecarlo.dart ---------------------------------------------------------
+DR_DEV void ConcentricSampleDisk(double u1, double u2, double* dx, double* dy) {  // montecarlo.dart:155-201
+  double r, theta;
+  double sx = 2 * u1 - 1;
+  double sy = 2 * u2 - 1;
+  if (sx == 0.0 && sy == 0.0) {
+    *dx = 0.0;
+    *dy = 0.0;
+    return;
+  }
+  if (sx >= -sy) {
+    if (sx > sy) {
+      r = sx;
+      if (sy > 0.0) theta = sy / r;
+      else theta = 8.0 + sy / r;
+    } else {
+      r = sy;
+      theta = 2.0 - sx / r;
+    }
+  } else {
+    if (sx <= sy) {
+      r = -sx;
+      theta = 4.0 - sy / r;
+    } else {
+      r = -sy;
+      theta = 6.0 + sx / r;
+    }
+  }
+  theta *= DR_PI / 4.0;
+  *dx = r * cos(theta);
+  *dy = r * sin(theta);
+}
+DR_DEV F3 CosineSampleHemisphere(double u1, double u2) {  // montecarlo.dart:203-209
+  double dx, dy;
+  ConcentricSampleDisk(u1, u2, &dx, &dy);
+  double z = sqrt(fmax(0.0, 1.0 - dx * dx - dy * dy));
+  return f3(dx, dy, z);
+}
+DR_DEV double PowerHeuristic(double fPdf, double gPdf) {  // montecarlo.dart:480-484 with nf = ng = 1
+  double f = 1 * fPdf;
+  double g = 1 * gPdf;
+  return (f * f) / (f * f + g * g);
+}
+
+// ---- ShapeSet / DiffuseAreaLight ---------------------------------------------
+DR_DEV void ltri_verts(const DLightTri& t, F3* a, F3* b, F3* c) {
+  *a = F3{t.p[0], t.p[1], t.p[2]};
+  *b = F3{t.p[3], t.p[4], t.p[5]};
+  *c = F3{t.p[6], t.p[7], t.p[8]};
+}
+// Distribution1D.sampleDiscrete (montecarlo.dart:82-92) via upper_bound (common.dart:304-333).
+DR_DEV int sampleDiscrete(const float* cdf, int count, double u) {
+  int first = 0;
+  int cnt = count + 1;
+  while (cnt > 0) {
+    int step = cnt >> 1;
+    int index = first + step;
+    if (!(u < (double)cdf[index])) {
+      first = index + 1;
+      cnt -= step + 1;
+    } else {
+      cnt = step;
+    }
+  }
+  int off = first - 1;
+  return off < 0 ? 0 : off;
+}
+// ShapeSet.sample(ls, Ns, p) (shape_set.dart:53-80): pick by area, sample the
+// triangle (triangle.dart:366-383), then intersect p->pt with EVERY shape; the
+// last hitting shape in list order wins (r.maxDistance is never shrunk).
+DR_DEV F3 shapeset_sample(const DScene& sc, const DLight& L, double uPos0, double uPos1, double uComponent, F3* Ns, F3 p) {
+  int sn = sampleDiscrete(sc.lcdf + L.cdf_off, (int)L.ntris, uComponent) % (int)L.ntris;
+  F3 a, b, c;
+  const DLightTri& lt = sc.ltris[L.first_tri + sn];
+  ltri_verts(lt, &a, &b, &c);
+  double su1 = sqrt(uPos0);  // UniformSampleTriangle montecarlo.dart:215-220
+  double b1 = 1.0 - su1;
+  double b2 = uPos1 * su1;
+  F3 pt = vadd(vadd(vmul(a, b1), vmul(b, b2)), vmul(c, (1.0 - b1 - b2)));
+  F3 n = vnormalize(vcross(vsub(b, a), vsub(c, a)));
+  if (lt.reverse) n = F3{(float)((double)n.x * -1.0), (float)((double)n.y * -1.0), (float)((double)n.z * -1.0)};
+  *Ns = n;
+  F3 rd = vsub(pt, p);
+  double thit = 1.0;
+  bool anyHit = false;
+  for (uint32_t i = 0; i < L.ntris; ++i) {
+    const DLightTri& t = sc.ltris[L.first_tri + i];
+    ltri_verts(t, &a, &b, &c);
+    double th, bb1, bb2;
+    if (tri_hit(a, b, c, p, rd, 1.0e-3, DR_INF, &th, &bb1, &bb2)) {
+      DGeo dg;
+      tri_dg(a, b, c, t.reverse, p, rd, th, &dg);
+      thit = th;
+      *Ns = dg.nn;
+      anyHit = true;
+    }
+  }
+  (void)anyHit;
+  return vadd(p, vmul(rd, thit));
+}
+// ShapeSet.pdf(p, wi) (shape_set.dart:82-89) with Shape.pdf2 (shape.dart:100-121).
+DR_DEV double shapeset_pdf(const DScene& sc, const DLight& L, F3 p, F3 wi) {
+  double pdf = 0.0;
+  for (uint32_t i = 0; i < L.ntris; ++i) {
+    const DLightTri& t = sc.ltris[L.first_tri + i];
+    F3 a, b, c;
+    ltri_verts(t, &a, &b, &c);
+    double pdf2;
+    double th, bb1, bb2;
+    if (!tri_hit(a, b, c, p, wi, 1.0e-3, DR_INF, &th, &bb1, &bb2)) {
+      pdf2 = 0.0;
+    } else {
+      DGeo dg;
+      tri_dg(a, b, c, t.reverse, p, wi, th, &dg);
+      pdf2 = vlen2(vsub(dg.p, p)) / (fabs(vdot(dg.nn, vneg(wi))) * tri_area(a, b, c));
+      if (isinf(pdf2)) pdf2 = 0.0;
+    }
+    pdf += t.area * pdf2;
+  }
+  return pdf / L.area;
+}
+DR_DEV C3 light_L(const DLight& L, F3 n, F3 w) {  // diffuse_area_light.dart:44-46
+  return vdot(n, w) > 0.0 ? C3{L.L[0], L.L[1], L.L[2]} : C3{0.f, 0.f, 0.f};
+}
+
+// ---- BSDF with one Lambertian lobe -------------------------------------------
+// (matte_material.dart:41-65; reflection/bsdf.dart:45-211; bxdf.dart:31-48,84-88;
+//  lambertian.dart:31-37)
+#define BSDF_REFLECTION 1
+#define BSDF_TRANSMISSION 2
+#define BSDF_DIFFUSE 4
+#define BSDF_GLOSSY 8
+#define BSDF_SPECULAR 16
+#define BSDF_ALL 31
+#define LAMBERT_TYPE (BSDF_REFLECTION | BSDF_DIFFUSE)
+
+struct Bsdf {
+  F3 p, nn, sn, tn;  // ng == nn for triangles without shading normals (triangle.dart:273-276)
+  C3 R;
+  int nBxDFs;
+};
+DR_DEV bool lambert_matches(int flags) { return (LAMBERT_TYPE & flags) == LAMBERT_TYPE; }
+DR_DEV Bsdf make_bsdf(const DScene& sc, const DGeo& dg, uint32_t mat) {
+  Bsdf b;
+  b.p = dg.p;
+  b.nn = dg.nn;
+  b.sn = vnormalize(dg.dpdu);  // bsdf.dart:45-51
+  b.tn = vcross(b.nn, b.sn);
+  float4 m = sc.mats[mat];
+  // Kd.evaluate(dgs).clamp() (matte_material.dart:54)
+  C3 r = C3{m.x < 0.f ? 0.f : m.x, m.y < 0.f ? 0.f : m.y, m.z < 0.f ? 0.f : m.z};
+  b.R = r;
+  b.nBxDFs = cblack(r) ? 0 : 1;
+  return b;
+}
+DR_DEV F3 bsdf_w2l(const Bsdf& b, F3 v) { return f3(vdot(v, b.sn), vdot(v, b.tn), vdot(v, b.nn)); }  // bsdf.dart:177-179
+DR_DEV F3 bsdf_l2w(const Bsdf& b, F3 v) {                                                         // bsdf.dart:181-185
+  double vx = v.x, vy = v.y, vz = v.z;
+  return f3((double)b.sn.x * vx + (double)b.tn.x * vy + (double)b.nn.x * vz,
+            (double)b.sn.y * vx + (double)b.tn.y * vy + (double)b.nn.y * vz,
+            (double)b.sn.z * vx + (double)b.tn.z * vy + (double)b.nn.z * vz);
+}
+DR_DEV double lambert_pdf(F3 wo, F3 wi) {  // bxdf.dart:84-88
+  return ((double)wo.z * (double)wi.z > 0.0) ? fabs((double)wi.z) * DR_INV_PI : 0.0;
+}
+DR_DEV C3 bsdf_f(const Bsdf& b, F3 woW, F3 wiW, int flags) {  // bsdf.dart:187-211
+  if (vdot(wiW, b.nn) * vdot(woW, b.nn) > 0) flags = flags & ~BSDF_TRANSMISSION;
+  else flags = flags & ~BSDF_REFLECTION;
+  C3 f = C3{0.f, 0.f, 0.f};
+  if (b.nBxDFs > 0 && lambert_matches(flags)) f = cadd(f, cmulD(b.R, DR_INV_PI));
+  return f;
+}
+DR_DEV double bsdf_pdf(const Bsdf& b, F3 woW, F3 wiW, int flags) {  // bsdf.dart:135-156
+  if (b.nBxDFs == 0) return 0.0;
+  F3 wo = bsdf_w2l(b, woW);
+  F3 wi = bsdf_w2l(b, wiW);
+  double pdf = 0.0;
+  int matchingComps = 0;
+  if (lambert_matches(flags)) {
+    ++matchingComps;
+    pdf += lambert_pdf(wo, wi);
+  }
+  return matchingComps > 0 ? pdf / matchingComps : 0.0;
+}
+DR_DEV C3 bsdf_sample_f(const Bsdf& b, F3 woW, F3* wiW, double uDir0, double uDir1, double* pdf, int flags) {
+  // bsdf.dart:53-133 with a single non-specular lobe
+  if (!(b.nBxDFs > 0 && lambert_matches(flags))) {
+    *pdf = 0.0;
+    return C3{0.f, 0.f, 0.f};
+  }
+  F3 wo = bsdf_w2l(b, woW);
+  F3 wi = CosineSampleHemisphere(uDir0, uDir1);  // bxdf.dart:37-48
+  if (wo.z < 0.0f) wi.z = (float)((double)wi.z * -1.0);
+  *pdf = lambert_pdf(wo, wi);
+  if (*pdf == 0.0) return C3{0.f, 0.f, 0.f};
+  *wiW = bsdf_l2w(b, wi);
+  C3 f = C3{0.f, 0.f, 0.f};
+  if (vdot(*wiW, b.nn) * vdot(woW, b.nn) > 0) flags = flags & ~BSDF_TRANSMISSION;
+  else flags = flags & ~BSDF_REFLECTION;
+  if (lambert_matches(flags)) f = cadd(f, cmulD(b.R, DR_INV_PI));
+  return f;
+}
+
+#endif

@@ -1,0 +1,105 @@
+// dr_kernels.h -- structures shared between the kernels (dr_kernels.hip) and
+// the host driver (dr_api.hip).
+#ifndef DR_KERNELS_H
+#define DR_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dartray_hip.h"
+#include "dr_device.h"
+
+// Per-render constants (by-value kernel argument).
+struct RenderParams {
+  float r2c[16], c2w[16];
+  float lensRadius, focalDistance, shutterOpen, shutterClose;
+  // ImageFilm window (image_film.dart:61-65)
+  int32_t xres, yres, left, top, width, height;
+  double fxw, fyw, invX, invY;
+  int32_t integrator, maxDepth, spp, sppShift;
+  int32_t nFloats, n1D;  // floats per sample vector, number of 1-D floats
+  int32_t samplerMode;
+  int32_t nLights;
+  uint64_t seed;
+  // full sampler extent (ImageFilm.getSampleExtent image_film.dart:247-252): keys of the counter streams
+  int32_t extX0, extY0, extW, extH;
+  int32_t maxTail;
+  int32_t pad;
+};
+
+// Flags of a path slot.
+#define PF_HAS_SH 1u    // shadow (any-hit) ray of the light-sampling half is pending
+#define PF_HAS_MIS 2u   // closest-hit ray of the BSDF-sampling half is pending
+#define PF_HAS_CONT 4u  // continuation ray is pending
+
+#define Q_MIS_BIT 0x80000000u
+
+// Structure-of-arrays state of one batch of camera samples.  Slot s belongs to
+// batch pixel s >> sppShift, sample s & (spp-1).  Arrays of 3-vectors are laid
+// out [component][slot].
+struct BatchState {
+  uint32_t cap;     // slots allocated
+  uint32_t nslots;  // slots used by the current batch
+  const int2* pix;  // raster pixel of each batch pixel
+  float* sv;        // [nFloats][cap] sample vectors
+  const double* tail;  // [cap][maxTail] host-buffer mode, else null
+  float* ro;        // ray origin (vertex position p once a vertex has been shaded)
+  float* rd;        // continuation / camera ray direction
+  double* rtmin;    // Ray.minDistance (isect.rayEpsilon after the first vertex)
+  int32_t* hprim;   // closest-hit result of the camera / continuation ray
+  double* ht;
+  float* beta;      // pathThroughput (path) / running all-lights sum (direct)
+  float* L;         // radiance of the sample
+  float* betaNee;   // pathThroughput at the vertex whose NEE is pending
+  float* shD;       // shadow-ray direction
+  double* shTmax;
+  float* Ld1;       // light-sampling contribution if unoccluded
+  int32_t* shOcc;   // any-hit result
+  float* misD;      // BSDF-sampled direction of the MIS half
+  float* Ld2;       // its contribution if it reaches the sampled light's front face
+  int32_t* misLight;
+  int32_t* misPrim; // closest-hit result of the MIS ray
+  uint32_t* flags;
+};
+
+// Work queues of one stage.  Counts live in device memory so that no host
+// round trip is needed between launches.
+struct StageQueues {
+  const uint32_t* activeIn;   // slots shaded in the previous stage (null => identity)
+  const uint32_t* nActiveIn;  // device count (null => nslots)
+  uint32_t* activeOut;
+  uint32_t* nActiveOut;
+  uint32_t* closestQ;  // slot | Q_MIS_BIT
+  uint32_t* nClosest;
+  uint32_t* anyQ;
+  uint32_t* nAny;
+};
+
+struct TraceCounters {  // device-side totals (Stats probes of bvh_accel.dart:106-163)
+  unsigned long long closest_rays, any_rays, closest_nodes, any_nodes, closest_tris, any_tris;
+};
+
+#define DR_LDS_STACK 32       // stack entries per lane kept in LDS
+#define DR_MAX_STACK 128      // LDS + spill entries per lane (the reference uses 64, bvh_accel.dart:120)
+#define DR_TRACE_BLOCK 256
+
+// ---- launchers (dr_kernels.hip) ----
+void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t* mat, const int32_t* light,
+                        const uint8_t* rev, float4* out, uint64_t ntris, hipStream_t s);
+void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
+                      uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s);
+void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
+                  uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s);
+void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s);
+void launch_transpose_samples(const float* aos, int stride, const BatchState& st, int nFloats, hipStream_t s);
+void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s);
+void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
+                       int grid, hipStream_t s);
+void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
+                         int grid, hipStream_t s);
+void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
+                 hipStream_t s);
+void launch_film_resolve(const float* film, int64_t npix, float* rgb, hipStream_t s);
+void launch_copy(const float4* src, float4* dst, uint64_t n4, hipStream_t s);
+
+#endif

@@ -1,0 +1,777 @@
+// dr_kernels.hip -- hand-written gfx950 kernels of the DartRay hot path:
+//   k_trace<ANY>     BVHAccel.intersect / intersectP   (accelerators/bvh_accel.dart:101-226,439-472)
+//   k_shade_path     PathIntegrator.Li vertex step      (surface_integrators/path_integrator.dart:29-122,
+//                                                        core/integrator.dart:79-185)
+//   k_shade_direct   DirectLightingIntegrator.Li         (surface_integrators/direct_lighting_integrator.dart:30-68)
+//   k_gen_samples    LDPixelSample                       (core/montecarlo.dart:407-551)
+//   k_raygen         PerspectiveCamera.generateRayDifferential (cameras/perspective_camera.dart:93-132)
+//   k_film / k_film_resolve  ImageFilm.addSample / writeImage (film/image_film.dart:99-185,268-299)
+//
+// One ray per lane, 64-lane waves.  The traversal kernel is persistent: each
+// wave pulls 64 queue entries at a time from a device-side work counter and
+// keeps its todo stack in LDS ([depth][lane] => bank == lane, conflict free).
+// This path is latency / HBM bound (about 1 flop per byte): no MFMA.
+//
+// Compiled with -ffp-contract=off: the Dart VM never fuses a*b+c.
+#include "dr_kernels.h"
+#include "dr_rng.h"
+
+// ---------------------------------------------------------------------------
+// small wave helpers
+// ---------------------------------------------------------------------------
+DR_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+DR_DEV uint32_t wave_bcast_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// Append `val` for every lane with `pred` to a device queue: one ballot, one
+// prefix popcount and ONE atomic per wave.  Must be reached by the whole wave.
+DR_DEV void wave_push(uint32_t* q, uint32_t* count, bool pred, uint32_t val) {
+  unsigned long long m = __ballot(pred);
+  if (m == 0ull) return;
+  int lane = lane_id();
+  int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, leader);
+  if (pred) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = val;
+}
+DR_DEV unsigned long long wave_sum(uint32_t v) {
+  unsigned long long x = v;
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned int lo = (unsigned int)__shfl_xor((int)(uint32_t)(x & 0xffffffffull), off);
+    unsigned int hi = (unsigned int)__shfl_xor((int)(uint32_t)(x >> 32), off);
+    x += ((unsigned long long)hi << 32) | lo;
+  }
+  return x;
+}
+
+// ---------------------------------------------------------------------------
+// BVH traversal (bvh_accel.dart:101-226).  Returns the hit primitive (closest)
+// or 0 / -1 (any-hit: occluded / free).
+// ---------------------------------------------------------------------------
+template <int ANY>
+DR_DEV int traverse(const DScene& sc, F3 o, F3 d, double tmin, double tmax, uint32_t* lds, uint32_t* spill,
+                    uint32_t spillStride, double* tOut, uint32_t* nNodes, uint32_t* nTris) {
+  if (sc.nnodes == 0) return -1;
+  // invDir is a Vector: rounded to f32 (bvh_accel.dart:109-111)
+  const float ivx = (float)(1.0 / (double)d.x), ivy = (float)(1.0 / (double)d.y), ivz = (float)(1.0 / (double)d.z);
+  const bool n0 = ivx < 0.f, n1 = ivy < 0.f, n2 = ivz < 0.f;
+  const double ox = o.x, oy = o.y, oz = o.z;
+  const double dix = ivx, diy = ivy, diz = ivz;
+  int sp = 0;
+  uint32_t node = 0;
+  int hit = -1;
+  for (;;) {
+    const uint4 a = sc.nodes[2 * (size_t)node];
+    const uint4 b = sc.nodes[2 * (size_t)node + 1];
+    ++*nNodes;
+    const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
+    const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
+    const uint32_t offset = b.z, meta = b.w;
+    // _intersectP slab test (bvh_accel.dart:439-472), f64 products of f32 values
+    double t0 = ((double)(n0 ? bmaxx : bminx) - ox) * dix;
+    double t1 = ((double)(n0 ? bminx : bmaxx) - ox) * dix;
+    const double ty0 = ((double)(n1 ? bmaxy : bminy) - oy) * diy;
+    const double ty1 = ((double)(n1 ? bminy : bmaxy) - oy) * diy;
+    bool ok = !((t0 > ty1) || (ty0 > t1));
+    if (ok) {
+      if (ty0 > t0) t0 = ty0;
+      if (ty1 < t1) t1 = ty1;
+      const double tz0 = ((double)(n2 ? bmaxz : bminz) - oz) * diz;
+      const double tz1 = ((double)(n2 ? bminz : bmaxz) - oz) * diz;
+      ok = !((t0 > tz1) || (tz0 > t1));
+      if (ok) {
+        if (tz0 > t0) t0 = tz0;
+        if (tz1 < t1) t1 = tz1;
+        ok = (t0 < tmax) && (t1 > tmin);
+      }
+    }
+    bool pop = true;
+    if (ok) {
+      const uint32_t nprims = meta & 0xffffu;
+      if (nprims > 0) {
+        for (uint32_t i = 0; i < nprims; ++i) {
+          ++*nTris;
+          const float4* tp = sc.tris + 3 * (size_t)(offset + i);
+          const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+          const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
+          if (ANY) {
+            if (tri_hitP(p1, p2, p3, o, d, tmin, tmax)) return 0;  // bvh_accel.dart:193-195
+          } else {
+            double t, b1, b2;
+            if (tri_hit(p1, p2, p3, o, d, tmin, tmax, &t, &b1, &b2)) {
+              tmax = t;  // r.maxDistance = thit (geometric_primitive.dart:59)
+              hit = (int)(offset + i);
+            }
+          }
+        }
+      } else {
+        const uint32_t axis = (meta >> 16) & 0xffu;
+        const bool neg = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
+        const uint32_t far = neg ? node + 1 : offset;  // bvh_accel.dart:147-153
+        node = neg ? offset : node + 1;
+        if (sp < DR_LDS_STACK) lds[sp * DR_TRACE_BLOCK] = far;
+        else if (sp < DR_MAX_STACK) spill[(size_t)(sp - DR_LDS_STACK) * spillStride] = far;
+        ++sp;
+        pop = false;
+      }
+    }
+    if (pop) {
+      if (sp == 0) break;
+      --sp;
+      node = sp < DR_LDS_STACK ? lds[sp * DR_TRACE_BLOCK] : spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
+    }
+  }
+  if (!ANY) *tOut = tmax;
+  return hit;
+}
+
+DR_DEV void flush_counters(TraceCounters* ctr, int any, uint32_t rays, uint32_t nodes, uint32_t tris) {
+  unsigned long long r = wave_sum(rays), n = wave_sum(nodes), t = wave_sum(tris);
+  if (lane_id() == 0 && ctr) {
+    if (any) {
+      atomicAdd(&ctr->any_rays, r);
+      atomicAdd(&ctr->any_nodes, n);
+      atomicAdd(&ctr->any_tris, t);
+    } else {
+      atomicAdd(&ctr->closest_rays, r);
+      atomicAdd(&ctr->closest_nodes, n);
+      atomicAdd(&ctr->closest_tris, t);
+    }
+  }
+}
+
+// Persistent traversal kernel over a queue of path slots.
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace(DScene sc, BatchState st, const uint32_t* queue,
+                                                          const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
+                                                          TraceCounters* ctr) {
+  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
+  uint32_t* lds = s_stack + threadIdx.x;
+  const uint32_t spillStride = gridDim.x * DR_TRACE_BLOCK;
+  uint32_t* mySpill = spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr;
+  const uint32_t n = nQueue ? *nQueue : st.nslots;
+  const uint32_t cap = st.cap;
+  uint32_t rays = 0, nodes = 0, tris = 0;
+  for (;;) {
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(work, 64u);
+    base = wave_bcast_first(base);
+    if (base >= n) break;
+    const uint32_t idx = base + (uint32_t)lane_id();
+    if (idx < n) {
+      const uint32_t e = queue ? queue[idx] : idx;
+      const uint32_t slot = e & ~Q_MIS_BIT;
+      const F3 o = F3{st.ro[slot], st.ro[cap + slot], st.ro[2 * cap + slot]};
+      const double tmin = st.rtmin[slot];
+      ++rays;
+      if (ANY) {
+        const F3 d = F3{st.shD[slot], st.shD[cap + slot], st.shD[2 * cap + slot]};
+        double t;
+        int r = traverse<1>(sc, o, d, tmin, st.shTmax[slot], lds, mySpill, spillStride, &t, &nodes, &tris);
+        st.shOcc[slot] = (r >= 0) ? 1 : 0;
+      } else if (e & Q_MIS_BIT) {
+        const F3 d = F3{st.misD[slot], st.misD[cap + slot], st.misD[2 * cap + slot]};
+        double t;
+        st.misPrim[slot] = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
+      } else {
+        const F3 d = F3{st.rd[slot], st.rd[cap + slot], st.rd[2 * cap + slot]};
+        double t;
+        int r = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
+        st.hprim[slot] = r;
+        st.ht[slot] = t;
+      }
+    }
+  }
+  flush_counters(ctr, ANY, rays, nodes, tris);
+}
+
+// Aggregate.intersect / intersectP on caller-supplied rays (dr_intersect).
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect(DScene sc, const DrRay* rays, uint32_t n, DrHit* out,
+                                                              uint32_t* spill, uint32_t* work, TraceCounters* ctr) {
+  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
+  uint32_t* lds = s_stack + threadIdx.x;
+  const uint32_t spillStride = gridDim.x * DR_TRACE_BLOCK;
+  uint32_t* mySpill = spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr;
+  uint32_t nr = 0, nodes = 0, tris = 0;
+  for (;;) {
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(work, 64u);
+    base = wave_bcast_first(base);
+    if (base >= n) break;
+    const uint32_t idx = base + (uint32_t)lane_id();
+    if (idx < n) {
+      const DrRay r = rays[idx];
+      const F3 o = F3{r.o[0], r.o[1], r.o[2]}, d = F3{r.d[0], r.d[1], r.d[2]};
+      ++nr;
+      DrHit h;
+      h.pad = 0;
+      h.t = h.b1 = h.b2 = 0.0;
+      double t = 0.0;
+      h.prim = traverse<ANY>(sc, o, d, r.tmin, r.tmax, lds, mySpill, spillStride, &t, &nodes, &tris);
+      if (!ANY && h.prim >= 0) {
+        Tri tr = load_tri(sc, (uint32_t)h.prim);
+        double tt, b1, b2;
+        // same arithmetic as the accepting test; only the [tmin,tmax] gate differs
+        tri_hit(tr.p1, tr.p2, tr.p3, o, d, r.tmin, DR_INF, &tt, &b1, &b2);
+        h.t = t;
+        h.b1 = b1;
+        h.b2 = b2;
+      }
+      out[idx] = h;
+    }
+  }
+  flush_counters(ctr, ANY, nr, nodes, tris);
+}
+
+// ---------------------------------------------------------------------------
+// scene upload: gather each primitive's vertices into its 48-byte record
+// ---------------------------------------------------------------------------
+__global__ void k_gather_tris(const float* verts, const uint32_t* idx, const uint32_t* mat, const int32_t* light,
+                              const uint8_t* rev, float4* out, uint64_t ntris) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntris) return;
+  uint32_t a = idx[3 * i], b = idx[3 * i + 1], c = idx[3 * i + 2];
+  float4 q0 = make_float4(verts[3 * (size_t)a], verts[3 * (size_t)a + 1], verts[3 * (size_t)a + 2], verts[3 * (size_t)b]);
+  float4 q1 = make_float4(verts[3 * (size_t)b + 1], verts[3 * (size_t)b + 2], verts[3 * (size_t)c], verts[3 * (size_t)c + 1]);
+  float4 q2 = make_float4(verts[3 * (size_t)c + 2], __uint_as_float(mat[i]), __uint_as_float((uint32_t)light[i]),
+                          __uint_as_float((uint32_t)rev[i]));
+  out[3 * i] = q0;
+  out[3 * i + 1] = q1;
+  out[3 * i + 2] = q2;
+}
+
+// ---------------------------------------------------------------------------
+// LD sampler (montecarlo.dart:407-551), counter mode: lane = (pixel, LD block)
+// ---------------------------------------------------------------------------
+DR_DEV float VanDerCorput(uint32_t n, uint32_t scramble) {  // montecarlo.dart:495-504
+  n = __brev(n);
+  n ^= scramble;
+  // min(((n>>8)&0xffffff)/2^24, ONE_MINUS_EPSILON): the quotient never exceeds 1-2^-24
+  return (float)((double)((n >> 8) & 0xffffffu) / 16777216.0);
+}
+DR_DEV float Sobol2(uint32_t n, uint32_t scramble) {  // montecarlo.dart:486-493
+  for (uint32_t v = 1u << 31; n != 0; n >>= 1, v ^= v >> 1)
+    if (n & 1u) scramble ^= v;
+  return (float)((double)((scramble >> 8) & 0xffffffu) / 16777216.0);
+}
+
+__global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState st, uint32_t npix) {
+  extern __shared__ uint16_t s_perm[];  // [spp][64]
+  const int lane = threadIdx.x;
+  const uint32_t p = blockIdx.x * 64u + lane;
+  const int k = blockIdx.y;  // LD block: image, lens, time, 1-D slots, 2-D slots (montecarlo.dart:437-448)
+  const int spp = rp.spp;
+  bool is2D;
+  int dst;
+  if (k == 0) { is2D = true; dst = 0; }
+  else if (k == 1) { is2D = true; dst = 2; }
+  else if (k == 2) { is2D = false; dst = 4; }
+  else if (k < 3 + rp.n1D) { is2D = false; dst = 5 + (k - 3); }
+  else { is2D = true; dst = 5 + rp.n1D + 2 * (k - 3 - rp.n1D); }
+  if (p >= npix) return;
+  const int2 xy = st.pix[p];
+  const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
+  DartRandom rng;
+  rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
+  // LDShuffleScrambled1D/2D with nSamples == 1 (montecarlo.dart:524-551)
+  const uint32_t s0 = rng.randomUint();
+  const uint32_t s1 = is2D ? rng.randomUint() : 0u;
+  for (int i = 0; i < spp; ++i) (void)rng.randomUint();  // Shuffle of ONE entry: other = i + r % 1 (:294-303)
+  for (int i = 0; i < spp; ++i) s_perm[i * 64 + lane] = (uint16_t)i;
+  for (int i = 0; i < spp; ++i) {
+    const int other = i + (int)(rng.randomUint() % (uint32_t)(spp - i));
+    const uint16_t a = s_perm[i * 64 + lane];
+    s_perm[i * 64 + lane] = s_perm[other * 64 + lane];
+    s_perm[other * 64 + lane] = a;
+  }
+  float* out0 = st.sv + (size_t)dst * st.cap + (size_t)p * spp;
+  float* out1 = out0 + st.cap;
+  for (int j = 0; j < spp; ++j) {
+    const uint32_t idx = s_perm[j * 64 + lane];
+    out0[j] = VanDerCorput(idx, s0);
+    if (is2D) out1[j] = Sobol2(idx, s1);
+  }
+}
+
+// Host-buffer mode: [n][stride] -> [nFloats][cap]
+__global__ void k_transpose_samples(const float* aos, int stride, BatchState st, int nFloats) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= st.nslots) return;
+  for (int k = 0; k < nFloats; ++k) st.sv[(size_t)k * st.cap + s] = aos[(size_t)s * stride + k];
+}
+
+// ---------------------------------------------------------------------------
+// camera (perspective_camera.dart:93-132; transform.dart:110-144)
+// ---------------------------------------------------------------------------
+DR_DEV F3 xf_point(const float* m, F3 p) {
+  double x = p.x, y = p.y, z = p.z;
+  F3 o = f3((double)m[0] * x + (double)m[1] * y + (double)m[2] * z + (double)m[3],
+            (double)m[4] * x + (double)m[5] * y + (double)m[6] * z + (double)m[7],
+            (double)m[8] * x + (double)m[9] * y + (double)m[10] * z + (double)m[11]);
+  double w = (double)m[12] * x + (double)m[13] * y + (double)m[14] * z + (double)m[15];
+  if (w != 1.0) o = f3((double)o.x / w, (double)o.y / w, (double)o.z / w);  // invScale
+  return o;
+}
+DR_DEV F3 xf_vector(const float* m, F3 p) {
+  double x = p.x, y = p.y, z = p.z;
+  return f3((double)m[0] * x + (double)m[1] * y + (double)m[2] * z, (double)m[4] * x + (double)m[5] * y + (double)m[6] * z,
+            (double)m[8] * x + (double)m[9] * y + (double)m[10] * z);
+}
+
+__global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= st.nslots) return;
+  const uint32_t cap = st.cap;
+  const int2 xy = st.pix[s >> rp.sppShift];
+  const double imageX = (double)xy.x + (double)st.sv[s];               // montecarlo.dart:451-452
+  const double imageY = (double)xy.y + (double)st.sv[(size_t)cap + s];
+  F3 Pras = f3(imageX, imageY, 0.0);
+  F3 Pcamera = xf_point(rp.r2c, Pras);
+  F3 o = F3{0.f, 0.f, 0.f};
+  F3 d = vnormalize(Pcamera);
+  if (rp.lensRadius > 0.0f) {
+    double lu, lv;
+    ConcentricSampleDisk((double)st.sv[2 * (size_t)cap + s], (double)st.sv[3 * (size_t)cap + s], &lu, &lv);
+    lu *= (double)rp.lensRadius;
+    lv *= (double)rp.lensRadius;
+    double ft = (double)rp.focalDistance / (double)d.z;
+    F3 Pfocus = vadd(o, vmul(d, ft));
+    o = f3(lu, lv, 0.0);
+    d = vnormalize(vsub(Pfocus, o));
+  }
+  o = xf_point(rp.c2w, o);
+  d = xf_vector(rp.c2w, d);
+  st.ro[s] = o.x; st.ro[cap + s] = o.y; st.ro[2 * cap + s] = o.z;
+  st.rd[s] = d.x; st.rd[cap + s] = d.y; st.rd[2 * cap + s] = d.z;
+  st.rtmin[s] = 0.0;
+  st.hprim[s] = -1;
+  st.beta[s] = 1.f; st.beta[cap + s] = 1.f; st.beta[2 * cap + s] = 1.f;
+  st.L[s] = 0.f; st.L[cap + s] = 0.f; st.L[2 * cap + s] = 0.f;
+  st.flags[s] = PF_HAS_CONT;
+}
+
+// ---------------------------------------------------------------------------
+// shading
+// ---------------------------------------------------------------------------
+DR_DEV F3 ld3(const float* a, uint32_t cap, uint32_t s) { return F3{a[s], a[cap + s], a[2 * cap + s]}; }
+DR_DEV void st3(float* a, uint32_t cap, uint32_t s, F3 v) { a[s] = v.x; a[cap + s] = v.y; a[2 * cap + s] = v.z; }
+DR_DEV C3 ldc(const float* a, uint32_t cap, uint32_t s) { return C3{a[s], a[cap + s], a[2 * cap + s]}; }
+DR_DEV void stc(float* a, uint32_t cap, uint32_t s, C3 v) { a[s] = v.r; a[cap + s] = v.g; a[2 * cap + s] = v.b; }
+
+// EstimateDirect's contribution of the pending NEE rays (integrator.dart:135-145,169-180).
+DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uint32_t flags) {
+  const uint32_t cap = st.cap;
+  C3 Ld = C3{0.f, 0.f, 0.f};
+  if ((flags & PF_HAS_SH) && st.shOcc[slot] == 0) Ld = cadd(Ld, ldc(st.Ld1, cap, slot));
+  if (flags & PF_HAS_MIS) {
+    const int prim = st.misPrim[slot];
+    if (prim >= 0) {
+      Tri tr = load_tri(sc, (uint32_t)prim);
+      const int li = st.misLight[slot];
+      if (tr.light == li) {  // lightIsect.primitive.getAreaLight() == light (integrator.dart:170-172)
+        const F3 wi = ld3(st.misD, cap, slot);
+        DGeo dg;
+        tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, wi, 0.0, &dg);  // only nn is used
+        C3 Li = light_L(sc.lights[li], dg.nn, vneg(wi));
+        if (!cblack(Li)) Ld = cadd(Ld, ldc(st.Ld2, cap, slot));
+      }
+    }
+  }
+  return Ld;
+}
+
+// EstimateDirect up to the points where it must trace (integrator.dart:119-185):
+// writes the shadow ray / MIS ray and their candidate contributions.
+DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
+                          F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1) {
+  const uint32_t cap = st.cap;
+  const DLight& light = sc.lights[lightNum];
+  const int flags = BSDF_ALL & ~BSDF_SPECULAR;
+  uint32_t pf = 0;
+  // light.sampleLAtPoint (diffuse_area_light.dart:60-70)
+  F3 ns;
+  F3 ps = shapeset_sample(sc, light, ls0, ls1, lsc, &ns, p);
+  F3 wi = vnormalize(vsub(ps, p));
+  double lightPdf = shapeset_pdf(sc, light, p, wi);
+  C3 Li = light_L(light, ns, vneg(wi));
+  if (lightPdf > 0.0 && !cblack(Li)) {
+    C3 f = bsdf_f(bsdf, wo, wi, flags);
+    if (!cblack(f)) {
+      // VisibilityTester.setSegment (visibility_tester.dart:26-29)
+      F3 seg = vsub(ps, p);
+      double dist = vlen(seg);
+      st3(st.shD, cap, slot, vdiv(seg, dist));
+      st.shTmax[slot] = dist * (1.0 - 1.0e-3);
+      double bsdfPdf = bsdf_pdf(bsdf, wo, wi, flags);
+      double weight = PowerHeuristic(lightPdf, bsdfPdf);
+      stc(st.Ld1, cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) * weight / lightPdf)));
+      pf |= PF_HAS_SH;
+    }
+  }
+  // BSDF-sampling half
+  {
+    F3 wi2 = F3{0, 0, 0};
+    double bsdfPdf = 0.0;
+    C3 f = bsdf_sample_f(bsdf, wo, &wi2, bs0, bs1, &bsdfPdf, flags);
+    if (!cblack(f) && bsdfPdf > 0.0) {
+      double lightPdf2 = shapeset_pdf(sc, light, p, wi2);
+      if (lightPdf2 != 0.0) {
+        double weight = PowerHeuristic(bsdfPdf, lightPdf2);
+        C3 Lemit = C3{light.L[0], light.L[1], light.L[2]};
+        st3(st.misD, cap, slot, wi2);
+        stc(st.Ld2, cap, slot, cmulD(cmul(f, Lemit), (fabs(vdot(wi2, n)) * weight / bsdfPdf)));
+        st.misLight[slot] = lightNum;
+        pf |= PF_HAS_MIS;
+      }
+    }
+  }
+  return pf;
+}
+
+// In-Li random floats (rng.randomFloat() inside PathIntegrator.Li): recorded
+// values in host-buffer mode, the (pixel, sample) stream in counter mode.
+struct TailSrc {
+  const double* rec;
+  DartRandom rng;
+  int pos;
+  DR_DEV void init(const RenderParams& rp, const BatchState& st, uint32_t slot, int startPos) {
+    pos = startPos;
+    if (st.tail) {
+      rec = st.tail + (size_t)slot * rp.maxTail;
+    } else {
+      rec = nullptr;
+      const int2 xy = st.pix[slot >> rp.sppShift];
+      const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
+      rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)(slot & (uint32_t)(rp.spp - 1)), 2));
+      for (int i = 0; i < 2 * startPos; ++i) rng.step();
+    }
+  }
+  DR_DEV double next(const RenderParams& rp) {
+    if (rec) {
+      double v = pos < rp.maxTail ? rec[pos] : 0.0;
+      ++pos;
+      return v;
+    }
+    ++pos;
+    return rng.randomFloat();
+  }
+};
+
+// One vertex of PathIntegrator.Li (path_integrator.dart:44-119).
+__global__ void __launch_bounds__(256) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
+  const uint32_t cap = st.cap;
+  const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t nIter = (nIn + stride - 1) / stride;
+  for (uint32_t it = 0; it < nIter; ++it) {
+    const uint32_t idx = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = idx < nIn;
+    uint32_t slot = 0, pf = 0;
+    bool pushCont = false;
+    if (valid) {
+      slot = q.activeIn ? q.activeIn[idx] : idx;
+      const uint32_t flags = st.flags[slot];
+      C3 L = ldc(st.L, cap, slot);
+      if (bounce > 0 && rp.nLights > 0) {
+        // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
+        C3 Ld = resolve_nee(sc, st, slot, flags);
+        C3 tot = cmulD(Ld, (double)rp.nLights);  // integrator.dart:113-116
+        L = cadd(L, cmul(ldc(st.betaNee, cap, slot), tot));
+      }
+      const int prim = (flags & PF_HAS_CONT) ? st.hprim[slot] : -1;
+      if (prim >= 0 && bounce <= rp.maxDepth) {
+        const F3 o = ld3(st.ro, cap, slot), d = ld3(st.rd, cap, slot);
+        const double t = st.ht[slot];
+        Tri tr = load_tri(sc, (uint32_t)prim);
+        DGeo dg;
+        tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
+        C3 beta = ldc(st.beta, cap, slot);
+        const F3 wo = vneg(d);
+        if (bounce == 0) {  // specularBounce is never set by a matte BSDF
+          C3 Le = tr.light >= 0 ? light_L(sc.lights[tr.light], dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
+          L = cadd(L, cmul(beta, Le));
+        }
+        Bsdf bsdf = make_bsdf(sc, dg, tr.mat);
+        const F3 p = bsdf.p, n = bsdf.nn;
+        const double eps = 1.0e-3 * t;  // triangle.dart:157
+        TailSrc ts;
+        const int perNee = rp.nLights > 0 ? 7 : 0;
+        if (bounce >= 3) ts.init(rp, st, slot, (bounce - 3) * (perNee + 3) + (bounce > 4 ? bounce - 4 : 0));
+        const float* sv = st.sv;
+        if (rp.nLights > 0) {
+          double lu, ls0, ls1, lsc, bs0, bs1;
+          if (bounce < 3) {  // SAMPLE_DEPTH (path_integrator.dart:139), slots of Appendix B
+            lu = sv[(size_t)(5 + 4 * bounce + 1) * cap + slot];
+            lsc = sv[(size_t)(5 + 4 * bounce + 0) * cap + slot];
+            ls0 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 0)) * cap + slot];
+            ls1 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 0) + 1) * cap + slot];
+            bs0 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 1)) * cap + slot];
+            bs1 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 1) + 1) * cap + slot];
+          } else {
+            lu = ts.next(rp);                                   // integrator.dart:96
+            ls0 = (float)ts.next(rp); ls1 = (float)ts.next(rp); // LightSample.random light_sample.dart:46-51
+            lsc = ts.next(rp);
+            bs0 = (float)ts.next(rp); bs1 = (float)ts.next(rp); // BSDFSample.random bsdf_sample.dart:37-42
+            (void)ts.next(rp);                                  // uComponent (single lobe)
+          }
+          int lightNum = (int)floor(lu * rp.nLights);
+          lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
+          pf |= setup_nee(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1);
+          stc(st.betaNee, cap, slot, beta);
+        }
+        // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
+        double o0, o1;
+        if (bounce < 3) {
+          o0 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 2)) * cap + slot];
+          o1 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 2) + 1) * cap + slot];
+        } else {
+          o0 = (float)ts.next(rp); o1 = (float)ts.next(rp);
+          (void)ts.next(rp);
+        }
+        F3 wi = F3{0, 0, 0};
+        double pdf = 0.0;
+        C3 f = bsdf_sample_f(bsdf, wo, &wi, o0, o1, &pdf, BSDF_ALL);
+        bool alive = !(cblack(f) || pdf == 0.0);
+        if (alive) {
+          beta = cmul(beta, cdivD(cmulD(f, fabs(vdot(wi, n))), pdf));
+          if (bounce > 3) {  // Russian roulette, drawn BEFORE the maxDepth test (path_integrator.dart:93-103)
+            double lum = clum(beta);
+            double cp = (lum != lum) ? lum : (lum < 0.5 ? lum : 0.5);  // Math.min(0.5, lum) propagates NaN
+            if (ts.next(rp) > cp) alive = false;
+            else beta = cdivD(beta, cp);
+          }
+        }
+        if (alive && bounce != rp.maxDepth) {
+          st3(st.rd, cap, slot, wi);
+          stc(st.beta, cap, slot, beta);
+          pf |= PF_HAS_CONT;
+          pushCont = true;
+        }
+        st3(st.ro, cap, slot, p);
+        st.rtmin[slot] = eps;
+      }
+      stc(st.L, cap, slot, L);
+      st.flags[slot] = pf;
+    }
+    wave_push(q.closestQ, q.nClosest, pushCont, slot);
+    wave_push(q.closestQ, q.nClosest, (pf & PF_HAS_MIS) != 0, slot | Q_MIS_BIT);
+    wave_push(q.anyQ, q.nAny, (pf & PF_HAS_SH) != 0, slot);
+    wave_push(q.activeOut, q.nActiveOut, pf != 0, slot);
+  }
+}
+
+// DirectLightingIntegrator.Li with strategy "all" (direct_lighting_integrator.dart:30-68;
+// integrator.dart:39-77).  Stage s sets up the NEE of light s at the camera hit;
+// stage nLights finishes the sum.  st.beta carries UniformSampleAllLights' L.
+__global__ void __launch_bounds__(256) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
+  const uint32_t cap = st.cap;
+  const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t nIter = (nIn + stride - 1) / stride;
+  for (uint32_t it = 0; it < nIter; ++it) {
+    const uint32_t idx = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = idx < nIn;
+    uint32_t slot = 0, pf = 0;
+    bool again = false;
+    if (valid) {
+      slot = q.activeIn ? q.activeIn[idx] : idx;
+      const uint32_t flags = st.flags[slot];
+      const int prim = st.hprim[slot];
+      if (prim >= 0) {
+        Tri tr = load_tri(sc, (uint32_t)prim);
+        const F3 d = ld3(st.rd, cap, slot);
+        const F3 wo = vneg(d);
+        C3 L = ldc(st.L, cap, slot);
+        C3 Lall = ldc(st.beta, cap, slot);
+        DGeo dg;
+        if (stage == 0) {
+          const F3 o = ld3(st.ro, cap, slot);
+          const double t = st.ht[slot];
+          tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
+          C3 Le = tr.light >= 0 ? light_L(sc.lights[tr.light], dg.nn, wo) : C3{0.f, 0.f, 0.f};
+          L = cadd(L, Le);
+          Lall = C3{0.f, 0.f, 0.f};
+          st3(st.ro, cap, slot, dg.p);
+          st.rtmin[slot] = 1.0e-3 * t;
+        } else {
+          tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
+          dg.p = ld3(st.ro, cap, slot);
+          C3 Ld = resolve_nee(sc, st, slot, flags);               // Ld += EstimateDirect (one sample per light)
+          Lall = cadd(Lall, cdivD(Ld, 1.0));                      // L += Ld / nSamples
+        }
+        if (stage < rp.nLights) {
+          Bsdf bsdf = make_bsdf(sc, dg, tr.mat);
+          const float* sv = st.sv;
+          // slots of light `stage` (direct_lighting_integrator.dart:70-87)
+          double lsc = sv[(size_t)(5 + 2 * stage) * cap + slot];
+          double ls0 = sv[(size_t)(5 + rp.n1D + 4 * stage) * cap + slot];
+          double ls1 = sv[(size_t)(5 + rp.n1D + 4 * stage + 1) * cap + slot];
+          double bs0 = sv[(size_t)(5 + rp.n1D + 4 * stage + 2) * cap + slot];
+          double bs1 = sv[(size_t)(5 + rp.n1D + 4 * stage + 3) * cap + slot];
+          pf |= setup_nee(sc, st, slot, stage, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1);
+          again = true;
+        } else {
+          if (rp.nLights > 0) L = cadd(L, Lall);
+          if (0 + 1 < rp.maxDepth) {  // SpecularReflect / SpecularTransmit find no specular lobe: += 0
+            L = cadd(L, C3{0.f, 0.f, 0.f});
+            L = cadd(L, C3{0.f, 0.f, 0.f});
+          }
+        }
+        stc(st.L, cap, slot, L);
+        stc(st.beta, cap, slot, Lall);
+      }
+      st.flags[slot] = pf;
+    }
+    wave_push(q.closestQ, q.nClosest, (pf & PF_HAS_MIS) != 0, slot | Q_MIS_BIT);
+    wave_push(q.anyQ, q.nAny, (pf & PF_HAS_SH) != 0, slot);
+    wave_push(q.activeOut, q.nActiveOut, again, slot);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// film (image_film.dart:99-185): one lane owns one batch pixel and adds its spp
+// samples in the reference's order; contributions to other pixels (wide
+// filters, or imageX exactly integral) go through float atomics.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, const float* table, uint32_t npix, float* film) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const uint32_t cap = st.cap;
+  const int2 xy = st.pix[p];
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accw = 0.f;
+  const bool ownInside = xy.x >= rp.left && xy.x < rp.left + rp.width && xy.y >= rp.top && xy.y < rp.top + rp.height;
+  for (int i = 0; i < rp.spp; ++i) {
+    const uint32_t s = p * (uint32_t)rp.spp + (uint32_t)i;
+    C3 L = ldc(st.L, cap, s);
+    // guards of sampler_renderer.dart:181-193
+    double lum = clum(L);
+    if (L.r != L.r || L.g != L.g || L.b != L.b) L = C3{0.f, 0.f, 0.f};
+    else if (lum < -1e-5) L = C3{0.f, 0.f, 0.f};
+    else if (isinf(lum)) L = C3{0.f, 0.f, 0.f};
+    const double dimageX = ((double)xy.x + (double)st.sv[s]) - 0.5;
+    const double dimageY = ((double)xy.y + (double)st.sv[(size_t)cap + s]) - 0.5;
+    int x0 = (int)ceil(dimageX - rp.fxw), x1 = (int)floor(dimageX + rp.fxw);
+    int y0 = (int)ceil(dimageY - rp.fyw), y1 = (int)floor(dimageY + rp.fyw);
+    x0 = max(x0, rp.left); x1 = min(x1, rp.left + rp.width - 1);
+    y0 = max(y0, rp.top);  y1 = min(y1, rp.top + rp.height - 1);
+    if ((x1 - x0) < 0 || (y1 - y0) < 0) continue;
+    // L.toXYZ(): Float32List store (xyz_color.dart:39-42; spectrum.dart:294-298)
+    const float X = (float)(0.412453 * (double)L.r + 0.357580 * (double)L.g + 0.180423 * (double)L.b);
+    const float Y = (float)(0.212671 * (double)L.r + 0.715160 * (double)L.g + 0.072169 * (double)L.b);
+    const float Z = (float)(0.019334 * (double)L.r + 0.119193 * (double)L.g + 0.950227 * (double)L.b);
+    for (int y = y0; y <= y1; ++y) {
+      const double fy = fabs(((double)y - dimageY) * rp.invY * 16);
+      const int iy = min((int)floor(fy), 15);
+      for (int x = x0; x <= x1; ++x) {
+        const double fx = fabs(((double)x - dimageX) * rp.invX * 16);
+        const int ix = min((int)floor(fx), 15);
+        const double wt = table[iy * 16 + ix];
+        if (x == xy.x && y == xy.y) {
+          acc0 = (float)((double)acc0 + wt * (double)X);
+          acc1 = (float)((double)acc1 + wt * (double)Y);
+          acc2 = (float)((double)acc2 + wt * (double)Z);
+          accw = (float)((double)accw + wt);
+        } else {
+          float* px = film + 4 * ((size_t)(y - rp.top) * rp.width + (size_t)(x - rp.left));
+          atomicAdd(px + 0, (float)(wt * (double)X));
+          atomicAdd(px + 1, (float)(wt * (double)Y));
+          atomicAdd(px + 2, (float)(wt * (double)Z));
+          atomicAdd(px + 3, (float)wt);
+        }
+      }
+    }
+  }
+  if (ownInside) {
+    float* px = film + 4 * ((size_t)(xy.y - rp.top) * rp.width + (size_t)(xy.x - rp.left));
+    atomicAdd(px + 0, acc0);
+    atomicAdd(px + 1, acc1);
+    atomicAdd(px + 2, acc2);
+    atomicAdd(px + 3, accw);
+  }
+}
+
+// ImageFilm.writeImage (image_film.dart:268-299), splat == 0.
+__global__ void k_film_resolve(const float* film, int64_t npix, float* rgb) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const double X = film[4 * p], Y = film[4 * p + 1], Z = film[4 * p + 2], w = film[4 * p + 3];
+  const double c0 = 3.240479 * X - 1.537150 * Y - 0.498535 * Z;  // spectrum.dart:287-291
+  const double c1 = -0.969256 * X + 1.875991 * Y + 0.041556 * Z;
+  const double c2 = 0.055648 * X - 0.204043 * Y + 1.057311 * Z;
+  float r = 0.f, g = 0.f, b = 0.f;
+  if (w != 0.0) {
+    const double invWt = 1.0 / w;
+    r = (float)fmax(0.0, c0 * invWt);
+    g = (float)fmax(0.0, c1 * invWt);
+    b = (float)fmax(0.0, c2 * invWt);
+  }
+  rgb[3 * p] = (float)((double)r + 0.0);
+  rgb[3 * p + 1] = (float)((double)g + 0.0);
+  rgb[3 * p + 2] = (float)((double)b + 0.0);
+}
+
+// float4 copy: the measured HBM-bandwidth denominator of the roofline.
+__global__ void __launch_bounds__(256) k_copy(const float4* __restrict__ src, float4* __restrict__ dst, uint64_t n4) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t* mat, const int32_t* light,
+                        const uint8_t* rev, float4* out, uint64_t ntris, hipStream_t s) {
+  if (ntris == 0) return;
+  hipLaunchKernelGGL(k_gather_tris, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, verts, idx, mat, light, rev, out,
+                     ntris);
+}
+void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
+                      uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
+  if (anyHit)
+    hipLaunchKernelGGL(k_intersect<1>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+  else
+    hipLaunchKernelGGL(k_intersect<0>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+}
+void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
+                  uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
+  if (anyHit)
+    hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+  else
+    hipLaunchKernelGGL(k_trace<0>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+}
+void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s) {
+  const int nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
+  const size_t lds = (size_t)rp.spp * 64 * sizeof(uint16_t);
+  static bool attrSet = false;
+  if (!attrSet) {
+    (void)hipFuncSetAttribute((const void*)k_gen_samples, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attrSet = true;
+  }
+  hipLaunchKernelGGL(k_gen_samples, dim3((npix + 63) / 64, nBlocks), dim3(64), lds, s, rp, st, npix);
+}
+void launch_transpose_samples(const float* aos, int stride, const BatchState& st, int nFloats, hipStream_t s) {
+  hipLaunchKernelGGL(k_transpose_samples, dim3((st.nslots + 255) / 256), dim3(256), 0, s, aos, stride, st, nFloats);
+}
+void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) {
+  hipLaunchKernelGGL(k_raygen, dim3((st.nslots + 255) / 256), dim3(256), 0, s, rp, st);
+}
+void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
+                       int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_shade_path, dim3(grid), dim3(256), 0, s, sc, rp, st, q, bounce);
+}
+void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
+                         int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_shade_direct, dim3(grid), dim3(256), 0, s, sc, rp, st, q, stage);
+}
+void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
+                 hipStream_t s) {
+  hipLaunchKernelGGL(k_film, dim3((npix + 255) / 256), dim3(256), 0, s, rp, st, filterTable, npix, film);
+}
+void launch_film_resolve(const float* film, int64_t npix, float* rgb, hipStream_t s) {
+  hipLaunchKernelGGL(k_film_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, film, npix, rgb);
+}
+void launch_copy(const float4* src, float4* dst, uint64_t n4, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, s, src, dst, n4);
+}

@@ -1,0 +1,168 @@
+"""Procedural scenes of BASELINE.json's configs.
+
+All geometry is synthetic and seeded; vertices are f32 world-space.  The Cornell
+box follows web/scenes/cornell-path.pbrt:5-31 semantics: 20x20x20 box centred at
+the origin, open towards -z, camera LookAt 0 0 -35 -> 0 0 0, fov 35, one quad
+emitter L = 36 under the ceiling whose own surface is matte Kd 0.5
+(graphics_state.dart:25, matte_material.dart:68).
+"""
+import math
+
+import numpy as np
+
+from .core import (BVHAccel, BoxFilter, DiffuseAreaLight, DirectLightingIntegrator, EmissionIntegrator,
+                   GeometricPrimitive, ImageFilm, LowDiscrepancySampler, MatteMaterial, PathIntegrator,
+                   PerspectiveCamera, SamplerRenderer, Scene, TriangleMesh)
+
+WHITE = (0.75, 0.75, 0.75)
+RED = (0.48, 0.1125, 0.075)
+GREEN = (0.1125, 0.375, 0.1125)
+
+
+def _quad(p0, p1, p2, p3, Kd, light=None):
+    """Quad p0 p1 p2 p3 as triangles (p0,p1,p2), (p0,p2,p3)."""
+    P = np.array([p0, p1, p2, p3], dtype=np.float32)
+    idx = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32)
+    mesh = TriangleMesh(idx, P)
+    return GeometricPrimitive(mesh, MatteMaterial(Kd), light)
+
+
+def emitter_quad(L=(36.0, 36.0, 36.0), half=3.0, y=9.9):
+    """6x6 quad facing down: area lights are one-sided (diffuse_area_light.dart:44-46) and the
+    normal is normalize((p2-p1) x (p3-p1)), so the winding makes it (0,-1,0)."""
+    h = half
+    return _quad((-h, y, -h), (h, y, -h), (h, y, h), (-h, y, h), (0.5, 0.5, 0.5), DiffuseAreaLight(L, 1))
+
+
+def floor_quad():
+    return _quad((-10, -10, -10), (10, -10, -10), (10, -10, 10), (-10, -10, 10), WHITE)
+
+
+def cornell_walls():
+    s = 10.0
+    return [
+        floor_quad(),
+        _quad((-s, s, -s), (-s, s, s), (s, s, s), (s, s, -s), WHITE),        # ceiling
+        _quad((-s, -s, s), (s, -s, s), (s, s, s), (-s, s, s), WHITE),         # back wall (z = +10)
+        _quad((-s, -s, -s), (-s, -s, s), (-s, s, s), (-s, s, -s), RED),       # left wall (x = -10)
+        _quad((s, -s, -s), (s, s, -s), (s, s, s), (s, -s, s), GREEN),         # right wall (x = +10)
+    ]
+
+
+def blob_mesh(segments=1000, rows=500, radius=5.0, centre=(0.0, -5.0, 0.0)):
+    """Displaced UV sphere, closed, no degenerate triangles:
+    (rows-1) bands x segments x 2 + 2 polar fans x segments  ==  2 * rows * segments triangles
+    (1000 x 500 -> exactly 1 000 000).  Radial displacement
+    1 + 0.15 sin(7 theta) sin(5 phi) + 0.05 sin(31 theta + 1) sin(29 phi + 2)."""
+    j = np.arange(rows, dtype=np.float64)
+    theta = math.pi * (j + 0.5) / rows                  # polar angle, poles excluded
+    i = np.arange(segments, dtype=np.float64)
+    phi = 2.0 * math.pi * i / segments
+    th, ph = np.meshgrid(theta, phi, indexing="ij")
+
+    def disp(t, p):
+        return 1.0 + 0.15 * np.sin(7 * t) * np.sin(5 * p) + 0.05 * np.sin(31 * t + 1) * np.sin(29 * p + 2)
+
+    r = radius * disp(th, ph)
+    x = r * np.sin(th) * np.cos(ph)
+    y = r * np.cos(th)
+    z = r * np.sin(th) * np.sin(ph)
+    grid = np.stack([x, y, z], axis=-1).reshape(-1, 3)
+    top = np.array([[0.0, radius * disp(0.0, 0.0), 0.0]])
+    bottom = np.array([[0.0, -radius * disp(math.pi, 0.0), 0.0]])
+    P = (np.concatenate([grid, top, bottom]) + np.asarray(centre, dtype=np.float64)).astype(np.float32)
+    nt, nb = rows * segments, rows * segments + 1
+    a = (np.arange(rows - 1)[:, None] * segments + np.arange(segments)[None, :])
+    b = (np.arange(rows - 1)[:, None] * segments + (np.arange(segments)[None, :] + 1) % segments)
+    c, d = a + segments, b + segments
+    bands = np.concatenate([np.stack([a, c, b], -1).reshape(-1, 3), np.stack([b, c, d], -1).reshape(-1, 3)])
+    s0 = np.arange(segments)
+    s1 = (s0 + 1) % segments
+    fan_top = np.stack([np.full(segments, nt), s0, s1], -1)
+    last = (rows - 1) * segments
+    fan_bot = np.stack([np.full(segments, nb), last + s1, last + s0], -1)
+    idx = np.concatenate([bands, fan_top, fan_bot]).astype(np.uint32)
+    assert len(idx) == 2 * rows * segments
+    return TriangleMesh(idx, P)
+
+
+def hairball_mesh(strands=10000, segments=500, seed=0x9E3779B97F4A7C15, step=0.02, jitter=0.3, half_width=0.002,
+                  scale=8.0):
+    """Procedural hairball: each strand is a random walk from a point on the unit sphere, drawn as a
+    ribbon of 2 triangles per segment (10 000 x 500 x 2 = 10 000 000 triangles)."""
+    rng = np.random.Generator(np.random.PCG64(seed & 0xFFFFFFFFFFFFFFFF))
+    v = rng.normal(size=(strands, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    pos = v.copy()
+    dirn = v.copy()
+    pts = np.empty((strands, segments + 1, 3), dtype=np.float64)
+    pts[:, 0] = pos
+    for s in range(segments):
+        dirn = dirn + jitter * rng.normal(size=(strands, 3))
+        dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+        pos = pos + step * dirn
+        pts[:, s + 1] = pos
+    side = np.cross(pts[:, 1:] - pts[:, :-1], pts[:, :-1])
+    side = np.concatenate([side, side[:, -1:]], axis=1)
+    side /= np.maximum(np.linalg.norm(side, axis=2, keepdims=True), 1e-12)
+    left = (pts - half_width * side) * scale
+    right = (pts + half_width * side) * scale
+    P = np.stack([left, right], axis=2).reshape(-1, 3).astype(np.float32)  # vertex (strand, k, side)
+    base = (np.arange(strands)[:, None] * (segments + 1) + np.arange(segments)[None, :]) * 2
+    a, b, c, d = base, base + 1, base + 2, base + 3
+    idx = np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([b, d, c], -1).reshape(-1, 3)])
+    return TriangleMesh(idx.astype(np.uint32), P)
+
+
+def cornell_c1_prims():
+    """Config C1: floor quad (2 matte triangles) + the quad emitter."""
+    return [floor_quad(), emitter_quad()]
+
+
+def cornell_prims(extra=None):
+    prims = cornell_walls() + [emitter_quad()]
+    if extra is not None:
+        prims.append(extra)
+    return prims
+
+
+def blob_prim(segments=1000, rows=500):
+    return GeometricPrimitive(blob_mesh(segments, rows), MatteMaterial((0.48, 0.48, 0.48)))
+
+
+def hairball_prim(strands=10000, segments=500):
+    return GeometricPrimitive(hairball_mesh(strands, segments), MatteMaterial((0.48, 0.48, 0.48)))
+
+
+def make_scene(prims):
+    accel = BVHAccel(prims)
+    return Scene(accel, accel.lights())
+
+
+def cornell_camera(xres, yres):
+    film = ImageFilm(xres, yres, BoxFilter(0.5, 0.5))
+    return PerspectiveCamera.lookAt((0.0, 0.0, -35.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 35.0, film)
+
+
+def config(name, xres=None, yres=None, spp=None, blob=(1000, 500), hair=(10000, 500), seed=5489, **renderer_kw):
+    """(scene prims, renderer factory) for BASELINE.json's configs: 'C1', 'C2', 'C4'."""
+    if name == "C1":
+        prims = cornell_c1_prims()
+        xres, yres, spp = xres or 64, yres or 64, spp or 4
+        integ = DirectLightingIntegrator(0, 5)
+    elif name == "C2":
+        prims = cornell_prims(blob_prim(*blob))
+        xres, yres, spp = xres or 1024, yres or 1024, spp or 256
+        integ = PathIntegrator(5)
+    elif name == "C4":
+        prims = cornell_prims(hairball_prim(*hair))
+        xres, yres, spp = xres or 1024, yres or 1024, spp or 64
+        integ = PathIntegrator(5)
+    else:
+        raise ValueError(name)
+    cam = cornell_camera(xres, yres)
+
+    def renderer():
+        return SamplerRenderer(LowDiscrepancySampler(cam, spp, seed), cam, integ, EmissionIntegrator(), **renderer_kw)
+
+    return prims, renderer

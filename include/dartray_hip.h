@@ -1,0 +1,223 @@
+/* dartray_hip.h -- C ABI of the MI355X-native DartRay hot path.
+ *
+ * The reference (brendan-duncan/dartray, pure Dart) has NO native boundary; the
+ * coarse Dart-level seam this library sits behind is
+ *
+ *     abstract class Renderer { Future<OutputImage> render(Scene scene); ... }
+ *                                              (lib/core/renderer.dart:27-35)
+ *
+ * called once per task from DartRay.worldEnd (lib/dartray/dartray.dart:574).
+ * A Dart `HipSamplerRenderer extends Renderer` flattens the
+ * Scene (BVHAccel.nodes/primitives are public fields, bvh_accel.dart:486-487,
+ * :533-538) into the POD structs below and calls these entry points through
+ * dart:ffi.  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions: plain C, POD structs, little endian.  The caller owns every
+ * host buffer for the duration of the call; the library owns device memory.
+ * All functions return DR_OK (0) or a negative error code; dr_last_error()
+ * gives the message (the Dart shim turns it into LogSevere -> Exception ->
+ * completeError, log.dart:42-47, dartray.dart:573-583).  Calls are blocking
+ * unless they take a stream.  One DrScene per GPU / rank, one calling thread
+ * per DrScene.
+ */
+#ifndef DARTRAY_HIP_H
+#define DARTRAY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR_OK 0
+#define DR_ERR_INVALID (-1)
+#define DR_ERR_HIP (-2)
+#define DR_ERR_NO_DEVICE (-3)
+#define DR_ERR_UNSUPPORTED (-4)
+
+/* _LinearBVHNode (lib/accelerators/bvh_accel.dart:533-538): bounds, offset
+ * (first primitive for a leaf, second-child index for an interior node; the
+ * first child is index+1, :432), nPrimitives (0 => interior), split axis. */
+typedef struct DrBvhNode {
+  float bmin[3];
+  float bmax[3];
+  uint32_t offset;
+  uint16_t nprims;
+  uint8_t axis;
+  uint8_t pad;
+} DrBvhNode; /* 32 bytes */
+
+/* MatteMaterial with constant textures (lib/materials/matte_material.dart:41-65). */
+typedef struct DrMaterial {
+  float kd[3];
+  float sigma; /* must be 0 (Lambertian); Oren-Nayar is not on the path */
+} DrMaterial;
+
+/* DiffuseAreaLight + its ShapeSet (lib/lights/diffuse_area_light.dart:36-43,
+ * lib/core/light/shape_set.dart:24-51).  The triangle list is in ShapeSet
+ * order (i.e. after the LIFO refine reversal). */
+typedef struct DrAreaLight {
+  float L[3];
+  int32_t nsamples;
+  uint32_t first_tri; /* into light_tris */
+  uint32_t ntris;
+} DrAreaLight;
+
+typedef struct DrLightTri {
+  uint32_t v[3]; /* vertex indices */
+  uint32_t reverse_orientation;
+} DrLightTri;
+
+/* Flattened Scene (lib/core/scene.dart:26-45): aggregate + lights. */
+typedef struct DrSceneDesc {
+  const DrBvhNode* nodes; /* BVHAccel.nodes, depth-first (bvh_accel.dart:419-437) */
+  uint64_t nnodes;
+  const float* verts; /* world-space f32 xyz (lib/shapes/triangle_mesh.dart:29-36) */
+  uint64_t nverts;
+  const uint32_t* tri_idx; /* ntris*3, BVHAccel.primitives order */
+  uint64_t ntris;
+  const uint32_t* tri_material; /* per primitive: index into materials */
+  const int32_t* tri_light;     /* per primitive: area-light index or -1 (geometric_primitive.dart:63-65) */
+  const uint8_t* tri_reverse;   /* per primitive: Shape.reverseOrientation (shape.dart:29) */
+  const DrMaterial* materials;
+  uint32_t nmaterials;
+  const DrAreaLight* lights; /* Scene.lights order */
+  uint32_t nlights;
+  const DrLightTri* light_tris;
+  uint32_t nlight_tris;
+  uint32_t bvh_depth; /* max depth of the tree, 0 = unknown */
+} DrSceneDesc;
+
+typedef struct DrScene DrScene;
+
+/* Ray (lib/core/ray.dart:27-47) and the hit record of
+ * GeometricPrimitive.intersect (geometric_primitive.dart:47-61). */
+typedef struct DrRay {
+  float o[3];
+  float d[3];
+  double tmin;
+  double tmax;
+} DrRay;
+
+typedef struct DrHit {
+  int32_t prim; /* index in BVH primitive order; -1 = miss.  any-hit: 0 = occluded, -1 = free */
+  int32_t pad;
+  double t;
+  double b1;
+  double b2;
+} DrHit;
+
+/* ProjectiveCamera/PerspectiveCamera state (lib/core/projective_camera.dart:27-32). */
+typedef struct DrCamera {
+  float raster_to_camera[16]; /* row-major, Matrix4x4.data order (matrix4x4.dart:170-176) */
+  float camera_to_world[16];
+  float lens_radius;
+  float focal_distance;
+  float shutter_open;
+  float shutter_close;
+} DrCamera;
+
+/* ImageFilm + Filter (lib/film/image_film.dart:51-97). */
+typedef struct DrFilm {
+  int32_t xres, yres;
+  float crop[4];
+  float filter_xw, filter_yw;
+  float filter_table[256]; /* 16x16, image_film.dart:74-82 */
+} DrFilm;
+
+#define DR_INTEGRATOR_DIRECT_ALL 0 /* DirectLightingIntegrator, strategy "all" (direct_lighting_integrator.dart) */
+#define DR_INTEGRATOR_PATH 1       /* PathIntegrator (path_integrator.dart) */
+
+#define DR_SAMPLER_HOST_BUFFER 0 /* caller supplies sample vectors (+ the in-Li RNG draws) */
+#define DR_SAMPLER_COUNTER 1     /* on-device LD sampler, keyed per (pixel, block) / (pixel, sample) */
+
+/* Everything SamplerRenderer.render needs besides the Scene
+ * (lib/renderers/sampler_renderer.dart:29-31,36-65). */
+typedef struct DrRenderDesc {
+  DrCamera camera;
+  DrFilm film;
+  int32_t integrator;
+  int32_t max_depth; /* PathIntegrator.maxDepth / DirectLightingIntegrator.maxDepth (default 5) */
+  int32_t spp;       /* LowDiscrepancySampler.nPixelSamples, power of two */
+  int32_t sampler_mode;
+  int64_t seed; /* DR_SAMPLER_COUNTER */
+  /* Work split.  task_*: the reference's GetSubWindow rectangle of the sampler
+   * window (lib/core/common.dart:52-73, dartray.dart:1009-1023).  tile_*: 32x32
+   * tiles (TilePixelSampler.tileSize, tile_pixel_sampler.dart:37) dealt
+   * round-robin over ranks; tile_count <= 1 disables it. */
+  int32_t task_num, task_count;
+  int32_t tile_rank, tile_count, tile_size;
+  /* DR_SAMPLER_HOST_BUFFER: nsamples camera samples, in reference order
+   * (pixel-major, all spp of a pixel adjacent). */
+  int64_t nsamples;
+  const int32_t* pixel_xy;  /* [nsamples/spp][2] raster pixel of each group of spp samples */
+  const float* sample_vec;  /* [nsamples][sample_stride]: imageU, imageV, lensU, lensV, time, oneD..., twoD... */
+  int32_t sample_stride;
+  const double* tail;       /* [nsamples][max_tail] RNG.randomFloat() values drawn inside Li, or NULL */
+  int32_t max_tail;
+} DrRenderDesc;
+
+/* Counters and timings of the last dr_render* call on a scene. */
+typedef struct DrRenderStats {
+  uint64_t camera_samples; /* samples traced (incl. the sampler's dead border, image_film.dart:247-252) */
+  uint64_t film_samples;   /* film pixels in this rank's window x spp: the throughput numerator */
+  uint64_t closest_rays, any_rays;
+  uint64_t closest_nodes, any_nodes; /* iterations of the loops at bvh_accel.dart:122 / :185 */
+  uint64_t closest_tris, any_tris;   /* primitive tests at bvh_accel.dart:131 / :193 */
+  uint64_t trace_launches;           /* number of traversal-kernel launches */
+  double trace_ms;                   /* summed device time of the traversal launches (HIP events) */
+  double total_ms;                   /* device time of the whole render (HIP events) */
+  uint64_t batches;
+} DrRenderStats;
+
+/* Select the GPU.  Must precede everything else. */
+int dr_init(int device);
+
+/* Host-side BVHAccel constructor (bvh_accel.dart:41-91,228-437; SAH, 12
+ * buckets): used by the standalone host; a Dart caller marshals its own
+ * BVHAccel.nodes instead.  tri_idx is in *refined* primitive order.
+ * nodes_out holds 2*ntris-1 nodes; order_out[i] = input triangle placed at
+ * BVH primitive slot i. */
+int dr_bvh_build(const float* verts, uint64_t nverts, const uint32_t* tri_idx, uint64_t ntris, int32_t max_prims_in_node,
+                 DrBvhNode* nodes_out, uint64_t* nnodes_out, uint32_t* order_out, uint32_t* depth_out);
+
+/* Scene upload (replaces the construction of lib/core/scene.dart Scene). */
+int dr_scene_create(const DrSceneDesc* desc, DrScene** out);
+void dr_scene_destroy(DrScene* scene);
+
+/* Aggregate.intersect / Aggregate.intersectP (lib/core/primitive.dart:33-55 ->
+ * bvh_accel.dart:101-226) on a batch of rays; host buffers. */
+int dr_intersect(DrScene* scene, const DrRay* rays, int64_t n, DrHit* out, int32_t any_hit);
+
+/* Floats per camera-sample vector for an integrator (Sample layout,
+ * lib/core/sample.dart:23-79). */
+int32_t dr_sample_floats(int32_t integrator, uint32_t nlights);
+
+/* Renderer.render(Scene) (lib/core/renderer.dart:28;
+ * sampler_renderer.dart:36-65): traces this task's window and returns the
+ * film.  film_out: [height*width*4] f32 (X, Y, Z, weightSum) -- ImageFilm's
+ * _Lxyz/_weightSum (image_film.dart:69-71); rgb_out (optional):
+ * [height*width*3] = OutputImage.rgb after ImageFilm.writeImage (:268-299). */
+int dr_render(DrScene* scene, const DrRenderDesc* desc, float* film_out, float* rgb_out);
+
+/* Same, with the film left in device memory (accumulated into film_dev, which
+ * the caller zero-initialises) on the given hipStream_t; used by bench.py and
+ * by the multi-GPU path, which reduces film_dev over RCCL before resolving. */
+int dr_render_device(DrScene* scene, const DrRenderDesc* desc, void* film_dev, void* hip_stream);
+
+/* ImageFilm.writeImage on a device film: XYZ -> RGB, divide by weightSum. */
+int dr_film_resolve_device(const void* film_dev, int64_t npixels, void* rgb_dev, void* hip_stream);
+
+/* Stats of the last render on this scene (valid after the stream has been synchronised). */
+int dr_get_stats(DrScene* scene, DrRenderStats* out);
+
+/* Device float4 copy kernel: the measured HBM-bandwidth denominator. Returns GB/s. */
+int dr_copy_bandwidth(uint64_t bytes, int32_t iters, double* gbps_out);
+
+const char* dr_last_error(void);
+const char* dr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DARTRAY_HIP_H */

@@ -1,0 +1,263 @@
+"""ctypes binding of the CPU oracle (oracle/dartray_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke().  Nothing under dartray_amd/ may import this module.
+PARITY UNPINNED: see the header of dartray_oracle.cpp.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libdartray_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "dartray_oracle.cpp")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+class OrcMesh(C.Structure):
+    _fields_ = [("P", C.c_void_p), ("idx", C.c_void_p), ("nverts", C.c_int32), ("ntris", C.c_int32),
+                ("Kd", C.c_float * 3), ("sigma", C.c_float), ("reverse_orientation", C.c_int32),
+                ("has_light", C.c_int32), ("L", C.c_float * 3), ("light_nsamples", C.c_int32)]
+
+
+class OrcSceneDesc(C.Structure):
+    _fields_ = [("nmeshes", C.c_int32), ("meshes", C.POINTER(OrcMesh)), ("max_prims_in_node", C.c_int32)]
+
+
+class OrcRenderDesc(C.Structure):
+    _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_float * 4),
+                ("filter_xw", C.c_float), ("filter_yw", C.c_float), ("filter_table", C.c_float * 256),
+                ("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float),
+                ("integrator", C.c_int32), ("max_depth", C.c_int32), ("spp", C.c_int32), ("sampler_mode", C.c_int32),
+                ("seed", C.c_int64), ("task_num", C.c_int32), ("task_count", C.c_int32),
+                ("npixels", C.c_int32), ("pixels", C.c_void_p)]
+
+
+class OrcRecord(C.Structure):
+    _fields_ = [("capacity", C.c_int64), ("count", C.c_int64), ("nfloats", C.c_int32), ("max_tail", C.c_int32),
+                ("pixel_xy", C.c_void_p), ("sample_vec", C.c_void_p), ("nfloats_cap", C.c_int32),
+                ("tail", C.c_void_p), ("tail_count", C.c_void_p), ("Ls", C.c_void_p)]
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("closest_rays", "any_rays", "closest_nodes", "any_nodes", "closest_tris",
+                                          "any_tris", "light_tris", "camera_samples")]
+
+
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("tmin", "<f8"), ("tmax", "<f8")])
+HIT_DTYPE = np.dtype([("prim", "<i4"), ("pad", "<i4"), ("t", "<f8"), ("b1", "<f8"), ("b2", "<f8")])
+NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<u4"), ("nprims", "<u2"),
+                       ("axis", "u1"), ("pad", "u1")])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        l = C.CDLL(LIB_PATH)
+        l.orc_scene_create.restype = C.c_void_p
+        l.orc_scene_create.argtypes = [C.POINTER(OrcSceneDesc)]
+        l.orc_scene_destroy.argtypes = [C.c_void_p]
+        l.orc_scene_info.argtypes = [C.c_void_p, C.c_void_p]
+        l.orc_scene_get_bvh.argtypes = [C.c_void_p] * 5
+        l.orc_scene_get_verts.argtypes = [C.c_void_p, C.c_void_p]
+        l.orc_counters.argtypes = [C.c_void_p, C.POINTER(OrcCounters), C.c_int]
+        l.orc_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        l.orc_intersect_brute.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        l.orc_sample_floats.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.orc_render.argtypes = [C.c_void_p, C.POINTER(OrcRenderDesc), C.c_void_p, C.c_void_p, C.POINTER(OrcRecord)]
+        l.orc_li_samples.argtypes = [C.c_void_p, C.POINTER(OrcRenderDesc), C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        l.orc_film_accumulate.argtypes = [C.POINTER(OrcRenderDesc), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.orc_film_resolve.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        l.orc_camera_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        l.orc_van_der_corput.restype = C.c_double
+        l.orc_van_der_corput.argtypes = [C.c_uint32, C.c_uint32]
+        l.orc_sobol2.restype = C.c_double
+        l.orc_sobol2.argtypes = [C.c_uint32, C.c_uint32]
+        l.orc_concentric_sample_disk.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        l.orc_cosine_sample_hemisphere.argtypes = [C.c_double, C.c_double, C.c_void_p]
+        l.orc_power_heuristic.restype = C.c_double
+        l.orc_power_heuristic.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double]
+        l.orc_get_sub_window.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.orc_distribution1d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_int, C.c_void_p]
+        l.orc_dart_random.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        l.orc_counter_key.restype = C.c_int64
+        l.orc_counter_key.argtypes = [C.c_uint64] * 4
+        l.orc_ld_pixel_sample.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        l.orc_triangle_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        l.orc_triangle_intersectP.argtypes = [C.c_void_p, C.c_void_p]
+        l.orc_slab.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.orc_version.restype = C.c_char_p
+        _lib = l
+    return _lib
+
+
+def make_rays(o, d, tmin=0.0, tmax=np.inf):
+    o = np.asarray(o, np.float32).reshape(-1, 3)
+    r = np.zeros(len(o), dtype=RAY_DTYPE)
+    r["o"] = o
+    r["d"] = np.asarray(d, np.float32).reshape(-1, 3)
+    r["tmin"] = tmin
+    r["tmax"] = tmax
+    return r
+
+
+class OracleScene:
+    """Scene built by the oracle from the same GeometricPrimitive list the product takes
+    (objects with .shape.{P,vertexIndex,reverseOrientation}, .material.{Kd,sigma}, .areaLight)."""
+
+    def __init__(self, prims, max_prims=4):
+        l = lib()
+        meshes = (OrcMesh * max(len(prims), 1))()
+        self._keep = []
+        for i, gp in enumerate(prims):
+            P = np.ascontiguousarray(gp.shape.P, np.float32)
+            idx = np.ascontiguousarray(gp.shape.vertexIndex, np.uint32)
+            self._keep += [P, idx]
+            m = meshes[i]
+            m.P, m.idx = P.ctypes.data, idx.ctypes.data
+            m.nverts, m.ntris = len(P), len(idx)
+            m.Kd[:] = [float(x) for x in gp.material.Kd]
+            m.sigma = gp.material.sigma
+            m.reverse_orientation = 1 if gp.shape.reverseOrientation else 0
+            if gp.areaLight is not None:
+                m.has_light = 1
+                m.L[:] = [float(x) for x in gp.areaLight.Lemit]
+                m.light_nsamples = gp.areaLight.nSamples
+        d = OrcSceneDesc(len(prims), meshes, max_prims)
+        self.h = l.orc_scene_create(C.byref(d))
+        info = (C.c_int64 * 6)()
+        l.orc_scene_info(self.h, info)
+        self.nnodes, self.nprims, self.depth, self.nlights, self.nverts, self.nlighttris = [int(v) for v in info]
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_scene_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def bvh(self):
+        nodes = np.zeros(self.nnodes, dtype=NODE_DTYPE)
+        tri = np.zeros((self.nprims, 3), dtype=np.uint32)
+        mesh = np.zeros(self.nprims, dtype=np.int32)
+        src = np.zeros(self.nprims, dtype=np.int32)
+        lib().orc_scene_get_bvh(self.h, nodes.ctypes.data, tri.ctypes.data, mesh.ctypes.data, src.ctypes.data)
+        return nodes, tri, mesh, src
+
+    def verts(self):
+        P = np.zeros((self.nverts, 3), np.float32)
+        lib().orc_scene_get_verts(self.h, P.ctypes.data)
+        return P
+
+    def counters(self, reset=False):
+        c = OrcCounters()
+        lib().orc_counters(self.h, C.byref(c), 1 if reset else 0)
+        return {n: getattr(c, n) for n, _ in OrcCounters._fields_}
+
+    def intersect(self, rays, any_hit=False, brute=False):
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros(len(rays), dtype=HIT_DTYPE)
+        fn = lib().orc_intersect_brute if brute else lib().orc_intersect
+        fn(self.h, rays.ctypes.data, len(rays), out.ctypes.data, 1 if any_hit else 0)
+        return out
+
+    def sample_floats(self, integrator, max_depth):
+        return lib().orc_sample_floats(self.h, integrator, max_depth)
+
+    def render(self, rd, record=0, max_tail=40, want_film=True):
+        """SamplerRenderer.render.  Returns dict(rgb, film, and -- if record > 0 -- the per-sample
+        recording: pixel_xy, sample_vec, tail, tail_count, Ls)."""
+        l = lib()
+        # ImageFilm window
+        import math
+        left = math.ceil(rd.xres * rd.crop[0]); width = max(1, math.ceil(rd.xres * rd.crop[1]) - left)
+        top = math.ceil(rd.yres * rd.crop[2]); height = max(1, math.ceil(rd.yres * rd.crop[3]) - top)
+        rgb = np.zeros((height, width, 3), np.float32)
+        film = np.zeros((height, width, 4), np.float32)
+        rec = None
+        out = {}
+        if record > 0:
+            nf = self.sample_floats(rd.integrator, rd.max_depth)
+            rec = OrcRecord()
+            rec.capacity = record
+            rec.max_tail = max_tail
+            rec.nfloats_cap = nf
+            out["pixel_xy"] = np.zeros((record, 2), np.int32)
+            out["sample_vec"] = np.zeros((record, nf), np.float32)
+            out["tail"] = np.zeros((record, max_tail), np.float64)
+            out["tail_count"] = np.zeros(record, np.int32)
+            out["Ls"] = np.zeros((record, 3), np.float32)
+            rec.pixel_xy = out["pixel_xy"].ctypes.data
+            rec.sample_vec = out["sample_vec"].ctypes.data
+            rec.tail = out["tail"].ctypes.data
+            rec.tail_count = out["tail_count"].ctypes.data
+            rec.Ls = out["Ls"].ctypes.data
+        rc = l.orc_render(self.h, C.byref(rd), rgb.ctypes.data, film.ctypes.data if want_film else None,
+                          C.byref(rec) if rec is not None else None)
+        if rc != 0:
+            raise RuntimeError("orc_render failed: %d" % rc)
+        out["rgb"], out["film"] = rgb, film
+        if rec is not None:
+            n = rec.count
+            out["count"] = n
+            for k in ("pixel_xy", "sample_vec", "tail", "tail_count", "Ls"):
+                out[k] = out[k][:n]
+        return out
+
+    def li_samples(self, rd, pixel_xy, sample_vec, tail=None, tail_count=None):
+        pixel_xy = np.ascontiguousarray(pixel_xy, np.int32)
+        sample_vec = np.ascontiguousarray(sample_vec, np.float32)
+        n = len(sample_vec)
+        out = np.zeros((n, 3), np.float32)
+        if tail is not None:
+            tail = np.ascontiguousarray(tail, np.float64)
+        if tail_count is not None:
+            tail_count = np.ascontiguousarray(tail_count, np.int32)
+        rc = lib().orc_li_samples(self.h, C.byref(rd), n, pixel_xy.ctypes.data, sample_vec.ctypes.data,
+                                  sample_vec.shape[1], tail.ctypes.data if tail is not None else None,
+                                  tail_count.ctypes.data if tail_count is not None else None,
+                                  tail.shape[1] if tail is not None else 0, out.ctypes.data)
+        if rc < 0:
+            raise RuntimeError("orc_li_samples failed: %d" % rc)
+        return out
+
+
+def render_desc(renderer, sampler_mode=None, pixels=None):
+    """OrcRenderDesc from a dartray_amd.core.SamplerRenderer-like object (duck typed: no import of
+    the product package happens here)."""
+    cam, film = renderer.camera, renderer.camera.film
+    rd = OrcRenderDesc()
+    rd.xres, rd.yres = film.xResolution, film.yResolution
+    rd.crop[:] = film.cropWindow
+    rd.filter_xw, rd.filter_yw = film.filter.xWidth, film.filter.yWidth
+    rd.filter_table[:] = [float(v) for v in film.filterTable]
+    rd.raster_to_camera[:] = [float(v) for v in cam.rasterToCamera.reshape(-1)]
+    rd.camera_to_world[:] = [float(v) for v in cam.cameraToWorld.reshape(-1)]
+    rd.lens_radius, rd.focal_distance = cam.lensRadius, cam.focalDistance
+    rd.shutter_open, rd.shutter_close = cam.shutterOpen, cam.shutterClose
+    rd.integrator = renderer.surfaceIntegrator.kind
+    rd.max_depth = renderer.surfaceIntegrator.maxDepth
+    rd.spp = renderer.sampler.samplesPerPixel
+    rd.sampler_mode = 1 if sampler_mode is None else sampler_mode
+    rd.seed = getattr(renderer.sampler, "seed", 0)
+    rd.task_num, rd.task_count = renderer.taskNum, renderer.taskCount
+    if pixels is not None:
+        pixels = np.ascontiguousarray(pixels, np.int32).reshape(-1, 2)
+        rd._pixels_keep = pixels
+        rd.npixels = len(pixels)
+        rd.pixels = pixels.ctypes.data
+    return rd

@@ -1,0 +1,1941 @@
+// oracle/dartray_oracle.cpp
+//
+// TEST INFRASTRUCTURE ONLY -- NOT PRODUCT CODE.
+//
+// CPU restatement of the DartRay hot path
+//   SamplerRenderer.render -> PathIntegrator.Li -> BVHAccel.intersect / Triangle.intersect
+// used as (a) the parity oracle for the HIP kernels in dartray_amd/csrc and
+// (b) the "port" CPU baseline timed by bench.py.  Only tests/, bench.py's
+// cpu_baseline leg and __graft_entry__.smoke() may load this library.
+//
+// PARITY UNPINNED: the reference ships no golden vectors, no known-answer
+// tests and cannot be executed here (no Dart SDK).  What
+// pins this file instead: (1) line-by-line fidelity to the cited reference
+// source, including its numerics contract (every arithmetic expression is
+// evaluated in f64; Vector/Point/Normal/Spectrum/Float32List stores round to
+// f32), (2) hand-derivable KATs in tests/, (3) BVH == brute force self checks.
+//
+// Numerics contract: compile with
+//   g++ -O2 -ffp-contract=off  (no fast-math)  -- Dart never fuses mul+add.
+//
+// All citations are relative to /root/reference/lib/.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace {
+
+typedef double D;
+
+// A store into a Float32List (vector.dart:27, spectrum.dart:27): round to f32.
+static inline D r32(D x) { return (D)(float)x; }
+
+static const D kInf = std::numeric_limits<double>::infinity();  // common.dart:26 (1.0e500)
+static const D INV_PI = 0.31830988618379067154;                  // common.dart:23
+static const D ONE_MINUS_EPSILON = 0.9999999403953552;           // montecarlo.dart:23
+static const D kPi = 3.141592653589793;                          // dart:math pi
+
+// ---------------------------------------------------------------------------
+// Vector / Point / Normal (core/vector.dart, point.dart, normal.dart).
+// Invariant: the three components are always f32-representable values.
+// ---------------------------------------------------------------------------
+struct V {
+  D x, y, z;
+  D operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+static inline V vec(D x, D y, D z) { return V{r32(x), r32(y), r32(z)}; }           // vector.dart:29-34
+static inline V vadd(const V& a, const V& b) { return vec(a.x + b.x, a.y + b.y, a.z + b.z); }  // :57-60
+static inline V vsub(const V& a, const V& b) { return vec(a.x - b.x, a.y - b.y, a.z - b.z); }  // :62-65
+static inline V vmul(const V& a, D f) { return vec(a.x * f, a.y * f, a.z * f); }   // :67-68
+static inline V vdiv(const V& a, D f) { return vec(a.x / f, a.y / f, a.z / f); }   // :70-71
+static inline V vneg(const V& a) { return vec(-a.x, -a.y, -a.z); }                  // :73-74
+static inline D vdot(const V& a, const V& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // :153-155
+static inline D vabsdot(const V& a, const V& b) { return std::fabs(vdot(a, b)); }   // :157-159
+static inline D vlen2(const V& a) { return a.x * a.x + a.y * a.y + a.z * a.z; }    // :80-81
+static inline D vlen(const V& a) { return std::sqrt(vlen2(a)); }                    // :83
+static inline V vcross(const V& a, const V& b) {                                    // :161-171
+  return vec((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
+}
+static inline V vnormalize(const V& v) { return vdiv(v, vlen(v)); }                 // :173
+
+// ---------------------------------------------------------------------------
+// Spectrum == RGBColor (spectrum.dart:40,53-58; rgb_color.dart:136-176).
+// ---------------------------------------------------------------------------
+struct S {
+  D r, g, b;
+};
+static inline S rgb(D r, D g, D b) { return S{r32(r), r32(g), r32(b)}; }
+static inline S sadd(const S& a, const S& b) { return rgb(a.r + b.r, a.g + b.g, a.b + b.b); }
+static inline S smul(const S& a, const S& b) { return rgb(a.r * b.r, a.g * b.g, a.b * b.b); }
+static inline S smulD(const S& a, D s) { return rgb(a.r * s, a.g * s, a.b * s); }
+static inline S sdivD(const S& a, D s) { return rgb(a.r / s, a.g / s, a.b / s); }
+static inline bool sblack(const S& a) { return !(a.r != 0.0 || a.g != 0.0 || a.b != 0.0); }  // rgb_color.dart:171-176
+static inline D slum(const S& a) { return 0.212671 * a.r + 0.715160 * a.g + 0.072169 * a.b; }  // :167-169
+static inline bool snan(const S& a) { return std::isnan(a.r) || std::isnan(a.g) || std::isnan(a.b); }
+static inline D clampD(D v, D lo, D hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------
+// dart:math Random on the Dart VM (NOT in /root/reference: un-vendored SDK
+// dependency, version unpinned; restated from the published algorithm --
+// SURVEY.md Appendix E).  Parity never depends on it: sample values and
+// in-Li draws are explicit inputs of the GPU path.
+// ---------------------------------------------------------------------------
+static inline uint64_t mix64(uint64_t n) {  // Thomas Wang 64-bit mix
+  n = (~n) + (n << 21);
+  n = n ^ (n >> 24);
+  n = n * 265;
+  n = n ^ (n >> 14);
+  n = n * 21;
+  n = n ^ (n >> 28);
+  n = n + (n << 31);
+  return n;
+}
+
+struct DartRandom {
+  uint32_t lo, hi;
+  explicit DartRandom(int64_t seed = 5489) { reseed(seed); }  // rng.dart:29-30
+  void reseed(int64_t seed) {
+    uint64_t hash = mix64((uint64_t)seed);
+    if (hash == 0) hash = 0x5A17;
+    lo = (uint32_t)(hash & 0xffffffffu);
+    hi = (uint32_t)(hash >> 32);
+    step(); step(); step(); step();  // "crank a couple of times"
+  }
+  void step() {
+    uint64_t s = 0xffffda61ULL * (uint64_t)lo + (uint64_t)hi;
+    lo = (uint32_t)(s & 0xffffffffu);
+    hi = (uint32_t)(s >> 32);
+  }
+  uint32_t nextInt(uint64_t max) {
+    if ((max & (~max + 1)) == max) {  // power of two
+      step();
+      return (uint32_t)(lo & (max - 1));
+    }
+    uint64_t rnd32, result;
+    do {
+      step();
+      rnd32 = lo;
+      result = rnd32 % max;
+    } while ((rnd32 - result + max) > (1ULL << 32));
+    return (uint32_t)result;
+  }
+  D nextDouble() {
+    D a = (D)nextInt(1u << 26);
+    D b = (D)nextInt(1u << 27);
+    return (a * 134217728.0 + b) / 9007199254740992.0;
+  }
+  D randomFloat() { return nextDouble(); }               // rng.dart:36-38
+  uint32_t randomUint() { return nextInt(0xffffffffULL); }  // rng.dart:40-42
+};
+
+// Key derivation of the build's own "counter" sampler mode (not in the
+// reference: the reference's single serial stream cannot be parallelised,
+// SURVEY.md section 7.2).  Each (pixel, LD block) and each (pixel, sample) owns an
+// independent DartRandom stream seeded with this hash.  The HIP path uses the
+// identical derivation (dartray_amd/csrc/dr_rng.h).
+static inline int64_t counter_key(uint64_t seed, uint64_t a, uint64_t b, uint64_t kind) {
+  uint64_t h = mix64(seed ^ 0x9E3779B97F4A7C15ULL);
+  h = mix64(h ^ (a * 0xD1B54A32D192ED03ULL + kind));
+  h = mix64(h ^ (b * 0x8CB92BA72F3D8DD7ULL + 0x5851F42D4C957F2DULL));
+  return (int64_t)(h & 0x7fffffffffffffffULL);
+}
+
+// ---------------------------------------------------------------------------
+// montecarlo.dart
+// ---------------------------------------------------------------------------
+static inline D VanDerCorput(uint64_t n, uint64_t scramble) {  // montecarlo.dart:495-504
+  n = (n << 16) | (n >> 16);
+  n = ((n & 0x00ff00ffULL) << 8) | ((n & 0xff00ff00ULL) >> 8);
+  n = ((n & 0x0f0f0f0fULL) << 4) | ((n & 0xf0f0f0f0ULL) >> 4);
+  n = ((n & 0x33333333ULL) << 2) | ((n & 0xccccccccULL) >> 2);
+  n = ((n & 0x55555555ULL) << 1) | ((n & 0xaaaaaaaaULL) >> 1);
+  n ^= scramble;
+  return std::min((D)((n >> 8) & 0xffffff) / (D)(1 << 24), ONE_MINUS_EPSILON);
+}
+static inline D Sobol2(uint64_t n, uint64_t scramble) {  // montecarlo.dart:486-493
+  for (uint64_t v = 1ULL << 31; n != 0; n >>= 1, v ^= v >> 1) {
+    if ((n & 0x1) != 0) scramble ^= v;
+  }
+  return std::min((D)((scramble >> 8) & 0xffffff) / (D)(1 << 24), ONE_MINUS_EPSILON);
+}
+
+// Shuffle on a Float32List (montecarlo.dart:294-303).
+template <class RNG>
+static void Shuffle(float* samples, int offset, int count, int dims, RNG& rng) {
+  for (int i = 0; i < count; ++i) {
+    int other = i + (int)(rng.randomUint() % (uint32_t)(count - i));
+    for (int j = 0; j < dims; ++j) {
+      float s = samples[offset + dims * i + j];
+      samples[offset + dims * i + j] = samples[offset + dims * other + j];
+      samples[offset + dims * other + j] = s;
+    }
+  }
+}
+template <class RNG>
+static void LDShuffleScrambled1D(int nSamples, int nPixel, float* samples, RNG& rng) {  // :524-536
+  uint64_t scramble = rng.randomUint();
+  for (int i = 0; i < nSamples * nPixel; ++i) samples[i] = (float)VanDerCorput((uint64_t)i, scramble);
+  for (int i = 0; i < nPixel; ++i) Shuffle(samples, i * nSamples, nSamples, 1, rng);
+  Shuffle(samples, 0, nPixel, nSamples, rng);
+}
+template <class RNG>
+static void LDShuffleScrambled2D(int nSamples, int nPixel, float* samples, RNG& rng) {  // :539-551
+  uint64_t s0 = rng.randomUint();
+  uint64_t s1 = rng.randomUint();
+  for (int i = 0; i < nSamples * nPixel; ++i) {  // Sample02 :507-511
+    samples[2 * i + 0] = (float)VanDerCorput((uint64_t)i, s0);
+    samples[2 * i + 1] = (float)Sobol2((uint64_t)i, s1);
+  }
+  for (int i = 0; i < nPixel; ++i) Shuffle(samples, 2 * i * nSamples, nSamples, 2, rng);
+  Shuffle(samples, 0, nPixel, 2 * nSamples, rng);
+}
+
+static void ConcentricSampleDisk(D u1, D u2, D* dx, D* dy) {  // montecarlo.dart:155-201
+  D r, theta;
+  D sx = 2 * u1 - 1;
+  D sy = 2 * u2 - 1;
+  if (sx == 0.0 && sy == 0.0) {
+    *dx = 0.0;
+    *dy = 0.0;
+    return;
+  }
+  if (sx >= -sy) {
+    if (sx > sy) {
+      r = sx;
+      if (sy > 0.0) theta = sy / r; else theta = 8.0 + sy / r;
+    } else {
+      r = sy;
+      theta = 2.0 - sx / r;
+    }
+  } else {
+    if (sx <= sy) {
+      r = -sx;
+      theta = 4.0 - sy / r;
+    } else {
+      r = -sy;
+      theta = 6.0 + sx / r;
+    }
+  }
+  theta *= kPi / 4.0;
+  *dx = r * std::cos(theta);
+  *dy = r * std::sin(theta);
+}
+static V CosineSampleHemisphere(D u1, D u2) {  // montecarlo.dart:203-209
+  D dx, dy;
+  ConcentricSampleDisk(u1, u2, &dx, &dy);
+  D z = std::sqrt(std::max(0.0, 1.0 - dx * dx - dy * dy));
+  return vec(dx, dy, z);
+}
+static inline D PowerHeuristic(int nf, D fPdf, int ng, D gPdf) {  // montecarlo.dart:480-484
+  D f = nf * fPdf;
+  D g = ng * gPdf;
+  return (f * f) / (f * f + g * g);
+}
+
+// Distribution1D (montecarlo.dart:25-98); upper_bound (common.dart:304-333).
+struct Distribution1D {
+  std::vector<float> func, cdf;
+  D funcInt = 0;
+  int count = 0;
+  void init(const std::vector<D>& f) {
+    count = (int)f.size();
+    func.resize(count);
+    for (int i = 0; i < count; ++i) func[i] = (float)f[i];
+    cdf.assign(count + 1, 0.0f);
+    cdf[0] = 0.0f;
+    for (int i = 1; i < count + 1; ++i) cdf[i] = (float)((D)cdf[i - 1] + (D)func[i - 1] / (D)count);
+    funcInt = (D)cdf[count];
+    if (funcInt == 0.0) {
+      for (int i = 1; i < count + 1; ++i) cdf[i] = (float)((D)i / (D)count);
+    } else {
+      for (int i = 1; i < count + 1; ++i) cdf[i] = (float)((D)cdf[i] / funcInt);
+    }
+  }
+  int upper_bound(D value, int last) const {
+    if (cdf.empty()) return -1;
+    if (cdf.size() == 1) return 0;
+    int first = 0;
+    int cnt = last;
+    while (cnt > 0) {
+      int index = first;
+      int step = cnt >> 1;
+      index += step;
+      if (!(value < (D)cdf[index])) {  // !compare(value, list[index]) with less_than
+        first = ++index;
+        cnt -= step + 1;
+      } else {
+        cnt = step;
+      }
+    }
+    return first;
+  }
+  int sampleDiscrete(D u) const {  // montecarlo.dart:82-92
+    int ptr = upper_bound(u, count + 1);
+    return std::max(0, ptr - 1);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Ray (core/ray.dart:27-71)
+// ---------------------------------------------------------------------------
+struct Ray {
+  V o, d;
+  D mint, maxt;
+  D time;
+  int depth;
+};
+static inline V pointAt(const Ray& r, D t) { return vadd(r.o, vmul(r.d, t)); }  // ray.dart:66-67
+
+// DifferentialGeometry subset that matters with constant textures
+// (differential_geometry.dart:77-102).
+struct DG {
+  V p, dpdu, dpdv, nn;
+};
+
+// ---------------------------------------------------------------------------
+// Scene storage
+// ---------------------------------------------------------------------------
+struct Mesh {
+  S Kd;
+  D sigma;
+  bool reverse;
+  int light;  // index into lights or -1
+};
+struct Prim {  // one refined Triangle wrapped in a GeometricPrimitive
+  uint32_t v[3];
+  int mesh;
+  int src_tri;  // triangle index inside its mesh (before the refine reversal)
+};
+struct LinearNode {  // bvh_accel.dart:533-538
+  V bmin, bmax;
+  uint32_t offset;
+  int nPrimitives;
+  int axis;
+};
+struct Counters {
+  uint64_t closest_rays = 0, any_rays = 0;
+  uint64_t closest_nodes = 0, any_nodes = 0;
+  uint64_t closest_tris = 0, any_tris = 0;
+  uint64_t light_tris = 0;
+  uint64_t camera_samples = 0;
+};
+
+struct Light {  // DiffuseAreaLight (diffuse_area_light.dart:36-70) + ShapeSet (shape_set.dart:24-51)
+  S Lemit;
+  int nSamples;
+  std::vector<int> shapes;  // indices into Scene::lightTris
+  std::vector<D> areas;
+  D area;
+  Distribution1D areaDistribution;
+};
+struct LightTri {
+  uint32_t v[3];
+  bool reverse;
+};
+
+struct Scene {
+  std::vector<float> P;  // world-space f32 vertices (triangle_mesh.dart:29-36)
+  std::vector<Mesh> meshes;
+  std::vector<Prim> prims;  // after the build: BVH 'primitives' order
+  std::vector<LinearNode> nodes;
+  std::vector<Light> lights;
+  std::vector<LightTri> lightTris;
+  int maxPrimsInNode = 4;
+  int bvhDepth = 0;
+  mutable Counters ctr;
+
+  V vert(uint32_t i) const { return V{(D)P[3 * i], (D)P[3 * i + 1], (D)P[3 * i + 2]}; }
+};
+
+// ---------------------------------------------------------------------------
+// Triangle (shapes/triangle.dart)
+// ---------------------------------------------------------------------------
+static const D kUVs[6] = {0.0, 0.0, 1.0, 0.0, 1.0, 1.0};  // triangle.dart:255-262 (mesh.uvs == null)
+
+// Triangle.intersect (triangle.dart:44-160): all scalars f64 on f32 inputs.
+static bool tri_intersect(const V& p1, const V& p2, const V& p3, bool reverse, const Ray& ray, D* tHit,
+                          D* rayEpsilon, DG* dg, D* ob1 = nullptr, D* ob2 = nullptr) {
+  D e1x = p2.x - p1.x, e1y = p2.y - p1.y, e1z = p2.z - p1.z;
+  D e2x = p3.x - p1.x, e2y = p3.y - p1.y, e2z = p3.z - p1.z;
+  D s1x = (ray.d.y * e2z) - (ray.d.z * e2y);
+  D s1y = (ray.d.z * e2x) - (ray.d.x * e2z);
+  D s1z = (ray.d.x * e2y) - (ray.d.y * e2x);
+  D divisor = (s1x * e1x) + (s1y * e1y) + (s1z * e1z);
+  if (divisor == 0.0) return false;
+  D invDivisor = 1.0 / divisor;
+  D sx = ray.o.x - p1.x, sy = ray.o.y - p1.y, sz = ray.o.z - p1.z;
+  D b1 = (sx * s1x + sy * s1y + sz * s1z) * invDivisor;
+  if (b1 < 0.0 || b1 > 1.0) return false;
+  D s2x = (sy * e1z) - (sz * e1y);
+  D s2y = (sz * e1x) - (sx * e1z);
+  D s2z = (sx * e1y) - (sy * e1x);
+  D b2 = ((ray.d.x * s2x) + (ray.d.y * s2y) + (ray.d.z * s2z)) * invDivisor;
+  if (b2 < 0.0 || b1 + b2 > 1.0) return false;
+  D t = (e2x * s2x + e2y * s2y + e2z * s2z) * invDivisor;
+  if (t < ray.mint || t > ray.maxt) return false;
+
+  // Partial derivatives (triangle.dart:100-132) with the default UVs.
+  V dpdu, dpdv;
+  D du1 = kUVs[0] - kUVs[4];
+  D du2 = kUVs[2] - kUVs[4];
+  D dv1 = kUVs[1] - kUVs[5];
+  D dv2 = kUVs[3] - kUVs[5];
+  V dp1 = vsub(p1, p3);
+  V dp2 = vsub(p2, p3);
+  D determinant = du1 * dv2 - dv1 * du2;
+  if (determinant == 0.0) {  // unreachable with the default UVs; kept for fidelity
+    D e3x = (e2y * e1z) - (e2z * e1y);
+    D e3y = (e2z * e1x) - (e2x * e1z);
+    D e3z = (e2x * e1y) - (e2y * e1x);
+    D len = std::sqrt(e3x * e3x + e3y * e3y + e3z * e3z);
+    V v1 = vec(e3x / len, e3y / len, e3z / len);
+    if (std::fabs(v1.x) > std::fabs(v1.y)) {  // Vector.CoordinateSystem vector.dart:207-224
+      D invLen = 1.0 / std::sqrt(v1.x * v1.x + v1.z * v1.z);
+      dpdu = vec(-v1.z * invLen, 0.0, v1.x * invLen);
+    } else {
+      D invLen = 1.0 / std::sqrt(v1.y * v1.y + v1.z * v1.z);
+      dpdu = vec(0.0, v1.z * invLen, -v1.y * invLen);
+    }
+    dpdv = vcross(v1, dpdu);
+  } else {
+    D invdet = 1.0 / determinant;
+    dpdu = vmul(vsub(vmul(dp1, dv2), vmul(dp2, dv1)), invdet);
+    dpdv = vmul(vadd(vmul(dp1, -du2), vmul(dp2, du1)), invdet);
+  }
+  // No alpha texture (triangle.dart:139-150).
+  // dg.set (differential_geometry.dart:77-102).
+  dg->p = pointAt(ray, t);
+  dg->dpdu = dpdu;
+  dg->dpdv = dpdv;
+  dg->nn = vnormalize(vcross(dpdu, dpdv));  // Normal.Normalize normal.dart:53-55
+  if (reverse) dg->nn = vmul(dg->nn, -1.0);  // transformSwapsHandedness is never set (shape.dart:30)
+  *tHit = t;
+  *rayEpsilon = 1.0e-3 * t;
+  if (ob1) *ob1 = b1;
+  if (ob2) *ob2 = b2;
+  return true;
+}
+
+// Triangle.intersectP (triangle.dart:162-240): Vector temporaries rounded to f32.
+static bool tri_intersectP(const V& p1, const V& p2, const V& p3, const Ray& ray) {
+  V e1 = vsub(p2, p1);
+  V e2 = vsub(p3, p1);
+  V s1 = vcross(ray.d, e2);
+  D divisor = vdot(s1, e1);
+  if (divisor == 0.0) return false;
+  D invDivisor = 1.0 / divisor;
+  V s = vsub(ray.o, p1);
+  D b1 = vdot(s, s1) * invDivisor;
+  if (b1 < 0.0 || b1 > 1.0) return false;
+  V s2 = vcross(s, e1);
+  D b2 = vdot(ray.d, s2) * invDivisor;
+  if (b2 < 0.0 || b1 + b2 > 1.0) return false;
+  D t = vdot(e2, s2) * invDivisor;
+  if (t < ray.mint || t > ray.maxt) return false;
+  return true;
+}
+static D tri_area(const V& p1, const V& p2, const V& p3) {  // triangle.dart:265-269
+  return 0.5 * vlen(vcross(vsub(p2, p1), vsub(p3, p1)));
+}
+static V tri_sample(const V& p1, const V& p2, const V& p3, bool reverse, D u1, D u2, V* Ns) {  // :366-383
+  D su1 = std::sqrt(u1);  // UniformSampleTriangle montecarlo.dart:215-220
+  D b1 = 1.0 - su1;
+  D b2 = u2 * su1;
+  V p = vadd(vadd(vmul(p1, b1), vmul(p2, b2)), vmul(p3, (1.0 - b1 - b2)));
+  V n = vcross(vsub(p2, p1), vsub(p3, p1));
+  *Ns = vnormalize(n);
+  if (reverse) *Ns = V{Ns->x * -1.0, Ns->y * -1.0, Ns->z * -1.0};
+  return p;
+}
+
+// ---------------------------------------------------------------------------
+// BVHAccel build (accelerators/bvh_accel.dart:41-91,228-437)
+// ---------------------------------------------------------------------------
+struct BBox {
+  V pMin{kInf, kInf, kInf}, pMax{-kInf, -kInf, -kInf};  // bbox.dart:31-34
+};
+static inline BBox bunion(const BBox& a, const BBox& b) {  // bbox.dart:152-161,203-205
+  BBox r;
+  r.pMin = V{std::min(a.pMin.x, b.pMin.x), std::min(a.pMin.y, b.pMin.y), std::min(a.pMin.z, b.pMin.z)};
+  r.pMax = V{std::max(a.pMax.x, b.pMax.x), std::max(a.pMax.y, b.pMax.y), std::max(a.pMax.z, b.pMax.z)};
+  return r;
+}
+static inline BBox bunionP(const BBox& a, const V& p) {  // bbox.dart:141-150,199-201
+  BBox r;
+  r.pMin = V{std::min(a.pMin.x, p.x), std::min(a.pMin.y, p.y), std::min(a.pMin.z, p.z)};
+  r.pMax = V{std::max(a.pMax.x, p.x), std::max(a.pMax.y, p.y), std::max(a.pMax.z, p.z)};
+  return r;
+}
+static inline D bsurfaceArea(const BBox& b) {  // bbox.dart:163-166
+  V d = vsub(b.pMax, b.pMin);
+  return 2.0 * (d.x * d.y + d.x * d.z + d.y * d.z);
+}
+static inline int bmaximumExtent(const BBox& b) {  // bbox.dart:173-182
+  V diag = vsub(b.pMax, b.pMin);
+  if (diag.x > diag.y && diag.x > diag.z) return 0;
+  else if (diag.y > diag.z) return 1;
+  else return 2;
+}
+struct PrimInfo {  // _BVHPrimitiveInfo bvh_accel.dart:490-501
+  int primitiveNumber;
+  V centroid;
+  BBox bounds;
+};
+struct BuildNode {  // _BVHBuildNode bvh_accel.dart:508-531
+  BBox bounds;
+  int children[2] = {-1, -1};
+  int splitAxis = 0, firstPrimOffset = 0, nPrimitives = 0;
+};
+
+struct Builder {
+  Scene* sc;
+  std::vector<PrimInfo> buildData;
+  std::vector<BuildNode> bnodes;
+  std::vector<Prim> orderedPrims;
+  int maxPrimsInNode;
+  int maxDepth = 0;
+
+  // common.dart:256-287
+  template <class Pred>
+  int partition(Pred pred, int first, int last) {
+    while (first < last) {
+      while (pred(buildData[first])) {
+        ++first;
+        if (first == last) return first;
+      }
+      do {
+        --last;
+        if (first == last) return first;
+      } while (!pred(buildData[last]));
+      std::swap(buildData[first], buildData[last]);
+      ++first;
+    }
+    return first;
+  }
+  // common.dart:289-297: a full List.sort with comparator pred(a,b) ? -1 : 1.
+  // Dart's List.sort uses insertion sort below 32 elements (SDK sort.dart,
+  // restated from the published algorithm; the SDK is not vendored).  In SAH
+  // mode nth_element is only reached with <= 4 elements (bvh_accel.dart:313).
+  void nth_element(int first, int /*nth*/, int last, int dim) {
+    std::vector<PrimInfo> l(buildData.begin() + first, buildData.begin() + last);
+    int n = (int)l.size();
+    if (n <= 32) {
+      for (int i = 1; i < n; ++i) {
+        PrimInfo el = l[i];
+        int j = i;
+        // compare(a[j-1], el) > 0  <=>  !(a[j-1].c < el.c)
+        while (j > 0 && !(l[j - 1].centroid[dim] < el.centroid[dim])) {
+          l[j] = l[j - 1];
+          j--;
+        }
+        l[j] = el;
+      }
+    } else {
+      std::stable_sort(l.begin(), l.end(),
+                       [dim](const PrimInfo& a, const PrimInfo& b) { return a.centroid[dim] < b.centroid[dim]; });
+    }
+    for (int i = first, j = 0; i < last; ++i, ++j) buildData[i] = l[j];
+  }
+
+  int recursiveBuild(int start, int end, int depth) {  // bvh_accel.dart:228-417
+    maxDepth = std::max(maxDepth, depth);
+    int me = (int)bnodes.size();
+    bnodes.push_back(BuildNode());
+    BBox bbox;
+    for (int i = start; i < end; ++i) bbox = bunion(bbox, buildData[i].bounds);
+    int nPrimitives = end - start;
+    auto makeLeaf = [&]() {
+      int firstPrimOffset = (int)orderedPrims.size();
+      for (int i = start; i < end; ++i) orderedPrims.push_back(sc->prims[buildData[i].primitiveNumber]);
+      bnodes[me].firstPrimOffset = firstPrimOffset;
+      bnodes[me].nPrimitives = nPrimitives;
+      bnodes[me].bounds = bbox;
+    };
+    if (nPrimitives == 1) {
+      makeLeaf();
+      return me;
+    }
+    BBox centroidBounds;
+    for (int i = start; i < end; ++i) centroidBounds = bunionP(centroidBounds, buildData[i].centroid);
+    int dim = bmaximumExtent(centroidBounds);
+    int mid = (start + end) / 2;
+    if (centroidBounds.pMax[dim] == centroidBounds.pMin[dim]) {
+      makeLeaf();
+      return me;
+    }
+    // SPLIT_SAH (the default, bvh_accel.dart:310-404)
+    if (nPrimitives <= 4) {
+      mid = (start + end) / 2;
+      nth_element(start, mid, end, dim);
+    } else {
+      const int nBuckets = 12;
+      int count[nBuckets];
+      BBox bounds[nBuckets];
+      for (int i = 0; i < nBuckets; ++i) count[i] = 0;
+      D cmin = centroidBounds.pMin[dim], cmax = centroidBounds.pMax[dim];
+      for (int i = start; i < end; ++i) {
+        int b = (int)(nBuckets * ((buildData[i].centroid[dim] - cmin) / (cmax - cmin)));  // toInt()
+        if (b == nBuckets) b = nBuckets - 1;
+        count[b]++;
+        bounds[b] = bunion(bounds[b], buildData[i].bounds);
+      }
+      float cost[nBuckets - 1];  // Float32List bvh_accel.dart:345
+      for (int i = 0; i < nBuckets - 1; ++i) {
+        BBox b0, b1;
+        int count0 = 0, count1 = 0;
+        for (int j = 0; j <= i; ++j) {
+          b0 = bunion(b0, bounds[j]);
+          count0 += count[j];
+        }
+        for (int j = i + 1; j < nBuckets; ++j) {
+          b1 = bunion(b1, bounds[j]);
+          count1 += count[j];
+        }
+        cost[i] = (float)(0.125 + (count0 * bsurfaceArea(b0) + count1 * bsurfaceArea(b1)) / bsurfaceArea(bbox));
+      }
+      D minCost = cost[0];
+      int minCostSplit = 0;
+      for (int i = 1; i < nBuckets - 1; ++i) {
+        if ((D)cost[i] < minCost) {
+          minCost = cost[i];
+          minCostSplit = i;
+        }
+      }
+      if (nPrimitives > maxPrimsInNode || minCost < nPrimitives) {
+        auto pred = [&](const PrimInfo& p) {
+          int b = (int)std::floor(nBuckets * ((p.centroid[dim] - cmin) / (cmax - cmin)));
+          if (b == nBuckets) b = nBuckets - 1;
+          return b <= minCostSplit;
+        };
+        mid = partition(pred, start, end);
+      } else {
+        makeLeaf();
+        return me;
+      }
+    }
+    // Right child first (bvh_accel.dart:407-411).
+    int c2 = recursiveBuild(mid, end, depth + 1);
+    int c1 = recursiveBuild(start, mid, depth + 1);
+    bnodes[me].children[0] = c1;
+    bnodes[me].children[1] = c2;
+    bnodes[me].bounds = bunion(bnodes[c1].bounds, bnodes[c2].bounds);
+    bnodes[me].splitAxis = dim;
+    bnodes[me].nPrimitives = 0;
+    return me;
+  }
+
+  int flatten(int bn, int* offset) {  // bvh_accel.dart:419-437
+    LinearNode& ln = sc->nodes[*offset];
+    ln.bmin = bnodes[bn].bounds.pMin;
+    ln.bmax = bnodes[bn].bounds.pMax;
+    int myOffset = (*offset)++;
+    if (bnodes[bn].nPrimitives > 0) {
+      ln.offset = (uint32_t)bnodes[bn].firstPrimOffset;
+      ln.nPrimitives = bnodes[bn].nPrimitives;
+      ln.axis = 0;
+    } else {
+      ln.axis = bnodes[bn].splitAxis;
+      ln.nPrimitives = 0;
+      flatten(bnodes[bn].children[0], offset);
+      int second = flatten(bnodes[bn].children[1], offset);
+      sc->nodes[myOffset].offset = (uint32_t)second;
+    }
+    return myOffset;
+  }
+
+  void build() {  // bvh_accel.dart:41-91
+    int n = (int)sc->prims.size();
+    if (n == 0) return;
+    buildData.resize(n);
+    for (int i = 0; i < n; ++i) {
+      const Prim& pr = sc->prims[i];
+      V a = sc->vert(pr.v[0]), b = sc->vert(pr.v[1]), c = sc->vert(pr.v[2]);
+      BBox bb;  // Triangle.worldBound triangle.dart:39-42
+      bb.pMin = V{std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)};
+      bb.pMax = V{std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)};
+      bb = bunionP(bb, c);
+      buildData[i].primitiveNumber = i;
+      buildData[i].bounds = bb;
+      buildData[i].centroid = vadd(vmul(bb.pMin, 0.5), vmul(bb.pMax, 0.5));  // bbox.dart:66
+    }
+    bnodes.reserve(2 * n);
+    orderedPrims.reserve(n);
+    recursiveBuild(0, n, 0);
+    sc->prims = orderedPrims;
+    sc->nodes.resize(bnodes.size());
+    int offset = 0;
+    flatten(0, &offset);
+    sc->bvhDepth = maxDepth;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// BVHAccel traversal (bvh_accel.dart:101-226,439-472)
+// ---------------------------------------------------------------------------
+static inline bool slab(const LinearNode& n, const Ray& ray, const V& invDir, const int dirIsNeg[3]) {
+  const V* b[2] = {&n.bmin, &n.bmax};
+  D tmin = (b[dirIsNeg[0]]->x - ray.o.x) * invDir.x;
+  D tmax = (b[1 - dirIsNeg[0]]->x - ray.o.x) * invDir.x;
+  D tymin = (b[dirIsNeg[1]]->y - ray.o.y) * invDir.y;
+  D tymax = (b[1 - dirIsNeg[1]]->y - ray.o.y) * invDir.y;
+  if ((tmin > tymax) || (tymin > tmax)) return false;
+  if (tymin > tmin) tmin = tymin;
+  if (tymax < tmax) tmax = tymax;
+  D tzmin = (b[dirIsNeg[2]]->z - ray.o.z) * invDir.z;
+  D tzmax = (b[1 - dirIsNeg[2]]->z - ray.o.z) * invDir.z;
+  if ((tmin > tzmax) || (tzmin > tmax)) return false;
+  if (tzmin > tmin) tmin = tzmin;
+  if (tzmax < tmax) tmax = tzmax;
+  return (tmin < ray.maxt) && (tmax > ray.mint);
+}
+
+struct Isect {  // Intersection (intersection.dart) + GeometricPrimitive.intersect (geometric_primitive.dart:47-61)
+  DG dg;
+  int prim = -1;
+  D rayEpsilon = 0;
+  D t = 0, b1 = 0, b2 = 0;
+};
+
+static bool bvh_intersect(const Scene& sc, Ray& ray, Isect* isect) {  // bvh_accel.dart:101-165
+  sc.ctr.closest_rays++;
+  if (sc.nodes.empty()) return false;
+  bool hit = false;
+  V invDir = vec(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);  // f32-rounded (:109-111)
+  int dirIsNeg[3] = {invDir.x < 0 ? 1 : 0, invDir.y < 0 ? 1 : 0, invDir.z < 0 ? 1 : 0};
+  int todoOffset = 0, nodeNum = 0;
+  std::vector<uint32_t> todoHeap;
+  uint32_t todoSmall[64];
+  uint32_t* todo = todoSmall;
+  size_t todoCap = 64;
+  auto push = [&](uint32_t v) {
+    if ((size_t)todoOffset == todoCap) {  // the reference would throw a RangeError at 64
+      todoHeap.assign(todo, todo + todoCap);
+      todoCap *= 2;
+      todoHeap.resize(todoCap);
+      todo = todoHeap.data();
+    }
+    todo[todoOffset++] = v;
+  };
+  while (true) {
+    const LinearNode& node = sc.nodes[nodeNum];
+    sc.ctr.closest_nodes++;
+    if (slab(node, ray, invDir, dirIsNeg)) {
+      if (node.nPrimitives > 0) {
+        for (int i = 0; i < node.nPrimitives; ++i) {
+          sc.ctr.closest_tris++;
+          const Prim& pr = sc.prims[node.offset + i];
+          D thit, eps, b1, b2;
+          DG dg;
+          if (tri_intersect(sc.vert(pr.v[0]), sc.vert(pr.v[1]), sc.vert(pr.v[2]), sc.meshes[pr.mesh].reverse, ray,
+                            &thit, &eps, &dg, &b1, &b2)) {
+            isect->dg = dg;
+            isect->prim = (int)(node.offset + i);
+            isect->rayEpsilon = eps;
+            isect->t = thit;
+            isect->b1 = b1;
+            isect->b2 = b2;
+            ray.maxt = thit;  // geometric_primitive.dart:59
+            hit = true;
+          }
+        }
+        if (todoOffset == 0) break;
+        nodeNum = (int)todo[--todoOffset];
+      } else {
+        if (dirIsNeg[node.axis] != 0) {
+          push((uint32_t)(nodeNum + 1));
+          nodeNum = (int)node.offset;
+        } else {
+          push(node.offset);
+          nodeNum = nodeNum + 1;
+        }
+      }
+    } else {
+      if (todoOffset == 0) break;
+      nodeNum = (int)todo[--todoOffset];
+    }
+  }
+  return hit;
+}
+
+static bool bvh_intersectP(const Scene& sc, const Ray& ray) {  // bvh_accel.dart:167-226
+  sc.ctr.any_rays++;
+  if (sc.nodes.empty()) return false;
+  V invDir = vec(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+  int dirIsNeg[3] = {invDir.x < 0 ? 1 : 0, invDir.y < 0 ? 1 : 0, invDir.z < 0 ? 1 : 0};
+  std::vector<uint32_t> todo(64);
+  int todoOffset = 0, nodeNum = 0;
+  auto push = [&](uint32_t v) {
+    if ((size_t)todoOffset == todo.size()) todo.resize(todo.size() * 2);
+    todo[todoOffset++] = v;
+  };
+  while (true) {
+    const LinearNode& node = sc.nodes[nodeNum];
+    sc.ctr.any_nodes++;
+    if (slab(node, ray, invDir, dirIsNeg)) {
+      if (node.nPrimitives > 0) {
+        for (int i = 0; i < node.nPrimitives; ++i) {
+          sc.ctr.any_tris++;
+          const Prim& pr = sc.prims[node.offset + i];
+          if (tri_intersectP(sc.vert(pr.v[0]), sc.vert(pr.v[1]), sc.vert(pr.v[2]), ray)) return true;
+        }
+        if (todoOffset == 0) break;
+        nodeNum = (int)todo[--todoOffset];
+      } else {
+        if (dirIsNeg[node.axis] != 0) {
+          push((uint32_t)(nodeNum + 1));
+          nodeNum = (int)node.offset;
+        } else {
+          push(node.offset);
+          nodeNum = nodeNum + 1;
+        }
+      }
+    } else {
+      if (todoOffset == 0) break;
+      nodeNum = (int)todo[--todoOffset];
+    }
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------
+// ShapeSet / DiffuseAreaLight (shape_set.dart:53-96, shape.dart:100-121,
+// diffuse_area_light.dart:44-70)
+// ---------------------------------------------------------------------------
+static void lt_verts(const Scene& sc, const LightTri& lt, V* a, V* b, V* c) {
+  *a = sc.vert(lt.v[0]);
+  *b = sc.vert(lt.v[1]);
+  *c = sc.vert(lt.v[2]);
+}
+static V shapeset_sample(const Scene& sc, const Light& L, D uPos0, D uPos1, D uComponent, V* Ns, const V& p) {
+  int sn = L.areaDistribution.sampleDiscrete(uComponent) % (int)L.shapes.size();
+  V a, b, c;
+  const LightTri& lt = sc.lightTris[L.shapes[sn]];
+  lt_verts(sc, lt, &a, &b, &c);
+  V pt = tri_sample(a, b, c, lt.reverse, uPos0, uPos1, Ns);  // Shape.sample2 -> sample (shape.dart:96-98)
+  Ray r{p, vsub(pt, p), 1.0e-3, kInf, 0.0, 0};
+  D rayEps = 0.0, thit = 1.0;
+  bool anyHit = false;
+  DG dg;
+  for (size_t i = 0; i < L.shapes.size(); ++i) {
+    const LightTri& t = sc.lightTris[L.shapes[i]];
+    lt_verts(sc, t, &a, &b, &c);
+    sc.ctr.light_tris++;
+    anyHit = tri_intersect(a, b, c, t.reverse, r, &thit, &rayEps, &dg) || anyHit;
+  }
+  if (anyHit) *Ns = dg.nn;
+  return pointAt(r, thit);
+}
+static D shapeset_pdf(const Scene& sc, const Light& L, const V& p, const V& wi) {  // shape_set.dart:82-89
+  D pdf = 0.0;
+  for (size_t i = 0; i < L.shapes.size(); ++i) {
+    const LightTri& t = sc.lightTris[L.shapes[i]];
+    V a, b, c;
+    lt_verts(sc, t, &a, &b, &c);
+    // Shape.pdf2 (shape.dart:100-121)
+    D pdf2;
+    DG dgLight;
+    Ray ray{p, wi, 1.0e-3, kInf, 0.0, -1};
+    D thit = 0.0, rayEpsilon = 0.0;
+    sc.ctr.light_tris++;
+    if (!tri_intersect(a, b, c, t.reverse, ray, &thit, &rayEpsilon, &dgLight)) {
+      pdf2 = 0.0;
+    } else {
+      V q = pointAt(ray, thit);
+      pdf2 = vlen2(vsub(q, p)) / (vabsdot(dgLight.nn, vneg(wi)) * tri_area(a, b, c));
+      if (std::isinf(pdf2)) pdf2 = 0.0;
+    }
+    pdf += L.areas[i] * pdf2;
+  }
+  return pdf / L.area;
+}
+static inline S light_L(const Light& L, const V& n, const V& w) {  // diffuse_area_light.dart:44-46
+  return vdot(n, w) > 0.0 ? L.Lemit : S{0, 0, 0};
+}
+
+// ---------------------------------------------------------------------------
+// BSDF with a single Lambertian lobe (matte_material.dart:41-65, bsdf.dart,
+// bxdf.dart, lambertian.dart)
+// ---------------------------------------------------------------------------
+enum {
+  BSDF_REFLECTION = 1 << 0,
+  BSDF_TRANSMISSION = 1 << 1,
+  BSDF_DIFFUSE = 1 << 2,
+  BSDF_GLOSSY = 1 << 3,
+  BSDF_SPECULAR = 1 << 4,
+  BSDF_ALL_TYPES = BSDF_DIFFUSE | BSDF_GLOSSY | BSDF_SPECULAR,
+  BSDF_ALL = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_ALL_TYPES
+};
+struct BSDF {
+  V p, nn, ng, sn, tn;
+  int nBxDFs;
+  S R;                // Lambertian reflectance
+  static const int kType = BSDF_REFLECTION | BSDF_DIFFUSE;
+  static bool matches(int flags) { return (kType & flags) == kType; }  // bxdf.dart:31-33
+  int numComponents(int flags) const { return (nBxDFs > 0 && matches(flags)) ? 1 : 0; }
+  V worldToLocal(const V& v) const { return vec(vdot(v, sn), vdot(v, tn), vdot(v, nn)); }  // bsdf.dart:177-179
+  V localToWorld(const V& v) const {                                                        // bsdf.dart:181-185
+    return vec(sn.x * v.x + tn.x * v.y + nn.x * v.z, sn.y * v.x + tn.y * v.y + nn.y * v.z,
+               sn.z * v.x + tn.z * v.y + nn.z * v.z);
+  }
+  S bxdf_f() const { return smulD(R, INV_PI); }  // lambertian.dart:35-37
+  static D bxdf_pdf(const V& wo, const V& wi) {  // bxdf.dart:84-88
+    return (wo.z * wi.z > 0.0) ? std::fabs(wi.z) * INV_PI : 0.0;
+  }
+  S f(const V& woW, const V& wiW, int flags) const {  // bsdf.dart:187-211
+    if (vdot(wiW, ng) * vdot(woW, ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
+    else flags = flags & ~BSDF_REFLECTION;
+    S f{0, 0, 0};
+    if (nBxDFs > 0 && matches(flags)) f = sadd(f, bxdf_f());
+    return f;
+  }
+  D pdf(const V& woW, const V& wiW, int flags) const {  // bsdf.dart:135-156
+    if (nBxDFs == 0) return 0.0;
+    V wo = worldToLocal(woW);
+    V wi = worldToLocal(wiW);
+    D pdf = 0.0;
+    int matchingComps = 0;
+    if (matches(flags)) {
+      ++matchingComps;
+      pdf += bxdf_pdf(wo, wi);
+    }
+    return matchingComps > 0 ? pdf / matchingComps : 0.0;
+  }
+  S sample_f(const V& woW, V* wiW, D uDir0, D uDir1, D uComponent, D* pdf, int flags, int* sampledType) const {
+    // bsdf.dart:53-133
+    int matchingComps = numComponents(flags);
+    if (matchingComps == 0) {
+      *pdf = 0.0;
+      if (sampledType) *sampledType = 0;
+      return S{0, 0, 0};
+    }
+    int which = std::min((int)std::floor(uComponent * matchingComps), matchingComps - 1);
+    (void)which;
+    V wo = worldToLocal(woW);
+    *pdf = 0.0;
+    V wi = CosineSampleHemisphere(uDir0, uDir1);  // bxdf.dart:37-48
+    if (wo.z < 0.0) wi.z *= -1.0;
+    *pdf = bxdf_pdf(wo, wi);
+    if (*pdf == 0.0) {
+      if (sampledType) *sampledType = 0;
+      return S{0, 0, 0};
+    }
+    if (sampledType) *sampledType = kType;
+    *wiW = localToWorld(wi);
+    // matchingComps == 1: no pdf averaging.
+    S f{0, 0, 0};
+    if (vdot(*wiW, ng) * vdot(woW, ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
+    else flags = flags & ~BSDF_REFLECTION;
+    if (matches(flags)) f = sadd(f, bxdf_f());
+    return f;
+  }
+};
+
+// Intersection.getBSDF -> GeometricPrimitive.getBSDF -> Triangle.getShadingGeometry
+// (copy, no per-vertex N/S) -> MatteMaterial.getBSDF.
+static BSDF make_bsdf(const Scene& sc, const Isect& is) {
+  const Mesh& m = sc.meshes[sc.prims[is.prim].mesh];
+  BSDF b;
+  b.p = is.dg.p;
+  b.ng = is.dg.nn;
+  b.nn = is.dg.nn;
+  b.sn = vnormalize(is.dg.dpdu);   // bsdf.dart:45-51
+  b.tn = vcross(b.nn, b.sn);
+  S r = rgb(clampD(m.Kd.r, 0.0, kInf), clampD(m.Kd.g, 0.0, kInf), clampD(m.Kd.b, 0.0, kInf));
+  b.nBxDFs = sblack(r) ? 0 : 1;
+  b.R = r;
+  return b;
+}
+static S isect_Le(const Scene& sc, const Isect& is, const V& wo) {  // intersection.dart:60-63
+  int li = sc.meshes[sc.prims[is.prim].mesh].light;
+  return li >= 0 ? light_L(sc.lights[li], is.dg.nn, wo) : S{0, 0, 0};
+}
+
+// ---------------------------------------------------------------------------
+// Random-number source seen by the integrators.  Serial mode: the task's
+// shared RNG (sampler_renderer.dart:137).  Replay mode: recorded values.
+// ---------------------------------------------------------------------------
+struct LiRng {
+  DartRandom* rng = nullptr;
+  std::vector<D>* record = nullptr;  // every randomFloat drawn inside Li
+  const D* replay = nullptr;
+  int replayN = 0, replayPos = 0;
+  bool underflow = false;
+  D randomFloat() {
+    D v;
+    if (replay) {
+      if (replayPos < replayN) v = replay[replayPos++];
+      else { underflow = true; v = 0.0; }
+    } else {
+      v = rng->randomFloat();
+    }
+    if (record) record->push_back(v);
+    return v;
+  }
+};
+
+struct SampleView {  // Sample (sample.dart:23-79) flattened: [imageU, imageV, lensU, lensV, time, oneD..., twoD...]
+  const float* v;
+  int n1D;
+  D oneD(int i) const { return (D)v[5 + i]; }
+  D twoD(int i, int k) const { return (D)v[5 + n1D + 2 * i + k]; }
+};
+
+// EstimateDirect (integrator.dart:119-185)
+static S EstimateDirect(const Scene& sc, int lightIdx, const V& p, const V& n, const V& wo, D rayEpsilon,
+                        const BSDF& bsdf, D lsU0, D lsU1, D lsComp, D bsU0, D bsU1, D bsComp, int flags) {
+  const Light& light = sc.lights[lightIdx];
+  S Ld{0, 0, 0};
+  V wi{0, 0, 0};
+  D lightPdf = 0.0, bsdfPdf = 0.0;
+  // light.sampleLAtPoint (diffuse_area_light.dart:60-70)
+  V ns{0, 0, 0};
+  V ps = shapeset_sample(sc, light, lsU0, lsU1, lsComp, &ns, p);
+  wi = vnormalize(vsub(ps, p));
+  lightPdf = shapeset_pdf(sc, light, p, wi);
+  // VisibilityTester.setSegment (visibility_tester.dart:26-29)
+  D dist = vlen(vsub(ps, p));
+  Ray vr{p, vdiv(vsub(ps, p), dist), rayEpsilon, dist * (1.0 - 1.0e-3), 0.0, 0};
+  S Li = light_L(light, ns, vneg(wi));
+  if (lightPdf > 0.0 && !sblack(Li)) {
+    S f = bsdf.f(wo, wi, flags);
+    if (!sblack(f) && !bvh_intersectP(sc, vr)) {
+      Li = smul(Li, S{1, 1, 1});  // transmittance == 1 (emission_integrator.dart:85-87)
+      bsdfPdf = bsdf.pdf(wo, wi, flags);
+      D weight = PowerHeuristic(1, lightPdf, 1, bsdfPdf);
+      Ld = sadd(Ld, smulD(smul(f, Li), (vabsdot(wi, n) * weight / lightPdf)));
+    }
+  }
+  // BSDF sampling half (not a delta light)
+  {
+    int sampledType = 0;
+    S f = bsdf.sample_f(wo, &wi, bsU0, bsU1, bsComp, &bsdfPdf, flags, &sampledType);
+    if (!sblack(f) && bsdfPdf > 0.0) {
+      D weight = 1.0;
+      if ((sampledType & BSDF_SPECULAR) == 0) {
+        lightPdf = shapeset_pdf(sc, light, p, wi);
+        if (lightPdf == 0.0) return Ld;
+        weight = PowerHeuristic(1, bsdfPdf, 1, lightPdf);
+      }
+      Isect lightIsect;
+      S Li2{0, 0, 0};
+      Ray ray{p, wi, rayEpsilon, kInf, 0.0, 0};
+      if (bvh_intersect(sc, ray, &lightIsect)) {
+        if (sc.meshes[sc.prims[lightIsect.prim].mesh].light == lightIdx) Li2 = isect_Le(sc, lightIsect, vneg(wi));
+      } else {
+        Li2 = S{0, 0, 0};  // light.Le(ray) == 0 for area lights (light.dart:70-72)
+      }
+      if (!sblack(Li2)) {
+        Li2 = smul(Li2, S{1, 1, 1});
+        Ld = sadd(Ld, smulD(smul(f, Li2), (vabsdot(wi, n) * weight / bsdfPdf)));
+      }
+    }
+  }
+  return Ld;
+}
+
+struct IntegratorCfg {
+  int kind;      // 0 = DirectLighting(all), 1 = Path
+  int maxDepth;
+};
+static const int SAMPLE_DEPTH = 3;  // path_integrator.dart:139
+
+// Sample-slot layout.
+static void sample_layout(const Scene& sc, const IntegratorCfg& cfg, std::vector<int>* n1D, std::vector<int>* n2D,
+                          bool roundPow2) {
+  n1D->clear();
+  n2D->clear();
+  auto rp2 = [](int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; };
+  if (cfg.kind == 1) {  // path_integrator.dart:124-131
+    for (int i = 0; i < SAMPLE_DEPTH; ++i) {
+      n1D->push_back(1); n2D->push_back(1);  // LightSampleOffsets
+      n1D->push_back(1);                     // lightNumOffset
+      n1D->push_back(1); n2D->push_back(1);  // bsdfSampleOffsets
+      n1D->push_back(1); n2D->push_back(1);  // pathSampleOffsets
+    }
+  } else {  // direct_lighting_integrator.dart:70-87
+    for (size_t i = 0; i < sc.lights.size(); ++i) {
+      int ns = sc.lights[i].nSamples;
+      if (roundPow2) ns = rp2(ns);
+      n1D->push_back(ns); n2D->push_back(ns);
+      n1D->push_back(ns); n2D->push_back(ns);
+    }
+  }
+  n1D->push_back(1);  // emission_integrator.dart:26-29 tau
+  n1D->push_back(1);  // scatter
+}
+
+// PathIntegrator.Li (path_integrator.dart:29-122)
+static S PathLi(const Scene& sc, const IntegratorCfg& cfg, const Ray& r, const Isect& isect0, const SampleView& sv,
+                LiRng& rng) {
+  S pathThroughput{1, 1, 1};
+  S L{0, 0, 0};
+  Ray ray = r;
+  bool specularBounce = false;
+  Isect isectP = isect0;
+  int nLights = (int)sc.lights.size();
+  for (int bounces = 0;; ++bounces) {
+    if (bounces == 0 || specularBounce) L = sadd(L, smul(pathThroughput, isect_Le(sc, isectP, vneg(ray.d))));
+    BSDF bsdf = make_bsdf(sc, isectP);
+    V p = bsdf.p;
+    V n = bsdf.nn;
+    V wo = vneg(ray.d);
+    // UniformSampleOneLight (integrator.dart:79-117)
+    S Ld{0, 0, 0};
+    if (nLights > 0) {
+      int lightNum;
+      D ls0, ls1, lsc, bs0, bs1, bsc;
+      if (bounces < SAMPLE_DEPTH) {
+        lightNum = (int)std::floor(sv.oneD(4 * bounces + 1) * nLights);
+        ls0 = sv.twoD(3 * bounces + 0, 0); ls1 = sv.twoD(3 * bounces + 0, 1); lsc = sv.oneD(4 * bounces + 0);
+        bs0 = sv.twoD(3 * bounces + 1, 0); bs1 = sv.twoD(3 * bounces + 1, 1); bsc = sv.oneD(4 * bounces + 2);
+      } else {
+        lightNum = (int)std::floor(rng.randomFloat() * nLights);
+        ls0 = r32(rng.randomFloat()); ls1 = r32(rng.randomFloat()); lsc = rng.randomFloat();  // light_sample.dart:46-51
+        bs0 = r32(rng.randomFloat()); bs1 = r32(rng.randomFloat()); bsc = rng.randomFloat();  // bsdf_sample.dart:37-42
+      }
+      lightNum = std::min(lightNum, nLights - 1);
+      Ld = smulD(EstimateDirect(sc, lightNum, p, n, wo, isectP.rayEpsilon, bsdf, ls0, ls1, lsc, bs0, bs1, bsc,
+                                BSDF_ALL & ~BSDF_SPECULAR),
+                 (D)nLights);
+    }
+    L = sadd(L, smul(pathThroughput, Ld));
+    // Outgoing BSDF sample
+    D o0, o1, oc;
+    if (bounces < SAMPLE_DEPTH) {
+      o0 = sv.twoD(3 * bounces + 2, 0); o1 = sv.twoD(3 * bounces + 2, 1); oc = sv.oneD(4 * bounces + 3);
+    } else {
+      o0 = r32(rng.randomFloat()); o1 = r32(rng.randomFloat()); oc = rng.randomFloat();
+    }
+    V wi{0, 0, 0};
+    D pdf = 0.0;
+    int flags = 0;
+    S f = bsdf.sample_f(wo, &wi, o0, o1, oc, &pdf, BSDF_ALL, &flags);
+    if (sblack(f) || pdf == 0.0) break;
+    specularBounce = (flags & BSDF_SPECULAR) != 0;
+    pathThroughput = smul(pathThroughput, sdivD(smulD(f, vabsdot(wi, n)), pdf));
+    ray = Ray{p, wi, isectP.rayEpsilon, kInf, ray.time, ray.depth + 1};  // RayDifferential.child
+    if (bounces > 3) {
+      D continueProbability = std::min(0.5, slum(pathThroughput));
+      if (rng.randomFloat() > continueProbability) break;
+      pathThroughput = sdivD(pathThroughput, continueProbability);
+    }
+    if (bounces == cfg.maxDepth) break;
+    Isect localIsect;
+    if (!bvh_intersect(sc, ray, &localIsect)) break;  // specularBounce is never true for matte
+    // transmittance == 1
+    isectP = localIsect;
+  }
+  return L;
+}
+
+// DirectLightingIntegrator.Li, strategy "all" (direct_lighting_integrator.dart:30-68)
+static S DirectLi(const Scene& sc, const IntegratorCfg& cfg, const Ray& ray, const Isect& isect, const SampleView& sv,
+                  const std::vector<int>& n1D, const std::vector<int>& n2D, LiRng& rng) {
+  S L{0, 0, 0};
+  BSDF bsdf = make_bsdf(sc, isect);
+  V wo = vneg(ray.d);
+  V p = bsdf.p;
+  V n = bsdf.nn;
+  L = sadd(L, isect_Le(sc, isect, wo));
+  if (!sc.lights.empty()) {
+    // UniformSampleAllLights (integrator.dart:39-77)
+    S Lall{0, 0, 0};
+    int off1 = 0, off2 = 0;  // running float offsets of the slots
+    for (size_t i = 0; i < sc.lights.size(); ++i) {
+      int nSamples = n1D[2 * i];
+      int lc = off1;                 // light component slot
+      int bc = off1 + n1D[2 * i];    // bsdf component slot
+      int lp = off2;                 // light pos slot (floats)
+      int bd = off2 + 2 * n2D[2 * i];
+      off1 += n1D[2 * i] + n1D[2 * i + 1];
+      off2 += 2 * (n2D[2 * i] + n2D[2 * i + 1]);
+      int base2 = 5;
+      for (size_t k = 0; k < n1D.size(); ++k) base2 += n1D[k];
+      S Ld{0, 0, 0};
+      for (int j = 0; j < nSamples; ++j) {
+        D ls0 = sv.v[base2 + lp + 2 * j], ls1 = sv.v[base2 + lp + 2 * j + 1], lsc = sv.v[5 + lc + j];
+        D bs0 = sv.v[base2 + bd + 2 * j], bs1 = sv.v[base2 + bd + 2 * j + 1], bsc = sv.v[5 + bc + j];
+        Ld = sadd(Ld, EstimateDirect(sc, (int)i, p, n, wo, isect.rayEpsilon, bsdf, ls0, ls1, lsc, bs0, bs1, bsc,
+                                     BSDF_ALL & ~BSDF_SPECULAR));
+      }
+      Lall = sadd(Lall, sdivD(Ld, (D)nSamples));
+    }
+    L = sadd(L, Lall);
+  }
+  if (ray.depth + 1 < cfg.maxDepth) {
+    // SpecularReflect / SpecularTransmit (integrator.dart:187-290): each draws
+    // BSDFSample.random(rng) (3 floats) and then finds no specular lobe => +0.
+    for (int k = 0; k < 6; ++k) (void)rng.randomFloat();
+    L = sadd(L, S{0, 0, 0});
+    L = sadd(L, S{0, 0, 0});
+  }
+  return L;
+}
+
+// ---------------------------------------------------------------------------
+// Camera (perspective_camera.dart:93-132) and film (image_film.dart)
+// ---------------------------------------------------------------------------
+struct Camera {
+  float r2c[16], c2w[16];
+  D lensRadius, focalDistance;
+};
+static V xfPoint(const float* m, const V& p) {  // transform.dart:110-128
+  D x = p.x, y = p.y, z = p.z;
+  V o = vec(m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7],
+            m[8] * x + m[9] * y + m[10] * z + m[11]);
+  D w = (D)m[12] * x + (D)m[13] * y + (D)m[14] * z + (D)m[15];
+  if (w != 1.0) o = vec(o.x / w, o.y / w, o.z / w);  // invScale
+  return o;
+}
+static V xfVector(const float* m, const V& p) {  // transform.dart:130-144
+  D x = p.x, y = p.y, z = p.z;
+  return vec(m[0] * x + m[1] * y + m[2] * z, m[4] * x + m[5] * y + m[6] * z, m[8] * x + m[9] * y + m[10] * z);
+}
+static Ray generateRay(const Camera& cam, D imageX, D imageY, D lensU, D lensV, D time) {
+  V Pras = vec(imageX, imageY, 0.0);
+  V Pcamera = xfPoint(cam.r2c, Pras);
+  Ray ray;
+  ray.o = vec(0, 0, 0);
+  ray.d = vnormalize(Pcamera);
+  ray.mint = 0.0;
+  ray.maxt = kInf;
+  if (cam.lensRadius > 0.0) {
+    D lu, lv;
+    ConcentricSampleDisk(lensU, lensV, &lu, &lv);
+    lu *= cam.lensRadius;
+    lv *= cam.lensRadius;
+    D ft = cam.focalDistance / ray.d.z;
+    V Pfocus = pointAt(ray, ft);
+    ray.o = vec(lu, lv, 0.0);
+    ray.d = vnormalize(vsub(Pfocus, ray.o));
+  }
+  ray.time = time;
+  ray.depth = 0;
+  ray.o = xfPoint(cam.c2w, ray.o);   // AnimatedTransform static path (animated_transform.dart:158-169)
+  ray.d = xfVector(cam.c2w, ray.d);
+  return ray;
+}
+
+struct Film {  // ImageFilm (image_film.dart:51-97)
+  int xres, yres, left, top, width, height;
+  D fxw, fyw, invX, invY;
+  float table[256];
+  std::vector<float> Lxyz, weightSum;
+  void init(int xr, int yr, const float crop[4], D xw, D yw, const float* tbl) {
+    xres = xr; yres = yr;
+    left = (int)std::ceil(xres * (D)crop[0]);
+    width = std::max(1, (int)std::ceil(xres * (D)crop[1]) - left);
+    top = (int)std::ceil(yres * (D)crop[2]);
+    height = std::max(1, (int)std::ceil(yres * (D)crop[3]) - top);
+    fxw = xw; fyw = yw; invX = 1.0 / xw; invY = 1.0 / yw;
+    memcpy(table, tbl, sizeof(table));
+    Lxyz.assign((size_t)width * height * 3, 0.0f);
+    weightSum.assign((size_t)width * height, 0.0f);
+  }
+  void getSampleExtent(int e[4]) const {  // image_film.dart:247-252
+    e[0] = (int)std::floor(left + 0.5 - fxw);
+    e[1] = (int)std::ceil(left + 0.5 + width + fxw);
+    e[2] = (int)std::floor(top + 0.5 - fyw);
+    e[3] = (int)std::ceil(top + 0.5 + height + fyw);
+  }
+  void addSample(D imageX, D imageY, const S& L) {  // image_film.dart:99-185 (preview repaint omitted)
+    D dimageX = imageX - 0.5, dimageY = imageY - 0.5;
+    int x0 = (int)std::ceil(dimageX - fxw), x1 = (int)std::floor(dimageX + fxw);
+    int y0 = (int)std::ceil(dimageY - fyw), y1 = (int)std::floor(dimageY + fyw);
+    x0 = std::max(x0, left); x1 = std::min(x1, left + width - 1);
+    y0 = std::max(y0, top);  y1 = std::min(y1, top + height - 1);
+    if ((x1 - x0) < 0 || (y1 - y0) < 0) return;
+    D xyz[3];  // XYZColor.from(RGBColor): Float32List store (xyz_color.dart:39-42; spectrum.dart:294-298)
+    xyz[0] = r32(0.412453 * L.r + 0.357580 * L.g + 0.180423 * L.b);
+    xyz[1] = r32(0.212671 * L.r + 0.715160 * L.g + 0.072169 * L.b);
+    xyz[2] = r32(0.019334 * L.r + 0.119193 * L.g + 0.950227 * L.b);
+    for (int y = y0; y <= y1; ++y) {
+      D fy = std::fabs((y - dimageY) * invY * 16);
+      int iy = std::min((int)std::floor(fy), 15);
+      for (int x = x0; x <= x1; ++x) {
+        D fx = std::fabs((x - dimageX) * invX * 16);
+        int ix = std::min((int)std::floor(fx), 15);
+        D filterWt = table[iy * 16 + ix];
+        size_t pi = (size_t)(y - top) * width + (x - left);
+        Lxyz[3 * pi] = (float)((D)Lxyz[3 * pi] + filterWt * xyz[0]);
+        Lxyz[3 * pi + 1] = (float)((D)Lxyz[3 * pi + 1] + filterWt * xyz[1]);
+        Lxyz[3 * pi + 2] = (float)((D)Lxyz[3 * pi + 2] + filterWt * xyz[2]);
+        weightSum[pi] = (float)((D)weightSum[pi] + filterWt);
+      }
+    }
+  }
+};
+// ImageFilm.writeImage for one pixel (image_film.dart:268-299), splat == 0.
+static void write_pixel(D X, D Y, D Z, D weightSum, float out[3]) {
+  D c0 = 3.240479 * X - 1.537150 * Y - 0.498535 * Z;   // spectrum.dart:287-291
+  D c1 = -0.969256 * X + 1.875991 * Y + 0.041556 * Z;
+  D c2 = 0.055648 * X - 0.204043 * Y + 1.057311 * Z;
+  out[0] = out[1] = out[2] = 0.0f;
+  if (weightSum != 0.0) {
+    D invWt = 1.0 / weightSum;
+    out[0] = (float)std::max(0.0, c0 * invWt);
+    out[1] = (float)std::max(0.0, c1 * invWt);
+    out[2] = (float)std::max(0.0, c2 * invWt);
+  }
+  // += splatScale * splatRGB (== +0.0)
+  out[0] = (float)((D)out[0] + 0.0);
+  out[1] = (float)((D)out[1] + 0.0);
+  out[2] = (float)((D)out[2] + 0.0);
+}
+
+// GetSubWindow (common.dart:52-73)
+static void GetSubWindow(int w, int h, int num, int count, int extents[4]) {
+  int nx = count, ny = 1;
+  while ((nx & 0x1) == 0 && 2 * w * ny < h * nx) {
+    nx >>= 1;
+    ny <<= 1;
+  }
+  int xo = num % nx, yo = num / nx;
+  D tx0 = (D)xo / nx, tx1 = (D)(xo + 1) / nx;
+  D ty0 = (D)yo / ny, ty1 = (D)(yo + 1) / ny;
+  auto lerp = [](D t, D v1, D v2) { return v1 * (1.0 - t) + v2 * t; };
+  extents[0] = (int)std::floor(lerp(tx0, 0, w));
+  extents[1] = std::min((int)std::floor(lerp(tx1, 0, w)), w);
+  extents[2] = (int)std::floor(lerp(ty0, 0, h));
+  extents[3] = std::min((int)std::floor(lerp(ty1, 0, h)), h);
+}
+
+// LDPixelSample (montecarlo.dart:407-473) -> out[spp][nFloats] in the flat layout.
+template <class RNG>
+static void LDPixelSample(int nPixelSamples, const std::vector<int>& n1D, const std::vector<int>& n2D,
+                          std::vector<float>& buffer, RNG& rng, std::vector<float>& out, int nFloats) {
+  size_t need = 5 * (size_t)nPixelSamples;
+  for (int c : n1D) need += (size_t)c * nPixelSamples;
+  for (int c : n2D) need += 2 * (size_t)c * nPixelSamples;
+  buffer.resize(need);
+  float* imageSamples = buffer.data();
+  float* lensSamples = imageSamples + 2 * nPixelSamples;
+  float* timeSamples = lensSamples + 2 * nPixelSamples;
+  float* cur = timeSamples + nPixelSamples;
+  std::vector<float*> oneD(n1D.size()), twoD(n2D.size());
+  for (size_t i = 0; i < n1D.size(); ++i) { oneD[i] = cur; cur += (size_t)n1D[i] * nPixelSamples; }
+  for (size_t i = 0; i < n2D.size(); ++i) { twoD[i] = cur; cur += 2 * (size_t)n2D[i] * nPixelSamples; }
+  LDShuffleScrambled2D(1, nPixelSamples, imageSamples, rng);
+  LDShuffleScrambled2D(1, nPixelSamples, lensSamples, rng);
+  LDShuffleScrambled1D(1, nPixelSamples, timeSamples, rng);
+  for (size_t i = 0; i < n1D.size(); ++i) LDShuffleScrambled1D(n1D[i], nPixelSamples, oneD[i], rng);
+  for (size_t i = 0; i < n2D.size(); ++i) LDShuffleScrambled2D(n2D[i], nPixelSamples, twoD[i], rng);
+  out.resize((size_t)nPixelSamples * nFloats);
+  for (int i = 0; i < nPixelSamples; ++i) {
+    float* s = &out[(size_t)i * nFloats];
+    s[0] = imageSamples[2 * i];
+    s[1] = imageSamples[2 * i + 1];
+    s[2] = lensSamples[2 * i];
+    s[3] = lensSamples[2 * i + 1];
+    s[4] = timeSamples[i];
+    int o = 5;
+    for (size_t j = 0; j < n1D.size(); ++j)
+      for (int k = 0; k < n1D[j]; ++k) s[o++] = oneD[j][n1D[j] * i + k];
+    for (size_t j = 0; j < n2D.size(); ++j)
+      for (int k = 0; k < 2 * n2D[j]; ++k) s[o++] = twoD[j][2 * n2D[j] * i + k];
+  }
+}
+
+// Counter-mode LD pixel sample: every block draws from its own keyed stream;
+// otherwise the same LDShuffleScrambled* code.
+static void LDPixelSampleCounter(int nPixelSamples, const std::vector<int>& n1D, const std::vector<int>& n2D,
+                                 uint64_t seed, uint64_t pixelIndex, std::vector<float>& out, int nFloats) {
+  std::vector<float> tmp;
+  out.resize((size_t)nPixelSamples * nFloats);
+  int block = 0;
+  auto run2D = [&](int ns, int dst) {
+    DartRandom rng(counter_key(seed, pixelIndex, (uint64_t)block++, 1));
+    tmp.resize(2 * (size_t)ns * nPixelSamples);
+    LDShuffleScrambled2D(ns, nPixelSamples, tmp.data(), rng);
+    for (int i = 0; i < nPixelSamples; ++i)
+      for (int k = 0; k < 2 * ns; ++k) out[(size_t)i * nFloats + dst + k] = tmp[2 * (size_t)ns * i + k];
+  };
+  auto run1D = [&](int ns, int dst) {
+    DartRandom rng(counter_key(seed, pixelIndex, (uint64_t)block++, 1));
+    tmp.resize((size_t)ns * nPixelSamples);
+    LDShuffleScrambled1D(ns, nPixelSamples, tmp.data(), rng);
+    for (int i = 0; i < nPixelSamples; ++i)
+      for (int k = 0; k < ns; ++k) out[(size_t)i * nFloats + dst + k] = tmp[(size_t)ns * i + k];
+  };
+  run2D(1, 0);
+  run2D(1, 2);
+  run1D(1, 4);
+  int o = 5;
+  for (size_t j = 0; j < n1D.size(); ++j) { run1D(n1D[j], o); o += n1D[j]; }
+  for (size_t j = 0; j < n2D.size(); ++j) { run2D(n2D[j], o); o += 2 * n2D[j]; }
+}
+
+}  // namespace
+
+// ===========================================================================
+// C API (ctypes)
+// ===========================================================================
+extern "C" {
+
+struct OrcMesh {
+  const float* P;        // nverts*3 world-space f32
+  const uint32_t* idx;   // ntris*3
+  int32_t nverts, ntris;
+  float Kd[3];
+  float sigma;
+  int32_t reverse_orientation;
+  int32_t has_light;
+  float L[3];
+  int32_t light_nsamples;
+};
+struct OrcSceneDesc {
+  int32_t nmeshes;
+  const OrcMesh* meshes;
+  int32_t max_prims_in_node;  // "maxnodeprims", default 4
+};
+struct OrcNode {  // the 32-byte marshalled node of SURVEY.md Appendix F
+  float bmin[3], bmax[3];
+  uint32_t offset;
+  uint16_t nprims;
+  uint8_t axis, pad;
+};
+struct OrcRay {
+  float o[3], d[3];
+  double tmin, tmax;
+};
+struct OrcHit {
+  int32_t prim;  // index in BVH primitive order, -1 = miss
+  int32_t pad;
+  double t, b1, b2;
+};
+struct OrcRenderDesc {
+  int32_t xres, yres;
+  float crop[4];
+  float filter_xw, filter_yw;
+  float filter_table[256];
+  float raster_to_camera[16], camera_to_world[16];
+  float lens_radius, focal_distance, shutter_open, shutter_close;
+  int32_t integrator;  // 0 direct(all), 1 path
+  int32_t max_depth;
+  int32_t spp;
+  int32_t sampler_mode;  // 0 = serial (reference: one DartRandom(taskNum) per task), 1 = counter (keyed streams)
+  int64_t seed;          // counter mode
+  int32_t task_num, task_count;
+  // Optional explicit pixel list (counter mode only); when npixels == 0 the whole sampler window is rendered in
+  // linear pixel order (linear_pixel_sampler.dart:29-40).
+  int32_t npixels;
+  const int32_t* pixels;  // npixels * 2 raster pixels (x, y)
+};
+struct OrcRecord {  // optional per-sample recording (all host arrays sized by the caller)
+  int64_t capacity;       // max samples
+  int64_t count;          // out
+  int32_t nfloats;        // out: floats per sample vector
+  int32_t max_tail;       // in: tail doubles reserved per sample
+  int32_t* pixel_xy;      // [capacity*2]
+  float* sample_vec;      // [capacity*nfloats_cap]
+  int32_t nfloats_cap;    // in
+  double* tail;           // [capacity*max_tail]
+  int32_t* tail_count;    // [capacity]
+  float* Ls;              // [capacity*3] radiance after the NaN/neg/inf guards
+};
+struct OrcCounters {
+  uint64_t closest_rays, any_rays, closest_nodes, any_nodes, closest_tris, any_tris, light_tris, camera_samples;
+};
+
+const char* orc_version() { return "dartray-oracle 1 (CPU restatement; parity unpinned)"; }
+
+void* orc_scene_create(const OrcSceneDesc* d) {
+  Scene* sc = new Scene();
+  sc->maxPrimsInNode = std::min(255, d->max_prims_in_node > 0 ? d->max_prims_in_node : 4);
+  // DartRay.shape: one GeometricPrimitive per mesh, one DiffuseAreaLight per emissive shape (dartray.dart:380-401).
+  // Primitive.fullyRefine / ShapeSet pop a LIFO stack => triangle order within a mesh is reversed
+  // (primitive.dart:71-84; shape_set.dart:25-35).
+  for (int m = 0; m < d->nmeshes; ++m) {
+    const OrcMesh& om = d->meshes[m];
+    uint32_t base = (uint32_t)(sc->P.size() / 3);
+    sc->P.insert(sc->P.end(), om.P, om.P + 3 * (size_t)om.nverts);
+    Mesh me;
+    me.Kd = rgb(om.Kd[0], om.Kd[1], om.Kd[2]);
+    me.sigma = om.sigma;
+    me.reverse = om.reverse_orientation != 0;
+    me.light = -1;
+    if (om.has_light) {
+      Light L;
+      L.Lemit = rgb(om.L[0], om.L[1], om.L[2]);
+      L.nSamples = std::max(1, om.light_nsamples);
+      L.area = 0.0;
+      for (int t = om.ntris - 1; t >= 0; --t) {
+        LightTri lt;
+        for (int k = 0; k < 3; ++k) lt.v[k] = base + om.idx[3 * t + k];
+        lt.reverse = me.reverse;
+        L.shapes.push_back((int)sc->lightTris.size());
+        sc->lightTris.push_back(lt);
+      }
+      // Areas need vertex data which is complete for this mesh now.
+      for (size_t i = 0; i < L.shapes.size(); ++i) {
+        const LightTri& lt = sc->lightTris[L.shapes[i]];
+        D a = tri_area(sc->vert(lt.v[0]), sc->vert(lt.v[1]), sc->vert(lt.v[2]));
+        L.areas.push_back(a);
+        L.area += a;
+      }
+      L.areaDistribution.init(L.areas);
+      me.light = (int)sc->lights.size();
+      sc->lights.push_back(L);
+    }
+    sc->meshes.push_back(me);
+    for (int t = om.ntris - 1; t >= 0; --t) {
+      Prim p;
+      for (int k = 0; k < 3; ++k) p.v[k] = base + om.idx[3 * t + k];
+      p.mesh = m;
+      p.src_tri = t;
+      sc->prims.push_back(p);
+    }
+  }
+  Builder b;
+  b.sc = sc;
+  b.maxPrimsInNode = sc->maxPrimsInNode;
+  b.build();
+  return sc;
+}
+void orc_scene_destroy(void* h) { delete (Scene*)h; }
+void orc_scene_info(void* h, int64_t out[6]) {
+  Scene* sc = (Scene*)h;
+  out[0] = (int64_t)sc->nodes.size();
+  out[1] = (int64_t)sc->prims.size();
+  out[2] = sc->bvhDepth;
+  out[3] = (int64_t)sc->lights.size();
+  out[4] = (int64_t)sc->P.size() / 3;
+  out[5] = (int64_t)sc->lightTris.size();
+}
+// Flattened scene exactly as a Dart-side shim would marshal it.
+void orc_scene_get_bvh(void* h, OrcNode* nodes, uint32_t* tri_idx, int32_t* prim_mesh, int32_t* prim_src_tri) {
+  Scene* sc = (Scene*)h;
+  for (size_t i = 0; i < sc->nodes.size(); ++i) {
+    const LinearNode& n = sc->nodes[i];
+    OrcNode& o = nodes[i];
+    o.bmin[0] = (float)n.bmin.x; o.bmin[1] = (float)n.bmin.y; o.bmin[2] = (float)n.bmin.z;
+    o.bmax[0] = (float)n.bmax.x; o.bmax[1] = (float)n.bmax.y; o.bmax[2] = (float)n.bmax.z;
+    o.offset = n.offset;
+    o.nprims = (uint16_t)n.nPrimitives;
+    o.axis = (uint8_t)n.axis;
+    o.pad = 0;
+  }
+  for (size_t i = 0; i < sc->prims.size(); ++i) {
+    if (tri_idx) for (int k = 0; k < 3; ++k) tri_idx[3 * i + k] = sc->prims[i].v[k];
+    if (prim_mesh) prim_mesh[i] = sc->prims[i].mesh;
+    if (prim_src_tri) prim_src_tri[i] = sc->prims[i].src_tri;
+  }
+}
+void orc_scene_get_verts(void* h, float* P) {
+  Scene* sc = (Scene*)h;
+  memcpy(P, sc->P.data(), sc->P.size() * sizeof(float));
+}
+void orc_counters(void* h, OrcCounters* out, int reset) {
+  Scene* sc = (Scene*)h;
+  if (out) {
+    out->closest_rays = sc->ctr.closest_rays; out->any_rays = sc->ctr.any_rays;
+    out->closest_nodes = sc->ctr.closest_nodes; out->any_nodes = sc->ctr.any_nodes;
+    out->closest_tris = sc->ctr.closest_tris; out->any_tris = sc->ctr.any_tris;
+    out->light_tris = sc->ctr.light_tris; out->camera_samples = sc->ctr.camera_samples;
+  }
+  if (reset) sc->ctr = Counters();
+}
+
+static Ray to_ray(const OrcRay& r) {
+  Ray q;
+  q.o = V{(D)r.o[0], (D)r.o[1], (D)r.o[2]};
+  q.d = V{(D)r.d[0], (D)r.d[1], (D)r.d[2]};
+  q.mint = r.tmin; q.maxt = r.tmax; q.time = 0.0; q.depth = 0;
+  return q;
+}
+// BVHAccel.intersect / intersectP on a batch of rays.
+void orc_intersect(void* h, const OrcRay* rays, int64_t n, OrcHit* out, int any_hit) {
+  Scene* sc = (Scene*)h;
+  for (int64_t i = 0; i < n; ++i) {
+    Ray r = to_ray(rays[i]);
+    OrcHit& o = out[i];
+    o.pad = 0;
+    if (any_hit) {
+      o.prim = bvh_intersectP(*sc, r) ? 0 : -1;
+      o.t = o.b1 = o.b2 = 0.0;
+    } else {
+      Isect is;
+      if (bvh_intersect(*sc, r, &is)) { o.prim = is.prim; o.t = is.t; o.b1 = is.b1; o.b2 = is.b2; }
+      else { o.prim = -1; o.t = o.b1 = o.b2 = 0.0; }
+    }
+  }
+}
+// Exhaustive per-primitive testing in primitive order (the AggregateTestRenderer recipe,
+// renderers/aggregate_test_renderer.dart:42-118): same tie rule as the BVH (later equal-t hit overwrites).
+void orc_intersect_brute(void* h, const OrcRay* rays, int64_t n, OrcHit* out, int any_hit) {
+  Scene* sc = (Scene*)h;
+  for (int64_t i = 0; i < n; ++i) {
+    Ray r = to_ray(rays[i]);
+    OrcHit& o = out[i];
+    o.prim = -1; o.pad = 0; o.t = o.b1 = o.b2 = 0.0;
+    for (size_t p = 0; p < sc->prims.size(); ++p) {
+      const Prim& pr = sc->prims[p];
+      V a = sc->vert(pr.v[0]), b = sc->vert(pr.v[1]), c = sc->vert(pr.v[2]);
+      if (any_hit) {
+        if (tri_intersectP(a, b, c, r)) { o.prim = 0; break; }
+      } else {
+        D t, e, b1, b2;
+        DG dg;
+        if (tri_intersect(a, b, c, sc->meshes[pr.mesh].reverse, r, &t, &e, &dg, &b1, &b2)) {
+          o.prim = (int)p; o.t = t; o.b1 = b1; o.b2 = b2;
+          r.maxt = t;
+        }
+      }
+    }
+  }
+}
+
+int orc_sample_floats(void* h, int integrator, int max_depth) {
+  Scene* sc = (Scene*)h;
+  IntegratorCfg cfg{integrator, max_depth};
+  std::vector<int> n1D, n2D;
+  sample_layout(*sc, cfg, &n1D, &n2D, true);
+  int n = 5;
+  for (int c : n1D) n += c;
+  for (int c : n2D) n += 2 * c;
+  return n;
+}
+
+// SamplerRenderer.Li for one camera sample (sampler_renderer.dart:67-98 + :165-193).
+static S li_one(const Scene& sc, const IntegratorCfg& cfg, const Camera& cam, const std::vector<int>& n1D,
+                const std::vector<int>& n2D, int px, int py, const float* sv, LiRng& rng, D shutterOpen,
+                D shutterClose, D* imageX, D* imageY) {
+  sc.ctr.camera_samples++;
+  *imageX = (D)px + (D)sv[0];   // montecarlo.dart:451-452
+  *imageY = (D)py + (D)sv[1];
+  D time = shutterOpen * (1.0 - (D)sv[4]) + shutterClose * (D)sv[4];  // Lerp common.dart:80-81
+  Ray ray = generateRay(cam, *imageX, *imageY, sv[2], sv[3], time);
+  D rayWeight = 1.0;
+  Isect isect;
+  S Li;
+  SampleView view{sv, (int)0};
+  int c1 = 0;
+  for (int c : n1D) c1 += c;
+  view.n1D = c1;
+  if (bvh_intersect(sc, ray, &isect)) {
+    if (cfg.kind == 1) Li = PathLi(sc, cfg, ray, isect, view, rng);
+    else Li = DirectLi(sc, cfg, ray, isect, view, n1D, n2D, rng);
+  } else {
+    Li = S{0, 0, 0};  // sum of light.Le(ray) == 0 for area lights
+  }
+  // T * Li + Lvi with T = 1, Lvi = 0 (emission_integrator.dart:39-42), then * rayWeight.
+  S Ls = smulD(sadd(smul(S{1, 1, 1}, Li), S{0, 0, 0}), rayWeight);
+  if (snan(Ls)) Ls = S{0, 0, 0};                       // sampler_renderer.dart:181-193
+  else if (slum(Ls) < -1e-5) Ls = S{0, 0, 0};
+  else if (std::isinf(slum(Ls))) Ls = S{0, 0, 0};
+  return Ls;
+}
+
+static void setup_render(const Scene& sc, const OrcRenderDesc* rd, IntegratorCfg* cfg, Camera* cam, Film* film,
+                         std::vector<int>* n1D, std::vector<int>* n2D, int* nFloats, int win[4], int full[4] = nullptr) {
+  cfg->kind = rd->integrator;
+  cfg->maxDepth = rd->max_depth;
+  memcpy(cam->r2c, rd->raster_to_camera, sizeof(cam->r2c));
+  memcpy(cam->c2w, rd->camera_to_world, sizeof(cam->c2w));
+  cam->lensRadius = rd->lens_radius;
+  cam->focalDistance = rd->focal_distance;
+  film->init(rd->xres, rd->yres, rd->crop, rd->filter_xw, rd->filter_yw, rd->filter_table);
+  sample_layout(sc, *cfg, n1D, n2D, true);
+  *nFloats = 5;
+  for (int c : *n1D) *nFloats += c;
+  for (int c : *n2D) *nFloats += 2 * c;
+  // DartRay._makeSampler (dartray.dart:1009-1023)
+  int extent[4];
+  film->getSampleExtent(extent);
+  int w = extent[1] - extent[0], h = extent[3] - extent[2];
+  if (full) { full[0] = extent[0]; full[1] = extent[2]; full[2] = w; full[3] = h; }
+  // NB GetSubWindow computes from 0 and ignores the window origin (common.dart:69-72): only right for
+  // un-cropped films, which is what every parity run uses.
+  GetSubWindow(w, h, rd->task_num, std::max(1, rd->task_count), extent);
+  win[0] = extent[0]; win[1] = extent[2]; win[2] = extent[1] - extent[0]; win[3] = extent[3] - extent[2];
+}
+
+// SamplerRenderer.render (sampler_renderer.dart:36-65,118-218).
+// out_rgb: [height*width*3] (OutputImage.rgb); out_film: [height*width*4] (X,Y,Z,weight) or null.
+int orc_render(void* h, const OrcRenderDesc* rd, float* out_rgb, float* out_film, OrcRecord* rec) {
+  Scene* sc = (Scene*)h;
+  IntegratorCfg cfg;
+  Camera cam;
+  Film film;
+  std::vector<int> n1D, n2D;
+  int nFloats, win[4], full[4];
+  setup_render(*sc, rd, &cfg, &cam, &film, &n1D, &n2D, &nFloats, win, full);
+  int spp = rd->spp;
+  if ((spp & (spp - 1)) != 0) return -2;  // LowDiscrepancySampler rounds up; callers pass powers of two
+  if (rec) { rec->count = 0; rec->nfloats = nFloats; if (rec->nfloats_cap < nFloats) return -3; }
+  DartRandom rng((int64_t)rd->task_num);  // sampler_renderer.dart:137
+  std::vector<float> buffer, samples;
+  std::vector<D> tailRec;
+  int64_t npix = rd->npixels > 0 ? rd->npixels : (int64_t)win[2] * win[3];
+  if (rd->npixels > 0 && rd->sampler_mode == 0) return -4;
+  std::vector<S> Ls(spp);
+  std::vector<D> ix(spp), iy(spp);
+  for (int64_t pi = 0; pi < npix; ++pi) {
+    int px, py;  // raster pixel
+    if (rd->npixels > 0) { px = rd->pixels[2 * pi]; py = rd->pixels[2 * pi + 1]; }
+    else { px = win[0] + (int)(pi % win[2]); py = win[1] + (int)(pi / win[2]); }
+    // counter streams are keyed by the pixel's position in the FULL sampler extent, so that any task /
+    // tile split traces identical samples
+    uint64_t pixelIndex = (uint64_t)(py - full[1]) * (uint64_t)full[2] + (uint64_t)(px - full[0]);
+    if (rd->sampler_mode == 0) LDPixelSample(spp, n1D, n2D, buffer, rng, samples, nFloats);
+    else LDPixelSampleCounter(spp, n1D, n2D, (uint64_t)rd->seed, pixelIndex, samples, nFloats);
+    for (int i = 0; i < spp; ++i) {
+      LiRng lr;
+      DartRandom crng(0);
+      if (rd->sampler_mode == 0) lr.rng = &rng;
+      else { crng.reseed(counter_key((uint64_t)rd->seed, pixelIndex, (uint64_t)i, 2)); lr.rng = &crng; }
+      tailRec.clear();
+      if (rec) lr.record = &tailRec;
+      const float* sv = &samples[(size_t)i * nFloats];
+      Ls[i] = li_one(*sc, cfg, cam, n1D, n2D, px, py, sv, lr, rd->shutter_open, rd->shutter_close, &ix[i], &iy[i]);
+      if (rec && rec->count < rec->capacity) {
+        int64_t k = rec->count++;
+        if (rec->pixel_xy) { rec->pixel_xy[2 * k] = px; rec->pixel_xy[2 * k + 1] = py; }
+        if (rec->sample_vec) memcpy(rec->sample_vec + k * rec->nfloats_cap, sv, sizeof(float) * nFloats);
+        int nt = std::min((int)tailRec.size(), rec->max_tail);
+        if (rec->tail) for (int t = 0; t < nt; ++t) rec->tail[k * rec->max_tail + t] = tailRec[t];
+        if (rec->tail_count) rec->tail_count[k] = (int)tailRec.size();
+        if (rec->Ls) { rec->Ls[3 * k] = (float)Ls[i].r; rec->Ls[3 * k + 1] = (float)Ls[i].g; rec->Ls[3 * k + 2] = (float)Ls[i].b; }
+      }
+    }
+    for (int i = 0; i < spp; ++i) film.addSample(ix[i], iy[i], Ls[i]);  // sampler_renderer.dart:199-203
+  }
+  if (out_film) {
+    for (size_t p = 0; p < film.weightSum.size(); ++p) {
+      out_film[4 * p] = film.Lxyz[3 * p]; out_film[4 * p + 1] = film.Lxyz[3 * p + 1];
+      out_film[4 * p + 2] = film.Lxyz[3 * p + 2]; out_film[4 * p + 3] = film.weightSum[p];
+    }
+  }
+  if (out_rgb) {
+    for (size_t p = 0; p < film.weightSum.size(); ++p)
+      write_pixel(film.Lxyz[3 * p], film.Lxyz[3 * p + 1], film.Lxyz[3 * p + 2], film.weightSum[p], out_rgb + 3 * p);
+  }
+  return 0;
+}
+
+// Replay: radiance of explicit camera samples (sample vectors + recorded in-Li draws).  This is the
+// host-buffer protocol of the GPU path.
+int orc_li_samples(void* h, const OrcRenderDesc* rd, int64_t n, const int32_t* pixel_xy, const float* sample_vec,
+                   int32_t nfloats_stride, const double* tail, const int32_t* tail_count, int32_t max_tail,
+                   float* out_Ls) {
+  Scene* sc = (Scene*)h;
+  IntegratorCfg cfg;
+  Camera cam;
+  Film film;
+  std::vector<int> n1D, n2D;
+  int nFloats, win[4];
+  setup_render(*sc, rd, &cfg, &cam, &film, &n1D, &n2D, &nFloats, win);
+  if (nfloats_stride < nFloats) return -3;
+  int rc = 0;
+  for (int64_t k = 0; k < n; ++k) {
+    LiRng lr;
+    lr.replay = tail ? tail + k * max_tail : nullptr;
+    lr.replayN = tail_count ? std::min(tail_count[k], max_tail) : (tail ? max_tail : 0);
+    static const D kNoTail = 0.0;
+    if (!lr.replay) { lr.replay = &kNoTail; lr.replayN = 0; }
+    D ix, iy;
+    S Ls = li_one(*sc, cfg, cam, n1D, n2D, pixel_xy[2 * k], pixel_xy[2 * k + 1], sample_vec + k * nfloats_stride, lr,
+                  rd->shutter_open, rd->shutter_close, &ix, &iy);
+    if (lr.underflow && cfg.kind == 1) rc = 1;
+    out_Ls[3 * k] = (float)Ls.r; out_Ls[3 * k + 1] = (float)Ls.g; out_Ls[3 * k + 2] = (float)Ls.b;
+  }
+  return rc;
+}
+
+// Film-only helpers: addSample in order, then writeImage (image_film.dart:99-185,268-299).
+int orc_film_accumulate(const OrcRenderDesc* rd, int64_t n, const double* imageXY, const float* Ls, float* out_film,
+                        float* out_rgb) {
+  Film film;
+  film.init(rd->xres, rd->yres, rd->crop, rd->filter_xw, rd->filter_yw, rd->filter_table);
+  for (int64_t k = 0; k < n; ++k) film.addSample(imageXY[2 * k], imageXY[2 * k + 1], S{Ls[3 * k], Ls[3 * k + 1], Ls[3 * k + 2]});
+  for (size_t p = 0; p < film.weightSum.size(); ++p) {
+    if (out_film) {
+      out_film[4 * p] = film.Lxyz[3 * p]; out_film[4 * p + 1] = film.Lxyz[3 * p + 1];
+      out_film[4 * p + 2] = film.Lxyz[3 * p + 2]; out_film[4 * p + 3] = film.weightSum[p];
+    }
+    if (out_rgb) write_pixel(film.Lxyz[3 * p], film.Lxyz[3 * p + 1], film.Lxyz[3 * p + 2], film.weightSum[p], out_rgb + 3 * p);
+  }
+  return 0;
+}
+// writeImage on an accumulated (X,Y,Z,w) film.
+void orc_film_resolve(const float* film, int64_t npix, float* out_rgb) {
+  for (int64_t p = 0; p < npix; ++p) write_pixel(film[4 * p], film[4 * p + 1], film[4 * p + 2], film[4 * p + 3], out_rgb + 3 * p);
+}
+
+// ---------------------------------------------------------------------------
+// Camera set-up helper (host logic; projective_camera.dart:34-53, perspective_camera.dart:46-49,
+// transform.dart:301-349, matrix4x4.dart:211-343).  Matrices are f32 stores of f64 expressions.
+// ---------------------------------------------------------------------------
+namespace {
+struct M4 { float m[16]; };
+static M4 m4identity() { M4 r; memset(r.m, 0, sizeof(r.m)); r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
+static M4 m4mul(const M4& a, const M4& b) {  // matrix4x4.dart:193-206
+  M4 r;
+  for (int i = 0, k = 0; i < 4; ++i, k += 4)
+    for (int j = 0; j < 4; ++j)
+      r.m[k + j] = (float)((D)a.m[k] * b.m[j] + (D)a.m[k + 1] * b.m[4 + j] + (D)a.m[k + 2] * b.m[8 + j] + (D)a.m[k + 3] * b.m[12 + j]);
+  return r;
+}
+static M4 m4inverse(const M4& in) {  // matrix4x4.dart:232-343 (cofactor expansion)
+  const float* d = in.m;
+  D n11 = d[0], n12 = d[4], n13 = d[8], n14 = d[12];
+  D n21 = d[1], n22 = d[5], n23 = d[9], n24 = d[13];
+  D n31 = d[2], n32 = d[6], n33 = d[10], n34 = d[14];
+  D n41 = d[3], n42 = d[7], n43 = d[11], n44 = d[15];
+  D det = (n14 * n23 * n32 * n41) - (n13 * n24 * n32 * n41) - (n14 * n22 * n33 * n41) + (n12 * n24 * n33 * n41) +
+          (n13 * n22 * n34 * n41) - (n12 * n23 * n34 * n41) - (n14 * n23 * n31 * n42) + (n13 * n24 * n31 * n42) +
+          (n14 * n21 * n33 * n42) - (n11 * n24 * n33 * n42) - (n13 * n21 * n34 * n42) + (n11 * n23 * n34 * n42) +
+          (n14 * n22 * n31 * n43) - (n12 * n24 * n31 * n43) - (n14 * n21 * n32 * n43) + (n11 * n24 * n32 * n43) +
+          (n12 * n21 * n34 * n43) - (n11 * n22 * n34 * n43) - (n13 * n22 * n31 * n44) + (n12 * n23 * n31 * n44) +
+          (n13 * n21 * n32 * n44) - (n11 * n23 * n32 * n44) - (n12 * n21 * n33 * n44) + (n11 * n22 * n33 * n44);
+  M4 r = in;
+  if (det == 0.0) return r;
+  D invDet = 1.0 / det;
+  r.m[0] = (float)((n23 * n34 * n42 - n24 * n33 * n42 + n24 * n32 * n43 - n22 * n34 * n43 - n23 * n32 * n44 + n22 * n33 * n44) * invDet);
+  r.m[4] = (float)((n14 * n33 * n42 - n13 * n34 * n42 - n14 * n32 * n43 + n12 * n34 * n43 + n13 * n32 * n44 - n12 * n33 * n44) * invDet);
+  r.m[8] = (float)((n13 * n24 * n42 - n14 * n23 * n42 + n14 * n22 * n43 - n12 * n24 * n43 - n13 * n22 * n44 + n12 * n23 * n44) * invDet);
+  r.m[12] = (float)((n14 * n23 * n32 - n13 * n24 * n32 - n14 * n22 * n33 + n12 * n24 * n33 + n13 * n22 * n34 - n12 * n23 * n34) * invDet);
+  r.m[1] = (float)((n24 * n33 * n41 - n23 * n34 * n41 - n24 * n31 * n43 + n21 * n34 * n43 + n23 * n31 * n44 - n21 * n33 * n44) * invDet);
+  r.m[5] = (float)((n13 * n34 * n41 - n14 * n33 * n41 + n14 * n31 * n43 - n11 * n34 * n43 - n13 * n31 * n44 + n11 * n33 * n44) * invDet);
+  r.m[9] = (float)((n14 * n23 * n41 - n13 * n24 * n41 - n14 * n21 * n43 + n11 * n24 * n43 + n13 * n21 * n44 - n11 * n23 * n44) * invDet);
+  r.m[13] = (float)((n13 * n24 * n31 - n14 * n23 * n31 + n14 * n21 * n33 - n11 * n24 * n33 - n13 * n21 * n34 + n11 * n23 * n34) * invDet);
+  r.m[2] = (float)((n22 * n34 * n41 - n24 * n32 * n41 + n24 * n31 * n42 - n21 * n34 * n42 - n22 * n31 * n44 + n21 * n32 * n44) * invDet);
+  r.m[6] = (float)((n14 * n32 * n41 - n12 * n34 * n41 - n14 * n31 * n42 + n11 * n34 * n42 + n12 * n31 * n44 - n11 * n32 * n44) * invDet);
+  r.m[10] = (float)((n12 * n24 * n41 - n14 * n22 * n41 + n14 * n21 * n42 - n11 * n24 * n42 - n12 * n21 * n44 + n11 * n22 * n44) * invDet);
+  r.m[14] = (float)((n14 * n22 * n31 - n12 * n24 * n31 - n14 * n21 * n32 + n11 * n24 * n32 + n12 * n21 * n34 - n11 * n22 * n34) * invDet);
+  r.m[3] = (float)((n23 * n32 * n41 - n22 * n33 * n41 - n23 * n31 * n42 + n21 * n33 * n42 + n22 * n31 * n43 - n21 * n32 * n43) * invDet);
+  r.m[7] = (float)((n12 * n33 * n41 - n13 * n32 * n41 + n13 * n31 * n42 - n11 * n33 * n42 - n12 * n31 * n43 + n11 * n32 * n43) * invDet);
+  r.m[11] = (float)((n13 * n22 * n41 - n12 * n23 * n41 - n13 * n21 * n42 + n11 * n23 * n42 + n12 * n21 * n43 - n11 * n22 * n43) * invDet);
+  r.m[15] = (float)((n12 * n23 * n31 - n13 * n22 * n31 + n13 * n21 * n32 - n11 * n23 * n32 - n12 * n21 * n33 + n11 * n22 * n33) * invDet);
+  return r;
+}
+struct Xf { M4 m, mInv; };
+static Xf xfmul(const Xf& a, const Xf& b) { return Xf{m4mul(a.m, b.m), m4mul(b.mInv, a.mInv)}; }  // transform.dart:83-86
+static Xf xfinv(const Xf& a) { return Xf{a.mInv, a.m}; }
+static Xf xfscale(D x, D y, D z) {  // transform.dart:226-239
+  Xf r{m4identity(), m4identity()};
+  r.m.m[0] = (float)x; r.m.m[5] = (float)y; r.m.m[10] = (float)z;
+  r.mInv.m[0] = (float)(1.0 / x); r.mInv.m[5] = (float)(1.0 / y); r.mInv.m[10] = (float)(1.0 / z);
+  return r;
+}
+static Xf xftranslate(D x, D y, D z) {  // transform.dart:210-224 (delta is a Vector: f32 components)
+  Xf r{m4identity(), m4identity()};
+  D dx = r32(x), dy = r32(y), dz = r32(z);
+  r.m.m[3] = (float)dx; r.m.m[7] = (float)dy; r.m.m[11] = (float)dz;
+  r.mInv.m[3] = (float)-dx; r.mInv.m[7] = (float)-dy; r.mInv.m[11] = (float)-dz;
+  return r;
+}
+}  // namespace
+
+// LookAt + perspective camera -> rasterToCamera, cameraToWorld.
+void orc_camera_setup(const float pos[3], const float look[3], const float up[3], float fov, int xres, int yres,
+                      float r2c[16], float c2w[16]) {
+  // Transform.LookAt (transform.dart:301-329): returns worldToCamera = Transform(Inverse(m), m); the camera uses
+  // its inverse (cameraToWorld = m) (dartray.dart camera directive).
+  V p = vec(pos[0], pos[1], pos[2]), l = vec(look[0], look[1], look[2]), u = vec(up[0], up[1], up[2]);
+  M4 m = m4identity();
+  m.m[3] = (float)p.x; m.m[7] = (float)p.y; m.m[11] = (float)p.z; m.m[15] = 1.0f;
+  V dir = vnormalize(vsub(l, p));
+  V left = vnormalize(vcross(vnormalize(u), dir));
+  V newUp = vcross(dir, left);
+  m.m[0] = (float)left.x; m.m[4] = (float)left.y; m.m[8] = (float)left.z; m.m[12] = 0.0f;
+  m.m[1] = (float)newUp.x; m.m[5] = (float)newUp.y; m.m[9] = (float)newUp.z; m.m[13] = 0.0f;
+  m.m[2] = (float)dir.x; m.m[6] = (float)dir.y; m.m[10] = (float)dir.z; m.m[14] = 0.0f;
+  memcpy(c2w, m.m, sizeof(m.m));
+  // Transform.Perspective(fov, 1e-2, 1000) (transform.dart:338-349)
+  D znear = 1.0e-2, zfar = 1000.0;
+  M4 persp = m4identity();
+  persp.m[10] = (float)(zfar / (zfar - znear));
+  persp.m[11] = (float)(-zfar * znear / (zfar - znear));
+  persp.m[14] = 1.0f;
+  persp.m[15] = 0.0f;
+  D invTanAng = 1.0 / std::tan(((kPi / 180.0) * (D)fov) / 2.0);
+  Xf cameraToScreen = xfmul(xfscale(invTanAng, invTanAng, 1.0), Xf{persp, m4inverse(persp)});
+  // screen window (perspective_camera.dart:152-168)
+  D frame = (D)xres / (D)yres;
+  D screen[4];
+  if (frame > 1.0) { screen[0] = -frame; screen[1] = frame; screen[2] = -1.0; screen[3] = 1.0; }
+  else { screen[0] = -1.0; screen[1] = 1.0; screen[2] = -1.0 / frame; screen[3] = 1.0 / frame; }
+  // projective_camera.dart:39-52
+  Xf screenToRaster = xfmul(xfmul(xfscale((D)xres, (D)yres, 1.0),
+                                  xfscale(1.0 / (screen[1] - screen[0]), 1.0 / (screen[2] - screen[3]), 1.0)),
+                            xftranslate(-screen[0], -screen[3], 0.0));
+  Xf rasterToScreen = xfinv(screenToRaster);
+  Xf rasterToCamera = xfmul(xfinv(cameraToScreen), rasterToScreen);
+  memcpy(r2c, rasterToCamera.m.m, sizeof(float) * 16);
+}
+
+// ---------------------------------------------------------------------------
+// KAT entry points
+// ---------------------------------------------------------------------------
+double orc_van_der_corput(uint32_t n, uint32_t scramble) { return VanDerCorput(n, scramble); }
+double orc_sobol2(uint32_t n, uint32_t scramble) { return Sobol2(n, scramble); }
+void orc_concentric_sample_disk(double u1, double u2, double* dx, double* dy) { ConcentricSampleDisk(u1, u2, dx, dy); }
+void orc_cosine_sample_hemisphere(double u1, double u2, double out[3]) {
+  V v = CosineSampleHemisphere(u1, u2);
+  out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
+double orc_power_heuristic(int nf, double f, int ng, double g) { return PowerHeuristic(nf, f, ng, g); }
+void orc_get_sub_window(int w, int h, int num, int count, int32_t ext[4]) {
+  int e[4];
+  GetSubWindow(w, h, num, count, e);
+  for (int i = 0; i < 4; ++i) ext[i] = e[i];
+}
+void orc_distribution1d(const double* f, int n, float* cdf_out, double* funcInt, const double* u, int nu, int32_t* idx_out) {
+  Distribution1D d;
+  d.init(std::vector<D>(f, f + n));
+  for (int i = 0; i <= n; ++i) cdf_out[i] = d.cdf[i];
+  *funcInt = d.funcInt;
+  for (int i = 0; i < nu; ++i) idx_out[i] = d.sampleDiscrete(u[i]);
+}
+void orc_dart_random(int64_t seed, int n, uint32_t* uints, double* floats) {
+  DartRandom a(seed), b(seed);
+  for (int i = 0; i < n; ++i) { if (uints) uints[i] = a.randomUint(); if (floats) floats[i] = b.randomFloat(); }
+}
+int64_t orc_counter_key(uint64_t seed, uint64_t a, uint64_t b, uint64_t kind) { return counter_key(seed, a, b, kind); }
+// One pixel of the LD sampler: mode 0 = serial stream from DartRandom(seed); mode 1 = counter streams.
+void orc_ld_pixel_sample(int mode, int64_t seed, uint64_t pixel_index, int spp, const int32_t* n1D, int c1, const int32_t* n2D,
+                         int c2, float* out) {
+  std::vector<int> a(n1D, n1D + c1), b(n2D, n2D + c2);
+  int nFloats = 5;
+  for (int c : a) nFloats += c;
+  for (int c : b) nFloats += 2 * c;
+  std::vector<float> buf, res;
+  if (mode == 0) { DartRandom rng(seed); LDPixelSample(spp, a, b, buf, rng, res, nFloats); }
+  else LDPixelSampleCounter(spp, a, b, (uint64_t)seed, pixel_index, res, nFloats);
+  memcpy(out, res.data(), res.size() * sizeof(float));
+}
+// Single-triangle tests (KATs): returns hit flag; out = {t, b1, b2, p.xyz, nn.xyz}.
+int orc_triangle_intersect(const float tri[9], const OrcRay* ray, int reverse, double out[9]) {
+  Ray r = to_ray(*ray);
+  V a{tri[0], tri[1], tri[2]}, b{tri[3], tri[4], tri[5]}, c{tri[6], tri[7], tri[8]};
+  D t, e, b1, b2;
+  DG dg;
+  if (!tri_intersect(a, b, c, reverse != 0, r, &t, &e, &dg, &b1, &b2)) return 0;
+  out[0] = t; out[1] = b1; out[2] = b2;
+  out[3] = dg.p.x; out[4] = dg.p.y; out[5] = dg.p.z;
+  out[6] = dg.nn.x; out[7] = dg.nn.y; out[8] = dg.nn.z;
+  return 1;
+}
+int orc_triangle_intersectP(const float tri[9], const OrcRay* ray) {
+  Ray r = to_ray(*ray);
+  V a{tri[0], tri[1], tri[2]}, b{tri[3], tri[4], tri[5]}, c{tri[6], tri[7], tri[8]};
+  return tri_intersectP(a, b, c, r) ? 1 : 0;
+}
+// Slab test of one box (bvh_accel.dart:439-472).
+int orc_slab(const float bmin[3], const float bmax[3], const OrcRay* ray) {
+  Ray r = to_ray(*ray);
+  LinearNode n;
+  n.bmin = V{bmin[0], bmin[1], bmin[2]};
+  n.bmax = V{bmax[0], bmax[1], bmax[2]};
+  V invDir = vec(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+  int neg[3] = {invDir.x < 0 ? 1 : 0, invDir.y < 0 ? 1 : 0, invDir.z < 0 ? 1 : 0};
+  return slab(n, r, invDir, neg) ? 1 : 0;
+}
+
+}  // extern "C"
