@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its named config.
+
+    python bench.py --gpus N --steps K --warmup W
+
+metric  : Msamples/s (primary + path rays), film pixels x spp per second, whole job over N GPUs
+workload: configs[1] -- Cornell box + 1M-triangle displaced blob, PathIntegrator maxdepth 5,
+          1024x1024, 256 spp (2.68e8 camera samples per step).  One "step" = one full render of
+          that image.  At N > 1 the SAME image is sharded by 32x32 tiles over the ranks and the
+          film is reduced over RCCL: strong scaling.
+Inputs (scene, BVH) are resident in HBM before the timed region; samples are generated on the
+device.  Synthetic procedural scene, no files.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel k_trace<0> (closest-hit BVH
+traversal): algorithmic bytes (32 B per node visit + 48 B per triangle test, counted on the
+device) / the kernel's summed HIP-event time; "cpu_baseline": the CPU oracle (a C++ port of the
+reference path) timed on one host core on a strided 64x64-pixel subset of the same image.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C2", choices=["C2", "C4"])
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pixels", type=int, default=96, help="cpu baseline: side of the strided pixel grid")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from dartray_amd import _abi, scenes, dist as drdist
+
+    rank, world, local = drdist.init_process_group()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    _abi.init(local)
+
+    spp = args.spp or (256 if args.config == "C2" else 64)
+    prims, mk = scenes.config(args.config, xres=args.res, yres=args.res, spp=spp)
+    renderer = drdist.shard(mk(), rank, world)
+    scene = scenes.make_scene(prims)  # every rank builds + uploads its own copy (render_isolate.dart:31-41)
+    film_desc = renderer.camera.film
+    H, W = film_desc.height, film_desc.width
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    dev = scene._device()
+    lib = _abi.lib()
+
+    def step():
+        film.zero_()
+        renderer.render_device(scene, film.data_ptr(), stream)
+        drdist.reduce_film(film, 0)
+        if rank == 0:
+            _abi.check(lib.dr_film_resolve_device(film.data_ptr(), H * W, rgb.data_ptr(), stream))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dev.reset_stats()
+    drdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    drdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    st = dev.stats()
+
+    if rank == 0:
+        samples_per_step = H * W * spp
+        value = samples_per_step * args.steps / dt / 1e6
+        alg_bytes = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
+        launches = max(1, st["closest_launches"])
+        achieved = alg_bytes / max(st["closest_ms"] * 1e-3, 1e-12) / 1e9
+        peak = 8000.0  # HBM3E spec GB/s (MI355X_MICROARCH.md chip table)
+        all_alg = alg_bytes + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
+        out = {
+            "metric": "Msamples/sec (primary+path rays)",
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s: Cornell box + %s, PathIntegrator maxdepth=5, %dx%d, %d spp, LD sampler (device, counter streams), box filter"
+                       % (args.config, "1M-triangle displaced blob" if args.config == "C2" else "10M-triangle hairball", args.res, args.res, spp),
+                       "triangles": int(len(scene.aggregate.tri_idx)), "bvh_nodes": int(len(scene.aggregate.nodes)),
+                       "samples_per_step": samples_per_step, "parallelism": "tiles32x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_trace<0> (closest-hit BVH traversal)",
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
+                         "traffic": None,
+                         "alg_bytes_per_launch": round(alg_bytes / launches, 1),
+                         "avg_launch_ms": round(st["closest_ms"] / launches, 4), "launches": int(st["closest_launches"]),
+                         "rank0_job_alg_GBps": round(all_alg / dt / 1e9, 2),
+                         "rank0_trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt, 4)},
+            "per_sample": {"rays": round((st["closest_rays"] + st["any_rays"]) / max(1, st["camera_samples"]), 3),
+                           "nodes": round((st["closest_nodes"] + st["any_nodes"]) / max(1, st["camera_samples"]), 2),
+                           "tris": round((st["closest_tris"] + st["any_tris"]) / max(1, st["camera_samples"]), 3),
+                           "alg_bytes": round(all_alg / max(1, st["camera_samples"]) + 148 + 32, 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(prims, renderer, args.cpu_pixels, H, W, spp)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(prims, renderer, grid, H, W, spp):
+    """The oracle (C++ port of the reference CPU path, -O2, no fast-math) on ONE host core, on a
+    strided grid x grid pixel subset of the same image with the same per-pixel sample streams."""
+    import numpy as np
+    import oracle.binding as ob
+    osc = ob.OracleScene(prims)
+    ys = (np.arange(grid) * (H // grid) + (H // grid) // 2).astype(np.int32)
+    xs = (np.arange(grid) * (W // grid) + (W // grid) // 2).astype(np.int32)
+    px = np.stack(np.meshgrid(xs, ys), axis=-1).reshape(-1, 2)
+    rd = ob.render_desc(renderer, sampler_mode=1, pixels=px)
+    t0 = time.perf_counter()
+    osc.render(rd, want_film=False)
+    dt = time.perf_counter() - t0
+    n = len(px) * spp
+    return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%dx%d pixels on a stride-%d grid of the %dx%d image x %d spp = %d samples in %.1f s; "
+                      "C++ restatement of the Dart reference path (oracle/), single thread"
+                      % (grid, grid, H // grid, W, H, spp, n, dt),
+            "host_cores": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

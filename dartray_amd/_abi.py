@@ -80,7 +80,9 @@ class DrRenderStats(C.Structure):
                 ("closest_nodes", C.c_uint64), ("any_nodes", C.c_uint64),
                 ("closest_tris", C.c_uint64), ("any_tris", C.c_uint64),
                 ("trace_launches", C.c_uint64), ("trace_ms", C.c_double), ("total_ms", C.c_double),
-                ("batches", C.c_uint64)]
+                ("batches", C.c_uint64),
+                ("closest_launches", C.c_uint64), ("any_launches", C.c_uint64),
+                ("closest_ms", C.c_double), ("any_ms", C.c_double)]
 
 
 # name -> (restype, argtypes): every symbol include/dartray_hip.h declares.
@@ -95,7 +97,9 @@ EXPORTS = {
     "dr_render": (C.c_int, [C.c_void_p, C.POINTER(DrRenderDesc), C.c_void_p, C.c_void_p]),
     "dr_render_device": (C.c_int, [C.c_void_p, C.POINTER(DrRenderDesc), C.c_void_p, C.c_void_p]),
     "dr_film_resolve_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dr_enumerate_pixels": (C.c_int, [C.POINTER(DrRenderDesc), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "dr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(DrRenderStats)]),
+    "dr_reset_stats": (C.c_int, [C.c_void_p]),
     "dr_copy_bandwidth": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
     "dr_last_error": (C.c_char_p, []),
     "dr_version": (C.c_char_p, []),

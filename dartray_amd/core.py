@@ -290,6 +290,9 @@ class _DeviceScene:
         _abi.check(_abi.lib().dr_get_stats(self.handle, C.byref(s)))
         return {k: getattr(s, k) for k, _ in _abi.DrRenderStats._fields_}
 
+    def reset_stats(self):
+        _abi.check(_abi.lib().dr_reset_stats(self.handle))
+
 
 class Scene:
     """core/scene.dart:26-45."""
@@ -575,10 +578,29 @@ class SamplerRenderer:
         out_film = np.zeros((film.height, film.width, 4), dtype=np.float32)
         out_rgb = np.zeros((film.height, film.width, 3), dtype=np.float32)
         dev = scene._device()
+        dev.reset_stats()
         _abi.check(_abi.lib().dr_render(dev.handle, C.byref(d), out_film.ctypes.data, out_rgb.ctypes.data))
         del keep
         self.last_stats = dev.stats()
         return OutputImage(film.left, film.top, film.width, film.height, out_rgb, out_film)
+
+    def pixels(self):
+        """Raster pixels this renderer's task / tile share traces, in trace order (host-only)."""
+        d, keep = self.describe()
+        n = C.c_uint64(0)
+        _abi.check(_abi.lib().dr_enumerate_pixels(C.byref(d), None, 0, C.byref(n)))
+        out = np.zeros((n.value, 2), dtype=np.int32)
+        _abi.check(_abi.lib().dr_enumerate_pixels(C.byref(d), out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def render_device(self, scene, film_ptr, stream=0):
+        """Renderer.render with the film left in HBM: accumulates this renderer's share into the
+        [height, width, 4] f32 device buffer at `film_ptr` on HIP stream `stream` (asynchronous)."""
+        d, keep = self.describe()
+        dev = scene._device()
+        _abi.check(_abi.lib().dr_render_device(dev.handle, C.byref(d), film_ptr, stream))
+        self._keep = keep
+        return dev
 
     def Li(self, *a, **k):  # a per-ray FFI seam is far too fine grained (SURVEY.md section 8b)
         raise NotImplementedError("SamplerRenderer.Li is evaluated on the device inside render()")

@@ -82,11 +82,13 @@ struct DrScene {
   Workspace ws;
   // stats of the last render
   DrRenderStats stats;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> traceEvents;
+  struct TraceEv { hipEvent_t e0, e1; int any; };
+  std::vector<TraceEv> traceEvents;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> renderEvents;
   std::vector<hipEvent_t> eventPool;
   size_t eventsUsed = 0;
-  hipEvent_t evStart = nullptr, evStop = nullptr;
   bool statsPending = false;
+  hipEvent_t lastEvent = nullptr;
   hipEvent_t getEvent() {
     if (eventsUsed == eventPool.size()) {
       hipEvent_t e;
@@ -97,8 +99,6 @@ struct DrScene {
   }
   ~DrScene() {
     for (auto e : eventPool) (void)hipEventDestroy(e);
-    if (evStart) (void)hipEventDestroy(evStart);
-    if (evStop) (void)hipEventDestroy(evStop);
   }
 };
 
@@ -234,6 +234,33 @@ BatchState makeState(Workspace& w, const int2* pix, uint32_t nslots, bool useTai
   st.misPrim = w.misPrim.p;
   st.flags = w.flags.p;
   return st;
+}
+
+// Raster pixels one call traces in counter mode, in trace order.  task_*: the reference's
+// GetSubWindow rectangle; tile_*: tile_size^2 tiles dealt round-robin over ranks.  The dead
+// border row/column of the sampler window (W+1 x H+1 for the box filter, image_film.dart:247-252)
+// is traced as the reference does; a border sample only reaches the film when imageX/Y is integral.
+void enumeratePixels(const RenderParams& rp, const DrRenderDesc* rd, std::vector<int2>& pixels) {
+  int ext[4];
+  getSubWindow(rp.extW, rp.extH, rd->task_num, std::max(1, rd->task_count), ext);
+  const int ts = rd->tile_size > 0 ? rd->tile_size : 32;
+  const int ntx = (rp.extW + ts - 1) / ts;
+  const bool tiled = rd->tile_count > 1;
+  pixels.clear();
+  pixels.reserve((size_t)(ext[1] - ext[0]) * (ext[3] - ext[2]) / (tiled ? rd->tile_count : 1) + 1024);
+  if (!tiled) {  // LinearPixelSampler order (linear_pixel_sampler.dart:29-40)
+    for (int y = ext[2]; y < ext[3]; ++y)
+      for (int x = ext[0]; x < ext[1]; ++x) pixels.push_back(make_int2(rp.extX0 + x, rp.extY0 + y));
+  } else {  // tile-major so that a batch covers whole tiles (coherent camera rays)
+    const int nty = (rp.extH + ts - 1) / ts;
+    for (int ty = 0; ty < nty; ++ty)
+      for (int tx = 0; tx < ntx; ++tx) {
+        if ((ty * ntx + tx) % rd->tile_count != rd->tile_rank) continue;
+        for (int y = std::max(ty * ts, ext[2]); y < std::min((ty + 1) * ts, ext[3]); ++y)
+          for (int x = std::max(tx * ts, ext[0]); x < std::min((tx + 1) * ts, ext[1]); ++x)
+            pixels.push_back(make_int2(rp.extX0 + x, rp.extY0 + y));
+      }
+  }
 }
 
 }  // namespace
@@ -386,8 +413,6 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   sc->d.ntris = (uint32_t)desc->ntris;
   sc->d.nlights = desc->nlights;
   sc->d.nmats = desc->nmaterials;
-  TRY_SC(hipEventCreate(&sc->evStart));
-  TRY_SC(hipEventCreate(&sc->evStop));
   *out = sc;
   return DR_OK;
 #undef TRY_SC
@@ -418,10 +443,14 @@ int dr_intersect(DrScene* sc, const DrRay* rays, int64_t n, DrHit* out, int32_t 
   TraceCounters c;
   HIP_TRY(hipMemcpy(&c, sc->ctr.p, sizeof(c), hipMemcpyDeviceToHost));
   memset(&sc->stats, 0, sizeof(sc->stats));
+  sc->traceEvents.clear();
+  sc->renderEvents.clear();
+  sc->eventsUsed = 0;
   sc->stats.closest_rays = c.closest_rays; sc->stats.any_rays = c.any_rays;
   sc->stats.closest_nodes = c.closest_nodes; sc->stats.any_nodes = c.any_nodes;
   sc->stats.closest_tris = c.closest_tris; sc->stats.any_tris = c.any_tris;
   sc->statsPending = false;
+  HIP_TRY(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
   return DR_OK;
 }
 
@@ -476,40 +505,18 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     pixels.resize(np);
     for (int64_t i = 0; i < np; ++i) pixels[i] = make_int2(rd->pixel_xy[2 * i], rd->pixel_xy[2 * i + 1]);
   } else if (rd->sampler_mode == DR_SAMPLER_COUNTER) {
-    int ext[4];
-    getSubWindow(rp.extW, rp.extH, rd->task_num, std::max(1, rd->task_count), ext);
-    const int ts = rd->tile_size > 0 ? rd->tile_size : 32;
-    const int ntx = (rp.extW + ts - 1) / ts;
-    const bool tiled = rd->tile_count > 1;
-    // The dead border row/column of the sampler window (W+1 x H+1 for the box filter) is traced as the
-    // reference does; a border sample only reaches the film when imageX/Y is exactly integral.
-    pixels.reserve((size_t)(ext[1] - ext[0]) * (ext[3] - ext[2]) / (tiled ? rd->tile_count : 1) + 1024);
-    if (!tiled) {
-      for (int y = ext[2]; y < ext[3]; ++y)
-        for (int x = ext[0]; x < ext[1]; ++x) pixels.push_back(make_int2(rp.extX0 + x, rp.extY0 + y));
-    } else {
-      // tile-major so that a batch covers whole tiles (coherent camera rays)
-      const int nty = (rp.extH + ts - 1) / ts;
-      for (int ty = 0; ty < nty; ++ty)
-        for (int tx = 0; tx < ntx; ++tx) {
-          if ((ty * ntx + tx) % rd->tile_count != rd->tile_rank) continue;
-          for (int y = std::max(ty * ts, ext[2]); y < std::min((ty + 1) * ts, ext[3]); ++y)
-            for (int x = std::max(tx * ts, ext[0]); x < std::min((tx + 1) * ts, ext[1]); ++x)
-              pixels.push_back(make_int2(rp.extX0 + x, rp.extY0 + y));
-        }
-    }
+    enumeratePixels(rp, rd, pixels);
   } else {
     return fail(DR_ERR_INVALID, "unknown sampler mode");
   }
   const size_t npixTotal = pixels.size();
-  memset(&sc->stats, 0, sizeof(sc->stats));
-  sc->traceEvents.clear();
-  sc->eventsUsed = 0;
   sc->statsPending = true;
-  HIP_TRY(hipMemsetAsync(sc->ctr.p, 0, sizeof(TraceCounters), s));
-  HIP_TRY(hipEventRecord(sc->evStart, s));
+  hipEvent_t evStart = sc->getEvent(), evStop = sc->getEvent();
+  sc->renderEvents.push_back({evStart, evStop});
+  sc->lastEvent = evStop;
+  HIP_TRY(hipEventRecord(evStart, s));
   if (npixTotal == 0) {
-    HIP_TRY(hipEventRecord(sc->evStop, s));
+    HIP_TRY(hipEventRecord(evStop, s));
     return DR_OK;
   }
   uint64_t filmSamples = 0;
@@ -561,7 +568,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       (void)hipEventRecord(e0, s);
       launch_trace(sc->d, st, queue, nQ, any, w.spill.p, C + 512 + (wc++), sc->ctr.p, tgrid, s);
       (void)hipEventRecord(e1, s);
-      sc->traceEvents.push_back({e0, e1});
+      sc->traceEvents.push_back({e0, e1, any});
     };
     trace(nullptr, nullptr, 0);  // camera rays
     for (int b = 0; b < nStages; ++b) {
@@ -586,33 +593,72 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     sc->stats.batches++;
     if (hostBuf) HIP_TRY(hipStreamSynchronize(s));  // host buffers of the next batch reuse the staging area
   }
-  HIP_TRY(hipEventRecord(sc->evStop, s));
-  sc->stats.camera_samples = (uint64_t)npixTotal * spp;
-  sc->stats.film_samples = filmSamples;
+  HIP_TRY(hipEventRecord(evStop, s));
+  sc->stats.camera_samples += (uint64_t)npixTotal * spp;
+  sc->stats.film_samples += filmSamples;
+  return DR_OK;
+}
+
+int dr_enumerate_pixels(const DrRenderDesc* rd, int32_t* out_xy, uint64_t cap, uint64_t* n_out) {
+  if (!rd || !n_out) return fail(DR_ERR_INVALID, "null argument");
+  RenderParams rp;
+  memset(&rp, 0, sizeof(rp));
+  rp_film(rp, rd->film);
+  std::vector<int2> pixels;
+  enumeratePixels(rp, rd, pixels);
+  *n_out = pixels.size();
+  if (out_xy) {
+    if (cap < pixels.size()) return fail(DR_ERR_INVALID, "pixel buffer too small");
+    for (size_t i = 0; i < pixels.size(); ++i) {
+      out_xy[2 * i] = pixels[i].x;
+      out_xy[2 * i + 1] = pixels[i].y;
+    }
+  }
   return DR_OK;
 }
 
 int dr_get_stats(DrScene* sc, DrRenderStats* out) {
   if (!sc || !out) return fail(DR_ERR_INVALID, "null argument");
   if (sc->statsPending) {
-    HIP_TRY(hipEventSynchronize(sc->evStop));
+    if (sc->lastEvent) HIP_TRY(hipEventSynchronize(sc->lastEvent));
     TraceCounters c;
     HIP_TRY(hipMemcpy(&c, sc->ctr.p, sizeof(c), hipMemcpyDeviceToHost));
     sc->stats.closest_rays = c.closest_rays; sc->stats.any_rays = c.any_rays;
     sc->stats.closest_nodes = c.closest_nodes; sc->stats.any_nodes = c.any_nodes;
     sc->stats.closest_tris = c.closest_tris; sc->stats.any_tris = c.any_tris;
-    double ms = 0.0;
+    double msC = 0.0, msA = 0.0;
+    uint64_t nC = 0, nA = 0;
     for (auto& ev : sc->traceEvents) {
       float t = 0.f;
-      if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) ms += t;
+      if (hipEventElapsedTime(&t, ev.e0, ev.e1) != hipSuccess) continue;
+      if (ev.any) { msA += t; ++nA; } else { msC += t; ++nC; }
     }
-    sc->stats.trace_ms = ms;
-    sc->stats.trace_launches = sc->traceEvents.size();
-    float tot = 0.f;
-    if (hipEventElapsedTime(&tot, sc->evStart, sc->evStop) == hipSuccess) sc->stats.total_ms = tot;
+    sc->stats.closest_ms = msC; sc->stats.any_ms = msA;
+    sc->stats.closest_launches = nC; sc->stats.any_launches = nA;
+    sc->stats.trace_ms = msC + msA;
+    sc->stats.trace_launches = nC + nA;
+    double tot = 0.0;
+    for (auto& ev : sc->renderEvents) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) tot += t;
+    }
+    sc->stats.total_ms = tot;
     sc->statsPending = false;
   }
   *out = sc->stats;
+  return DR_OK;
+}
+
+int dr_reset_stats(DrScene* sc) {
+  if (!sc) return fail(DR_ERR_INVALID, "null argument");
+  if (sc->lastEvent) HIP_TRY(hipEventSynchronize(sc->lastEvent));
+  memset(&sc->stats, 0, sizeof(sc->stats));
+  sc->traceEvents.clear();
+  sc->renderEvents.clear();
+  sc->eventsUsed = 0;
+  sc->lastEvent = nullptr;
+  sc->statsPending = false;
+  HIP_TRY(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
   return DR_OK;
 }
 

@@ -157,17 +157,21 @@ typedef struct DrRenderDesc {
   int32_t max_tail;
 } DrRenderDesc;
 
-/* Counters and timings of the last dr_render* call on a scene. */
+/* Counters and timings accumulated over the dr_render* calls on a scene since
+ * the last dr_reset_stats (the "Stats" probes of lib/core/stats.dart that the
+ * hot loops call, e.g. bvh_accel.dart:106-163). */
 typedef struct DrRenderStats {
   uint64_t camera_samples; /* samples traced (incl. the sampler's dead border, image_film.dart:247-252) */
   uint64_t film_samples;   /* film pixels in this rank's window x spp: the throughput numerator */
   uint64_t closest_rays, any_rays;
   uint64_t closest_nodes, any_nodes; /* iterations of the loops at bvh_accel.dart:122 / :185 */
   uint64_t closest_tris, any_tris;   /* primitive tests at bvh_accel.dart:131 / :193 */
-  uint64_t trace_launches;           /* number of traversal-kernel launches */
+  uint64_t trace_launches;           /* number of traversal-kernel launches (closest + any) */
   double trace_ms;                   /* summed device time of the traversal launches (HIP events) */
-  double total_ms;                   /* device time of the whole render (HIP events) */
+  double total_ms;                   /* device time of the render calls (HIP events) */
   uint64_t batches;
+  uint64_t closest_launches, any_launches; /* per kernel: k_trace<0> (closest hit), k_trace<1> (any hit) */
+  double closest_ms, any_ms;
 } DrRenderStats;
 
 /* Select the GPU.  Must precede everything else. */
@@ -205,11 +209,17 @@ int dr_render(DrScene* scene, const DrRenderDesc* desc, float* film_out, float* 
  * by the multi-GPU path, which reduces film_dev over RCCL before resolving. */
 int dr_render_device(DrScene* scene, const DrRenderDesc* desc, void* film_dev, void* hip_stream);
 
+/* The raster pixels a DR_SAMPLER_COUNTER render of `desc` traces, in trace
+ * order (GetSubWindow rectangle, common.dart:52-73, intersected with this
+ * rank's round-robin tiles).  Host-only; out_xy may be NULL to query the count. */
+int dr_enumerate_pixels(const DrRenderDesc* desc, int32_t* out_xy, uint64_t cap, uint64_t* n_out);
+
 /* ImageFilm.writeImage on a device film: XYZ -> RGB, divide by weightSum. */
 int dr_film_resolve_device(const void* film_dev, int64_t npixels, void* rgb_dev, void* hip_stream);
 
-/* Stats of the last render on this scene (valid after the stream has been synchronised). */
+/* Accumulated stats of this scene (synchronises with the last render's stream work). */
 int dr_get_stats(DrScene* scene, DrRenderStats* out);
+int dr_reset_stats(DrScene* scene);
 
 /* Device float4 copy kernel: the measured HBM-bandwidth denominator. Returns GB/s. */
 int dr_copy_bandwidth(uint64_t bytes, int32_t iters, double* gbps_out);

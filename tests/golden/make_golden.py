@@ -1,0 +1,58 @@
+"""Generates the golden fixtures under tests/golden/ with the CPU oracle.
+
+The reference (Dart) cannot be executed here and ships no golden vectors of its own
+(test/spectrum_test.dart is an empty function), so these vectors pin the ORACLE: they guard
+the restatement against accidental change and are replayed against the HIP path on the GPU
+box.  Re-run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle.binding as ob  # noqa: E402
+from dartray_amd import scenes  # noqa: E402
+from util import aggregate_test_rays  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    # (1) C1 in the reference's own serial mode: one DartRandom(taskNum) through sampler and integrator.
+    prims, mk = scenes.config("C1")
+    r = mk()
+    osc = ob.OracleScene(prims)
+    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=65 * 65 * 4, max_tail=8)
+    np.savez_compressed(os.path.join(OUT, "c1_serial.npz"), rgb=rec["rgb"], film=rec["film"],
+                        pixel_xy=rec["pixel_xy"][::4].copy(), sample_vec=rec["sample_vec"], Ls=rec["Ls"],
+                        tail_count=rec["tail_count"])
+    # (2) hit records on a small C2-class scene
+    prims, mk = scenes.config("C2", xres=16, yres=16, spp=8, blob=(32, 16))
+    osc = ob.OracleScene(prims)
+    nodes, tri, _, _ = osc.bvh()
+    o, d, tmin, tmax = aggregate_test_rays(nodes[0]["bmin"], nodes[0]["bmax"], 4000, seed=11)
+    rays = ob.make_rays(o, d, tmin, tmax)
+    h = osc.intersect(rays)
+    hp = osc.intersect(rays, any_hit=True)
+    np.savez_compressed(os.path.join(OUT, "c2small_hits.npz"), o=o, d=d, tmin=tmin, tmax=tmax, prim=h["prim"], t=h["t"],
+                        b1=h["b1"], b2=h["b2"], occluded=(hp["prim"] >= 0), nodes=nodes, tri=tri)
+    # (3) the same scene path traced in serial mode, with the in-Li RNG draws recorded
+    r = mk()
+    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=17 * 17 * 8, max_tail=40)
+    np.savez_compressed(os.path.join(OUT, "c2small_path_serial.npz"), rgb=rec["rgb"], film=rec["film"],
+                        pixel_xy=rec["pixel_xy"][::8].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
+                        tail_count=rec["tail_count"], Ls=rec["Ls"])
+    # (4) counter-mode image (the device sampler's mode) of the same scene
+    ref = osc.render(ob.render_desc(r, sampler_mode=1))
+    np.savez_compressed(os.path.join(OUT, "c2small_path_counter.npz"), rgb=ref["rgb"], film=ref["film"])
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@ def aggregate_test_rays(bmin, bmax, n, seed=1, hits=None):
     ext = bmax - bmin
     lo, hi = bmin - ext, bmax + ext
     o = lo + rng.random((n, 3)) * (hi - lo)
+    pick = np.zeros(n, bool)
     if hits is not None and len(hits):
         pick = rng.random(n) < 0.25
         o[pick] = hits[rng.integers(0, len(hits), pick.sum())]
@@ -26,6 +27,10 @@ def aggregate_test_rays(bmin, bmax, n, seed=1, hits=None):
     ax[np.arange(n), which] = np.where(rng.random(n) < 0.5, -1.0, 1.0)
     d[axis] = ax[axis]
     tmin = np.where(rng.random(n) < 0.5, 0.0, 1.0e-3)
+    # Rays that start ON a surface use the epsilon real secondary rays carry (isect.rayEpsilon): with tmin == 0 a
+    # t == 0 hit is accepted by Triangle.intersect but its flat leaf box fails `tmax > minDistance`
+    # (bvh_accel.dart:471), a disagreement the reference's AggregateTestRenderer would merely log.
+    tmin[pick] = 1.0e-3
     tmax = np.where(rng.random(n) < 0.25, rng.random(n) * np.linalg.norm(ext) * 2.0, np.inf)
     return o.astype(np.float32), d.astype(np.float32), tmin, tmax
 
