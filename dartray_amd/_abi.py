@@ -113,6 +113,32 @@ class DartRayHipError(RuntimeError):
     it to LogSevere -> Exception, lib/core/log.dart:42-47)."""
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so /
+    libhsa-runtime64.so; if this library pulled in /opt/rocm's copy first, torch's later
+    initialisation would find "No HIP GPUs" (two HSA runtimes cannot share the device).  torch is
+    this package's plumbing for device memory, streams and RCCL, so when it is installed its HIP
+    runtime is loaded first (by path, without importing torch) and libdartray_hip.so's
+    DT_NEEDED libamdhip64.so.7 then resolves to that same object."""
+    import importlib.util
+    override = os.environ.get("DARTRAY_HIP_RUNTIME")
+    if override:
+        C.CDLL(override, mode=C.RTLD_GLOBAL)
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libdartray_hip.so (built in-tree by __graft_entry__.build())."""
     global _lib
@@ -120,6 +146,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise DartRayHipError(
                 "HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(l, name)

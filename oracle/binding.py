@@ -50,7 +50,7 @@ class OrcRecord(C.Structure):
 
 class OrcCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("closest_rays", "any_rays", "closest_nodes", "any_nodes", "closest_tris",
-                                          "any_tris", "light_tris", "camera_samples")]
+                                          "any_tris", "light_tris", "camera_samples", "max_stack")]
 
 
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("tmin", "<f8"), ("tmax", "<f8")])

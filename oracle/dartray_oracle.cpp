@@ -323,6 +323,7 @@ struct Counters {
   uint64_t closest_tris = 0, any_tris = 0;
   uint64_t light_tris = 0;
   uint64_t camera_samples = 0;
+  uint64_t max_stack = 0;  // deepest todo stack seen (the reference allocates 64 entries, bvh_accel.dart:120)
 };
 
 struct Light {  // DiffuseAreaLight (diffuse_area_light.dart:36-70) + ShapeSet (shape_set.dart:24-51)
@@ -720,6 +721,7 @@ static bool bvh_intersect(const Scene& sc, Ray& ray, Isect* isect) {  // bvh_acc
       todo = todoHeap.data();
     }
     todo[todoOffset++] = v;
+    if ((uint64_t)todoOffset > sc.ctr.max_stack) sc.ctr.max_stack = (uint64_t)todoOffset;
   };
   while (true) {
     const LinearNode& node = sc.nodes[nodeNum];
@@ -1440,6 +1442,7 @@ struct OrcRecord {  // optional per-sample recording (all host arrays sized by t
 };
 struct OrcCounters {
   uint64_t closest_rays, any_rays, closest_nodes, any_nodes, closest_tris, any_tris, light_tris, camera_samples;
+  uint64_t max_stack;
 };
 
 const char* orc_version() { return "dartray-oracle 1 (CPU restatement; parity unpinned)"; }
@@ -1537,6 +1540,7 @@ void orc_counters(void* h, OrcCounters* out, int reset) {
     out->closest_nodes = sc->ctr.closest_nodes; out->any_nodes = sc->ctr.any_nodes;
     out->closest_tris = sc->ctr.closest_tris; out->any_tris = sc->ctr.any_tris;
     out->light_tris = sc->ctr.light_tris; out->camera_samples = sc->ctr.camera_samples;
+    out->max_stack = sc->ctr.max_stack;
   }
   if (reset) sc->ctr = Counters();
 }

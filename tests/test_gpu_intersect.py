@@ -65,7 +65,7 @@ def test_deep_tree_uses_the_spill_stack(ob, gpu):
     """A geometric progression of triangles makes the SAH tree a long chain: deeper than the 32 LDS stack
     entries per lane, exercising the global-memory spill (the reference's todo stack holds 64)."""
     n = 60
-    s = 1.6 ** np.arange(n)
+    s = 4.0 ** np.arange(n)
     P = np.zeros((n, 3, 3), np.float32)
     P[:, 0] = np.stack([s, 0 * s, 0 * s], 1)
     P[:, 1] = np.stack([s, 0.3 * s, 0 * s], 1)
@@ -78,11 +78,20 @@ def test_deep_tree_uses_the_spill_stack(ob, gpu):
     rng = np.random.Generator(np.random.PCG64(5))
     m = 20000
     # rays from beyond the largest triangle back towards the origin cross many boxes
-    o = np.stack([np.full(m, s[-1] * 2), rng.random(m) * 0.2 * s[-1] * 0.1, rng.random(m) * 0.2 * s[-1] * 0.1], 1).astype(np.float32)
+    # rays from beyond the k-th triangle back towards the origin cross many nested boxes
+    k = rng.integers(10, n, m)
+    o = np.stack([s[k] * 2, rng.random(m) * 0.02 * s[k], rng.random(m) * 0.02 * s[k]], 1).astype(np.float32)
     tgt = np.stack([np.zeros(m), rng.random(m) * 0.05, rng.random(m) * 0.05], 1)
-    d = (tgt - o).astype(np.float32)
+    # ... and rays from the origin outwards visit the small boxes first, stacking one far sibling per level
+    o2 = np.stack([np.full(m, -1.0), rng.random(m) * 0.05, rng.random(m) * 0.05], 1).astype(np.float32)
+    tgt = np.concatenate([tgt, o.astype(np.float64)])
+    o = np.concatenate([o, o2])
+    d = (tgt - o.astype(np.float64))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     h = scene.intersect(core.Ray(o, d))
+    osc.counters(reset=True)
     ho = osc.intersect(ob.make_rays(o, d))
+    assert osc.counters()["max_stack"] > 32  # the rays really do overflow the LDS part of the stack
     assert np.array_equal(h["prim"], ho["prim"]) and np.array_equal(h["t"], ho["t"])
     assert (h["prim"] >= 0).sum() > 1000
     assert np.array_equal(scene.intersectP(core.Ray(o, d)), osc.intersect(ob.make_rays(o, d), any_hit=True)["prim"] >= 0)
@@ -100,9 +109,14 @@ def test_edge_cases(ob, gpu):
     h = scene.intersect(core.Ray(o, d))
     ho = osc.intersect(ob.make_rays(o, d))
     assert np.array_equal(h["prim"], ho["prim"]) and np.array_equal(h["t"], ho["t"])
-    # t == tmax is accepted (triangle.dart:96), tmin above the hit rejects
-    h = scene.intersect(core.Ray([[0, 5, 0]] * 3, [[0, -1, 0]] * 3, [0.0, 0.0, 15.5], [15.0, 14.999, np.inf]))
-    assert list(h["prim"] >= 0) == [True, False, False] and h["t"][0] == 15.0
+    # Triangle.intersect accepts t == tmax (triangle.dart:96) but the leaf's box test is strict
+    # (`tmin < ray.maxDistance`, bvh_accel.dart:471): through the BVH a hit at exactly tmax is lost
+    o3, d3 = [[0.5, 5, 0.25]] * 4, [[0, -1, 0]] * 4
+    tmin3, tmax3 = [0.0, 0.0, 15.5, 0.0], [15.0, 14.999, np.inf, 15.001]
+    h = scene.intersect(core.Ray(o3, d3, tmin3, tmax3))
+    ho = osc.intersect(ob.make_rays(o3, d3, np.array(tmin3), np.array(tmax3)))
+    assert np.array_equal(h["prim"], ho["prim"]) and np.array_equal(h["t"], ho["t"])
+    assert list(h["prim"] >= 0) == [False, False, False, True] and h["t"][3] == 15.0
     # an empty scene never hits
     empty = core.Scene(core.BVHAccel([]), [])
     assert np.all(empty.intersect(core.Ray(o, d))["prim"] == -1) and not empty.intersectP(core.Ray(o, d)).any()
