@@ -15,214 +15,7 @@
 // Compiled with -ffp-contract=off: the Dart VM never fuses a*b+c.
 #include "dr_kernels.h"
 #include "dr_rng.h"
-
-// ---------------------------------------------------------------------------
-// small wave helpers
-// ---------------------------------------------------------------------------
-DR_DEV int lane_id() { return (int)(threadIdx.x & 63); }
-DR_DEV uint32_t wave_bcast_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-// Append `val` for every lane with `pred` to a device queue: one ballot, one
-// prefix popcount and ONE atomic per wave.  Must be reached by the whole wave.
-DR_DEV void wave_push(uint32_t* q, uint32_t* count, bool pred, uint32_t val) {
-  unsigned long long m = __ballot(pred);
-  if (m == 0ull) return;
-  int lane = lane_id();
-  int leader = __ffsll((long long)m) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
-  base = (uint32_t)__shfl((int)base, leader);
-  if (pred) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = val;
-}
-DR_DEV unsigned long long wave_sum(uint32_t v) {
-  unsigned long long x = v;
-  for (int off = 32; off > 0; off >>= 1) {
-    unsigned int lo = (unsigned int)__shfl_xor((int)(uint32_t)(x & 0xffffffffull), off);
-    unsigned int hi = (unsigned int)__shfl_xor((int)(uint32_t)(x >> 32), off);
-    x += ((unsigned long long)hi << 32) | lo;
-  }
-  return x;
-}
-
-// ---------------------------------------------------------------------------
-// BVH traversal (bvh_accel.dart:101-226).  Returns the hit primitive (closest)
-// or 0 / -1 (any-hit: occluded / free).
-// ---------------------------------------------------------------------------
-template <int ANY>
-DR_DEV int traverse(const DScene& sc, F3 o, F3 d, double tmin, double tmax, uint32_t* lds, uint32_t* spill,
-                    uint32_t spillStride, double* tOut, uint32_t* nNodes, uint32_t* nTris) {
-  if (sc.nnodes == 0) return -1;
-  // invDir is a Vector: rounded to f32 (bvh_accel.dart:109-111)
-  const float ivx = (float)(1.0 / (double)d.x), ivy = (float)(1.0 / (double)d.y), ivz = (float)(1.0 / (double)d.z);
-  const bool n0 = ivx < 0.f, n1 = ivy < 0.f, n2 = ivz < 0.f;
-  const double ox = o.x, oy = o.y, oz = o.z;
-  const double dix = ivx, diy = ivy, diz = ivz;
-  int sp = 0;
-  uint32_t node = 0;
-  int hit = -1;
-  for (;;) {
-    const uint4 a = sc.nodes[2 * (size_t)node];
-    const uint4 b = sc.nodes[2 * (size_t)node + 1];
-    ++*nNodes;
-    const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
-    const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
-    const uint32_t offset = b.z, meta = b.w;
-    // _intersectP slab test (bvh_accel.dart:439-472), f64 products of f32 values
-    double t0 = ((double)(n0 ? bmaxx : bminx) - ox) * dix;
-    double t1 = ((double)(n0 ? bminx : bmaxx) - ox) * dix;
-    const double ty0 = ((double)(n1 ? bmaxy : bminy) - oy) * diy;
-    const double ty1 = ((double)(n1 ? bminy : bmaxy) - oy) * diy;
-    bool ok = !((t0 > ty1) || (ty0 > t1));
-    if (ok) {
-      if (ty0 > t0) t0 = ty0;
-      if (ty1 < t1) t1 = ty1;
-      const double tz0 = ((double)(n2 ? bmaxz : bminz) - oz) * diz;
-      const double tz1 = ((double)(n2 ? bminz : bmaxz) - oz) * diz;
-      ok = !((t0 > tz1) || (tz0 > t1));
-      if (ok) {
-        if (tz0 > t0) t0 = tz0;
-        if (tz1 < t1) t1 = tz1;
-        ok = (t0 < tmax) && (t1 > tmin);
-      }
-    }
-    bool pop = true;
-    if (ok) {
-      const uint32_t nprims = meta & 0xffffu;
-      if (nprims > 0) {
-        for (uint32_t i = 0; i < nprims; ++i) {
-          ++*nTris;
-          const float4* tp = sc.tris + 3 * (size_t)(offset + i);
-          const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-          const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
-          if (ANY) {
-            if (tri_hitP(p1, p2, p3, o, d, tmin, tmax)) return 0;  // bvh_accel.dart:193-195
-          } else {
-            double t, b1, b2;
-            if (tri_hit(p1, p2, p3, o, d, tmin, tmax, &t, &b1, &b2)) {
-              tmax = t;  // r.maxDistance = thit (geometric_primitive.dart:59)
-              hit = (int)(offset + i);
-            }
-          }
-        }
-      } else {
-        const uint32_t axis = (meta >> 16) & 0xffu;
-        const bool neg = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
-        const uint32_t far = neg ? node + 1 : offset;  // bvh_accel.dart:147-153
-        node = neg ? offset : node + 1;
-        if (sp < DR_LDS_STACK) lds[sp * DR_TRACE_BLOCK] = far;
-        else if (sp < DR_MAX_STACK) spill[(size_t)(sp - DR_LDS_STACK) * spillStride] = far;
-        ++sp;
-        pop = false;
-      }
-    }
-    if (pop) {
-      if (sp == 0) break;
-      --sp;
-      node = sp < DR_LDS_STACK ? lds[sp * DR_TRACE_BLOCK] : spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
-    }
-  }
-  if (!ANY) *tOut = tmax;
-  return hit;
-}
-
-DR_DEV void flush_counters(TraceCounters* ctr, int any, uint32_t rays, uint32_t nodes, uint32_t tris) {
-  unsigned long long r = wave_sum(rays), n = wave_sum(nodes), t = wave_sum(tris);
-  if (lane_id() == 0 && ctr) {
-    if (any) {
-      atomicAdd(&ctr->any_rays, r);
-      atomicAdd(&ctr->any_nodes, n);
-      atomicAdd(&ctr->any_tris, t);
-    } else {
-      atomicAdd(&ctr->closest_rays, r);
-      atomicAdd(&ctr->closest_nodes, n);
-      atomicAdd(&ctr->closest_tris, t);
-    }
-  }
-}
-
-// Persistent traversal kernel over a queue of path slots.
-template <int ANY>
-__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace(DScene sc, BatchState st, const uint32_t* queue,
-                                                          const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
-                                                          TraceCounters* ctr) {
-  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
-  uint32_t* lds = s_stack + threadIdx.x;
-  const uint32_t spillStride = gridDim.x * DR_TRACE_BLOCK;
-  uint32_t* mySpill = spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr;
-  const uint32_t n = nQueue ? *nQueue : st.nslots;
-  const uint32_t cap = st.cap;
-  uint32_t rays = 0, nodes = 0, tris = 0;
-  for (;;) {
-    uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(work, 64u);
-    base = wave_bcast_first(base);
-    if (base >= n) break;
-    const uint32_t idx = base + (uint32_t)lane_id();
-    if (idx < n) {
-      const uint32_t e = queue ? queue[idx] : idx;
-      const uint32_t slot = e & ~Q_MIS_BIT;
-      const F3 o = F3{st.ro[slot], st.ro[cap + slot], st.ro[2 * cap + slot]};
-      const double tmin = st.rtmin[slot];
-      ++rays;
-      if (ANY) {
-        const F3 d = F3{st.shD[slot], st.shD[cap + slot], st.shD[2 * cap + slot]};
-        double t;
-        int r = traverse<1>(sc, o, d, tmin, st.shTmax[slot], lds, mySpill, spillStride, &t, &nodes, &tris);
-        st.shOcc[slot] = (r >= 0) ? 1 : 0;
-      } else if (e & Q_MIS_BIT) {
-        const F3 d = F3{st.misD[slot], st.misD[cap + slot], st.misD[2 * cap + slot]};
-        double t;
-        st.misPrim[slot] = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
-      } else {
-        const F3 d = F3{st.rd[slot], st.rd[cap + slot], st.rd[2 * cap + slot]};
-        double t;
-        int r = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
-        st.hprim[slot] = r;
-        st.ht[slot] = t;
-      }
-    }
-  }
-  flush_counters(ctr, ANY, rays, nodes, tris);
-}
-
-// Aggregate.intersect / intersectP on caller-supplied rays (dr_intersect).
-template <int ANY>
-__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect(DScene sc, const DrRay* rays, uint32_t n, DrHit* out,
-                                                              uint32_t* spill, uint32_t* work, TraceCounters* ctr) {
-  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
-  uint32_t* lds = s_stack + threadIdx.x;
-  const uint32_t spillStride = gridDim.x * DR_TRACE_BLOCK;
-  uint32_t* mySpill = spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr;
-  uint32_t nr = 0, nodes = 0, tris = 0;
-  for (;;) {
-    uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(work, 64u);
-    base = wave_bcast_first(base);
-    if (base >= n) break;
-    const uint32_t idx = base + (uint32_t)lane_id();
-    if (idx < n) {
-      const DrRay r = rays[idx];
-      const F3 o = F3{r.o[0], r.o[1], r.o[2]}, d = F3{r.d[0], r.d[1], r.d[2]};
-      ++nr;
-      DrHit h;
-      h.pad = 0;
-      h.t = h.b1 = h.b2 = 0.0;
-      double t = 0.0;
-      h.prim = traverse<ANY>(sc, o, d, r.tmin, r.tmax, lds, mySpill, spillStride, &t, &nodes, &tris);
-      if (!ANY && h.prim >= 0) {
-        Tri tr = load_tri(sc, (uint32_t)h.prim);
-        double tt, b1, b2;
-        // same arithmetic as the accepting test; only the [tmin,tmax] gate differs
-        tri_hit(tr.p1, tr.p2, tr.p3, o, d, r.tmin, DR_INF, &tt, &b1, &b2);
-        h.t = t;
-        h.b1 = b1;
-        h.b2 = b2;
-      }
-      out[idx] = h;
-    }
-  }
-  flush_counters(ctr, ANY, nr, nodes, tris);
-}
+#include "dr_wave.h"
 
 // ---------------------------------------------------------------------------
 // scene upload: gather each primitive's vertices into its 48-byte record
@@ -726,20 +519,6 @@ void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t*
   if (ntris == 0) return;
   hipLaunchKernelGGL(k_gather_tris, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, verts, idx, mat, light, rev, out,
                      ntris);
-}
-void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
-                      uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
-  if (anyHit)
-    hipLaunchKernelGGL(k_intersect<1>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
-  else
-    hipLaunchKernelGGL(k_intersect<0>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
-}
-void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
-                  uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
-  if (anyHit)
-    hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
-  else
-    hipLaunchKernelGGL(k_trace<0>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
 }
 void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s) {
   const int nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;

@@ -1,0 +1,533 @@
+// dr_trace.hip -- BVHAccel.intersect / intersectP (accelerators/bvh_accel.dart:101-226,439-472)
+// and Triangle.intersect / intersectP (shapes/triangle.dart:44-240) as persistent gfx950 kernels.
+//
+// v2 design (k_trace / k_intersect):
+//  * persistent threads, ONE RAY PER LANE, per-lane refill: a lane whose ray has finished becomes
+//    idle; when >= DR_REFILL_TH lanes of the wave are idle the wave takes that many queue entries
+//    with one atomicAdd on the device work counter, so a wave no longer runs as long as its
+//    longest ray;
+//  * the traversal ORDER of the reference is kept exactly (near child first by dirIsNeg[axis], far
+//    child pushed; maxDistance shrinks on every accepted hit), so hit records, equal-t tie breaks
+//    and the node/triangle visit counts equal the reference's;
+//  * leaf batching: a lane that reaches a leaf WAITS (it may not run ahead: the next box test
+//    depends on the shrunk maxDistance) until >= DR_LEAF_TH lanes are at leaves or nobody can
+//    traverse; the f64 Moeller-Trumbore code then runs for all of them at once instead of for
+//    ~7 % of the lanes every iteration;
+//  * slab test: an f32 interval filter decides almost every box; only when the f32 enclosure of
+//    the f64 quantities straddles a comparison (or the ray has a zero direction component, where
+//    0*inf = NaN matters) is the literal f64 test of bvh_accel.dart:439-472 evaluated.  The
+//    decision is therefore always the f64 one;
+//  * todo stack: [depth][lane] u32 in LDS (bank == lane => conflict free) + global spill.
+// The path is latency / HBM bound (about 1 flop per byte): no MFMA.
+#include "dr_kernels.h"
+#include "dr_wave.h"
+
+#ifndef DR_REFILL_TH
+#define DR_REFILL_TH 20
+#endif
+#ifndef DR_LEAF_TH
+#define DR_LEAF_TH 16
+#endif
+
+// ===========================================================================
+// v1: the first correct version (kept for A/B runs, DARTRAY_TRACE_IMPL=1): 64 queue entries per
+// wave at a time, one node visit OR leaf per iteration for every lane.
+// ===========================================================================
+// ---------------------------------------------------------------------------
+// BVH traversal (bvh_accel.dart:101-226).  Returns the hit primitive (closest)
+// or 0 / -1 (any-hit: occluded / free).
+// ---------------------------------------------------------------------------
+template <int ANY>
+DR_DEV int traverse(const DScene& sc, F3 o, F3 d, double tmin, double tmax, uint32_t* lds, uint32_t* spill,
+                    uint32_t spillStride, double* tOut, uint32_t* nNodes, uint32_t* nTris) {
+  if (sc.nnodes == 0) return -1;
+  // invDir is a Vector: rounded to f32 (bvh_accel.dart:109-111)
+  const float ivx = (float)(1.0 / (double)d.x), ivy = (float)(1.0 / (double)d.y), ivz = (float)(1.0 / (double)d.z);
+  const bool n0 = ivx < 0.f, n1 = ivy < 0.f, n2 = ivz < 0.f;
+  const double ox = o.x, oy = o.y, oz = o.z;
+  const double dix = ivx, diy = ivy, diz = ivz;
+  int sp = 0;
+  uint32_t node = 0;
+  int hit = -1;
+  for (;;) {
+    const uint4 a = sc.nodes[2 * (size_t)node];
+    const uint4 b = sc.nodes[2 * (size_t)node + 1];
+    ++*nNodes;
+    const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
+    const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
+    const uint32_t offset = b.z, meta = b.w;
+    // _intersectP slab test (bvh_accel.dart:439-472), f64 products of f32 values
+    double t0 = ((double)(n0 ? bmaxx : bminx) - ox) * dix;
+    double t1 = ((double)(n0 ? bminx : bmaxx) - ox) * dix;
+    const double ty0 = ((double)(n1 ? bmaxy : bminy) - oy) * diy;
+    const double ty1 = ((double)(n1 ? bminy : bmaxy) - oy) * diy;
+    bool ok = !((t0 > ty1) || (ty0 > t1));
+    if (ok) {
+      if (ty0 > t0) t0 = ty0;
+      if (ty1 < t1) t1 = ty1;
+      const double tz0 = ((double)(n2 ? bmaxz : bminz) - oz) * diz;
+      const double tz1 = ((double)(n2 ? bminz : bmaxz) - oz) * diz;
+      ok = !((t0 > tz1) || (tz0 > t1));
+      if (ok) {
+        if (tz0 > t0) t0 = tz0;
+        if (tz1 < t1) t1 = tz1;
+        ok = (t0 < tmax) && (t1 > tmin);
+      }
+    }
+    bool pop = true;
+    if (ok) {
+      const uint32_t nprims = meta & 0xffffu;
+      if (nprims > 0) {
+        for (uint32_t i = 0; i < nprims; ++i) {
+          ++*nTris;
+          const float4* tp = sc.tris + 3 * (size_t)(offset + i);
+          const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+          const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
+          if (ANY) {
+            if (tri_hitP(p1, p2, p3, o, d, tmin, tmax)) return 0;  // bvh_accel.dart:193-195
+          } else {
+            double t, b1, b2;
+            if (tri_hit(p1, p2, p3, o, d, tmin, tmax, &t, &b1, &b2)) {
+              tmax = t;  // r.maxDistance = thit (geometric_primitive.dart:59)
+              hit = (int)(offset + i);
+            }
+          }
+        }
+      } else {
+        const uint32_t axis = (meta >> 16) & 0xffu;
+        const bool neg = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
+        const uint32_t far = neg ? node + 1 : offset;  // bvh_accel.dart:147-153
+        node = neg ? offset : node + 1;
+        if (sp < DR_LDS_STACK) lds[sp * DR_TRACE_BLOCK] = far;
+        else if (sp < DR_MAX_STACK) spill[(size_t)(sp - DR_LDS_STACK) * spillStride] = far;
+        ++sp;
+        pop = false;
+      }
+    }
+    if (pop) {
+      if (sp == 0) break;
+      --sp;
+      node = sp < DR_LDS_STACK ? lds[sp * DR_TRACE_BLOCK] : spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
+    }
+  }
+  if (!ANY) *tOut = tmax;
+  return hit;
+}
+
+DR_DEV void flush_counters(TraceCounters* ctr, int any, uint32_t rays, uint32_t nodes, uint32_t tris) {
+  unsigned long long r = wave_sum(rays), n = wave_sum(nodes), t = wave_sum(tris);
+  if (lane_id() == 0 && ctr) {
+    if (any) {
+      atomicAdd(&ctr->any_rays, r);
+      atomicAdd(&ctr->any_nodes, n);
+      atomicAdd(&ctr->any_tris, t);
+    } else {
+      atomicAdd(&ctr->closest_rays, r);
+      atomicAdd(&ctr->closest_nodes, n);
+      atomicAdd(&ctr->closest_tris, t);
+    }
+  }
+}
+
+// Persistent traversal kernel over a queue of path slots.
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace_v1(DScene sc, BatchState st, const uint32_t* queue,
+                                                          const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
+                                                          TraceCounters* ctr) {
+  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
+  uint32_t* lds = s_stack + threadIdx.x;
+  const uint32_t spillStride = gridDim.x * DR_TRACE_BLOCK;
+  uint32_t* mySpill = spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr;
+  const uint32_t n = nQueue ? *nQueue : st.nslots;
+  const uint32_t cap = st.cap;
+  uint32_t rays = 0, nodes = 0, tris = 0;
+  for (;;) {
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(work, 64u);
+    base = wave_bcast_first(base);
+    if (base >= n) break;
+    const uint32_t idx = base + (uint32_t)lane_id();
+    if (idx < n) {
+      const uint32_t e = queue ? queue[idx] : idx;
+      const uint32_t slot = e & ~Q_MIS_BIT;
+      const F3 o = F3{st.ro[slot], st.ro[cap + slot], st.ro[2 * cap + slot]};
+      const double tmin = st.rtmin[slot];
+      ++rays;
+      if (ANY) {
+        const F3 d = F3{st.shD[slot], st.shD[cap + slot], st.shD[2 * cap + slot]};
+        double t;
+        int r = traverse<1>(sc, o, d, tmin, st.shTmax[slot], lds, mySpill, spillStride, &t, &nodes, &tris);
+        st.shOcc[slot] = (r >= 0) ? 1 : 0;
+      } else if (e & Q_MIS_BIT) {
+        const F3 d = F3{st.misD[slot], st.misD[cap + slot], st.misD[2 * cap + slot]};
+        double t;
+        st.misPrim[slot] = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
+      } else {
+        const F3 d = F3{st.rd[slot], st.rd[cap + slot], st.rd[2 * cap + slot]};
+        double t;
+        int r = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
+        st.hprim[slot] = r;
+        st.ht[slot] = t;
+      }
+    }
+  }
+  flush_counters(ctr, ANY, rays, nodes, tris);
+}
+
+// Aggregate.intersect / intersectP on caller-supplied rays (dr_intersect).
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect_v1(DScene sc, const DrRay* rays, uint32_t n, DrHit* out,
+                                                              uint32_t* spill, uint32_t* work, TraceCounters* ctr) {
+  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
+  uint32_t* lds = s_stack + threadIdx.x;
+  const uint32_t spillStride = gridDim.x * DR_TRACE_BLOCK;
+  uint32_t* mySpill = spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr;
+  uint32_t nr = 0, nodes = 0, tris = 0;
+  for (;;) {
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(work, 64u);
+    base = wave_bcast_first(base);
+    if (base >= n) break;
+    const uint32_t idx = base + (uint32_t)lane_id();
+    if (idx < n) {
+      const DrRay r = rays[idx];
+      const F3 o = F3{r.o[0], r.o[1], r.o[2]}, d = F3{r.d[0], r.d[1], r.d[2]};
+      ++nr;
+      DrHit h;
+      h.pad = 0;
+      h.t = h.b1 = h.b2 = 0.0;
+      double t = 0.0;
+      h.prim = traverse<ANY>(sc, o, d, r.tmin, r.tmax, lds, mySpill, spillStride, &t, &nodes, &tris);
+      if (!ANY && h.prim >= 0) {
+        Tri tr = load_tri(sc, (uint32_t)h.prim);
+        double tt, b1, b2;
+        // same arithmetic as the accepting test; only the [tmin,tmax] gate differs
+        tri_hit(tr.p1, tr.p2, tr.p3, o, d, r.tmin, DR_INF, &tt, &b1, &b2);
+        h.t = t;
+        h.b1 = b1;
+        h.b2 = b2;
+      }
+      out[idx] = h;
+    }
+  }
+  flush_counters(ctr, ANY, nr, nodes, tris);
+}
+
+
+// ===========================================================================
+// v2
+// ===========================================================================
+struct TraceRay {
+  F3 o, d;
+  float ivx, ivy, ivz;         // invDir: a Vector, i.e. rounded to f32 (bvh_accel.dart:109-111)
+  double tmin, tmax;           // Ray.minDistance / maxDistance (f64)
+  float tminLo, tminHi;        // f32 brackets: tminLo <= tmin <= tminHi
+  float tmaxLo, tmaxHi;
+  bool needF64;                // a zero direction component: 0*inf = NaN can occur, always take the literal test
+};
+DR_DEV float f32_below(double v) {  // largest float <= v
+  float f = (float)v;
+  if ((double)f > v) f = __uint_as_float(f > 0.f ? __float_as_uint(f) - 1u : (f < 0.f ? __float_as_uint(f) + 1u : 0x80000001u));
+  return f;
+}
+DR_DEV float f32_above(double v) {  // smallest float >= v
+  float f = (float)v;
+  if ((double)f < v) f = __uint_as_float(f > 0.f ? __float_as_uint(f) + 1u : (f < 0.f ? __float_as_uint(f) - 1u : 0x00000001u));
+  return f;
+}
+DR_DEV void ray_set_tmax(TraceRay& r, double tmax) {
+  r.tmax = tmax;
+  r.tmaxLo = f32_below(tmax);
+  r.tmaxHi = f32_above(tmax);
+}
+DR_DEV void ray_init(TraceRay& r, F3 o, F3 d, double tmin, double tmax) {
+  r.o = o;
+  r.d = d;
+  r.ivx = (float)(1.0 / (double)d.x);
+  r.ivy = (float)(1.0 / (double)d.y);
+  r.ivz = (float)(1.0 / (double)d.z);
+  r.tmin = tmin;
+  r.tminLo = f32_below(tmin);
+  r.tminHi = f32_above(tmin);
+  ray_set_tmax(r, tmax);
+  r.needF64 = (d.x == 0.f) || (d.y == 0.f) || (d.z == 0.f);
+}
+
+// The literal slab test (bvh_accel.dart:439-472).
+DR_DEV bool slab_f64(const TraceRay& r, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz) {
+  const bool n0 = r.ivx < 0.f, n1 = r.ivy < 0.f, n2 = r.ivz < 0.f;
+  const double ox = r.o.x, oy = r.o.y, oz = r.o.z;
+  double t0 = ((double)(n0 ? bmaxx : bminx) - ox) * (double)r.ivx;
+  double t1 = ((double)(n0 ? bminx : bmaxx) - ox) * (double)r.ivx;
+  const double ty0 = ((double)(n1 ? bmaxy : bminy) - oy) * (double)r.ivy;
+  const double ty1 = ((double)(n1 ? bminy : bmaxy) - oy) * (double)r.ivy;
+  if ((t0 > ty1) || (ty0 > t1)) return false;
+  if (ty0 > t0) t0 = ty0;
+  if (ty1 < t1) t1 = ty1;
+  const double tz0 = ((double)(n2 ? bmaxz : bminz) - oz) * (double)r.ivz;
+  const double tz1 = ((double)(n2 ? bminz : bmaxz) - oz) * (double)r.ivz;
+  if ((t0 > tz1) || (tz0 > t1)) return false;
+  if (tz0 > t0) t0 = tz0;
+  if (tz1 < t1) t1 = tz1;
+  return (t0 < r.tmax) && (t1 > r.tmin);
+}
+
+// f32 enclosure of the slab test.  With E = max of the three entry parameters and X = min of the
+// three exit parameters, the reference's test is (E <= X) && (E < maxDistance) && (X > minDistance)
+// whenever no NaN occurs (same-axis entry <= exit holds by monotonic rounding).  Each f32 product
+// (b - o) * inv is within 2^-23 relative of the f64 one; +-(|x| * 2^-21 + 1e-37) encloses it with
+// room for the rounding of the enclosure arithmetic itself and for f32 denormals.  Overflow to
+// +-inf makes an enclosure bound NaN or +-inf, every comparison below is then false and the box
+// is reported ambiguous.  Returns 1 = certain hit, 0 = certain miss, -1 = evaluate the f64 test.
+DR_DEV int slab_f32(const TraceRay& r, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz) {
+  const float ax = (bminx - r.o.x) * r.ivx, bx = (bmaxx - r.o.x) * r.ivx;
+  const float ay = (bminy - r.o.y) * r.ivy, by = (bmaxy - r.o.y) * r.ivy;
+  const float az = (bminz - r.o.z) * r.ivz, bz = (bmaxz - r.o.z) * r.ivz;
+  const float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+  const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  const float R = 4.76837158203125e-07f;  // 2^-21
+  const float A = 1.0e-37f;
+  const float eLo = __fmaf_rn(fabsf(lo), R, A), eHi = __fmaf_rn(fabsf(hi), R, A);
+  const float loU = lo + eLo, loL = lo - eLo, hiU = hi + eHi, hiL = hi - eHi;
+  const bool sureHit = (loU <= hiL) && (loU < r.tmaxLo) && (hiL > r.tminHi);
+  const bool sureMiss = (loL > hiU) || (loL >= r.tmaxHi) || (hiU <= r.tminLo);
+  return sureHit ? 1 : (sureMiss ? 0 : -1);
+}
+
+#define M_IDLE 0
+#define M_TRAV 1
+#define M_LEAF 2
+
+// IO policy of the path-state kernel: queue entries -> rays, results -> slot arrays.
+template <int ANY>
+struct StateIO {
+  BatchState st;
+  const uint32_t* queue;
+  DR_DEV void load(uint32_t idx, TraceRay& r, uint32_t& handle) const {
+    const uint32_t e = queue ? queue[idx] : idx;
+    const uint32_t slot = e & ~Q_MIS_BIT;
+    const uint32_t cap = st.cap;
+    handle = e;
+    const F3 o = F3{st.ro[slot], st.ro[cap + slot], st.ro[2 * cap + slot]};
+    const float* dir = ANY ? st.shD : ((e & Q_MIS_BIT) ? st.misD : st.rd);
+    const F3 d = F3{dir[slot], dir[cap + slot], dir[2 * cap + slot]};
+    ray_init(r, o, d, st.rtmin[slot], ANY ? st.shTmax[slot] : DR_INF);
+  }
+  DR_DEV void store(uint32_t handle, const TraceRay& r, int prim, const DScene&) const {
+    const uint32_t slot = handle & ~Q_MIS_BIT;
+    if (ANY) {
+      st.shOcc[slot] = (prim >= 0) ? 1 : 0;
+    } else if (handle & Q_MIS_BIT) {
+      st.misPrim[slot] = prim;
+    } else {
+      st.hprim[slot] = prim;
+      st.ht[slot] = r.tmax;
+    }
+  }
+};
+// IO policy of dr_intersect: caller-supplied DrRay -> DrHit.
+template <int ANY>
+struct RayIO {
+  const DrRay* rays;
+  DrHit* out;
+  DR_DEV void load(uint32_t idx, TraceRay& r, uint32_t& handle) const {
+    const DrRay q = rays[idx];
+    handle = idx;
+    ray_init(r, F3{q.o[0], q.o[1], q.o[2]}, F3{q.d[0], q.d[1], q.d[2]}, q.tmin, q.tmax);
+  }
+  DR_DEV void store(uint32_t handle, const TraceRay& r, int prim, const DScene& sc) const {
+    DrHit h;
+    h.prim = prim;
+    h.pad = 0;
+    h.t = h.b1 = h.b2 = 0.0;
+    if (!ANY && prim >= 0) {
+      Tri tr = load_tri(sc, (uint32_t)prim);
+      double tt, b1, b2;
+      tri_hit(tr.p1, tr.p2, tr.p3, r.o, r.d, r.tmin, DR_INF, &tt, &b1, &b2);  // same arithmetic as the accepting test
+      h.t = r.tmax;
+      h.b1 = b1;
+      h.b2 = b2;
+    }
+    out[handle] = h;
+  }
+};
+
+template <int ANY, class IO>
+DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_t* lds, uint32_t* spill,
+                             uint32_t spillStride, uint32_t* work, TraceCounters* ctr) {
+  const int lane = lane_id();
+  const unsigned long long ltMask = (1ull << lane) - 1ull;
+  uint32_t nRays = 0, nNodes = 0, nTris = 0;
+  TraceRay ray;
+  ray.needF64 = false;
+  uint32_t handle = 0, node = 0, leafOff = 0, leafN = 0;
+  int sp = 0, hit = -1, mode = M_IDLE;
+  bool exhausted = false;  // wave-uniform: the queue has no more entries
+  for (;;) {
+    // ---- refill idle lanes ----
+    const unsigned long long idleMask = __ballot(mode == M_IDLE);
+    const int nIdle = __popcll(idleMask);
+    if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(work, (uint32_t)nIdle);
+      base = wave_bcast_first(base);
+      if (mode == M_IDLE) {
+        const uint32_t idx = base + (uint32_t)__popcll(idleMask & ltMask);
+        if (idx < n) {
+          io.load(idx, ray, handle);
+          ++nRays;
+          if (sc.nnodes == 0) {
+            io.store(handle, ray, -1, sc);
+          } else {
+            mode = M_TRAV;
+            node = 0;
+            sp = 0;
+            hit = -1;
+          }
+        }
+      }
+      if (base + (uint32_t)nIdle >= n) exhausted = true;
+    }
+    const unsigned long long travMask = __ballot(mode == M_TRAV);
+    unsigned long long leafMask = __ballot(mode == M_LEAF);
+    if ((travMask | leafMask) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+    bool finished = false;
+    // ---- one node visit (bvh_accel.dart:122-160) ----
+    if (mode == M_TRAV) {
+      const uint4 a = sc.nodes[2 * (size_t)node];
+      const uint4 b = sc.nodes[2 * (size_t)node + 1];
+      ++nNodes;
+      const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
+      const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
+      int ok = ray.needF64 ? -1 : slab_f32(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz);
+      if (ok < 0) ok = slab_f64(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz) ? 1 : 0;
+      bool pop = true;
+      if (ok) {
+        const uint32_t nprims = b.w & 0xffffu;
+        if (nprims > 0) {
+          mode = M_LEAF;
+          leafOff = b.z;
+          leafN = nprims;
+          pop = false;
+        } else {
+          const uint32_t axis = (b.w >> 16) & 0xffu;
+          const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
+          const bool neg = iv < 0.f;
+          const uint32_t far = neg ? node + 1 : b.z;  // bvh_accel.dart:147-153
+          node = neg ? b.z : node + 1;
+          if (sp < DR_LDS_STACK) lds[sp * DR_TRACE_BLOCK] = far;
+          else if (sp < DR_MAX_STACK) spill[(size_t)(sp - DR_LDS_STACK) * spillStride] = far;
+          ++sp;
+          pop = false;
+        }
+      }
+      if (pop) {
+        if (sp == 0) {
+          finished = true;
+        } else {
+          --sp;
+          node = sp < DR_LDS_STACK ? lds[sp * DR_TRACE_BLOCK] : spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
+        }
+      }
+    }
+    // ---- batched leaf tests (bvh_accel.dart:126-143 / :189-204) ----
+    leafMask = __ballot(mode == M_LEAF);
+    const unsigned long long stillTrav = __ballot(mode == M_TRAV && !finished);
+    if (leafMask != 0ull && (__popcll(leafMask) >= DR_LEAF_TH || stillTrav == 0ull)) {
+      if (mode == M_LEAF) {
+        bool occluded = false;
+        for (uint32_t i = 0; i < leafN; ++i) {
+          ++nTris;
+          const float4* tp = sc.tris + 3 * (size_t)(leafOff + i);
+          const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+          const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
+          if (ANY) {
+            if (tri_hitP(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax)) {  // return true (bvh_accel.dart:193-195)
+              occluded = true;
+              break;
+            }
+          } else {
+            double t, b1, b2;
+            if (tri_hit(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax, &t, &b1, &b2)) {
+              ray_set_tmax(ray, t);  // r.maxDistance = thit (geometric_primitive.dart:59)
+              hit = (int)(leafOff + i);
+            }
+          }
+        }
+        if (occluded) {
+          hit = 0;
+          finished = true;
+        } else if (sp == 0) {
+          finished = true;
+        } else {
+          --sp;
+          node = sp < DR_LDS_STACK ? lds[sp * DR_TRACE_BLOCK] : spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
+          mode = M_TRAV;
+        }
+      }
+    }
+    if (finished) {
+      io.store(handle, ray, hit, sc);
+      mode = M_IDLE;
+    }
+  }
+  flush_counters(ctr, ANY, nRays, nNodes, nTris);
+}
+
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace(DScene sc, BatchState st, const uint32_t* queue,
+                                                          const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
+                                                          TraceCounters* ctr) {
+  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
+  StateIO<ANY> io{st, queue};
+  const uint32_t n = nQueue ? *nQueue : st.nslots;
+  trace_persistent<ANY>(sc, io, n, s_stack + threadIdx.x,
+                        spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
+                        gridDim.x * DR_TRACE_BLOCK, work, ctr);
+}
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect(DScene sc, const DrRay* rays, uint32_t n, DrHit* out,
+                                                              uint32_t* spill, uint32_t* work, TraceCounters* ctr) {
+  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
+  RayIO<ANY> io{rays, out};
+  trace_persistent<ANY>(sc, io, n, s_stack + threadIdx.x,
+                        spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
+                        gridDim.x * DR_TRACE_BLOCK, work, ctr);
+}
+
+// ---------------------------------------------------------------------------
+// launchers.  DARTRAY_TRACE_IMPL=1 selects the first (non-refilling) version for A/B runs.
+// ---------------------------------------------------------------------------
+static int traceImpl() {
+  static int impl = -1;
+  if (impl < 0) {
+    const char* e = getenv("DARTRAY_TRACE_IMPL");
+    impl = (e && e[0] == '1') ? 1 : 2;
+  }
+  return impl;
+}
+void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
+                      uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
+  const dim3 g(grid), b(DR_TRACE_BLOCK);
+  if (traceImpl() == 1) {
+    if (anyHit) hipLaunchKernelGGL(k_intersect_v1<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+    else hipLaunchKernelGGL(k_intersect_v1<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+  } else {
+    if (anyHit) hipLaunchKernelGGL(k_intersect<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+    else hipLaunchKernelGGL(k_intersect<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+  }
+}
+void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
+                  uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
+  const dim3 g(grid), b(DR_TRACE_BLOCK);
+  if (traceImpl() == 1) {
+    if (anyHit) hipLaunchKernelGGL(k_trace_v1<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+    else hipLaunchKernelGGL(k_trace_v1<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+  } else {
+    if (anyHit) hipLaunchKernelGGL(k_trace<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+    else hipLaunchKernelGGL(k_trace<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+  }
+}
