@@ -121,6 +121,7 @@ def main():
                          "avg_launch_ms": round(st["closest_ms"] / launches, 4), "launches": int(st["closest_launches"]),
                          "rank0_job_alg_GBps": round(all_alg / dt / 1e9, 2),
                          "rank0_trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt, 4)},
+            "kernel_ms_per_step": {k: round(st[k] / args.steps, 2) for k in ("closest_ms", "any_ms", "shade_ms", "gen_ms", "film_ms", "total_ms")},
             "per_sample": {"rays": round((st["closest_rays"] + st["any_rays"]) / max(1, st["camera_samples"]), 3),
                            "nodes": round((st["closest_nodes"] + st["any_nodes"]) / max(1, st["camera_samples"]), 2),
                            "tris": round((st["closest_tris"] + st["any_tris"]) / max(1, st["camera_samples"]), 3),

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdartray_hip.so")
+LIB_PATH = os.environ.get("DARTRAY_LIB") or os.path.join(_HERE, "libdartray_hip.so")  # DARTRAY_LIB: A/B builds
 
 DR_OK = 0
 DR_INTEGRATOR_DIRECT_ALL = 0
@@ -82,7 +82,8 @@ class DrRenderStats(C.Structure):
                 ("trace_launches", C.c_uint64), ("trace_ms", C.c_double), ("total_ms", C.c_double),
                 ("batches", C.c_uint64),
                 ("closest_launches", C.c_uint64), ("any_launches", C.c_uint64),
-                ("closest_ms", C.c_double), ("any_ms", C.c_double)]
+                ("closest_ms", C.c_double), ("any_ms", C.c_double),
+                ("shade_ms", C.c_double), ("gen_ms", C.c_double), ("film_ms", C.c_double)]
 
 
 # name -> (restype, argtypes): every symbol include/dartray_hip.h declares.

@@ -82,7 +82,7 @@ struct DrScene {
   Workspace ws;
   // stats of the last render
   DrRenderStats stats;
-  struct TraceEv { hipEvent_t e0, e1; int any; };
+  struct TraceEv { hipEvent_t e0, e1; int any; };  // any: 0 closest, 1 any-hit, 2 shade, 3 sample gen + raygen, 4 film
   std::vector<TraceEv> traceEvents;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> renderEvents;
   std::vector<hipEvent_t> eventPool;
@@ -117,6 +117,35 @@ double host_tri_area(const float* a, const float* b, const float* c) {
   double cy = r32(e1[2] * e2[0] - e1[0] * e2[2]);
   double cz = r32(e1[0] * e2[1] - e1[1] * e2[0]);
   return 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+}
+
+// DifferentialGeometry.nn of a hit on triangle (a,b,c) with the default UVs (triangle.dart:100-132,
+// differential_geometry.dart:84-99) and the normal Triangle.sample returns (triangle.dart:376-381);
+// the same f64-expression / f32-store arithmetic as tri_dg() in dr_device.h.
+void host_tri_normals(const float* a, const float* b, const float* c, bool reverse, float nn[3], float ns[3]) {
+  const double du1 = 0.0 - 1.0, du2 = 1.0 - 1.0, dv1 = 0.0 - 1.0, dv2 = 0.0 - 1.0;
+  const double invdet = 1.0 / (du1 * dv2 - dv1 * du2);
+  double dpdu[3], dpdv[3];
+  for (int k = 0; k < 3; ++k) {
+    const double dp1 = r32((double)a[k] - (double)c[k]), dp2 = r32((double)b[k] - (double)c[k]);
+    dpdu[k] = r32(r32(r32(dp1 * dv2) - r32(dp2 * dv1)) * invdet);
+    dpdv[k] = r32(r32(r32(dp1 * -du2) + r32(dp2 * du1)) * invdet);
+  }
+  auto crossNorm = [](const double* u, const double* v, double out[3]) {
+    const double cx = r32(u[1] * v[2] - u[2] * v[1]), cy = r32(u[2] * v[0] - u[0] * v[2]), cz = r32(u[0] * v[1] - u[1] * v[0]);
+    const double len = std::sqrt(cx * cx + cy * cy + cz * cz);
+    out[0] = r32(cx / len); out[1] = r32(cy / len); out[2] = r32(cz / len);
+  };
+  double n[3];
+  crossNorm(dpdu, dpdv, n);
+  for (int k = 0; k < 3; ++k) nn[k] = (float)(reverse ? r32(n[k] * -1.0) : n[k]);
+  double e1[3], e2[3];
+  for (int k = 0; k < 3; ++k) {
+    e1[k] = r32((double)b[k] - (double)a[k]);
+    e2[k] = r32((double)c[k] - (double)a[k]);
+  }
+  crossNorm(e1, e2, n);
+  for (int k = 0; k < 3; ++k) ns[k] = (float)(reverse ? n[k] * -1.0 : n[k]);
 }
 
 int traceGrid() {
@@ -374,6 +403,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         }
         o.reverse = lt.reverse_orientation;
         o.area = host_tri_area(o.p, o.p + 3, o.p + 6);
+        host_tri_normals(o.p, o.p + 3, o.p + 6, lt.reverse_orientation != 0, o.nn, o.ns);
         areas[t] = o.area;
         area += o.area;
       }
@@ -540,7 +570,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   HIP_TRY(hipMemcpyAsync(w.filterTable.p, rd->film.filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s));
   // pixels is a local: the async copy above must complete before it goes out of scope
   HIP_TRY(hipStreamSynchronize(s));
-  const int sgrid = g_numCU * 8;
+  const int sgrid = g_numCU * 2;  // 512-thread workgroups, grid-stride over the active list
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : rp.nLights + 1;
   if (4 * nStages + 8 > N_COUNTERS) return fail(DR_ERR_UNSUPPORTED, "too many stages");
 
@@ -549,6 +579,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     const uint32_t nslots = np * (uint32_t)spp;
     BatchState st = makeState(w, w.pix.p + p0, nslots, hostBuf && needTail > 0);
     HIP_TRY(hipMemsetAsync(w.counters.p, 0, N_COUNTERS * sizeof(uint32_t), s));
+    auto timed = [&](int kind, hipEvent_t e0) {
+      hipEvent_t e1 = sc->getEvent();
+      (void)hipEventRecord(e1, s);
+      sc->traceEvents.push_back({e0, e1, kind});
+    };
+    hipEvent_t evGen = sc->getEvent();
+    (void)hipEventRecord(evGen, s);
     if (hostBuf) {
       HIP_TRY(w.aosSamples.alloc((size_t)w.cap * rd->sample_stride));
       HIP_TRY(hipMemcpyAsync(w.aosSamples.p, rd->sample_vec + (size_t)p0 * spp * rd->sample_stride,
@@ -561,6 +598,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       launch_gen_samples(rp, st, np, s);
     }
     launch_raygen(rp, st, s);
+    timed(3, evGen);
     uint32_t* C = w.counters.p;
     int wc = 0;  // work counters live at C[512..]
     auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any) {
@@ -581,14 +619,20 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       q.nClosest = C + 4 * b + 1;
       q.anyQ = w.anyQ.p;
       q.nAny = C + 4 * b + 2;
+      hipEvent_t evS = sc->getEvent();
+      (void)hipEventRecord(evS, s);
       if (rd->integrator == DR_INTEGRATOR_PATH) launch_shade_path(sc->d, rp, st, q, b, sgrid, s);
       else launch_shade_direct(sc->d, rp, st, q, b, sgrid, s);
+      timed(2, evS);
       if (b + 1 < nStages) {
         trace(q.closestQ, q.nClosest, 0);
         trace(q.anyQ, q.nAny, 1);
       }
     }
+    hipEvent_t evF = sc->getEvent();
+    (void)hipEventRecord(evF, s);
     launch_film(rp, st, w.filterTable.p, np, (float*)film_dev, s);
+    timed(4, evF);
     HIP_TRY(hipGetLastError());
     sc->stats.batches++;
     if (hostBuf) HIP_TRY(hipStreamSynchronize(s));  // host buffers of the next batch reuse the staging area
@@ -626,13 +670,18 @@ int dr_get_stats(DrScene* sc, DrRenderStats* out) {
     sc->stats.closest_rays = c.closest_rays; sc->stats.any_rays = c.any_rays;
     sc->stats.closest_nodes = c.closest_nodes; sc->stats.any_nodes = c.any_nodes;
     sc->stats.closest_tris = c.closest_tris; sc->stats.any_tris = c.any_tris;
-    double msC = 0.0, msA = 0.0;
+    double msC = 0.0, msA = 0.0, msS = 0.0, msG = 0.0, msF = 0.0;
     uint64_t nC = 0, nA = 0;
     for (auto& ev : sc->traceEvents) {
       float t = 0.f;
       if (hipEventElapsedTime(&t, ev.e0, ev.e1) != hipSuccess) continue;
-      if (ev.any) { msA += t; ++nA; } else { msC += t; ++nC; }
+      if (ev.any == 1) { msA += t; ++nA; }
+      else if (ev.any == 0) { msC += t; ++nC; }
+      else if (ev.any == 2) msS += t;
+      else if (ev.any == 3) msG += t;
+      else msF += t;
     }
+    sc->stats.shade_ms = msS; sc->stats.gen_ms = msG; sc->stats.film_ms = msF;
     sc->stats.closest_ms = msC; sc->stats.any_ms = msA;
     sc->stats.closest_launches = nC; sc->stats.any_launches = nA;
     sc->stats.trace_ms = msC + msA;

@@ -69,10 +69,17 @@ struct DLight {
   uint32_t pad;
   double area;
 };
-struct DLightTri {  // 48 B
+// One triangle of a light's ShapeSet.  nn / ns / area are functions of the vertices only, so they
+// are evaluated once at upload with the reference's arithmetic (host code in dr_api.hip) instead of
+// at every path vertex: nn = DifferentialGeometry.nn of a hit on this triangle
+// (differential_geometry.dart:84-99), ns = the normal Triangle.sample returns (triangle.dart:376-381),
+// area = Triangle.area() (triangle.dart:265-269).
+struct DLightTri {  // 72 B
   float p[9];
   uint32_t reverse;
   double area;
+  float nn[3];
+  float ns[3];
 };
 struct DScene {
   const uint4* nodes;   // 2 x uint4 per node (DrBvhNode)
@@ -251,25 +258,18 @@ DR_DEV F3 shapeset_sample(const DScene& sc, const DLight& L, double uPos0, doubl
   double b1 = 1.0 - su1;
   double b2 = uPos1 * su1;
   F3 pt = vadd(vadd(vmul(a, b1), vmul(b, b2)), vmul(c, (1.0 - b1 - b2)));
-  F3 n = vnormalize(vcross(vsub(b, a), vsub(c, a)));
-  if (lt.reverse) n = F3{(float)((double)n.x * -1.0), (float)((double)n.y * -1.0), (float)((double)n.z * -1.0)};
-  *Ns = n;
+  *Ns = F3{lt.ns[0], lt.ns[1], lt.ns[2]};
   F3 rd = vsub(pt, p);
   double thit = 1.0;
-  bool anyHit = false;
   for (uint32_t i = 0; i < L.ntris; ++i) {
     const DLightTri& t = sc.ltris[L.first_tri + i];
     ltri_verts(t, &a, &b, &c);
     double th, bb1, bb2;
     if (tri_hit(a, b, c, p, rd, 1.0e-3, DR_INF, &th, &bb1, &bb2)) {
-      DGeo dg;
-      tri_dg(a, b, c, t.reverse, p, rd, th, &dg);
       thit = th;
-      *Ns = dg.nn;
-      anyHit = true;
+      *Ns = F3{t.nn[0], t.nn[1], t.nn[2]};  // dg.nn of the last hitting shape (shape_set.dart:71-77)
     }
   }
-  (void)anyHit;
   return vadd(p, vmul(rd, thit));
 }
 // ShapeSet.pdf(p, wi) (shape_set.dart:82-89) with Shape.pdf2 (shape.dart:100-121).
@@ -284,9 +284,9 @@ DR_DEV double shapeset_pdf(const DScene& sc, const DLight& L, F3 p, F3 wi) {
     if (!tri_hit(a, b, c, p, wi, 1.0e-3, DR_INF, &th, &bb1, &bb2)) {
       pdf2 = 0.0;
     } else {
-      DGeo dg;
-      tri_dg(a, b, c, t.reverse, p, wi, th, &dg);
-      pdf2 = vlen2(vsub(dg.p, p)) / (fabs(vdot(dg.nn, vneg(wi))) * tri_area(a, b, c));
+      const F3 q = vadd(p, vmul(wi, th));  // ray.pointAt(thit)
+      const F3 nn = F3{t.nn[0], t.nn[1], t.nn[2]};
+      pdf2 = vlen2(vsub(q, p)) / (fabs(vdot(nn, vneg(wi))) * t.area);
       if (isinf(pdf2)) pdf2 = 0.0;
     }
     pdf += t.area * pdf2;

@@ -252,7 +252,12 @@ struct TailSrc {
 };
 
 // One vertex of PathIntegrator.Li (path_integrator.dart:44-119).
-__global__ void __launch_bounds__(256) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
+#ifndef DR_SHADE_WAVES
+#define DR_SHADE_WAVES 2
+#endif
+#define DR_SHADE_BLOCK 512
+__global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
+  __shared__ PushScratch s_push;
   const uint32_t cap = st.cap;
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -347,17 +352,16 @@ __global__ void __launch_bounds__(256) k_shade_path(DScene sc, RenderParams rp, 
       stc(st.L, cap, slot, L);
       st.flags[slot] = pf;
     }
-    wave_push(q.closestQ, q.nClosest, pushCont, slot);
-    wave_push(q.closestQ, q.nClosest, (pf & PF_HAS_MIS) != 0, slot | Q_MIS_BIT);
-    wave_push(q.anyQ, q.nAny, (pf & PF_HAS_SH) != 0, slot);
-    wave_push(q.activeOut, q.nActiveOut, pf != 0, slot);
+    block_push(s_push, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, pushCont,
+               (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT);
   }
 }
 
 // DirectLightingIntegrator.Li with strategy "all" (direct_lighting_integrator.dart:30-68;
 // integrator.dart:39-77).  Stage s sets up the NEE of light s at the camera hit;
 // stage nLights finishes the sum.  st.beta carries UniformSampleAllLights' L.
-__global__ void __launch_bounds__(256) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
+__global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
+  __shared__ PushScratch s_push;
   const uint32_t cap = st.cap;
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -416,9 +420,8 @@ __global__ void __launch_bounds__(256) k_shade_direct(DScene sc, RenderParams rp
       }
       st.flags[slot] = pf;
     }
-    wave_push(q.closestQ, q.nClosest, (pf & PF_HAS_MIS) != 0, slot | Q_MIS_BIT);
-    wave_push(q.anyQ, q.nAny, (pf & PF_HAS_SH) != 0, slot);
-    wave_push(q.activeOut, q.nActiveOut, again, slot);
+    block_push(s_push, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, false,
+               (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, again, slot, Q_MIS_BIT);
   }
 }
 
@@ -538,11 +541,11 @@ void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) 
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_shade_path, dim3(grid), dim3(256), 0, s, sc, rp, st, q, bounce);
+  hipLaunchKernelGGL(k_shade_path, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_shade_direct, dim3(grid), dim3(256), 0, s, sc, rp, st, q, stage);
+  hipLaunchKernelGGL(k_shade_direct, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
                  hipStream_t s) {

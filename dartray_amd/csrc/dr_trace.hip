@@ -28,6 +28,9 @@
 #ifndef DR_LEAF_TH
 #define DR_LEAF_TH 16
 #endif
+#ifndef DR_WORK_CHUNK
+#define DR_WORK_CHUNK 256  // queue entries a wave reserves per atomic on the work counter
+#endif
 
 // ===========================================================================
 // v1: the first correct version (kept for A/B runs, DARTRAY_TRACE_IMPL=1): 64 queue entries per
@@ -363,16 +366,22 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
   uint32_t handle = 0, node = 0, leafOff = 0, leafN = 0;
   int sp = 0, hit = -1, mode = M_IDLE;
   bool exhausted = false;  // wave-uniform: the queue has no more entries
+  uint32_t resNext = 0, resEnd = 0;  // wave-uniform: this wave's reservation [resNext, resEnd) of queue indices
   for (;;) {
     // ---- refill idle lanes ----
     const unsigned long long idleMask = __ballot(mode == M_IDLE);
     const int nIdle = __popcll(idleMask);
     if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(work, (uint32_t)nIdle);
-      base = wave_bcast_first(base);
+      // Reserve DR_WORK_CHUNK entries per atomic: same-address atomics are a chip-wide serial resource.
+      const uint32_t left = resEnd - resNext;
+      uint32_t fresh = 0;
+      if (left < (uint32_t)nIdle) {
+        if (lane == 0) fresh = atomicAdd(work, (uint32_t)DR_WORK_CHUNK);
+        fresh = wave_bcast_first(fresh);
+      }
       if (mode == M_IDLE) {
-        const uint32_t idx = base + (uint32_t)__popcll(idleMask & ltMask);
+        const uint32_t j = (uint32_t)__popcll(idleMask & ltMask);
+        const uint32_t idx = j < left ? resNext + j : fresh + (j - left);
         if (idx < n) {
           io.load(idx, ray, handle);
           ++nRays;
@@ -386,7 +395,13 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           }
         }
       }
-      if (base + (uint32_t)nIdle >= n) exhausted = true;
+      if (left < (uint32_t)nIdle) {
+        resNext = fresh + ((uint32_t)nIdle - left);
+        resEnd = fresh + (uint32_t)DR_WORK_CHUNK;
+      } else {
+        resNext += (uint32_t)nIdle;
+      }
+      if (resNext >= n) exhausted = true;  // the counter is monotonic: every later reservation starts beyond n too
     }
     const unsigned long long travMask = __ballot(mode == M_TRAV);
     unsigned long long leafMask = __ballot(mode == M_LEAF);

@@ -172,6 +172,9 @@ typedef struct DrRenderStats {
   uint64_t batches;
   uint64_t closest_launches, any_launches; /* per kernel: k_trace<0> (closest hit), k_trace<1> (any hit) */
   double closest_ms, any_ms;
+  double shade_ms;  /* k_shade_path / k_shade_direct */
+  double gen_ms;    /* k_gen_samples (+ host-buffer transpose) and k_raygen */
+  double film_ms;   /* k_film */
 } DrRenderStats;
 
 /* Select the GPU.  Must precede everything else. */
