@@ -65,7 +65,7 @@ struct Workspace {
   int spillGrid = 0;
 };
 
-#define N_COUNTERS 1024
+#define N_COUNTERS 4096  // [0,1024): stage queue counts; [1024,4096): 8 per-XCD work counters per trace launch
 
 }  // namespace
 
@@ -149,8 +149,12 @@ void host_tri_normals(const float* a, const float* b, const float* c, bool rever
 }
 
 int traceGrid() {
-  // DR_LDS_STACK*256*4 = 32 KiB of LDS per workgroup => 5 workgroups (20 waves) per CU.
-  return g_numCU * 5;
+  // DR_LDS_STACK*256*4 bytes of LDS per workgroup (32 KiB at 32 entries => 5 workgroups = 20 waves per CU);
+  // at most 8 workgroups of 4 waves fit the 32-wave CU.
+  int perCU = (160 * 1024) / (DR_LDS_STACK * DR_TRACE_BLOCK * 4);
+  const char* e = getenv("DARTRAY_TRACE_WG_PER_CU");
+  if (e) perCU = atoi(e);
+  return g_numCU * std::max(1, std::min(perCU, 8));
 }
 
 int ensureSpill(DrScene* sc, int grid) {
@@ -462,9 +466,9 @@ int dr_intersect(DrScene* sc, const DrRay* rays, int64_t n, DrHit* out, int32_t 
   DevBuf<uint32_t> work;
   HIP_TRY(dR.alloc(n));
   HIP_TRY(dH.alloc(n));
-  HIP_TRY(work.alloc(1));
+  HIP_TRY(work.alloc(8));
   HIP_TRY(hipMemcpy(dR.p, rays, n * sizeof(DrRay), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(work.p, 0, sizeof(uint32_t)));
+  HIP_TRY(hipMemset(work.p, 0, 8 * sizeof(uint32_t)));
   HIP_TRY(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
   launch_intersect(sc->d, dR.p, n, dH.p, any_hit, sc->ws.spill.p, work.p, sc->ctr.p, grid, 0);
   HIP_TRY(hipGetLastError());
@@ -572,7 +576,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   HIP_TRY(hipStreamSynchronize(s));
   const int sgrid = g_numCU * 2;  // 512-thread workgroups, grid-stride over the active list
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : rp.nLights + 1;
-  if (4 * nStages + 8 > N_COUNTERS) return fail(DR_ERR_UNSUPPORTED, "too many stages");
+  if (4 * nStages + 8 > 1024 || 8 * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
 
   for (size_t p0 = 0; p0 < npixTotal; p0 += pixPerBatch) {
     const uint32_t np = (uint32_t)std::min<size_t>(pixPerBatch, npixTotal - p0);
@@ -600,11 +604,11 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     launch_raygen(rp, st, s);
     timed(3, evGen);
     uint32_t* C = w.counters.p;
-    int wc = 0;  // work counters live at C[512..]
+    int wc = 0;  // work counters live at C[1024..], 8 per launch
     auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any) {
       hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
       (void)hipEventRecord(e0, s);
-      launch_trace(sc->d, st, queue, nQ, any, w.spill.p, C + 512 + (wc++), sc->ctr.p, tgrid, s);
+      launch_trace(sc->d, st, queue, nQ, any, w.spill.p, C + 1024 + 8 * (wc++), sc->ctr.p, tgrid, s);
       (void)hipEventRecord(e1, s);
       sc->traceEvents.push_back({e0, e1, any});
     };

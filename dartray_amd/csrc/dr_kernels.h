@@ -79,7 +79,9 @@ struct TraceCounters {  // device-side totals (Stats probes of bvh_accel.dart:10
   unsigned long long closest_rays, any_rays, closest_nodes, any_nodes, closest_tris, any_tris;
 };
 
-#define DR_LDS_STACK 32       // stack entries per lane kept in LDS
+#ifndef DR_LDS_STACK
+#define DR_LDS_STACK 24       // stack entries per lane kept in LDS: 24 KiB per workgroup => 6 workgroups (24 waves) per CU
+#endif
 #define DR_MAX_STACK 128      // LDS + spill entries per lane (the reference uses 64, bvh_accel.dart:120)
 #define DR_TRACE_BLOCK 256
 

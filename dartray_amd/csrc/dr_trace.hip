@@ -23,13 +23,19 @@
 #include "dr_wave.h"
 
 #ifndef DR_REFILL_TH
-#define DR_REFILL_TH 20
+#define DR_REFILL_TH 16
 #endif
 #ifndef DR_LEAF_TH
-#define DR_LEAF_TH 16
+#define DR_LEAF_TH 12
+#endif
+#ifndef DR_TRACE_WAVES
+#define DR_TRACE_WAVES 6  // __launch_bounds__ minimum waves per SIMD for k_trace: 80 VGPRs, measured best (7 and 8 spill)
+#endif
+#ifndef DR_NSHARD
+#define DR_NSHARD 1  // work-queue shards: 1 = one shared counter; 8 = one per XCD.  Measured on C2: 8 shards are 12 % SLOWER (each XCD walks its own eighth of the queue, so the chip-wide working set in the shared Infinity Cache is 8 regions instead of 1)
 #endif
 #ifndef DR_WORK_CHUNK
-#define DR_WORK_CHUNK 256  // queue entries a wave reserves per atomic on the work counter
+#define DR_WORK_CHUNK 128  // queue entries a wave reserves per atomic on the work counter (256+ loses cache locality, 64 is atomic bound)
 #endif
 
 // ===========================================================================
@@ -297,6 +303,14 @@ DR_DEV int slab_f32(const TraceRay& r, float bminx, float bminy, float bminz, fl
   return sureHit ? 1 : (sureMiss ? 0 : -1);
 }
 
+// Pop: the LDS read is issued unconditionally (ds_read, not a flat load through a selected pointer);
+// the global spill is only touched by lanes deeper than DR_LDS_STACK.
+DR_DEV uint32_t stack_pop(const uint32_t* lds, const uint32_t* spill, uint32_t spillStride, int sp) {
+  uint32_t v = lds[(sp < DR_LDS_STACK ? sp : DR_LDS_STACK - 1) * DR_TRACE_BLOCK];
+  if (sp >= DR_LDS_STACK) v = spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
+  return v;
+}
+
 #define M_IDLE 0
 #define M_TRAV 1
 #define M_LEAF 2
@@ -367,22 +381,42 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
   int sp = 0, hit = -1, mode = M_IDLE;
   bool exhausted = false;  // wave-uniform: the queue has no more entries
   uint32_t resNext = 0, resEnd = 0;  // wave-uniform: this wave's reservation [resNext, resEnd) of queue indices
+  // XCD-aware work distribution: the queue is cut into 8 contiguous shards, one per XCD (each XCD has its
+  // own 4 MiB L2); a wave drains its own XCD's shard first and then steals from the others.  Placement is
+  // read from HW_REG_XCC_ID and only affects speed, never results.
+  uint32_t shard = ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (uint32_t)DR_NSHARD;  // XCC_ID[3:0]
+  uint32_t tried = 0;
   for (;;) {
     // ---- refill idle lanes ----
     const unsigned long long idleMask = __ballot(mode == M_IDLE);
     const int nIdle = __popcll(idleMask);
     if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
-      // Reserve DR_WORK_CHUNK entries per atomic: same-address atomics are a chip-wide serial resource.
-      const uint32_t left = resEnd - resNext;
-      uint32_t fresh = 0;
-      if (left < (uint32_t)nIdle) {
-        if (lane == 0) fresh = atomicAdd(work, (uint32_t)DR_WORK_CHUNK);
-        fresh = wave_bcast_first(fresh);
+      if (resNext == resEnd) {
+        // Reserve DR_WORK_CHUNK entries per atomic: same-address atomics are a chip-wide serial resource.
+        for (;;) {
+          if (tried == (uint32_t)DR_NSHARD) {
+            exhausted = true;
+            break;
+          }
+          const uint32_t s0 = (uint32_t)(((unsigned long long)n * shard) / DR_NSHARD);
+          const uint32_t s1 = (uint32_t)(((unsigned long long)n * (shard + 1u)) / DR_NSHARD);
+          uint32_t fresh = 0;
+          if (lane == 0) fresh = atomicAdd(work + shard, (uint32_t)DR_WORK_CHUNK);
+          fresh = wave_bcast_first(fresh);
+          if (fresh < s1 - s0) {
+            resNext = s0 + fresh;
+            resEnd = min(s0 + fresh + (uint32_t)DR_WORK_CHUNK, s1);
+            break;
+          }
+          shard = (shard + 1u) % (uint32_t)DR_NSHARD;  // this shard is drained (its counter only grows)
+          ++tried;
+        }
       }
+      const uint32_t take = min(resEnd - resNext, (uint32_t)nIdle);
       if (mode == M_IDLE) {
         const uint32_t j = (uint32_t)__popcll(idleMask & ltMask);
-        const uint32_t idx = j < left ? resNext + j : fresh + (j - left);
-        if (idx < n) {
+        if (j < take) {
+          const uint32_t idx = resNext + j;
           io.load(idx, ray, handle);
           ++nRays;
           if (sc.nnodes == 0) {
@@ -395,13 +429,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           }
         }
       }
-      if (left < (uint32_t)nIdle) {
-        resNext = fresh + ((uint32_t)nIdle - left);
-        resEnd = fresh + (uint32_t)DR_WORK_CHUNK;
-      } else {
-        resNext += (uint32_t)nIdle;
-      }
-      if (resNext >= n) exhausted = true;  // the counter is monotonic: every later reservation starts beyond n too
+      resNext += take;
     }
     const unsigned long long travMask = __ballot(mode == M_TRAV);
     unsigned long long leafMask = __ballot(mode == M_LEAF);
@@ -444,7 +472,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           finished = true;
         } else {
           --sp;
-          node = sp < DR_LDS_STACK ? lds[sp * DR_TRACE_BLOCK] : spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
+          node = stack_pop(lds, spill, spillStride, sp);
         }
       }
     }
@@ -479,7 +507,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           finished = true;
         } else {
           --sp;
-          node = sp < DR_LDS_STACK ? lds[sp * DR_TRACE_BLOCK] : spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
+          node = stack_pop(lds, spill, spillStride, sp);
           mode = M_TRAV;
         }
       }
@@ -493,7 +521,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
 }
 
 template <int ANY>
-__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace(DScene sc, BatchState st, const uint32_t* queue,
+__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE_WAVES) k_trace(DScene sc, BatchState st, const uint32_t* queue,
                                                           const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
                                                           TraceCounters* ctr) {
   __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
