@@ -89,7 +89,8 @@ def blob_mesh(segments=1000, rows=500, radius=5.0, centre=(0.0, -5.0, 0.0)):
 def hairball_mesh(strands=10000, segments=500, seed=0x9E3779B97F4A7C15, step=0.02, jitter=0.3, half_width=0.002,
                   scale=8.0):
     """Procedural hairball: each strand is a random walk from a point on the unit sphere, drawn as a
-    ribbon of 2 triangles per segment (10 000 x 500 x 2 = 10 000 000 triangles)."""
+    ribbon of 2 triangles per segment (10 000 x 500 x 2 = 10 000 000 triangles), scaled so that it
+    fits inside the Cornell box (max |coordinate| == `scale`)."""
     rng = np.random.Generator(np.random.PCG64(seed & 0xFFFFFFFFFFFFFFFF))
     v = rng.normal(size=(strands, 3))
     v /= np.linalg.norm(v, axis=1, keepdims=True)
@@ -105,8 +106,10 @@ def hairball_mesh(strands=10000, segments=500, seed=0x9E3779B97F4A7C15, step=0.0
     side = np.cross(pts[:, 1:] - pts[:, :-1], pts[:, :-1])
     side = np.concatenate([side, side[:, -1:]], axis=1)
     side /= np.maximum(np.linalg.norm(side, axis=2, keepdims=True), 1e-12)
-    left = (pts - half_width * side) * scale
-    right = (pts + half_width * side) * scale
+    # fit the ball inside the 20^3 box: the farthest strand point lands at |coordinate| == scale
+    fit = scale / np.abs(pts).max()
+    left = (pts - half_width * side) * fit
+    right = (pts + half_width * side) * fit
     P = np.stack([left, right], axis=2).reshape(-1, 3).astype(np.float32)  # vertex (strand, k, side)
     base = (np.arange(strands)[:, None] * (segments + 1) + np.arange(segments)[None, :]) * 2
     a, b, c, d = base, base + 1, base + 2, base + 3
