@@ -97,6 +97,11 @@ def main():
         achieved = alg_bytes / max(st["closest_ms"] * 1e-3, 1e-12) / 1e9
         peak = 8000.0  # HBM3E spec GB/s (MI355X_MICROARCH.md chip table)
         all_alg = alg_bytes + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if args.config == "C2" and args.res == 1024 and spp == 256 and world == 1 and os.path.exists(tpath):
+            # HBM-side bytes per launch of k_trace<0> from the PMC passes of this same command (see the file)
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
         out = {
             "metric": "Msamples/sec (primary+path rays)",
             "value": round(value, 3),
@@ -116,7 +121,7 @@ def main():
                        "samples_per_step": samples_per_step, "parallelism": "tiles32x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_trace<0> (closest-hit BVH traversal)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
-                         "traffic": None,
+                         "traffic": traffic,
                          "alg_bytes_per_launch": round(alg_bytes / launches, 1),
                          "avg_launch_ms": round(st["closest_ms"] / launches, 4), "launches": int(st["closest_launches"]),
                          "rank0_job_alg_GBps": round(all_alg / dt / 1e9, 2),

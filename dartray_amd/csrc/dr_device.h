@@ -18,6 +18,19 @@
 
 #define DR_DEV __device__ __forceinline__
 
+// Streaming accesses to the per-sample path state (read or written once per stage, ~5 GB per batch)
+// can be made non-temporal with -DDR_NT=1 (an experiment to keep the BVH resident in L2 / Infinity Cache).
+#ifndef DR_NT
+#define DR_NT 0  // measured on C2: no gain for k_trace / k_shade_path, and scattered nt stores defeat L2 write combining
+#endif
+#if DR_NT
+#define LDS_STREAM(p) __builtin_nontemporal_load(p)
+#define STS_STREAM(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define LDS_STREAM(p) (*(p))
+#define STS_STREAM(p, v) (*(p) = (v))
+#endif
+
 #define DR_INV_PI 0.31830988618379067154  // core/common.dart:23
 #define DR_PI 3.141592653589793
 #define DR_INF __longlong_as_double(0x7ff0000000000000LL)

@@ -49,10 +49,18 @@ DR_DEV float Sobol2(uint32_t n, uint32_t scramble) {  // montecarlo.dart:486-493
   return (float)((double)((scramble >> 8) & 0xffffffu) / 16777216.0);
 }
 
+// PT = uint8_t while spp <= 256 (half the LDS => twice the waves per CU), uint16_t above.  Rows of the
+// permutation table are padded (68 B / 132 B) so that both phases are bank-conflict free: Fisher-Yates
+// (lane = pixel, random row) and the write-out (consecutive lanes = consecutive rows of ONE pixel), which
+// makes every global store a fully coalesced 256-byte wave store.
+template <class PT, int ROW>
 __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState st, uint32_t npix) {
-  extern __shared__ uint16_t s_perm[];  // [spp][64]
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  PT* s_perm = (PT*)s_raw;                                      // [spp][ROW]
+  uint32_t* s_scr = (uint32_t*)(s_raw + (size_t)rp.spp * ROW * sizeof(PT));  // [2][64]
   const int lane = threadIdx.x;
-  const uint32_t p = blockIdx.x * 64u + lane;
+  const uint32_t p0 = blockIdx.x * 64u;
+  const uint32_t p = p0 + lane;
   const int k = blockIdx.y;  // LD block: image, lens, time, 1-D slots, 2-D slots (montecarlo.dart:437-448)
   const int spp = rp.spp;
   bool is2D;
@@ -62,28 +70,33 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
   else if (k == 2) { is2D = false; dst = 4; }
   else if (k < 3 + rp.n1D) { is2D = false; dst = 5 + (k - 3); }
   else { is2D = true; dst = 5 + rp.n1D + 2 * (k - 3 - rp.n1D); }
-  if (p >= npix) return;
-  const int2 xy = st.pix[p];
-  const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
-  DartRandom rng;
-  rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
-  // LDShuffleScrambled1D/2D with nSamples == 1 (montecarlo.dart:524-551)
-  const uint32_t s0 = rng.randomUint();
-  const uint32_t s1 = is2D ? rng.randomUint() : 0u;
-  for (int i = 0; i < spp; ++i) (void)rng.randomUint();  // Shuffle of ONE entry: other = i + r % 1 (:294-303)
-  for (int i = 0; i < spp; ++i) s_perm[i * 64 + lane] = (uint16_t)i;
-  for (int i = 0; i < spp; ++i) {
-    const int other = i + (int)(rng.randomUint() % (uint32_t)(spp - i));
-    const uint16_t a = s_perm[i * 64 + lane];
-    s_perm[i * 64 + lane] = s_perm[other * 64 + lane];
-    s_perm[other * 64 + lane] = a;
+  if (p < npix) {
+    const int2 xy = st.pix[p];
+    const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
+    DartRandom rng;
+    rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
+    // LDShuffleScrambled1D/2D with nSamples == 1 (montecarlo.dart:524-551)
+    s_scr[lane] = rng.randomUint();
+    s_scr[64 + lane] = is2D ? rng.randomUint() : 0u;
+    for (int i = 0; i < spp; ++i) (void)rng.randomUint();  // Shuffle of ONE entry: other = i + r % 1 (:294-303)
+    for (int i = 0; i < spp; ++i) s_perm[i * ROW + lane] = (PT)i;
+    for (int i = 0; i < spp; ++i) {
+      const int other = i + (int)(rng.randomUint() % (uint32_t)(spp - i));
+      const PT a = s_perm[i * ROW + lane];
+      s_perm[i * ROW + lane] = s_perm[other * ROW + lane];
+      s_perm[other * ROW + lane] = a;
+    }
   }
-  float* out0 = st.sv + (size_t)dst * st.cap + (size_t)p * spp;
+  __syncthreads();
+  // write-out: element e of this wave's 64*spp contiguous outputs belongs to pixel e >> sppShift
+  const uint32_t nOut = min(64u, npix - p0) * (uint32_t)spp;
+  float* out0 = st.sv + (size_t)dst * st.cap + (size_t)p0 * spp;
   float* out1 = out0 + st.cap;
-  for (int j = 0; j < spp; ++j) {
-    const uint32_t idx = s_perm[j * 64 + lane];
-    out0[j] = VanDerCorput(idx, s0);
-    if (is2D) out1[j] = Sobol2(idx, s1);
+  for (uint32_t e = lane; e < nOut; e += 64u) {
+    const uint32_t pl = e >> rp.sppShift, j = e & (uint32_t)(spp - 1);
+    const uint32_t idx = s_perm[j * ROW + pl];
+    out0[e] = VanDerCorput(idx, s_scr[pl]);
+    if (is2D) out1[e] = Sobol2(idx, s_scr[64 + pl]);
   }
 }
 
@@ -147,16 +160,28 @@ __global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) 
 // ---------------------------------------------------------------------------
 // shading
 // ---------------------------------------------------------------------------
-DR_DEV F3 ld3(const float* a, uint32_t cap, uint32_t s) { return F3{a[s], a[cap + s], a[2 * cap + s]}; }
-DR_DEV void st3(float* a, uint32_t cap, uint32_t s, F3 v) { a[s] = v.x; a[cap + s] = v.y; a[2 * cap + s] = v.z; }
-DR_DEV C3 ldc(const float* a, uint32_t cap, uint32_t s) { return C3{a[s], a[cap + s], a[2 * cap + s]}; }
-DR_DEV void stc(float* a, uint32_t cap, uint32_t s, C3 v) { a[s] = v.r; a[cap + s] = v.g; a[2 * cap + s] = v.b; }
+DR_DEV F3 ld3(const float* a, uint32_t cap, uint32_t s) {
+  return F3{LDS_STREAM(a + s), LDS_STREAM(a + cap + s), LDS_STREAM(a + 2 * (size_t)cap + s)};
+}
+DR_DEV void st3(float* a, uint32_t cap, uint32_t s, F3 v) {
+  STS_STREAM(a + s, v.x);
+  STS_STREAM(a + cap + s, v.y);
+  STS_STREAM(a + 2 * (size_t)cap + s, v.z);
+}
+DR_DEV C3 ldc(const float* a, uint32_t cap, uint32_t s) {
+  return C3{LDS_STREAM(a + s), LDS_STREAM(a + cap + s), LDS_STREAM(a + 2 * (size_t)cap + s)};
+}
+DR_DEV void stc(float* a, uint32_t cap, uint32_t s, C3 v) {
+  STS_STREAM(a + s, v.r);
+  STS_STREAM(a + cap + s, v.g);
+  STS_STREAM(a + 2 * (size_t)cap + s, v.b);
+}
 
 // EstimateDirect's contribution of the pending NEE rays (integrator.dart:135-145,169-180).
-DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uint32_t flags) {
+DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uint32_t flags, int shOcc, C3 Ld1) {
   const uint32_t cap = st.cap;
   C3 Ld = C3{0.f, 0.f, 0.f};
-  if ((flags & PF_HAS_SH) && st.shOcc[slot] == 0) Ld = cadd(Ld, ldc(st.Ld1, cap, slot));
+  if ((flags & PF_HAS_SH) && shOcc == 0) Ld = cadd(Ld, Ld1);
   if (flags & PF_HAS_MIS) {
     const int prim = st.misPrim[slot];
     if (prim >= 0) {
@@ -269,22 +294,37 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
     bool pushCont = false;
     if (valid) {
       slot = q.activeIn ? q.activeIn[idx] : idx;
+      // Every slot-indexed input is fetched up front (independent loads, ONE memory round trip; the
+      // state streams from HBM and this kernel runs at 2 waves per SIMD).  Arrays that were never
+      // written for this slot yield garbage that is never used.
       const uint32_t flags = st.flags[slot];
+      const int hprimIn = st.hprim[slot];
+      const double t = st.ht[slot];
+      const int shOccIn = st.shOcc[slot];
       C3 L = ldc(st.L, cap, slot);
+      C3 beta = ldc(st.beta, cap, slot);
+      const C3 betaNeeIn = ldc(st.betaNee, cap, slot);
+      const C3 Ld1In = ldc(st.Ld1, cap, slot);
+      const F3 o = ld3(st.ro, cap, slot), d = ld3(st.rd, cap, slot);
+      float su[10];  // this bounce's sample-vector slots (Appendix B): lightNum, light comp, light pos, bsdf dir, path dir
+      if (bounce < 3) {
+        const float* sv = st.sv;
+        su[0] = sv[(size_t)(5 + 4 * bounce + 1) * cap + slot];
+        su[1] = sv[(size_t)(5 + 4 * bounce + 0) * cap + slot];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) su[2 + k] = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce) + k) * cap + slot];
+      }
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
-        C3 Ld = resolve_nee(sc, st, slot, flags);
+        C3 Ld = resolve_nee(sc, st, slot, flags, shOccIn, Ld1In);
         C3 tot = cmulD(Ld, (double)rp.nLights);  // integrator.dart:113-116
-        L = cadd(L, cmul(ldc(st.betaNee, cap, slot), tot));
+        L = cadd(L, cmul(betaNeeIn, tot));
       }
-      const int prim = (flags & PF_HAS_CONT) ? st.hprim[slot] : -1;
+      const int prim = (flags & PF_HAS_CONT) ? hprimIn : -1;
       if (prim >= 0 && bounce <= rp.maxDepth) {
-        const F3 o = ld3(st.ro, cap, slot), d = ld3(st.rd, cap, slot);
-        const double t = st.ht[slot];
         Tri tr = load_tri(sc, (uint32_t)prim);
         DGeo dg;
         tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
-        C3 beta = ldc(st.beta, cap, slot);
         const F3 wo = vneg(d);
         if (bounce == 0) {  // specularBounce is never set by a matte BSDF
           C3 Le = tr.light >= 0 ? light_L(sc.lights[tr.light], dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
@@ -296,16 +336,15 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         TailSrc ts;
         const int perNee = rp.nLights > 0 ? 7 : 0;
         if (bounce >= 3) ts.init(rp, st, slot, (bounce - 3) * (perNee + 3) + (bounce > 4 ? bounce - 4 : 0));
-        const float* sv = st.sv;
         if (rp.nLights > 0) {
           double lu, ls0, ls1, lsc, bs0, bs1;
           if (bounce < 3) {  // SAMPLE_DEPTH (path_integrator.dart:139), slots of Appendix B
-            lu = sv[(size_t)(5 + 4 * bounce + 1) * cap + slot];
-            lsc = sv[(size_t)(5 + 4 * bounce + 0) * cap + slot];
-            ls0 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 0)) * cap + slot];
-            ls1 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 0) + 1) * cap + slot];
-            bs0 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 1)) * cap + slot];
-            bs1 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 1) + 1) * cap + slot];
+            lu = su[0];
+            lsc = su[1];
+            ls0 = su[2];
+            ls1 = su[3];
+            bs0 = su[4];
+            bs1 = su[5];
           } else {
             lu = ts.next(rp);                                   // integrator.dart:96
             ls0 = (float)ts.next(rp); ls1 = (float)ts.next(rp); // LightSample.random light_sample.dart:46-51
@@ -321,8 +360,8 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
         double o0, o1;
         if (bounce < 3) {
-          o0 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 2)) * cap + slot];
-          o1 = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce + 2) + 1) * cap + slot];
+          o0 = su[6];
+          o1 = su[7];
         } else {
           o0 = (float)ts.next(rp); o1 = (float)ts.next(rp);
           (void)ts.next(rp);
@@ -394,18 +433,18 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
         } else {
           tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
           dg.p = ld3(st.ro, cap, slot);
-          C3 Ld = resolve_nee(sc, st, slot, flags);               // Ld += EstimateDirect (one sample per light)
+          C3 Ld = resolve_nee(sc, st, slot, flags, st.shOcc[slot], ldc(st.Ld1, cap, slot));  // Ld += EstimateDirect (one sample per light)
           Lall = cadd(Lall, cdivD(Ld, 1.0));                      // L += Ld / nSamples
         }
         if (stage < rp.nLights) {
           Bsdf bsdf = make_bsdf(sc, dg, tr.mat);
           const float* sv = st.sv;
           // slots of light `stage` (direct_lighting_integrator.dart:70-87)
-          double lsc = sv[(size_t)(5 + 2 * stage) * cap + slot];
-          double ls0 = sv[(size_t)(5 + rp.n1D + 4 * stage) * cap + slot];
-          double ls1 = sv[(size_t)(5 + rp.n1D + 4 * stage + 1) * cap + slot];
-          double bs0 = sv[(size_t)(5 + rp.n1D + 4 * stage + 2) * cap + slot];
-          double bs1 = sv[(size_t)(5 + rp.n1D + 4 * stage + 3) * cap + slot];
+          double lsc = LDS_STREAM(sv + (size_t)(5 + 2 * stage) * cap + slot);
+          double ls0 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage) * cap + slot);
+          double ls1 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage + 1) * cap + slot);
+          double bs0 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage + 2) * cap + slot);
+          double bs1 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage + 3) * cap + slot);
           pf |= setup_nee(sc, st, slot, stage, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1);
           again = true;
         } else {
@@ -525,13 +564,19 @@ void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t*
 }
 void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s) {
   const int nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
-  const size_t lds = (size_t)rp.spp * 64 * sizeof(uint16_t);
-  static bool attrSet = false;
-  if (!attrSet) {
-    (void)hipFuncSetAttribute((const void*)k_gen_samples, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attrSet = true;
+  const dim3 grid((npix + 63) / 64, nBlocks);
+  if (rp.spp <= 256) {
+    const size_t lds = (size_t)rp.spp * 68 + 512;
+    hipLaunchKernelGGL((k_gen_samples<uint8_t, 68>), grid, dim3(64), lds, s, rp, st, npix);
+  } else {
+    const size_t lds = (size_t)rp.spp * 66 * sizeof(uint16_t) + 512;
+    static bool attrSet = false;
+    if (!attrSet) {
+      (void)hipFuncSetAttribute((const void*)k_gen_samples<uint16_t, 66>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attrSet = true;
+    }
+    hipLaunchKernelGGL((k_gen_samples<uint16_t, 66>), grid, dim3(64), lds, s, rp, st, npix);
   }
-  hipLaunchKernelGGL(k_gen_samples, dim3((npix + 63) / 64, nBlocks), dim3(64), lds, s, rp, st, npix);
 }
 void launch_transpose_samples(const float* aos, int stride, const BatchState& st, int nFloats, hipStream_t s) {
   hipLaunchKernelGGL(k_transpose_samples, dim3((st.nslots + 255) / 256), dim3(256), 0, s, aos, stride, st, nFloats);

@@ -325,20 +325,20 @@ struct StateIO {
     const uint32_t slot = e & ~Q_MIS_BIT;
     const uint32_t cap = st.cap;
     handle = e;
-    const F3 o = F3{st.ro[slot], st.ro[cap + slot], st.ro[2 * cap + slot]};
+    const F3 o = F3{LDS_STREAM(st.ro + slot), LDS_STREAM(st.ro + cap + slot), LDS_STREAM(st.ro + 2 * (size_t)cap + slot)};
     const float* dir = ANY ? st.shD : ((e & Q_MIS_BIT) ? st.misD : st.rd);
-    const F3 d = F3{dir[slot], dir[cap + slot], dir[2 * cap + slot]};
-    ray_init(r, o, d, st.rtmin[slot], ANY ? st.shTmax[slot] : DR_INF);
+    const F3 d = F3{LDS_STREAM(dir + slot), LDS_STREAM(dir + cap + slot), LDS_STREAM(dir + 2 * (size_t)cap + slot)};
+    ray_init(r, o, d, LDS_STREAM(st.rtmin + slot), ANY ? LDS_STREAM(st.shTmax + slot) : DR_INF);
   }
   DR_DEV void store(uint32_t handle, const TraceRay& r, int prim, const DScene&) const {
     const uint32_t slot = handle & ~Q_MIS_BIT;
     if (ANY) {
-      st.shOcc[slot] = (prim >= 0) ? 1 : 0;
+      STS_STREAM(st.shOcc + slot, (prim >= 0) ? 1 : 0);
     } else if (handle & Q_MIS_BIT) {
-      st.misPrim[slot] = prim;
+      STS_STREAM(st.misPrim + slot, prim);
     } else {
-      st.hprim[slot] = prim;
-      st.ht[slot] = r.tmax;
+      STS_STREAM(st.hprim + slot, prim);
+      STS_STREAM(st.ht + slot, r.tmax);
     }
   }
 };
