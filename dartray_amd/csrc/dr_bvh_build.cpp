@@ -11,6 +11,11 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
+#include <chrono>
+#include <cstdio>
 #include <vector>
 
 #include "../../include/dartray_hip.h"
@@ -60,33 +65,42 @@ struct Item {  // _BVHPrimitiveInfo (bvh_accel.dart:490-501)
   Box b;
 };
 
-struct TNode {
+struct TNode {  // trivially constructible: the scratch tree (2n slots) is allocated without initialisation
   Box b;
-  int32_t left = -1, right = -1;
-  uint32_t firstPrim = 0, nPrims = 0;
-  uint8_t axis = 0;
+  int32_t left, right;
+  int32_t itemStart, itemEnd;  // leaf: its primitives are items[itemStart, itemEnd)
+  uint32_t nPrims;
+  uint32_t axis;
+  uint32_t subNodes;   // nodes in this sub-tree
+  uint32_t subPrims;   // primitives in this sub-tree
+  uint32_t subDepth;   // height of this sub-tree
 };
 
+// The recursion of bvh_accel.dart:228-417.  Sub-trees only communicate through `orderedPrims` and the
+// node numbering, and both follow from the finished tree (right-child-first leaf order, left-first
+// depth-first numbering), so sub-trees are built by concurrent tasks and the two numberings are
+// assigned afterwards.  Inside one node the bounds / centroid-bounds / SAH-bucket passes are
+// order-independent reductions (min, max, integer counts) and run on several threads for big nodes;
+// the reference's two-pointer `partition` (common.dart:256-287) decides the order of the items
+// inside each half and is therefore kept serial.  The result is bit-identical for any thread count.
 class SahBuilder {
  public:
   std::vector<Item> items;
-  std::vector<TNode> tree;
-  std::vector<uint32_t> order;
+  TNode* tree = nullptr;
+  ~SahBuilder() { free(tree); }
+  std::atomic<int> running{1};
+  std::atomic<uint32_t> maxLeaf{1};  // largest multi-primitive leaf (rare: coincident centroids)
   int maxPrims = 4;
-  uint32_t depth = 0;
+  int maxThreads = 1;
 
-  int build(int start, int end, uint32_t d) {
-    depth = std::max(depth, d);
-    const int self = (int)tree.size();
-    tree.emplace_back();
-    Box bb;
-    bb.reset();
-    for (int i = start; i < end; ++i) bb.grow(items[i].b);
+  // Scratch-tree slots are handed out arithmetically, not through a shared counter: a sub-tree over n
+  // items has at most 2n-1 nodes, so the node of [start,end) sits at `self`, its left sub-tree starts at
+  // self+1 and its right sub-tree at self + 2*|left| -- no atomics on the hot path, depth-first locality.
+  int build(int start, int end, int self) {
     const int n = end - start;
+    Box bb, cb;
+    bounds(start, end, &bb, &cb);
     if (n == 1) return leaf(self, start, end, bb);
-    Box cb;
-    cb.reset();
-    for (int i = start; i < end; ++i) cb.growPoint(items[i].c);
     const int dim = cb.widestAxis();
     if (cb.hi[dim] == cb.lo[dim]) return leaf(self, start, end, bb);  // bvh_accel.dart:265-274
     int mid = (start + end) / 2;
@@ -94,19 +108,14 @@ class SahBuilder {
       sortRange(start, end, dim);  // nth_element (common.dart:289-297)
     } else {
       constexpr int NB = 12;
-      int cnt[NB] = {0};
-      Box bk[NB];
-      for (auto& b : bk) b.reset();
       const double cmin = cb.lo[dim], cmax = cb.hi[dim];
       auto bucketOf = [&](const Item& it) {
         int b = (int)(NB * (((double)it.c[dim] - cmin) / (cmax - cmin)));
         return b == NB ? NB - 1 : b;
       };
-      for (int i = start; i < end; ++i) {
-        int b = bucketOf(items[i]);
-        cnt[b]++;
-        bk[b].grow(items[i].b);
-      }
+      int cnt[NB];
+      Box bk[NB];
+      buckets(start, end, bucketOf, cnt, bk);
       float cost[NB - 1];  // Float32List (bvh_accel.dart:345)
       const double total = bb.area();
       for (int s = 0; s < NB - 1; ++s) {
@@ -128,25 +137,178 @@ class SahBuilder {
         return leaf(self, start, end, bb);
       }
     }
-    const int r = build(mid, end, d + 1);  // right child first (bvh_accel.dart:407-411)
-    const int l = build(start, mid, d + 1);
+    // Right child first (bvh_accel.dart:407-411) -- as a concurrent task when the range is big.
+    int r, l;
+    const int leftSlot = self + 1, rightSlot = self + 2 * (mid - start);
+    if (n > kTaskCutoff && acquireThread()) {
+      std::thread t([&] {
+        r = build(mid, end, rightSlot);
+        running.fetch_sub(1);
+      });
+      l = build(start, mid, leftSlot);
+      t.join();
+    } else {
+      r = build(mid, end, rightSlot);
+      l = build(start, mid, leftSlot);
+    }
     TNode& t = tree[self];
     t.left = l;
     t.right = r;
     t.b = tree[l].b;
     t.b.grow(tree[r].b);
-    t.axis = (uint8_t)dim;
+    t.axis = (uint32_t)dim;
     t.nPrims = 0;
+    t.itemStart = t.itemEnd = 0;
+    t.subNodes = 1 + tree[l].subNodes + tree[r].subNodes;
+    t.subPrims = tree[l].subPrims + tree[r].subPrims;
+    t.subDepth = 1 + std::max(tree[l].subDepth, tree[r].subDepth);
     return self;
   }
 
+  // orderedPrims + _flattenBVHTree (bvh_accel.dart:407-411,419-437) in one top-down pass: a node's index is
+  // its parent's + 1 (first child) or + 1 + |left sub-tree| (second child, stored in the parent's `offset`);
+  // the right sub-tree's primitives precede the left one's because the right child is built first.
+  void emit(int n, uint32_t index, uint32_t primBase, DrBvhNode* out, uint32_t* order) {
+    const TNode& t = tree[n];
+    DrBvhNode& o = out[index];
+    for (int k = 0; k < 3; ++k) {
+      o.bmin[k] = t.b.lo[k];
+      o.bmax[k] = t.b.hi[k];
+    }
+    o.pad = 0;
+    if (t.nPrims > 0) {
+      o.offset = primBase;
+      o.nprims = (uint16_t)t.nPrims;
+      o.axis = 0;
+      for (int i = t.itemStart; i < t.itemEnd; ++i) order[primBase + (uint32_t)(i - t.itemStart)] = items[i].prim;
+      return;
+    }
+    const uint32_t li = index + 1, ri = index + 1 + tree[t.left].subNodes;
+    o.offset = ri;
+    o.nprims = 0;
+    o.axis = (uint8_t)t.axis;
+    const uint32_t rightBase = primBase, leftBase = primBase + tree[t.right].subPrims;
+    if (t.subNodes > (uint32_t)kTaskCutoff && acquireThread()) {
+      std::thread th([&] {
+        emit(t.right, ri, rightBase, out, order);
+        running.fetch_sub(1);
+      });
+      emit(t.left, li, leftBase, out, order);
+      th.join();
+    } else {
+      emit(t.left, li, leftBase, out, order);
+      emit(t.right, ri, rightBase, out, order);
+    }
+  }
+
  private:
+  static constexpr int kTaskCutoff = 1 << 15;   // ranges above this may be built by their own task
+  static constexpr int kSliceCutoff = 1 << 20;  // ranges above this run their reductions on several threads
+
+  bool acquireThread() {
+    if (running.fetch_add(1) < maxThreads) return true;
+    running.fetch_sub(1);
+    return false;
+  }
+  // fn(lo, hi, slot): slot indexes a per-slice partial result
+  template <class F>
+  void slices(int start, int end, int* nSlices, F fn) {
+    int want = 1;
+    if (end - start > kSliceCutoff) want = std::max(1, std::min(16, maxThreads - running.load() + 1));
+    *nSlices = want;
+    if (want == 1) {
+      fn(start, end, 0);
+      return;
+    }
+    std::vector<std::thread> th;
+    const int64_t n = end - start;
+    for (int k = 1; k < want; ++k)
+      th.emplace_back([=] { fn(start + (int)(n * k / want), start + (int)(n * (k + 1) / want), k); });
+    fn(start, start + (int)(n / want), 0);
+    for (auto& t : th) t.join();
+  }
+  void bounds(int start, int end, Box* bb, Box* cb) {
+    if (end - start <= kSliceCutoff) {
+      bb->reset();
+      cb->reset();
+      for (int i = start; i < end; ++i) {
+        bb->grow(items[i].b);
+        cb->growPoint(items[i].c);
+      }
+      return;
+    }
+    Box pb[16], pc[16];
+    int ns = 1;
+    slices(start, end, &ns, [&](int lo, int hi, int k) {
+      Box b, c;
+      b.reset();
+      c.reset();
+      for (int i = lo; i < hi; ++i) {
+        b.grow(items[i].b);
+        c.growPoint(items[i].c);
+      }
+      pb[k] = b;
+      pc[k] = c;
+    });
+    *bb = pb[0];
+    *cb = pc[0];
+    for (int k = 1; k < ns; ++k) {
+      bb->grow(pb[k]);
+      cb->grow(pc[k]);
+    }
+  }
+  template <class B>
+  void buckets(int start, int end, B bucketOf, int* cnt, Box* bk) {
+    constexpr int NB = 12;
+    if (end - start <= kSliceCutoff) {
+      for (int b = 0; b < NB; ++b) {
+        cnt[b] = 0;
+        bk[b].reset();
+      }
+      for (int i = start; i < end; ++i) {
+        int b = bucketOf(items[i]);
+        cnt[b]++;
+        bk[b].grow(items[i].b);
+      }
+      return;
+    }
+    std::vector<int> pcnt(16 * NB, 0);
+    std::vector<Box> pbk(16 * NB);
+    for (auto& b : pbk) b.reset();
+    int ns = 1;
+    slices(start, end, &ns, [&](int lo, int hi, int k) {
+      int* c = &pcnt[k * NB];
+      Box* bx = &pbk[k * NB];
+      for (int i = lo; i < hi; ++i) {
+        int b = bucketOf(items[i]);
+        c[b]++;
+        bx[b].grow(items[i].b);
+      }
+    });
+    for (int b = 0; b < NB; ++b) {
+      cnt[b] = 0;
+      bk[b].reset();
+      for (int k = 0; k < ns; ++k) {
+        cnt[b] += pcnt[k * NB + b];
+        bk[b].grow(pbk[k * NB + b]);
+      }
+    }
+  }
   int leaf(int self, int start, int end, const Box& bb) {
     TNode& t = tree[self];
-    t.firstPrim = (uint32_t)order.size();
+    t.left = t.right = -1;
+    t.axis = 0;
+    t.itemStart = start;
+    t.itemEnd = end;
     t.nPrims = (uint32_t)(end - start);
+    if (t.nPrims > 1) {
+      for (uint32_t cur = maxLeaf.load(); t.nPrims > cur && !maxLeaf.compare_exchange_weak(cur, t.nPrims);) {
+      }
+    }
     t.b = bb;
-    for (int i = start; i < end; ++i) order.push_back(items[i].prim);
+    t.subNodes = 1;
+    t.subPrims = t.nPrims;
+    t.subDepth = 0;
     return self;
   }
   // partition (common.dart:256-287)
@@ -180,28 +342,6 @@ class SahBuilder {
   }
 };
 
-uint32_t flatten(const std::vector<TNode>& tree, int n, DrBvhNode* out, uint32_t* next) {
-  const uint32_t me = (*next)++;
-  const TNode& t = tree[n];
-  DrBvhNode& o = out[me];
-  for (int k = 0; k < 3; ++k) {
-    o.bmin[k] = t.b.lo[k];
-    o.bmax[k] = t.b.hi[k];
-  }
-  o.pad = 0;
-  if (t.nPrims > 0) {
-    o.offset = t.firstPrim;
-    o.nprims = (uint16_t)t.nPrims;
-    o.axis = 0;
-  } else {
-    o.nprims = 0;
-    o.axis = t.axis;
-    flatten(tree, t.left, out, next);
-    out[me].offset = flatten(tree, t.right, out, next);
-  }
-  return me;
-}
-
 }  // namespace
 
 extern "C" int dr_bvh_build(const float* verts, uint64_t nverts, const uint32_t* tri_idx, uint64_t ntris,
@@ -211,30 +351,47 @@ extern "C" int dr_bvh_build(const float* verts, uint64_t nverts, const uint32_t*
   *nnodes_out = 0;
   if (depth_out) *depth_out = 0;
   if (ntris == 0) return DR_OK;
-  if (!verts || !tri_idx || !nodes_out || !order_out || ntris >= (1ull << 31)) return DR_ERR_INVALID;
+  if (!verts || !tri_idx || !nodes_out || !order_out || ntris >= (1ull << 30)) return DR_ERR_INVALID;
+  for (uint64_t i = 0; i < 3 * ntris; ++i)
+    if (tri_idx[i] >= nverts) return DR_ERR_INVALID;
   SahBuilder b;
   b.maxPrims = std::min(255, max_prims_in_node > 0 ? max_prims_in_node : 4);  // bvh_accel.dart:44
+  const char* env = getenv("DARTRAY_BUILD_THREADS");
+  int hw = (int)std::thread::hardware_concurrency();
+  b.maxThreads = env ? std::max(1, atoi(env)) : std::max(1, std::min(hw, 64));
+  const bool dbg = getenv("DARTRAY_BUILD_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   b.items.resize(ntris);
-  for (uint64_t i = 0; i < ntris; ++i) {
-    Item& it = b.items[i];
-    it.prim = (uint32_t)i;
-    it.b.reset();
-    for (int k = 0; k < 3; ++k) {
-      if (tri_idx[3 * i + k] >= nverts) return DR_ERR_INVALID;
-      it.b.growPoint(verts + 3 * (size_t)tri_idx[3 * i + k]);  // Triangle.worldBound (triangle.dart:39-42)
+  auto fill = [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; ++i) {
+      Item& it = b.items[i];
+      it.prim = (uint32_t)i;
+      it.b.reset();
+      for (int k = 0; k < 3; ++k) it.b.growPoint(verts + 3 * (size_t)tri_idx[3 * i + k]);  // Triangle.worldBound (triangle.dart:39-42)
+      for (int k = 0; k < 3; ++k)  // BBox.center: (pMin*0.5) + (pMax*0.5), each a Point (bbox.dart:66)
+        it.c[k] = (float)((double)(float)((double)it.b.lo[k] * 0.5) + (double)(float)((double)it.b.hi[k] * 0.5));
     }
-    for (int k = 0; k < 3; ++k)  // BBox.center: (pMin*0.5) + (pMax*0.5), each a Point (bbox.dart:66)
-      it.c[k] = (float)((double)(float)((double)it.b.lo[k] * 0.5) + (double)(float)((double)it.b.hi[k] * 0.5));
+  };
+  {
+    const int nt = ntris > (1u << 20) ? std::min(b.maxThreads, 16) : 1;
+    std::vector<std::thread> th;
+    for (int k = 1; k < nt; ++k) th.emplace_back(fill, ntris * k / nt, ntris * (k + 1) / nt);
+    fill(0, ntris / nt);
+    for (auto& t : th) t.join();
   }
-  b.tree.reserve(2 * ntris);
-  b.order.reserve(ntris);
-  b.build(0, (int)ntris, 0);
-  for (const TNode& t : b.tree)
-    if (t.nPrims > 65535) return DR_ERR_UNSUPPORTED;
-  uint32_t next = 0;
-  flatten(b.tree, 0, nodes_out, &next);
-  *nnodes_out = next;
-  memcpy(order_out, b.order.data(), ntris * sizeof(uint32_t));
-  if (depth_out) *depth_out = b.depth;
+  const double t1 = now();
+  b.tree = (TNode*)malloc(2 * ntris * sizeof(TNode));  // upper bound on the node count (one-primitive leaves)
+  if (!b.tree) return DR_ERR_INVALID;
+  const double t2 = now();
+  const int root = b.build(0, (int)ntris, 0);
+  const double t3 = now();
+  if (b.maxLeaf.load() > 65535) return DR_ERR_UNSUPPORTED;
+  b.emit(root, 0, 0, nodes_out, order_out);
+  *nnodes_out = b.tree[root].subNodes;
+  if (dbg)
+    fprintf(stderr, "dr_bvh_build: %d threads, fill %.3f s, alloc %.3f s, build %.3f s, emit %.3f s\n", b.maxThreads, t1 - t0,
+            t2 - t1, t3 - t2, now() - t3);
+  if (depth_out) *depth_out = b.tree[root].subDepth;
   return DR_OK;
 }

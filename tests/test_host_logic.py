@@ -61,6 +61,18 @@ def test_host_bvh_builder_equals_oracle(ob, hip, name):
     assert np.array_equal(acc.tri_light, exp_light)
 
 
+def test_parallel_builder_is_thread_count_invariant(hip, monkeypatch):
+    """the parallel SAH builder (concurrent sub-tree tasks) yields the same bytes for any
+    thread count -- the tree only depends on the reference's algorithm, not on scheduling."""
+    prims = scenes.cornell_prims(scenes.blob_prim(300, 150))  # 90k triangles: above the task cut-off
+    out = []
+    for th in ("1", "3", "8"):
+        monkeypatch.setenv("DARTRAY_BUILD_THREADS", th)
+        acc = core.BVHAccel(prims)
+        out.append((acc.nodes.tobytes(), acc.tri_idx.tobytes(), acc.depth))
+    assert out[0] == out[1] == out[2]
+
+
 def test_refine_reverses_triangle_order():
     # Primitive.fullyRefine pops a LIFO stack (primitive.dart:71-84)
     m = core.TriangleMesh(np.arange(12).reshape(4, 3), np.zeros((12, 3)))
