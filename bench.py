@@ -32,8 +32,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C2", choices=["C2", "C4"])
-    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--config", default="C2", choices=["C2", "C4", "C5"])
+    ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pixels", type=int, default=96, help="cpu baseline: side of the strided pixel grid")
@@ -51,10 +51,11 @@ def main():
     torch.cuda.set_device(local)
     _abi.init(local)
 
-    spp = args.spp or (256 if args.config == "C2" else 64)
+    spp = args.spp or {"C2": 256, "C4": 64, "C5": 512}[args.config]
+    args.res = args.res or {"C2": 1024, "C4": 1024, "C5": 2048}[args.config]
     prims, mk = scenes.config(args.config, xres=args.res, yres=args.res, spp=spp)
     renderer = drdist.shard(mk(), rank, world)
-    scene = scenes.make_scene(prims)  # every rank builds + uploads its own copy (render_isolate.dart:31-41)
+    scene = scenes.make_scene(prims, renderer.env)  # every rank builds + uploads its own copy (render_isolate.dart:31-41)
     film_desc = renderer.camera.film
     H, W = film_desc.height, film_desc.width
     film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
@@ -115,8 +116,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s: Cornell box + %s, PathIntegrator maxdepth=5, %dx%d, %d spp, LD sampler (device, counter streams), box filter"
-                       % (args.config, "1M-triangle displaced blob" if args.config == "C2" else "10M-triangle hairball", args.res, args.res, spp),
+            "config": {"workload": "%s: %s, PathIntegrator maxdepth=%d, %dx%d, %d spp, LD sampler (device, counter streams), box filter"
+                       % (args.config, {"C2": "Cornell box + 1M-triangle displaced blob", "C4": "Cornell box + 10M-triangle hairball",
+                                        "C5": "8M-triangle courtyard, 8 area lights + env map"}[args.config],
+                          renderer.surfaceIntegrator.maxDepth, args.res, args.res, spp),
                        "triangles": int(len(scene.aggregate.tri_idx)), "bvh_nodes": int(len(scene.aggregate.nodes)),
                        "samples_per_step": samples_per_step, "parallelism": "tiles32x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_trace<0> (closest-hit BVH traversal)",

@@ -14,6 +14,8 @@ DR_INTEGRATOR_DIRECT_ALL = 0
 DR_INTEGRATOR_PATH = 1
 DR_SAMPLER_HOST_BUFFER = 0
 DR_SAMPLER_COUNTER = 1
+DR_LIGHT_DIFFUSE_AREA = 0
+DR_LIGHT_INFINITE = 1
 
 
 class DrBvhNode(C.Structure):
@@ -26,7 +28,13 @@ class DrMaterial(C.Structure):
 
 
 class DrAreaLight(C.Structure):
-    _fields_ = [("L", C.c_float * 3), ("nsamples", C.c_int32), ("first_tri", C.c_uint32), ("ntris", C.c_uint32)]
+    _fields_ = [("L", C.c_float * 3), ("nsamples", C.c_int32), ("first_tri", C.c_uint32), ("ntris", C.c_uint32),
+                ("kind", C.c_uint32), ("env_index", C.c_uint32)]
+
+
+class DrEnvMap(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+                ("light_to_world", C.c_float * 16), ("world_to_light", C.c_float * 16)]
 
 
 class DrLightTri(C.Structure):
@@ -41,7 +49,8 @@ class DrSceneDesc(C.Structure):
                 ("materials", C.c_void_p), ("nmaterials", C.c_uint32),
                 ("lights", C.c_void_p), ("nlights", C.c_uint32),
                 ("light_tris", C.c_void_p), ("nlight_tris", C.c_uint32),
-                ("bvh_depth", C.c_uint32)]
+                ("bvh_depth", C.c_uint32),
+                ("env_maps", C.c_void_p), ("nenv_maps", C.c_uint32)]
 
 
 class DrRay(C.Structure):

@@ -69,6 +69,32 @@ class DiffuseAreaLight:
         self.shape = shape
 
 
+class InfiniteAreaLight:
+    """lights/infinite_area_light.dart:36-68.  `texels` is the radiance map's level-0 image [H, W, 3] f32
+    (MIPMap.pyramid[0]; power-of-two size) -- None gives the 1x1 white map of the no-'mapname' case;
+    `L` the factor _radiance() multiplies in (:180-182).  NB when the reference loads a map from a file it
+    ALSO pre-multiplies the texels by L (:44-49), i.e. L is applied twice; callers that want that pass
+    pre-multiplied texels."""
+
+    def __init__(self, light2world=None, L=(1.0, 1.0, 1.0), nSamples=1, texels=None):
+        m = np.eye(4, dtype=np.float32) if light2world is None else np.asarray(light2world, np.float32).reshape(4, 4)
+        self.lightToWorld = m
+        self.worldToLight = np.linalg.inv(m.astype(np.float64)).astype(np.float32)  # Transform.Inverse (light.dart:30)
+        self.L = np.asarray(L, dtype=np.float32).reshape(3)
+        self.Lemit = self.L
+        self.nSamples = max(1, int(nSamples))
+        if texels is None:
+            texels = np.ones((1, 1, 3), dtype=np.float32)
+        self.texels = np.ascontiguousarray(texels, dtype=np.float32)
+        h, w = self.texels.shape[:2]
+        if w & (w - 1) or h & (h - 1):
+            raise NotImplementedError("non power-of-two radiance maps are resampled by MIPMap (mipmap.dart:69-138): not on the path")
+        self.shape = None
+
+    def isDeltaLight(self):
+        return False
+
+
 class GeometricPrimitive:
     """core/primitive/geometric_primitive.dart:27-29."""
 
@@ -232,7 +258,20 @@ class _DeviceScene:
         for gp in accel.prims_in:
             base_of[id(gp.shape)] = base
             base += len(gp.shape.P)
+        envs = []
         for i, L in enumerate(self.lights):
+            if isinstance(L, InfiniteAreaLight):
+                e = _abi.DrEnvMap()
+                e.texels = L.texels.ctypes.data
+                e.height, e.width = L.texels.shape[0], L.texels.shape[1]
+                e.light_to_world[:] = [float(v) for v in L.lightToWorld.reshape(-1)]
+                e.world_to_light[:] = [float(v) for v in L.worldToLight.reshape(-1)]
+                dl[i].L[:] = [float(x) for x in L.L]
+                dl[i].nsamples = L.nSamples
+                dl[i].kind = _abi.DR_LIGHT_INFINITE
+                dl[i].env_index = len(envs)
+                envs.append(e)
+                continue
             mesh = L.shape
             first = len(ltris)
             for t in mesh.refine():
@@ -248,7 +287,10 @@ class _DeviceScene:
             lt[i].reverse_orientation = t[3]
         d = _abi.DrSceneDesc()
         n = len(accel.tri_idx)
-        self._keep = (mats, dl, lt)
+        env_arr = (_abi.DrEnvMap * max(len(envs), 1))(*envs)
+        d.env_maps = C.cast(env_arr, C.c_void_p)
+        d.nenv_maps = len(envs)
+        self._keep = (mats, dl, lt, env_arr)
         d.nodes = accel.nodes.ctypes.data if accel.nodes is not None else None
         d.nnodes = len(accel.nodes) if accel.nodes is not None else 0
         d.verts = accel.verts.ctypes.data
@@ -256,7 +298,15 @@ class _DeviceScene:
         d.tri_idx = accel.tri_idx.ctypes.data
         d.ntris = n
         d.tri_material = accel.tri_material.ctypes.data
-        d.tri_light = accel.tri_light.ctypes.data
+        # per-primitive area-light index = position of its DiffuseAreaLight in Scene.lights
+        pos = np.full(len(accel._lights) + 1, -1, dtype=np.int32)
+        for i, al in enumerate(accel._lights):
+            if al not in self.lights:
+                raise ValueError("an emissive primitive's area light is missing from Scene.lights")
+            pos[i] = self.lights.index(al)
+        tri_light = np.ascontiguousarray(np.where(accel.tri_light >= 0, pos[accel.tri_light], -1).astype(np.int32))
+        self._keep = self._keep + (tri_light,)
+        d.tri_light = tri_light.ctypes.data
         d.tri_reverse = accel.tri_reverse.ctypes.data
         d.materials = C.cast(mats, C.c_void_p)
         d.nmaterials = len(accel.materials)

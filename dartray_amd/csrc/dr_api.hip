@@ -76,6 +76,7 @@ struct DrScene {
   DevBuf<DLight> lights;
   DevBuf<DLightTri> ltris;
   DevBuf<float> lcdf;
+  DevBuf<float> envTexels, envCondFunc, envCondCdf, envCondInt, envMargFunc, envMargCdf;
   DevBuf<TraceCounters> ctr;
   uint32_t bvhDepth = 0;
   std::vector<int32_t> lightNSamples;
@@ -386,15 +387,30 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     std::vector<DLight> L(std::max<uint32_t>(desc->nlights, 1));
     std::vector<DLightTri> LT(std::max<uint32_t>(desc->nlight_tris, 1));
     std::vector<float> cdf;
+    int envLight = -1;
     for (uint32_t i = 0; i < desc->nlights; ++i) {
       const DrAreaLight& a = desc->lights[i];
+      if (a.kind == DR_LIGHT_INFINITE) {
+        if (a.env_index >= desc->nenv_maps || !desc->env_maps) return bail(DR_ERR_INVALID, "infinite light without a radiance map");
+        if (envLight >= 0) return bail(DR_ERR_UNSUPPORTED, "more than one infinite light");
+        envLight = (int)i;
+        DLight& d = L[i];
+        d.L[0] = a.L[0]; d.L[1] = a.L[1]; d.L[2] = a.L[2];
+        d.nsamples = std::max(1, a.nsamples);
+        d.first_tri = d.ntris = d.cdf_off = 0;
+        d.kind = DR_LIGHT_INFINITE;
+        d.area = 0.0;
+        sc->lightNSamples.push_back(d.nsamples);
+        continue;
+      }
+      if (a.kind != DR_LIGHT_DIFFUSE_AREA) return bail(DR_ERR_INVALID, "unknown light kind");
       if (a.ntris == 0 || (uint64_t)a.first_tri + a.ntris > desc->nlight_tris) return bail(DR_ERR_INVALID, "light triangle range");
       DLight& d = L[i];
       d.L[0] = a.L[0]; d.L[1] = a.L[1]; d.L[2] = a.L[2];
       d.nsamples = std::max(1, a.nsamples);
       d.first_tri = a.first_tri;
       d.ntris = a.ntris;
-      d.pad = 0;
+      d.kind = DR_LIGHT_DIFFUSE_AREA;
       sc->lightNSamples.push_back(d.nsamples);
       double area = 0.0;
       std::vector<double> areas(a.ntris);
@@ -428,6 +444,89 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       cdf.insert(cdf.end(), c.begin(), c.end());
     }
     if (cdf.empty()) cdf.push_back(0.f);
+    memset(&sc->d.env, 0, sizeof(sc->d.env));
+    sc->d.hasEnv = 0;
+    if (envLight >= 0) {
+      const DrAreaLight& a = desc->lights[envLight];
+      const DrEnvMap& m = desc->env_maps[a.env_index];
+      const int w = m.width, h = m.height;
+      if (!m.texels || w <= 0 || h <= 0 || (w & (w - 1)) || (h & (h - 1)))
+        return bail(DR_ERR_UNSUPPORTED, "radiance map must have power-of-two width and height (mipmap.dart:69-138 resamples others)");
+      // _setRadianceMap (infinite_area_light.dart:283-307): img = luminance(_radiance(u/w, v/h, filter)) * sin(theta),
+      // filter = 1/max(w,h).  For a power-of-two map MIPMap.lookup's level = levels-1 + log2(filter) is 0 up to
+      // rounding (mipmap.dart:211): either `triangle(0,s,t)` directly or triangle(0)*(1-d) + triangle(1)*d with
+      // d ~ 1e-15, which rounds to the same f32 -- so the bilinear level-0 value is used.
+      std::vector<float> img((size_t)w * h);
+      auto texel = [&](int s, int t, int c) {
+        s %= w; if (s < 0) s += w;
+        t %= h; if (t < 0) t += h;
+        return (double)m.texels[3 * ((size_t)t * w + s) + c];
+      };
+      for (int v = 0; v < h; ++v) {
+        const double sinTheta = std::sin(3.141592653589793 * (v + 0.5) / h);
+        for (int u = 0; u < w; ++u) {
+          double s = ((double)u / w) * w - 0.5, t = ((double)v / h) * h - 0.5;
+          const int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
+          const double ds = s - s0, dt = t - t0;
+          double rgbv[3];
+          for (int c = 0; c < 3; ++c) {
+            double acc = r32(texel(s0, t0, c) * ((1.0 - ds) * (1.0 - dt)));
+            acc = r32(acc + r32(texel(s0, t0 + 1, c) * ((1.0 - ds) * dt)));
+            acc = r32(acc + r32(texel(s0 + 1, t0, c) * (ds * (1.0 - dt))));
+            acc = r32(acc + r32(texel(s0 + 1, t0 + 1, c) * (ds * dt)));
+            rgbv[c] = r32(acc * (double)a.L[c]);
+          }
+          float y = (float)(0.212671 * rgbv[0] + 0.715160 * rgbv[1] + 0.072169 * rgbv[2]);
+          img[u + (size_t)v * w] = (float)((double)y * sinTheta);
+        }
+      }
+      // Distribution2D (montecarlo.dart:223-237): one Distribution1D per row + the marginal over their integrals
+      auto dist1d = [](const float* f, int count, float* func, float* c, float* funcIntOut) {
+        for (int k = 0; k < count; ++k) func[k] = f[k];
+        c[0] = 0.0f;
+        for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)c[k - 1] + (double)func[k - 1] / (double)count);
+        const double funcInt = c[count];
+        if (funcInt == 0.0) {
+          for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)k / (double)count);
+        } else {
+          for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)c[k] / funcInt);
+        }
+        *funcIntOut = (float)funcInt;
+      };
+      std::vector<float> cf((size_t)w * h), cc((size_t)(w + 1) * h), ci(h), mf(h), mc(h + 1);
+      for (int v = 0; v < h; ++v) dist1d(&img[(size_t)v * w], w, &cf[(size_t)v * w], &cc[(size_t)v * (w + 1)], &ci[v]);
+      float mi = 0.f;
+      dist1d(ci.data(), h, mf.data(), mc.data(), &mi);
+      TRY_SC(sc->envTexels.alloc(3 * (size_t)w * h));
+      TRY_SC(hipMemcpy(sc->envTexels.p, m.texels, 3 * (size_t)w * h * sizeof(float), hipMemcpyHostToDevice));
+      TRY_SC(sc->envCondFunc.alloc(cf.size()));
+      TRY_SC(hipMemcpy(sc->envCondFunc.p, cf.data(), cf.size() * sizeof(float), hipMemcpyHostToDevice));
+      TRY_SC(sc->envCondCdf.alloc(cc.size()));
+      TRY_SC(hipMemcpy(sc->envCondCdf.p, cc.data(), cc.size() * sizeof(float), hipMemcpyHostToDevice));
+      TRY_SC(sc->envCondInt.alloc(ci.size()));
+      TRY_SC(hipMemcpy(sc->envCondInt.p, ci.data(), ci.size() * sizeof(float), hipMemcpyHostToDevice));
+      TRY_SC(sc->envMargFunc.alloc(mf.size()));
+      TRY_SC(hipMemcpy(sc->envMargFunc.p, mf.data(), mf.size() * sizeof(float), hipMemcpyHostToDevice));
+      TRY_SC(sc->envMargCdf.alloc(mc.size()));
+      TRY_SC(hipMemcpy(sc->envMargCdf.p, mc.data(), mc.size() * sizeof(float), hipMemcpyHostToDevice));
+      DEnv& e = sc->d.env;
+      e.texels = sc->envTexels.p;
+      e.condFunc = sc->envCondFunc.p;
+      e.condCdf = sc->envCondCdf.p;
+      e.condInt = sc->envCondInt.p;
+      e.margFunc = sc->envMargFunc.p;
+      e.margCdf = sc->envMargCdf.p;
+      e.margInt = mi;
+      e.w = w;
+      e.h = h;
+      for (int c = 0; c < 3; ++c) e.L[c] = a.L[c];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          e.l2w[3 * r + c] = m.light_to_world[4 * r + c];
+          e.w2l[3 * r + c] = m.world_to_light[4 * r + c];
+        }
+      sc->d.hasEnv = 1;
+    }
     TRY_SC(sc->lights.alloc(L.size()));
     TRY_SC(hipMemcpy(sc->lights.p, L.data(), L.size() * sizeof(DLight), hipMemcpyHostToDevice));
     TRY_SC(sc->ltris.alloc(LT.size()));

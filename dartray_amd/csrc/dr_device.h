@@ -79,8 +79,21 @@ struct DLight {
   int32_t nsamples;
   uint32_t first_tri, ntris;
   uint32_t cdf_off;  // into lcdf: ntris+1 floats
-  uint32_t pad;
+  uint32_t kind;     // DR_LIGHT_DIFFUSE_AREA / DR_LIGHT_INFINITE
   double area;
+};
+// InfiniteAreaLight: level-0 radiance texels + Distribution2D (montecarlo.dart:222-268) tables.
+struct DEnv {
+  const float* texels;    // [h][w][3]
+  const float* condFunc;  // [h][w]      pConditionalV[v].func
+  const float* condCdf;   // [h][w+1]    pConditionalV[v].cdf
+  const float* condInt;   // [h]         pConditionalV[v].funcInt (an f32 value)
+  const float* margFunc;  // [h]
+  const float* margCdf;   // [h+1]
+  float margInt;
+  int32_t w, h;
+  float L[3];
+  float l2w[9], w2l[9];   // rows of the 3x3 part of lightToWorld / worldToLight
 };
 // One triangle of a light's ShapeSet.  nn / ns / area are functions of the vertices only, so they
 // are evaluated once at upload with the reference's arithmetic (host code in dr_api.hip) instead of
@@ -102,6 +115,8 @@ struct DScene {
   const DLightTri* ltris;
   const float* lcdf;
   uint32_t nnodes, ntris, nlights, nmats;
+  DEnv env;
+  int32_t hasEnv;
 };
 
 struct Tri {
@@ -308,6 +323,107 @@ DR_DEV double shapeset_pdf(const DScene& sc, const DLight& L, F3 p, F3 wi) {
 }
 DR_DEV C3 light_L(const DLight& L, F3 n, F3 w) {  // diffuse_area_light.dart:44-46
   return vdot(n, w) > 0.0 ? C3{L.L[0], L.L[1], L.L[2]} : C3{0.f, 0.f, 0.f};
+}
+
+// ---- InfiniteAreaLight (lights/infinite_area_light.dart; core/mipmap.dart; montecarlo.dart:222-268) -------
+DR_DEV int emod(int a, int m) {  // Dart's % is Euclidean
+  int r = a % m;
+  return r < 0 ? r + m : r;
+}
+DR_DEV C3 env_texel(const DEnv& e, int s, int t) {  // MIPMap.texel, TEXTURE_REPEAT (mipmap.dart:184-207)
+  const float* p = e.texels + 3 * ((size_t)emod(t, e.h) * e.w + emod(s, e.w));
+  return C3{p[0], p[1], p[2]};
+}
+// _radiance(u, v) with width 0: MIPMap.lookup takes the `level < 0` branch => triangle(0, s, t)
+// (mipmap.dart:209-224,342-355), then * L (infinite_area_light.dart:180-182).
+DR_DEV C3 env_radiance(const DEnv& e, double s, double t) {
+  s = s * e.w - 0.5;
+  t = t * e.h - 0.5;
+  const int s0 = (int)floor(s), t0 = (int)floor(t);
+  const double ds = s - s0, dt = t - t0;
+  C3 v = cadd(cadd(cadd(cmulD(env_texel(e, s0, t0), ((1.0 - ds) * (1.0 - dt))),
+                        cmulD(env_texel(e, s0, t0 + 1), ((1.0 - ds) * dt))),
+                   cmulD(env_texel(e, s0 + 1, t0), (ds * (1.0 - dt)))),
+              cmulD(env_texel(e, s0 + 1, t0 + 1), (ds * dt)));
+  return cmul(v, C3{e.L[0], e.L[1], e.L[2]});
+}
+DR_DEV F3 xf3(const float* m, F3 p) {  // Transform.transformVector (transform.dart:130-144)
+  const double x = p.x, y = p.y, z = p.z;
+  return f3((double)m[0] * x + (double)m[1] * y + (double)m[2] * z, (double)m[3] * x + (double)m[4] * y + (double)m[5] * z,
+            (double)m[6] * x + (double)m[7] * y + (double)m[8] * z);
+}
+DR_DEV double SphericalTheta(F3 v) {  // vector.dart:195-197
+  double z = v.z;
+  z = z < -1.0 ? -1.0 : (z > 1.0 ? 1.0 : z);
+  return acos(z);
+}
+DR_DEV double SphericalPhi(F3 v) {  // vector.dart:199-202
+  double p = atan2((double)v.y, (double)v.x);
+  return (p < 0.0) ? p + 2.0 * DR_PI : p;
+}
+#define DR_INV_TWOPI 0.15915494309189533577
+DR_DEV C3 env_Le(const DEnv& e, F3 dir) {  // infinite_area_light.dart:84-90
+  F3 wh = vnormalize(xf3(e.w2l, dir));
+  const double s = SphericalPhi(wh) * DR_INV_TWOPI;
+  const double t = SphericalTheta(wh) * DR_INV_PI;
+  return env_radiance(e, s, t);
+}
+// upper_bound over cdf[0..count] (common.dart:304-333) then Distribution1D.sampleContinuous (montecarlo.dart:50-80)
+DR_DEV double dist1d_sample(const float* func, const float* cdf, double funcInt, int count, double u, double* pdf, int* off) {
+  int first = 0, cnt = count + 1;
+  while (cnt > 0) {
+    int step = cnt >> 1;
+    int index = first + step;
+    if (!(u < (double)cdf[index])) {
+      first = index + 1;
+      cnt -= step + 1;
+    } else {
+      cnt = step;
+    }
+  }
+  int offset = first - 1 < 0 ? 0 : first - 1;
+  if (offset == count) offset = count - 1;
+  if (off) *off = offset;
+  const double dc = ((double)cdf[offset + 1] - (double)cdf[offset]);
+  double du = 0.0;
+  if (dc != 0.0) du = (u - (double)cdf[offset]) / dc;
+  *pdf = (double)func[offset] / funcInt;
+  return (offset + du) / count;
+}
+// sampleLAtPoint (infinite_area_light.dart:92-131): wi, pdf and the radiance; the shadow ray is p + t wi, t < inf.
+DR_DEV C3 env_sample(const DEnv& e, double u0, double u1, F3* wi, double* pdf) {
+  double pdfs1, pdfs0;
+  int voff;
+  const double v = dist1d_sample(e.margFunc, e.margCdf, (double)e.margInt, e.h, u1, &pdfs1, &voff);
+  const double u = dist1d_sample(e.condFunc + (size_t)voff * e.w, e.condCdf + (size_t)voff * (e.w + 1),
+                                 (double)e.condInt[voff], e.w, u0, &pdfs0, nullptr);
+  const double mapPdf = pdfs0 * pdfs1;
+  if (mapPdf == 0.0) {
+    *pdf = 0.0;
+    return C3{0.f, 0.f, 0.f};
+  }
+  const double theta = v * DR_PI, phi = u * 2.0 * DR_PI;
+  const double costheta = cos(theta), sintheta = sin(theta);
+  const double sinphi = sin(phi), cosphi = cos(phi);
+  *wi = xf3(e.l2w, f3(sintheta * cosphi, sintheta * sinphi, costheta));
+  if (sintheta == 0.0) *pdf = 0.0;
+  else *pdf = mapPdf / (2.0 * DR_PI * DR_PI * sintheta);
+  return env_radiance(e, u, v);
+}
+DR_DEV double env_pdf(const DEnv& e, F3 w) {  // infinite_area_light.dart:190-205 + Distribution2D.pdf (montecarlo.dart:250-263)
+  F3 wi = xf3(e.w2l, w);
+  const double theta = SphericalTheta(wi), phi = SphericalPhi(wi);
+  const double sintheta = sin(theta);
+  if (sintheta == 0.0) return 0.0;
+  const double uu = phi * DR_INV_TWOPI, vv = theta * DR_INV_PI;
+  int iu = (int)(uu * e.w), iv = (int)(vv * e.h);
+  iu = iu < 0 ? 0 : (iu > e.w - 1 ? e.w - 1 : iu);
+  iv = iv < 0 ? 0 : (iv > e.h - 1 ? e.h - 1 : iv);
+  const double ci = (double)e.condInt[iv], mi = (double)e.margInt;
+  double p2;
+  if (ci * mi == 0.0) p2 = 0.0;
+  else p2 = ((double)e.condFunc[(size_t)iv * e.w + iu] * (double)e.margFunc[iv]) / (ci * mi);
+  return p2 / (2.0 * DR_PI * DR_PI * sintheta);
 }
 
 // ---- BSDF with one Lambertian lobe -------------------------------------------

@@ -184,9 +184,12 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
   if ((flags & PF_HAS_SH) && shOcc == 0) Ld = cadd(Ld, Ld1);
   if (flags & PF_HAS_MIS) {
     const int prim = st.misPrim[slot];
-    if (prim >= 0) {
+    const int li = st.misLight[slot];
+    if (sc.lights[li].kind == DR_LIGHT_INFINITE) {
+      // the MIS ray escaped: Li = light.Le(ray) (integrator.dart:173-175), folded into Ld2 at set-up
+      if (prim < 0) Ld = cadd(Ld, ldc(st.Ld2, cap, slot));
+    } else if (prim >= 0) {
       Tri tr = load_tri(sc, (uint32_t)prim);
-      const int li = st.misLight[slot];
       if (tr.light == li) {  // lightIsect.primitive.getAreaLight() == light (integrator.dart:170-172)
         const F3 wi = ld3(st.misD, cap, slot);
         DGeo dg;
@@ -207,20 +210,35 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
   const DLight& light = sc.lights[lightNum];
   const int flags = BSDF_ALL & ~BSDF_SPECULAR;
   uint32_t pf = 0;
-  // light.sampleLAtPoint (diffuse_area_light.dart:60-70)
-  F3 ns;
-  F3 ps = shapeset_sample(sc, light, ls0, ls1, lsc, &ns, p);
-  F3 wi = vnormalize(vsub(ps, p));
-  double lightPdf = shapeset_pdf(sc, light, p, wi);
-  C3 Li = light_L(light, ns, vneg(wi));
+  const bool infinite = light.kind == DR_LIGHT_INFINITE;
+  F3 wi = F3{0, 0, 0}, ps = F3{0, 0, 0};
+  double lightPdf = 0.0;
+  C3 Li;
+  if (!infinite) {
+    // DiffuseAreaLight.sampleLAtPoint (diffuse_area_light.dart:60-70)
+    F3 ns;
+    ps = shapeset_sample(sc, light, ls0, ls1, lsc, &ns, p);
+    wi = vnormalize(vsub(ps, p));
+    lightPdf = shapeset_pdf(sc, light, p, wi);
+    Li = light_L(light, ns, vneg(wi));
+  } else {
+    // InfiniteAreaLight.sampleLAtPoint (infinite_area_light.dart:92-131)
+    Li = env_sample(sc.env, ls0, ls1, &wi, &lightPdf);
+  }
   if (lightPdf > 0.0 && !cblack(Li)) {
     C3 f = bsdf_f(bsdf, wo, wi, flags);
     if (!cblack(f)) {
-      // VisibilityTester.setSegment (visibility_tester.dart:26-29)
-      F3 seg = vsub(ps, p);
-      double dist = vlen(seg);
-      st3(st.shD, cap, slot, vdiv(seg, dist));
-      st.shTmax[slot] = dist * (1.0 - 1.0e-3);
+      if (!infinite) {
+        // VisibilityTester.setSegment (visibility_tester.dart:26-29)
+        F3 seg = vsub(ps, p);
+        double dist = vlen(seg);
+        st3(st.shD, cap, slot, vdiv(seg, dist));
+        st.shTmax[slot] = dist * (1.0 - 1.0e-3);
+      } else {
+        // VisibilityTester.setRay (visibility_tester.dart:31-33)
+        st3(st.shD, cap, slot, wi);
+        st.shTmax[slot] = DR_INF;
+      }
       double bsdfPdf = bsdf_pdf(bsdf, wo, wi, flags);
       double weight = PowerHeuristic(lightPdf, bsdfPdf);
       stc(st.Ld1, cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) * weight / lightPdf)));
@@ -233,14 +251,16 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
     double bsdfPdf = 0.0;
     C3 f = bsdf_sample_f(bsdf, wo, &wi2, bs0, bs1, &bsdfPdf, flags);
     if (!cblack(f) && bsdfPdf > 0.0) {
-      double lightPdf2 = shapeset_pdf(sc, light, p, wi2);
+      double lightPdf2 = infinite ? env_pdf(sc.env, wi2) : shapeset_pdf(sc, light, p, wi2);
       if (lightPdf2 != 0.0) {
         double weight = PowerHeuristic(bsdfPdf, lightPdf2);
-        C3 Lemit = C3{light.L[0], light.L[1], light.L[2]};
+        // the radiance the MIS ray returns IF it reaches the light: Lemit of the sampled area light (its
+        // front face is checked at resolve), or the map along wi2 if the ray escapes (light.Le(ray))
+        C3 Lhit = infinite ? env_Le(sc.env, wi2) : C3{light.L[0], light.L[1], light.L[2]};
         st3(st.misD, cap, slot, wi2);
-        stc(st.Ld2, cap, slot, cmulD(cmul(f, Lemit), (fabs(vdot(wi2, n)) * weight / bsdfPdf)));
+        stc(st.Ld2, cap, slot, cmulD(cmul(f, Lhit), (fabs(vdot(wi2, n)) * weight / bsdfPdf)));
         st.misLight[slot] = lightNum;
-        pf |= PF_HAS_MIS;
+        pf |= PF_HAS_MIS;  // scene.intersect is called before `if (!Li.isBlack())` (integrator.dart:169-177)
       }
     }
   }
@@ -321,6 +341,11 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         L = cadd(L, cmul(betaNeeIn, tot));
       }
       const int prim = (flags & PF_HAS_CONT) ? hprimIn : -1;
+      if (bounce == 0 && prim < 0 && sc.hasEnv) {
+        // the camera ray escaped: Li = sum over lights of light.Le(ray) (sampler_renderer.dart:87-92); area
+        // lights return 0 (light.dart:70-72), the infinite light its map
+        L = cadd(L, env_Le(sc.env, d));
+      }
       if (prim >= 0 && bounce <= rp.maxDepth) {
         Tri tr = load_tri(sc, (uint32_t)prim);
         DGeo dg;
@@ -456,6 +481,8 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
         }
         stc(st.L, cap, slot, L);
         stc(st.beta, cap, slot, Lall);
+      } else if (stage == 0 && sc.hasEnv) {
+        stc(st.L, cap, slot, env_Le(sc.env, ld3(st.rd, cap, slot)));  // escaped camera ray (sampler_renderer.dart:87-92)
       }
       st.flags[slot] = pf;
     }

@@ -11,8 +11,8 @@ import math
 import numpy as np
 
 from .core import (BVHAccel, BoxFilter, DiffuseAreaLight, DirectLightingIntegrator, EmissionIntegrator,
-                   GeometricPrimitive, ImageFilm, LowDiscrepancySampler, MatteMaterial, PathIntegrator,
-                   PerspectiveCamera, SamplerRenderer, Scene, TriangleMesh)
+                   GeometricPrimitive, ImageFilm, InfiniteAreaLight, LowDiscrepancySampler, MatteMaterial,
+                   PathIntegrator, PerspectiveCamera, SamplerRenderer, Scene, TriangleMesh)
 
 WHITE = (0.75, 0.75, 0.75)
 RED = (0.48, 0.1125, 0.075)
@@ -137,9 +137,74 @@ def hairball_prim(strands=10000, segments=500):
     return GeometricPrimitive(hairball_mesh(strands, segments), MatteMaterial((0.48, 0.48, 0.48)))
 
 
-def make_scene(prims):
+def make_scene(prims, env=None):
+    """Scene with one DiffuseAreaLight per emissive shape (dartray.dart:398-401) followed by the optional
+    InfiniteAreaLight."""
     accel = BVHAccel(prims)
-    return Scene(accel, accel.lights())
+    return Scene(accel, accel.lights() + ([env] if env is not None else []))
+
+
+# light space z (theta = 0) -> world +y: columns are the images of the light axes (x -> x, y -> -z, z -> y)
+SKY_TO_WORLD = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=np.float32)
+
+
+def sky_env(width=1024, height=512, L=(1.0, 1.0, 1.0), nsamples=1):
+    """Procedural lat-long radiance map: sky gradient over a dim ground plus a sun lobe (analytic, f32)."""
+    v = (np.arange(height) + 0.5) / height * math.pi          # theta from the zenith
+    u = (np.arange(width) + 0.5) / width * 2.0 * math.pi      # phi
+    th, ph = np.meshgrid(v, u, indexing="ij")
+    cz = np.cos(th)
+    sky = np.stack([0.25 + 0.15 * cz, 0.45 + 0.2 * cz, 0.9 + 0.0 * cz], -1) * (0.35 + 0.65 * np.clip(cz, 0, 1))[..., None]
+    ground = np.array([0.08, 0.07, 0.06])
+    base = np.where((cz > 0)[..., None], sky, ground)
+    sun_t, sun_p = math.radians(40.0), math.radians(200.0)
+    sd = np.array([math.sin(sun_t) * math.cos(sun_p), math.sin(sun_t) * math.sin(sun_p), math.cos(sun_t)])
+    d = np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), cz], -1)
+    lobe = np.exp(400.0 * (d @ sd - 1.0))[..., None] * np.array([40.0, 36.0, 30.0])
+    return InfiniteAreaLight(SKY_TO_WORLD, L, nsamples, (base + lobe).astype(np.float32))
+
+
+def courtyard_prims(patches=16, cells=125, size=100.0, seed=42):
+    """San-Miguel-class synthetic courtyard (config C5): a patches x patches grid of displaced height-field
+    patches (cells x cells x 2 triangles each; 16 x 16 x 125 x 125 x 2 = 8 000 000), one box column per patch,
+    8 quad emitters (L = 20) and 12 matte Kd values drawn from a seeded generator."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    kds = 0.05 + 0.75 * rng.random((12, 3))
+    pick = rng.integers(0, 12, (patches, patches))
+    prims = []
+    half = size / 2.0
+    step = size / patches
+
+    def height(x, z):
+        return 0.6 * np.sin(0.35 * x) * np.cos(0.27 * z) + 0.25 * np.sin(1.7 * x + 0.3) * np.sin(1.3 * z + 1.1)
+
+    g = np.arange(cells + 1) / cells
+    ii, jj = np.meshgrid(np.arange(cells), np.arange(cells), indexing="ij")
+    a = (ii * (cells + 1) + jj).reshape(-1)
+    idx = np.concatenate([np.stack([a, a + 1, a + cells + 1], -1), np.stack([a + 1, a + cells + 2, a + cells + 1], -1)]).astype(np.uint32)
+    for pi in range(patches):
+        for pj in range(patches):
+            x = -half + (pi + g) * step
+            z = -half + (pj + g) * step
+            X, Z = np.meshgrid(x, z, indexing="ij")
+            P = np.stack([X, height(X, Z), Z], -1).reshape(-1, 3).astype(np.float32)
+            prims.append(GeometricPrimitive(TriangleMesh(idx, P), MatteMaterial(kds[pick[pi, pj]])))
+    # columns: one box (12 triangles) per patch corner
+    bx = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], dtype=np.float64)
+    bi = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6],
+                   [3, 0, 4], [3, 4, 7]], dtype=np.uint32)
+    for pi in range(patches):
+        for pj in range(patches):
+            cx, cz = -half + (pi + 0.5) * step, -half + (pj + 0.5) * step
+            P = (bx * np.array([0.8, 10.0, 0.8]) + np.array([cx - 0.4, float(height(cx, cz)) - 0.5, cz - 0.4])).astype(np.float32)
+            prims.append(GeometricPrimitive(TriangleMesh(bi, P), MatteMaterial(kds[pick[pi, pj] - 1])))
+    # 8 quad emitters on a ring, facing down
+    for k in range(8):
+        ang = 2.0 * math.pi * k / 8
+        cx, cz, h = 0.3 * size * math.cos(ang), 0.3 * size * math.sin(ang), 1.5
+        prims.append(_quad((cx - h, 15.0, cz - h), (cx + h, 15.0, cz - h), (cx + h, 15.0, cz + h), (cx - h, 15.0, cz + h),
+                           (0.5, 0.5, 0.5), DiffuseAreaLight((20.0, 20.0, 20.0), 1)))
+    return prims
 
 
 def cornell_camera(xres, yres):
@@ -147,8 +212,10 @@ def cornell_camera(xres, yres):
     return PerspectiveCamera.lookAt((0.0, 0.0, -35.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 35.0, film)
 
 
-def config(name, xres=None, yres=None, spp=None, blob=(1000, 500), hair=(10000, 500), seed=5489, **renderer_kw):
-    """(scene prims, renderer factory) for BASELINE.json's configs: 'C1', 'C2', 'C4'."""
+def config(name, xres=None, yres=None, spp=None, blob=(1000, 500), hair=(10000, 500), yard=(16, 125), env_res=(1024, 512),
+           seed=5489, **renderer_kw):
+    """(scene prims, renderer factory) for BASELINE.json's configs: 'C1', 'C2', 'C4', 'C5' (C3 is C2 at 4096^2 x
+    1024 spp).  For C5 the InfiniteAreaLight is attached to the factory as `renderer.env` (make_scene(prims, env))."""
     if name == "C1":
         prims = cornell_c1_prims()
         xres, yres, spp = xres or 64, yres or 64, spp or 4
@@ -161,11 +228,23 @@ def config(name, xres=None, yres=None, spp=None, blob=(1000, 500), hair=(10000, 
         prims = cornell_prims(hairball_prim(*hair))
         xres, yres, spp = xres or 1024, yres or 1024, spp or 64
         integ = PathIntegrator(5)
+    elif name == "C5":
+        prims = courtyard_prims(*yard)
+        xres, yres, spp = xres or 2048, yres or 2048, spp or 512
+        integ = PathIntegrator(8)
     else:
         raise ValueError(name)
-    cam = cornell_camera(xres, yres)
+    if name == "C5":
+        film = ImageFilm(xres, yres, BoxFilter(0.5, 0.5))
+        cam = PerspectiveCamera.lookAt((0.0, 14.0, -72.0), (0.0, 3.0, 0.0), (0.0, 1.0, 0.0), 45.0, film)
+        env = sky_env(*env_res)
+    else:
+        cam = cornell_camera(xres, yres)
+        env = None
 
     def renderer():
-        return SamplerRenderer(LowDiscrepancySampler(cam, spp, seed), cam, integ, EmissionIntegrator(), **renderer_kw)
+        r = SamplerRenderer(LowDiscrepancySampler(cam, spp, seed), cam, integ, EmissionIntegrator(), **renderer_kw)
+        r.env = env
+        return r
 
     return prims, renderer

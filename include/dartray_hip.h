@@ -53,15 +53,34 @@ typedef struct DrMaterial {
   float sigma; /* must be 0 (Lambertian); Oren-Nayar is not on the path */
 } DrMaterial;
 
-/* DiffuseAreaLight + its ShapeSet (lib/lights/diffuse_area_light.dart:36-43,
- * lib/core/light/shape_set.dart:24-51).  The triangle list is in ShapeSet
- * order (i.e. after the LIFO refine reversal). */
+#define DR_LIGHT_DIFFUSE_AREA 0 /* DiffuseAreaLight (lib/lights/diffuse_area_light.dart) */
+#define DR_LIGHT_INFINITE 1     /* InfiniteAreaLight (lib/lights/infinite_area_light.dart) */
+
+/* One entry of Scene.lights.  kind DR_LIGHT_DIFFUSE_AREA: DiffuseAreaLight + its
+ * ShapeSet (diffuse_area_light.dart:36-43, lib/core/light/shape_set.dart:24-51);
+ * the triangle list is in ShapeSet order (i.e. after the LIFO refine
+ * reversal).  kind DR_LIGHT_INFINITE: InfiniteAreaLight; L is the factor
+ * _radiance() applies (infinite_area_light.dart:180-182), env_index selects the
+ * radiance map. */
 typedef struct DrAreaLight {
   float L[3];
   int32_t nsamples;
   uint32_t first_tri; /* into light_tris */
   uint32_t ntris;
+  uint32_t kind;
+  uint32_t env_index; /* into env_maps */
 } DrAreaLight;
+
+/* InfiniteAreaLight.radianceMap level 0 (MIPMap.pyramid[0], lib/core/mipmap.dart:139,
+ * f32 RGB texels, power-of-two size, TEXTURE_REPEAT) and Light.lightToWorld /
+ * worldToLight (lib/core/light.dart:28-34).  The Distribution2D over
+ * luminance x sin(theta) (infinite_area_light.dart:283-307) is rebuilt by the library. */
+typedef struct DrEnvMap {
+  const float* texels; /* [height][width][3] */
+  int32_t width, height;
+  float light_to_world[16];
+  float world_to_light[16];
+} DrEnvMap;
 
 typedef struct DrLightTri {
   uint32_t v[3]; /* vertex indices */
@@ -86,6 +105,8 @@ typedef struct DrSceneDesc {
   const DrLightTri* light_tris;
   uint32_t nlight_tris;
   uint32_t bvh_depth; /* max depth of the tree, 0 = unknown */
+  const DrEnvMap* env_maps; /* at most one infinite light is supported */
+  uint32_t nenv_maps;
 } DrSceneDesc;
 
 typedef struct DrScene DrScene;

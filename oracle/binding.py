@@ -28,7 +28,10 @@ class OrcMesh(C.Structure):
 
 
 class OrcSceneDesc(C.Structure):
-    _fields_ = [("nmeshes", C.c_int32), ("meshes", C.POINTER(OrcMesh)), ("max_prims_in_node", C.c_int32)]
+    _fields_ = [("nmeshes", C.c_int32), ("meshes", C.POINTER(OrcMesh)), ("max_prims_in_node", C.c_int32),
+                ("has_env", C.c_int32), ("env_texels", C.c_void_p), ("env_w", C.c_int32), ("env_h", C.c_int32),
+                ("env_L", C.c_float * 3), ("env_l2w", C.c_float * 16), ("env_w2l", C.c_float * 16),
+                ("env_nsamples", C.c_int32)]
 
 
 class OrcRenderDesc(C.Structure):
@@ -99,6 +102,7 @@ def lib():
         l.orc_triangle_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         l.orc_triangle_intersectP.argtypes = [C.c_void_p, C.c_void_p]
         l.orc_slab.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.orc_env_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         l.orc_version.restype = C.c_char_p
         _lib = l
     return _lib
@@ -118,7 +122,8 @@ class OracleScene:
     """Scene built by the oracle from the same GeometricPrimitive list the product takes
     (objects with .shape.{P,vertexIndex,reverseOrientation}, .material.{Kd,sigma}, .areaLight)."""
 
-    def __init__(self, prims, max_prims=4):
+    def __init__(self, prims, max_prims=4, env=None):
+        """env: optional InfiniteAreaLight-like object (.texels [H,W,3] f32, .L, .lightToWorld, .worldToLight, .nSamples)."""
         l = lib()
         meshes = (OrcMesh * max(len(prims), 1))()
         self._keep = []
@@ -137,7 +142,19 @@ class OracleScene:
                 m.L[:] = [float(x) for x in gp.areaLight.Lemit]
                 m.light_nsamples = gp.areaLight.nSamples
         d = OrcSceneDesc(len(prims), meshes, max_prims)
+        if env is not None:
+            tex = np.ascontiguousarray(env.texels, np.float32)
+            self._keep.append(tex)
+            d.has_env = 1
+            d.env_texels = tex.ctypes.data
+            d.env_h, d.env_w = tex.shape[0], tex.shape[1]
+            d.env_L[:] = [float(x) for x in env.L]
+            d.env_l2w[:] = [float(x) for x in np.asarray(env.lightToWorld, np.float32).reshape(-1)]
+            d.env_w2l[:] = [float(x) for x in np.asarray(env.worldToLight, np.float32).reshape(-1)]
+            d.env_nsamples = env.nSamples
         self.h = l.orc_scene_create(C.byref(d))
+        if not self.h:
+            raise RuntimeError("orc_scene_create failed (environment maps must have power-of-two sizes)")
         info = (C.c_int64 * 6)()
         l.orc_scene_info(self.h, info)
         self.nnodes, self.nprims, self.depth, self.nlights, self.nverts, self.nlighttris = [int(v) for v in info]
@@ -174,6 +191,14 @@ class OracleScene:
         fn = lib().orc_intersect_brute if brute else lib().orc_intersect
         fn(self.h, rays.ctypes.data, len(rays), out.ctypes.data, 1 if any_hit else 0)
         return out
+
+    def env_probe(self, what, a, b=0.0, c=0.0):
+        """what: 0 = Le(dir) -> rgb, 1 = pdf(dir), 2 = sampleLAtPoint(u0, u1) -> (wi, pdf, Ls)."""
+        i = np.array([a, b, c], np.float64)
+        o = np.zeros(8, np.float64)
+        if lib().orc_env_probe(self.h, what, i.ctypes.data, o.ctypes.data) != 0:
+            raise RuntimeError("scene has no infinite light")
+        return o
 
     def sample_floats(self, integrator, max_depth):
         return lib().orc_sample_floats(self.h, integrator, max_depth)

@@ -278,6 +278,17 @@ struct Distribution1D {
     int ptr = upper_bound(u, count + 1);
     return std::max(0, ptr - 1);
   }
+  D sampleContinuous(D u, D* pdf, int* off) const {  // montecarlo.dart:50-80
+    int ptr = upper_bound(u, count + 1);
+    int offset = std::max(0, ptr - 1);
+    if (offset == count) offset = count - 1;
+    if (off) *off = offset;
+    D dc = ((D)cdf[offset + 1] - (D)cdf[offset]);
+    D du = 0.0;
+    if (dc != 0.0) du = (u - (D)cdf[offset]) / dc;
+    if (pdf) *pdf = (D)func[offset] / funcInt;
+    return (offset + du) / count;
+  }
 };
 
 // ---------------------------------------------------------------------------
@@ -326,7 +337,8 @@ struct Counters {
   uint64_t max_stack = 0;  // deepest todo stack seen (the reference allocates 64 entries, bvh_accel.dart:120)
 };
 
-struct Light {  // DiffuseAreaLight (diffuse_area_light.dart:36-70) + ShapeSet (shape_set.dart:24-51)
+struct Light {  // DiffuseAreaLight (diffuse_area_light.dart:36-70) + ShapeSet (shape_set.dart:24-51), or the InfiniteAreaLight
+  int kind = 0;  // 0 = diffuse area light, 1 = infinite area light (Scene::env)
   S Lemit;
   int nSamples;
   std::vector<int> shapes;  // indices into Scene::lightTris
@@ -339,6 +351,140 @@ struct LightTri {
   bool reverse;
 };
 
+// InfiniteAreaLight (lights/infinite_area_light.dart) with its MIPMap radiance map (core/mipmap.dart,
+// core/spectrum_image.dart) and Distribution2D (core/montecarlo.dart:222-268).
+struct EnvLight {
+  int levels = 0;
+  std::vector<int> lw, lh;
+  std::vector<std::vector<float>> pyramid;  // RGB f32 texels per level (SpectrumImage.data)
+  S L{1, 1, 1};
+  float l2w[16], w2l[16];
+  std::vector<Distribution1D> cond;  // pConditionalV
+  Distribution1D marginal;           // pMarginal
+  int nSamples = 1;
+
+  static int emod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }  // Dart % is Euclidean
+  S texel(int level, int s, int t) const {  // mipmap.dart:184-207, TEXTURE_REPEAT
+    s = emod(s, lw[level]);
+    t = emod(t, lh[level]);
+    const float* p = &pyramid[level][3 * ((size_t)t * lw[level] + s)];
+    return S{p[0], p[1], p[2]};
+  }
+  S triangle(int level, D s, D t) const {  // mipmap.dart:342-355
+    level = std::min(std::max(level, 0), levels - 1);
+    s = s * lw[level] - 0.5;
+    t = t * lh[level] - 0.5;
+    int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
+    D ds = s - s0, dt = t - t0;
+    return sadd(sadd(sadd(smulD(texel(level, s0, t0), ((1.0 - ds) * (1.0 - dt))),
+                          smulD(texel(level, s0, t0 + 1), ((1.0 - ds) * dt))),
+                     smulD(texel(level, s0 + 1, t0), (ds * (1.0 - dt)))),
+                smulD(texel(level, s0 + 1, t0 + 1), (ds * dt)));
+  }
+  static D Log2(D x) { static const D invLog2 = 1.0 / std::log(2.0); return std::log(x) * invLog2; }  // common.dart:98-103
+  S lookup(D s, D t, D width) const {  // mipmap.dart:209-224
+    D level = levels - 1 + Log2(std::max(width, 1.0e-8));
+    if (level < 0) return triangle(0, s, t);
+    else if (level >= levels - 1) return texel(levels - 1, 0, 0);
+    int iLevel = (int)std::floor(level);
+    D delta = level - iLevel;
+    return sadd(smulD(triangle(iLevel, s, t), (1.0 - delta)), smulD(triangle(iLevel + 1, s, t), delta));
+  }
+  S radiance(D u, D v, D width = 0.0) const { return smul(lookup(u, v, width), L); }  // infinite_area_light.dart:180-182
+
+  // MIPMap.texture (mipmap.dart:61-170) for power-of-two maps + _setRadianceMap (infinite_area_light.dart:283-307)
+  bool init(const float* texels, int w, int h) {
+    if (w <= 0 || h <= 0 || (w & (w - 1)) || (h & (h - 1))) return false;  // non-pow2 maps are resampled first: not restated
+    levels = 1 + (int)Log2((D)std::max(w, h));
+    lw.assign(levels, 0); lh.assign(levels, 0);
+    pyramid.resize(levels);
+    lw[0] = w; lh[0] = h;
+    pyramid[0].assign(texels, texels + 3 * (size_t)w * h);
+    for (int i = 1; i < levels; ++i) {
+      int sRes = std::max(1, lw[i - 1] / 2), tRes = std::max(1, lh[i - 1] / 2);
+      lw[i] = sRes; lh[i] = tRes;
+      pyramid[i].assign(3 * (size_t)sRes * tRes, 0.f);
+      for (int t = 0, p = 0; t < tRes; ++t)
+        for (int s = 0; s < sRes; ++s, ++p) {
+          // (texel(a) + texel(b) + texel(c) + texel(d)) * 0.25 -- but SpectrumImage.operator[] returns ONE shared
+          // static RGBColor (spectrum_image.dart:104-113,131), so when `texel(a) + texel(b)` is evaluated the
+          // receiver already holds b's values: the sum is 2b + c + d.  Only levels >= 1 are affected.
+          S b = texel(i - 1, 2 * s + 1, 2 * t), c = texel(i - 1, 2 * s, 2 * t + 1), d = texel(i - 1, 2 * s + 1, 2 * t + 1);
+          S v = smulD(sadd(sadd(sadd(b, b), c), d), 0.25);
+          pyramid[i][3 * p] = (float)v.r; pyramid[i][3 * p + 1] = (float)v.g; pyramid[i][3 * p + 2] = (float)v.b;
+        }
+    }
+    D filter = 1.0 / std::max(w, h);
+    std::vector<float> img((size_t)w * h);
+    for (int v = 0; v < h; ++v) {
+      D vp = (D)v / h;
+      D sinTheta = std::sin(kPi * (v + 0.5) / h);
+      for (int u = 0; u < w; ++u) {
+        D up = (D)u / w;
+        img[u + (size_t)v * w] = (float)slum(radiance(up, vp, filter));
+        img[u + (size_t)v * w] = (float)((D)img[u + (size_t)v * w] * sinTheta);
+      }
+    }
+    // Distribution2D(img, width, height) (montecarlo.dart:223-237)
+    cond.resize(h);
+    std::vector<D> marg(h);
+    for (int v = 0; v < h; ++v) {
+      std::vector<D> row(w);
+      for (int u = 0; u < w; ++u) row[u] = img[u + (size_t)v * w];
+      cond[v].init(row);
+      marg[v] = (D)(float)cond[v].funcInt;
+    }
+    marginal.init(marg);
+    return true;
+  }
+  V xf(const float* m, const V& p) const {  // Transform.transformVector
+    D x = p.x, y = p.y, z = p.z;
+    return vec(m[0] * x + m[1] * y + m[2] * z, m[4] * x + m[5] * y + m[6] * z, m[8] * x + m[9] * y + m[10] * z);
+  }
+  static D SphericalTheta(const V& v) { return std::acos(clampD(v.z, -1.0, 1.0)); }  // vector.dart:195-197
+  static D SphericalPhi(const V& v) {                                                 // vector.dart:199-202
+    D p = std::atan2(v.y, v.x);
+    return (p < 0.0) ? p + 2.0 * kPi : p;
+  }
+  S Le(const V& dir) const {  // infinite_area_light.dart:84-90
+    V wh = vnormalize(xf(w2l, dir));
+    D s = SphericalPhi(wh) * 0.15915494309189533577;  // INV_TWOPI
+    D t = SphericalTheta(wh) * INV_PI;
+    return radiance(s, t);
+  }
+  // sampleLAtPoint (infinite_area_light.dart:92-131): returns Ls, sets wi and pdf
+  S sampleL(D u0, D u1, V* wi, D* pdf) const {
+    D pdfs1, pdfs0;
+    int voff;
+    D v = marginal.sampleContinuous(u1, &pdfs1, &voff);
+    D u = cond[voff].sampleContinuous(u0, &pdfs0, nullptr);
+    D mapPdf = pdfs0 * pdfs1;
+    if (mapPdf == 0.0) { *pdf = 0.0; return S{0, 0, 0}; }  // pdf[0] is left at its initial 0.0
+    D theta = v * kPi, phi = u * 2.0 * kPi;
+    D costheta = std::cos(theta), sintheta = std::sin(theta);
+    D sinphi = std::sin(phi), cosphi = std::cos(phi);
+    *wi = xf(l2w, vec(sintheta * cosphi, sintheta * sinphi, costheta));
+    if (sintheta == 0.0) *pdf = 0.0;
+    else *pdf = mapPdf / (2.0 * kPi * kPi * sintheta);
+    return radiance(u, v);
+  }
+  D pdfW(const V& w) const {  // infinite_area_light.dart:190-205
+    V wi = xf(w2l, w);
+    D theta = SphericalTheta(wi), phi = SphericalPhi(wi);
+    D sintheta = std::sin(theta);
+    if (sintheta == 0.0) return 0.0;
+    // Distribution2D.pdf (montecarlo.dart:250-263)
+    D uu = phi * 0.15915494309189533577, vv = theta * INV_PI;
+    int nu = cond[0].count, nv = marginal.count;
+    int iu = std::min(std::max((int)(uu * nu), 0), nu - 1);
+    int iv = std::min(std::max((int)(vv * nv), 0), nv - 1);
+    D p2;
+    if (cond[iv].funcInt * marginal.funcInt == 0.0) p2 = 0.0;
+    else p2 = ((D)cond[iv].func[iu] * (D)marginal.func[iv]) / (cond[iv].funcInt * marginal.funcInt);
+    return p2 / (2.0 * kPi * kPi * sintheta);
+  }
+};
+
 struct Scene {
   std::vector<float> P;  // world-space f32 vertices (triangle_mesh.dart:29-36)
   std::vector<Mesh> meshes;
@@ -346,6 +492,8 @@ struct Scene {
   std::vector<LinearNode> nodes;
   std::vector<Light> lights;
   std::vector<LightTri> lightTris;
+  EnvLight env;
+  bool hasEnv = false;
   int maxPrimsInNode = 4;
   int bvhDepth = 0;
   mutable Counters ctr;
@@ -994,15 +1142,23 @@ static S EstimateDirect(const Scene& sc, int lightIdx, const V& p, const V& n, c
   S Ld{0, 0, 0};
   V wi{0, 0, 0};
   D lightPdf = 0.0, bsdfPdf = 0.0;
-  // light.sampleLAtPoint (diffuse_area_light.dart:60-70)
-  V ns{0, 0, 0};
-  V ps = shapeset_sample(sc, light, lsU0, lsU1, lsComp, &ns, p);
-  wi = vnormalize(vsub(ps, p));
-  lightPdf = shapeset_pdf(sc, light, p, wi);
-  // VisibilityTester.setSegment (visibility_tester.dart:26-29)
-  D dist = vlen(vsub(ps, p));
-  Ray vr{p, vdiv(vsub(ps, p), dist), rayEpsilon, dist * (1.0 - 1.0e-3), 0.0, 0};
-  S Li = light_L(light, ns, vneg(wi));
+  Ray vr;
+  S Li;
+  if (light.kind == 0) {
+    // light.sampleLAtPoint (diffuse_area_light.dart:60-70)
+    V ns{0, 0, 0};
+    V ps = shapeset_sample(sc, light, lsU0, lsU1, lsComp, &ns, p);
+    wi = vnormalize(vsub(ps, p));
+    lightPdf = shapeset_pdf(sc, light, p, wi);
+    // VisibilityTester.setSegment (visibility_tester.dart:26-29)
+    D dist = vlen(vsub(ps, p));
+    vr = Ray{p, vdiv(vsub(ps, p), dist), rayEpsilon, dist * (1.0 - 1.0e-3), 0.0, 0};
+    Li = light_L(light, ns, vneg(wi));
+  } else {
+    // InfiniteAreaLight.sampleLAtPoint (infinite_area_light.dart:92-131); visibility.setRay (visibility_tester.dart:31-33)
+    Li = sc.env.sampleL(lsU0, lsU1, &wi, &lightPdf);
+    vr = Ray{p, wi, rayEpsilon, kInf, 0.0, 0};
+  }
   if (lightPdf > 0.0 && !sblack(Li)) {
     S f = bsdf.f(wo, wi, flags);
     if (!sblack(f) && !bvh_intersectP(sc, vr)) {
@@ -1019,7 +1175,7 @@ static S EstimateDirect(const Scene& sc, int lightIdx, const V& p, const V& n, c
     if (!sblack(f) && bsdfPdf > 0.0) {
       D weight = 1.0;
       if ((sampledType & BSDF_SPECULAR) == 0) {
-        lightPdf = shapeset_pdf(sc, light, p, wi);
+        lightPdf = light.kind == 0 ? shapeset_pdf(sc, light, p, wi) : sc.env.pdfW(wi);
         if (lightPdf == 0.0) return Ld;
         weight = PowerHeuristic(1, bsdfPdf, 1, lightPdf);
       }
@@ -1029,7 +1185,8 @@ static S EstimateDirect(const Scene& sc, int lightIdx, const V& p, const V& n, c
       if (bvh_intersect(sc, ray, &lightIsect)) {
         if (sc.meshes[sc.prims[lightIsect.prim].mesh].light == lightIdx) Li2 = isect_Le(sc, lightIsect, vneg(wi));
       } else {
-        Li2 = S{0, 0, 0};  // light.Le(ray) == 0 for area lights (light.dart:70-72)
+        // light.Le(ray): 0 for area lights (light.dart:70-72), the map for the infinite light
+        Li2 = light.kind == 1 ? sc.env.Le(wi) : S{0, 0, 0};
       }
       if (!sblack(Li2)) {
         Li2 = smul(Li2, S{1, 1, 1});
@@ -1394,6 +1551,13 @@ struct OrcSceneDesc {
   int32_t nmeshes;
   const OrcMesh* meshes;
   int32_t max_prims_in_node;  // "maxnodeprims", default 4
+  // optional InfiniteAreaLight, appended to Scene.lights after the area lights
+  int32_t has_env;
+  const float* env_texels;  // [h][w][3] level-0 texels of the radiance MIPMap (power-of-two size)
+  int32_t env_w, env_h;
+  float env_L[3];
+  float env_l2w[16], env_w2l[16];
+  int32_t env_nsamples;
 };
 struct OrcNode {  // the 32-byte marshalled node of SURVEY.md Appendix F
   float bmin[3], bmax[3];
@@ -1493,6 +1657,23 @@ void* orc_scene_create(const OrcSceneDesc* d) {
       p.src_tri = t;
       sc->prims.push_back(p);
     }
+  }
+  if (d->has_env) {
+    sc->env.L = rgb(d->env_L[0], d->env_L[1], d->env_L[2]);
+    memcpy(sc->env.l2w, d->env_l2w, sizeof(sc->env.l2w));
+    memcpy(sc->env.w2l, d->env_w2l, sizeof(sc->env.w2l));
+    sc->env.nSamples = std::max(1, d->env_nsamples);
+    if (!sc->env.init(d->env_texels, d->env_w, d->env_h)) {
+      delete sc;
+      return nullptr;
+    }
+    sc->hasEnv = true;
+    Light L;
+    L.kind = 1;
+    L.Lemit = sc->env.L;
+    L.nSamples = sc->env.nSamples;
+    L.area = 0.0;
+    sc->lights.push_back(L);
   }
   Builder b;
   b.sc = sc;
@@ -1625,7 +1806,8 @@ static S li_one(const Scene& sc, const IntegratorCfg& cfg, const Camera& cam, co
     if (cfg.kind == 1) Li = PathLi(sc, cfg, ray, isect, view, rng);
     else Li = DirectLi(sc, cfg, ray, isect, view, n1D, n2D, rng);
   } else {
-    Li = S{0, 0, 0};  // sum of light.Le(ray) == 0 for area lights
+    Li = S{0, 0, 0};  // Li += light.Le(ray) for every light (sampler_renderer.dart:87-92): 0 for area lights
+    for (const Light& l : sc.lights) Li = sadd(Li, l.kind == 1 ? sc.env.Le(ray.d) : S{0, 0, 0});
   }
   // T * Li + Lvi with T = 1, Lvi = 0 (emission_integrator.dart:39-42), then * rayWeight.
   S Ls = smulD(sadd(smul(S{1, 1, 1}, Li), S{0, 0, 0}), rayWeight);
@@ -1913,6 +2095,17 @@ void orc_ld_pixel_sample(int mode, int64_t seed, uint64_t pixel_index, int spp, 
   if (mode == 0) { DartRandom rng(seed); LDPixelSample(spp, a, b, buf, rng, res, nFloats); }
   else LDPixelSampleCounter(spp, a, b, (uint64_t)seed, pixel_index, res, nFloats);
   memcpy(out, res.data(), res.size() * sizeof(float));
+}
+// InfiniteAreaLight probes: Le(dir), pdf(dir), sampleLAtPoint(u0,u1) -> wi, pdf, Ls.
+int orc_env_probe(void* h, int what, const double in[3], double out[8]) {
+  Scene* sc = (Scene*)h;
+  if (!sc->hasEnv) return -1;
+  V d = vec(in[0], in[1], in[2]);
+  if (what == 0) { S l = sc->env.Le(d); out[0] = l.r; out[1] = l.g; out[2] = l.b; }
+  else if (what == 1) { out[0] = sc->env.pdfW(d); }
+  else { V wi{0, 0, 0}; D pdf = 0; S l = sc->env.sampleL(in[0], in[1], &wi, &pdf);
+         out[0] = wi.x; out[1] = wi.y; out[2] = wi.z; out[3] = pdf; out[4] = l.r; out[5] = l.g; out[6] = l.b; }
+  return 0;
 }
 // Single-triangle tests (KATs): returns hit flag; out = {t, b1, b2, p.xyz, nn.xyz}.
 int orc_triangle_intersect(const float tri[9], const OrcRay* ray, int reverse, double out[9]) {
