@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -71,7 +72,7 @@ struct Workspace {
 
 struct DrScene {
   DScene d;
-  DevBuf<uint4> nodes;
+  DevBuf<uint4> nodes, pairs;
   DevBuf<float4> tris, mats;
   DevBuf<DLight> lights;
   DevBuf<DLightTri> ltris;
@@ -152,15 +153,16 @@ void host_tri_normals(const float* a, const float* b, const float* c, bool rever
 int traceGrid() {
   // DR_LDS_STACK*256*4 bytes of LDS per workgroup (32 KiB at 32 entries => 5 workgroups = 20 waves per CU);
   // at most 8 workgroups of 4 waves fit the 32-wave CU.
-  int perCU = (160 * 1024) / (DR_LDS_STACK * DR_TRACE_BLOCK * 4);
+  int perCU = 6;  // v2: 24 KiB per workgroup -> 6; v3: 32 KiB -> 5 resident, the sixth queues behind them
   const char* e = getenv("DARTRAY_TRACE_WG_PER_CU");
   if (e) perCU = atoi(e);
   return g_numCU * std::max(1, std::min(perCU, 8));
 }
 
 int ensureSpill(DrScene* sc, int grid) {
-  if (sc->bvhDepth != 0 && sc->bvhDepth <= DR_LDS_STACK) return DR_OK;
-  size_t need = (size_t)grid * DR_TRACE_BLOCK * (DR_MAX_STACK - DR_LDS_STACK);
+  // deepest stack == tree depth; the v3 kernel keeps 16 (reference, E) pairs in LDS, v2 24 references
+  if (sc->bvhDepth != 0 && sc->bvhDepth <= 16) return DR_OK;
+  size_t need = (size_t)grid * DR_TRACE_BLOCK * (DR_MAX_STACK - 16) * 2;
   HIP_TRY(sc->ws.spill.alloc(need));
   sc->ws.spillGrid = grid;
   return DR_OK;
@@ -348,6 +350,79 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   // nodes: the 32-byte marshalled node is consumed as two 16-byte loads
   TRY_SC(sc->nodes.alloc(2 * desc->nnodes));
   if (desc->nnodes) TRY_SC(hipMemcpy(sc->nodes.p, desc->nodes, desc->nnodes * sizeof(DrBvhNode), hipMemcpyHostToDevice));
+  // sibling-pair layout for the v3 traversal (see dr_device.h): children of the k-th interior node side by side
+  sc->d.pairs = nullptr;
+  sc->d.npairs = 0;
+  sc->d.rootRef = PREF_DEAD;
+  if (desc->nnodes) {
+    const DrBvhNode* N = desc->nodes;
+    bool ok = desc->ntris < (1ull << 26);
+    std::vector<uint32_t> pairIndex(desc->nnodes, 0);
+    uint32_t np = 0;
+    for (uint64_t i = 0; i < desc->nnodes; ++i) {
+      if (N[i].nprims == 0) {
+        if (i + 1 >= desc->nnodes || N[i].offset >= desc->nnodes || N[i].axis > 2) return bail(DR_ERR_INVALID, "malformed BVH node");
+        pairIndex[i] = np++;
+      } else if (N[i].nprims > 31) {
+        ok = false;  // packed references carry at most 31 primitives per leaf; fall back to the v2 kernel
+      }
+    }
+    if (np >= (1u << 29)) ok = false;
+    // The v3 kernel re-derives a node's own box when it needs the literal test: an interior node's bounds
+    // must be the union of its children's (initInterior, bvh_accel.dart:518-524) and a leaf's the union of
+    // its triangles' vertices (:238-241).  Trees built otherwise keep the v2 kernel.
+    for (uint64_t i = 0; ok && i < desc->nnodes; ++i) {
+      float lo[3], hi[3];
+      if (N[i].nprims == 0) {
+        const DrBvhNode &a = N[i + 1], &b = N[N[i].offset];
+        for (int k = 0; k < 3; ++k) {
+          lo[k] = std::min(a.bmin[k], b.bmin[k]);
+          hi[k] = std::max(a.bmax[k], b.bmax[k]);
+        }
+      } else {
+        if ((uint64_t)N[i].offset + N[i].nprims > desc->ntris) return bail(DR_ERR_INVALID, "leaf primitive range");
+        for (int k = 0; k < 3; ++k) {
+          lo[k] = std::numeric_limits<float>::infinity();
+          hi[k] = -lo[k];
+        }
+        for (uint32_t t = 0; t < N[i].nprims; ++t)
+          for (int v = 0; v < 3; ++v) {
+            const uint32_t vi = desc->tri_idx[3 * ((uint64_t)N[i].offset + t) + v];
+            if (vi >= desc->nverts) return bail(DR_ERR_INVALID, "vertex index out of range");
+            for (int k = 0; k < 3; ++k) {
+              lo[k] = std::min(lo[k], desc->verts[3 * (size_t)vi + k]);
+              hi[k] = std::max(hi[k], desc->verts[3 * (size_t)vi + k]);
+            }
+          }
+      }
+      for (int k = 0; k < 3; ++k)
+        if (lo[k] != N[i].bmin[k] || hi[k] != N[i].bmax[k]) ok = false;
+    }
+    if (ok) {
+      auto packRef = [&](uint64_t c) -> uint32_t {
+        return N[c].nprims ? (PREF_LEAF | ((uint32_t)N[c].nprims << 26) | N[c].offset) : (((uint32_t)N[c].axis << 29) | pairIndex[c]);
+      };
+      std::vector<DrBvhNode> P(2 * (size_t)std::max<uint32_t>(np, 1));
+      for (uint64_t i = 0; i < desc->nnodes; ++i) {
+        if (N[i].nprims != 0) continue;
+        const uint64_t c[2] = {i + 1, N[i].offset};
+        for (int k = 0; k < 2; ++k) {
+          DrBvhNode r = N[c[k]];
+          if (r.nprims == 0) r.offset = pairIndex[c[k]];
+          P[2 * (size_t)pairIndex[i] + k] = r;
+        }
+      }
+      TRY_SC(sc->pairs.alloc(4 * (size_t)std::max<uint32_t>(np, 1)));
+      TRY_SC(hipMemcpy(sc->pairs.p, P.data(), P.size() * sizeof(DrBvhNode), hipMemcpyHostToDevice));
+      sc->d.pairs = sc->pairs.p;
+      sc->d.npairs = np;
+      sc->d.rootRef = packRef(0);
+      for (int k = 0; k < 3; ++k) {
+        sc->d.rootBox[k] = N[0].bmin[k];
+        sc->d.rootBox[3 + k] = N[0].bmax[k];
+      }
+    }
+  }
   // primitives: gather vertices on the device
   TRY_SC(sc->tris.alloc(3 * desc->ntris));
   if (desc->ntris) {

@@ -107,7 +107,16 @@ struct DLightTri {  // 72 B
   float nn[3];
   float ns[3];
 };
+// Sibling-pair layout used by the v3 traversal: pairs[k] holds the two child records (each a DrBvhNode
+// whose `offset` is the child's own pair index if it is interior, the first primitive if it is a leaf)
+// of the k-th interior node, 64 bytes, so ONE aligned fetch brings both children's boxes.
+#define PREF_DEAD 0xffffffffu
+#define PREF_LEAF 0x80000000u
 struct DScene {
+  const uint4* pairs;   // 4 x uint4 per interior node, or null (then the v2 kernel is used)
+  float rootBox[6];     // bounds of node 0
+  uint32_t rootRef;     // packed reference of node 0 (see pack_ref)
+  uint32_t npairs;
   const uint4* nodes;   // 2 x uint4 per node (DrBvhNode)
   const float4* tris;   // 3 x float4 per primitive
   const float4* mats;   // kd.rgb, sigma

@@ -178,6 +178,8 @@ DR_DEV void stc(float* a, uint32_t cap, uint32_t s, C3 v) {
 }
 
 // EstimateDirect's contribution of the pending NEE rays (integrator.dart:135-145,169-180).
+// ENV: the scene has an InfiniteAreaLight (compiled out otherwise: the area-light-only path keeps its registers)
+template <bool ENV>
 DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uint32_t flags, int shOcc, C3 Ld1) {
   const uint32_t cap = st.cap;
   C3 Ld = C3{0.f, 0.f, 0.f};
@@ -185,7 +187,7 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
   if (flags & PF_HAS_MIS) {
     const int prim = st.misPrim[slot];
     const int li = st.misLight[slot];
-    if (sc.lights[li].kind == DR_LIGHT_INFINITE) {
+    if (ENV && sc.lights[li].kind == DR_LIGHT_INFINITE) {
       // the MIS ray escaped: Li = light.Le(ray) (integrator.dart:173-175), folded into Ld2 at set-up
       if (prim < 0) Ld = cadd(Ld, ldc(st.Ld2, cap, slot));
     } else if (prim >= 0) {
@@ -204,13 +206,14 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
 
 // EstimateDirect up to the points where it must trace (integrator.dart:119-185):
 // writes the shadow ray / MIS ray and their candidate contributions.
+template <bool ENV>
 DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
                           F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1) {
   const uint32_t cap = st.cap;
   const DLight& light = sc.lights[lightNum];
   const int flags = BSDF_ALL & ~BSDF_SPECULAR;
   uint32_t pf = 0;
-  const bool infinite = light.kind == DR_LIGHT_INFINITE;
+  const bool infinite = ENV && light.kind == DR_LIGHT_INFINITE;
   F3 wi = F3{0, 0, 0}, ps = F3{0, 0, 0};
   double lightPdf = 0.0;
   C3 Li;
@@ -301,6 +304,7 @@ struct TailSrc {
 #define DR_SHADE_WAVES 2
 #endif
 #define DR_SHADE_BLOCK 512
+template <bool ENV>
 __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
   __shared__ PushScratch s_push;
   const uint32_t cap = st.cap;
@@ -336,12 +340,12 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
       }
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
-        C3 Ld = resolve_nee(sc, st, slot, flags, shOccIn, Ld1In);
+        C3 Ld = resolve_nee<ENV>(sc, st, slot, flags, shOccIn, Ld1In);
         C3 tot = cmulD(Ld, (double)rp.nLights);  // integrator.dart:113-116
         L = cadd(L, cmul(betaNeeIn, tot));
       }
       const int prim = (flags & PF_HAS_CONT) ? hprimIn : -1;
-      if (bounce == 0 && prim < 0 && sc.hasEnv) {
+      if (ENV && bounce == 0 && prim < 0 && sc.hasEnv) {
         // the camera ray escaped: Li = sum over lights of light.Le(ray) (sampler_renderer.dart:87-92); area
         // lights return 0 (light.dart:70-72), the infinite light its map
         L = cadd(L, env_Le(sc.env, d));
@@ -379,7 +383,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
           }
           int lightNum = (int)floor(lu * rp.nLights);
           lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
-          pf |= setup_nee(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1);
+          pf |= setup_nee<ENV>(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1);
           stc(st.betaNee, cap, slot, beta);
         }
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
@@ -458,7 +462,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
         } else {
           tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
           dg.p = ld3(st.ro, cap, slot);
-          C3 Ld = resolve_nee(sc, st, slot, flags, st.shOcc[slot], ldc(st.Ld1, cap, slot));  // Ld += EstimateDirect (one sample per light)
+          C3 Ld = resolve_nee<true>(sc, st, slot, flags, st.shOcc[slot], ldc(st.Ld1, cap, slot));  // Ld += EstimateDirect (one sample per light)
           Lall = cadd(Lall, cdivD(Ld, 1.0));                      // L += Ld / nSamples
         }
         if (stage < rp.nLights) {
@@ -470,7 +474,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
           double ls1 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage + 1) * cap + slot);
           double bs0 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage + 2) * cap + slot);
           double bs1 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage + 3) * cap + slot);
-          pf |= setup_nee(sc, st, slot, stage, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1);
+          pf |= setup_nee<true>(sc, st, slot, stage, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1);
           again = true;
         } else {
           if (rp.nLights > 0) L = cadd(L, Lall);
@@ -613,7 +617,8 @@ void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) 
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_shade_path, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  if (sc.hasEnv) hipLaunchKernelGGL(k_shade_path<true>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  else hipLaunchKernelGGL(k_shade_path<false>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {

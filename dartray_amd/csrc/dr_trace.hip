@@ -34,6 +34,9 @@
 #ifndef DR_NSHARD
 #define DR_NSHARD 1  // work-queue shards: 1 = one shared counter; 8 = one per XCD.  Measured on C2: 8 shards are 12 % SLOWER (each XCD walks its own eighth of the queue, so the chip-wide working set in the shared Infinity Cache is 8 regions instead of 1)
 #endif
+#ifndef DR_TRACE3_WAVES
+#define DR_TRACE3_WAVES 5  // k_trace3: 32 KiB of LDS per workgroup => 5 workgroups per CU anyway
+#endif
 #ifndef DR_WORK_CHUNK
 #define DR_WORK_CHUNK 128  // queue entries a wave reserves per atomic on the work counter (256+ loses cache locality, 64 is atomic bound)
 #endif
@@ -541,21 +544,391 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect(DScene sc, const D
                         gridDim.x * DR_TRACE_BLOCK, work, ctr);
 }
 
+// ===========================================================================
+// v3: sibling-pair traversal (an experiment kept for A/B: DARTRAY_TRACE_IMPL=3; bit-exact like v2).
+// Measured on C2: closest 329 ms vs 319 ms (v2), any-hit 206 vs 176 ms -- 30 % fewer memory-wait cycles, but
+// 94 VGPRs / 8-byte stack entries leave 20 instead of 24 waves per CU and the step has ~2x the instructions;
+// v2's near-child fetches were already cheap (depth-first layout => same or adjacent cache line).
+//
+// Same visits, same order, same decisions as bvh_accel.dart:101-226 -- but the box of a child is read
+// from its PARENT's 64-byte pair record, so one fetch serves two box tests:
+//   * expanding an interior node (its own box is already known to be hit) fetches pairs[k] = {left, right};
+//   * the near child (by dirIsNeg[axis], :147-153) is tested at once against the current maxDistance --
+//     exactly when the reference would visit it (no triangle test can happen in between);
+//   * the far child is what the reference pushes.  Its box test happens at POP time in the reference, with
+//     the maxDistance of that moment; only `entry < maxDistance` depends on it.  So the maxDistance-free part
+//     (entry <= exit, exit > minDistance) is decided now (f32 filter, f64 fallback), a child failing it is
+//     pushed as a DEAD entry (it still counts as a visit when popped, like the reference), and for a live
+//     child the f32 estimate of its entry parameter E is kept next to its reference on the stack;
+//   * at pop time E's enclosure is compared with the current maxDistance: surely beyond => pruned with NO
+//     memory access (this is where closest-hit rays spend most pops after their first hit), surely before
+//     => expanded; in the ambiguous band (|E - maxDistance| within ~5e-7 relative) the literal f64 test is
+//     evaluated on the child's own box, reconstructed exactly from data that is fetched anyway: an interior
+//     node's bounds are the union of its children's (initInterior, bvh_accel.dart:518-524), a leaf's the
+//     union of its triangles' vertices (:238-241).
+// Rays with a zero direction component (0*inf = NaN possible) take the literal test for every box.
+// Packed child reference: 0xffffffff dead | leaf: 1<<31 | nprims<<26 | firstPrim | interior: axis<<29 | pair.
+// ===========================================================================
+#ifndef DR_PSTACK
+#define DR_PSTACK 16  // (reference, E) entries per lane kept in LDS: 8 B x 16 x 256 = 32 KiB per workgroup
+#endif
+
+struct SlabB {
+  float lo, hi, loU, loL, hiU, hiL;
+};
+DR_DEV SlabB slab_bounds(const TraceRay& r, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz) {
+  const float ax = (bminx - r.o.x) * r.ivx, bx = (bmaxx - r.o.x) * r.ivx;
+  const float ay = (bminy - r.o.y) * r.ivy, by = (bmaxy - r.o.y) * r.ivy;
+  const float az = (bminz - r.o.z) * r.ivz, bz = (bmaxz - r.o.z) * r.ivz;
+  SlabB s;
+  s.lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+  s.hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  const float R = 4.76837158203125e-07f, A = 1.0e-37f;  // 2^-21, see slab_f32
+  const float eLo = __fmaf_rn(fabsf(s.lo), R, A), eHi = __fmaf_rn(fabsf(s.hi), R, A);
+  s.loU = s.lo + eLo;
+  s.loL = s.lo - eLo;
+  s.hiU = s.hi + eHi;
+  s.hiL = s.hi - eHi;
+  return s;
+}
+// The maxDistance-free part of the slab test in f64 (no NaN can occur: no zero direction component):
+// returns whether entry <= exit on all axis pairs and exit > minDistance; *E = the entry parameter.
+DR_DEV bool slab_geom_f64(const TraceRay& r, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
+                          double* E) {
+  const bool n0 = r.ivx < 0.f, n1 = r.ivy < 0.f, n2 = r.ivz < 0.f;
+  const double ox = r.o.x, oy = r.o.y, oz = r.o.z;
+  double t0 = ((double)(n0 ? bmaxx : bminx) - ox) * (double)r.ivx;
+  double t1 = ((double)(n0 ? bminx : bmaxx) - ox) * (double)r.ivx;
+  const double ty0 = ((double)(n1 ? bmaxy : bminy) - oy) * (double)r.ivy;
+  const double ty1 = ((double)(n1 ? bminy : bmaxy) - oy) * (double)r.ivy;
+  if ((t0 > ty1) || (ty0 > t1)) return false;
+  if (ty0 > t0) t0 = ty0;
+  if (ty1 < t1) t1 = ty1;
+  const double tz0 = ((double)(n2 ? bmaxz : bminz) - oz) * (double)r.ivz;
+  const double tz1 = ((double)(n2 ? bminz : bmaxz) - oz) * (double)r.ivz;
+  if ((t0 > tz1) || (tz0 > t1)) return false;
+  if (tz0 > t0) t0 = tz0;
+  if (tz1 < t1) t1 = tz1;
+  *E = t0;
+  return t1 > r.tmin;
+}
+DR_DEV uint32_t pack_ref(uint32_t ref, uint32_t meta) {
+  const uint32_t nprims = meta & 0xffffu;
+  return nprims ? (PREF_LEAF | (nprims << 26) | ref) : ((((meta >> 16) & 3u) << 29) | ref);
+}
+
+#define M_EXPAND 1  // `cur` is an interior node whose box is hit (or must be re-tested): fetch its pair
+
+template <int ANY, class IO>
+DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ldsRef, float* ldsE, uint32_t* spill,
+                        uint32_t spillStride, uint32_t spillHalf, uint32_t* work, TraceCounters* ctr) {
+  const int lane = lane_id();
+  const unsigned long long ltMask = (1ull << lane) - 1ull;
+  uint32_t nRays = 0, nNodes = 0, nTris = 0;
+  TraceRay ray;
+  ray.needF64 = false;
+  uint32_t handle = 0, cur = 0;
+  int sp = 0, hit = -1, mode = M_IDLE;
+  bool retest = false;  // cur was popped inside the ambiguous band: evaluate the literal test on its own box
+  bool exhausted = false;
+  uint32_t resNext = 0, resEnd = 0;
+
+  auto stackGet = [&](int i, uint32_t* ref, float* e) {
+    *ref = ldsRef[(i < DR_PSTACK ? i : DR_PSTACK - 1) * DR_TRACE_BLOCK];
+    *e = ldsE[(i < DR_PSTACK ? i : DR_PSTACK - 1) * DR_TRACE_BLOCK];
+    if (i >= DR_PSTACK) {
+      *ref = spill[(size_t)(i - DR_PSTACK) * spillStride];
+      *e = __uint_as_float(spill[spillHalf + (size_t)(i - DR_PSTACK) * spillStride]);
+    }
+  };
+  auto stackSet = [&](int i, uint32_t ref, float e) {
+    if (i < DR_PSTACK) {
+      ldsRef[i * DR_TRACE_BLOCK] = ref;
+      ldsE[i * DR_TRACE_BLOCK] = e;
+    } else if (i < DR_MAX_STACK) {
+      spill[(size_t)(i - DR_PSTACK) * spillStride] = ref;
+      spill[spillHalf + (size_t)(i - DR_PSTACK) * spillStride] = __float_as_uint(e);
+    }
+  };
+  auto push = [&](uint32_t ref, float e) {
+    stackSet(sp, ref, e);
+    ++sp;
+  };
+  // A far child that can never be hit still is ONE visit when the reference pops it.  Closest-hit rays pop
+  // every entry sooner or later, so the visit is counted right away and nothing is pushed; any-hit rays may
+  // stop early, so they push a DEAD entry -- consecutive ones merged into one entry whose E field is a count.
+  auto pushDead = [&]() {
+    if (!ANY) {
+      ++nNodes;
+      return;
+    }
+    if (sp > 0) {
+      uint32_t r;
+      float c;
+      stackGet(sp - 1, &r, &c);
+      if (r == PREF_DEAD) {
+        stackSet(sp - 1, PREF_DEAD, __uint_as_float(__float_as_uint(c) + 1u));
+        return;
+      }
+    }
+    push(PREF_DEAD, __uint_as_float(1u));
+  };
+  // maxDistance just shrank (closest hit only): drop every entry that is now certainly beyond it and count
+  // its visit -- the reference would pop and reject each of them later, with no other effect.  What stays on
+  // the stack survives its pop (up to the ambiguous band), so pops never turn into long chains.
+  auto pruneStack = [&]() {
+    const float R = 4.76837158203125e-07f, A = 1.0e-37f;
+    int j = 0;
+    for (int i = 0; i < sp; ++i) {
+      uint32_t r;
+      float e;
+      stackGet(i, &r, &e);
+      const float eb = __fmaf_rn(fabsf(e), R, A);
+      if (e - eb >= ray.tmaxHi) {
+        ++nNodes;
+        continue;
+      }
+      if (j != i) stackSet(j, r, e);
+      ++j;
+    }
+    sp = j;
+  };
+  // Pop until an entry survives (bvh_accel.dart:139-143,156-159); every popped entry is one node visit.
+  // Returns false when the stack is empty (the ray is finished).
+  auto popNext = [&]() -> bool {
+    for (;;) {
+      if (sp == 0) return false;
+      --sp;
+      uint32_t ref;
+      float e;
+      stackGet(sp, &ref, &e);
+      if (ref == PREF_DEAD) {
+        nNodes += __float_as_uint(e);  // merged dead entries (any-hit rays only)
+        continue;
+      }
+      ++nNodes;
+      const float R = 4.76837158203125e-07f, A = 1.0e-37f;
+      const float eb = __fmaf_rn(fabsf(e), R, A);
+      if (e - eb >= ray.tmaxHi) continue;  // entry >= maxDistance for certain: pruned, nothing fetched
+      retest = !(e + eb < ray.tmaxLo);     // not certainly before maxDistance (also NaN: needF64 rays)
+      cur = ref;
+      mode = (ref & PREF_LEAF) ? M_LEAF : M_EXPAND;
+      return true;
+    }
+  };
+
+  for (;;) {
+    // ---- refill idle lanes (as in v2) ----
+    const unsigned long long idleMask = __ballot(mode == M_IDLE);
+    const int nIdle = __popcll(idleMask);
+    if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
+      if (resNext == resEnd) {
+        uint32_t fresh = 0;
+        if (lane == 0) fresh = atomicAdd(work, (uint32_t)DR_WORK_CHUNK);
+        fresh = wave_bcast_first(fresh);
+        if (fresh < n) {
+          resNext = fresh;
+          resEnd = min(fresh + (uint32_t)DR_WORK_CHUNK, n);
+        } else {
+          exhausted = true;
+        }
+      }
+      const uint32_t take = min(resEnd - resNext, (uint32_t)nIdle);
+      if (mode == M_IDLE) {
+        const uint32_t j = (uint32_t)__popcll(idleMask & ltMask);
+        if (j < take) {
+          io.load(resNext + j, ray, handle);
+          ++nRays;
+          sp = 0;
+          hit = -1;
+          retest = false;
+          // visit node 0 (its box and packed reference live in kernel arguments)
+          bool ok = false;
+          if (sc.rootRef != PREF_DEAD) {
+            ++nNodes;
+            int d = ray.needF64 ? -1 : slab_f32(ray, sc.rootBox[0], sc.rootBox[1], sc.rootBox[2], sc.rootBox[3], sc.rootBox[4], sc.rootBox[5]);
+            if (d < 0) d = slab_f64(ray, sc.rootBox[0], sc.rootBox[1], sc.rootBox[2], sc.rootBox[3], sc.rootBox[4], sc.rootBox[5]) ? 1 : 0;
+            ok = d != 0;
+          }
+          if (ok) {
+            cur = sc.rootRef;
+            mode = (cur & PREF_LEAF) ? M_LEAF : M_EXPAND;
+          } else {
+            io.store(handle, ray, -1, sc);
+          }
+        }
+      }
+      resNext += take;
+    }
+    const unsigned long long expMask = __ballot(mode == M_EXPAND);
+    unsigned long long leafMask = __ballot(mode == M_LEAF);
+    if ((expMask | leafMask) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+    bool finished = false;
+    // ---- expand one interior node: ONE 64-byte fetch, two box tests ----
+    if (mode == M_EXPAND) {
+      const uint4* pp = sc.pairs + 4 * (size_t)(cur & 0x1fffffffu);
+      const uint4 l0 = pp[0], l1 = pp[1], r0 = pp[2], r1 = pp[3];
+      bool alive = true;
+      if (retest) {
+        // own box = union of the children's (bvh_accel.dart:521): the literal test the reference does at this pop
+        const float ux0 = fminf(__uint_as_float(l0.x), __uint_as_float(r0.x)), uy0 = fminf(__uint_as_float(l0.y), __uint_as_float(r0.y));
+        const float uz0 = fminf(__uint_as_float(l0.z), __uint_as_float(r0.z)), ux1 = fmaxf(__uint_as_float(l0.w), __uint_as_float(r0.w));
+        const float uy1 = fmaxf(__uint_as_float(l1.x), __uint_as_float(r1.x)), uz1 = fmaxf(__uint_as_float(l1.y), __uint_as_float(r1.y));
+        alive = slab_f64(ray, ux0, uy0, uz0, ux1, uy1, uz1);
+        retest = false;
+      }
+      if (alive) {
+        const uint32_t axis = (cur >> 29) & 3u;
+        const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
+        const bool neg = iv < 0.f;  // near = second child when the ray runs against the split axis (:147-153)
+        const uint4 n0 = neg ? r0 : l0, n1 = neg ? r1 : l1, f0 = neg ? l0 : r0, f1 = neg ? l1 : r1;
+        const float nbx0 = __uint_as_float(n0.x), nby0 = __uint_as_float(n0.y), nbz0 = __uint_as_float(n0.z);
+        const float nbx1 = __uint_as_float(n0.w), nby1 = __uint_as_float(n1.x), nbz1 = __uint_as_float(n1.y);
+        const float fbx0 = __uint_as_float(f0.x), fby0 = __uint_as_float(f0.y), fbz0 = __uint_as_float(f0.z);
+        const float fbx1 = __uint_as_float(f0.w), fby1 = __uint_as_float(f1.x), fbz1 = __uint_as_float(f1.y);
+        // far child: what the reference pushes; decide everything that does not depend on maxDistance now
+        uint32_t farRef = pack_ref(f1.z, f1.w);
+        float farE;
+        if (ray.needF64) {
+          farE = __uint_as_float(0x7fc00000u);  // NaN: always evaluated literally when popped
+        } else {
+          const SlabB fb = slab_bounds(ray, fbx0, fby0, fbz0, fbx1, fby1, fbz1);
+          const bool sureIn = (fb.loU <= fb.hiL) && (fb.hiL > ray.tminHi);
+          const bool sureOut = (fb.loL > fb.hiU) || (fb.hiU <= ray.tminLo);
+          farE = fb.lo;
+          if (sureOut) {
+            farRef = PREF_DEAD;
+          } else if (!sureIn) {
+            double E;
+            if (slab_geom_f64(ray, fbx0, fby0, fbz0, fbx1, fby1, fbz1, &E)) farE = (float)E;
+            else farRef = PREF_DEAD;
+          }
+          // already beyond maxDistance for certain => it will be when popped (maxDistance only shrinks)
+          if (farRef != PREF_DEAD && fb.loL >= ray.tmaxHi && sureIn) farRef = PREF_DEAD;
+        }
+        if (farRef == PREF_DEAD) pushDead();
+        else push(farRef, farE);
+        // near child: visited now
+        ++nNodes;
+        int d = ray.needF64 ? -1 : slab_f32(ray, nbx0, nby0, nbz0, nbx1, nby1, nbz1);
+        if (d < 0) d = slab_f64(ray, nbx0, nby0, nbz0, nbx1, nby1, nbz1) ? 1 : 0;
+        if (d) {
+          cur = pack_ref(n1.z, n1.w);
+          mode = (cur & PREF_LEAF) ? M_LEAF : M_EXPAND;
+        } else if (!popNext()) {
+          finished = true;
+        }
+      } else if (!popNext()) {
+        finished = true;
+      }
+    }
+    // ---- batched leaf tests ----
+    leafMask = __ballot(mode == M_LEAF);
+    const unsigned long long stillExp = __ballot(mode == M_EXPAND && !finished);
+    if (leafMask != 0ull && (__popcll(leafMask) >= DR_LEAF_TH || stillExp == 0ull)) {
+      if (mode == M_LEAF) {
+        const uint32_t leafN = (cur >> 26) & 31u, leafOff = cur & 0x3ffffffu;
+        bool alive = true;
+        if (retest) {
+          // own box = union of the triangles' vertices (Triangle.worldBound, :238-241)
+          float x0 = __uint_as_float(0x7f800000u), y0 = x0, z0 = x0, x1 = -x0, y1 = -x0, z1 = -x0;
+          for (uint32_t i = 0; i < leafN; ++i) {
+            const float4* tp = sc.tris + 3 * (size_t)(leafOff + i);
+            const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+            x0 = fminf(x0, fminf(q0.x, fminf(q0.w, q1.z))); x1 = fmaxf(x1, fmaxf(q0.x, fmaxf(q0.w, q1.z)));
+            y0 = fminf(y0, fminf(q0.y, fminf(q1.x, q1.w))); y1 = fmaxf(y1, fmaxf(q0.y, fmaxf(q1.x, q1.w)));
+            z0 = fminf(z0, fminf(q0.z, fminf(q1.y, q2.x))); z1 = fmaxf(z1, fmaxf(q0.z, fmaxf(q1.y, q2.x)));
+          }
+          alive = slab_f64(ray, x0, y0, z0, x1, y1, z1);
+          retest = false;
+        }
+        bool occluded = false, shrunk = false;
+        if (alive) {
+          for (uint32_t i = 0; i < leafN; ++i) {
+            ++nTris;
+            const float4* tp = sc.tris + 3 * (size_t)(leafOff + i);
+            const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+            const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
+            if (ANY) {
+              if (tri_hitP(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax)) {
+                occluded = true;
+                break;
+              }
+            } else {
+              double t, b1, b2;
+              if (tri_hit(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax, &t, &b1, &b2)) {
+                ray_set_tmax(ray, t);
+                hit = (int)(leafOff + i);
+                shrunk = true;
+              }
+            }
+          }
+        }
+        if (shrunk) pruneStack();
+        if (occluded) {
+          hit = 0;
+          finished = true;
+        } else if (!popNext()) {
+          finished = true;
+        }
+      }
+    }
+    if (finished) {
+      io.store(handle, ray, hit, sc);
+      mode = M_IDLE;
+    }
+  }
+  flush_counters(ctr, ANY, nRays, nNodes, nTris);
+}
+
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_trace3(DScene sc, BatchState st, const uint32_t* queue,
+                                                                            const uint32_t* nQueue, uint32_t* spill,
+                                                                            uint32_t* work, TraceCounters* ctr) {
+  __shared__ uint32_t s_ref[DR_PSTACK * DR_TRACE_BLOCK];
+  __shared__ float s_e[DR_PSTACK * DR_TRACE_BLOCK];
+  StateIO<ANY> io{st, queue};
+  const uint32_t n = nQueue ? *nQueue : st.nslots;
+  const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
+  trace_pairs<ANY>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x,
+                   spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr, stride,
+                   stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
+}
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_intersect3(DScene sc, const DrRay* rays, uint32_t n,
+                                                                                DrHit* out, uint32_t* spill, uint32_t* work,
+                                                                                TraceCounters* ctr) {
+  __shared__ uint32_t s_ref[DR_PSTACK * DR_TRACE_BLOCK];
+  __shared__ float s_e[DR_PSTACK * DR_TRACE_BLOCK];
+  RayIO<ANY> io{rays, out};
+  const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
+  trace_pairs<ANY>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x,
+                   spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr, stride,
+                   stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
+}
+
 // ---------------------------------------------------------------------------
-// launchers.  DARTRAY_TRACE_IMPL=1 selects the first (non-refilling) version for A/B runs.
+// launchers.  DARTRAY_TRACE_IMPL selects the kernel for A/B runs: 1 = first version, 2 = default, 3 = sibling pairs.
 // ---------------------------------------------------------------------------
-static int traceImpl() {
+static int traceImpl(const DScene& sc) {
   static int impl = -1;
   if (impl < 0) {
     const char* e = getenv("DARTRAY_TRACE_IMPL");
-    impl = (e && e[0] == '1') ? 1 : 2;
+    impl = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 2;  // v2 is the fastest measured
   }
-  return impl;
+  return (impl == 3 && !sc.pairs) ? 2 : impl;  // scenes the pair layout cannot encode use v2
 }
 void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
                       uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
   const dim3 g(grid), b(DR_TRACE_BLOCK);
-  if (traceImpl() == 1) {
+  const int impl = traceImpl(sc);
+  if (impl == 3) {
+    if (anyHit) hipLaunchKernelGGL(k_intersect3<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+    else hipLaunchKernelGGL(k_intersect3<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+  } else if (impl == 1) {
     if (anyHit) hipLaunchKernelGGL(k_intersect_v1<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_intersect_v1<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
   } else {
@@ -566,7 +939,11 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
 void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
   const dim3 g(grid), b(DR_TRACE_BLOCK);
-  if (traceImpl() == 1) {
+  const int impl = traceImpl(sc);
+  if (impl == 3) {
+    if (anyHit) hipLaunchKernelGGL(k_trace3<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+    else hipLaunchKernelGGL(k_trace3<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+  } else if (impl == 1) {
     if (anyHit) hipLaunchKernelGGL(k_trace_v1<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace_v1<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
   } else {

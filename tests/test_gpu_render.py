@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from dartray_amd import _abi, core, scenes
 from util import rel_err_image
 
@@ -166,6 +166,30 @@ def test_render_is_deterministic_and_device_film_accumulates(gpu):
     _abi.check(_abi.lib().dr_film_resolve_device(film.data_ptr(), 32 * 32, rgb.data_ptr(), stream))
     torch.cuda.synchronize()
     assert np.array_equal(film.cpu().numpy(), a.film) and np.array_equal(rgb.cpu().numpy(), a.rgb)
+
+
+@pytest.mark.parametrize("impl", ["1", "3"])
+def test_alternative_traversal_kernels_are_bit_exact_too(impl):
+    """DARTRAY_TRACE_IMPL selects the first traversal kernel (1) or the sibling-pair experiment (3) for A/B
+    runs; both must reproduce the oracle's hits, visit counts and image exactly, like the default (2)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "import oracle.binding as ob\n"
+        "from dartray_amd import _abi, scenes\n"
+        "_abi.init(0)\n"
+        "prims, mk = scenes.config('C2', xres=40, yres=40, spp=16, blob=(60, 30))\n"
+        "r = mk(); out = r.render(scenes.make_scene(prims))\n"
+        "osc = ob.OracleScene(prims); osc.counters(reset=True)\n"
+        "ref = osc.render(ob.render_desc(r, sampler_mode=1)); c = osc.counters(); st = r.last_stats\n"
+        "assert np.array_equal(out.film, ref['film'])\n"
+        "assert all(st[k] == c[k] for k in ('closest_nodes', 'any_nodes', 'closest_tris', 'any_tris', 'closest_rays', 'any_rays'))\n"
+        "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ, DARTRAY_TRACE_IMPL=impl)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
 
 
 def test_invalid_arguments_raise(gpu):
