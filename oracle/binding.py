@@ -31,7 +31,7 @@ class OrcSceneDesc(C.Structure):
     _fields_ = [("nmeshes", C.c_int32), ("meshes", C.POINTER(OrcMesh)), ("max_prims_in_node", C.c_int32),
                 ("has_env", C.c_int32), ("env_texels", C.c_void_p), ("env_w", C.c_int32), ("env_h", C.c_int32),
                 ("env_L", C.c_float * 3), ("env_l2w", C.c_float * 16), ("env_w2l", C.c_float * 16),
-                ("env_nsamples", C.c_int32)]
+                ("env_nsamples", C.c_int32), ("env_before_mesh", C.c_int32)]
 
 
 class OrcRenderDesc(C.Structure):
@@ -122,8 +122,9 @@ class OracleScene:
     """Scene built by the oracle from the same GeometricPrimitive list the product takes
     (objects with .shape.{P,vertexIndex,reverseOrientation}, .material.{Kd,sigma}, .areaLight)."""
 
-    def __init__(self, prims, max_prims=4, env=None):
-        """env: optional InfiniteAreaLight-like object (.texels [H,W,3] f32, .L, .lightToWorld, .worldToLight, .nSamples)."""
+    def __init__(self, prims, max_prims=4, env=None, env_before=None):
+        """env: optional InfiniteAreaLight-like object (.texels [H,W,3] f32, .L, .lightToWorld, .worldToLight, .nSamples);
+        env_before: index of the primitive whose area light follows it in Scene.lights (None: the env light is last)."""
         l = lib()
         meshes = (OrcMesh * max(len(prims), 1))()
         self._keep = []
@@ -142,6 +143,7 @@ class OracleScene:
                 m.L[:] = [float(x) for x in gp.areaLight.Lemit]
                 m.light_nsamples = gp.areaLight.nSamples
         d = OrcSceneDesc(len(prims), meshes, max_prims)
+        d.env_before_mesh = -1 if env_before is None else int(env_before)
         if env is not None:
             tex = np.ascontiguousarray(env.texels, np.float32)
             self._keep.append(tex)

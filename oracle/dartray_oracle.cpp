@@ -1558,6 +1558,9 @@ struct OrcSceneDesc {
   float env_L[3];
   float env_l2w[16], env_w2l[16];
   int32_t env_nsamples;
+  // position in Scene.lights: the InfiniteAreaLight precedes the area light of mesh `env_before_mesh`
+  // (LightSource and Shape directives append in file order, dartray.dart:368-375,461-466); < 0 => after all
+  int32_t env_before_mesh;
 };
 struct OrcNode {  // the 32-byte marshalled node of SURVEY.md Appendix F
   float bmin[3], bmax[3];
@@ -1617,7 +1620,27 @@ void* orc_scene_create(const OrcSceneDesc* d) {
   // DartRay.shape: one GeometricPrimitive per mesh, one DiffuseAreaLight per emissive shape (dartray.dart:380-401).
   // Primitive.fullyRefine / ShapeSet pop a LIFO stack => triangle order within a mesh is reversed
   // (primitive.dart:71-84; shape_set.dart:25-35).
+  bool envFailed = false;
+  auto addEnv = [&]() {
+    if (!d->has_env || sc->hasEnv || envFailed) return;
+    sc->env.L = rgb(d->env_L[0], d->env_L[1], d->env_L[2]);
+    memcpy(sc->env.l2w, d->env_l2w, sizeof(sc->env.l2w));
+    memcpy(sc->env.w2l, d->env_w2l, sizeof(sc->env.w2l));
+    sc->env.nSamples = std::max(1, d->env_nsamples);
+    if (!sc->env.init(d->env_texels, d->env_w, d->env_h)) {
+      envFailed = true;
+      return;
+    }
+    sc->hasEnv = true;
+    Light L;
+    L.kind = 1;
+    L.Lemit = sc->env.L;
+    L.nSamples = sc->env.nSamples;
+    L.area = 0.0;
+    sc->lights.push_back(L);
+  };
   for (int m = 0; m < d->nmeshes; ++m) {
+    if (d->env_before_mesh >= 0 && m == d->env_before_mesh) addEnv();
     const OrcMesh& om = d->meshes[m];
     uint32_t base = (uint32_t)(sc->P.size() / 3);
     sc->P.insert(sc->P.end(), om.P, om.P + 3 * (size_t)om.nverts);
@@ -1658,22 +1681,10 @@ void* orc_scene_create(const OrcSceneDesc* d) {
       sc->prims.push_back(p);
     }
   }
-  if (d->has_env) {
-    sc->env.L = rgb(d->env_L[0], d->env_L[1], d->env_L[2]);
-    memcpy(sc->env.l2w, d->env_l2w, sizeof(sc->env.l2w));
-    memcpy(sc->env.w2l, d->env_w2l, sizeof(sc->env.w2l));
-    sc->env.nSamples = std::max(1, d->env_nsamples);
-    if (!sc->env.init(d->env_texels, d->env_w, d->env_h)) {
-      delete sc;
-      return nullptr;
-    }
-    sc->hasEnv = true;
-    Light L;
-    L.kind = 1;
-    L.Lemit = sc->env.L;
-    L.nSamples = sc->env.nSamples;
-    L.area = 0.0;
-    sc->lights.push_back(L);
+  addEnv();
+  if (envFailed) {
+    delete sc;
+    return nullptr;
   }
   Builder b;
   b.sc = sc;

@@ -90,3 +90,20 @@ def test_c5_class_scene_renders_and_uses_all_lights(ob):
     assert r.surfaceIntegrator.maxDepth == 8
     # the full-size generator yields exactly 8 003 088 triangles (8M +- 1 %)
     assert 16 * 16 * 125 * 125 * 2 + 256 * 12 + 16 == 8003088
+
+
+def test_position_of_the_infinite_light_in_scene_lights(ob):
+    """LightSource / Shape directives append to Scene.lights in file order (dartray.dart:368-375, 461-466);
+    OrcSceneDesc.env_before_mesh places the infinite light accordingly and the order is observable."""
+    prims = scenes.cornell_prims()
+    env = core.InfiniteAreaLight(scenes.SKY_TO_WORLD, (0.5, 0.6, 0.7), 1, None)
+    film = core.ImageFilm(12, 12)
+    cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
+    r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 8), cam, core.PathIntegrator(3), core.EmissionIntegrator())
+    first_light = next(i for i, gp in enumerate(prims) if gp.areaLight is not None)
+    last = ob.OracleScene(prims, env=env).render(ob.render_desc(r, sampler_mode=1))["film"]
+    same = ob.OracleScene(prims, env=env, env_before=len(prims)).render(ob.render_desc(r, sampler_mode=1))["film"]
+    first = ob.OracleScene(prims, env=env, env_before=first_light).render(ob.render_desc(r, sampler_mode=1))["film"]
+    assert np.array_equal(last, same)
+    assert not np.array_equal(last, first)
+    assert np.isfinite(first).all() and first[..., :3].mean() > 0

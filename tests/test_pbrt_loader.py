@@ -1,0 +1,258 @@
+"""Host logic of the PBRT scene front end: lexer, parameter sets, CTM /
+attribute-stack semantics of lib/dartray/dartray.dart and the hand-off to the BVH builder.  CPU only."""
+import gzip
+import math
+import os
+
+import numpy as np
+import pytest
+
+from dartray_amd import core, pbrt, scenes
+
+HEADER = '''
+Film "image" "integer xresolution" [64] "integer yresolution" [48]
+SurfaceIntegrator "path" "integer maxdepth" [3]
+Sampler "lowdiscrepancy" "integer pixelsamples" [6]   # rounds up to 8
+LookAt 0 0 -35  0 0 0  0 1 0
+Camera "perspective" "float fov" [35]
+'''
+
+QUAD = '"integer indices" [0 1 2 0 2 3] "point P" [-1 0 -1  1 0 -1  1 0 1  -1 0 1]'
+
+
+def test_lexer_tokens_comments_and_strings():
+    lx = pbrt.PbrtLexer('Shape "disk" # comment "x"\n  \'float radius\' [ -3.5e-1 .25 4 ]\nWorldEnd')
+    toks = []
+    while True:
+        t = lx.next()
+        if t[0] == "eof":
+            break
+        toks.append(t)
+    assert toks == [("id", "Shape"), ("str", "disk"), ("str", "float radius"), ("[",), ("num", "-3.5e-1"), ("num", ".25"),
+                    ("num", "4"), ("]",), ("id", "WorldEnd")]
+
+
+def test_param_set_types_and_case_insensitive_names():
+    ps = pbrt.ParamSet()
+    ps.add("color", "Kd", ["0.1", "0.2", "0.3"])
+    ps.add("float", "fov", ["35"])
+    ps.add("integer", "indices", ["0", "1", "2"])
+    ps.add("bool", "flag", ["true"])
+    ps.add("point", "P", ["0", "1", "2", "3", "4", "5"])
+    assert np.allclose(ps.findOneSpectrum("kd", (0, 0, 0)), [0.1, 0.2, 0.3])
+    assert ps.findOneFloat("fov", 60.0) == 35.0
+    assert ps.findOneInt("fov", 7) == 7            # typed lookups: a float is not an integer
+    assert ps.findOneInt("indices", 9) == 9        # findOne* only returns single-valued entries
+    assert ps.findInt("indices") == [0, 1, 2]
+    assert ps.findOneBool("flag", False) is True
+    assert ps.findPoint("p").shape == (2, 3)
+    assert ps.unused() == []
+    with pytest.raises(pbrt.UnsupportedFeature):
+        ps.add("spectrum", "Kd", ["300", "1"])
+    with pytest.raises(ValueError):
+        ps.add("quaternion", "q", ["1"])
+
+
+def test_transform_factories_follow_the_reference_numerics():
+    t = pbrt.Transform.Translate(4, -7, 4) * pbrt.Transform.Scale(0.3, 0.4, 0.3) * pbrt.Transform.Rotate(30, 0, 1, 0)
+    c, s = math.cos(math.radians(30)), math.sin(math.radians(30))
+    want = np.array([[0.3 * c, 0, 0.3 * s, 4], [0, 0.4, 0, -7], [-0.3 * s, 0, 0.3 * c, 4], [0, 0, 0, 1]])
+    assert t.m.dtype == np.float32 and np.allclose(t.m, want, atol=1e-6)
+    assert np.allclose(t.m.astype(np.float64) @ t.mInv.astype(np.float64), np.eye(4), atol=1e-6)
+    # every factor is rounded to f32 before the next product (Matrix4x4.Mul stores into a Float32List)
+    step = (pbrt.Transform.Translate(4, -7, 4).m.astype(np.float64) @ pbrt.Transform.Scale(0.3, 0.4, 0.3).m.astype(np.float64))
+    step = step.astype(np.float32).astype(np.float64) @ pbrt.Transform.Rotate(30, 0, 1, 0).m.astype(np.float64)
+    assert np.array_equal(t.m, step.astype(np.float32))
+    # adjugate inverse, singular matrices are returned unchanged (matrix4x4.dart:264-266)
+    sing = np.zeros((4, 4), np.float32)
+    assert np.array_equal(pbrt._inverse(sing), sing)
+    m = pbrt.Transform.Rotate(17, 1, 2, 3).m
+    assert np.allclose(pbrt._inverse(m), m.T, atol=1e-6)
+    p = pbrt.Transform.Translate(1, 2, 3).transformPoints([[1, 1, 1]])
+    assert p.dtype == np.float32 and p.tolist() == [[2.0, 3.0, 4.0]]
+
+
+def test_lookat_camera_matches_the_programmatic_camera():
+    api = pbrt.loads(HEADER + "WorldBegin\nShape \"trianglemesh\" " + QUAD + "\nWorldEnd")
+    r = api.rendererObject
+    film = core.ImageFilm(64, 48)
+    cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
+    assert np.array_equal(r.camera.cameraToWorld, cam.cameraToWorld)
+    assert np.array_equal(r.camera.rasterToCamera, cam.rasterToCamera)
+    assert r.sampler.samplesPerPixel == 8 and r.surfaceIntegrator.maxDepth == 3
+    assert isinstance(r.surfaceIntegrator, core.PathIntegrator)
+    assert (r.camera.film.xResolution, r.camera.film.yResolution) == (64, 48)
+
+
+def test_defaults_are_the_reference_render_options():
+    api = pbrt.loads("WorldBegin\nShape \"trianglemesh\" " + QUAD + "\nWorldEnd")  # render_options.dart:24-40
+    r = api.rendererObject
+    assert isinstance(r.surfaceIntegrator, core.DirectLightingIntegrator)
+    assert (r.camera.film.xResolution, r.camera.film.yResolution) == (640, 480)
+    assert r.sampler.samplesPerPixel == 4
+    assert np.array_equal(r.camera.cameraToWorld, np.eye(4, dtype=np.float32))
+    assert np.allclose(api.scenePrimitives[0].material.Kd, 0.5)
+
+
+def test_attribute_stack_restores_ctm_material_area_light_and_orientation():
+    api = pbrt.loads(HEADER + f'''
+WorldBegin
+Material "matte" "color Kd" [0.1 0.2 0.3]
+AttributeBegin
+  Translate 0 5 0
+  ReverseOrientation
+  Material "matte" "color Kd" [0.9 0.9 0.9]
+  AreaLightSource "area" "color L" [2 3 4] "color scale" [2 2 2] "integer nsamples" [3]
+  Shape "trianglemesh" {QUAD}
+  TransformBegin
+    Scale 2 2 2
+    Shape "trianglemesh" {QUAD} "color Kd" [0.4 0.4 0.4]
+  TransformEnd
+  Shape "trianglemesh" {QUAD}
+AttributeEnd
+Shape "trianglemesh" {QUAD}
+WorldEnd
+''')
+    p = api.scenePrimitives
+    assert len(p) == 4
+    assert [g.shape.reverseOrientation for g in p] == [True, True, True, False]
+    assert np.allclose(p[0].material.Kd, 0.9) and np.allclose(p[1].material.Kd, 0.4) and np.allclose(p[3].material.Kd, [0.1, 0.2, 0.3])
+    assert p[0].shape.P[:, 1].tolist() == [5.0] * 4
+    assert p[1].shape.P[0].tolist() == [-2.0, 5.0, -2.0]     # CTM = Translate * Scale
+    assert p[2].shape.P[0].tolist() == [-1.0, 5.0, -1.0]     # TransformEnd restored it
+    assert p[3].shape.P[0].tolist() == [-1.0, 0.0, -1.0]     # AttributeEnd restored it
+    assert [g.areaLight is not None for g in p] == [True, True, True, False]
+    assert np.allclose(p[0].areaLight.Lemit, [4, 6, 8]) and p[0].areaLight.nSamples == 3
+    assert api.sceneLights == [g.areaLight for g in p[:3]]   # one DiffuseAreaLight per emissive shape, file order
+
+
+def test_lights_keep_file_order_and_named_coordinate_systems():
+    api = pbrt.loads(HEADER + f'''
+WorldBegin
+AttributeBegin
+  AreaLightSource "area" "color L" [1 1 1]
+  Shape "trianglemesh" {QUAD}
+AttributeEnd
+AttributeBegin
+  Rotate 90 1 0 0
+  CoordinateSystem "sky"
+  LightSource "infinite" "color L" [0.5 0.5 0.5] "integer nsamples" [4]
+AttributeEnd
+AttributeBegin
+  AreaLightSource "area" "color L" [2 2 2]
+  Shape "trianglemesh" {QUAD}
+AttributeEnd
+AttributeBegin
+  CoordSysTransform "camera"
+  Shape "trianglemesh" {QUAD}
+AttributeEnd
+WorldEnd
+''')
+    kinds = [type(l).__name__ for l in api.sceneLights]
+    assert kinds == ["DiffuseAreaLight", "InfiniteAreaLight", "DiffuseAreaLight"]
+    env, before = api.envLight()
+    assert env.nSamples == 4 and before == 1
+    assert np.allclose(env.lightToWorld @ env.worldToLight, np.eye(4), atol=1e-6)
+    assert np.allclose(env.lightToWorld[:3, :3], [[1, 0, 0], [0, 0, -1], [0, 1, 0]], atol=1e-6)
+    # the 'camera' coordinate system is camera-to-world: the quad moves to the eye point
+    assert np.allclose(api.scenePrimitives[2].shape.P.mean(0), [0, 0, -35])
+    assert api.scene.lights == api.sceneLights
+
+
+def test_include_gz_and_relative_paths(tmp_path):
+    geo = tmp_path / "geometry"
+    geo.mkdir()
+    with gzip.open(geo / "quad.pbrt.gz", "wt") as f:
+        f.write(f'Shape "trianglemesh" {QUAD}\n')
+    (tmp_path / "mat.pbrt").write_text('Material "matte" "color Kd" [0.2 0.4 0.6]\nInclude "geometry/quad.pbrt.gz"\n')
+    (tmp_path / "scene.pbrt").write_text(HEADER + 'WorldBegin\nInclude "mat.pbrt"\nTranslate 1 0 0\nInclude "geometry/quad.pbrt.gz"\nWorldEnd\n')
+    api = pbrt.load(str(tmp_path / "scene.pbrt"))
+    assert len(api.scenePrimitives) == 2
+    assert np.allclose(api.scenePrimitives[1].material.Kd, [0.2, 0.4, 0.6])
+    assert api.scenePrimitives[1].shape.P[0].tolist() == [0.0, 0.0, -1.0]
+    with pytest.raises(FileNotFoundError):
+        pbrt.loads('Include "nope.pbrt"', base=str(tmp_path))
+
+
+@pytest.mark.parametrize("snippet,needle", [
+    ('Shape "sphere" "float radius" 3', 'Shape "sphere"'),
+    ('Shape "disk" "float radius" [3]', 'Shape "disk"'),
+    ('Material "glass"\nShape "trianglemesh" ' + QUAD, 'Material "glass"'),
+    ('Material "matte" "float sigma" [20]\nShape "trianglemesh" ' + QUAD, "Oren-Nayar"),
+    ('Texture "t" "color" "imagemap" "string filename" "x.png"', "Texture"),
+    ('LightSource "point" "color I" [1 1 1]', 'LightSource "point"'),
+    ('LightSource "infinite" "string mapname" ["sky.exr"]', "image decoders"),
+    ('Volume "homogeneous"', "Volume"),
+    ('ObjectBegin "a"', "instancing"),
+    ('ActiveTransform StartTime', "animated"),
+    ('Shape "trianglemesh" ' + QUAD + ' "float uv" [0 0 1 0 1 1 0 1]', "uv"),
+    ('Shape "trianglemesh" ' + QUAD + ' "normal N" [0 1 0 0 1 0 0 1 0 0 1 0]', "'N'"),
+    ('Material "matte" "spectrum Kd" [400 1 700 1]', "spectrum"),
+])
+def test_plugins_outside_the_path_fail_loudly_with_position(snippet, needle):
+    with pytest.raises(pbrt.UnsupportedFeature) as e:
+        pbrt.loads(HEADER + "WorldBegin\n" + snippet + "\nWorldEnd\n")
+    assert needle in str(e.value) and "<string>:" in str(e.value)
+
+
+@pytest.mark.parametrize("opt,needle", [
+    ('PixelFilter "gaussian"', "PixelFilter"), ('Sampler "random"', "Sampler"), ('Camera "orthographic"', "Camera"),
+    ('Renderer "metropolis"', "Renderer"), ('SurfaceIntegrator "whitted"', "SurfaceIntegrator"),
+    ('Accelerator "kdtree"', "Accelerator"), ('Film "other"', "Film"),
+])
+def test_render_options_outside_the_path_fail_at_world_end(opt, needle):
+    with pytest.raises(pbrt.UnsupportedFeature) as e:
+        pbrt.loads(opt + "\nWorldBegin\nShape \"trianglemesh\" " + QUAD + "\nWorldEnd\n")
+    assert needle in str(e.value)
+
+
+def test_malformed_input_is_rejected():
+    with pytest.raises(ValueError):
+        pbrt.loads("Translate 1 2")
+    with pytest.raises(ValueError):
+        pbrt.loads("Frobnicate \"x\"")
+    with pytest.raises(ValueError):
+        pbrt.loads('Shape "trianglemesh" "integerindices" [0 1 2]')
+
+
+def test_cornell_text_scene_equals_the_programmatic_scene(ob):
+    """The Cornell walls of scenes.py written as .pbrt text flatten to the same primitives, the same BVH
+    (bit-identical nodes) and the same oracle image inputs."""
+    prims = scenes.cornell_prims(scenes.blob_prim(12, 6))
+    body = []
+    for gp in prims:
+        P = " ".join(repr(float(v)) for v in gp.shape.P.reshape(-1))
+        idx = " ".join(str(int(v)) for v in gp.shape.vertexIndex.reshape(-1))
+        kd = " ".join(repr(float(v)) for v in gp.material.Kd)
+        body.append("AttributeBegin")
+        if gp.areaLight is not None:
+            L = " ".join(repr(float(v)) for v in gp.areaLight.Lemit)
+            body.append(f'AreaLightSource "area" "color L" [{L}] "integer nsamples" [{gp.areaLight.nSamples}]')
+        body.append(f'Material "matte" "color Kd" [{kd}]')
+        body.append(f'Shape "trianglemesh" "integer indices" [{idx}] "point P" [{P}]')
+        body.append("AttributeEnd")
+    api = pbrt.loads(HEADER + "WorldBegin\n" + "\n".join(body) + "\nWorldEnd\n")
+    assert len(api.scenePrimitives) == len(prims)
+    for a, b in zip(api.scenePrimitives, prims):
+        assert np.array_equal(a.shape.P, b.shape.P) and np.array_equal(a.shape.vertexIndex, b.shape.vertexIndex)
+        assert np.array_equal(a.material.Kd, b.material.Kd)
+        assert (a.areaLight is None) == (b.areaLight is None)
+    want = core.BVHAccel(prims)
+    assert np.array_equal(api.scene.aggregate.nodes, want.nodes)
+    onodes = ob.OracleScene(api.scenePrimitives).bvh()[0]
+    assert len(onodes) == len(want.nodes)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/web/scenes"), reason="reference checkout not present")
+def test_bundled_reference_scenes_parse_up_to_the_first_plugin_off_the_path():
+    """The bundled demo scenes all use at least one plugin outside SURVEY.md section 8 (disk / sphere shapes,
+    measured / plastic / metal materials, volumes, image maps): the loader must name it, never skip it."""
+    base = "/root/reference/web/scenes"
+    seen = {}
+    for name in sorted(os.listdir(base)):
+        if name.endswith(".pbrt"):
+            with pytest.raises(pbrt.UnsupportedFeature) as e:
+                pbrt.load(os.path.join(base, name))
+            seen[name] = str(e.value)
+    assert 'Shape "disk"' in seen["cornell-path.pbrt"] and "cornell-path.pbrt:17" in seen["cornell-path.pbrt"]
+    assert len(seen) >= 8
