@@ -104,6 +104,7 @@ EXPORTS = {
     "dr_scene_destroy": (None, [C.c_void_p]),
     "dr_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "dr_sample_floats": (C.c_int32, [C.c_int32, C.c_uint32]),
+    "dr_scene_sample_floats": (C.c_int32, [C.c_void_p, C.c_int32]),
     "dr_render": (C.c_int, [C.c_void_p, C.POINTER(DrRenderDesc), C.c_void_p, C.c_void_p]),
     "dr_render_device": (C.c_int, [C.c_void_p, C.POINTER(DrRenderDesc), C.c_void_p, C.c_void_p]),
     "dr_film_resolve_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -81,6 +81,11 @@ struct DrScene {
   DevBuf<TraceCounters> ctr;
   uint32_t bvhDepth = 0;
   std::vector<int32_t> lightNSamples;
+  // DirectLighting sample layout (direct_lighting_integrator.dart:70-87), fixed by the lights' nsamples
+  DevBuf<LdBlock> dlBlocks;
+  DevBuf<DirectStage> dlStages;
+  int dlNBlocks = 0, dlNStages = 0, dlNFloats = 0, dlN1D = 0;
+  bool dlMulti = false;
   Workspace ws;
   // stats of the last render
   DrRenderStats stats;
@@ -323,6 +328,11 @@ int32_t dr_sample_floats(int32_t integrator, uint32_t nlights) {
   // SURVEY.md Appendix B.  Path: 3 x (light 1D+2D, lightNum 1D, bsdf 1D+2D, path 1D+2D) + tau + scatter.
   if (integrator == DR_INTEGRATOR_PATH) return 5 + 14 + 18;
   return 5 + (2 * (int)nlights + 2) + 4 * (int)nlights;
+}
+
+int32_t dr_scene_sample_floats(const DrScene* scene, int32_t integrator) {
+  if (!scene) return -1;
+  return integrator == DR_INTEGRATOR_DIRECT_ALL ? scene->dlNFloats : dr_sample_floats(integrator, scene->d.nlights);
 }
 
 int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
@@ -621,6 +631,51 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   sc->d.ntris = (uint32_t)desc->ntris;
   sc->d.nlights = desc->nlights;
   sc->d.nmats = desc->nmaterials;
+  {  // DirectLighting: one 1-D + one 2-D slot pair per light for the light sample and one for the BSDF sample, each
+     // with roundSize(nSamples) entries (low_discrepancy_sampler.dart:43-49), then the two 1-D volume slots
+    auto rp2 = [](int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; };
+    const size_t nl = sc->lightNSamples.size();
+    std::vector<int> ns(nl);
+    int n1D = 2;
+    for (size_t i = 0; i < nl; ++i) {
+      ns[i] = rp2(std::max(1, sc->lightNSamples[i]));
+      n1D += 2 * ns[i];
+      if (ns[i] != 1) sc->dlMulti = true;
+    }
+    std::vector<LdBlock> blocks;
+    blocks.push_back({0, 1, 1, 0});
+    blocks.push_back({2, 1, 1, 0});
+    blocks.push_back({4, 1, 0, 0});
+    std::vector<DirectStage> stages;
+    int o1 = 5, o2 = 5 + n1D;
+    for (size_t i = 0; i < nl; ++i) {
+      blocks.push_back({o1, ns[i], 0, 0});
+      blocks.push_back({o1 + ns[i], ns[i], 0, 0});
+      for (int j = 0; j < ns[i]; ++j)
+        stages.push_back({(int)i, ns[i], j == ns[i] - 1 ? 1 : 0, o1 + j, o2 + 2 * j, o2 + 2 * ns[i] + 2 * j, 0, 0});
+      o1 += 2 * ns[i];
+      o2 += 4 * ns[i];
+    }
+    blocks.push_back({o1, 1, 0, 0});
+    blocks.push_back({o1 + 1, 1, 0, 0});
+    {  // the 2-D blocks follow all 1-D blocks (montecarlo.dart:441-448)
+      int p2 = 5 + n1D;
+      for (size_t i = 0; i < nl; ++i) {
+        blocks.push_back({p2, ns[i], 1, 0});
+        blocks.push_back({p2 + 2 * ns[i], ns[i], 1, 0});
+        p2 += 4 * ns[i];
+      }
+    }
+    sc->dlNBlocks = (int)blocks.size();
+    sc->dlNStages = (int)stages.size();
+    sc->dlNFloats = o2;
+    sc->dlN1D = n1D;
+    TRY_SC(sc->dlBlocks.alloc(blocks.size()));
+    TRY_SC(sc->dlStages.alloc(std::max<size_t>(stages.size(), 1)));
+    TRY_SC(hipMemcpy(sc->dlBlocks.p, blocks.data(), blocks.size() * sizeof(LdBlock), hipMemcpyHostToDevice));
+    if (!stages.empty())
+      TRY_SC(hipMemcpy(sc->dlStages.p, stages.data(), stages.size() * sizeof(DirectStage), hipMemcpyHostToDevice));
+  }
   *out = sc;
   return DR_OK;
 #undef TRY_SC
@@ -670,9 +725,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (spp > 1024) return fail(DR_ERR_UNSUPPORTED, "spp > 1024");
   if (rd->integrator != DR_INTEGRATOR_PATH && rd->integrator != DR_INTEGRATOR_DIRECT_ALL)
     return fail(DR_ERR_INVALID, "unknown integrator");
-  if (rd->integrator == DR_INTEGRATOR_DIRECT_ALL)
-    for (int32_t ns : sc->lightNSamples)
-      if (ns != 1) return fail(DR_ERR_UNSUPPORTED, "DirectLighting on the device needs light nsamples == 1");
   if (rd->max_depth < 0 || rd->max_depth > 64) return fail(DR_ERR_INVALID, "max_depth out of range");
 
   RenderParams rp;
@@ -690,8 +742,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.sppShift = 0;
   while ((1 << rp.sppShift) < spp) ++rp.sppShift;
   rp.nLights = (int)sc->d.nlights;
-  rp.nFloats = dr_sample_floats(rd->integrator, sc->d.nlights);
-  rp.n1D = rd->integrator == DR_INTEGRATOR_PATH ? 14 : 2 * rp.nLights + 2;
+  const bool direct = rd->integrator == DR_INTEGRATOR_DIRECT_ALL;
+  rp.nFloats = direct ? sc->dlNFloats : dr_sample_floats(rd->integrator, sc->d.nlights);
+  rp.n1D = direct ? sc->dlN1D : 14;
+  rp.blocks = direct && sc->dlMulti ? sc->dlBlocks.p : nullptr;
+  rp.nBlocks = sc->dlNBlocks;
+  rp.dstages = sc->dlStages.p;
+  rp.nDirectStages = direct ? sc->dlNStages : 0;
   rp.samplerMode = rd->sampler_mode;
   rp.seed = (uint64_t)rd->seed;
   const int perNee = rp.nLights > 0 ? 7 : 0;
@@ -749,7 +806,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // pixels is a local: the async copy above must complete before it goes out of scope
   HIP_TRY(hipStreamSynchronize(s));
   const int sgrid = g_numCU * 2;  // 512-thread workgroups, grid-stride over the active list
-  const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : rp.nLights + 1;
+  const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
   if (4 * nStages + 8 > 1024 || 8 * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
 
   for (size_t p0 = 0; p0 < npixTotal; p0 += pixPerBatch) {

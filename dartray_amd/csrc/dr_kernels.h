@@ -9,6 +9,17 @@
 #include "../../include/dartray_hip.h"
 #include "dr_device.h"
 
+// One LDShuffleScrambled1D/2D block of the camera-sample vector (montecarlo.dart:437-448): `n` entries per
+// pixel sample starting at float `dst` (2-D entries interleave x, y).
+struct LdBlock {
+  int32_t dst, n, is2D, pad;
+};
+// One EstimateDirect call of UniformSampleAllLights (integrator.dart:39-77): sample j of light `light`;
+// lc / lp / bd are the float indices of its light component, light position and BSDF direction samples.
+struct DirectStage {
+  int32_t light, n, last, lc, lp, bd, pad0, pad1;
+};
+
 // Per-render constants (by-value kernel argument).
 struct RenderParams {
   float r2c[16], c2w[16];
@@ -24,7 +35,10 @@ struct RenderParams {
   // full sampler extent (ImageFilm.getSampleExtent image_film.dart:247-252): keys of the counter streams
   int32_t extX0, extY0, extW, extH;
   int32_t maxTail;
-  int32_t pad;
+  int32_t nBlocks;             // LD blocks per pixel: image, lens, time, 1-D slots, 2-D slots
+  const LdBlock* blocks;       // null => every slot has one entry and the layout is arithmetic
+  const DirectStage* dstages;  // DirectLighting: nDirectStages entries
+  int32_t nDirectStages, pad;
 };
 
 // Flags of a path slot.

@@ -65,7 +65,13 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
   const int spp = rp.spp;
   bool is2D;
   int dst;
-  if (k == 0) { is2D = true; dst = 0; }
+  if (rp.blocks) {
+    const LdBlock b = rp.blocks[k];
+    if (b.n != 1) return;  // k_gen_samples_multi's
+    is2D = b.is2D != 0;
+    dst = b.dst;
+  }
+  else if (k == 0) { is2D = true; dst = 0; }
   else if (k == 1) { is2D = true; dst = 2; }
   else if (k == 2) { is2D = false; dst = 4; }
   else if (k < 3 + rp.n1D) { is2D = false; dst = 5 + (k - 3); }
@@ -97,6 +103,49 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
     const uint32_t idx = s_perm[j * ROW + pl];
     out0[e] = VanDerCorput(idx, s_scr[pl]);
     if (is2D) out1[e] = Sobol2(idx, s_scr[64 + pl]);
+  }
+}
+
+// Blocks with n > 1 entries per pixel sample (DirectLighting with light nsamples > 1): lane = pixel, the
+// n*spp values are generated and shuffled in place in the sample-vector arrays.  Element (sample i, entry j,
+// dim d) lives at sv[(dst + dims*j + d)][p*spp + i].  Rare configuration: correctness over speed.
+__global__ void __launch_bounds__(64) k_gen_samples_multi(RenderParams rp, BatchState st, uint32_t npix) {
+  const uint32_t p = blockIdx.x * 64u + threadIdx.x;
+  const int k = blockIdx.y;
+  const LdBlock b = rp.blocks[k];
+  if (b.n == 1 || p >= npix) return;
+  const int spp = rp.spp, n = b.n, dims = b.is2D ? 2 : 1;
+  const int2 xy = st.pix[p];
+  const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
+  DartRandom rng;
+  rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
+  const uint32_t s0 = rng.randomUint();
+  const uint32_t s1 = b.is2D ? rng.randomUint() : 0u;
+  float* base = st.sv + (size_t)b.dst * st.cap + (size_t)p * spp;
+  auto at = [&](int i, int j, int d) -> float& { return base[(size_t)(dims * j + d) * st.cap + i]; };
+  for (int i = 0; i < spp; ++i)
+    for (int j = 0; j < n; ++j) {
+      const uint32_t e = (uint32_t)(i * n + j);
+      at(i, j, 0) = VanDerCorput(e, s0);
+      if (b.is2D) at(i, j, 1) = Sobol2(e, s1);
+    }
+  for (int i = 0; i < spp; ++i)      // Shuffle(samples + i*n, n, dims) (montecarlo.dart:294-303,531-533)
+    for (int j = 0; j < n; ++j) {
+      const int other = j + (int)(rng.randomUint() % (uint32_t)(n - j));
+      for (int d = 0; d < dims; ++d) {
+        const float t = at(i, j, d);
+        at(i, j, d) = at(i, other, d);
+        at(i, other, d) = t;
+      }
+    }
+  for (int i = 0; i < spp; ++i) {    // Shuffle(samples, spp, n*dims)
+    const int other = i + (int)(rng.randomUint() % (uint32_t)(spp - i));
+    for (int j = 0; j < n; ++j)
+      for (int d = 0; d < dims; ++d) {
+        const float t = at(i, j, d);
+        at(i, j, d) = at(other, j, d);
+        at(other, j, d) = t;
+      }
   }
 }
 
@@ -426,14 +475,19 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
 }
 
 // DirectLightingIntegrator.Li with strategy "all" (direct_lighting_integrator.dart:30-68;
-// integrator.dart:39-77).  Stage s sets up the NEE of light s at the camera hit;
-// stage nLights finishes the sum.  st.beta carries UniformSampleAllLights' L.
+// integrator.dart:39-77).  Stage s sets up EstimateDirect call s of UniformSampleAllLights (rp.dstages[s]:
+// sample j of light i) at the camera hit and folds in the result of call s-1; the last stage finishes the
+// sum.  st.betaNee carries the current light's Ld, st.beta the running L of UniformSampleAllLights.
 __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
   __shared__ PushScratch s_push;
   const uint32_t cap = st.cap;
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
+  const int nCalls = rp.nDirectStages;
+  DirectStage prev{}, cur{};
+  if (stage > 0) prev = rp.dstages[stage - 1];
+  if (stage < nCalls) cur = rp.dstages[stage];
   for (uint32_t it = 0; it < nIter; ++it) {
     const uint32_t idx = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = idx < nIn;
@@ -449,6 +503,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
         const F3 wo = vneg(d);
         C3 L = ldc(st.L, cap, slot);
         C3 Lall = ldc(st.beta, cap, slot);
+        C3 Ld = C3{0.f, 0.f, 0.f};
         DGeo dg;
         if (stage == 0) {
           const F3 o = ld3(st.ro, cap, slot);
@@ -462,19 +517,23 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
         } else {
           tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
           dg.p = ld3(st.ro, cap, slot);
-          C3 Ld = resolve_nee<true>(sc, st, slot, flags, st.shOcc[slot], ldc(st.Ld1, cap, slot));  // Ld += EstimateDirect (one sample per light)
-          Lall = cadd(Lall, cdivD(Ld, 1.0));                      // L += Ld / nSamples
+          Ld = ldc(st.betaNee, cap, slot);
+          Ld = cadd(Ld, resolve_nee<true>(sc, st, slot, flags, st.shOcc[slot], ldc(st.Ld1, cap, slot)));  // Ld += EstimateDirect
+          if (prev.last) {
+            Lall = cadd(Lall, cdivD(Ld, (double)prev.n));  // L += Ld / nSamples
+            Ld = C3{0.f, 0.f, 0.f};
+          }
         }
-        if (stage < rp.nLights) {
+        if (stage < nCalls) {
           Bsdf bsdf = make_bsdf(sc, dg, tr.mat);
           const float* sv = st.sv;
-          // slots of light `stage` (direct_lighting_integrator.dart:70-87)
-          double lsc = LDS_STREAM(sv + (size_t)(5 + 2 * stage) * cap + slot);
-          double ls0 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage) * cap + slot);
-          double ls1 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage + 1) * cap + slot);
-          double bs0 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage + 2) * cap + slot);
-          double bs1 = LDS_STREAM(sv + (size_t)(5 + rp.n1D + 4 * stage + 3) * cap + slot);
-          pf |= setup_nee<true>(sc, st, slot, stage, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1);
+          // sample slots of this call (direct_lighting_integrator.dart:70-87)
+          double lsc = LDS_STREAM(sv + (size_t)cur.lc * cap + slot);
+          double ls0 = LDS_STREAM(sv + (size_t)cur.lp * cap + slot);
+          double ls1 = LDS_STREAM(sv + (size_t)(cur.lp + 1) * cap + slot);
+          double bs0 = LDS_STREAM(sv + (size_t)cur.bd * cap + slot);
+          double bs1 = LDS_STREAM(sv + (size_t)(cur.bd + 1) * cap + slot);
+          pf |= setup_nee<true>(sc, st, slot, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1);
           again = true;
         } else {
           if (rp.nLights > 0) L = cadd(L, Lall);
@@ -485,6 +544,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
         }
         stc(st.L, cap, slot, L);
         stc(st.beta, cap, slot, Lall);
+        stc(st.betaNee, cap, slot, Ld);
       } else if (stage == 0 && sc.hasEnv) {
         stc(st.L, cap, slot, env_Le(sc.env, ld3(st.rd, cap, slot)));  // escaped camera ray (sampler_renderer.dart:87-92)
       }
@@ -594,8 +654,9 @@ void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t*
                      ntris);
 }
 void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s) {
-  const int nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
+  const int nBlocks = rp.blocks ? rp.nBlocks : 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
   const dim3 grid((npix + 63) / 64, nBlocks);
+  if (rp.blocks) hipLaunchKernelGGL(k_gen_samples_multi, grid, dim3(64), 0, s, rp, st, npix);
   if (rp.spp <= 256) {
     const size_t lds = (size_t)rp.spp * 68 + 512;
     hipLaunchKernelGGL((k_gen_samples<uint8_t, 68>), grid, dim3(64), lds, s, rp, st, npix);

@@ -220,6 +220,10 @@ int dr_intersect(DrScene* scene, const DrRay* rays, int64_t n, DrHit* out, int32
 /* Floats per camera-sample vector for an integrator (Sample layout,
  * lib/core/sample.dart:23-79). */
 int32_t dr_sample_floats(int32_t integrator, uint32_t nlights);
+/* Same for an uploaded scene: DirectLighting requests roundSize(light.nSamples) entries per light slot
+ * (direct_lighting_integrator.dart:70-87; low_discrepancy_sampler.dart:43-49), so the vector length depends on
+ * the lights; dr_sample_floats assumes nsamples == 1 everywhere. */
+int32_t dr_scene_sample_floats(const DrScene* scene, int32_t integrator);
 
 /* Renderer.render(Scene) (lib/core/renderer.dart:28;
  * sampler_renderer.dart:36-65): traces this task's window and returns the

@@ -135,6 +135,41 @@ def test_two_emitters_direct_and_path(ob, gpu):
         assert out.rgb.mean() > 0
 
 
+@pytest.mark.parametrize("ns", [(2, 1), (3, 5), (16, 1)])
+def test_direct_lighting_with_several_samples_per_light(ob, gpu, ns):
+    """UniformSampleAllLights with light.nSamples > 1 (integrator.dart:39-77): the LD sampler hands out
+    roundSize(nSamples) entries per light slot (direct_lighting_integrator.dart:70-87); counter streams and the
+    reference's serial stream replayed through host buffers."""
+    e2 = scenes._quad((-9.9, -2, -2), (-9.9, 2, -2), (-9.9, 2, 2), (-9.9, -2, 2), (0.5, 0.5, 0.5),
+                      core.DiffuseAreaLight((5.0, 9.0, 3.0), ns[1]))
+    prims = scenes.cornell_prims(scenes.blob_prim(16, 8)) + [e2]
+    next(gp for gp in prims if gp.areaLight is not None).areaLight.nSamples = ns[0]
+    env = core.InfiniteAreaLight(scenes.SKY_TO_WORLD, (0.2, 0.3, 0.5), 2, None)
+    film = core.ImageFilm(20, 16)
+    cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
+    r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 8), cam, core.DirectLightingIntegrator(0, 5),
+                             core.EmissionIntegrator())
+    scene = scenes.make_scene(prims, env)
+    out = r.render(scene)
+    osc = ob.OracleScene(prims, env=env)
+    osc.counters(reset=True)
+    ref = osc.render(ob.render_desc(r, sampler_mode=1))
+    _check(out, ref)
+    c, st = osc.counters(), r.last_stats
+    for k in ("closest_rays", "any_rays", "closest_nodes", "any_nodes", "closest_tris", "any_tris"):
+        assert st[k] == c[k], k
+    rp2 = [core.RoundUpPow2(n) for n in ns] + [2]
+    nfloats = _abi.lib().dr_scene_sample_floats(scene._device().handle, _abi.DR_INTEGRATOR_DIRECT_ALL)
+    assert nfloats == 5 + 2 + 6 * sum(rp2)
+    # serial reference stream -> host buffers
+    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=21 * 17 * 8, max_tail=8)
+    assert rec["sample_vec"].shape[1] == nfloats
+    r.sampler = core.HostBufferSampler(cam, 8, rec["pixel_xy"][::8].copy(), rec["sample_vec"])
+    out2 = r.render(scene)
+    assert np.array_equal(out2.film, rec["film"]) and np.array_equal(out2.rgb, rec["rgb"])
+    assert not np.array_equal(out2.film, out.film)
+
+
 def test_task_and_tile_shards_sum_to_the_full_film(gpu):
     """GetSubWindow tasks (the reference's split) and round-robin tiles (the multi-GPU split): the sum of
     the shard films is bit-identical to the unsharded film (box filter => disjoint pixels)."""
