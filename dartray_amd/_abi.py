@@ -41,6 +41,15 @@ class DrLightTri(C.Structure):
     _fields_ = [("v", C.c_uint32 * 3), ("reverse_orientation", C.c_uint32)]
 
 
+DR_PRIM_QUADRIC = 0xFFFFFFFF
+DR_QUADRIC_SPHERE, DR_QUADRIC_DISK = 1, 2
+
+
+class DrQuadric(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pad", C.c_int32), ("object_to_world", C.c_float * 16),
+                ("world_to_object", C.c_float * 16), ("params", C.c_double * 4)]
+
+
 class DrSceneDesc(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("nnodes", C.c_uint64),
                 ("verts", C.c_void_p), ("nverts", C.c_uint64),
@@ -50,7 +59,8 @@ class DrSceneDesc(C.Structure):
                 ("lights", C.c_void_p), ("nlights", C.c_uint32),
                 ("light_tris", C.c_void_p), ("nlight_tris", C.c_uint32),
                 ("bvh_depth", C.c_uint32),
-                ("env_maps", C.c_void_p), ("nenv_maps", C.c_uint32)]
+                ("env_maps", C.c_void_p), ("nenv_maps", C.c_uint32),
+                ("quadrics", C.c_void_p), ("nquadrics", C.c_uint32)]
 
 
 class DrRay(C.Structure):
@@ -100,6 +110,8 @@ EXPORTS = {
     "dr_init": (C.c_int, [C.c_int]),
     "dr_bvh_build": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint32)]),
+    "dr_bvh_build_mixed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32,
+                                     C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint32)]),
     "dr_scene_create": (C.c_int, [C.POINTER(DrSceneDesc), C.POINTER(C.c_void_p)]),
     "dr_scene_destroy": (None, [C.c_void_p]),
     "dr_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),

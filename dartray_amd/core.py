@@ -52,6 +52,82 @@ class TriangleMesh:
         return np.arange(self.ntris - 1, -1, -1, dtype=np.int64)
 
 
+def _bbox_transform(m, lo, hi):
+    """Transform.transformBBox (transform.dart:163-178): union of the 8 transformed corners, f32."""
+    m = np.asarray(m, np.float32).astype(np.float64)
+    lo = np.asarray(lo, np.float64).astype(np.float32).astype(np.float64)  # Point(...) stores f32
+    hi = np.asarray(hi, np.float64).astype(np.float32).astype(np.float64)
+    lo, hi = np.minimum(lo, hi), np.maximum(lo, hi)                         # BBox(p1, p2) bbox.dart:36-40
+    corners = np.array([[(hi if (k >> a) & 1 else lo)[a] for a in range(3)] for k in range(8)])
+    pts = transform_points(m, corners)
+    return pts.min(0), pts.max(0)
+
+
+def transform_points(m, P):
+    """Transform.transformPoint (transform.dart:110-129) over an [n,3] array: the reference's left-to-right
+    f64 sums (no fused multiply-add, which a BLAS matmul may use), stored f32; w != 1 divides (Point.invScale)."""
+    m = np.asarray(m, np.float32).astype(np.float64).reshape(4, 4)
+    P = np.asarray(P, np.float64).astype(np.float32).astype(np.float64)
+    x, y, z = P[:, 0], P[:, 1], P[:, 2]
+    out = np.stack([m[r, 0] * x + m[r, 1] * y + m[r, 2] * z + m[r, 3] for r in range(3)], axis=1).astype(np.float32)
+    w = m[3, 0] * x + m[3, 1] * y + m[3, 2] * z + m[3, 3]
+    sel = w != 1.0
+    if np.any(sel):
+        out[sel] = (out[sel].astype(np.float64) / w[sel, None]).astype(np.float32)
+    return out
+
+
+class _Quadric:
+    """Common part of the quadric shapes: they keep objectToWorld and transform the ray per test
+    (shape.dart:24-39) instead of pre-transforming geometry, and are intersectable as they are."""
+
+    kind = 0
+
+    def __init__(self, o2w, w2o, reverseOrientation):
+        self.objectToWorld = np.ascontiguousarray(np.asarray(o2w, np.float32).reshape(4, 4))
+        self.worldToObject = np.ascontiguousarray(np.asarray(w2o, np.float32).reshape(4, 4))
+        self.reverseOrientation = bool(reverseOrientation)
+
+    def canIntersect(self):
+        return True
+
+    def worldBound(self):  # shape.dart:37-39
+        lo, hi = self.objectBound()
+        return _bbox_transform(self.objectToWorld, lo, hi)
+
+
+class Sphere(_Quadric):
+    """shapes/sphere.dart:23-38 (constructor arguments as in Sphere.Create :313-321; phiMax in degrees)."""
+
+    kind = _abi.DR_QUADRIC_SPHERE
+
+    def __init__(self, o2w, w2o, ro, radius=1.0, z0=None, z1=None, phiMax=360.0):
+        super().__init__(o2w, w2o, ro)
+        self.radius = float(radius)
+        z0 = -self.radius if z0 is None else float(z0)
+        z1 = self.radius if z1 is None else float(z1)
+        self.params = (self.radius, z0, z1, float(phiMax))
+        self.zmin = min(max(min(z0, z1), -self.radius), self.radius)
+        self.zmax = min(max(max(z0, z1), -self.radius), self.radius)
+
+    def objectBound(self):  # sphere.dart:35-38
+        return (-self.radius, -self.radius, self.zmin), (self.radius, self.radius, self.zmax)
+
+
+class Disk(_Quadric):
+    """shapes/disk.dart:23-29 (arguments as in Disk.Create :157-165; phiMax in degrees)."""
+
+    kind = _abi.DR_QUADRIC_DISK
+
+    def __init__(self, o2w, w2o, ro, height=0.0, radius=1.0, innerRadius=0.0, phiMax=360.0):
+        super().__init__(o2w, w2o, ro)
+        self.height, self.radius, self.innerRadius = float(height), float(radius), float(innerRadius)
+        self.params = (self.height, self.radius, self.innerRadius, float(phiMax))
+
+    def objectBound(self):  # disk.dart:31-34
+        return (-self.radius, -self.radius, self.height), (self.radius, self.radius, self.height)
+
+
 class MatteMaterial:
     """materials/matte_material.dart:37-77 with constant textures."""
 
@@ -157,22 +233,29 @@ class BVHAccel:
         base = 0
         self.materials = []
         self._lights = []  # DiffuseAreaLight objects in first-seen order
+        self.quadrics = []  # Sphere / Disk shapes: intersectable, so fullyRefine keeps them whole (primitive.dart:71-84)
         for gp in self.prims_in:
             mesh = gp.shape
-            order = mesh.refine()
-            verts.append(mesh.P)
-            tri.append(mesh.vertexIndex[order].astype(np.uint32) + np.uint32(base))
             mid = len(self.materials)
             self.materials.append(gp.material)
-            mat.append(np.full(len(order), mid, dtype=np.uint32))
             li = -1
             if gp.areaLight is not None:
                 if gp.areaLight not in self._lights:
                     self._lights.append(gp.areaLight)
                 li = self._lights.index(gp.areaLight)
-            lightOf.append(np.full(len(order), li, dtype=np.int32))
-            rev.append(np.full(len(order), 1 if mesh.reverseOrientation else 0, dtype=np.uint8))
-            base += len(mesh.P)
+            if isinstance(mesh, _Quadric):
+                tri.append(np.array([[_abi.DR_PRIM_QUADRIC, len(self.quadrics), 0]], dtype=np.uint32))
+                self.quadrics.append(mesh)
+                nprim = 1
+            else:
+                order = mesh.refine()
+                verts.append(mesh.P)
+                tri.append(mesh.vertexIndex[order].astype(np.uint32) + np.uint32(base))
+                base += len(mesh.P)
+                nprim = len(order)
+            mat.append(np.full(nprim, mid, dtype=np.uint32))
+            lightOf.append(np.full(nprim, li, dtype=np.int32))
+            rev.append(np.full(nprim, 1 if mesh.reverseOrientation else 0, dtype=np.uint8))
         self.verts = np.ascontiguousarray(np.concatenate(verts) if verts else np.zeros((0, 3), np.float32))
         refined = np.ascontiguousarray(np.concatenate(tri) if tri else np.zeros((0, 3), np.uint32))
         mat = np.concatenate(mat) if mat else np.zeros(0, np.uint32)
@@ -184,9 +267,13 @@ class BVHAccel:
         order = np.zeros(max(n, 1), dtype=np.uint32)
         nn = C.c_uint64(0)
         depth = C.c_uint32(0)
-        _abi.check(lib.dr_bvh_build(self.verts.ctypes.data, len(self.verts), refined.ctypes.data, n,
-                                    self.maxPrimsInNode, nodes.ctypes.data, C.byref(nn), order.ctypes.data,
-                                    C.byref(depth)))
+        qb = np.zeros((max(len(self.quadrics), 1), 6), dtype=np.float32)
+        for i, q in enumerate(self.quadrics):
+            lo, hi = q.worldBound()
+            qb[i, :3], qb[i, 3:] = lo, hi
+        _abi.check(lib.dr_bvh_build_mixed(self.verts.ctypes.data, len(self.verts), refined.ctypes.data, n,
+                                          qb.ctypes.data, len(self.quadrics), self.maxPrimsInNode, nodes.ctypes.data,
+                                          C.byref(nn), order.ctypes.data, C.byref(depth)))
         order = order[:n]
         self.nodes = nodes[:nn.value] if n else None  # bvh_accel.dart:50-53
         self.depth = int(depth.value)
@@ -255,7 +342,10 @@ class _DeviceScene:
         ltris = []
         base_of = {}
         base = 0
+        quad_of = {id(q): i for i, q in enumerate(accel.quadrics)}
         for gp in accel.prims_in:
+            if isinstance(gp.shape, _Quadric):
+                continue
             base_of[id(gp.shape)] = base
             base += len(gp.shape.P)
         envs = []
@@ -274,9 +364,12 @@ class _DeviceScene:
                 continue
             mesh = L.shape
             first = len(ltris)
-            for t in mesh.refine():
-                v = mesh.vertexIndex[t] + base_of[id(mesh)]
-                ltris.append((int(v[0]), int(v[1]), int(v[2]), 1 if mesh.reverseOrientation else 0))
+            if isinstance(mesh, _Quadric):  # ShapeSet keeps an intersectable shape whole (shape_set.dart:25-35)
+                ltris.append((_abi.DR_PRIM_QUADRIC, quad_of[id(mesh)], 0, 1 if mesh.reverseOrientation else 0))
+            else:
+                for t in mesh.refine():
+                    v = mesh.vertexIndex[t] + base_of[id(mesh)]
+                    ltris.append((int(v[0]), int(v[1]), int(v[2]), 1 if mesh.reverseOrientation else 0))
             dl[i].L[:] = [float(x) for x in L.Lemit]
             dl[i].nsamples = L.nSamples
             dl[i].first_tri = first
@@ -290,7 +383,15 @@ class _DeviceScene:
         env_arr = (_abi.DrEnvMap * max(len(envs), 1))(*envs)
         d.env_maps = C.cast(env_arr, C.c_void_p)
         d.nenv_maps = len(envs)
-        self._keep = (mats, dl, lt, env_arr)
+        qa = (_abi.DrQuadric * max(len(accel.quadrics), 1))()
+        for i, q in enumerate(accel.quadrics):
+            qa[i].kind = q.kind
+            qa[i].object_to_world[:] = [float(v) for v in q.objectToWorld.reshape(-1)]
+            qa[i].world_to_object[:] = [float(v) for v in q.worldToObject.reshape(-1)]
+            qa[i].params[:] = [float(v) for v in q.params]
+        d.quadrics = C.cast(qa, C.c_void_p)
+        d.nquadrics = len(accel.quadrics)
+        self._keep = (mats, dl, lt, env_arr, qa)
         d.nodes = accel.nodes.ctypes.data if accel.nodes is not None else None
         d.nnodes = len(accel.nodes) if accel.nodes is not None else 0
         d.verts = accel.verts.ctypes.data
@@ -420,8 +521,12 @@ def _m4(a):
     return np.asarray(a, dtype=np.float64).astype(np.float32).reshape(4, 4)
 
 
-def _mul(a, b):  # Matrix4x4.Mul: f64 expression, f32 store (matrix4x4.dart:193-206)
-    return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+def _mul(a, b):  # Matrix4x4.Mul: left-to-right f64 sums, f32 store (matrix4x4.dart:193-206)
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    r = np.empty((4, 4), dtype=np.float64)
+    for i in range(4):
+        r[i] = a[i, 0] * b[0] + a[i, 1] * b[1] + a[i, 2] * b[2] + a[i, 3] * b[3]
+    return r.astype(np.float32)
 
 
 def _inv(a):  # Matrix4x4.Inverse (matrix4x4.dart:208-343) -- host logic, evaluated in f64, stored f32

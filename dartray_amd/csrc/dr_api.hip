@@ -57,7 +57,7 @@ struct DevBuf {
 struct Workspace {
   uint32_t cap = 0;
   int nFloats = 0, maxTail = 0;
-  DevBuf<float> sv, ro, rd, beta, L, betaNee, shD, Ld1, misD, Ld2;
+  DevBuf<float> sv, ro, ro0, rd, beta, L, betaNee, shD, Ld1, misD, Ld2;
   DevBuf<double> rtmin, ht, shTmax, tail;
   DevBuf<int32_t> hprim, shOcc, misLight, misPrim;
   DevBuf<uint32_t> flags, activeA, activeB, closestQ, anyQ, counters, spill;
@@ -76,6 +76,8 @@ struct DrScene {
   DevBuf<float4> tris, mats;
   DevBuf<DLight> lights;
   DevBuf<DLightTri> ltris;
+  DevBuf<DQuadric> quads;
+  std::vector<DQuadric> hostQuads;
   DevBuf<float> lcdf;
   DevBuf<float> envTexels, envCondFunc, envCondCdf, envCondInt, envMargFunc, envMargCdf;
   DevBuf<TraceCounters> ctr;
@@ -243,6 +245,7 @@ int allocWorkspace(DrScene* sc, uint32_t cap, int nFloats, int maxTail, bool nee
     w.cap = c;
     w.nFloats = nf;
   }
+  if (!sc->hostQuads.empty() && w.ro0.n < 3 * (size_t)w.cap) HIP_TRY(w.ro0.alloc(3 * (size_t)w.cap));
   if (needTail && ((size_t)w.cap * maxTail > w.tail.n)) HIP_TRY(w.tail.alloc((size_t)w.cap * maxTail));
   w.maxTail = maxTail;
   HIP_TRY(w.counters.alloc(N_COUNTERS));
@@ -258,6 +261,7 @@ BatchState makeState(Workspace& w, const int2* pix, uint32_t nslots, bool useTai
   st.sv = w.sv.p;
   st.tail = useTail ? w.tail.p : nullptr;
   st.ro = w.ro.p;
+  st.ro0 = w.ro0.p;
   st.rd = w.rd.p;
   st.rtmin = w.rtmin.p;
   st.hprim = w.hprim.p;
@@ -356,6 +360,42 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     hipError_t e_ = (expr);                                                      \
     if (e_ != hipSuccess) return bail(DR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
+  // quadric shapes (sphere.dart:24-32, disk.dart:24-28): constructor-derived fields in f64
+  for (uint32_t i = 0; i < desc->nquadrics; ++i) {
+    if (!desc->quadrics) return bail(DR_ERR_INVALID, "quadrics missing");
+    const DrQuadric& a = desc->quadrics[i];
+    DQuadric q;
+    memset(&q, 0, sizeof(q));
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) {
+        q.o2w[4 * r + c] = a.object_to_world[4 * r + c];
+        q.w2o[4 * r + c] = a.world_to_object[4 * r + c];
+      }
+    for (int c = 0; c < 4; ++c)
+      if (a.object_to_world[12 + c] != (c == 3 ? 1.0f : 0.0f) || a.world_to_object[12 + c] != (c == 3 ? 1.0f : 0.0f))
+        return bail(DR_ERR_UNSUPPORTED, "projective object transforms are not on the path");
+    auto clampd = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    auto radians = [](double deg) { return (3.141592653589793 / 180.0) * deg; };  // common.dart:87-88
+    q.kind = a.kind;
+    if (a.kind == DR_QUADRIC_SPHERE) {
+      q.radius = a.params[0];
+      const double z0 = a.params[1], z1 = a.params[2];
+      q.zmin = clampd(std::min(z0, z1), -q.radius, q.radius);
+      q.zmax = clampd(std::max(z0, z1), -q.radius, q.radius);
+      q.thetaMin = std::acos(clampd(q.zmin / q.radius, -1.0, 1.0));
+      q.thetaMax = std::acos(clampd(q.zmax / q.radius, -1.0, 1.0));
+      q.phiMax = radians(clampd(a.params[3], 0.0, 360.0));
+    } else if (a.kind == DR_QUADRIC_DISK) {
+      q.height = a.params[0];
+      q.radius = a.params[1];
+      q.innerRadius = a.params[2];
+      q.phiMax = radians(clampd(a.params[3], 0.0, 360.0));
+    } else {
+      return bail(DR_ERR_INVALID, "unknown quadric kind");
+    }
+    sc->hostQuads.push_back(q);
+  }
+
   sc->bvhDepth = desc->bvh_depth;
   // nodes: the 32-byte marshalled node is consumed as two 16-byte loads
   TRY_SC(sc->nodes.alloc(2 * desc->nnodes));
@@ -366,7 +406,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   sc->d.rootRef = PREF_DEAD;
   if (desc->nnodes) {
     const DrBvhNode* N = desc->nodes;
-    bool ok = desc->ntris < (1ull << 26);
+    bool ok = desc->ntris < (1ull << 26) && desc->nquadrics == 0;  // only the v2 kernel tests quadrics
     std::vector<uint32_t> pairIndex(desc->nnodes, 0);
     uint32_t np = 0;
     for (uint64_t i = 0; i < desc->nnodes; ++i) {
@@ -440,22 +480,33 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     DevBuf<uint32_t> dI, dM;
     DevBuf<int32_t> dL;
     DevBuf<uint8_t> dR;
-    TRY_SC(dV.alloc(3 * desc->nverts));
+    TRY_SC(dV.alloc(3 * std::max<uint64_t>(desc->nverts, 1)));
     TRY_SC(dI.alloc(3 * desc->ntris));
     TRY_SC(dM.alloc(desc->ntris));
     TRY_SC(dL.alloc(desc->ntris));
     TRY_SC(dR.alloc(desc->ntris));
-    for (uint64_t i = 0; i < 3 * desc->ntris; ++i)
-      if (desc->tri_idx[i] >= desc->nverts) return bail(DR_ERR_INVALID, "vertex index out of range");
+    std::vector<uint8_t> flags(desc->ntris);
+    for (uint64_t i = 0; i < desc->ntris; ++i) {
+      flags[i] = desc->tri_reverse[i] ? 1 : 0;
+      if (desc->tri_idx[3 * i] == DR_PRIM_QUADRIC) {
+        const uint32_t qi = desc->tri_idx[3 * i + 1];
+        if (qi >= desc->nquadrics) return bail(DR_ERR_INVALID, "quadric index out of range");
+        flags[i] |= (uint8_t)(sc->hostQuads[qi].kind << 1);
+        sc->hostQuads[qi].reverse = desc->tri_reverse[i] ? 1 : 0;  // Shape.reverseOrientation of the primitive's shape
+        continue;
+      }
+      for (int k = 0; k < 3; ++k)
+        if (desc->tri_idx[3 * i + k] >= desc->nverts) return bail(DR_ERR_INVALID, "vertex index out of range");
+    }
     for (uint64_t i = 0; i < desc->ntris; ++i) {
       if (desc->tri_material[i] >= desc->nmaterials) return bail(DR_ERR_INVALID, "material index out of range");
       if (desc->tri_light[i] >= (int32_t)desc->nlights) return bail(DR_ERR_INVALID, "light index out of range");
     }
-    TRY_SC(hipMemcpy(dV.p, desc->verts, 3 * desc->nverts * sizeof(float), hipMemcpyHostToDevice));
+    if (desc->nverts) TRY_SC(hipMemcpy(dV.p, desc->verts, 3 * desc->nverts * sizeof(float), hipMemcpyHostToDevice));
     TRY_SC(hipMemcpy(dI.p, desc->tri_idx, 3 * desc->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
     TRY_SC(hipMemcpy(dM.p, desc->tri_material, desc->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
     TRY_SC(hipMemcpy(dL.p, desc->tri_light, desc->ntris * sizeof(int32_t), hipMemcpyHostToDevice));
-    TRY_SC(hipMemcpy(dR.p, desc->tri_reverse, desc->ntris, hipMemcpyHostToDevice));
+    TRY_SC(hipMemcpy(dR.p, flags.data(), desc->ntris, hipMemcpyHostToDevice));
     launch_gather_tris(dV.p, dI.p, dM.p, dL.p, dR.p, sc->tris.p, desc->ntris, 0);
     TRY_SC(hipDeviceSynchronize());
   }
@@ -502,6 +553,29 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       for (uint32_t t = 0; t < a.ntris; ++t) {
         const DrLightTri& lt = desc->light_tris[a.first_tri + t];
         DLightTri& o = LT[a.first_tri + t];
+        if (lt.v[0] == DR_PRIM_QUADRIC) {
+          if (lt.v[1] >= desc->nquadrics) return bail(DR_ERR_INVALID, "light quadric index out of range");
+          const DQuadric& q = sc->hostQuads[lt.v[1]];
+          if (q.kind != DR_QUADRIC_DISK)
+            return bail(DR_ERR_UNSUPPORTED, "sphere area lights (Sphere.sample2 cone sampling) are not on the path");
+          memset(o.p, 0, sizeof(o.p));
+          memcpy(&o.p[0], &lt.v[1], sizeof(uint32_t));
+          o.reverse = (lt.reverse_orientation ? 1u : 0u) | ((uint32_t)q.kind << 8);
+          o.area = q.phiMax * 0.5 * (q.radius * q.radius - q.innerRadius * q.innerRadius);  // disk.dart:139-142
+          // Ns of Disk.sample (disk.dart:149-153): normalize(objectToWorld.transformNormal((0,0,1))), flipped
+          // when reverseOrientation; nn (the hit's dg.nn) depends on the hit point and is evaluated on the device
+          double n[3] = {(double)(float)q.w2o[8], (double)(float)q.w2o[9], (double)(float)q.w2o[10]};  // mInv^T * (0,0,1), stored f32
+          const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+          for (int k = 0; k < 3; ++k) {
+            float v = (float)(n[k] / len);
+            if (lt.reverse_orientation) v = (float)((double)v * -1.0);
+            o.ns[k] = v;
+            o.nn[k] = v;
+          }
+          areas[t] = o.area;
+          area += o.area;
+          continue;
+        }
         for (int k = 0; k < 3; ++k) {
           if (lt.v[k] >= desc->nverts) return bail(DR_ERR_INVALID, "light vertex index out of range");
           for (int c = 0; c < 3; ++c) o.p[3 * k + c] = desc->verts[3 * (size_t)lt.v[k] + c];
@@ -621,6 +695,12 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   }
   TRY_SC(sc->ctr.alloc(1));
   TRY_SC(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
+  TRY_SC(sc->quads.alloc(std::max<size_t>(sc->hostQuads.size(), 1)));
+  if (!sc->hostQuads.empty())
+    TRY_SC(hipMemcpy(sc->quads.p, sc->hostQuads.data(), sc->hostQuads.size() * sizeof(DQuadric), hipMemcpyHostToDevice));
+  sc->d.quads = sc->quads.p;
+  sc->d.nquads = (uint32_t)sc->hostQuads.size();
+  sc->d.padq = 0;
   sc->d.nodes = sc->nodes.p;
   sc->d.tris = sc->tris.p;
   sc->d.mats = sc->mats.p;

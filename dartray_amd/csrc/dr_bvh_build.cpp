@@ -347,13 +347,27 @@ class SahBuilder {
 extern "C" int dr_bvh_build(const float* verts, uint64_t nverts, const uint32_t* tri_idx, uint64_t ntris,
                             int32_t max_prims_in_node, DrBvhNode* nodes_out, uint64_t* nnodes_out, uint32_t* order_out,
                             uint32_t* depth_out) {
+  return dr_bvh_build_mixed(verts, nverts, tri_idx, ntris, nullptr, 0, max_prims_in_node, nodes_out, nnodes_out, order_out,
+                            depth_out);
+}
+
+extern "C" int dr_bvh_build_mixed(const float* verts, uint64_t nverts, const uint32_t* tri_idx, uint64_t ntris,
+                                  const float* quadric_bounds, uint64_t nquadrics, int32_t max_prims_in_node,
+                                  DrBvhNode* nodes_out, uint64_t* nnodes_out, uint32_t* order_out, uint32_t* depth_out) {
   if (!nnodes_out) return DR_ERR_INVALID;
   *nnodes_out = 0;
   if (depth_out) *depth_out = 0;
   if (ntris == 0) return DR_OK;
-  if (!verts || !tri_idx || !nodes_out || !order_out || ntris >= (1ull << 30)) return DR_ERR_INVALID;
-  for (uint64_t i = 0; i < 3 * ntris; ++i)
-    if (tri_idx[i] >= nverts) return DR_ERR_INVALID;
+  if (!tri_idx || !nodes_out || !order_out || ntris >= (1ull << 30)) return DR_ERR_INVALID;
+  for (uint64_t i = 0; i < ntris; ++i) {
+    if (tri_idx[3 * i] == DR_PRIM_QUADRIC) {
+      if (!quadric_bounds || tri_idx[3 * i + 1] >= nquadrics) return DR_ERR_INVALID;
+      continue;
+    }
+    if (!verts) return DR_ERR_INVALID;
+    for (int k = 0; k < 3; ++k)
+      if (tri_idx[3 * i + k] >= nverts) return DR_ERR_INVALID;
+  }
   SahBuilder b;
   b.maxPrims = std::min(255, max_prims_in_node > 0 ? max_prims_in_node : 4);  // bvh_accel.dart:44
   const char* env = getenv("DARTRAY_BUILD_THREADS");
@@ -368,7 +382,12 @@ extern "C" int dr_bvh_build(const float* verts, uint64_t nverts, const uint32_t*
       Item& it = b.items[i];
       it.prim = (uint32_t)i;
       it.b.reset();
-      for (int k = 0; k < 3; ++k) it.b.growPoint(verts + 3 * (size_t)tri_idx[3 * i + k]);  // Triangle.worldBound (triangle.dart:39-42)
+      if (tri_idx[3 * i] == DR_PRIM_QUADRIC) {  // Shape.worldBound of a quadric, computed by the caller (shape.dart:37-39)
+        const float* qb = quadric_bounds + 6 * (size_t)tri_idx[3 * i + 1];
+        for (int k = 0; k < 3; ++k) { it.b.lo[k] = qb[k]; it.b.hi[k] = qb[3 + k]; }
+      } else {
+        for (int k = 0; k < 3; ++k) it.b.growPoint(verts + 3 * (size_t)tri_idx[3 * i + k]);  // Triangle.worldBound (triangle.dart:39-42)
+      }
       for (int k = 0; k < 3; ++k)  // BBox.center: (pMin*0.5) + (pMax*0.5), each a Point (bbox.dart:66)
         it.c[k] = (float)((double)(float)((double)it.b.lo[k] * 0.5) + (double)(float)((double)it.b.hi[k] * 0.5));
     }

@@ -33,6 +33,7 @@
 
 #define DR_INV_PI 0.31830988618379067154  // core/common.dart:23
 #define DR_PI 3.141592653589793
+#define DR_INV_TWOPI 0.15915494309189533577
 #define DR_INF __longlong_as_double(0x7ff0000000000000LL)
 
 // ---- Vector / Point / Normal (core/vector.dart) ---------------------------
@@ -107,6 +108,14 @@ struct DLightTri {  // 72 B
   float nn[3];
   float ns[3];
 };
+// Sphere / Disk (shapes/sphere.dart:23-38, shapes/disk.dart:23-29): affine objectToWorld (rows of the 3x4
+// part; the host rejects projective transforms, so transformPoint's w is exactly 1) and the
+// constructor-derived doubles.
+struct DQuadric {  // 176 B
+  float o2w[12], w2o[12];
+  double radius, zmin, zmax, thetaMin, thetaMax, phiMax, height, innerRadius;
+  int32_t kind, reverse;
+};
 // Sibling-pair layout used by the v3 traversal: pairs[k] holds the two child records (each a DrBvhNode
 // whose `offset` is the child's own pair index if it is interior, the first primitive if it is a leaf)
 // of the k-th interior node, 64 bytes, so ONE aligned fetch brings both children's boxes.
@@ -126,13 +135,18 @@ struct DScene {
   uint32_t nnodes, ntris, nlights, nmats;
   DEnv env;
   int32_t hasEnv;
+  const DQuadric* quads;  // spheres / disks; a primitive record with kind != 0 holds its index in q0.x
+  uint32_t nquads, padq;
 };
 
+// Primitive record flags (q2.w): bit 0 = Shape.reverseOrientation, bits 8.. = 0 triangle / DR_QUADRIC_*.
+#define PRIM_KIND(w) ((w) >> 8)
 struct Tri {
   F3 p1, p2, p3;
   uint32_t mat;
   int32_t light;
   uint32_t reverse;
+  uint32_t kind, quad;  // kind != 0: quadric `quad` (p1..p3 are meaningless)
 };
 DR_DEV Tri load_tri(const DScene& sc, uint32_t prim) {
   const float4* tp = sc.tris + 3 * (size_t)prim;
@@ -143,7 +157,10 @@ DR_DEV Tri load_tri(const DScene& sc, uint32_t prim) {
   t.p3 = F3{q1.z, q1.w, q2.x};
   t.mat = __float_as_uint(q2.y);
   t.light = (int32_t)__float_as_uint(q2.z);
-  t.reverse = __float_as_uint(q2.w);
+  const uint32_t w = __float_as_uint(q2.w);
+  t.reverse = w & 1u;
+  t.kind = PRIM_KIND(w);
+  t.quad = __float_as_uint(q0.x);
   return t;
 }
 
@@ -216,6 +233,130 @@ DR_DEV double tri_area(F3 p1, F3 p2, F3 p3) {  // triangle.dart:265-269
   return 0.5 * vlen(vcross(vsub(p2, p1), vsub(p3, p1)));
 }
 
+// ---- Quadrics (shapes/sphere.dart, shapes/disk.dart) ---------------------------
+DR_DEV F3 q_point(const float* m, F3 p) {  // Transform.transformPoint, affine (transform.dart:110-129)
+  const double x = p.x, y = p.y, z = p.z;
+  return f3((double)m[0] * x + (double)m[1] * y + (double)m[2] * z + (double)m[3],
+            (double)m[4] * x + (double)m[5] * y + (double)m[6] * z + (double)m[7],
+            (double)m[8] * x + (double)m[9] * y + (double)m[10] * z + (double)m[11]);
+}
+DR_DEV F3 q_vector(const float* m, F3 p) {  // Transform.transformVector (transform.dart:131-145)
+  const double x = p.x, y = p.y, z = p.z;
+  return f3((double)m[0] * x + (double)m[1] * y + (double)m[2] * z, (double)m[4] * x + (double)m[5] * y + (double)m[6] * z,
+            (double)m[8] * x + (double)m[9] * y + (double)m[10] * z);
+}
+DR_DEV double q_phi(F3 phit) {
+  double phi = atan2((double)phit.y, (double)phit.x);
+  if (phi < 0.0) phi += 2.0 * DR_PI;
+  return phi;
+}
+DR_DEV bool Quadratic(double A, double B, double C, double* t0, double* t1) {  // common.dart:140-167
+  const double discrim = B * B - 4.0 * A * C;
+  if (discrim < 0.0) return false;
+  const double rootDiscrim = sqrt(discrim);
+  double q;
+  if (B < 0.0) q = -0.5 * (B - rootDiscrim);
+  else q = -0.5 * (B + rootDiscrim);
+  *t0 = q / A;
+  *t1 = C / q;
+  if (*t0 > *t1) {
+    const double t = *t0;
+    *t0 = *t1;
+    *t1 = t;
+  }
+  return true;
+}
+DR_DEV bool sphere_clipped(const DQuadric& q, F3 ph, double phi) {
+  return (q.zmin > -q.radius && (double)ph.z < q.zmin) || (q.zmax < q.radius && (double)ph.z > q.zmax) || phi > q.phiMax;
+}
+// Sphere.intersect / intersectP hit test (sphere.dart:40-116,174-247): object-space ray (oo, od)
+DR_DEV bool sphere_hit(const DQuadric& q, F3 oo, F3 od, double tmin, double tmax, double* tOut, F3* phitOut) {
+  const double dx = od.x, dy = od.y, dz = od.z, ox = oo.x, oy = oo.y, oz = oo.z;
+  const double A = dx * dx + dy * dy + dz * dz;
+  const double B = 2 * (dx * ox + dy * oy + dz * oz);
+  const double C = ox * ox + oy * oy + oz * oz - q.radius * q.radius;
+  double t0, t1;
+  if (!Quadratic(A, B, C, &t0, &t1)) return false;
+  if (t0 > tmax || t1 < tmin) return false;
+  double thit = t0;
+  if (thit < tmin) {
+    thit = t1;
+    if (thit > tmax) return false;
+  }
+  F3 phit = vadd(oo, vmul(od, thit));
+  if (phit.x == 0.0f && phit.y == 0.0f) phit.x = (float)(1.0e-5 * q.radius);
+  double phi = q_phi(phit);
+  if (sphere_clipped(q, phit, phi)) {
+    if (thit == t1) return false;
+    if (t1 > tmax) return false;
+    thit = t1;
+    phit = vadd(oo, vmul(od, thit));
+    if (phit.x == 0.0f && phit.y == 0.0f) phit.x = (float)(1.0e-5 * q.radius);
+    phi = q_phi(phit);
+    if (sphere_clipped(q, phit, phi)) return false;
+  }
+  *tOut = thit;
+  *phitOut = phit;
+  return true;
+}
+// Disk.intersect / intersectP hit test (disk.dart:37-67,103-137)
+DR_DEV bool disk_hit(const DQuadric& q, F3 oo, F3 od, double tmin, double tmax, double* tOut, F3* phitOut) {
+  if (fabs((double)od.z) < 1.0e-7) return false;
+  const double thit = (q.height - (double)oo.z) / (double)od.z;
+  if (thit < tmin || thit > tmax) return false;
+  const F3 phit = vadd(oo, vmul(od, thit));
+  const double dist2 = (double)phit.x * (double)phit.x + (double)phit.y * (double)phit.y;
+  if (dist2 > q.radius * q.radius || dist2 < q.innerRadius * q.innerRadius) return false;
+  if (q_phi(phit) > q.phiMax) return false;
+  *tOut = thit;
+  *phitOut = phit;
+  return true;
+}
+// world-space ray against a quadric: t and the object-space hit point
+DR_DEV bool quadric_hit(const DQuadric& q, F3 o, F3 d, double tmin, double tmax, double* tOut, F3* phitOut) {
+  const F3 oo = q_point(q.w2o, o), od = q_vector(q.w2o, d);  // transformRay (transform.dart:180-196)
+  return q.kind == DR_QUADRIC_SPHERE ? sphere_hit(q, oo, od, tmin, tmax, tOut, phitOut)
+                                     : disk_hit(q, oo, od, tmin, tmax, tOut, phitOut);
+}
+// DifferentialGeometry of a quadric hit at object-space point phit (sphere.dart:118-165, disk.dart:69-96,
+// differential_geometry.dart:77-102).  dndu / dndv are not evaluated: nothing on the path reads them.
+DR_DEV void quadric_dg(const DQuadric& q, F3 phit, DGeo* dg) {
+  F3 dpdu, dpdv;
+  if (q.kind == DR_QUADRIC_SPHERE) {
+    double r = (double)phit.z / q.radius;
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    const double theta = acos(r);
+    const double zradius = sqrt((double)phit.x * (double)phit.x + (double)phit.y * (double)phit.y);
+    const double invzradius = 1.0 / zradius;
+    const double cosphi = (double)phit.x * invzradius;
+    const double sinphi = (double)phit.y * invzradius;
+    dpdu = f3(-q.phiMax * (double)phit.y, q.phiMax * (double)phit.x, 0.0);
+    dpdv = vmul(f3((double)phit.z * cosphi, (double)phit.z * sinphi, -q.radius * sin(theta)), q.thetaMax - q.thetaMin);
+  } else {
+    const double dist2 = (double)phit.x * (double)phit.x + (double)phit.y * (double)phit.y;
+    const double oneMinusV = (sqrt(dist2) - q.innerRadius) / (q.radius - q.innerRadius);
+    const double invOneMinusV = (oneMinusV > 0.0) ? (1.0 / oneMinusV) : 0.0;
+    dpdu = f3(-q.phiMax * (double)phit.y, q.phiMax * (double)phit.x, 0.0);
+    dpdv = f3(-(double)phit.x * invOneMinusV, -(double)phit.y * invOneMinusV, 0.0);
+    dpdu = vmul(dpdu, q.phiMax * DR_INV_TWOPI);
+    dpdv = vmul(dpdv, (q.radius - q.innerRadius) / q.radius);
+  }
+  dg->p = q_point(q.o2w, phit);
+  dg->dpdu = q_vector(q.o2w, dpdu);
+  dg->dpdv = q_vector(q.o2w, dpdv);
+  F3 nn = vnormalize(vcross(dg->dpdu, dg->dpdv));
+  if (q.reverse) nn = vmul(nn, -1.0);
+  dg->nn = nn;
+}
+// The hit a closest-hit query reported (prim, t) turned back into its DifferentialGeometry: the same
+// object-space arithmetic as the test itself (transformRay, pointAt, the pole fix-up of sphere.dart:71-73).
+DR_DEV void quadric_dg_at(const DQuadric& q, F3 o, F3 d, double t, DGeo* dg) {
+  const F3 oo = q_point(q.w2o, o), od = q_vector(q.w2o, d);
+  F3 phit = vadd(oo, vmul(od, t));
+  if (q.kind == DR_QUADRIC_SPHERE && phit.x == 0.0f && phit.y == 0.0f) phit.x = (float)(1.0e-5 * q.radius);
+  quadric_dg(q, phit, dg);
+}
+
 // ---- montecarlo.dart ---------------------------------------------------------
 DR_DEV void ConcentricSampleDisk(double u1, double u2, double* dx, double* dy) {  // montecarlo.dart:155-201
   double r, theta;
@@ -286,22 +427,43 @@ DR_DEV int sampleDiscrete(const float* cdf, int count, double u) {
 // ShapeSet.sample(ls, Ns, p) (shape_set.dart:53-80): pick by area, sample the
 // triangle (triangle.dart:366-383), then intersect p->pt with EVERY shape; the
 // last hitting shape in list order wins (r.maxDistance is never shrunk).
+template <bool QUAD>
 DR_DEV F3 shapeset_sample(const DScene& sc, const DLight& L, double uPos0, double uPos1, double uComponent, F3* Ns, F3 p) {
   int sn = sampleDiscrete(sc.lcdf + L.cdf_off, (int)L.ntris, uComponent) % (int)L.ntris;
   F3 a, b, c;
   const DLightTri& lt = sc.ltris[L.first_tri + sn];
-  ltri_verts(lt, &a, &b, &c);
-  double su1 = sqrt(uPos0);  // UniformSampleTriangle montecarlo.dart:215-220
-  double b1 = 1.0 - su1;
-  double b2 = uPos1 * su1;
-  F3 pt = vadd(vadd(vmul(a, b1), vmul(b, b2)), vmul(c, (1.0 - b1 - b2)));
+  F3 pt;
+  if (QUAD && PRIM_KIND(lt.reverse)) {
+    // Disk.sample (disk.dart:144-155); Shape.sample2 defaults to it (shape.dart:96-98)
+    const DQuadric& q = sc.quads[__float_as_uint(lt.p[0])];
+    double t0, t1;
+    ConcentricSampleDisk(uPos0, uPos1, &t0, &t1);
+    pt = q_point(q.o2w, f3(t0 * q.radius, t1 * q.radius, q.height));
+  } else {
+    ltri_verts(lt, &a, &b, &c);
+    double su1 = sqrt(uPos0);  // UniformSampleTriangle montecarlo.dart:215-220
+    double b1 = 1.0 - su1;
+    double b2 = uPos1 * su1;
+    pt = vadd(vadd(vmul(a, b1), vmul(b, b2)), vmul(c, (1.0 - b1 - b2)));
+  }
   *Ns = F3{lt.ns[0], lt.ns[1], lt.ns[2]};
   F3 rd = vsub(pt, p);
   double thit = 1.0;
   for (uint32_t i = 0; i < L.ntris; ++i) {
     const DLightTri& t = sc.ltris[L.first_tri + i];
-    ltri_verts(t, &a, &b, &c);
     double th, bb1, bb2;
+    if (QUAD && PRIM_KIND(t.reverse)) {
+      const DQuadric& q = sc.quads[__float_as_uint(t.p[0])];
+      F3 phit;
+      if (quadric_hit(q, p, rd, 1.0e-3, DR_INF, &th, &phit)) {
+        DGeo dg;
+        quadric_dg(q, phit, &dg);
+        thit = th;
+        *Ns = dg.nn;
+      }
+      continue;
+    }
+    ltri_verts(t, &a, &b, &c);
     if (tri_hit(a, b, c, p, rd, 1.0e-3, DR_INF, &th, &bb1, &bb2)) {
       thit = th;
       *Ns = F3{t.nn[0], t.nn[1], t.nn[2]};  // dg.nn of the last hitting shape (shape_set.dart:71-77)
@@ -310,19 +472,34 @@ DR_DEV F3 shapeset_sample(const DScene& sc, const DLight& L, double uPos0, doubl
   return vadd(p, vmul(rd, thit));
 }
 // ShapeSet.pdf(p, wi) (shape_set.dart:82-89) with Shape.pdf2 (shape.dart:100-121).
+template <bool QUAD>
 DR_DEV double shapeset_pdf(const DScene& sc, const DLight& L, F3 p, F3 wi) {
   double pdf = 0.0;
   for (uint32_t i = 0; i < L.ntris; ++i) {
     const DLightTri& t = sc.ltris[L.first_tri + i];
     F3 a, b, c;
-    ltri_verts(t, &a, &b, &c);
     double pdf2;
     double th, bb1, bb2;
-    if (!tri_hit(a, b, c, p, wi, 1.0e-3, DR_INF, &th, &bb1, &bb2)) {
+    bool h;
+    F3 nn;
+    if (QUAD && PRIM_KIND(t.reverse)) {
+      const DQuadric& q = sc.quads[__float_as_uint(t.p[0])];
+      F3 phit;
+      h = quadric_hit(q, p, wi, 1.0e-3, DR_INF, &th, &phit);
+      if (h) {
+        DGeo dg;
+        quadric_dg(q, phit, &dg);
+        nn = dg.nn;
+      }
+    } else {
+      ltri_verts(t, &a, &b, &c);
+      h = tri_hit(a, b, c, p, wi, 1.0e-3, DR_INF, &th, &bb1, &bb2);
+      nn = F3{t.nn[0], t.nn[1], t.nn[2]};
+    }
+    if (!h) {
       pdf2 = 0.0;
     } else {
       const F3 q = vadd(p, vmul(wi, th));  // ray.pointAt(thit)
-      const F3 nn = F3{t.nn[0], t.nn[1], t.nn[2]};
       pdf2 = vlen2(vsub(q, p)) / (fabs(vdot(nn, vneg(wi))) * t.area);
       if (isinf(pdf2)) pdf2 = 0.0;
     }
@@ -370,7 +547,6 @@ DR_DEV double SphericalPhi(F3 v) {  // vector.dart:199-202
   double p = atan2((double)v.y, (double)v.x);
   return (p < 0.0) ? p + 2.0 * DR_PI : p;
 }
-#define DR_INV_TWOPI 0.15915494309189533577
 DR_DEV C3 env_Le(const DEnv& e, F3 dir) {  // infinite_area_light.dart:84-90
   F3 wh = vnormalize(xf3(e.w2l, dir));
   const double s = SphericalPhi(wh) * DR_INV_TWOPI;

@@ -58,6 +58,7 @@ struct BatchState {
   float* sv;        // [nFloats][cap] sample vectors
   const double* tail;  // [cap][maxTail] host-buffer mode, else null
   float* ro;        // ray origin (vertex position p once a vertex has been shaded)
+  float* ro0;       // DirectLighting with quadrics: the camera ray's origin (null otherwise)
   float* rd;        // continuation / camera ray direction
   double* rtmin;    // Ray.minDistance (isect.rayEpsilon after the first vertex)
   int32_t* hprim;   // closest-hit result of the camera / continuation ray

@@ -25,10 +25,19 @@ __global__ void k_gather_tris(const float* verts, const uint32_t* idx, const uin
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ntris) return;
   uint32_t a = idx[3 * i], b = idx[3 * i + 1], c = idx[3 * i + 2];
-  float4 q0 = make_float4(verts[3 * (size_t)a], verts[3 * (size_t)a + 1], verts[3 * (size_t)a + 2], verts[3 * (size_t)b]);
-  float4 q1 = make_float4(verts[3 * (size_t)b + 1], verts[3 * (size_t)b + 2], verts[3 * (size_t)c], verts[3 * (size_t)c + 1]);
-  float4 q2 = make_float4(verts[3 * (size_t)c + 2], __uint_as_float(mat[i]), __uint_as_float((uint32_t)light[i]),
-                          __uint_as_float((uint32_t)rev[i]));
+  // rev[i]: bit 0 = reverseOrientation, bits 1.. = quadric kind (set by the host for DR_PRIM_QUADRIC rows)
+  const uint32_t flags = ((uint32_t)rev[i] & 1u) | (((uint32_t)rev[i] >> 1) << 8);
+  float4 q0, q1, q2;
+  if (a == DR_PRIM_QUADRIC) {
+    q0 = make_float4(__uint_as_float(b), 0.f, 0.f, 0.f);
+    q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    q2 = make_float4(0.f, __uint_as_float(mat[i]), __uint_as_float((uint32_t)light[i]), __uint_as_float(flags));
+  } else {
+    q0 = make_float4(verts[3 * (size_t)a], verts[3 * (size_t)a + 1], verts[3 * (size_t)a + 2], verts[3 * (size_t)b]);
+    q1 = make_float4(verts[3 * (size_t)b + 1], verts[3 * (size_t)b + 2], verts[3 * (size_t)c], verts[3 * (size_t)c + 1]);
+    q2 = make_float4(verts[3 * (size_t)c + 2], __uint_as_float(mat[i]), __uint_as_float((uint32_t)light[i]),
+                     __uint_as_float(flags));
+  }
   out[3 * i] = q0;
   out[3 * i + 1] = q1;
   out[3 * i + 2] = q2;
@@ -228,7 +237,8 @@ DR_DEV void stc(float* a, uint32_t cap, uint32_t s, C3 v) {
 
 // EstimateDirect's contribution of the pending NEE rays (integrator.dart:135-145,169-180).
 // ENV: the scene has an InfiniteAreaLight (compiled out otherwise: the area-light-only path keeps its registers)
-template <bool ENV>
+// QUAD: the scene has sphere / disk primitives (likewise)
+template <bool ENV, bool QUAD>
 DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uint32_t flags, int shOcc, C3 Ld1) {
   const uint32_t cap = st.cap;
   C3 Ld = C3{0.f, 0.f, 0.f};
@@ -244,7 +254,16 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
       if (tr.light == li) {  // lightIsect.primitive.getAreaLight() == light (integrator.dart:170-172)
         const F3 wi = ld3(st.misD, cap, slot);
         DGeo dg;
-        tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, wi, 0.0, &dg);  // only nn is used
+        if (QUAD && tr.kind) {
+          // dg.nn of a quadric depends on the hit point: repeat the (deterministic) test of the MIS ray
+          const DQuadric& qd = sc.quads[tr.quad];
+          double th;
+          F3 phit;
+          (void)quadric_hit(qd, ld3(st.ro, cap, slot), wi, st.rtmin[slot], DR_INF, &th, &phit);
+          quadric_dg(qd, phit, &dg);
+        } else {
+          tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, wi, 0.0, &dg);  // only nn is used
+        }
         C3 Li = light_L(sc.lights[li], dg.nn, vneg(wi));
         if (!cblack(Li)) Ld = cadd(Ld, ldc(st.Ld2, cap, slot));
       }
@@ -255,7 +274,7 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
 
 // EstimateDirect up to the points where it must trace (integrator.dart:119-185):
 // writes the shadow ray / MIS ray and their candidate contributions.
-template <bool ENV>
+template <bool ENV, bool QUAD>
 DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
                           F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1) {
   const uint32_t cap = st.cap;
@@ -269,9 +288,9 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
   if (!infinite) {
     // DiffuseAreaLight.sampleLAtPoint (diffuse_area_light.dart:60-70)
     F3 ns;
-    ps = shapeset_sample(sc, light, ls0, ls1, lsc, &ns, p);
+    ps = shapeset_sample<QUAD>(sc, light, ls0, ls1, lsc, &ns, p);
     wi = vnormalize(vsub(ps, p));
-    lightPdf = shapeset_pdf(sc, light, p, wi);
+    lightPdf = shapeset_pdf<QUAD>(sc, light, p, wi);
     Li = light_L(light, ns, vneg(wi));
   } else {
     // InfiniteAreaLight.sampleLAtPoint (infinite_area_light.dart:92-131)
@@ -303,7 +322,7 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
     double bsdfPdf = 0.0;
     C3 f = bsdf_sample_f(bsdf, wo, &wi2, bs0, bs1, &bsdfPdf, flags);
     if (!cblack(f) && bsdfPdf > 0.0) {
-      double lightPdf2 = infinite ? env_pdf(sc.env, wi2) : shapeset_pdf(sc, light, p, wi2);
+      double lightPdf2 = infinite ? env_pdf(sc.env, wi2) : shapeset_pdf<QUAD>(sc, light, p, wi2);
       if (lightPdf2 != 0.0) {
         double weight = PowerHeuristic(bsdfPdf, lightPdf2);
         // the radiance the MIS ray returns IF it reaches the light: Lemit of the sampled area light (its
@@ -353,7 +372,7 @@ struct TailSrc {
 #define DR_SHADE_WAVES 2
 #endif
 #define DR_SHADE_BLOCK 512
-template <bool ENV>
+template <bool ENV, bool QUAD>
 __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
   __shared__ PushScratch s_push;
   const uint32_t cap = st.cap;
@@ -389,7 +408,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
       }
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
-        C3 Ld = resolve_nee<ENV>(sc, st, slot, flags, shOccIn, Ld1In);
+        C3 Ld = resolve_nee<ENV, QUAD>(sc, st, slot, flags, shOccIn, Ld1In);
         C3 tot = cmulD(Ld, (double)rp.nLights);  // integrator.dart:113-116
         L = cadd(L, cmul(betaNeeIn, tot));
       }
@@ -402,7 +421,9 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
       if (prim >= 0 && bounce <= rp.maxDepth) {
         Tri tr = load_tri(sc, (uint32_t)prim);
         DGeo dg;
-        tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
+        const bool isQuad = QUAD && tr.kind != 0;
+        if (isQuad) quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
+        else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
         const F3 wo = vneg(d);
         if (bounce == 0) {  // specularBounce is never set by a matte BSDF
           C3 Le = tr.light >= 0 ? light_L(sc.lights[tr.light], dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
@@ -410,7 +431,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         }
         Bsdf bsdf = make_bsdf(sc, dg, tr.mat);
         const F3 p = bsdf.p, n = bsdf.nn;
-        const double eps = 1.0e-3 * t;  // triangle.dart:157
+        const double eps = (isQuad ? 5.0e-4 : 1.0e-3) * t;  // triangle.dart:157; sphere.dart:169, disk.dart:98
         TailSrc ts;
         const int perNee = rp.nLights > 0 ? 7 : 0;
         if (bounce >= 3) ts.init(rp, st, slot, (bounce - 3) * (perNee + 3) + (bounce > 4 ? bounce - 4 : 0));
@@ -432,7 +453,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
           }
           int lightNum = (int)floor(lu * rp.nLights);
           lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
-          pf |= setup_nee<ENV>(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1);
+          pf |= setup_nee<ENV, QUAD>(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1);
           stc(st.betaNee, cap, slot, beta);
         }
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
@@ -478,6 +499,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
 // integrator.dart:39-77).  Stage s sets up EstimateDirect call s of UniformSampleAllLights (rp.dstages[s]:
 // sample j of light i) at the camera hit and folds in the result of call s-1; the last stage finishes the
 // sum.  st.betaNee carries the current light's Ld, st.beta the running L of UniformSampleAllLights.
+template <bool QUAD>
 __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
   __shared__ PushScratch s_push;
   const uint32_t cap = st.cap;
@@ -505,20 +527,27 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
         C3 Lall = ldc(st.beta, cap, slot);
         C3 Ld = C3{0.f, 0.f, 0.f};
         DGeo dg;
+        const bool isQuad = QUAD && tr.kind != 0;
         if (stage == 0) {
           const F3 o = ld3(st.ro, cap, slot);
           const double t = st.ht[slot];
-          tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
+          if (isQuad) {
+            quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
+            st3(st.ro0, cap, slot, o);  // later stages rebuild the hit from the camera ray
+          } else {
+            tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
+          }
           C3 Le = tr.light >= 0 ? light_L(sc.lights[tr.light], dg.nn, wo) : C3{0.f, 0.f, 0.f};
           L = cadd(L, Le);
           Lall = C3{0.f, 0.f, 0.f};
           st3(st.ro, cap, slot, dg.p);
-          st.rtmin[slot] = 1.0e-3 * t;
+          st.rtmin[slot] = (isQuad ? 5.0e-4 : 1.0e-3) * t;
         } else {
-          tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
+          if (isQuad) quadric_dg_at(sc.quads[tr.quad], ld3(st.ro0, cap, slot), d, st.ht[slot], &dg);
+          else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
           dg.p = ld3(st.ro, cap, slot);
           Ld = ldc(st.betaNee, cap, slot);
-          Ld = cadd(Ld, resolve_nee<true>(sc, st, slot, flags, st.shOcc[slot], ldc(st.Ld1, cap, slot)));  // Ld += EstimateDirect
+          Ld = cadd(Ld, resolve_nee<true, QUAD>(sc, st, slot, flags, st.shOcc[slot], ldc(st.Ld1, cap, slot)));  // Ld += EstimateDirect
           if (prev.last) {
             Lall = cadd(Lall, cdivD(Ld, (double)prev.n));  // L += Ld / nSamples
             Ld = C3{0.f, 0.f, 0.f};
@@ -533,7 +562,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
           double ls1 = LDS_STREAM(sv + (size_t)(cur.lp + 1) * cap + slot);
           double bs0 = LDS_STREAM(sv + (size_t)cur.bd * cap + slot);
           double bs1 = LDS_STREAM(sv + (size_t)(cur.bd + 1) * cap + slot);
-          pf |= setup_nee<true>(sc, st, slot, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1);
+          pf |= setup_nee<true, QUAD>(sc, st, slot, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1);
           again = true;
         } else {
           if (rp.nLights > 0) L = cadd(L, Lall);
@@ -678,12 +707,14 @@ void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) 
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
-  if (sc.hasEnv) hipLaunchKernelGGL(k_shade_path<true>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
-  else hipLaunchKernelGGL(k_shade_path<false>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  if (sc.nquads) hipLaunchKernelGGL((k_shade_path<true, true>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  else if (sc.hasEnv) hipLaunchKernelGGL((k_shade_path<true, false>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  else hipLaunchKernelGGL((k_shade_path<false, false>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_shade_direct, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
+  if (sc.nquads) hipLaunchKernelGGL(k_shade_direct<true>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
+  else hipLaunchKernelGGL(k_shade_direct<false>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
                  hipStream_t s) {

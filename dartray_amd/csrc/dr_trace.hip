@@ -362,8 +362,8 @@ struct RayIO {
     h.t = h.b1 = h.b2 = 0.0;
     if (!ANY && prim >= 0) {
       Tri tr = load_tri(sc, (uint32_t)prim);
-      double tt, b1, b2;
-      tri_hit(tr.p1, tr.p2, tr.p3, r.o, r.d, r.tmin, DR_INF, &tt, &b1, &b2);  // same arithmetic as the accepting test
+      double tt, b1 = 0.0, b2 = 0.0;
+      if (tr.kind == 0) tri_hit(tr.p1, tr.p2, tr.p3, r.o, r.d, r.tmin, DR_INF, &tt, &b1, &b2);  // same arithmetic as the accepting test
       h.t = r.tmax;
       h.b1 = b1;
       h.b2 = b2;
@@ -372,7 +372,7 @@ struct RayIO {
   }
 };
 
-template <int ANY, class IO>
+template <int ANY, bool QUAD, class IO>
 DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_t* lds, uint32_t* spill,
                              uint32_t spillStride, uint32_t* work, TraceCounters* ctr) {
   const int lane = lane_id();
@@ -489,6 +489,19 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           ++nTris;
           const float4* tp = sc.tris + 3 * (size_t)(leafOff + i);
           const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+          if (QUAD && PRIM_KIND(__float_as_uint(q2.w))) {  // GeometricPrimitive over a Sphere / Disk
+            double t;
+            F3 phit;
+            if (quadric_hit(sc.quads[__float_as_uint(q0.x)], ray.o, ray.d, ray.tmin, ray.tmax, &t, &phit)) {
+              if (ANY) {
+                occluded = true;
+                break;
+              }
+              ray_set_tmax(ray, t);
+              hit = (int)(leafOff + i);
+            }
+            continue;
+          }
           const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
           if (ANY) {
             if (tri_hitP(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax)) {  // return true (bvh_accel.dart:193-195)
@@ -530,7 +543,19 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE_WAVES) k_trace(DScene
   __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
   StateIO<ANY> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
-  trace_persistent<ANY>(sc, io, n, s_stack + threadIdx.x,
+  trace_persistent<ANY, false>(sc, io, n, s_stack + threadIdx.x,
+                        spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
+                        gridDim.x * DR_TRACE_BLOCK, work, ctr);
+}
+// scenes with sphere / disk primitives: the quadric tests cost registers, so they get their own instantiation
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace_quad(DScene sc, BatchState st, const uint32_t* queue,
+                                                               const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
+                                                               TraceCounters* ctr) {
+  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
+  StateIO<ANY> io{st, queue};
+  const uint32_t n = nQueue ? *nQueue : st.nslots;
+  trace_persistent<ANY, true>(sc, io, n, s_stack + threadIdx.x,
                         spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
                         gridDim.x * DR_TRACE_BLOCK, work, ctr);
 }
@@ -539,7 +564,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect(DScene sc, const D
                                                               uint32_t* spill, uint32_t* work, TraceCounters* ctr) {
   __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
   RayIO<ANY> io{rays, out};
-  trace_persistent<ANY>(sc, io, n, s_stack + threadIdx.x,
+  trace_persistent<ANY, true>(sc, io, n, s_stack + threadIdx.x,
                         spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
                         gridDim.x * DR_TRACE_BLOCK, work, ctr);
 }
@@ -919,6 +944,7 @@ static int traceImpl(const DScene& sc) {
     const char* e = getenv("DARTRAY_TRACE_IMPL");
     impl = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 2;  // v2 is the fastest measured
   }
+  if (sc.nquads) return 2;                     // only v2 tests quadric primitives
   return (impl == 3 && !sc.pairs) ? 2 : impl;  // scenes the pair layout cannot encode use v2
 }
 void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
@@ -946,6 +972,9 @@ void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue,
   } else if (impl == 1) {
     if (anyHit) hipLaunchKernelGGL(k_trace_v1<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace_v1<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+  } else if (sc.nquads) {
+    if (anyHit) hipLaunchKernelGGL(k_trace_quad<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+    else hipLaunchKernelGGL(k_trace_quad<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
   } else {
     if (anyHit) hipLaunchKernelGGL(k_trace<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);

@@ -47,8 +47,7 @@ def _mat(rows):
     return _f32(rows).reshape(4, 4)
 
 
-def _mul(a, b):  # Matrix4x4.Mul (matrix4x4.dart:193-206): f64 expression, f32 store
-    return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+_mul = core._mul  # Matrix4x4.Mul (matrix4x4.dart:193-206): left-to-right f64 sums, f32 store
 
 
 def _inverse(m):
@@ -121,14 +120,7 @@ class Transform:
 
     def transformPoints(self, P):
         """Transform.transformPoint (transform.dart:110-129) over an [n,3] f32 array."""
-        P = np.asarray(P, dtype=np.float32).astype(np.float64)
-        m = self.m.astype(np.float64)
-        out = (P @ m[:3, :3].T + m[:3, 3]).astype(np.float32)
-        w = P @ m[3, :3] + m[3, 3]
-        if np.any(w != 1.0):
-            sel = w != 1.0
-            out[sel] = (out[sel].astype(np.float64) / w[sel, None]).astype(np.float32)  # Point.invScale
-        return out
+        return core.transform_points(self.m, np.asarray(P, dtype=np.float32).reshape(-1, 3))
 
 
 # ---------------------------------------------------------------------------
@@ -678,13 +670,24 @@ class DartRay:
     def areaLightSource(self, name, ps):
         self.gs.areaLight, self.gs.areaLightParams = name, ps
 
-    def shape(self, name, ps):  # dartray.dart:380-470
+    def _makeShape(self, name, ps):
+        """_makeShape (dartray.dart:1001-1060) for the shapes on the path; None drops the directive like the
+        reference does for a malformed mesh."""
+        o2w, ro = self.ctm, self.gs.reverseOrientation
+        if name == "sphere":                  # sphere.dart:313-321
+            radius = ps.findOneFloat("radius", 1.0)
+            return core.Sphere(o2w.m, o2w.mInv, ro, radius, ps.findOneFloat("zmin", -radius),
+                               ps.findOneFloat("zmax", radius), ps.findOneFloat("phimax", 360.0))
+        if name == "disk":                    # disk.dart:157-165
+            return core.Disk(o2w.m, o2w.mInv, ro, ps.findOneFloat("height", 0.0), ps.findOneFloat("radius", 1.0),
+                             ps.findOneFloat("innerradius", 0.0), ps.findOneFloat("phimax", 360.0))
         if name != "trianglemesh":
-            raise UnsupportedFeature(f"Shape \"{name}\": only 'trianglemesh' is on the path (SURVEY.md section 8 row f4)")
+            raise UnsupportedFeature(f"Shape \"{name}\": only 'trianglemesh', 'sphere' and 'disk' are on the path "
+                                     "(SURVEY.md section 8 row f4)")
         vi = ps.findInt("indices")            # triangle_mesh.dart:91-193
         P = ps.findPoint("P")
         if vi is None or P is None:
-            return
+            return None
         for kind, pname, why in (("float", "uv", "per-vertex UVs change dpdu/dpdv"), ("float", "st", "per-vertex UVs"),
                                  ("normal", "N", "shading normals"), ("vector", "S", "shading tangents"),
                                  ("texture", "alpha", "alpha textures")):
@@ -695,8 +698,13 @@ class DartRay:
         idx = np.asarray(vi[:3 * ntris], dtype=np.int64).reshape(-1, 3)
         if idx.size and (idx.min() < 0 or idx.max() >= len(P)):
             self.warn("trianglemesh has out of-bounds vertex index")  # triangle_mesh.dart:160-166: shape dropped
+            return None
+        return core.TriangleMesh(idx.astype(np.uint32), self.ctm.transformPoints(P), self.gs.reverseOrientation)
+
+    def shape(self, name, ps):  # dartray.dart:380-470
+        mesh = self._makeShape(name, ps)
+        if mesh is None:
             return
-        mesh = core.TriangleMesh(idx.astype(np.uint32), self.ctm.transformPoints(P), self.gs.reverseOrientation)
         mtl = self._createMaterial(ps)
         for k in ps.unused():
             self.warn(f"Parameter '{k[1]}' not used")  # ParamSet.reportUnused
@@ -704,6 +712,9 @@ class DartRay:
         if self.gs.areaLight:
             if self.gs.areaLight not in ("area", "diffuse"):
                 raise UnsupportedFeature(f"AreaLightSource \"{self.gs.areaLight}\"")
+            if isinstance(mesh, core.Sphere):
+                raise UnsupportedFeature("a sphere as an area light (Sphere.sample2 cone sampling, sphere.dart:267-311) "
+                                         "is not on the path; disks and triangle meshes are")
             lp = self.gs.areaLightParams      # diffuse_area_light.dart:91-97
             L = lp.findOneSpectrum("L", (1.0, 1.0, 1.0))
             sc = lp.findOneSpectrum("scale", (1.0, 1.0, 1.0))

@@ -83,9 +83,26 @@ typedef struct DrEnvMap {
 } DrEnvMap;
 
 typedef struct DrLightTri {
-  uint32_t v[3]; /* vertex indices */
+  uint32_t v[3]; /* vertex indices; v[0] == DR_PRIM_QUADRIC: v[1] indexes DrSceneDesc.quadrics (a Disk) */
   uint32_t reverse_orientation;
 } DrLightTri;
+
+/* Quadric shapes (lib/shapes/sphere.dart:23-38, lib/shapes/disk.dart:23-29).  Unlike triangle meshes they keep
+ * their objectToWorld Transform and transform the RAY per test (transform.dart:180-196).  A primitive whose
+ * tri_idx[3*i] is DR_PRIM_QUADRIC is the quadric tri_idx[3*i+1]; its material / light / orientation come from
+ * the same per-primitive tables as a triangle's. */
+#define DR_PRIM_QUADRIC 0xFFFFFFFFu
+#define DR_QUADRIC_SPHERE 1
+#define DR_QUADRIC_DISK 2
+typedef struct DrQuadric {
+  int32_t kind; /* DR_QUADRIC_* */
+  int32_t pad;
+  float object_to_world[16]; /* Shape.objectToWorld.m, row-major */
+  float world_to_object[16]; /* Shape.objectToWorld.mInv == worldToObject.m (dartray.dart:383-384) */
+  /* constructor arguments as Dart doubles -- sphere: radius, z0, z1, phimax [deg] (sphere.dart:313-321);
+   * disk: height, radius, innerradius, phimax [deg] (disk.dart:157-165) */
+  double params[4];
+} DrQuadric;
 
 /* Flattened Scene (lib/core/scene.dart:26-45): aggregate + lights. */
 typedef struct DrSceneDesc {
@@ -107,6 +124,8 @@ typedef struct DrSceneDesc {
   uint32_t bvh_depth; /* max depth of the tree, 0 = unknown */
   const DrEnvMap* env_maps; /* at most one infinite light is supported */
   uint32_t nenv_maps;
+  const DrQuadric* quadrics; /* spheres / disks referenced from tri_idx and light_tris */
+  uint32_t nquadrics;
 } DrSceneDesc;
 
 typedef struct DrScene DrScene;
@@ -208,6 +227,12 @@ int dr_init(int device);
  * BVH primitive slot i. */
 int dr_bvh_build(const float* verts, uint64_t nverts, const uint32_t* tri_idx, uint64_t ntris, int32_t max_prims_in_node,
                  DrBvhNode* nodes_out, uint64_t* nnodes_out, uint32_t* order_out, uint32_t* depth_out);
+
+/* Same with quadric primitives in the list: a row tri_idx[3*i] == DR_PRIM_QUADRIC takes its world bound
+ * (Shape.worldBound, shape.dart:37-39) from quadric_bounds[6 * tri_idx[3*i+1]] = (pMin xyz, pMax xyz). */
+int dr_bvh_build_mixed(const float* verts, uint64_t nverts, const uint32_t* tri_idx, uint64_t ntris,
+                       const float* quadric_bounds, uint64_t nquadrics, int32_t max_prims_in_node,
+                       DrBvhNode* nodes_out, uint64_t* nnodes_out, uint32_t* order_out, uint32_t* depth_out);
 
 /* Scene upload (replaces the construction of lib/core/scene.dart Scene). */
 int dr_scene_create(const DrSceneDesc* desc, DrScene** out);

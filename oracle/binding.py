@@ -24,7 +24,8 @@ def build(force=False):
 class OrcMesh(C.Structure):
     _fields_ = [("P", C.c_void_p), ("idx", C.c_void_p), ("nverts", C.c_int32), ("ntris", C.c_int32),
                 ("Kd", C.c_float * 3), ("sigma", C.c_float), ("reverse_orientation", C.c_int32),
-                ("has_light", C.c_int32), ("L", C.c_float * 3), ("light_nsamples", C.c_int32)]
+                ("has_light", C.c_int32), ("L", C.c_float * 3), ("light_nsamples", C.c_int32),
+                ("kind", C.c_int32), ("o2w", C.c_float * 16), ("w2o", C.c_float * 16), ("params", C.c_double * 4)]
 
 
 class OrcSceneDesc(C.Structure):
@@ -129,12 +130,18 @@ class OracleScene:
         meshes = (OrcMesh * max(len(prims), 1))()
         self._keep = []
         for i, gp in enumerate(prims):
-            P = np.ascontiguousarray(gp.shape.P, np.float32)
-            idx = np.ascontiguousarray(gp.shape.vertexIndex, np.uint32)
-            self._keep += [P, idx]
             m = meshes[i]
-            m.P, m.idx = P.ctypes.data, idx.ctypes.data
-            m.nverts, m.ntris = len(P), len(idx)
+            if getattr(gp.shape, "kind", 0):  # Sphere (1) / Disk (2): .objectToWorld, .worldToObject, .params
+                m.kind = gp.shape.kind
+                m.o2w[:] = [float(x) for x in np.asarray(gp.shape.objectToWorld, np.float32).reshape(-1)]
+                m.w2o[:] = [float(x) for x in np.asarray(gp.shape.worldToObject, np.float32).reshape(-1)]
+                m.params[:] = [float(x) for x in gp.shape.params]
+            else:
+                P = np.ascontiguousarray(gp.shape.P, np.float32)
+                idx = np.ascontiguousarray(gp.shape.vertexIndex, np.uint32)
+                self._keep += [P, idx]
+                m.P, m.idx = P.ctypes.data, idx.ctypes.data
+                m.nverts, m.ntris = len(P), len(idx)
             m.Kd[:] = [float(x) for x in gp.material.Kd]
             m.sigma = gp.material.sigma
             m.reverse_orientation = 1 if gp.shape.reverseOrientation else 0
@@ -156,7 +163,7 @@ class OracleScene:
             d.env_nsamples = env.nSamples
         self.h = l.orc_scene_create(C.byref(d))
         if not self.h:
-            raise RuntimeError("orc_scene_create failed (environment maps must have power-of-two sizes)")
+            raise RuntimeError("orc_scene_create failed (non power-of-two environment map, or a sphere used as an area light)")
         info = (C.c_int64 * 6)()
         l.orc_scene_info(self.h, info)
         self.nnodes, self.nprims, self.depth, self.nlights, self.nverts, self.nlighttris = [int(v) for v in info]

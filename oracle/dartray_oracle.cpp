@@ -317,10 +317,18 @@ struct Mesh {
   bool reverse;
   int light;  // index into lights or -1
 };
-struct Prim {  // one refined Triangle wrapped in a GeometricPrimitive
+struct Prim {  // one refined Triangle, or a quadric Shape, wrapped in a GeometricPrimitive
   uint32_t v[3];
   int mesh;
   int src_tri;  // triangle index inside its mesh (before the refine reversal)
+  int quadric = -1;  // index into Scene::quadrics (Shape.canIntersect() == true: not refined)
+};
+// Sphere (shapes/sphere.dart:23-38) / Disk (shapes/disk.dart:23-29): constructor-derived fields are Dart doubles.
+struct Quadric {
+  int kind = 0;  // 1 = sphere, 2 = disk
+  float o2w[16], w2o[16];  // objectToWorld.m and its mInv (== worldToObject.m, dartray.dart:383-384)
+  D radius = 0, zmin = 0, zmax = 0, thetaMin = 0, thetaMax = 0, phiMax = 0, height = 0, innerRadius = 0;
+  bool reverse = false;
 };
 struct LinearNode {  // bvh_accel.dart:533-538
   V bmin, bmax;
@@ -346,9 +354,10 @@ struct Light {  // DiffuseAreaLight (diffuse_area_light.dart:36-70) + ShapeSet (
   D area;
   Distribution1D areaDistribution;
 };
-struct LightTri {
+struct LightTri {  // one Shape of a ShapeSet: a refined triangle or a quadric
   uint32_t v[3];
   bool reverse;
+  int quadric = -1;
 };
 
 // InfiniteAreaLight (lights/infinite_area_light.dart) with its MIPMap radiance map (core/mipmap.dart,
@@ -492,6 +501,7 @@ struct Scene {
   std::vector<LinearNode> nodes;
   std::vector<Light> lights;
   std::vector<LightTri> lightTris;
+  std::vector<Quadric> quadrics;
   EnvLight env;
   bool hasEnv = false;
   int maxPrimsInNode = 4;
@@ -602,6 +612,146 @@ static V tri_sample(const V& p1, const V& p2, const V& p3, bool reverse, D u1, D
   return p;
 }
 
+static V xfPoint(const float* m, const V& p) {  // transform.dart:110-128
+  D x = p.x, y = p.y, z = p.z;
+  V o = vec(m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7],
+            m[8] * x + m[9] * y + m[10] * z + m[11]);
+  D w = (D)m[12] * x + (D)m[13] * y + (D)m[14] * z + (D)m[15];
+  if (w != 1.0) o = vec(o.x / w, o.y / w, o.z / w);  // invScale
+  return o;
+}
+static V xfVector(const float* m, const V& p) {  // transform.dart:130-144
+  D x = p.x, y = p.y, z = p.z;
+  return vec(m[0] * x + m[1] * y + m[2] * z, m[4] * x + m[5] * y + m[6] * z, m[8] * x + m[9] * y + m[10] * z);
+}
+static V xfNormal(const float* mInv, const V& n) {  // transform.dart:147-161 (transpose of the inverse)
+  D x = n.x, y = n.y, z = n.z;
+  return vec(mInv[0] * x + mInv[4] * y + mInv[8] * z, mInv[1] * x + mInv[5] * y + mInv[9] * z,
+             mInv[2] * x + mInv[6] * y + mInv[10] * z);
+}
+
+// ---------------------------------------------------------------------------
+// Quadrics: Sphere (shapes/sphere.dart) and Disk (shapes/disk.dart).  They transform the RAY into object
+// space per test (transform.dart:180-196) instead of pre-transforming geometry.  dndu / dndv are not
+// restated: nothing on the path (constant textures, Lambertian BSDF) reads them.
+// ---------------------------------------------------------------------------
+static const D INV_TWOPI = 0.15915494309189533577;  // common.dart:24
+static bool Quadratic(D A, D B, D C, D* t0, D* t1) {  // common.dart:140-167
+  D discrim = B * B - 4.0 * A * C;
+  if (discrim < 0.0) return false;
+  D rootDiscrim = std::sqrt(discrim);
+  D q;
+  if (B < 0.0) q = -0.5 * (B - rootDiscrim);
+  else q = -0.5 * (B + rootDiscrim);
+  *t0 = q / A;
+  *t1 = C / q;
+  if (*t0 > *t1) std::swap(*t0, *t1);
+  return true;
+}
+static inline Ray xfRay(const float* m, const Ray& r) {  // transform.dart:180-196
+  Ray t = r;
+  t.o = xfPoint(m, r.o);
+  t.d = xfVector(m, r.d);
+  return t;
+}
+// DifferentialGeometry.set (differential_geometry.dart:77-102)
+static void dg_set(DG* dg, const V& p, const V& dpdu, const V& dpdv, bool reverse) {
+  dg->p = p;
+  dg->dpdu = dpdu;
+  dg->dpdv = dpdv;
+  dg->nn = vnormalize(vcross(dpdu, dpdv));
+  if (reverse) dg->nn = vmul(dg->nn, -1.0);
+}
+// phi of an object-space hit point; shared by sphere and disk
+static inline D hit_phi(const V& phit) {
+  D phi = std::atan2(phit.y, phit.x);
+  if (phi < 0.0) phi += 2.0 * M_PI;
+  return phi;
+}
+// Sphere.intersect (sphere.dart:40-172) / intersectP (:174-249); dg == nullptr => the predicate
+static bool sphere_intersect(const Quadric& q, const Ray& r, D* tHit, D* rayEpsilon, DG* dg) {
+  Ray ray = xfRay(q.w2o, r);
+  D A = ray.d.x * ray.d.x + ray.d.y * ray.d.y + ray.d.z * ray.d.z;
+  D B = 2 * (ray.d.x * ray.o.x + ray.d.y * ray.o.y + ray.d.z * ray.o.z);
+  D C = ray.o.x * ray.o.x + ray.o.y * ray.o.y + ray.o.z * ray.o.z - q.radius * q.radius;
+  D t0, t1;
+  if (!Quadratic(A, B, C, &t0, &t1)) return false;
+  if (t0 > ray.maxt || t1 < ray.mint) return false;
+  D thit = t0;
+  if (thit < ray.mint) {
+    thit = t1;
+    if (thit > ray.maxt) return false;
+  }
+  V phit = pointAt(ray, thit);
+  if (phit.x == 0.0 && phit.y == 0.0) phit.x = r32(1.0e-5 * q.radius);
+  D phi = hit_phi(phit);
+  auto clipped = [&](const V& ph, D ph_phi) {
+    return (q.zmin > -q.radius && ph.z < q.zmin) || (q.zmax < q.radius && ph.z > q.zmax) || ph_phi > q.phiMax;
+  };
+  if (clipped(phit, phi)) {
+    // intersectP compares thit with the LIST t1 (sphere.dart:222: always unequal) and so re-tests the same
+    // point, which fails the same clip: both variants return false here.
+    if (thit == t1) return false;
+    if (t1 > ray.maxt) return false;
+    thit = t1;
+    phit = pointAt(ray, thit);
+    if (phit.x == 0.0 && phit.y == 0.0) phit.x = r32(1.0e-5 * q.radius);
+    phi = hit_phi(phit);
+    if (clipped(phit, phi)) return false;
+  }
+  if (!dg) return true;
+  D theta = std::acos(clampD(phit.z / q.radius, -1.0, 1.0));
+  D zradius = std::sqrt(phit.x * phit.x + phit.y * phit.y);
+  D invzradius = 1.0 / zradius;
+  D cosphi = phit.x * invzradius;
+  D sinphi = phit.y * invzradius;
+  V dpdu = vec(-q.phiMax * phit.y, q.phiMax * phit.x, 0.0);
+  V dpdv = vmul(vec(phit.z * cosphi, phit.z * sinphi, -q.radius * std::sin(theta)), q.thetaMax - q.thetaMin);
+  dg_set(dg, xfPoint(q.o2w, phit), xfVector(q.o2w, dpdu), xfVector(q.o2w, dpdv), q.reverse);
+  *tHit = thit;
+  *rayEpsilon = 5.0e-4 * thit;
+  return true;
+}
+// Disk.intersect (disk.dart:37-101) / intersectP (:103-137)
+static bool disk_intersect(const Quadric& q, const Ray& r, D* tHit, D* rayEpsilon, DG* dg) {
+  Ray ray = xfRay(q.w2o, r);
+  if (std::fabs(ray.d.z) < 1.0e-7) return false;
+  D thit = (q.height - ray.o.z) / ray.d.z;
+  if (thit < ray.mint || thit > ray.maxt) return false;
+  V phit = pointAt(ray, thit);
+  D dist2 = phit.x * phit.x + phit.y * phit.y;
+  if (dist2 > q.radius * q.radius || dist2 < q.innerRadius * q.innerRadius) return false;
+  D phi = hit_phi(phit);
+  if (phi > q.phiMax) return false;
+  if (!dg) return true;
+  D oneMinusV = (std::sqrt(dist2) - q.innerRadius) / (q.radius - q.innerRadius);
+  D invOneMinusV = (oneMinusV > 0.0) ? (1.0 / oneMinusV) : 0.0;
+  V dpdu = vec(-q.phiMax * phit.y, q.phiMax * phit.x, 0.0);
+  V dpdv = vec(-phit.x * invOneMinusV, -phit.y * invOneMinusV, 0.0);
+  dpdu = vmul(dpdu, q.phiMax * INV_TWOPI);
+  dpdv = vmul(dpdv, (q.radius - q.innerRadius) / q.radius);
+  dg_set(dg, xfPoint(q.o2w, phit), xfVector(q.o2w, dpdu), xfVector(q.o2w, dpdv), q.reverse);
+  *tHit = thit;
+  *rayEpsilon = 5.0e-4 * thit;
+  return true;
+}
+static bool quadric_intersect(const Quadric& q, const Ray& r, D* tHit, D* rayEpsilon, DG* dg) {
+  return q.kind == 1 ? sphere_intersect(q, r, tHit, rayEpsilon, dg) : disk_intersect(q, r, tHit, rayEpsilon, dg);
+}
+static D quadric_area(const Quadric& q) {  // sphere.dart:251-253, disk.dart:139-142
+  if (q.kind == 1) return q.phiMax * q.radius * (q.zmax - q.zmin);
+  return q.phiMax * 0.5 * (q.radius * q.radius - q.innerRadius * q.innerRadius);
+}
+// Disk.sample (disk.dart:144-155); Shape.sample2 defaults to it (shape.dart:96-98)
+static V disk_sample(const Quadric& q, D u1, D u2, V* Ns) {
+  D t0, t1;
+  ConcentricSampleDisk(u1, u2, &t0, &t1);
+  V p = vec(t0 * q.radius, t1 * q.radius, q.height);
+  V n = vnormalize(xfNormal(q.w2o, vec(0.0, 0.0, 1.0)));
+  if (q.reverse) n = vmul(n, -1.0);
+  *Ns = n;
+  return xfPoint(q.o2w, p);
+}
 // ---------------------------------------------------------------------------
 // BVHAccel build (accelerators/bvh_accel.dart:41-91,228-437)
 // ---------------------------------------------------------------------------
@@ -803,11 +953,26 @@ struct Builder {
     buildData.resize(n);
     for (int i = 0; i < n; ++i) {
       const Prim& pr = sc->prims[i];
-      V a = sc->vert(pr.v[0]), b = sc->vert(pr.v[1]), c = sc->vert(pr.v[2]);
-      BBox bb;  // Triangle.worldBound triangle.dart:39-42
-      bb.pMin = V{std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)};
-      bb.pMax = V{std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)};
-      bb = bunionP(bb, c);
+      BBox bb;
+      if (pr.quadric >= 0) {
+        // Shape.worldBound = objectToWorld.transformBBox(objectBound()) (shape.dart:37-39, transform.dart:163-178)
+        const Quadric& q = sc->quadrics[pr.quadric];
+        V lo = q.kind == 1 ? vec(-q.radius, -q.radius, q.zmin) : vec(-q.radius, -q.radius, q.height);
+        V hi = q.kind == 1 ? vec(q.radius, q.radius, q.zmax) : vec(q.radius, q.radius, q.height);
+        BBox ob;  // BBox(p1, p2) bbox.dart:36-40
+        ob.pMin = V{std::min(lo.x, hi.x), std::min(lo.y, hi.y), std::min(lo.z, hi.z)};
+        ob.pMax = V{std::max(lo.x, hi.x), std::max(lo.y, hi.y), std::max(lo.z, hi.z)};
+        const V c8[8] = {ob.pMin, V{ob.pMax.x, ob.pMin.y, ob.pMin.z}, V{ob.pMin.x, ob.pMax.y, ob.pMin.z},
+                         V{ob.pMin.x, ob.pMin.y, ob.pMax.z}, V{ob.pMin.x, ob.pMax.y, ob.pMax.z},
+                         V{ob.pMax.x, ob.pMax.y, ob.pMin.z}, V{ob.pMax.x, ob.pMin.y, ob.pMax.z}, ob.pMax};
+        for (int k = 0; k < 8; ++k) bb = bunionP(bb, xfPoint(q.o2w, c8[k]));
+      } else {
+        V a = sc->vert(pr.v[0]), b = sc->vert(pr.v[1]), c = sc->vert(pr.v[2]);
+        // Triangle.worldBound triangle.dart:39-42
+        bb.pMin = V{std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)};
+        bb.pMax = V{std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)};
+        bb = bunionP(bb, c);
+      }
       buildData[i].primitiveNumber = i;
       buildData[i].bounds = bb;
       buildData[i].centroid = vadd(vmul(bb.pMin, 0.5), vmul(bb.pMax, 0.5));  // bbox.dart:66
@@ -879,10 +1044,13 @@ static bool bvh_intersect(const Scene& sc, Ray& ray, Isect* isect) {  // bvh_acc
         for (int i = 0; i < node.nPrimitives; ++i) {
           sc.ctr.closest_tris++;
           const Prim& pr = sc.prims[node.offset + i];
-          D thit, eps, b1, b2;
+          D thit, eps, b1 = 0.0, b2 = 0.0;
           DG dg;
-          if (tri_intersect(sc.vert(pr.v[0]), sc.vert(pr.v[1]), sc.vert(pr.v[2]), sc.meshes[pr.mesh].reverse, ray,
-                            &thit, &eps, &dg, &b1, &b2)) {
+          const bool h = pr.quadric >= 0
+                             ? quadric_intersect(sc.quadrics[pr.quadric], ray, &thit, &eps, &dg)
+                             : tri_intersect(sc.vert(pr.v[0]), sc.vert(pr.v[1]), sc.vert(pr.v[2]),
+                                             sc.meshes[pr.mesh].reverse, ray, &thit, &eps, &dg, &b1, &b2);
+          if (h) {
             isect->dg = dg;
             isect->prim = (int)(node.offset + i);
             isect->rayEpsilon = eps;
@@ -931,7 +1099,11 @@ static bool bvh_intersectP(const Scene& sc, const Ray& ray) {  // bvh_accel.dart
         for (int i = 0; i < node.nPrimitives; ++i) {
           sc.ctr.any_tris++;
           const Prim& pr = sc.prims[node.offset + i];
-          if (tri_intersectP(sc.vert(pr.v[0]), sc.vert(pr.v[1]), sc.vert(pr.v[2]), ray)) return true;
+          if (pr.quadric >= 0) {
+            if (quadric_intersect(sc.quadrics[pr.quadric], ray, nullptr, nullptr, nullptr)) return true;
+          } else if (tri_intersectP(sc.vert(pr.v[0]), sc.vert(pr.v[1]), sc.vert(pr.v[2]), ray)) {
+            return true;
+          }
         }
         if (todoOffset == 0) break;
         nodeNum = (int)todo[--todoOffset];
@@ -965,16 +1137,25 @@ static V shapeset_sample(const Scene& sc, const Light& L, D uPos0, D uPos1, D uC
   int sn = L.areaDistribution.sampleDiscrete(uComponent) % (int)L.shapes.size();
   V a, b, c;
   const LightTri& lt = sc.lightTris[L.shapes[sn]];
-  lt_verts(sc, lt, &a, &b, &c);
-  V pt = tri_sample(a, b, c, lt.reverse, uPos0, uPos1, Ns);  // Shape.sample2 -> sample (shape.dart:96-98)
+  V pt;
+  if (lt.quadric >= 0) {
+    pt = disk_sample(sc.quadrics[lt.quadric], uPos0, uPos1, Ns);
+  } else {
+    lt_verts(sc, lt, &a, &b, &c);
+    pt = tri_sample(a, b, c, lt.reverse, uPos0, uPos1, Ns);  // Shape.sample2 -> sample (shape.dart:96-98)
+  }
   Ray r{p, vsub(pt, p), 1.0e-3, kInf, 0.0, 0};
   D rayEps = 0.0, thit = 1.0;
   bool anyHit = false;
   DG dg;
   for (size_t i = 0; i < L.shapes.size(); ++i) {
     const LightTri& t = sc.lightTris[L.shapes[i]];
-    lt_verts(sc, t, &a, &b, &c);
     sc.ctr.light_tris++;
+    if (t.quadric >= 0) {
+      anyHit = quadric_intersect(sc.quadrics[t.quadric], r, &thit, &rayEps, &dg) || anyHit;
+      continue;
+    }
+    lt_verts(sc, t, &a, &b, &c);
     anyHit = tri_intersect(a, b, c, t.reverse, r, &thit, &rayEps, &dg) || anyHit;
   }
   if (anyHit) *Ns = dg.nn;
@@ -985,18 +1166,21 @@ static D shapeset_pdf(const Scene& sc, const Light& L, const V& p, const V& wi) 
   for (size_t i = 0; i < L.shapes.size(); ++i) {
     const LightTri& t = sc.lightTris[L.shapes[i]];
     V a, b, c;
-    lt_verts(sc, t, &a, &b, &c);
+    if (t.quadric < 0) lt_verts(sc, t, &a, &b, &c);
     // Shape.pdf2 (shape.dart:100-121)
     D pdf2;
     DG dgLight;
     Ray ray{p, wi, 1.0e-3, kInf, 0.0, -1};
     D thit = 0.0, rayEpsilon = 0.0;
     sc.ctr.light_tris++;
-    if (!tri_intersect(a, b, c, t.reverse, ray, &thit, &rayEpsilon, &dgLight)) {
+    const bool h = t.quadric >= 0 ? quadric_intersect(sc.quadrics[t.quadric], ray, &thit, &rayEpsilon, &dgLight)
+                                  : tri_intersect(a, b, c, t.reverse, ray, &thit, &rayEpsilon, &dgLight);
+    if (!h) {
       pdf2 = 0.0;
     } else {
       V q = pointAt(ray, thit);
-      pdf2 = vlen2(vsub(q, p)) / (vabsdot(dgLight.nn, vneg(wi)) * tri_area(a, b, c));
+      const D shapeArea = t.quadric >= 0 ? quadric_area(sc.quadrics[t.quadric]) : tri_area(a, b, c);
+      pdf2 = vlen2(vsub(q, p)) / (vabsdot(dgLight.nn, vneg(wi)) * shapeArea);
       if (std::isinf(pdf2)) pdf2 = 0.0;
     }
     pdf += L.areas[i] * pdf2;
@@ -1343,18 +1527,6 @@ struct Camera {
   float r2c[16], c2w[16];
   D lensRadius, focalDistance;
 };
-static V xfPoint(const float* m, const V& p) {  // transform.dart:110-128
-  D x = p.x, y = p.y, z = p.z;
-  V o = vec(m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7],
-            m[8] * x + m[9] * y + m[10] * z + m[11]);
-  D w = (D)m[12] * x + (D)m[13] * y + (D)m[14] * z + (D)m[15];
-  if (w != 1.0) o = vec(o.x / w, o.y / w, o.z / w);  // invScale
-  return o;
-}
-static V xfVector(const float* m, const V& p) {  // transform.dart:130-144
-  D x = p.x, y = p.y, z = p.z;
-  return vec(m[0] * x + m[1] * y + m[2] * z, m[4] * x + m[5] * y + m[6] * z, m[8] * x + m[9] * y + m[10] * z);
-}
 static Ray generateRay(const Camera& cam, D imageX, D imageY, D lensU, D lensV, D time) {
   V Pras = vec(imageX, imageY, 0.0);
   V Pcamera = xfPoint(cam.r2c, Pras);
@@ -1546,6 +1718,12 @@ struct OrcMesh {
   int32_t has_light;
   float L[3];
   int32_t light_nsamples;
+  // kind 0: triangle mesh (the fields above); 1: Sphere(radius, z0, z1, phimax [deg]) (sphere.dart:313-321);
+  // 2: Disk(height, radius, innerradius, phimax [deg]) (disk.dart:157-165).  Quadrics keep objectToWorld
+  // (o2w = .m, w2o = .mInv) and ignore P / idx.
+  int32_t kind;
+  float o2w[16], w2o[16];
+  double params[4];
 };
 struct OrcSceneDesc {
   int32_t nmeshes;
@@ -1643,12 +1821,67 @@ void* orc_scene_create(const OrcSceneDesc* d) {
     if (d->env_before_mesh >= 0 && m == d->env_before_mesh) addEnv();
     const OrcMesh& om = d->meshes[m];
     uint32_t base = (uint32_t)(sc->P.size() / 3);
-    sc->P.insert(sc->P.end(), om.P, om.P + 3 * (size_t)om.nverts);
     Mesh me;
     me.Kd = rgb(om.Kd[0], om.Kd[1], om.Kd[2]);
     me.sigma = om.sigma;
     me.reverse = om.reverse_orientation != 0;
     me.light = -1;
+    if (om.kind != 0) {
+      Quadric q;
+      q.kind = om.kind;
+      memcpy(q.o2w, om.o2w, sizeof(q.o2w));
+      memcpy(q.w2o, om.w2o, sizeof(q.w2o));
+      q.reverse = me.reverse;
+      auto radians = [](D deg) { return (M_PI / 180.0) * deg; };  // common.dart:87-88
+      if (om.kind == 1) {  // sphere.dart:24-32
+        q.radius = om.params[0];
+        D z0 = om.params[1], z1 = om.params[2];
+        q.zmin = clampD(std::min(z0, z1), -q.radius, q.radius);
+        q.zmax = clampD(std::max(z0, z1), -q.radius, q.radius);
+        q.thetaMin = std::acos(clampD(q.zmin / q.radius, -1.0, 1.0));
+        q.thetaMax = std::acos(clampD(q.zmax / q.radius, -1.0, 1.0));
+        q.phiMax = radians(clampD(om.params[3], 0.0, 360.0));
+      } else if (om.kind == 2) {  // disk.dart:24-28
+        q.height = om.params[0];
+        q.radius = om.params[1];
+        q.innerRadius = om.params[2];
+        q.phiMax = radians(clampD(om.params[3], 0.0, 360.0));
+      } else {
+        delete sc;
+        return nullptr;
+      }
+      int qi = (int)sc->quadrics.size();
+      sc->quadrics.push_back(q);
+      if (om.has_light) {
+        if (om.kind != 2) {  // Sphere.sample2 / pdf2 (cone sampling) are not restated
+          delete sc;
+          return nullptr;
+        }
+        Light L;
+        L.Lemit = rgb(om.L[0], om.L[1], om.L[2]);
+        L.nSamples = std::max(1, om.light_nsamples);
+        LightTri lt;
+        lt.v[0] = lt.v[1] = lt.v[2] = 0;
+        lt.reverse = me.reverse;
+        lt.quadric = qi;
+        L.shapes.push_back((int)sc->lightTris.size());
+        sc->lightTris.push_back(lt);
+        L.area = quadric_area(q);  // one shape: sumArea = area (shape_set.dart:37-44)
+        L.areas.push_back(L.area);
+        L.areaDistribution.init(L.areas);
+        me.light = (int)sc->lights.size();
+        sc->lights.push_back(L);
+      }
+      sc->meshes.push_back(me);
+      Prim p;
+      p.v[0] = p.v[1] = p.v[2] = 0;
+      p.mesh = m;
+      p.src_tri = 0;
+      p.quadric = qi;
+      sc->prims.push_back(p);
+      continue;
+    }
+    sc->P.insert(sc->P.end(), om.P, om.P + 3 * (size_t)om.nverts);
     if (om.has_light) {
       Light L;
       L.Lemit = rgb(om.L[0], om.L[1], om.L[2]);
@@ -1771,6 +2004,17 @@ void orc_intersect_brute(void* h, const OrcRay* rays, int64_t n, OrcHit* out, in
     o.prim = -1; o.pad = 0; o.t = o.b1 = o.b2 = 0.0;
     for (size_t p = 0; p < sc->prims.size(); ++p) {
       const Prim& pr = sc->prims[p];
+      if (pr.quadric >= 0) {
+        D t, e;
+        DG dg;
+        if (any_hit) {
+          if (quadric_intersect(sc->quadrics[pr.quadric], r, nullptr, nullptr, nullptr)) { o.prim = 0; break; }
+        } else if (quadric_intersect(sc->quadrics[pr.quadric], r, &t, &e, &dg)) {
+          o.prim = (int)p; o.t = t; o.b1 = o.b2 = 0.0;
+          r.maxt = t;
+        }
+        continue;
+      }
       V a = sc->vert(pr.v[0]), b = sc->vert(pr.v[1]), c = sc->vert(pr.v[2]);
       if (any_hit) {
         if (tri_intersectP(a, b, c, r)) { o.prim = 0; break; }

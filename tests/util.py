@@ -1,6 +1,8 @@
 """Helpers shared by the tests (inputs only; the checker lives in oracle/)."""
 import numpy as np
 
+from dartray_amd import core, pbrt, scenes
+
 
 def aggregate_test_rays(bmin, bmax, n, seed=1, hits=None):
     """Random rays after the reference's AggregateTestRenderer recipe
@@ -39,3 +41,29 @@ def rel_err_image(gpu, ref):
     """SURVEY.md section 8d parity metric: per pixel max_c |gpu-ref| / max(max_c |ref|, 1e-6)."""
     denom = np.maximum(np.abs(ref).max(axis=-1), 1e-6)
     return np.abs(gpu - ref).max(axis=-1) / denom
+
+
+def quadric_prims(seed=3, nspheres=24, ndisks=12):
+    """Random full / clipped spheres and (annular, partial) disks under random affine transforms, mixed with
+    the Cornell walls so that leaves hold triangles and quadrics side by side."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    prims = scenes.cornell_walls()
+    for k in range(nspheres + ndisks):
+        t = pbrt.Transform.Translate(*(rng.random(3) * 16 - 8))
+        t = t * pbrt.Transform.Rotate(rng.random() * 360, *(rng.random(3) - 0.5))
+        if k % 3 == 0:
+            t = t * pbrt.Transform.Scale(*(0.5 + rng.random(3)))
+        ro = bool(k % 5 == 0)
+        if k < nspheres:
+            r = 0.5 + 2 * rng.random()
+            kw = {}
+            if k % 2:
+                kw = dict(z0=-r * rng.random(), z1=r * rng.random(), phiMax=90 + 270 * rng.random())
+            shape = core.Sphere(t.m, t.mInv, ro, r, **kw)
+        else:
+            r = 0.5 + 2 * rng.random()
+            shape = core.Disk(t.m, t.mInv, ro, height=rng.random() - 0.5, radius=r,
+                              innerRadius=(r * 0.5 * rng.random() if k % 2 else 0.0),
+                              phiMax=(360.0 if k % 4 else 200.0))
+        prims.append(core.GeometricPrimitive(shape, core.MatteMaterial(tuple(0.2 + 0.6 * rng.random(3)))))
+    return prims
