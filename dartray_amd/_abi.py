@@ -24,7 +24,11 @@ class DrBvhNode(C.Structure):
 
 
 class DrMaterial(C.Structure):
-    _fields_ = [("kd", C.c_float * 3), ("sigma", C.c_float)]
+    _fields_ = [("kd", C.c_float * 3), ("sigma", C.c_float), ("type", C.c_int32), ("kr", C.c_float * 3),
+                ("kt", C.c_float * 3), ("pad", C.c_float), ("index", C.c_double)]
+
+
+DR_MATERIAL_MATTE, DR_MATERIAL_MIRROR, DR_MATERIAL_GLASS = 0, 1, 2
 
 
 class DrAreaLight(C.Structure):

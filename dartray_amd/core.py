@@ -131,9 +131,32 @@ class Disk(_Quadric):
 class MatteMaterial:
     """materials/matte_material.dart:37-77 with constant textures."""
 
+    kind = _abi.DR_MATERIAL_MATTE
+
     def __init__(self, Kd=(0.5, 0.5, 0.5), sigma=0.0):
         self.Kd = np.asarray(Kd, dtype=np.float32).reshape(3)
         self.sigma = float(sigma)
+
+
+class MirrorMaterial:
+    """materials/mirror_material.dart:35-62 with a constant Kr: one SpecularReflection(Kr, FresnelNoOp) lobe."""
+
+    kind = _abi.DR_MATERIAL_MIRROR
+
+    def __init__(self, Kr=(0.9, 0.9, 0.9)):
+        self.Kr = np.asarray(Kr, dtype=np.float32).reshape(3)
+
+
+class GlassMaterial:
+    """materials/glass_material.dart:41-85 with constant textures: SpecularReflection(Kr, FresnelDielectric(1, index))
+    + SpecularTransmission(Kt, 1, index)."""
+
+    kind = _abi.DR_MATERIAL_GLASS
+
+    def __init__(self, Kr=(1.0, 1.0, 1.0), Kt=(1.0, 1.0, 1.0), index=1.5):
+        self.Kr = np.asarray(Kr, dtype=np.float32).reshape(3)
+        self.Kt = np.asarray(Kt, dtype=np.float32).reshape(3)
+        self.index = float(index)
 
 
 class DiffuseAreaLight:
@@ -335,8 +358,15 @@ class _DeviceScene:
         self.lights = list(lights)
         mats = (_abi.DrMaterial * max(len(accel.materials), 1))()
         for i, m in enumerate(accel.materials):
-            mats[i].kd[:] = [float(x) for x in m.Kd]
-            mats[i].sigma = m.sigma
+            mats[i].type = getattr(m, "kind", _abi.DR_MATERIAL_MATTE)
+            if mats[i].type == _abi.DR_MATERIAL_MATTE:
+                mats[i].kd[:] = [float(x) for x in m.Kd]
+                mats[i].sigma = m.sigma
+            else:
+                mats[i].kr[:] = [float(x) for x in m.Kr]
+                if mats[i].type == _abi.DR_MATERIAL_GLASS:
+                    mats[i].kt[:] = [float(x) for x in m.Kt]
+                    mats[i].index = m.index
         # lights: ShapeSet triangle lists in refine (reversed) order (shape_set.dart:25-35)
         dl = (_abi.DrAreaLight * max(len(self.lights), 1))()
         ltris = []

@@ -136,7 +136,8 @@ struct DScene {
   DEnv env;
   int32_t hasEnv;
   const DQuadric* quads;  // spheres / disks; a primitive record with kind != 0 holds its index in q0.x
-  uint32_t nquads, padq;
+  uint32_t nquads;
+  uint32_t hasSpec;  // some material is a mirror / glass (general shading kernels)
 };
 
 // Primitive record flags (q2.w): bit 0 = Shape.reverseOrientation, bits 8.. = 0 triangle / DR_QUADRIC_*.
@@ -625,20 +626,41 @@ DR_DEV double env_pdf(const DEnv& e, F3 w) {  // infinite_area_light.dart:190-20
 struct Bsdf {
   F3 p, nn, sn, tn;  // ng == nn for triangles without shading normals (triangle.dart:273-276)
   C3 R;
-  int nBxDFs;
+  int nBxDFs;        // number of NON-specular lobes (0 or 1: the Lambertian)
+  // specular materials (GEN kernels only): mirror = SpecularReflection(Kr, FresnelNoOp) (mirror_material.dart:38-55),
+  // glass = SpecularReflection(Kr, FresnelDielectric(1, ior)) + SpecularTransmission(Kt, 1, ior) (glass_material.dart:44-69)
+  int mtype;
+  C3 Kr, Kt;
+  double ior;
 };
 DR_DEV bool lambert_matches(int flags) { return (LAMBERT_TYPE & flags) == LAMBERT_TYPE; }
+DR_DEV C3 clamp0(float4 m) { return C3{m.x < 0.f ? 0.f : m.x, m.y < 0.f ? 0.f : m.y, m.z < 0.f ? 0.f : m.z}; }
+// Material record: 4 x float4 = (Kd, sigma) (Kr, type) (Kt, -) (index as the two halves of a double, -, -)
+template <bool GEN>
 DR_DEV Bsdf make_bsdf(const DScene& sc, const DGeo& dg, uint32_t mat) {
   Bsdf b;
   b.p = dg.p;
   b.nn = dg.nn;
   b.sn = vnormalize(dg.dpdu);  // bsdf.dart:45-51
   b.tn = vcross(b.nn, b.sn);
-  float4 m = sc.mats[mat];
+  const float4* mp = sc.mats + 4 * (size_t)mat;
   // Kd.evaluate(dgs).clamp() (matte_material.dart:54)
-  C3 r = C3{m.x < 0.f ? 0.f : m.x, m.y < 0.f ? 0.f : m.y, m.z < 0.f ? 0.f : m.z};
+  C3 r = clamp0(mp[0]);
   b.R = r;
   b.nBxDFs = cblack(r) ? 0 : 1;
+  b.mtype = DR_MATERIAL_MATTE;
+  if (GEN) {
+    const float4 m1 = mp[1];
+    b.mtype = (int)__float_as_uint(m1.w);
+    if (b.mtype != DR_MATERIAL_MATTE) {
+      const float4 m2 = mp[2], m3 = mp[3];
+      b.nBxDFs = 0;
+      b.R = C3{0.f, 0.f, 0.f};
+      b.Kr = clamp0(m1);
+      b.Kt = clamp0(m2);
+      b.ior = __hiloint2double((int)__float_as_uint(m3.y), (int)__float_as_uint(m3.x));
+    }
+  }
   return b;
 }
 DR_DEV F3 bsdf_w2l(const Bsdf& b, F3 v) { return f3(vdot(v, b.sn), vdot(v, b.tn), vdot(v, b.nn)); }  // bsdf.dart:177-179
@@ -686,6 +708,56 @@ DR_DEV C3 bsdf_sample_f(const Bsdf& b, F3 woW, F3* wiW, double uDir0, double uDi
   if (vdot(*wiW, b.nn) * vdot(woW, b.nn) > 0) flags = flags & ~BSDF_TRANSMISSION;
   else flags = flags & ~BSDF_REFLECTION;
   if (lambert_matches(flags)) f = cadd(f, cmulD(b.R, DR_INV_PI));
+  return f;
+}
+// FresnelDielectric.evaluate (fresnel_dielectric.dart:30-64); the Spectrum it returns has three equal f32 channels
+DR_DEV float fresnel_dielectric(double cosi, double eta_i, double eta_t) {
+  cosi = cosi < -1.0 ? -1.0 : (cosi > 1.0 ? 1.0 : cosi);
+  const bool entering = cosi > 0.0;
+  const double ei = entering ? eta_i : eta_t, et = entering ? eta_t : eta_i;
+  const double sint = ei / et * sqrt(fmax(0.0, 1.0 - cosi * cosi));
+  if (sint >= 1.0) return 1.0f;
+  const double cost = sqrt(fmax(0.0, 1.0 - sint * sint));
+  cosi = fabs(cosi);
+  const double Rparl = ((et * cosi) - (ei * cost)) / ((et * cosi) + (ei * cost));
+  const double Rperp = ((ei * cosi) - (et * cost)) / ((ei * cosi) + (et * cost));
+  return (float)((Rparl * Rparl + Rperp * Rperp) / 2.0);
+}
+// BSDF.sample_f(flags = BSDF_ALL) of a mirror / glass BSDF (bsdf.dart:53-133): every lobe is specular, so the
+// chosen lobe's f and pdf are returned as they are and pdf is divided by the number of lobes.
+DR_DEV C3 spec_sample_f(const Bsdf& b, F3 woW, F3* wiW, double uComponent, double* pdf) {
+  const bool hasR = !cblack(b.Kr), hasT = b.mtype == DR_MATERIAL_GLASS && !cblack(b.Kt);
+  const int matchingComps = (hasR ? 1 : 0) + (hasT ? 1 : 0);
+  *pdf = 0.0;
+  if (matchingComps == 0) return C3{0.f, 0.f, 0.f};
+  int which = (int)floor(uComponent * matchingComps);
+  which = which < matchingComps - 1 ? which : matchingComps - 1;
+  const bool reflect = hasR && which == 0;
+  const F3 wo = bsdf_w2l(b, woW);
+  F3 wi;
+  C3 f;
+  if (reflect) {  // specular_reflection.dart:33-41
+    wi = F3{-wo.x, -wo.y, wo.z};
+    *pdf = 1.0;
+    const float F = b.mtype == DR_MATERIAL_GLASS ? fresnel_dielectric((double)wo.z, 1.0, b.ior) : 1.0f;
+    f = cdivD(cmul(C3{F, F, F}, b.Kr), fabs((double)wi.z));
+  } else {  // specular_transmission.dart:37-71
+    const bool entering = wo.z > 0.0f;
+    const double ei = entering ? 1.0 : b.ior, et = entering ? b.ior : 1.0;
+    const double sini2 = fmax(0.0, 1.0 - (double)wo.z * (double)wo.z);
+    const double eta = ei / et;
+    const double sint2 = eta * eta * sini2;
+    if (sint2 >= 1.0) return C3{0.f, 0.f, 0.f};  // total internal reflection (pdf stays 0)
+    double cost = sqrt(fmax(0.0, 1.0 - sint2));
+    if (entering) cost = -cost;
+    wi = f3(eta * -(double)wo.x, eta * -(double)wo.y, cost);
+    *pdf = 1.0;
+    const float F = fresnel_dielectric((double)wo.z, 1.0, b.ior);
+    const float omf = (float)(1.0 - (double)F);
+    f = cdivD(cmul(C3{omf, omf, omf}, b.Kt), fabs((double)wi.z));
+  }
+  *wiW = bsdf_l2w(b, wi);
+  if (matchingComps > 1) *pdf /= matchingComps;
   return f;
 }
 

@@ -45,6 +45,7 @@ struct RenderParams {
 #define PF_HAS_SH 1u    // shadow (any-hit) ray of the light-sampling half is pending
 #define PF_HAS_MIS 2u   // closest-hit ray of the BSDF-sampling half is pending
 #define PF_HAS_CONT 4u  // continuation ray is pending
+#define PF_SPECULAR 8u  // the continuation ray was sampled from a specular lobe (specularBounce)
 
 #define Q_MIS_BIT 0x80000000u
 

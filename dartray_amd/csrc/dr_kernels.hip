@@ -398,13 +398,14 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
       const C3 betaNeeIn = ldc(st.betaNee, cap, slot);
       const C3 Ld1In = ldc(st.Ld1, cap, slot);
       const F3 o = ld3(st.ro, cap, slot), d = ld3(st.rd, cap, slot);
-      float su[10];  // this bounce's sample-vector slots (Appendix B): lightNum, light comp, light pos, bsdf dir, path dir
+      float su[10];  // this bounce's sample-vector slots (Appendix B): lightNum, light comp, light pos, bsdf dir, path dir, path comp
       if (bounce < 3) {
         const float* sv = st.sv;
         su[0] = sv[(size_t)(5 + 4 * bounce + 1) * cap + slot];
         su[1] = sv[(size_t)(5 + 4 * bounce + 0) * cap + slot];
 #pragma unroll
         for (int k = 0; k < 6; ++k) su[2 + k] = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce) + k) * cap + slot];
+        if (QUAD) su[8] = sv[(size_t)(5 + 4 * bounce + 3) * cap + slot];
       }
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
@@ -418,6 +419,10 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         // lights return 0 (light.dart:70-72), the infinite light its map
         L = cadd(L, env_Le(sc.env, d));
       }
+      if (ENV && QUAD && bounce > 0 && prim < 0 && (flags & PF_HAS_CONT) && (flags & PF_SPECULAR) && sc.hasEnv) {
+        // a ray that left the scene after a specular bounce still sees the lights (path_integrator.dart:107-111)
+        L = cadd(L, cmul(beta, env_Le(sc.env, d)));
+      }
       if (prim >= 0 && bounce <= rp.maxDepth) {
         Tri tr = load_tri(sc, (uint32_t)prim);
         DGeo dg;
@@ -425,11 +430,11 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         if (isQuad) quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
         else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
         const F3 wo = vneg(d);
-        if (bounce == 0) {  // specularBounce is never set by a matte BSDF
+        if (bounce == 0 || (QUAD && (flags & PF_SPECULAR))) {  // bounces == 0 || specularBounce (path_integrator.dart:46)
           C3 Le = tr.light >= 0 ? light_L(sc.lights[tr.light], dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
           L = cadd(L, cmul(beta, Le));
         }
-        Bsdf bsdf = make_bsdf(sc, dg, tr.mat);
+        Bsdf bsdf = make_bsdf<QUAD>(sc, dg, tr.mat);
         const F3 p = bsdf.p, n = bsdf.nn;
         const double eps = (isQuad ? 5.0e-4 : 1.0e-3) * t;  // triangle.dart:157; sphere.dart:169, disk.dart:98
         TailSrc ts;
@@ -457,17 +462,19 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
           stc(st.betaNee, cap, slot, beta);
         }
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
-        double o0, o1;
+        double o0, o1, oc = 0.0;
         if (bounce < 3) {
           o0 = su[6];
           o1 = su[7];
+          if (QUAD) oc = su[8];
         } else {
           o0 = (float)ts.next(rp); o1 = (float)ts.next(rp);
-          (void)ts.next(rp);
+          oc = ts.next(rp);
         }
         F3 wi = F3{0, 0, 0};
         double pdf = 0.0;
-        C3 f = bsdf_sample_f(bsdf, wo, &wi, o0, o1, &pdf, BSDF_ALL);
+        const bool specular = QUAD && bsdf.mtype != DR_MATERIAL_MATTE;
+        C3 f = specular ? spec_sample_f(bsdf, wo, &wi, oc, &pdf) : bsdf_sample_f(bsdf, wo, &wi, o0, o1, &pdf, BSDF_ALL);
         bool alive = !(cblack(f) || pdf == 0.0);
         if (alive) {
           beta = cmul(beta, cdivD(cmulD(f, fabs(vdot(wi, n))), pdf));
@@ -482,6 +489,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
           st3(st.rd, cap, slot, wi);
           stc(st.beta, cap, slot, beta);
           pf |= PF_HAS_CONT;
+          if (specular) pf |= PF_SPECULAR;  // specularBounce (path_integrator.dart:87)
           pushCont = true;
         }
         st3(st.ro, cap, slot, p);
@@ -554,7 +562,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
           }
         }
         if (stage < nCalls) {
-          Bsdf bsdf = make_bsdf(sc, dg, tr.mat);
+          Bsdf bsdf = make_bsdf<false>(sc, dg, tr.mat);  // specular materials are refused for DirectLighting
           const float* sv = st.sv;
           // sample slots of this call (direct_lighting_integrator.dart:70-87)
           double lsc = LDS_STREAM(sv + (size_t)cur.lc * cap + slot);
@@ -707,7 +715,7 @@ void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) 
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
-  if (sc.nquads) hipLaunchKernelGGL((k_shade_path<true, true>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  if (sc.nquads || sc.hasSpec) hipLaunchKernelGGL((k_shade_path<true, true>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
   else if (sc.hasEnv) hipLaunchKernelGGL((k_shade_path<true, false>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
   else hipLaunchKernelGGL((k_shade_path<false, false>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
 }

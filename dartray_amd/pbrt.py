@@ -620,12 +620,24 @@ class DartRay:
     def _makeMaterial(self, name, geomParams, matParams):
         """MatteMaterial.Create through TextureParams (matte_material.dart:67-72; texture_params.dart: the shape's
         own parameters are searched before the Material directive's)."""
-        if name != "matte":
-            raise UnsupportedFeature(f"Material \"{name}\": only 'matte' (Lambertian) is on the path (SURVEY.md section 8 row f4)")
+        if name not in ("matte", "mirror", "glass"):
+            raise UnsupportedFeature(f"Material \"{name}\": only 'matte' (Lambertian), 'mirror' and 'glass' are on the path "
+                                     "(SURVEY.md section 8 row f4)")
         for ps in (geomParams, matParams):
-            for tex in ("Kd", "sigma", "bumpmap"):
+            for tex in ("Kd", "sigma", "bumpmap", "Kr", "Kt", "index"):
                 if ps.has("texture", tex):
-                    raise UnsupportedFeature(f"matte '{tex}' bound to a texture: only constant textures are on the path")
+                    raise UnsupportedFeature(f"{name} '{tex}' bound to a texture: only constant textures are on the path")
+
+        def spectrum(pname, default):  # TextureParams.getSpectrumTexture: the shape's parameters first
+            return geomParams.findOneSpectrum(pname, None) if geomParams.has("spectrum", pname) else \
+                matParams.findOneSpectrum(pname, default)
+
+        if name == "mirror":                  # mirror_material.dart:57-61
+            return core.MirrorMaterial(spectrum("Kr", (0.9, 0.9, 0.9)))
+        if name == "glass":                   # glass_material.dart:71-78
+            index = geomParams.findOneFloat("index", None) if geomParams.has("float", "index") else \
+                matParams.findOneFloat("index", 1.5)
+            return core.GlassMaterial(spectrum("Kr", (1.0, 1.0, 1.0)), spectrum("Kt", (1.0, 1.0, 1.0)), index)
         kd = geomParams.findOneSpectrum("Kd", None) if geomParams.has("spectrum", "Kd") else \
             matParams.findOneSpectrum("Kd", (0.5, 0.5, 0.5))
         sigma = geomParams.findOneFloat("sigma", None) if geomParams.has("float", "sigma") else \

@@ -25,7 +25,8 @@ class OrcMesh(C.Structure):
     _fields_ = [("P", C.c_void_p), ("idx", C.c_void_p), ("nverts", C.c_int32), ("ntris", C.c_int32),
                 ("Kd", C.c_float * 3), ("sigma", C.c_float), ("reverse_orientation", C.c_int32),
                 ("has_light", C.c_int32), ("L", C.c_float * 3), ("light_nsamples", C.c_int32),
-                ("kind", C.c_int32), ("o2w", C.c_float * 16), ("w2o", C.c_float * 16), ("params", C.c_double * 4)]
+                ("kind", C.c_int32), ("o2w", C.c_float * 16), ("w2o", C.c_float * 16), ("params", C.c_double * 4),
+                ("mat_type", C.c_int32), ("Kr", C.c_float * 3), ("Kt", C.c_float * 3), ("ior", C.c_double)]
 
 
 class OrcSceneDesc(C.Structure):
@@ -142,8 +143,16 @@ class OracleScene:
                 self._keep += [P, idx]
                 m.P, m.idx = P.ctypes.data, idx.ctypes.data
                 m.nverts, m.ntris = len(P), len(idx)
-            m.Kd[:] = [float(x) for x in gp.material.Kd]
-            m.sigma = gp.material.sigma
+            mt = getattr(gp.material, "kind", 0)  # 0 matte, 1 mirror, 2 glass
+            m.mat_type = mt
+            if mt == 0:
+                m.Kd[:] = [float(x) for x in gp.material.Kd]
+                m.sigma = gp.material.sigma
+            else:
+                m.Kr[:] = [float(x) for x in gp.material.Kr]
+                if mt == 2:
+                    m.Kt[:] = [float(x) for x in gp.material.Kt]
+                    m.ior = float(gp.material.index)
             m.reverse_orientation = 1 if gp.shape.reverseOrientation else 0
             if gp.areaLight is not None:
                 m.has_light = 1

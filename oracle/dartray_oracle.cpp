@@ -316,6 +316,10 @@ struct Mesh {
   D sigma;
   bool reverse;
   int light;  // index into lights or -1
+  // material: 0 matte (matte_material.dart), 1 mirror (mirror_material.dart), 2 glass (glass_material.dart)
+  int matType = 0;
+  S Kr{0, 0, 0}, Kt{0, 0, 0};
+  D ior = 1.5;
 };
 struct Prim {  // one refined Triangle, or a quadric Shape, wrapped in a GeometricPrimitive
   uint32_t v[3];
@@ -1204,27 +1208,85 @@ enum {
   BSDF_ALL_TYPES = BSDF_DIFFUSE | BSDF_GLOSSY | BSDF_SPECULAR,
   BSDF_ALL = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_ALL_TYPES
 };
+// Fresnel terms (fresnel_dielectric.dart:30-64, fresnel_no_op.dart): returned as a Spectrum (f32).
+static S fresnel_dielectric(D cosi, D eta_i, D eta_t) {
+  cosi = clampD(cosi, -1.0, 1.0);
+  bool entering = cosi > 0.0;
+  D ei = eta_i, et = eta_t;
+  if (!entering) std::swap(ei, et);
+  D sint = ei / et * std::sqrt(std::max(0.0, 1.0 - cosi * cosi));
+  if (sint >= 1.0) return S{1, 1, 1};  // total internal reflection
+  D cost = std::sqrt(std::max(0.0, 1.0 - sint * sint));
+  cosi = std::fabs(cosi);
+  D Rparl = ((et * cosi) - (ei * cost)) / ((et * cosi) + (ei * cost));
+  D Rperp = ((ei * cosi) - (et * cost)) / ((ei * cosi) + (et * cost));
+  D v = (Rparl * Rparl + Rperp * Rperp) / 2.0;
+  return rgb(v, v, v);
+}
+struct BxDF {
+  int kind = 0;  // 0 Lambertian (lambertian.dart), 1 SpecularReflection, 2 SpecularTransmission
+  int type = 0;  // BxDFType flags
+  S R{0, 0, 0};  // reflectance / transmittance
+  bool dielectric = false;  // SpecularReflection: FresnelDielectric(ei, et) instead of FresnelNoOp
+  D ei = 1.0, et = 1.0;
+  bool matches(int flags) const { return (type & flags) == type; }  // bxdf.dart:31-33
+  S f() const { return kind == 0 ? smulD(R, INV_PI) : S{0, 0, 0}; }  // lambertian.dart:35-37; specular_*.dart f() == 0
+  D pdf(const V& wo, const V& wi) const {                              // bxdf.dart:84-88; specular_*.dart pdf() == 0
+    if (kind != 0) return 0.0;
+    return (wo.z * wi.z > 0.0) ? std::fabs(wi.z) * INV_PI : 0.0;
+  }
+  S sample_f(const V& wo, V* wi, D u1, D u2, D* pdf) const {
+    if (kind == 0) {  // BxDF.sample_f (bxdf.dart:37-48)
+      *wi = CosineSampleHemisphere(u1, u2);
+      if (wo.z < 0.0) wi->z *= -1.0;
+      *pdf = this->pdf(wo, *wi);
+      return f();
+    }
+    if (kind == 1) {  // specular_reflection.dart:33-41
+      *wi = vec(-wo.x, -wo.y, wo.z);
+      *pdf = 1.0;
+      S F = dielectric ? fresnel_dielectric(wo.z, ei, et) : S{1, 1, 1};
+      return sdivD(smul(F, R), std::fabs(wi->z));
+    }
+    // specular_transmission.dart:37-71
+    bool entering = wo.z > 0.0;
+    D e_i = ei, e_t = et;
+    if (!entering) std::swap(e_i, e_t);
+    D sini2 = std::max(0.0, 1.0 - wo.z * wo.z);  // Vector.SinTheta2 (vector.dart)
+    D eta = e_i / e_t;
+    D sint2 = eta * eta * sini2;
+    if (sint2 >= 1.0) return S{0, 0, 0};  // total internal reflection: pdf stays 0
+    D cost = std::sqrt(std::max(0.0, 1.0 - sint2));
+    if (entering) cost = -cost;
+    D sintOverSini = eta;
+    *wi = vec(sintOverSini * -wo.x, sintOverSini * -wo.y, cost);
+    *pdf = 1.0;
+    S F = fresnel_dielectric(wo.z, ei, et);
+    S oneMinusF = rgb(1.0 - F.r, 1.0 - F.g, 1.0 - F.b);
+    return sdivD(smul(oneMinusF, R), std::fabs(wi->z));
+  }
+};
 struct BSDF {
   V p, nn, ng, sn, tn;
-  int nBxDFs;
-  S R;                // Lambertian reflectance
-  static const int kType = BSDF_REFLECTION | BSDF_DIFFUSE;
-  static bool matches(int flags) { return (kType & flags) == kType; }  // bxdf.dart:31-33
-  int numComponents(int flags) const { return (nBxDFs > 0 && matches(flags)) ? 1 : 0; }
+  int nBxDFs = 0;
+  BxDF bx[2];
+  void add(const BxDF& b) { bx[nBxDFs++] = b; }
+  int numComponents(int flags) const {  // bsdf.dart:162-175
+    int n = 0;
+    for (int i = 0; i < nBxDFs; ++i) n += bx[i].matches(flags) ? 1 : 0;
+    return n;
+  }
   V worldToLocal(const V& v) const { return vec(vdot(v, sn), vdot(v, tn), vdot(v, nn)); }  // bsdf.dart:177-179
   V localToWorld(const V& v) const {                                                        // bsdf.dart:181-185
     return vec(sn.x * v.x + tn.x * v.y + nn.x * v.z, sn.y * v.x + tn.y * v.y + nn.y * v.z,
                sn.z * v.x + tn.z * v.y + nn.z * v.z);
   }
-  S bxdf_f() const { return smulD(R, INV_PI); }  // lambertian.dart:35-37
-  static D bxdf_pdf(const V& wo, const V& wi) {  // bxdf.dart:84-88
-    return (wo.z * wi.z > 0.0) ? std::fabs(wi.z) * INV_PI : 0.0;
-  }
   S f(const V& woW, const V& wiW, int flags) const {  // bsdf.dart:187-211
     if (vdot(wiW, ng) * vdot(woW, ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
     else flags = flags & ~BSDF_REFLECTION;
     S f{0, 0, 0};
-    if (nBxDFs > 0 && matches(flags)) f = sadd(f, bxdf_f());
+    for (int i = 0; i < nBxDFs; ++i)
+      if (bx[i].matches(flags)) f = sadd(f, bx[i].f());
     return f;
   }
   D pdf(const V& woW, const V& wiW, int flags) const {  // bsdf.dart:135-156
@@ -1233,10 +1295,11 @@ struct BSDF {
     V wi = worldToLocal(wiW);
     D pdf = 0.0;
     int matchingComps = 0;
-    if (matches(flags)) {
-      ++matchingComps;
-      pdf += bxdf_pdf(wo, wi);
-    }
+    for (int i = 0; i < nBxDFs; ++i)
+      if (bx[i].matches(flags)) {
+        ++matchingComps;
+        pdf += bx[i].pdf(wo, wi);
+      }
     return matchingComps > 0 ? pdf / matchingComps : 0.0;
   }
   S sample_f(const V& woW, V* wiW, D uDir0, D uDir1, D uComponent, D* pdf, int flags, int* sampledType) const {
@@ -1248,23 +1311,34 @@ struct BSDF {
       return S{0, 0, 0};
     }
     int which = std::min((int)std::floor(uComponent * matchingComps), matchingComps - 1);
-    (void)which;
+    const BxDF* bxdf = nullptr;
+    int count = which;
+    for (int i = 0; i < nBxDFs; ++i)
+      if (bx[i].matches(flags) && count-- == 0) {
+        bxdf = &bx[i];
+        break;
+      }
     V wo = worldToLocal(woW);
+    V wi{0, 0, 0};
     *pdf = 0.0;
-    V wi = CosineSampleHemisphere(uDir0, uDir1);  // bxdf.dart:37-48
-    if (wo.z < 0.0) wi.z *= -1.0;
-    *pdf = bxdf_pdf(wo, wi);
+    S f = bxdf->sample_f(wo, &wi, uDir0, uDir1, pdf);
     if (*pdf == 0.0) {
       if (sampledType) *sampledType = 0;
       return S{0, 0, 0};
     }
-    if (sampledType) *sampledType = kType;
+    if (sampledType) *sampledType = bxdf->type;
     *wiW = localToWorld(wi);
-    // matchingComps == 1: no pdf averaging.
-    S f{0, 0, 0};
-    if (vdot(*wiW, ng) * vdot(woW, ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
-    else flags = flags & ~BSDF_REFLECTION;
-    if (matches(flags)) f = sadd(f, bxdf_f());
+    if (!(bxdf->type & BSDF_SPECULAR) && matchingComps > 1)
+      for (int i = 0; i < nBxDFs; ++i)
+        if (&bx[i] != bxdf && bx[i].matches(flags)) *pdf += bx[i].pdf(wo, wi);
+    if (matchingComps > 1) *pdf /= matchingComps;
+    if ((bxdf->type & BSDF_SPECULAR) == 0) {
+      f = S{0, 0, 0};
+      if (vdot(*wiW, ng) * vdot(woW, ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
+      else flags = flags & ~BSDF_REFLECTION;
+      for (int i = 0; i < nBxDFs; ++i)
+        if (bx[i].matches(flags)) f = sadd(f, bx[i].f());
+    }
     return f;
   }
 };
@@ -1279,9 +1353,47 @@ static BSDF make_bsdf(const Scene& sc, const Isect& is) {
   b.nn = is.dg.nn;
   b.sn = vnormalize(is.dg.dpdu);   // bsdf.dart:45-51
   b.tn = vcross(b.nn, b.sn);
-  S r = rgb(clampD(m.Kd.r, 0.0, kInf), clampD(m.Kd.g, 0.0, kInf), clampD(m.Kd.b, 0.0, kInf));
-  b.nBxDFs = sblack(r) ? 0 : 1;
-  b.R = r;
+  auto clampS = [](const S& c) { return rgb(clampD(c.r, 0.0, kInf), clampD(c.g, 0.0, kInf), clampD(c.b, 0.0, kInf)); };
+  if (m.matType == 0) {  // matte_material.dart:41-65 (sigma == 0: Lambertian)
+    S r = clampS(m.Kd);
+    if (!sblack(r)) {
+      BxDF x;
+      x.kind = 0;
+      x.type = BSDF_REFLECTION | BSDF_DIFFUSE;
+      x.R = r;
+      b.add(x);
+    }
+  } else if (m.matType == 1) {  // mirror_material.dart:38-55
+    S r = clampS(m.Kr);
+    if (!sblack(r)) {
+      BxDF x;
+      x.kind = 1;
+      x.type = BSDF_REFLECTION | BSDF_SPECULAR;
+      x.R = r;
+      b.add(x);
+    }
+  } else {  // glass_material.dart:44-69
+    S r = clampS(m.Kr), t = clampS(m.Kt);
+    if (!sblack(r)) {
+      BxDF x;
+      x.kind = 1;
+      x.type = BSDF_REFLECTION | BSDF_SPECULAR;
+      x.R = r;
+      x.dielectric = true;
+      x.ei = 1.0;
+      x.et = m.ior;
+      b.add(x);
+    }
+    if (!sblack(t)) {
+      BxDF x;
+      x.kind = 2;
+      x.type = BSDF_TRANSMISSION | BSDF_SPECULAR;
+      x.R = t;
+      x.ei = 1.0;
+      x.et = m.ior;
+      b.add(x);
+    }
+  }
   return b;
 }
 static S isect_Le(const Scene& sc, const Isect& is, const V& wo) {  // intersection.dart:60-63
@@ -1469,7 +1581,12 @@ static S PathLi(const Scene& sc, const IntegratorCfg& cfg, const Ray& r, const I
     }
     if (bounces == cfg.maxDepth) break;
     Isect localIsect;
-    if (!bvh_intersect(sc, ray, &localIsect)) break;  // specularBounce is never true for matte
+    if (!bvh_intersect(sc, ray, &localIsect)) {
+      if (specularBounce)  // path_integrator.dart:107-111: area lights' Le(ray) is 0 (light.dart:70-72)
+        for (size_t i = 0; i < sc.lights.size(); ++i)
+          if (sc.lights[i].kind == 1) L = sadd(L, smul(pathThroughput, sc.env.Le(ray.d)));
+      break;
+    }
     // transmittance == 1
     isectP = localIsect;
   }
@@ -1724,6 +1841,10 @@ struct OrcMesh {
   int32_t kind;
   float o2w[16], w2o[16];
   double params[4];
+  // material: 0 matte (Kd, sigma), 1 mirror (Kr), 2 glass (Kr, Kt, index)
+  int32_t mat_type;
+  float Kr[3], Kt[3];
+  double ior;
 };
 struct OrcSceneDesc {
   int32_t nmeshes;
@@ -1826,6 +1947,10 @@ void* orc_scene_create(const OrcSceneDesc* d) {
     me.sigma = om.sigma;
     me.reverse = om.reverse_orientation != 0;
     me.light = -1;
+    me.matType = om.mat_type;
+    me.Kr = rgb(om.Kr[0], om.Kr[1], om.Kr[2]);
+    me.Kt = rgb(om.Kt[0], om.Kt[1], om.Kt[2]);
+    me.ior = om.ior;
     if (om.kind != 0) {
       Quadric q;
       q.kind = om.kind;
@@ -2108,6 +2233,9 @@ int orc_render(void* h, const OrcRenderDesc* rd, float* out_rgb, float* out_film
   setup_render(*sc, rd, &cfg, &cam, &film, &n1D, &n2D, &nFloats, win, full);
   int spp = rd->spp;
   if ((spp & (spp - 1)) != 0) return -2;  // LowDiscrepancySampler rounds up; callers pass powers of two
+  if (cfg.kind == 0)  // DirectLighting recurses through SpecularReflect / SpecularTransmit (integrator.dart:187-290): not restated
+    for (const Mesh& m : sc->meshes)
+      if (m.matType != 0) return -5;
   if (rec) { rec->count = 0; rec->nfloats = nFloats; if (rec->nfloats_cap < nFloats) return -3; }
   DartRandom rng((int64_t)rd->task_num);  // sampler_renderer.dart:137
   std::vector<float> buffer, samples;

@@ -1,0 +1,97 @@
+"""GPU parity of mirror / glass materials in the path tracer: specular lobes,
+Fresnel, the specularBounce branches (emitted radiance after a specular bounce, lights seen by escaped specular
+rays) -- bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+from dartray_amd import _abi, pbrt
+from util import rel_err_image
+
+pytestmark = pytest.mark.gpu
+
+SCENE = '''
+Film "image" "integer xresolution" [48] "integer yresolution" [36]
+SurfaceIntegrator "path" "integer maxdepth" [{depth}]
+Sampler "lowdiscrepancy" "integer pixelsamples" [16]
+LookAt 0 0 -35 0 0 0 0 1 0
+Camera "perspective" "float fov" [35]
+WorldBegin
+{env}
+AttributeBegin
+  AreaLightSource "area" "color L" [36 36 36] "integer nsamples" [1]
+  Translate 0 9.9 0
+  Rotate 90 1 0 0
+  Shape "disk" "float radius" [3]
+AttributeEnd
+AttributeBegin
+  Material "matte" "color Kd" [0.75 0.75 0.75]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [10 -10 -10 -10 -10 -10 -10 -10 10 10 -10 10]
+  {ceiling}
+  Material "mirror" "color Kr" [0.9 0.85 0.8]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [10 -10 10 -10 -10 10 -10 10 10 10 10 10]
+  Material "matte" "color Kd" [0.48 0.1125 0.075]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-10 -10 10 -10 -10 -10 -10 10 -10 -10 10 10]
+  Material "matte" "color Kd" [0.1125 0.375 0.1125]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [10 -10 -10 10 -10 10 10 10 10 10 10 -10]
+AttributeEnd
+AttributeBegin
+  Material "glass" "float index" [1.5] "color Kr" [0.1 0.8 0.8] "color Kt" [0.1 0.8 0.8]
+  Translate -4 -4 0
+  Shape "sphere" "float radius" 3
+AttributeEnd
+AttributeBegin
+  Material "mirror"
+  Translate 4.5 -7 3
+  Shape "sphere" "float radius" 3
+AttributeEnd
+AttributeBegin
+  Material "glass" "float index" [1.33]
+  Translate 0 -8 -4  Rotate 30 0 1 0  Scale 0.15 0.15 0.15
+  Shape "trianglemesh" "integer indices" [0 2 1 0 3 2] "point P" [10 -10 -10 -10 -10 -10 -10 -10 10 10 -10 10]
+  Shape "trianglemesh" "integer indices" [0 2 1 0 3 2] "point P" [10 10 -10 10 10 10 -10 10 10 -10 10 -10]
+  Shape "trianglemesh" "integer indices" [0 2 1 0 3 2] "point P" [10 -10 10 -10 -10 10 -10 10 10 10 10 10]
+  Shape "trianglemesh" "integer indices" [0 2 1 0 3 2] "point P" [-10 -10 10 -10 -10 -10 -10 10 -10 -10 10 10]
+  Shape "trianglemesh" "integer indices" [0 2 1 0 3 2] "point P" [10 -10 -10 10 -10 10 10 10 10 10 10 -10]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [10 -10 -10 -10 -10 -10 -10 10 -10 10 10 -10]
+AttributeEnd
+WorldEnd
+'''
+CEILING = 'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [10 10 -10 10 10 10 -10 10 10 -10 10 -10]'
+ENV = 'AttributeBegin Rotate -90 1 0 0 LightSource "infinite" "color L" [0.4 0.5 0.7] AttributeEnd'
+
+
+@pytest.mark.parametrize("depth,env,ceiling", [(5, "", CEILING), (8, ENV, ""), (2, ENV, CEILING)])
+def test_mirror_and_glass_render_like_the_oracle(ob, gpu, depth, env, ceiling):
+    api = pbrt.loads(SCENE.format(depth=depth, env=env, ceiling=ceiling), render=True)
+    out, r = api.outputImage, api.rendererObject
+    e, before = api.envLight()
+    osc = ob.OracleScene(api.scenePrimitives, env=e, env_before=before)
+    osc.counters(reset=True)
+    ref = osc.render(ob.render_desc(r, sampler_mode=1))
+    err = rel_err_image(out.rgb, ref["rgb"])
+    assert err.max() <= 1e-4, (err.max(), (err > 1e-4).sum())
+    assert np.array_equal(out.film, ref["film"])
+    c, st = osc.counters(), r.last_stats
+    for k in ("closest_rays", "any_rays", "closest_nodes", "any_nodes", "closest_tris", "any_tris"):
+        assert st[k] == c[k], k
+    assert out.rgb.mean() > 0.05
+
+
+def test_serial_reference_stream_with_specular_materials(ob, gpu):
+    """The reference-faithful serial RNG stream (recorded by the oracle) replayed through host buffers: the
+    in-Li draws now include the lobe-selection uComponent of bounces >= 3."""
+    api = pbrt.loads(SCENE.format(depth=6, env="", ceiling=CEILING).replace('[48]', '[20]').replace('[36]', '[16]'))
+    r = api.rendererObject
+    osc = ob.OracleScene(api.scenePrimitives)
+    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=21 * 17 * 16, max_tail=64)
+    from dartray_amd import core
+    r.sampler = core.HostBufferSampler(r.camera, 16, rec["pixel_xy"][::16].copy(), rec["sample_vec"], rec["tail"])
+    out = r.render(api.scene)
+    assert np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"])
+
+
+def test_direct_lighting_with_specular_materials_is_refused(gpu):
+    txt = SCENE.format(depth=5, env="", ceiling=CEILING).replace('SurfaceIntegrator "path"', 'SurfaceIntegrator "directlighting"')
+    with pytest.raises(_abi.DartRayHipError) as e:
+        pbrt.loads(txt, render=True)
+    assert "SpecularReflect" in str(e.value)

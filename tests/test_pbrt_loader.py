@@ -177,7 +177,8 @@ def test_include_gz_and_relative_paths(tmp_path):
 @pytest.mark.parametrize("snippet,needle", [
     ('Shape "cylinder" "float radius" 3', 'Shape "cylinder"'),
     ('AreaLightSource "area"\nShape "sphere" "float radius" [3]', "sphere as an area light"),
-    ('Material "glass"\nShape "trianglemesh" ' + QUAD, 'Material "glass"'),
+    ('Material "plastic"\nShape "trianglemesh" ' + QUAD, 'Material "plastic"'),
+    ('Material "mirror" "texture Kr" "checks"\nShape "trianglemesh" ' + QUAD, "bound to a texture"),
     ('Material "matte" "float sigma" [20]\nShape "trianglemesh" ' + QUAD, "Oren-Nayar"),
     ('Texture "t" "color" "imagemap" "string filename" "x.png"', "Texture"),
     ('LightSource "point" "color I" [1 1 1]', 'LightSource "point"'),
@@ -204,6 +205,28 @@ def test_render_options_outside_the_path_fail_at_world_end(opt, needle):
     with pytest.raises(pbrt.UnsupportedFeature) as e:
         pbrt.loads(opt + "\nWorldBegin\nShape \"trianglemesh\" " + QUAD + "\nWorldEnd\n")
     assert needle in str(e.value)
+
+
+def test_mirror_and_glass_materials():
+    api = pbrt.loads(HEADER + f'''
+WorldBegin
+Material "mirror"
+Shape "trianglemesh" {QUAD}
+Material "mirror" "color Kr" [0.5 0.6 0.7]
+Shape "trianglemesh" {QUAD}
+Material "glass" "float index" [1.33] "color Kt" [0.9 0.9 1]
+Shape "trianglemesh" {QUAD}
+Shape "sphere" "float radius" 2 "color Kr" [0.1 0.1 0.1] "float index" 2.0
+Material "glass"
+Shape "trianglemesh" {QUAD}
+WorldEnd
+''')
+    m = [g.material for g in api.scenePrimitives]
+    assert [type(x).__name__ for x in m] == ["MirrorMaterial", "MirrorMaterial", "GlassMaterial", "GlassMaterial", "GlassMaterial"]
+    assert np.allclose(m[0].Kr, 0.9) and np.allclose(m[1].Kr, [0.5, 0.6, 0.7])          # mirror_material.dart:57-61
+    assert m[2].index == 1.33 and np.allclose(m[2].Kt, [0.9, 0.9, 1]) and np.allclose(m[2].Kr, 1.0)
+    assert m[3].index == 2.0 and np.allclose(m[3].Kr, 0.1) and np.allclose(m[3].Kt, [0.9, 0.9, 1])  # shape overrides
+    assert m[4].index == 1.5 and np.allclose(m[4].Kr, 1.0) and np.allclose(m[4].Kt, 1.0)    # glass_material.dart:71-78
 
 
 def test_malformed_input_is_rejected():
