@@ -82,8 +82,8 @@ class DrCamera(C.Structure):
 
 
 class DrFilm(C.Structure):
-    _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_float * 4),
-                ("filter_xw", C.c_float), ("filter_yw", C.c_float), ("filter_table", C.c_float * 256)]
+    _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_double * 4),
+                ("filter_xw", C.c_double), ("filter_yw", C.c_double), ("filter_table", C.c_float * 256)]
 
 
 class DrRenderDesc(C.Structure):

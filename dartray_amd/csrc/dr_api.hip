@@ -286,6 +286,10 @@ BatchState makeState(Workspace& w, const int2* pix, uint32_t nslots, bool useTai
 // border row/column of the sampler window (W+1 x H+1 for the box filter, image_film.dart:247-252)
 // is traced as the reference does; a border sample only reaches the film when imageX/Y is integral.
 void enumeratePixels(const RenderParams& rp, const DrRenderDesc* rd, std::vector<int2>& pixels) {
+  // NB the reference hands GetSubWindow's extents to the sampler as they are (dartray.dart:1009-1022): they are
+  // computed from 0 and ignore the sample extent's origin (common.dart:69-72), so a cropped film -- or a filter
+  // wider than half a pixel, whose extent starts at -1 -- samples the window [0, w) x [0, h) instead of
+  // [x0, x0 + w) x [y0, y0 + h).  Reproduced: the window is an input of the path.
   int ext[4];
   getSubWindow(rp.extW, rp.extH, rd->task_num, std::max(1, rd->task_count), ext);
   const int ts = rd->tile_size > 0 ? rd->tile_size : 32;
@@ -295,7 +299,7 @@ void enumeratePixels(const RenderParams& rp, const DrRenderDesc* rd, std::vector
   pixels.reserve((size_t)(ext[1] - ext[0]) * (ext[3] - ext[2]) / (tiled ? rd->tile_count : 1) + 1024);
   if (!tiled) {  // LinearPixelSampler order (linear_pixel_sampler.dart:29-40)
     for (int y = ext[2]; y < ext[3]; ++y)
-      for (int x = ext[0]; x < ext[1]; ++x) pixels.push_back(make_int2(rp.extX0 + x, rp.extY0 + y));
+      for (int x = ext[0]; x < ext[1]; ++x) pixels.push_back(make_int2(x, y));
   } else {  // tile-major so that a batch covers whole tiles (coherent camera rays)
     const int nty = (rp.extH + ts - 1) / ts;
     for (int ty = 0; ty < nty; ++ty)
@@ -303,7 +307,7 @@ void enumeratePixels(const RenderParams& rp, const DrRenderDesc* rd, std::vector
         if ((ty * ntx + tx) % rd->tile_count != rd->tile_rank) continue;
         for (int y = std::max(ty * ts, ext[2]); y < std::min((ty + 1) * ts, ext[3]); ++y)
           for (int x = std::max(tx * ts, ext[0]); x < std::min((tx + 1) * ts, ext[1]); ++x)
-            pixels.push_back(make_int2(rp.extX0 + x, rp.extY0 + y));
+            pixels.push_back(make_int2(x, y));
       }
   }
 }

@@ -168,9 +168,9 @@ typedef struct DrCamera {
 /* ImageFilm + Filter (lib/film/image_film.dart:51-97). */
 typedef struct DrFilm {
   int32_t xres, yres;
-  float crop[4];
-  float filter_xw, filter_yw;
-  float filter_table[256]; /* 16x16, image_film.dart:74-82 */
+  double crop[4];              /* cropWindow: Dart doubles (image_film.dart:61-65 rounds xres * crop up) */
+  double filter_xw, filter_yw; /* Filter.xWidth / yWidth (filter.dart:33-37), Dart doubles */
+  float filter_table[256];     /* 16x16, image_film.dart:74-82 */
 } DrFilm;
 
 #define DR_INTEGRATOR_DIRECT_ALL 0 /* DirectLightingIntegrator, strategy "all" (direct_lighting_integrator.dart) */

@@ -37,8 +37,8 @@ class OrcSceneDesc(C.Structure):
 
 
 class OrcRenderDesc(C.Structure):
-    _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_float * 4),
-                ("filter_xw", C.c_float), ("filter_yw", C.c_float), ("filter_table", C.c_float * 256),
+    _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_double * 4),
+                ("filter_xw", C.c_double), ("filter_yw", C.c_double), ("filter_table", C.c_float * 256),
                 ("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
                 ("lens_radius", C.c_float), ("focal_distance", C.c_float),
                 ("shutter_open", C.c_float), ("shutter_close", C.c_float),

@@ -1674,7 +1674,7 @@ struct Film {  // ImageFilm (image_film.dart:51-97)
   D fxw, fyw, invX, invY;
   float table[256];
   std::vector<float> Lxyz, weightSum;
-  void init(int xr, int yr, const float crop[4], D xw, D yw, const float* tbl) {
+  void init(int xr, int yr, const double crop[4], D xw, D yw, const float* tbl) {
     xres = xr; yres = yr;
     left = (int)std::ceil(xres * (D)crop[0]);
     width = std::max(1, (int)std::ceil(xres * (D)crop[1]) - left);
@@ -1878,8 +1878,8 @@ struct OrcHit {
 };
 struct OrcRenderDesc {
   int32_t xres, yres;
-  float crop[4];
-  float filter_xw, filter_yw;
+  double crop[4];                // cropWindow and the filter widths are Dart doubles
+  double filter_xw, filter_yw;
   float filter_table[256];
   float raster_to_camera[16], camera_to_world[16];
   float lens_radius, focal_distance, shutter_open, shutter_close;

@@ -88,6 +88,50 @@ def test_path_counter_mode_vs_oracle(ob, gpu, cfg):
         assert st[k] == c[k], k
 
 
+@pytest.mark.parametrize("spp", [1, 2, 512, 1024])
+def test_sample_counts_at_the_ends_of_the_range(ob, gpu, spp):
+    """spp 1 / 2 (degenerate LD blocks) and 512 / 1024 (the u16 permutation tables of k_gen_samples)."""
+    prims, mk = scenes.config("C2", xres=8, yres=6, spp=spp, blob=(16, 8))
+    r = mk()
+    out = r.render(scenes.make_scene(prims))
+    ref = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=1))
+    _check(out, ref)
+
+
+@pytest.mark.parametrize("crop,fw,res", [((0.25, 0.75, 0.5, 1.0), 0.5, (40, 24)), ((0.0, 1.0, 0.0, 1.0), 1.0, (17, 29)),
+                                          ((0.1, 0.33, 0.2, 0.9), 1.5, (31, 20))])
+def test_crop_windows_and_wide_box_filters(ob, gpu, crop, fw, res):
+    """ImageFilm crop windows (image_film.dart:61-65) and filters wider than a pixel: samples then spread over
+    several pixels (float atomics on the device: the sum order differs, so the film is compared to 1e-6).  The
+    reference samples the window [0,w) x [0,h) whatever the extent's origin: reproduced, so a
+    cropped image is only partly covered -- in the oracle and on the device alike."""
+    prims = scenes.cornell_prims(scenes.blob_prim(16, 8))
+    film = core.ImageFilm(res[0], res[1], core.BoxFilter(fw, fw), crop)
+    cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
+    r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 8), cam, core.PathIntegrator(3), core.EmissionIntegrator())
+    out = r.render(scenes.make_scene(prims))
+    ref = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=1))
+    assert out.rgb.shape == ref["rgb"].shape == (film.height, film.width, 3)
+    assert rel_err_image(out.rgb, ref["rgb"]).max() <= REL_TOL
+    assert np.allclose(out.film, ref["film"], rtol=1e-5, atol=1e-6)
+    if fw == 0.5:
+        assert np.array_equal(out.film, ref["film"])
+
+
+def test_c4_class_hairball(ob, gpu):
+    """BASELINE config 3 at reduced size: thin strands => deep, unbalanced tree, many leaf tests per ray."""
+    prims, mk = scenes.config("C4", xres=32, yres=32, spp=8, hair=(200, 40))
+    r = mk()
+    out = r.render(scenes.make_scene(prims))
+    osc = ob.OracleScene(prims)
+    osc.counters(reset=True)
+    ref = osc.render(ob.render_desc(r, sampler_mode=1))
+    _check(out, ref)
+    c, st = osc.counters(), r.last_stats
+    for k in ("closest_rays", "any_rays", "closest_nodes", "any_nodes", "closest_tris", "any_tris"):
+        assert st[k] == c[k], k
+
+
 @pytest.mark.parametrize("depth", [0, 1, 3, 4, 8])
 def test_path_max_depth(ob, gpu, depth):
     prims, mk = scenes.config("C2", xres=24, yres=24, spp=8, blob=(16, 8))
