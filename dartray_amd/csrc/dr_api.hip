@@ -572,21 +572,24 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         if (lt.v[0] == DR_PRIM_QUADRIC) {
           if (lt.v[1] >= desc->nquadrics) return bail(DR_ERR_INVALID, "light quadric index out of range");
           const DQuadric& q = sc->hostQuads[lt.v[1]];
-          if (q.kind != DR_QUADRIC_DISK)
-            return bail(DR_ERR_UNSUPPORTED, "sphere area lights (Sphere.sample2 cone sampling) are not on the path");
           memset(o.p, 0, sizeof(o.p));
           memcpy(&o.p[0], &lt.v[1], sizeof(uint32_t));
           o.reverse = (lt.reverse_orientation ? 1u : 0u) | ((uint32_t)q.kind << 8);
-          o.area = q.phiMax * 0.5 * (q.radius * q.radius - q.innerRadius * q.innerRadius);  // disk.dart:139-142
-          // Ns of Disk.sample (disk.dart:149-153): normalize(objectToWorld.transformNormal((0,0,1))), flipped
-          // when reverseOrientation; nn (the hit's dg.nn) depends on the hit point and is evaluated on the device
-          double n[3] = {(double)(float)q.w2o[8], (double)(float)q.w2o[9], (double)(float)q.w2o[10]};  // mInv^T * (0,0,1), stored f32
-          const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-          for (int k = 0; k < 3; ++k) {
-            float v = (float)(n[k] / len);
-            if (lt.reverse_orientation) v = (float)((double)v * -1.0);
-            o.ns[k] = v;
-            o.nn[k] = v;
+          if (q.kind == DR_QUADRIC_SPHERE) {
+            o.area = q.phiMax * q.radius * (q.zmax - q.zmin);  // sphere.dart:251-253
+            for (int k = 0; k < 3; ++k) o.ns[k] = o.nn[k] = 0.f;  // Sphere.sample2 computes Ns per sample
+          } else {
+            o.area = q.phiMax * 0.5 * (q.radius * q.radius - q.innerRadius * q.innerRadius);  // disk.dart:139-142
+            // Ns of Disk.sample (disk.dart:149-153): normalize(objectToWorld.transformNormal((0,0,1))), flipped
+            // when reverseOrientation; nn (the hit's dg.nn) depends on the hit point and is evaluated on the device
+            double n[3] = {(double)(float)q.w2o[8], (double)(float)q.w2o[9], (double)(float)q.w2o[10]};  // mInv^T * (0,0,1), stored f32
+            const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            for (int k = 0; k < 3; ++k) {
+              float v = (float)(n[k] / len);
+              if (lt.reverse_orientation) v = (float)((double)v * -1.0);
+              o.ns[k] = v;
+              o.nn[k] = v;
+            }
           }
           areas[t] = o.area;
           area += o.area;

@@ -402,6 +402,55 @@ DR_DEV double PowerHeuristic(double fPdf, double gPdf) {  // montecarlo.dart:480
   return (f * f) / (f * f + g * g);
 }
 
+// ---- Sphere as an area light (sphere.dart:255-326) -----------------------------
+DR_DEV F3 q_normal(const float* mInv, F3 n) {  // Transform.transformNormal: transpose of the inverse (transform.dart:147-161)
+  const double x = n.x, y = n.y, z = n.z;
+  return f3((double)mInv[0] * x + (double)mInv[4] * y + (double)mInv[8] * z, (double)mInv[1] * x + (double)mInv[5] * y + (double)mInv[9] * z,
+            (double)mInv[2] * x + (double)mInv[6] * y + (double)mInv[10] * z);
+}
+DR_DEV F3 sphere_sample(const DQuadric& q, double u1, double u2, F3* ns) {  // sphere.dart:255-267
+  const double z = 1.0 - 2.0 * u1;  // UniformSampleSphere (montecarlo.dart:113-120)
+  const double r = sqrt(fmax(0.0, 1.0 - z * z));
+  const double phi = 2.0 * DR_PI * u2;
+  const F3 us = f3(r * cos(phi), r * sin(phi), z);
+  const F3 p = vadd(F3{0.f, 0.f, 0.f}, vmul(us, q.radius));
+  F3 n = vnormalize(q_normal(q.w2o, p));
+  if (q.reverse) n = F3{-n.x, -n.y, -n.z};
+  *ns = n;
+  return q_point(q.o2w, p);
+}
+DR_DEV double sphere_cos_theta_max(const DQuadric& q, F3 p, F3 Pcenter) {
+  const double sinThetaMax2 = q.radius * q.radius / vlen2(vsub(Pcenter, p));
+  return sqrt(fmax(0.0, 1.0 - sinThetaMax2));
+}
+DR_DEV F3 sphere_sample2(const DQuadric& q, F3 p, double u1, double u2, F3* ns) {  // sphere.dart:269-311
+  const F3 Pcenter = q_point(q.o2w, F3{0.f, 0.f, 0.f});
+  const F3 wc = vnormalize(vsub(Pcenter, p));
+  F3 wcX;  // Vector.CoordinateSystem (vector.dart:198-214)
+  if (fabs((double)wc.x) > fabs((double)wc.y)) {
+    const double invLen = 1.0 / sqrt((double)wc.x * (double)wc.x + (double)wc.z * (double)wc.z);
+    wcX = f3(-(double)wc.z * invLen, 0.0, (double)wc.x * invLen);
+  } else {
+    const double invLen = 1.0 / sqrt((double)wc.y * (double)wc.y + (double)wc.z * (double)wc.z);
+    wcX = f3(0.0, (double)wc.z * invLen, -(double)wc.y * invLen);
+  }
+  const F3 wcY = vcross(wc, wcX);
+  if (vlen2(vsub(Pcenter, p)) - q.radius * q.radius < 1.0e-4) return sphere_sample(q, u1, u2, ns);
+  const double cosThetaMax = sphere_cos_theta_max(q, p, Pcenter);
+  const double costheta = cosThetaMax * (1.0 - u1) + 1.0 * u1;  // Lerp (common.dart:80-81)
+  const double sintheta = sqrt(1.0 - costheta * costheta);
+  const double phi = u2 * 2.0 * DR_PI;
+  const F3 d = vadd(vadd(vmul(wcX, cos(phi) * sintheta), vmul(wcY, sin(phi) * sintheta)), vmul(wc, costheta));
+  double thit;
+  F3 phit;
+  if (!quadric_hit(q, p, d, 1.0e-3, DR_INF, &thit, &phit)) thit = vdot(vsub(Pcenter, p), vnormalize(d));
+  const F3 ps = vadd(p, vmul(d, thit));
+  F3 n = vnormalize(vsub(ps, Pcenter));
+  if (q.reverse) n = F3{-n.x, -n.y, -n.z};
+  *ns = n;
+  return ps;
+}
+
 // ---- ShapeSet / DiffuseAreaLight ---------------------------------------------
 DR_DEV void ltri_verts(const DLightTri& t, F3* a, F3* b, F3* c) {
   *a = F3{t.p[0], t.p[1], t.p[2]};
@@ -435,19 +484,24 @@ DR_DEV F3 shapeset_sample(const DScene& sc, const DLight& L, double uPos0, doubl
   const DLightTri& lt = sc.ltris[L.first_tri + sn];
   F3 pt;
   if (QUAD && PRIM_KIND(lt.reverse)) {
-    // Disk.sample (disk.dart:144-155); Shape.sample2 defaults to it (shape.dart:96-98)
     const DQuadric& q = sc.quads[__float_as_uint(lt.p[0])];
-    double t0, t1;
-    ConcentricSampleDisk(uPos0, uPos1, &t0, &t1);
-    pt = q_point(q.o2w, f3(t0 * q.radius, t1 * q.radius, q.height));
+    if (q.kind == DR_QUADRIC_SPHERE) {
+      pt = sphere_sample2(q, p, uPos0, uPos1, Ns);
+    } else {
+      // Disk.sample (disk.dart:144-155); Shape.sample2 defaults to it (shape.dart:96-98)
+      double t0, t1;
+      ConcentricSampleDisk(uPos0, uPos1, &t0, &t1);
+      pt = q_point(q.o2w, f3(t0 * q.radius, t1 * q.radius, q.height));
+      *Ns = F3{lt.ns[0], lt.ns[1], lt.ns[2]};
+    }
   } else {
     ltri_verts(lt, &a, &b, &c);
     double su1 = sqrt(uPos0);  // UniformSampleTriangle montecarlo.dart:215-220
     double b1 = 1.0 - su1;
     double b2 = uPos1 * su1;
     pt = vadd(vadd(vmul(a, b1), vmul(b, b2)), vmul(c, (1.0 - b1 - b2)));
+    *Ns = F3{lt.ns[0], lt.ns[1], lt.ns[2]};
   }
-  *Ns = F3{lt.ns[0], lt.ns[1], lt.ns[2]};
   F3 rd = vsub(pt, p);
   double thit = 1.0;
   for (uint32_t i = 0; i < L.ntris; ++i) {
@@ -485,6 +539,14 @@ DR_DEV double shapeset_pdf(const DScene& sc, const DLight& L, F3 p, F3 wi) {
     F3 nn;
     if (QUAD && PRIM_KIND(t.reverse)) {
       const DQuadric& q = sc.quads[__float_as_uint(t.p[0])];
+      if (q.kind == DR_QUADRIC_SPHERE) {
+        // Sphere.pdf2 (sphere.dart:313-326): the subtended cone's solid angle unless p is inside the sphere
+        const F3 Pcenter = q_point(q.o2w, F3{0.f, 0.f, 0.f});
+        if (!(vlen2(vsub(Pcenter, p)) - q.radius * q.radius < 1.0e-4)) {
+          pdf += t.area * (1.0 / (2.0 * DR_PI * (1.0 - sphere_cos_theta_max(q, p, Pcenter))));  // UniformConePdf
+          continue;
+        }
+      }
       F3 phit;
       h = quadric_hit(q, p, wi, 1.0e-3, DR_INF, &th, &phit);
       if (h) {

@@ -724,9 +724,6 @@ class DartRay:
         if self.gs.areaLight:
             if self.gs.areaLight not in ("area", "diffuse"):
                 raise UnsupportedFeature(f"AreaLightSource \"{self.gs.areaLight}\"")
-            if isinstance(mesh, core.Sphere):
-                raise UnsupportedFeature("a sphere as an area light (Sphere.sample2 cone sampling, sphere.dart:267-311) "
-                                         "is not on the path; disks and triangle meshes are")
             lp = self.gs.areaLightParams      # diffuse_area_light.dart:91-97
             L = lp.findOneSpectrum("L", (1.0, 1.0, 1.0))
             sc = lp.findOneSpectrum("scale", (1.0, 1.0, 1.0))

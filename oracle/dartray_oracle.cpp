@@ -756,6 +756,52 @@ static V disk_sample(const Quadric& q, D u1, D u2, V* Ns) {
   *Ns = n;
   return xfPoint(q.o2w, p);
 }
+// Sphere.sample (sphere.dart:255-267)
+static V sphere_sample(const Quadric& q, D u1, D u2, V* ns) {
+  D z = 1.0 - 2.0 * u1;  // UniformSampleSphere (montecarlo.dart:113-120)
+  D r = std::sqrt(std::max(0.0, 1.0 - z * z));
+  D phi = 2.0 * M_PI * u2;
+  V us = vec(r * std::cos(phi), r * std::sin(phi), z);
+  V p = vadd(V{0, 0, 0}, vmul(us, q.radius));
+  V n = vnormalize(xfNormal(q.w2o, p));
+  if (q.reverse) n = V{-n.x, -n.y, -n.z};
+  *ns = n;
+  return xfPoint(q.o2w, p);
+}
+static inline D sphere_cos_theta_max(const Quadric& q, const V& p, const V& Pcenter) {
+  D sinThetaMax2 = q.radius * q.radius / vlen2(vsub(Pcenter, p));
+  return std::sqrt(std::max(0.0, 1.0 - sinThetaMax2));
+}
+// Sphere.sample2 (sphere.dart:269-311): uniform inside the cone the sphere subtends from p
+static V sphere_sample2(const Quadric& q, const V& p, D u1, D u2, V* ns) {
+  V Pcenter = xfPoint(q.o2w, V{0, 0, 0});
+  V wc = vnormalize(vsub(Pcenter, p));
+  V wcX, wcY;  // Vector.CoordinateSystem (vector.dart:198-214)
+  if (std::fabs(wc.x) > std::fabs(wc.y)) {
+    D invLen = 1.0 / std::sqrt(wc.x * wc.x + wc.z * wc.z);
+    wcX = vec(-wc.z * invLen, 0.0, wc.x * invLen);
+  } else {
+    D invLen = 1.0 / std::sqrt(wc.y * wc.y + wc.z * wc.z);
+    wcX = vec(0.0, wc.z * invLen, -wc.y * invLen);
+  }
+  wcY = vcross(wc, wcX);
+  if (vlen2(vsub(Pcenter, p)) - q.radius * q.radius < 1.0e-4) return sphere_sample(q, u1, u2, ns);
+  D cosThetaMax = sphere_cos_theta_max(q, p, Pcenter);
+  // UniformSampleCone2 (montecarlo.dart:135-142)
+  D costheta = cosThetaMax * (1.0 - u1) + 1.0 * u1;  // Lerp(u1, costhetamax, 1.0) (common.dart:80-81)
+  D sintheta = std::sqrt(1.0 - costheta * costheta);
+  D phi = u2 * 2.0 * M_PI;
+  V d = vadd(vadd(vmul(wcX, std::cos(phi) * sintheta), vmul(wcY, std::sin(phi) * sintheta)), vmul(wc, costheta));
+  Ray r{p, d, 1.0e-3, kInf, 0.0, 0};
+  D thit = 0.0, eps = 0.0;
+  DG dg;
+  if (!sphere_intersect(q, r, &thit, &eps, &dg)) thit = vdot(vsub(Pcenter, p), vnormalize(r.d));
+  V ps = pointAt(r, thit);
+  V n = vnormalize(vsub(ps, Pcenter));
+  if (q.reverse) n = V{-n.x, -n.y, -n.z};
+  *ns = n;
+  return ps;
+}
 // ---------------------------------------------------------------------------
 // BVHAccel build (accelerators/bvh_accel.dart:41-91,228-437)
 // ---------------------------------------------------------------------------
@@ -1143,7 +1189,8 @@ static V shapeset_sample(const Scene& sc, const Light& L, D uPos0, D uPos1, D uC
   const LightTri& lt = sc.lightTris[L.shapes[sn]];
   V pt;
   if (lt.quadric >= 0) {
-    pt = disk_sample(sc.quadrics[lt.quadric], uPos0, uPos1, Ns);
+    const Quadric& q = sc.quadrics[lt.quadric];
+    pt = q.kind == 1 ? sphere_sample2(q, p, uPos0, uPos1, Ns) : disk_sample(q, uPos0, uPos1, Ns);
   } else {
     lt_verts(sc, lt, &a, &b, &c);
     pt = tri_sample(a, b, c, lt.reverse, uPos0, uPos1, Ns);  // Shape.sample2 -> sample (shape.dart:96-98)
@@ -1177,6 +1224,15 @@ static D shapeset_pdf(const Scene& sc, const Light& L, const V& p, const V& wi) 
     Ray ray{p, wi, 1.0e-3, kInf, 0.0, -1};
     D thit = 0.0, rayEpsilon = 0.0;
     sc.ctr.light_tris++;
+    if (t.quadric >= 0 && sc.quadrics[t.quadric].kind == 1) {
+      // Sphere.pdf2 (sphere.dart:313-326): the cone's solid angle unless p is inside the sphere
+      const Quadric& q = sc.quadrics[t.quadric];
+      V Pcenter = xfPoint(q.o2w, V{0, 0, 0});
+      if (!(vlen2(vsub(Pcenter, p)) - q.radius * q.radius < 1.0e-4)) {
+        pdf += L.areas[i] * (1.0 / (2.0 * M_PI * (1.0 - sphere_cos_theta_max(q, p, Pcenter))));  // UniformConePdf
+        continue;
+      }
+    }
     const bool h = t.quadric >= 0 ? quadric_intersect(sc.quadrics[t.quadric], ray, &thit, &rayEpsilon, &dgLight)
                                   : tri_intersect(a, b, c, t.reverse, ray, &thit, &rayEpsilon, &dgLight);
     if (!h) {
@@ -1978,10 +2034,6 @@ void* orc_scene_create(const OrcSceneDesc* d) {
       int qi = (int)sc->quadrics.size();
       sc->quadrics.push_back(q);
       if (om.has_light) {
-        if (om.kind != 2) {  // Sphere.sample2 / pdf2 (cone sampling) are not restated
-          delete sc;
-          return nullptr;
-        }
         Light L;
         L.Lemit = rgb(om.L[0], om.L[1], om.L[2]);
         L.nSamples = std::max(1, om.light_nsamples);

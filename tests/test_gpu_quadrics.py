@@ -97,11 +97,50 @@ def test_disk_lights_and_spheres_render_like_the_oracle(ob, gpu, integ, ns):
     assert out.rgb.mean() > 0.05
 
 
-def test_sphere_area_light_is_refused_not_approximated(gpu):
-    with pytest.raises(pbrt.UnsupportedFeature):
-        pbrt.loads('WorldBegin\nAreaLightSource "area"\nShape "sphere" "float radius" 1\nWorldEnd')
-    t = pbrt.Transform()
-    gp = core.GeometricPrimitive(core.Sphere(t.m, t.mInv, False, 1.0), core.MatteMaterial(), core.DiffuseAreaLight((1, 1, 1), 1))
-    from dartray_amd import _abi
-    with pytest.raises(_abi.DartRayHipError):
-        scenes.make_scene([gp])._device()
+SPHERE_LIGHTS = '''
+Film "image" "integer xresolution" [40] "integer yresolution" [30]
+SurfaceIntegrator "{integ}" "integer maxdepth" [4]
+Sampler "lowdiscrepancy" "integer pixelsamples" [16]
+LookAt 0 0 -35 0 0 0 0 1 0
+Camera "perspective" "float fov" [35]
+WorldBegin
+AttributeBegin
+  AreaLightSource "area" "color L" [20 18 15] "integer nsamples" [{ns}]
+  Translate 3 5 0
+  Shape "sphere" "float radius" [1.5]
+AttributeEnd
+AttributeBegin
+  AreaLightSource "area" "color L" [4 8 16]
+  ReverseOrientation
+  Translate -5 -6 3  Rotate 35 1 1 0  Scale 1 1.4 0.8
+  Shape "sphere" "float radius" [2.5]
+AttributeEnd
+AttributeBegin
+  Material "matte" "color Kd" [0.75 0.75 0.75]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [10 -10 -10 -10 -10 -10 -10 -10 10 10 -10 10]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [10 -10 10 -10 -10 10 -10 10 10 10 10 10]
+  Material "matte" "color Kd" [0.48 0.1125 0.075]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-10 -10 10 -10 -10 -10 -10 10 -10 -10 10 10]
+  Translate 0 -8 -3
+  Shape "sphere" "float radius" [2]
+AttributeEnd
+WorldEnd
+'''
+
+
+@pytest.mark.parametrize("integ,ns", [("path", 1), ("directlighting", 1), ("directlighting", 2)])
+def test_sphere_area_lights_render_like_the_oracle(ob, gpu, integ, ns):
+    """Sphere.sample2 (cone sampling from outside, uniform sphere sampling from inside the reversed emitter's
+    hull is not reached here) and Sphere.pdf2 (sphere.dart:269-326) on the device."""
+    api = pbrt.loads(SPHERE_LIGHTS.format(integ=integ, ns=ns), render=True)
+    out, r = api.outputImage, api.rendererObject
+    osc = ob.OracleScene(api.scenePrimitives)
+    osc.counters(reset=True)
+    ref = osc.render(ob.render_desc(r, sampler_mode=1))
+    err = rel_err_image(out.rgb, ref["rgb"])
+    assert err.max() <= 1e-4, (err.max(), (err > 1e-4).sum())
+    assert np.array_equal(out.film, ref["film"])
+    c, st = osc.counters(), r.last_stats
+    for k in ("closest_rays", "any_rays", "closest_nodes", "any_nodes", "closest_tris", "any_tris"):
+        assert st[k] == c[k], k
+    assert out.rgb.mean() > 0.05

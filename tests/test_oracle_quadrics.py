@@ -133,3 +133,20 @@ def test_reverse_orientation_flips_the_emitting_side(ob):
         imgs.append(_render(ob, [floor, lamp], core.DirectLightingIntegrator(0, 5), spp=8, res=16))
     lit = [im[12:].mean() for im in imgs]   # bottom rows see the floor
     assert (lit[0] > 0.1) != (lit[1] > 0.1)
+
+
+@pytest.mark.parametrize("integ", [core.DirectLightingIntegrator(0, 5), core.PathIntegrator(1)])
+def test_spherical_emitter_irradiance_is_closed_form(ob, integ):
+    """A Lambertian spherical emitter of radius R whose centre is at distance d straight above a matte floor
+    point gives E = pi L (R/d)^2 there, so the floor's radiance is Kd L (R/d)^2: checks Sphere.sample2 /
+    pdf2 (cone sampling) and the MIS combination."""
+    R, d, L, kd = 1.0, 6.0, 50.0, 0.8
+    t = pbrt.Transform.Translate(0, d, 0)
+    lamp = core.GeometricPrimitive(core.Sphere(t.m, t.mInv, False, R), MAT, core.DiffuseAreaLight((L, L, L), 1))
+    floor = scenes._quad((-60, 0, -60), (-60, 0, 60), (60, 0, 60), (60, 0, -60), (kd, kd, kd))
+    film = core.ImageFilm(4, 4)
+    cam = core.PerspectiveCamera.lookAt((0.0, 3.0, -0.01), (0, 0, 0), (0, 0, 1), 0.5, film)   # looks at the floor point below
+    r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 256), cam, integ, core.EmissionIntegrator())
+    img = ob.OracleScene([floor, lamp]).render(ob.render_desc(r, sampler_mode=1))["rgb"]
+    expect = kd * L * (R / d) ** 2
+    assert abs(img.mean() / expect - 1.0) < 0.02, (img.mean(), expect)

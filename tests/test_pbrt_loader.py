@@ -176,7 +176,6 @@ def test_include_gz_and_relative_paths(tmp_path):
 
 @pytest.mark.parametrize("snippet,needle", [
     ('Shape "cylinder" "float radius" 3', 'Shape "cylinder"'),
-    ('AreaLightSource "area"\nShape "sphere" "float radius" [3]', "sphere as an area light"),
     ('Material "plastic"\nShape "trianglemesh" ' + QUAD, 'Material "plastic"'),
     ('Material "mirror" "texture Kr" "checks"\nShape "trianglemesh" ' + QUAD, "bound to a texture"),
     ('Material "matte" "float sigma" [20]\nShape "trianglemesh" ' + QUAD, "Oren-Nayar"),
