@@ -24,8 +24,8 @@ class DrBvhNode(C.Structure):
 
 
 class DrMaterial(C.Structure):
-    _fields_ = [("kd", C.c_float * 3), ("sigma", C.c_float), ("type", C.c_int32), ("kr", C.c_float * 3),
-                ("kt", C.c_float * 3), ("pad", C.c_float), ("index", C.c_double)]
+    _fields_ = [("type", C.c_int32), ("kd", C.c_float * 3), ("kr", C.c_float * 3), ("kt", C.c_float * 3),
+                ("sigma", C.c_double), ("index", C.c_double)]
 
 
 DR_MATERIAL_MATTE, DR_MATERIAL_MIRROR, DR_MATERIAL_GLASS = 0, 1, 2

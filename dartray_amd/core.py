@@ -361,7 +361,7 @@ class _DeviceScene:
             mats[i].type = getattr(m, "kind", _abi.DR_MATERIAL_MATTE)
             if mats[i].type == _abi.DR_MATERIAL_MATTE:
                 mats[i].kd[:] = [float(x) for x in m.Kd]
-                mats[i].sigma = m.sigma
+                mats[i].sigma = float(m.sigma)
             else:
                 mats[i].kr[:] = [float(x) for x in m.Kr]
                 if mats[i].type == _abi.DR_MATERIAL_GLASS:

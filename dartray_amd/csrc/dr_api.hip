@@ -83,6 +83,7 @@ struct DrScene {
   DevBuf<TraceCounters> ctr;
   uint32_t bvhDepth = 0;
   std::vector<int32_t> lightNSamples;
+  bool hasSpecular = false;  // some material is a mirror / glass
   // DirectLighting sample layout (direct_lighting_integrator.dart:70-87), fixed by the lights' nsamples
   DevBuf<LdBlock> dlBlocks;
   DevBuf<DirectStage> dlStages;
@@ -351,7 +352,6 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     return fail(DR_ERR_INVALID, "scene arrays missing");
   if (desc->ntris >= (1ull << 31) || desc->nnodes >= (1ull << 31)) return fail(DR_ERR_INVALID, "scene too large");
   for (uint32_t i = 0; i < desc->nmaterials; ++i) {
-    if (desc->materials[i].sigma != 0.0f) return fail(DR_ERR_UNSUPPORTED, "matte sigma != 0 (Oren-Nayar) is not on the path");
     if (desc->materials[i].type < DR_MATERIAL_MATTE || desc->materials[i].type > DR_MATERIAL_GLASS)
       return fail(DR_ERR_INVALID, "unknown material type");
   }
@@ -519,17 +519,18 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   }
   // materials
   {
-    // 4 x float4 per material: (Kd, sigma) (Kr, type) (Kt, -) (index: the double's low / high word, -, -)
+    // 4 x float4 per material: (Kd, -) (Kr, type) (Kt, -) (index, sigma: each double's low / high word)
     std::vector<float4> m(4 * (size_t)std::max<uint32_t>(desc->nmaterials, 1), make_float4(0.f, 0.f, 0.f, 0.f));
     auto bitsf = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
     for (uint32_t i = 0; i < desc->nmaterials; ++i) {
       const DrMaterial& a = desc->materials[i];
-      uint64_t ib;
+      uint64_t ib, sb;
       memcpy(&ib, &a.index, 8);
-      m[4 * i] = make_float4(a.kd[0], a.kd[1], a.kd[2], a.sigma);
+      memcpy(&sb, &a.sigma, 8);
+      m[4 * i] = make_float4(a.kd[0], a.kd[1], a.kd[2], 0.f);
       m[4 * i + 1] = make_float4(a.kr[0], a.kr[1], a.kr[2], bitsf((uint32_t)a.type));
       m[4 * i + 2] = make_float4(a.kt[0], a.kt[1], a.kt[2], 0.f);
-      m[4 * i + 3] = make_float4(bitsf((uint32_t)ib), bitsf((uint32_t)(ib >> 32)), 0.f, 0.f);
+      m[4 * i + 3] = make_float4(bitsf((uint32_t)ib), bitsf((uint32_t)(ib >> 32)), bitsf((uint32_t)sb), bitsf((uint32_t)(sb >> 32)));
     }
     TRY_SC(sc->mats.alloc(m.size()));
     TRY_SC(hipMemcpy(sc->mats.p, m.data(), m.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -722,6 +723,10 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   sc->d.hasSpec = 0;
   for (uint32_t i = 0; i < desc->nmaterials; ++i)
     if (desc->materials[i].type != DR_MATERIAL_MATTE) sc->d.hasSpec = 1;
+    else if (desc->materials[i].sigma != 0.0) sc->d.hasSpec = 1;  // Oren-Nayar: general shading kernels too
+  sc->hasSpecular = false;
+  for (uint32_t i = 0; i < desc->nmaterials; ++i)
+    if (desc->materials[i].type != DR_MATERIAL_MATTE) sc->hasSpecular = true;
   sc->d.nodes = sc->nodes.p;
   sc->d.tris = sc->tris.p;
   sc->d.mats = sc->mats.p;
@@ -827,7 +832,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (rd->integrator != DR_INTEGRATOR_PATH && rd->integrator != DR_INTEGRATOR_DIRECT_ALL)
     return fail(DR_ERR_INVALID, "unknown integrator");
   if (rd->max_depth < 0 || rd->max_depth > 64) return fail(DR_ERR_INVALID, "max_depth out of range");
-  if (rd->integrator == DR_INTEGRATOR_DIRECT_ALL && sc->d.hasSpec)
+  if (rd->integrator == DR_INTEGRATOR_DIRECT_ALL && sc->hasSpecular)
     return fail(DR_ERR_UNSUPPORTED, "DirectLighting recurses through SpecularReflect / SpecularTransmit (integrator.dart:187-290): "
                                     "mirror and glass are traced by the PathIntegrator only");
 

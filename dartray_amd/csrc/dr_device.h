@@ -137,7 +137,7 @@ struct DScene {
   int32_t hasEnv;
   const DQuadric* quads;  // spheres / disks; a primitive record with kind != 0 holds its index in q0.x
   uint32_t nquads;
-  uint32_t hasSpec;  // some material is a mirror / glass (general shading kernels)
+  uint32_t hasSpec;  // some material is not a plain Lambertian matte (general shading kernels)
 };
 
 // Primitive record flags (q2.w): bit 0 = Shape.reverseOrientation, bits 8.. = 0 triangle / DR_QUADRIC_*.
@@ -694,6 +694,8 @@ struct Bsdf {
   int mtype;
   C3 Kr, Kt;
   double ior;
+  bool on;       // the non-specular lobe is OrenNayar(R, sigma) with the coefficients below (oren_nayar.dart:24-32)
+  double onA, onB;
 };
 DR_DEV bool lambert_matches(int flags) { return (LAMBERT_TYPE & flags) == LAMBERT_TYPE; }
 DR_DEV C3 clamp0(float4 m) { return C3{m.x < 0.f ? 0.f : m.x, m.y < 0.f ? 0.f : m.y, m.z < 0.f ? 0.f : m.z}; }
@@ -711,11 +713,22 @@ DR_DEV Bsdf make_bsdf(const DScene& sc, const DGeo& dg, uint32_t mat) {
   b.R = r;
   b.nBxDFs = cblack(r) ? 0 : 1;
   b.mtype = DR_MATERIAL_MATTE;
+  b.on = false;
   if (GEN) {
-    const float4 m1 = mp[1];
+    const float4 m1 = mp[1], m3 = mp[3];
     b.mtype = (int)__float_as_uint(m1.w);
-    if (b.mtype != DR_MATERIAL_MATTE) {
-      const float4 m2 = mp[2], m3 = mp[3];
+    if (b.mtype == DR_MATERIAL_MATTE) {
+      double sig = __hiloint2double((int)__float_as_uint(m3.w), (int)__float_as_uint(m3.z));
+      sig = sig < 0.0 ? 0.0 : (sig > 90.0 ? 90.0 : sig);  // sigma.evaluate(dgs).clamp(0, 90) (matte_material.dart:55)
+      if (sig != 0.0) {
+        const double sigma = (DR_PI / 180.0) * sig;
+        const double sigma2 = sigma * sigma;
+        b.on = true;
+        b.onA = 1.0 - (sigma2 / (2.0 * (sigma2 + 0.33)));
+        b.onB = 0.45 * sigma2 / (sigma2 + 0.09);
+      }
+    } else {
+      const float4 m2 = mp[2];
       b.nBxDFs = 0;
       b.R = C3{0.f, 0.f, 0.f};
       b.Kr = clamp0(m1);
@@ -735,11 +748,35 @@ DR_DEV F3 bsdf_l2w(const Bsdf& b, F3 v) {                                       
 DR_DEV double lambert_pdf(F3 wo, F3 wi) {  // bxdf.dart:84-88
   return ((double)wo.z * (double)wi.z > 0.0) ? fabs((double)wi.z) * DR_INV_PI : 0.0;
 }
+// The diffuse lobe's f(wo, wi) in the local frame: Lambertian (lambertian.dart:35-37) or OrenNayar (oren_nayar.dart:34-60)
+DR_DEV double v_sin_theta(F3 v) { return sqrt(fmax(0.0, 1.0 - (double)v.z * (double)v.z)); }  // vector.dart:121-124
+DR_DEV C3 diffuse_f(const Bsdf& b, F3 wo, F3 wi) {
+  if (!b.on) return cmulD(b.R, DR_INV_PI);
+  const double sinthetai = v_sin_theta(wi), sinthetao = v_sin_theta(wo);
+  double maxcos = 0.0;
+  if (sinthetai > 1e-4 && sinthetao > 1e-4) {
+    // Vector.CosPhi / SinPhi (vector.dart:126-140); sintheta != 0 here
+    auto cl = [](double x) { return x < -1.0 ? -1.0 : (x > 1.0 ? 1.0 : x); };
+    const double cosphii = cl((double)wi.x / sinthetai), sinphii = cl((double)wi.y / sinthetai);
+    const double cosphio = cl((double)wo.x / sinthetao), sinphio = cl((double)wo.y / sinthetao);
+    const double dcos = cosphii * cosphio + sinphii * sinphio;
+    maxcos = fmax(0.0, dcos);
+  }
+  double sinalpha, tanbeta;
+  if (fabs((double)wi.z) > fabs((double)wo.z)) {
+    sinalpha = sinthetao;
+    tanbeta = sinthetai / fabs((double)wi.z);
+  } else {
+    sinalpha = sinthetai;
+    tanbeta = sinthetao / fabs((double)wo.z);
+  }
+  return cmulD(b.R, DR_INV_PI * (b.onA + b.onB * maxcos * sinalpha * tanbeta));
+}
 DR_DEV C3 bsdf_f(const Bsdf& b, F3 woW, F3 wiW, int flags) {  // bsdf.dart:187-211
   if (vdot(wiW, b.nn) * vdot(woW, b.nn) > 0) flags = flags & ~BSDF_TRANSMISSION;
   else flags = flags & ~BSDF_REFLECTION;
   C3 f = C3{0.f, 0.f, 0.f};
-  if (b.nBxDFs > 0 && lambert_matches(flags)) f = cadd(f, cmulD(b.R, DR_INV_PI));
+  if (b.nBxDFs > 0 && lambert_matches(flags)) f = cadd(f, b.on ? diffuse_f(b, bsdf_w2l(b, woW), bsdf_w2l(b, wiW)) : cmulD(b.R, DR_INV_PI));
   return f;
 }
 DR_DEV double bsdf_pdf(const Bsdf& b, F3 woW, F3 wiW, int flags) {  // bsdf.dart:135-156
@@ -769,7 +806,7 @@ DR_DEV C3 bsdf_sample_f(const Bsdf& b, F3 woW, F3* wiW, double uDir0, double uDi
   C3 f = C3{0.f, 0.f, 0.f};
   if (vdot(*wiW, b.nn) * vdot(woW, b.nn) > 0) flags = flags & ~BSDF_TRANSMISSION;
   else flags = flags & ~BSDF_REFLECTION;
-  if (lambert_matches(flags)) f = cadd(f, cmulD(b.R, DR_INV_PI));
+  if (lambert_matches(flags)) f = cadd(f, diffuse_f(b, wo, wi));
   return f;
 }
 // FresnelDielectric.evaluate (fresnel_dielectric.dart:30-64); the Spectrum it returns has three equal f32 channels

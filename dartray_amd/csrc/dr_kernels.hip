@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
           }
         }
         if (stage < nCalls) {
-          Bsdf bsdf = make_bsdf<false>(sc, dg, tr.mat);  // specular materials are refused for DirectLighting
+          Bsdf bsdf = make_bsdf<QUAD>(sc, dg, tr.mat);  // mirror / glass are refused for DirectLighting; Oren-Nayar is not
           const float* sv = st.sv;
           // sample slots of this call (direct_lighting_integrator.dart:70-87)
           double lsc = LDS_STREAM(sv + (size_t)cur.lc * cap + slot);
@@ -721,7 +721,7 @@ void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchStat
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
-  if (sc.nquads) hipLaunchKernelGGL(k_shade_direct<true>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
+  if (sc.nquads || sc.hasSpec) hipLaunchKernelGGL(k_shade_direct<true>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
   else hipLaunchKernelGGL(k_shade_direct<false>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,

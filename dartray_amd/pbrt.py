@@ -642,8 +642,6 @@ class DartRay:
             matParams.findOneSpectrum("Kd", (0.5, 0.5, 0.5))
         sigma = geomParams.findOneFloat("sigma", None) if geomParams.has("float", "sigma") else \
             matParams.findOneFloat("sigma", 0.0)
-        if sigma != 0.0:
-            raise UnsupportedFeature("matte sigma != 0 (Oren-Nayar) is not on the path")
         return core.MatteMaterial(kd, sigma)
 
     def _createMaterial(self, shapeParams):  # dartray.dart:780-804

@@ -52,13 +52,12 @@ typedef struct DrBvhNode {
 #define DR_MATERIAL_MIRROR 1 /* MirrorMaterial (mirror_material.dart:38-55): kr */
 #define DR_MATERIAL_GLASS 2  /* GlassMaterial (glass_material.dart:44-69): kr, kt, index */
 typedef struct DrMaterial {
-  float kd[3];
-  float sigma; /* must be 0 (Lambertian); Oren-Nayar is not on the path */
   int32_t type; /* DR_MATERIAL_*; specular materials are traced by the PathIntegrator only */
+  float kd[3];
   float kr[3];
   float kt[3];
-  float pad;
-  double index; /* the constant 'index' texture's value (a Dart double) */
+  double sigma; /* matte: 0 => Lambertian, else OrenNayar(Kd, sigma) (matte_material.dart:54-61); a Dart double */
+  double index; /* glass: the constant 'index' texture's value (a Dart double) */
 } DrMaterial;
 
 #define DR_LIGHT_DIFFUSE_AREA 0 /* DiffuseAreaLight (lib/lights/diffuse_area_light.dart) */

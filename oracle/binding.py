@@ -26,7 +26,8 @@ class OrcMesh(C.Structure):
                 ("Kd", C.c_float * 3), ("sigma", C.c_float), ("reverse_orientation", C.c_int32),
                 ("has_light", C.c_int32), ("L", C.c_float * 3), ("light_nsamples", C.c_int32),
                 ("kind", C.c_int32), ("o2w", C.c_float * 16), ("w2o", C.c_float * 16), ("params", C.c_double * 4),
-                ("mat_type", C.c_int32), ("Kr", C.c_float * 3), ("Kt", C.c_float * 3), ("ior", C.c_double)]
+                ("mat_type", C.c_int32), ("Kr", C.c_float * 3), ("Kt", C.c_float * 3), ("ior", C.c_double),
+                ("sigma_d", C.c_double)]
 
 
 class OrcSceneDesc(C.Structure):
@@ -147,7 +148,7 @@ class OracleScene:
             m.mat_type = mt
             if mt == 0:
                 m.Kd[:] = [float(x) for x in gp.material.Kd]
-                m.sigma = gp.material.sigma
+                m.sigma_d = float(gp.material.sigma)
             else:
                 m.Kr[:] = [float(x) for x in gp.material.Kr]
                 if mt == 2:

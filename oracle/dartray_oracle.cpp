@@ -1280,23 +1280,52 @@ static S fresnel_dielectric(D cosi, D eta_i, D eta_t) {
   return rgb(v, v, v);
 }
 struct BxDF {
-  int kind = 0;  // 0 Lambertian (lambertian.dart), 1 SpecularReflection, 2 SpecularTransmission
+  int kind = 0;  // 0 Lambertian (lambertian.dart), 1 SpecularReflection, 2 SpecularTransmission, 3 OrenNayar
+  D A = 0.0, B = 0.0;  // OrenNayar (oren_nayar.dart:24-32)
   int type = 0;  // BxDFType flags
   S R{0, 0, 0};  // reflectance / transmittance
   bool dielectric = false;  // SpecularReflection: FresnelDielectric(ei, et) instead of FresnelNoOp
   D ei = 1.0, et = 1.0;
   bool matches(int flags) const { return (type & flags) == type; }  // bxdf.dart:31-33
-  S f() const { return kind == 0 ? smulD(R, INV_PI) : S{0, 0, 0}; }  // lambertian.dart:35-37; specular_*.dart f() == 0
-  D pdf(const V& wo, const V& wi) const {                              // bxdf.dart:84-88; specular_*.dart pdf() == 0
-    if (kind != 0) return 0.0;
+  static D sinTheta(const V& v) { return std::sqrt(std::max(0.0, 1.0 - v.z * v.z)); }  // vector.dart:121-124
+  static D cosPhi(const V& v) {                                                          // vector.dart:126-132
+    D st = sinTheta(v);
+    return st == 0.0 ? 1.0 : clampD(v.x / st, -1.0, 1.0);
+  }
+  static D sinPhi(const V& v) {                                                          // vector.dart:134-140
+    D st = sinTheta(v);
+    return st == 0.0 ? 0.0 : clampD(v.y / st, -1.0, 1.0);
+  }
+  S f(const V& wo, const V& wi) const {
+    if (kind == 0) return smulD(R, INV_PI);  // lambertian.dart:35-37
+    if (kind != 3) return S{0, 0, 0};        // specular_*.dart: f() == 0
+    // oren_nayar.dart:34-60
+    D sinthetai = sinTheta(wi), sinthetao = sinTheta(wo);
+    D maxcos = 0.0;
+    if (sinthetai > 1e-4 && sinthetao > 1e-4) {
+      D dcos = cosPhi(wi) * cosPhi(wo) + sinPhi(wi) * sinPhi(wo);
+      maxcos = std::max(0.0, dcos);
+    }
+    D sinalpha, tanbeta;
+    if (std::fabs(wi.z) > std::fabs(wo.z)) {
+      sinalpha = sinthetao;
+      tanbeta = sinthetai / std::fabs(wi.z);
+    } else {
+      sinalpha = sinthetai;
+      tanbeta = sinthetao / std::fabs(wo.z);
+    }
+    return smulD(R, INV_PI * (A + B * maxcos * sinalpha * tanbeta));
+  }
+  D pdf(const V& wo, const V& wi) const {  // bxdf.dart:84-88; specular_*.dart pdf() == 0
+    if (kind == 1 || kind == 2) return 0.0;
     return (wo.z * wi.z > 0.0) ? std::fabs(wi.z) * INV_PI : 0.0;
   }
   S sample_f(const V& wo, V* wi, D u1, D u2, D* pdf) const {
-    if (kind == 0) {  // BxDF.sample_f (bxdf.dart:37-48)
+    if (kind == 0 || kind == 3) {  // BxDF.sample_f (bxdf.dart:37-48)
       *wi = CosineSampleHemisphere(u1, u2);
       if (wo.z < 0.0) wi->z *= -1.0;
       *pdf = this->pdf(wo, *wi);
-      return f();
+      return f(wo, *wi);
     }
     if (kind == 1) {  // specular_reflection.dart:33-41
       *wi = vec(-wo.x, -wo.y, wo.z);
@@ -1340,9 +1369,10 @@ struct BSDF {
   S f(const V& woW, const V& wiW, int flags) const {  // bsdf.dart:187-211
     if (vdot(wiW, ng) * vdot(woW, ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
     else flags = flags & ~BSDF_REFLECTION;
+    V wo = worldToLocal(woW), wi = worldToLocal(wiW);
     S f{0, 0, 0};
     for (int i = 0; i < nBxDFs; ++i)
-      if (bx[i].matches(flags)) f = sadd(f, bx[i].f());
+      if (bx[i].matches(flags)) f = sadd(f, bx[i].f(wo, wi));
     return f;
   }
   D pdf(const V& woW, const V& wiW, int flags) const {  // bsdf.dart:135-156
@@ -1393,7 +1423,7 @@ struct BSDF {
       if (vdot(*wiW, ng) * vdot(woW, ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
       else flags = flags & ~BSDF_REFLECTION;
       for (int i = 0; i < nBxDFs; ++i)
-        if (bx[i].matches(flags)) f = sadd(f, bx[i].f());
+        if (bx[i].matches(flags)) f = sadd(f, bx[i].f(wo, wi));
     }
     return f;
   }
@@ -1410,13 +1440,21 @@ static BSDF make_bsdf(const Scene& sc, const Isect& is) {
   b.sn = vnormalize(is.dg.dpdu);   // bsdf.dart:45-51
   b.tn = vcross(b.nn, b.sn);
   auto clampS = [](const S& c) { return rgb(clampD(c.r, 0.0, kInf), clampD(c.g, 0.0, kInf), clampD(c.b, 0.0, kInf)); };
-  if (m.matType == 0) {  // matte_material.dart:41-65 (sigma == 0: Lambertian)
+  if (m.matType == 0) {  // matte_material.dart:41-65
     S r = clampS(m.Kd);
+    D sig = clampD(m.sigma, 0.0, 90.0);
     if (!sblack(r)) {
       BxDF x;
       x.kind = 0;
       x.type = BSDF_REFLECTION | BSDF_DIFFUSE;
       x.R = r;
+      if (sig != 0.0) {  // OrenNayar(r, sig) (oren_nayar.dart:24-32)
+        x.kind = 3;
+        D sigma = (M_PI / 180.0) * sig;
+        D sigma2 = sigma * sigma;
+        x.A = 1.0 - (sigma2 / (2.0 * (sigma2 + 0.33)));
+        x.B = 0.45 * sigma2 / (sigma2 + 0.09);
+      }
       b.add(x);
     }
   } else if (m.matType == 1) {  // mirror_material.dart:38-55
@@ -1901,6 +1939,7 @@ struct OrcMesh {
   int32_t mat_type;
   float Kr[3], Kt[3];
   double ior;
+  double sigma_d;  // matte 'sigma' as the Dart double it is (the f32 field above is ignored)
 };
 struct OrcSceneDesc {
   int32_t nmeshes;
@@ -2000,7 +2039,7 @@ void* orc_scene_create(const OrcSceneDesc* d) {
     uint32_t base = (uint32_t)(sc->P.size() / 3);
     Mesh me;
     me.Kd = rgb(om.Kd[0], om.Kd[1], om.Kd[2]);
-    me.sigma = om.sigma;
+    me.sigma = om.sigma_d;
     me.reverse = om.reverse_orientation != 0;
     me.light = -1;
     me.matType = om.mat_type;

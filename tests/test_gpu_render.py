@@ -278,10 +278,23 @@ def test_invalid_arguments_raise(gpu):
     r.sampler.samplesPerPixel = 3  # not a power of two
     with pytest.raises(_abi.DartRayHipError):
         r.render(scene)
-    with pytest.raises(_abi.DartRayHipError):  # Oren-Nayar is not on the path
-        bad = scenes.cornell_c1_prims()
-        bad[0].material = core.MatteMaterial((0.5, 0.5, 0.5), sigma=20.0)
-        mk().render(scenes.make_scene(bad))
+
+
+@pytest.mark.parametrize("integ", [core.PathIntegrator(4), core.DirectLightingIntegrator(0, 5)])
+def test_oren_nayar_matte(ob, gpu, integ):
+    """MatteMaterial with sigma != 0 adds OrenNayar(Kd, sigma) instead of Lambertian (matte_material.dart:54-61,
+    oren_nayar.dart); sigma is clamped to [0, 90] degrees."""
+    prims = scenes.cornell_prims(scenes.blob_prim(16, 8))
+    for gp, sig in zip(prims, [20.0, 0.0, 55.5, 120.0, 0.3, 5.0, 90.0, 33.0, 1.0]):
+        gp.material = core.MatteMaterial(tuple(gp.material.Kd), sigma=sig)
+    film = core.ImageFilm(32, 24)
+    cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
+    r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 16), cam, integ, core.EmissionIntegrator())
+    out = r.render(scenes.make_scene(prims))
+    ref = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=1))
+    _check(out, ref)
+    lam = [core.GeometricPrimitive(gp.shape, core.MatteMaterial(tuple(gp.material.Kd)), gp.areaLight) for gp in prims]
+    assert not np.array_equal(ob.OracleScene(lam).render(ob.render_desc(r, sampler_mode=1))["film"], ref["film"])
 
 
 def test_full_size_c2_properties_and_sparse_parity(ob, gpu):

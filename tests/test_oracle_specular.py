@@ -95,3 +95,23 @@ def test_direct_lighting_refuses_specular_materials(ob):
     floor = _quad((-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50), core.MirrorMaterial())
     with pytest.raises(RuntimeError):
         _render(ob, [floor, EMIT((1, 1, 1))], core.DirectLightingIntegrator(0, 5), (0, 5, -5), (0, 0, 0))
+
+
+def test_oren_nayar_known_values(ob):
+    """OrenNayar (oren_nayar.dart): at sigma -> 0 it tends to the Lambertian; with wo = wi = the normal the model
+    reduces to R/pi * A, A = 1 - sigma^2 / (2 (sigma^2 + 0.33)).  A matte floor under a large uniform emitter seen
+    from straight above: L = R * Le * (A + B * <maxcos sin(alpha) tan(beta)>) with the B term vanishing for wo
+    along the normal (sin(theta_o) = 0 => sinalpha = 0 or tanbeta = 0)."""
+    import math
+    Le, kd = 2.0, 0.6
+    imgs = {}
+    for sig in (0.0, 1e-6, 30.0, 90.0, 200.0):
+        floor = _quad((-2000, 0, -2000), (-2000, 0, 2000), (2000, 0, 2000), (2000, 0, -2000), core.MatteMaterial((kd, kd, kd), sigma=sig))
+        emit = _quad((-2000, 10, -2000), (2000, 10, -2000), (2000, 10, 2000), (-2000, 10, 2000), BLACK, core.DiffuseAreaLight((Le, Le, Le), 1))
+        imgs[sig] = _render(ob, [floor, emit], core.DirectLightingIntegrator(0, 5), (0, 5, 0), (0, 0, 0), spp=256, res=4, fov=1.0).mean()
+    A = lambda deg: 1.0 - (math.radians(deg) ** 2) / (2.0 * (math.radians(deg) ** 2 + 0.33))
+    assert abs(imgs[0.0] / (kd * Le) - 1.0) < 0.02                       # Lambertian under a (nearly) full hemisphere
+    assert abs(imgs[1e-6] / imgs[0.0] - 1.0) < 1e-6
+    assert abs(imgs[30.0] / imgs[0.0] - A(30.0)) < 0.01
+    assert abs(imgs[90.0] / imgs[0.0] - A(90.0)) < 0.01
+    assert imgs[200.0] == imgs[90.0]                                     # clamp(0, 90) (matte_material.dart:55)

@@ -178,7 +178,6 @@ def test_include_gz_and_relative_paths(tmp_path):
     ('Shape "cylinder" "float radius" 3', 'Shape "cylinder"'),
     ('Material "plastic"\nShape "trianglemesh" ' + QUAD, 'Material "plastic"'),
     ('Material "mirror" "texture Kr" "checks"\nShape "trianglemesh" ' + QUAD, "bound to a texture"),
-    ('Material "matte" "float sigma" [20]\nShape "trianglemesh" ' + QUAD, "Oren-Nayar"),
     ('Texture "t" "color" "imagemap" "string filename" "x.png"', "Texture"),
     ('LightSource "point" "color I" [1 1 1]', 'LightSource "point"'),
     ('LightSource "infinite" "string mapname" ["sky.exr"]', "image decoders"),
