@@ -54,6 +54,13 @@ class DrQuadric(C.Structure):
                 ("world_to_object", C.c_float * 16), ("params", C.c_double * 4)]
 
 
+class DrMeshXform(C.Structure):
+    _fields_ = [("object_to_world", C.c_float * 16), ("world_to_object", C.c_float * 16)]
+
+
+DR_SHADING_N, DR_SHADING_S, DR_SHADING_UV = 1, 2, 4
+
+
 class DrSceneDesc(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("nnodes", C.c_uint64),
                 ("verts", C.c_void_p), ("nverts", C.c_uint64),
@@ -64,7 +71,10 @@ class DrSceneDesc(C.Structure):
                 ("light_tris", C.c_void_p), ("nlight_tris", C.c_uint32),
                 ("bvh_depth", C.c_uint32),
                 ("env_maps", C.c_void_p), ("nenv_maps", C.c_uint32),
-                ("quadrics", C.c_void_p), ("nquadrics", C.c_uint32)]
+                ("quadrics", C.c_void_p), ("nquadrics", C.c_uint32),
+                ("vert_normals", C.c_void_p), ("vert_tangents", C.c_void_p), ("vert_uvs", C.c_void_p),
+                ("tri_shading", C.c_void_p), ("tri_xform", C.c_void_p), ("mesh_xforms", C.c_void_p),
+                ("nmesh_xforms", C.c_uint32)]
 
 
 class DrRay(C.Structure):

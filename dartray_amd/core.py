@@ -29,12 +29,24 @@ from ._abi import DartRayHipError  # noqa: F401  (re-export)
 # ---------------------------------------------------------------------------
 class TriangleMesh:
     """shapes/triangle_mesh.dart:23-36.  P is already in world space (the
-    reference pre-transforms vertices to world space, f32)."""
+    reference pre-transforms vertices to world space, f32).  Optional per-vertex shading data: `n` (normals)
+    and `s` (tangents) stay in OBJECT space and are transformed by objectToWorld at shading time
+    (triangle.dart:303-317), so a mesh that has them also carries its transform; `uvs` [nverts,2] replace the
+    default (0,0),(1,0),(1,1) parametrisation (triangle.dart:247-263)."""
 
-    def __init__(self, vertexIndex, P, reverseOrientation=False):
+    def __init__(self, vertexIndex, P, reverseOrientation=False, n=None, s=None, uvs=None, objectToWorld=None,
+                 worldToObject=None):
         self.vertexIndex = np.ascontiguousarray(vertexIndex, dtype=np.uint32).reshape(-1, 3)
         self.P = np.ascontiguousarray(P, dtype=np.float32).reshape(-1, 3)
         self.reverseOrientation = bool(reverseOrientation)
+        nv = len(self.P)
+        self.n = None if n is None else np.ascontiguousarray(n, dtype=np.float32).reshape(nv, 3)
+        self.s = None if s is None else np.ascontiguousarray(s, dtype=np.float32).reshape(nv, 3)
+        self.uvs = None if uvs is None else np.ascontiguousarray(uvs, dtype=np.float32).reshape(-1)[:2 * nv].reshape(nv, 2)
+        eye = np.eye(4, dtype=np.float32)
+        self.objectToWorld = eye if objectToWorld is None else np.ascontiguousarray(np.asarray(objectToWorld, np.float32).reshape(4, 4))
+        self.worldToObject = (eye if objectToWorld is None else _inv(self.objectToWorld)) if worldToObject is None else \
+            np.ascontiguousarray(np.asarray(worldToObject, np.float32).reshape(4, 4))
         if self.vertexIndex.size and int(self.vertexIndex.max()) >= len(self.P):
             raise ValueError("TriangleMesh has out of-bounds vertex index")  # triangle_mesh.dart:160-166
 
@@ -253,6 +265,8 @@ class BVHAccel:
         self.maxPrimsInNode = min(255, int(maxPrims))
         self.prims_in = list(p)
         verts, tri, mat, lightOf, rev = [], [], [], [], []
+        vn, vs, vuv, shade, xform = [], [], [], [], []  # optional per-vertex shading data (triangle_mesh.dart:195-203)
+        self.mesh_xforms = []
         base = 0
         self.materials = []
         self._lights = []  # DiffuseAreaLight objects in first-seen order
@@ -266,6 +280,7 @@ class BVHAccel:
                 if gp.areaLight not in self._lights:
                     self._lights.append(gp.areaLight)
                 li = self._lights.index(gp.areaLight)
+            sflags, xf = 0, 0
             if isinstance(mesh, _Quadric):
                 tri.append(np.array([[_abi.DR_PRIM_QUADRIC, len(self.quadrics), 0]], dtype=np.uint32))
                 self.quadrics.append(mesh)
@@ -276,6 +291,17 @@ class BVHAccel:
                 tri.append(mesh.vertexIndex[order].astype(np.uint32) + np.uint32(base))
                 base += len(mesh.P)
                 nprim = len(order)
+                n, s, uv = (getattr(mesh, a, None) for a in ("n", "s", "uvs"))
+                sflags = (_abi.DR_SHADING_N if n is not None else 0) | (_abi.DR_SHADING_S if s is not None else 0) | \
+                    (_abi.DR_SHADING_UV if uv is not None else 0)
+                vn.append(n if n is not None else np.zeros((len(mesh.P), 3), np.float32))
+                vs.append(s if s is not None else np.zeros((len(mesh.P), 3), np.float32))
+                vuv.append(uv if uv is not None else np.zeros((len(mesh.P), 2), np.float32))
+                if sflags & (_abi.DR_SHADING_N | _abi.DR_SHADING_S):
+                    xf = len(self.mesh_xforms)
+                    self.mesh_xforms.append((mesh.objectToWorld, mesh.worldToObject))
+            shade.append(np.full(nprim, sflags, dtype=np.uint8))
+            xform.append(np.full(nprim, xf, dtype=np.uint32))
             mat.append(np.full(nprim, mid, dtype=np.uint32))
             lightOf.append(np.full(nprim, li, dtype=np.int32))
             rev.append(np.full(nprim, 1 if mesh.reverseOrientation else 0, dtype=np.uint8))
@@ -284,6 +310,13 @@ class BVHAccel:
         mat = np.concatenate(mat) if mat else np.zeros(0, np.uint32)
         lightOf = np.concatenate(lightOf) if lightOf else np.zeros(0, np.int32)
         rev = np.concatenate(rev) if rev else np.zeros(0, np.uint8)
+        shade = np.concatenate(shade) if shade else np.zeros(0, np.uint8)
+        xform = np.concatenate(xform) if xform else np.zeros(0, np.uint32)
+        self.has_shading = bool(shade.any())
+        if self.has_shading:
+            self.vert_normals = np.ascontiguousarray(np.concatenate(vn), np.float32)
+            self.vert_tangents = np.ascontiguousarray(np.concatenate(vs), np.float32)
+            self.vert_uvs = np.ascontiguousarray(np.concatenate(vuv), np.float32)
         n = len(refined)
         lib = _abi.lib()
         nodes = np.zeros(max(2 * n - 1, 1), dtype=NODE_DTYPE)
@@ -306,6 +339,8 @@ class BVHAccel:
         self.tri_material = np.ascontiguousarray(mat[order])
         self.tri_light = np.ascontiguousarray(lightOf[order])
         self.tri_reverse = np.ascontiguousarray(rev[order])
+        self.tri_shading = np.ascontiguousarray(shade[order])
+        self.tri_xform = np.ascontiguousarray(xform[order])
         self._scene = None
 
     @staticmethod
@@ -397,9 +432,10 @@ class _DeviceScene:
             if isinstance(mesh, _Quadric):  # ShapeSet keeps an intersectable shape whole (shape_set.dart:25-35)
                 ltris.append((_abi.DR_PRIM_QUADRIC, quad_of[id(mesh)], 0, 1 if mesh.reverseOrientation else 0))
             else:
+                lflags = (1 if mesh.reverseOrientation else 0) | (2 if getattr(mesh, "uvs", None) is not None else 0)
                 for t in mesh.refine():
                     v = mesh.vertexIndex[t] + base_of[id(mesh)]
-                    ltris.append((int(v[0]), int(v[1]), int(v[2]), 1 if mesh.reverseOrientation else 0))
+                    ltris.append((int(v[0]), int(v[1]), int(v[2]), lflags))
             dl[i].L[:] = [float(x) for x in L.Lemit]
             dl[i].nsamples = L.nSamples
             dl[i].first_tri = first
@@ -421,7 +457,19 @@ class _DeviceScene:
             qa[i].params[:] = [float(v) for v in q.params]
         d.quadrics = C.cast(qa, C.c_void_p)
         d.nquadrics = len(accel.quadrics)
-        self._keep = (mats, dl, lt, env_arr, qa)
+        xa = (_abi.DrMeshXform * max(len(accel.mesh_xforms), 1))()
+        if accel.has_shading:
+            for i, (o2w, w2o) in enumerate(accel.mesh_xforms):
+                xa[i].object_to_world[:] = [float(v) for v in np.asarray(o2w, np.float32).reshape(-1)]
+                xa[i].world_to_object[:] = [float(v) for v in np.asarray(w2o, np.float32).reshape(-1)]
+            d.vert_normals = accel.vert_normals.ctypes.data
+            d.vert_tangents = accel.vert_tangents.ctypes.data
+            d.vert_uvs = accel.vert_uvs.ctypes.data
+            d.tri_shading = accel.tri_shading.ctypes.data
+            d.tri_xform = accel.tri_xform.ctypes.data
+            d.mesh_xforms = C.cast(xa, C.c_void_p)
+            d.nmesh_xforms = len(accel.mesh_xforms)
+        self._keep = (mats, dl, lt, env_arr, qa, xa)
         d.nodes = accel.nodes.ctypes.data if accel.nodes is not None else None
         d.nnodes = len(accel.nodes) if accel.nodes is not None else 0
         d.verts = accel.verts.ctypes.data

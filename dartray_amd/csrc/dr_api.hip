@@ -78,6 +78,8 @@ struct DrScene {
   DevBuf<DLightTri> ltris;
   DevBuf<DQuadric> quads;
   std::vector<DQuadric> hostQuads;
+  DevBuf<float4> srec;
+  DevBuf<float> xforms;
   DevBuf<float> lcdf;
   DevBuf<float> envTexels, envCondFunc, envCondCdf, envCondInt, envMargFunc, envMargCdf;
   DevBuf<TraceCounters> ctr;
@@ -132,14 +134,40 @@ double host_tri_area(const float* a, const float* b, const float* c) {
 // DifferentialGeometry.nn of a hit on triangle (a,b,c) with the default UVs (triangle.dart:100-132,
 // differential_geometry.dart:84-99) and the normal Triangle.sample returns (triangle.dart:376-381);
 // the same f64-expression / f32-store arithmetic as tri_dg() in dr_device.h.
-void host_tri_normals(const float* a, const float* b, const float* c, bool reverse, float nn[3], float ns[3]) {
-  const double du1 = 0.0 - 1.0, du2 = 1.0 - 1.0, dv1 = 0.0 - 1.0, dv2 = 0.0 - 1.0;
-  const double invdet = 1.0 / (du1 * dv2 - dv1 * du2);
+void host_tri_normals(const float* a, const float* b, const float* c, bool reverse, float nn[3], float ns[3],
+                      const float* uv = nullptr) {
+  static const float kDefaultUV[6] = {0.f, 0.f, 1.f, 0.f, 1.f, 1.f};  // triangle.dart:255-262
+  if (!uv) uv = kDefaultUV;
+  const double du1 = (double)uv[0] - (double)uv[4], du2 = (double)uv[2] - (double)uv[4];
+  const double dv1 = (double)uv[1] - (double)uv[5], dv2 = (double)uv[3] - (double)uv[5];
+  const double determinant = du1 * dv2 - dv1 * du2;
   double dpdu[3], dpdv[3];
-  for (int k = 0; k < 3; ++k) {
-    const double dp1 = r32((double)a[k] - (double)c[k]), dp2 = r32((double)b[k] - (double)c[k]);
-    dpdu[k] = r32(r32(r32(dp1 * dv2) - r32(dp2 * dv1)) * invdet);
-    dpdv[k] = r32(r32(r32(dp1 * -du2) + r32(dp2 * du1)) * invdet);
+  if (determinant == 0.0) {  // degenerate uv mapping: Vector.CoordinateSystem on the face normal (triangle.dart:108-127)
+    double e1[3], e2[3];
+    for (int k = 0; k < 3; ++k) {
+      e1[k] = (double)b[k] - (double)a[k];
+      e2[k] = (double)c[k] - (double)a[k];
+    }
+    const double e3x = (e2[1] * e1[2]) - (e2[2] * e1[1]), e3y = (e2[2] * e1[0]) - (e2[0] * e1[2]), e3z = (e2[0] * e1[1]) - (e2[1] * e1[0]);
+    const double len = std::sqrt(e3x * e3x + e3y * e3y + e3z * e3z);
+    const double v1[3] = {r32(e3x / len), r32(e3y / len), r32(e3z / len)};
+    if (std::fabs(v1[0]) > std::fabs(v1[1])) {
+      const double invLen = 1.0 / std::sqrt(v1[0] * v1[0] + v1[2] * v1[2]);
+      dpdu[0] = r32(-v1[2] * invLen); dpdu[1] = 0.0; dpdu[2] = r32(v1[0] * invLen);
+    } else {
+      const double invLen = 1.0 / std::sqrt(v1[1] * v1[1] + v1[2] * v1[2]);
+      dpdu[0] = 0.0; dpdu[1] = r32(v1[2] * invLen); dpdu[2] = r32(-v1[1] * invLen);
+    }
+    dpdv[0] = r32(v1[1] * dpdu[2] - v1[2] * dpdu[1]);
+    dpdv[1] = r32(v1[2] * dpdu[0] - v1[0] * dpdu[2]);
+    dpdv[2] = r32(v1[0] * dpdu[1] - v1[1] * dpdu[0]);
+  } else {
+    const double invdet = 1.0 / determinant;
+    for (int k = 0; k < 3; ++k) {
+      const double dp1 = r32((double)a[k] - (double)c[k]), dp2 = r32((double)b[k] - (double)c[k]);
+      dpdu[k] = r32(r32(r32(dp1 * dv2) - r32(dp2 * dv1)) * invdet);
+      dpdv[k] = r32(r32(r32(dp1 * -du2) + r32(dp2 * du1)) * invdet);
+    }
   }
   auto crossNorm = [](const double* u, const double* v, double out[3]) {
     const double cx = r32(u[1] * v[2] - u[2] * v[1]), cy = r32(u[2] * v[0] - u[0] * v[2]), cz = r32(u[0] * v[1] - u[1] * v[0]);
@@ -246,7 +274,7 @@ int allocWorkspace(DrScene* sc, uint32_t cap, int nFloats, int maxTail, bool nee
     w.cap = c;
     w.nFloats = nf;
   }
-  if (!sc->hostQuads.empty() && w.ro0.n < 3 * (size_t)w.cap) HIP_TRY(w.ro0.alloc(3 * (size_t)w.cap));
+  if ((!sc->hostQuads.empty() || sc->d.srec) && w.ro0.n < 3 * (size_t)w.cap) HIP_TRY(w.ro0.alloc(3 * (size_t)w.cap));
   if (needTail && ((size_t)w.cap * maxTail > w.tail.n)) HIP_TRY(w.tail.alloc((size_t)w.cap * maxTail));
   w.maxTail = maxTail;
   HIP_TRY(w.counters.alloc(N_COUNTERS));
@@ -517,6 +545,57 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     launch_gather_tris(dV.p, dI.p, dM.p, dL.p, dR.p, sc->tris.p, desc->ntris, 0);
     TRY_SC(hipDeviceSynchronize());
   }
+  // per-primitive shading records of meshes with N / S / uv (see ShadeRec in dr_device.h)
+  sc->d.srec = nullptr;
+  sc->d.xforms = nullptr;
+  if (desc->tri_shading && desc->ntris) {
+    bool any = false;
+    for (uint64_t i = 0; i < desc->ntris; ++i)
+      if (desc->tri_shading[i] && desc->tri_idx[3 * i] != DR_PRIM_QUADRIC) any = true;
+    if (any) {
+      std::vector<float> R(28 * (size_t)desc->ntris, 0.f);
+      for (uint64_t i = 0; i < desc->ntris; ++i) {
+        const uint32_t f = desc->tri_shading[i];
+        if (!f || desc->tri_idx[3 * i] == DR_PRIM_QUADRIC) continue;
+        if (f > 7u) return bail(DR_ERR_INVALID, "unknown tri_shading bits");
+        if (((f & DR_SHADING_N) && !desc->vert_normals) || ((f & DR_SHADING_S) && !desc->vert_tangents) ||
+            ((f & DR_SHADING_UV) && !desc->vert_uvs))
+          return bail(DR_ERR_INVALID, "tri_shading names an attribute whose vertex array is missing");
+        uint32_t xf = 0;
+        if (f & (DR_SHADING_N | DR_SHADING_S)) {
+          if (!desc->tri_xform || !desc->mesh_xforms || desc->tri_xform[i] >= desc->nmesh_xforms)
+            return bail(DR_ERR_INVALID, "per-vertex normals / tangents need their mesh transform");
+          xf = desc->tri_xform[i];
+        }
+        float* r = &R[28 * (size_t)i];
+        for (int k = 0; k < 3; ++k) {
+          const size_t v = desc->tri_idx[3 * i + k];
+          for (int c = 0; c < 3; ++c) {
+            if (f & DR_SHADING_N) r[3 * k + c] = desc->vert_normals[3 * v + c];
+            if (f & DR_SHADING_S) r[9 + 3 * k + c] = desc->vert_tangents[3 * v + c];
+          }
+          if (f & DR_SHADING_UV) {
+            r[18 + 2 * k] = desc->vert_uvs[2 * v];
+            r[18 + 2 * k + 1] = desc->vert_uvs[2 * v + 1];
+          }
+        }
+        memcpy(&r[24], &f, 4);
+        memcpy(&r[25], &xf, 4);
+      }
+      TRY_SC(sc->srec.alloc(7 * (size_t)desc->ntris));
+      TRY_SC(hipMemcpy(sc->srec.p, R.data(), R.size() * sizeof(float), hipMemcpyHostToDevice));
+      sc->d.srec = sc->srec.p;
+      std::vector<float> X(24 * (size_t)std::max<uint32_t>(desc->nmesh_xforms, 1), 0.f);
+      for (uint32_t i = 0; i < desc->nmesh_xforms; ++i)
+        for (int k = 0; k < 12; ++k) {
+          X[24 * (size_t)i + k] = desc->mesh_xforms[i].object_to_world[k];
+          X[24 * (size_t)i + 12 + k] = desc->mesh_xforms[i].world_to_object[k];
+        }
+      TRY_SC(sc->xforms.alloc(X.size()));
+      TRY_SC(hipMemcpy(sc->xforms.p, X.data(), X.size() * sizeof(float), hipMemcpyHostToDevice));
+      sc->d.xforms = sc->xforms.p;
+    }
+  }
   // materials
   {
     // 4 x float4 per material: (Kd, -) (Kr, type) (Kt, -) (index, sigma: each double's low / high word)
@@ -600,9 +679,18 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
           if (lt.v[k] >= desc->nverts) return bail(DR_ERR_INVALID, "light vertex index out of range");
           for (int c = 0; c < 3; ++c) o.p[3 * k + c] = desc->verts[3 * (size_t)lt.v[k] + c];
         }
-        o.reverse = lt.reverse_orientation;
+        o.reverse = lt.reverse_orientation & 1u;
         o.area = host_tri_area(o.p, o.p + 3, o.p + 6);
-        host_tri_normals(o.p, o.p + 3, o.p + 6, lt.reverse_orientation != 0, o.nn, o.ns);
+        float luv[6];
+        const bool hasUV = (lt.reverse_orientation & 2u) != 0;
+        if (hasUV) {
+          if (!desc->vert_uvs) return bail(DR_ERR_INVALID, "light triangle with uvs but no vert_uvs");
+          for (int k = 0; k < 3; ++k) {
+            luv[2 * k] = desc->vert_uvs[2 * (size_t)lt.v[k]];
+            luv[2 * k + 1] = desc->vert_uvs[2 * (size_t)lt.v[k] + 1];
+          }
+        }
+        host_tri_normals(o.p, o.p + 3, o.p + 6, (lt.reverse_orientation & 1u) != 0, o.nn, o.ns, hasUV ? luv : nullptr);
         areas[t] = o.area;
         area += o.area;
       }

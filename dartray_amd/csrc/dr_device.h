@@ -136,6 +136,10 @@ struct DScene {
   DEnv env;
   int32_t hasEnv;
   const DQuadric* quads;  // spheres / disks; a primitive record with kind != 0 holds its index in q0.x
+  // per-primitive shading record (7 x float4) of meshes with N / S / uv, or null: n0 n1 n2 | s0 s1 s2 | uv0 uv1 uv2 |
+  // (flags, xform index); and the mesh transforms (2 x 12 floats: rows of objectToWorld, rows of its inverse)
+  const float4* srec;
+  const float* xforms;
   uint32_t nquads;
   uint32_t hasSpec;  // some material is not a plain Lambertian matte (general shading kernels)
 };
@@ -216,6 +220,7 @@ DR_DEV bool tri_hitP(F3 p1, F3 p2, F3 p3, F3 o, F3 d, double tmin, double tmax) 
 // default UVs (0,0),(1,0),(1,1) of :255-262; differential_geometry.dart:77-102).
 struct DGeo {
   F3 p, dpdu, dpdv, nn;
+  double u, v;  // parametric coordinates (only written / read by the uv-aware path)
 };
 DR_DEV void tri_dg(F3 p1, F3 p2, F3 p3, uint32_t reverse, F3 o, F3 d, double t, DGeo* dg) {
   // du1 = -1, du2 = 0, dv1 = -1, dv2 = -1  =>  determinant = 1, invdet = 1
@@ -226,6 +231,40 @@ DR_DEV void tri_dg(F3 p1, F3 p2, F3 p3, uint32_t reverse, F3 o, F3 d, double t, 
   dg->dpdu = vmul(vsub(vmul(dp1, dv2), vmul(dp2, dv1)), invdet);
   dg->dpdv = vmul(vadd(vmul(dp1, -du2), vmul(dp2, du1)), invdet);
   dg->p = vadd(o, vmul(d, t));  // Ray.pointAt ray.dart:66-67
+  F3 nn = vnormalize(vcross(dg->dpdu, dg->dpdv));
+  if (reverse) nn = vmul(nn, -1.0);
+  dg->nn = nn;
+}
+// The same with per-vertex uvs (Triangle.getUVs, triangle.dart:247-263) and the hit's barycentrics: dpdu / dpdv from
+// the uv deltas, Vector.CoordinateSystem for a degenerate mapping (:108-127), interpolated (u, v) (:134-137).
+DR_DEV void tri_dg_uv(F3 p1, F3 p2, F3 p3, const float* uv, uint32_t reverse, F3 o, F3 d, double t, double b1, double b2, DGeo* dg) {
+  const double du1 = (double)uv[0] - (double)uv[4], du2 = (double)uv[2] - (double)uv[4];
+  const double dv1 = (double)uv[1] - (double)uv[5], dv2 = (double)uv[3] - (double)uv[5];
+  const F3 dp1 = vsub(p1, p3), dp2 = vsub(p2, p3);
+  const double determinant = du1 * dv2 - dv1 * du2;
+  if (determinant == 0.0) {
+    const double e1x = (double)p2.x - (double)p1.x, e1y = (double)p2.y - (double)p1.y, e1z = (double)p2.z - (double)p1.z;
+    const double e2x = (double)p3.x - (double)p1.x, e2y = (double)p3.y - (double)p1.y, e2z = (double)p3.z - (double)p1.z;
+    const double e3x = (e2y * e1z) - (e2z * e1y), e3y = (e2z * e1x) - (e2x * e1z), e3z = (e2x * e1y) - (e2y * e1x);
+    const double len = sqrt(e3x * e3x + e3y * e3y + e3z * e3z);
+    const F3 v1 = f3(e3x / len, e3y / len, e3z / len);
+    if (fabs((double)v1.x) > fabs((double)v1.y)) {  // Vector.CoordinateSystem (vector.dart:198-214)
+      const double invLen = 1.0 / sqrt((double)v1.x * (double)v1.x + (double)v1.z * (double)v1.z);
+      dg->dpdu = f3(-(double)v1.z * invLen, 0.0, (double)v1.x * invLen);
+    } else {
+      const double invLen = 1.0 / sqrt((double)v1.y * (double)v1.y + (double)v1.z * (double)v1.z);
+      dg->dpdu = f3(0.0, (double)v1.z * invLen, -(double)v1.y * invLen);
+    }
+    dg->dpdv = vcross(v1, dg->dpdu);
+  } else {
+    const double invdet = 1.0 / determinant;
+    dg->dpdu = vmul(vsub(vmul(dp1, dv2), vmul(dp2, dv1)), invdet);
+    dg->dpdv = vmul(vadd(vmul(dp1, -du2), vmul(dp2, du1)), invdet);
+  }
+  const double b0 = 1.0 - b1 - b2;
+  dg->u = b0 * (double)uv[0] + b1 * (double)uv[2] + b2 * (double)uv[4];
+  dg->v = b0 * (double)uv[1] + b1 * (double)uv[3] + b2 * (double)uv[5];
+  dg->p = vadd(o, vmul(d, t));
   F3 nn = vnormalize(vcross(dg->dpdu, dg->dpdv));
   if (reverse) nn = vmul(nn, -1.0);
   dg->nn = nn;
@@ -449,6 +488,88 @@ DR_DEV F3 sphere_sample2(const DQuadric& q, F3 p, double u1, double u2, F3* ns) 
   if (q.reverse) n = F3{-n.x, -n.y, -n.z};
   *ns = n;
   return ps;
+}
+
+// ---- per-vertex shading data (triangle.dart:247-263, 271-364) -------------------
+struct ShadeRec {  // one primitive's record in DScene::srec
+  float n[9], s[9], uv[6];
+  uint32_t flags, xform;
+};
+DR_DEV ShadeRec load_srec(const DScene& sc, uint32_t prim) {
+  const float4* r = sc.srec + 7 * (size_t)prim;
+  const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5], g = r[6];
+  ShadeRec o;
+  o.n[0] = a.x; o.n[1] = a.y; o.n[2] = a.z; o.n[3] = a.w; o.n[4] = b.x; o.n[5] = b.y; o.n[6] = b.z; o.n[7] = b.w; o.n[8] = c.x;
+  o.s[0] = c.y; o.s[1] = c.z; o.s[2] = c.w; o.s[3] = d.x; o.s[4] = d.y; o.s[5] = d.z; o.s[6] = d.w; o.s[7] = e.x; o.s[8] = e.y;
+  o.uv[0] = e.z; o.uv[1] = e.w; o.uv[2] = f.x; o.uv[3] = f.y; o.uv[4] = f.z; o.uv[5] = f.w;
+  o.flags = __float_as_uint(g.x);
+  o.xform = __float_as_uint(g.y);
+  if (!(o.flags & DR_SHADING_UV)) {  // Triangle.getUVs without a uv array (triangle.dart:255-262)
+    o.uv[0] = 0.f; o.uv[1] = 0.f; o.uv[2] = 1.f; o.uv[3] = 0.f; o.uv[4] = 1.f; o.uv[5] = 1.f;
+  }
+  return o;
+}
+// Triangle.getShadingGeometry (triangle.dart:271-364) for a mesh with N and / or S: barycentrics back from (u, v)
+// (SolveLinearSystem2x2, common.dart:170-185), interpolated normal / tangent through objectToWorld, an orthonormal
+// (ss, ts) pair, and DifferentialGeometry.set on them.  dndu / dndv are not evaluated.
+DR_DEV void shading_geometry(const DScene& sc, const ShadeRec& sr, uint32_t reverse, const DGeo& dg, DGeo* out) {
+  const float* uv = sr.uv;
+  const double A0 = (double)uv[2] - (double)uv[0], A1 = (double)uv[4] - (double)uv[0];
+  const double A2 = (double)uv[3] - (double)uv[1], A3 = (double)uv[5] - (double)uv[1];
+  const double C0 = dg.u - (double)uv[0], C1 = dg.v - (double)uv[1];
+  double bx, by = 0.0, bz = 0.0;
+  const double det = A0 * A3 - A1 * A2;
+  bool ok = !(fabs(det) < 1.0e-10);
+  if (ok) {
+    by = (A3 * C0 - A1 * C1) / det;
+    bz = (A0 * C1 - A2 * C0) / det;
+    if (by != by || bz != bz) ok = false;
+  }
+  if (!ok) bx = by = bz = 1.0 / 3.0;
+  else bx = 1.0 - by - bz;
+  const float* xf = sc.xforms + 24 * (size_t)sr.xform;
+  F3 ns, ss, ts;
+  if (sr.flags & DR_SHADING_N) {
+    const F3 n0 = F3{sr.n[0], sr.n[1], sr.n[2]}, n1 = F3{sr.n[3], sr.n[4], sr.n[5]}, n2 = F3{sr.n[6], sr.n[7], sr.n[8]};
+    ns = vnormalize(q_normal(xf + 12, vadd(vadd(vmul(n0, bx), vmul(n1, by)), vmul(n2, bz))));
+  } else {
+    ns = dg.nn;
+  }
+  if (sr.flags & DR_SHADING_S) {
+    const F3 s0 = F3{sr.s[0], sr.s[1], sr.s[2]}, s1 = F3{sr.s[3], sr.s[4], sr.s[5]}, s2 = F3{sr.s[6], sr.s[7], sr.s[8]};
+    ss = vnormalize(q_vector(xf, vadd(vadd(vmul(s0, bx), vmul(s1, by)), vmul(s2, bz))));
+  } else {
+    ss = vnormalize(dg.dpdu);
+  }
+  ts = vcross(ss, ns);
+  if (vlen2(ts) > 0.0) {
+    ts = vnormalize(ts);
+    ss = vcross(ts, ns);
+  } else {  // Vector.CoordinateSystem(ns, ss, ts)
+    if (fabs((double)ns.x) > fabs((double)ns.y)) {
+      const double invLen = 1.0 / sqrt((double)ns.x * (double)ns.x + (double)ns.z * (double)ns.z);
+      ss = f3(-(double)ns.z * invLen, 0.0, (double)ns.x * invLen);
+    } else {
+      const double invLen = 1.0 / sqrt((double)ns.y * (double)ns.y + (double)ns.z * (double)ns.z);
+      ss = f3(0.0, (double)ns.z * invLen, -(double)ns.y * invLen);
+    }
+    ts = vcross(ns, ss);
+  }
+  out->p = dg.p;
+  out->dpdu = ss;
+  out->dpdv = ts;
+  F3 nn = vnormalize(vcross(ss, ts));
+  if (reverse) nn = vmul(nn, -1.0);
+  out->nn = nn;
+  out->u = dg.u;
+  out->v = dg.v;
+}
+// DifferentialGeometry of the hit (prim, t) of ray (o, d) on a triangle whose mesh has uvs: the barycentrics are
+// recomputed with the accepting test's own arithmetic.
+DR_DEV void tri_dg_srec(const Tri& tr, const ShadeRec& sr, F3 o, F3 d, double t, DGeo* dg) {
+  double tt, b1 = 0.0, b2 = 0.0;
+  (void)tri_hit(tr.p1, tr.p2, tr.p3, o, d, -DR_INF, DR_INF, &tt, &b1, &b2);
+  tri_dg_uv(tr.p1, tr.p2, tr.p3, sr.uv, tr.reverse, o, d, t, b1, b2, dg);
 }
 
 // ---- ShapeSet / DiffuseAreaLight ---------------------------------------------
@@ -686,7 +807,8 @@ DR_DEV double env_pdf(const DEnv& e, F3 w) {  // infinite_area_light.dart:190-20
 #define LAMBERT_TYPE (BSDF_REFLECTION | BSDF_DIFFUSE)
 
 struct Bsdf {
-  F3 p, nn, sn, tn;  // ng == nn for triangles without shading normals (triangle.dart:273-276)
+  F3 p, nn, sn, tn;  // shading frame
+  F3 ng;             // geometric normal (BSDF(dgs, dgGeom.nn)); == nn without per-vertex N / S (triangle.dart:273-276)
   C3 R;
   int nBxDFs;        // number of NON-specular lobes (0 or 1: the Lambertian)
   // specular materials (GEN kernels only): mirror = SpecularReflection(Kr, FresnelNoOp) (mirror_material.dart:38-55),
@@ -705,6 +827,7 @@ DR_DEV Bsdf make_bsdf(const DScene& sc, const DGeo& dg, uint32_t mat) {
   Bsdf b;
   b.p = dg.p;
   b.nn = dg.nn;
+  b.ng = dg.nn;
   b.sn = vnormalize(dg.dpdu);  // bsdf.dart:45-51
   b.tn = vcross(b.nn, b.sn);
   const float4* mp = sc.mats + 4 * (size_t)mat;
@@ -773,7 +896,7 @@ DR_DEV C3 diffuse_f(const Bsdf& b, F3 wo, F3 wi) {
   return cmulD(b.R, DR_INV_PI * (b.onA + b.onB * maxcos * sinalpha * tanbeta));
 }
 DR_DEV C3 bsdf_f(const Bsdf& b, F3 woW, F3 wiW, int flags) {  // bsdf.dart:187-211
-  if (vdot(wiW, b.nn) * vdot(woW, b.nn) > 0) flags = flags & ~BSDF_TRANSMISSION;
+  if (vdot(wiW, b.ng) * vdot(woW, b.ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
   else flags = flags & ~BSDF_REFLECTION;
   C3 f = C3{0.f, 0.f, 0.f};
   if (b.nBxDFs > 0 && lambert_matches(flags)) f = cadd(f, b.on ? diffuse_f(b, bsdf_w2l(b, woW), bsdf_w2l(b, wiW)) : cmulD(b.R, DR_INV_PI));
@@ -804,7 +927,7 @@ DR_DEV C3 bsdf_sample_f(const Bsdf& b, F3 woW, F3* wiW, double uDir0, double uDi
   if (*pdf == 0.0) return C3{0.f, 0.f, 0.f};
   *wiW = bsdf_l2w(b, wi);
   C3 f = C3{0.f, 0.f, 0.f};
-  if (vdot(*wiW, b.nn) * vdot(woW, b.nn) > 0) flags = flags & ~BSDF_TRANSMISSION;
+  if (vdot(*wiW, b.ng) * vdot(woW, b.ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
   else flags = flags & ~BSDF_REFLECTION;
   if (lambert_matches(flags)) f = cadd(f, diffuse_f(b, wo, wi));
   return f;

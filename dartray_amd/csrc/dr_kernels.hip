@@ -261,6 +261,9 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
           F3 phit;
           (void)quadric_hit(qd, ld3(st.ro, cap, slot), wi, st.rtmin[slot], DR_INF, &th, &phit);
           quadric_dg(qd, phit, &dg);
+        } else if (QUAD && sc.srec && (__float_as_uint(sc.srec[7 * (size_t)prim + 6].x) & DR_SHADING_UV)) {
+          const ShadeRec sr = load_srec(sc, (uint32_t)prim);
+          tri_dg_uv(tr.p1, tr.p2, tr.p3, sr.uv, tr.reverse, F3{0, 0, 0}, wi, 0.0, 0.0, 0.0, &dg);  // only nn is used
         } else {
           tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, wi, 0.0, &dg);  // only nn is used
         }
@@ -427,14 +430,26 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         Tri tr = load_tri(sc, (uint32_t)prim);
         DGeo dg;
         const bool isQuad = QUAD && tr.kind != 0;
-        if (isQuad) quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
-        else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
+        DGeo dgs;  // shading geometry (GeometricPrimitive.getBSDF -> Shape.getShadingGeometry)
+        if (isQuad) {
+          quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
+          dgs = dg;
+        } else if (QUAD && sc.srec && __float_as_uint(sc.srec[7 * (size_t)prim + 6].x) != 0u) {
+          const ShadeRec sr = load_srec(sc, (uint32_t)prim);
+          tri_dg_srec(tr, sr, o, d, t, &dg);
+          if (sr.flags & (DR_SHADING_N | DR_SHADING_S)) shading_geometry(sc, sr, tr.reverse, dg, &dgs);
+          else dgs = dg;
+        } else {
+          tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
+          dgs = dg;
+        }
         const F3 wo = vneg(d);
         if (bounce == 0 || (QUAD && (flags & PF_SPECULAR))) {  // bounces == 0 || specularBounce (path_integrator.dart:46)
           C3 Le = tr.light >= 0 ? light_L(sc.lights[tr.light], dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
           L = cadd(L, cmul(beta, Le));
         }
-        Bsdf bsdf = make_bsdf<QUAD>(sc, dg, tr.mat);
+        Bsdf bsdf = make_bsdf<QUAD>(sc, dgs, tr.mat);
+        bsdf.ng = dg.nn;  // BSDF(dgs, dgGeom.nn)
         const F3 p = bsdf.p, n = bsdf.nn;
         const double eps = (isQuad ? 5.0e-4 : 1.0e-3) * t;  // triangle.dart:157; sphere.dart:169, disk.dart:98
         TailSrc ts;
@@ -534,14 +549,20 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
         C3 L = ldc(st.L, cap, slot);
         C3 Lall = ldc(st.beta, cap, slot);
         C3 Ld = C3{0.f, 0.f, 0.f};
-        DGeo dg;
+        DGeo dg, dgs;
         const bool isQuad = QUAD && tr.kind != 0;
+        const bool hasRec = QUAD && !isQuad && sc.srec && __float_as_uint(sc.srec[7 * (size_t)prim + 6].x) != 0u;
+        ShadeRec sr;
+        if (hasRec) sr = load_srec(sc, (uint32_t)prim);
         if (stage == 0) {
           const F3 o = ld3(st.ro, cap, slot);
           const double t = st.ht[slot];
           if (isQuad) {
             quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
             st3(st.ro0, cap, slot, o);  // later stages rebuild the hit from the camera ray
+          } else if (hasRec) {
+            tri_dg_srec(tr, sr, o, d, t, &dg);
+            st3(st.ro0, cap, slot, o);
           } else {
             tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
           }
@@ -552,6 +573,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
           st.rtmin[slot] = (isQuad ? 5.0e-4 : 1.0e-3) * t;
         } else {
           if (isQuad) quadric_dg_at(sc.quads[tr.quad], ld3(st.ro0, cap, slot), d, st.ht[slot], &dg);
+          else if (hasRec) tri_dg_srec(tr, sr, ld3(st.ro0, cap, slot), d, st.ht[slot], &dg);
           else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
           dg.p = ld3(st.ro, cap, slot);
           Ld = ldc(st.betaNee, cap, slot);
@@ -562,7 +584,10 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
           }
         }
         if (stage < nCalls) {
-          Bsdf bsdf = make_bsdf<QUAD>(sc, dg, tr.mat);  // mirror / glass are refused for DirectLighting; Oren-Nayar is not
+          if (hasRec && (sr.flags & (DR_SHADING_N | DR_SHADING_S))) shading_geometry(sc, sr, tr.reverse, dg, &dgs);
+          else dgs = dg;
+          Bsdf bsdf = make_bsdf<QUAD>(sc, dgs, tr.mat);  // mirror / glass are refused for DirectLighting; Oren-Nayar is not
+          bsdf.ng = dg.nn;
           const float* sv = st.sv;
           // sample slots of this call (direct_lighting_integrator.dart:70-87)
           double lsc = LDS_STREAM(sv + (size_t)cur.lc * cap + slot);
@@ -715,13 +740,13 @@ void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) 
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec) hipLaunchKernelGGL((k_shade_path<true, true>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL((k_shade_path<true, true>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
   else if (sc.hasEnv) hipLaunchKernelGGL((k_shade_path<true, false>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
   else hipLaunchKernelGGL((k_shade_path<false, false>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec) hipLaunchKernelGGL(k_shade_direct<true>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
+  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL(k_shade_direct<true>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
   else hipLaunchKernelGGL(k_shade_direct<false>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,

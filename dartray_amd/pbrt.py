@@ -184,9 +184,15 @@ class ParamSet:
     def findInt(self, name):
         return self._get("int", name)
 
-    def findPoint(self, name):
-        v = self._get("point", name)
+    def findPoint(self, name, kind="point"):
+        v = self._get(kind, name)
         return None if v is None else np.asarray(v[:len(v) // 3 * 3], dtype=np.float32).reshape(-1, 3)
+
+    def findNormal(self, name):
+        return self.findPoint(name, "normal")
+
+    def findVector(self, name):
+        return self.findPoint(name, "vector")
 
     def findOneSpectrum(self, name, d):
         v = self._get("spectrum", name)
@@ -698,18 +704,51 @@ class DartRay:
         P = ps.findPoint("P")
         if vi is None or P is None:
             return None
-        for kind, pname, why in (("float", "uv", "per-vertex UVs change dpdu/dpdv"), ("float", "st", "per-vertex UVs"),
-                                 ("normal", "N", "shading normals"), ("vector", "S", "shading tangents"),
-                                 ("texture", "alpha", "alpha textures")):
-            if ps.has(kind, pname):
-                raise UnsupportedFeature(f"trianglemesh '{pname}' ({why}) is not on the path")
-        ps.findOneBool("discarddegenerateUVs", False)
+        if ps.has("texture", "alpha") or ps.findOneFloat("alpha", 1.0) == 0.0:
+            raise UnsupportedFeature("trianglemesh 'alpha' (alpha textures) is not on the path")
+        uvs = ps.findFloat("uv")
+        if uvs is None:
+            uvs = ps.findFloat("st")
+        discard = ps.findOneBool("discarddegenerateUVs", False)
+        if uvs is not None:                   # triangle_mesh.dart:114-126
+            if len(uvs) < 2 * len(P):
+                self.warn(f"Not enough of 'uv's for triangle mesh. Expected {2 * len(P)}, found {len(uvs)}.  Discarding.")
+                uvs = None
+            elif len(uvs) > 2 * len(P):
+                self.warn("More 'uv's provided than will be used for triangle mesh.")
+        S = ps.findVector("S")
+        if S is not None and len(S) != len(P):
+            self.warn("Number of 'S's for triangle mesh must match 'P's")
+            S = None
+        N = ps.findNormal("N")
+        if N is not None and len(N) != len(P):
+            self.warn("Number of 'N's for triangle mesh must match 'P's")
+            N = None
         ntris = len(vi) // 3
         idx = np.asarray(vi[:3 * ntris], dtype=np.int64).reshape(-1, 3)
+        if discard and uvs is not None and N is not None:   # triangle_mesh.dart:140-165
+            uv = np.asarray(uvs[:2 * len(P)], np.float32).reshape(-1, 2)
+            P64 = P.astype(np.float64)
+            for vp in range(0, len(N) - len(N) % 3, 3):     # the reference walks nvi = N.length index slots
+                if vp + 2 >= idx.size:
+                    break
+                a, b, c = (int(idx.reshape(-1)[vp + k]) for k in range(3))
+                if max(a, b, c) >= len(P):
+                    break
+                e1 = (P64[a] - P64[b]).astype(np.float32).astype(np.float64)
+                e2 = (P64[c] - P64[b]).astype(np.float32).astype(np.float64)
+                if 0.5 * float(np.linalg.norm(np.cross(e1, e2).astype(np.float32).astype(np.float64))) < 1.0e-7:
+                    continue
+                if (uv[a] == uv[b]).all() or (uv[b] == uv[c]).all() or (uv[c] == uv[a]).all():
+                    self.warn("Degenerate uv coordinates in triangle mesh.  Discarding all uvs.")
+                    uvs = None
+                    break
         if idx.size and (idx.min() < 0 or idx.max() >= len(P)):
             self.warn("trianglemesh has out of-bounds vertex index")  # triangle_mesh.dart:160-166: shape dropped
             return None
-        return core.TriangleMesh(idx.astype(np.uint32), self.ctm.transformPoints(P), self.gs.reverseOrientation)
+        return core.TriangleMesh(idx.astype(np.uint32), self.ctm.transformPoints(P), self.gs.reverseOrientation,
+                                 n=N, s=S, uvs=None if uvs is None else np.asarray(uvs[:2 * len(P)], np.float32),
+                                 objectToWorld=self.ctm.m, worldToObject=self.ctm.mInv)
 
     def shape(self, name, ps):  # dartray.dart:380-470
         mesh = self._makeShape(name, ps)

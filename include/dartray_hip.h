@@ -90,9 +90,19 @@ typedef struct DrEnvMap {
 } DrEnvMap;
 
 typedef struct DrLightTri {
-  uint32_t v[3]; /* vertex indices; v[0] == DR_PRIM_QUADRIC: v[1] indexes DrSceneDesc.quadrics (a Disk) */
-  uint32_t reverse_orientation;
+  uint32_t v[3]; /* vertex indices; v[0] == DR_PRIM_QUADRIC: v[1] indexes DrSceneDesc.quadrics */
+  uint32_t reverse_orientation; /* bit 0: Shape.reverseOrientation; bit 1: the mesh has uvs (vert_uvs) */
 } DrLightTri;
+
+/* objectToWorld of a TriangleMesh that carries per-vertex normals / tangents: they stay in object space and are
+ * transformed at shading time (lib/shapes/triangle.dart:303-317). */
+typedef struct DrMeshXform {
+  float object_to_world[16];
+  float world_to_object[16];
+} DrMeshXform;
+#define DR_SHADING_N 1u  /* tri_shading bits: the primitive's mesh has 'N' */
+#define DR_SHADING_S 2u  /* ... 'S' */
+#define DR_SHADING_UV 4u /* ... 'uv' / 'st' */
 
 /* Quadric shapes (lib/shapes/sphere.dart:23-38, lib/shapes/disk.dart:23-29).  Unlike triangle meshes they keep
  * their objectToWorld Transform and transform the RAY per test (transform.dart:180-196).  A primitive whose
@@ -133,6 +143,16 @@ typedef struct DrSceneDesc {
   uint32_t nenv_maps;
   const DrQuadric* quadrics; /* spheres / disks referenced from tri_idx and light_tris */
   uint32_t nquadrics;
+  /* optional per-vertex shading data (triangle_mesh.dart:195-203; Triangle.getShadingGeometry triangle.dart:271-364,
+   * Triangle.getUVs :247-263): arrays indexed like verts (entries of meshes without the attribute are ignored),
+   * and per primitive which attributes its mesh has / which transform it uses.  All NULL: no mesh has any. */
+  const float* vert_normals;   /* nverts*3, OBJECT space */
+  const float* vert_tangents;  /* nverts*3, OBJECT space */
+  const float* vert_uvs;       /* nverts*2 */
+  const uint8_t* tri_shading;  /* ntris: DR_SHADING_* bits */
+  const uint32_t* tri_xform;   /* ntris: index into mesh_xforms (read when DR_SHADING_N or _S is set) */
+  const DrMeshXform* mesh_xforms;
+  uint32_t nmesh_xforms;
 } DrSceneDesc;
 
 typedef struct DrScene DrScene;

@@ -27,7 +27,7 @@ class OrcMesh(C.Structure):
                 ("has_light", C.c_int32), ("L", C.c_float * 3), ("light_nsamples", C.c_int32),
                 ("kind", C.c_int32), ("o2w", C.c_float * 16), ("w2o", C.c_float * 16), ("params", C.c_double * 4),
                 ("mat_type", C.c_int32), ("Kr", C.c_float * 3), ("Kt", C.c_float * 3), ("ior", C.c_double),
-                ("sigma_d", C.c_double)]
+                ("sigma_d", C.c_double), ("N", C.c_void_p), ("S", C.c_void_p), ("uv", C.c_void_p)]
 
 
 class OrcSceneDesc(C.Structure):
@@ -144,6 +144,15 @@ class OracleScene:
                 self._keep += [P, idx]
                 m.P, m.idx = P.ctypes.data, idx.ctypes.data
                 m.nverts, m.ntris = len(P), len(idx)
+                for field, attr in (("N", "n"), ("S", "s"), ("uv", "uvs")):  # optional per-vertex shading data
+                    a = getattr(gp.shape, attr, None)
+                    if a is not None:
+                        a = np.ascontiguousarray(a, np.float32)
+                        self._keep.append(a)
+                        setattr(m, field, a.ctypes.data)
+                if getattr(gp.shape, "n", None) is not None or getattr(gp.shape, "s", None) is not None:
+                    m.o2w[:] = [float(x) for x in np.asarray(gp.shape.objectToWorld, np.float32).reshape(-1)]
+                    m.w2o[:] = [float(x) for x in np.asarray(gp.shape.worldToObject, np.float32).reshape(-1)]
             mt = getattr(gp.material, "kind", 0)  # 0 matte, 1 mirror, 2 glass
             m.mat_type = mt
             if mt == 0:

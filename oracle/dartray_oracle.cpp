@@ -306,6 +306,7 @@ static inline V pointAt(const Ray& r, D t) { return vadd(r.o, vmul(r.d, t)); }  
 // (differential_geometry.dart:77-102).
 struct DG {
   V p, dpdu, dpdv, nn;
+  D u = 0, v = 0;  // parametric coordinates (Triangle.getShadingGeometry reads them back, triangle.dart:291)
 };
 
 // ---------------------------------------------------------------------------
@@ -316,6 +317,10 @@ struct Mesh {
   D sigma;
   bool reverse;
   int light;  // index into lights or -1
+  // per-vertex shading data of the TriangleMesh (triangle_mesh.dart:195-203): N / S stay in OBJECT space and are
+  // transformed by objectToWorld at shading time (triangle.dart:303-317); uvs replace the default (0,0),(1,0),(1,1)
+  bool hasN = false, hasS = false, hasUV = false;
+  float o2w[16], w2o[16];
   // material: 0 matte (matte_material.dart), 1 mirror (mirror_material.dart), 2 glass (glass_material.dart)
   int matType = 0;
   S Kr{0, 0, 0}, Kt{0, 0, 0};
@@ -362,6 +367,7 @@ struct LightTri {  // one Shape of a ShapeSet: a refined triangle or a quadric
   uint32_t v[3];
   bool reverse;
   int quadric = -1;
+  int mesh = -1;  // its TriangleMesh (for the uvs)
 };
 
 // InfiniteAreaLight (lights/infinite_area_light.dart) with its MIPMap radiance map (core/mipmap.dart,
@@ -500,6 +506,7 @@ struct EnvLight {
 
 struct Scene {
   std::vector<float> P;  // world-space f32 vertices (triangle_mesh.dart:29-36)
+  std::vector<float> N, S, UV;  // per-vertex normals / tangents (object space) / uvs; zero where a mesh has none
   std::vector<Mesh> meshes;
   std::vector<Prim> prims;  // after the build: BVH 'primitives' order
   std::vector<LinearNode> nodes;
@@ -519,10 +526,21 @@ struct Scene {
 // Triangle (shapes/triangle.dart)
 // ---------------------------------------------------------------------------
 static const D kUVs[6] = {0.0, 0.0, 1.0, 0.0, 1.0, 1.0};  // triangle.dart:255-262 (mesh.uvs == null)
+// Triangle.getUVs (triangle.dart:247-263)
+static void tri_uvs(const Scene& sc, int mesh, const uint32_t v[3], D uv[6]) {
+  if (mesh >= 0 && sc.meshes[mesh].hasUV) {
+    for (int k = 0; k < 3; ++k) {
+      uv[2 * k] = sc.UV[2 * (size_t)v[k]];
+      uv[2 * k + 1] = sc.UV[2 * (size_t)v[k] + 1];
+    }
+  } else {
+    for (int k = 0; k < 6; ++k) uv[k] = kUVs[k];
+  }
+}
 
 // Triangle.intersect (triangle.dart:44-160): all scalars f64 on f32 inputs.
 static bool tri_intersect(const V& p1, const V& p2, const V& p3, bool reverse, const Ray& ray, D* tHit,
-                          D* rayEpsilon, DG* dg, D* ob1 = nullptr, D* ob2 = nullptr) {
+                          D* rayEpsilon, DG* dg, D* ob1 = nullptr, D* ob2 = nullptr, const D* uvs = kUVs) {
   D e1x = p2.x - p1.x, e1y = p2.y - p1.y, e1z = p2.z - p1.z;
   D e2x = p3.x - p1.x, e2y = p3.y - p1.y, e2z = p3.z - p1.z;
   D s1x = (ray.d.y * e2z) - (ray.d.z * e2y);
@@ -542,16 +560,16 @@ static bool tri_intersect(const V& p1, const V& p2, const V& p3, bool reverse, c
   D t = (e2x * s2x + e2y * s2y + e2z * s2z) * invDivisor;
   if (t < ray.mint || t > ray.maxt) return false;
 
-  // Partial derivatives (triangle.dart:100-132) with the default UVs.
+  // Partial derivatives (triangle.dart:100-132).
   V dpdu, dpdv;
-  D du1 = kUVs[0] - kUVs[4];
-  D du2 = kUVs[2] - kUVs[4];
-  D dv1 = kUVs[1] - kUVs[5];
-  D dv2 = kUVs[3] - kUVs[5];
+  D du1 = uvs[0] - uvs[4];
+  D du2 = uvs[2] - uvs[4];
+  D dv1 = uvs[1] - uvs[5];
+  D dv2 = uvs[3] - uvs[5];
   V dp1 = vsub(p1, p3);
   V dp2 = vsub(p2, p3);
   D determinant = du1 * dv2 - dv1 * du2;
-  if (determinant == 0.0) {  // unreachable with the default UVs; kept for fidelity
+  if (determinant == 0.0) {  // degenerate uv mapping
     D e3x = (e2y * e1z) - (e2z * e1y);
     D e3y = (e2z * e1x) - (e2x * e1z);
     D e3z = (e2x * e1y) - (e2y * e1x);
@@ -577,6 +595,11 @@ static bool tri_intersect(const V& p1, const V& p2, const V& p3, bool reverse, c
   dg->dpdv = dpdv;
   dg->nn = vnormalize(vcross(dpdu, dpdv));  // Normal.Normalize normal.dart:53-55
   if (reverse) dg->nn = vmul(dg->nn, -1.0);  // transformSwapsHandedness is never set (shape.dart:30)
+  {  // interpolated (u, v) (triangle.dart:134-137)
+    D b0 = 1.0 - b1 - b2;
+    dg->u = b0 * uvs[0] + b1 * uvs[2] + b2 * uvs[4];
+    dg->v = b0 * uvs[1] + b1 * uvs[3] + b2 * uvs[5];
+  }
   *tHit = t;
   *rayEpsilon = 1.0e-3 * t;
   if (ob1) *ob1 = b1;
@@ -1094,12 +1117,13 @@ static bool bvh_intersect(const Scene& sc, Ray& ray, Isect* isect) {  // bvh_acc
         for (int i = 0; i < node.nPrimitives; ++i) {
           sc.ctr.closest_tris++;
           const Prim& pr = sc.prims[node.offset + i];
-          D thit, eps, b1 = 0.0, b2 = 0.0;
+          D thit, eps, b1 = 0.0, b2 = 0.0, uvs[6];
           DG dg;
           const bool h = pr.quadric >= 0
                              ? quadric_intersect(sc.quadrics[pr.quadric], ray, &thit, &eps, &dg)
-                             : tri_intersect(sc.vert(pr.v[0]), sc.vert(pr.v[1]), sc.vert(pr.v[2]),
-                                             sc.meshes[pr.mesh].reverse, ray, &thit, &eps, &dg, &b1, &b2);
+                             : (tri_uvs(sc, pr.mesh, pr.v, uvs),
+                                tri_intersect(sc.vert(pr.v[0]), sc.vert(pr.v[1]), sc.vert(pr.v[2]),
+                                              sc.meshes[pr.mesh].reverse, ray, &thit, &eps, &dg, &b1, &b2, uvs));
           if (h) {
             isect->dg = dg;
             isect->prim = (int)(node.offset + i);
@@ -1207,7 +1231,9 @@ static V shapeset_sample(const Scene& sc, const Light& L, D uPos0, D uPos1, D uC
       continue;
     }
     lt_verts(sc, t, &a, &b, &c);
-    anyHit = tri_intersect(a, b, c, t.reverse, r, &thit, &rayEps, &dg) || anyHit;
+    D uvs[6];
+    tri_uvs(sc, t.mesh, t.v, uvs);
+    anyHit = tri_intersect(a, b, c, t.reverse, r, &thit, &rayEps, &dg, nullptr, nullptr, uvs) || anyHit;
   }
   if (anyHit) *Ns = dg.nn;
   return pointAt(r, thit);
@@ -1233,8 +1259,10 @@ static D shapeset_pdf(const Scene& sc, const Light& L, const V& p, const V& wi) 
         continue;
       }
     }
+    D uvs[6];
+    if (t.quadric < 0) tri_uvs(sc, t.mesh, t.v, uvs);
     const bool h = t.quadric >= 0 ? quadric_intersect(sc.quadrics[t.quadric], ray, &thit, &rayEpsilon, &dgLight)
-                                  : tri_intersect(a, b, c, t.reverse, ray, &thit, &rayEpsilon, &dgLight);
+                                  : tri_intersect(a, b, c, t.reverse, ray, &thit, &rayEpsilon, &dgLight, nullptr, nullptr, uvs);
     if (!h) {
       pdf2 = 0.0;
     } else {
@@ -1431,13 +1459,63 @@ struct BSDF {
 
 // Intersection.getBSDF -> GeometricPrimitive.getBSDF -> Triangle.getShadingGeometry
 // (copy, no per-vertex N/S) -> MatteMaterial.getBSDF.
+// Triangle.getShadingGeometry (triangle.dart:271-364) for meshes with per-vertex N and / or S; dndu / dndv and the
+// ray differentials only feed texture filtering and are not restated.
+static DG tri_shading_geometry(const Scene& sc, const Prim& pr, const DG& dg) {
+  const Mesh& m = sc.meshes[pr.mesh];
+  if (pr.quadric >= 0 || (!m.hasN && !m.hasS)) return dg;  // dgShading.copy(dg) (:273-276, shape.dart:78-82)
+  D uv[6];
+  tri_uvs(sc, pr.mesh, pr.v, uv);
+  D A[4] = {uv[2] - uv[0], uv[4] - uv[0], uv[3] - uv[1], uv[5] - uv[1]};
+  D C[2] = {dg.u - uv[0], dg.v - uv[1]};
+  D bx, by, bz;
+  {  // SolveLinearSystem2x2 (common.dart:170-185)
+    D det = A[0] * A[3] - A[1] * A[2];
+    bool ok = !(std::fabs(det) < 1.0e-10);
+    if (ok) {
+      by = (A[3] * C[0] - A[1] * C[1]) / det;
+      bz = (A[0] * C[1] - A[2] * C[0]) / det;
+      if (std::isnan(by) || std::isnan(bz)) ok = false;
+    }
+    if (!ok) bx = by = bz = 1.0 / 3.0;  // degenerate parametric mapping
+    else bx = 1.0 - by - bz;
+  }
+  auto vtx = [&](const std::vector<float>& a, int k) {
+    return V{(D)a[3 * (size_t)pr.v[k]], (D)a[3 * (size_t)pr.v[k] + 1], (D)a[3 * (size_t)pr.v[k] + 2]};
+  };
+  V ns, ss, ts;
+  if (m.hasN) ns = vnormalize(xfNormal(m.w2o, vadd(vadd(vmul(vtx(sc.N, 0), bx), vmul(vtx(sc.N, 1), by)), vmul(vtx(sc.N, 2), bz))));
+  else ns = dg.nn;
+  if (m.hasS) ss = vnormalize(xfVector(m.o2w, vadd(vadd(vmul(vtx(sc.S, 0), bx), vmul(vtx(sc.S, 1), by)), vmul(vtx(sc.S, 2), bz))));
+  else ss = vnormalize(dg.dpdu);
+  ts = vcross(ss, ns);
+  if (vlen2(ts) > 0.0) {
+    ts = vnormalize(ts);
+    ss = vcross(ts, ns);
+  } else {  // Vector.CoordinateSystem(ns, ss, ts) (vector.dart:198-214)
+    if (std::fabs(ns.x) > std::fabs(ns.y)) {
+      D invLen = 1.0 / std::sqrt(ns.x * ns.x + ns.z * ns.z);
+      ss = vec(-ns.z * invLen, 0.0, ns.x * invLen);
+    } else {
+      D invLen = 1.0 / std::sqrt(ns.y * ns.y + ns.z * ns.z);
+      ss = vec(0.0, ns.z * invLen, -ns.y * invLen);
+    }
+    ts = vcross(ns, ss);
+  }
+  DG out;
+  dg_set(&out, dg.p, ss, ts, m.reverse);  // dgShading.set(dg.p, ss, ts, ...): nn = normalize(ss x ts), flipped like dg's
+  out.u = dg.u;
+  out.v = dg.v;
+  return out;
+}
 static BSDF make_bsdf(const Scene& sc, const Isect& is) {
   const Mesh& m = sc.meshes[sc.prims[is.prim].mesh];
+  const DG dgs = tri_shading_geometry(sc, sc.prims[is.prim], is.dg);  // GeometricPrimitive.getBSDF (geometric_primitive.dart:67-71)
   BSDF b;
-  b.p = is.dg.p;
-  b.ng = is.dg.nn;
-  b.nn = is.dg.nn;
-  b.sn = vnormalize(is.dg.dpdu);   // bsdf.dart:45-51
+  b.p = dgs.p;
+  b.ng = is.dg.nn;                 // BSDF(dgs, dgGeom.nn)
+  b.nn = dgs.nn;
+  b.sn = vnormalize(dgs.dpdu);     // bsdf.dart:45-51
   b.tn = vcross(b.nn, b.sn);
   auto clampS = [](const S& c) { return rgb(clampD(c.r, 0.0, kInf), clampD(c.g, 0.0, kInf), clampD(c.b, 0.0, kInf)); };
   if (m.matType == 0) {  // matte_material.dart:41-65
@@ -1940,6 +2018,11 @@ struct OrcMesh {
   float Kr[3], Kt[3];
   double ior;
   double sigma_d;  // matte 'sigma' as the Dart double it is (the f32 field above is ignored)
+  // optional per-vertex shading data of a triangle mesh (nverts entries each; null = absent): normals and
+  // tangents in OBJECT space (then o2w / w2o above must be set), uvs
+  const float* N;
+  const float* S;
+  const float* uv;
 };
 struct OrcSceneDesc {
   int32_t nmeshes;
@@ -2098,6 +2181,20 @@ void* orc_scene_create(const OrcSceneDesc* d) {
       continue;
     }
     sc->P.insert(sc->P.end(), om.P, om.P + 3 * (size_t)om.nverts);
+    me.hasN = om.N != nullptr;
+    me.hasS = om.S != nullptr;
+    me.hasUV = om.uv != nullptr;
+    memcpy(me.o2w, om.o2w, sizeof(me.o2w));
+    memcpy(me.w2o, om.w2o, sizeof(me.w2o));
+    {
+      const size_t nv = (size_t)om.nverts;
+      sc->N.resize(sc->P.size(), 0.f);
+      sc->S.resize(sc->P.size(), 0.f);
+      sc->UV.resize(sc->P.size() / 3 * 2, 0.f);
+      if (om.N) memcpy(&sc->N[3 * (size_t)base], om.N, 3 * nv * sizeof(float));
+      if (om.S) memcpy(&sc->S[3 * (size_t)base], om.S, 3 * nv * sizeof(float));
+      if (om.uv) memcpy(&sc->UV[2 * (size_t)base], om.uv, 2 * nv * sizeof(float));
+    }
     if (om.has_light) {
       Light L;
       L.Lemit = rgb(om.L[0], om.L[1], om.L[2]);
@@ -2107,6 +2204,7 @@ void* orc_scene_create(const OrcSceneDesc* d) {
         LightTri lt;
         for (int k = 0; k < 3; ++k) lt.v[k] = base + om.idx[3 * t + k];
         lt.reverse = me.reverse;
+        lt.mesh = m;
         L.shapes.push_back((int)sc->lightTris.size());
         sc->lightTris.push_back(lt);
       }
@@ -2237,7 +2335,9 @@ void orc_intersect_brute(void* h, const OrcRay* rays, int64_t n, OrcHit* out, in
       } else {
         D t, e, b1, b2;
         DG dg;
-        if (tri_intersect(a, b, c, sc->meshes[pr.mesh].reverse, r, &t, &e, &dg, &b1, &b2)) {
+        D uvs[6];
+        tri_uvs(*sc, pr.mesh, pr.v, uvs);
+        if (tri_intersect(a, b, c, sc->meshes[pr.mesh].reverse, r, &t, &e, &dg, &b1, &b2, uvs)) {
           o.prim = (int)p; o.t = t; o.b1 = b1; o.b2 = b2;
           r.maxt = t;
         }

@@ -184,8 +184,7 @@ def test_include_gz_and_relative_paths(tmp_path):
     ('Volume "homogeneous"', "Volume"),
     ('ObjectBegin "a"', "instancing"),
     ('ActiveTransform StartTime', "animated"),
-    ('Shape "trianglemesh" ' + QUAD + ' "float uv" [0 0 1 0 1 1 0 1]', "uv"),
-    ('Shape "trianglemesh" ' + QUAD + ' "normal N" [0 1 0 0 1 0 0 1 0 0 1 0]', "'N'"),
+    ('Shape "trianglemesh" ' + QUAD + ' "texture alpha" "holes"', "alpha"),
     ('Material "matte" "spectrum Kd" [400 1 700 1]', "spectrum"),
 ])
 def test_plugins_outside_the_path_fail_loudly_with_position(snippet, needle):
@@ -203,6 +202,28 @@ def test_render_options_outside_the_path_fail_at_world_end(opt, needle):
     with pytest.raises(pbrt.UnsupportedFeature) as e:
         pbrt.loads(opt + "\nWorldBegin\nShape \"trianglemesh\" " + QUAD + "\nWorldEnd\n")
     assert needle in str(e.value)
+
+
+def test_mesh_normals_tangents_and_uvs():
+    api = pbrt.loads(HEADER + f'''
+WorldBegin
+Translate 0 2 0  Rotate 90 1 0 0
+Shape "trianglemesh" {QUAD} "normal N" [0 1 0 0 1 0 0 1 0 0 1 0] "float uv" [0 0 1 0 1 1 0 1]
+Shape "trianglemesh" {QUAD} "vector S" [1 0 0 1 0 0 1 0 0 1 0 0] "float st" [0 0 1 0 1 1 0 1 9 9]
+Shape "trianglemesh" {QUAD} "normal N" [0 1 0 0 1 0] "float uv" [0 0 1 0]
+Shape "trianglemesh" {QUAD} "normal N" [0 1 0 0 1 0 0 1 0 0 1 0] "float uv" [0 0 0 0 1 1 0 1] "bool discarddegenerateUVs" ["true"]
+WorldEnd
+''')
+    m = [g.shape for g in api.scenePrimitives]
+    assert m[0].n.shape == (4, 3) and m[0].uvs.shape == (4, 2) and m[0].s is None
+    assert np.array_equal(m[0].n[0], [0, 1, 0])                # normals stay in OBJECT space (triangle.dart:303-305)
+    assert np.allclose(m[0].objectToWorld, api.scenePrimitives[0].shape.objectToWorld)
+    assert np.allclose(m[0].objectToWorld @ m[0].worldToObject, np.eye(4), atol=1e-6)
+    assert m[1].s.shape == (4, 3) and m[1].n is None and m[1].uvs.shape == (4, 2)   # surplus 'st' values are dropped
+    assert m[2].n is None and m[2].uvs is None                 # counts that do not match 'P' discard the attribute
+    assert m[3].n is not None and m[3].uvs is None             # a degenerate uv pair discards all uvs
+    acc = api.scene.aggregate
+    assert acc.has_shading and acc.tri_shading.tolist().count(5) == 2 and len(acc.mesh_xforms) == 3
 
 
 def test_mirror_and_glass_materials():
