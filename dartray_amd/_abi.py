@@ -16,6 +16,7 @@ DR_SAMPLER_HOST_BUFFER = 0
 DR_SAMPLER_COUNTER = 1
 DR_LIGHT_DIFFUSE_AREA = 0
 DR_LIGHT_INFINITE = 1
+DR_LIGHT_POINT = 2
 
 
 class DrBvhNode(C.Structure):
@@ -28,12 +29,12 @@ class DrMaterial(C.Structure):
                 ("sigma", C.c_double), ("index", C.c_double)]
 
 
-DR_MATERIAL_MATTE, DR_MATERIAL_MIRROR, DR_MATERIAL_GLASS = 0, 1, 2
+DR_MATERIAL_MATTE, DR_MATERIAL_MIRROR, DR_MATERIAL_GLASS, DR_MATERIAL_PLASTIC = 0, 1, 2, 3
 
 
 class DrAreaLight(C.Structure):
     _fields_ = [("L", C.c_float * 3), ("nsamples", C.c_int32), ("first_tri", C.c_uint32), ("ntris", C.c_uint32),
-                ("kind", C.c_uint32), ("env_index", C.c_uint32)]
+                ("kind", C.c_uint32), ("env_index", C.c_uint32), ("position", C.c_float * 3), ("pad", C.c_float)]
 
 
 class DrEnvMap(C.Structure):

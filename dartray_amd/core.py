@@ -171,6 +171,34 @@ class GlassMaterial:
         self.index = float(index)
 
 
+class PlasticMaterial:
+    """materials/plastic_material.dart:40-85 with constant textures: Lambertian(Kd) + Microfacet(Ks,
+    FresnelDielectric(1.5, 1.0), Blinn(1 / roughness))."""
+
+    kind = _abi.DR_MATERIAL_PLASTIC
+
+    def __init__(self, Kd=(0.25, 0.25, 0.25), Ks=(0.25, 0.25, 0.25), roughness=0.1):
+        self.Kd = np.asarray(Kd, dtype=np.float32).reshape(3)
+        self.Ks = np.asarray(Ks, dtype=np.float32).reshape(3)
+        self.roughness = float(roughness)
+        self.Kr, self.index = self.Ks, self.roughness  # the fields the C ABI / oracle carry them in
+
+
+class PointLight:
+    """lights/point_light.dart:35-47: an isotropic delta light at lightToWorld(0,0,0) with intensity I."""
+
+    def __init__(self, light2world=None, I=(1.0, 1.0, 1.0)):
+        m = np.eye(4, dtype=np.float32) if light2world is None else np.asarray(light2world, np.float32).reshape(4, 4)
+        self.lightToWorld = m
+        self.lightPos = transform_points(m, np.zeros((1, 3), np.float32))[0]
+        self.intensity = np.asarray(I, dtype=np.float32).reshape(3)
+        self.nSamples = 1
+        self.shape = None
+
+    def isDeltaLight(self):
+        return True
+
+
 class DiffuseAreaLight:
     """lights/diffuse_area_light.dart:36-43."""
 
@@ -397,6 +425,10 @@ class _DeviceScene:
             if mats[i].type == _abi.DR_MATERIAL_MATTE:
                 mats[i].kd[:] = [float(x) for x in m.Kd]
                 mats[i].sigma = float(m.sigma)
+            elif mats[i].type == _abi.DR_MATERIAL_PLASTIC:
+                mats[i].kd[:] = [float(x) for x in m.Kd]
+                mats[i].kr[:] = [float(x) for x in m.Ks]
+                mats[i].index = m.roughness
             else:
                 mats[i].kr[:] = [float(x) for x in m.Kr]
                 if mats[i].type == _abi.DR_MATERIAL_GLASS:
@@ -415,6 +447,12 @@ class _DeviceScene:
             base += len(gp.shape.P)
         envs = []
         for i, L in enumerate(self.lights):
+            if isinstance(L, PointLight):
+                dl[i].L[:] = [float(x) for x in L.intensity]
+                dl[i].nsamples = 1
+                dl[i].kind = _abi.DR_LIGHT_POINT
+                dl[i].position[:] = [float(x) for x in L.lightPos]
+                continue
             if isinstance(L, InfiniteAreaLight):
                 e = _abi.DrEnvMap()
                 e.texels = L.texels.ctypes.data

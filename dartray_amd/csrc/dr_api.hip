@@ -86,6 +86,7 @@ struct DrScene {
   uint32_t bvhDepth = 0;
   std::vector<int32_t> lightNSamples;
   bool hasSpecular = false;  // some material is a mirror / glass
+  bool hasDeltaLight = false;
   // DirectLighting sample layout (direct_lighting_integrator.dart:70-87), fixed by the lights' nsamples
   DevBuf<LdBlock> dlBlocks;
   DevBuf<DirectStage> dlStages;
@@ -380,7 +381,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     return fail(DR_ERR_INVALID, "scene arrays missing");
   if (desc->ntris >= (1ull << 31) || desc->nnodes >= (1ull << 31)) return fail(DR_ERR_INVALID, "scene too large");
   for (uint32_t i = 0; i < desc->nmaterials; ++i) {
-    if (desc->materials[i].type < DR_MATERIAL_MATTE || desc->materials[i].type > DR_MATERIAL_GLASS)
+    if (desc->materials[i].type < DR_MATERIAL_MATTE || desc->materials[i].type > DR_MATERIAL_PLASTIC)
       return fail(DR_ERR_INVALID, "unknown material type");
   }
   if (desc->bvh_depth > DR_MAX_STACK) return fail(DR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
@@ -635,6 +636,17 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         sc->lightNSamples.push_back(d.nsamples);
         continue;
       }
+      if (a.kind == DR_LIGHT_POINT) {
+        DLight& d = L[i];
+        memset(&d, 0, sizeof(d));
+        d.L[0] = a.L[0]; d.L[1] = a.L[1]; d.L[2] = a.L[2];
+        d.nsamples = 1;
+        d.kind = DR_LIGHT_POINT;
+        d.pos[0] = a.position[0]; d.pos[1] = a.position[1]; d.pos[2] = a.position[2];
+        sc->lightNSamples.push_back(1);
+        sc->hasDeltaLight = true;
+        continue;
+      }
       if (a.kind != DR_LIGHT_DIFFUSE_AREA) return bail(DR_ERR_INVALID, "unknown light kind");
       if (a.ntris == 0 || (uint64_t)a.first_tri + a.ntris > desc->nlight_tris) return bail(DR_ERR_INVALID, "light triangle range");
       DLight& d = L[i];
@@ -812,9 +824,10 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   for (uint32_t i = 0; i < desc->nmaterials; ++i)
     if (desc->materials[i].type != DR_MATERIAL_MATTE) sc->d.hasSpec = 1;
     else if (desc->materials[i].sigma != 0.0) sc->d.hasSpec = 1;  // Oren-Nayar: general shading kernels too
+  if (sc->hasDeltaLight) sc->d.hasSpec = 1;  // point lights are handled by the general kernels
   sc->hasSpecular = false;
   for (uint32_t i = 0; i < desc->nmaterials; ++i)
-    if (desc->materials[i].type != DR_MATERIAL_MATTE) sc->hasSpecular = true;
+    if (desc->materials[i].type == DR_MATERIAL_MIRROR || desc->materials[i].type == DR_MATERIAL_GLASS) sc->hasSpecular = true;
   sc->d.nodes = sc->nodes.p;
   sc->d.tris = sc->tris.p;
   sc->d.mats = sc->mats.p;
@@ -846,7 +859,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       blocks.push_back({o1, ns[i], 0, 0});
       blocks.push_back({o1 + ns[i], ns[i], 0, 0});
       for (int j = 0; j < ns[i]; ++j)
-        stages.push_back({(int)i, ns[i], j == ns[i] - 1 ? 1 : 0, o1 + j, o2 + 2 * j, o2 + 2 * ns[i] + 2 * j, 0, 0});
+        stages.push_back({(int)i, ns[i], j == ns[i] - 1 ? 1 : 0, o1 + j, o2 + 2 * j, o2 + 2 * ns[i] + 2 * j, o1 + ns[i] + j, 0});
       o1 += 2 * ns[i];
       o2 += 4 * ns[i];
     }

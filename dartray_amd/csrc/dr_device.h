@@ -80,8 +80,10 @@ struct DLight {
   int32_t nsamples;
   uint32_t first_tri, ntris;
   uint32_t cdf_off;  // into lcdf: ntris+1 floats
-  uint32_t kind;     // DR_LIGHT_DIFFUSE_AREA / DR_LIGHT_INFINITE
+  uint32_t kind;     // DR_LIGHT_DIFFUSE_AREA / DR_LIGHT_INFINITE / DR_LIGHT_POINT
   double area;
+  float pos[3];      // DR_LIGHT_POINT: lightPos (L holds the intensity)
+  float padp;
 };
 // InfiniteAreaLight: level-0 radiance texels + Distribution2D (montecarlo.dart:222-268) tables.
 struct DEnv {
@@ -818,6 +820,11 @@ struct Bsdf {
   double ior;
   bool on;       // the non-specular lobe is OrenNayar(R, sigma) with the coefficients below (oren_nayar.dart:24-32)
   double onA, onB;
+  // plastic (plastic_material.dart:43-70): a second non-specular lobe Microfacet(Ks, FresnelDielectric(1.5, 1),
+  // Blinn(bexp)) after the Lambertian one (either may be absent when its colour is black)
+  bool glossy;
+  C3 Ks;
+  double bexp;
 };
 DR_DEV bool lambert_matches(int flags) { return (LAMBERT_TYPE & flags) == LAMBERT_TYPE; }
 DR_DEV C3 clamp0(float4 m) { return C3{m.x < 0.f ? 0.f : m.x, m.y < 0.f ? 0.f : m.y, m.z < 0.f ? 0.f : m.z}; }
@@ -837,6 +844,7 @@ DR_DEV Bsdf make_bsdf(const DScene& sc, const DGeo& dg, uint32_t mat) {
   b.nBxDFs = cblack(r) ? 0 : 1;
   b.mtype = DR_MATERIAL_MATTE;
   b.on = false;
+  b.glossy = false;
   if (GEN) {
     const float4 m1 = mp[1], m3 = mp[3];
     b.mtype = (int)__float_as_uint(m1.w);
@@ -850,6 +858,13 @@ DR_DEV Bsdf make_bsdf(const DScene& sc, const DGeo& dg, uint32_t mat) {
         b.onA = 1.0 - (sigma2 / (2.0 * (sigma2 + 0.33)));
         b.onB = 0.45 * sigma2 / (sigma2 + 0.09);
       }
+    } else if (b.mtype == DR_MATERIAL_PLASTIC) {
+      b.Ks = clamp0(m1);
+      b.glossy = !cblack(b.Ks);
+      double e = 1.0 / __hiloint2double((int)__float_as_uint(m3.y), (int)__float_as_uint(m3.x));  // Blinn(1 / roughness)
+      if (e > 10000.0 || e != e) e = 10000.0;
+      b.bexp = e;
+      b.mtype = DR_MATERIAL_MATTE;  // non-specular: shaded through bsdf_f / bsdf_pdf / bsdf_sample_f
     } else {
       const float4 m2 = mp[2];
       b.nBxDFs = 0;
@@ -895,43 +910,6 @@ DR_DEV C3 diffuse_f(const Bsdf& b, F3 wo, F3 wi) {
   }
   return cmulD(b.R, DR_INV_PI * (b.onA + b.onB * maxcos * sinalpha * tanbeta));
 }
-DR_DEV C3 bsdf_f(const Bsdf& b, F3 woW, F3 wiW, int flags) {  // bsdf.dart:187-211
-  if (vdot(wiW, b.ng) * vdot(woW, b.ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
-  else flags = flags & ~BSDF_REFLECTION;
-  C3 f = C3{0.f, 0.f, 0.f};
-  if (b.nBxDFs > 0 && lambert_matches(flags)) f = cadd(f, b.on ? diffuse_f(b, bsdf_w2l(b, woW), bsdf_w2l(b, wiW)) : cmulD(b.R, DR_INV_PI));
-  return f;
-}
-DR_DEV double bsdf_pdf(const Bsdf& b, F3 woW, F3 wiW, int flags) {  // bsdf.dart:135-156
-  if (b.nBxDFs == 0) return 0.0;
-  F3 wo = bsdf_w2l(b, woW);
-  F3 wi = bsdf_w2l(b, wiW);
-  double pdf = 0.0;
-  int matchingComps = 0;
-  if (lambert_matches(flags)) {
-    ++matchingComps;
-    pdf += lambert_pdf(wo, wi);
-  }
-  return matchingComps > 0 ? pdf / matchingComps : 0.0;
-}
-DR_DEV C3 bsdf_sample_f(const Bsdf& b, F3 woW, F3* wiW, double uDir0, double uDir1, double* pdf, int flags) {
-  // bsdf.dart:53-133 with a single non-specular lobe
-  if (!(b.nBxDFs > 0 && lambert_matches(flags))) {
-    *pdf = 0.0;
-    return C3{0.f, 0.f, 0.f};
-  }
-  F3 wo = bsdf_w2l(b, woW);
-  F3 wi = CosineSampleHemisphere(uDir0, uDir1);  // bxdf.dart:37-48
-  if (wo.z < 0.0f) wi.z = (float)((double)wi.z * -1.0);
-  *pdf = lambert_pdf(wo, wi);
-  if (*pdf == 0.0) return C3{0.f, 0.f, 0.f};
-  *wiW = bsdf_l2w(b, wi);
-  C3 f = C3{0.f, 0.f, 0.f};
-  if (vdot(*wiW, b.ng) * vdot(woW, b.ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
-  else flags = flags & ~BSDF_REFLECTION;
-  if (lambert_matches(flags)) f = cadd(f, diffuse_f(b, wo, wi));
-  return f;
-}
 // FresnelDielectric.evaluate (fresnel_dielectric.dart:30-64); the Spectrum it returns has three equal f32 channels
 DR_DEV float fresnel_dielectric(double cosi, double eta_i, double eta_t) {
   cosi = cosi < -1.0 ? -1.0 : (cosi > 1.0 ? 1.0 : cosi);
@@ -944,6 +922,98 @@ DR_DEV float fresnel_dielectric(double cosi, double eta_i, double eta_t) {
   const double Rparl = ((et * cosi) - (ei * cost)) / ((et * cosi) + (ei * cost));
   const double Rperp = ((ei * cosi) - (et * cost)) / ((ei * cosi) + (et * cost));
   return (float)((Rparl * Rparl + Rperp * Rperp) / 2.0);
+}
+#define GLOSSY_TYPE (BSDF_REFLECTION | BSDF_GLOSSY)
+DR_DEV bool glossy_matches(int flags) { return (GLOSSY_TYPE & flags) == GLOSSY_TYPE; }
+// Blinn.pdf (blinn.dart:62-73) from the half vector's cos(theta) and dot(wo, wh)
+DR_DEV double blinn_pdf(double bexp, double costheta, double woDotWh) {
+  double p = ((bexp + 1.0) * pow(costheta, bexp)) / (2.0 * DR_PI * 4.0 * woDotWh);
+  if (woDotWh <= 0.0) p = 0.0;
+  return p;
+}
+// Microfacet.f (microfacet.dart:27-56) with Blinn.d (blinn.dart:30-33) and FresnelDielectric(1.5, 1.0)
+DR_DEV C3 microfacet_f(const Bsdf& b, F3 wo, F3 wi) {
+  const double cosThetaO = fabs((double)wo.z), cosThetaI = fabs((double)wi.z);
+  if (cosThetaI == 0.0 || cosThetaO == 0.0) return C3{0.f, 0.f, 0.f};
+  F3 wh = vadd(wi, wo);
+  if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return C3{0.f, 0.f, 0.f};
+  wh = vnormalize(wh);
+  const double cosThetaH = vdot(wi, wh);
+  const float F = fresnel_dielectric(cosThetaH, 1.5, 1.0);
+  const double d = (b.bexp + 2.0) * DR_INV_TWOPI * pow(fabs((double)wh.z), b.bexp);
+  const double NdotWh = fabs((double)wh.z), WOdotWh = fabs(vdot(wo, wh));
+  const double g = fmin(1.0, fmin((2.0 * NdotWh * cosThetaO / WOdotWh), (2.0 * NdotWh * cosThetaI / WOdotWh)));
+  return cdivD(cmul(cmulD(b.Ks, d * g), C3{F, F, F}), 4.0 * cosThetaI * cosThetaO);
+}
+DR_DEV double microfacet_pdf(const Bsdf& b, F3 wo, F3 wi) {  // microfacet.dart:75-80
+  if (!((double)wo.z * (double)wi.z > 0.0)) return 0.0;
+  const F3 wh = vnormalize(vadd(wo, wi));
+  return blinn_pdf(b.bexp, fabs((double)wh.z), vdot(wo, wh));
+}
+DR_DEV C3 bsdf_f(const Bsdf& b, F3 woW, F3 wiW, int flags) {  // bsdf.dart:187-211
+  if (vdot(wiW, b.ng) * vdot(woW, b.ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
+  else flags = flags & ~BSDF_REFLECTION;
+  C3 f = C3{0.f, 0.f, 0.f};
+  if (b.nBxDFs > 0 && lambert_matches(flags)) f = cadd(f, b.on ? diffuse_f(b, bsdf_w2l(b, woW), bsdf_w2l(b, wiW)) : cmulD(b.R, DR_INV_PI));
+  if (b.glossy && glossy_matches(flags)) f = cadd(f, microfacet_f(b, bsdf_w2l(b, woW), bsdf_w2l(b, wiW)));
+  return f;
+}
+DR_DEV double bsdf_pdf(const Bsdf& b, F3 woW, F3 wiW, int flags) {  // bsdf.dart:135-156
+  if (b.nBxDFs == 0 && !b.glossy) return 0.0;
+  F3 wo = bsdf_w2l(b, woW);
+  F3 wi = bsdf_w2l(b, wiW);
+  double pdf = 0.0;
+  int matchingComps = 0;
+  if (b.nBxDFs > 0 && lambert_matches(flags)) {
+    ++matchingComps;
+    pdf += lambert_pdf(wo, wi);
+  }
+  if (b.glossy && glossy_matches(flags)) {
+    ++matchingComps;
+    pdf += microfacet_pdf(b, wo, wi);
+  }
+  return matchingComps > 0 ? pdf / matchingComps : 0.0;
+}
+DR_DEV C3 bsdf_sample_f(const Bsdf& b, F3 woW, F3* wiW, double uDir0, double uDir1, double uComponent, double* pdf, int flags) {
+  // bsdf.dart:53-133 with up to two non-specular lobes: [Lambertian | OrenNayar], Microfacet
+  const bool m0 = b.nBxDFs > 0 && lambert_matches(flags), m1 = b.glossy && glossy_matches(flags);
+  const int matchingComps = (m0 ? 1 : 0) + (m1 ? 1 : 0);
+  *pdf = 0.0;
+  if (matchingComps == 0) return C3{0.f, 0.f, 0.f};
+  bool pickGlossy = !m0;
+  if (matchingComps > 1) {
+    int which = (int)floor(uComponent * matchingComps);
+    which = which < matchingComps - 1 ? which : matchingComps - 1;
+    pickGlossy = which == 1;
+  }
+  F3 wo = bsdf_w2l(b, woW);
+  F3 wi;
+  if (pickGlossy) {  // Microfacet.sample_f -> Blinn.sample_f (microfacet.dart:66-73, blinn.dart:35-60)
+    const double costheta = pow(uDir0, 1.0 / (b.bexp + 1.0));
+    const double sintheta = sqrt(fmax(0.0, 1.0 - costheta * costheta));
+    const double phi = uDir1 * 2.0 * DR_PI;
+    F3 wh = f3(sintheta * cos(phi), sintheta * sin(phi), costheta);  // Vector.SphericalDirection
+    if (!((double)wo.z * (double)wh.z > 0.0)) wh = vneg(wh);
+    wi = vadd(vneg(wo), vmul(vmul(wh, 2.0), vdot(wo, wh)));
+    *pdf = blinn_pdf(b.bexp, costheta, vdot(wo, wh));
+    // (a wi in the other hemisphere makes f black but pdf is kept, microfacet.dart:68-71)
+  } else {
+    wi = CosineSampleHemisphere(uDir0, uDir1);  // bxdf.dart:37-48
+    if (wo.z < 0.0f) wi.z = (float)((double)wi.z * -1.0);
+    *pdf = lambert_pdf(wo, wi);
+  }
+  if (*pdf == 0.0) return C3{0.f, 0.f, 0.f};
+  *wiW = bsdf_l2w(b, wi);
+  if (matchingComps > 1) {  // add the other lobe's pdf, average (bsdf.dart:102-113)
+    *pdf += pickGlossy ? lambert_pdf(wo, wi) : microfacet_pdf(b, wo, wi);
+    *pdf /= matchingComps;
+  }
+  C3 f = C3{0.f, 0.f, 0.f};
+  if (vdot(*wiW, b.ng) * vdot(woW, b.ng) > 0) flags = flags & ~BSDF_TRANSMISSION;
+  else flags = flags & ~BSDF_REFLECTION;
+  if (b.nBxDFs > 0 && lambert_matches(flags)) f = cadd(f, diffuse_f(b, wo, wi));
+  if (b.glossy && glossy_matches(flags)) f = cadd(f, microfacet_f(b, wo, wi));
+  return f;
 }
 // BSDF.sample_f(flags = BSDF_ALL) of a mirror / glass BSDF (bsdf.dart:53-133): every lobe is specular, so the
 // chosen lobe's f and pdf are returned as they are and pdf is divided by the number of lobes.

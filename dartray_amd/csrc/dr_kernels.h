@@ -17,7 +17,7 @@ struct LdBlock {
 // One EstimateDirect call of UniformSampleAllLights (integrator.dart:39-77): sample j of light `light`;
 // lc / lp / bd are the float indices of its light component, light position and BSDF direction samples.
 struct DirectStage {
-  int32_t light, n, last, lc, lp, bd, pad0, pad1;
+  int32_t light, n, last, lc, lp, bd, bc, pad1;  // bc: float index of the BSDF sample's uComponent
 };
 
 // Per-render constants (by-value kernel argument).

@@ -279,7 +279,7 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
 // writes the shadow ray / MIS ray and their candidate contributions.
 template <bool ENV, bool QUAD>
 DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
-                          F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1) {
+                          F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1, double bsc) {
   const uint32_t cap = st.cap;
   const DLight& light = sc.lights[lightNum];
   const int flags = BSDF_ALL & ~BSDF_SPECULAR;
@@ -288,6 +288,25 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
   F3 wi = F3{0, 0, 0}, ps = F3{0, 0, 0};
   double lightPdf = 0.0;
   C3 Li;
+  if (QUAD && light.kind == DR_LIGHT_POINT) {
+    // PointLight.sampleLAtPoint (point_light.dart:41-47): a delta light -- one shadow ray, no MIS weight and no
+    // BSDF-sampling half (integrator.dart:146-150,153)
+    const F3 lp = F3{light.pos[0], light.pos[1], light.pos[2]};
+    const F3 seg = vsub(lp, p);
+    wi = vnormalize(seg);
+    Li = cdivD(C3{light.L[0], light.L[1], light.L[2]}, vlen2(seg));
+    if (!cblack(Li)) {
+      C3 f = bsdf_f(bsdf, wo, wi, flags);
+      if (!cblack(f)) {
+        const double dist = vlen(seg);
+        st3(st.shD, cap, slot, vdiv(seg, dist));  // VisibilityTester.setSegment(p, eps, lightPos, 0)
+        st.shTmax[slot] = dist * (1.0 - 0.0);
+        stc(st.Ld1, cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) / 1.0)));
+        pf |= PF_HAS_SH;
+      }
+    }
+    return pf;
+  }
   if (!infinite) {
     // DiffuseAreaLight.sampleLAtPoint (diffuse_area_light.dart:60-70)
     F3 ns;
@@ -323,7 +342,7 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
   {
     F3 wi2 = F3{0, 0, 0};
     double bsdfPdf = 0.0;
-    C3 f = bsdf_sample_f(bsdf, wo, &wi2, bs0, bs1, &bsdfPdf, flags);
+    C3 f = bsdf_sample_f(bsdf, wo, &wi2, bs0, bs1, bsc, &bsdfPdf, flags);
     if (!cblack(f) && bsdfPdf > 0.0) {
       double lightPdf2 = infinite ? env_pdf(sc.env, wi2) : shapeset_pdf<QUAD>(sc, light, p, wi2);
       if (lightPdf2 != 0.0) {
@@ -408,7 +427,10 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         su[1] = sv[(size_t)(5 + 4 * bounce + 0) * cap + slot];
 #pragma unroll
         for (int k = 0; k < 6; ++k) su[2 + k] = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce) + k) * cap + slot];
-        if (QUAD) su[8] = sv[(size_t)(5 + 4 * bounce + 3) * cap + slot];
+        if (QUAD) {
+          su[8] = sv[(size_t)(5 + 4 * bounce + 3) * cap + slot];  // path-sample uComponent
+          su[9] = sv[(size_t)(5 + 4 * bounce + 2) * cap + slot];  // BSDF-sample uComponent of the light estimate
+        }
       }
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
@@ -456,7 +478,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         const int perNee = rp.nLights > 0 ? 7 : 0;
         if (bounce >= 3) ts.init(rp, st, slot, (bounce - 3) * (perNee + 3) + (bounce > 4 ? bounce - 4 : 0));
         if (rp.nLights > 0) {
-          double lu, ls0, ls1, lsc, bs0, bs1;
+          double lu, ls0, ls1, lsc, bs0, bs1, bsc = 0.0;
           if (bounce < 3) {  // SAMPLE_DEPTH (path_integrator.dart:139), slots of Appendix B
             lu = su[0];
             lsc = su[1];
@@ -464,16 +486,17 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
             ls1 = su[3];
             bs0 = su[4];
             bs1 = su[5];
+            if (QUAD) bsc = su[9];
           } else {
             lu = ts.next(rp);                                   // integrator.dart:96
             ls0 = (float)ts.next(rp); ls1 = (float)ts.next(rp); // LightSample.random light_sample.dart:46-51
             lsc = ts.next(rp);
             bs0 = (float)ts.next(rp); bs1 = (float)ts.next(rp); // BSDFSample.random bsdf_sample.dart:37-42
-            (void)ts.next(rp);                                  // uComponent (single lobe)
+            bsc = ts.next(rp);                                  // uComponent
           }
           int lightNum = (int)floor(lu * rp.nLights);
           lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
-          pf |= setup_nee<ENV, QUAD>(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1);
+          pf |= setup_nee<ENV, QUAD>(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc);
           stc(st.betaNee, cap, slot, beta);
         }
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
@@ -489,7 +512,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         F3 wi = F3{0, 0, 0};
         double pdf = 0.0;
         const bool specular = QUAD && bsdf.mtype != DR_MATERIAL_MATTE;
-        C3 f = specular ? spec_sample_f(bsdf, wo, &wi, oc, &pdf) : bsdf_sample_f(bsdf, wo, &wi, o0, o1, &pdf, BSDF_ALL);
+        C3 f = specular ? spec_sample_f(bsdf, wo, &wi, oc, &pdf) : bsdf_sample_f(bsdf, wo, &wi, o0, o1, oc, &pdf, BSDF_ALL);
         bool alive = !(cblack(f) || pdf == 0.0);
         if (alive) {
           beta = cmul(beta, cdivD(cmulD(f, fabs(vdot(wi, n))), pdf));
@@ -595,7 +618,8 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
           double ls1 = LDS_STREAM(sv + (size_t)(cur.lp + 1) * cap + slot);
           double bs0 = LDS_STREAM(sv + (size_t)cur.bd * cap + slot);
           double bs1 = LDS_STREAM(sv + (size_t)(cur.bd + 1) * cap + slot);
-          pf |= setup_nee<true, QUAD>(sc, st, slot, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1);
+          double bsc = QUAD ? (double)LDS_STREAM(sv + (size_t)cur.bc * cap + slot) : 0.0;
+          pf |= setup_nee<true, QUAD>(sc, st, slot, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
           again = true;
         } else {
           if (rp.nLights > 0) L = cadd(L, Lall);

@@ -626,11 +626,11 @@ class DartRay:
     def _makeMaterial(self, name, geomParams, matParams):
         """MatteMaterial.Create through TextureParams (matte_material.dart:67-72; texture_params.dart: the shape's
         own parameters are searched before the Material directive's)."""
-        if name not in ("matte", "mirror", "glass"):
-            raise UnsupportedFeature(f"Material \"{name}\": only 'matte' (Lambertian), 'mirror' and 'glass' are on the path "
+        if name not in ("matte", "mirror", "glass", "plastic"):
+            raise UnsupportedFeature(f"Material \"{name}\": only 'matte', 'plastic', 'mirror' and 'glass' are on the path "
                                      "(SURVEY.md section 8 row f4)")
         for ps in (geomParams, matParams):
-            for tex in ("Kd", "sigma", "bumpmap", "Kr", "Kt", "index"):
+            for tex in ("Kd", "sigma", "bumpmap", "Kr", "Kt", "index", "Ks", "roughness"):
                 if ps.has("texture", tex):
                     raise UnsupportedFeature(f"{name} '{tex}' bound to a texture: only constant textures are on the path")
 
@@ -638,6 +638,10 @@ class DartRay:
             return geomParams.findOneSpectrum(pname, None) if geomParams.has("spectrum", pname) else \
                 matParams.findOneSpectrum(pname, default)
 
+        if name == "plastic":                 # plastic_material.dart:72-78
+            rough = geomParams.findOneFloat("roughness", None) if geomParams.has("float", "roughness") else \
+                matParams.findOneFloat("roughness", 0.1)
+            return core.PlasticMaterial(spectrum("Kd", (0.25, 0.25, 0.25)), spectrum("Ks", (0.25, 0.25, 0.25)), rough)
         if name == "mirror":                  # mirror_material.dart:57-61
             return core.MirrorMaterial(spectrum("Kr", (0.9, 0.9, 0.9)))
         if name == "glass":                   # glass_material.dart:71-78
@@ -657,9 +661,16 @@ class DartRay:
         return self._makeMaterial(gs.material, shapeParams, gs.materialParams)
 
     def lightSource(self, name, ps):  # dartray.dart:368-376
+        if name == "point":                   # point_light.dart:99-105
+            I = ps.findOneSpectrum("I", (1.0, 1.0, 1.0))
+            sc = ps.findOneSpectrum("scale", (1.0, 1.0, 1.0))
+            frm = ps.findPoint("from")
+            frm = (0.0, 0.0, 0.0) if frm is None or len(frm) != 1 else tuple(float(v) for v in frm[0])
+            l2w = Transform.Translate(*frm) * self.ctm
+            self.lights.append(core.PointLight(l2w.m, (I.astype(np.float64) * sc.astype(np.float64)).astype(np.float32)))
+            return
         if name != "infinite":
-            raise UnsupportedFeature(f"LightSource \"{name}\": delta / projection lights are not on the path "
-                                     "(area and infinite lights are)")
+            raise UnsupportedFeature(f"LightSource \"{name}\": only 'point' and 'infinite' are on the path (besides area lights)")
         L = ps.findOneSpectrum("L", (1.0, 1.0, 1.0))          # infinite_area_light.dart:309-316
         sc = ps.findOneSpectrum("scale", (1.0, 1.0, 1.0))
         nsamples = ps.findOneInt("nsamples", 1)
@@ -875,6 +886,20 @@ class DartRay:
         return self.outputImage
 
     # -- conveniences for tests / tools ---------------------------------------
+    def pointLights(self):
+        """[(PointLight, index of the first primitive whose area light follows it in Scene.lights, or None)]."""
+        out = []
+        for k, l in enumerate(self.sceneLights):
+            if not isinstance(l, core.PointLight):
+                continue
+            before = None
+            for i, gp in enumerate(self.scenePrimitives):
+                if gp.areaLight is not None and any(gp.areaLight is a for a in self.sceneLights[k + 1:]):
+                    before = i
+                    break
+            out.append((l, before))
+        return out
+
     def envLight(self):
         """(InfiniteAreaLight or None, index of the first primitive whose area light follows it or None)."""
         env = [l for l in self.sceneLights if isinstance(l, core.InfiniteAreaLight)]

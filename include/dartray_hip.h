@@ -51,6 +51,7 @@ typedef struct DrBvhNode {
 #define DR_MATERIAL_MATTE 0  /* MatteMaterial (lib/materials/matte_material.dart): kd, sigma */
 #define DR_MATERIAL_MIRROR 1 /* MirrorMaterial (mirror_material.dart:38-55): kr */
 #define DR_MATERIAL_GLASS 2  /* GlassMaterial (glass_material.dart:44-69): kr, kt, index */
+#define DR_MATERIAL_PLASTIC 3 /* PlasticMaterial (plastic_material.dart:43-70): kd, ks in kr, roughness in index */
 typedef struct DrMaterial {
   int32_t type; /* DR_MATERIAL_*; specular materials are traced by the PathIntegrator only */
   float kd[3];
@@ -62,6 +63,7 @@ typedef struct DrMaterial {
 
 #define DR_LIGHT_DIFFUSE_AREA 0 /* DiffuseAreaLight (lib/lights/diffuse_area_light.dart) */
 #define DR_LIGHT_INFINITE 1     /* InfiniteAreaLight (lib/lights/infinite_area_light.dart) */
+#define DR_LIGHT_POINT 2        /* PointLight (lib/lights/point_light.dart): a delta light */
 
 /* One entry of Scene.lights.  kind DR_LIGHT_DIFFUSE_AREA: DiffuseAreaLight + its
  * ShapeSet (diffuse_area_light.dart:36-43, lib/core/light/shape_set.dart:24-51);
@@ -76,6 +78,8 @@ typedef struct DrAreaLight {
   uint32_t ntris;
   uint32_t kind;
   uint32_t env_index; /* into env_maps */
+  float position[3];  /* DR_LIGHT_POINT: PointLight.lightPos = lightToWorld(0,0,0) (point_light.dart:36-39); L = intensity */
+  float pad;
 } DrAreaLight;
 
 /* InfiniteAreaLight.radianceMap level 0 (MIPMap.pyramid[0], lib/core/mipmap.dart:139,

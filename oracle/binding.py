@@ -34,7 +34,9 @@ class OrcSceneDesc(C.Structure):
     _fields_ = [("nmeshes", C.c_int32), ("meshes", C.POINTER(OrcMesh)), ("max_prims_in_node", C.c_int32),
                 ("has_env", C.c_int32), ("env_texels", C.c_void_p), ("env_w", C.c_int32), ("env_h", C.c_int32),
                 ("env_L", C.c_float * 3), ("env_l2w", C.c_float * 16), ("env_w2l", C.c_float * 16),
-                ("env_nsamples", C.c_int32), ("env_before_mesh", C.c_int32)]
+                ("env_nsamples", C.c_int32), ("env_before_mesh", C.c_int32),
+                ("npoint_lights", C.c_int32), ("point_pos", C.c_void_p), ("point_intensity", C.c_void_p),
+                ("point_before_mesh", C.c_void_p)]
 
 
 class OrcRenderDesc(C.Structure):
@@ -125,9 +127,10 @@ class OracleScene:
     """Scene built by the oracle from the same GeometricPrimitive list the product takes
     (objects with .shape.{P,vertexIndex,reverseOrientation}, .material.{Kd,sigma}, .areaLight)."""
 
-    def __init__(self, prims, max_prims=4, env=None, env_before=None):
+    def __init__(self, prims, max_prims=4, env=None, env_before=None, points=()):
         """env: optional InfiniteAreaLight-like object (.texels [H,W,3] f32, .L, .lightToWorld, .worldToLight, .nSamples);
-        env_before: index of the primitive whose area light follows it in Scene.lights (None: the env light is last)."""
+        env_before: index of the primitive whose area light follows it in Scene.lights (None: the env light is last);
+        points: [(PointLight-like with .lightPos / .intensity, index of the primitive whose area light follows it or None)]."""
         l = lib()
         meshes = (OrcMesh * max(len(prims), 1))()
         self._keep = []
@@ -158,6 +161,10 @@ class OracleScene:
             if mt == 0:
                 m.Kd[:] = [float(x) for x in gp.material.Kd]
                 m.sigma_d = float(gp.material.sigma)
+            elif mt == 3:  # plastic: Ks travels in Kr, roughness in ior
+                m.Kd[:] = [float(x) for x in gp.material.Kd]
+                m.Kr[:] = [float(x) for x in gp.material.Ks]
+                m.ior = float(gp.material.roughness)
             else:
                 m.Kr[:] = [float(x) for x in gp.material.Kr]
                 if mt == 2:
@@ -170,6 +177,13 @@ class OracleScene:
                 m.light_nsamples = gp.areaLight.nSamples
         d = OrcSceneDesc(len(prims), meshes, max_prims)
         d.env_before_mesh = -1 if env_before is None else int(env_before)
+        if points:
+            pos = np.ascontiguousarray([p.lightPos for p, _ in points], np.float32)
+            inten = np.ascontiguousarray([p.intensity for p, _ in points], np.float32)
+            before = np.ascontiguousarray([-1 if b is None else int(b) for _, b in points], np.int32)
+            self._keep += [pos, inten, before]
+            d.npoint_lights = len(points)
+            d.point_pos, d.point_intensity, d.point_before_mesh = pos.ctypes.data, inten.ctypes.data, before.ctypes.data
         if env is not None:
             tex = np.ascontiguousarray(env.texels, np.float32)
             self._keep.append(tex)

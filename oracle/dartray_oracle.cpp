@@ -321,7 +321,8 @@ struct Mesh {
   // transformed by objectToWorld at shading time (triangle.dart:303-317); uvs replace the default (0,0),(1,0),(1,1)
   bool hasN = false, hasS = false, hasUV = false;
   float o2w[16], w2o[16];
-  // material: 0 matte (matte_material.dart), 1 mirror (mirror_material.dart), 2 glass (glass_material.dart)
+  // material: 0 matte (matte_material.dart), 1 mirror (mirror_material.dart), 2 glass (glass_material.dart),
+  // 3 plastic (plastic_material.dart: Kd, Ks in Kr, roughness in ior)
   int matType = 0;
   S Kr{0, 0, 0}, Kt{0, 0, 0};
   D ior = 1.5;
@@ -355,7 +356,8 @@ struct Counters {
 };
 
 struct Light {  // DiffuseAreaLight (diffuse_area_light.dart:36-70) + ShapeSet (shape_set.dart:24-51), or the InfiniteAreaLight
-  int kind = 0;  // 0 = diffuse area light, 1 = infinite area light (Scene::env)
+  int kind = 0;  // 0 = diffuse area light, 1 = infinite area light (Scene::env), 2 = point light (point_light.dart)
+  V lightPos{0, 0, 0};  // PointLight: lightToWorld(0,0,0); Lemit holds the intensity
   S Lemit;
   int nSamples;
   std::vector<int> shapes;  // indices into Scene::lightTris
@@ -1308,8 +1310,10 @@ static S fresnel_dielectric(D cosi, D eta_i, D eta_t) {
   return rgb(v, v, v);
 }
 struct BxDF {
-  int kind = 0;  // 0 Lambertian (lambertian.dart), 1 SpecularReflection, 2 SpecularTransmission, 3 OrenNayar
+  int kind = 0;  // 0 Lambertian (lambertian.dart), 1 SpecularReflection, 2 SpecularTransmission, 3 OrenNayar,
+                 // 4 Microfacet(R, FresnelDielectric(ei, et), Blinn(exponent)) (microfacet.dart, blinn.dart)
   D A = 0.0, B = 0.0;  // OrenNayar (oren_nayar.dart:24-32)
+  D exponent = 0.0;    // Blinn (blinn.dart:24-28)
   int type = 0;  // BxDFType flags
   S R{0, 0, 0};  // reflectance / transmittance
   bool dielectric = false;  // SpecularReflection: FresnelDielectric(ei, et) instead of FresnelNoOp
@@ -1324,8 +1328,28 @@ struct BxDF {
     D st = sinTheta(v);
     return st == 0.0 ? 0.0 : clampD(v.y / st, -1.0, 1.0);
   }
+  // Blinn.pdf (blinn.dart:62-73) given the half vector's cos(theta) and dot(wo, wh)
+  D blinn_pdf(D costheta, D woDotWh) const {
+    D p = ((exponent + 1.0) * std::pow(costheta, exponent)) / (2.0 * M_PI * 4.0 * woDotWh);
+    if (woDotWh <= 0.0) p = 0.0;
+    return p;
+  }
+  S microfacet_f(const V& wo, const V& wi) const {  // microfacet.dart:27-56
+    D cosThetaO = std::fabs(wo.z), cosThetaI = std::fabs(wi.z);
+    if (cosThetaI == 0.0 || cosThetaO == 0.0) return S{0, 0, 0};
+    V wh = vadd(wi, wo);
+    if (wh.x == 0.0 && wh.y == 0.0 && wh.z == 0.0) return S{0, 0, 0};
+    wh = vnormalize(wh);
+    D cosThetaH = vdot(wi, wh);
+    S F = fresnel_dielectric(cosThetaH, ei, et);
+    D d = (exponent + 2.0) * INV_TWOPI * std::pow(std::fabs(wh.z), exponent);  // Blinn.d (blinn.dart:30-33)
+    D NdotWh = std::fabs(wh.z), NdotWo = std::fabs(wo.z), NdotWi = std::fabs(wi.z), WOdotWh = vabsdot(wo, wh);
+    D g = std::min(1.0, std::min((2.0 * NdotWh * NdotWo / WOdotWh), (2.0 * NdotWh * NdotWi / WOdotWh)));
+    return sdivD(smul(smulD(R, d * g), F), 4.0 * cosThetaI * cosThetaO);  // R * (D G) * F / (4 cos cos)
+  }
   S f(const V& wo, const V& wi) const {
     if (kind == 0) return smulD(R, INV_PI);  // lambertian.dart:35-37
+    if (kind == 4) return microfacet_f(wo, wi);
     if (kind != 3) return S{0, 0, 0};        // specular_*.dart: f() == 0
     // oren_nayar.dart:34-60
     D sinthetai = sinTheta(wi), sinthetao = sinTheta(wo);
@@ -1346,9 +1370,26 @@ struct BxDF {
   }
   D pdf(const V& wo, const V& wi) const {  // bxdf.dart:84-88; specular_*.dart pdf() == 0
     if (kind == 1 || kind == 2) return 0.0;
+    if (kind == 4) {  // microfacet.dart:75-80, blinn.dart:62-73
+      if (!(wo.z * wi.z > 0.0)) return 0.0;
+      V wh = vnormalize(vadd(wo, wi));
+      return blinn_pdf(std::fabs(wh.z), vdot(wo, wh));
+    }
     return (wo.z * wi.z > 0.0) ? std::fabs(wi.z) * INV_PI : 0.0;
   }
   S sample_f(const V& wo, V* wi, D u1, D u2, D* pdf) const {
+    if (kind == 4) {  // microfacet.dart:66-73, blinn.dart:35-60
+      D costheta = std::pow(u1, 1.0 / (exponent + 1.0));
+      D sintheta = std::sqrt(std::max(0.0, 1.0 - costheta * costheta));
+      D phi = u2 * 2.0 * M_PI;
+      V wh = vec(sintheta * std::cos(phi), sintheta * std::sin(phi), costheta);  // Vector.SphericalDirection
+      if (!(wo.z * wh.z > 0.0)) wh = vneg(wh);
+      // wi = -wo + wh * 2.0 * Dot(wo, wh): ((wh * 2.0) * dot) added to -wo, each a Vector (f32)
+      *wi = vadd(vneg(wo), vmul(vmul(wh, 2.0), vdot(wo, wh)));
+      *pdf = blinn_pdf(costheta, vdot(wo, wh));
+      if (!(wo.z * wi->z > 0.0)) return S{0, 0, 0};
+      return microfacet_f(wo, *wi);
+    }
     if (kind == 0 || kind == 3) {  // BxDF.sample_f (bxdf.dart:37-48)
       *wi = CosineSampleHemisphere(u1, u2);
       if (wo.z < 0.0) wi->z *= -1.0;
@@ -1535,6 +1576,26 @@ static BSDF make_bsdf(const Scene& sc, const Isect& is) {
       }
       b.add(x);
     }
+  } else if (m.matType == 3) {  // plastic_material.dart:43-70: Lambertian(kd) + Microfacet(ks, FresnelDielectric(1.5, 1), Blinn(1/roughness))
+    S kd = clampS(m.Kd), ks = clampS(m.Kr);
+    if (!sblack(kd)) {
+      BxDF x;
+      x.kind = 0;
+      x.type = BSDF_REFLECTION | BSDF_DIFFUSE;
+      x.R = kd;
+      b.add(x);
+    }
+    if (!sblack(ks)) {
+      BxDF x;
+      x.kind = 4;
+      x.type = BSDF_REFLECTION | BSDF_GLOSSY;
+      x.R = ks;
+      x.ei = 1.5;
+      x.et = 1.0;
+      x.exponent = 1.0 / m.ior;  // roughness travels in the `ior` field
+      if (x.exponent > 10000.0 || std::isnan(x.exponent)) x.exponent = 10000.0;
+      b.add(x);
+    }
   } else if (m.matType == 1) {  // mirror_material.dart:38-55
     S r = clampS(m.Kr);
     if (!sblack(r)) {
@@ -1612,6 +1673,23 @@ static S EstimateDirect(const Scene& sc, int lightIdx, const V& p, const V& n, c
   D lightPdf = 0.0, bsdfPdf = 0.0;
   Ray vr;
   S Li;
+  if (light.kind == 2) {
+    // PointLight.sampleLAtPoint (point_light.dart:41-47); a delta light: no MIS, no BSDF-sampling half
+    // (integrator.dart:146-150,153)
+    wi = vnormalize(vsub(light.lightPos, p));
+    lightPdf = 1.0;
+    D dist = vlen(vsub(light.lightPos, p));  // VisibilityTester.setSegment(p, eps, lightPos, 0)
+    vr = Ray{p, vdiv(vsub(light.lightPos, p), dist), rayEpsilon, dist * (1.0 - 0.0), 0.0, 0};
+    Li = sdivD(light.Lemit, vlen2(vsub(light.lightPos, p)));
+    if (lightPdf > 0.0 && !sblack(Li)) {
+      S f = bsdf.f(wo, wi, flags);
+      if (!sblack(f) && !bvh_intersectP(sc, vr)) {
+        Li = smul(Li, S{1, 1, 1});
+        Ld = sadd(Ld, smulD(smul(f, Li), (vabsdot(wi, n) / lightPdf)));
+      }
+    }
+    return Ld;
+  }
   if (light.kind == 0) {
     // light.sampleLAtPoint (diffuse_area_light.dart:60-70)
     V ns{0, 0, 0};
@@ -2038,6 +2116,12 @@ struct OrcSceneDesc {
   // position in Scene.lights: the InfiniteAreaLight precedes the area light of mesh `env_before_mesh`
   // (LightSource and Shape directives append in file order, dartray.dart:368-375,461-466); < 0 => after all
   int32_t env_before_mesh;
+  // point lights (point_light.dart): position = lightToWorld(0,0,0) and intensity; point light i precedes the area
+  // light of mesh point_before_mesh[i] in Scene.lights (< 0 or >= nmeshes: after all meshes, in array order)
+  int32_t npoint_lights;
+  const float* point_pos;        // [n][3]
+  const float* point_intensity;  // [n][3]
+  const int32_t* point_before_mesh;
 };
 struct OrcNode {  // the 32-byte marshalled node of SURVEY.md Appendix F
   float bmin[3], bmax[3];
@@ -2116,7 +2200,22 @@ void* orc_scene_create(const OrcSceneDesc* d) {
     L.area = 0.0;
     sc->lights.push_back(L);
   };
+  auto addPoints = [&](int m) {
+    for (int i = 0; i < d->npoint_lights; ++i) {
+      int before = d->point_before_mesh ? d->point_before_mesh[i] : -1;
+      if (before < 0 || before >= d->nmeshes) before = d->nmeshes;
+      if (before != m) continue;
+      Light L;
+      L.kind = 2;
+      L.Lemit = rgb(d->point_intensity[3 * i], d->point_intensity[3 * i + 1], d->point_intensity[3 * i + 2]);
+      L.lightPos = V{(D)d->point_pos[3 * i], (D)d->point_pos[3 * i + 1], (D)d->point_pos[3 * i + 2]};
+      L.nSamples = 1;
+      L.area = 0.0;
+      sc->lights.push_back(L);
+    }
+  };
   for (int m = 0; m < d->nmeshes; ++m) {
+    addPoints(m);
     if (d->env_before_mesh >= 0 && m == d->env_before_mesh) addEnv();
     const OrcMesh& om = d->meshes[m];
     uint32_t base = (uint32_t)(sc->P.size() / 3);
@@ -2228,6 +2327,7 @@ void* orc_scene_create(const OrcSceneDesc* d) {
       sc->prims.push_back(p);
     }
   }
+  addPoints(d->nmeshes);
   addEnv();
   if (envFailed) {
     delete sc;
@@ -2426,7 +2526,7 @@ int orc_render(void* h, const OrcRenderDesc* rd, float* out_rgb, float* out_film
   if ((spp & (spp - 1)) != 0) return -2;  // LowDiscrepancySampler rounds up; callers pass powers of two
   if (cfg.kind == 0)  // DirectLighting recurses through SpecularReflect / SpecularTransmit (integrator.dart:187-290): not restated
     for (const Mesh& m : sc->meshes)
-      if (m.matType != 0) return -5;
+      if (m.matType == 1 || m.matType == 2) return -5;
   if (rec) { rec->count = 0; rec->nfloats = nFloats; if (rec->nfloats_cap < nFloats) return -3; }
   DartRandom rng((int64_t)rd->task_num);  // sampler_renderer.dart:137
   std::vector<float> buffer, samples;

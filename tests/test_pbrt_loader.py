@@ -176,10 +176,10 @@ def test_include_gz_and_relative_paths(tmp_path):
 
 @pytest.mark.parametrize("snippet,needle", [
     ('Shape "cylinder" "float radius" 3', 'Shape "cylinder"'),
-    ('Material "plastic"\nShape "trianglemesh" ' + QUAD, 'Material "plastic"'),
+    ('Material "uber"\nShape "trianglemesh" ' + QUAD, 'Material "uber"'),
     ('Material "mirror" "texture Kr" "checks"\nShape "trianglemesh" ' + QUAD, "bound to a texture"),
     ('Texture "t" "color" "imagemap" "string filename" "x.png"', "Texture"),
-    ('LightSource "point" "color I" [1 1 1]', 'LightSource "point"'),
+    ('LightSource "spot" "color I" [1 1 1]', 'LightSource "spot"'),
     ('LightSource "infinite" "string mapname" ["sky.exr"]', "image decoders"),
     ('Volume "homogeneous"', "Volume"),
     ('ObjectBegin "a"', "instancing"),
@@ -287,18 +287,20 @@ def test_cornell_text_scene_equals_the_programmatic_scene(ob):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/web/scenes"), reason="reference checkout not present")
 def test_bundled_reference_scenes(ob):
-    """cornell-path.pbrt (disk emitter, matte walls / box / sphere, PathIntegrator) loads unchanged and the BVH
-    over its 24 primitives equals the oracle's; every other bundled demo scene uses at least one plugin outside
-    SURVEY.md section 8 (measured / plastic / metal materials, point lights, volumes, image maps): the loader
-    must name it, never skip it."""
+    """cornell-path.pbrt (disk emitter, matte walls / box / sphere, PathIntegrator) and teapot-area-light.pbrt (2256
+    smooth-shaded plastic patches with per-vertex normals, a disk emitter with 16 samples, a point light placed
+    through CoordSysTransform "camera", DirectLighting) load unchanged and the BVH equals the oracle's; every other
+    bundled demo scene uses at least one plugin outside the path (measured / metal / uber materials, image maps,
+    volumes, other quadrics, the Metropolis renderer): the loader must name it, never skip it."""
     base = "/root/reference/web/scenes"
+    ok = ("cornell-path.pbrt", "teapot-area-light.pbrt")
     seen = {}
     for name in sorted(os.listdir(base)):
-        if name.endswith(".pbrt") and name != "cornell-path.pbrt":
+        if name.endswith(".pbrt") and name not in ok:
             with pytest.raises(pbrt.UnsupportedFeature) as e:
                 pbrt.load(os.path.join(base, name))
             seen[name] = str(e.value)
-    assert len(seen) >= 8 and all(".pbrt" in v for v in seen.values())
+    assert len(seen) >= 7 and all(".pbrt" in v for v in seen.values())
     api = pbrt.load(os.path.join(base, "cornell-path.pbrt"))
     kinds = [type(g.shape).__name__ for g in api.scenePrimitives]
     assert kinds == ["Disk"] + ["TriangleMesh"] * 11 + ["Sphere"]
@@ -310,3 +312,16 @@ def test_bundled_reference_scenes(ob):
     for k in ("bmin", "bmax", "offset", "nprims", "axis"):
         assert np.array_equal(nodes[k], acc.nodes[k]), k
     assert len(acc.tri_idx) == 24 and len(acc.quadrics) == 2
+
+    api = pbrt.load(os.path.join(base, "teapot-area-light.pbrt"))
+    assert [type(l).__name__ for l in api.sceneLights] == ["DiffuseAreaLight", "PointLight"]
+    assert api.sceneLights[0].nSamples == 16 and isinstance(api.sceneLights[0].shape, core.Disk)
+    # CoordSysTransform "camera" puts the point light at the eye (the camera-to-world translation)
+    assert np.allclose(api.sceneLights[1].lightPos, api.rendererObject.camera.cameraToWorld[:3, 3], atol=1e-5)
+    mats = [type(g.material).__name__ for g in api.scenePrimitives]
+    assert mats.count("PlasticMaterial") == 2292 and mats.count("MatteMaterial") == 1
+    acc = api.scene.aggregate
+    assert acc.has_shading and int((acc.tri_shading == 1).sum()) == 2256 and isinstance(api.rendererObject.surfaceIntegrator, core.DirectLightingIntegrator)
+    nodes = ob.OracleScene(api.scenePrimitives, points=api.pointLights()).bvh()[0]
+    for k in ("bmin", "bmax", "offset", "nprims", "axis"):
+        assert np.array_equal(nodes[k], acc.nodes[k]), k
