@@ -16,10 +16,17 @@ produce, and hands them to core.BVHAccel / core.SamplerRenderer (the C ABI).
 Matrices follow the reference's numerics (Float32List storage, f64
 expressions): matrix4x4.dart:193-343, transform.dart:83-86,110-129,214-331.
 
-A directive that needs a plugin outside the path (quadric shapes, non-matte
-materials, textures, delta lights, volumes, instancing, animated transforms,
-image-file radiance maps, non-box filters, non-LD samplers) raises
-`UnsupportedFeature` naming it -- never a silent approximation.
+Plugins on the path: shapes trianglemesh (with N / S / uv), sphere, disk;
+materials matte (Lambertian / Oren-Nayar), plastic, mirror, glass; area lights
+on any of those shapes, infinite lights (constant or .npy lat-long map), point
+lights; perspective camera, image film, box filter, low-discrepancy sampler,
+bvh accelerator, path and directlighting (strategy "all") integrators.
+
+A directive that needs a plugin outside that list (other quadrics, measured /
+metal / uber materials, textures, spot / distant / projection lights, volumes,
+instancing, animated transforms, image-file radiance maps, non-box filters,
+non-LD samplers, the Metropolis renderer) raises `UnsupportedFeature` naming it
+with file:line -- never a silent approximation.
 """
 import gzip
 import math
