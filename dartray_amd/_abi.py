@@ -17,6 +17,8 @@ DR_SAMPLER_COUNTER = 1
 DR_LIGHT_DIFFUSE_AREA = 0
 DR_LIGHT_INFINITE = 1
 DR_LIGHT_POINT = 2
+DR_LIGHT_SPOT = 3
+DR_LIGHT_DISTANT = 4
 
 
 class DrBvhNode(C.Structure):
@@ -34,7 +36,8 @@ DR_MATERIAL_MATTE, DR_MATERIAL_MIRROR, DR_MATERIAL_GLASS, DR_MATERIAL_PLASTIC = 
 
 class DrAreaLight(C.Structure):
     _fields_ = [("L", C.c_float * 3), ("nsamples", C.c_int32), ("first_tri", C.c_uint32), ("ntris", C.c_uint32),
-                ("kind", C.c_uint32), ("env_index", C.c_uint32), ("position", C.c_float * 3), ("pad", C.c_float)]
+                ("kind", C.c_uint32), ("env_index", C.c_uint32), ("position", C.c_float * 3), ("pad", C.c_float),
+                ("world_to_light", C.c_float * 16), ("cone_width", C.c_double), ("cone_falloff_start", C.c_double)]
 
 
 class DrEnvMap(C.Structure):

@@ -199,6 +199,34 @@ class PointLight:
         return True
 
 
+class SpotLight(PointLight):
+    """lights/spot_light.dart:40-85: a point light with a smooth-step cone about light-space +z; `width` and `fall`
+    are the total cone angle and the falloff start, degrees."""
+
+    def __init__(self, light2world=None, I=(1.0, 1.0, 1.0), width=30.0, fall=25.0, world2light=None):
+        super().__init__(light2world, I)
+        self.worldToLight = _inv(self.lightToWorld) if world2light is None else np.asarray(world2light, np.float32).reshape(4, 4)
+        self.width, self.fall = float(width), float(fall)
+
+
+class DistantLight:
+    """lights/distant_light.dart:37-61: radiance L arriving from direction lightDir = normalize(lightToWorld(dir))."""
+
+    def __init__(self, light2world=None, L=(1.0, 1.0, 1.0), dir=(0.0, 0.0, -1.0)):
+        m = np.eye(4, dtype=np.float32) if light2world is None else np.asarray(light2world, np.float32).reshape(4, 4)
+        self.lightToWorld = m
+        d = np.asarray(dir, np.float64).astype(np.float32).astype(np.float64)
+        v = np.array([m[r, 0] * d[0] + m[r, 1] * d[1] + m[r, 2] * d[2] for r in range(3)], np.float64).astype(np.float32)
+        self.lightDir = _normalize(v)
+        self.lightPos = self.lightDir  # the field the C ABI / oracle carry it in
+        self.intensity = np.asarray(L, dtype=np.float32).reshape(3)
+        self.nSamples = 1
+        self.shape = None
+
+    def isDeltaLight(self):
+        return True
+
+
 class DiffuseAreaLight:
     """lights/diffuse_area_light.dart:36-43."""
 
@@ -411,6 +439,10 @@ class BVHAccel:
         return self._device_scene().stats()
 
 
+def delta_light_kind(L):
+    return _abi.DR_LIGHT_SPOT if isinstance(L, SpotLight) else (_abi.DR_LIGHT_DISTANT if isinstance(L, DistantLight) else _abi.DR_LIGHT_POINT)
+
+
 class _DeviceScene:
     """Owns the DrScene handle (scene arrays resident in HBM)."""
 
@@ -447,11 +479,14 @@ class _DeviceScene:
             base += len(gp.shape.P)
         envs = []
         for i, L in enumerate(self.lights):
-            if isinstance(L, PointLight):
+            if isinstance(L, (PointLight, DistantLight)):
                 dl[i].L[:] = [float(x) for x in L.intensity]
                 dl[i].nsamples = 1
-                dl[i].kind = _abi.DR_LIGHT_POINT
+                dl[i].kind = delta_light_kind(L)
                 dl[i].position[:] = [float(x) for x in L.lightPos]
+                if isinstance(L, SpotLight):
+                    dl[i].world_to_light[:] = [float(x) for x in L.worldToLight.reshape(-1)]
+                    dl[i].cone_width, dl[i].cone_falloff_start = L.width, L.fall
                 continue
             if isinstance(L, InfiniteAreaLight):
                 e = _abi.DrEnvMap()

@@ -636,13 +636,18 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         sc->lightNSamples.push_back(d.nsamples);
         continue;
       }
-      if (a.kind == DR_LIGHT_POINT) {
+      if (a.kind == DR_LIGHT_POINT || a.kind == DR_LIGHT_SPOT || a.kind == DR_LIGHT_DISTANT) {
         DLight& d = L[i];
         memset(&d, 0, sizeof(d));
         d.L[0] = a.L[0]; d.L[1] = a.L[1]; d.L[2] = a.L[2];
         d.nsamples = 1;
-        d.kind = DR_LIGHT_POINT;
+        d.kind = a.kind;
         d.pos[0] = a.position[0]; d.pos[1] = a.position[1]; d.pos[2] = a.position[2];
+        if (a.kind == DR_LIGHT_SPOT) {  // spot_light.dart:42-48
+          for (int k = 0; k < 12; ++k) d.w2l[k] = a.world_to_light[k];
+          d.cosTotalWidth = std::cos((3.141592653589793 / 180.0) * a.cone_width);
+          d.cosFalloffStart = std::cos((3.141592653589793 / 180.0) * a.cone_falloff_start);
+        }
         sc->lightNSamples.push_back(1);
         sc->hasDeltaLight = true;
         continue;

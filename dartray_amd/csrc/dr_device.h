@@ -82,8 +82,10 @@ struct DLight {
   uint32_t cdf_off;  // into lcdf: ntris+1 floats
   uint32_t kind;     // DR_LIGHT_DIFFUSE_AREA / DR_LIGHT_INFINITE / DR_LIGHT_POINT
   double area;
-  float pos[3];      // DR_LIGHT_POINT: lightPos (L holds the intensity)
+  float pos[3];      // DR_LIGHT_POINT / _SPOT: lightPos (L holds the intensity); DR_LIGHT_DISTANT: lightDir
   float padp;
+  float w2l[12];     // DR_LIGHT_SPOT: rows of worldToLight
+  double cosTotalWidth, cosFalloffStart;
 };
 // InfiniteAreaLight: level-0 radiance texels + Distribution2D (montecarlo.dart:222-268) tables.
 struct DEnv {

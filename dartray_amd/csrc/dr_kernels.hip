@@ -288,19 +288,44 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
   F3 wi = F3{0, 0, 0}, ps = F3{0, 0, 0};
   double lightPdf = 0.0;
   C3 Li;
-  if (QUAD && light.kind == DR_LIGHT_POINT) {
-    // PointLight.sampleLAtPoint (point_light.dart:41-47): a delta light -- one shadow ray, no MIS weight and no
-    // BSDF-sampling half (integrator.dart:146-150,153)
+  if (QUAD && light.kind >= DR_LIGHT_POINT) {
+    // Delta lights -- one shadow ray, no MIS weight and no BSDF-sampling half (integrator.dart:146-150,153).
+    // PointLight.sampleLAtPoint (point_light.dart:41-47), SpotLight (spot_light.dart:54-85), DistantLight
+    // (distant_light.dart:54-61)
     const F3 lp = F3{light.pos[0], light.pos[1], light.pos[2]};
     const F3 seg = vsub(lp, p);
-    wi = vnormalize(seg);
-    Li = cdivD(C3{light.L[0], light.L[1], light.L[2]}, vlen2(seg));
+    const bool distant = light.kind == DR_LIGHT_DISTANT;
+    if (distant) {
+      wi = lp;
+      Li = C3{light.L[0], light.L[1], light.L[2]};
+    } else {
+      wi = vnormalize(seg);
+      C3 I = C3{light.L[0], light.L[1], light.L[2]};
+      if (light.kind == DR_LIGHT_SPOT) {
+        const F3 wl = vnormalize(q_vector(light.w2l, vneg(wi)));
+        const double costheta = wl.z;
+        double fo;
+        if (costheta < light.cosTotalWidth) fo = 0.0;
+        else if (costheta > light.cosFalloffStart) fo = 1.0;
+        else {
+          const double delta = (costheta - light.cosTotalWidth) / (light.cosFalloffStart - light.cosTotalWidth);
+          fo = delta * delta * delta * delta;
+        }
+        I = cmulD(I, fo);
+      }
+      Li = cdivD(I, vlen2(seg));
+    }
     if (!cblack(Li)) {
       C3 f = bsdf_f(bsdf, wo, wi, flags);
       if (!cblack(f)) {
-        const double dist = vlen(seg);
-        st3(st.shD, cap, slot, vdiv(seg, dist));  // VisibilityTester.setSegment(p, eps, lightPos, 0)
-        st.shTmax[slot] = dist * (1.0 - 0.0);
+        if (distant) {  // VisibilityTester.setRay(p, eps, wi)
+          st3(st.shD, cap, slot, wi);
+          st.shTmax[slot] = DR_INF;
+        } else {        // VisibilityTester.setSegment(p, eps, lightPos, 0)
+          const double dist = vlen(seg);
+          st3(st.shD, cap, slot, vdiv(seg, dist));
+          st.shTmax[slot] = dist * (1.0 - 0.0);
+        }
         stc(st.Ld1, cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) / 1.0)));
         pf |= PF_HAS_SH;
       }

@@ -18,12 +18,12 @@ expressions): matrix4x4.dart:193-343, transform.dart:83-86,110-129,214-331.
 
 Plugins on the path: shapes trianglemesh (with N / S / uv), sphere, disk;
 materials matte (Lambertian / Oren-Nayar), plastic, mirror, glass; area lights
-on any of those shapes, infinite lights (constant or .npy lat-long map), point
-lights; perspective camera, image film, box filter, low-discrepancy sampler,
+on any of those shapes, infinite lights (constant or .npy lat-long map), point,
+spot and distant lights; perspective camera, image film, box filter, low-discrepancy sampler,
 bvh accelerator, path and directlighting (strategy "all") integrators.
 
 A directive that needs a plugin outside that list (other quadrics, measured /
-metal / uber materials, textures, spot / distant / projection lights, volumes,
+metal / uber materials, textures, projection / goniometric lights, volumes,
 instancing, animated transforms, image-file radiance maps, non-box filters,
 non-LD samplers, the Metropolis renderer) raises `UnsupportedFeature` naming it
 with file:line -- never a silent approximation.
@@ -676,8 +676,39 @@ class DartRay:
             l2w = Transform.Translate(*frm) * self.ctm
             self.lights.append(core.PointLight(l2w.m, (I.astype(np.float64) * sc.astype(np.float64)).astype(np.float32)))
             return
+        if name == "distant":                 # distant_light.dart:91-98
+            L = ps.findOneSpectrum("L", (1.0, 1.0, 1.0))
+            sc = ps.findOneSpectrum("scale", (1.0, 1.0, 1.0))
+            frm, to = ps.findPoint("from"), ps.findPoint("to")
+            frm = np.zeros(3, np.float32) if frm is None or len(frm) != 1 else frm[0]
+            to = np.array([0, 0, 1], np.float32) if to is None or len(to) != 1 else to[0]
+            d = (frm.astype(np.float64) - to.astype(np.float64)).astype(np.float32)
+            self.lights.append(core.DistantLight(self.ctm.m, (L.astype(np.float64) * sc.astype(np.float64)).astype(np.float32), d))
+            return
+        if name == "spot":                    # spot_light.dart:100-125
+            I = ps.findOneSpectrum("I", (1.0, 1.0, 1.0))
+            sc = ps.findOneSpectrum("scale", (1.0, 1.0, 1.0))
+            coneangle = ps.findOneFloat("coneangle", 30.0)
+            conedelta = ps.findOneFloat("conedeltaangle", 5.0)
+            frm, to = ps.findPoint("from"), ps.findPoint("to")
+            frm = np.zeros(3, np.float32) if frm is None or len(frm) != 1 else frm[0]
+            to = np.array([0, 0, 1], np.float32) if to is None or len(to) != 1 else to[0]
+            d = core._normalize((to.astype(np.float64) - frm.astype(np.float64)).astype(np.float32)).astype(np.float64)
+            if abs(d[0]) > abs(d[1]):         # Vector.CoordinateSystem (vector.dart:198-214)
+                inv = 1.0 / math.sqrt(d[0] * d[0] + d[2] * d[2])
+                du = _f32([-d[2] * inv, 0.0, d[0] * inv]).astype(np.float64)
+            else:
+                inv = 1.0 / math.sqrt(d[1] * d[1] + d[2] * d[2])
+                du = _f32([0.0, d[2] * inv, -d[1] * inv]).astype(np.float64)
+            dv = _f32(np.cross(d, du)).astype(np.float64)
+            dirToZ = Transform(_mat([[du[0], du[1], du[2], 0], [dv[0], dv[1], dv[2], 0], [d[0], d[1], d[2], 0], [0, 0, 0, 1]]))
+            l2w = self.ctm * Transform.Translate(float(frm[0]), float(frm[1]), float(frm[2])) * Transform.Inverse(dirToZ)
+            self.lights.append(core.SpotLight(l2w.m, (I.astype(np.float64) * sc.astype(np.float64)).astype(np.float32), coneangle,
+                                              coneangle - conedelta, l2w.mInv))
+            return
         if name != "infinite":
-            raise UnsupportedFeature(f"LightSource \"{name}\": only 'point' and 'infinite' are on the path (besides area lights)")
+            raise UnsupportedFeature(f"LightSource \"{name}\": only 'point', 'spot', 'distant' and 'infinite' are on the path "
+                                     "(besides area lights)")
         L = ps.findOneSpectrum("L", (1.0, 1.0, 1.0))          # infinite_area_light.dart:309-316
         sc = ps.findOneSpectrum("scale", (1.0, 1.0, 1.0))
         nsamples = ps.findOneInt("nsamples", 1)
@@ -894,10 +925,10 @@ class DartRay:
 
     # -- conveniences for tests / tools ---------------------------------------
     def pointLights(self):
-        """[(PointLight, index of the first primitive whose area light follows it in Scene.lights, or None)]."""
+        """Delta lights: [(PointLight | SpotLight | DistantLight, index of the first primitive whose area light follows it in Scene.lights, or None)]."""
         out = []
         for k, l in enumerate(self.sceneLights):
-            if not isinstance(l, core.PointLight):
+            if not isinstance(l, (core.PointLight, core.DistantLight)):
                 continue
             before = None
             for i, gp in enumerate(self.scenePrimitives):

@@ -64,6 +64,8 @@ typedef struct DrMaterial {
 #define DR_LIGHT_DIFFUSE_AREA 0 /* DiffuseAreaLight (lib/lights/diffuse_area_light.dart) */
 #define DR_LIGHT_INFINITE 1     /* InfiniteAreaLight (lib/lights/infinite_area_light.dart) */
 #define DR_LIGHT_POINT 2        /* PointLight (lib/lights/point_light.dart): a delta light */
+#define DR_LIGHT_SPOT 3         /* SpotLight (lib/lights/spot_light.dart): a delta light */
+#define DR_LIGHT_DISTANT 4      /* DistantLight (lib/lights/distant_light.dart): a delta light */
 
 /* One entry of Scene.lights.  kind DR_LIGHT_DIFFUSE_AREA: DiffuseAreaLight + its
  * ShapeSet (diffuse_area_light.dart:36-43, lib/core/light/shape_set.dart:24-51);
@@ -78,8 +80,11 @@ typedef struct DrAreaLight {
   uint32_t ntris;
   uint32_t kind;
   uint32_t env_index; /* into env_maps */
-  float position[3];  /* DR_LIGHT_POINT: PointLight.lightPos = lightToWorld(0,0,0) (point_light.dart:36-39); L = intensity */
+  float position[3];  /* DR_LIGHT_POINT / _SPOT: lightPos = lightToWorld(0,0,0) (point_light.dart:36-39); L = intensity.
+                       * DR_LIGHT_DISTANT: lightDir = normalize(lightToWorld(dir)) (distant_light.dart:38-42); L = radiance */
   float pad;
+  float world_to_light[16];  /* DR_LIGHT_SPOT: Light.worldToLight (falloff is evaluated in light space, spot_light.dart:54-70) */
+  double cone_width, cone_falloff_start;  /* DR_LIGHT_SPOT: total width and falloff start, degrees (spot_light.dart:42-48) */
 } DrAreaLight;
 
 /* InfiniteAreaLight.radianceMap level 0 (MIPMap.pyramid[0], lib/core/mipmap.dart:139,

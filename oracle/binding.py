@@ -36,7 +36,8 @@ class OrcSceneDesc(C.Structure):
                 ("env_L", C.c_float * 3), ("env_l2w", C.c_float * 16), ("env_w2l", C.c_float * 16),
                 ("env_nsamples", C.c_int32), ("env_before_mesh", C.c_int32),
                 ("npoint_lights", C.c_int32), ("point_pos", C.c_void_p), ("point_intensity", C.c_void_p),
-                ("point_before_mesh", C.c_void_p)]
+                ("point_before_mesh", C.c_void_p), ("point_kind", C.c_void_p), ("spot_w2l", C.c_void_p),
+                ("spot_angles", C.c_void_p)]
 
 
 class OrcRenderDesc(C.Structure):
@@ -181,9 +182,14 @@ class OracleScene:
             pos = np.ascontiguousarray([p.lightPos for p, _ in points], np.float32)
             inten = np.ascontiguousarray([p.intensity for p, _ in points], np.float32)
             before = np.ascontiguousarray([-1 if b is None else int(b) for _, b in points], np.int32)
-            self._keep += [pos, inten, before]
+            # 2 point, 3 spot (has .worldToLight, .width, .fall), 4 distant (has .lightDir; carried in lightPos)
+            kind = np.ascontiguousarray([3 if hasattr(p, "width") else (4 if hasattr(p, "lightDir") else 2) for p, _ in points], np.int32)
+            w2l = np.ascontiguousarray([np.asarray(getattr(p, "worldToLight", np.eye(4)), np.float32).reshape(-1) for p, _ in points], np.float32)
+            ang = np.ascontiguousarray([(getattr(p, "width", 0.0), getattr(p, "fall", 0.0)) for p, _ in points], np.float64)
+            self._keep += [pos, inten, before, kind, w2l, ang]
             d.npoint_lights = len(points)
             d.point_pos, d.point_intensity, d.point_before_mesh = pos.ctypes.data, inten.ctypes.data, before.ctypes.data
+            d.point_kind, d.spot_w2l, d.spot_angles = kind.ctypes.data, w2l.ctypes.data, ang.ctypes.data
         if env is not None:
             tex = np.ascontiguousarray(env.texels, np.float32)
             self._keep.append(tex)

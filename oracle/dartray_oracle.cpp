@@ -356,8 +356,11 @@ struct Counters {
 };
 
 struct Light {  // DiffuseAreaLight (diffuse_area_light.dart:36-70) + ShapeSet (shape_set.dart:24-51), or the InfiniteAreaLight
-  int kind = 0;  // 0 = diffuse area light, 1 = infinite area light (Scene::env), 2 = point light (point_light.dart)
-  V lightPos{0, 0, 0};  // PointLight: lightToWorld(0,0,0); Lemit holds the intensity
+  int kind = 0;  // 0 = diffuse area light, 1 = infinite area light (Scene::env), 2 = point light (point_light.dart),
+                 // 3 = spot light (spot_light.dart), 4 = distant light (distant_light.dart)
+  V lightPos{0, 0, 0};  // Point / Spot: lightToWorld(0,0,0); Distant: lightDir.  Lemit holds the intensity / radiance
+  float w2l[16];        // Spot: worldToLight
+  D cosTotalWidth = 0, cosFalloffStart = 0;
   S Lemit;
   int nSamples;
   std::vector<int> shapes;  // indices into Scene::lightTris
@@ -1673,14 +1676,33 @@ static S EstimateDirect(const Scene& sc, int lightIdx, const V& p, const V& n, c
   D lightPdf = 0.0, bsdfPdf = 0.0;
   Ray vr;
   S Li;
-  if (light.kind == 2) {
-    // PointLight.sampleLAtPoint (point_light.dart:41-47); a delta light: no MIS, no BSDF-sampling half
-    // (integrator.dart:146-150,153)
-    wi = vnormalize(vsub(light.lightPos, p));
+  if (light.kind >= 2) {
+    // delta lights: no MIS, no BSDF-sampling half (integrator.dart:146-150,153)
     lightPdf = 1.0;
-    D dist = vlen(vsub(light.lightPos, p));  // VisibilityTester.setSegment(p, eps, lightPos, 0)
-    vr = Ray{p, vdiv(vsub(light.lightPos, p), dist), rayEpsilon, dist * (1.0 - 0.0), 0.0, 0};
-    Li = sdivD(light.Lemit, vlen2(vsub(light.lightPos, p)));
+    if (light.kind == 4) {
+      // DistantLight.sampleLAtPoint (distant_light.dart:54-61): visibility.setRay(p, eps, wi)
+      wi = light.lightPos;
+      vr = Ray{p, wi, rayEpsilon, kInf, 0.0, 0};
+      Li = light.Lemit;
+    } else {
+      // PointLight.sampleLAtPoint (point_light.dart:41-47) / SpotLight (spot_light.dart:78-85)
+      wi = vnormalize(vsub(light.lightPos, p));
+      D dist = vlen(vsub(light.lightPos, p));  // VisibilityTester.setSegment(p, eps, lightPos, 0)
+      vr = Ray{p, vdiv(vsub(light.lightPos, p), dist), rayEpsilon, dist * (1.0 - 0.0), 0.0, 0};
+      if (light.kind == 3) {  // intensity * falloff(-wi) / DistanceSquared (spot_light.dart:54-70)
+        V wl = vnormalize(xfVector(light.w2l, vneg(wi)));
+        D costheta = wl.z, fo;
+        if (costheta < light.cosTotalWidth) fo = 0.0;
+        else if (costheta > light.cosFalloffStart) fo = 1.0;
+        else {
+          D delta = (costheta - light.cosTotalWidth) / (light.cosFalloffStart - light.cosTotalWidth);
+          fo = delta * delta * delta * delta;
+        }
+        Li = sdivD(smulD(light.Lemit, fo), vlen2(vsub(light.lightPos, p)));
+      } else {
+        Li = sdivD(light.Lemit, vlen2(vsub(light.lightPos, p)));
+      }
+    }
     if (lightPdf > 0.0 && !sblack(Li)) {
       S f = bsdf.f(wo, wi, flags);
       if (!sblack(f) && !bvh_intersectP(sc, vr)) {
@@ -2122,6 +2144,11 @@ struct OrcSceneDesc {
   const float* point_pos;        // [n][3]
   const float* point_intensity;  // [n][3]
   const int32_t* point_before_mesh;
+  // kind per entry (null: all point lights): 2 point, 3 spot, 4 distant (point_pos then holds lightDir);
+  // spots: worldToLight [n][16] and (width, falloff start) in degrees [n][2]
+  const int32_t* point_kind;
+  const float* spot_w2l;
+  const double* spot_angles;
 };
 struct OrcNode {  // the 32-byte marshalled node of SURVEY.md Appendix F
   float bmin[3], bmax[3];
@@ -2206,7 +2233,12 @@ void* orc_scene_create(const OrcSceneDesc* d) {
       if (before < 0 || before >= d->nmeshes) before = d->nmeshes;
       if (before != m) continue;
       Light L;
-      L.kind = 2;
+      L.kind = d->point_kind ? d->point_kind[i] : 2;
+      if (L.kind == 3) {  // spot_light.dart:42-48
+        memcpy(L.w2l, d->spot_w2l + 16 * (size_t)i, sizeof(L.w2l));
+        L.cosTotalWidth = std::cos((M_PI / 180.0) * d->spot_angles[2 * i]);
+        L.cosFalloffStart = std::cos((M_PI / 180.0) * d->spot_angles[2 * i + 1]);
+      }
       L.Lemit = rgb(d->point_intensity[3 * i], d->point_intensity[3 * i + 1], d->point_intensity[3 * i + 2]);
       L.lightPos = V{(D)d->point_pos[3 * i], (D)d->point_pos[3 * i + 1], (D)d->point_pos[3 * i + 2]};
       L.nSamples = 1;

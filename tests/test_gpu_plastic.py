@@ -27,6 +27,7 @@ AttributeBegin
   LightSource "point" "color I" [400 380 350]
 AttributeEnd
 LightSource "point" "color I" [60 60 90] "point from" [6 -6 -4] "color scale" [0.5 0.5 0.5]
+{extra}
 AttributeBegin
   Material "plastic" "color Kd" [0.5 0.3 0.8] "color Ks" [0.2 0.2 0.2] "float roughness" [0.1]
   Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [10 -10 -10 -10 -10 -10 -10 -10 10 10 -10 10]
@@ -46,11 +47,21 @@ WorldEnd
 '''
 
 
+EXTRA = '''
+AttributeBegin
+  Rotate 20 0 0 1
+  LightSource "spot" "color I" [300 200 100] "point from" [-6 8 -6] "point to" [0 -8 2] "float coneangle" [25] "float conedeltaangle" [8]
+AttributeEnd
+LightSource "distant" "color L" [0.6 0.7 1.0] "point from" [2 9 -8] "point to" [0 0 0]
+'''
+
+
 @pytest.mark.parametrize("integ,ns", [("path", 1), ("directlighting", 1), ("directlighting", 4)])
 def test_plastic_and_point_lights_render_like_the_oracle(ob, gpu, integ, ns):
-    api = pbrt.loads(SCENE.format(integ=integ, ns=ns), render=True)
+    api = pbrt.loads(SCENE.format(integ=integ, ns=ns, extra=EXTRA if ns == 1 else ""), render=True)
     out, r = api.outputImage, api.rendererObject
-    assert [type(l).__name__ for l in api.sceneLights] == ["DiffuseAreaLight", "PointLight", "PointLight"]
+    assert [type(l).__name__ for l in api.sceneLights][:3] == ["DiffuseAreaLight", "PointLight", "PointLight"]
+    assert len(api.sceneLights) == (5 if ns == 1 else 3)
     osc = ob.OracleScene(api.scenePrimitives, points=api.pointLights())
     osc.counters(reset=True)
     ref = osc.render(ob.render_desc(r, sampler_mode=1))
@@ -69,7 +80,7 @@ def test_smooth_plastic_mesh_serial_stream(ob, gpu):
     """The structure of the bundled teapot-area-light.pbrt: a smooth-shaded (per-vertex N) plastic mesh under a disk
     emitter and a point light at the eye, DirectLighting; also through the reference's serial RNG stream."""
     from dartray_amd import core
-    txt = SCENE.format(integ="directlighting", ns=2).replace('[40]', '[24]').replace('[30]', '[18]')
+    txt = SCENE.format(integ="directlighting", ns=2, extra="").replace('[40]', '[24]').replace('[30]', '[18]')
     api = pbrt.loads(txt)
     xf = pbrt.Transform.Translate(4, -6, 2) * pbrt.Transform.Rotate(-90, 1, 0, 0)
     ball = core.GeometricPrimitive(uv_sphere(3.0, 16, 8, xf, normals=True), core.PlasticMaterial((.5, .3, .8), (.2, .2, .2), .1))

@@ -178,3 +178,34 @@ def test_plastic_reduces_to_matte_and_adds_a_highlight(ob):
         F = (rpar ** 2 + rper ** 2) / 2
     spec = 0.5 * D * G * F / (4 * cos * cos) * (I / 25.0) * cos
     assert abs((Lp - Lm) / spec - 1.0) < 0.02, (Lp - Lm, spec)
+
+
+def test_spot_and_distant_lights_closed_form(ob):
+    """DistantLight: L cos(theta) Kd/pi on a matte floor, any distance; SpotLight: I/d^2 inside the falloff start,
+    the smooth step delta^4 between falloff start and the cone edge, 0 outside (spot_light.dart:54-70)."""
+    kd = 0.5
+    floor = _quad((-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50), core.MatteMaterial((kd, kd, kd)))
+
+    def lit(light, look=(0, 0, 0)):
+        film = core.ImageFilm(2, 2)
+        cam = core.PerspectiveCamera.lookAt((look[0], 8.0, look[2] + 0.001), look, (0, 0, 1), 0.1, film)
+        r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 4), cam, core.DirectLightingIntegrator(0, 5), core.EmissionIntegrator())
+        return ob.OracleScene([floor], points=[(light, None)]).render(ob.render_desc(r, sampler_mode=1))["rgb"].mean()
+
+    # light arriving from 60 degrees off the normal: wi = lightDir = normalize(dir)
+    dl = core.DistantLight(None, (3.0, 3.0, 3.0), (np.sin(np.radians(60)), np.cos(np.radians(60)), 0.0))
+    assert abs(lit(dl) / (kd / np.pi * 3.0 * 0.5) - 1.0) < 1e-4
+    # spot at height 4 looking straight down (light space +z -> world -y), cone 30 degrees, falloff from 20
+    api = pbrt.loads('WorldBegin\nLightSource "spot" "color I" [50 50 50] "point from" [0 4 0] "point to" [0 0 0] '
+                     '"float coneangle" [30] "float conedeltaangle" [10]\nWorldEnd')
+    sp = api.sceneLights[0]
+    assert np.allclose(sp.lightPos, [0, 4, 0]) and sp.width == 30.0 and sp.fall == 20.0
+    assert abs(lit(sp) / (kd / np.pi * 50.0 / 16.0) - 1.0) < 1e-4                      # on the axis
+    for ang in (10.0, 25.0, 35.0):
+        x = 4.0 * np.tan(np.radians(ang))
+        d2 = 16.0 + x * x
+        ct, cw, cf = np.cos(np.radians(ang)), np.cos(np.radians(30.0)), np.cos(np.radians(20.0))
+        fo = 1.0 if ct > cf else (0.0 if ct < cw else ((ct - cw) / (cf - cw)) ** 4)
+        want = kd / np.pi * 50.0 * fo / d2 * ct
+        got = lit(sp, look=(x, 0, 0))
+        assert abs(got - want) <= 1e-2 * max(want, 1e-3), (ang, got, want)

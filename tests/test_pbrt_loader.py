@@ -179,7 +179,7 @@ def test_include_gz_and_relative_paths(tmp_path):
     ('Material "uber"\nShape "trianglemesh" ' + QUAD, 'Material "uber"'),
     ('Material "mirror" "texture Kr" "checks"\nShape "trianglemesh" ' + QUAD, "bound to a texture"),
     ('Texture "t" "color" "imagemap" "string filename" "x.png"', "Texture"),
-    ('LightSource "spot" "color I" [1 1 1]', 'LightSource "spot"'),
+    ('LightSource "goniometric" "color I" [1 1 1]', 'LightSource "goniometric"'),
     ('LightSource "infinite" "string mapname" ["sky.exr"]', "image decoders"),
     ('Volume "homogeneous"', "Volume"),
     ('ObjectBegin "a"', "instancing"),
