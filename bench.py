@@ -36,9 +36,14 @@ def main():
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipelines", type=int, default=1, choices=[1, 2],
+                    help="2: odd batches run on a second stream / workspace (kernel tails and memory-bound shading overlap "
+                         "the ALU-bound traversal: +10 %% on C2) -- per-kernel event times then overlap, so the roofline "
+                         "object is only meaningful with 1")
     ap.add_argument("--cpu-pixels", type=int, default=96, help="cpu baseline: side of the strided pixel grid")
     args = ap.parse_args()
 
+    os.environ["DARTRAY_PIPELINES"] = str(args.pipelines)  # read once by the library
     import numpy as np
     import torch
     from dartray_amd import _abi, scenes, dist as drdist
@@ -121,7 +126,7 @@ def main():
                                         "C5": "8M-triangle courtyard, 8 area lights + env map"}[args.config],
                           renderer.surfaceIntegrator.maxDepth, args.res, args.res, spp),
                        "triangles": int(len(scene.aggregate.tri_idx)), "bvh_nodes": int(len(scene.aggregate.nodes)),
-                       "samples_per_step": samples_per_step, "parallelism": "tiles32x%d" % world},
+                       "samples_per_step": samples_per_step, "parallelism": "tiles32x%d" % world, "pipelines": args.pipelines},
             "roofline": {"bound": "hbm", "kernel": "k_trace<0> (closest-hit BVH traversal)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic,

@@ -93,6 +93,10 @@ struct DrScene {
   int dlNBlocks = 0, dlNStages = 0, dlNFloats = 0, dlN1D = 0;
   bool dlMulti = false;
   Workspace ws;
+  // optional second pipeline (DARTRAY_PIPELINES=2): odd batches run on their own stream and workspace so that
+  // one batch's kernel tails / memory-bound shading overlap the other's ALU-bound traversal
+  Workspace ws2;
+  hipStream_t s2 = nullptr;
   // stats of the last render
   DrRenderStats stats;
   struct TraceEv { hipEvent_t e0, e1; int any; };  // any: 0 closest, 1 any-hit, 2 shade, 3 sample gen + raygen, 4 film
@@ -112,6 +116,7 @@ struct DrScene {
   }
   ~DrScene() {
     for (auto e : eventPool) (void)hipEventDestroy(e);
+    if (s2) (void)hipStreamDestroy(s2);
   }
 };
 
@@ -196,12 +201,12 @@ int traceGrid() {
   return g_numCU * std::max(1, std::min(perCU, 8));
 }
 
-int ensureSpill(DrScene* sc, int grid) {
+int ensureSpill(DrScene* sc, Workspace& w, int grid) {
   // deepest stack == tree depth; the v3 kernel keeps 16 (reference, E) pairs in LDS, v2 24 references
   if (sc->bvhDepth != 0 && sc->bvhDepth <= 16) return DR_OK;
   size_t need = (size_t)grid * DR_TRACE_BLOCK * (DR_MAX_STACK - 16) * 2;
-  HIP_TRY(sc->ws.spill.alloc(need));
-  sc->ws.spillGrid = grid;
+  HIP_TRY(w.spill.alloc(need));
+  w.spillGrid = grid;
   return DR_OK;
 }
 
@@ -245,8 +250,7 @@ void getSubWindow(int w, int h, int num, int count, int ext[4]) {
   ext[3] = std::min((int)std::floor(lerp(ty1, 0, h)), h);
 }
 
-int allocWorkspace(DrScene* sc, uint32_t cap, int nFloats, int maxTail, bool needTail) {
-  Workspace& w = sc->ws;
+int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, int nFloats, int maxTail, bool needTail) {
   if (cap > w.cap || nFloats > w.nFloats) {
     uint32_t c = std::max(cap, w.cap);
     int nf = std::max(nFloats, w.nFloats);
@@ -900,7 +904,7 @@ int dr_intersect(DrScene* sc, const DrRay* rays, int64_t n, DrHit* out, int32_t 
   if (n <= 0) return DR_OK;
   if (n >= (1ll << 31)) return fail(DR_ERR_INVALID, "too many rays in one call");
   int grid = std::min<int64_t>(traceGrid(), (n + DR_TRACE_BLOCK - 1) / DR_TRACE_BLOCK);
-  int rc = ensureSpill(sc, traceGrid());
+  int rc = ensureSpill(sc, sc->ws, traceGrid());
   if (rc) return rc;
   DevBuf<DrRay> dR;
   DevBuf<DrHit> dH;
@@ -1009,25 +1013,43 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const uint32_t pixPerBatch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(npixTotal, maxSlots / spp));
   const uint32_t cap = pixPerBatch * (uint32_t)spp;
   (void)totalSlots;
-  int rc = allocWorkspace(sc, cap, rp.nFloats, rd->max_tail, hostBuf && needTail > 0);
+  int rc = allocWorkspace(sc, sc->ws, cap, rp.nFloats, rd->max_tail, hostBuf && needTail > 0);
   if (rc) return rc;
   const int tgrid = traceGrid();
-  rc = ensureSpill(sc, tgrid);
+  rc = ensureSpill(sc, sc->ws, tgrid);
   if (rc) return rc;
-  Workspace& w = sc->ws;
-  HIP_TRY(w.pix.alloc(npixTotal));
-  HIP_TRY(hipMemcpyAsync(w.pix.p, pixels.data(), npixTotal * sizeof(int2), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(w.filterTable.p, rd->film.filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s));
+  static const int nPipesEnv = getenv("DARTRAY_PIPELINES") ? atoi(getenv("DARTRAY_PIPELINES")) : 1;
+  const bool twoPipes = nPipesEnv >= 2 && !hostBuf && npixTotal > pixPerBatch;
+  if (twoPipes) {
+    rc = allocWorkspace(sc, sc->ws2, cap, rp.nFloats, rd->max_tail, false);
+    if (rc) return rc;
+    rc = ensureSpill(sc, sc->ws2, tgrid);
+    if (rc) return rc;
+    if (!sc->s2) HIP_TRY(hipStreamCreateWithFlags(&sc->s2, hipStreamNonBlocking));
+  }
+  HIP_TRY(sc->ws.pix.alloc(npixTotal));
+  HIP_TRY(hipMemcpyAsync(sc->ws.pix.p, pixels.data(), npixTotal * sizeof(int2), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(sc->ws.filterTable.p, rd->film.filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s));
   // pixels is a local: the async copy above must complete before it goes out of scope
   HIP_TRY(hipStreamSynchronize(s));
+  hipStream_t const callerStream = s;
+  if (twoPipes) {  // everything enqueued on the caller's stream so far (e.g. the film clear) precedes the second pipeline
+    hipEvent_t ev = sc->getEvent();
+    HIP_TRY(hipEventRecord(ev, callerStream));
+    HIP_TRY(hipStreamWaitEvent(sc->s2, ev, 0));
+  }
+  size_t batchIndex = 0;
   const int sgrid = g_numCU * 2;  // 512-thread workgroups, grid-stride over the active list
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
   if (4 * nStages + 8 > 1024 || 8 * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
 
-  for (size_t p0 = 0; p0 < npixTotal; p0 += pixPerBatch) {
+  for (size_t p0 = 0; p0 < npixTotal; p0 += pixPerBatch, ++batchIndex) {
+    const bool second = twoPipes && (batchIndex & 1);
+    Workspace& w = second ? sc->ws2 : sc->ws;
+    s = second ? sc->s2 : callerStream;
     const uint32_t np = (uint32_t)std::min<size_t>(pixPerBatch, npixTotal - p0);
     const uint32_t nslots = np * (uint32_t)spp;
-    BatchState st = makeState(w, w.pix.p + p0, nslots, hostBuf && needTail > 0);
+    BatchState st = makeState(w, sc->ws.pix.p + p0, nslots, hostBuf && needTail > 0);
     HIP_TRY(hipMemsetAsync(w.counters.p, 0, N_COUNTERS * sizeof(uint32_t), s));
     auto timed = [&](int kind, hipEvent_t e0) {
       hipEvent_t e1 = sc->getEvent();
@@ -1081,11 +1103,17 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     }
     hipEvent_t evF = sc->getEvent();
     (void)hipEventRecord(evF, s);
-    launch_film(rp, st, w.filterTable.p, np, (float*)film_dev, s);
+    launch_film(rp, st, sc->ws.filterTable.p, np, (float*)film_dev, s);
     timed(4, evF);
     HIP_TRY(hipGetLastError());
     sc->stats.batches++;
     if (hostBuf) HIP_TRY(hipStreamSynchronize(s));  // host buffers of the next batch reuse the staging area
+  }
+  s = callerStream;
+  if (twoPipes) {  // the caller's stream continues after both pipelines
+    hipEvent_t ev = sc->getEvent();
+    HIP_TRY(hipEventRecord(ev, sc->s2));
+    HIP_TRY(hipStreamWaitEvent(callerStream, ev, 0));
   }
   HIP_TRY(hipEventRecord(evStop, s));
   sc->stats.camera_samples += (uint64_t)npixTotal * spp;

@@ -271,6 +271,30 @@ def test_alternative_traversal_kernels_are_bit_exact_too(impl):
     assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
 
 
+def test_two_pipelines_render_the_same_film():
+    """DARTRAY_PIPELINES=2 (odd batches on a second stream and workspace) only changes scheduling: a render that
+    needs several batches gives the same film as the single-pipeline run."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from dartray_amd import scenes\n"
+        "prims, mk = scenes.config('C2', xres=600, yres=500, spp=128, blob=(60, 30))\n"   # 3e5 pixels x 128 spp: 3 batches
+        "r = mk(); out = r.render(scenes.make_scene(prims))\n"
+        "assert r.last_stats['batches'] >= 3, r.last_stats['batches']\n"
+        "np.save(sys.argv[1], out.film)\n" % ROOT)
+    films = []
+    for pipes in ("1", "2"):
+        path = os.path.join(ROOT, "gpurun_out", "film_p%s.npy" % pipes)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        env = dict(os.environ, DARTRAY_PIPELINES=pipes)
+        res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=280)
+        assert res.returncode == 0, res.stderr[-2000:]
+        films.append(np.load(path))
+        os.remove(path)
+    assert np.array_equal(films[0], films[1])
+
+
 def test_invalid_arguments_raise(gpu):
     prims, mk = scenes.config("C1")
     scene = scenes.make_scene(prims)
