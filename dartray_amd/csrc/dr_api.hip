@@ -1008,7 +1008,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     if (p.x >= rp.left && p.x < rp.left + rp.width && p.y >= rp.top && p.y < rp.top + rp.height) filmSamples += spp;
 
   // ---- workspace ----
-  const uint64_t maxSlots = 1ull << 24;
+  static const int slotBits = getenv("DARTRAY_BATCH_BITS") ? std::min(28, std::max(16, atoi(getenv("DARTRAY_BATCH_BITS")))) : 28;
+  const uint64_t maxSlots = 1ull << slotBits;  // camera samples in flight per batch (about 250 B of path state each)
   const uint64_t totalSlots = (uint64_t)npixTotal * spp;
   const uint32_t pixPerBatch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(npixTotal, maxSlots / spp));
   const uint32_t cap = pixPerBatch * (uint32_t)spp;

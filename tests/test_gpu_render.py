@@ -287,7 +287,7 @@ def test_two_pipelines_render_the_same_film():
     for pipes in ("1", "2"):
         path = os.path.join(ROOT, "gpurun_out", "film_p%s.npy" % pipes)
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        env = dict(os.environ, DARTRAY_PIPELINES=pipes)
+        env = dict(os.environ, DARTRAY_PIPELINES=pipes, DARTRAY_BATCH_BITS="24")  # 2^24 samples per batch => 3 batches
         res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=280)
         assert res.returncode == 0, res.stderr[-2000:]
         films.append(np.load(path))
