@@ -115,6 +115,7 @@ struct DrScene {
     return eventPool[eventsUsed++];
   }
   ~DrScene() {
+    (void)hipDeviceSynchronize();  // nothing of this scene may still be in flight when its buffers and events go away
     for (auto e : eventPool) (void)hipEventDestroy(e);
     if (s2) (void)hipStreamDestroy(s2);
   }
@@ -1009,17 +1010,30 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
 
   // ---- workspace ----
   static const int slotBits = getenv("DARTRAY_BATCH_BITS") ? std::min(28, std::max(16, atoi(getenv("DARTRAY_BATCH_BITS")))) : 28;
-  const uint64_t maxSlots = 1ull << slotBits;  // camera samples in flight per batch (about 250 B of path state each)
-  const uint64_t totalSlots = (uint64_t)npixTotal * spp;
+  static const int nPipesEnv = getenv("DARTRAY_PIPELINES") ? atoi(getenv("DARTRAY_PIPELINES")) : 1;
+  uint64_t maxSlots = 1ull << slotBits;  // camera samples in flight per batch
+  {
+    // path state per camera sample: the sample vector + 172 B of ray / hit / NEE state and queues (+ the RNG tail in
+    // host-buffer mode).  The default batch (2^28) takes 86 GB of a 288 GB MI355X; on a device with less free
+    // memory the batch shrinks instead of failing (results do not depend on the batch size).
+    const uint64_t perSlot = (uint64_t)rp.nFloats * 4 + 172 + (hostBuf && needTail > 0 ? (uint64_t)rd->max_tail * 8 : 0) +
+                             (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0);
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)sc->ws.nFloats * 4 + 172) +
+                            (uint64_t)sc->ws2.cap * ((uint64_t)sc->ws2.nFloats * 4 + 172);
+      const uint64_t budget = (uint64_t)(0.9 * (double)freeB) + have;
+      const uint64_t pipes = nPipesEnv >= 2 && !hostBuf ? 2 : 1;
+      while (maxSlots > (1ull << 16) && std::min<uint64_t>(maxSlots, (uint64_t)npixTotal * spp) * perSlot * pipes > budget) maxSlots >>= 1;
+    }
+  }
   const uint32_t pixPerBatch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(npixTotal, maxSlots / spp));
   const uint32_t cap = pixPerBatch * (uint32_t)spp;
-  (void)totalSlots;
   int rc = allocWorkspace(sc, sc->ws, cap, rp.nFloats, rd->max_tail, hostBuf && needTail > 0);
   if (rc) return rc;
   const int tgrid = traceGrid();
   rc = ensureSpill(sc, sc->ws, tgrid);
   if (rc) return rc;
-  static const int nPipesEnv = getenv("DARTRAY_PIPELINES") ? atoi(getenv("DARTRAY_PIPELINES")) : 1;
   const bool twoPipes = nPipesEnv >= 2 && !hostBuf && npixTotal > pixPerBatch;
   if (twoPipes) {
     rc = allocWorkspace(sc, sc->ws2, cap, rp.nFloats, rd->max_tail, false);
