@@ -57,15 +57,15 @@ struct DevBuf {
 struct Workspace {
   uint32_t cap = 0;
   int nFloats = 0, maxTail = 0;
-  DevBuf<float> sv, ro, ro0, rd, beta, L, betaNee, shD, Ld1, misD, Ld2;
-  DevBuf<double> rtmin, ht, shTmax, tail;
-  DevBuf<int32_t> hprim, shOcc, misLight, misPrim;
-  DevBuf<uint32_t> flags, activeA, activeB, closestQ, anyQ, counters, spill;
+  DevBuf<float> tiles;  // the tiled path state (see BatchState in dr_kernels.h): cap/64 tiles of 64*(41+nFloats) words
+  DevBuf<double> tail;
+  DevBuf<uint32_t> activeA, activeB, closestQ, anyQ, counters, spill;
   DevBuf<int2> pix;
   DevBuf<float> filterTable, aosSamples;
   int spillGrid = 0;
 };
 
+#define DR_STATE_WORDS 41  // 4-byte words of fixed path state per slot: 3 f64 + 10 3-vectors + 5 i32
 #define N_COUNTERS 4096  // [0,1024): stage queue counts; [1024,4096): 8 per-XCD work counters per trace launch
 
 }  // namespace
@@ -252,27 +252,11 @@ void getSubWindow(int w, int h, int num, int count, int ext[4]) {
 }
 
 int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, int nFloats, int maxTail, bool needTail) {
+  cap = (cap + 63u) & ~63u;  // whole tiles
   if (cap > w.cap || nFloats > w.nFloats) {
     uint32_t c = std::max(cap, w.cap);
     int nf = std::max(nFloats, w.nFloats);
-    HIP_TRY(w.sv.alloc((size_t)nf * c));
-    HIP_TRY(w.ro.alloc(3 * (size_t)c));
-    HIP_TRY(w.rd.alloc(3 * (size_t)c));
-    HIP_TRY(w.beta.alloc(3 * (size_t)c));
-    HIP_TRY(w.L.alloc(3 * (size_t)c));
-    HIP_TRY(w.betaNee.alloc(3 * (size_t)c));
-    HIP_TRY(w.shD.alloc(3 * (size_t)c));
-    HIP_TRY(w.Ld1.alloc(3 * (size_t)c));
-    HIP_TRY(w.misD.alloc(3 * (size_t)c));
-    HIP_TRY(w.Ld2.alloc(3 * (size_t)c));
-    HIP_TRY(w.rtmin.alloc(c));
-    HIP_TRY(w.ht.alloc(c));
-    HIP_TRY(w.shTmax.alloc(c));
-    HIP_TRY(w.hprim.alloc(c));
-    HIP_TRY(w.shOcc.alloc(c));
-    HIP_TRY(w.misLight.alloc(c));
-    HIP_TRY(w.misPrim.alloc(c));
-    HIP_TRY(w.flags.alloc(c));
+    HIP_TRY(w.tiles.alloc((size_t)(c / 64) * 64 * (size_t)(DR_STATE_WORDS + nf)));
     HIP_TRY(w.activeA.alloc(c));
     HIP_TRY(w.activeB.alloc(c));
     HIP_TRY(w.closestQ.alloc(2 * (size_t)c));
@@ -280,7 +264,6 @@ int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, int nFloats, int max
     w.cap = c;
     w.nFloats = nf;
   }
-  if ((!sc->hostQuads.empty() || sc->d.srec) && w.ro0.n < 3 * (size_t)w.cap) HIP_TRY(w.ro0.alloc(3 * (size_t)w.cap));
   if (needTail && ((size_t)w.cap * maxTail > w.tail.n)) HIP_TRY(w.tail.alloc((size_t)w.cap * maxTail));
   w.maxTail = maxTail;
   HIP_TRY(w.counters.alloc(N_COUNTERS));
@@ -292,27 +275,36 @@ BatchState makeState(Workspace& w, const int2* pix, uint32_t nslots, bool useTai
   BatchState st;
   st.cap = w.cap;
   st.nslots = nslots;
+  st.tileStride = 64u * (uint32_t)(DR_STATE_WORDS + w.nFloats);
+  st.padts = 0;
   st.pix = pix;
-  st.sv = w.sv.p;
   st.tail = useTail ? w.tail.p : nullptr;
-  st.ro = w.ro.p;
-  st.ro0 = w.ro0.p;
-  st.rd = w.rd.p;
-  st.rtmin = w.rtmin.p;
-  st.hprim = w.hprim.p;
-  st.ht = w.ht.p;
-  st.beta = w.beta.p;
-  st.L = w.L.p;
-  st.betaNee = w.betaNee.p;
-  st.shD = w.shD.p;
-  st.shTmax = w.shTmax.p;
-  st.Ld1 = w.Ld1.p;
-  st.shOcc = w.shOcc.p;
-  st.misD = w.misD.p;
-  st.Ld2 = w.Ld2.p;
-  st.misLight = w.misLight.p;
-  st.misPrim = w.misPrim.p;
-  st.flags = w.flags.p;
+  // field offsets inside a tile, in 64-word runs: the three f64 fields first (8-byte aligned), then the
+  // 3-vectors, the i32 fields and the sample vector
+  float* b = w.tiles.p;
+  int f = 0;
+  auto f64 = [&]() { double* p = (double*)(b + 64 * (size_t)f); f += 2; return p; };
+  auto v3 = [&]() { float* p = b + 64 * (size_t)f; f += 3; return p; };
+  auto i32 = [&]() { int32_t* p = (int32_t*)(b + 64 * (size_t)f); f += 1; return p; };
+  st.rtmin = f64();
+  st.ht = f64();
+  st.shTmax = f64();
+  st.ro = v3();
+  st.ro0 = v3();
+  st.rd = v3();
+  st.beta = v3();
+  st.L = v3();
+  st.betaNee = v3();
+  st.shD = v3();
+  st.Ld1 = v3();
+  st.misD = v3();
+  st.Ld2 = v3();
+  st.hprim = i32();
+  st.shOcc = i32();
+  st.misLight = i32();
+  st.misPrim = i32();
+  st.flags = (uint32_t*)i32();
+  st.sv = b + 64 * (size_t)f;  // f == DR_STATE_WORDS
   return st;
 }
 
@@ -1016,12 +1008,12 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // path state per camera sample: the sample vector + 172 B of ray / hit / NEE state and queues (+ the RNG tail in
     // host-buffer mode).  The default batch (2^28) takes 86 GB of a 288 GB MI355X; on a device with less free
     // memory the batch shrinks instead of failing (results do not depend on the batch size).
-    const uint64_t perSlot = (uint64_t)rp.nFloats * 4 + 172 + (hostBuf && needTail > 0 ? (uint64_t)rd->max_tail * 8 : 0) +
+    const uint64_t perSlot = (uint64_t)(DR_STATE_WORDS + rp.nFloats) * 4 + 20 + (hostBuf && needTail > 0 ? (uint64_t)rd->max_tail * 8 : 0) +
                              (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0);
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)sc->ws.nFloats * 4 + 172) +
-                            (uint64_t)sc->ws2.cap * ((uint64_t)sc->ws2.nFloats * 4 + 172);
+      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)(DR_STATE_WORDS + sc->ws.nFloats) * 4 + 20) +
+                            (uint64_t)sc->ws2.cap * ((uint64_t)(DR_STATE_WORDS + sc->ws2.nFloats) * 4 + 20);
       const uint64_t budget = (uint64_t)(0.9 * (double)freeB) + have;
       const uint64_t pipes = nPipesEnv >= 2 && !hostBuf ? 2 : 1;
       while (maxSlots > (1ull << 16) && std::min<uint64_t>(maxSlots, (uint64_t)npixTotal * spp) * perSlot * pipes > budget) maxSlots >>= 1;

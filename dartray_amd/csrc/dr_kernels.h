@@ -49,12 +49,20 @@ struct RenderParams {
 
 #define Q_MIS_BIT 0x80000000u
 
-// Structure-of-arrays state of one batch of camera samples.  Slot s belongs to
-// batch pixel s >> sppShift, sample s & (spp-1).  Arrays of 3-vectors are laid
-// out [component][slot].
+// State of one batch of camera samples.  Slot s belongs to batch pixel s >> sppShift, sample s & (spp-1).
+// Layout: array-of-structures-of-arrays in tiles of 64 slots (one wave).  A tile holds, for its 64 slots, every
+// field as one 256-byte run -- the f64 fields, the 3-vectors component by component, the i32 fields and the
+// nFloats sample-vector entries -- so the ~45 coalesced loads and ~35 stores of one shading step all land in one
+// contiguous ~tileStride*4-byte region (a handful of DRAM rows) instead of 80 arrays a gigabyte apart.
+// Field pointers below already include the field's offset inside the tile: element (field, slot) is
+// ptr[TI(tileStride, slot)]; component c of a 3-vector is 64 words further per component; the f64 arrays use TD.
+#define TI(ts, s) ((size_t)((s) >> 6) * (size_t)(ts) + (size_t)((s) & 63u))
+#define TD(ts, s) ((size_t)((s) >> 6) * (size_t)((ts) >> 1) + (size_t)((s) & 63u))
 struct BatchState {
-  uint32_t cap;     // slots allocated
+  uint32_t cap;     // slots allocated (a multiple of 64)
   uint32_t nslots;  // slots used by the current batch
+  uint32_t tileStride;  // 4-byte words per 64-slot tile = 64 * (41 + nFloats)
+  uint32_t padts;
   const int2* pix;  // raster pixel of each batch pixel
   float* sv;        // [nFloats][cap] sample vectors
   const double* tail;  // [cap][maxTail] host-buffer mode, else null

@@ -105,13 +105,14 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
   __syncthreads();
   // write-out: element e of this wave's 64*spp contiguous outputs belongs to pixel e >> sppShift
   const uint32_t nOut = min(64u, npix - p0) * (uint32_t)spp;
-  float* out0 = st.sv + (size_t)dst * st.cap + (size_t)p0 * spp;
-  float* out1 = out0 + st.cap;
+  float* out0 = st.sv + (size_t)dst * 64;  // field `dst` of the sample vector inside each tile
+  const uint32_t slot0 = p0 * (uint32_t)spp;
   for (uint32_t e = lane; e < nOut; e += 64u) {
     const uint32_t pl = e >> rp.sppShift, j = e & (uint32_t)(spp - 1);
     const uint32_t idx = s_perm[j * ROW + pl];
-    out0[e] = VanDerCorput(idx, s_scr[pl]);
-    if (is2D) out1[e] = Sobol2(idx, s_scr[64 + pl]);
+    float* o = out0 + TI(st.tileStride, slot0 + e);
+    o[0] = VanDerCorput(idx, s_scr[pl]);
+    if (is2D) o[64] = Sobol2(idx, s_scr[64 + pl]);
   }
 }
 
@@ -130,8 +131,9 @@ __global__ void __launch_bounds__(64) k_gen_samples_multi(RenderParams rp, Batch
   rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
   const uint32_t s0 = rng.randomUint();
   const uint32_t s1 = b.is2D ? rng.randomUint() : 0u;
-  float* base = st.sv + (size_t)b.dst * st.cap + (size_t)p * spp;
-  auto at = [&](int i, int j, int d) -> float& { return base[(size_t)(dims * j + d) * st.cap + i]; };
+  float* base = st.sv + (size_t)b.dst * 64;
+  const uint32_t slot0 = p * (uint32_t)spp;
+  auto at = [&](int i, int j, int d) -> float& { return base[TI(st.tileStride, slot0 + (uint32_t)i) + (size_t)(dims * j + d) * 64]; };
   for (int i = 0; i < spp; ++i)
     for (int j = 0; j < n; ++j) {
       const uint32_t e = (uint32_t)(i * n + j);
@@ -162,7 +164,29 @@ __global__ void __launch_bounds__(64) k_gen_samples_multi(RenderParams rp, Batch
 __global__ void k_transpose_samples(const float* aos, int stride, BatchState st, int nFloats) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= st.nslots) return;
-  for (int k = 0; k < nFloats; ++k) st.sv[(size_t)k * st.cap + s] = aos[(size_t)s * stride + k];
+  for (int k = 0; k < nFloats; ++k) st.sv[TI(st.tileStride, s) + (size_t)k * 64] = aos[(size_t)s * stride + k];
+}
+
+// 3-vector / colour fields: `cap` in the callers below is the tile stride (see BatchState)
+DR_DEV F3 ld3(const float* a, uint32_t cap, uint32_t s) {
+  a += TI(cap, s);
+  return F3{LDS_STREAM(a), LDS_STREAM(a + 64), LDS_STREAM(a + 128)};
+}
+DR_DEV void st3(float* a, uint32_t cap, uint32_t s, F3 v) {
+  a += TI(cap, s);
+  STS_STREAM(a, v.x);
+  STS_STREAM(a + 64, v.y);
+  STS_STREAM(a + 128, v.z);
+}
+DR_DEV C3 ldc(const float* a, uint32_t cap, uint32_t s) {
+  a += TI(cap, s);
+  return C3{LDS_STREAM(a), LDS_STREAM(a + 64), LDS_STREAM(a + 128)};
+}
+DR_DEV void stc(float* a, uint32_t cap, uint32_t s, C3 v) {
+  a += TI(cap, s);
+  STS_STREAM(a, v.r);
+  STS_STREAM(a + 64, v.g);
+  STS_STREAM(a + 128, v.b);
 }
 
 // ---------------------------------------------------------------------------
@@ -186,17 +210,18 @@ DR_DEV F3 xf_vector(const float* m, F3 p) {
 __global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= st.nslots) return;
-  const uint32_t cap = st.cap;
+  const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const int2 xy = st.pix[s >> rp.sppShift];
-  const double imageX = (double)xy.x + (double)st.sv[s];               // montecarlo.dart:451-452
-  const double imageY = (double)xy.y + (double)st.sv[(size_t)cap + s];
+  const float* svs = st.sv + TI(cap, s);
+  const double imageX = (double)xy.x + (double)svs[0];               // montecarlo.dart:451-452
+  const double imageY = (double)xy.y + (double)svs[64];
   F3 Pras = f3(imageX, imageY, 0.0);
   F3 Pcamera = xf_point(rp.r2c, Pras);
   F3 o = F3{0.f, 0.f, 0.f};
   F3 d = vnormalize(Pcamera);
   if (rp.lensRadius > 0.0f) {
     double lu, lv;
-    ConcentricSampleDisk((double)st.sv[2 * (size_t)cap + s], (double)st.sv[3 * (size_t)cap + s], &lu, &lv);
+    ConcentricSampleDisk((double)svs[128], (double)svs[192], &lu, &lv);
     lu *= (double)rp.lensRadius;
     lv *= (double)rp.lensRadius;
     double ft = (double)rp.focalDistance / (double)d.z;
@@ -206,46 +231,30 @@ __global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) 
   }
   o = xf_point(rp.c2w, o);
   d = xf_vector(rp.c2w, d);
-  st.ro[s] = o.x; st.ro[cap + s] = o.y; st.ro[2 * cap + s] = o.z;
-  st.rd[s] = d.x; st.rd[cap + s] = d.y; st.rd[2 * cap + s] = d.z;
-  st.rtmin[s] = 0.0;
-  st.hprim[s] = -1;
-  st.beta[s] = 1.f; st.beta[cap + s] = 1.f; st.beta[2 * cap + s] = 1.f;
-  st.L[s] = 0.f; st.L[cap + s] = 0.f; st.L[2 * cap + s] = 0.f;
-  st.flags[s] = PF_HAS_CONT;
+  st3(st.ro, cap, s, o);
+  st3(st.rd, cap, s, d);
+  st.rtmin[TD(cap, s)] = 0.0;
+  st.hprim[TI(cap, s)] = -1;
+  stc(st.beta, cap, s, C3{1.f, 1.f, 1.f});
+  stc(st.L, cap, s, C3{0.f, 0.f, 0.f});
+  st.flags[TI(cap, s)] = PF_HAS_CONT;
 }
 
 // ---------------------------------------------------------------------------
 // shading
 // ---------------------------------------------------------------------------
-DR_DEV F3 ld3(const float* a, uint32_t cap, uint32_t s) {
-  return F3{LDS_STREAM(a + s), LDS_STREAM(a + cap + s), LDS_STREAM(a + 2 * (size_t)cap + s)};
-}
-DR_DEV void st3(float* a, uint32_t cap, uint32_t s, F3 v) {
-  STS_STREAM(a + s, v.x);
-  STS_STREAM(a + cap + s, v.y);
-  STS_STREAM(a + 2 * (size_t)cap + s, v.z);
-}
-DR_DEV C3 ldc(const float* a, uint32_t cap, uint32_t s) {
-  return C3{LDS_STREAM(a + s), LDS_STREAM(a + cap + s), LDS_STREAM(a + 2 * (size_t)cap + s)};
-}
-DR_DEV void stc(float* a, uint32_t cap, uint32_t s, C3 v) {
-  STS_STREAM(a + s, v.r);
-  STS_STREAM(a + cap + s, v.g);
-  STS_STREAM(a + 2 * (size_t)cap + s, v.b);
-}
 
 // EstimateDirect's contribution of the pending NEE rays (integrator.dart:135-145,169-180).
 // ENV: the scene has an InfiniteAreaLight (compiled out otherwise: the area-light-only path keeps its registers)
 // QUAD: the scene has sphere / disk primitives (likewise)
 template <bool ENV, bool QUAD>
 DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uint32_t flags, int shOcc, C3 Ld1) {
-  const uint32_t cap = st.cap;
+  const uint32_t cap = st.tileStride;  // words per 64-slot tile
   C3 Ld = C3{0.f, 0.f, 0.f};
   if ((flags & PF_HAS_SH) && shOcc == 0) Ld = cadd(Ld, Ld1);
   if (flags & PF_HAS_MIS) {
-    const int prim = st.misPrim[slot];
-    const int li = st.misLight[slot];
+    const int prim = st.misPrim[TI(cap, slot)];
+    const int li = st.misLight[TI(cap, slot)];
     if (ENV && sc.lights[li].kind == DR_LIGHT_INFINITE) {
       // the MIS ray escaped: Li = light.Le(ray) (integrator.dart:173-175), folded into Ld2 at set-up
       if (prim < 0) Ld = cadd(Ld, ldc(st.Ld2, cap, slot));
@@ -259,7 +268,7 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
           const DQuadric& qd = sc.quads[tr.quad];
           double th;
           F3 phit;
-          (void)quadric_hit(qd, ld3(st.ro, cap, slot), wi, st.rtmin[slot], DR_INF, &th, &phit);
+          (void)quadric_hit(qd, ld3(st.ro, cap, slot), wi, st.rtmin[TD(cap, slot)], DR_INF, &th, &phit);
           quadric_dg(qd, phit, &dg);
         } else if (QUAD && sc.srec && (__float_as_uint(sc.srec[7 * (size_t)prim + 6].x) & DR_SHADING_UV)) {
           const ShadeRec sr = load_srec(sc, (uint32_t)prim);
@@ -280,7 +289,7 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
 template <bool ENV, bool QUAD>
 DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
                           F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1, double bsc) {
-  const uint32_t cap = st.cap;
+  const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const DLight& light = sc.lights[lightNum];
   const int flags = BSDF_ALL & ~BSDF_SPECULAR;
   uint32_t pf = 0;
@@ -320,11 +329,11 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
       if (!cblack(f)) {
         if (distant) {  // VisibilityTester.setRay(p, eps, wi)
           st3(st.shD, cap, slot, wi);
-          st.shTmax[slot] = DR_INF;
+          st.shTmax[TD(cap, slot)] = DR_INF;
         } else {        // VisibilityTester.setSegment(p, eps, lightPos, 0)
           const double dist = vlen(seg);
           st3(st.shD, cap, slot, vdiv(seg, dist));
-          st.shTmax[slot] = dist * (1.0 - 0.0);
+          st.shTmax[TD(cap, slot)] = dist * (1.0 - 0.0);
         }
         stc(st.Ld1, cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) / 1.0)));
         pf |= PF_HAS_SH;
@@ -351,11 +360,11 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
         F3 seg = vsub(ps, p);
         double dist = vlen(seg);
         st3(st.shD, cap, slot, vdiv(seg, dist));
-        st.shTmax[slot] = dist * (1.0 - 1.0e-3);
+        st.shTmax[TD(cap, slot)] = dist * (1.0 - 1.0e-3);
       } else {
         // VisibilityTester.setRay (visibility_tester.dart:31-33)
         st3(st.shD, cap, slot, wi);
-        st.shTmax[slot] = DR_INF;
+        st.shTmax[TD(cap, slot)] = DR_INF;
       }
       double bsdfPdf = bsdf_pdf(bsdf, wo, wi, flags);
       double weight = PowerHeuristic(lightPdf, bsdfPdf);
@@ -377,7 +386,7 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
         C3 Lhit = infinite ? env_Le(sc.env, wi2) : C3{light.L[0], light.L[1], light.L[2]};
         st3(st.misD, cap, slot, wi2);
         stc(st.Ld2, cap, slot, cmulD(cmul(f, Lhit), (fabs(vdot(wi2, n)) * weight / bsdfPdf)));
-        st.misLight[slot] = lightNum;
+        st.misLight[TI(cap, slot)] = lightNum;
         pf |= PF_HAS_MIS;  // scene.intersect is called before `if (!Li.isBlack())` (integrator.dart:169-177)
       }
     }
@@ -414,49 +423,90 @@ struct TailSrc {
   }
 };
 
+// Everything k_shade_path reads that is indexed by the slot alone: fetched with independent loads (ONE memory
+// round trip).  Arrays that were never written for this slot yield garbage that is never used.
+struct ShadeIn {
+  uint32_t slot, flags;
+  int hprim, shOcc;
+  double t;
+  C3 L, beta, betaNee, Ld1;
+  F3 o, d;
+  float su[10];  // this bounce's sample-vector slots (Appendix B): lightNum, light comp, light pos, bsdf dir, path dir, the two uComponents
+  bool valid;
+};
+template <bool QUAD>
+DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int bounce, uint32_t slot, bool valid, ShadeIn* in) {
+  in->valid = valid;
+  in->slot = slot;
+  if (!valid) return;
+  const uint32_t cap = st.tileStride;  // words per 64-slot tile
+  in->flags = st.flags[TI(cap, slot)];
+  in->hprim = st.hprim[TI(cap, slot)];
+  in->t = st.ht[TD(cap, slot)];
+  in->shOcc = st.shOcc[TI(cap, slot)];
+  in->L = ldc(st.L, cap, slot);
+  in->beta = ldc(st.beta, cap, slot);
+  in->betaNee = ldc(st.betaNee, cap, slot);
+  in->Ld1 = ldc(st.Ld1, cap, slot);
+  in->o = ld3(st.ro, cap, slot);
+  in->d = ld3(st.rd, cap, slot);
+  if (bounce < 3) {
+    const float* sv = st.sv;
+    in->su[0] = sv[TI(cap, slot) + (size_t)(5 + 4 * bounce + 1) * 64];
+    in->su[1] = sv[TI(cap, slot) + (size_t)(5 + 4 * bounce + 0) * 64];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) in->su[2 + k] = sv[TI(cap, slot) + (size_t)(5 + rp.n1D + 2 * (3 * bounce) + k) * 64];
+    if (QUAD) {
+      in->su[8] = sv[TI(cap, slot) + (size_t)(5 + 4 * bounce + 3) * 64];  // path-sample uComponent
+      in->su[9] = sv[TI(cap, slot) + (size_t)(5 + 4 * bounce + 2) * 64];  // BSDF-sample uComponent of the light estimate
+    }
+  }
+}
+
 // One vertex of PathIntegrator.Li (path_integrator.dart:44-119).
 #ifndef DR_SHADE_WAVES
 #define DR_SHADE_WAVES 2
 #endif
+#ifndef DR_SHADE_BLOCK
 #define DR_SHADE_BLOCK 512
+#endif
 template <bool ENV, bool QUAD>
 __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
   __shared__ PushScratch s_push;
-  const uint32_t cap = st.cap;
+  const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
+  // Software pipeline over the grid-stride loop: the active-list entry of item it+2 and the whole slot state of item
+  // it+1 are requested before item it is shaded, so their two dependent HBM round trips overlap the ~3000
+  // instructions of shading instead of stalling a SIMD that only holds two of these waves.
+  const uint32_t tid0 = blockIdx.x * blockDim.x + threadIdx.x;
+  auto slotOf = [&](uint32_t i) -> uint32_t { return i < nIn ? (q.activeIn ? q.activeIn[i] : i) : 0u; };
+  ShadeIn nxt;
+  uint32_t slotNext2 = slotOf(tid0 + stride);
+  load_shade_in<QUAD>(st, rp, bounce, slotOf(tid0), tid0 < nIn, &nxt);
   for (uint32_t it = 0; it < nIter; ++it) {
-    const uint32_t idx = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = idx < nIn;
-    uint32_t slot = 0, pf = 0;
+    const ShadeIn cur = nxt;
+    {
+      const uint32_t i1 = (it + 1) * stride + tid0, i2 = (it + 2) * stride + tid0;
+      const uint32_t s1 = slotNext2;
+      slotNext2 = (it + 2 < nIter) ? slotOf(i2) : 0u;
+      if (it + 1 < nIter) load_shade_in<QUAD>(st, rp, bounce, s1, i1 < nIn, &nxt);
+    }
+    const bool valid = cur.valid;
+    uint32_t slot = cur.slot, pf = 0;
     bool pushCont = false;
     if (valid) {
-      slot = q.activeIn ? q.activeIn[idx] : idx;
-      // Every slot-indexed input is fetched up front (independent loads, ONE memory round trip; the
-      // state streams from HBM and this kernel runs at 2 waves per SIMD).  Arrays that were never
-      // written for this slot yield garbage that is never used.
-      const uint32_t flags = st.flags[slot];
-      const int hprimIn = st.hprim[slot];
-      const double t = st.ht[slot];
-      const int shOccIn = st.shOcc[slot];
-      C3 L = ldc(st.L, cap, slot);
-      C3 beta = ldc(st.beta, cap, slot);
-      const C3 betaNeeIn = ldc(st.betaNee, cap, slot);
-      const C3 Ld1In = ldc(st.Ld1, cap, slot);
-      const F3 o = ld3(st.ro, cap, slot), d = ld3(st.rd, cap, slot);
-      float su[10];  // this bounce's sample-vector slots (Appendix B): lightNum, light comp, light pos, bsdf dir, path dir, path comp
-      if (bounce < 3) {
-        const float* sv = st.sv;
-        su[0] = sv[(size_t)(5 + 4 * bounce + 1) * cap + slot];
-        su[1] = sv[(size_t)(5 + 4 * bounce + 0) * cap + slot];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) su[2 + k] = sv[(size_t)(5 + rp.n1D + 2 * (3 * bounce) + k) * cap + slot];
-        if (QUAD) {
-          su[8] = sv[(size_t)(5 + 4 * bounce + 3) * cap + slot];  // path-sample uComponent
-          su[9] = sv[(size_t)(5 + 4 * bounce + 2) * cap + slot];  // BSDF-sample uComponent of the light estimate
-        }
-      }
+      const uint32_t flags = cur.flags;
+      const int hprimIn = cur.hprim;
+      const double t = cur.t;
+      const int shOccIn = cur.shOcc;
+      C3 L = cur.L;
+      C3 beta = cur.beta;
+      const C3 betaNeeIn = cur.betaNee;
+      const C3 Ld1In = cur.Ld1;
+      const F3 o = cur.o, d = cur.d;
+      const float* su = cur.su;
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
         C3 Ld = resolve_nee<ENV, QUAD>(sc, st, slot, flags, shOccIn, Ld1In);
@@ -556,10 +606,10 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
           pushCont = true;
         }
         st3(st.ro, cap, slot, p);
-        st.rtmin[slot] = eps;
+        st.rtmin[TD(cap, slot)] = eps;
       }
       stc(st.L, cap, slot, L);
-      st.flags[slot] = pf;
+      st.flags[TI(cap, slot)] = pf;
     }
     block_push(s_push, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, pushCont,
                (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT);
@@ -573,7 +623,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
 template <bool QUAD>
 __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
   __shared__ PushScratch s_push;
-  const uint32_t cap = st.cap;
+  const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
@@ -588,8 +638,8 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
     bool again = false;
     if (valid) {
       slot = q.activeIn ? q.activeIn[idx] : idx;
-      const uint32_t flags = st.flags[slot];
-      const int prim = st.hprim[slot];
+      const uint32_t flags = st.flags[TI(cap, slot)];
+      const int prim = st.hprim[TI(cap, slot)];
       if (prim >= 0) {
         Tri tr = load_tri(sc, (uint32_t)prim);
         const F3 d = ld3(st.rd, cap, slot);
@@ -604,7 +654,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
         if (hasRec) sr = load_srec(sc, (uint32_t)prim);
         if (stage == 0) {
           const F3 o = ld3(st.ro, cap, slot);
-          const double t = st.ht[slot];
+          const double t = st.ht[TD(cap, slot)];
           if (isQuad) {
             quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
             st3(st.ro0, cap, slot, o);  // later stages rebuild the hit from the camera ray
@@ -618,14 +668,14 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
           L = cadd(L, Le);
           Lall = C3{0.f, 0.f, 0.f};
           st3(st.ro, cap, slot, dg.p);
-          st.rtmin[slot] = (isQuad ? 5.0e-4 : 1.0e-3) * t;
+          st.rtmin[TD(cap, slot)] = (isQuad ? 5.0e-4 : 1.0e-3) * t;
         } else {
-          if (isQuad) quadric_dg_at(sc.quads[tr.quad], ld3(st.ro0, cap, slot), d, st.ht[slot], &dg);
-          else if (hasRec) tri_dg_srec(tr, sr, ld3(st.ro0, cap, slot), d, st.ht[slot], &dg);
+          if (isQuad) quadric_dg_at(sc.quads[tr.quad], ld3(st.ro0, cap, slot), d, st.ht[TD(cap, slot)], &dg);
+          else if (hasRec) tri_dg_srec(tr, sr, ld3(st.ro0, cap, slot), d, st.ht[TD(cap, slot)], &dg);
           else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
           dg.p = ld3(st.ro, cap, slot);
           Ld = ldc(st.betaNee, cap, slot);
-          Ld = cadd(Ld, resolve_nee<true, QUAD>(sc, st, slot, flags, st.shOcc[slot], ldc(st.Ld1, cap, slot)));  // Ld += EstimateDirect
+          Ld = cadd(Ld, resolve_nee<true, QUAD>(sc, st, slot, flags, st.shOcc[TI(cap, slot)], ldc(st.Ld1, cap, slot)));  // Ld += EstimateDirect
           if (prev.last) {
             Lall = cadd(Lall, cdivD(Ld, (double)prev.n));  // L += Ld / nSamples
             Ld = C3{0.f, 0.f, 0.f};
@@ -638,12 +688,12 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
           bsdf.ng = dg.nn;
           const float* sv = st.sv;
           // sample slots of this call (direct_lighting_integrator.dart:70-87)
-          double lsc = LDS_STREAM(sv + (size_t)cur.lc * cap + slot);
-          double ls0 = LDS_STREAM(sv + (size_t)cur.lp * cap + slot);
-          double ls1 = LDS_STREAM(sv + (size_t)(cur.lp + 1) * cap + slot);
-          double bs0 = LDS_STREAM(sv + (size_t)cur.bd * cap + slot);
-          double bs1 = LDS_STREAM(sv + (size_t)(cur.bd + 1) * cap + slot);
-          double bsc = QUAD ? (double)LDS_STREAM(sv + (size_t)cur.bc * cap + slot) : 0.0;
+          double lsc = LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.lc) * 64);
+          double ls0 = LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.lp) * 64);
+          double ls1 = LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.lp + 1) * 64);
+          double bs0 = LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.bd) * 64);
+          double bs1 = LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.bd + 1) * 64);
+          double bsc = QUAD ? (double)LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.bc) * 64) : 0.0;
           pf |= setup_nee<true, QUAD>(sc, st, slot, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
           again = true;
         } else {
@@ -659,7 +709,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
       } else if (stage == 0 && sc.hasEnv) {
         stc(st.L, cap, slot, env_Le(sc.env, ld3(st.rd, cap, slot)));  // escaped camera ray (sampler_renderer.dart:87-92)
       }
-      st.flags[slot] = pf;
+      st.flags[TI(cap, slot)] = pf;
     }
     block_push(s_push, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, false,
                (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, again, slot, Q_MIS_BIT);
@@ -667,64 +717,96 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
 }
 
 // ---------------------------------------------------------------------------
-// film (image_film.dart:99-185): one lane owns one batch pixel and adds its spp
-// samples in the reference's order; contributions to other pixels (wide
-// filters, or imageX exactly integral) go through float atomics.
+// film (image_film.dart:99-185).  A block owns 1024 consecutive slots (whole pixels: spp is a power of
+// two <= 1024, dr_render refuses more): first lane = sample (coalesced reads of L and the image
+// sample; XYZ conversion and filter weight; the sample's contribution to its OWN pixel parked in LDS,
+// contributions to other pixels -- wide filters, or imageX exactly integral -- sent through float atomics),
+// then lane = pixel adds the parked contributions in the reference's sample order.
 // ---------------------------------------------------------------------------
+#define DR_FILM_CHUNK 1024
 __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, const float* table, uint32_t npix, float* film) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npix) return;
-  const uint32_t cap = st.cap;
-  const int2 xy = st.pix[p];
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accw = 0.f;
-  const bool ownInside = xy.x >= rp.left && xy.x < rp.left + rp.width && xy.y >= rp.top && xy.y < rp.top + rp.height;
-  for (int i = 0; i < rp.spp; ++i) {
-    const uint32_t s = p * (uint32_t)rp.spp + (uint32_t)i;
-    C3 L = ldc(st.L, cap, s);
-    // guards of sampler_renderer.dart:181-193
-    double lum = clum(L);
-    if (L.r != L.r || L.g != L.g || L.b != L.b) L = C3{0.f, 0.f, 0.f};
-    else if (lum < -1e-5) L = C3{0.f, 0.f, 0.f};
-    else if (isinf(lum)) L = C3{0.f, 0.f, 0.f};
-    const double dimageX = ((double)xy.x + (double)st.sv[s]) - 0.5;
-    const double dimageY = ((double)xy.y + (double)st.sv[(size_t)cap + s]) - 0.5;
-    int x0 = (int)ceil(dimageX - rp.fxw), x1 = (int)floor(dimageX + rp.fxw);
-    int y0 = (int)ceil(dimageY - rp.fyw), y1 = (int)floor(dimageY + rp.fyw);
-    x0 = max(x0, rp.left); x1 = min(x1, rp.left + rp.width - 1);
-    y0 = max(y0, rp.top);  y1 = min(y1, rp.top + rp.height - 1);
-    if ((x1 - x0) < 0 || (y1 - y0) < 0) continue;
-    // L.toXYZ(): Float32List store (xyz_color.dart:39-42; spectrum.dart:294-298)
-    const float X = (float)(0.412453 * (double)L.r + 0.357580 * (double)L.g + 0.180423 * (double)L.b);
-    const float Y = (float)(0.212671 * (double)L.r + 0.715160 * (double)L.g + 0.072169 * (double)L.b);
-    const float Z = (float)(0.019334 * (double)L.r + 0.119193 * (double)L.g + 0.950227 * (double)L.b);
-    for (int y = y0; y <= y1; ++y) {
-      const double fy = fabs(((double)y - dimageY) * rp.invY * 16);
-      const int iy = min((int)floor(fy), 15);
-      for (int x = x0; x <= x1; ++x) {
-        const double fx = fabs(((double)x - dimageX) * rp.invX * 16);
-        const int ix = min((int)floor(fx), 15);
-        const double wt = table[iy * 16 + ix];
-        if (x == xy.x && y == xy.y) {
-          acc0 = (float)((double)acc0 + wt * (double)X);
-          acc1 = (float)((double)acc1 + wt * (double)Y);
-          acc2 = (float)((double)acc2 + wt * (double)Z);
+  __shared__ float s_X[DR_FILM_CHUNK], s_Y[DR_FILM_CHUNK], s_Z[DR_FILM_CHUNK], s_W[DR_FILM_CHUNK];
+  __shared__ uint8_t s_own[DR_FILM_CHUNK];
+  const uint32_t cap = st.tileStride;  // words per 64-slot tile
+  const uint32_t spp = (uint32_t)rp.spp;
+  const uint64_t base = (uint64_t)blockIdx.x * DR_FILM_CHUNK;
+  const uint32_t nslots = st.nslots;
+  const uint32_t perPix = spp;                      // samples of one pixel
+  const uint32_t nPixChunk = DR_FILM_CHUNK / spp;   // pixels of this block
+  {
+    for (uint32_t e = threadIdx.x; e < DR_FILM_CHUNK; e += 256u) {
+      const uint64_t s64 = base + e;
+      uint8_t own = 0;
+      if (s64 < nslots) {
+        const uint32_t s = (uint32_t)s64;
+        const int2 xy = st.pix[s >> rp.sppShift];
+        C3 L = ldc(st.L, cap, s);
+        // guards of sampler_renderer.dart:181-193
+        double lum = clum(L);
+        if (L.r != L.r || L.g != L.g || L.b != L.b) L = C3{0.f, 0.f, 0.f};
+        else if (lum < -1e-5) L = C3{0.f, 0.f, 0.f};
+        else if (isinf(lum)) L = C3{0.f, 0.f, 0.f};
+        const float* svs = st.sv + TI(cap, s);
+        const double dimageX = ((double)xy.x + (double)svs[0]) - 0.5;
+        const double dimageY = ((double)xy.y + (double)svs[64]) - 0.5;
+        int x0 = (int)ceil(dimageX - rp.fxw), x1 = (int)floor(dimageX + rp.fxw);
+        int y0 = (int)ceil(dimageY - rp.fyw), y1 = (int)floor(dimageY + rp.fyw);
+        x0 = max(x0, rp.left); x1 = min(x1, rp.left + rp.width - 1);
+        y0 = max(y0, rp.top);  y1 = min(y1, rp.top + rp.height - 1);
+        if ((x1 - x0) >= 0 && (y1 - y0) >= 0) {
+          // L.toXYZ(): Float32List store (xyz_color.dart:39-42; spectrum.dart:294-298)
+          const float X = (float)(0.412453 * (double)L.r + 0.357580 * (double)L.g + 0.180423 * (double)L.b);
+          const float Y = (float)(0.212671 * (double)L.r + 0.715160 * (double)L.g + 0.072169 * (double)L.b);
+          const float Z = (float)(0.019334 * (double)L.r + 0.119193 * (double)L.g + 0.950227 * (double)L.b);
+          for (int y = y0; y <= y1; ++y) {
+            const double fy = fabs(((double)y - dimageY) * rp.invY * 16);
+            const int iy = min((int)floor(fy), 15);
+            for (int x = x0; x <= x1; ++x) {
+              const double fx = fabs(((double)x - dimageX) * rp.invX * 16);
+              const int ix = min((int)floor(fx), 15);
+              const float wt = table[iy * 16 + ix];
+              if (x == xy.x && y == xy.y) {
+                s_X[e] = X; s_Y[e] = Y; s_Z[e] = Z; s_W[e] = wt;
+                own = 1;
+              } else {
+                float* px = film + 4 * ((size_t)(y - rp.top) * rp.width + (size_t)(x - rp.left));
+                atomicAdd(px + 0, (float)((double)wt * (double)X));
+                atomicAdd(px + 1, (float)((double)wt * (double)Y));
+                atomicAdd(px + 2, (float)((double)wt * (double)Z));
+                atomicAdd(px + 3, wt);
+              }
+            }
+          }
+        }
+      }
+      s_own[e] = own;
+    }
+    __syncthreads();
+    for (uint32_t pl = threadIdx.x; pl < nPixChunk; pl += 256u) {
+      const uint32_t e0 = pl * perPix;
+      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accw = 0.f;
+      for (uint32_t i = 0; i < perPix; ++i) {
+        const uint32_t e = e0 + i;
+        if (s_own[e]) {
+          const double wt = s_W[e];
+          acc0 = (float)((double)acc0 + wt * (double)s_X[e]);
+          acc1 = (float)((double)acc1 + wt * (double)s_Y[e]);
+          acc2 = (float)((double)acc2 + wt * (double)s_Z[e]);
           accw = (float)((double)accw + wt);
-        } else {
-          float* px = film + 4 * ((size_t)(y - rp.top) * rp.width + (size_t)(x - rp.left));
-          atomicAdd(px + 0, (float)(wt * (double)X));
-          atomicAdd(px + 1, (float)(wt * (double)Y));
-          atomicAdd(px + 2, (float)(wt * (double)Z));
-          atomicAdd(px + 3, (float)wt);
+        }
+      }
+      const uint64_t s64 = base + e0;  // the first slot of this lane's pixel
+      if (s64 < nslots) {
+        const int2 xy = st.pix[(uint32_t)s64 >> rp.sppShift];
+        if (xy.x >= rp.left && xy.x < rp.left + rp.width && xy.y >= rp.top && xy.y < rp.top + rp.height) {
+          float* px = film + 4 * ((size_t)(xy.y - rp.top) * rp.width + (size_t)(xy.x - rp.left));
+          atomicAdd(px + 0, acc0);
+          atomicAdd(px + 1, acc1);
+          atomicAdd(px + 2, acc2);
+          atomicAdd(px + 3, accw);
         }
       }
     }
-  }
-  if (ownInside) {
-    float* px = film + 4 * ((size_t)(xy.y - rp.top) * rp.width + (size_t)(xy.x - rp.left));
-    atomicAdd(px + 0, acc0);
-    atomicAdd(px + 1, acc1);
-    atomicAdd(px + 2, acc2);
-    atomicAdd(px + 3, accw);
   }
 }
 
@@ -789,18 +871,20 @@ void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) 
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL((k_shade_path<true, true>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
-  else if (sc.hasEnv) hipLaunchKernelGGL((k_shade_path<true, false>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
-  else hipLaunchKernelGGL((k_shade_path<false, false>), dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL((k_shade_path<true, true>), dim3(grid * 512 / DR_SHADE_BLOCK), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  else if (sc.hasEnv) hipLaunchKernelGGL((k_shade_path<true, false>), dim3(grid * 512 / DR_SHADE_BLOCK), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  else hipLaunchKernelGGL((k_shade_path<false, false>), dim3(grid * 512 / DR_SHADE_BLOCK), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL(k_shade_direct<true>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
-  else hipLaunchKernelGGL(k_shade_direct<false>, dim3(grid), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
+  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL(k_shade_direct<true>, dim3(grid * 512 / DR_SHADE_BLOCK), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
+  else hipLaunchKernelGGL(k_shade_direct<false>, dim3(grid * 512 / DR_SHADE_BLOCK), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
                  hipStream_t s) {
-  hipLaunchKernelGGL(k_film, dim3((npix + 255) / 256), dim3(256), 0, s, rp, st, filterTable, npix, film);
+  const uint64_t nblk = ((uint64_t)npix * (uint64_t)rp.spp + DR_FILM_CHUNK - 1) / DR_FILM_CHUNK;
+  if (nblk == 0) return;
+  hipLaunchKernelGGL(k_film, dim3((unsigned)nblk), dim3(256), 0, s, rp, st, filterTable, npix, film);
 }
 void launch_film_resolve(const float* film, int64_t npix, float* rgb, hipStream_t s) {
   hipLaunchKernelGGL(k_film_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, film, npix, rgb);

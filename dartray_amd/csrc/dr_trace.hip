@@ -38,7 +38,7 @@
 #define DR_TRACE3_WAVES 5  // k_trace3: 32 KiB of LDS per workgroup => 5 workgroups per CU anyway
 #endif
 #ifndef DR_WORK_CHUNK
-#define DR_WORK_CHUNK 128  // queue entries a wave reserves per atomic on the work counter (256+ loses cache locality, 64 is atomic bound)
+#define DR_WORK_CHUNK 256  // queue entries a wave reserves per atomic on the work counter (256+ loses cache locality, 64 is atomic bound)
 #endif
 
 // ===========================================================================
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace_v1(DScene sc, BatchSta
   const uint32_t spillStride = gridDim.x * DR_TRACE_BLOCK;
   uint32_t* mySpill = spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr;
   const uint32_t n = nQueue ? *nQueue : st.nslots;
-  const uint32_t cap = st.cap;
+  const uint32_t cap = st.tileStride;  // words per 64-slot tile
   uint32_t rays = 0, nodes = 0, tris = 0;
   for (;;) {
     uint32_t base = 0;
@@ -162,24 +162,25 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace_v1(DScene sc, BatchSta
     if (idx < n) {
       const uint32_t e = queue ? queue[idx] : idx;
       const uint32_t slot = e & ~Q_MIS_BIT;
-      const F3 o = F3{st.ro[slot], st.ro[cap + slot], st.ro[2 * cap + slot]};
-      const double tmin = st.rtmin[slot];
+      const size_t ti = TI(cap, slot);
+      const F3 o = F3{st.ro[ti], st.ro[ti + 64], st.ro[ti + 128]};
+      const double tmin = st.rtmin[TD(cap, slot)];
       ++rays;
       if (ANY) {
-        const F3 d = F3{st.shD[slot], st.shD[cap + slot], st.shD[2 * cap + slot]};
+        const F3 d = F3{st.shD[ti], st.shD[ti + 64], st.shD[ti + 128]};
         double t;
-        int r = traverse<1>(sc, o, d, tmin, st.shTmax[slot], lds, mySpill, spillStride, &t, &nodes, &tris);
-        st.shOcc[slot] = (r >= 0) ? 1 : 0;
+        int r = traverse<1>(sc, o, d, tmin, st.shTmax[TD(cap, slot)], lds, mySpill, spillStride, &t, &nodes, &tris);
+        st.shOcc[ti] = (r >= 0) ? 1 : 0;
       } else if (e & Q_MIS_BIT) {
-        const F3 d = F3{st.misD[slot], st.misD[cap + slot], st.misD[2 * cap + slot]};
+        const F3 d = F3{st.misD[ti], st.misD[ti + 64], st.misD[ti + 128]};
         double t;
-        st.misPrim[slot] = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
+        st.misPrim[ti] = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
       } else {
-        const F3 d = F3{st.rd[slot], st.rd[cap + slot], st.rd[2 * cap + slot]};
+        const F3 d = F3{st.rd[ti], st.rd[ti + 64], st.rd[ti + 128]};
         double t;
         int r = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
-        st.hprim[slot] = r;
-        st.ht[slot] = t;
+        st.hprim[ti] = r;
+        st.ht[TD(cap, slot)] = t;
       }
     }
   }
@@ -326,22 +327,24 @@ struct StateIO {
   DR_DEV void load(uint32_t idx, TraceRay& r, uint32_t& handle) const {
     const uint32_t e = queue ? queue[idx] : idx;
     const uint32_t slot = e & ~Q_MIS_BIT;
-    const uint32_t cap = st.cap;
+    const uint32_t cap = st.tileStride;  // words per 64-slot tile
     handle = e;
-    const F3 o = F3{LDS_STREAM(st.ro + slot), LDS_STREAM(st.ro + cap + slot), LDS_STREAM(st.ro + 2 * (size_t)cap + slot)};
-    const float* dir = ANY ? st.shD : ((e & Q_MIS_BIT) ? st.misD : st.rd);
-    const F3 d = F3{LDS_STREAM(dir + slot), LDS_STREAM(dir + cap + slot), LDS_STREAM(dir + 2 * (size_t)cap + slot)};
-    ray_init(r, o, d, LDS_STREAM(st.rtmin + slot), ANY ? LDS_STREAM(st.shTmax + slot) : DR_INF);
+    const size_t ti = TI(cap, slot), td = TD(cap, slot);
+    const F3 o = F3{LDS_STREAM(st.ro + ti), LDS_STREAM(st.ro + ti + 64), LDS_STREAM(st.ro + ti + 128)};
+    const float* dir = (ANY ? st.shD : ((e & Q_MIS_BIT) ? st.misD : st.rd)) + ti;
+    const F3 d = F3{LDS_STREAM(dir), LDS_STREAM(dir + 64), LDS_STREAM(dir + 128)};
+    ray_init(r, o, d, LDS_STREAM(st.rtmin + td), ANY ? LDS_STREAM(st.shTmax + td) : DR_INF);
   }
   DR_DEV void store(uint32_t handle, const TraceRay& r, int prim, const DScene&) const {
     const uint32_t slot = handle & ~Q_MIS_BIT;
+    const size_t ti = TI(st.tileStride, slot);
     if (ANY) {
-      STS_STREAM(st.shOcc + slot, (prim >= 0) ? 1 : 0);
+      STS_STREAM(st.shOcc + ti, (prim >= 0) ? 1 : 0);
     } else if (handle & Q_MIS_BIT) {
-      STS_STREAM(st.misPrim + slot, prim);
+      STS_STREAM(st.misPrim + ti, prim);
     } else {
-      STS_STREAM(st.hprim + slot, prim);
-      STS_STREAM(st.ht + slot, r.tmax);
+      STS_STREAM(st.hprim + ti, prim);
+      STS_STREAM(st.ht + TD(st.tileStride, slot), r.tmax);
     }
   }
 };
