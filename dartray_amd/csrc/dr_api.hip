@@ -56,8 +56,10 @@ struct DevBuf {
 
 struct Workspace {
   uint32_t cap = 0;
-  int nFloats = 0, maxTail = 0;
-  DevBuf<float> tiles;  // the tiled path state (see BatchState in dr_kernels.h): cap/64 tiles of 64*(41+nFloats) words
+  int svWords = 0, maxTail = 0;  // svWords: 4-byte words of the sample region of one tile
+  uint32_t pixCap = 0;
+  DevBuf<float> tiles;  // the tiled path state (see BatchState in dr_kernels.h): cap/64 tiles of 64*41+svWords words
+  DevBuf<uint32_t> scr;  // compact samples: scramble words [2 * nBlocks][pixCap]
   DevBuf<double> tail;
   DevBuf<uint32_t> activeA, activeB, closestQ, anyQ, counters, spill;
   DevBuf<int2> pix;
@@ -251,18 +253,29 @@ void getSubWindow(int w, int h, int num, int count, int ext[4]) {
   ext[3] = std::min((int)std::floor(lerp(ty1, 0, h)), h);
 }
 
-int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, int nFloats, int maxTail, bool needTail) {
+// How the sample vectors of one render are stored (see BatchState)
+struct SampleForm {
+  bool compact;
+  int nFloats, nBlocks, idxShift;
+  int svWords() const { return compact ? ((nBlocks * 64) << idxShift) / 4 : 64 * nFloats; }
+};
+
+int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, const SampleForm& sf, uint32_t pixCap, int maxTail, bool needTail) {
   cap = (cap + 63u) & ~63u;  // whole tiles
-  if (cap > w.cap || nFloats > w.nFloats) {
+  if (cap > w.cap || sf.svWords() > w.svWords) {
     uint32_t c = std::max(cap, w.cap);
-    int nf = std::max(nFloats, w.nFloats);
-    HIP_TRY(w.tiles.alloc((size_t)(c / 64) * 64 * (size_t)(DR_STATE_WORDS + nf)));
+    int sw = std::max(sf.svWords(), w.svWords);
+    HIP_TRY(w.tiles.alloc((size_t)(c / 64) * (64 * (size_t)DR_STATE_WORDS + (size_t)sw)));
     HIP_TRY(w.activeA.alloc(c));
     HIP_TRY(w.activeB.alloc(c));
     HIP_TRY(w.closestQ.alloc(2 * (size_t)c));
     HIP_TRY(w.anyQ.alloc(c));
     w.cap = c;
-    w.nFloats = nf;
+    w.svWords = sw;
+  }
+  if (sf.compact) {
+    w.pixCap = std::max(w.pixCap, pixCap);
+    HIP_TRY(w.scr.alloc(2 * (size_t)sf.nBlocks * w.pixCap));
   }
   if (needTail && ((size_t)w.cap * maxTail > w.tail.n)) HIP_TRY(w.tail.alloc((size_t)w.cap * maxTail));
   w.maxTail = maxTail;
@@ -271,16 +284,16 @@ int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, int nFloats, int max
   return DR_OK;
 }
 
-BatchState makeState(Workspace& w, const int2* pix, uint32_t nslots, bool useTail) {
+BatchState makeState(Workspace& w, const SampleForm& sf, const int2* pix, uint32_t nslots, bool useTail) {
   BatchState st;
   st.cap = w.cap;
   st.nslots = nslots;
-  st.tileStride = 64u * (uint32_t)(DR_STATE_WORDS + w.nFloats);
-  st.padts = 0;
+  st.tileStride = 64u * (uint32_t)DR_STATE_WORDS + (uint32_t)w.svWords;
+  st.idxShift = (uint32_t)sf.idxShift;
   st.pix = pix;
   st.tail = useTail ? w.tail.p : nullptr;
   // field offsets inside a tile, in 64-word runs: the three f64 fields first (8-byte aligned), then the
-  // 3-vectors, the i32 fields and the sample vector
+  // 3-vectors, the i32 fields and the sample region
   float* b = w.tiles.p;
   int f = 0;
   auto f64 = [&]() { double* p = (double*)(b + 64 * (size_t)f); f += 2; return p; };
@@ -304,7 +317,12 @@ BatchState makeState(Workspace& w, const int2* pix, uint32_t nslots, bool useTai
   st.misLight = i32();
   st.misPrim = i32();
   st.flags = (uint32_t*)i32();
-  st.sv = b + 64 * (size_t)f;  // f == DR_STATE_WORDS
+  float* region = b + 64 * (size_t)f;  // f == DR_STATE_WORDS
+  st.sv = sf.compact ? nullptr : region;
+  st.svIdx = sf.compact ? (uint8_t*)region : nullptr;
+  st.svScr = sf.compact ? w.scr.p : nullptr;
+  st.pixCap = w.pixCap;
+  st.padpc = 0;
   return st;
 }
 
@@ -1001,19 +1019,28 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     if (p.x >= rp.left && p.x < rp.left + rp.width && p.y >= rp.top && p.y < rp.top + rp.height) filmSamples += spp;
 
   // ---- workspace ----
+  // Sample vectors: the on-device LD sampler stores permuted indices + scrambles (compact form) whenever every LD block
+  // has one entry per pixel sample; host buffers and multi-entry blocks (DirectLighting with nsamples > 1) use floats.
+  SampleForm sf;
+  sf.compact = !hostBuf && rp.blocks == nullptr && !getenv("DARTRAY_FLOAT_SAMPLES");
+  sf.nFloats = rp.nFloats;
+  sf.nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
+  sf.idxShift = spp > 256 ? 1 : 0;
   static const int slotBits = getenv("DARTRAY_BATCH_BITS") ? std::min(28, std::max(16, atoi(getenv("DARTRAY_BATCH_BITS")))) : 28;
   static const int nPipesEnv = getenv("DARTRAY_PIPELINES") ? atoi(getenv("DARTRAY_PIPELINES")) : 1;
   uint64_t maxSlots = 1ull << slotBits;  // camera samples in flight per batch
   {
-    // path state per camera sample: the sample vector + 172 B of ray / hit / NEE state and queues (+ the RNG tail in
-    // host-buffer mode).  The default batch (2^28) takes 86 GB of a 288 GB MI355X; on a device with less free
+    // path state per camera sample: 164 B of ray / hit / NEE state, 20 B of queues and the sample vector (24 B of
+    // permuted indices in the compact form, 4 B per float otherwise; + the RNG tail in host-buffer mode).  The
+    // default batch (2^28) takes 56 GB of a 288 GB MI355X; on a device with less free
     // memory the batch shrinks instead of failing (results do not depend on the batch size).
-    const uint64_t perSlot = (uint64_t)(DR_STATE_WORDS + rp.nFloats) * 4 + 20 + (hostBuf && needTail > 0 ? (uint64_t)rd->max_tail * 8 : 0) +
-                             (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0);
+    const uint64_t perSlot = (uint64_t)DR_STATE_WORDS * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 +
+                             (hostBuf && needTail > 0 ? (uint64_t)rd->max_tail * 8 : 0) + (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0) +
+                             (sf.compact ? (uint64_t)(8 * sf.nBlocks + spp - 1) / spp : 0);
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)(DR_STATE_WORDS + sc->ws.nFloats) * 4 + 20) +
-                            (uint64_t)sc->ws2.cap * ((uint64_t)(DR_STATE_WORDS + sc->ws2.nFloats) * 4 + 20);
+      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)DR_STATE_WORDS * 4 + sc->ws.svWords / 16 + 20) +
+                            (uint64_t)sc->ws2.cap * ((uint64_t)DR_STATE_WORDS * 4 + sc->ws2.svWords / 16 + 20);
       const uint64_t budget = (uint64_t)(0.9 * (double)freeB) + have;
       const uint64_t pipes = nPipesEnv >= 2 && !hostBuf ? 2 : 1;
       while (maxSlots > (1ull << 16) && std::min<uint64_t>(maxSlots, (uint64_t)npixTotal * spp) * perSlot * pipes > budget) maxSlots >>= 1;
@@ -1021,14 +1048,14 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   }
   const uint32_t pixPerBatch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(npixTotal, maxSlots / spp));
   const uint32_t cap = pixPerBatch * (uint32_t)spp;
-  int rc = allocWorkspace(sc, sc->ws, cap, rp.nFloats, rd->max_tail, hostBuf && needTail > 0);
+  int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0);
   if (rc) return rc;
   const int tgrid = traceGrid();
   rc = ensureSpill(sc, sc->ws, tgrid);
   if (rc) return rc;
   const bool twoPipes = nPipesEnv >= 2 && !hostBuf && npixTotal > pixPerBatch;
   if (twoPipes) {
-    rc = allocWorkspace(sc, sc->ws2, cap, rp.nFloats, rd->max_tail, false);
+    rc = allocWorkspace(sc, sc->ws2, cap, sf, pixPerBatch, rd->max_tail, false);
     if (rc) return rc;
     rc = ensureSpill(sc, sc->ws2, tgrid);
     if (rc) return rc;
@@ -1046,7 +1073,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     HIP_TRY(hipStreamWaitEvent(sc->s2, ev, 0));
   }
   size_t batchIndex = 0;
-  const int sgrid = g_numCU * 2;  // 512-thread workgroups, grid-stride over the active list
+  const int sgrid = g_numCU;  // the shade launchers size their grid per CU (DR_SHADE_GRID), grid-stride over the active list
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
   if (4 * nStages + 8 > 1024 || 8 * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
 
@@ -1056,7 +1083,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     s = second ? sc->s2 : callerStream;
     const uint32_t np = (uint32_t)std::min<size_t>(pixPerBatch, npixTotal - p0);
     const uint32_t nslots = np * (uint32_t)spp;
-    BatchState st = makeState(w, sc->ws.pix.p + p0, nslots, hostBuf && needTail > 0);
+    BatchState st = makeState(w, sf, sc->ws.pix.p + p0, nslots, hostBuf && needTail > 0);
     HIP_TRY(hipMemsetAsync(w.counters.p, 0, N_COUNTERS * sizeof(uint32_t), s));
     auto timed = [&](int kind, hipEvent_t e0) {
       hipEvent_t e1 = sc->getEvent();

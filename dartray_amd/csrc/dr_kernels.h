@@ -52,7 +52,7 @@ struct RenderParams {
 // State of one batch of camera samples.  Slot s belongs to batch pixel s >> sppShift, sample s & (spp-1).
 // Layout: array-of-structures-of-arrays in tiles of 64 slots (one wave).  A tile holds, for its 64 slots, every
 // field as one 256-byte run -- the f64 fields, the 3-vectors component by component, the i32 fields and the
-// nFloats sample-vector entries -- so the ~45 coalesced loads and ~35 stores of one shading step all land in one
+// sample vectors -- so the ~45 coalesced loads and ~35 stores of one shading step all land in one
 // contiguous ~tileStride*4-byte region (a handful of DRAM rows) instead of 80 arrays a gigabyte apart.
 // Field pointers below already include the field's offset inside the tile: element (field, slot) is
 // ptr[TI(tileStride, slot)]; component c of a 3-vector is 64 words further per component; the f64 arrays use TD.
@@ -61,10 +61,19 @@ struct RenderParams {
 struct BatchState {
   uint32_t cap;     // slots allocated (a multiple of 64)
   uint32_t nslots;  // slots used by the current batch
-  uint32_t tileStride;  // 4-byte words per 64-slot tile = 64 * (41 + nFloats)
-  uint32_t padts;
+  uint32_t tileStride;  // 4-byte words per 64-slot tile = 64 * 41 + the sample region
+  uint32_t idxShift;    // compact samples: 0 = u8 indices (spp <= 256), 1 = u16
   const int2* pix;  // raster pixel of each batch pixel
-  float* sv;        // [nFloats][cap] sample vectors
+  // The camera-sample vectors (Sample, montecarlo.dart:437-452), in one of two forms:
+  //  float:   sv != null -- nFloats 64-word runs per tile (host-buffer sampler, multi-entry LD blocks);
+  //  compact: sv == null -- the on-device LD sampler only stores what cannot be recomputed: per (LD block, slot)
+  //           the Fisher-Yates-permuted sample index (one byte; a 64-byte run per block and tile) and per
+  //           (LD block, batch pixel) the two scramble words; consumers evaluate VanDerCorput / Sobol2 themselves
+  //           (sv_one / sv_pair in dr_kernels.hip).  24 B instead of 148 B per path sample.
+  float* sv;
+  uint8_t* svIdx;     // tile-relative base of the index runs
+  uint32_t* svScr;    // [2 * nBlocks][pixCap]
+  uint32_t pixCap, padpc;
   const double* tail;  // [cap][maxTail] host-buffer mode, else null
   float* ro;        // ray origin (vertex position p once a vertex has been shaded)
   float* ro0;       // DirectLighting with quadrics: the camera ray's origin (null otherwise)

@@ -49,13 +49,82 @@ __global__ void k_gather_tris(const float* verts, const uint32_t* idx, const uin
 DR_DEV float VanDerCorput(uint32_t n, uint32_t scramble) {  // montecarlo.dart:495-504
   n = __brev(n);
   n ^= scramble;
-  // min(((n>>8)&0xffffff)/2^24, ONE_MINUS_EPSILON): the quotient never exceeds 1-2^-24
-  return (float)((double)((n >> 8) & 0xffffffu) / 16777216.0);
+  // min(((n>>8)&0xffffff)/2^24, ONE_MINUS_EPSILON): the quotient never exceeds 1-2^-24; a 24-bit integer times
+  // 2^-24 is exact in f32, so this equals the reference's f64 quotient stored to f32
+  return (float)(n >> 8) * 5.9604644775390625e-8f;
 }
-DR_DEV float Sobol2(uint32_t n, uint32_t scramble) {  // montecarlo.dart:486-493
-  for (uint32_t v = 1u << 31; n != 0; n >>= 1, v ^= v >> 1)
+// Sobol2 (montecarlo.dart:486-493) XORs the direction number v_b = v_{b-1} ^ (v_{b-1} >> 1), v_0 = 2^31, into the
+// scramble for every set bit b of n: linear over GF(2), so the low byte of n is one table look-up.
+struct SobolTable {
+  uint32_t lo[256];
+  uint32_t v8;  // direction number of bit 8
+  constexpr SobolTable() : lo(), v8(0) {
+    for (uint32_t n = 0; n < 256; ++n) {
+      uint32_t r = 0, v = 1u << 31;
+      for (uint32_t m = n; m != 0; m >>= 1, v ^= v >> 1)
+        if (m & 1u) r ^= v;
+      lo[n] = r;
+    }
+    uint32_t v = 1u << 31;
+    for (int b = 0; b < 8; ++b) v ^= v >> 1;
+    v8 = v;
+  }
+};
+__constant__ SobolTable c_sobol = SobolTable();
+DR_DEV float Sobol2(uint32_t n, uint32_t scramble) {
+  scramble ^= c_sobol.lo[n & 255u];
+  n >>= 8;
+  for (uint32_t v = c_sobol.v8; n != 0; n >>= 1, v ^= v >> 1)
     if (n & 1u) scramble ^= v;
-  return (float)((double)((scramble >> 8) & 0xffffffu) / 16777216.0);
+  return (float)(scramble >> 8) * 5.9604644775390625e-8f;
+}
+
+// ---- camera-sample vector access (see BatchState): float form or compact (index, scramble) form ----
+// LD block of float field f (Appendix B layout: image, lens, time, n1D 1-D slots, then the 2-D slots)
+DR_DEV int sv_block(const RenderParams& rp, int f) {
+  return f < 5 ? (f >> 1) : (f < 5 + rp.n1D ? f - 2 : 3 + rp.n1D + ((f - 5 - rp.n1D) >> 1));
+}
+// raw fetch of 1-D field f: float bits, or the permuted index + its scramble
+DR_DEV void sv_fetch1(const RenderParams& rp, const BatchState& st, uint32_t slot, int f, uint32_t* raw, uint32_t* scr) {
+  if (st.sv) {
+    *raw = __float_as_uint(LDS_STREAM(st.sv + TI(st.tileStride, slot) + (size_t)f * 64));
+    *scr = 0u;
+    return;
+  }
+  const int k = sv_block(rp, f);
+  const uint8_t* q = st.svIdx + (size_t)(slot >> 6) * st.tileStride * 4 + (((size_t)k * 64 + (slot & 63u)) << st.idxShift);
+  *raw = st.idxShift ? (uint32_t)*(const uint16_t*)q : (uint32_t)*q;
+  *scr = st.svScr[(size_t)(2 * k) * st.pixCap + (slot >> rp.sppShift)];
+}
+// raw fetch of the 2-D entry whose first float is field f
+DR_DEV void sv_fetch2(const RenderParams& rp, const BatchState& st, uint32_t slot, int f, uint32_t* raw, uint32_t* scr) {
+  if (st.sv) {
+    raw[0] = __float_as_uint(LDS_STREAM(st.sv + TI(st.tileStride, slot) + (size_t)f * 64));
+    raw[1] = __float_as_uint(LDS_STREAM(st.sv + TI(st.tileStride, slot) + (size_t)(f + 1) * 64));
+    scr[0] = scr[1] = 0u;
+    return;
+  }
+  const int k = sv_block(rp, f);
+  const uint8_t* q = st.svIdx + (size_t)(slot >> 6) * st.tileStride * 4 + (((size_t)k * 64 + (slot & 63u)) << st.idxShift);
+  raw[0] = raw[1] = st.idxShift ? (uint32_t)*(const uint16_t*)q : (uint32_t)*q;
+  scr[0] = st.svScr[(size_t)(2 * k) * st.pixCap + (slot >> rp.sppShift)];
+  scr[1] = st.svScr[(size_t)(2 * k + 1) * st.pixCap + (slot >> rp.sppShift)];
+}
+// value of a fetched entry; second: the y half of a 2-D entry (Sample02, montecarlo.dart:480-484)
+DR_DEV float sv_value(const BatchState& st, uint32_t raw, uint32_t scr, bool second) {
+  if (st.sv) return __uint_as_float(raw);
+  return second ? Sobol2(raw, scr) : VanDerCorput(raw, scr);
+}
+DR_DEV float sv_one(const RenderParams& rp, const BatchState& st, uint32_t slot, int f) {
+  uint32_t raw, scr;
+  sv_fetch1(rp, st, slot, f, &raw, &scr);
+  return sv_value(st, raw, scr, false);
+}
+DR_DEV void sv_pair(const RenderParams& rp, const BatchState& st, uint32_t slot, int f, float* x, float* y) {
+  uint32_t raw[2], scr[2];
+  sv_fetch2(rp, st, slot, f, raw, scr);
+  *x = sv_value(st, raw[0], scr[0], false);
+  *y = sv_value(st, raw[1], scr[1], true);
 }
 
 // PT = uint8_t while spp <= 256 (half the LDS => twice the waves per CU), uint16_t above.  Rows of the
@@ -105,8 +174,20 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
   __syncthreads();
   // write-out: element e of this wave's 64*spp contiguous outputs belongs to pixel e >> sppShift
   const uint32_t nOut = min(64u, npix - p0) * (uint32_t)spp;
-  float* out0 = st.sv + (size_t)dst * 64;  // field `dst` of the sample vector inside each tile
   const uint32_t slot0 = p0 * (uint32_t)spp;
+  if (!st.sv) {  // compact form: the permuted indices and the scrambles (block k == blockIdx.y: rp.blocks is null)
+    if (p < npix) {
+      st.svScr[(size_t)(2 * k) * st.pixCap + p] = s_scr[lane];
+      st.svScr[(size_t)(2 * k + 1) * st.pixCap + p] = s_scr[64 + lane];
+    }
+    for (uint32_t e = lane; e < nOut; e += 64u) {
+      const uint32_t pl = e >> rp.sppShift, j = e & (uint32_t)(spp - 1), slot = slot0 + e;
+      PT* o = (PT*)(st.svIdx + (size_t)(slot >> 6) * st.tileStride * 4) + (size_t)k * 64 + (slot & 63u);
+      *o = s_perm[j * ROW + pl];
+    }
+    return;
+  }
+  float* out0 = st.sv + (size_t)dst * 64;  // field `dst` of the sample vector inside each tile
   for (uint32_t e = lane; e < nOut; e += 64u) {
     const uint32_t pl = e >> rp.sppShift, j = e & (uint32_t)(spp - 1);
     const uint32_t idx = s_perm[j * ROW + pl];
@@ -212,16 +293,18 @@ __global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) 
   if (s >= st.nslots) return;
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const int2 xy = st.pix[s >> rp.sppShift];
-  const float* svs = st.sv + TI(cap, s);
-  const double imageX = (double)xy.x + (double)svs[0];               // montecarlo.dart:451-452
-  const double imageY = (double)xy.y + (double)svs[64];
+  float sx, sy;
+  sv_pair(rp, st, s, 0, &sx, &sy);
+  const double imageX = (double)xy.x + (double)sx;               // montecarlo.dart:451-452
+  const double imageY = (double)xy.y + (double)sy;
   F3 Pras = f3(imageX, imageY, 0.0);
   F3 Pcamera = xf_point(rp.r2c, Pras);
   F3 o = F3{0.f, 0.f, 0.f};
   F3 d = vnormalize(Pcamera);
   if (rp.lensRadius > 0.0f) {
     double lu, lv;
-    ConcentricSampleDisk((double)svs[128], (double)svs[192], &lu, &lv);
+    sv_pair(rp, st, s, 2, &sx, &sy);
+    ConcentricSampleDisk((double)sx, (double)sy, &lu, &lv);
     lu *= (double)rp.lensRadius;
     lv *= (double)rp.lensRadius;
     double ft = (double)rp.focalDistance / (double)d.z;
@@ -431,7 +514,9 @@ struct ShadeIn {
   double t;
   C3 L, beta, betaNee, Ld1;
   F3 o, d;
-  float su[10];  // this bounce's sample-vector slots (Appendix B): lightNum, light comp, light pos, bsdf dir, path dir, the two uComponents
+  // this bounce's sample-vector entries (Appendix B), as fetched (sv_fetch1/2): lightNum, light comp, light pos,
+  // bsdf dir, path dir, the two uComponents; evaluated when the item is shaded
+  uint32_t raw[10], scr[10];
   bool valid;
 };
 template <bool QUAD>
@@ -451,25 +536,35 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
   in->o = ld3(st.ro, cap, slot);
   in->d = ld3(st.rd, cap, slot);
   if (bounce < 3) {
-    const float* sv = st.sv;
-    in->su[0] = sv[TI(cap, slot) + (size_t)(5 + 4 * bounce + 1) * 64];
-    in->su[1] = sv[TI(cap, slot) + (size_t)(5 + 4 * bounce + 0) * 64];
+    sv_fetch1(rp, st, slot, 5 + 4 * bounce + 1, &in->raw[0], &in->scr[0]);
+    sv_fetch1(rp, st, slot, 5 + 4 * bounce + 0, &in->raw[1], &in->scr[1]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) in->su[2 + k] = sv[TI(cap, slot) + (size_t)(5 + rp.n1D + 2 * (3 * bounce) + k) * 64];
+    for (int k = 0; k < 3; ++k) sv_fetch2(rp, st, slot, 5 + rp.n1D + 2 * (3 * bounce + k), &in->raw[2 + 2 * k], &in->scr[2 + 2 * k]);
     if (QUAD) {
-      in->su[8] = sv[TI(cap, slot) + (size_t)(5 + 4 * bounce + 3) * 64];  // path-sample uComponent
-      in->su[9] = sv[TI(cap, slot) + (size_t)(5 + 4 * bounce + 2) * 64];  // BSDF-sample uComponent of the light estimate
+      sv_fetch1(rp, st, slot, 5 + 4 * bounce + 3, &in->raw[8], &in->scr[8]);  // path-sample uComponent
+      sv_fetch1(rp, st, slot, 5 + 4 * bounce + 2, &in->raw[9], &in->scr[9]);  // BSDF-sample uComponent of the light estimate
     }
   }
 }
 
 // One vertex of PathIntegrator.Li (path_integrator.dart:44-119).
+// Launch shape (measured): ONE 768-thread workgroup per CU = 3 waves per SIMD (168 VGPRs each).
+// Smaller workgroups pay more same-address queue atomics (one per workgroup, counter and iteration), 4 waves per
+// SIMD spill; prefetching the next item's state (DR_SHADE_PIPELINE) costs registers and cannot overlap anything
+// because vmcnt retires in order.
 #ifndef DR_SHADE_WAVES
-#define DR_SHADE_WAVES 2
+#define DR_SHADE_WAVES 3
 #endif
 #ifndef DR_SHADE_BLOCK
-#define DR_SHADE_BLOCK 512
+#define DR_SHADE_BLOCK 768
 #endif
+#ifndef DR_SHADE_PIPELINE
+#define DR_SHADE_PIPELINE 0
+#endif
+#ifndef DR_SHADE_GRID_PER_CU
+#define DR_SHADE_GRID_PER_CU 1
+#endif
+#define DR_SHADE_GRID(numCU) ((numCU) * DR_SHADE_GRID_PER_CU)
 template <bool ENV, bool QUAD>
 __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
   __shared__ PushScratch s_push;
@@ -482,10 +577,13 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
   // instructions of shading instead of stalling a SIMD that only holds two of these waves.
   const uint32_t tid0 = blockIdx.x * blockDim.x + threadIdx.x;
   auto slotOf = [&](uint32_t i) -> uint32_t { return i < nIn ? (q.activeIn ? q.activeIn[i] : i) : 0u; };
+#if DR_SHADE_PIPELINE
   ShadeIn nxt;
   uint32_t slotNext2 = slotOf(tid0 + stride);
   load_shade_in<QUAD>(st, rp, bounce, slotOf(tid0), tid0 < nIn, &nxt);
+#endif
   for (uint32_t it = 0; it < nIter; ++it) {
+#if DR_SHADE_PIPELINE
     const ShadeIn cur = nxt;
     {
       const uint32_t i1 = (it + 1) * stride + tid0, i2 = (it + 2) * stride + tid0;
@@ -493,6 +591,10 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
       slotNext2 = (it + 2 < nIter) ? slotOf(i2) : 0u;
       if (it + 1 < nIter) load_shade_in<QUAD>(st, rp, bounce, s1, i1 < nIn, &nxt);
     }
+#else
+    ShadeIn cur;
+    load_shade_in<QUAD>(st, rp, bounce, slotOf(it * stride + tid0), it * stride + tid0 < nIn, &cur);
+#endif
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
     bool pushCont = false;
@@ -506,7 +608,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
       const C3 betaNeeIn = cur.betaNee;
       const C3 Ld1In = cur.Ld1;
       const F3 o = cur.o, d = cur.d;
-      const float* su = cur.su;
+      auto su = [&](int k) -> float { return sv_value(st, cur.raw[k], cur.scr[k], k >= 2 && k < 8 && (k & 1)); };
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
         C3 Ld = resolve_nee<ENV, QUAD>(sc, st, slot, flags, shOccIn, Ld1In);
@@ -555,13 +657,13 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         if (rp.nLights > 0) {
           double lu, ls0, ls1, lsc, bs0, bs1, bsc = 0.0;
           if (bounce < 3) {  // SAMPLE_DEPTH (path_integrator.dart:139), slots of Appendix B
-            lu = su[0];
-            lsc = su[1];
-            ls0 = su[2];
-            ls1 = su[3];
-            bs0 = su[4];
-            bs1 = su[5];
-            if (QUAD) bsc = su[9];
+            lu = su(0);
+            lsc = su(1);
+            ls0 = su(2);
+            ls1 = su(3);
+            bs0 = su(4);
+            bs1 = su(5);
+            if (QUAD) bsc = su(9);
           } else {
             lu = ts.next(rp);                                   // integrator.dart:96
             ls0 = (float)ts.next(rp); ls1 = (float)ts.next(rp); // LightSample.random light_sample.dart:46-51
@@ -577,9 +679,9 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
         double o0, o1, oc = 0.0;
         if (bounce < 3) {
-          o0 = su[6];
-          o1 = su[7];
-          if (QUAD) oc = su[8];
+          o0 = su(6);
+          o1 = su(7);
+          if (QUAD) oc = su(8);
         } else {
           o0 = (float)ts.next(rp); o1 = (float)ts.next(rp);
           oc = ts.next(rp);
@@ -686,14 +788,13 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
           else dgs = dg;
           Bsdf bsdf = make_bsdf<QUAD>(sc, dgs, tr.mat);  // mirror / glass are refused for DirectLighting; Oren-Nayar is not
           bsdf.ng = dg.nn;
-          const float* sv = st.sv;
           // sample slots of this call (direct_lighting_integrator.dart:70-87)
-          double lsc = LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.lc) * 64);
-          double ls0 = LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.lp) * 64);
-          double ls1 = LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.lp + 1) * 64);
-          double bs0 = LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.bd) * 64);
-          double bs1 = LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.bd + 1) * 64);
-          double bsc = QUAD ? (double)LDS_STREAM(sv + TI(cap, slot) + (size_t)(cur.bc) * 64) : 0.0;
+          float l0, l1, b0, b1;
+          sv_pair(rp, st, slot, cur.lp, &l0, &l1);
+          sv_pair(rp, st, slot, cur.bd, &b0, &b1);
+          double lsc = sv_one(rp, st, slot, cur.lc);
+          double ls0 = l0, ls1 = l1, bs0 = b0, bs1 = b1;
+          double bsc = QUAD ? (double)sv_one(rp, st, slot, cur.bc) : 0.0;
           pf |= setup_nee<true, QUAD>(sc, st, slot, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
           again = true;
         } else {
@@ -746,9 +847,10 @@ __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, co
         if (L.r != L.r || L.g != L.g || L.b != L.b) L = C3{0.f, 0.f, 0.f};
         else if (lum < -1e-5) L = C3{0.f, 0.f, 0.f};
         else if (isinf(lum)) L = C3{0.f, 0.f, 0.f};
-        const float* svs = st.sv + TI(cap, s);
-        const double dimageX = ((double)xy.x + (double)svs[0]) - 0.5;
-        const double dimageY = ((double)xy.y + (double)svs[64]) - 0.5;
+        float sx, sy;
+        sv_pair(rp, st, s, 0, &sx, &sy);
+        const double dimageX = ((double)xy.x + (double)sx) - 0.5;
+        const double dimageY = ((double)xy.y + (double)sy) - 0.5;
         int x0 = (int)ceil(dimageX - rp.fxw), x1 = (int)floor(dimageX + rp.fxw);
         int y0 = (int)ceil(dimageY - rp.fyw), y1 = (int)floor(dimageY + rp.fyw);
         x0 = max(x0, rp.left); x1 = min(x1, rp.left + rp.width - 1);
@@ -871,14 +973,14 @@ void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) 
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL((k_shade_path<true, true>), dim3(grid * 512 / DR_SHADE_BLOCK), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
-  else if (sc.hasEnv) hipLaunchKernelGGL((k_shade_path<true, false>), dim3(grid * 512 / DR_SHADE_BLOCK), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
-  else hipLaunchKernelGGL((k_shade_path<false, false>), dim3(grid * 512 / DR_SHADE_BLOCK), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL((k_shade_path<true, true>), dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  else if (sc.hasEnv) hipLaunchKernelGGL((k_shade_path<true, false>), dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  else hipLaunchKernelGGL((k_shade_path<false, false>), dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL(k_shade_direct<true>, dim3(grid * 512 / DR_SHADE_BLOCK), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
-  else hipLaunchKernelGGL(k_shade_direct<false>, dim3(grid * 512 / DR_SHADE_BLOCK), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
+  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL(k_shade_direct<true>, dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
+  else hipLaunchKernelGGL(k_shade_direct<false>, dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
                  hipStream_t s) {
