@@ -567,7 +567,9 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
 #define DR_SHADE_GRID(numCU) ((numCU) * DR_SHADE_GRID_PER_CU)
 template <bool ENV, bool QUAD>
 __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
-  __shared__ PushScratch s_push;
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  PushStage& s_push = *(PushStage*)s_dyn;
+  PushCtx pctx = {{0, 0, 0, 0}, 0};
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -713,8 +715,8 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
       stc(st.L, cap, slot, L);
       st.flags[TI(cap, slot)] = pf;
     }
-    block_push(s_push, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, pushCont,
-               (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT);
+    stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT);
+    if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter) stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut);
   }
 }
 
@@ -724,7 +726,9 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
 // sum.  st.betaNee carries the current light's Ld, st.beta the running L of UniformSampleAllLights.
 template <bool QUAD>
 __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
-  __shared__ PushScratch s_push;
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  PushStage& s_push = *(PushStage*)s_dyn;
+  PushCtx pctx = {{0, 0, 0, 0}, 0};
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -812,8 +816,8 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
       }
       st.flags[TI(cap, slot)] = pf;
     }
-    block_push(s_push, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, false,
-               (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, again, slot, Q_MIS_BIT);
+    stage_push(s_push, pctx, false, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, again, slot, Q_MIS_BIT);
+    if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter) stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut);
   }
 }
 
@@ -971,16 +975,27 @@ void launch_transpose_samples(const float* aos, int stride, const BatchState& st
 void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) {
   hipLaunchKernelGGL(k_raygen, dim3((st.nslots + 255) / 256), dim3(256), 0, s, rp, st);
 }
+// The shade kernels stage their queue entries in dynamic LDS (PushStage, dr_wave.h): ~96 KB of the CU's 160 KB.
+template <auto kernel, class... A>
+static void launch_shade(int grid, hipStream_t s, A... args) {
+  const size_t lds = push_stage_bytes(DR_SHADE_BLOCK);
+  static bool attrSet = false;  // one instance of this template, hence one flag, per kernel
+  if (!attrSet) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attrSet = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), lds, s, args...);
+}
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL((k_shade_path<true, true>), dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
-  else if (sc.hasEnv) hipLaunchKernelGGL((k_shade_path<true, false>), dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
-  else hipLaunchKernelGGL((k_shade_path<false, false>), dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, bounce);
+  if (sc.nquads || sc.hasSpec || sc.srec) launch_shade<k_shade_path<true, true>>(grid, s, sc, rp, st, q, bounce);
+  else if (sc.hasEnv) launch_shade<k_shade_path<true, false>>(grid, s, sc, rp, st, q, bounce);
+  else launch_shade<k_shade_path<false, false>>(grid, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec || sc.srec) hipLaunchKernelGGL(k_shade_direct<true>, dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
-  else hipLaunchKernelGGL(k_shade_direct<false>, dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), 0, s, sc, rp, st, q, stage);
+  if (sc.nquads || sc.hasSpec || sc.srec) launch_shade<k_shade_direct<true>>(grid, s, sc, rp, st, q, stage);
+  else launch_shade<k_shade_direct<false>>(grid, s, sc, rp, st, q, stage);
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
                  hipStream_t s) {
