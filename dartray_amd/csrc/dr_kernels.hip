@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
   extern __shared__ __align__(16) unsigned char s_raw[];
   PT* s_perm = (PT*)s_raw;                                      // [spp][ROW]
   uint32_t* s_scr = (uint32_t*)(s_raw + (size_t)rp.spp * ROW * sizeof(PT));  // [2][64]
+  uint32_t* s_magic = s_scr + 128;  // [spp + 1]: floor(2^32 / m), the reciprocal of the Fisher-Yates divisors
   const int lane = threadIdx.x;
   const uint32_t p0 = blockIdx.x * 64u;
   const uint32_t p = p0 + lane;
@@ -154,6 +155,8 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
   else if (k == 2) { is2D = false; dst = 4; }
   else if (k < 3 + rp.n1D) { is2D = false; dst = 5 + (k - 3); }
   else { is2D = true; dst = 5 + rp.n1D + 2 * (k - 3 - rp.n1D); }
+  for (int m = 1 + lane; m <= spp; m += 64) s_magic[m] = m == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)m);
+  __syncthreads();
   if (p < npix) {
     const int2 xy = st.pix[p];
     const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
@@ -165,7 +168,11 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
     for (int i = 0; i < spp; ++i) (void)rng.randomUint();  // Shuffle of ONE entry: other = i + r % 1 (:294-303)
     for (int i = 0; i < spp; ++i) s_perm[i * ROW + lane] = (PT)i;
     for (int i = 0; i < spp; ++i) {
-      const int other = i + (int)(rng.randomUint() % (uint32_t)(spp - i));
+      // r % m for the wave-uniform divisor m = spp - i: q = mulhi(r, floor(2^32 / m)) is r / m or one less
+      const uint32_t r = rng.randomUint(), m = (uint32_t)(spp - i);
+      uint32_t rem = r - __umulhi(r, s_magic[m]) * m;
+      if (rem >= m) rem -= m;
+      const int other = i + (int)rem;
       const PT a = s_perm[i * ROW + lane];
       s_perm[i * ROW + lane] = s_perm[other * ROW + lane];
       s_perm[other * ROW + lane] = a;
@@ -574,9 +581,11 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
-  // Software pipeline over the grid-stride loop: the active-list entry of item it+2 and the whole slot state of item
-  // it+1 are requested before item it is shaded, so their two dependent HBM round trips overlap the ~3000
-  // instructions of shading instead of stalling a SIMD that only holds two of these waves.
+  // DR_SHADE_PIPELINE 0: every iteration fetches its active-list entry, then the slot state (two dependent trips).
+  // 1: the state of item it+1 is requested before item it is shaded (costs ~45 registers for the whole iteration and
+  //    cannot overlap much: vmcnt retires in order, so the first load of the shading code waits for the prefetch).
+  // 2: the active-list entry is fetched two iterations ahead (one register) and the state of item it+1 is requested
+  //    AFTER item it has been shaded, ahead of the queue push and its barriers.
   const uint32_t tid0 = blockIdx.x * blockDim.x + threadIdx.x;
   auto slotOf = [&](uint32_t i) -> uint32_t { return i < nIn ? (q.activeIn ? q.activeIn[i] : i) : 0u; };
 #if DR_SHADE_PIPELINE
@@ -585,7 +594,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
   load_shade_in<QUAD>(st, rp, bounce, slotOf(tid0), tid0 < nIn, &nxt);
 #endif
   for (uint32_t it = 0; it < nIter; ++it) {
-#if DR_SHADE_PIPELINE
+#if DR_SHADE_PIPELINE == 1
     const ShadeIn cur = nxt;
     {
       const uint32_t i1 = (it + 1) * stride + tid0, i2 = (it + 2) * stride + tid0;
@@ -593,6 +602,10 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
       slotNext2 = (it + 2 < nIter) ? slotOf(i2) : 0u;
       if (it + 1 < nIter) load_shade_in<QUAD>(st, rp, bounce, s1, i1 < nIn, &nxt);
     }
+#elif DR_SHADE_PIPELINE == 2
+    const ShadeIn cur = nxt;
+    const uint32_t slotNext1 = slotNext2;
+    slotNext2 = (it + 2 < nIter) ? slotOf((it + 2) * stride + tid0) : 0u;
 #else
     ShadeIn cur;
     load_shade_in<QUAD>(st, rp, bounce, slotOf(it * stride + tid0), it * stride + tid0 < nIn, &cur);
@@ -715,6 +728,9 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
       stc(st.L, cap, slot, L);
       st.flags[TI(cap, slot)] = pf;
     }
+#if DR_SHADE_PIPELINE == 2
+    if (it + 1 < nIter) load_shade_in<QUAD>(st, rp, bounce, slotNext1, (it + 1) * stride + tid0 < nIn, &nxt);
+#endif
     stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT);
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter) stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut);
   }
@@ -957,10 +973,10 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t n
   const dim3 grid((npix + 63) / 64, nBlocks);
   if (rp.blocks) hipLaunchKernelGGL(k_gen_samples_multi, grid, dim3(64), 0, s, rp, st, npix);
   if (rp.spp <= 256) {
-    const size_t lds = (size_t)rp.spp * 68 + 512;
+    const size_t lds = (size_t)rp.spp * 68 + 512 + ((size_t)rp.spp + 1) * 4;
     hipLaunchKernelGGL((k_gen_samples<uint8_t, 68>), grid, dim3(64), lds, s, rp, st, npix);
   } else {
-    const size_t lds = (size_t)rp.spp * 66 * sizeof(uint16_t) + 512;
+    const size_t lds = (size_t)rp.spp * 66 * sizeof(uint16_t) + 512 + ((size_t)rp.spp + 1) * 4;
     static bool attrSet = false;
     if (!attrSet) {
       (void)hipFuncSetAttribute((const void*)k_gen_samples<uint16_t, 66>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -48,14 +48,13 @@ struct DartRandom {
     lo = (uint32_t)(s & 0xffffffffu);
     hi = (uint32_t)(s >> 32);
   }
-  // Random.nextInt(0xffffffff) (rng.dart:40-42): rejection only when lo == 0xffffffff.
+  // Random.nextInt(0xffffffff) (rng.dart:40-42): `result = rnd32 % max` with the retry test
+  // `rnd32 - result + max > 2^32`; for max = 2^32 - 1 the result is lo itself and the only rejected draw is
+  // lo == 0xffffffff.
   DR_HD uint32_t randomUint() {
-    for (;;) {
-      step();
-      uint64_t rnd32 = lo;
-      uint64_t result = rnd32 % 0xffffffffULL;
-      if (!((rnd32 - result + 0xffffffffULL) > (1ULL << 32))) return (uint32_t)result;
-    }
+    do step();
+    while (lo == 0xffffffffu);
+    return lo;
   }
   // Random.nextDouble() (rng.dart:36-38): 26 + 27 bits from two steps.
   DR_HD double randomFloat() {

@@ -9,7 +9,8 @@ dealt round-robin over ranks for load balance, every rank accumulating into a ze
 full-frame (X, Y, Z, weight) film and ONE reduce(sum) of that film to rank 0 per render.  With
 the box filter of radius 0.5 the tiles are disjoint, so the sum adds zeros and is exact; with
 wider filters the sum also carries the splats across tile borders that the reference's
-rectangle copy drops.  torch is plumbing here (device memory, streams, the collective).
+rectangle copy drops.  `sample_set` is the weak-scaling alternative (bench.py's default at N > 1): every rank
+renders the whole image with its own sampler seed and the same reduce adds the sample sets up.  torch is plumbing here (device memory, streams, the collective).
 """
 import os
 
@@ -35,6 +36,13 @@ def init_process_group():
 def shard(renderer, rank, world, tile_size=32):
     """Give `renderer` this rank's share of the image: round-robin tiles."""
     renderer.tileRank, renderer.tileCount, renderer.tileSize = rank, world, tile_size
+    return renderer
+
+
+def sample_set(renderer, rank):
+    """Weak scaling: every rank renders ALL pixels with its own sample set (sampler seed + rank); the summed
+    films are the image at world x spp samples per pixel (ImageFilm keeps weighted sums, image_film.dart:99-185)."""
+    renderer.sampler.seed = int(renderer.sampler.seed) + int(rank)
     return renderer
 
 

@@ -12,7 +12,7 @@ import pytest
 from conftest import ROOT
 
 
-def _worker(rank, world, init_file, out_file):
+def _worker(rank, world, init_file, out_file, weak=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -21,7 +21,7 @@ def _worker(rank, world, init_file, out_file):
     import oracle.binding as ob
     dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
     prims, mk = scenes.config("C2", xres=40, yres=40, spp=4, blob=(12, 6))
-    r = drdist.shard(mk(), rank, world, tile_size=16)
+    r = drdist.sample_set(mk(), rank) if weak else drdist.shard(mk(), rank, world, tile_size=16)
     px = r.pixels()
     osc = ob.OracleScene(prims)
     film = osc.render(ob.render_desc(r, sampler_mode=1, pixels=px))["film"]
@@ -46,6 +46,27 @@ def test_two_rank_tile_sharding_and_film_reduce(ob):
     # box filter radius 0.5: tiles are disjoint, the sum only adds zeros => bit-exact
     assert np.array_equal(merged, single)
     assert np.all(merged[..., 3] >= 4)
+
+
+def test_two_rank_sample_sets_and_film_reduce(ob):
+    """bench.py's default N > 1 mode: each rank renders the whole image with sampler seed + rank, one reduce(sum)."""
+    import torch.multiprocessing as mp
+    from dartray_amd import scenes
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "init")
+        out_file = os.path.join(tmp, "film.npy")
+        mp.spawn(_worker, args=(2, init_file, out_file, True), nprocs=2, join=True)
+        merged = np.load(out_file)
+    prims, mk = scenes.config("C2", xres=40, yres=40, spp=4, blob=(12, 6))
+    osc = ob.OracleScene(prims)
+    films = []
+    for rank in range(2):
+        r = mk()
+        r.sampler.seed += rank
+        films.append(osc.render(ob.render_desc(r, sampler_mode=1))["film"])
+    assert not np.array_equal(films[0], films[1])
+    assert np.array_equal(merged, films[0] + films[1])  # one f32 add per element either way
+    assert np.all(merged[..., 3] == 8)
 
 
 def test_init_process_group_single_rank_is_a_noop(monkeypatch):
