@@ -1043,10 +1043,16 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
                             (uint64_t)sc->ws2.cap * ((uint64_t)DR_STATE_WORDS * 4 + sc->ws2.svWords / 16 + 20);
       const uint64_t budget = (uint64_t)(0.9 * (double)freeB) + have;
       const uint64_t pipes = nPipesEnv >= 2 && !hostBuf ? 2 : 1;
-      while (maxSlots > (1ull << 16) && std::min<uint64_t>(maxSlots, (uint64_t)npixTotal * spp) * perSlot * pipes > budget) maxSlots >>= 1;
+      // (+ 1/4: the slack that lets a slightly larger window still go as one batch, below)
+      while (maxSlots > (1ull << 16) && std::min<uint64_t>(maxSlots + maxSlots / 4, (uint64_t)npixTotal * spp) * perSlot * pipes > budget) maxSlots >>= 1;
     }
   }
-  const uint32_t pixPerBatch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(npixTotal, maxSlots / spp));
+  // Equal batches, and no tiny tail batch: every stage launch costs ~0.4 ms of ramp-up and tail however small it is
+  // (the sampler window of a 1024 x 1024 film is 1025 x 1025 pixels -- 2^20 + 2049).
+  uint64_t pixCapBatch = std::max<uint64_t>(1, maxSlots / spp);
+  uint64_t nBatches = (npixTotal + pixCapBatch - 1) / pixCapBatch;
+  if (nBatches > 1 && npixTotal <= pixCapBatch + pixCapBatch / 4 && !(nPipesEnv >= 2 && !hostBuf)) nBatches = 1;
+  const uint32_t pixPerBatch = (uint32_t)((npixTotal + nBatches - 1) / nBatches);
   const uint32_t cap = pixPerBatch * (uint32_t)spp;
   int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0);
   if (rc) return rc;
