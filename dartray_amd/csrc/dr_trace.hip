@@ -310,7 +310,10 @@ DR_DEV int slab_f32(const TraceRay& r, float bminx, float bminy, float bminz, fl
 // Pop: the LDS read is issued unconditionally (ds_read, not a flat load through a selected pointer);
 // the global spill is only touched by lanes deeper than DR_LDS_STACK.
 DR_DEV uint32_t stack_pop(const uint32_t* lds, const uint32_t* spill, uint32_t spillStride, int sp) {
-  uint32_t v = lds[(sp < DR_LDS_STACK ? sp : DR_LDS_STACK - 1) * DR_TRACE_BLOCK];
+  // (an explicit LDS-address-space load: left generic, the compiler merges the two loads into ONE flat load
+  // through a selected pointer)
+  typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+  uint32_t v = ((lds_u32*)lds)[(sp < DR_LDS_STACK ? sp : DR_LDS_STACK - 1) * DR_TRACE_BLOCK];
   if (sp >= DR_LDS_STACK) v = spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
   return v;
 }
