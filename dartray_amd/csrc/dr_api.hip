@@ -67,7 +67,7 @@ struct Workspace {
   int spillGrid = 0;
 };
 
-#define DR_STATE_WORDS 41  // 4-byte words of fixed path state per slot: 3 f64 + 10 3-vectors + 5 i32
+#define DR_STATE_WORDS F_SAMPLES  // 41 4-byte words of fixed path state per slot: 3 f64 + 10 3-vectors + 5 i32
 #define N_COUNTERS 4096  // [0,1024): stage queue counts; [1024,4096): 8 per-XCD work counters per trace launch
 
 }  // namespace
@@ -292,37 +292,10 @@ BatchState makeState(Workspace& w, const SampleForm& sf, const int2* pix, uint32
   st.idxShift = (uint32_t)sf.idxShift;
   st.pix = pix;
   st.tail = useTail ? w.tail.p : nullptr;
-  // field offsets inside a tile, in 64-word runs: the three f64 fields first (8-byte aligned), then the
-  // 3-vectors, the i32 fields and the sample region
-  float* b = w.tiles.p;
-  int f = 0;
-  auto f64 = [&]() { double* p = (double*)(b + 64 * (size_t)f); f += 2; return p; };
-  auto v3 = [&]() { float* p = b + 64 * (size_t)f; f += 3; return p; };
-  auto i32 = [&]() { int32_t* p = (int32_t*)(b + 64 * (size_t)f); f += 1; return p; };
-  st.rtmin = f64();
-  st.ht = f64();
-  st.shTmax = f64();
-  st.ro = v3();
-  st.ro0 = v3();
-  st.rd = v3();
-  st.beta = v3();
-  st.L = v3();
-  st.betaNee = v3();
-  st.shD = v3();
-  st.Ld1 = v3();
-  st.misD = v3();
-  st.Ld2 = v3();
-  st.hprim = i32();
-  st.shOcc = i32();
-  st.misLight = i32();
-  st.misPrim = i32();
-  st.flags = (uint32_t*)i32();
-  float* region = b + 64 * (size_t)f;  // f == DR_STATE_WORDS
-  st.sv = sf.compact ? nullptr : region;
-  st.svIdx = sf.compact ? (uint8_t*)region : nullptr;
+  st.tiles = w.tiles.p;  // field offsets inside a tile: the F_* constants of dr_kernels.h
+  st.svFloat = sf.compact ? 0u : 1u;
   st.svScr = sf.compact ? w.scr.p : nullptr;
   st.pixCap = w.pixCap;
-  st.padpc = 0;
   return st;
 }
 

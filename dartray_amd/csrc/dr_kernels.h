@@ -58,41 +58,56 @@ struct RenderParams {
 // ptr[TI(tileStride, slot)]; component c of a 3-vector is 64 words further per component; the f64 arrays use TD.
 #define TI(ts, s) ((size_t)((s) >> 6) * (size_t)(ts) + (size_t)((s) & 63u))
 #define TD(ts, s) ((size_t)((s) >> 6) * (size_t)((ts) >> 1) + (size_t)((s) & 63u))
+// Field offsets inside a tile, in 64-word (256-byte) runs: the three f64 fields first (8-byte aligned), then the
+// 3-vectors, the i32 fields and the sample region.  Every field address is ONE base pointer + a constant: the shade
+// kernels touch ~25 fields, and 25 separate pointers (50 SGPRs) pushed them into SGPR spilling -- two v_readlane
+// per memory access.
+enum {
+  F_RTMIN = 0, F_HT = 2, F_SHTMAX = 4,
+  F_RO = 6, F_RO0 = 9, F_RD = 12, F_BETA = 15, F_L = 18, F_BETANEE = 21, F_SHD = 24, F_LD1 = 27, F_MISD = 30, F_LD2 = 33,
+  F_HPRIM = 36, F_SHOCC = 37, F_MISLIGHT = 38, F_MISPRIM = 39, F_FLAGS = 40,
+  F_SAMPLES = 41  // == DR_STATE_WORDS
+};
 struct BatchState {
   uint32_t cap;     // slots allocated (a multiple of 64)
   uint32_t nslots;  // slots used by the current batch
   uint32_t tileStride;  // 4-byte words per 64-slot tile = 64 * 41 + the sample region
   uint32_t idxShift;    // compact samples: 0 = u8 indices (spp <= 256), 1 = u16
   const int2* pix;  // raster pixel of each batch pixel
-  // The camera-sample vectors (Sample, montecarlo.dart:437-452), in one of two forms:
-  //  float:   sv != null -- nFloats 64-word runs per tile (host-buffer sampler, multi-entry LD blocks);
-  //  compact: sv == null -- the on-device LD sampler only stores what cannot be recomputed: per (LD block, slot)
+  float* tiles;     // the tiled state
+  const double* tail;  // [cap][maxTail] host-buffer mode, else null
+  // The camera-sample vectors (Sample, montecarlo.dart:437-452) live in the sample region of each tile, in one of two forms:
+  //  float (svFloat != 0) -- nFloats 64-word runs per tile (host-buffer sampler, multi-entry LD blocks);
+  //  compact              -- the on-device LD sampler only stores what cannot be recomputed: per (LD block, slot)
   //           the Fisher-Yates-permuted sample index (one byte; a 64-byte run per block and tile) and per
   //           (LD block, batch pixel) the two scramble words; consumers evaluate VanDerCorput / Sobol2 themselves
-  //           (sv_one / sv_pair in dr_kernels.hip).  24 B instead of 148 B per path sample.
-  float* sv;
-  uint8_t* svIdx;     // tile-relative base of the index runs
+  //           (sv_one / sv_pair in dr_kernels.hip).  26 B instead of 148 B per path sample.
+  uint32_t svFloat;
+  uint32_t pixCap;
   uint32_t* svScr;    // [2 * nBlocks][pixCap]
-  uint32_t pixCap, padpc;
-  const double* tail;  // [cap][maxTail] host-buffer mode, else null
-  float* ro;        // ray origin (vertex position p once a vertex has been shaded)
-  float* ro0;       // DirectLighting with quadrics: the camera ray's origin (null otherwise)
-  float* rd;        // continuation / camera ray direction
-  double* rtmin;    // Ray.minDistance (isect.rayEpsilon after the first vertex)
-  int32_t* hprim;   // closest-hit result of the camera / continuation ray
-  double* ht;
-  float* beta;      // pathThroughput (path) / running all-lights sum (direct)
-  float* L;         // radiance of the sample
-  float* betaNee;   // pathThroughput at the vertex whose NEE is pending
-  float* shD;       // shadow-ray direction
-  double* shTmax;
-  float* Ld1;       // light-sampling contribution if unoccluded
-  int32_t* shOcc;   // any-hit result
-  float* misD;      // BSDF-sampled direction of the MIS half
-  float* Ld2;       // its contribution if it reaches the sampled light's front face
-  int32_t* misLight;
-  int32_t* misPrim; // closest-hit result of the MIS ray
-  uint32_t* flags;
+#define DR_FIELD(T, name, F) \
+  __host__ __device__ T* name() const { return (T*)(tiles + 64 * (F)); }
+  DR_FIELD(double, rtmin, F_RTMIN)      // Ray.minDistance (isect.rayEpsilon after the first vertex)
+  DR_FIELD(double, ht, F_HT)            // closest-hit parameter of the camera / continuation ray
+  DR_FIELD(double, shTmax, F_SHTMAX)
+  DR_FIELD(float, ro, F_RO)             // ray origin (vertex position p once a vertex has been shaded)
+  DR_FIELD(float, ro0, F_RO0)           // DirectLighting with quadrics: the camera ray's origin
+  DR_FIELD(float, rd, F_RD)             // continuation / camera ray direction
+  DR_FIELD(float, beta, F_BETA)         // pathThroughput (path) / running all-lights sum (direct)
+  DR_FIELD(float, L, F_L)               // radiance of the sample
+  DR_FIELD(float, betaNee, F_BETANEE)   // pathThroughput at the vertex whose NEE is pending
+  DR_FIELD(float, shD, F_SHD)           // shadow-ray direction
+  DR_FIELD(float, Ld1, F_LD1)           // light-sampling contribution if unoccluded
+  DR_FIELD(float, misD, F_MISD)         // BSDF-sampled direction of the MIS half
+  DR_FIELD(float, Ld2, F_LD2)           // its contribution if it reaches the sampled light's front face
+  DR_FIELD(int32_t, hprim, F_HPRIM)     // closest-hit result of the camera / continuation ray
+  DR_FIELD(int32_t, shOcc, F_SHOCC)     // any-hit result
+  DR_FIELD(int32_t, misLight, F_MISLIGHT)
+  DR_FIELD(int32_t, misPrim, F_MISPRIM) // closest-hit result of the MIS ray
+  DR_FIELD(uint32_t, flags, F_FLAGS)
+  DR_FIELD(float, sv, F_SAMPLES)        // float form
+  DR_FIELD(uint8_t, svIdx, F_SAMPLES)   // compact form: the index runs
+#undef DR_FIELD
 };
 
 // Work queues of one stage.  Counts live in device memory so that no host

@@ -86,33 +86,33 @@ DR_DEV int sv_block(const RenderParams& rp, int f) {
 }
 // raw fetch of 1-D field f: float bits, or the permuted index + its scramble
 DR_DEV void sv_fetch1(const RenderParams& rp, const BatchState& st, uint32_t slot, int f, uint32_t* raw, uint32_t* scr) {
-  if (st.sv) {
-    *raw = __float_as_uint(LDS_STREAM(st.sv + TI(st.tileStride, slot) + (size_t)f * 64));
+  if (st.svFloat) {
+    *raw = __float_as_uint(LDS_STREAM(st.sv() + TI(st.tileStride, slot) + (size_t)f * 64));
     *scr = 0u;
     return;
   }
   const int k = sv_block(rp, f);
-  const uint8_t* q = st.svIdx + (size_t)(slot >> 6) * st.tileStride * 4 + (((size_t)k * 64 + (slot & 63u)) << st.idxShift);
+  const uint8_t* q = st.svIdx() + (size_t)(slot >> 6) * st.tileStride * 4 + (((size_t)k * 64 + (slot & 63u)) << st.idxShift);
   *raw = st.idxShift ? (uint32_t)*(const uint16_t*)q : (uint32_t)*q;
   *scr = st.svScr[(size_t)(2 * k) * st.pixCap + (slot >> rp.sppShift)];
 }
 // raw fetch of the 2-D entry whose first float is field f
 DR_DEV void sv_fetch2(const RenderParams& rp, const BatchState& st, uint32_t slot, int f, uint32_t* raw, uint32_t* scr) {
-  if (st.sv) {
-    raw[0] = __float_as_uint(LDS_STREAM(st.sv + TI(st.tileStride, slot) + (size_t)f * 64));
-    raw[1] = __float_as_uint(LDS_STREAM(st.sv + TI(st.tileStride, slot) + (size_t)(f + 1) * 64));
+  if (st.svFloat) {
+    raw[0] = __float_as_uint(LDS_STREAM(st.sv() + TI(st.tileStride, slot) + (size_t)f * 64));
+    raw[1] = __float_as_uint(LDS_STREAM(st.sv() + TI(st.tileStride, slot) + (size_t)(f + 1) * 64));
     scr[0] = scr[1] = 0u;
     return;
   }
   const int k = sv_block(rp, f);
-  const uint8_t* q = st.svIdx + (size_t)(slot >> 6) * st.tileStride * 4 + (((size_t)k * 64 + (slot & 63u)) << st.idxShift);
+  const uint8_t* q = st.svIdx() + (size_t)(slot >> 6) * st.tileStride * 4 + (((size_t)k * 64 + (slot & 63u)) << st.idxShift);
   raw[0] = raw[1] = st.idxShift ? (uint32_t)*(const uint16_t*)q : (uint32_t)*q;
   scr[0] = st.svScr[(size_t)(2 * k) * st.pixCap + (slot >> rp.sppShift)];
   scr[1] = st.svScr[(size_t)(2 * k + 1) * st.pixCap + (slot >> rp.sppShift)];
 }
 // value of a fetched entry; second: the y half of a 2-D entry (Sample02, montecarlo.dart:480-484)
 DR_DEV float sv_value(const BatchState& st, uint32_t raw, uint32_t scr, bool second) {
-  if (st.sv) return __uint_as_float(raw);
+  if (st.svFloat) return __uint_as_float(raw);
   return second ? Sobol2(raw, scr) : VanDerCorput(raw, scr);
 }
 DR_DEV float sv_one(const RenderParams& rp, const BatchState& st, uint32_t slot, int f) {
@@ -182,19 +182,19 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
   // write-out: element e of this wave's 64*spp contiguous outputs belongs to pixel e >> sppShift
   const uint32_t nOut = min(64u, npix - p0) * (uint32_t)spp;
   const uint32_t slot0 = p0 * (uint32_t)spp;
-  if (!st.sv) {  // compact form: the permuted indices and the scrambles (block k == blockIdx.y: rp.blocks is null)
+  if (!st.svFloat) {  // compact form: the permuted indices and the scrambles (block k == blockIdx.y: rp.blocks is null)
     if (p < npix) {
       st.svScr[(size_t)(2 * k) * st.pixCap + p] = s_scr[lane];
       st.svScr[(size_t)(2 * k + 1) * st.pixCap + p] = s_scr[64 + lane];
     }
     for (uint32_t e = lane; e < nOut; e += 64u) {
       const uint32_t pl = e >> rp.sppShift, j = e & (uint32_t)(spp - 1), slot = slot0 + e;
-      PT* o = (PT*)(st.svIdx + (size_t)(slot >> 6) * st.tileStride * 4) + (size_t)k * 64 + (slot & 63u);
+      PT* o = (PT*)(st.svIdx() + (size_t)(slot >> 6) * st.tileStride * 4) + (size_t)k * 64 + (slot & 63u);
       *o = s_perm[j * ROW + pl];
     }
     return;
   }
-  float* out0 = st.sv + (size_t)dst * 64;  // field `dst` of the sample vector inside each tile
+  float* out0 = st.sv() + (size_t)dst * 64;  // field `dst` of the sample vector inside each tile
   for (uint32_t e = lane; e < nOut; e += 64u) {
     const uint32_t pl = e >> rp.sppShift, j = e & (uint32_t)(spp - 1);
     const uint32_t idx = s_perm[j * ROW + pl];
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(64) k_gen_samples_multi(RenderParams rp, Batch
   rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
   const uint32_t s0 = rng.randomUint();
   const uint32_t s1 = b.is2D ? rng.randomUint() : 0u;
-  float* base = st.sv + (size_t)b.dst * 64;
+  float* base = st.sv() + (size_t)b.dst * 64;
   const uint32_t slot0 = p * (uint32_t)spp;
   auto at = [&](int i, int j, int d) -> float& { return base[TI(st.tileStride, slot0 + (uint32_t)i) + (size_t)(dims * j + d) * 64]; };
   for (int i = 0; i < spp; ++i)
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(64) k_gen_samples_multi(RenderParams rp, Batch
 __global__ void k_transpose_samples(const float* aos, int stride, BatchState st, int nFloats) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= st.nslots) return;
-  for (int k = 0; k < nFloats; ++k) st.sv[TI(st.tileStride, s) + (size_t)k * 64] = aos[(size_t)s * stride + k];
+  for (int k = 0; k < nFloats; ++k) st.sv()[TI(st.tileStride, s) + (size_t)k * 64] = aos[(size_t)s * stride + k];
 }
 
 // 3-vector / colour fields: `cap` in the callers below is the tile stride (see BatchState)
@@ -321,13 +321,13 @@ __global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) 
   }
   o = xf_point(rp.c2w, o);
   d = xf_vector(rp.c2w, d);
-  st3(st.ro, cap, s, o);
-  st3(st.rd, cap, s, d);
-  st.rtmin[TD(cap, s)] = 0.0;
-  st.hprim[TI(cap, s)] = -1;
-  stc(st.beta, cap, s, C3{1.f, 1.f, 1.f});
-  stc(st.L, cap, s, C3{0.f, 0.f, 0.f});
-  st.flags[TI(cap, s)] = PF_HAS_CONT;
+  st3(st.ro(), cap, s, o);
+  st3(st.rd(), cap, s, d);
+  st.rtmin()[TD(cap, s)] = 0.0;
+  st.hprim()[TI(cap, s)] = -1;
+  stc(st.beta(), cap, s, C3{1.f, 1.f, 1.f});
+  stc(st.L(), cap, s, C3{0.f, 0.f, 0.f});
+  st.flags()[TI(cap, s)] = PF_HAS_CONT;
 }
 
 // ---------------------------------------------------------------------------
@@ -343,22 +343,22 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
   C3 Ld = C3{0.f, 0.f, 0.f};
   if ((flags & PF_HAS_SH) && shOcc == 0) Ld = cadd(Ld, Ld1);
   if (flags & PF_HAS_MIS) {
-    const int prim = st.misPrim[TI(cap, slot)];
-    const int li = st.misLight[TI(cap, slot)];
+    const int prim = st.misPrim()[TI(cap, slot)];
+    const int li = st.misLight()[TI(cap, slot)];
     if (ENV && sc.lights[li].kind == DR_LIGHT_INFINITE) {
       // the MIS ray escaped: Li = light.Le(ray) (integrator.dart:173-175), folded into Ld2 at set-up
-      if (prim < 0) Ld = cadd(Ld, ldc(st.Ld2, cap, slot));
+      if (prim < 0) Ld = cadd(Ld, ldc(st.Ld2(), cap, slot));
     } else if (prim >= 0) {
       Tri tr = load_tri(sc, (uint32_t)prim);
       if (tr.light == li) {  // lightIsect.primitive.getAreaLight() == light (integrator.dart:170-172)
-        const F3 wi = ld3(st.misD, cap, slot);
+        const F3 wi = ld3(st.misD(), cap, slot);
         DGeo dg;
         if (QUAD && tr.kind) {
           // dg.nn of a quadric depends on the hit point: repeat the (deterministic) test of the MIS ray
           const DQuadric& qd = sc.quads[tr.quad];
           double th;
           F3 phit;
-          (void)quadric_hit(qd, ld3(st.ro, cap, slot), wi, st.rtmin[TD(cap, slot)], DR_INF, &th, &phit);
+          (void)quadric_hit(qd, ld3(st.ro(), cap, slot), wi, st.rtmin()[TD(cap, slot)], DR_INF, &th, &phit);
           quadric_dg(qd, phit, &dg);
         } else if (QUAD && sc.srec && (__float_as_uint(sc.srec[7 * (size_t)prim + 6].x) & DR_SHADING_UV)) {
           const ShadeRec sr = load_srec(sc, (uint32_t)prim);
@@ -367,7 +367,7 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
           tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, wi, 0.0, &dg);  // only nn is used
         }
         C3 Li = light_L(sc.lights[li], dg.nn, vneg(wi));
-        if (!cblack(Li)) Ld = cadd(Ld, ldc(st.Ld2, cap, slot));
+        if (!cblack(Li)) Ld = cadd(Ld, ldc(st.Ld2(), cap, slot));
       }
     }
   }
@@ -418,14 +418,14 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
       C3 f = bsdf_f(bsdf, wo, wi, flags);
       if (!cblack(f)) {
         if (distant) {  // VisibilityTester.setRay(p, eps, wi)
-          st3(st.shD, cap, slot, wi);
-          st.shTmax[TD(cap, slot)] = DR_INF;
+          st3(st.shD(), cap, slot, wi);
+          st.shTmax()[TD(cap, slot)] = DR_INF;
         } else {        // VisibilityTester.setSegment(p, eps, lightPos, 0)
           const double dist = vlen(seg);
-          st3(st.shD, cap, slot, vdiv(seg, dist));
-          st.shTmax[TD(cap, slot)] = dist * (1.0 - 0.0);
+          st3(st.shD(), cap, slot, vdiv(seg, dist));
+          st.shTmax()[TD(cap, slot)] = dist * (1.0 - 0.0);
         }
-        stc(st.Ld1, cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) / 1.0)));
+        stc(st.Ld1(), cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) / 1.0)));
         pf |= PF_HAS_SH;
       }
     }
@@ -449,16 +449,16 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
         // VisibilityTester.setSegment (visibility_tester.dart:26-29)
         F3 seg = vsub(ps, p);
         double dist = vlen(seg);
-        st3(st.shD, cap, slot, vdiv(seg, dist));
-        st.shTmax[TD(cap, slot)] = dist * (1.0 - 1.0e-3);
+        st3(st.shD(), cap, slot, vdiv(seg, dist));
+        st.shTmax()[TD(cap, slot)] = dist * (1.0 - 1.0e-3);
       } else {
         // VisibilityTester.setRay (visibility_tester.dart:31-33)
-        st3(st.shD, cap, slot, wi);
-        st.shTmax[TD(cap, slot)] = DR_INF;
+        st3(st.shD(), cap, slot, wi);
+        st.shTmax()[TD(cap, slot)] = DR_INF;
       }
       double bsdfPdf = bsdf_pdf(bsdf, wo, wi, flags);
       double weight = PowerHeuristic(lightPdf, bsdfPdf);
-      stc(st.Ld1, cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) * weight / lightPdf)));
+      stc(st.Ld1(), cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) * weight / lightPdf)));
       pf |= PF_HAS_SH;
     }
   }
@@ -474,9 +474,9 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
         // the radiance the MIS ray returns IF it reaches the light: Lemit of the sampled area light (its
         // front face is checked at resolve), or the map along wi2 if the ray escapes (light.Le(ray))
         C3 Lhit = infinite ? env_Le(sc.env, wi2) : C3{light.L[0], light.L[1], light.L[2]};
-        st3(st.misD, cap, slot, wi2);
-        stc(st.Ld2, cap, slot, cmulD(cmul(f, Lhit), (fabs(vdot(wi2, n)) * weight / bsdfPdf)));
-        st.misLight[TI(cap, slot)] = lightNum;
+        st3(st.misD(), cap, slot, wi2);
+        stc(st.Ld2(), cap, slot, cmulD(cmul(f, Lhit), (fabs(vdot(wi2, n)) * weight / bsdfPdf)));
+        st.misLight()[TI(cap, slot)] = lightNum;
         pf |= PF_HAS_MIS;  // scene.intersect is called before `if (!Li.isBlack())` (integrator.dart:169-177)
       }
     }
@@ -532,16 +532,16 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
   in->slot = slot;
   if (!valid) return;
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
-  in->flags = st.flags[TI(cap, slot)];
-  in->hprim = st.hprim[TI(cap, slot)];
-  in->t = st.ht[TD(cap, slot)];
-  in->shOcc = st.shOcc[TI(cap, slot)];
-  in->L = ldc(st.L, cap, slot);
-  in->beta = ldc(st.beta, cap, slot);
-  in->betaNee = ldc(st.betaNee, cap, slot);
-  in->Ld1 = ldc(st.Ld1, cap, slot);
-  in->o = ld3(st.ro, cap, slot);
-  in->d = ld3(st.rd, cap, slot);
+  in->flags = st.flags()[TI(cap, slot)];
+  in->hprim = st.hprim()[TI(cap, slot)];
+  in->t = st.ht()[TD(cap, slot)];
+  in->shOcc = st.shOcc()[TI(cap, slot)];
+  in->L = ldc(st.L(), cap, slot);
+  in->beta = ldc(st.beta(), cap, slot);
+  in->betaNee = ldc(st.betaNee(), cap, slot);
+  in->Ld1 = ldc(st.Ld1(), cap, slot);
+  in->o = ld3(st.ro(), cap, slot);
+  in->d = ld3(st.rd(), cap, slot);
   if (bounce < 3) {
     sv_fetch1(rp, st, slot, 5 + 4 * bounce + 1, &in->raw[0], &in->scr[0]);
     sv_fetch1(rp, st, slot, 5 + 4 * bounce + 0, &in->raw[1], &in->scr[1]);
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
           int lightNum = (int)floor(lu * rp.nLights);
           lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
           pf |= setup_nee<ENV, QUAD>(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc);
-          stc(st.betaNee, cap, slot, beta);
+          stc(st.betaNee(), cap, slot, beta);
         }
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
         double o0, o1, oc = 0.0;
@@ -716,17 +716,17 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
           }
         }
         if (alive && bounce != rp.maxDepth) {
-          st3(st.rd, cap, slot, wi);
-          stc(st.beta, cap, slot, beta);
+          st3(st.rd(), cap, slot, wi);
+          stc(st.beta(), cap, slot, beta);
           pf |= PF_HAS_CONT;
           if (specular) pf |= PF_SPECULAR;  // specularBounce (path_integrator.dart:87)
           pushCont = true;
         }
-        st3(st.ro, cap, slot, p);
-        st.rtmin[TD(cap, slot)] = eps;
+        st3(st.ro(), cap, slot, p);
+        st.rtmin()[TD(cap, slot)] = eps;
       }
-      stc(st.L, cap, slot, L);
-      st.flags[TI(cap, slot)] = pf;
+      stc(st.L(), cap, slot, L);
+      st.flags()[TI(cap, slot)] = pf;
     }
 #if DR_SHADE_PIPELINE == 2
     if (it + 1 < nIter) load_shade_in<QUAD>(st, rp, bounce, slotNext1, (it + 1) * stride + tid0 < nIn, &nxt);
@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
 // DirectLightingIntegrator.Li with strategy "all" (direct_lighting_integrator.dart:30-68;
 // integrator.dart:39-77).  Stage s sets up EstimateDirect call s of UniformSampleAllLights (rp.dstages[s]:
 // sample j of light i) at the camera hit and folds in the result of call s-1; the last stage finishes the
-// sum.  st.betaNee carries the current light's Ld, st.beta the running L of UniformSampleAllLights.
+// sum.  st.betaNee() carries the current light's Ld, st.beta() the running L of UniformSampleAllLights.
 template <bool QUAD>
 __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -760,14 +760,14 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
     bool again = false;
     if (valid) {
       slot = q.activeIn ? q.activeIn[idx] : idx;
-      const uint32_t flags = st.flags[TI(cap, slot)];
-      const int prim = st.hprim[TI(cap, slot)];
+      const uint32_t flags = st.flags()[TI(cap, slot)];
+      const int prim = st.hprim()[TI(cap, slot)];
       if (prim >= 0) {
         Tri tr = load_tri(sc, (uint32_t)prim);
-        const F3 d = ld3(st.rd, cap, slot);
+        const F3 d = ld3(st.rd(), cap, slot);
         const F3 wo = vneg(d);
-        C3 L = ldc(st.L, cap, slot);
-        C3 Lall = ldc(st.beta, cap, slot);
+        C3 L = ldc(st.L(), cap, slot);
+        C3 Lall = ldc(st.beta(), cap, slot);
         C3 Ld = C3{0.f, 0.f, 0.f};
         DGeo dg, dgs;
         const bool isQuad = QUAD && tr.kind != 0;
@@ -775,29 +775,29 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
         ShadeRec sr;
         if (hasRec) sr = load_srec(sc, (uint32_t)prim);
         if (stage == 0) {
-          const F3 o = ld3(st.ro, cap, slot);
-          const double t = st.ht[TD(cap, slot)];
+          const F3 o = ld3(st.ro(), cap, slot);
+          const double t = st.ht()[TD(cap, slot)];
           if (isQuad) {
             quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
-            st3(st.ro0, cap, slot, o);  // later stages rebuild the hit from the camera ray
+            st3(st.ro0(), cap, slot, o);  // later stages rebuild the hit from the camera ray
           } else if (hasRec) {
             tri_dg_srec(tr, sr, o, d, t, &dg);
-            st3(st.ro0, cap, slot, o);
+            st3(st.ro0(), cap, slot, o);
           } else {
             tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
           }
           C3 Le = tr.light >= 0 ? light_L(sc.lights[tr.light], dg.nn, wo) : C3{0.f, 0.f, 0.f};
           L = cadd(L, Le);
           Lall = C3{0.f, 0.f, 0.f};
-          st3(st.ro, cap, slot, dg.p);
-          st.rtmin[TD(cap, slot)] = (isQuad ? 5.0e-4 : 1.0e-3) * t;
+          st3(st.ro(), cap, slot, dg.p);
+          st.rtmin()[TD(cap, slot)] = (isQuad ? 5.0e-4 : 1.0e-3) * t;
         } else {
-          if (isQuad) quadric_dg_at(sc.quads[tr.quad], ld3(st.ro0, cap, slot), d, st.ht[TD(cap, slot)], &dg);
-          else if (hasRec) tri_dg_srec(tr, sr, ld3(st.ro0, cap, slot), d, st.ht[TD(cap, slot)], &dg);
+          if (isQuad) quadric_dg_at(sc.quads[tr.quad], ld3(st.ro0(), cap, slot), d, st.ht()[TD(cap, slot)], &dg);
+          else if (hasRec) tri_dg_srec(tr, sr, ld3(st.ro0(), cap, slot), d, st.ht()[TD(cap, slot)], &dg);
           else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
-          dg.p = ld3(st.ro, cap, slot);
-          Ld = ldc(st.betaNee, cap, slot);
-          Ld = cadd(Ld, resolve_nee<true, QUAD>(sc, st, slot, flags, st.shOcc[TI(cap, slot)], ldc(st.Ld1, cap, slot)));  // Ld += EstimateDirect
+          dg.p = ld3(st.ro(), cap, slot);
+          Ld = ldc(st.betaNee(), cap, slot);
+          Ld = cadd(Ld, resolve_nee<true, QUAD>(sc, st, slot, flags, st.shOcc()[TI(cap, slot)], ldc(st.Ld1(), cap, slot)));  // Ld += EstimateDirect
           if (prev.last) {
             Lall = cadd(Lall, cdivD(Ld, (double)prev.n));  // L += Ld / nSamples
             Ld = C3{0.f, 0.f, 0.f};
@@ -824,13 +824,13 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, Rend
             L = cadd(L, C3{0.f, 0.f, 0.f});
           }
         }
-        stc(st.L, cap, slot, L);
-        stc(st.beta, cap, slot, Lall);
-        stc(st.betaNee, cap, slot, Ld);
+        stc(st.L(), cap, slot, L);
+        stc(st.beta(), cap, slot, Lall);
+        stc(st.betaNee(), cap, slot, Ld);
       } else if (stage == 0 && sc.hasEnv) {
-        stc(st.L, cap, slot, env_Le(sc.env, ld3(st.rd, cap, slot)));  // escaped camera ray (sampler_renderer.dart:87-92)
+        stc(st.L(), cap, slot, env_Le(sc.env, ld3(st.rd(), cap, slot)));  // escaped camera ray (sampler_renderer.dart:87-92)
       }
-      st.flags[TI(cap, slot)] = pf;
+      st.flags()[TI(cap, slot)] = pf;
     }
     stage_push(s_push, pctx, false, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, again, slot, Q_MIS_BIT);
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter) stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut);
@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, co
       if (s64 < nslots) {
         const uint32_t s = (uint32_t)s64;
         const int2 xy = st.pix[s >> rp.sppShift];
-        C3 L = ldc(st.L, cap, s);
+        C3 L = ldc(st.L(), cap, s);
         // guards of sampler_renderer.dart:181-193
         double lum = clum(L);
         if (L.r != L.r || L.g != L.g || L.b != L.b) L = C3{0.f, 0.f, 0.f};

@@ -163,24 +163,24 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace_v1(DScene sc, BatchSta
       const uint32_t e = queue ? queue[idx] : idx;
       const uint32_t slot = e & ~Q_MIS_BIT;
       const size_t ti = TI(cap, slot);
-      const F3 o = F3{st.ro[ti], st.ro[ti + 64], st.ro[ti + 128]};
-      const double tmin = st.rtmin[TD(cap, slot)];
+      const F3 o = F3{st.ro()[ti], st.ro()[ti + 64], st.ro()[ti + 128]};
+      const double tmin = st.rtmin()[TD(cap, slot)];
       ++rays;
       if (ANY) {
-        const F3 d = F3{st.shD[ti], st.shD[ti + 64], st.shD[ti + 128]};
+        const F3 d = F3{st.shD()[ti], st.shD()[ti + 64], st.shD()[ti + 128]};
         double t;
-        int r = traverse<1>(sc, o, d, tmin, st.shTmax[TD(cap, slot)], lds, mySpill, spillStride, &t, &nodes, &tris);
-        st.shOcc[ti] = (r >= 0) ? 1 : 0;
+        int r = traverse<1>(sc, o, d, tmin, st.shTmax()[TD(cap, slot)], lds, mySpill, spillStride, &t, &nodes, &tris);
+        st.shOcc()[ti] = (r >= 0) ? 1 : 0;
       } else if (e & Q_MIS_BIT) {
-        const F3 d = F3{st.misD[ti], st.misD[ti + 64], st.misD[ti + 128]};
+        const F3 d = F3{st.misD()[ti], st.misD()[ti + 64], st.misD()[ti + 128]};
         double t;
-        st.misPrim[ti] = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
+        st.misPrim()[ti] = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
       } else {
-        const F3 d = F3{st.rd[ti], st.rd[ti + 64], st.rd[ti + 128]};
+        const F3 d = F3{st.rd()[ti], st.rd()[ti + 64], st.rd()[ti + 128]};
         double t;
         int r = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
-        st.hprim[ti] = r;
-        st.ht[TD(cap, slot)] = t;
+        st.hprim()[ti] = r;
+        st.ht()[TD(cap, slot)] = t;
       }
     }
   }
@@ -333,21 +333,21 @@ struct StateIO {
     const uint32_t cap = st.tileStride;  // words per 64-slot tile
     handle = e;
     const size_t ti = TI(cap, slot), td = TD(cap, slot);
-    const F3 o = F3{LDS_STREAM(st.ro + ti), LDS_STREAM(st.ro + ti + 64), LDS_STREAM(st.ro + ti + 128)};
-    const float* dir = (ANY ? st.shD : ((e & Q_MIS_BIT) ? st.misD : st.rd)) + ti;
+    const F3 o = F3{LDS_STREAM(st.ro() + ti), LDS_STREAM(st.ro() + ti + 64), LDS_STREAM(st.ro() + ti + 128)};
+    const float* dir = (ANY ? st.shD() : ((e & Q_MIS_BIT) ? st.misD() : st.rd())) + ti;
     const F3 d = F3{LDS_STREAM(dir), LDS_STREAM(dir + 64), LDS_STREAM(dir + 128)};
-    ray_init(r, o, d, LDS_STREAM(st.rtmin + td), ANY ? LDS_STREAM(st.shTmax + td) : DR_INF);
+    ray_init(r, o, d, LDS_STREAM(st.rtmin() + td), ANY ? LDS_STREAM(st.shTmax() + td) : DR_INF);
   }
   DR_DEV void store(uint32_t handle, const TraceRay& r, int prim, const DScene&) const {
     const uint32_t slot = handle & ~Q_MIS_BIT;
     const size_t ti = TI(st.tileStride, slot);
     if (ANY) {
-      STS_STREAM(st.shOcc + ti, (prim >= 0) ? 1 : 0);
+      STS_STREAM(st.shOcc() + ti, (prim >= 0) ? 1 : 0);
     } else if (handle & Q_MIS_BIT) {
-      STS_STREAM(st.misPrim + ti, prim);
+      STS_STREAM(st.misPrim() + ti, prim);
     } else {
-      STS_STREAM(st.hprim + ti, prim);
-      STS_STREAM(st.ht + TD(st.tileStride, slot), r.tmax);
+      STS_STREAM(st.hprim() + ti, prim);
+      STS_STREAM(st.ht() + TD(st.tileStride, slot), r.tmax);
     }
   }
 };
