@@ -621,13 +621,81 @@ class Scene:
 # filter, film, camera (lib/filters/box_filter.dart, lib/film/image_film.dart,
 # lib/cameras/perspective_camera.dart, lib/core/projective_camera.dart)
 # ---------------------------------------------------------------------------
-class BoxFilter:
-    def __init__(self, xw=0.5, yw=0.5):  # box_filter.dart:33-46
+class Filter:
+    """core/filter.dart:26-39.  ImageFilm tabulates evaluate() at 16 x 16 points (image_film.dart:74-82); the table and
+    the two widths are what cross the C ABI (DrFilm.filter_table), so every filter below runs on the device path."""
+    def __init__(self, xw, yw):
         self.xWidth = float(xw)
         self.yWidth = float(yw)
+        self.invXWidth = 1.0 / self.xWidth
+        self.invYWidth = 1.0 / self.yWidth
+
+
+class BoxFilter(Filter):
+    def __init__(self, xw=0.5, yw=0.5):  # box_filter.dart:33-46
+        super().__init__(xw, yw)
 
     def evaluate(self, x, y):
         return 1.0
+
+
+class GaussianFilter(Filter):
+    def __init__(self, xw=2.0, yw=2.0, alpha=2.0):  # gaussian_filter.dart:24-47
+        super().__init__(xw, yw)
+        self.alpha = float(alpha)
+        self.expX = math.exp(-self.alpha * self.xWidth * self.xWidth)
+        self.expY = math.exp(-self.alpha * self.yWidth * self.yWidth)
+
+    def _gaussian(self, d, expv):
+        return max(0.0, math.exp(-self.alpha * d * d) - expv)
+
+    def evaluate(self, x, y):
+        return self._gaussian(x, self.expX) * self._gaussian(y, self.expY)
+
+
+class MitchellFilter(Filter):
+    def __init__(self, b=1.0 / 3.0, c=1.0 / 3.0, xw=2.0, yw=2.0):  # mitchell_filter.dart:24-53
+        super().__init__(xw, yw)
+        self.b = float(b)
+        self.c = float(c)
+
+    def _mitchell1D(self, x):
+        b, c = self.b, self.c
+        x = abs(2.0 * x)
+        if x > 1.0:
+            return ((-b - 6 * c) * x * x * x + (6 * b + 30 * c) * x * x + (-12 * b - 48 * c) * x + (8 * b + 24 * c)) * (1.0 / 6.0)
+        return ((12 - 9 * b - 6 * c) * x * x * x + (-18 + 12 * b + 6 * c) * x * x + (6 - 2 * b)) * (1.0 / 6.0)
+
+    def evaluate(self, x, y):
+        return self._mitchell1D(x * self.invXWidth) * self._mitchell1D(y * self.invYWidth)
+
+
+class TriangleFilter(Filter):
+    def __init__(self, xw=2.0, yw=2.0):  # triangle_filter.dart:24-38
+        super().__init__(xw, yw)
+
+    def evaluate(self, x, y):
+        return max(0.0, self.xWidth - abs(x)) * max(0.0, self.yWidth - abs(y))
+
+
+class LanczosSincFilter(Filter):
+    def __init__(self, xw=4.0, yw=4.0, tau=3.0):  # lanczos_sinc_filter.dart:24-56
+        super().__init__(xw, yw)
+        self.tau = float(tau)
+
+    def _sinc1D(self, x):
+        x = abs(x)
+        if x < 1e-5:
+            return 1.0
+        if x > 1.0:
+            return 0.0
+        x *= math.pi
+        sinc = math.sin(x) / x
+        lanczos = math.sin(x * self.tau) / (x * self.tau)
+        return sinc * lanczos
+
+    def evaluate(self, x, y):
+        return self._sinc1D(x * self.invXWidth) * self._sinc1D(y * self.invYWidth)
 
 
 FILTER_TABLE_SIZE = 16  # image_film.dart:307
@@ -939,6 +1007,13 @@ def RegisterStandardPlugins():
     Plugin.register("sampler", "lowdiscrepancy", LowDiscrepancySampler)
     Plugin.register("film", "image", ImageFilm)
     Plugin.register("filter", "box", lambda ps=None: BoxFilter((ps or {}).get("xwidth", 0.5), (ps or {}).get("ywidth", 0.5)))
+    Plugin.register("filter", "gaussian", lambda ps=None: GaussianFilter((ps or {}).get("xwidth", 2.0), (ps or {}).get("ywidth", 2.0),
+                                                                           (ps or {}).get("alpha", 2.0)))
+    Plugin.register("filter", "sinc", lambda ps=None: LanczosSincFilter((ps or {}).get("xwidth", 4.0), (ps or {}).get("ywidth", 4.0),
+                                                                          (ps or {}).get("tau", 3.0)))
+    Plugin.register("filter", "mitchell", lambda ps=None: MitchellFilter((ps or {}).get("B", 1.0 / 3.0), (ps or {}).get("C", 1.0 / 3.0),
+                                                                           (ps or {}).get("xwidth", 2.0), (ps or {}).get("ywidth", 2.0)))
+    Plugin.register("filter", "triangle", lambda ps=None: TriangleFilter((ps or {}).get("xwidth", 2.0), (ps or {}).get("ywidth", 2.0)))
     Plugin.register("camera", "perspective", PerspectiveCamera)
     Plugin.register("material", "matte", MatteMaterial)
     Plugin.register("shape", "trianglemesh", TriangleMesh)

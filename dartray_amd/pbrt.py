@@ -19,12 +19,13 @@ expressions): matrix4x4.dart:193-343, transform.dart:83-86,110-129,214-331.
 Plugins on the path: shapes trianglemesh (with N / S / uv), sphere, disk;
 materials matte (Lambertian / Oren-Nayar), plastic, mirror, glass; area lights
 on any of those shapes, infinite lights (constant or .npy lat-long map), point,
-spot and distant lights; perspective camera, image film, box filter, low-discrepancy sampler,
+spot and distant lights; perspective camera, image film, box / gaussian / mitchell / triangle / sinc filters,
+low-discrepancy sampler,
 bvh accelerator, path and directlighting (strategy "all") integrators.
 
 A directive that needs a plugin outside that list (other quadrics, measured /
 metal / uber materials, textures, projection / goniometric lights, volumes,
-instancing, animated transforms, image-file radiance maps, non-box filters,
+instancing, animated transforms, image-file radiance maps,
 non-LD samplers, the Metropolis renderer) raises `UnsupportedFeature` naming it
 with file:line -- never a silent approximation.
 """
@@ -834,10 +835,21 @@ class DartRay:
     # -- worldEnd (dartray.dart:549-780) --------------------------------------
     def _makeFilm(self):
         o = self.opt
-        if o["filterName"] != "box":
-            raise UnsupportedFeature(f"PixelFilter \"{o['filterName']}\": only 'box' is on the path")
         fp = o["filterParams"]
-        filt = core.BoxFilter(fp.findOneFloat("xwidth", 0.5), fp.findOneFloat("ywidth", 0.5))  # box_filter.dart:41-45
+        name = o["filterName"]
+        if name == "box":
+            filt = core.BoxFilter(fp.findOneFloat("xwidth", 0.5), fp.findOneFloat("ywidth", 0.5))  # box_filter.dart:41-45
+        elif name == "gaussian":   # gaussian_filter.dart:39-46
+            filt = core.GaussianFilter(fp.findOneFloat("xwidth", 2.0), fp.findOneFloat("ywidth", 2.0), fp.findOneFloat("alpha", 2.0))
+        elif name == "mitchell":   # mitchell_filter.dart:44-50
+            xw, yw = fp.findOneFloat("xwidth", 2.0), fp.findOneFloat("ywidth", 2.0)
+            filt = core.MitchellFilter(fp.findOneFloat("B", 1.0 / 3.0), fp.findOneFloat("C", 1.0 / 3.0), xw, yw)
+        elif name == "triangle":   # triangle_filter.dart:32-37
+            filt = core.TriangleFilter(fp.findOneFloat("xwidth", 2.0), fp.findOneFloat("ywidth", 2.0))
+        elif name == "sinc":       # lanczos_sinc_filter.dart:47-53
+            filt = core.LanczosSincFilter(fp.findOneFloat("xwidth", 4.0), fp.findOneFloat("ywidth", 4.0), fp.findOneFloat("tau", 3.0))
+        else:
+            raise UnsupportedFeature(f"PixelFilter \"{name}\"")
         if o["filmName"] != "image":
             raise UnsupportedFeature(f"Film \"{o['filmName']}\"")
         ps = o["filmParams"]                                   # image_film.dart:309-324

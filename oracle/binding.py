@@ -100,6 +100,9 @@ def lib():
         l.orc_power_heuristic.restype = C.c_double
         l.orc_power_heuristic.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double]
         l.orc_get_sub_window.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.orc_filter_evaluate.restype = C.c_double
+        l.orc_filter_evaluate.argtypes = [C.c_int] + [C.c_double] * 6
+        l.orc_filter_table.argtypes = [C.c_int] + [C.c_double] * 4 + [C.c_void_p]
         l.orc_distribution1d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_int, C.c_void_p]
         l.orc_dart_random.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         l.orc_counter_key.restype = C.c_int64

@@ -2773,6 +2773,56 @@ void orc_cosine_sample_hemisphere(double u1, double u2, double out[3]) {
   out[0] = v.x; out[1] = v.y; out[2] = v.z;
 }
 double orc_power_heuristic(int nf, double f, int ng, double g) { return PowerHeuristic(nf, f, ng, g); }
+// Pixel filters (lib/filters/*.dart; Filter base: core/filter.dart:26-39).  kind: 0 box (box_filter.dart:33-46),
+// 1 gaussian (gaussian_filter.dart:24-37; p0 = alpha), 2 mitchell (mitchell_filter.dart:24-43; p0 = B, p1 = C),
+// 3 triangle (triangle_filter.dart:24-30), 4 Lanczos sinc (lanczos_sinc_filter.dart:24-45; p0 = tau).
+// ImageFilm tabulates evaluate() at 16 x 16 points (image_film.dart:74-82); the table is what crosses the ABI.
+double orc_filter_evaluate(int kind, double xw, double yw, double p0, double p1, double x, double y) {
+  const double invX = 1.0 / xw, invY = 1.0 / yw;
+  switch (kind) {
+    case 0: return 1.0;
+    case 1: {
+      const double alpha = p0, expX = std::exp(-alpha * xw * xw), expY = std::exp(-alpha * yw * yw);
+      auto g = [&](double d, double expv) { return std::max(0.0, std::exp(-alpha * d * d) - expv); };
+      return g(x, expX) * g(y, expY);
+    }
+    case 2: {
+      const double b = p0, c = p1;
+      auto m = [&](double v) {
+        v = std::fabs(2.0 * v);
+        if (v > 1.0)
+          return ((-b - 6 * c) * v * v * v + (6 * b + 30 * c) * v * v + (-12 * b - 48 * c) * v + (8 * b + 24 * c)) * (1.0 / 6.0);
+        return ((12 - 9 * b - 6 * c) * v * v * v + (-18 + 12 * b + 6 * c) * v * v + (6 - 2 * b)) * (1.0 / 6.0);
+      };
+      return m(x * invX) * m(y * invY);
+    }
+    case 3: return std::max(0.0, xw - std::fabs(x)) * std::max(0.0, yw - std::fabs(y));
+    case 4: {
+      const double tau = p0;
+      auto sc = [&](double v) {
+        v = std::fabs(v);
+        if (v < 1e-5) return 1.0;
+        if (v > 1.0) return 0.0;
+        v *= M_PI;
+        const double sinc = std::sin(v) / v;
+        const double lanczos = std::sin(v * tau) / (v * tau);
+        return sinc * lanczos;
+      };
+      return sc(x * invX) * sc(y * invY);
+    }
+  }
+  return 0.0;
+}
+void orc_filter_table(int kind, double xw, double yw, double p0, double p1, float table[256]) {  // image_film.dart:74-82
+  int fi = 0;
+  for (int y = 0; y < 16; ++y) {
+    const double fy = (y + 0.5) * yw / 16;
+    for (int x = 0; x < 16; ++x) {
+      const double fx = (x + 0.5) * xw / 16;
+      table[fi++] = (float)orc_filter_evaluate(kind, xw, yw, p0, p1, fx, fy);
+    }
+  }
+}
 void orc_get_sub_window(int w, int h, int num, int count, int32_t ext[4]) {
   int e[4];
   GetSubWindow(w, h, num, count, e);
