@@ -167,15 +167,20 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
     s_scr[64 + lane] = is2D ? rng.randomUint() : 0u;
     for (int i = 0; i < spp; ++i) (void)rng.randomUint();  // Shuffle of ONE entry: other = i + r % 1 (:294-303)
     for (int i = 0; i < spp; ++i) s_perm[i * ROW + lane] = (PT)i;
+    // Fisher-Yates (montecarlo.dart:294-303).  The only serial chain left is the RNG: entry i + 1 is fetched before the
+    // swap of step i is stored (and patched if that swap hits it), so no LDS round trip sits between two steps.
+    PT a = s_perm[lane];
     for (int i = 0; i < spp; ++i) {
       // r % m for the wave-uniform divisor m = spp - i: q = mulhi(r, floor(2^32 / m)) is r / m or one less
       const uint32_t r = rng.randomUint(), m = (uint32_t)(spp - i);
       uint32_t rem = r - __umulhi(r, s_magic[m]) * m;
       if (rem >= m) rem -= m;
       const int other = i + (int)rem;
-      const PT a = s_perm[i * ROW + lane];
-      s_perm[i * ROW + lane] = s_perm[other * ROW + lane];
+      const PT ahead = s_perm[(i + 1 < spp ? i + 1 : i) * ROW + lane];
+      const PT b = s_perm[other * ROW + lane];
+      s_perm[i * ROW + lane] = b;
       s_perm[other * ROW + lane] = a;
+      a = (other == i + 1) ? a : ahead;
     }
   }
   __syncthreads();
@@ -201,6 +206,59 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
     float* o = out0 + TI(st.tileStride, slot0 + e);
     o[0] = VanDerCorput(idx, s_scr[pl]);
     if (is2D) o[64] = Sobol2(idx, s_scr[64 + pl]);
+  }
+}
+
+// Compact form, spp >= 64 (the common case): the same shuffle with a LANE-MAJOR table -- entry i of lane l lives in
+// dword column l, [i / EPW][l][i % EPW] with EPW entries per dword -- so every lane only ever touches its own LDS
+// bank whatever row the random swap partner is in (the row-major table above takes ~6-way bank conflicts there), and
+// a lane's 64 consecutive entries are one tile's whole 64-entry index run: it stores them itself, 16 bytes at a time.
+template <class PT>
+__global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchState st, uint32_t npix) {
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  constexpr int EPW = 4 / (int)sizeof(PT);  // entries per dword
+  PT* s_perm = (PT*)s_raw;                  // [spp / EPW][64][EPW]
+  uint32_t* s_magic = (uint32_t*)(s_raw + (size_t)rp.spp * 64 * sizeof(PT));  // [spp + 1]: floor(2^32 / m)
+  const int lane = threadIdx.x;
+  const uint32_t p = blockIdx.x * 64u + lane;
+  const int k = blockIdx.y;  // LD block: image, lens, time, 1-D slots, 2-D slots (montecarlo.dart:437-448)
+  const int spp = rp.spp;
+  const bool is2D = k < 2 || k >= 3 + rp.n1D;
+  auto at = [&](int i) -> PT& { return s_perm[(i / EPW) * (64 * EPW) + lane * EPW + (i % EPW)]; };
+  for (int m = 1 + lane; m <= spp; m += 64) s_magic[m] = m == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)m);
+  __syncthreads();
+  if (p >= npix) return;
+  const int2 xy = st.pix[p];
+  const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
+  DartRandom rng;
+  rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
+  // LDShuffleScrambled1D/2D with nSamples == 1 (montecarlo.dart:524-551)
+  st.svScr[(size_t)(2 * k) * st.pixCap + p] = rng.randomUint();
+  st.svScr[(size_t)(2 * k + 1) * st.pixCap + p] = is2D ? rng.randomUint() : 0u;
+  for (int i = 0; i < spp; ++i) (void)rng.randomUint();  // Shuffle of ONE entry: other = i + r % 1 (:294-303)
+  for (int i = 0; i < spp; ++i) at(i) = (PT)i;
+  PT a = at(0);
+  for (int i = 0; i < spp; ++i) {  // Fisher-Yates (montecarlo.dart:294-303), as in k_gen_samples
+    const uint32_t r = rng.randomUint(), m = (uint32_t)(spp - i);
+    uint32_t rem = r - __umulhi(r, s_magic[m]) * m;
+    if (rem >= m) rem -= m;
+    const int other = i + (int)rem;
+    const PT ahead = at(i + 1 < spp ? i + 1 : i);
+    const PT b = at(other);
+    at(i) = b;
+    at(other) = a;
+    a = (other == i + 1) ? a : ahead;
+  }
+  // this lane's spp entries are spp / 64 whole index runs: slot p * spp + i is entry i & 63 of tile (p * spp + i) >> 6
+  const uint32_t* cols = (const uint32_t*)s_raw + lane;  // dword d of this lane's column is cols[d * 64]
+  const size_t tile0 = ((size_t)p * (size_t)spp) >> 6;
+  constexpr int DPR = 64 / EPW;  // dwords per 64-entry run
+  for (int t = 0; t < spp / 64; ++t) {
+    uint4* o = (uint4*)(st.svIdx() + (tile0 + t) * (size_t)st.tileStride * 4 + (size_t)k * 64 * sizeof(PT));
+    for (int q = 0; q < DPR / 4; ++q) {
+      const int d = t * DPR + 4 * q;
+      o[q] = make_uint4(cols[(d + 0) * 64], cols[(d + 1) * 64], cols[(d + 2) * 64], cols[(d + 3) * 64]);
+    }
   }
 }
 
@@ -572,8 +630,18 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
 #define DR_SHADE_GRID_PER_CU 1
 #endif
 #define DR_SHADE_GRID(numCU) ((numCU) * DR_SHADE_GRID_PER_CU)
+// the variants with the env-map / general-material code need more registers (132+ spilled VGPRs at 3 waves per SIMD):
+// 512 threads x 2 waves per SIMD is 23 % faster for them (C5 shade 1354 -> 1046 ms)
+#ifndef DR_SHADE_BLOCK_GEN
+#define DR_SHADE_BLOCK_GEN 512
+#endif
+#ifndef DR_SHADE_WAVES_GEN
+#define DR_SHADE_WAVES_GEN 2
+#endif
+#define SHADE_BLOCK_OF(general) ((general) ? DR_SHADE_BLOCK_GEN : DR_SHADE_BLOCK)
+#define SHADE_WAVES_OF(general) ((general) ? DR_SHADE_WAVES_GEN : DR_SHADE_WAVES)
 template <bool ENV, bool QUAD>
-__global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
+__global__ void __launch_bounds__(SHADE_BLOCK_OF(ENV || QUAD), SHADE_WAVES_OF(ENV || QUAD)) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
   PushCtx pctx = {{0, 0, 0, 0}, 0};
@@ -741,7 +809,7 @@ __global__ void __launch_bounds__(DR_SHADE_BLOCK, DR_SHADE_WAVES) k_shade_path(D
 // sample j of light i) at the camera hit and folds in the result of call s-1; the last stage finishes the
 // sum.  st.betaNee() carries the current light's Ld, st.beta() the running L of UniformSampleAllLights.
 template <bool QUAD>
-__global__ void __launch_bounds__(DR_SHADE_BLOCK) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
+__global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
   PushCtx pctx = {{0, 0, 0, 0}, 0};
@@ -971,6 +1039,20 @@ void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t*
 void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s) {
   const int nBlocks = rp.blocks ? rp.nBlocks : 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
   const dim3 grid((npix + 63) / 64, nBlocks);
+  if (!st.svFloat && rp.spp >= 64) {  // compact form (rp.blocks is null), whole index runs per pixel
+    const size_t lds = (size_t)rp.spp * 64 * (rp.spp <= 256 ? 1 : 2) + ((size_t)rp.spp + 1) * 4;
+    if (rp.spp <= 256) {
+      hipLaunchKernelGGL(k_gen_samples_lm<uint8_t>, grid, dim3(64), lds, s, rp, st, npix);
+    } else {
+      static bool attrSet = false;
+      if (!attrSet) {
+        (void)hipFuncSetAttribute((const void*)k_gen_samples_lm<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attrSet = true;
+      }
+      hipLaunchKernelGGL(k_gen_samples_lm<uint16_t>, grid, dim3(64), lds, s, rp, st, npix);
+    }
+    return;
+  }
   if (rp.blocks) hipLaunchKernelGGL(k_gen_samples_multi, grid, dim3(64), 0, s, rp, st, npix);
   if (rp.spp <= 256) {
     const size_t lds = (size_t)rp.spp * 68 + 512 + ((size_t)rp.spp + 1) * 4;
@@ -992,26 +1074,26 @@ void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) 
   hipLaunchKernelGGL(k_raygen, dim3((st.nslots + 255) / 256), dim3(256), 0, s, rp, st);
 }
 // The shade kernels stage their queue entries in dynamic LDS (PushStage, dr_wave.h): ~96 KB of the CU's 160 KB.
-template <auto kernel, class... A>
+template <auto kernel, int BLOCK, class... A>
 static void launch_shade(int grid, hipStream_t s, A... args) {
-  const size_t lds = push_stage_bytes(DR_SHADE_BLOCK);
+  const size_t lds = push_stage_bytes(BLOCK);
   static bool attrSet = false;  // one instance of this template, hence one flag, per kernel
   if (!attrSet) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attrSet = true;
   }
-  hipLaunchKernelGGL(kernel, dim3(DR_SHADE_GRID(grid)), dim3(DR_SHADE_BLOCK), lds, s, args...);
+  hipLaunchKernelGGL(kernel, dim3(DR_SHADE_GRID(grid)), dim3(BLOCK), lds, s, args...);
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec || sc.srec) launch_shade<k_shade_path<true, true>>(grid, s, sc, rp, st, q, bounce);
-  else if (sc.hasEnv) launch_shade<k_shade_path<true, false>>(grid, s, sc, rp, st, q, bounce);
-  else launch_shade<k_shade_path<false, false>>(grid, s, sc, rp, st, q, bounce);
+  if (sc.nquads || sc.hasSpec || sc.srec) launch_shade<k_shade_path<true, true>, SHADE_BLOCK_OF(true)>(grid, s, sc, rp, st, q, bounce);
+  else if (sc.hasEnv) launch_shade<k_shade_path<true, false>, SHADE_BLOCK_OF(true)>(grid, s, sc, rp, st, q, bounce);
+  else launch_shade<k_shade_path<false, false>, SHADE_BLOCK_OF(false)>(grid, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec || sc.srec) launch_shade<k_shade_direct<true>>(grid, s, sc, rp, st, q, stage);
-  else launch_shade<k_shade_direct<false>>(grid, s, sc, rp, st, q, stage);
+  if (sc.nquads || sc.hasSpec || sc.srec) launch_shade<k_shade_direct<true>, SHADE_BLOCK_OF(true)>(grid, s, sc, rp, st, q, stage);
+  else launch_shade<k_shade_direct<false>, SHADE_BLOCK_OF(false)>(grid, s, sc, rp, st, q, stage);
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
                  hipStream_t s) {
