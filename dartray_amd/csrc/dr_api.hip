@@ -86,6 +86,9 @@ struct DrScene {
   DevBuf<float> envTexels, envCondFunc, envCondCdf, envCondInt, envMargFunc, envMargCdf;
   DevBuf<TraceCounters> ctr;
   uint32_t bvhDepth = 0;
+  bool traceCalibrated = false;
+  float calibMs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // pilot of dr_render_device: [closest / any][v2 / v3] ms
+  DevBuf<int2> pilotPix;
   std::vector<int32_t> lightNSamples;
   bool hasSpecular = false;  // some material is a mirror / glass
   bool hasDeltaLight = false;
@@ -876,6 +879,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     if (!stages.empty())
       TRY_SC(hipMemcpy(sc->dlStages.p, stages.data(), stages.size() * sizeof(DirectStage), hipMemcpyHostToDevice));
   }
+  sc->d.traceKernel[0] = sc->d.traceKernel[1] = 0;
   *out = sc;
   return DR_OK;
 #undef TRY_SC
@@ -1056,18 +1060,19 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
   if (4 * nStages + 8 > 1024 || 8 * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
 
-  for (size_t p0 = 0; p0 < npixTotal; p0 += pixPerBatch, ++batchIndex) {
-    const bool second = twoPipes && (batchIndex & 1);
-    Workspace& w = second ? sc->ws2 : sc->ws;
-    s = second ? sc->s2 : callerStream;
-    const uint32_t np = (uint32_t)std::min<size_t>(pixPerBatch, npixTotal - p0);
+  // One batch through the stage loop.  pilot != null: a measurement run (no film, its trace launches timed into
+  // pilot[kind]) -- see the calibration below.
+  struct PilotTimes {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+  };
+  auto runBatch = [&](Workspace& w, const int2* pixDev, size_t p0, uint32_t np, PilotTimes* pilot) -> int {
     const uint32_t nslots = np * (uint32_t)spp;
-    BatchState st = makeState(w, sf, sc->ws.pix.p + p0, nslots, hostBuf && needTail > 0);
+    BatchState st = makeState(w, sf, pixDev, nslots, hostBuf && needTail > 0);
     HIP_TRY(hipMemsetAsync(w.counters.p, 0, N_COUNTERS * sizeof(uint32_t), s));
     auto timed = [&](int kind, hipEvent_t e0) {
       hipEvent_t e1 = sc->getEvent();
       (void)hipEventRecord(e1, s);
-      sc->traceEvents.push_back({e0, e1, kind});
+      if (!pilot) sc->traceEvents.push_back({e0, e1, kind});
     };
     hipEvent_t evGen = sc->getEvent();
     (void)hipEventRecord(evGen, s);
@@ -1091,7 +1096,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       (void)hipEventRecord(e0, s);
       launch_trace(sc->d, st, queue, nQ, any, w.spill.p, C + 1024 + 8 * (wc++), sc->ctr.p, tgrid, s);
       (void)hipEventRecord(e1, s);
-      sc->traceEvents.push_back({e0, e1, any});
+      if (pilot) pilot->ev[any].push_back({e0, e1});
+      else sc->traceEvents.push_back({e0, e1, any});
     };
     trace(nullptr, nullptr, 0);  // camera rays
     for (int b = 0; b < nStages; ++b) {
@@ -1114,13 +1120,78 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
         trace(q.anyQ, q.nAny, 1);
       }
     }
-    hipEvent_t evF = sc->getEvent();
-    (void)hipEventRecord(evF, s);
-    launch_film(rp, st, sc->ws.filterTable.p, np, (float*)film_dev, s);
-    timed(4, evF);
+    if (!pilot) {
+      hipEvent_t evF = sc->getEvent();
+      (void)hipEventRecord(evF, s);
+      launch_film(rp, st, sc->ws.filterTable.p, np, (float*)film_dev, s);
+      timed(4, evF);
+      sc->stats.batches++;
+    }
     HIP_TRY(hipGetLastError());
-    sc->stats.batches++;
     if (hostBuf) HIP_TRY(hipStreamSynchronize(s));  // host buffers of the next batch reuse the staging area
+    return DR_OK;
+  };
+
+  // Which traversal kernel?  v2 (one node per step, f32 filter) is issue bound and wins while the hot part of the tree
+  // stays in cache; v3 (sibling pairs, half the dependent fetches) wins on big incoherent trees (C4 hairball +26 %)
+  // and loses on others of the same size (C5 courtyard: closest -8 %, any hit -33 %); random probe rays mispredict
+  // both.  So the first big render of a big scene measures it on its own rays: 2^22 camera samples (64-pixel groups
+  // spread over the image) go through the stage loop once per kernel without touching the film, and each ray kind
+  // keeps v3 only if it was 5 % faster.  Both kernels are bit-exact, so results do not depend on the choice;
+  // DARTRAY_TRACE_IMPL fixes it.
+  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || getenv("DARTRAY_PILOT_FORCE");
+  if (!sc->traceCalibrated && !hostBuf && !getenv("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads && bigJob && npixTotal >= 64) {
+    // pilot size: ~3 % of the render, between 2^22 and 2^25 camera samples (small launches are dominated by their
+    // ramp-up and tail and mispredict: C5 needs 2^24 before the order of the two kernels matches the full render)
+    uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 22, (uint64_t)npixTotal * spp / 32));
+    if (getenv("DARTRAY_PILOT_BITS")) pilotSamples = 1ull << atoi(getenv("DARTRAY_PILOT_BITS"));
+    pilotSamples = std::min<uint64_t>(pilotSamples, (uint64_t)(pixPerBatch / 64 * 64) * spp);
+    const size_t groups = std::max<size_t>(1, (size_t)(pilotSamples / spp) / 64);
+    const size_t totalGroups = npixTotal / 64;
+    std::vector<int2> pp;
+    for (size_t g = 0; g < groups; ++g) {
+      const size_t src = (g * totalGroups / groups) * 64;
+      pp.insert(pp.end(), pixels.begin() + src, pixels.begin() + src + 64);
+    }
+    HIP_TRY(sc->pilotPix.alloc(pp.size()));
+    HIP_TRY(hipMemcpy(sc->pilotPix.p, pp.data(), pp.size() * sizeof(int2), hipMemcpyHostToDevice));
+    const size_t evSaved = sc->eventsUsed;
+    float ms[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int impl = 2; impl <= 3; ++impl) {
+      sc->d.traceKernel[0] = sc->d.traceKernel[1] = (uint32_t)impl;
+      for (int rep = 0; rep < 2; ++rep) {  // the first pass warms the caches
+        PilotTimes pt;
+        int prc = runBatch(sc->ws, sc->pilotPix.p, 0, (uint32_t)pp.size(), &pt);
+        if (prc) return prc;
+        HIP_TRY(hipStreamSynchronize(s));
+        if (rep == 1)
+          for (int kind = 0; kind < 2; ++kind)
+            for (auto& e : pt.ev[kind]) {
+              float t = 0.f;
+              (void)hipEventElapsedTime(&t, e.first, e.second);
+              ms[kind][impl - 2] += t;
+            }
+        sc->eventsUsed = evSaved;
+      }
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+      sc->d.traceKernel[kind] = ms[kind][1] < 0.95f * ms[kind][0] ? 3u : 2u;
+      sc->calibMs[kind][0] = ms[kind][0];
+      sc->calibMs[kind][1] = ms[kind][1];
+    }
+    sc->traceCalibrated = true;
+    HIP_TRY(hipMemsetAsync(sc->ctr.p, 0, sizeof(TraceCounters), s));  // the probes of bvh_accel.dart count the render only
+    if (getenv("DARTRAY_VERBOSE"))
+      fprintf(stderr, "dartray_hip: traversal pilot, closest v2 %.2f ms / v3 %.2f ms -> v%u; any hit v2 %.2f / v3 %.2f -> v%u\n",
+              ms[0][0], ms[0][1], sc->d.traceKernel[0], ms[1][0], ms[1][1], sc->d.traceKernel[1]);
+  }
+
+  for (size_t p0 = 0; p0 < npixTotal; p0 += pixPerBatch, ++batchIndex) {
+    const bool second = twoPipes && (batchIndex & 1);
+    s = second ? sc->s2 : callerStream;
+    const uint32_t np = (uint32_t)std::min<size_t>(pixPerBatch, npixTotal - p0);
+    int brc = runBatch(second ? sc->ws2 : sc->ws, sc->ws.pix.p + p0, p0, np, nullptr);
+    if (brc) return brc;
   }
   s = callerStream;
   if (twoPipes) {  // the caller's stream continues after both pipelines

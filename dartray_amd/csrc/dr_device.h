@@ -146,6 +146,9 @@ struct DScene {
   const float* xforms;
   uint32_t nquads;
   uint32_t hasSpec;  // some material is not a plain Lambertian matte (general shading kernels)
+  // traversal kernel per ray kind (0 closest, 1 any hit): 0 = the default (v2), else 2 / 3 as measured on this
+  // scene by the pilot of its first big render (dr_render_device)
+  uint32_t traceKernel[2];
 };
 
 // Primitive record flags (q2.w): bit 0 = Shape.reverseOrientation, bits 8.. = 0 triangle / DR_QUADRIC_*.

@@ -137,7 +137,7 @@ struct TraceCounters {  // device-side totals (Stats probes of bvh_accel.dart:10
 void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t* mat, const int32_t* light,
                         const uint8_t* rev, float4* out, uint64_t ntris, hipStream_t s);
 void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
-                      uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s);
+                      uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s, int forceImpl = 0);
 void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s);
 void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s);

@@ -21,6 +21,7 @@
 // The path is latency / HBM bound (about 1 flop per byte): no MFMA.
 #include "dr_kernels.h"
 #include "dr_wave.h"
+#include "dr_rng.h"
 
 #ifndef DR_REFILL_TH
 #define DR_REFILL_TH 16
@@ -944,19 +945,23 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_intersect3(
 // ---------------------------------------------------------------------------
 // launchers.  DARTRAY_TRACE_IMPL selects the kernel for A/B runs: 1 = first version, 2 = default, 3 = sibling pairs.
 // ---------------------------------------------------------------------------
-static int traceImpl(const DScene& sc) {
-  static int impl = -1;
-  if (impl < 0) {
+static int traceImpl(const DScene& sc, int anyHit, int force = 0) {
+  static int env = -1;
+  if (env < 0) {
     const char* e = getenv("DARTRAY_TRACE_IMPL");
-    impl = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 2;  // v2 is the fastest measured
+    env = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
   }
+  // v2 is the fastest on cache-resident trees, v3 (sibling pairs) on big incoherent ones:
+  // unless DARTRAY_TRACE_IMPL fixes it, the choice is the one measured for this scene (sc.traceKernel, set by the
+  // pilot of dr_render_device)
+  int impl = force ? force : (env ? env : (sc.traceKernel[anyHit ? 1 : 0] ? (int)sc.traceKernel[anyHit ? 1 : 0] : 2));
   if (sc.nquads) return 2;                     // only v2 tests quadric primitives
   return (impl == 3 && !sc.pairs) ? 2 : impl;  // scenes the pair layout cannot encode use v2
 }
 void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
-                      uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
+                      uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s, int forceImpl) {
   const dim3 g(grid), b(DR_TRACE_BLOCK);
-  const int impl = traceImpl(sc);
+  const int impl = traceImpl(sc, anyHit, forceImpl);
   if (impl == 3) {
     if (anyHit) hipLaunchKernelGGL(k_intersect3<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_intersect3<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
@@ -971,7 +976,7 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
 void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
   const dim3 g(grid), b(DR_TRACE_BLOCK);
-  const int impl = traceImpl(sc);
+  const int impl = traceImpl(sc, anyHit);
   if (impl == 3) {
     if (anyHit) hipLaunchKernelGGL(k_trace3<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace3<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);

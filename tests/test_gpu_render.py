@@ -271,6 +271,32 @@ def test_alternative_traversal_kernels_are_bit_exact_too(impl):
     assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
 
 
+def test_traversal_pilot_leaves_results_and_counters_untouched():
+    """The first big render of a big scene times both traversal kernels on a sample of its own rays
+    (dr_render_device's pilot) before rendering; forced here on a small scene: film and visit counters must equal
+    the oracle's exactly, i.e. nothing of the pilot leaks into the film, the statistics or the sampler streams."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "import oracle.binding as ob\n"
+        "from dartray_amd import _abi, scenes\n"
+        "_abi.init(0)\n"
+        "prims, mk = scenes.config('C2', xres=48, yres=40, spp=16, blob=(60, 30))\n"
+        "r = mk(); scene = scenes.make_scene(prims); out = r.render(scene); out2 = r.render(scene)\n"
+        "osc = ob.OracleScene(prims); osc.counters(reset=True)\n"
+        "ref = osc.render(ob.render_desc(r, sampler_mode=1)); c = osc.counters(); st = r.last_stats\n"
+        "assert np.array_equal(out.film, ref['film']) and np.array_equal(out2.film, ref['film'])\n"
+        "assert all(st[k] == c[k] for k in ('closest_nodes', 'any_nodes', 'closest_tris', 'any_tris', 'closest_rays', 'any_rays')), (st, c)\n"
+        "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ, DARTRAY_PILOT_FORCE="1", DARTRAY_VERBOSE="1")
+    env.pop("DARTRAY_TRACE_IMPL", None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
+    assert res.stderr.count("traversal pilot") == 1, res.stderr[-2000:]   # once per scene
+
+
 def test_two_pipelines_render_the_same_film():
     """DARTRAY_PIPELINES=2 (odd batches on a second stream and workspace) only changes scheduling: a render that
     needs several batches gives the same film as the single-pipeline run."""
