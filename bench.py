@@ -115,7 +115,7 @@ def main():
         peak = 8000.0  # HBM3E spec GB/s (MI355X_MICROARCH.md chip table)
         all_alg = alg_bytes + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_i_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_k_traffic.json")
         if (args.config == "C2" and args.res == 1024 and spp == 256 and world == 1 and args.pipelines == 1
                 and not os.environ.get("DARTRAY_BATCH_BITS") and os.path.exists(tpath)):
             # HBM-side bytes per launch of k_trace<0> from the PMC passes of this same command (see the file)
