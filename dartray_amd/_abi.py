@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DARTRAY_LIB") or os.path.join(_HERE, "libdartray_hip.so")  # DARTRAY_LIB: A/B builds
 
 DR_OK = 0
+DR_CAMERA_PERSPECTIVE, DR_CAMERA_ORTHOGRAPHIC, DR_CAMERA_ENVIRONMENT = 0, 1, 2
 DR_INTEGRATOR_DIRECT_ALL = 0
 DR_INTEGRATOR_PATH = 1
 DR_SAMPLER_HOST_BUFFER = 0
@@ -92,7 +93,7 @@ class DrHit(C.Structure):
 class DrCamera(C.Structure):
     _fields_ = [("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
                 ("lens_radius", C.c_float), ("focal_distance", C.c_float),
-                ("shutter_open", C.c_float), ("shutter_close", C.c_float)]
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float), ("type", C.c_int32), ("pad", C.c_int32)]
 
 
 class DrFilm(C.Structure):

@@ -814,11 +814,75 @@ class PerspectiveCamera:
         return PerspectiveCamera(look_at(pos, look, up), screen, shutteropen, shutterclose, lensradius, focaldistance,
                                  fov, film)
 
+    cameraType = 0  # DR_CAMERA_PERSPECTIVE
+
     def to_abi(self, c):
         c.raster_to_camera[:] = [float(v) for v in self.rasterToCamera.reshape(-1)]
         c.camera_to_world[:] = [float(v) for v in self.cameraToWorld.reshape(-1)]
         c.lens_radius, c.focal_distance = self.lensRadius, self.focalDistance
         c.shutter_open, c.shutter_close = self.shutterOpen, self.shutterClose
+        c.type = self.cameraType
+
+
+def _default_screen_window(film):
+    frame = film.xResolution / film.yResolution   # perspective_camera.dart:152-168 (the same in all three cameras)
+    return [-frame, frame, -1.0, 1.0] if frame > 1.0 else [-1.0, 1.0, -1.0 / frame, 1.0 / frame]
+
+
+def _raster_to_screen(film, screenWindow):
+    """Inverse of ProjectiveCamera's screenToRaster = Scale(xres, yres, 1) * Scale(1/(sw1-sw0), 1/(sw2-sw3), 1) *
+    Translate(-sw0, -sw3, 0) (projective_camera.dart:39-52): the inverses multiplied in reverse order, every factor
+    and product rounded to f32 like Matrix4x4."""
+    sw = [float(s) for s in screenWindow]
+    s1i = _m4(np.diag([1.0 / film.xResolution, 1.0 / film.yResolution, 1.0, 1.0]))
+    s2i = _m4(np.diag([1.0 / (1.0 / (sw[1] - sw[0])), 1.0 / (1.0 / (sw[2] - sw[3])), 1.0, 1.0]))
+    tri = np.eye(4, dtype=np.float32)
+    tri[0, 3], tri[1, 3] = -np.float32(-sw[0]), -np.float32(-sw[3])
+    return _mul(tri, _mul(s2i, s1i))
+
+
+class OrthographicCamera(PerspectiveCamera):
+    """cameras/orthographic_camera.dart:44-80: a ProjectiveCamera over Transform.Orthographic(0, 1)
+    (transform.dart:333-336); rays leave the raster point along +z of camera space."""
+    cameraType = 1  # DR_CAMERA_ORTHOGRAPHIC
+
+    def __init__(self, cam2world, screenWindow, sopen, sclose, lensr, focald, film):
+        self.cameraToWorld = _m4(cam2world)
+        self.shutterOpen, self.shutterClose = float(sopen), float(sclose)
+        self.lensRadius, self.focalDistance = float(lensr), float(focald)
+        self.film = film
+        znear, zfar = 0.0, 1.0
+        tr = np.eye(4, dtype=np.float32)
+        tr[2, 3] = np.float32(-znear)
+        tri = np.eye(4, dtype=np.float32)
+        tri[2, 3] = np.float32(znear)
+        sc = _m4(np.diag([1.0, 1.0, 1.0 / (zfar - znear), 1.0]))
+        sci = _m4(np.diag([1.0, 1.0, 1.0 / (1.0 / (zfar - znear)), 1.0]))
+        self.cameraToScreen = _mul(sc, tr)
+        self.rasterToCamera = _mul(_mul(tri, sci), _raster_to_screen(film, screenWindow))
+
+    @staticmethod
+    def lookAt(pos, look, up, film, lensradius=0.0, focaldistance=1.0e30, shutteropen=0.0, shutterclose=1.0, screenWindow=None):
+        return OrthographicCamera(look_at(pos, look, up), screenWindow or _default_screen_window(film), shutteropen,
+                                  shutterclose, lensradius, focaldistance, film)
+
+
+class EnvironmentCamera(PerspectiveCamera):
+    """cameras/environment_camera.dart:38-52: every raster point maps to a lat-long direction from the camera origin;
+    no lens, no projection matrix (rasterToCamera is unused)."""
+    cameraType = 2  # DR_CAMERA_ENVIRONMENT
+
+    def __init__(self, cam2world, sopen, sclose, film):
+        self.cameraToWorld = _m4(cam2world)
+        self.shutterOpen, self.shutterClose = float(sopen), float(sclose)
+        self.lensRadius, self.focalDistance = 0.0, 1.0e30
+        self.film = film
+        self.rasterToCamera = np.eye(4, dtype=np.float32)
+        self.cameraToScreen = np.eye(4, dtype=np.float32)
+
+    @staticmethod
+    def lookAt(pos, look, up, film, shutteropen=0.0, shutterclose=1.0):
+        return EnvironmentCamera(look_at(pos, look, up), shutteropen, shutterclose, film)
 
 
 # ---------------------------------------------------------------------------
@@ -1015,6 +1079,8 @@ def RegisterStandardPlugins():
                                                                            (ps or {}).get("xwidth", 2.0), (ps or {}).get("ywidth", 2.0)))
     Plugin.register("filter", "triangle", lambda ps=None: TriangleFilter((ps or {}).get("xwidth", 2.0), (ps or {}).get("ywidth", 2.0)))
     Plugin.register("camera", "perspective", PerspectiveCamera)
+    Plugin.register("camera", "orthographic", OrthographicCamera)
+    Plugin.register("camera", "environment", EnvironmentCamera)
     Plugin.register("material", "matte", MatteMaterial)
     Plugin.register("shape", "trianglemesh", TriangleMesh)
     Plugin.register("areaLight", "diffuse", DiffuseAreaLight)

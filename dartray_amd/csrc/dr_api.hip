@@ -942,6 +942,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.focalDistance = rd->camera.focal_distance;
   rp.shutterOpen = rd->camera.shutter_open;
   rp.shutterClose = rd->camera.shutter_close;
+  rp.cameraType = rd->camera.type;
+  if (rp.cameraType < DR_CAMERA_PERSPECTIVE || rp.cameraType > DR_CAMERA_ENVIRONMENT) return fail(DR_ERR_INVALID, "unknown camera type");
   rp_film(rp, rd->film);
   rp.integrator = rd->integrator;
   rp.maxDepth = rd->max_depth;

@@ -24,6 +24,7 @@ struct DirectStage {
 struct RenderParams {
   float r2c[16], c2w[16];
   float lensRadius, focalDistance, shutterOpen, shutterClose;
+  int32_t cameraType, padCam;  // DR_CAMERA_*
   // ImageFilm window (image_film.dart:61-65)
   int32_t xres, yres, left, top, width, height;
   double fxw, fyw, invX, invY;

@@ -362,20 +362,32 @@ __global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) 
   sv_pair(rp, st, s, 0, &sx, &sy);
   const double imageX = (double)xy.x + (double)sx;               // montecarlo.dart:451-452
   const double imageY = (double)xy.y + (double)sy;
-  F3 Pras = f3(imageX, imageY, 0.0);
-  F3 Pcamera = xf_point(rp.r2c, Pras);
-  F3 o = F3{0.f, 0.f, 0.f};
-  F3 d = vnormalize(Pcamera);
-  if (rp.lensRadius > 0.0f) {
-    double lu, lv;
-    sv_pair(rp, st, s, 2, &sx, &sy);
-    ConcentricSampleDisk((double)sx, (double)sy, &lu, &lv);
-    lu *= (double)rp.lensRadius;
-    lv *= (double)rp.lensRadius;
-    double ft = (double)rp.focalDistance / (double)d.z;
-    F3 Pfocus = vadd(o, vmul(d, ft));
-    o = f3(lu, lv, 0.0);
-    d = vnormalize(vsub(Pfocus, o));
+  F3 o = F3{0.f, 0.f, 0.f}, d;
+  if (rp.cameraType == DR_CAMERA_ENVIRONMENT) {
+    // EnvironmentCamera.generateRay (environment_camera.dart:42-52)
+    const double theta = DR_PI * imageY / (double)rp.yres;
+    const double phi = 2 * DR_PI * imageX / (double)rp.xres;
+    d = f3(sin(theta) * cos(phi), cos(theta), sin(theta) * sin(phi));
+  } else {
+    F3 Pras = f3(imageX, imageY, 0.0);
+    F3 Pcamera = xf_point(rp.r2c, Pras);
+    if (rp.cameraType == DR_CAMERA_ORTHOGRAPHIC) {  // orthographic_camera.dart:52-80
+      o = Pcamera;
+      d = F3{0.f, 0.f, 1.f};
+    } else {
+      d = vnormalize(Pcamera);
+    }
+    if (rp.lensRadius > 0.0f) {
+      double lu, lv;
+      sv_pair(rp, st, s, 2, &sx, &sy);
+      ConcentricSampleDisk((double)sx, (double)sy, &lu, &lv);
+      lu *= (double)rp.lensRadius;
+      lv *= (double)rp.lensRadius;
+      double ft = (double)rp.focalDistance / (double)d.z;
+      F3 Pfocus = vadd(o, vmul(d, ft));
+      o = f3(lu, lv, 0.0);   // (the orthographic camera, too, REPLACES the origin: orthographic_camera.dart:73)
+      d = vnormalize(vsub(Pfocus, o));
+    }
   }
   o = xf_point(rp.c2w, o);
   d = xf_vector(rp.c2w, d);

@@ -19,7 +19,7 @@ expressions): matrix4x4.dart:193-343, transform.dart:83-86,110-129,214-331.
 Plugins on the path: shapes trianglemesh (with N / S / uv), sphere, disk;
 materials matte (Lambertian / Oren-Nayar), plastic, mirror, glass; area lights
 on any of those shapes, infinite lights (constant or .npy lat-long map), point,
-spot and distant lights; perspective camera, image film, box / gaussian / mitchell / triangle / sinc filters,
+spot and distant lights; perspective / orthographic / environment cameras, image film, box / gaussian / mitchell / triangle / sinc filters,
 low-discrepancy sampler,
 bvh accelerator, path and directlighting (strategy "all") integrators.
 
@@ -863,8 +863,8 @@ class DartRay:
 
     def _makeCamera(self, film):
         o = self.opt
-        if o["cameraName"] != "perspective":
-            raise UnsupportedFeature(f"Camera \"{o['cameraName']}\": only 'perspective' is on the path")
+        if o["cameraName"] not in ("perspective", "orthographic", "environment"):
+            raise UnsupportedFeature(f"Camera \"{o['cameraName']}\"")
         ps = o["cameraParams"]                                 # perspective_camera.dart:134-183
         sopen, sclose = ps.findOneFloat("shutteropen", 0.0), ps.findOneFloat("shutterclose", 1.0)
         if sclose < sopen:
@@ -879,6 +879,10 @@ class DartRay:
             screen = [-frame, frame, -1.0, 1.0]
         else:
             screen = [-1.0, 1.0, -1.0 / frame, 1.0 / frame]
+        if o["cameraName"] == "orthographic":                  # orthographic_camera.dart:120-160
+            return core.OrthographicCamera(o["cameraToWorld"].m, screen, sopen, sclose, lensr, focald, film)
+        if o["cameraName"] == "environment":                   # environment_camera.dart:54-90
+            return core.EnvironmentCamera(o["cameraToWorld"].m, sopen, sclose, film)
         fov = ps.findOneFloat("fov", 60.0)
         halffov = ps.findOneFloat("halffov", -1.0)
         if halffov > 0.0:

@@ -183,7 +183,13 @@ typedef struct DrHit {
   double b2;
 } DrHit;
 
-/* ProjectiveCamera/PerspectiveCamera state (lib/core/projective_camera.dart:27-32). */
+/* Camera state (lib/core/projective_camera.dart:27-32): PerspectiveCamera (cameras/perspective_camera.dart:93-132),
+ * OrthographicCamera (cameras/orthographic_camera.dart:52-80) -- both ProjectiveCameras with their own
+ * raster_to_camera -- and EnvironmentCamera (cameras/environment_camera.dart:42-52), which only uses camera_to_world
+ * and the film resolution. */
+#define DR_CAMERA_PERSPECTIVE 0
+#define DR_CAMERA_ORTHOGRAPHIC 1
+#define DR_CAMERA_ENVIRONMENT 2
 typedef struct DrCamera {
   float raster_to_camera[16]; /* row-major, Matrix4x4.data order (matrix4x4.dart:170-176) */
   float camera_to_world[16];
@@ -191,6 +197,8 @@ typedef struct DrCamera {
   float focal_distance;
   float shutter_open;
   float shutter_close;
+  int32_t type; /* DR_CAMERA_* */
+  int32_t pad;
 } DrCamera;
 
 /* ImageFilm + Filter (lib/film/image_film.dart:51-97). */

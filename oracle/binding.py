@@ -45,7 +45,7 @@ class OrcRenderDesc(C.Structure):
                 ("filter_xw", C.c_double), ("filter_yw", C.c_double), ("filter_table", C.c_float * 256),
                 ("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
                 ("lens_radius", C.c_float), ("focal_distance", C.c_float),
-                ("shutter_open", C.c_float), ("shutter_close", C.c_float),
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float), ("camera_type", C.c_int32),
                 ("integrator", C.c_int32), ("max_depth", C.c_int32), ("spp", C.c_int32), ("sampler_mode", C.c_int32),
                 ("seed", C.c_int64), ("task_num", C.c_int32), ("task_count", C.c_int32),
                 ("npixels", C.c_int32), ("pixels", C.c_void_p)]
@@ -100,6 +100,8 @@ def lib():
         l.orc_power_heuristic.restype = C.c_double
         l.orc_power_heuristic.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double]
         l.orc_get_sub_window.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.orc_camera_setup_ortho.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        l.orc_generate_ray.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
         l.orc_filter_evaluate.restype = C.c_double
         l.orc_filter_evaluate.argtypes = [C.c_int] + [C.c_double] * 6
         l.orc_filter_table.argtypes = [C.c_int] + [C.c_double] * 4 + [C.c_void_p]
@@ -324,6 +326,7 @@ def render_desc(renderer, sampler_mode=None, pixels=None):
     rd.raster_to_camera[:] = [float(v) for v in cam.rasterToCamera.reshape(-1)]
     rd.camera_to_world[:] = [float(v) for v in cam.cameraToWorld.reshape(-1)]
     rd.lens_radius, rd.focal_distance = cam.lensRadius, cam.focalDistance
+    rd.camera_type = getattr(cam, "cameraType", 0)
     rd.shutter_open, rd.shutter_close = cam.shutterOpen, cam.shutterClose
     rd.integrator = renderer.surfaceIntegrator.kind
     rd.max_depth = renderer.surfaceIntegrator.maxDepth

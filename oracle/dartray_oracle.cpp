@@ -1915,15 +1915,34 @@ static S DirectLi(const Scene& sc, const IntegratorCfg& cfg, const Ray& ray, con
 struct Camera {
   float r2c[16], c2w[16];
   D lensRadius, focalDistance;
+  int type = 0;      // 0 perspective, 1 orthographic (orthographic_camera.dart:52-80), 2 environment (environment_camera.dart:42-52)
+  int xres = 0, yres = 0;  // film resolution (environment camera)
 };
 static Ray generateRay(const Camera& cam, D imageX, D imageY, D lensU, D lensV, D time) {
-  V Pras = vec(imageX, imageY, 0.0);
-  V Pcamera = xfPoint(cam.r2c, Pras);
   Ray ray;
-  ray.o = vec(0, 0, 0);
-  ray.d = vnormalize(Pcamera);
   ray.mint = 0.0;
   ray.maxt = kInf;
+  if (cam.type == 2) {
+    // EnvironmentCamera.generateRay (environment_camera.dart:42-52): a lat-long direction from the camera origin
+    D theta = kPi * imageY / (D)cam.yres;
+    D phi = 2 * kPi * imageX / (D)cam.xres;
+    ray.o = vec(0, 0, 0);
+    ray.d = vec(std::sin(theta) * std::cos(phi), std::cos(theta), std::sin(theta) * std::sin(phi));
+    ray.time = time;
+    ray.depth = 0;
+    ray.o = xfPoint(cam.c2w, ray.o);
+    ray.d = xfVector(cam.c2w, ray.d);
+    return ray;
+  }
+  V Pras = vec(imageX, imageY, 0.0);
+  V Pcamera = xfPoint(cam.r2c, Pras);
+  if (cam.type == 1) {  // OrthographicCamera.generateRay (orthographic_camera.dart:52-80)
+    ray.o = Pcamera;
+    ray.d = vec(0.0, 0.0, 1.0);
+  } else {
+    ray.o = vec(0, 0, 0);
+    ray.d = vnormalize(Pcamera);
+  }
   if (cam.lensRadius > 0.0) {
     D lu, lv;
     ConcentricSampleDisk(lensU, lensV, &lu, &lv);
@@ -2172,6 +2191,7 @@ struct OrcRenderDesc {
   float filter_table[256];
   float raster_to_camera[16], camera_to_world[16];
   float lens_radius, focal_distance, shutter_open, shutter_close;
+  int32_t camera_type;  // 0 perspective, 1 orthographic, 2 environment
   int32_t integrator;  // 0 direct(all), 1 path
   int32_t max_depth;
   int32_t spp;
@@ -2528,6 +2548,9 @@ static void setup_render(const Scene& sc, const OrcRenderDesc* rd, IntegratorCfg
   memcpy(cam->c2w, rd->camera_to_world, sizeof(cam->c2w));
   cam->lensRadius = rd->lens_radius;
   cam->focalDistance = rd->focal_distance;
+  cam->type = rd->camera_type;
+  cam->xres = rd->xres;
+  cam->yres = rd->yres;
   film->init(rd->xres, rd->yres, rd->crop, rd->filter_xw, rd->filter_yw, rd->filter_table);
   sample_layout(sc, *cfg, n1D, n2D, true);
   *nFloats = 5;
@@ -2760,6 +2783,34 @@ void orc_camera_setup(const float pos[3], const float look[3], const float up[3]
   Xf rasterToScreen = xfinv(screenToRaster);
   Xf rasterToCamera = xfmul(xfinv(cameraToScreen), rasterToScreen);
   memcpy(r2c, rasterToCamera.m.m, sizeof(float) * 16);
+}
+
+// OrthographicCamera's rasterToCamera (orthographic_camera.dart:44-50: Transform.Orthographic(0, 1),
+// transform.dart:333-336; projective_camera.dart:39-52) for the default screen window.
+void orc_camera_setup_ortho(int xres, int yres, float r2c[16]) {
+  Xf cameraToScreen = xfmul(xfscale(1.0, 1.0, 1.0 / (1.0 - 0.0)), xftranslate(0.0, 0.0, -0.0));
+  D frame = (D)xres / (D)yres;
+  D screen[4];
+  if (frame > 1.0) { screen[0] = -frame; screen[1] = frame; screen[2] = -1.0; screen[3] = 1.0; }
+  else { screen[0] = -1.0; screen[1] = 1.0; screen[2] = -1.0 / frame; screen[3] = 1.0 / frame; }
+  Xf screenToRaster = xfmul(xfmul(xfscale((D)xres, (D)yres, 1.0),
+                                  xfscale(1.0 / (screen[1] - screen[0]), 1.0 / (screen[2] - screen[3]), 1.0)),
+                            xftranslate(-screen[0], -screen[3], 0.0));
+  Xf rasterToCamera = xfmul(xfinv(cameraToScreen), xfinv(screenToRaster));
+  memcpy(r2c, rasterToCamera.m.m, sizeof(float) * 16);
+}
+// one camera ray (KATs): out = o[3], d[3]
+void orc_generate_ray(const OrcRenderDesc* rd, double imageX, double imageY, double lensU, double lensV, double out[6]) {
+  Camera cam;
+  memcpy(cam.r2c, rd->raster_to_camera, sizeof(cam.r2c));
+  memcpy(cam.c2w, rd->camera_to_world, sizeof(cam.c2w));
+  cam.lensRadius = rd->lens_radius;
+  cam.focalDistance = rd->focal_distance;
+  cam.type = rd->camera_type;
+  cam.xres = rd->xres;
+  cam.yres = rd->yres;
+  Ray r = generateRay(cam, imageX, imageY, lensU, lensV, 0.0);
+  out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z;
 }
 
 // ---------------------------------------------------------------------------

@@ -194,7 +194,7 @@ def test_plugins_outside_the_path_fail_loudly_with_position(snippet, needle):
 
 
 @pytest.mark.parametrize("opt,needle", [
-    ('PixelFilter "bessel"', "PixelFilter"), ('Sampler "random"', "Sampler"), ('Camera "orthographic"', "Camera"),
+    ('PixelFilter "bessel"', "PixelFilter"), ('Sampler "random"', "Sampler"), ('Camera "realistic"', "Camera"),
     ('Renderer "metropolis"', "Renderer"), ('SurfaceIntegrator "whitted"', "SurfaceIntegrator"),
     ('Accelerator "kdtree"', "Accelerator"), ('Film "other"', "Film"),
 ])
