@@ -801,6 +801,27 @@ DR_DEV double env_pdf(const DEnv& e, F3 w) {  // infinite_area_light.dart:190-20
   else p2 = ((double)e.condFunc[(size_t)iv * e.w + iu] * (double)e.margFunc[iv]) / (ci * mi);
   return p2 / (2.0 * DR_PI * DR_PI * sintheta);
 }
+// Out-of-line copies for the env-map path kernel (ENV && !QUAD): called, not inlined, these three keep their ~90
+// registers out of the caller's live set -- that variant then fits 3 waves per SIMD without spilling (C5 shade
+// 1047 -> 883 ms).  The DirectLighting and general kernels measured slower with them and keep the inline forms.
+__device__ __noinline__ C3 env_Le_ni(const DEnv& e, F3 dir) { return env_Le(e, dir); }
+__device__ __noinline__ C3 env_sample_ni(const DEnv& e, double u0, double u1, F3* wi, double* pdf) { return env_sample(e, u0, u1, wi, pdf); }
+__device__ __noinline__ double env_pdf_ni(const DEnv& e, F3 w) { return env_pdf(e, w); }
+template <bool NI>
+DR_DEV C3 env_Le_x(const DEnv& e, F3 dir) {
+  if constexpr (NI) return env_Le_ni(e, dir);
+  else return env_Le(e, dir);
+}
+template <bool NI>
+DR_DEV C3 env_sample_x(const DEnv& e, double u0, double u1, F3* wi, double* pdf) {
+  if constexpr (NI) return env_sample_ni(e, u0, u1, wi, pdf);
+  else return env_sample(e, u0, u1, wi, pdf);
+}
+template <bool NI>
+DR_DEV double env_pdf_x(const DEnv& e, F3 w) {
+  if constexpr (NI) return env_pdf_ni(e, w);
+  else return env_pdf(e, w);
+}
 
 // ---- BSDF with one Lambertian lobe -------------------------------------------
 // (matte_material.dart:41-65; reflection/bsdf.dart:45-211; bxdf.dart:31-48,84-88;

@@ -446,7 +446,7 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
 
 // EstimateDirect up to the points where it must trace (integrator.dart:119-185):
 // writes the shadow ray / MIS ray and their candidate contributions.
-template <bool ENV, bool QUAD>
+template <bool ENV, bool QUAD, bool NI = false>
 DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
                           F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1, double bsc) {
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
@@ -510,7 +510,7 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
     Li = light_L(light, ns, vneg(wi));
   } else {
     // InfiniteAreaLight.sampleLAtPoint (infinite_area_light.dart:92-131)
-    Li = env_sample(sc.env, ls0, ls1, &wi, &lightPdf);
+    Li = env_sample_x<NI>(sc.env, ls0, ls1, &wi, &lightPdf);
   }
   if (lightPdf > 0.0 && !cblack(Li)) {
     C3 f = bsdf_f(bsdf, wo, wi, flags);
@@ -538,12 +538,12 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
     double bsdfPdf = 0.0;
     C3 f = bsdf_sample_f(bsdf, wo, &wi2, bs0, bs1, bsc, &bsdfPdf, flags);
     if (!cblack(f) && bsdfPdf > 0.0) {
-      double lightPdf2 = infinite ? env_pdf(sc.env, wi2) : shapeset_pdf<QUAD>(sc, light, p, wi2);
+      double lightPdf2 = infinite ? env_pdf_x<NI>(sc.env, wi2) : shapeset_pdf<QUAD>(sc, light, p, wi2);
       if (lightPdf2 != 0.0) {
         double weight = PowerHeuristic(bsdfPdf, lightPdf2);
         // the radiance the MIS ray returns IF it reaches the light: Lemit of the sampled area light (its
         // front face is checked at resolve), or the map along wi2 if the ray escapes (light.Le(ray))
-        C3 Lhit = infinite ? env_Le(sc.env, wi2) : C3{light.L[0], light.L[1], light.L[2]};
+        C3 Lhit = infinite ? env_Le_x<NI>(sc.env, wi2) : C3{light.L[0], light.L[1], light.L[2]};
         st3(st.misD(), cap, slot, wi2);
         stc(st.Ld2(), cap, slot, cmulD(cmul(f, Lhit), (fabs(vdot(wi2, n)) * weight / bsdfPdf)));
         st.misLight()[TI(cap, slot)] = lightNum;
@@ -642,8 +642,9 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
 #define DR_SHADE_GRID_PER_CU 1
 #endif
 #define DR_SHADE_GRID(numCU) ((numCU) * DR_SHADE_GRID_PER_CU)
-// the variants with the env-map / general-material code need more registers (132+ spilled VGPRs at 3 waves per SIMD):
-// 512 threads x 2 waves per SIMD is 23 % faster for them (C5 shade 1354 -> 1046 ms)
+// the general-material variants need more registers (188+ spilled VGPRs even at 2 waves per SIMD): 512 threads x 2
+// waves per SIMD is ~20 % faster for them; the env-map path variant fits 3 waves once its env-map functions are
+// called out of line (env_*_ni in dr_device.h)
 #ifndef DR_SHADE_BLOCK_GEN
 #define DR_SHADE_BLOCK_GEN 512
 #endif
@@ -653,7 +654,7 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
 #define SHADE_BLOCK_OF(general) ((general) ? DR_SHADE_BLOCK_GEN : DR_SHADE_BLOCK)
 #define SHADE_WAVES_OF(general) ((general) ? DR_SHADE_WAVES_GEN : DR_SHADE_WAVES)
 template <bool ENV, bool QUAD>
-__global__ void __launch_bounds__(SHADE_BLOCK_OF(ENV || QUAD), SHADE_WAVES_OF(ENV || QUAD)) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
+__global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
   PushCtx pctx = {{0, 0, 0, 0}, 0};
@@ -714,11 +715,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(ENV || QUAD), SHADE_WAVES_OF(EN
       if (ENV && bounce == 0 && prim < 0 && sc.hasEnv) {
         // the camera ray escaped: Li = sum over lights of light.Le(ray) (sampler_renderer.dart:87-92); area
         // lights return 0 (light.dart:70-72), the infinite light its map
-        L = cadd(L, env_Le(sc.env, d));
+        L = cadd(L, env_Le_x<(ENV && !QUAD)>(sc.env, d));
       }
       if (ENV && QUAD && bounce > 0 && prim < 0 && (flags & PF_HAS_CONT) && (flags & PF_SPECULAR) && sc.hasEnv) {
         // a ray that left the scene after a specular bounce still sees the lights (path_integrator.dart:107-111)
-        L = cadd(L, cmul(beta, env_Le(sc.env, d)));
+        L = cadd(L, cmul(beta, env_Le_x<(ENV && !QUAD)>(sc.env, d)));
       }
       if (prim >= 0 && bounce <= rp.maxDepth) {
         Tri tr = load_tri(sc, (uint32_t)prim);
@@ -768,7 +769,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(ENV || QUAD), SHADE_WAVES_OF(EN
           }
           int lightNum = (int)floor(lu * rp.nLights);
           lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
-          pf |= setup_nee<ENV, QUAD>(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc);
+          pf |= setup_nee<ENV, QUAD, (ENV && !QUAD)>(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc);
           stc(st.betaNee(), cap, slot, beta);
         }
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
@@ -1099,7 +1100,7 @@ static void launch_shade(int grid, hipStream_t s, A... args) {
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
   if (sc.nquads || sc.hasSpec || sc.srec) launch_shade<k_shade_path<true, true>, SHADE_BLOCK_OF(true)>(grid, s, sc, rp, st, q, bounce);
-  else if (sc.hasEnv) launch_shade<k_shade_path<true, false>, SHADE_BLOCK_OF(true)>(grid, s, sc, rp, st, q, bounce);
+  else if (sc.hasEnv) launch_shade<k_shade_path<true, false>, SHADE_BLOCK_OF(false)>(grid, s, sc, rp, st, q, bounce);
   else launch_shade<k_shade_path<false, false>, SHADE_BLOCK_OF(false)>(grid, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
