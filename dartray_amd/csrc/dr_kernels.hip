@@ -394,10 +394,8 @@ __global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) 
   st3(st.ro(), cap, s, o);
   st3(st.rd(), cap, s, d);
   st.rtmin()[TD(cap, s)] = 0.0;
-  st.hprim()[TI(cap, s)] = -1;
-  stc(st.beta(), cap, s, C3{1.f, 1.f, 1.f});
-  stc(st.L(), cap, s, C3{0.f, 0.f, 0.f});
-  st.flags()[TI(cap, s)] = PF_HAS_CONT;
+  // hprim is written by the camera trace for every slot; pathThroughput = 1, L = 0 and flags = PF_HAS_CONT are what the
+  // first shading stage assumes instead of reading them (52 B per camera sample less to write here and to read there)
 }
 
 // ---------------------------------------------------------------------------
@@ -602,14 +600,20 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
   in->slot = slot;
   if (!valid) return;
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
-  in->flags = st.flags()[TI(cap, slot)];
+  in->flags = bounce == 0 ? PF_HAS_CONT : st.flags()[TI(cap, slot)];
   in->hprim = st.hprim()[TI(cap, slot)];
   in->t = st.ht()[TD(cap, slot)];
-  in->shOcc = st.shOcc()[TI(cap, slot)];
-  in->L = ldc(st.L(), cap, slot);
-  in->beta = ldc(st.beta(), cap, slot);
-  in->betaNee = ldc(st.betaNee(), cap, slot);
-  in->Ld1 = ldc(st.Ld1(), cap, slot);
+  if (bounce == 0) {  // the camera vertex: nothing pending, pathThroughput = 1, L = 0 (k_raygen does not store them)
+    in->shOcc = 0;
+    in->L = in->betaNee = in->Ld1 = C3{0.f, 0.f, 0.f};
+    in->beta = C3{1.f, 1.f, 1.f};
+  } else {
+    in->shOcc = st.shOcc()[TI(cap, slot)];
+    in->L = ldc(st.L(), cap, slot);
+    in->beta = ldc(st.beta(), cap, slot);
+    in->betaNee = ldc(st.betaNee(), cap, slot);
+    in->Ld1 = ldc(st.Ld1(), cap, slot);
+  }
   in->o = ld3(st.ro(), cap, slot);
   in->d = ld3(st.rd(), cap, slot);
   if (bounce < 3) {
@@ -841,14 +845,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     bool again = false;
     if (valid) {
       slot = q.activeIn ? q.activeIn[idx] : idx;
-      const uint32_t flags = st.flags()[TI(cap, slot)];
+      const uint32_t flags = stage == 0 ? PF_HAS_CONT : st.flags()[TI(cap, slot)];  // k_raygen leaves flags / L / beta unwritten
       const int prim = st.hprim()[TI(cap, slot)];
       if (prim >= 0) {
         Tri tr = load_tri(sc, (uint32_t)prim);
         const F3 d = ld3(st.rd(), cap, slot);
         const F3 wo = vneg(d);
-        C3 L = ldc(st.L(), cap, slot);
-        C3 Lall = ldc(st.beta(), cap, slot);
+        C3 L = stage == 0 ? C3{0.f, 0.f, 0.f} : ldc(st.L(), cap, slot);
+        C3 Lall = stage == 0 ? C3{0.f, 0.f, 0.f} : ldc(st.beta(), cap, slot);
         C3 Ld = C3{0.f, 0.f, 0.f};
         DGeo dg, dgs;
         const bool isQuad = QUAD && tr.kind != 0;
@@ -908,8 +912,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         stc(st.L(), cap, slot, L);
         stc(st.beta(), cap, slot, Lall);
         stc(st.betaNee(), cap, slot, Ld);
-      } else if (stage == 0 && sc.hasEnv) {
-        stc(st.L(), cap, slot, env_Le(sc.env, ld3(st.rd(), cap, slot)));  // escaped camera ray (sampler_renderer.dart:87-92)
+      } else if (stage == 0) {
+        // escaped camera ray: Li = sum of light.Le(ray) (sampler_renderer.dart:87-92) -- the env map's, else 0
+        stc(st.L(), cap, slot, sc.hasEnv ? env_Le(sc.env, ld3(st.rd(), cap, slot)) : C3{0.f, 0.f, 0.f});
       }
       st.flags()[TI(cap, slot)] = pf;
     }

@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+# Heavy imports happen HERE, at collection time, outside pytest-timeout's per-test clock: on a fresh GPU box the
+# first `import torch` pages ~2 GB of libraries in and has been seen to take more than five minutes -- inside a
+# test that is a spurious timeout (it looked like a hang of the test that happened to import it first).
+try:
+    import numpy  # noqa: F401
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -267,7 +267,7 @@ def test_alternative_traversal_kernels_are_bit_exact_too(impl):
         "assert all(st[k] == c[k] for k in ('closest_nodes', 'any_nodes', 'closest_tris', 'any_tris', 'closest_rays', 'any_rays'))\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
     env = dict(os.environ, DARTRAY_TRACE_IMPL=impl)
-    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)
     assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
 
 
@@ -292,7 +292,7 @@ def test_traversal_pilot_leaves_results_and_counters_untouched():
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
     env = dict(os.environ, DARTRAY_PILOT_FORCE="1", DARTRAY_VERBOSE="1")
     env.pop("DARTRAY_TRACE_IMPL", None)
-    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)
     assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
     assert res.stderr.count("traversal pilot") == 1, res.stderr[-2000:]   # once per scene
 
@@ -314,7 +314,7 @@ def test_two_pipelines_render_the_same_film():
         path = os.path.join(ROOT, "gpurun_out", "film_p%s.npy" % pipes)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         env = dict(os.environ, DARTRAY_PIPELINES=pipes, DARTRAY_BATCH_BITS="24")  # 2^24 samples per batch => 3 batches
-        res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=280)
+        res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=500)
         assert res.returncode == 0, res.stderr[-2000:]
         films.append(np.load(path))
         os.remove(path)
