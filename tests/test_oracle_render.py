@@ -162,3 +162,37 @@ def test_direct_lighting_matches_the_form_factor_integral(ob):
         expect = 0.75 / math.pi * E
         assert got[0] == pytest.approx(expect, rel=0.03), (px, py, got, expect)
         assert got[0] == pytest.approx(got[1], rel=1e-5) and got[1] == pytest.approx(got[2], rel=1e-5)
+
+
+def _furnace_prims(rho, Le):
+    """A closed cube whose six walls all emit Le towards the inside and reflect a fraction rho (Lambertian)."""
+    s = 1.0
+    c = [(-s, -s, -s), (s, -s, -s), (s, s, -s), (-s, s, -s), (-s, -s, s), (s, -s, s), (s, s, s), (-s, s, s)]
+    faces = [(0, 1, 2, 3), (4, 5, 6, 7), (0, 1, 5, 4), (3, 2, 6, 7), (0, 3, 7, 4), (1, 2, 6, 5)]
+    prims = []
+    for f in faces:
+        p = [np.array(c[i], np.float64) for i in f]
+        n = np.cross(p[1] - p[0], p[2] - p[0])
+        if np.dot(n, -(p[0] + p[2]) / 2) < 0:      # the one-sided emitter must face the cube centre
+            p = [p[0], p[3], p[2], p[1]]
+        mesh = core.TriangleMesh(np.array([[0, 1, 2], [0, 2, 3]], np.uint32), np.array(p, np.float32))
+        prims.append(core.GeometricPrimitive(mesh, core.MatteMaterial((rho,) * 3), core.DiffuseAreaLight((Le,) * 3, 1)))
+    return prims
+
+
+@pytest.mark.parametrize("maxdepth,rho", [(0, 0.5), (2, 0.5), (6, 0.7)])
+def test_white_furnace_pins_the_whole_path_integrator(ob, maxdepth, rho):
+    """Known answer for PathIntegrator.Li as a whole (emission at the camera vertex, UniformSampleOneLight with both MIS
+    halves at every vertex, cosine-sampled continuation, Russian roulette after bounce 3, the maxDepth break): inside a
+    closed box whose walls all emit Le and reflect rho, every vertex i adds beta_i * rho * Le with beta_i = rho^i, so
+    L = Le * (1 + rho + ... + rho^(maxDepth + 1)) for EVERY pixel, whatever the geometry."""
+    Le = 1.25
+    prims = _furnace_prims(rho, Le)
+    film = core.ImageFilm(12, 12)
+    cam = core.PerspectiveCamera.lookAt((0.1, -0.2, 0.05), (0.3, 0.1, 1.0), (0, 1, 0), 70.0, film)
+    r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 256), cam, core.PathIntegrator(maxdepth), core.EmissionIntegrator())
+    rgb = ob.OracleScene(prims, max_prims=4).render(ob.render_desc(r, sampler_mode=1))["rgb"]
+    expect = Le * sum(rho ** j for j in range(maxdepth + 2))
+    assert rgb.mean() == pytest.approx(expect, rel=0.01), (rgb.mean(), expect)
+    assert np.abs(rgb - expect).max() < 0.15 * expect      # per pixel: 256 spp
+    assert np.allclose(rgb[..., 0], rgb[..., 1], rtol=1e-5)
