@@ -1,16 +1,14 @@
-// dr_kernels.hip -- hand-written gfx950 kernels of the DartRay hot path:
-//   k_trace<ANY>     BVHAccel.intersect / intersectP   (accelerators/bvh_accel.dart:101-226,439-472)
+// dr_kernels.hip -- hand-written gfx950 kernels of the DartRay hot path (the traversal kernels are in dr_trace.hip):
 //   k_shade_path     PathIntegrator.Li vertex step      (surface_integrators/path_integrator.dart:29-122,
 //                                                        core/integrator.dart:79-185)
 //   k_shade_direct   DirectLightingIntegrator.Li         (surface_integrators/direct_lighting_integrator.dart:30-68)
-//   k_gen_samples    LDPixelSample                       (core/montecarlo.dart:407-551)
-//   k_raygen         PerspectiveCamera.generateRayDifferential (cameras/perspective_camera.dart:93-132)
+//   k_gen_samples(_lm / _multi)  LDPixelSample           (core/montecarlo.dart:407-551)
+//   k_raygen         Perspective / Orthographic / EnvironmentCamera.generateRay (cameras/*.dart)
 //   k_film / k_film_resolve  ImageFilm.addSample / writeImage (film/image_film.dart:99-185,268-299)
 //
-// One ray per lane, 64-lane waves.  The traversal kernel is persistent: each
-// wave pulls 64 queue entries at a time from a device-side work counter and
-// keeps its todo stack in LDS ([depth][lane] => bank == lane, conflict free).
-// This path is latency / HBM bound (about 1 flop per byte): no MFMA.
+// One path per lane, 64-lane waves, path state in 64-slot tiles (BatchState, dr_kernels.h).  The shade kernels run
+// one large workgroup per CU, grid-stride over the active list, and stage their queue entries in LDS; what bounds
+// each kernel is in DESIGN.md section 3 / 5.  The path is about 1 flop per byte: no MFMA.
 //
 // Compiled with -ffp-contract=off: the Dart VM never fuses a*b+c.
 #include "dr_kernels.h"

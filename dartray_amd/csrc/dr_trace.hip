@@ -18,7 +18,9 @@
 //    0*inf = NaN matters) is the literal f64 test of bvh_accel.dart:439-472 evaluated.  The
 //    decision is therefore always the f64 one;
 //  * todo stack: [depth][lane] u32 in LDS (bank == lane => conflict free) + global spill.
-// The path is latency / HBM bound (about 1 flop per byte): no MFMA.
+// Measured: v2 is VALU-issue bound (93 % busy, 45 % of the lanes of an instruction active) on
+// cache-resident trees; k_trace3 (sibling pairs, further down) wins on big incoherent ones and is chosen per scene
+// and ray kind by the pilot in dr_render_device.  About 1 flop per byte: no MFMA.
 #include "dr_kernels.h"
 #include "dr_wave.h"
 #include "dr_rng.h"
