@@ -19,7 +19,8 @@ path-state workspace and lets the library pick its traversal kernel for the scen
 Extra objects on the JSON line: "roofline" for the dominant kernel k_trace<0> (closest-hit BVH
 traversal): algorithmic bytes (32 B per node visit + 48 B per triangle test, counted on the
 device) / the kernel's summed HIP-event time; "cpu_baseline": the CPU oracle (a C++ port of the
-reference path) timed on one host core on a strided 64x64-pixel subset of the same image.
+reference path) timed on one host core on a strided pixel subset of the same image; "cpu_baseline_threads": the
+same oracle on up to 64 host threads (one serial loop per thread).
 """
 import argparse
 import ctypes as C
@@ -159,6 +160,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prims, renderer, args.cpu_pixels, H, W, spp)
+            out["cpu_baseline_threads"] = cpu_baseline_threads(prims, renderer, 2 * args.cpu_pixels, H, W, spp)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -182,6 +184,42 @@ def cpu_baseline(prims, renderer, grid, H, W, spp):
             "sample": "%dx%d pixels on a stride-%d grid of the %dx%d image x %d spp = %d samples in %.1f s; "
                       "C++ restatement of the Dart reference path (oracle/), single thread"
                       % (grid, grid, H // grid, W, H, spp, n, dt),
+            "host_cores": os.cpu_count()}
+
+
+def cpu_baseline_threads(prims, renderer, grid, H, W, spp):
+    """the same oracle on min(host cores, 64) OS threads, each running the unmodified serial
+    loop on its own rows of a strided grid x grid pixel subset -- the reference's one-isolate-per-task model
+    (dartray_web/render_manager.dart:100-141) with a shared read-only scene.  ctypes releases the GIL inside the call."""
+    import threading
+    import numpy as np
+    import oracle.binding as ob
+    osc = ob.OracleScene(prims)
+    nthreads = max(1, min(os.cpu_count() or 1, 64))
+    ys = (np.arange(grid) * (H // grid) + (H // grid) // 2).astype(np.int32)
+    xs = (np.arange(grid) * (W // grid) + (W // grid) // 2).astype(np.int32)
+    px = np.stack(np.meshgrid(xs, ys), axis=-1).reshape(-1, 2)
+    parts = [p for p in np.array_split(px, nthreads) if len(p)]
+    descs = [ob.render_desc(renderer, sampler_mode=1, pixels=p) for p in parts]
+    # a first threaded pass on one pixel per thread pays the process's one-off costs (thread stacks, malloc arenas, TLS)
+    warm = [threading.Thread(target=osc.render, args=(ob.render_desc(renderer, sampler_mode=1, pixels=p[:1]),),
+                             kwargs={"want_film": False}) for p in parts]
+    for t in warm:
+        t.start()
+    for t in warm:
+        t.join()
+    threads = [threading.Thread(target=osc.render, args=(d,), kwargs={"want_film": False}) for d in descs]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    n = len(px) * spp
+    return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": len(parts), "kind": "port",
+            "sample": "%dx%d pixels on a strided grid of the %dx%d image x %d spp = %d samples in %.1f s on %d threads; "
+                      "C++ restatement of the Dart reference path (oracle/), one serial loop per thread over a shared scene"
+                      % (grid, grid, W, H, spp, n, dt, len(parts)),
             "host_cores": os.cpu_count()}
 
 

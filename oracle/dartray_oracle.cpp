@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -353,7 +354,18 @@ struct Counters {
   uint64_t light_tris = 0;
   uint64_t camera_samples = 0;
   uint64_t max_stack = 0;  // deepest todo stack seen (the reference allocates 64 entries, bvh_accel.dart:120)
+  void add(const Counters& o) {
+    closest_rays += o.closest_rays; any_rays += o.any_rays;
+    closest_nodes += o.closest_nodes; any_nodes += o.any_nodes;
+    closest_tris += o.closest_tris; any_tris += o.any_tris;
+    light_tris += o.light_tris; camera_samples += o.camera_samples;
+    if (o.max_stack > max_stack) max_stack = o.max_stack;
+  }
 };
+// The hot loops count into a per-thread tally (several threads may render one scene: bench.py's threaded CPU baseline;
+// a shared counter would bounce its cache line between the cores on every node visit); CounterScope folds it into the
+// scene's totals when an entry point returns.
+static thread_local Counters t_ctr;
 
 struct Light {  // DiffuseAreaLight (diffuse_area_light.dart:36-70) + ShapeSet (shape_set.dart:24-51), or the InfiniteAreaLight
   int kind = 0;  // 0 = diffuse area light, 1 = infinite area light (Scene::env), 2 = point light (point_light.dart),
@@ -523,8 +535,18 @@ struct Scene {
   int maxPrimsInNode = 4;
   int bvhDepth = 0;
   mutable Counters ctr;
+  mutable std::mutex ctrMutex;
 
   V vert(uint32_t i) const { return V{(D)P[3 * i], (D)P[3 * i + 1], (D)P[3 * i + 2]}; }
+};
+struct CounterScope {  // see t_ctr
+  const Scene& sc;
+  explicit CounterScope(const Scene& s) : sc(s) { t_ctr = Counters(); }
+  ~CounterScope() {
+    std::lock_guard<std::mutex> g(sc.ctrMutex);
+    sc.ctr.add(t_ctr);
+    t_ctr = Counters();
+  }
 };
 
 // ---------------------------------------------------------------------------
@@ -1094,7 +1116,7 @@ struct Isect {  // Intersection (intersection.dart) + GeometricPrimitive.interse
 };
 
 static bool bvh_intersect(const Scene& sc, Ray& ray, Isect* isect) {  // bvh_accel.dart:101-165
-  sc.ctr.closest_rays++;
+  t_ctr.closest_rays++;
   if (sc.nodes.empty()) return false;
   bool hit = false;
   V invDir = vec(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);  // f32-rounded (:109-111)
@@ -1112,15 +1134,15 @@ static bool bvh_intersect(const Scene& sc, Ray& ray, Isect* isect) {  // bvh_acc
       todo = todoHeap.data();
     }
     todo[todoOffset++] = v;
-    if ((uint64_t)todoOffset > sc.ctr.max_stack) sc.ctr.max_stack = (uint64_t)todoOffset;
+    if ((uint64_t)todoOffset > t_ctr.max_stack) t_ctr.max_stack = (uint64_t)todoOffset;
   };
   while (true) {
     const LinearNode& node = sc.nodes[nodeNum];
-    sc.ctr.closest_nodes++;
+    t_ctr.closest_nodes++;
     if (slab(node, ray, invDir, dirIsNeg)) {
       if (node.nPrimitives > 0) {
         for (int i = 0; i < node.nPrimitives; ++i) {
-          sc.ctr.closest_tris++;
+          t_ctr.closest_tris++;
           const Prim& pr = sc.prims[node.offset + i];
           D thit, eps, b1 = 0.0, b2 = 0.0, uvs[6];
           DG dg;
@@ -1160,7 +1182,7 @@ static bool bvh_intersect(const Scene& sc, Ray& ray, Isect* isect) {  // bvh_acc
 }
 
 static bool bvh_intersectP(const Scene& sc, const Ray& ray) {  // bvh_accel.dart:167-226
-  sc.ctr.any_rays++;
+  t_ctr.any_rays++;
   if (sc.nodes.empty()) return false;
   V invDir = vec(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
   int dirIsNeg[3] = {invDir.x < 0 ? 1 : 0, invDir.y < 0 ? 1 : 0, invDir.z < 0 ? 1 : 0};
@@ -1172,11 +1194,11 @@ static bool bvh_intersectP(const Scene& sc, const Ray& ray) {  // bvh_accel.dart
   };
   while (true) {
     const LinearNode& node = sc.nodes[nodeNum];
-    sc.ctr.any_nodes++;
+    t_ctr.any_nodes++;
     if (slab(node, ray, invDir, dirIsNeg)) {
       if (node.nPrimitives > 0) {
         for (int i = 0; i < node.nPrimitives; ++i) {
-          sc.ctr.any_tris++;
+          t_ctr.any_tris++;
           const Prim& pr = sc.prims[node.offset + i];
           if (pr.quadric >= 0) {
             if (quadric_intersect(sc.quadrics[pr.quadric], ray, nullptr, nullptr, nullptr)) return true;
@@ -1230,7 +1252,7 @@ static V shapeset_sample(const Scene& sc, const Light& L, D uPos0, D uPos1, D uC
   DG dg;
   for (size_t i = 0; i < L.shapes.size(); ++i) {
     const LightTri& t = sc.lightTris[L.shapes[i]];
-    sc.ctr.light_tris++;
+    t_ctr.light_tris++;
     if (t.quadric >= 0) {
       anyHit = quadric_intersect(sc.quadrics[t.quadric], r, &thit, &rayEps, &dg) || anyHit;
       continue;
@@ -1254,7 +1276,7 @@ static D shapeset_pdf(const Scene& sc, const Light& L, const V& p, const V& wi) 
     DG dgLight;
     Ray ray{p, wi, 1.0e-3, kInf, 0.0, -1};
     D thit = 0.0, rayEpsilon = 0.0;
-    sc.ctr.light_tris++;
+    t_ctr.light_tris++;
     if (t.quadric >= 0 && sc.quadrics[t.quadric].kind == 1) {
       // Sphere.pdf2 (sphere.dart:313-326): the cone's solid angle unless p is inside the sphere
       const Quadric& q = sc.quadrics[t.quadric];
@@ -2446,6 +2468,7 @@ static Ray to_ray(const OrcRay& r) {
 // BVHAccel.intersect / intersectP on a batch of rays.
 void orc_intersect(void* h, const OrcRay* rays, int64_t n, OrcHit* out, int any_hit) {
   Scene* sc = (Scene*)h;
+  CounterScope counterScope(*sc);
   for (int64_t i = 0; i < n; ++i) {
     Ray r = to_ray(rays[i]);
     OrcHit& o = out[i];
@@ -2464,6 +2487,7 @@ void orc_intersect(void* h, const OrcRay* rays, int64_t n, OrcHit* out, int any_
 // renderers/aggregate_test_renderer.dart:42-118): same tie rule as the BVH (later equal-t hit overwrites).
 void orc_intersect_brute(void* h, const OrcRay* rays, int64_t n, OrcHit* out, int any_hit) {
   Scene* sc = (Scene*)h;
+  CounterScope counterScope(*sc);
   for (int64_t i = 0; i < n; ++i) {
     Ray r = to_ray(rays[i]);
     OrcHit& o = out[i];
@@ -2513,7 +2537,7 @@ int orc_sample_floats(void* h, int integrator, int max_depth) {
 static S li_one(const Scene& sc, const IntegratorCfg& cfg, const Camera& cam, const std::vector<int>& n1D,
                 const std::vector<int>& n2D, int px, int py, const float* sv, LiRng& rng, D shutterOpen,
                 D shutterClose, D* imageX, D* imageY) {
-  sc.ctr.camera_samples++;
+  t_ctr.camera_samples++;
   *imageX = (D)px + (D)sv[0];   // montecarlo.dart:451-452
   *imageY = (D)py + (D)sv[1];
   D time = shutterOpen * (1.0 - (D)sv[4]) + shutterClose * (D)sv[4];  // Lerp common.dart:80-81
@@ -2571,6 +2595,7 @@ static void setup_render(const Scene& sc, const OrcRenderDesc* rd, IntegratorCfg
 // out_rgb: [height*width*3] (OutputImage.rgb); out_film: [height*width*4] (X,Y,Z,weight) or null.
 int orc_render(void* h, const OrcRenderDesc* rd, float* out_rgb, float* out_film, OrcRecord* rec) {
   Scene* sc = (Scene*)h;
+  CounterScope counterScope(*sc);
   IntegratorCfg cfg;
   Camera cam;
   Film film;
@@ -2639,6 +2664,7 @@ int orc_li_samples(void* h, const OrcRenderDesc* rd, int64_t n, const int32_t* p
                    int32_t nfloats_stride, const double* tail, const int32_t* tail_count, int32_t max_tail,
                    float* out_Ls) {
   Scene* sc = (Scene*)h;
+  CounterScope counterScope(*sc);
   IntegratorCfg cfg;
   Camera cam;
   Film film;
