@@ -629,16 +629,12 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
 // One vertex of PathIntegrator.Li (path_integrator.dart:44-119).
 // Launch shape (measured): ONE 768-thread workgroup per CU = 3 waves per SIMD (168 VGPRs each).
 // Smaller workgroups pay more same-address queue atomics (one per workgroup, counter and iteration), 4 waves per
-// SIMD spill; prefetching the next item's state (DR_SHADE_PIPELINE) costs registers and cannot overlap anything
-// because vmcnt retires in order.
+// SIMD spill.
 #ifndef DR_SHADE_WAVES
 #define DR_SHADE_WAVES 3
 #endif
 #ifndef DR_SHADE_BLOCK
 #define DR_SHADE_BLOCK 768
-#endif
-#ifndef DR_SHADE_PIPELINE
-#define DR_SHADE_PIPELINE 0
 #endif
 #ifndef DR_SHADE_GRID_PER_CU
 #define DR_SHADE_GRID_PER_CU 1
@@ -664,35 +660,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
-  // DR_SHADE_PIPELINE 0: every iteration fetches its active-list entry, then the slot state (two dependent trips).
-  // 1: the state of item it+1 is requested before item it is shaded (costs ~45 registers for the whole iteration and
-  //    cannot overlap much: vmcnt retires in order, so the first load of the shading code waits for the prefetch).
-  // 2: the active-list entry is fetched two iterations ahead (one register) and the state of item it+1 is requested
-  //    AFTER item it has been shaded, ahead of the queue push and its barriers.
+  // Every iteration fetches its active-list entry, then the whole slot state with independent loads.  Prefetching the
+  // next item's state did not pay (DESIGN.md section 5 row i: vmcnt retires in order, so a prefetch issued before the
+  // shading code is waited for at its first load; issued after it, it costs 16 spilled registers).
   const uint32_t tid0 = blockIdx.x * blockDim.x + threadIdx.x;
   auto slotOf = [&](uint32_t i) -> uint32_t { return i < nIn ? (q.activeIn ? q.activeIn[i] : i) : 0u; };
-#if DR_SHADE_PIPELINE
-  ShadeIn nxt;
-  uint32_t slotNext2 = slotOf(tid0 + stride);
-  load_shade_in<QUAD>(st, rp, bounce, slotOf(tid0), tid0 < nIn, &nxt);
-#endif
   for (uint32_t it = 0; it < nIter; ++it) {
-#if DR_SHADE_PIPELINE == 1
-    const ShadeIn cur = nxt;
-    {
-      const uint32_t i1 = (it + 1) * stride + tid0, i2 = (it + 2) * stride + tid0;
-      const uint32_t s1 = slotNext2;
-      slotNext2 = (it + 2 < nIter) ? slotOf(i2) : 0u;
-      if (it + 1 < nIter) load_shade_in<QUAD>(st, rp, bounce, s1, i1 < nIn, &nxt);
-    }
-#elif DR_SHADE_PIPELINE == 2
-    const ShadeIn cur = nxt;
-    const uint32_t slotNext1 = slotNext2;
-    slotNext2 = (it + 2 < nIter) ? slotOf((it + 2) * stride + tid0) : 0u;
-#else
     ShadeIn cur;
     load_shade_in<QUAD>(st, rp, bounce, slotOf(it * stride + tid0), it * stride + tid0 < nIn, &cur);
-#endif
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
     bool pushCont = false;
@@ -811,9 +786,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       stc(st.L(), cap, slot, L);
       st.flags()[TI(cap, slot)] = pf;
     }
-#if DR_SHADE_PIPELINE == 2
-    if (it + 1 < nIter) load_shade_in<QUAD>(st, rp, bounce, slotNext1, (it + 1) * stride + tid0 < nIn, &nxt);
-#endif
     stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT);
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter) stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut);
   }
