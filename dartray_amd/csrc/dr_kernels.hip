@@ -211,19 +211,23 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
 // dword column l, [i / EPW][l][i % EPW] with EPW entries per dword -- so every lane only ever touches its own LDS
 // bank whatever row the random swap partner is in (the row-major table above takes ~6-way bank conflicts there), and
 // a lane's 64 consecutive entries are one tile's whole 64-entry index run: it stores them itself, 16 bytes at a time.
+// The workgroup has LN = blockDim.x <= 64 lanes (pixels): what limits this kernel is the LDS footprint of a shuffle
+// (spp entries per pixel) and the latency of its dependent steps, so the 160 KB of a CU are better spent on many
+// narrow waves than on few full ones -- 64 lanes up to 128 spp, 32 at 256, 16 above (launch_gen_samples).
 template <class PT>
 __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchState st, uint32_t npix) {
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int EPW = 4 / (int)sizeof(PT);  // entries per dword
-  PT* s_perm = (PT*)s_raw;                  // [spp / EPW][64][EPW]
-  uint32_t* s_magic = (uint32_t*)(s_raw + (size_t)rp.spp * 64 * sizeof(PT));  // [spp + 1]: floor(2^32 / m)
+  const int LN = (int)blockDim.x;
+  PT* s_perm = (PT*)s_raw;                  // [spp / EPW][LN][EPW]
+  uint32_t* s_magic = (uint32_t*)(s_raw + (size_t)rp.spp * LN * sizeof(PT));  // [spp + 1]: floor(2^32 / m)
   const int lane = threadIdx.x;
-  const uint32_t p = blockIdx.x * 64u + lane;
+  const uint32_t p = blockIdx.x * (uint32_t)LN + lane;
   const int k = blockIdx.y;  // LD block: image, lens, time, 1-D slots, 2-D slots (montecarlo.dart:437-448)
   const int spp = rp.spp;
   const bool is2D = k < 2 || k >= 3 + rp.n1D;
-  auto at = [&](int i) -> PT& { return s_perm[(i / EPW) * (64 * EPW) + lane * EPW + (i % EPW)]; };
-  for (int m = 1 + lane; m <= spp; m += 64) s_magic[m] = m == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)m);
+  auto at = [&](int i) -> PT& { return s_perm[(i / EPW) * (LN * EPW) + lane * EPW + (i % EPW)]; };
+  for (int m = 1 + lane; m <= spp; m += LN) s_magic[m] = m == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)m);
   __syncthreads();
   if (p >= npix) return;
   const int2 xy = st.pix[p];
@@ -248,14 +252,14 @@ __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchSta
     a = (other == i + 1) ? a : ahead;
   }
   // this lane's spp entries are spp / 64 whole index runs: slot p * spp + i is entry i & 63 of tile (p * spp + i) >> 6
-  const uint32_t* cols = (const uint32_t*)s_raw + lane;  // dword d of this lane's column is cols[d * 64]
+  const uint32_t* cols = (const uint32_t*)s_raw + lane;  // dword d of this lane's column is cols[d * LN]
   const size_t tile0 = ((size_t)p * (size_t)spp) >> 6;
   constexpr int DPR = 64 / EPW;  // dwords per 64-entry run
   for (int t = 0; t < spp / 64; ++t) {
     uint4* o = (uint4*)(st.svIdx() + (tile0 + t) * (size_t)st.tileStride * 4 + (size_t)k * 64 * sizeof(PT));
     for (int q = 0; q < DPR / 4; ++q) {
       const int d = t * DPR + 4 * q;
-      o[q] = make_uint4(cols[(d + 0) * 64], cols[(d + 1) * 64], cols[(d + 2) * 64], cols[(d + 3) * 64]);
+      o[q] = make_uint4(cols[(d + 0) * LN], cols[(d + 1) * LN], cols[(d + 2) * LN], cols[(d + 3) * LN]);
     }
   }
 }
@@ -960,29 +964,24 @@ __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, co
       s_own[e] = own;
     }
     __syncthreads();
-    for (uint32_t pl = threadIdx.x; pl < nPixChunk; pl += 256u) {
+    // lane = (pixel, channel): X, Y, Z and the weight sum are four independent f32 chains
+    for (uint32_t w = threadIdx.x; w < 4u * nPixChunk; w += 256u) {
+      const uint32_t pl = w >> 2, c = w & 3u;
       const uint32_t e0 = pl * perPix;
-      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accw = 0.f;
+      const float* val = c == 0 ? s_X : (c == 1 ? s_Y : s_Z);
+      float acc = 0.f;
       for (uint32_t i = 0; i < perPix; ++i) {
         const uint32_t e = e0 + i;
         if (s_own[e]) {
           const double wt = s_W[e];
-          acc0 = (float)((double)acc0 + wt * (double)s_X[e]);
-          acc1 = (float)((double)acc1 + wt * (double)s_Y[e]);
-          acc2 = (float)((double)acc2 + wt * (double)s_Z[e]);
-          accw = (float)((double)accw + wt);
+          acc = (float)((double)acc + wt * (c == 3 ? 1.0 : (double)val[e]));  // weightSum += wt (wt * 1.0 is exact)
         }
       }
       const uint64_t s64 = base + e0;  // the first slot of this lane's pixel
       if (s64 < nslots) {
         const int2 xy = st.pix[(uint32_t)s64 >> rp.sppShift];
-        if (xy.x >= rp.left && xy.x < rp.left + rp.width && xy.y >= rp.top && xy.y < rp.top + rp.height) {
-          float* px = film + 4 * ((size_t)(xy.y - rp.top) * rp.width + (size_t)(xy.x - rp.left));
-          atomicAdd(px + 0, acc0);
-          atomicAdd(px + 1, acc1);
-          atomicAdd(px + 2, acc2);
-          atomicAdd(px + 3, accw);
-        }
+        if (xy.x >= rp.left && xy.x < rp.left + rp.width && xy.y >= rp.top && xy.y < rp.top + rp.height)
+          atomicAdd(film + 4 * ((size_t)(xy.y - rp.top) * rp.width + (size_t)(xy.x - rp.left)) + c, acc);
       }
     }
   }
@@ -1024,20 +1023,29 @@ void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t*
   hipLaunchKernelGGL(k_gather_tris, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, verts, idx, mat, light, rev, out,
                      ntris);
 }
+#ifndef DR_GEN_LANES_256
+#define DR_GEN_LANES_256 64
+#endif
+#ifndef DR_GEN_LANES_BIG
+#define DR_GEN_LANES_BIG 64
+#endif
 void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s) {
   const int nBlocks = rp.blocks ? rp.nBlocks : 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
   const dim3 grid((npix + 63) / 64, nBlocks);
   if (!st.svFloat && rp.spp >= 64) {  // compact form (rp.blocks is null), whole index runs per pixel
-    const size_t lds = (size_t)rp.spp * 64 * (rp.spp <= 256 ? 1 : 2) + ((size_t)rp.spp + 1) * 4;
+    static const int lanesEnv = getenv("DARTRAY_GEN_LANES") ? atoi(getenv("DARTRAY_GEN_LANES")) : 0;
+    const int ln = lanesEnv ? lanesEnv : (rp.spp <= 128 ? 64 : (rp.spp <= 256 ? DR_GEN_LANES_256 : DR_GEN_LANES_BIG));
+    const dim3 g((npix + ln - 1) / ln, nBlocks);
+    const size_t lds = (size_t)rp.spp * ln * (rp.spp <= 256 ? 1 : 2) + ((size_t)rp.spp + 1) * 4;
     if (rp.spp <= 256) {
-      hipLaunchKernelGGL(k_gen_samples_lm<uint8_t>, grid, dim3(64), lds, s, rp, st, npix);
+      hipLaunchKernelGGL(k_gen_samples_lm<uint8_t>, g, dim3(ln), lds, s, rp, st, npix);
     } else {
       static bool attrSet = false;
       if (!attrSet) {
         (void)hipFuncSetAttribute((const void*)k_gen_samples_lm<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrSet = true;
       }
-      hipLaunchKernelGGL(k_gen_samples_lm<uint16_t>, grid, dim3(64), lds, s, rp, st, npix);
+      hipLaunchKernelGGL(k_gen_samples_lm<uint16_t>, g, dim3(ln), lds, s, rp, st, npix);
     }
     return;
   }
