@@ -898,6 +898,89 @@ def RoundUpPow2(v):  # common.dart:113-123
     return v + 1
 
 
+class DartRandom:
+    """dart:math Random(seed) of the Dart VM as used by core/rng.dart:27-43 (multiply-with-carry, A = 0xffffda61,
+    Thomas-Wang seeding, four warm-up steps) -- host side only: the pixel samplers below shuffle
+    with their own RNG(5489)."""
+    _M64 = (1 << 64) - 1
+
+    def __init__(self, seed=5489):
+        n = seed & self._M64
+        n = ((~n) + (n << 21)) & self._M64
+        n ^= n >> 24
+        n = (n * 265) & self._M64
+        n ^= n >> 14
+        n = (n * 21) & self._M64
+        n ^= n >> 28
+        n = (n + (n << 31)) & self._M64
+        n = n or 0x5A17
+        self.lo, self.hi = n & 0xffffffff, n >> 32
+        for _ in range(4):
+            self._step()
+
+    def _step(self):
+        s = (0xffffda61 * self.lo + self.hi) & self._M64
+        self.lo, self.hi = s & 0xffffffff, s >> 32
+
+    def randomUint(self):  # Random.nextInt(0xffffffff): only lo == 0xffffffff is rejected
+        while True:
+            self._step()
+            if self.lo != 0xffffffff:
+                return self.lo
+
+
+class LinearPixelSampler:
+    """Pixels "linear" (pixel_samplers/linear_pixel_sampler.dart:29-40): rows top to bottom."""
+    kind, tileSize, randomize = 0, 32, False
+
+    def setup(self, x, y, width, height):
+        ys, xs = np.meshgrid(np.arange(y, y + height, dtype=np.int32), np.arange(x, x + width, dtype=np.int32), indexing="ij")
+        return np.stack([xs, ys], axis=-1).reshape(-1, 2)
+
+
+class TilePixelSampler(LinearPixelSampler):
+    """Pixels "tile" (tile_pixel_sampler.dart:33-100), the reference's default: tileSize^2 tiles in row-major order,
+    shuffled (from tile 1 on, each with a uniformly drawn partner) by the sampler's own RNG(5489)."""
+    kind = 1
+
+    def __init__(self, tileSize=32, randomize=True):
+        self.tileSize, self.randomize = int(tileSize), bool(randomize)
+
+    def setup(self, x, y, width, height):
+        ts = self.tileSize
+        nx = width // ts + (0 if width % ts == 0 else 1)
+        ny = height // ts + (0 if height % ts == 0 else 1)
+        tiles = [(xi, yi) for yi in range(ny) for xi in range(nx)]
+        if self.randomize:
+            rng = DartRandom()
+            for ti in range(1, len(tiles)):
+                r = rng.randomUint() % len(tiles)
+                tiles[ti], tiles[r] = tiles[r], tiles[ti]
+        right, bottom = x + width - 1, y + height - 1
+        out = []
+        for tx, ty in tiles:
+            sx, sy = x + tx * ts, y + ty * ts
+            xs = np.arange(sx, min(sx + ts - 1, right) + 1, dtype=np.int32)
+            ys = np.arange(sy, min(sy + ts - 1, bottom) + 1, dtype=np.int32)
+            gy, gx = np.meshgrid(ys, xs, indexing="ij")
+            out.append(np.stack([gx, gy], axis=-1).reshape(-1, 2))
+        return np.concatenate(out) if out else np.zeros((0, 2), np.int32)
+
+
+class RandomPixelSampler(LinearPixelSampler):
+    """Pixels "random" (random_pixel_sampler.dart:27-58): the linear list, entry i swapped with a uniformly drawn one."""
+    kind = 2
+
+    def setup(self, x, y, width, height):
+        p = LinearPixelSampler.setup(self, x, y, width, height).copy()
+        rng = DartRandom()
+        n = len(p)
+        for i in range(n):
+            l = rng.randomUint() % n
+            p[[i, l]] = p[[l, i]]
+        return p
+
+
 class LowDiscrepancySampler:
     """samplers/low_discrepancy_sampler.dart:32-88.  The reference threads ONE
     serial RNG through sampler and integrator (sampler_renderer.dart:137); on
@@ -905,10 +988,13 @@ class LowDiscrepancySampler:
     (DR_SAMPLER_COUNTER), or the caller supplies recorded sample vectors
     (HostBufferSampler)."""
 
-    def __init__(self, camera, nsamp=4, seed=5489):
+    def __init__(self, camera, nsamp=4, seed=5489, pixels=None):
         self.camera = camera
         self.samplesPerPixel = RoundUpPow2(int(nsamp))
         self.seed = int(seed)
+        # PixelSampler: the ORDER in which pixels are sampled only matters to the serial reference stream (which RNG
+        # numbers a pixel gets); the device's keyed streams give every pixel the same samples in any order
+        self.pixelSampler = pixels or LinearPixelSampler()
 
     def roundSize(self, size):
         return RoundUpPow2(size)
@@ -1050,7 +1136,7 @@ class SamplerRenderer:
 # ---------------------------------------------------------------------------
 class Plugin:
     _reg = {"accelerator": {}, "surfaceIntegrator": {}, "renderer": {}, "sampler": {}, "film": {}, "filter": {},
-            "camera": {}, "material": {}, "shape": {}, "areaLight": {}, "volumeIntegrator": {}}
+            "camera": {}, "material": {}, "shape": {}, "areaLight": {}, "volumeIntegrator": {}, "pixelSampler": {}}
 
     @classmethod
     def register(cls, kind, name, creator):
@@ -1070,6 +1156,9 @@ def RegisterStandardPlugins():
     Plugin.register("renderer", "sampler", SamplerRenderer)
     Plugin.register("sampler", "lowdiscrepancy", LowDiscrepancySampler)
     Plugin.register("film", "image", ImageFilm)
+    Plugin.register("pixelSampler", "linear", lambda ps=None: LinearPixelSampler())
+    Plugin.register("pixelSampler", "tile", lambda ps=None: TilePixelSampler((ps or {}).get("tilesize", 32), (ps or {}).get("random", True)))
+    Plugin.register("pixelSampler", "random", lambda ps=None: RandomPixelSampler())
     Plugin.register("filter", "box", lambda ps=None: BoxFilter((ps or {}).get("xwidth", 0.5), (ps or {}).get("ywidth", 0.5)))
     Plugin.register("filter", "gaussian", lambda ps=None: GaussianFilter((ps or {}).get("xwidth", 2.0), (ps or {}).get("ywidth", 2.0),
                                                                            (ps or {}).get("alpha", 2.0)))

@@ -502,7 +502,8 @@ class DartRay:
                         acceleratorParams=ParamSet(), rendererName="sampler", rendererParams=ParamSet(),
                         surfaceIntegratorName="directlighting", surfaceIntegratorParams=ParamSet(),
                         volumeIntegratorName="emission", volumeIntegratorParams=ParamSet(),
-                        cameraName="perspective", cameraParams=ParamSet(), cameraToWorld=Transform())
+                        cameraName="perspective", cameraParams=ParamSet(), cameraToWorld=Transform(),
+                        pixelSamplerName="tile", pixelSamplerParams=ParamSet())
         self.primitives = []
         self.lights = []
 
@@ -562,8 +563,10 @@ class DartRay:
         self.opt["filmName"], self.opt["filmParams"] = name, ps
 
     def pixels(self, name, ps):
-        # pixel ORDER does not change the image in counter-stream mode; accepted, unused
+        # pixel ORDER does not change the image in counter-stream mode; it is kept on the
+        # sampler for the serial reference stream (oracle / host-buffer replays)
         self.opt["pixelSamplerName"] = name
+        self.opt["pixelSamplerParams"] = ps
 
     def sampler(self, name, ps):
         self.opt["samplerName"], self.opt["samplerParams"] = name, ps
@@ -911,7 +914,16 @@ class DartRay:
         film = self._makeFilm()
         camera = self._makeCamera(film)
         nsamp = int(self.overrides.get("pixelsamples", o["samplerParams"].findOneInt("pixelsamples", 4)))
-        sampler = core.LowDiscrepancySampler(camera, nsamp, int(self.overrides.get("seed", 5489)))
+        pname, pps = o["pixelSamplerName"], o["pixelSamplerParams"]          # dartray.dart:980-996
+        if pname == "tile":                                                  # tile_pixel_sampler.dart:102-106
+            pixels = core.TilePixelSampler(pps.findOneInt("tilesize", 32), pps.findOneBool("random", True))
+        elif pname == "random":
+            pixels = core.RandomPixelSampler()
+        elif pname == "linear":
+            pixels = core.LinearPixelSampler()
+        else:
+            raise UnsupportedFeature(f"Pixels \"{pname}\"")
+        sampler = core.LowDiscrepancySampler(camera, nsamp, int(self.overrides.get("seed", 5489)), pixels)
         kw = dict(taskNum=self.overrides.get("taskNum", 0), taskCount=self.overrides.get("taskCount", 1))
         kw.update(renderer_kw)
         return core.SamplerRenderer(sampler, camera, self._makeSurfaceIntegrator(), core.EmissionIntegrator(), **kw)

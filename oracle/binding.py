@@ -48,7 +48,8 @@ class OrcRenderDesc(C.Structure):
                 ("shutter_open", C.c_float), ("shutter_close", C.c_float), ("camera_type", C.c_int32),
                 ("integrator", C.c_int32), ("max_depth", C.c_int32), ("spp", C.c_int32), ("sampler_mode", C.c_int32),
                 ("seed", C.c_int64), ("task_num", C.c_int32), ("task_count", C.c_int32),
-                ("npixels", C.c_int32), ("pixels", C.c_void_p)]
+                ("npixels", C.c_int32), ("pixels", C.c_void_p),
+                ("pixel_order", C.c_int32), ("tile_size", C.c_int32), ("tile_random", C.c_int32), ("pad_po", C.c_int32)]
 
 
 class OrcRecord(C.Structure):
@@ -100,6 +101,7 @@ def lib():
         l.orc_power_heuristic.restype = C.c_double
         l.orc_power_heuristic.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double]
         l.orc_get_sub_window.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.orc_pixel_order.argtypes = [C.c_int] * 7 + [C.c_void_p]
         l.orc_camera_setup_ortho.argtypes = [C.c_int, C.c_int, C.c_void_p]
         l.orc_generate_ray.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
         l.orc_filter_evaluate.restype = C.c_double
@@ -334,6 +336,9 @@ def render_desc(renderer, sampler_mode=None, pixels=None):
     rd.sampler_mode = 1 if sampler_mode is None else sampler_mode
     rd.seed = getattr(renderer.sampler, "seed", 0)
     rd.task_num, rd.task_count = renderer.taskNum, renderer.taskCount
+    ps = getattr(renderer.sampler, "pixelSampler", None)
+    if ps is not None:
+        rd.pixel_order, rd.tile_size, rd.tile_random = ps.kind, ps.tileSize, int(ps.randomize)
     if pixels is not None:
         pixels = np.ascontiguousarray(pixels, np.int32).reshape(-1, 2)
         rd._pixels_keep = pixels

@@ -2224,6 +2224,10 @@ struct OrcRenderDesc {
   // linear pixel order (linear_pixel_sampler.dart:29-40).
   int32_t npixels;
   const int32_t* pixels;  // npixels * 2 raster pixels (x, y)
+  // Pixel order of the whole-window render (npixels == 0): 0 = Pixels "linear" (linear_pixel_sampler.dart:29-40),
+  // 1 = "tile" (tile_pixel_sampler.dart:33-100; the reference's default: 32 x 32 tiles, shuffled by their own
+  // RNG(5489)), 2 = "random" (random_pixel_sampler.dart:27-58).  Only the serial mode's images depend on it.
+  int32_t pixel_order, tile_size, tile_random, pad_po;
 };
 struct OrcRecord {  // optional per-sample recording (all host arrays sized by the caller)
   int64_t capacity;       // max samples
@@ -2593,6 +2597,60 @@ static void setup_render(const Scene& sc, const OrcRenderDesc* rd, IntegratorCfg
 
 // SamplerRenderer.render (sampler_renderer.dart:36-65,118-218).
 // out_rgb: [height*width*3] (OutputImage.rgb); out_film: [height*width*4] (X,Y,Z,weight) or null.
+// PixelSampler.setup of the three pixel samplers over the window (x, y, width, height) -> x0 y0 x1 y1 ...
+static void pixel_order(int kind, int left, int top, int width, int height, int tileSize, bool randomize, std::vector<int>& out) {
+  const int right = left + width - 1, bottom = top + height - 1;  // pixel_sampler.dart:36-38
+  out.clear();
+  out.reserve((size_t)width * height * 2);
+  if (kind == 1) {  // tile_pixel_sampler.dart:38-95
+    const int numXTiles = width / tileSize + ((width % tileSize == 0) ? 0 : 1);
+    const int numYTiles = height / tileSize + ((height % tileSize == 0) ? 0 : 1);
+    std::vector<int> tiles;
+    for (int yi = 0; yi < numYTiles; ++yi)
+      for (int xi = 0; xi < numXTiles; ++xi) { tiles.push_back(xi); tiles.push_back(yi); }
+    const int numTiles = (int)tiles.size() / 2;
+    if (randomize) {
+      DartRandom rng(5489);  // RNG() (rng.dart:27-29)
+      for (int ti = 1; ti < numTiles; ++ti) {  // NB starts at tile 1 (`ti = 01`, :59)
+        const int lx = ti * 2, ly = lx + 1;
+        const int rx = (int)(rng.randomUint() % (uint32_t)numTiles) * 2, ry = rx + 1;
+        std::swap(tiles[lx], tiles[rx]);
+        std::swap(tiles[ly], tiles[ry]);
+      }
+    }
+    for (int i = 0, ti = 0; i < numTiles; ++i) {
+      const int tx = tiles[ti++], ty = tiles[ti++];
+      const int sx = left + tx * tileSize, sy = top + ty * tileSize;
+      for (int yi = 0; yi < tileSize; ++yi) {
+        const int y = sy + yi;
+        if (y > bottom) break;
+        for (int xi = 0; xi < tileSize; ++xi) {
+          const int x = sx + xi;
+          if (x > right) break;
+          out.push_back(x); out.push_back(y);
+        }
+      }
+    }
+    return;
+  }
+  for (int y = top; y <= bottom; ++y)
+    for (int x = left; x <= right; ++x) { out.push_back(x); out.push_back(y); }
+  if (kind == 2) {  // random_pixel_sampler.dart:40-56
+    DartRandom rng(5489);
+    const int n = (int)out.size() / 2;
+    for (int i = 0, r = 0; i < n; ++i, r += 2) {
+      const int l = (int)(rng.randomUint() % (uint32_t)n) * 2;
+      std::swap(out[r], out[l]);
+      std::swap(out[r + 1], out[l + 1]);
+    }
+  }
+}
+void orc_pixel_order(int kind, int left, int top, int width, int height, int tile_size, int randomize, int32_t* out_xy) {
+  std::vector<int> v;
+  pixel_order(kind, left, top, width, height, tile_size, randomize != 0, v);
+  for (size_t i = 0; i < v.size(); ++i) out_xy[i] = v[i];
+}
+
 int orc_render(void* h, const OrcRenderDesc* rd, float* out_rgb, float* out_film, OrcRecord* rec) {
   Scene* sc = (Scene*)h;
   CounterScope counterScope(*sc);
@@ -2615,9 +2673,13 @@ int orc_render(void* h, const OrcRenderDesc* rd, float* out_rgb, float* out_film
   if (rd->npixels > 0 && rd->sampler_mode == 0) return -4;
   std::vector<S> Ls(spp);
   std::vector<D> ix(spp), iy(spp);
+  std::vector<int> order;  // the window's pixels in the PixelSampler's order
+  if (rd->npixels == 0 && rd->pixel_order != 0)
+    pixel_order(rd->pixel_order, win[0], win[1], win[2], win[3], rd->tile_size > 0 ? rd->tile_size : 32, rd->tile_random != 0, order);
   for (int64_t pi = 0; pi < npix; ++pi) {
     int px, py;  // raster pixel
     if (rd->npixels > 0) { px = rd->pixels[2 * pi]; py = rd->pixels[2 * pi + 1]; }
+    else if (!order.empty()) { px = order[2 * pi]; py = order[2 * pi + 1]; }
     else { px = win[0] + (int)(pi % win[2]); py = win[1] + (int)(pi / win[2]); }
     // counter streams are keyed by the pixel's position in the FULL sampler extent, so that any task /
     // tile split traces identical samples

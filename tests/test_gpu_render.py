@@ -65,6 +65,21 @@ def test_path_serial_stream_with_recorded_rng_tail(gpu):
         r.render(scenes.make_scene(prims))
 
 
+def test_reference_default_tile_order_replayed_through_host_buffers(ob, gpu):
+    """The reference's default pixel order is Pixels "tile" (32 x 32 tiles shuffled by RNG(5489),
+    tile_pixel_sampler.dart:38-95): the oracle walks the window in that order with the task's serial RNG, records every
+    sample's inputs, and the device -- given the recording in the same order -- reproduces the serial image exactly."""
+    prims, mk = scenes.config("C2", xres=70, yres=40, spp=4, blob=(24, 12))
+    r = mk()
+    r.sampler.pixelSampler = core.TilePixelSampler()
+    rec = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=0), record=71 * 41 * 4, max_tail=40)
+    order = core.TilePixelSampler().setup(0, 0, 71, 41)
+    assert np.array_equal(rec["pixel_xy"][::4], order)            # the recording follows the tile order
+    r.sampler = core.HostBufferSampler(r.camera, 4, rec["pixel_xy"][::4], rec["sample_vec"], rec["tail"])
+    out = r.render(scenes.make_scene(prims))
+    assert np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"])
+
+
 def test_path_counter_mode_golden(gpu):
     g = np.load(os.path.join(GOLDEN, "c2small_path_counter.npz"))
     prims, mk = scenes.config("C2", xres=16, yres=16, spp=8, blob=(32, 16))
