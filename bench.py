@@ -6,12 +6,13 @@
 metric  : Msamples/s (primary + path rays), film pixels x spp per second, whole job over N GPUs
 workload: configs[1] -- Cornell box + 1M-triangle displaced blob, PathIntegrator maxdepth 5,
           1024x1024, 256 spp (2.68e8 camera samples per GPU and step).  One "step" = one full pass
-          of the hot path over that batch.  At N > 1 (default --scaling weak) every rank adds its own
-          256 spp to the SAME image -- rank r samples with seed + r -- and the (X, Y, Z, weight) films
-          are summed onto rank 0 with ONE RCCL reduce per step: an N x 256-spp image, per-GPU work
-          fixed.  --scaling strong instead deals the 32x32 tiles of the single 256-spp image round-robin
-          over the ranks (the reference's task split, render_manager.dart:100-141) and reduces the film
-          the same way; each GPU's launches then shrink with N.
+          of the hot path over that batch.  At N > 1 the image's 32x32 tiles are dealt round-robin over
+          the ranks (north_star; the reference's task split, render_manager.dart:100-141), every rank
+          accumulates a full-frame (X, Y, Z, weight) film and ONE RCCL reduce per step sums them on rank 0.
+          --scaling weak (default): the image has N times the pixels (side 1024 * sqrt(N), same scene and
+          camera, towards configs[2]'s 4096x4096), so every GPU keeps 2.68e8 samples per step;
+          --scaling strong: the 1024x1024 image itself is split, each GPU's launches shrink with N;
+          --scaling samples: no tiles -- every rank adds its own 256 spp (seed + rank) to the same image.
 Inputs (scene, BVH) are resident in HBM before the timed region; samples are generated on the
 device.  Synthetic procedural scene, no files.  Before the W warm-up steps one priming render allocates the
 path-state workspace and lets the library pick its traversal kernel for the scene (set-up, like the BVH build).
@@ -46,9 +47,9 @@ def main():
                     help="2: odd batches run on a second stream / workspace (kernel tails and memory-bound shading overlap "
                          "the ALU-bound traversal: +10 %% on C2) -- per-kernel event times then overlap, so the roofline "
                          "object is only meaningful with 1")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = every rank renders spp samples of the whole image with its own seed, films summed; "
-                         "strong = the tiles of one spp-sample image dealt over the ranks")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "samples"],
+                    help="N > 1: weak = tiles of an image with N x the pixels (per-GPU work fixed); strong = tiles of the same "
+                         "image; samples = every rank renders spp samples of the whole image with its own seed, films summed")
     ap.add_argument("--cpu-pixels", type=int, default=96, help="cpu baseline: side of the strided pixel grid")
     args = ap.parse_args()
 
@@ -67,12 +68,14 @@ def main():
 
     spp = args.spp or {"C2": 256, "C4": 64, "C5": 512}[args.config]
     args.res = args.res or {"C2": 1024, "C4": 1024, "C5": 2048}[args.config]
+    if args.scaling == "weak" and world > 1:
+        args.res = int(round(args.res * world ** 0.5 / 32.0)) * 32  # N x the pixels, whole tiles
     prims, mk = scenes.config(args.config, xres=args.res, yres=args.res, spp=spp)
     renderer = mk()
-    if args.scaling == "strong":
-        renderer = drdist.shard(renderer, rank, world)
-    else:
+    if args.scaling == "samples":
         renderer = drdist.sample_set(renderer, rank)  # independent sample sets of the same image
+    else:
+        renderer = drdist.shard(renderer, rank, world)  # round-robin 32 x 32 tiles
     scene = scenes.make_scene(prims, renderer.env)  # every rank builds + uploads its own copy (render_isolate.dart:31-41)
     film_desc = renderer.camera.film
     H, W = film_desc.height, film_desc.width
@@ -113,7 +116,7 @@ def main():
     st = dev.stats()
 
     if rank == 0:
-        samples_per_step = H * W * spp * (world if args.scaling == "weak" else 1)
+        samples_per_step = H * W * spp * (world if args.scaling == "samples" else 1)
         value = samples_per_step * args.steps / dt / 1e6
         alg_bytes = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
         launches = max(1, st["closest_launches"])
@@ -135,7 +138,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": "strong" if args.scaling == "strong" else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -144,7 +147,7 @@ def main():
                                         "C5": "8M-triangle courtyard, 8 area lights + env map"}[args.config],
                           renderer.surfaceIntegrator.maxDepth, args.res, args.res, spp),
                        "triangles": int(len(scene.aggregate.tri_idx)), "bvh_nodes": int(len(scene.aggregate.nodes)),
-                       "samples_per_step": samples_per_step, "parallelism": ("spp-sets x%d, film reduce" if args.scaling == "weak" else "tiles32 x%d, film reduce") % world, "pipelines": args.pipelines},
+                       "samples_per_step": samples_per_step, "parallelism": ("spp-sets x%d, film reduce" if args.scaling == "samples" else "tiles32 x%d, film reduce") % world, "pipelines": args.pipelines},
             "roofline": {"bound": "hbm", "kernel": "k_trace<0> (closest-hit BVH traversal)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic,
