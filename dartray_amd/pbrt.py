@@ -16,7 +16,7 @@ produce, and hands them to core.BVHAccel / core.SamplerRenderer (the C ABI).
 Matrices follow the reference's numerics (Float32List storage, f64
 expressions): matrix4x4.dart:193-343, transform.dart:83-86,110-129,214-331.
 
-Plugins on the path: shapes trianglemesh (with N / S / uv), sphere, disk;
+Plugins on the path: shapes trianglemesh (with N / S / uv), heightfield, sphere, disk;
 materials matte (Lambertian / Oren-Nayar), plastic, mirror, glass; area lights
 on any of those shapes, infinite lights (constant or .npy lat-long map), point,
 spot and distant lights; perspective / orthographic / environment cameras, image film, box / gaussian / mitchell / triangle / sinc filters,
@@ -750,8 +750,24 @@ class DartRay:
         if name == "disk":                    # disk.dart:157-165
             return core.Disk(o2w.m, o2w.mInv, ro, ps.findOneFloat("height", 0.0), ps.findOneFloat("radius", 1.0),
                              ps.findOneFloat("innerradius", 0.0), ps.findOneFloat("phimax", 360.0))
+        if name == "heightfield":             # heightfield.dart:23-94: refines into ONE TriangleMesh with uvs
+            nu, nv = ps.findOneInt("nu", -1), ps.findOneInt("nv", -1)
+            Pz = ps.findFloat("Pz")
+            if nu < 2 or nv < 2 or Pz is None or len(Pz) != nu * nv:
+                raise ValueError("heightfield needs nu, nv >= 2 and nu * nv values of Pz")
+            xs = (np.arange(nu, dtype=np.float64) / (nu - 1)).astype(np.float32)   # uvs[ui] = x / (nx - 1), a Float32List
+            ys = (np.arange(nv, dtype=np.float64) / (nv - 1)).astype(np.float32)
+            gy, gx = np.meshgrid(ys, xs, indexing="ij")
+            uv = np.stack([gx, gy], axis=-1).reshape(-1, 2)
+            P = np.concatenate([uv, np.asarray(Pz, np.float32).reshape(-1, 1)], axis=1)   # Point(uvs[ui], uvs[ui+1], z[pi])
+            x, y = np.meshgrid(np.arange(nu - 1), np.arange(nv - 1), indexing="xy")
+            x, y = x.reshape(-1), y.reshape(-1)
+            v = lambda a, b: a + b * nu
+            idx = np.stack([v(x, y), v(x + 1, y), v(x + 1, y + 1), v(x, y), v(x + 1, y + 1), v(x, y + 1)], axis=1).reshape(-1, 3)
+            return core.TriangleMesh(idx.astype(np.uint32), self.ctm.transformPoints(P), ro, uvs=uv.reshape(-1),
+                                     objectToWorld=self.ctm.m, worldToObject=self.ctm.mInv)
         if name != "trianglemesh":
-            raise UnsupportedFeature(f"Shape \"{name}\": only 'trianglemesh', 'sphere' and 'disk' are on the path "
+            raise UnsupportedFeature(f"Shape \"{name}\": only 'trianglemesh', 'heightfield', 'sphere' and 'disk' are on the path "
                                      "(SURVEY.md section 8 row f4)")
         vi = ps.findInt("indices")            # triangle_mesh.dart:91-193
         P = ps.findPoint("P")

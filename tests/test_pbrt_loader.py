@@ -325,3 +325,17 @@ def test_bundled_reference_scenes(ob):
     nodes = ob.OracleScene(api.scenePrimitives, points=api.pointLights()).bvh()[0]
     for k in ("bmin", "bmax", "offset", "nprims", "axis"):
         assert np.array_equal(nodes[k], acc.nodes[k]), k
+
+
+def test_heightfield_refines_into_one_uv_mapped_triangle_mesh():
+    """Shape "heightfield" (heightfield.dart:30-70): nu x nv vertices at (x / (nu-1), y / (nv-1), Pz) with those uvs,
+    two triangles per cell in the reference's winding; it is a TriangleMesh from there on."""
+    api = pbrt.loads(HEADER + 'WorldBegin\nTranslate 1 2 3\nShape "heightfield" "integer nu" [3] "integer nv" [2] '
+                              '"float Pz" [0 0.5 1  1 1.5 2]\nWorldEnd')
+    m = api.scenePrimitives[0].shape
+    assert isinstance(m, core.TriangleMesh) and len(m.P) == 6
+    assert m.P[4].tolist() == [1.5, 3.0, 4.5] and np.allclose(np.asarray(m.uvs).reshape(-1, 2)[4], [0.5, 1.0])
+    tri = np.asarray(m.vertexIndex if hasattr(m, "vertexIndex") else m.idx).reshape(-1, 3)
+    assert tri.tolist() == [[0, 1, 4], [0, 4, 3], [1, 2, 5], [1, 5, 4]]
+    with pytest.raises(ValueError):
+        pbrt.loads(HEADER + 'WorldBegin\nShape "heightfield" "integer nu" [3] "integer nv" [2] "float Pz" [0 1 2]\nWorldEnd')
