@@ -1,37 +1,108 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on its named config.
+"""bench.py -- BASELINE.json's metric on its named configs.
 
     python bench.py --gpus N --steps K --warmup W
 
 metric  : Msamples/s (primary + path rays), film pixels x spp per second, whole job over N GPUs
-workload: configs[1] -- Cornell box + 1M-triangle displaced blob, PathIntegrator maxdepth 5,
-          1024x1024, 256 spp (2.68e8 camera samples per GPU and step).  One "step" = one full pass
-          of the hot path over that batch.  At N > 1 the image's 32x32 tiles are dealt round-robin over
-          the ranks (north_star; the reference's task split, render_manager.dart:100-141), every rank
-          accumulates a full-frame (X, Y, Z, weight) film and ONE RCCL reduce per step sums them on rank 0.
-          --scaling weak (default): the image has N times the pixels (side 1024 * sqrt(N), same scene and
-          camera, towards configs[2]'s 4096x4096), so every GPU keeps 2.68e8 samples per step;
-          --scaling strong: the 1024x1024 image itself is split, each GPU's launches shrink with N;
-          --scaling samples: no tiles -- every rank adds its own 256 spp (seed + rank) to the same image.
-Inputs (scene, BVH) are resident in HBM before the timed region; samples are generated on the
-device.  Synthetic procedural scene, no files.  Before the W warm-up steps one priming render allocates the
-path-state workspace and lets the library pick its traversal kernel for the scene (set-up, like the BVH build).
+workload: N = 1 -- configs[1] (C2): Cornell box + 1M-triangle displaced blob, PathIntegrator maxdepth 5,
+          1024x1024, 256 spp (2.68e8 camera samples per step).
+          N > 1 -- configs[2] (C3) verbatim: the same scene at 4096x4096, 1024 spp (1.72e10 samples per step), the
+          image's 32x32 tiles dealt round-robin over the ranks (north_star; the reference's task split,
+          render_manager.dart:100-141), every rank accumulating a full-frame (X, Y, Z, weight) film and ONE RCCL
+          reduce per step (dr_film_reduce of the C ABI: ncclReduce over xGMI) summing them on rank 0.  Total work is
+          fixed for every N > 1 ("scaling": "strong").  Options: --scaling weak (the C2 image with N x the pixels,
+          per-GPU work fixed), --scaling strong-c2 (the 1024x1024 image itself split), --scaling samples (no tiles:
+          every rank adds its own 256 spp of the C2 image, seed + rank).
+          One "step" = one full pass of the hot path over the image.  Launch: `python bench.py --gpus N` starts
+          the N ranks itself (torch.distributed.run, one process per GPU) unless it already runs under torchrun.
+Inputs (scene, BVH) are resident in HBM before the timed region; samples are generated on the device.  Synthetic
+procedural scene, no files.  The FIRST render of a scene allocates the path-state workspace and runs the library's
+traversal-kernel pilot: it is timed separately ("first_render_ms", "pilot_ms") and is not one of the W + K steps.
 
-Extra objects on the JSON line: "roofline" for the dominant kernel k_trace<0> (closest-hit BVH
-traversal): algorithmic bytes (32 B per node visit + 48 B per triangle test, counted on the
-device) / the kernel's summed HIP-event time; "cpu_baseline": the CPU oracle (a C++ port of the
-reference path) timed on one host core on a strided pixel subset of the same image; "cpu_baseline_threads": the
-same oracle on up to 64 host threads (one serial loop per thread).
+Extra objects on the JSON line: "roofline" for the dominant kernel k_trace<0> (closest-hit BVH traversal):
+algorithmic bytes (32 B per node visit + 48 B per triangle test, counted on the device) / the kernel's summed
+HIP-event time, against the 8 TB/s spec ("frac") and against this run's measured float4-copy rate
+("frac_of_measured"); "roofline_shade" likewise for k_shade_path; "cpu_baseline": the CPU oracle (a C++ port of
+the reference path) on one host core on a strided pixel subset; "cpu_baseline_threads": the same oracle, one OS thread
+per GetSubWindow task rectangle (the reference's isolate-per-task model); "extra_configs": short C4 and C5 runs
+(2 steps each, N = 1 only, after the headline's timed region) with their own roofline objects.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+NAMES = {"C2": "Cornell box + 1M-triangle displaced blob", "C3": "Cornell box + 1M-triangle displaced blob",
+         "C4": "Cornell box + 10M-triangle hairball", "C5": "8M-triangle courtyard, 8 area lights + env map"}
+PEAK_GBPS = 8000.0  # HBM3E spec (MI355X_MICROARCH.md chip table)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child job (before anything touches the GPU)
+    and exit with its code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def shade_alg_bytes(st):
+    """Algorithmic bytes of the shading stages: what one vertex step of PathIntegrator.Li
+    must read and write of the per-sample path state and the scene, from the device's own counts."""
+    items, verts = st["shade_items"], st["shade_vertices"]
+    later = max(0, items - st["camera_samples"])  # entries of stages > 0: they carry a pending light estimate
+    return (items * 40.0            # active entry, flags, hprim, L in; L, flags out
+            + later * (28.0 + 4.0)  # shOcc, Ld1, betaNee in; the active-list entry that brought it here
+            + st["shade_mis"] * (32.0 + 48.0 + 32.0)   # MIS resolve: misPrim, misLight, Ld2, misD + the hit's record; set-up writes
+            + verts * 129.0         # ht, ro, rd, beta, 48-B primitive record, sample indices in; ro, rtmin, betaNee out
+            + st["shade_cont"] * 28.0 + st["shade_shadow"] * 36.0)  # rd, beta | shD, shTmax, Ld1 + queue entries
+
+
+def roofline_objects(st, dt_total, copy_gbps):
+    alg = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
+    launches = max(1, st["closest_launches"])
+    achieved = alg / max(st["closest_ms"] * 1e-3, 1e-12) / 1e9
+    all_alg = alg + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
+    roof = {"bound": "hbm", "kernel": "k_trace<0> (closest-hit BVH traversal)",
+            "achieved": round(achieved, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_GBPS, 4),
+            "traffic": None,  # HBM-side bytes come from separate rocprofv3 --pmc passes: see "traffic_profiled"
+            "hbm_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
+            "frac_of_measured": round(achieved / copy_gbps, 4) if copy_gbps else None,
+            "alg_bytes_per_launch": round(alg / launches, 1),
+            "avg_launch_ms": round(st["closest_ms"] / launches, 4), "launches": int(st["closest_launches"]),
+            "rank0_job_alg_GBps": round(all_alg / dt_total / 1e9, 2),
+            "rank0_trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt_total, 4)}
+    sb = shade_alg_bytes(st)
+    sa = sb / max(st["shade_ms"] * 1e-3, 1e-12) / 1e9
+    shade = {"bound": "hbm", "kernel": "k_shade_path (vertex step of PathIntegrator.Li)", "achieved": round(sa, 2),
+             "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(sa / PEAK_GBPS, 4), "traffic": None,
+             "frac_of_measured": round(sa / copy_gbps, 4) if copy_gbps else None,
+             "alg_bytes_per_item": round(sb / max(1, st["shade_items"]), 1),
+             "items": int(st["shade_items"]), "vertices": int(st["shade_vertices"])}
+    return roof, shade, all_alg
+
+
+def profiled_traffic(tag):
+    """HBM-side bytes per launch from committed rocprofv3 --pmc passes of the same command, labelled with the file
+    they come from (never presented as this run's measurement)."""
+    for name in ("r02_%s_traffic.json" % tag.lower(), "r01_k_traffic.json" if tag == "C2" else None):
+        if not name:
+            continue
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "source": "profiles/" + name,
+                    "note": "separate rocprofv3 --pmc passes (TCC_EA0_RDREQ 32/64/128 B + WRITE_SIZE), not this run"}
+    return None
 
 
 def main():
@@ -39,134 +110,179 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C2", choices=["C2", "C4", "C5"])
+    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short C4 / C5 runs appended at N = 1")
     ap.add_argument("--pipelines", type=int, default=1, choices=[1, 2],
                     help="2: odd batches run on a second stream / workspace (kernel tails and memory-bound shading overlap "
-                         "the ALU-bound traversal: +10 %% on C2) -- per-kernel event times then overlap, so the roofline "
+                         "the ALU-bound traversal) -- per-kernel event times then overlap, so the roofline "
                          "object is only meaningful with 1")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "samples"],
-                    help="N > 1: weak = tiles of an image with N x the pixels (per-GPU work fixed); strong = tiles of the same "
-                         "image; samples = every rank renders spp samples of the whole image with its own seed, films summed")
+    ap.add_argument("--scaling", default=None, choices=["c3", "weak", "strong-c2", "samples"],
+                    help="N > 1: c3 (default) = configs[2] verbatim, tiles of the 4096^2 x 1024 spp image; weak = tiles of the C2 "
+                         "image with N x the pixels; strong-c2 = tiles of the 1024^2 image; samples = every rank renders "
+                         "256 spp of the whole C2 image with its own seed, films summed")
     ap.add_argument("--cpu-pixels", type=int, default=96, help="cpu baseline: side of the strided pixel grid")
     args = ap.parse_args()
 
+    world_env = int(os.environ.get("WORLD_SIZE", "0"))
+    if args.gpus > 1 and world_env == 0:
+        launch_ranks(args)
+    if world_env not in (0, args.gpus) or (world_env == 0 and args.gpus != 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s: launch one rank per GPU" % (args.gpus, os.environ.get("WORLD_SIZE")))
+
     os.environ["DARTRAY_PIPELINES"] = str(args.pipelines)  # read once by the library
-    import numpy as np
     import torch
     from dartray_amd import _abi, scenes, dist as drdist
 
-    rank, world, local = drdist.init_process_group()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    _abi.init(local)
-
-    spp = args.spp or {"C2": 256, "C4": 64, "C5": 512}[args.config]
-    args.res = args.res or {"C2": 1024, "C4": 1024, "C5": 2048}[args.config]
-    if args.scaling == "weak" and world > 1:
-        args.res = int(round(args.res * world ** 0.5 / 32.0)) * 32  # N x the pixels, whole tiles
-    prims, mk = scenes.config(args.config, xres=args.res, yres=args.res, spp=spp)
-    renderer = mk()
-    if args.scaling == "samples":
-        renderer = drdist.sample_set(renderer, rank)  # independent sample sets of the same image
-    else:
-        renderer = drdist.shard(renderer, rank, world)  # round-robin 32 x 32 tiles
-    scene = scenes.make_scene(prims, renderer.env)  # every rank builds + uploads its own copy (render_isolate.dart:31-41)
-    film_desc = renderer.camera.film
-    H, W = film_desc.height, film_desc.width
-    film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    dev = scene._device()
+    rank, world, local = drdist.init_process_group()  # gloo control plane + dr_comm_init (RCCL) on every rank
     lib = _abi.lib()
 
-    def step():
-        film.zero_()
-        renderer.render_device(scene, film.data_ptr(), stream)
-        drdist.reduce_film(film, 0)
-        if rank == 0:
-            _abi.check(lib.dr_film_resolve_device(film.data_ptr(), H * W, rgb.data_ptr(), stream))
-
-    # Set-up, not a step: the first render of a scene allocates the path-state workspace (56 GB for C2) and runs the
-    # traversal-kernel pilot (DESIGN.md section 5 row j) -- like the BVH build and the scene upload, outside the W + K steps.
-    step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    dev.reset_stats()
-    drdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    drdist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    st = dev.stats()
+    mode = args.scaling or "c3"
+    cfg = args.config or ("C2" if world == 1 or mode != "c3" else "C3")
+    spp = args.spp or {"C2": 256, "C3": 1024, "C4": 64, "C5": 512}[cfg]
+    res = args.res or {"C2": 1024, "C3": 4096, "C4": 1024, "C5": 2048}[cfg]
+    if mode == "weak" and world > 1:
+        res = int(round(res * world ** 0.5 / 32.0)) * 32  # N x the pixels, whole tiles
+    run = Run(cfg, res, spp, rank, world, mode, args)
+    out = run.headline(args.steps, args.warmup)
 
     if rank == 0:
-        samples_per_step = H * W * spp * (world if args.scaling == "samples" else 1)
-        value = samples_per_step * args.steps / dt / 1e6
-        alg_bytes = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
-        launches = max(1, st["closest_launches"])
-        achieved = alg_bytes / max(st["closest_ms"] * 1e-3, 1e-12) / 1e9
-        peak = 8000.0  # HBM3E spec GB/s (MI355X_MICROARCH.md chip table)
-        all_alg = alg_bytes + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_k_traffic.json")
-        if (args.config == "C2" and args.res == 1024 and spp == 256 and world == 1 and args.pipelines == 1
-                and not os.environ.get("DARTRAY_BATCH_BITS") and os.path.exists(tpath)):
-            # HBM-side bytes per launch of k_trace<0> from the PMC passes of this same command (see the file)
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(run.prims, run.renderer, args.cpu_pixels, run.H, run.W, spp)
+            out["cpu_baseline_threads"] = cpu_baseline_threads(run.prims, run.renderer, run.H, run.W, spp)
+        if world == 1 and not args.no_extra and cfg == "C2" and not args.res and not args.spp:
+            del run
+            torch.cuda.empty_cache()
+            extra = []
+            for c in ("C4", "C5"):
+                r = Run(c, {"C4": 1024, "C5": 2048}[c], {"C4": 64, "C5": 512}[c], 0, 1, mode, args)
+                e = r.headline(2, 1)
+                extra.append({k: e[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
+                                                "roofline_shade", "kernel_ms_per_step", "per_sample", "first_render_ms",
+                                                "pilot_ms", "traffic_profiled") if k in e})
+                del r
+                torch.cuda.empty_cache()
+            out["extra_configs"] = extra
+        print(json.dumps(out))
+    drdist.barrier()
+    drdist.comm_destroy()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+class Run:
+    """One configuration resident on this rank's GPU: scene, renderer, device film."""
+
+    def __init__(self, cfg, res, spp, rank, world, mode, args):
+        import torch
+        from dartray_amd import _abi, scenes, dist as drdist
+        self.cfg, self.res, self.spp, self.rank, self.world, self.mode, self.args = cfg, res, spp, rank, world, mode, args
+        self.prims, mk = scenes.config("C2" if cfg == "C3" else cfg, xres=res, yres=res, spp=spp)
+        r = mk()
+        if mode == "samples" and world > 1:
+            r = drdist.sample_set(r, rank)  # independent sample sets of the same image
+        else:
+            r = drdist.shard(r, rank, world)  # round-robin 32 x 32 tiles
+        self.renderer = r
+        self.scene = scenes.make_scene(self.prims, r.env)  # every rank builds + uploads its own copy (render_isolate.dart:31-41)
+        fd = r.camera.film
+        self.H, self.W = fd.height, fd.width
+        self.film = torch.zeros((self.H, self.W, 4), dtype=torch.float32, device="cuda")
+        self.rgb = torch.zeros((self.H, self.W, 3), dtype=torch.float32, device="cuda")
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.dev = self.scene._device()
+        self.lib = _abi.lib()
+
+    def step(self):
+        from dartray_amd import _abi, dist as drdist
+        self.film.zero_()
+        self.renderer.render_device(self.scene, self.film.data_ptr(), self.stream)
+        drdist.reduce_film(self.film, 0, self.stream)
+        if self.rank == 0:
+            _abi.check(self.lib.dr_film_resolve_device(self.film.data_ptr(), self.H * self.W, self.rgb.data_ptr(), self.stream))
+
+    def headline(self, steps, warmup):
+        import ctypes as C
+        import torch
+        from dartray_amd import _abi, dist as drdist
+        args, world, rank = self.args, self.world, self.rank
+        # The first render of a scene: workspace allocation + the traversal-kernel pilot (DESIGN.md section 5) -- what a
+        # one-shot render pays on top of a steady-state step; timed on its own, not one of the W + K steps.
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.step()
+        torch.cuda.synchronize()
+        first_ms = (time.perf_counter() - t0) * 1e3
+        pilot_ms = self.dev.stats()["pilot_ms"]
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        self.dev.reset_stats()
+        drdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        drdist.barrier()
+        torch.cuda.synchronize()
+        dt = drdist.max_over_ranks(time.perf_counter() - t0)
+        st = self.dev.stats()
+        if rank != 0:
+            return None
+        copy = C.c_double(0.0)
+        _abi.check(self.lib.dr_copy_bandwidth(1 << 30, 10, C.byref(copy)))  # measured HBM denominator (float4 copy, 2 GiB moved per pass)
+        samples_per_step = self.H * self.W * self.spp * (world if (self.mode == "samples" and world > 1) else 1)
+        value = samples_per_step * steps / dt / 1e6
+        roof, shade, all_alg = roofline_objects(st, dt, copy.value)
+        agg = self.scene.aggregate
+        if world == 1:
+            par = "1 GPU"
+        elif self.mode == "samples":
+            par = "spp-sets x%d, RCCL film reduce (world %d)" % (world, self.lib.dr_comm_world())
+        else:
+            par = "tiles32 x%d, RCCL film reduce (world %d)" % (world, self.lib.dr_comm_world())
         out = {
             "metric": "Msamples/sec (primary+path rays)",
             "value": round(value, 3),
             "unit": "Msamples/s",
-            "n_gpus": args.gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "strong" if args.scaling == "strong" else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "%s: %s, PathIntegrator maxdepth=%d, %dx%d, %d spp, LD sampler (device, counter streams), box filter"
-                       % (args.config, {"C2": "Cornell box + 1M-triangle displaced blob", "C4": "Cornell box + 10M-triangle hairball",
-                                        "C5": "8M-triangle courtyard, 8 area lights + env map"}[args.config],
-                          renderer.surfaceIntegrator.maxDepth, args.res, args.res, spp),
-                       "triangles": int(len(scene.aggregate.tri_idx)), "bvh_nodes": int(len(scene.aggregate.nodes)),
-                       "samples_per_step": samples_per_step, "parallelism": ("spp-sets x%d, film reduce" if args.scaling == "samples" else "tiles32 x%d, film reduce") % world, "pipelines": args.pipelines},
-            "roofline": {"bound": "hbm", "kernel": "k_trace<0> (closest-hit BVH traversal)",
-                         "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
-                         "traffic": traffic,
-                         "alg_bytes_per_launch": round(alg_bytes / launches, 1),
-                         "avg_launch_ms": round(st["closest_ms"] / launches, 4), "launches": int(st["closest_launches"]),
-                         "rank0_job_alg_GBps": round(all_alg / dt / 1e9, 2),
-                         "rank0_trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt, 4)},
-            "kernel_ms_per_step": {k: round(st[k] / args.steps, 2) for k in ("closest_ms", "any_ms", "shade_ms", "gen_ms", "film_ms", "total_ms")},
+                       % (self.cfg, NAMES[self.cfg], self.renderer.surfaceIntegrator.maxDepth, self.res, self.res, self.spp),
+                       "triangles": int(len(agg.tri_idx)), "bvh_nodes": int(len(agg.nodes)),
+                       "samples_per_step": samples_per_step, "parallelism": par, "pipelines": args.pipelines,
+                       "sampler_mode": "DR_SAMPLER_COUNTER (keyed per-pixel streams, bit-exact vs the oracle's same mode); the reference's "
+                                       "single serial Random(taskNum) stream is replayed bit-exactly through DR_SAMPLER_HOST_BUFFER in the "
+                                       "tests but is not a throughput mode (one serial stream; 148 B + RNG tail per sample over PCIe)"},
+            "roofline": roof,
+            "roofline_shade": shade,
+            "kernel_ms_per_step": {k: round(st[k] / steps, 2) for k in ("closest_ms", "any_ms", "shade_ms", "gen_ms", "film_ms", "total_ms")},
             "per_sample": {"rays": round((st["closest_rays"] + st["any_rays"]) / max(1, st["camera_samples"]), 3),
                            "nodes": round((st["closest_nodes"] + st["any_nodes"]) / max(1, st["camera_samples"]), 2),
                            "tris": round((st["closest_tris"] + st["any_tris"]) / max(1, st["camera_samples"]), 3),
                            "alg_bytes": round(all_alg / max(1, st["camera_samples"]) + 148 + 32, 1)},
+            "first_render_ms": round(first_ms, 1),
+            "pilot_ms": round(pilot_ms, 1),
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(prims, renderer, args.cpu_pixels, H, W, spp)
-            out["cpu_baseline_threads"] = cpu_baseline_threads(prims, renderer, 2 * args.cpu_pixels, H, W, spp)
-        print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+        if world > 1:
+            out["scaling"] = {"c3": "strong", "strong-c2": "strong", "weak": "weak", "samples": "weak"}[self.mode]
+        tp = profiled_traffic(self.cfg)
+        if tp and world == 1 and args.pipelines == 1 and not os.environ.get("DARTRAY_BATCH_BITS"):
+            out["traffic_profiled"] = tp
+        return out
 
 
 def cpu_baseline(prims, renderer, grid, H, W, spp):
@@ -190,19 +306,29 @@ def cpu_baseline(prims, renderer, grid, H, W, spp):
             "host_cores": os.cpu_count()}
 
 
-def cpu_baseline_threads(prims, renderer, grid, H, W, spp):
-    """the same oracle on min(host cores, 64) OS threads, each running the unmodified serial
-    loop on its own rows of a strided grid x grid pixel subset -- the reference's one-isolate-per-task model
-    (dartray_web/render_manager.dart:100-141) with a shared read-only scene.  ctypes releases the GIL inside the call."""
+def cpu_baseline_threads(prims, renderer, H, W, spp, budget_samples=3.0e7):
+    """the reference's multi-worker model -- one isolate per task, task t tracing its
+    GetSubWindow rectangle (lib/core/common.dart:52-73, dartray_web/render_manager.dart:100-141) -- as one OS thread
+    per task running the unmodified serial oracle loop over a shared read-only scene, task count = host cores.  Bounded:
+    every task traces a strided subset of ITS rectangle (the same stride for all, so the load imbalance between
+    rectangles is kept).  ctypes releases the GIL inside the call."""
+    import copy
     import threading
     import numpy as np
     import oracle.binding as ob
     osc = ob.OracleScene(prims)
-    nthreads = max(1, min(os.cpu_count() or 1, 64))
-    ys = (np.arange(grid) * (H // grid) + (H // grid) // 2).astype(np.int32)
-    xs = (np.arange(grid) * (W // grid) + (W // grid) // 2).astype(np.int32)
-    px = np.stack(np.meshgrid(xs, ys), axis=-1).reshape(-1, 2)
-    parts = [p for p in np.array_split(px, nthreads) if len(p)]
+    ntasks = max(1, os.cpu_count() or 1)
+    stride = 1
+    while (H // stride) * (W // stride) * spp > budget_samples:
+        stride += 1
+    parts = []
+    for t in range(ntasks):
+        r = copy.copy(renderer)
+        r.taskNum, r.taskCount, r.tileRank, r.tileCount = t, ntasks, 0, 1
+        px = r.pixels()  # this task's GetSubWindow rectangle (dr_enumerate_pixels, host-only)
+        px = px[(px[:, 0] % stride == stride // 2) & (px[:, 1] % stride == stride // 2) & (px[:, 0] < W) & (px[:, 1] < H)]
+        if len(px):
+            parts.append(px)
     descs = [ob.render_desc(renderer, sampler_mode=1, pixels=p) for p in parts]
     # a first threaded pass on one pixel per thread pays the process's one-off costs (thread stacks, malloc arenas, TLS)
     warm = [threading.Thread(target=osc.render, args=(ob.render_desc(renderer, sampler_mode=1, pixels=p[:1]),),
@@ -218,11 +344,11 @@ def cpu_baseline_threads(prims, renderer, grid, H, W, spp):
     for t in threads:
         t.join()
     dt = time.perf_counter() - t0
-    n = len(px) * spp
+    n = sum(len(p) for p in parts) * spp
     return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": len(parts), "kind": "port",
-            "sample": "%dx%d pixels on a strided grid of the %dx%d image x %d spp = %d samples in %.1f s on %d threads; "
-                      "C++ restatement of the Dart reference path (oracle/), one serial loop per thread over a shared scene"
-                      % (grid, grid, W, H, spp, n, dt, len(parts)),
+            "sample": "%d GetSubWindow task rectangles of the %dx%d image (one OS thread each), every %d-th pixel per axis x %d spp = %d "
+                      "samples in %.1f s; C++ restatement of the Dart reference path (oracle/), shared read-only scene"
+                      % (len(parts), W, H, stride, spp, n, dt),
             "host_cores": os.cpu_count()}
 
 

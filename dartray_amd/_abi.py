@@ -121,7 +121,12 @@ class DrRenderStats(C.Structure):
                 ("batches", C.c_uint64),
                 ("closest_launches", C.c_uint64), ("any_launches", C.c_uint64),
                 ("closest_ms", C.c_double), ("any_ms", C.c_double),
-                ("shade_ms", C.c_double), ("gen_ms", C.c_double), ("film_ms", C.c_double)]
+                ("shade_ms", C.c_double), ("gen_ms", C.c_double), ("film_ms", C.c_double),
+                ("shade_items", C.c_uint64), ("shade_vertices", C.c_uint64), ("shade_cont", C.c_uint64),
+                ("shade_mis", C.c_uint64), ("shade_shadow", C.c_uint64), ("pilot_ms", C.c_double)]
+
+
+DR_COMM_ID_BYTES = 128
 
 
 # name -> (restype, argtypes): every symbol include/dartray_hip.h declares.
@@ -133,6 +138,8 @@ EXPORTS = {
                                      C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint32)]),
     "dr_scene_create": (C.c_int, [C.POINTER(DrSceneDesc), C.POINTER(C.c_void_p)]),
     "dr_scene_destroy": (None, [C.c_void_p]),
+    "dr_scene_get_trace_kernels": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32 * 2)]),
+    "dr_scene_set_trace_kernels": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32 * 2)]),
     "dr_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "dr_sample_floats": (C.c_int32, [C.c_int32, C.c_uint32]),
     "dr_scene_sample_floats": (C.c_int32, [C.c_void_p, C.c_int32]),
@@ -143,6 +150,13 @@ EXPORTS = {
     "dr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(DrRenderStats)]),
     "dr_reset_stats": (C.c_int, [C.c_void_p]),
     "dr_copy_bandwidth": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
+    "dr_comm_unique_id": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "dr_comm_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_uint64]),
+    "dr_film_reduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dr_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dr_comm_rank": (C.c_int, []),
+    "dr_comm_world": (C.c_int, []),
+    "dr_comm_destroy": (C.c_int, []),
     "dr_last_error": (C.c_char_p, []),
     "dr_version": (C.c_char_p, []),
 }
@@ -181,6 +195,26 @@ def _share_hip_runtime_with_torch():
             pass
 
 
+def _check_build_info():
+    """The shipped .so must be the one built from the sources next to it: __graft_entry__.build() records the sha256
+    of every source and header in libdartray_hip.buildinfo.json; a mismatch (a stale library) fails loudly."""
+    if os.environ.get("DARTRAY_LIB"):
+        return  # an explicitly chosen A/B build
+    import hashlib
+    import json
+    info_path = os.path.join(_HERE, "libdartray_hip.buildinfo.json")
+    csrc = os.path.join(_HERE, "csrc")
+    if not os.path.isdir(csrc):
+        return  # a binary-only deployment
+    if not os.path.exists(info_path):
+        raise DartRayHipError("libdartray_hip.buildinfo.json missing: rebuild with __graft_entry__.build()")
+    want = json.load(open(info_path)).get("sources", {})
+    for rel, digest in want.items():
+        path = os.path.join(csrc, rel)
+        if not os.path.exists(path) or hashlib.sha256(open(path, "rb").read()).hexdigest() != digest:
+            raise DartRayHipError("libdartray_hip.so is stale: %s changed since it was built (run __graft_entry__.build())" % rel)
+
+
 def lib():
     """Load libdartray_hip.so (built in-tree by __graft_entry__.build())."""
     global _lib
@@ -188,6 +222,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise DartRayHipError(
                 "HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+        _check_build_info()
         _share_hip_runtime_with_torch()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():

@@ -398,6 +398,7 @@ class BVHAccel:
         self.tri_shading = np.ascontiguousarray(shade[order])
         self.tri_xform = np.ascontiguousarray(xform[order])
         self._scene = None
+        self._scene_key = None
 
     @staticmethod
     def Create(prims, ps=None):  # bvh_accel.dart:474-482
@@ -422,8 +423,13 @@ class BVHAccel:
 
     # --- device scene (created lazily, shared with Scene) ---
     def _device_scene(self, lights=None):
-        if self._scene is None:
-            self._scene = _DeviceScene(self, self._lights if lights is None else lights)
+        """The uploaded DrScene of this aggregate + light list.  One aggregate can serve several Scenes whose light
+        lists differ (e.g. with and without an InfiniteAreaLight): the cache is keyed on the list's identity."""
+        want = self._lights if lights is None else lights
+        key = tuple(id(l) for l in want)
+        if self._scene is None or self._scene_key != key:
+            self._scene = _DeviceScene(self, want)
+            self._scene_key = key
         return self._scene
 
     def intersect(self, ray):
@@ -594,6 +600,15 @@ class _DeviceScene:
 
     def reset_stats(self):
         _abi.check(_abi.lib().dr_reset_stats(self.handle))
+
+    def trace_kernels(self, kernels=None):
+        """Get (closest, any-hit) traversal kernels of this scene (0 = not measured yet), or set them (2 / 3; (0, 0)
+        makes the next big render measure again)."""
+        arr = (C.c_uint32 * 2)(*(kernels or (0, 0)))
+        if kernels is not None:
+            _abi.check(_abi.lib().dr_scene_set_trace_kernels(self.handle, C.byref(arr)))
+        _abi.check(_abi.lib().dr_scene_get_trace_kernels(self.handle, C.byref(arr)))
+        return int(arr[0]), int(arr[1])
 
 
 class Scene:

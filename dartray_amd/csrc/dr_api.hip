@@ -72,6 +72,8 @@ struct Workspace {
 
 }  // namespace
 
+int dr_fail(int code, const std::string& msg) { return fail(code, msg); }  // for dr_comm.cpp
+
 struct DrScene {
   DScene d;
   DevBuf<uint4> nodes, pairs;
@@ -111,6 +113,29 @@ struct DrScene {
   size_t eventsUsed = 0;
   bool statsPending = false;
   hipEvent_t lastEvent = nullptr;
+  // Timings of finished launches are folded into `stats` and their events recycled, so a long-lived scene (a frame
+  // loop calling dr_render_device) does not grow the pool or the lists without bound.
+  void foldEvents() {
+    for (auto& ev : traceEvents) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ev.e0, ev.e1) != hipSuccess) continue;
+      if (ev.any == 1) { stats.any_ms += t; stats.any_launches++; }
+      else if (ev.any == 0) { stats.closest_ms += t; stats.closest_launches++; }
+      else if (ev.any == 2) stats.shade_ms += t;
+      else if (ev.any == 3) stats.gen_ms += t;
+      else if (ev.any == 5) stats.pilot_ms += t;
+      else stats.film_ms += t;
+    }
+    for (auto& ev : renderEvents) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) stats.total_ms += t;
+    }
+    stats.trace_ms = stats.closest_ms + stats.any_ms;
+    stats.trace_launches = stats.closest_launches + stats.any_launches;
+    traceEvents.clear();
+    renderEvents.clear();
+    eventsUsed = 0;
+  }
   hipEvent_t getEvent() {
     if (eventsUsed == eventPool.size()) {
       hipEvent_t e;
@@ -375,7 +400,37 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     if (desc->materials[i].type < DR_MATERIAL_MATTE || desc->materials[i].type > DR_MATERIAL_PLASTIC)
       return fail(DR_ERR_INVALID, "unknown material type");
   }
+  // Validation of the marshalled tree, independent of which kernels can use it: a foreign host's BVHAccel.nodes are
+  // input, and a malformed node must come back as DR_ERR_INVALID, not as an out-of-bounds device read or an endless
+  // traversal.  Children always have larger indices than their parent (first child i + 1, second child offset > i + 1:
+  // the depth-first numbering of bvh_accel.dart:419-437), so every walk terminates, and one forward pass gives each
+  // node's level: the height of the tree bounds the traversal stack (desc->bvh_depth == 0, "unknown", is measured here).
+  uint32_t measuredDepth = 0;
+  if (desc->nnodes) {
+    const DrBvhNode* N = desc->nodes;
+    std::vector<uint8_t> level(desc->nnodes, 0);
+    for (uint64_t i = 0; i < desc->nnodes; ++i) {
+      if (N[i].nprims == 0) {
+        if (N[i].offset <= i + 1 || N[i].offset >= desc->nnodes || N[i].axis > 2)
+          return fail(DR_ERR_INVALID, "malformed BVH node (interior node: second child must follow the first sub-tree, axis 0..2)");
+        const uint32_t l = (uint32_t)level[i] + 1u;
+        if (l > DR_MAX_STACK) return fail(DR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+        level[i + 1] = std::max<uint8_t>(level[i + 1], (uint8_t)l);
+        level[N[i].offset] = std::max<uint8_t>(level[N[i].offset], (uint8_t)l);
+        measuredDepth = std::max(measuredDepth, l);
+      } else if ((uint64_t)N[i].offset + N[i].nprims > desc->ntris) {
+        return fail(DR_ERR_INVALID, "leaf primitive range");
+      }
+    }
+  }
   if (desc->bvh_depth > DR_MAX_STACK) return fail(DR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+  if (desc->bvh_depth != 0 && desc->bvh_depth < measuredDepth)
+    return fail(DR_ERR_INVALID, "bvh_depth is smaller than the tree's height (pass 0 to have it measured)");
+  for (uint64_t i = 0; i < 3 * desc->ntris; i += 3) {
+    if (desc->tri_idx[i] == DR_PRIM_QUADRIC) continue;
+    for (int k = 0; k < 3; ++k)
+      if (desc->tri_idx[i + k] >= desc->nverts) return fail(DR_ERR_INVALID, "vertex index out of range");
+  }
   DrScene* sc = new DrScene();
   memset(&sc->stats, 0, sizeof(sc->stats));
   auto bail = [&](int code, const std::string& m) {
@@ -423,7 +478,8 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     sc->hostQuads.push_back(q);
   }
 
-  sc->bvhDepth = desc->bvh_depth;
+  sc->bvhDepth = std::max(desc->bvh_depth, measuredDepth);  // (a caller may pass a bound larger than the height)
+  if (desc->nnodes && sc->bvhDepth == 0) sc->bvhDepth = 1;  // a single leaf: "known, no stack needed"
   // nodes: the 32-byte marshalled node is consumed as two 16-byte loads
   TRY_SC(sc->nodes.alloc(2 * desc->nnodes));
   if (desc->nnodes) TRY_SC(hipMemcpy(sc->nodes.p, desc->nodes, desc->nnodes * sizeof(DrBvhNode), hipMemcpyHostToDevice));
@@ -809,8 +865,8 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     TRY_SC(sc->lcdf.alloc(cdf.size()));
     TRY_SC(hipMemcpy(sc->lcdf.p, cdf.data(), cdf.size() * sizeof(float), hipMemcpyHostToDevice));
   }
-  TRY_SC(sc->ctr.alloc(1));
-  TRY_SC(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
+  TRY_SC(sc->ctr.alloc(2));  // [0] live, [1] snapshot taken around the traversal pilot
+  TRY_SC(hipMemset(sc->ctr.p, 0, 2 * sizeof(TraceCounters)));
   TRY_SC(sc->quads.alloc(std::max<size_t>(sc->hostQuads.size(), 1)));
   if (!sc->hostQuads.empty())
     TRY_SC(hipMemcpy(sc->quads.p, sc->hostQuads.data(), sc->hostQuads.size() * sizeof(DQuadric), hipMemcpyHostToDevice));
@@ -886,6 +942,30 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
 }
 
 void dr_scene_destroy(DrScene* scene) { delete scene; }
+
+int dr_scene_get_trace_kernels(const DrScene* sc, uint32_t out[2]) {
+  if (!sc || !out) return fail(DR_ERR_INVALID, "null argument");
+  out[0] = sc->traceCalibrated ? sc->d.traceKernel[0] : 0u;
+  out[1] = sc->traceCalibrated ? sc->d.traceKernel[1] : 0u;
+  return DR_OK;
+}
+
+int dr_scene_set_trace_kernels(DrScene* sc, const uint32_t in[2]) {
+  if (!sc || !in) return fail(DR_ERR_INVALID, "null argument");
+  if (in[0] == 0u && in[1] == 0u) {
+    sc->traceCalibrated = false;
+    sc->d.traceKernel[0] = sc->d.traceKernel[1] = 0u;
+    return DR_OK;
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (in[k] != 2u && in[k] != 3u) return fail(DR_ERR_INVALID, "trace kernel must be 2 or 3 (or 0, 0 to measure again)");
+    if (in[k] == 3u && (!sc->d.pairs || sc->d.nquads)) return fail(DR_ERR_UNSUPPORTED, "this scene cannot use the sibling-pair kernel");
+  }
+  sc->d.traceKernel[0] = in[0];
+  sc->d.traceKernel[1] = in[1];
+  sc->traceCalibrated = true;
+  return DR_OK;
+}
 
 int dr_intersect(DrScene* sc, const DrRay* rays, int64_t n, DrHit* out, int32_t any_hit) {
   if (!sc || (n > 0 && (!rays || !out))) return fail(DR_ERR_INVALID, "null argument");
@@ -984,6 +1064,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     return fail(DR_ERR_INVALID, "unknown sampler mode");
   }
   const size_t npixTotal = pixels.size();
+  // recycle the events of earlier renders once they have completed (or when too many are pending)
+  if (sc->lastEvent && !sc->traceEvents.empty()) {
+    hipError_t q = hipEventQuery(sc->lastEvent);
+    if (q != hipSuccess && sc->eventsUsed > 8192) q = hipEventSynchronize(sc->lastEvent);
+    if (q == hipSuccess) sc->foldEvents();
+    (void)hipGetLastError();  // hipErrorNotReady is not an error
+  }
   sc->statsPending = true;
   hipEvent_t evStart = sc->getEvent(), evStop = sc->getEvent();
   sc->renderEvents.push_back({evStart, evStop});
@@ -1112,6 +1199,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       q.nClosest = C + 4 * b + 1;
       q.anyQ = w.anyQ.p;
       q.nAny = C + 4 * b + 2;
+      q.ctr = sc->ctr.p;
       hipEvent_t evS = sc->getEvent();
       (void)hipEventRecord(evS, s);
       if (rd->integrator == DR_INTEGRATOR_PATH) launch_shade_path(sc->d, rp, st, q, b, sgrid, s);
@@ -1141,11 +1229,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // spread over the image) go through the stage loop once per kernel without touching the film, and each ray kind
   // keeps v3 only if it was 5 % faster.  Both kernels are bit-exact, so results do not depend on the choice;
   // DARTRAY_TRACE_IMPL fixes it.
+  static const bool pilotOff = getenv("DARTRAY_PILOT") && atoi(getenv("DARTRAY_PILOT")) == 0;
   const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || getenv("DARTRAY_PILOT_FORCE");
-  if (!sc->traceCalibrated && !hostBuf && !getenv("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads && bigJob && npixTotal >= 64) {
-    // pilot size: ~3 % of the render, between 2^22 and 2^25 camera samples (small launches are dominated by their
-    // ramp-up and tail and mispredict: C5 needs 2^24 before the order of the two kernels matches the full render)
-    uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 22, (uint64_t)npixTotal * spp / 32));
+  if (!sc->traceCalibrated && !pilotOff && !hostBuf && !getenv("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads && bigJob && npixTotal >= 64) {
+    // pilot size: ~1.5 % of the render, between 2^22 and 2^25 camera samples (small launches are dominated by their
+    // ramp-up and tail and mispredict), one warm-up pass and one timed pass per kernel: ~6 % of this first render
+    // (DrRenderStats.pilot_ms); DARTRAY_PILOT=0 skips it (the default kernel, v2, is then used)
+    uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 22, (uint64_t)npixTotal * spp / 64));
     if (getenv("DARTRAY_PILOT_BITS")) pilotSamples = 1ull << atoi(getenv("DARTRAY_PILOT_BITS"));
     pilotSamples = std::min<uint64_t>(pilotSamples, (uint64_t)(pixPerBatch / 64 * 64) * spp);
     const size_t groups = std::max<size_t>(1, (size_t)(pilotSamples / spp) / 64);
@@ -1157,11 +1247,15 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     }
     HIP_TRY(sc->pilotPix.alloc(pp.size()));
     HIP_TRY(hipMemcpy(sc->pilotPix.p, pp.data(), pp.size() * sizeof(int2), hipMemcpyHostToDevice));
+    // the Stats probes count renders, not the pilot: counters of earlier renders that have not been read yet survive it
+    HIP_TRY(hipMemcpyAsync(sc->ctr.p + 1, sc->ctr.p, sizeof(TraceCounters), hipMemcpyDeviceToDevice, s));
+    hipEvent_t evP0 = sc->getEvent(), evP1 = sc->getEvent();
+    HIP_TRY(hipEventRecord(evP0, s));
     const size_t evSaved = sc->eventsUsed;
     float ms[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     for (int impl = 2; impl <= 3; ++impl) {
       sc->d.traceKernel[0] = sc->d.traceKernel[1] = (uint32_t)impl;
-      for (int rep = 0; rep < 3; ++rep) {  // the first pass warms the caches; the faster of the other two counts
+      for (int rep = 0; rep < 2; ++rep) {  // the first pass warms the caches, the second one counts
         PilotTimes pt;
         int prc = runBatch(sc->ws, sc->pilotPix.p, 0, (uint32_t)pp.size(), &pt);
         if (prc) return prc;
@@ -1174,7 +1268,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
               (void)hipEventElapsedTime(&t, e.first, e.second);
               sum += t;
             }
-            ms[kind][impl - 2] = rep == 1 ? sum : std::min(ms[kind][impl - 2], sum);
+            ms[kind][impl - 2] = sum;
           }
         sc->eventsUsed = evSaved;
       }
@@ -1188,10 +1282,12 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // the closest-hit rays prefer v3 clearly, the any-hit rays take it as soon as it is not slower
     if (ms[0][1] < 0.85f * ms[0][0] && ms[1][1] <= ms[1][0]) sc->d.traceKernel[1] = 3u;
     sc->traceCalibrated = true;
-    HIP_TRY(hipMemsetAsync(sc->ctr.p, 0, sizeof(TraceCounters), s));  // the probes of bvh_accel.dart count the render only
+    HIP_TRY(hipMemcpyAsync(sc->ctr.p, sc->ctr.p + 1, sizeof(TraceCounters), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipEventRecord(evP1, s));
+    sc->traceEvents.push_back({evP0, evP1, 5});
     if (getenv("DARTRAY_VERBOSE"))
-      fprintf(stderr, "dartray_hip: traversal pilot, closest v2 %.2f ms / v3 %.2f ms -> v%u; any hit v2 %.2f / v3 %.2f -> v%u\n",
-              ms[0][0], ms[0][1], sc->d.traceKernel[0], ms[1][0], ms[1][1], sc->d.traceKernel[1]);
+      fprintf(stderr, "dartray_hip: traversal pilot (%zu samples), closest v2 %.2f ms / v3 %.2f ms -> v%u; any hit v2 %.2f / v3 %.2f -> v%u\n",
+              pp.size() * (size_t)spp, ms[0][0], ms[0][1], sc->d.traceKernel[0], ms[1][0], ms[1][1], sc->d.traceKernel[1]);
   }
 
   for (size_t p0 = 0; p0 < npixTotal; p0 += pixPerBatch, ++batchIndex) {
@@ -1240,28 +1336,9 @@ int dr_get_stats(DrScene* sc, DrRenderStats* out) {
     sc->stats.closest_rays = c.closest_rays; sc->stats.any_rays = c.any_rays;
     sc->stats.closest_nodes = c.closest_nodes; sc->stats.any_nodes = c.any_nodes;
     sc->stats.closest_tris = c.closest_tris; sc->stats.any_tris = c.any_tris;
-    double msC = 0.0, msA = 0.0, msS = 0.0, msG = 0.0, msF = 0.0;
-    uint64_t nC = 0, nA = 0;
-    for (auto& ev : sc->traceEvents) {
-      float t = 0.f;
-      if (hipEventElapsedTime(&t, ev.e0, ev.e1) != hipSuccess) continue;
-      if (ev.any == 1) { msA += t; ++nA; }
-      else if (ev.any == 0) { msC += t; ++nC; }
-      else if (ev.any == 2) msS += t;
-      else if (ev.any == 3) msG += t;
-      else msF += t;
-    }
-    sc->stats.shade_ms = msS; sc->stats.gen_ms = msG; sc->stats.film_ms = msF;
-    sc->stats.closest_ms = msC; sc->stats.any_ms = msA;
-    sc->stats.closest_launches = nC; sc->stats.any_launches = nA;
-    sc->stats.trace_ms = msC + msA;
-    sc->stats.trace_launches = nC + nA;
-    double tot = 0.0;
-    for (auto& ev : sc->renderEvents) {
-      float t = 0.f;
-      if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) tot += t;
-    }
-    sc->stats.total_ms = tot;
+    sc->stats.shade_items = c.shade_items; sc->stats.shade_vertices = c.shade_vertices;
+    sc->stats.shade_cont = c.shade_cont; sc->stats.shade_mis = c.shade_mis; sc->stats.shade_shadow = c.shade_shadow;
+    sc->foldEvents();
     sc->statsPending = false;
   }
   *out = sc->stats;

@@ -111,6 +111,12 @@ struct BatchState {
 #undef DR_FIELD
 };
 
+struct TraceCounters {  // device-side totals (Stats probes of bvh_accel.dart:106-163)
+  unsigned long long closest_rays, any_rays, closest_nodes, any_nodes, closest_tris, any_tris;
+  // shading stages: active-list entries processed, path vertices set up, rays queued (DrRenderStats.shade_*)
+  unsigned long long shade_items, shade_vertices, shade_cont, shade_mis, shade_shadow;
+};
+
 // Work queues of one stage.  Counts live in device memory so that no host
 // round trip is needed between launches.
 struct StageQueues {
@@ -122,10 +128,7 @@ struct StageQueues {
   uint32_t* nClosest;
   uint32_t* anyQ;
   uint32_t* nAny;
-};
-
-struct TraceCounters {  // device-side totals (Stats probes of bvh_accel.dart:106-163)
-  unsigned long long closest_rays, any_rays, closest_nodes, any_nodes, closest_tris, any_tris;
+  TraceCounters* ctr;  // shade_* totals (one no-return atomic per counter, workgroup and flush)
 };
 
 #ifndef DR_LDS_STACK

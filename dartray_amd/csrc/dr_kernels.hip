@@ -630,6 +630,13 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
   }
 }
 
+// DrRenderStats.shade_items / shade_vertices: one no-return atomic per wave at the end of a shade kernel
+DR_DEV void shade_count(TraceCounters* ctr, uint32_t nIn, uint32_t nVert) {
+  const unsigned long long v = wave_sum(nVert);
+  if (lane_id() == 0 && v) atomicAdd(&ctr->shade_vertices, v);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shade_items, (unsigned long long)nIn);
+}
+
 // One vertex of PathIntegrator.Li (path_integrator.dart:44-119).
 // Launch shape (measured): ONE 768-thread workgroup per CU = 3 waves per SIMD (168 VGPRs each).
 // Smaller workgroups pay more same-address queue atomics (one per workgroup, counter and iteration), 4 waves per
@@ -669,6 +676,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   // shading code is waited for at its first load; issued after it, it costs 16 spilled registers).
   const uint32_t tid0 = blockIdx.x * blockDim.x + threadIdx.x;
   auto slotOf = [&](uint32_t i) -> uint32_t { return i < nIn ? (q.activeIn ? q.activeIn[i] : i) : 0u; };
+  uint32_t nVert = 0;  // path vertices this thread set up (DrRenderStats.shade_vertices)
   for (uint32_t it = 0; it < nIter; ++it) {
     ShadeIn cur;
     load_shade_in<QUAD>(st, rp, bounce, slotOf(it * stride + tid0), it * stride + tid0 < nIn, &cur);
@@ -786,13 +794,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         }
         st3(st.ro(), cap, slot, p);
         st.rtmin()[TD(cap, slot)] = eps;
+        ++nVert;
       }
       stc(st.L(), cap, slot, L);
       st.flags()[TI(cap, slot)] = pf;
     }
     stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT);
-    if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter) stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut);
+    if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
+      stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont, &q.ctr->shade_mis,
+                  &q.ctr->shade_shadow);
   }
+  shade_count(q.ctr, nIn, nVert);
 }
 
 // DirectLightingIntegrator.Li with strategy "all" (direct_lighting_integrator.dart:30-68;
@@ -809,6 +821,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
   const int nCalls = rp.nDirectStages;
+  uint32_t nVert = 0;
   DirectStage prev{}, cur{};
   if (stage > 0) prev = rp.dstages[stage - 1];
   if (stage < nCalls) cur = rp.dstages[stage];
@@ -893,8 +906,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       st.flags()[TI(cap, slot)] = pf;
     }
     stage_push(s_push, pctx, false, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, again, slot, Q_MIS_BIT);
-    if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter) stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut);
+    if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
+      stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont, &q.ctr->shade_mis,
+                  &q.ctr->shade_shadow);
+    if (again) ++nVert;
   }
+  shade_count(q.ctr, nIn, nVert);
 }
 
 // ---------------------------------------------------------------------------

@@ -67,12 +67,18 @@ DR_DEV void stage_push(PushStage& sm, PushCtx& c, bool pCont, bool pMis, bool pA
   __syncthreads();  // sm.cnt is reused by the next iteration; the staged entries are visible to a flush
 }
 DR_DEV void stage_flush(PushStage& sm, PushCtx& c, uint32_t* closestQ, uint32_t* nClosest, uint32_t* anyQ, uint32_t* nAny,
-                        uint32_t* activeQ, uint32_t* nActive) {
+                        uint32_t* activeQ, uint32_t* nActive, unsigned long long* nCont = nullptr,
+                        unsigned long long* nMis = nullptr, unsigned long long* nShadow = nullptr) {
   const uint32_t* buf = (const uint32_t*)(&sm + 1);
   const uint32_t capQ = blockDim.x * DR_PUSH_ITERS;
   if (threadIdx.x == 0) sm.base[0] = (c.n[0] + c.n[1]) ? atomicAdd(nClosest, c.n[0] + c.n[1]) : 0u;
   else if (threadIdx.x == 64) sm.base[1] = c.n[2] ? atomicAdd(nAny, c.n[2]) : 0u;
   else if (threadIdx.x == 128) sm.base[2] = c.n[3] ? atomicAdd(nActive, c.n[3]) : 0u;
+  else if (threadIdx.x == 192 && nCont) {  // statistics only: no-return atomics, nobody waits for them
+    if (c.n[0]) atomicAdd(nCont, (unsigned long long)c.n[0]);
+    if (c.n[1]) atomicAdd(nMis, (unsigned long long)c.n[1]);
+    if (c.n[2]) atomicAdd(nShadow, (unsigned long long)c.n[2]);
+  }
   __syncthreads();
   const uint32_t b0 = sm.base[0], b1 = sm.base[1], b2 = sm.base[2];
   for (uint32_t i = threadIdx.x; i < c.n[0]; i += blockDim.x) closestQ[b0 + i] = buf[i];

@@ -3,34 +3,72 @@
 The reference shards a render by image sub-window, one web-worker isolate per task, each with
 its own scene copy, and merges by copying the disjoint rectangles into the output
 (lib/dartray_web/render_manager.dart:100-141; GetSubWindow, lib/core/common.dart:52-73).  Here:
-one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI), the full scene
-replicated on every GPU, 32x32-pixel tiles (TilePixelSampler.tileSize, tile_pixel_sampler.dart:37)
-dealt round-robin over ranks for load balance, every rank accumulating into a zero-initialised
-full-frame (X, Y, Z, weight) film and ONE reduce(sum) of that film to rank 0 per render.  With
-the box filter of radius 0.5 the tiles are disjoint, so the sum adds zeros and is exact; with
-wider filters the sum also carries the splats across tile borders that the reference's
-rectangle copy drops.  `sample_set` is the weak-scaling alternative (bench.py's default at N > 1): every rank
-renders the whole image with its own sampler seed and the same reduce adds the sample sets up.  torch is plumbing here (device memory, streams, the collective).
+one process per GPU, the full scene replicated on every GPU, 32x32-pixel tiles
+(TilePixelSampler.tileSize, tile_pixel_sampler.dart:37) dealt round-robin over ranks for load balance,
+every rank accumulating into a zero-initialised full-frame (X, Y, Z, weight) film and ONE reduce(sum)
+of that film to rank 0 per render.  With the box filter of radius 0.5 the tiles are disjoint, so the
+sum adds zeros and is exact; with wider filters the sum also carries the splats across tile borders
+that the reference's rectangle copy drops.
+
+The collective is the C ABI's: dr_comm_init / dr_film_reduce (include/dartray_hip.h) call librccl's
+ncclReduce over xGMI directly, exactly what a Dart host would call through dart:ffi.  torchrun is only the
+launcher here and torch.distributed (gloo) only the control plane: it carries the 128-byte RCCL unique id
+from rank 0 to the other ranks and provides the host barrier around a timed region.  `sample_set` is an
+alternative split (bench.py --scaling samples): every rank renders the whole image with its own sampler
+seed and the same reduce adds the sample sets up.
+
+CPU tensors (the world-2 gloo tests, which stand the CPU oracle in for the GPU) are reduced with gloo: test
+plumbing for the sharding logic, never a product path.
 """
+import ctypes as C
 import os
 
 import torch
 import torch.distributed as dist
 
+from . import _abi
 
-def init_process_group():
-    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank)."""
+_comm_ready = False
+
+
+def init_process_group(device_comm=None):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns
+    (rank, world, local_rank).  world > 1: a gloo control-plane group; on a GPU box also dr_init(local_rank) and the
+    RCCL communicator of the C ABI (device_comm=False skips it, True also builds it for world == 1)."""
+    global _comm_ready
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if device_comm is None:
+        device_comm = world > 1 and torch.cuda.is_available()
+    if device_comm and not _comm_ready:
+        comm_init(rank, world, local)
     return rank, world, local
+
+
+def comm_init(rank, world, local):
+    """dr_comm_init on every rank: rank 0 draws the unique id, the control plane broadcasts it."""
+    global _comm_ready
+    lib = _abi.lib()
+    _abi.init(local)
+    ident = torch.zeros(_abi.DR_COMM_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        _abi.check(lib.dr_comm_unique_id(ident.data_ptr(), ident.numel()))
+    if world > 1:
+        dist.broadcast(ident, src=0)
+    _abi.check(lib.dr_comm_init(rank, world, ident.data_ptr(), ident.numel()))
+    _comm_ready = True
+
+
+def comm_destroy():
+    global _comm_ready
+    if _comm_ready:
+        _abi.check(_abi.lib().dr_comm_destroy())
+        _comm_ready = False
 
 
 def shard(renderer, rank, world, tile_size=32):
@@ -40,17 +78,44 @@ def shard(renderer, rank, world, tile_size=32):
 
 
 def sample_set(renderer, rank):
-    """Weak scaling: every rank renders ALL pixels with its own sample set (sampler seed + rank); the summed
+    """Every rank renders ALL pixels with its own sample set (sampler seed + rank); the summed
     films are the image at world x spp samples per pixel (ImageFilm keeps weighted sums, image_film.dart:99-185)."""
     renderer.sampler.seed = int(renderer.sampler.seed) + int(rank)
     return renderer
 
 
-def reduce_film(film, dst=0):
-    """Sum the per-rank (X, Y, Z, weight) films onto rank `dst` (one collective per render)."""
+def reduce_film(film, dst=0, stream=None):
+    """Sum the per-rank (X, Y, Z, weight) films onto rank `dst` (one collective per render).  Device films go
+    through dr_film_reduce (RCCL) on `stream` (default: torch's current stream)."""
+    if film.is_cuda:
+        if not _comm_ready:
+            if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+                raise _abi.DartRayHipError("reduce_film: dr_comm_init has not run (init_process_group on a GPU box does it)")
+            return film
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        assert film.dtype == torch.float32 and film.is_contiguous() and film.shape[-1] == 4
+        _abi.check(_abi.lib().dr_film_reduce(film.data_ptr(), film.numel() // 4, dst, stream))
+        return film
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)  # CPU tensors: the gloo tests only
     return film
+
+
+def max_over_ranks(value, stream=None):
+    """max over ranks of a host float (the timed region of bench.py): ncclAllReduce(max) on the device when the
+    RCCL communicator exists, gloo otherwise."""
+    if _comm_ready and torch.cuda.is_available():
+        t = torch.tensor([value], dtype=torch.float64, device="cuda")
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _abi.check(_abi.lib().dr_comm_allreduce_f64(t.data_ptr(), 1, 1, stream))
+        return float(t.item())
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([value], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return value
 
 
 def barrier():

@@ -147,7 +147,7 @@ typedef struct DrSceneDesc {
   uint32_t nlights;
   const DrLightTri* light_tris;
   uint32_t nlight_tris;
-  uint32_t bvh_depth; /* max depth of the tree, 0 = unknown */
+  uint32_t bvh_depth; /* max depth of the tree; 0 = unknown: dr_scene_create measures it */
   const DrEnvMap* env_maps; /* at most one infinite light is supported */
   uint32_t nenv_maps;
   const DrQuadric* quadrics; /* spheres / disks referenced from tri_idx and light_tris */
@@ -259,6 +259,13 @@ typedef struct DrRenderStats {
   double shade_ms;  /* k_shade_path / k_shade_direct */
   double gen_ms;    /* k_gen_samples (+ host-buffer transpose) and k_raygen */
   double film_ms;   /* k_film */
+  /* shading-stage work items, summed over the stages of every batch: entries of the stage's active list
+   * (shade_items), of which path vertices that were set up (a surface hit within maxDepth: shade_vertices), and
+   * the rays they queued (continuation, MIS and shadow rays) */
+  uint64_t shade_items, shade_vertices, shade_cont, shade_mis, shade_shadow;
+  /* device time of the traversal-kernel pilot the FIRST big render of a big scene runs (dr_render_device); it is
+   * part of that call's total_ms */
+  double pilot_ms;
 } DrRenderStats;
 
 /* Select the GPU.  Must precede everything else. */
@@ -281,6 +288,14 @@ int dr_bvh_build_mixed(const float* verts, uint64_t nverts, const uint32_t* tri_
 /* Scene upload (replaces the construction of lib/core/scene.dart Scene). */
 int dr_scene_create(const DrSceneDesc* desc, DrScene** out);
 void dr_scene_destroy(DrScene* scene);
+
+/* Which traversal kernel each ray kind ([0] closest hit, [1] any hit) uses on this scene: 0 = not decided yet (the
+ * first big render of a big scene measures both on ~1.5 % of its own samples: DrRenderStats.pilot_ms), 2 = one node
+ * per step, 3 = sibling pairs.  Both are bit-exact; only speed depends on the choice.  A host that renders the same
+ * scene again (another frame, another process) can store the measured choice and hand it back: the pilot is then
+ * skipped.  Setting 0 makes the next big render measure again. */
+int dr_scene_get_trace_kernels(const DrScene* scene, uint32_t kernels_out[2]);
+int dr_scene_set_trace_kernels(DrScene* scene, const uint32_t kernels[2]);
 
 /* Aggregate.intersect / Aggregate.intersectP (lib/core/primitive.dart:33-55 ->
  * bvh_accel.dart:101-226) on a batch of rays; host buffers. */
@@ -321,8 +336,109 @@ int dr_reset_stats(DrScene* scene);
 /* Device float4 copy kernel: the measured HBM-bandwidth denominator. Returns GB/s. */
 int dr_copy_bandwidth(uint64_t bytes, int32_t iters, double* gbps_out);
 
+/* ---- multi-GPU: one process per GPU, the film merged over RCCL -------------------------------------------
+ * The reference fans a render out over isolates, one sub-window each, and merges their rectangles in the
+ * host (lib/dartray_web/render_manager.dart:100-141; GetSubWindow lib/core/common.dart:52-73).  Here every
+ * rank renders its tile share (DrRenderDesc.tile_*) into a zero-initialised full-frame device film with
+ * dr_render_device, and ONE ncclReduce(sum, f32) over xGMI merges the films on `root`.  The host only has to
+ * carry DR_COMM_ID_BYTES from rank 0 to the other ranks (any channel: a file, a socket, MPI, torchrun's
+ * store).  librccl is loaded on the first dr_comm_* call (DARTRAY_RCCL_LIB overrides the search), so
+ * single-GPU hosts need not have it.  One communicator per process. */
+#define DR_COMM_ID_BYTES 128 /* == NCCL_UNIQUE_ID_BYTES */
+/* rank 0: ncclGetUniqueId into id_out[DR_COMM_ID_BYTES] */
+int dr_comm_unique_id(void* id_out, uint64_t cap);
+/* every rank, after dr_init: ncclCommInitRank(world, id, rank); blocks until all ranks have called it */
+int dr_comm_init(int32_t rank, int32_t world, const void* unique_id, uint64_t id_bytes);
+/* film_dev: [npixels][4] f32 (X, Y, Z, weightSum) on every rank; summed in place into rank `root`'s buffer on
+ * the given hipStream_t (asynchronous like dr_render_device; other ranks' buffers are left as they were).
+ * world == 1: no-op through the same code path (an in-place single-rank ncclReduce). */
+int dr_film_reduce(void* film_dev, int64_t npixels, int32_t root, void* hip_stream);
+/* in-place ncclAllReduce(max / sum) of n doubles on the stream: the barrier + max-over-ranks of a timed region */
+int dr_comm_allreduce_f64(void* buf_dev, int64_t n, int32_t op_max, void* hip_stream);
+int dr_comm_rank(void);  /* -1 before dr_comm_init */
+int dr_comm_world(void); /* 0 before dr_comm_init */
+int dr_comm_destroy(void);
+
 const char* dr_last_error(void);
 const char* dr_version(void);
+
+
+/* ---- layout checks: a foreign host (dart:ffi Struct classes, ctypes, a C program) must see exactly these
+ * sizes and offsets (LP64, little endian, natural alignment) ---- */
+#include <stddef.h>
+#ifdef __cplusplus
+#define DR_ABI_ASSERT(c, m) static_assert(c, m)
+#else
+#define DR_ABI_ASSERT(c, m) _Static_assert(c, m)
+#endif
+#define DR_ABI_SIZE(T, n) DR_ABI_ASSERT(sizeof(T) == (n), "sizeof(" #T ") != " #n)
+#define DR_ABI_OFFSET(T, f, n) DR_ABI_ASSERT(offsetof(T, f) == (n), "offsetof(" #T ", " #f ") != " #n)
+DR_ABI_SIZE(DrBvhNode, 32);
+DR_ABI_OFFSET(DrBvhNode, offset, 24);
+DR_ABI_OFFSET(DrBvhNode, nprims, 28);
+DR_ABI_OFFSET(DrBvhNode, axis, 30);
+DR_ABI_SIZE(DrMaterial, 56);
+DR_ABI_OFFSET(DrMaterial, kd, 4);
+DR_ABI_OFFSET(DrMaterial, sigma, 40);
+DR_ABI_OFFSET(DrMaterial, index, 48);
+DR_ABI_SIZE(DrAreaLight, 128);
+DR_ABI_OFFSET(DrAreaLight, first_tri, 16);
+DR_ABI_OFFSET(DrAreaLight, position, 32);
+DR_ABI_OFFSET(DrAreaLight, world_to_light, 48);
+DR_ABI_OFFSET(DrAreaLight, cone_width, 112);
+DR_ABI_SIZE(DrEnvMap, 144);
+DR_ABI_OFFSET(DrEnvMap, width, 8);
+DR_ABI_OFFSET(DrEnvMap, light_to_world, 16);
+DR_ABI_SIZE(DrLightTri, 16);
+DR_ABI_SIZE(DrMeshXform, 128);
+DR_ABI_SIZE(DrQuadric, 168);
+DR_ABI_OFFSET(DrQuadric, object_to_world, 8);
+DR_ABI_OFFSET(DrQuadric, params, 136);
+DR_ABI_SIZE(DrSceneDesc, 208);
+DR_ABI_OFFSET(DrSceneDesc, nnodes, 8);
+DR_ABI_OFFSET(DrSceneDesc, verts, 16);
+DR_ABI_OFFSET(DrSceneDesc, tri_idx, 32);
+DR_ABI_OFFSET(DrSceneDesc, tri_material, 48);
+DR_ABI_OFFSET(DrSceneDesc, materials, 72);
+DR_ABI_OFFSET(DrSceneDesc, nmaterials, 80);
+DR_ABI_OFFSET(DrSceneDesc, lights, 88);
+DR_ABI_OFFSET(DrSceneDesc, nlights, 96);
+DR_ABI_OFFSET(DrSceneDesc, light_tris, 104);
+DR_ABI_OFFSET(DrSceneDesc, nlight_tris, 112);
+DR_ABI_OFFSET(DrSceneDesc, bvh_depth, 116);
+DR_ABI_OFFSET(DrSceneDesc, env_maps, 120);
+DR_ABI_OFFSET(DrSceneDesc, quadrics, 136);
+DR_ABI_OFFSET(DrSceneDesc, vert_normals, 152);
+DR_ABI_OFFSET(DrSceneDesc, mesh_xforms, 192);
+DR_ABI_OFFSET(DrSceneDesc, nmesh_xforms, 200);
+DR_ABI_SIZE(DrRay, 40);
+DR_ABI_OFFSET(DrRay, tmin, 24);
+DR_ABI_SIZE(DrHit, 32);
+DR_ABI_OFFSET(DrHit, t, 8);
+DR_ABI_SIZE(DrCamera, 152);
+DR_ABI_OFFSET(DrCamera, lens_radius, 128);
+DR_ABI_OFFSET(DrCamera, type, 144);
+DR_ABI_SIZE(DrFilm, 1080);
+DR_ABI_OFFSET(DrFilm, crop, 8);
+DR_ABI_OFFSET(DrFilm, filter_xw, 40);
+DR_ABI_OFFSET(DrFilm, filter_table, 56);
+DR_ABI_SIZE(DrRenderDesc, 1328);
+DR_ABI_OFFSET(DrRenderDesc, film, 152);
+DR_ABI_OFFSET(DrRenderDesc, integrator, 1232);
+DR_ABI_OFFSET(DrRenderDesc, seed, 1248);
+DR_ABI_OFFSET(DrRenderDesc, task_num, 1256);
+DR_ABI_OFFSET(DrRenderDesc, tile_rank, 1264);
+DR_ABI_OFFSET(DrRenderDesc, nsamples, 1280);
+DR_ABI_OFFSET(DrRenderDesc, pixel_xy, 1288);
+DR_ABI_OFFSET(DrRenderDesc, sample_vec, 1296);
+DR_ABI_OFFSET(DrRenderDesc, sample_stride, 1304);
+DR_ABI_OFFSET(DrRenderDesc, tail, 1312);
+DR_ABI_OFFSET(DrRenderDesc, max_tail, 1320);
+DR_ABI_SIZE(DrRenderStats, 200);
+DR_ABI_OFFSET(DrRenderStats, trace_ms, 72);
+DR_ABI_OFFSET(DrRenderStats, film_ms, 144);
+DR_ABI_OFFSET(DrRenderStats, shade_items, 152);
+DR_ABI_OFFSET(DrRenderStats, pilot_ms, 192);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,100 @@
+"""The C ABI seen from a foreign host: tests/abi/c1_from_c.c is compiled with gcc against include/dartray_hip.h alone
+(no Python, no HIP headers), links to the product library, builds BASELINE config C1 by hand and renders it with the
+recorded serial sample stream of tests/golden/c1_serial.npz.  CPU suite: the header compiles as C11 and as C++17 with
+its layout asserts, the program links, every declared symbol is exported, and the struct layouts of dartray_amd/_abi.py
+(the ctypes host) agree with the header's.  GPU suite: the program's film equals the golden."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from dartray_amd import _abi
+
+HEADER = os.path.join(ROOT, "include", "dartray_hip.h")
+SRC = os.path.join(ROOT, "tests", "abi", "c1_from_c.c")
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "c1_from_c")
+    libdir = os.path.join(ROOT, "dartray_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe,
+                           os.path.join(libdir, "libdartray_hip.so"), "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_header_compiles_as_c11_and_cxx17_with_its_layout_asserts():
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", HEADER])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", HEADER])
+
+
+def test_c_host_links_against_the_header_and_library_only(hip, tmp_path):
+    exe = _build(tmp_path)
+    assert os.path.exists(exe)
+    # without its input blob the program stops before any device call
+    assert subprocess.run([exe, str(tmp_path / "missing"), str(tmp_path / "out")]).returncode == 1
+
+
+def test_every_function_the_header_declares_is_exported_and_bound(hip):
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(dr_[a-z0-9_]+)\s*\(", text))
+    lib = hip.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
+
+
+def test_ctypes_layouts_equal_the_headers_static_asserts(hip):
+    """DR_ABI_SIZE / DR_ABI_OFFSET lines of the header vs the ctypes Structures of the Python host."""
+    text = open(HEADER).read()
+    sizes = re.findall(r"^DR_ABI_SIZE\((\w+), (\d+)\);", text, flags=re.M)
+    offsets = re.findall(r"^DR_ABI_OFFSET\((\w+), (\w+), (\d+)\);", text, flags=re.M)
+    assert len(sizes) >= 14 and len(offsets) >= 40
+    for name, n in sizes:
+        assert C.sizeof(getattr(_abi, name)) == int(n), name
+    for name, field, n in offsets:
+        assert getattr(getattr(_abi, name), field).offset == int(n), (name, field)
+
+
+def test_comm_entry_points_fail_loudly_without_a_communicator(hip):
+    lib = hip.lib()
+    assert lib.dr_comm_world() == 0 and lib.dr_comm_rank() == -1
+    buf = (C.c_float * 4)()
+    assert lib.dr_film_reduce(C.cast(buf, C.c_void_p), 1, 0, None) == -1  # DR_ERR_INVALID
+    assert b"dr_comm_init" in lib.dr_last_error()
+    assert lib.dr_comm_allreduce_f64(C.cast(buf, C.c_void_p), 1, 1, None) == -1
+    ident = (C.c_char * 128)()
+    assert lib.dr_comm_init(0, 0, C.cast(ident, C.c_void_p), 128) == -1  # world < 1
+    assert lib.dr_comm_init(0, 1, C.cast(ident, C.c_void_p), 64) == -1   # short id
+    assert lib.dr_comm_destroy() == 0                                    # nothing to destroy
+
+
+@pytest.mark.gpu
+def test_c1_rendered_by_the_c_host_equals_the_golden(gpu, tmp_path):
+    from dartray_amd import scenes
+    g = np.load(os.path.join(GOLDEN, "c1_serial.npz"))
+    prims, mk = scenes.config("C1")
+    r = mk()
+    d, keep = r.describe()  # camera + film as the host objects hold them (what a Dart host reads off its Camera / Film)
+    npix, spp, stride = len(g["pixel_xy"]), 4, g["sample_vec"].shape[1]
+    film = r.camera.film
+    blob = tmp_path / "in.blob"
+    with open(blob, "wb") as f:
+        f.write(np.array([npix, spp, stride, film.width, film.height], np.int32).tobytes())
+        f.write(bytes(d.camera))
+        f.write(bytes(d.film))
+        f.write(np.ascontiguousarray(g["pixel_xy"], np.int32).tobytes())
+        f.write(np.ascontiguousarray(g["sample_vec"], np.float32).tobytes())
+    exe = _build(tmp_path)
+    out = tmp_path / "out.blob"
+    res = subprocess.run([exe, str(blob), str(out)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "c1_from_c: 16900 camera samples" in res.stdout, res.stdout
+    raw = np.fromfile(out, np.float32)
+    n4 = film.width * film.height * 4
+    assert np.array_equal(raw[:n4].reshape(film.height, film.width, 4), g["film"])
+    assert np.array_equal(raw[n4:].reshape(film.height, film.width, 3), g["rgb"])

@@ -1,7 +1,9 @@
 """The N > 1 path on CPU: world_size 2, gloo.  Each rank takes its round-robin tiles
 (dartray_amd.dist.shard -> dr_enumerate_pixels), accumulates a full-frame film, and ONE reduce(sum)
 merges them on rank 0.  The per-rank compute is done by the CPU oracle here (test infrastructure
-standing in for the GPU), so what is tested is the product's sharding + collective plumbing."""
+standing in for the GPU), so what is tested is the product's sharding logic and the call sequence of
+dartray_amd.dist; on GPUs the same reduce_film goes through dr_film_reduce (RCCL, tests/test_gpu_comm.py).
+bench.py --gpus N runs exactly this split (on configs[2]'s 4096 x 4096 x 1024 spp image by default)."""
 import os
 import sys
 import tempfile
@@ -20,6 +22,7 @@ def _worker(rank, world, init_file, out_file, weak=False):
     from dartray_amd import scenes, dist as drdist
     import oracle.binding as ob
     dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    assert drdist.max_over_ranks(float(rank)) == float(world - 1)
     prims, mk = scenes.config("C2", xres=40, yres=40, spp=4, blob=(12, 6))
     r = drdist.sample_set(mk(), rank) if weak else drdist.shard(mk(), rank, world, tile_size=16)
     px = r.pixels()
@@ -49,7 +52,7 @@ def test_two_rank_tile_sharding_and_film_reduce(ob):
 
 
 def test_two_rank_sample_sets_and_film_reduce(ob):
-    """bench.py's default N > 1 mode: each rank renders the whole image with sampler seed + rank, one reduce(sum)."""
+    """bench.py --scaling samples: each rank renders the whole image with sampler seed + rank, one reduce(sum)."""
     import torch.multiprocessing as mp
     from dartray_amd import scenes
     with tempfile.TemporaryDirectory() as tmp:

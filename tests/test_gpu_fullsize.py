@@ -1,0 +1,126 @@
+"""BASELINE.json's configs at FULL size on the GPU (C2's full-size test is in test_gpu_render.py): the oracle cannot
+render them in reasonable time, so each test checks (a) size-independent properties of the whole film -- every owned
+pixel's weightSum == spp up to the rare integral-imageX splats, exactly 0 on pixels of other ranks' tiles, finite
+non-negative radiance, plausible traversal counters -- and (b) sparse parity: a handful of pixels spread over the
+image are rendered by the oracle with the same keyed sample streams and must equal the GPU's film entries bit for bit.
+Plus the renderer's NaN / negative / infinite radiance guards (sampler_renderer.dart:181-193)."""
+import numpy as np
+import pytest
+
+from dartray_amd import core, dist as drdist, scenes
+from util import rel_err_image
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-4
+
+
+def _sparse_parity(ob, prims, r, out, px, env=None):
+    osc = ob.OracleScene(prims, env=env) if env is not None else ob.OracleScene(prims)
+    ref = osc.render(ob.render_desc(r, sampler_mode=1, pixels=px))
+    for x, y in px:
+        err = rel_err_image(out.rgb[y, x][None], ref["rgb"][y, x][None]).max()
+        assert err <= REL_TOL, (x, y, out.rgb[y, x], ref["rgb"][y, x])
+        assert np.array_equal(out.film[y, x], ref["film"][y, x]), (x, y, out.film[y, x], ref["film"][y, x])
+
+
+def test_c3_rank0_share_of_eight_tile_shards(ob, gpu):
+    """configs[2]: the C2 scene at 4096 x 4096, 1024 spp, 32 x 32 tiles dealt round-robin over 8 ranks -- rank 0's
+    share (2.1e9 camera samples, 8 batches of the path-state workspace) on one GPU."""
+    prims, mk = scenes.config("C2", xres=4096, yres=4096, spp=1024)
+    scene = scenes.make_scene(prims)
+    r = drdist.shard(mk(), 0, 8)
+    out = r.render(scene)
+    st = r.last_stats
+    w = out.film[..., 3]
+    ty, tx = np.meshgrid(np.arange(4096) // 32, np.arange(4096) // 32, indexing="ij")
+    # the sampler window is 4097 wide: 129 tile columns (image_film.dart:247-252), tiles dealt over the window
+    owned = ((ty * 129 + tx) % 8) == 0
+    assert owned.sum() * 1024 == st["film_samples"]
+    assert np.all(w[~owned] <= 8) and np.mean(w[~owned] == 0) > 0.9999   # only integral-imageX splats of a neighbour tile
+    assert np.mean(w[owned] == 1024) > 0.9999 and abs(float(w[owned].sum()) - owned.sum() * 1024.0) <= 4096
+    assert st["batches"] >= 8
+    assert np.isfinite(out.rgb).all() and out.rgb.min() >= 0
+    assert np.all(out.film[..., :3][w == 0] == 0)
+    ys, xs = np.nonzero(owned)
+    rng = np.random.Generator(np.random.PCG64(11))
+    pick = rng.integers(0, len(ys), 18)
+    px = np.stack([xs[pick], ys[pick]], 1).astype(np.int32)
+    px[0], px[1] = [2048, 2816], [2080, 2050]  # tiles (64, 88) and (65, 64): 88*129+64 = 11416 = 8*1427, 64*129+65 = 8321 -> check below
+    px = np.array([p for p in px if owned[p[1], p[0]]], np.int32)
+    assert len(px) >= 16
+    _sparse_parity(ob, prims, r, out, px)
+
+
+def test_full_size_c4_hairball_both_traversal_kernels(ob, gpu):
+    """configs[3]: Cornell box + 10 000 012-triangle hairball (20M-node tree of depth > 24: global spill stack),
+    PathIntegrator, 1024 x 1024, 64 spp -- with the kernels the pilot picks, then each kernel forced."""
+    prims, mk = scenes.config("C4")
+    scene = scenes.make_scene(prims)
+    assert len(scene.aggregate.tri_idx) == 10000012
+    assert scene.aggregate.depth > 24
+    r = mk()
+    out = r.render(scene)
+    dev = scene._device()
+    picked = dev.trace_kernels()
+    assert picked[0] in (2, 3) and picked[1] in (2, 3)
+    assert r.last_stats["pilot_ms"] > 0
+    w = out.film[..., 3]
+    assert abs(float(w.sum()) - 1024 * 1024 * 64) <= 512 and np.mean(w == 64) > 0.9999
+    assert np.isfinite(out.rgb).all() and out.rgb.min() >= 0
+    counters = {k: r.last_stats[k] for k in ("closest_rays", "any_rays", "closest_nodes", "any_nodes", "closest_tris", "any_tris")}
+    rng = np.random.Generator(np.random.PCG64(4))
+    px = np.stack([rng.integers(200, 824, 20), rng.integers(200, 824, 20)], 1).astype(np.int32)  # mostly on the ball
+    px[:3] = [[512, 512], [40, 40], [512, 1000]]
+    _sparse_parity(ob, prims, r, out, px)
+    for forced in ((2, 2), (3, 3)):
+        assert dev.trace_kernels(forced) == forced
+        out2 = r.render(scene)
+        assert np.array_equal(out2.film, out.film), forced
+        assert r.last_stats["pilot_ms"] == 0
+        assert {k: r.last_stats[k] for k in counters} == counters, forced
+
+
+def test_full_size_c5_courtyard_env_map_and_eight_lights(ob, gpu):
+    """configs[4]: ~8M-triangle courtyard, 8 area lights + env map, PathIntegrator maxdepth 8, 2048 x 2048, 512 spp
+    (2.1e9 samples; 8 batches)."""
+    prims, mk = scenes.config("C5")
+    r = mk()
+    scene = scenes.make_scene(prims, r.env)
+    assert len(scene.aggregate.tri_idx) > 8.0e6 and len(scene.lights) == 9
+    out = r.render(scene)
+    w = out.film[..., 3]
+    assert abs(float(w.sum()) - 2048 * 2048 * 512) <= 2048 and np.mean(w == 512) > 0.9999
+    assert np.isfinite(out.rgb).all() and out.rgb.min() >= 0
+    rng = np.random.Generator(np.random.PCG64(5))
+    px = np.stack([rng.integers(0, 2048, 16), rng.integers(0, 2048, 16)], 1).astype(np.int32)
+    px[:2] = [[1024, 200], [1024, 1500]]  # sky, courtyard floor
+    osc = ob.OracleScene(prims, env=r.env)
+    ref = osc.render(ob.render_desc(r, sampler_mode=1, pixels=px))
+    for x, y in px:
+        assert rel_err_image(out.rgb[y, x][None], ref["rgb"][y, x][None]).max() <= REL_TOL, (x, y)
+        assert np.array_equal(out.film[y, x], ref["film"][y, x]), (x, y, out.film[y, x], ref["film"][y, x])
+
+
+@pytest.mark.parametrize("L", [(-4.0, -4.0, -4.0), (float("inf"),) * 3, (float("nan"), 1.0, 1.0), (1e30, -1e30, 5.0)])
+@pytest.mark.parametrize("integ", ["path", "direct"])
+def test_radiance_guards_nan_negative_infinite(ob, gpu, L, integ):
+    """SamplerRenderer's guards (sampler_renderer.dart:181-193): a sample whose radiance has a NaN component, a
+    luminance below -1e-5 or an infinite luminance is replaced by black BEFORE it reaches the film (its filter weight
+    still counts).  Emitters with negative / infinite / NaN radiance make every lit sample trip one of them."""
+    prims = scenes.cornell_walls() + [scenes.emitter_quad(L=L), scenes.blob_prim(16, 8)]
+    film = core.ImageFilm(40, 32)
+    cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
+    surf = core.PathIntegrator(5) if integ == "path" else core.DirectLightingIntegrator(0, 5)
+    r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 16), cam, surf, core.EmissionIntegrator())
+    out = r.render(scenes.make_scene(prims))
+    ref = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=1))
+    assert np.isfinite(ref["film"]).all() and np.isfinite(out.film).all()
+    assert np.array_equal(out.film, ref["film"]) and np.array_equal(out.rgb, ref["rgb"])
+    assert np.all(out.film[..., 3] >= 16)
+    if L[0] != 1e30:
+        # every sample that saw the emitter (directly or through a light estimate) was blacked out, the others are 0 anyway
+        assert np.all(out.film[..., :3] == 0)
+    # the same scene with a benign emitter is not black: the guards, not the scene, zeroed it
+    good = scenes.cornell_walls() + [scenes.emitter_quad(L=(4.0, 4.0, 4.0)), scenes.blob_prim(16, 8)]
+    assert core.SamplerRenderer(core.LowDiscrepancySampler(cam, 16), cam, surf, core.EmissionIntegrator()).render(
+        scenes.make_scene(good)).film[..., :3].max() > 0
