@@ -890,6 +890,8 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   sc->d.ntris = (uint32_t)desc->ntris;
   sc->d.nlights = desc->nlights;
   sc->d.nmats = desc->nmaterials;
+  sc->d.nltris = desc->nlight_tris;
+  sc->d.ncdf = (uint32_t)sc->lcdf.n;
   {  // DirectLighting: one 1-D + one 2-D slot pair per light for the light sample and one for the BSDF sample, each
      // with roundSize(nSamples) entries (low_discrepancy_sampler.dart:43-49), then the two 1-D volume slots
     auto rp2 = [](int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; };

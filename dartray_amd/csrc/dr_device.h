@@ -137,6 +137,7 @@ struct DScene {
   const DLightTri* ltris;
   const float* lcdf;
   uint32_t nnodes, ntris, nlights, nmats;
+  uint32_t nltris, ncdf;  // entries of ltris / lcdf (the shade kernels stage small tables in LDS)
   DEnv env;
   int32_t hasEnv;
   const DQuadric* quads;  // spheres / disks; a primitive record with kind != 0 holds its index in q0.x
@@ -579,6 +580,43 @@ DR_DEV void tri_dg_srec(const Tri& tr, const ShadeRec& sr, F3 o, F3 d, double t,
   tri_dg_uv(tr.p1, tr.p2, tr.p3, sr.uv, tr.reverse, o, d, t, b1, b2, dg);
 }
 
+// ---- light tables: global memory, or staged in LDS by the shade kernels ------------
+// Every path vertex walks the sampled light's ShapeSet three times (ShapeSet.sample and two ShapeSet.pdf calls each
+// intersect EVERY triangle of the set, shape_set.dart:65-89): a chain of dependent fetches of data that is the same
+// for all lanes.  From global memory each of them is a ~1000-cycle round trip with nothing else in flight (measured:
+// SQ_WAIT_ANY 62 % of the shade kernel's wave-cycles at < 1 vector-memory instruction in flight per wave).  When the
+// tables are small -- a handful of emitters, the usual case -- the shade kernels copy them into LDS once per
+// workgroup and read them with ds_read (~64 cycles).  Large emissive meshes keep the global tables.
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+struct GlobalLights {
+  const DLight* lights;
+  const DLightTri* ltris;
+  const float* lcdf;
+  DR_DEV DLight light(int i) const { return lights[i]; }
+  DR_DEV DLightTri ltri(uint32_t i) const { return ltris[i]; }
+  DR_DEV float cdf(uint32_t i) const { return lcdf[i]; }
+};
+template <class T>
+DR_DEV T lds_read_struct(lds_cu32* base, uint32_t index) {
+  constexpr int W = (int)(sizeof(T) / 4);
+  static_assert(sizeof(T) % 4 == 0, "word-sized records only");
+  uint32_t w[W];
+  lds_cu32* p = base + (size_t)index * W;
+#pragma unroll
+  for (int k = 0; k < W; ++k) w[k] = p[k];
+  T t;
+  __builtin_memcpy(&t, w, sizeof(T));
+  return t;
+}
+struct LdsLights {
+  lds_cu32* lights;
+  lds_cu32* ltris;
+  lds_cu32* lcdf;
+  DR_DEV DLight light(int i) const { return lds_read_struct<DLight>(lights, (uint32_t)i); }
+  DR_DEV DLightTri ltri(uint32_t i) const { return lds_read_struct<DLightTri>(ltris, i); }
+  DR_DEV float cdf(uint32_t i) const { return __uint_as_float(lcdf[i]); }
+};
+
 // ---- ShapeSet / DiffuseAreaLight ---------------------------------------------
 DR_DEV void ltri_verts(const DLightTri& t, F3* a, F3* b, F3* c) {
   *a = F3{t.p[0], t.p[1], t.p[2]};
@@ -586,13 +624,14 @@ DR_DEV void ltri_verts(const DLightTri& t, F3* a, F3* b, F3* c) {
   *c = F3{t.p[6], t.p[7], t.p[8]};
 }
 // Distribution1D.sampleDiscrete (montecarlo.dart:82-92) via upper_bound (common.dart:304-333).
-DR_DEV int sampleDiscrete(const float* cdf, int count, double u) {
+template <class LV>
+DR_DEV int sampleDiscrete(const LV& lv, uint32_t cdfOff, int count, double u) {
   int first = 0;
   int cnt = count + 1;
   while (cnt > 0) {
     int step = cnt >> 1;
     int index = first + step;
-    if (!(u < (double)cdf[index])) {
+    if (!(u < (double)lv.cdf(cdfOff + (uint32_t)index))) {
       first = index + 1;
       cnt -= step + 1;
     } else {
@@ -605,11 +644,11 @@ DR_DEV int sampleDiscrete(const float* cdf, int count, double u) {
 // ShapeSet.sample(ls, Ns, p) (shape_set.dart:53-80): pick by area, sample the
 // triangle (triangle.dart:366-383), then intersect p->pt with EVERY shape; the
 // last hitting shape in list order wins (r.maxDistance is never shrunk).
-template <bool QUAD>
-DR_DEV F3 shapeset_sample(const DScene& sc, const DLight& L, double uPos0, double uPos1, double uComponent, F3* Ns, F3 p) {
-  int sn = sampleDiscrete(sc.lcdf + L.cdf_off, (int)L.ntris, uComponent) % (int)L.ntris;
+template <bool QUAD, class LV>
+DR_DEV F3 shapeset_sample(const DScene& sc, const LV& lv, const DLight& L, double uPos0, double uPos1, double uComponent, F3* Ns, F3 p) {
+  int sn = sampleDiscrete(lv, L.cdf_off, (int)L.ntris, uComponent) % (int)L.ntris;
   F3 a, b, c;
-  const DLightTri& lt = sc.ltris[L.first_tri + sn];
+  const DLightTri lt = lv.ltri(L.first_tri + (uint32_t)sn);
   F3 pt;
   if (QUAD && PRIM_KIND(lt.reverse)) {
     const DQuadric& q = sc.quads[__float_as_uint(lt.p[0])];
@@ -633,7 +672,7 @@ DR_DEV F3 shapeset_sample(const DScene& sc, const DLight& L, double uPos0, doubl
   F3 rd = vsub(pt, p);
   double thit = 1.0;
   for (uint32_t i = 0; i < L.ntris; ++i) {
-    const DLightTri& t = sc.ltris[L.first_tri + i];
+    const DLightTri t = lv.ltri(L.first_tri + i);
     double th, bb1, bb2;
     if (QUAD && PRIM_KIND(t.reverse)) {
       const DQuadric& q = sc.quads[__float_as_uint(t.p[0])];
@@ -655,11 +694,11 @@ DR_DEV F3 shapeset_sample(const DScene& sc, const DLight& L, double uPos0, doubl
   return vadd(p, vmul(rd, thit));
 }
 // ShapeSet.pdf(p, wi) (shape_set.dart:82-89) with Shape.pdf2 (shape.dart:100-121).
-template <bool QUAD>
-DR_DEV double shapeset_pdf(const DScene& sc, const DLight& L, F3 p, F3 wi) {
+template <bool QUAD, class LV>
+DR_DEV double shapeset_pdf(const DScene& sc, const LV& lv, const DLight& L, F3 p, F3 wi) {
   double pdf = 0.0;
   for (uint32_t i = 0; i < L.ntris; ++i) {
-    const DLightTri& t = sc.ltris[L.first_tri + i];
+    const DLightTri t = lv.ltri(L.first_tri + i);
     F3 a, b, c;
     double pdf2;
     double th, bb1, bb2;

@@ -11,6 +11,8 @@
 // each kernel is in DESIGN.md section 3 / 5.  The path is about 1 flop per byte: no MFMA.
 //
 // Compiled with -ffp-contract=off: the Dart VM never fuses a*b+c.
+#include <type_traits>
+
 #include "dr_kernels.h"
 #include "dr_rng.h"
 #include "dr_wave.h"
@@ -407,15 +409,15 @@ __global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) 
 // EstimateDirect's contribution of the pending NEE rays (integrator.dart:135-145,169-180).
 // ENV: the scene has an InfiniteAreaLight (compiled out otherwise: the area-light-only path keeps its registers)
 // QUAD: the scene has sphere / disk primitives (likewise)
-template <bool ENV, bool QUAD>
-DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uint32_t flags, int shOcc, C3 Ld1) {
+template <bool ENV, bool QUAD, class LV>
+DR_DEV C3 resolve_nee(const DScene& sc, const LV& lv, const BatchState& st, uint32_t slot, uint32_t flags, int shOcc, C3 Ld1) {
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
   C3 Ld = C3{0.f, 0.f, 0.f};
   if ((flags & PF_HAS_SH) && shOcc == 0) Ld = cadd(Ld, Ld1);
   if (flags & PF_HAS_MIS) {
     const int prim = st.misPrim()[TI(cap, slot)];
     const int li = st.misLight()[TI(cap, slot)];
-    if (ENV && sc.lights[li].kind == DR_LIGHT_INFINITE) {
+    if (ENV && lv.light(li).kind == DR_LIGHT_INFINITE) {
       // the MIS ray escaped: Li = light.Le(ray) (integrator.dart:173-175), folded into Ld2 at set-up
       if (prim < 0) Ld = cadd(Ld, ldc(st.Ld2(), cap, slot));
     } else if (prim >= 0) {
@@ -436,7 +438,7 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
         } else {
           tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, wi, 0.0, &dg);  // only nn is used
         }
-        C3 Li = light_L(sc.lights[li], dg.nn, vneg(wi));
+        C3 Li = light_L(lv.light(li), dg.nn, vneg(wi));
         if (!cblack(Li)) Ld = cadd(Ld, ldc(st.Ld2(), cap, slot));
       }
     }
@@ -446,11 +448,11 @@ DR_DEV C3 resolve_nee(const DScene& sc, const BatchState& st, uint32_t slot, uin
 
 // EstimateDirect up to the points where it must trace (integrator.dart:119-185):
 // writes the shadow ray / MIS ray and their candidate contributions.
-template <bool ENV, bool QUAD, bool NI = false>
-DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
+template <bool ENV, bool QUAD, bool NI, class LV>
+DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const BatchState& st, uint32_t slot, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
                           F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1, double bsc) {
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
-  const DLight& light = sc.lights[lightNum];
+  const DLight light = lv.light(lightNum);
   const int flags = BSDF_ALL & ~BSDF_SPECULAR;
   uint32_t pf = 0;
   const bool infinite = ENV && light.kind == DR_LIGHT_INFINITE;
@@ -504,9 +506,9 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
   if (!infinite) {
     // DiffuseAreaLight.sampleLAtPoint (diffuse_area_light.dart:60-70)
     F3 ns;
-    ps = shapeset_sample<QUAD>(sc, light, ls0, ls1, lsc, &ns, p);
+    ps = shapeset_sample<QUAD>(sc, lv, light, ls0, ls1, lsc, &ns, p);
     wi = vnormalize(vsub(ps, p));
-    lightPdf = shapeset_pdf<QUAD>(sc, light, p, wi);
+    lightPdf = shapeset_pdf<QUAD>(sc, lv, light, p, wi);
     Li = light_L(light, ns, vneg(wi));
   } else {
     // InfiniteAreaLight.sampleLAtPoint (infinite_area_light.dart:92-131)
@@ -538,7 +540,7 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const BatchState& st, uint32_t slot,
     double bsdfPdf = 0.0;
     C3 f = bsdf_sample_f(bsdf, wo, &wi2, bs0, bs1, bsc, &bsdfPdf, flags);
     if (!cblack(f) && bsdfPdf > 0.0) {
-      double lightPdf2 = infinite ? env_pdf_x<NI>(sc.env, wi2) : shapeset_pdf<QUAD>(sc, light, p, wi2);
+      double lightPdf2 = infinite ? env_pdf_x<NI>(sc.env, wi2) : shapeset_pdf<QUAD>(sc, lv, light, p, wi2);
       if (lightPdf2 != 0.0) {
         double weight = PowerHeuristic(bsdfPdf, lightPdf2);
         // the radiance the MIS ray returns IF it reaches the light: Lemit of the sampled area light (its
@@ -630,11 +632,19 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
   }
 }
 
-// DrRenderStats.shade_items / shade_vertices: one no-return atomic per wave at the end of a shade kernel
-DR_DEV void shade_count(TraceCounters* ctr, uint32_t nIn, uint32_t nVert) {
-  const unsigned long long v = wave_sum(nVert);
-  if (lane_id() == 0 && v) atomicAdd(&ctr->shade_vertices, v);
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shade_items, (unsigned long long)nIn);
+// DrRenderStats.shade_items / shade_vertices: the per-wave vertex counts stage_push kept in LDS, one no-return atomic
+// per workgroup at the end of a shade kernel
+DR_DEV void shade_count_init(PushStage& sm) {
+  if (threadIdx.x < 16) sm.nVert[threadIdx.x] = 0;
+  __syncthreads();
+}
+DR_DEV void shade_count(PushStage& sm, TraceCounters* ctr, uint32_t nIn) {
+  if (threadIdx.x == 0) {
+    unsigned long long v = 0;
+    for (int w = 0; w < 16; ++w) v += sm.nVert[w];
+    if (v) atomicAdd(&ctr->shade_vertices, v);
+    if (blockIdx.x == 0) atomicAdd(&ctr->shade_items, (unsigned long long)nIn);
+  }
 }
 
 // One vertex of PathIntegrator.Li (path_integrator.dart:44-119).
@@ -662,11 +672,37 @@ DR_DEV void shade_count(TraceCounters* ctr, uint32_t nIn, uint32_t nVert) {
 #endif
 #define SHADE_BLOCK_OF(general) ((general) ? DR_SHADE_BLOCK_GEN : DR_SHADE_BLOCK)
 #define SHADE_WAVES_OF(general) ((general) ? DR_SHADE_WAVES_GEN : DR_SHADE_WAVES)
-template <bool ENV, bool QUAD>
+// LDS copy of the light tables (LdsLights) behind the queue-staging block of the dynamic LDS; a workgroup-wide copy + barrier.
+DR_DEV LdsLights stage_lights(const DScene& sc, unsigned char* dyn, size_t pushBytes) {
+  uint32_t* dst = (uint32_t*)(dyn + pushBytes);
+  const uint32_t nL = sc.nlights * (uint32_t)(sizeof(DLight) / 4), nT = sc.nltris * (uint32_t)(sizeof(DLightTri) / 4), nC = sc.ncdf;
+  const uint32_t* srcL = (const uint32_t*)sc.lights;
+  const uint32_t* srcT = (const uint32_t*)sc.ltris;
+  const uint32_t* srcC = (const uint32_t*)sc.lcdf;
+  for (uint32_t i = threadIdx.x; i < nL; i += blockDim.x) dst[i] = srcL[i];
+  for (uint32_t i = threadIdx.x; i < nT; i += blockDim.x) dst[nL + i] = srcT[i];
+  for (uint32_t i = threadIdx.x; i < nC; i += blockDim.x) dst[nL + nT + i] = srcC[i];
+  __syncthreads();
+  LdsLights lv;
+  lv.lights = (lds_cu32*)dst;
+  lv.ltris = (lds_cu32*)(dst + nL);
+  lv.lcdf = (lds_cu32*)(dst + nL + nT);
+  return lv;
+}
+inline size_t light_table_bytes(const DScene& sc) {
+  return (size_t)sc.nlights * sizeof(DLight) + (size_t)sc.nltris * sizeof(DLightTri) + (size_t)sc.ncdf * 4;
+}
+#define DR_LDS_LIGHT_BYTES (32 * 1024)  // tables up to this size are staged in LDS (the queue staging takes ~96 KB of the 160)
+
+template <bool ENV, bool QUAD, bool LLDS>
 __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
   PushCtx pctx = {{0, 0, 0, 0}, 0};
+  using LV = typename std::conditional<LLDS, LdsLights, GlobalLights>::type;
+  LV lv;
+  if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD)));
+  else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf};
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -676,13 +712,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   // shading code is waited for at its first load; issued after it, it costs 16 spilled registers).
   const uint32_t tid0 = blockIdx.x * blockDim.x + threadIdx.x;
   auto slotOf = [&](uint32_t i) -> uint32_t { return i < nIn ? (q.activeIn ? q.activeIn[i] : i) : 0u; };
-  uint32_t nVert = 0;  // path vertices this thread set up (DrRenderStats.shade_vertices)
+  shade_count_init(s_push);
   for (uint32_t it = 0; it < nIter; ++it) {
     ShadeIn cur;
     load_shade_in<QUAD>(st, rp, bounce, slotOf(it * stride + tid0), it * stride + tid0 < nIn, &cur);
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
-    bool pushCont = false;
+    bool pushCont = false, vert = false;
     if (valid) {
       const uint32_t flags = cur.flags;
       const int hprimIn = cur.hprim;
@@ -696,7 +732,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       auto su = [&](int k) -> float { return sv_value(st, cur.raw[k], cur.scr[k], k >= 2 && k < 8 && (k & 1)); };
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
-        C3 Ld = resolve_nee<ENV, QUAD>(sc, st, slot, flags, shOccIn, Ld1In);
+        C3 Ld = resolve_nee<ENV, QUAD>(sc, lv, st, slot, flags, shOccIn, Ld1In);
         C3 tot = cmulD(Ld, (double)rp.nLights);  // integrator.dart:113-116
         L = cadd(L, cmul(betaNeeIn, tot));
       }
@@ -729,7 +765,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         }
         const F3 wo = vneg(d);
         if (bounce == 0 || (QUAD && (flags & PF_SPECULAR))) {  // bounces == 0 || specularBounce (path_integrator.dart:46)
-          C3 Le = tr.light >= 0 ? light_L(sc.lights[tr.light], dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
+          C3 Le = tr.light >= 0 ? light_L(lv.light(tr.light), dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
           L = cadd(L, cmul(beta, Le));
         }
         Bsdf bsdf = make_bsdf<QUAD>(sc, dgs, tr.mat);
@@ -758,7 +794,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           }
           int lightNum = (int)floor(lu * rp.nLights);
           lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
-          pf |= setup_nee<ENV, QUAD, (ENV && !QUAD)>(sc, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc);
+          pf |= setup_nee<ENV, QUAD, (ENV && !QUAD)>(sc, lv, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc);
           stc(st.betaNee(), cap, slot, beta);
         }
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
@@ -794,34 +830,37 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         }
         st3(st.ro(), cap, slot, p);
         st.rtmin()[TD(cap, slot)] = eps;
-        ++nVert;
+        vert = true;
       }
       stc(st.L(), cap, slot, L);
       st.flags()[TI(cap, slot)] = pf;
     }
-    stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT);
+    stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT, vert);
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
-      stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont, &q.ctr->shade_mis,
-                  &q.ctr->shade_shadow);
+      stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);
   }
-  shade_count(q.ctr, nIn, nVert);
+  shade_count(s_push, q.ctr, nIn);
 }
 
 // DirectLightingIntegrator.Li with strategy "all" (direct_lighting_integrator.dart:30-68;
 // integrator.dart:39-77).  Stage s sets up EstimateDirect call s of UniformSampleAllLights (rp.dstages[s]:
 // sample j of light i) at the camera hit and folds in the result of call s-1; the last stage finishes the
 // sum.  st.betaNee() carries the current light's Ld, st.beta() the running L of UniformSampleAllLights.
-template <bool QUAD>
+template <bool QUAD, bool LLDS>
 __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
   PushCtx pctx = {{0, 0, 0, 0}, 0};
+  using LV = typename std::conditional<LLDS, LdsLights, GlobalLights>::type;
+  LV lv;
+  if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD)));
+  else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf};
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
   const int nCalls = rp.nDirectStages;
-  uint32_t nVert = 0;
+  shade_count_init(s_push);
   DirectStage prev{}, cur{};
   if (stage > 0) prev = rp.dstages[stage - 1];
   if (stage < nCalls) cur = rp.dstages[stage];
@@ -858,7 +897,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           } else {
             tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
           }
-          C3 Le = tr.light >= 0 ? light_L(sc.lights[tr.light], dg.nn, wo) : C3{0.f, 0.f, 0.f};
+          C3 Le = tr.light >= 0 ? light_L(lv.light(tr.light), dg.nn, wo) : C3{0.f, 0.f, 0.f};
           L = cadd(L, Le);
           Lall = C3{0.f, 0.f, 0.f};
           st3(st.ro(), cap, slot, dg.p);
@@ -869,7 +908,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
           dg.p = ld3(st.ro(), cap, slot);
           Ld = ldc(st.betaNee(), cap, slot);
-          Ld = cadd(Ld, resolve_nee<true, QUAD>(sc, st, slot, flags, st.shOcc()[TI(cap, slot)], ldc(st.Ld1(), cap, slot)));  // Ld += EstimateDirect
+          Ld = cadd(Ld, resolve_nee<true, QUAD>(sc, lv, st, slot, flags, st.shOcc()[TI(cap, slot)], ldc(st.Ld1(), cap, slot)));  // Ld += EstimateDirect
           if (prev.last) {
             Lall = cadd(Lall, cdivD(Ld, (double)prev.n));  // L += Ld / nSamples
             Ld = C3{0.f, 0.f, 0.f};
@@ -887,7 +926,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           double lsc = sv_one(rp, st, slot, cur.lc);
           double ls0 = l0, ls1 = l1, bs0 = b0, bs1 = b1;
           double bsc = QUAD ? (double)sv_one(rp, st, slot, cur.bc) : 0.0;
-          pf |= setup_nee<true, QUAD>(sc, st, slot, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
+          pf |= setup_nee<true, QUAD, false>(sc, lv, st, slot, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
           again = true;
         } else {
           if (rp.nLights > 0) L = cadd(L, Lall);
@@ -905,13 +944,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       }
       st.flags()[TI(cap, slot)] = pf;
     }
-    stage_push(s_push, pctx, false, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, again, slot, Q_MIS_BIT);
+    stage_push(s_push, pctx, false, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, again, slot, Q_MIS_BIT, again);
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
-      stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont, &q.ctr->shade_mis,
-                  &q.ctr->shade_shadow);
-    if (again) ++nVert;
+      stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);
   }
-  shade_count(q.ctr, nIn, nVert);
+  shade_count(s_push, q.ctr, nIn);
 }
 
 // ---------------------------------------------------------------------------
@@ -1024,10 +1061,18 @@ __global__ void k_film_resolve(const float* film, int64_t npix, float* rgb) {
   rgb[3 * p + 2] = (float)((double)b + 0.0);
 }
 
-// float4 copy: the measured HBM-bandwidth denominator of the roofline.
+// float4 copy: the measured HBM-bandwidth denominator of the roofline.  Four independent 16-byte loads per lane are
+// in flight before the first store (one load per lane leaves the memory pipeline half empty: 4.8 instead of ~6 TB/s).
 __global__ void __launch_bounds__(256) k_copy(const float4* __restrict__ src, float4* __restrict__ dst, uint64_t n4) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a;
+    dst[i + stride] = b;
+    dst[i + 2 * stride] = c;
+    dst[i + 3 * stride] = d;
+  }
   for (; i < n4; i += stride) dst[i] = src[i];
 }
 
@@ -1086,27 +1131,47 @@ void launch_transpose_samples(const float* aos, int stride, const BatchState& st
 void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) {
   hipLaunchKernelGGL(k_raygen, dim3((st.nslots + 255) / 256), dim3(256), 0, s, rp, st);
 }
-// The shade kernels stage their queue entries in dynamic LDS (PushStage, dr_wave.h): ~96 KB of the CU's 160 KB.
+// The shade kernels stage their queue entries in dynamic LDS (PushStage, dr_wave.h): ~96 KB of the CU's 160 KB; the
+// light tables follow when they are small (LLDS instantiations).
 template <auto kernel, int BLOCK, class... A>
-static void launch_shade(int grid, hipStream_t s, A... args) {
-  const size_t lds = push_stage_bytes(BLOCK);
-  static bool attrSet = false;  // one instance of this template, hence one flag, per kernel
-  if (!attrSet) {
+static void launch_shade(int grid, size_t extraLds, hipStream_t s, A... args) {
+  const size_t lds = push_stage_bytes(BLOCK) + extraLds;
+  static size_t attrSet = 0;  // one instance of this template, hence one value, per kernel
+  if (attrSet < lds) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attrSet = true;
+    attrSet = lds;
   }
   hipLaunchKernelGGL(kernel, dim3(DR_SHADE_GRID(grid)), dim3(BLOCK), lds, s, args...);
 }
+static bool lightsInLds(const DScene& sc) {
+  static const bool off = getenv("DARTRAY_LDS_LIGHTS") && atoi(getenv("DARTRAY_LDS_LIGHTS")) == 0;  // A/B runs
+  return !off && sc.nlights > 0 && light_table_bytes(sc) <= DR_LDS_LIGHT_BYTES;
+}
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec || sc.srec) launch_shade<k_shade_path<true, true>, SHADE_BLOCK_OF(true)>(grid, s, sc, rp, st, q, bounce);
-  else if (sc.hasEnv) launch_shade<k_shade_path<true, false>, SHADE_BLOCK_OF(false)>(grid, s, sc, rp, st, q, bounce);
-  else launch_shade<k_shade_path<false, false>, SHADE_BLOCK_OF(false)>(grid, s, sc, rp, st, q, bounce);
+  const bool gen = sc.nquads || sc.hasSpec || sc.srec;
+  if (lightsInLds(sc)) {
+    const size_t x = light_table_bytes(sc);
+    if (gen) launch_shade<k_shade_path<true, true, true>, SHADE_BLOCK_OF(true)>(grid, x, s, sc, rp, st, q, bounce);
+    else if (sc.hasEnv) launch_shade<k_shade_path<true, false, true>, SHADE_BLOCK_OF(false)>(grid, x, s, sc, rp, st, q, bounce);
+    else launch_shade<k_shade_path<false, false, true>, SHADE_BLOCK_OF(false)>(grid, x, s, sc, rp, st, q, bounce);
+  } else {
+    if (gen) launch_shade<k_shade_path<true, true, false>, SHADE_BLOCK_OF(true)>(grid, 0, s, sc, rp, st, q, bounce);
+    else if (sc.hasEnv) launch_shade<k_shade_path<true, false, false>, SHADE_BLOCK_OF(false)>(grid, 0, s, sc, rp, st, q, bounce);
+    else launch_shade<k_shade_path<false, false, false>, SHADE_BLOCK_OF(false)>(grid, 0, s, sc, rp, st, q, bounce);
+  }
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
-  if (sc.nquads || sc.hasSpec || sc.srec) launch_shade<k_shade_direct<true>, SHADE_BLOCK_OF(true)>(grid, s, sc, rp, st, q, stage);
-  else launch_shade<k_shade_direct<false>, SHADE_BLOCK_OF(false)>(grid, s, sc, rp, st, q, stage);
+  const bool gen = sc.nquads || sc.hasSpec || sc.srec;
+  if (lightsInLds(sc)) {
+    const size_t x = light_table_bytes(sc);
+    if (gen) launch_shade<k_shade_direct<true, true>, SHADE_BLOCK_OF(true)>(grid, x, s, sc, rp, st, q, stage);
+    else launch_shade<k_shade_direct<false, true>, SHADE_BLOCK_OF(false)>(grid, x, s, sc, rp, st, q, stage);
+  } else {
+    if (gen) launch_shade<k_shade_direct<true, false>, SHADE_BLOCK_OF(true)>(grid, 0, s, sc, rp, st, q, stage);
+    else launch_shade<k_shade_direct<false, false>, SHADE_BLOCK_OF(false)>(grid, 0, s, sc, rp, st, q, stage);
+  }
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
                  hipStream_t s) {

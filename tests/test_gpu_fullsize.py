@@ -36,8 +36,10 @@ def test_c3_rank0_share_of_eight_tile_shards(ob, gpu):
     # the sampler window is 4097 wide: 129 tile columns (image_film.dart:247-252), tiles dealt over the window
     owned = ((ty * 129 + tx) % 8) == 0
     assert owned.sum() * 1024 == st["film_samples"]
-    assert np.all(w[~owned] <= 8) and np.mean(w[~owned] == 0) > 0.9999   # only integral-imageX splats of a neighbour tile
-    assert np.mean(w[owned] == 1024) > 0.9999 and abs(float(w[owned].sum()) - owned.sum() * 1024.0) <= 4096
+    # (a sample whose imageX is integral lands in two pixels, image_film.dart:101-115: with 1024 samples per pixel
+    # about one pixel in 8000 has one, so a few pixels carry 1023 / 1025 and a neighbour tile's border pixel 1)
+    assert np.all(w[~owned] <= 8) and np.mean(w[~owned] == 0) > 0.999
+    assert np.mean(w[owned] == 1024) > 0.999 and abs(float(w[owned].sum()) - owned.sum() * 1024.0) <= 3.0e-4 * owned.sum()
     assert st["batches"] >= 8
     assert np.isfinite(out.rgb).all() and out.rgb.min() >= 0
     assert np.all(out.film[..., :3][w == 0] == 0)
