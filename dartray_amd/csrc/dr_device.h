@@ -592,6 +592,8 @@ struct GlobalLights {
   const DLight* lights;
   const DLightTri* ltris;
   const float* lcdf;
+  const float4* mats;
+  DR_DEV float4 mat(uint32_t m, int k) const { return mats[4 * (size_t)m + k]; }  // k-th float4 of material m's record
   DR_DEV DLight light(int i) const { return lights[i]; }
   DR_DEV DLightTri ltri(uint32_t i) const { return ltris[i]; }
   DR_DEV float cdf(uint32_t i) const { return lcdf[i]; }
@@ -612,6 +614,13 @@ struct LdsLights {
   lds_cu32* lights;
   lds_cu32* ltris;
   lds_cu32* lcdf;
+  lds_cu32* mats;          // null: the material table is too large for LDS, read it from global memory
+  const float4* gmats;
+  DR_DEV float4 mat(uint32_t m, int k) const {
+    if (!mats) return gmats[4 * (size_t)m + k];
+    lds_cu32* p = mats + 16 * (size_t)m + 4 * k;
+    return make_float4(__uint_as_float(p[0]), __uint_as_float(p[1]), __uint_as_float(p[2]), __uint_as_float(p[3]));
+  }
   DR_DEV DLight light(int i) const { return lds_read_struct<DLight>(lights, (uint32_t)i); }
   DR_DEV DLightTri ltri(uint32_t i) const { return lds_read_struct<DLightTri>(ltris, i); }
   DR_DEV float cdf(uint32_t i) const { return __uint_as_float(lcdf[i]); }
@@ -894,24 +903,23 @@ struct Bsdf {
 DR_DEV bool lambert_matches(int flags) { return (LAMBERT_TYPE & flags) == LAMBERT_TYPE; }
 DR_DEV C3 clamp0(float4 m) { return C3{m.x < 0.f ? 0.f : m.x, m.y < 0.f ? 0.f : m.y, m.z < 0.f ? 0.f : m.z}; }
 // Material record: 4 x float4 = (Kd, sigma) (Kr, type) (Kt, -) (index as the two halves of a double, -, -)
-template <bool GEN>
-DR_DEV Bsdf make_bsdf(const DScene& sc, const DGeo& dg, uint32_t mat) {
+template <bool GEN, class LV>
+DR_DEV Bsdf make_bsdf(const LV& lv, const DGeo& dg, uint32_t mat) {
   Bsdf b;
   b.p = dg.p;
   b.nn = dg.nn;
   b.ng = dg.nn;
   b.sn = vnormalize(dg.dpdu);  // bsdf.dart:45-51
   b.tn = vcross(b.nn, b.sn);
-  const float4* mp = sc.mats + 4 * (size_t)mat;
   // Kd.evaluate(dgs).clamp() (matte_material.dart:54)
-  C3 r = clamp0(mp[0]);
+  C3 r = clamp0(lv.mat(mat, 0));
   b.R = r;
   b.nBxDFs = cblack(r) ? 0 : 1;
   b.mtype = DR_MATERIAL_MATTE;
   b.on = false;
   b.glossy = false;
   if (GEN) {
-    const float4 m1 = mp[1], m3 = mp[3];
+    const float4 m1 = lv.mat(mat, 1), m3 = lv.mat(mat, 3);
     b.mtype = (int)__float_as_uint(m1.w);
     if (b.mtype == DR_MATERIAL_MATTE) {
       double sig = __hiloint2double((int)__float_as_uint(m3.w), (int)__float_as_uint(m3.z));
@@ -931,7 +939,7 @@ DR_DEV Bsdf make_bsdf(const DScene& sc, const DGeo& dg, uint32_t mat) {
       b.bexp = e;
       b.mtype = DR_MATERIAL_MATTE;  // non-specular: shaded through bsdf_f / bsdf_pdf / bsdf_sample_f
     } else {
-      const float4 m2 = mp[2];
+      const float4 m2 = lv.mat(mat, 2);
       b.nBxDFs = 0;
       b.R = C3{0.f, 0.f, 0.f};
       b.Kr = clamp0(m1);

@@ -79,6 +79,15 @@ DR_DEV float Sobol2(uint32_t n, uint32_t scramble) {
   return (float)(scramble >> 8) * 5.9604644775390625e-8f;
 }
 
+// the same with the low-byte table read from LDS (the shade kernels copy it there: shade_count_init)
+DR_DEV float Sobol2_lds(const uint32_t* tab, uint32_t n, uint32_t scramble) {
+  scramble ^= tab[n & 255u];
+  n >>= 8;
+  for (uint32_t v = c_sobol.v8; n != 0; n >>= 1, v ^= v >> 1)
+    if (n & 1u) scramble ^= v;
+  return (float)(scramble >> 8) * 5.9604644775390625e-8f;
+}
+
 // ---- camera-sample vector access (see BatchState): float form or compact (index, scramble) form ----
 // LD block of float field f (Appendix B layout: image, lens, time, n1D 1-D slots, then the 2-D slots)
 DR_DEV int sv_block(const RenderParams& rp, int f) {
@@ -636,6 +645,7 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
 // per workgroup at the end of a shade kernel
 DR_DEV void shade_count_init(PushStage& sm) {
   if (threadIdx.x < 16) sm.nVert[threadIdx.x] = 0;
+  if (threadIdx.x < 256) sm.sobol[threadIdx.x] = c_sobol.lo[threadIdx.x];
   __syncthreads();
 }
 DR_DEV void shade_count(PushStage& sm, TraceCounters* ctr, uint32_t nIn) {
@@ -672,27 +682,38 @@ DR_DEV void shade_count(PushStage& sm, TraceCounters* ctr, uint32_t nIn) {
 #endif
 #define SHADE_BLOCK_OF(general) ((general) ? DR_SHADE_BLOCK_GEN : DR_SHADE_BLOCK)
 #define SHADE_WAVES_OF(general) ((general) ? DR_SHADE_WAVES_GEN : DR_SHADE_WAVES)
-// LDS copy of the light tables (LdsLights) behind the queue-staging block of the dynamic LDS; a workgroup-wide copy + barrier.
+// LDS copy of the light tables and (when it is small too) the material table, behind the queue-staging block of the
+// dynamic LDS; a workgroup-wide copy + barrier.
+#define DR_LDS_LIGHT_BYTES (24 * 1024)  // light tables up to this size are staged in LDS (the queue staging takes ~96 KB of the 160)
+#define DR_LDS_MAT_BYTES (24 * 1024)    // likewise the material table (64 B per material)
+__host__ __device__ inline size_t light_table_bytes(const DScene& sc) {
+  return (size_t)sc.nlights * sizeof(DLight) + (size_t)sc.nltris * sizeof(DLightTri) + (size_t)sc.ncdf * 4;
+}
+__host__ __device__ inline size_t mat_table_bytes(const DScene& sc) {
+  const size_t b = (size_t)sc.nmats * 64;
+  return b <= DR_LDS_MAT_BYTES ? b : 0;
+}
 DR_DEV LdsLights stage_lights(const DScene& sc, unsigned char* dyn, size_t pushBytes) {
   uint32_t* dst = (uint32_t*)(dyn + pushBytes);
   const uint32_t nL = sc.nlights * (uint32_t)(sizeof(DLight) / 4), nT = sc.nltris * (uint32_t)(sizeof(DLightTri) / 4), nC = sc.ncdf;
+  const uint32_t nM = (uint32_t)(mat_table_bytes(sc) / 4);
   const uint32_t* srcL = (const uint32_t*)sc.lights;
   const uint32_t* srcT = (const uint32_t*)sc.ltris;
   const uint32_t* srcC = (const uint32_t*)sc.lcdf;
+  const uint32_t* srcM = (const uint32_t*)sc.mats;
   for (uint32_t i = threadIdx.x; i < nL; i += blockDim.x) dst[i] = srcL[i];
   for (uint32_t i = threadIdx.x; i < nT; i += blockDim.x) dst[nL + i] = srcT[i];
   for (uint32_t i = threadIdx.x; i < nC; i += blockDim.x) dst[nL + nT + i] = srcC[i];
+  for (uint32_t i = threadIdx.x; i < nM; i += blockDim.x) dst[nL + nT + nC + i] = srcM[i];
   __syncthreads();
   LdsLights lv;
   lv.lights = (lds_cu32*)dst;
   lv.ltris = (lds_cu32*)(dst + nL);
   lv.lcdf = (lds_cu32*)(dst + nL + nT);
+  lv.mats = nM ? (lds_cu32*)(dst + nL + nT + nC) : (lds_cu32*)nullptr;
+  lv.gmats = sc.mats;
   return lv;
 }
-inline size_t light_table_bytes(const DScene& sc) {
-  return (size_t)sc.nlights * sizeof(DLight) + (size_t)sc.nltris * sizeof(DLightTri) + (size_t)sc.ncdf * 4;
-}
-#define DR_LDS_LIGHT_BYTES (32 * 1024)  // tables up to this size are staged in LDS (the queue staging takes ~96 KB of the 160)
 
 template <bool ENV, bool QUAD, bool LLDS>
 __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
@@ -702,7 +723,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   using LV = typename std::conditional<LLDS, LdsLights, GlobalLights>::type;
   LV lv;
   if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD)));
-  else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf};
+  else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf, sc.mats};
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -713,9 +734,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   const uint32_t tid0 = blockIdx.x * blockDim.x + threadIdx.x;
   auto slotOf = [&](uint32_t i) -> uint32_t { return i < nIn ? (q.activeIn ? q.activeIn[i] : i) : 0u; };
   shade_count_init(s_push);
+  // the NEXT iteration's active-list entry is fetched one iteration ahead (one register): the entry -> slot state ->
+  // primitive record chain of dependent round trips loses its first link
+  uint32_t slotNext = slotOf(tid0);
   for (uint32_t it = 0; it < nIter; ++it) {
     ShadeIn cur;
-    load_shade_in<QUAD>(st, rp, bounce, slotOf(it * stride + tid0), it * stride + tid0 < nIn, &cur);
+    const uint32_t slotCur = slotNext;
+    slotNext = slotOf((it + 1) * stride + tid0);
+    load_shade_in<QUAD>(st, rp, bounce, slotCur, it * stride + tid0 < nIn, &cur);
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
     bool pushCont = false, vert = false;
@@ -729,7 +755,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       const C3 betaNeeIn = cur.betaNee;
       const C3 Ld1In = cur.Ld1;
       const F3 o = cur.o, d = cur.d;
-      auto su = [&](int k) -> float { return sv_value(st, cur.raw[k], cur.scr[k], k >= 2 && k < 8 && (k & 1)); };
+      auto su = [&](int k) -> float {
+        if (st.svFloat) return __uint_as_float(cur.raw[k]);
+        return (k >= 2 && k < 8 && (k & 1)) ? Sobol2_lds(s_push.sobol, cur.raw[k], cur.scr[k]) : VanDerCorput(cur.raw[k], cur.scr[k]);
+      };
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
         C3 Ld = resolve_nee<ENV, QUAD>(sc, lv, st, slot, flags, shOccIn, Ld1In);
@@ -768,7 +797,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           C3 Le = tr.light >= 0 ? light_L(lv.light(tr.light), dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
           L = cadd(L, cmul(beta, Le));
         }
-        Bsdf bsdf = make_bsdf<QUAD>(sc, dgs, tr.mat);
+        Bsdf bsdf = make_bsdf<QUAD>(lv, dgs, tr.mat);
         bsdf.ng = dg.nn;  // BSDF(dgs, dgGeom.nn)
         const F3 p = bsdf.p, n = bsdf.nn;
         const double eps = (isQuad ? 5.0e-4 : 1.0e-3) * t;  // triangle.dart:157; sphere.dart:169, disk.dart:98
@@ -854,7 +883,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   using LV = typename std::conditional<LLDS, LdsLights, GlobalLights>::type;
   LV lv;
   if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD)));
-  else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf};
+  else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf, sc.mats};
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -917,7 +946,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         if (stage < nCalls) {
           if (hasRec && (sr.flags & (DR_SHADING_N | DR_SHADING_S))) shading_geometry(sc, sr, tr.reverse, dg, &dgs);
           else dgs = dg;
-          Bsdf bsdf = make_bsdf<QUAD>(sc, dgs, tr.mat);  // mirror / glass are refused for DirectLighting; Oren-Nayar is not
+          Bsdf bsdf = make_bsdf<QUAD>(lv, dgs, tr.mat);  // mirror / glass are refused for DirectLighting; Oren-Nayar is not
           bsdf.ng = dg.nn;
           // sample slots of this call (direct_lighting_integrator.dart:70-87)
           float l0, l1, b0, b1;
@@ -1151,7 +1180,7 @@ void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchStat
                        int grid, hipStream_t s) {
   const bool gen = sc.nquads || sc.hasSpec || sc.srec;
   if (lightsInLds(sc)) {
-    const size_t x = light_table_bytes(sc);
+    const size_t x = light_table_bytes(sc) + mat_table_bytes(sc);
     if (gen) launch_shade<k_shade_path<true, true, true>, SHADE_BLOCK_OF(true)>(grid, x, s, sc, rp, st, q, bounce);
     else if (sc.hasEnv) launch_shade<k_shade_path<true, false, true>, SHADE_BLOCK_OF(false)>(grid, x, s, sc, rp, st, q, bounce);
     else launch_shade<k_shade_path<false, false, true>, SHADE_BLOCK_OF(false)>(grid, x, s, sc, rp, st, q, bounce);
@@ -1165,7 +1194,7 @@ void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchSt
                          int grid, hipStream_t s) {
   const bool gen = sc.nquads || sc.hasSpec || sc.srec;
   if (lightsInLds(sc)) {
-    const size_t x = light_table_bytes(sc);
+    const size_t x = light_table_bytes(sc) + mat_table_bytes(sc);
     if (gen) launch_shade<k_shade_direct<true, true>, SHADE_BLOCK_OF(true)>(grid, x, s, sc, rp, st, q, stage);
     else launch_shade<k_shade_direct<false, true>, SHADE_BLOCK_OF(false)>(grid, x, s, sc, rp, st, q, stage);
   } else {
