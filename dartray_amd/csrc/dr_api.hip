@@ -1342,6 +1342,7 @@ int dr_get_stats(DrScene* sc, DrRenderStats* out) {
     sc->stats.shade_cont = c.shade_cont; sc->stats.shade_mis = c.shade_mis; sc->stats.shade_shadow = c.shade_shadow;
     sc->foldEvents();
     sc->statsPending = false;
+    shade_prof_dump();
   }
   *out = sc->stats;
   return DR_OK;

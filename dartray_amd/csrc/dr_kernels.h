@@ -65,10 +65,15 @@ struct RenderParams {
 // per memory access.
 enum {
   F_RTMIN = 0, F_HT = 2, F_SHTMAX = 4,
-  F_RO = 6, F_RO0 = 9, F_RD = 12, F_BETA = 15, F_L = 18, F_BETANEE = 21, F_SHD = 24, F_LD1 = 27, F_MISD = 30, F_LD2 = 33,
-  F_HPRIM = 36, F_SHOCC = 37, F_MISLIGHT = 38, F_MISPRIM = 39, F_FLAGS = 40,
+  F_RO = 6, F_RD = 9, F_BETA = 12, F_L = 15, F_BETANEE = 18, F_SHD = 21, F_LD1 = 24, F_MISD = 27, F_LD2 = 30,
+  F_HPRIM = 33, F_SHOCC = 34, F_MISLIGHT = 35, F_MISPRIM = 36, F_FLAGS = 37,
+  F_RO0 = 38,     // (DirectLighting with quadrics / shading records only: outside the window below)
   F_SAMPLES = 41  // == DR_STATE_WORDS
 };
+// The 32 runs F_RO .. F_FLAGS are exactly 8 KiB: the whole signed 13-bit immediate-offset window of a global_load /
+// global_store around ONE per-lane base address (SlotRef below), so the shade kernels reach every hot field of a slot
+// without any per-access address arithmetic.
+#define SLOT_BIAS (F_RO * 256 + 4096)
 struct BatchState {
   uint32_t cap;     // slots allocated (a multiple of 64)
   uint32_t nslots;  // slots used by the current batch
@@ -117,6 +122,39 @@ struct TraceCounters {  // device-side totals (Stats probes of bvh_accel.dart:10
   unsigned long long shade_items, shade_vertices, shade_cont, shade_mis, shade_shadow;
 };
 
+// A slot's place in the tiled state: `a` addresses its element of the 4-byte fields (biased by SLOT_BIAS so that
+// field F sits at the compile-time offset F * 256 - SLOT_BIAS, within +-4 KiB for F_RO .. F_FLAGS), `b` its element
+// of the 8-byte fields (F_RTMIN, F_HT, F_SHTMAX at b + F * 256).  Round 1 indexed every field array separately,
+// `field()[TI(stride, slot)]`: ~40 scalar base pointers (spilled to VGPR lanes: two v_readlane per access) and a
+// 64-bit shift-add per access -- about a sixth of the shade kernel's VALU instructions.
+struct SlotRef {
+  char* a;
+  char* b;
+  DR_DEV static SlotRef of(const BatchState& st, uint32_t slot) {
+    char* tile = (char*)st.tiles + (size_t)(slot >> 6) * ((size_t)st.tileStride * 4);
+    SlotRef r;
+    r.a = tile + (slot & 63u) * 4 + SLOT_BIAS;
+    r.b = tile + (slot & 63u) * 8;
+    return r;
+  }
+  template <int F> DR_DEV float& f32(int comp = 0) const { return *(float*)(a + ((F + comp) * 256 - SLOT_BIAS)); }
+  template <int F> DR_DEV int32_t& i32() const { return *(int32_t*)(a + (F * 256 - SLOT_BIAS)); }
+  template <int F> DR_DEV uint32_t& u32() const { return *(uint32_t*)(a + (F * 256 - SLOT_BIAS)); }
+  template <int F> DR_DEV double& f64() const { return *(double*)(b + F * 256); }
+};
+template <int F> DR_DEV F3 ld3f(const SlotRef& r) { return F3{LDS_STREAM(&r.f32<F>(0)), LDS_STREAM(&r.f32<F>(1)), LDS_STREAM(&r.f32<F>(2))}; }
+template <int F> DR_DEV C3 ldcf(const SlotRef& r) { return C3{LDS_STREAM(&r.f32<F>(0)), LDS_STREAM(&r.f32<F>(1)), LDS_STREAM(&r.f32<F>(2))}; }
+template <int F> DR_DEV void st3f(const SlotRef& r, F3 v) {
+  STS_STREAM(&r.f32<F>(0), v.x);
+  STS_STREAM(&r.f32<F>(1), v.y);
+  STS_STREAM(&r.f32<F>(2), v.z);
+}
+template <int F> DR_DEV void stcf(const SlotRef& r, C3 v) {
+  STS_STREAM(&r.f32<F>(0), v.r);
+  STS_STREAM(&r.f32<F>(1), v.g);
+  STS_STREAM(&r.f32<F>(2), v.b);
+}
+
 // Work queues of one stage.  Counts live in device memory so that no host
 // round trip is needed between launches.
 struct StageQueues {
@@ -155,5 +193,6 @@ void launch_film(const RenderParams& rp, const BatchState& st, const float* filt
                  hipStream_t s);
 void launch_film_resolve(const float* film, int64_t npix, float* rgb, hipStream_t s);
 void launch_copy(const float4* src, float4* dst, uint64_t n4, hipStream_t s);
+void shade_prof_dump();  // -DDR_SHADE_PROF builds only: prints and clears the per-phase cycle sums of k_shade_path
 
 #endif

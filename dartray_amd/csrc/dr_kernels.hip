@@ -419,27 +419,26 @@ __global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) 
 // ENV: the scene has an InfiniteAreaLight (compiled out otherwise: the area-light-only path keeps its registers)
 // QUAD: the scene has sphere / disk primitives (likewise)
 template <bool ENV, bool QUAD, class LV>
-DR_DEV C3 resolve_nee(const DScene& sc, const LV& lv, const BatchState& st, uint32_t slot, uint32_t flags, int shOcc, C3 Ld1) {
-  const uint32_t cap = st.tileStride;  // words per 64-slot tile
+DR_DEV C3 resolve_nee(const DScene& sc, const LV& lv, const SlotRef& sr, uint32_t flags, int shOcc, C3 Ld1) {
   C3 Ld = C3{0.f, 0.f, 0.f};
   if ((flags & PF_HAS_SH) && shOcc == 0) Ld = cadd(Ld, Ld1);
   if (flags & PF_HAS_MIS) {
-    const int prim = st.misPrim()[TI(cap, slot)];
-    const int li = st.misLight()[TI(cap, slot)];
+    const int prim = sr.i32<F_MISPRIM>();
+    const int li = sr.i32<F_MISLIGHT>();
     if (ENV && lv.light(li).kind == DR_LIGHT_INFINITE) {
       // the MIS ray escaped: Li = light.Le(ray) (integrator.dart:173-175), folded into Ld2 at set-up
-      if (prim < 0) Ld = cadd(Ld, ldc(st.Ld2(), cap, slot));
+      if (prim < 0) Ld = cadd(Ld, ldcf<F_LD2>(sr));
     } else if (prim >= 0) {
       Tri tr = load_tri(sc, (uint32_t)prim);
       if (tr.light == li) {  // lightIsect.primitive.getAreaLight() == light (integrator.dart:170-172)
-        const F3 wi = ld3(st.misD(), cap, slot);
+        const F3 wi = ld3f<F_MISD>(sr);
         DGeo dg;
         if (QUAD && tr.kind) {
           // dg.nn of a quadric depends on the hit point: repeat the (deterministic) test of the MIS ray
           const DQuadric& qd = sc.quads[tr.quad];
           double th;
           F3 phit;
-          (void)quadric_hit(qd, ld3(st.ro(), cap, slot), wi, st.rtmin()[TD(cap, slot)], DR_INF, &th, &phit);
+          (void)quadric_hit(qd, ld3f<F_RO>(sr), wi, sr.f64<F_RTMIN>(), DR_INF, &th, &phit);
           quadric_dg(qd, phit, &dg);
         } else if (QUAD && sc.srec && (__float_as_uint(sc.srec[7 * (size_t)prim + 6].x) & DR_SHADING_UV)) {
           const ShadeRec sr = load_srec(sc, (uint32_t)prim);
@@ -448,7 +447,7 @@ DR_DEV C3 resolve_nee(const DScene& sc, const LV& lv, const BatchState& st, uint
           tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, wi, 0.0, &dg);  // only nn is used
         }
         C3 Li = light_L(lv.light(li), dg.nn, vneg(wi));
-        if (!cblack(Li)) Ld = cadd(Ld, ldc(st.Ld2(), cap, slot));
+        if (!cblack(Li)) Ld = cadd(Ld, ldcf<F_LD2>(sr));
       }
     }
   }
@@ -458,9 +457,8 @@ DR_DEV C3 resolve_nee(const DScene& sc, const LV& lv, const BatchState& st, uint
 // EstimateDirect up to the points where it must trace (integrator.dart:119-185):
 // writes the shadow ray / MIS ray and their candidate contributions.
 template <bool ENV, bool QUAD, bool NI, class LV>
-DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const BatchState& st, uint32_t slot, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
+DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const SlotRef& sr, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
                           F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1, double bsc) {
-  const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const DLight light = lv.light(lightNum);
   const int flags = BSDF_ALL & ~BSDF_SPECULAR;
   uint32_t pf = 0;
@@ -499,14 +497,14 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const BatchState& st, 
       C3 f = bsdf_f(bsdf, wo, wi, flags);
       if (!cblack(f)) {
         if (distant) {  // VisibilityTester.setRay(p, eps, wi)
-          st3(st.shD(), cap, slot, wi);
-          st.shTmax()[TD(cap, slot)] = DR_INF;
+          st3f<F_SHD>(sr, wi);
+          sr.f64<F_SHTMAX>() = DR_INF;
         } else {        // VisibilityTester.setSegment(p, eps, lightPos, 0)
           const double dist = vlen(seg);
-          st3(st.shD(), cap, slot, vdiv(seg, dist));
-          st.shTmax()[TD(cap, slot)] = dist * (1.0 - 0.0);
+          st3f<F_SHD>(sr, vdiv(seg, dist));
+          sr.f64<F_SHTMAX>() = dist * (1.0 - 0.0);
         }
-        stc(st.Ld1(), cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) / 1.0)));
+        stcf<F_LD1>(sr, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) / 1.0)));
         pf |= PF_HAS_SH;
       }
     }
@@ -530,16 +528,16 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const BatchState& st, 
         // VisibilityTester.setSegment (visibility_tester.dart:26-29)
         F3 seg = vsub(ps, p);
         double dist = vlen(seg);
-        st3(st.shD(), cap, slot, vdiv(seg, dist));
-        st.shTmax()[TD(cap, slot)] = dist * (1.0 - 1.0e-3);
+        st3f<F_SHD>(sr, vdiv(seg, dist));
+        sr.f64<F_SHTMAX>() = dist * (1.0 - 1.0e-3);
       } else {
         // VisibilityTester.setRay (visibility_tester.dart:31-33)
-        st3(st.shD(), cap, slot, wi);
-        st.shTmax()[TD(cap, slot)] = DR_INF;
+        st3f<F_SHD>(sr, wi);
+        sr.f64<F_SHTMAX>() = DR_INF;
       }
       double bsdfPdf = bsdf_pdf(bsdf, wo, wi, flags);
       double weight = PowerHeuristic(lightPdf, bsdfPdf);
-      stc(st.Ld1(), cap, slot, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) * weight / lightPdf)));
+      stcf<F_LD1>(sr, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) * weight / lightPdf)));
       pf |= PF_HAS_SH;
     }
   }
@@ -555,9 +553,9 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const BatchState& st, 
         // the radiance the MIS ray returns IF it reaches the light: Lemit of the sampled area light (its
         // front face is checked at resolve), or the map along wi2 if the ray escapes (light.Le(ray))
         C3 Lhit = infinite ? env_Le_x<NI>(sc.env, wi2) : C3{light.L[0], light.L[1], light.L[2]};
-        st3(st.misD(), cap, slot, wi2);
-        stc(st.Ld2(), cap, slot, cmulD(cmul(f, Lhit), (fabs(vdot(wi2, n)) * weight / bsdfPdf)));
-        st.misLight()[TI(cap, slot)] = lightNum;
+        st3f<F_MISD>(sr, wi2);
+        stcf<F_LD2>(sr, cmulD(cmul(f, Lhit), (fabs(vdot(wi2, n)) * weight / bsdfPdf)));
+        sr.i32<F_MISLIGHT>() = lightNum;
         pf |= PF_HAS_MIS;  // scene.intersect is called before `if (!Li.isBlack())` (integrator.dart:169-177)
       }
     }
@@ -606,29 +604,31 @@ struct ShadeIn {
   // bsdf dir, path dir, the two uComponents; evaluated when the item is shaded
   uint32_t raw[10], scr[10];
   bool valid;
+  SlotRef sr;
 };
 template <bool QUAD>
 DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int bounce, uint32_t slot, bool valid, ShadeIn* in) {
   in->valid = valid;
   in->slot = slot;
   if (!valid) return;
-  const uint32_t cap = st.tileStride;  // words per 64-slot tile
-  in->flags = bounce == 0 ? PF_HAS_CONT : st.flags()[TI(cap, slot)];
-  in->hprim = st.hprim()[TI(cap, slot)];
-  in->t = st.ht()[TD(cap, slot)];
+  const SlotRef sr = SlotRef::of(st, slot);
+  in->sr = sr;
+  in->flags = bounce == 0 ? PF_HAS_CONT : sr.u32<F_FLAGS>();
+  in->hprim = sr.i32<F_HPRIM>();
+  in->t = sr.f64<F_HT>();
   if (bounce == 0) {  // the camera vertex: nothing pending, pathThroughput = 1, L = 0 (k_raygen does not store them)
     in->shOcc = 0;
     in->L = in->betaNee = in->Ld1 = C3{0.f, 0.f, 0.f};
     in->beta = C3{1.f, 1.f, 1.f};
   } else {
-    in->shOcc = st.shOcc()[TI(cap, slot)];
-    in->L = ldc(st.L(), cap, slot);
-    in->beta = ldc(st.beta(), cap, slot);
-    in->betaNee = ldc(st.betaNee(), cap, slot);
-    in->Ld1 = ldc(st.Ld1(), cap, slot);
+    in->shOcc = sr.i32<F_SHOCC>();
+    in->L = ldcf<F_L>(sr);
+    in->beta = ldcf<F_BETA>(sr);
+    in->betaNee = ldcf<F_BETANEE>(sr);
+    in->Ld1 = ldcf<F_LD1>(sr);
   }
-  in->o = ld3(st.ro(), cap, slot);
-  in->d = ld3(st.rd(), cap, slot);
+  in->o = ld3f<F_RO>(sr);
+  in->d = ld3f<F_RD>(sr);
   if (bounce < 3) {
     sv_fetch1(rp, st, slot, 5 + 4 * bounce + 1, &in->raw[0], &in->scr[0]);
     sv_fetch1(rp, st, slot, 5 + 4 * bounce + 0, &in->raw[1], &in->scr[1]);
@@ -656,6 +656,48 @@ DR_DEV void shade_count(PushStage& sm, TraceCounters* ctr, uint32_t nIn) {
     if (blockIdx.x == 0) atomicAdd(&ctr->shade_items, (unsigned long long)nIn);
   }
 }
+
+// -DDR_SHADE_PROF: a diagnostic build that stamps s_memtime between the phases of k_shade_path and sums, per phase,
+// the cycles the waves spent there (tools/shade_prof.py prints them).  No stamp executes in the product build.
+#ifdef DR_SHADE_PROF
+__device__ unsigned long long g_shadeProf[16];
+DR_DEV unsigned long long prof_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define PROF_DECL                                                                     \
+  unsigned long long profT = prof_now();                                              \
+  if (lane_id() == 0)                                                                 \
+    for (int i_ = 0; i_ < 10; ++i_) s_push.prof[threadIdx.x >> 6][i_] = 0
+#define PROF(i)                                                   \
+  do {                                                            \
+    const unsigned long long n_ = prof_now();                     \
+    if (lane_id() == 0) s_push.prof[threadIdx.x >> 6][i] += n_ - profT; \
+    profT = n_;                                                   \
+  } while (0)
+#define PROF_FLUSH                                                                                  \
+  do {                                                                                              \
+    if (lane_id() == 0)                                                                             \
+      for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_shadeProf[i_], s_push.prof[threadIdx.x >> 6][i_]); \
+  } while (0)
+void shade_prof_dump() {
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shadeProf), sizeof(h)) != hipSuccess) return;
+  double tot = 0;
+  for (int i = 0; i < 10; ++i) tot += (double)h[i];
+  static const char* names[10] = {"state loads arrive", "resolve previous NEE", "primitive record + geometry + BSDF", "samples / RNG tail",
+                                  "(state loads issued)", "NEE: both halves", "continuation sample + RR", "stores", "queue push", "queue flush"};
+  for (int i = 0; i < 10; ++i) fprintf(stderr, "shade_prof %-38s %6.2f %%  (%.3g wave-cycles)\n", names[i], 100.0 * h[i] / tot, (double)h[i]);
+  for (int i = 0; i < 16; ++i) h[i] = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shadeProf), h, sizeof(h));
+}
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_FLUSH
+void shade_prof_dump() {}
+#endif
 
 // One vertex of PathIntegrator.Li (path_integrator.dart:44-119).
 // Launch shape (measured): ONE 768-thread workgroup per CU = 3 waves per SIMD (168 VGPRs each).
@@ -724,7 +766,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   LV lv;
   if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD)));
   else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf, sc.mats};
-  const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
@@ -737,15 +778,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   // the NEXT iteration's active-list entry is fetched one iteration ahead (one register): the entry -> slot state ->
   // primitive record chain of dependent round trips loses its first link
   uint32_t slotNext = slotOf(tid0);
+  PROF_DECL;
   for (uint32_t it = 0; it < nIter; ++it) {
     ShadeIn cur;
     const uint32_t slotCur = slotNext;
     slotNext = slotOf((it + 1) * stride + tid0);
     load_shade_in<QUAD>(st, rp, bounce, slotCur, it * stride + tid0 < nIn, &cur);
+    PROF(4);
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
     bool pushCont = false, vert = false;
     if (valid) {
+      const SlotRef sr = cur.sr;
       const uint32_t flags = cur.flags;
       const int hprimIn = cur.hprim;
       const double t = cur.t;
@@ -759,12 +803,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         if (st.svFloat) return __uint_as_float(cur.raw[k]);
         return (k >= 2 && k < 8 && (k & 1)) ? Sobol2_lds(s_push.sobol, cur.raw[k], cur.scr[k]) : VanDerCorput(cur.raw[k], cur.scr[k]);
       };
+#ifdef DR_SHADE_PROF
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      PROF(0);
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
-        C3 Ld = resolve_nee<ENV, QUAD>(sc, lv, st, slot, flags, shOccIn, Ld1In);
+        C3 Ld = resolve_nee<ENV, QUAD>(sc, lv, sr, flags, shOccIn, Ld1In);
         C3 tot = cmulD(Ld, (double)rp.nLights);  // integrator.dart:113-116
         L = cadd(L, cmul(betaNeeIn, tot));
       }
+      PROF(1);
       const int prim = (flags & PF_HAS_CONT) ? hprimIn : -1;
       if (ENV && bounce == 0 && prim < 0 && sc.hasEnv) {
         // the camera ray escaped: Li = sum over lights of light.Le(ray) (sampler_renderer.dart:87-92); area
@@ -801,6 +850,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         bsdf.ng = dg.nn;  // BSDF(dgs, dgGeom.nn)
         const F3 p = bsdf.p, n = bsdf.nn;
         const double eps = (isQuad ? 5.0e-4 : 1.0e-3) * t;  // triangle.dart:157; sphere.dart:169, disk.dart:98
+        PROF(2);
         TailSrc ts;
         const int perNee = rp.nLights > 0 ? 7 : 0;
         if (bounce >= 3) ts.init(rp, st, slot, (bounce - 3) * (perNee + 3) + (bounce > 4 ? bounce - 4 : 0));
@@ -823,9 +873,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           }
           int lightNum = (int)floor(lu * rp.nLights);
           lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
-          pf |= setup_nee<ENV, QUAD, (ENV && !QUAD)>(sc, lv, st, slot, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc);
-          stc(st.betaNee(), cap, slot, beta);
+          PROF(3);
+          pf |= setup_nee<ENV, QUAD, (ENV && !QUAD)>(sc, lv, sr, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc);
+          stcf<F_BETANEE>(sr, beta);
         }
+        PROF(5);
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
         double o0, o1, oc = 0.0;
         if (bounce < 3) {
@@ -851,23 +903,28 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           }
         }
         if (alive && bounce != rp.maxDepth) {
-          st3(st.rd(), cap, slot, wi);
-          stc(st.beta(), cap, slot, beta);
+          st3f<F_RD>(sr, wi);
+          stcf<F_BETA>(sr, beta);
           pf |= PF_HAS_CONT;
           if (specular) pf |= PF_SPECULAR;  // specularBounce (path_integrator.dart:87)
           pushCont = true;
         }
-        st3(st.ro(), cap, slot, p);
-        st.rtmin()[TD(cap, slot)] = eps;
+        PROF(6);
+        st3f<F_RO>(sr, p);
+        sr.f64<F_RTMIN>() = eps;
         vert = true;
       }
-      stc(st.L(), cap, slot, L);
-      st.flags()[TI(cap, slot)] = pf;
+      stcf<F_L>(sr, L);
+      sr.u32<F_FLAGS>() = pf;
+      PROF(7);
     }
     stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT, vert);
+    PROF(8);
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
       stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);
+    PROF(9);
   }
+  PROF_FLUSH;
   shade_count(s_push, q.ctr, nIn);
 }
 
@@ -884,7 +941,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   LV lv;
   if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD)));
   else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf, sc.mats};
-  const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
@@ -900,51 +956,52 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     bool again = false;
     if (valid) {
       slot = q.activeIn ? q.activeIn[idx] : idx;
-      const uint32_t flags = stage == 0 ? PF_HAS_CONT : st.flags()[TI(cap, slot)];  // k_raygen leaves flags / L / beta unwritten
-      const int prim = st.hprim()[TI(cap, slot)];
+      const SlotRef sr = SlotRef::of(st, slot);
+      const uint32_t flags = stage == 0 ? PF_HAS_CONT : sr.u32<F_FLAGS>();  // k_raygen leaves flags / L / beta unwritten
+      const int prim = sr.i32<F_HPRIM>();
       if (prim >= 0) {
         Tri tr = load_tri(sc, (uint32_t)prim);
-        const F3 d = ld3(st.rd(), cap, slot);
+        const F3 d = ld3f<F_RD>(sr);
         const F3 wo = vneg(d);
-        C3 L = stage == 0 ? C3{0.f, 0.f, 0.f} : ldc(st.L(), cap, slot);
-        C3 Lall = stage == 0 ? C3{0.f, 0.f, 0.f} : ldc(st.beta(), cap, slot);
+        C3 L = stage == 0 ? C3{0.f, 0.f, 0.f} : ldcf<F_L>(sr);
+        C3 Lall = stage == 0 ? C3{0.f, 0.f, 0.f} : ldcf<F_BETA>(sr);
         C3 Ld = C3{0.f, 0.f, 0.f};
         DGeo dg, dgs;
         const bool isQuad = QUAD && tr.kind != 0;
         const bool hasRec = QUAD && !isQuad && sc.srec && __float_as_uint(sc.srec[7 * (size_t)prim + 6].x) != 0u;
-        ShadeRec sr;
-        if (hasRec) sr = load_srec(sc, (uint32_t)prim);
+        ShadeRec srec;
+        if (hasRec) srec = load_srec(sc, (uint32_t)prim);
         if (stage == 0) {
-          const F3 o = ld3(st.ro(), cap, slot);
-          const double t = st.ht()[TD(cap, slot)];
+          const F3 o = ld3f<F_RO>(sr);
+          const double t = sr.f64<F_HT>();
           if (isQuad) {
             quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
-            st3(st.ro0(), cap, slot, o);  // later stages rebuild the hit from the camera ray
+            st3f<F_RO0>(sr, o);  // later stages rebuild the hit from the camera ray
           } else if (hasRec) {
-            tri_dg_srec(tr, sr, o, d, t, &dg);
-            st3(st.ro0(), cap, slot, o);
+            tri_dg_srec(tr, srec, o, d, t, &dg);
+            st3f<F_RO0>(sr, o);
           } else {
             tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
           }
           C3 Le = tr.light >= 0 ? light_L(lv.light(tr.light), dg.nn, wo) : C3{0.f, 0.f, 0.f};
           L = cadd(L, Le);
           Lall = C3{0.f, 0.f, 0.f};
-          st3(st.ro(), cap, slot, dg.p);
-          st.rtmin()[TD(cap, slot)] = (isQuad ? 5.0e-4 : 1.0e-3) * t;
+          st3f<F_RO>(sr, dg.p);
+          sr.f64<F_RTMIN>() = (isQuad ? 5.0e-4 : 1.0e-3) * t;
         } else {
-          if (isQuad) quadric_dg_at(sc.quads[tr.quad], ld3(st.ro0(), cap, slot), d, st.ht()[TD(cap, slot)], &dg);
-          else if (hasRec) tri_dg_srec(tr, sr, ld3(st.ro0(), cap, slot), d, st.ht()[TD(cap, slot)], &dg);
+          if (isQuad) quadric_dg_at(sc.quads[tr.quad], ld3f<F_RO0>(sr), d, sr.f64<F_HT>(), &dg);
+          else if (hasRec) tri_dg_srec(tr, srec, ld3f<F_RO0>(sr), d, sr.f64<F_HT>(), &dg);
           else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
-          dg.p = ld3(st.ro(), cap, slot);
-          Ld = ldc(st.betaNee(), cap, slot);
-          Ld = cadd(Ld, resolve_nee<true, QUAD>(sc, lv, st, slot, flags, st.shOcc()[TI(cap, slot)], ldc(st.Ld1(), cap, slot)));  // Ld += EstimateDirect
+          dg.p = ld3f<F_RO>(sr);
+          Ld = ldcf<F_BETANEE>(sr);
+          Ld = cadd(Ld, resolve_nee<true, QUAD>(sc, lv, sr, flags, sr.i32<F_SHOCC>(), ldcf<F_LD1>(sr)));  // Ld += EstimateDirect
           if (prev.last) {
             Lall = cadd(Lall, cdivD(Ld, (double)prev.n));  // L += Ld / nSamples
             Ld = C3{0.f, 0.f, 0.f};
           }
         }
         if (stage < nCalls) {
-          if (hasRec && (sr.flags & (DR_SHADING_N | DR_SHADING_S))) shading_geometry(sc, sr, tr.reverse, dg, &dgs);
+          if (hasRec && (srec.flags & (DR_SHADING_N | DR_SHADING_S))) shading_geometry(sc, srec, tr.reverse, dg, &dgs);
           else dgs = dg;
           Bsdf bsdf = make_bsdf<QUAD>(lv, dgs, tr.mat);  // mirror / glass are refused for DirectLighting; Oren-Nayar is not
           bsdf.ng = dg.nn;
@@ -955,7 +1012,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           double lsc = sv_one(rp, st, slot, cur.lc);
           double ls0 = l0, ls1 = l1, bs0 = b0, bs1 = b1;
           double bsc = QUAD ? (double)sv_one(rp, st, slot, cur.bc) : 0.0;
-          pf |= setup_nee<true, QUAD, false>(sc, lv, st, slot, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
+          pf |= setup_nee<true, QUAD, false>(sc, lv, sr, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
           again = true;
         } else {
           if (rp.nLights > 0) L = cadd(L, Lall);
@@ -964,14 +1021,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
             L = cadd(L, C3{0.f, 0.f, 0.f});
           }
         }
-        stc(st.L(), cap, slot, L);
-        stc(st.beta(), cap, slot, Lall);
-        stc(st.betaNee(), cap, slot, Ld);
+        stcf<F_L>(sr, L);
+        stcf<F_BETA>(sr, Lall);
+        stcf<F_BETANEE>(sr, Ld);
       } else if (stage == 0) {
         // escaped camera ray: Li = sum of light.Le(ray) (sampler_renderer.dart:87-92) -- the env map's, else 0
-        stc(st.L(), cap, slot, sc.hasEnv ? env_Le(sc.env, ld3(st.rd(), cap, slot)) : C3{0.f, 0.f, 0.f});
+        stcf<F_L>(sr, sc.hasEnv ? env_Le(sc.env, ld3f<F_RD>(sr)) : C3{0.f, 0.f, 0.f});
       }
-      st.flags()[TI(cap, slot)] = pf;
+      sr.u32<F_FLAGS>() = pf;
     }
     stage_push(s_push, pctx, false, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, again, slot, Q_MIS_BIT, again);
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)

@@ -38,6 +38,9 @@ struct PushStage {  // head of the dynamic LDS block; followed by one region per
   uint32_t base[3];
   uint32_t pad;
   uint32_t nVert[16];  // per wave: path vertices set up so far (statistics; kept in LDS, not in a register)
+#ifdef DR_SHADE_PROF
+  unsigned long long prof[16][10];
+#endif
   uint32_t sobol[256];  // Sobol2's low-byte table (dr_kernels.hip): a per-lane look-up, ds_read instead of a global round trip
 };
 struct PushCtx {  // wave-uniform registers

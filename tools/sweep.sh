@@ -5,8 +5,8 @@ cd "$(dirname "$0")/../dartray_amd/csrc"
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Wno-unused-function $flags \
-    -o ../libdartray_hip_$name.so dr_kernels.hip dr_trace.hip dr_api.hip dr_bvh_build.cpp 2>/dev/null || { echo "$name: build failed"; continue; }
-  DARTRAY_LIB=$PWD/../libdartray_hip_$name.so timeout 300 python ../../bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > /tmp/sweep_$name.log 2>&1
+    -o ../libdartray_hip_$name.so dr_kernels.hip dr_trace.hip dr_api.hip dr_bvh_build.cpp dr_comm.cpp -ldl 2>/dev/null || { echo "$name: build failed"; continue; }
+  DARTRAY_LIB=$PWD/../libdartray_hip_$name.so timeout 300 python ../../bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra ${BENCH_ARGS} > /tmp/sweep_$name.log 2>&1
   python - "$name" <<'PY'
 import json,sys
 name=sys.argv[1]
