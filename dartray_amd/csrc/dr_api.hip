@@ -62,6 +62,9 @@ struct Workspace {
   DevBuf<uint32_t> scr;  // compact samples: scramble words [2 * nBlocks][pixCap]
   DevBuf<double> tail;
   DevBuf<uint32_t> activeA, activeB, closestQ, anyQ, counters, spill;
+  DevBuf<uint32_t> roundA, roundB;  // DirectLighting over mirror / glass: the slots whose child ray is traced next round
+  DevBuf<float> specFrames;         //   [maxDepth][cap] SpecFrame
+  DevBuf<int32_t> specSp;           //   [cap]
   DevBuf<int2> pix;
   DevBuf<float> filterTable, aosSamples;
   int spillGrid = 0;
@@ -324,6 +327,8 @@ BatchState makeState(Workspace& w, const SampleForm& sf, const int2* pix, uint32
   st.svFloat = sf.compact ? 0u : 1u;
   st.svScr = sf.compact ? w.scr.p : nullptr;
   st.pixCap = w.pixCap;
+  st.specFrames = w.specFrames.p;
+  st.specSp = w.specSp.p;
   return st;
 }
 
@@ -1012,9 +1017,10 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (rd->integrator != DR_INTEGRATOR_PATH && rd->integrator != DR_INTEGRATOR_DIRECT_ALL)
     return fail(DR_ERR_INVALID, "unknown integrator");
   if (rd->max_depth < 0 || rd->max_depth > 64) return fail(DR_ERR_INVALID, "max_depth out of range");
-  if (rd->integrator == DR_INTEGRATOR_DIRECT_ALL && sc->hasSpecular)
-    return fail(DR_ERR_UNSUPPORTED, "DirectLighting recurses through SpecularReflect / SpecularTransmit (integrator.dart:187-290): "
-                                    "mirror and glass are traced by the PathIntegrator only");
+  // DirectLighting over mirror / glass recurses through SpecularReflect / SpecularTransmit (integrator.dart:187-290):
+  // an explicit per-slot stack and one round of the stage loop per vertex of the ray tree (k_shade_spec)
+  const bool dlSpec = rd->integrator == DR_INTEGRATOR_DIRECT_ALL && sc->hasSpecular;
+  if (dlSpec && rd->max_depth > 16) return fail(DR_ERR_UNSUPPORTED, "DirectLighting over mirror / glass: max_depth > 16");
 
   RenderParams rp;
   memset(&rp, 0, sizeof(rp));
@@ -1040,6 +1046,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.nBlocks = sc->dlNBlocks;
   rp.dstages = sc->dlStages.p;
   rp.nDirectStages = direct ? sc->dlNStages : 0;
+  rp.dlSpecular = dlSpec ? 1 : 0;
   rp.samplerMode = rd->sampler_mode;
   rp.seed = (uint64_t)rd->seed;
   const int perNee = rp.nLights > 0 ? 7 : 0;
@@ -1104,7 +1111,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // memory the batch shrinks instead of failing (results do not depend on the batch size).
     const uint64_t perSlot = (uint64_t)DR_STATE_WORDS * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 +
                              (hostBuf && needTail > 0 ? (uint64_t)rd->max_tail * 8 : 0) + (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0) +
-                             (sf.compact ? (uint64_t)(8 * sf.nBlocks + spp - 1) / spp : 0);
+                             (sf.compact ? (uint64_t)(8 * sf.nBlocks + spp - 1) / spp : 0) +
+                             (dlSpec ? (uint64_t)std::max(1, rd->max_depth) * sizeof(SpecFrame) + 12 : 0);
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
       const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)DR_STATE_WORDS * 4 + sc->ws.svWords / 16 + 20) +
@@ -1124,10 +1132,16 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const uint32_t cap = pixPerBatch * (uint32_t)spp;
   int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0);
   if (rc) return rc;
+  if (dlSpec) {
+    HIP_TRY(sc->ws.specFrames.alloc((size_t)sc->ws.cap * std::max(1, rd->max_depth) * DR_SPEC_FRAME_WORDS));
+    HIP_TRY(sc->ws.specSp.alloc(sc->ws.cap));
+    HIP_TRY(sc->ws.roundA.alloc(sc->ws.cap));
+    HIP_TRY(sc->ws.roundB.alloc(sc->ws.cap));
+  }
   const int tgrid = traceGrid();
   rc = ensureSpill(sc, sc->ws, tgrid);
   if (rc) return rc;
-  const bool twoPipes = nPipesEnv >= 2 && !hostBuf && npixTotal > pixPerBatch;
+  const bool twoPipes = nPipesEnv >= 2 && !hostBuf && !dlSpec && npixTotal > pixPerBatch;
   if (twoPipes) {
     rc = allocWorkspace(sc, sc->ws2, cap, sf, pixPerBatch, rd->max_tail, false);
     if (rc) return rc;
@@ -1149,7 +1163,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   size_t batchIndex = 0;
   const int sgrid = g_numCU;  // the shade launchers size their grid per CU (DR_SHADE_GRID), grid-stride over the active list
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
-  if (4 * nStages + 8 > 1024 || 8 * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
+  if (4 * nStages + 8 > 1000 || 8 * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
 
   // One batch through the stage loop.  pilot != null: a measurement run (no film, its trace launches timed into
   // pilot[kind]) -- see the calibration below.
@@ -1190,11 +1204,23 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       if (pilot) pilot->ev[any].push_back({e0, e1});
       else sc->traceEvents.push_back({e0, e1, any});
     };
-    trace(nullptr, nullptr, 0);  // camera rays
+    // DirectLighting over mirror / glass: one round of the stage loop per vertex of a slot's ray tree; `roundQ` lists
+    // the slots whose (camera or child) ray this round traces.  Everything else: one round.
+    const uint32_t* roundQ = nullptr;
+    const uint32_t* nRound = nullptr;
+    const int maxRounds = dlSpec ? (1 << std::min(16, std::max(1, rd->max_depth))) : 1;
+    if (dlSpec) HIP_TRY(hipMemsetAsync(w.specSp.p, 0, (size_t)w.cap * sizeof(int32_t), s));
+    for (int round = 0; round < maxRounds; ++round) {
+    if (round > 0) {  // the stage counters are reused every round; the round lists' counts live behind them
+      HIP_TRY(hipMemsetAsync(C, 0, 1000 * sizeof(uint32_t), s));
+      HIP_TRY(hipMemsetAsync(C + 1024, 0, (N_COUNTERS - 1024) * sizeof(uint32_t), s));
+      wc = 0;
+    }
+    trace(roundQ, nRound, 0);  // camera rays (or this round's child rays)
     for (int b = 0; b < nStages; ++b) {
       StageQueues q;
-      q.activeIn = b == 0 ? nullptr : ((b - 1) & 1 ? w.activeB.p : w.activeA.p);
-      q.nActiveIn = b == 0 ? nullptr : C + 4 * (b - 1);
+      q.activeIn = b == 0 ? roundQ : ((b - 1) & 1 ? w.activeB.p : w.activeA.p);
+      q.nActiveIn = b == 0 ? nRound : C + 4 * (b - 1);
       q.activeOut = (b & 1) ? w.activeB.p : w.activeA.p;
       q.nActiveOut = C + 4 * b;
       q.closestQ = w.closestQ.p;
@@ -1211,6 +1237,34 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
         trace(q.closestQ, q.nClosest, 0);
         trace(q.anyQ, q.nAny, 1);
       }
+    }
+    if (!dlSpec) break;
+    {
+      StageQueues q;
+      memset(&q, 0, sizeof(q));
+      q.activeIn = roundQ;
+      q.nActiveIn = nRound;
+      uint32_t* nextQ = (round & 1) ? w.roundB.p : w.roundA.p;
+      uint32_t* nNext = C + 1008 + (round & 1);
+      HIP_TRY(hipMemsetAsync(nNext, 0, sizeof(uint32_t), s));
+      q.activeOut = nextQ;
+      q.nActiveOut = nNext;
+      q.closestQ = w.closestQ.p;  // unused: the child rays are the next round's list
+      q.nClosest = C + 1010;
+      q.anyQ = w.anyQ.p;
+      q.nAny = C + 1011;
+      q.ctr = sc->ctr.p;
+      hipEvent_t evS = sc->getEvent();
+      (void)hipEventRecord(evS, s);
+      launch_shade_spec(sc->d, rp, st, q, sgrid, s);
+      timed(2, evS);
+      uint32_t live = 0;  // (a synchronous read-back per round: this is not the throughput path)
+      HIP_TRY(hipMemcpyAsync(&live, nNext, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (live == 0) break;
+      roundQ = nextQ;
+      nRound = nNext;
+    }
     }
     if (!pilot) {
       hipEvent_t evF = sc->getEvent();

@@ -1126,4 +1126,40 @@ DR_DEV C3 spec_sample_f(const Bsdf& b, F3 woW, F3* wiW, double uComponent, doubl
   return f;
 }
 
+// BSDF.sample_f(flags = BSDF_REFLECTION | BSDF_SPECULAR) or (BSDF_TRANSMISSION | BSDF_SPECULAR) as
+// Integrator.SpecularReflect / SpecularTransmit call it (integrator.dart:195,241): only the one specular lobe of that
+// hemisphere can match (mirror: reflection; glass: both), so there is no lobe choice and the pdf is the lobe's own.
+// A BSDF without such a lobe (matte, plastic) returns black with pdf 0.
+DR_DEV C3 spec_lobe_sample_f(const Bsdf& b, F3 woW, F3* wiW, double* pdf, bool reflection) {
+  *pdf = 0.0;
+  const bool isSpec = b.mtype == DR_MATERIAL_MIRROR || b.mtype == DR_MATERIAL_GLASS;
+  const bool hasR = isSpec && !cblack(b.Kr), hasT = b.mtype == DR_MATERIAL_GLASS && !cblack(b.Kt);
+  if (reflection ? !hasR : !hasT) return C3{0.f, 0.f, 0.f};
+  const F3 wo = bsdf_w2l(b, woW);
+  F3 wi;
+  C3 f;
+  if (reflection) {  // specular_reflection.dart:33-41
+    wi = F3{-wo.x, -wo.y, wo.z};
+    *pdf = 1.0;
+    const float F = b.mtype == DR_MATERIAL_GLASS ? fresnel_dielectric((double)wo.z, 1.0, b.ior) : 1.0f;
+    f = cdivD(cmul(C3{F, F, F}, b.Kr), fabs((double)wi.z));
+  } else {  // specular_transmission.dart:37-71
+    const bool entering = wo.z > 0.0f;
+    const double ei = entering ? 1.0 : b.ior, et = entering ? b.ior : 1.0;
+    const double sini2 = fmax(0.0, 1.0 - (double)wo.z * (double)wo.z);
+    const double eta = ei / et;
+    const double sint2 = eta * eta * sini2;
+    if (sint2 >= 1.0) return C3{0.f, 0.f, 0.f};  // total internal reflection (pdf stays 0)
+    double cost = sqrt(fmax(0.0, 1.0 - sint2));
+    if (entering) cost = -cost;
+    wi = f3(eta * -(double)wo.x, eta * -(double)wo.y, cost);
+    *pdf = 1.0;
+    const float F = fresnel_dielectric((double)wo.z, 1.0, b.ior);
+    const float omf = (float)(1.0 - (double)F);
+    f = cdivD(cmul(C3{omf, omf, omf}, b.Kt), fabs((double)wi.z));
+  }
+  *wiW = bsdf_l2w(b, wi);
+  return f;
+}
+
 #endif

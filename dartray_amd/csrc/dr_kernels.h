@@ -39,7 +39,8 @@ struct RenderParams {
   int32_t nBlocks;             // LD blocks per pixel: image, lens, time, 1-D slots, 2-D slots
   const LdBlock* blocks;       // null => every slot has one entry and the layout is arithmetic
   const DirectStage* dstages;  // DirectLighting: nDirectStages entries
-  int32_t nDirectStages, pad;
+  int32_t nDirectStages;
+  int32_t dlSpecular;  // DirectLighting over mirror / glass: k_shade_spec adds SpecularReflect / SpecularTransmit after the last stage
 };
 
 // Flags of a path slot.
@@ -91,6 +92,10 @@ struct BatchState {
   uint32_t svFloat;
   uint32_t pixCap;
   uint32_t* svScr;    // [2 * nBlocks][pixCap]
+  // DirectLighting over mirror / glass (Integrator.SpecularReflect / SpecularTransmit, integrator.dart:187-290): the
+  // per-slot stack of suspended vertices, [level][cap] SpecFrame records, and its depth per slot; null otherwise
+  float* specFrames;
+  int32_t* specSp;
 #define DR_FIELD(T, name, F) \
   __host__ __device__ T* name() const { return (T*)(tiles + 64 * (F)); }
   DR_FIELD(double, rtmin, F_RTMIN)      // Ray.minDistance (isect.rayEpsilon after the first vertex)
@@ -155,6 +160,22 @@ template <int F> DR_DEV void stcf(const SlotRef& r, C3 v) {
   STS_STREAM(&r.f32<F>(2), v.b);
 }
 
+// A vertex of DirectLightingIntegrator.Li that waits for the radiance of a specular child ray (the recursion of
+// direct_lighting_integrator.dart:59-65 unrolled into an explicit stack, one frame per suspended vertex).
+struct SpecFrame {   // 96 bytes
+  float L[3];        // Le + UniformSampleAllLights (+ the reflected radiance once it has come back)
+  float ft[3];       // transmission: f of the sampled lobe,
+  float wt[3];       //   its direction,
+  float p[3];        //   the vertex (origin of the child rays)
+  float fr[3];       // reflection: f of the sampled lobe (only while its child is being traced)
+  uint32_t state;    // 1 = the reflected ray is being traced, 2 = the transmitted ray; bit 8: a transmitted ray follows
+  double sr, st;     // AbsDot(wi, n) / pdf of the two lobes
+  double eps;        // isect.rayEpsilon
+  float pad[2];
+};
+#define DR_SPEC_FRAME_WORDS 24
+static_assert(sizeof(SpecFrame) == 4 * DR_SPEC_FRAME_WORDS, "SpecFrame layout");
+
 // Work queues of one stage.  Counts live in device memory so that no host
 // round trip is needed between launches.
 struct StageQueues {
@@ -189,6 +210,7 @@ void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchStat
                        int grid, hipStream_t s);
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s);
+void launch_shade_spec(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int grid, hipStream_t s);
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
                  hipStream_t s);
 void launch_film_resolve(const float* film, int64_t npix, float* rgb, hipStream_t s);

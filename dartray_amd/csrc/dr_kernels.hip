@@ -1016,8 +1016,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           again = true;
         } else {
           if (rp.nLights > 0) L = cadd(L, Lall);
-          if (0 + 1 < rp.maxDepth) {  // SpecularReflect / SpecularTransmit find no specular lobe: += 0
-            L = cadd(L, C3{0.f, 0.f, 0.f});
+          if (!rp.dlSpecular && 0 + 1 < rp.maxDepth) {  // SpecularReflect / SpecularTransmit find no specular lobe: += 0
+            L = cadd(L, C3{0.f, 0.f, 0.f});             // (scenes with mirror / glass: k_shade_spec adds them)
             L = cadd(L, C3{0.f, 0.f, 0.f});
           }
         }
@@ -1035,6 +1035,122 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);
   }
   shade_count(s_push, q.ctr, nIn);
+}
+
+// DirectLightingIntegrator.Li's recursion through Integrator.SpecularReflect / SpecularTransmit
+// (direct_lighting_integrator.dart:59-65, integrator.dart:187-290) for scenes with mirror / glass, as an explicit
+// depth-first walk: every slot works on ONE vertex of its ray tree per round (closest-hit trace, the all-lights
+// stages of k_shade_direct, then this kernel).  A vertex with a specular lobe is suspended in a SpecFrame while its
+// child ray is traced -- the reflected one first, then the transmitted one, the reference's order -- and a finished
+// vertex hands its radiance to the frame below it, `L += f * Li * (AbsDot(wi, n) / pdf)` with the reference's f32
+// rounding, until the stack is empty and st.L holds the camera sample's radiance.  The three RNG draws each call
+// burns (BSDFSample.random) only select among SEVERAL matching lobes; a BSDF has at most one specular lobe per
+// hemisphere here, so they never reach the image and the keyed per-sample streams need not reproduce them.
+// In: q.activeIn = the slots whose vertex was traced this round.  Out: q.activeOut = the slots that launched a child
+// ray (ro / rd / rtmin written), the next round's list.
+__global__ void __launch_bounds__(SHADE_BLOCK_OF(true), SHADE_WAVES_OF(true)) k_shade_spec(DScene sc, RenderParams rp, BatchState st, StageQueues q) {
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  PushStage& s_push = *(PushStage*)s_dyn;
+  PushCtx pctx = {{0, 0, 0, 0}, 0};
+  const GlobalLights lv{sc.lights, sc.ltris, sc.lcdf, sc.mats};
+  const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t nIter = (nIn + stride - 1) / stride;
+  shade_count_init(s_push);
+  for (uint32_t it = 0; it < nIter; ++it) {
+    const uint32_t idx = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t slot = 0;
+    bool launched = false;
+    if (idx < nIn) {
+      slot = q.activeIn ? q.activeIn[idx] : idx;
+      const SlotRef sr = SlotRef::of(st, slot);
+      int sp = st.specSp[slot];
+      auto frameAt = [&](int level) -> SpecFrame* { return (SpecFrame*)(st.specFrames + ((size_t)level * st.cap + slot) * DR_SPEC_FRAME_WORDS); };
+      auto launch = [&](F3 o, F3 dir, double eps) {  // RayDifferential.child(p, wi, ray, isect.rayEpsilon): [eps, inf)
+        st3f<F_RO>(sr, o);
+        st3f<F_RD>(sr, dir);
+        sr.f64<F_RTMIN>() = eps;
+        launched = true;
+      };
+      const int prim = sr.i32<F_HPRIM>();
+      C3 V = ldcf<F_L>(sr);  // this vertex's Le + direct lighting (a hit), or the lights' Le along an escaped ray
+      if (prim >= 0 && sp + 1 < rp.maxDepth) {  // ray.depth + 1 < maxDepth: ray.depth == the number of suspended ancestors
+        // the hit's geometry and BSDF, rebuilt as the later stages of k_shade_direct rebuild them
+        Tri tr = load_tri(sc, (uint32_t)prim);
+        const F3 d = ld3f<F_RD>(sr);
+        const F3 wo = vneg(d);
+        DGeo dg, dgs;
+        const bool isQuad = tr.kind != 0;
+        const bool hasRec = !isQuad && sc.srec && __float_as_uint(sc.srec[7 * (size_t)prim + 6].x) != 0u;
+        ShadeRec srec;
+        if (hasRec) srec = load_srec(sc, (uint32_t)prim);
+        if (isQuad) quadric_dg_at(sc.quads[tr.quad], ld3f<F_RO0>(sr), d, sr.f64<F_HT>(), &dg);
+        else if (hasRec) tri_dg_srec(tr, srec, ld3f<F_RO0>(sr), d, sr.f64<F_HT>(), &dg);
+        else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
+        dg.p = ld3f<F_RO>(sr);
+        if (hasRec && (srec.flags & (DR_SHADING_N | DR_SHADING_S))) shading_geometry(sc, srec, tr.reverse, dg, &dgs);
+        else dgs = dg;
+        Bsdf bsdf = make_bsdf<true>(lv, dgs, tr.mat);
+        bsdf.ng = dg.nn;
+        const F3 p = bsdf.p, n = bsdf.nn;
+        const double eps = sr.f64<F_RTMIN>();  // isect.rayEpsilon, stored by stage 0
+        F3 wr = F3{0, 0, 0}, wt = F3{0, 0, 0};
+        double pr = 0.0, pt = 0.0;
+        C3 fr = spec_lobe_sample_f(bsdf, wo, &wr, &pr, true);
+        C3 ft = spec_lobe_sample_f(bsdf, wo, &wt, &pt, false);
+        const bool hasR = pr > 0.0 && !cblack(fr) && fabs(vdot(wr, n)) != 0.0;
+        const bool hasT = pt > 0.0 && !cblack(ft) && fabs(vdot(wt, n)) != 0.0;
+        if (hasR || hasT) {
+          SpecFrame* f = frameAt(sp);
+          f->L[0] = V.r; f->L[1] = V.g; f->L[2] = V.b;
+          f->p[0] = p.x; f->p[1] = p.y; f->p[2] = p.z;
+          f->eps = eps;
+          if (hasT) {
+            f->ft[0] = ft.r; f->ft[1] = ft.g; f->ft[2] = ft.b;
+            f->wt[0] = wt.x; f->wt[1] = wt.y; f->wt[2] = wt.z;
+            f->st = fabs(vdot(wt, n)) / pt;
+          }
+          if (hasR) {
+            f->fr[0] = fr.r; f->fr[1] = fr.g; f->fr[2] = fr.b;
+            f->sr = fabs(vdot(wr, n)) / pr;
+            f->state = 1u | (hasT ? 256u : 0u);
+            launch(p, wr, eps);
+          } else {
+            f->L[0] = V.r + 0.f; f->L[1] = V.g + 0.f; f->L[2] = V.b + 0.f;  // L += SpecularReflect(...) == Spectrum(0)
+            f->state = 2u;
+            launch(p, wt, eps);
+          }
+          ++sp;
+        } else {
+          V = cadd(cadd(V, C3{0.f, 0.f, 0.f}), C3{0.f, 0.f, 0.f});  // both calls return Spectrum(0)
+        }
+      }
+      // a finished vertex returns to the frames below it
+      while (!launched && sp > 0) {
+        SpecFrame* f = frameAt(sp - 1);
+        C3 L = C3{f->L[0], f->L[1], f->L[2]};
+        if ((f->state & 255u) == 1u) {
+          L = cadd(L, cmulD(cmul(C3{f->fr[0], f->fr[1], f->fr[2]}, V), f->sr));  // L += f * Li * (AbsDot(wi, n) / pdf)
+          if (f->state & 256u) {
+            f->L[0] = L.r; f->L[1] = L.g; f->L[2] = L.b;
+            f->state = 2u;
+            launch(F3{f->p[0], f->p[1], f->p[2]}, F3{f->wt[0], f->wt[1], f->wt[2]}, f->eps);
+          } else {
+            V = cadd(L, C3{0.f, 0.f, 0.f});  // + SpecularTransmit(...) == Spectrum(0)
+            --sp;
+          }
+        } else {
+          V = cadd(L, cmulD(cmul(C3{f->ft[0], f->ft[1], f->ft[2]}, V), f->st));
+          --sp;
+        }
+      }
+      st.specSp[slot] = sp;
+      if (!launched) stcf<F_L>(sr, V);  // the camera sample's radiance
+    }
+    stage_push(s_push, pctx, false, false, false, launched, slot, Q_MIS_BIT, false);
+    if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
+      stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, nullptr);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1258,6 +1374,9 @@ void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchSt
     if (gen) launch_shade<k_shade_direct<true, false>, SHADE_BLOCK_OF(true)>(grid, 0, s, sc, rp, st, q, stage);
     else launch_shade<k_shade_direct<false, false>, SHADE_BLOCK_OF(false)>(grid, 0, s, sc, rp, st, q, stage);
   }
+}
+void launch_shade_spec(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int grid, hipStream_t s) {
+  launch_shade<k_shade_spec, SHADE_BLOCK_OF(true)>(grid, 0, s, sc, rp, st, q);
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
                  hipStream_t s) {

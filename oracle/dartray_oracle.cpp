@@ -1887,6 +1887,49 @@ static S PathLi(const Scene& sc, const IntegratorCfg& cfg, const Ray& r, const I
   return L;
 }
 
+// SamplerRenderer.Li (sampler_renderer.dart:67-98) as the integrators call it for a spawned ray: intersect, the
+// surface integrator on a hit, the sum of light.Le(ray) on a miss; T = 1, Lvi = 0 without a VolumeRegion
+// (emission_integrator.dart:39-42).  Only DirectLighting recurses through it (PathIntegrator iterates).
+static S DirectLi(const Scene& sc, const IntegratorCfg& cfg, const Ray& ray, const Isect& isect, const SampleView& sv,
+                  const std::vector<int>& n1D, const std::vector<int>& n2D, LiRng& rng);
+static S RendererLi(const Scene& sc, const IntegratorCfg& cfg, Ray ray, const SampleView& sv, const std::vector<int>& n1D,
+                    const std::vector<int>& n2D, LiRng& rng) {
+  Isect isect;
+  S Li{0, 0, 0};
+  if (bvh_intersect(sc, ray, &isect)) {
+    Li = DirectLi(sc, cfg, ray, isect, sv, n1D, n2D, rng);
+  } else {
+    for (const Light& l : sc.lights) Li = sadd(Li, l.kind == 1 ? sc.env.Le(ray.d) : S{0, 0, 0});
+  }
+  return sadd(smul(S{1, 1, 1}, Li), S{0, 0, 0});  // T * Li + Lvi
+}
+// Integrator.SpecularReflect / SpecularTransmit (integrator.dart:187-233 / :235-290).  The ray differentials only
+// feed texture filtering (constant textures here) and are not restated.
+static S SpecularBounce(const Scene& sc, const IntegratorCfg& cfg, const Ray& ray, const BSDF& bsdf, const Isect& isect,
+                        int lobeFlags, const SampleView& sv, const std::vector<int>& n1D, const std::vector<int>& n2D,
+                        LiRng& rng) {
+  V wo = vneg(ray.d);
+  V wi{0, 0, 0};
+  D pdf = 0.0;
+  V p = bsdf.p, n = bsdf.nn;
+  // new BSDFSample.random(rng): uDir[0], uDir[1] (Float32List), uComponent (bsdf_sample.dart:37-42)
+  D u0 = r32(rng.randomFloat()), u1 = r32(rng.randomFloat()), uc = rng.randomFloat();
+  S f = bsdf.sample_f(wo, &wi, u0, u1, uc, &pdf, lobeFlags | BSDF_SPECULAR, nullptr);
+  S L{0, 0, 0};
+  if (pdf > 0.0 && !sblack(f) && vabsdot(wi, n) != 0.0) {
+    Ray rd;  // RayDifferential.child(p, wi, ray, isect.rayEpsilon) (ray.dart: depth = parent.depth + 1, same time)
+    rd.o = p;
+    rd.d = wi;
+    rd.mint = isect.rayEpsilon;
+    rd.maxt = kInf;
+    rd.time = ray.time;
+    rd.depth = ray.depth + 1;
+    S Li = RendererLi(sc, cfg, rd, sv, n1D, n2D, rng);
+    L = smulD(smul(f, Li), vabsdot(wi, n) / pdf);  // f * Li * (AbsDot(wi, n) / pdf)
+  }
+  return L;
+}
+
 // DirectLightingIntegrator.Li, strategy "all" (direct_lighting_integrator.dart:30-68)
 static S DirectLi(const Scene& sc, const IntegratorCfg& cfg, const Ray& ray, const Isect& isect, const SampleView& sv,
                   const std::vector<int>& n1D, const std::vector<int>& n2D, LiRng& rng) {
@@ -1922,11 +1965,10 @@ static S DirectLi(const Scene& sc, const IntegratorCfg& cfg, const Ray& ray, con
     L = sadd(L, Lall);
   }
   if (ray.depth + 1 < cfg.maxDepth) {
-    // SpecularReflect / SpecularTransmit (integrator.dart:187-290): each draws
-    // BSDFSample.random(rng) (3 floats) and then finds no specular lobe => +0.
-    for (int k = 0; k < 6; ++k) (void)rng.randomFloat();
-    L = sadd(L, S{0, 0, 0});
-    L = sadd(L, S{0, 0, 0});
+    // Trace rays for specular reflection and refraction (direct_lighting_integrator.dart:59-65): each call draws a
+    // BSDFSample.random(rng) (3 floats) whether or not the BSDF has such a lobe, and recurses through Renderer.Li
+    L = sadd(L, SpecularBounce(sc, cfg, ray, bsdf, isect, BSDF_REFLECTION, sv, n1D, n2D, rng));
+    L = sadd(L, SpecularBounce(sc, cfg, ray, bsdf, isect, BSDF_TRANSMISSION, sv, n1D, n2D, rng));
   }
   return L;
 }
@@ -2662,9 +2704,6 @@ int orc_render(void* h, const OrcRenderDesc* rd, float* out_rgb, float* out_film
   setup_render(*sc, rd, &cfg, &cam, &film, &n1D, &n2D, &nFloats, win, full);
   int spp = rd->spp;
   if ((spp & (spp - 1)) != 0) return -2;  // LowDiscrepancySampler rounds up; callers pass powers of two
-  if (cfg.kind == 0)  // DirectLighting recurses through SpecularReflect / SpecularTransmit (integrator.dart:187-290): not restated
-    for (const Mesh& m : sc->meshes)
-      if (m.matType == 1 || m.matType == 2) return -5;
   if (rec) { rec->count = 0; rec->nfloats = nFloats; if (rec->nfloats_cap < nFloats) return -3; }
   DartRandom rng((int64_t)rd->task_num);  // sampler_renderer.dart:137
   std::vector<float> buffer, samples;

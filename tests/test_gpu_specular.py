@@ -1,6 +1,6 @@
-"""GPU parity of mirror / glass materials in the path tracer: specular lobes,
-Fresnel, the specularBounce branches (emitted radiance after a specular bounce, lights seen by escaped specular
-rays) -- bit-exact against the oracle."""
+"""GPU parity of mirror / glass materials: specular lobes, Fresnel, the specularBounce
+branches of the path tracer (emitted radiance after a specular bounce, lights seen by escaped specular rays) and the
+SpecularReflect / SpecularTransmit recursion of DirectLighting -- bit-exact against the oracle."""
 import numpy as np
 import pytest
 
@@ -90,8 +90,39 @@ def test_serial_reference_stream_with_specular_materials(ob, gpu):
     assert np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"])
 
 
-def test_direct_lighting_with_specular_materials_is_refused(gpu):
-    txt = SCENE.format(depth=5, env="", ceiling=CEILING).replace('SurfaceIntegrator "path"', 'SurfaceIntegrator "directlighting"')
-    with pytest.raises(_abi.DartRayHipError) as e:
-        pbrt.loads(txt, render=True)
-    assert "SpecularReflect" in str(e.value)
+@pytest.mark.parametrize("depth,env,ceiling", [(5, "", CEILING), (3, ENV, ""), (1, ENV, CEILING), (6, ENV, CEILING)])
+def test_direct_lighting_recurses_through_mirror_and_glass_like_the_oracle(ob, gpu, depth, env, ceiling):
+    """The reference's DEFAULT integrator over mirror / glass: DirectLightingIntegrator.Li -> SpecularReflect /
+    SpecularTransmit -> Renderer.Li (integrator.dart:187-290), a branching ray tree (two children per glass vertex),
+    walked depth first on the device (k_shade_spec): bit-exact films and equal traversal counters."""
+    txt = SCENE.format(depth=depth, env=env, ceiling=ceiling).replace('SurfaceIntegrator "path"', 'SurfaceIntegrator "directlighting"')
+    api = pbrt.loads(txt, render=True)
+    out, r = api.outputImage, api.rendererObject
+    e, before = api.envLight()
+    osc = ob.OracleScene(api.scenePrimitives, env=e, env_before=before)
+    osc.counters(reset=True)
+    ref = osc.render(ob.render_desc(r, sampler_mode=1))
+    assert rel_err_image(out.rgb, ref["rgb"]).max() <= 1e-4
+    assert np.array_equal(out.film, ref["film"])
+    c, st = osc.counters(), r.last_stats
+    for k in ("closest_rays", "any_rays", "closest_nodes", "any_nodes", "closest_tris", "any_tris"):
+        assert st[k] == c[k], k
+    if depth > 1:
+        path = pbrt.loads(SCENE.format(depth=depth, env=env, ceiling=ceiling), render=True).outputImage
+        assert not np.array_equal(path.film, out.film)
+
+
+def test_direct_lighting_serial_reference_stream_with_specular_materials(ob, gpu):
+    """The serial reference stream: every SpecularReflect / SpecularTransmit call burns three RNG floats, which shifts
+    the LD scrambles of all later pixels; the oracle records the sample vectors it drew and the device replays them."""
+    txt = SCENE.format(depth=4, env=ENV, ceiling=CEILING).replace('SurfaceIntegrator "path"', 'SurfaceIntegrator "directlighting"')
+    api = pbrt.loads(txt.replace('[48]', '[20]').replace('[36]', '[16]'))
+    r = api.rendererObject
+    e, before = api.envLight()
+    osc = ob.OracleScene(api.scenePrimitives, env=e, env_before=before)
+    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=21 * 17 * 16, max_tail=8)
+    from dartray_amd import core
+    r.sampler = core.HostBufferSampler(r.camera, 16, rec["pixel_xy"][::16].copy(), rec["sample_vec"])
+    out = r.render(api.scene)
+    assert np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"])
+    assert rec["tail_count"].max() > 6   # more than one vertex drew: the recursion happened

@@ -91,10 +91,56 @@ def test_escaped_specular_ray_sees_the_infinite_light(ob):
     assert np.allclose(img, [0.25, 0.5, 0.75], rtol=1e-5)
 
 
-def test_direct_lighting_refuses_specular_materials(ob):
-    floor = _quad((-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50), core.MirrorMaterial())
-    with pytest.raises(RuntimeError):
-        _render(ob, [floor, EMIT((1, 1, 1))], core.DirectLightingIntegrator(0, 5), (0, 5, -5), (0, 0, 0))
+def test_direct_lighting_recurses_through_a_mirror(ob):
+    """DirectLightingIntegrator.Li -> Integrator.SpecularReflect (integrator.dart:187-233): camera -> mirror floor ->
+    emitter gives L = Kr * Le exactly (f * |cos| / pdf = Kr), with `ray.depth + 1 < maxDepth` gating the recursion."""
+    kr = (0.5, 0.25, 1.0)
+    floor = _quad((-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50), core.MirrorMaterial(kr))
+    img = _render(ob, [floor, EMIT((4.0, 4.0, 4.0))], core.DirectLightingIntegrator(0, 5), (0, 5, -5), (0, 0, 0), spp=4)
+    assert np.allclose(img, np.array(kr) * 4.0, rtol=1e-5)
+    img = _render(ob, [floor, EMIT((4.0, 4.0, 4.0))], core.DirectLightingIntegrator(0, 2), (0, 5, -5), (0, 0, 0), spp=4)
+    assert np.allclose(img, np.array(kr) * 4.0, rtol=1e-5)   # depth 0 + 1 < 2: one bounce allowed
+    img = _render(ob, [floor, EMIT((4.0, 4.0, 4.0))], core.DirectLightingIntegrator(0, 1), (0, 5, -5), (0, 0, 0), spp=4)
+    assert np.all(img == 0)                                   # 0 + 1 < 1 is false: no specular rays at all
+
+
+def test_direct_lighting_two_facing_mirrors_truncate_at_maxdepth(ob):
+    """Two parallel mirrors (Kr = 0.5) around a camera that looks at one of them: the ray bounces until
+    `ray.depth + 1 < maxDepth` fails and nothing is ever added: black; a matte wall lit by an emitter seen after k
+    bounces carries Kr^k."""
+    m = core.MirrorMaterial((0.5, 0.5, 0.5))
+    left = _quad((-5, -50, -50), (-5, -50, 50), (-5, 50, 50), (-5, 50, -50), m)
+    right = _quad((5, -50, -50), (5, 50, -50), (5, 50, 50), (5, -50, 50), m)
+    img = _render(ob, [left, right], core.DirectLightingIntegrator(0, 6), (0, 0, 0), (5, 0, 0), spp=4)
+    assert np.all(img == 0)
+    # an emitter ceiling far above: the k-th reflected ray still goes sideways, never up: still black; but the
+    # emitter illuminates nothing specular (EstimateDirect finds no non-specular lobe on a mirror)
+    img = _render(ob, [left, right, EMIT((4.0, 4.0, 4.0))], core.DirectLightingIntegrator(0, 6), (0, 0, 0), (5, 0, 0), spp=4)
+    assert np.all(img == 0)
+
+
+@pytest.mark.parametrize("ior", [1.5, 2.4])
+def test_direct_lighting_glass_pane_series(ob, ior):
+    """Through a glass pane (Kr = Kt = 1) at normal incidence DirectLighting follows BOTH lobes at every interface
+    (SpecularReflect then SpecularTransmit, integrator.dart:187-290), deterministically: the emitter behind the pane
+    is reached at ray depths 2, 4, 6 with weights (1-F)^2 F^(2k).  maxDepth 8 keeps exactly those three terms."""
+    g = core.GlassMaterial(index=ior)
+    top = _quad((-50, 6, -50), (50, 6, -50), (50, 6, 50), (-50, 6, 50), g)
+    bot = _quad((-50, 5, -50), (-50, 5, 50), (50, 5, 50), (50, 5, -50), g)
+    img = _render(ob, [top, bot, EMIT((1.0, 1.0, 1.0))], core.DirectLightingIntegrator(0, 8), (0, 0, 0), (0, 5, 0), spp=4, res=4, fov=0.5)
+    F = ((ior - 1) / (ior + 1)) ** 2
+    expect = (1 - F) ** 2 * (1 + F ** 2 + F ** 4)
+    assert np.allclose(img, expect, rtol=2e-5), (img.mean(), expect)
+    img = _render(ob, [top, bot, EMIT((1.0, 1.0, 1.0))], core.DirectLightingIntegrator(0, 4), (0, 0, 0), (0, 5, 0), spp=4, res=4, fov=0.5)
+    assert np.allclose(img, (1 - F) ** 2, rtol=2e-5)          # only the direct term fits in depth < 4
+
+
+def test_direct_lighting_escaped_specular_ray_sees_the_infinite_light(ob):
+    """Renderer.Li on a miss sums light.Le(ray) (sampler_renderer.dart:87-92) for the child ray too."""
+    env = core.InfiniteAreaLight(scenes.SKY_TO_WORLD, (0.25, 0.5, 0.75), 1, None)
+    floor = _quad((-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50), core.MirrorMaterial((1, 0.5, 1)))
+    img = _render(ob, [floor], core.DirectLightingIntegrator(0, 5), (0, 5, -5), (0, 0, 0), env=env, spp=4)
+    assert np.allclose(img, [0.25, 0.25, 0.75], rtol=1e-5)
 
 
 def test_oren_nayar_known_values(ob):
