@@ -1,0 +1,854 @@
+"""A SECOND, independent restatement of the reference's per-sample path -- written from the Dart text of
+/root/reference/lib (file:line cited at every function), NOT from oracle/dartray_oracle.cpp -- in plain Python.
+
+Why it exists: the reference is Dart, no Dart SDK is available in the build image, and the reference ships no golden
+vectors, so the C++ oracle cannot be pinned against the reference itself.  HIP kernels and oracle have one author; a
+shared misreading of the Dart would go unnoticed.  This module is a separate reading: different language, different
+structure (objects mirroring the Dart classes, not the oracle's flat C++), arithmetic in Python floats (IEEE f64, never
+fused) with an explicit f32 round at every place the Dart code stores into a Float32List (Vector / Point / Normal /
+RGBColor constructors, `data[i] = ...`).  tests/golden/make_restatement_fixtures.py runs it on the recorded serial
+sample streams of C1 and C2-small and commits per-sample Li + films; tests compare the oracle and the GPU to them bit
+for bit.
+
+Scope (task 5): Triangle.intersect / intersectP, BVHAccel.intersect / intersectP + _intersectP,
+GeometricPrimitive.intersect, ShapeSet.sample / pdf, Shape.pdf2, DiffuseAreaLight, EstimateDirect,
+UniformSampleOneLight / AllLights, PathIntegrator.Li, DirectLightingIntegrator.Li, matte BSDF (Lambertian),
+PerspectiveCamera.generateRayDifferential, SamplerRenderer's guards, ImageFilm.addSample / writeImage.
+Inputs it does NOT derive: the flattened BVH node array and primitive order (built by the product's dr_bvh_build) and
+the recorded sample vectors / RNG draws.
+
+TEST INFRASTRUCTURE ONLY.
+"""
+import math
+import struct
+
+INFINITY = float("inf")            # common.dart:26 (1.0e500 parses to infinity)
+INV_PI = 0.31830988618379067154    # common.dart:23
+BSDF_REFLECTION, BSDF_TRANSMISSION, BSDF_DIFFUSE, BSDF_GLOSSY, BSDF_SPECULAR = 1, 2, 4, 8, 16  # bsdf.dart:23-27
+BSDF_ALL = 31
+
+
+_pack, _unpack = struct.Struct("<f").pack, struct.Struct("<f").unpack
+
+
+def f32(x):
+    """A store into a Float32List: round-to-nearest-even f64 -> f32 (overflow to +-inf like the VM)."""
+    try:
+        return _unpack(_pack(x))[0]
+    except OverflowError:
+        return math.copysign(INFINITY, x)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# core/vector.dart, point.dart, normal.dart: every constructor stores three f32 values
+# ---------------------------------------------------------------------------------------------------------------
+class Vec:
+    __slots__ = ("x", "y", "z")
+
+    def __init__(self, x=0.0, y=0.0, z=0.0):                     # vector.dart:29-34
+        self.x, self.y, self.z = f32(x), f32(y), f32(z)
+
+    def __add__(self, v):                                          # vector.dart:57-60
+        return Vec(self.x + v.x, self.y + v.y, self.z + v.z)
+
+    def __sub__(self, v):                                          # vector.dart:62-65
+        return Vec(self.x - v.x, self.y - v.y, self.z - v.z)
+
+    def __mul__(self, f):                                          # vector.dart:67-68
+        return Vec(self.x * f, self.y * f, self.z * f)
+
+    def __truediv__(self, f):                                      # vector.dart:70-71
+        return Vec(self.x / f, self.y / f, self.z / f)
+
+    def __neg__(self):                                             # vector.dart:73-74
+        return Vec(-self.x, -self.y, -self.z)
+
+    def lengthSquared(self):                                       # vector.dart:80-81
+        return self.x * self.x + self.y * self.y + self.z * self.z
+
+    def length(self):                                              # vector.dart:83
+        return math.sqrt(self.lengthSquared())
+
+
+def Dot(a, b):                                                     # vector.dart:153-155
+    return a.x * b.x + a.y * b.y + a.z * b.z
+
+
+def AbsDot(a, b):                                                  # vector.dart:157-159
+    return abs(a.x * b.x + a.y * b.y + a.z * b.z)
+
+
+def Cross(a, b):                                                   # vector.dart:161-171
+    return Vec((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x))
+
+
+def Normalize(v):                                                  # vector.dart:173 (v / v.length())
+    return v / v.length()
+
+
+def NormalNormalize(v):                                            # normal.dart:53-55: copy, then invScale(length()): data[i] /= s
+    l = v.length()
+    return Vec(v.x / l, v.y / l, v.z / l)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# core/rgb_color.dart:136-176 (Spectrum == RGBColor): three f32 stores per operation
+# ---------------------------------------------------------------------------------------------------------------
+class RGB:
+    __slots__ = ("r", "g", "b")
+
+    def __init__(self, r=0.0, g=None, b=None):
+        if g is None:
+            g = b = r
+        self.r, self.g, self.b = f32(r), f32(g), f32(b)
+
+    def __add__(self, s):
+        return RGB(self.r + s.r, self.g + s.g, self.b + s.b)
+
+    def __mul__(self, s):
+        if isinstance(s, RGB):
+            return RGB(self.r * s.r, self.g * s.g, self.b * s.b)
+        return RGB(self.r * s, self.g * s, self.b * s)
+
+    def __truediv__(self, s):
+        return RGB(self.r / s, self.g / s, self.b / s)
+
+    def luminance(self):                                           # rgb_color.dart:165-167
+        return 0.212671 * self.r + 0.715160 * self.g + 0.072169 * self.b
+
+    def isBlack(self):                                             # rgb_color.dart:169-174
+        return not (self.r != 0.0 or self.g != 0.0 or self.b != 0.0)
+
+    def hasNaNs(self):
+        return math.isnan(self.r) or math.isnan(self.g) or math.isnan(self.b)
+
+    def tuple(self):
+        return (self.r, self.g, self.b)
+
+
+class Ray:                                                         # core/ray.dart, ray_differential.dart (no differentials)
+    __slots__ = ("o", "d", "mint", "maxt", "depth")
+
+    def __init__(self, o, d, mint=0.0, maxt=INFINITY, depth=0):
+        self.o, self.d, self.mint, self.maxt, self.depth = o, d, mint, maxt, depth
+
+    def pointAt(self, t):                                          # ray.dart:66-67: origin + (direction * t)
+        return self.o + (self.d * t)
+
+
+class DG:                                                          # core/differential_geometry.dart:77-102 (`set`)
+    __slots__ = ("p", "dpdu", "dpdv", "nn")
+
+    def set(self, p, dpdu, dpdv, reverse):
+        self.p, self.dpdu, self.dpdv = p, dpdu, dpdv
+        self.nn = NormalNormalize(Cross(dpdu, dpdv))
+        if reverse:                                                # reverseOrientation ^ transformSwapsHandedness (identity transforms here)
+            self.nn = self.nn * -1.0
+        return self
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# shapes/triangle.dart
+# ---------------------------------------------------------------------------------------------------------------
+class Triangle:
+    def __init__(self, p1, p2, p3, reverse=False):
+        self.p1, self.p2, self.p3, self.reverse = p1, p2, p3, reverse
+
+    def intersect(self, ray):
+        """triangle.dart:44-160: returns (t, rayEpsilon, dg) or None.  All-f64 scalars on the f32 vertex data."""
+        p1, p2, p3 = self.p1, self.p2, self.p3
+        e1x = p2.x - p1.x; e1y = p2.y - p1.y; e1z = p2.z - p1.z
+        e2x = p3.x - p1.x; e2y = p3.y - p1.y; e2z = p3.z - p1.z
+        d = ray.d
+        s1x = (d.y * e2z) - (d.z * e2y)
+        s1y = (d.z * e2x) - (d.x * e2z)
+        s1z = (d.x * e2y) - (d.y * e2x)
+        divisor = (s1x * e1x) + (s1y * e1y) + (s1z * e1z)
+        if divisor == 0.0:
+            return None
+        invDivisor = 1.0 / divisor
+        sx = ray.o.x - p1.x; sy = ray.o.y - p1.y; sz = ray.o.z - p1.z
+        b1 = (sx * s1x + sy * s1y + sz * s1z) * invDivisor
+        if b1 < 0.0 or b1 > 1.0:
+            return None
+        s2x = (sy * e1z) - (sz * e1y)
+        s2y = (sz * e1x) - (sx * e1z)
+        s2z = (sx * e1y) - (sy * e1x)
+        b2 = ((d.x * s2x) + (d.y * s2y) + (d.z * s2z)) * invDivisor
+        if b2 < 0.0 or b1 + b2 > 1.0:
+            return None
+        t = (e2x * s2x + e2y * s2y + e2z * s2z) * invDivisor
+        if t < ray.mint or t > ray.maxt:
+            return None
+        # partial derivatives with the default uvs (0,0) (1,0) (1,1) of getUVs (:255-262)
+        uvs = (0.0, 0.0, 1.0, 0.0, 1.0, 1.0)
+        du1 = uvs[0] - uvs[4]; du2 = uvs[2] - uvs[4]; dv1 = uvs[1] - uvs[5]; dv2 = uvs[3] - uvs[5]
+        dp1 = p1 - p3
+        dp2 = p2 - p3
+        determinant = du1 * dv2 - dv1 * du2
+        assert determinant != 0.0
+        invdet = 1.0 / determinant
+        dpdu = (dp1 * dv2 - dp2 * dv1) * invdet
+        dpdv = (dp1 * -du2 + dp2 * du1) * invdet
+        dg = DG().set(ray.pointAt(t), dpdu, dpdv, self.reverse)
+        return t, 1.0e-3 * t, dg
+
+    def intersectP(self, ray):
+        """triangle.dart:162-194: Vector temporaries (f32) where intersect keeps f64 scalars."""
+        e1 = self.p2 - self.p1
+        e2 = self.p3 - self.p1
+        s1 = Cross(ray.d, e2)
+        divisor = Dot(s1, e1)
+        if divisor == 0.0:
+            return False
+        invDivisor = 1.0 / divisor
+        s = ray.o - self.p1
+        b1 = Dot(s, s1) * invDivisor
+        if b1 < 0.0 or b1 > 1.0:
+            return False
+        s2 = Cross(s, e1)
+        b2 = Dot(ray.d, s2) * invDivisor
+        if b2 < 0.0 or b1 + b2 > 1.0:
+            return False
+        t = Dot(e2, s2) * invDivisor
+        if t < ray.mint or t > ray.maxt:
+            return False
+        return True
+
+    def area(self):                                                # triangle.dart:265-269
+        return 0.5 * Cross(self.p2 - self.p1, self.p3 - self.p1).length()
+
+    def sample(self, u1, u2):
+        """triangle.dart:366-383 -> (point, Ns)."""
+        su1 = math.sqrt(u1)                                        # UniformSampleTriangle montecarlo.dart:215-220
+        b1 = 1.0 - su1
+        b2 = u2 * su1
+        p = self.p1 * b1 + self.p2 * b2 + self.p3 * (1.0 - b1 - b2)
+        n = Cross(self.p2 - self.p1, self.p3 - self.p1)
+        Ns = Normalize(n)
+        if self.reverse:
+            Ns = Vec(Ns.x * -1.0, Ns.y * -1.0, Ns.z * -1.0)
+        return p, Ns
+
+    def pdf2(self, p, wi):
+        """core/shape.dart:100-121."""
+        ray = Ray(p, wi, 1.0e-3)
+        hit = self.intersect(ray)
+        if hit is None:
+            return 0.0
+        thit, _, dgLight = hit
+        q = ray.pointAt(thit)
+        dist2 = (q - p).lengthSquared()                            # Vector.DistanceSquared(p, q) = (q - p).lengthSquared()
+        denom = AbsDot(dgLight.nn, -wi) * self.area()
+        try:
+            pdf = dist2 / denom
+        except ZeroDivisionError:                                  # a double division by zero is +-infinity / NaN in Dart
+            pdf = INFINITY if dist2 > 0 else float("nan")
+        if math.isinf(pdf):
+            pdf = 0.0
+        return pdf
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# accelerators/bvh_accel.dart
+# ---------------------------------------------------------------------------------------------------------------
+class Prim:                                                        # GeometricPrimitive (geometric_primitive.dart)
+    def __init__(self, shape, Kd, light=None):
+        self.shape, self.Kd, self.light = shape, Kd, light
+
+
+class Isect:
+    __slots__ = ("dg", "prim", "rayEpsilon")
+
+
+class BVH:
+    def __init__(self, nodes, prims):
+        """nodes: list of (bmin xyz, bmax xyz, offset, nprims, axis) of the flattened tree; prims in BVH order."""
+        self.nodes, self.prims = nodes, prims
+
+    @staticmethod
+    def _intersectP(node, ray, invDir, dirIsNeg):
+        """bvh_accel.dart:439-472 (bounds[0] = pMin, bounds[1] = pMax)."""
+        b = (node[0], node[1])
+        tmin = (b[dirIsNeg[0]][0] - ray.o.x) * invDir.x
+        tmax = (b[1 - dirIsNeg[0]][0] - ray.o.x) * invDir.x
+        tymin = (b[dirIsNeg[1]][1] - ray.o.y) * invDir.y
+        tymax = (b[1 - dirIsNeg[1]][1] - ray.o.y) * invDir.y
+        if (tmin > tymax) or (tymin > tmax):
+            return False
+        if tymin > tmin:
+            tmin = tymin
+        if tymax < tmax:
+            tmax = tymax
+        tzmin = (b[dirIsNeg[2]][2] - ray.o.z) * invDir.z
+        tzmax = (b[1 - dirIsNeg[2]][2] - ray.o.z) * invDir.z
+        if (tmin > tzmax) or (tzmin > tmax):
+            return False
+        if tzmin > tmin:
+            tmin = tzmin
+        if tzmax < tmax:
+            tmax = tzmax
+        return (tmin < ray.maxt) and (tmax > ray.mint)
+
+    @staticmethod
+    def _invdir(ray):
+        def inv(v):
+            return math.copysign(INFINITY, v) if v == 0.0 else 1.0 / v   # IEEE 1.0 / +-0.0
+        invDir = Vec(inv(ray.d.x), inv(ray.d.y), inv(ray.d.z))            # a Vector: f32 (:109-111)
+        return invDir, (1 if invDir.x < 0 else 0, 1 if invDir.y < 0 else 0, 1 if invDir.z < 0 else 0)
+
+    def intersect(self, ray):
+        """bvh_accel.dart:101-165 -> Isect or None; shrinks ray.maxt (geometric_primitive.dart:47-61)."""
+        if not self.nodes:
+            return None
+        found = None
+        invDir, dirIsNeg = self._invdir(ray)
+        todo, nodeNum = [], 0
+        while True:
+            node = self.nodes[nodeNum]
+            if self._intersectP(node, ray, invDir, dirIsNeg):
+                if node[3] > 0:
+                    for i in range(node[3]):
+                        prim = self.prims[node[2] + i]
+                        hit = prim.shape.intersect(ray)
+                        if hit is not None:
+                            thit, eps, dg = hit
+                            found = Isect()
+                            found.dg, found.prim, found.rayEpsilon = dg, prim, eps
+                            ray.maxt = thit
+                    if not todo:
+                        break
+                    nodeNum = todo.pop()
+                else:
+                    if dirIsNeg[node[4]] != 0:
+                        todo.append(nodeNum + 1)
+                        nodeNum = node[2]
+                    else:
+                        todo.append(node[2])
+                        nodeNum = nodeNum + 1
+            else:
+                if not todo:
+                    break
+                nodeNum = todo.pop()
+        return found
+
+    def intersectP(self, ray):
+        """bvh_accel.dart:167-226."""
+        if not self.nodes:
+            return False
+        invDir, dirIsNeg = self._invdir(ray)
+        todo, nodeNum = [], 0
+        while True:
+            node = self.nodes[nodeNum]
+            if self._intersectP(node, ray, invDir, dirIsNeg):
+                if node[3] > 0:
+                    for i in range(node[3]):
+                        if self.prims[node[2] + i].shape.intersectP(ray):
+                            return True
+                    if not todo:
+                        break
+                    nodeNum = todo.pop()
+                else:
+                    if dirIsNeg[node[4]] != 0:
+                        todo.append(nodeNum + 1)
+                        nodeNum = node[2]
+                    else:
+                        todo.append(node[2])
+                        nodeNum = nodeNum + 1
+            else:
+                if not todo:
+                    break
+                nodeNum = todo.pop()
+        return False
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# core/montecarlo.dart
+# ---------------------------------------------------------------------------------------------------------------
+class Distribution1D:
+    def __init__(self, f):                                         # montecarlo.dart:25-52
+        count = len(f)
+        self.count = count
+        self.func = [f32(v) for v in f]
+        cdf = [0.0] * (count + 1)
+        for i in range(1, count + 1):
+            cdf[i] = f32(cdf[i - 1] + self.func[i - 1] / count)
+        self.funcInt = cdf[count]
+        if self.funcInt == 0.0:
+            for i in range(1, count + 1):
+                cdf[i] = f32(i / count)
+        else:
+            for i in range(1, count + 1):
+                cdf[i] = f32(cdf[i] / self.funcInt)
+        self.cdf = cdf
+
+    def sampleDiscrete(self, u):                                   # montecarlo.dart:82-92 via upper_bound (common.dart:304-333)
+        lst, first, count = self.cdf, 0, self.count + 1
+        if len(lst) == 1:
+            ptr = 0
+        else:
+            while count > 0:
+                index = first
+                step = count >> 1
+                index += step
+                if not (u < lst[index]):
+                    index += 1
+                    first = index
+                    count -= step + 1
+                else:
+                    count = step
+            ptr = first
+        return max(0, ptr - 1)
+
+
+def ConcentricSampleDisk(u1, u2):                                  # montecarlo.dart:155-201
+    sx = 2 * u1 - 1
+    sy = 2 * u2 - 1
+    if sx == 0.0 and sy == 0.0:
+        return 0.0, 0.0
+    if sx >= -sy:
+        if sx > sy:
+            r = sx
+            theta = sy / r if sy > 0.0 else 8.0 + sy / r
+        else:
+            r = sy
+            theta = 2.0 - sx / r
+    else:
+        if sx <= sy:
+            r = -sx
+            theta = 4.0 - sy / r
+        else:
+            r = -sy
+            theta = 6.0 + sx / r
+    theta *= math.pi / 4.0
+    return r * math.cos(theta), r * math.sin(theta)
+
+
+def CosineSampleHemisphere(u1, u2):                                # montecarlo.dart:203-209
+    dx, dy = ConcentricSampleDisk(u1, u2)
+    z = math.sqrt(max(0.0, 1.0 - dx * dx - dy * dy))
+    return Vec(dx, dy, z)
+
+
+def PowerHeuristic(nf, fPdf, ng, gPdf):                            # montecarlo.dart:480-484
+    f = nf * fPdf
+    g = ng * gPdf
+    return (f * f) / (f * f + g * g)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# core/light/shape_set.dart + lights/diffuse_area_light.dart
+# ---------------------------------------------------------------------------------------------------------------
+class ShapeSet:
+    def __init__(self, shapes):                                    # shape_set.dart:24-51 (shapes already in refine order)
+        self.shapes = shapes
+        self.areas = [s.area() for s in shapes]
+        self.area = 0.0
+        for a in self.areas:
+            self.area += a
+        self.areaDistribution = Distribution1D(self.areas)
+
+    def sample(self, uPos, uComponent, p):
+        """shape_set.dart:53-80 (the overload with a reference point) -> (point, Ns)."""
+        sn = self.areaDistribution.sampleDiscrete(uComponent) % len(self.shapes)
+        pt, Ns = self.shapes[sn].sample(uPos[0], uPos[1])          # Shape.sample2 defaults to sample (shape.dart:96-98)
+        r = Ray(p, pt - p, 1.0e-3, INFINITY)
+        thit = 1.0
+        anyHit, dgn = False, None
+        for s in self.shapes:
+            hit = s.intersect(r)                                   # Shape.intersect never shrinks r.maxDistance: the LAST hit wins
+            if hit is not None:
+                thit, dgn = hit[0], hit[2].nn
+                anyHit = True
+        if anyHit:
+            Ns = dgn
+        return r.pointAt(thit), Ns
+
+    def pdf(self, p, wi):                                          # shape_set.dart:82-89
+        pdf = 0.0
+        for a, s in zip(self.areas, self.shapes):
+            pdf += a * s.pdf2(p, wi)
+        return pdf / self.area
+
+
+class DiffuseAreaLight:
+    def __init__(self, Lemit, shapes):
+        self.Lemit = RGB(*Lemit)
+        self.shapeSet = ShapeSet(shapes)
+
+    def L(self, n, w):                                             # diffuse_area_light.dart:44-46
+        return self.Lemit if Dot(n, w) > 0.0 else RGB(0.0)
+
+    def pdf(self, p, w):
+        return self.shapeSet.pdf(p, w)
+
+    def sampleLAtPoint(self, p, pEpsilon, uPos, uComponent):
+        """diffuse_area_light.dart:60-70 -> (Ls, wi, pdf, shadow ray)."""
+        ps, ns = self.shapeSet.sample(uPos, uComponent, p)
+        wo = Normalize(ps - p)
+        pdf = self.shapeSet.pdf(p, wo)
+        dist = (ps - p).length()                                   # VisibilityTester.setSegment (visibility_tester.dart:26-29)
+        shadow = Ray(p, (ps - p) / dist, pEpsilon, dist * (1.0 - 1.0e-3))
+        return self.L(ns, -wo), wo, pdf, shadow
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# core/reflection/bsdf.dart with one Lambertian lobe (materials/matte_material.dart:41-65)
+# ---------------------------------------------------------------------------------------------------------------
+LAMBERT_TYPE = BSDF_REFLECTION | BSDF_DIFFUSE
+
+
+class BSDF:
+    def __init__(self, dgs, ngeom, Kd):
+        self.p, self.nn, self.ng = dgs.p, dgs.nn, ngeom             # bsdf.dart:45-51
+        self.sn = Normalize(dgs.dpdu)
+        self.tn = Cross(self.nn, self.sn)
+        r = RGB(*[min(max(c, 0.0), INFINITY) for c in Kd])          # Kd.evaluate(dgs).clamp()
+        self.R = None if r.isBlack() else r                         # matte_material.dart:54-60: no lobe for a black Kd
+
+    def worldToLocal(self, v):                                      # bsdf.dart:177-179
+        return Vec(Dot(v, self.sn), Dot(v, self.tn), Dot(v, self.nn))
+
+    def localToWorld(self, v):                                      # bsdf.dart:181-185
+        sn, tn, nn = self.sn, self.tn, self.nn
+        return Vec(sn.x * v.x + tn.x * v.y + nn.x * v.z, sn.y * v.x + tn.y * v.y + nn.y * v.z, sn.z * v.x + tn.z * v.y + nn.z * v.z)
+
+    def _matches(self, flags):
+        return self.R is not None and (LAMBERT_TYPE & flags) == LAMBERT_TYPE
+
+    def f(self, woW, wiW, flags):                                   # bsdf.dart:187-211
+        if Dot(wiW, self.ng) * Dot(woW, self.ng) > 0:
+            flags = flags & ~BSDF_TRANSMISSION
+        else:
+            flags = flags & ~BSDF_REFLECTION
+        f = RGB(0.0)
+        if self._matches(flags):
+            f = f + self.R * INV_PI                                 # lambertian.dart:35-37
+        return f
+
+    @staticmethod
+    def _lambert_pdf(wo, wi):                                       # bxdf.dart:84-88
+        return abs(wi.z) * INV_PI if wo.z * wi.z > 0.0 else 0.0
+
+    def pdf(self, woW, wiW, flags):                                 # bsdf.dart:135-156
+        if self.R is None:
+            return 0.0
+        wo, wi = self.worldToLocal(woW), self.worldToLocal(wiW)
+        pdf, matching = 0.0, 0
+        if self._matches(flags):
+            matching += 1
+            pdf += self._lambert_pdf(wo, wi)
+        return pdf / matching if matching > 0 else 0.0
+
+    def sample_f(self, woW, uDir, uComponent, flags):
+        """bsdf.dart:53-133 -> (f, wiW, pdf, sampledType)."""
+        matching = 1 if self._matches(flags) else 0
+        if matching == 0:
+            return RGB(0.0), Vec(), 0.0, 0
+        which = min(math.floor(uComponent * matching), matching - 1)
+        assert which == 0
+        wo = self.worldToLocal(woW)
+        wi = CosineSampleHemisphere(uDir[0], uDir[1])               # BxDF.sample_f (bxdf.dart:37-48)
+        if wo.z < 0.0:
+            wi = Vec(wi.x, wi.y, wi.z * -1.0)
+        pdf = self._lambert_pdf(wo, wi)
+        if pdf == 0.0:
+            return RGB(0.0), Vec(), 0.0, 0
+        wiW = self.localToWorld(wi)
+        f = RGB(0.0)                                                # not specular: re-evaluate over the matching lobes
+        if Dot(wiW, self.ng) * Dot(woW, self.ng) > 0:
+            flags = flags & ~BSDF_TRANSMISSION
+        else:
+            flags = flags & ~BSDF_REFLECTION
+        if self._matches(flags):
+            f = f + self.R * INV_PI
+        return f, wiW, pdf, LAMBERT_TYPE
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# core/integrator.dart, surface_integrators/*.dart, renderers/sampler_renderer.dart
+# ---------------------------------------------------------------------------------------------------------------
+class Scene:
+    def __init__(self, bvh, lights):
+        self.bvh, self.lights = bvh, lights
+
+
+def isect_Le(isect, wo):                                            # intersection.dart:60-63
+    area = isect.prim.light
+    return area.L(isect.dg.nn, wo) if area is not None else RGB(0.0)
+
+
+def getBSDF(isect):
+    """Intersection.getBSDF -> GeometricPrimitive.getBSDF -> Triangle.getShadingGeometry (a copy without per-vertex
+    N / S, triangle.dart:273-276) -> MatteMaterial.getBSDF."""
+    return BSDF(isect.dg, isect.dg.nn, isect.prim.Kd)
+
+
+def EstimateDirect(scene, light, p, n, wo, rayEpsilon, bsdf, lightSample, bsdfSample, flags):
+    """integrator.dart:119-185.  lightSample = (uPos0, uPos1, uComponent), bsdfSample = (uDir0, uDir1, uComponent)."""
+    Ld = RGB(0.0)
+    Li, wi, lightPdf, shadow = light.sampleLAtPoint(p, rayEpsilon, (lightSample[0], lightSample[1]), lightSample[2])
+    if lightPdf > 0.0 and not Li.isBlack():
+        f = bsdf.f(wo, wi, flags)
+        if not f.isBlack() and not scene.bvh.intersectP(shadow):
+            Li = Li * RGB(1.0)                                      # visibility.transmittance: no VolumeRegion
+            bsdfPdf = bsdf.pdf(wo, wi, flags)
+            weight = PowerHeuristic(1, lightPdf, 1, bsdfPdf)
+            Ld = Ld + f * Li * ((AbsDot(wi, n) * weight / lightPdf))
+    f, wi, bsdfPdf, sampledType = bsdf.sample_f(wo, (bsdfSample[0], bsdfSample[1]), bsdfSample[2], flags)
+    if not f.isBlack() and bsdfPdf > 0.0:
+        weight = 1.0
+        if (sampledType & BSDF_SPECULAR) == 0:
+            lightPdf = light.pdf(p, wi)
+            if lightPdf == 0.0:
+                return Ld
+            weight = PowerHeuristic(1, bsdfPdf, 1, lightPdf)
+        Li = RGB(0.0)
+        ray = Ray(p, wi, rayEpsilon, INFINITY)
+        lightIsect = scene.bvh.intersect(ray)
+        if lightIsect is not None:
+            if lightIsect.prim.light is light:
+                Li = isect_Le(lightIsect, -wi)
+        # else: Li = light.Le(ray) == 0 for an area light (light.dart:70-72)
+        if not Li.isBlack():
+            Li = Li * RGB(1.0)                                      # renderer.transmittance
+            Ld = Ld + f * Li * (AbsDot(wi, n) * weight / bsdfPdf)
+    return Ld
+
+
+class Draws:
+    """The RNG.randomFloat() values drawn inside Li, in order (recorded by the serial run)."""
+
+    def __init__(self, values):
+        self.v, self.pos = values, 0
+
+    def randomFloat(self):
+        x = self.v[self.pos]
+        self.pos += 1
+        return float(x)
+
+
+def UniformSampleOneLight(scene, p, n, wo, rayEpsilon, bsdf, rng, lightNumU=None, lightSample=None, bsdfSample=None):
+    """integrator.dart:79-117."""
+    nLights = len(scene.lights)
+    if nLights == 0:
+        return RGB(0.0)
+    if lightNumU is not None:
+        lightNum = math.floor(lightNumU * nLights)
+    else:
+        lightNum = math.floor(rng.randomFloat() * nLights)
+    lightNum = min(lightNum, nLights - 1)
+    light = scene.lights[lightNum]
+    if lightSample is None:
+        lightSample = (f32(rng.randomFloat()), f32(rng.randomFloat()), rng.randomFloat())   # LightSample.random (light_sample.dart:46-51)
+        bsdfSample = (f32(rng.randomFloat()), f32(rng.randomFloat()), rng.randomFloat())    # BSDFSample.random (bsdf_sample.dart:37-42)
+    return EstimateDirect(scene, light, p, n, wo, rayEpsilon, bsdf, lightSample, bsdfSample, BSDF_ALL & ~BSDF_SPECULAR) * float(nLights)
+
+
+SAMPLE_DEPTH = 3                                                    # path_integrator.dart:139
+
+
+def PathLi(scene, r, isect, sv, rng, maxDepth):
+    """path_integrator.dart:29-122.  sv: the flat sample vector (5 camera floats, 14 1-D, 9 2-D entries): per bounce b
+    the 1-D slots (light component, light number, bsdf component, path component) = oneD[4b .. 4b+3] and the 2-D slots
+    (light position, bsdf direction, path direction) = twoD[3b .. 3b+2] -- the order of requestSamples (:124-131)."""
+    oneD = lambda k: float(sv[5 + k])
+    twoD = lambda k: (float(sv[5 + 14 + 2 * k]), float(sv[5 + 14 + 2 * k + 1]))
+    pathThroughput = RGB(1.0)
+    L = RGB(0.0)
+    ray = Ray(r.o, r.d, r.mint, r.maxt, r.depth)
+    specularBounce = False
+    isectP = isect
+    bounces = 0
+    while True:
+        if bounces == 0 or specularBounce:
+            L = L + pathThroughput * isect_Le(isectP, -ray.d)
+        bsdf = getBSDF(isectP)
+        p, n = bsdf.p, bsdf.nn
+        wo = -ray.d
+        if bounces < SAMPLE_DEPTH:
+            lp = twoD(3 * bounces)
+            bd = twoD(3 * bounces + 1)
+            L = L + pathThroughput * UniformSampleOneLight(
+                scene, p, n, wo, isectP.rayEpsilon, bsdf, rng, oneD(4 * bounces + 1),
+                (lp[0], lp[1], oneD(4 * bounces)), (bd[0], bd[1], oneD(4 * bounces + 2)))
+        else:
+            L = L + pathThroughput * UniformSampleOneLight(scene, p, n, wo, isectP.rayEpsilon, bsdf, rng)
+        if bounces < SAMPLE_DEPTH:
+            pd = twoD(3 * bounces + 2)
+            outgoing = (pd[0], pd[1], oneD(4 * bounces + 3))
+        else:
+            outgoing = (f32(rng.randomFloat()), f32(rng.randomFloat()), rng.randomFloat())
+        f, wi, pdf, flags = bsdf.sample_f(wo, (outgoing[0], outgoing[1]), outgoing[2], BSDF_ALL)
+        if f.isBlack() or pdf == 0.0:
+            break
+        specularBounce = (flags & BSDF_SPECULAR) != 0
+        pathThroughput = pathThroughput * (f * AbsDot(wi, n) / pdf)
+        ray = Ray(p, wi, isectP.rayEpsilon, INFINITY, ray.depth + 1)  # RayDifferential.child
+        if bounces > 3:
+            continueProbability = min(0.5, pathThroughput.luminance())
+            if rng.randomFloat() > continueProbability:
+                break
+            pathThroughput = pathThroughput / continueProbability
+        if bounces == maxDepth:
+            break
+        localIsect = scene.bvh.intersect(ray)
+        if localIsect is None:
+            break                                                   # (specularBounce never holds for matte surfaces)
+        pathThroughput = pathThroughput * RGB(1.0)                  # renderer.transmittance
+        isectP = localIsect
+        bounces += 1
+    return L
+
+
+def DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight):
+    """direct_lighting_integrator.dart:30-68 (strategy "all") with UniformSampleAllLights (integrator.dart:39-77).
+    Sample layout (requestSamples :70-87): per light a LightSampleOffsets then a BSDFSampleOffsets, each add1D(n) +
+    add2D(n); the volume integrator's two 1-D slots follow."""
+    bsdf = getBSDF(isect)
+    wo = -ray.d
+    p, n = bsdf.p, bsdf.nn
+    L = RGB(0.0)
+    L = L + isect_Le(isect, wo)
+    if scene.lights:
+        n1D = 2 + sum(2 * k for k in nSamplesPerLight)
+        Lall = RGB(0.0)
+        o1, o2 = 0, 0
+        for i, light in enumerate(scene.lights):
+            ns = nSamplesPerLight[i]
+            lc, lp = o1, o2            # light sample: component slot, position slot
+            bc, bd = o1 + ns, o2 + ns  # bsdf sample
+            o1 += 2 * ns
+            o2 += 2 * ns
+            Ld = RGB(0.0)
+            for j in range(ns):
+                ls = (float(sv[5 + n1D + 2 * (lp + j)]), float(sv[5 + n1D + 2 * (lp + j) + 1]), float(sv[5 + lc + j]))
+                bs = (float(sv[5 + n1D + 2 * (bd + j)]), float(sv[5 + n1D + 2 * (bd + j) + 1]), float(sv[5 + bc + j]))
+                Ld = Ld + EstimateDirect(scene, light, p, n, wo, isect.rayEpsilon, bsdf, ls, bs, BSDF_ALL & ~BSDF_SPECULAR)
+            Lall = Lall + Ld / float(ns)
+        L = L + Lall
+    if ray.depth + 1 < maxDepth:
+        # SpecularReflect / SpecularTransmit (integrator.dart:187-290): each draws a BSDFSample.random(rng); a matte
+        # BSDF has no specular lobe, so both return Spectrum(0)
+        for _ in range(6):
+            rng.randomFloat()
+        L = L + RGB(0.0)
+        L = L + RGB(0.0)
+    return L
+
+
+class PerspectiveCamera:
+    def __init__(self, rasterToCamera, cameraToWorld):
+        self.r2c = [float(v) for v in rasterToCamera]              # Matrix4x4.data: Float32List (row major)
+        self.c2w = [float(v) for v in cameraToWorld]
+
+    @staticmethod
+    def _point(m, p):                                               # transform.dart:110-129
+        x, y, z = p.x, p.y, p.z
+        out = Vec(m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11])
+        w = m[12] * x + m[13] * y + m[14] * z + m[15]
+        if w != 1.0:
+            out = Vec(out.x / w, out.y / w, out.z / w)              # invScale
+        return out
+
+    @staticmethod
+    def _vector(m, p):                                              # transform.dart:131-145
+        x, y, z = p.x, p.y, p.z
+        return Vec(m[0] * x + m[1] * y + m[2] * z, m[4] * x + m[5] * y + m[6] * z, m[8] * x + m[9] * y + m[10] * z)
+
+    def generateRay(self, imageX, imageY):
+        """perspective_camera.dart:93-132 without depth of field."""
+        Pras = Vec(imageX, imageY, 0.0)
+        Pcamera = self._point(self.r2c, Pras)
+        d = Normalize(Pcamera)
+        o = Vec(0.0, 0.0, 0.0)
+        return Ray(self._point(self.c2w, o), self._vector(self.c2w, d), 0.0, INFINITY, 0)
+
+
+def renderer_Li(scene, integrator, maxDepth, camera, px, py, sv, draws, nSamplesPerLight=None):
+    """SamplerRenderer: generateRayDifferential, Li (sampler_renderer.dart:67-98), the guards (:181-193).
+    -> (Ls, imageX, imageY)."""
+    imageX = px + float(sv[0])                                      # montecarlo.dart:451-452
+    imageY = py + float(sv[1])
+    ray = camera.generateRay(imageX, imageY)
+    rng = Draws(draws)
+    isect = scene.bvh.intersect(ray)
+    if isect is not None:
+        if integrator == "path":
+            Li = PathLi(scene, ray, isect, sv, rng, maxDepth)
+        else:
+            Li = DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight)
+    else:
+        Li = RGB(0.0)
+        for _ in scene.lights:
+            Li = Li + RGB(0.0)                                      # light.Le(ray): 0 for area lights
+    Ls = (RGB(1.0) * Li + RGB(0.0)) * 1.0                           # T * Li + Lvi, then * rayWeight
+    if Ls.hasNaNs():
+        Ls = RGB(0.0)
+    elif Ls.luminance() < -1e-5:
+        Ls = RGB(0.0)
+    elif math.isinf(Ls.luminance()):
+        Ls = RGB(0.0)
+    return Ls, imageX, imageY, rng.pos
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# film/image_film.dart
+# ---------------------------------------------------------------------------------------------------------------
+class ImageFilm:
+    FILTER_TABLE_SIZE = 16
+
+    def __init__(self, xres, yres, xWidth, yWidth, filterTable):
+        self.left, self.top, self.width, self.height = 0, 0, xres, yres      # cropWindow [0,1,0,1] (image_film.dart:61-65)
+        self.xWidth, self.yWidth = xWidth, yWidth
+        self.invX, self.invY = 1.0 / xWidth, 1.0 / yWidth                      # filter.dart:33-37
+        self.table = [float(v) for v in filterTable]                          # Float32List
+        self.Lxyz = [0.0] * (3 * xres * yres)                                  # Float32List
+        self.weightSum = [0.0] * (xres * yres)
+
+    def addSample(self, imageX, imageY, L):
+        """image_film.dart:99-150 (the preview repaint is UI only)."""
+        dimageX = imageX - 0.5
+        dimageY = imageY - 0.5
+        x0 = math.ceil(dimageX - self.xWidth)
+        x1 = math.floor(dimageX + self.xWidth)
+        y0 = math.ceil(dimageY - self.yWidth)
+        y1 = math.floor(dimageY + self.yWidth)
+        x0 = max(x0, self.left)
+        x1 = min(x1, self.left + self.width - 1)
+        y0 = max(y0, self.top)
+        y1 = min(y1, self.top + self.height - 1)
+        if (x1 - x0) < 0 or (y1 - y0) < 0:
+            return
+        xyz = (f32(0.412453 * L.r + 0.357580 * L.g + 0.180423 * L.b),       # L.toXYZ(): XYZColor.from (xyz_color.dart:39-42;
+               f32(0.212671 * L.r + 0.715160 * L.g + 0.072169 * L.b),       # spectrum.dart:294-298), stored in a Float32List
+               f32(0.019334 * L.r + 0.119193 * L.g + 0.950227 * L.b))
+        T = self.FILTER_TABLE_SIZE
+        ifx = [min(math.floor(abs((x - dimageX) * self.invX * T)), T - 1) for x in range(x0, x1 + 1)]
+        ify = [min(math.floor(abs((y - dimageY) * self.invY * T)), T - 1) for y in range(y0, y1 + 1)]
+        for y in range(y0, y1 + 1):
+            for x in range(x0, x1 + 1):
+                filterWt = self.table[ify[y - y0] * T + ifx[x - x0]]
+                pi = (y - self.top) * self.width + (x - self.left)
+                self.Lxyz[3 * pi] = f32(self.Lxyz[3 * pi] + filterWt * xyz[0])
+                self.Lxyz[3 * pi + 1] = f32(self.Lxyz[3 * pi + 1] + filterWt * xyz[1])
+                self.Lxyz[3 * pi + 2] = f32(self.Lxyz[3 * pi + 2] + filterWt * xyz[2])
+                self.weightSum[pi] = f32(self.weightSum[pi] + filterWt)
+
+    def writeImage(self):
+        """image_film.dart:268-299 with splatScale * splatRGB == +0."""
+        rgb = [0.0] * (3 * self.width * self.height)
+        for pi in range(self.width * self.height):
+            X, Y, Z = self.Lxyz[3 * pi], self.Lxyz[3 * pi + 1], self.Lxyz[3 * pi + 2]
+            c0 = 3.240479 * X - 1.537150 * Y - 0.498535 * Z             # spectrum.dart:287-291
+            c1 = -0.969256 * X + 1.875991 * Y + 0.041556 * Z
+            c2 = 0.055648 * X - 0.204043 * Y + 1.057311 * Z
+            w = self.weightSum[pi]
+            if w != 0.0:
+                invWt = 1.0 / w
+                rgb[3 * pi] = f32(max(0.0, c0 * invWt))
+                rgb[3 * pi + 1] = f32(max(0.0, c1 * invWt))
+                rgb[3 * pi + 2] = f32(max(0.0, c2 * invWt))
+            for k in range(3):
+                rgb[3 * pi + k] = f32(rgb[3 * pi + k] + 1.0 * 0.0)
+        return rgb

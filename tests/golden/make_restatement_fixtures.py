@@ -1,0 +1,112 @@
+"""Runs the independent Python restatement of the reference path (tests/golden/dart_restatement.py, written from the
+Dart text) on the recorded serial sample streams of the golden cases and commits what IT computes:
+
+  restatement_c1.npz       C1: Cornell floor + emitter, DirectLighting, 64 x 64, 4 spp (16 900 samples)
+  restatement_c2small.npz  C2-small: Cornell box + 1024-triangle blob, PathIntegrator maxdepth 5, 16 x 16, 8 spp
+
+each with per-sample Li (`Ls`), the film (X, Y, Z, weightSum) and the written image (`rgb`), plus the number of RNG
+draws each sample consumed.  Inputs: the scene as the product's host code flattens it (BVH nodes from dr_bvh_build,
+primitives in BVH order), the camera matrices of the product's PerspectiveCamera, and the sample vectors / RNG tails
+recorded in tests/golden/c1_serial.npz and c2small_path_serial.npz.  The tests then require
+oracle == restatement and GPU == restatement, bit for bit.
+
+    python tests/golden/make_restatement_fixtures.py          (about a minute, CPU only)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import dart_restatement as dr  # noqa: E402
+from dartray_amd import core, scenes  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def build_scene(prims_in):
+    """The flattened scene of core.BVHAccel -> restatement objects (no oracle involved)."""
+    acc = core.BVHAccel(prims_in)
+    P = acc.verts
+    pt = lambda i: dr.Vec(float(P[i, 0]), float(P[i, 1]), float(P[i, 2]))
+    # one DiffuseAreaLight per emissive shape; its ShapeSet holds the mesh's triangles in refine (LIFO) order
+    # (shape_set.dart:25-35, triangle_mesh.dart:83-89)
+    lights, light_of = [], {}
+    base = 0
+    for gp in prims_in:
+        mesh = gp.shape
+        if gp.areaLight is not None:
+            tris = []
+            for t in range(len(mesh.vertexIndex) - 1, -1, -1):
+                a, b, c = (int(v) + base for v in mesh.vertexIndex[t])
+                tris.append(dr.Triangle(pt(a), pt(b), pt(c), bool(mesh.reverseOrientation)))
+            light_of[id(gp.areaLight)] = len(lights)
+            lights.append(dr.DiffuseAreaLight(tuple(float(v) for v in gp.areaLight.Lemit), tris))
+        base += len(mesh.P)
+    prims = []
+    for i in range(len(acc.tri_idx)):
+        a, b, c = (int(v) for v in acc.tri_idx[i])
+        mat = acc.materials[int(acc.tri_material[i])]
+        li = int(acc.tri_light[i])
+        light = lights[light_of[id(acc._lights[li])]] if li >= 0 else None
+        prims.append(dr.Prim(dr.Triangle(pt(a), pt(b), pt(c), bool(acc.tri_reverse[i])), tuple(float(v) for v in mat.Kd), light))
+    nodes = [((float(n["bmin"][0]), float(n["bmin"][1]), float(n["bmin"][2])),
+              (float(n["bmax"][0]), float(n["bmax"][1]), float(n["bmax"][2])), int(n["offset"]), int(n["nprims"]), int(n["axis"]))
+             for n in acc.nodes]
+    return dr.Scene(dr.BVH(nodes, prims), lights)
+
+
+def run(name, prims_in, renderer, golden, integrator, nspl=None, limit=None):
+    g = np.load(os.path.join(OUT, golden))
+    scene = build_scene(prims_in)
+    cam = dr.PerspectiveCamera(renderer.camera.rasterToCamera.reshape(-1), renderer.camera.cameraToWorld.reshape(-1))
+    film_desc = renderer.camera.film
+    film = dr.ImageFilm(film_desc.xResolution, film_desc.yResolution, film_desc.filter.xWidth, film_desc.filter.yWidth, film_desc.filterTable)
+    spp = renderer.sampler.samplesPerPixel
+    sv, pix = g["sample_vec"], g["pixel_xy"]
+    tail = g["tail"] if "tail" in g.files else np.zeros((len(sv), 8))
+    n = len(sv) if limit is None else limit
+    Ls = np.zeros((n, 3), np.float32)
+    used = np.zeros(n, np.int32)
+    t0 = time.time()
+    pending = []
+    for k in range(n):
+        px, py = (int(v) for v in pix[k // spp])
+        L, ix, iy, nd = dr.renderer_Li(scene, integrator, renderer.surfaceIntegrator.maxDepth, cam, px, py, sv[k], tail[k], nspl)
+        Ls[k] = L.tuple()
+        used[k] = nd
+        pending.append((ix, iy, L))
+        if (k + 1) % spp == 0:  # the samples of a pixel reach the film after all of them were traced (sampler_renderer.dart:199-203)
+            for a in pending:
+                film.addSample(*a)
+            pending = []
+    out = {"Ls": Ls, "draws_used": used}
+    if limit is None:
+        H, W = film_desc.yResolution, film_desc.xResolution
+        lx = np.array(film.Lxyz, np.float32).reshape(H, W, 3)
+        out["film"] = np.concatenate([lx, np.array(film.weightSum, np.float32).reshape(H, W, 1)], axis=2)
+        out["rgb"] = np.array(film.writeImage(), np.float32).reshape(H, W, 3)
+    print("%s: %d samples in %.1f s" % (name, n, time.time() - t0))
+    return out
+
+
+def cases():
+    prims, mk = scenes.config("C1")
+    yield "restatement_c1.npz", prims, mk(), "c1_serial.npz", "direct", [1]
+    prims, mk = scenes.config("C2", xres=16, yres=16, spp=8, blob=(32, 16))
+    yield "restatement_c2small.npz", prims, mk(), "c2small_path_serial.npz", "path", None
+
+
+def main():
+    for name, prims, r, golden, integ, nspl in cases():
+        out = run(name, prims, r, golden, integ, nspl)
+        np.savez_compressed(os.path.join(OUT, name), **out)
+        print(name, os.path.getsize(os.path.join(OUT, name)))
+
+
+if __name__ == "__main__":
+    main()
