@@ -98,3 +98,30 @@ def test_c1_rendered_by_the_c_host_equals_the_golden(gpu, tmp_path):
     n4 = film.width * film.height * 4
     assert np.array_equal(raw[:n4].reshape(film.height, film.width, 4), g["film"])
     assert np.array_equal(raw[n4:].reshape(film.height, film.width, 3), g["rgb"])
+
+
+def test_dart_binding_offsets_equal_the_c_layout(tmp_path):
+    """integration/hip_sampler_renderer.dart writes the structs field by field at literal byte offsets (no Dart SDK
+    exists here to run it): every SIZEOF_<Struct> / OFF_<Struct>_<field> constant of that file is checked against
+    sizeof / offsetof of include/dartray_hip.h by a generated C program."""
+    dart = open(os.path.join(ROOT, "integration", "hip_sampler_renderer.dart")).read()
+    sizes = re.findall(r"^const int SIZEOF_(\w+) = (\d+);", dart, flags=re.M)
+    offs = re.findall(r"^const int OFF_(Dr[A-Za-z]+)_(\w+) = (\d+);", dart, flags=re.M)
+    assert len(sizes) >= 10 and len(offs) >= 80
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "dartray_hip.h"', 'int main(void) {', '  int bad = 0;']
+    for name, n in sizes:
+        src.append('  if (sizeof(%s) != %s) { printf("sizeof(%s) = %%zu, Dart says %s\\n", sizeof(%s)); bad = 1; }' % (name, n, name, n, name))
+    for name, field, n in offs:
+        src.append('  if (offsetof(%s, %s) != %s) { printf("offsetof(%s, %s) = %%zu, Dart says %s\\n", offsetof(%s, %s)); bad = 1; }'
+                   % (name, field, n, name, field, n, name, field))
+    src += ['  return bad;', '}']
+    c = tmp_path / "dart_offsets.c"
+    c.write_text("\n".join(src))
+    exe = str(tmp_path / "dart_offsets")
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(c), "-o", exe])
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout
+    # every entry point the Dart file looks up exists in the header
+    header = open(HEADER).read()
+    for sym in re.findall(r"lookupFunction<\w+, \w+>\('(dr_\w+)'\)", dart):
+        assert re.search(r"\b%s\s*\(" % sym, header), sym
