@@ -93,7 +93,6 @@ struct DrScene {
   uint32_t bvhDepth = 0;
   bool traceCalibrated = false;
   float calibMs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // pilot of dr_render_device: [closest / any][v2 / v3] ms
-  DevBuf<int2> pilotPix;
   std::vector<int32_t> lightNSamples;
   bool hasSpecular = false;  // some material is a mirror / glass
   bool hasDeltaLight = false;
@@ -870,8 +869,8 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     TRY_SC(sc->lcdf.alloc(cdf.size()));
     TRY_SC(hipMemcpy(sc->lcdf.p, cdf.data(), cdf.size() * sizeof(float), hipMemcpyHostToDevice));
   }
-  TRY_SC(sc->ctr.alloc(2));  // [0] live, [1] snapshot taken around the traversal pilot
-  TRY_SC(hipMemset(sc->ctr.p, 0, 2 * sizeof(TraceCounters)));
+  TRY_SC(sc->ctr.alloc(1));
+  TRY_SC(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
   TRY_SC(sc->quads.alloc(std::max<size_t>(sc->hostQuads.size(), 1)));
   if (!sc->hostQuads.empty())
     TRY_SC(hipMemcpy(sc->quads.p, sc->hostQuads.data(), sc->hostQuads.size() * sizeof(DQuadric), hipMemcpyHostToDevice));
@@ -1149,6 +1148,42 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     if (rc) return rc;
     if (!sc->s2) HIP_TRY(hipStreamCreateWithFlags(&sc->s2, hipStreamNonBlocking));
   }
+  // Which traversal kernel?  v2 (one node per step, f32 filter) is issue bound and wins while the hot part of the tree
+  // stays in cache; v3 (sibling pairs, half the dependent fetches) wins on big incoherent trees (C4 hairball +26 %)
+  // and loses on others of the same size (C5 courtyard: closest -8 %, any hit -33 %); random probe rays mispredict
+  // both.  So the first big render of a big scene measures it ON ITS OWN WORK: three small calibration batches -- 64-pixel
+  // groups spread over the image, ~1.5 % of the camera samples each -- are rendered first, into the film like every
+  // other batch: one with v2 to warm the caches, one with v2 and one with v3 that are timed; each ray kind then keeps
+  // the kernel with the better time per algorithmic byte (the device's own node / triangle counters of that batch).
+  // Nothing is traced twice: the calibration costs only what three small launches lose against one big one (round 1
+  // ran up to six extra passes over pilot rays that never reached the film: 19 % of a C2 render, 64 % of C4's).
+  // Both kernels are bit-exact, so results do not depend on the choice; dr_scene_set_trace_kernels / DARTRAY_TRACE_IMPL fix it.
+  static const bool pilotOff = getenv("DARTRAY_PILOT") && atoi(getenv("DARTRAY_PILOT")) == 0;
+  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || getenv("DARTRAY_PILOT_FORCE");
+  const bool calibrate = !sc->traceCalibrated && !pilotOff && !hostBuf && !dlSpec && !getenv("DARTRAY_TRACE_IMPL") && sc->d.pairs &&
+                         !sc->d.nquads && bigJob && npixTotal >= 3 * 64 * 4 && !(nPipesEnv >= 2);
+  size_t calibPix = 0;  // pixels per calibration batch; the three batches are the first 3 * calibPix entries of `pixels`
+  if (calibrate) {
+    uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 22, (uint64_t)npixTotal * spp / 64));
+    if (getenv("DARTRAY_PILOT_BITS")) pilotSamples = 1ull << atoi(getenv("DARTRAY_PILOT_BITS"));
+    pilotSamples = std::min<uint64_t>(pilotSamples, (uint64_t)(pixPerBatch / 64 * 64) * spp);
+    const size_t totalGroups = npixTotal / 64;
+    const size_t groups = std::min<size_t>(std::max<size_t>(1, (size_t)(pilotSamples / spp) / 64), totalGroups / 4);
+    calibPix = groups * 64;
+    std::vector<int2> ordered;
+    ordered.reserve(npixTotal);
+    std::vector<uint8_t> taken(totalGroups, 0);
+    for (int set = 0; set < 3; ++set)
+      for (size_t g = 0; g < groups; ++g) {
+        const size_t grp = ((3 * g + set) * totalGroups) / (3 * groups);  // interleaved: the three sets see the same regions
+        taken[grp] = 1;
+        ordered.insert(ordered.end(), pixels.begin() + grp * 64, pixels.begin() + grp * 64 + 64);
+      }
+    for (size_t grp = 0; grp < totalGroups; ++grp)
+      if (!taken[grp]) ordered.insert(ordered.end(), pixels.begin() + grp * 64, pixels.begin() + grp * 64 + 64);
+    ordered.insert(ordered.end(), pixels.begin() + totalGroups * 64, pixels.end());
+    pixels.swap(ordered);
+  }
   HIP_TRY(sc->ws.pix.alloc(npixTotal));
   HIP_TRY(hipMemcpyAsync(sc->ws.pix.p, pixels.data(), npixTotal * sizeof(int2), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(sc->ws.filterTable.p, rd->film.filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s));
@@ -1165,8 +1200,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
   if (4 * nStages + 8 > 1000 || 8 * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
 
-  // One batch through the stage loop.  pilot != null: a measurement run (no film, its trace launches timed into
-  // pilot[kind]) -- see the calibration below.
+  // One batch through the stage loop.  pilot != null: a calibration batch -- a normal batch whose traversal launches are
+  // also collected into pilot->ev[kind] (see above).
   struct PilotTimes {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
   };
@@ -1177,7 +1212,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     auto timed = [&](int kind, hipEvent_t e0) {
       hipEvent_t e1 = sc->getEvent();
       (void)hipEventRecord(e1, s);
-      if (!pilot) sc->traceEvents.push_back({e0, e1, kind});
+      sc->traceEvents.push_back({e0, e1, kind});
     };
     hipEvent_t evGen = sc->getEvent();
     (void)hipEventRecord(evGen, s);
@@ -1202,7 +1237,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       launch_trace(sc->d, st, queue, nQ, any, w.spill.p, C + 1024 + 8 * (wc++), sc->ctr.p, tgrid, s);
       (void)hipEventRecord(e1, s);
       if (pilot) pilot->ev[any].push_back({e0, e1});
-      else sc->traceEvents.push_back({e0, e1, any});
+      sc->traceEvents.push_back({e0, e1, any});
     };
     // DirectLighting over mirror / glass: one round of the stage loop per vertex of a slot's ray tree; `roundQ` lists
     // the slots whose (camera or child) ray this round traces.  Everything else: one round.
@@ -1266,7 +1301,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       nRound = nNext;
     }
     }
-    if (!pilot) {
+    {
       hipEvent_t evF = sc->getEvent();
       (void)hipEventRecord(evF, s);
       launch_film(rp, st, sc->ws.filterTable.p, np, (float*)film_dev, s);
@@ -1278,75 +1313,63 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     return DR_OK;
   };
 
-  // Which traversal kernel?  v2 (one node per step, f32 filter) is issue bound and wins while the hot part of the tree
-  // stays in cache; v3 (sibling pairs, half the dependent fetches) wins on big incoherent trees (C4 hairball +26 %)
-  // and loses on others of the same size (C5 courtyard: closest -8 %, any hit -33 %); random probe rays mispredict
-  // both.  So the first big render of a big scene measures it on its own rays: 2^22 camera samples (64-pixel groups
-  // spread over the image) go through the stage loop once per kernel without touching the film, and each ray kind
-  // keeps v3 only if it was 5 % faster.  Both kernels are bit-exact, so results do not depend on the choice;
-  // DARTRAY_TRACE_IMPL fixes it.
-  static const bool pilotOff = getenv("DARTRAY_PILOT") && atoi(getenv("DARTRAY_PILOT")) == 0;
-  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || getenv("DARTRAY_PILOT_FORCE");
-  if (!sc->traceCalibrated && !pilotOff && !hostBuf && !getenv("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads && bigJob && npixTotal >= 64) {
-    // pilot size: ~1.5 % of the render, between 2^22 and 2^25 camera samples (small launches are dominated by their
-    // ramp-up and tail and mispredict), one warm-up pass and one timed pass per kernel: ~6 % of this first render
-    // (DrRenderStats.pilot_ms); DARTRAY_PILOT=0 skips it (the default kernel, v2, is then used)
-    uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 22, (uint64_t)npixTotal * spp / 64));
-    if (getenv("DARTRAY_PILOT_BITS")) pilotSamples = 1ull << atoi(getenv("DARTRAY_PILOT_BITS"));
-    pilotSamples = std::min<uint64_t>(pilotSamples, (uint64_t)(pixPerBatch / 64 * 64) * spp);
-    const size_t groups = std::max<size_t>(1, (size_t)(pilotSamples / spp) / 64);
-    const size_t totalGroups = npixTotal / 64;
-    std::vector<int2> pp;
-    for (size_t g = 0; g < groups; ++g) {
-      const size_t src = (g * totalGroups / groups) * 64;
-      pp.insert(pp.end(), pixels.begin() + src, pixels.begin() + src + 64);
-    }
-    HIP_TRY(sc->pilotPix.alloc(pp.size()));
-    HIP_TRY(hipMemcpy(sc->pilotPix.p, pp.data(), pp.size() * sizeof(int2), hipMemcpyHostToDevice));
-    // the Stats probes count renders, not the pilot: counters of earlier renders that have not been read yet survive it
-    HIP_TRY(hipMemcpyAsync(sc->ctr.p + 1, sc->ctr.p, sizeof(TraceCounters), hipMemcpyDeviceToDevice, s));
+  size_t firstPix = 0;
+  if (calibrate) {
     hipEvent_t evP0 = sc->getEvent(), evP1 = sc->getEvent();
     HIP_TRY(hipEventRecord(evP0, s));
-    const size_t evSaved = sc->eventsUsed;
+    double perByte[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // [closest / any][v2 / v3]: ms per algorithmic GB
     float ms[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int impl = 2; impl <= 3; ++impl) {
+    auto readCtr = [&](TraceCounters* c) -> int {
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipMemcpy(c, sc->ctr.p, sizeof(TraceCounters), hipMemcpyDeviceToHost));
+      return DR_OK;
+    };
+    for (int set = 0; set < 3; ++set) {  // warm-up (v2), v2 timed, v3 timed
+      const int impl = set == 2 ? 3 : 2;
       sc->d.traceKernel[0] = sc->d.traceKernel[1] = (uint32_t)impl;
-      for (int rep = 0; rep < 2; ++rep) {  // the first pass warms the caches, the second one counts
-        PilotTimes pt;
-        int prc = runBatch(sc->ws, sc->pilotPix.p, 0, (uint32_t)pp.size(), &pt);
-        if (prc) return prc;
-        HIP_TRY(hipStreamSynchronize(s));
-        if (rep > 0)
-          for (int kind = 0; kind < 2; ++kind) {
-            float sum = 0.f;
-            for (auto& e : pt.ev[kind]) {
-              float t = 0.f;
-              (void)hipEventElapsedTime(&t, e.first, e.second);
-              sum += t;
-            }
-            ms[kind][impl - 2] = sum;
-          }
-        sc->eventsUsed = evSaved;
+      TraceCounters c0, c1;
+      int prc = readCtr(&c0);
+      if (prc) return prc;
+      PilotTimes pt;
+      prc = runBatch(sc->ws, sc->ws.pix.p + set * calibPix, set * calibPix, (uint32_t)calibPix, &pt);
+      if (prc) return prc;
+      prc = readCtr(&c1);
+      if (prc) return prc;
+      if (set == 0) continue;
+      const double bytes[2] = {32.0 * (double)(c1.closest_nodes - c0.closest_nodes) + 48.0 * (double)(c1.closest_tris - c0.closest_tris),
+                               32.0 * (double)(c1.any_nodes - c0.any_nodes) + 48.0 * (double)(c1.any_tris - c0.any_tris)};
+      for (int kind = 0; kind < 2; ++kind) {
+        float sum = 0.f;
+        for (auto& e : pt.ev[kind]) {
+          float t = 0.f;
+          (void)hipEventElapsedTime(&t, e.first, e.second);
+          sum += t;
+        }
+        ms[kind][impl - 2] = sum;
+        perByte[kind][impl - 2] = bytes[kind] > 0.0 ? (double)sum / (bytes[kind] * 1.0e-9) : 0.0;
       }
     }
     for (int kind = 0; kind < 2; ++kind) {
-      sc->d.traceKernel[kind] = ms[kind][1] < 0.95f * ms[kind][0] ? 3u : 2u;
+      sc->d.traceKernel[kind] = perByte[kind][1] < 0.95 * perByte[kind][0] ? 3u : 2u;
       sc->calibMs[kind][0] = ms[kind][0];
       sc->calibMs[kind][1] = ms[kind][1];
     }
-    // small pilot launches understate v3's advantage on shadow rays (C4: 6 % in the pilot, 25 % in the render): where
-    // the closest-hit rays prefer v3 clearly, the any-hit rays take it as soon as it is not slower
-    if (ms[0][1] < 0.85f * ms[0][0] && ms[1][1] <= ms[1][0]) sc->d.traceKernel[1] = 3u;
+    // small launches understate v3's advantage on shadow rays (C4: -2 ... +6 % in a calibration batch, +25 % in the
+    // full-size launches of the render): where the closest-hit rays prefer v3 clearly (10 %), the any-hit rays take
+    // it unless the calibration batch found it more than 5 % slower (C2 / C5, where v3 loses, are 30 - 40 % slower)
+    if (perByte[0][1] < 0.90 * perByte[0][0] && perByte[1][1] <= 1.05 * perByte[1][0]) sc->d.traceKernel[1] = 3u;
     sc->traceCalibrated = true;
-    HIP_TRY(hipMemcpyAsync(sc->ctr.p, sc->ctr.p + 1, sizeof(TraceCounters), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipEventRecord(evP1, s));
-    sc->traceEvents.push_back({evP0, evP1, 5});
+    sc->traceEvents.push_back({evP0, evP1, 5});  // DrRenderStats.pilot_ms: the time of the three calibration batches
+    firstPix = 3 * calibPix;
+    batchIndex = 3;
     if (getenv("DARTRAY_VERBOSE"))
-      fprintf(stderr, "dartray_hip: traversal pilot (%zu samples), closest v2 %.2f ms / v3 %.2f ms -> v%u; any hit v2 %.2f / v3 %.2f -> v%u\n",
-              pp.size() * (size_t)spp, ms[0][0], ms[0][1], sc->d.traceKernel[0], ms[1][0], ms[1][1], sc->d.traceKernel[1]);
+      fprintf(stderr, "dartray_hip: traversal pilot (3 x %zu samples, rendered into the film), ms per algorithmic GB: closest v2 %.4f / v3 %.4f -> v%u; "
+              "any hit v2 %.4f / v3 %.4f -> v%u\n", calibPix * (size_t)spp, perByte[0][0], perByte[0][1], sc->d.traceKernel[0],
+              perByte[1][0], perByte[1][1], sc->d.traceKernel[1]);
   }
 
-  for (size_t p0 = 0; p0 < npixTotal; p0 += pixPerBatch, ++batchIndex) {
+  for (size_t p0 = firstPix; p0 < npixTotal; p0 += pixPerBatch, ++batchIndex) {
     const bool second = twoPipes && (batchIndex & 1);
     s = second ? sc->s2 : callerStream;
     const uint32_t np = (uint32_t)std::min<size_t>(pixPerBatch, npixTotal - p0);
