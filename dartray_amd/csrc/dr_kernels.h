@@ -48,6 +48,8 @@ struct RenderParams {
 #define PF_HAS_MIS 2u   // closest-hit ray of the BSDF-sampling half is pending
 #define PF_HAS_CONT 4u  // continuation ray is pending
 #define PF_SPECULAR 8u  // the continuation ray was sampled from a specular lobe (specularBounce)
+#define PF_RAW_NEE 16u  // path kernel: Ld1 / Ld2 / betaNee hold the raw EstimateDirect terms (a MIS ray is pending, a delta
+                        // light, or a non-finite throughput); clear: Ld1 already is pathThroughput * (Ld1 * nLights)
 
 #define Q_MIS_BIT 0x80000000u
 

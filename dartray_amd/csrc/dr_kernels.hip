@@ -456,9 +456,15 @@ DR_DEV C3 resolve_nee(const DScene& sc, const LV& lv, const SlotRef& sr, uint32_
 
 // EstimateDirect up to the points where it must trace (integrator.dart:119-185):
 // writes the shadow ray / MIS ray and their candidate contributions.
-template <bool ENV, bool QUAD, bool NI, class LV>
+// PRE (the path kernel): the common outcome -- a shadow ray, no MIS ray -- stores the FINISHED contribution
+// pathThroughput * (Ld1 * nLights) in Ld1 (the reference's own roundings: Ld = 0 + Ld1; Ld * nLights; pathThroughput *
+// that, integrator.dart:113-116 / path_integrator.dart:56-68), so that the next stage reads 12 bytes instead of 24 and
+// nobody writes betaNee; the two halves are evaluated BSDF half first (they are independent) so that the light half
+// knows whether a MIS ray is pending.  Every other outcome keeps the raw terms and sets PF_RAW_NEE.
+template <bool ENV, bool QUAD, bool NI, bool PRE, class LV>
 DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const SlotRef& sr, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
-                          F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1, double bsc) {
+                          F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1, double bsc,
+                          C3 beta = C3{0.f, 0.f, 0.f}, double nLights = 0.0) {
   const DLight light = lv.light(lightNum);
   const int flags = BSDF_ALL & ~BSDF_SPECULAR;
   uint32_t pf = 0;
@@ -505,44 +511,13 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const SlotRef& sr, int
           sr.f64<F_SHTMAX>() = dist * (1.0 - 0.0);
         }
         stcf<F_LD1>(sr, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) / 1.0)));
-        pf |= PF_HAS_SH;
+        pf |= PF_HAS_SH | (PRE ? PF_RAW_NEE : 0u);
       }
     }
     return pf;
   }
-  if (!infinite) {
-    // DiffuseAreaLight.sampleLAtPoint (diffuse_area_light.dart:60-70)
-    F3 ns;
-    ps = shapeset_sample<QUAD>(sc, lv, light, ls0, ls1, lsc, &ns, p);
-    wi = vnormalize(vsub(ps, p));
-    lightPdf = shapeset_pdf<QUAD>(sc, lv, light, p, wi);
-    Li = light_L(light, ns, vneg(wi));
-  } else {
-    // InfiniteAreaLight.sampleLAtPoint (infinite_area_light.dart:92-131)
-    Li = env_sample_x<NI>(sc.env, ls0, ls1, &wi, &lightPdf);
-  }
-  if (lightPdf > 0.0 && !cblack(Li)) {
-    C3 f = bsdf_f(bsdf, wo, wi, flags);
-    if (!cblack(f)) {
-      if (!infinite) {
-        // VisibilityTester.setSegment (visibility_tester.dart:26-29)
-        F3 seg = vsub(ps, p);
-        double dist = vlen(seg);
-        st3f<F_SHD>(sr, vdiv(seg, dist));
-        sr.f64<F_SHTMAX>() = dist * (1.0 - 1.0e-3);
-      } else {
-        // VisibilityTester.setRay (visibility_tester.dart:31-33)
-        st3f<F_SHD>(sr, wi);
-        sr.f64<F_SHTMAX>() = DR_INF;
-      }
-      double bsdfPdf = bsdf_pdf(bsdf, wo, wi, flags);
-      double weight = PowerHeuristic(lightPdf, bsdfPdf);
-      stcf<F_LD1>(sr, cmulD(cmul(f, Li), (fabs(vdot(wi, n)) * weight / lightPdf)));
-      pf |= PF_HAS_SH;
-    }
-  }
-  // BSDF-sampling half
-  {
+  // the BSDF-sampling half (integrator.dart:152-182)
+  auto bsdfHalf = [&]() {
     F3 wi2 = F3{0, 0, 0};
     double bsdfPdf = 0.0;
     C3 f = bsdf_sample_f(bsdf, wo, &wi2, bs0, bs1, bsc, &bsdfPdf, flags);
@@ -559,6 +534,51 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const SlotRef& sr, int
         pf |= PF_HAS_MIS;  // scene.intersect is called before `if (!Li.isBlack())` (integrator.dart:169-177)
       }
     }
+  };
+  // the light-sampling half (integrator.dart:128-150)
+  auto lightHalf = [&](bool raw) {
+    if (!infinite) {
+      // DiffuseAreaLight.sampleLAtPoint (diffuse_area_light.dart:60-70)
+      F3 ns;
+      ps = shapeset_sample<QUAD>(sc, lv, light, ls0, ls1, lsc, &ns, p);
+      wi = vnormalize(vsub(ps, p));
+      lightPdf = shapeset_pdf<QUAD>(sc, lv, light, p, wi);
+      Li = light_L(light, ns, vneg(wi));
+    } else {
+      // InfiniteAreaLight.sampleLAtPoint (infinite_area_light.dart:92-131)
+      Li = env_sample_x<NI>(sc.env, ls0, ls1, &wi, &lightPdf);
+    }
+    if (lightPdf > 0.0 && !cblack(Li)) {
+      C3 f = bsdf_f(bsdf, wo, wi, flags);
+      if (!cblack(f)) {
+        if (!infinite) {
+          // VisibilityTester.setSegment (visibility_tester.dart:26-29)
+          F3 seg = vsub(ps, p);
+          double dist = vlen(seg);
+          st3f<F_SHD>(sr, vdiv(seg, dist));
+          sr.f64<F_SHTMAX>() = dist * (1.0 - 1.0e-3);
+        } else {
+          // VisibilityTester.setRay (visibility_tester.dart:31-33)
+          st3f<F_SHD>(sr, wi);
+          sr.f64<F_SHTMAX>() = DR_INF;
+        }
+        double bsdfPdf = bsdf_pdf(bsdf, wo, wi, flags);
+        double weight = PowerHeuristic(lightPdf, bsdfPdf);
+        C3 X = cmulD(cmul(f, Li), (fabs(vdot(wi, n)) * weight / lightPdf));
+        if (!raw) X = cmul(beta, cmulD(cadd(C3{0.f, 0.f, 0.f}, X), nLights));  // Ld = 0 + Ld1; * nLights; pathThroughput * ...
+        stcf<F_LD1>(sr, X);
+        pf |= PF_HAS_SH;
+      }
+    }
+  };
+  if (PRE) {
+    bsdfHalf();
+    const bool raw = (pf & PF_HAS_MIS) != 0 || !(isfinite(beta.r) && isfinite(beta.g) && isfinite(beta.b));
+    lightHalf(raw);
+    if (raw && pf != 0) pf |= PF_RAW_NEE;
+  } else {
+    lightHalf(true);
+    bsdfHalf();
   }
   return pf;
 }
@@ -598,7 +618,7 @@ struct ShadeIn {
   uint32_t slot, flags;
   int hprim, shOcc;
   double t;
-  C3 L, beta, betaNee, Ld1;
+  C3 L, beta, Ld1;
   F3 o, d;
   // this bounce's sample-vector entries (Appendix B), as fetched (sv_fetch1/2): lightNum, light comp, light pos,
   // bsdf dir, path dir, the two uComponents; evaluated when the item is shaded
@@ -618,13 +638,12 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
   in->t = sr.f64<F_HT>();
   if (bounce == 0) {  // the camera vertex: nothing pending, pathThroughput = 1, L = 0 (k_raygen does not store them)
     in->shOcc = 0;
-    in->L = in->betaNee = in->Ld1 = C3{0.f, 0.f, 0.f};
+    in->L = in->Ld1 = C3{0.f, 0.f, 0.f};
     in->beta = C3{1.f, 1.f, 1.f};
   } else {
     in->shOcc = sr.i32<F_SHOCC>();
     in->L = ldcf<F_L>(sr);
     in->beta = ldcf<F_BETA>(sr);
-    in->betaNee = ldcf<F_BETANEE>(sr);
     in->Ld1 = ldcf<F_LD1>(sr);
   }
   in->o = ld3f<F_RO>(sr);
@@ -796,8 +815,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       const int shOccIn = cur.shOcc;
       C3 L = cur.L;
       C3 beta = cur.beta;
-      const C3 betaNeeIn = cur.betaNee;
       const C3 Ld1In = cur.Ld1;
+      bool Lchanged = bounce == 0;  // L is stored when this stage changed it (the camera stage initialises it)
       const F3 o = cur.o, d = cur.d;
       auto su = [&](int k) -> float {
         if (st.svFloat) return __uint_as_float(cur.raw[k]);
@@ -809,9 +828,15 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       PROF(0);
       if (bounce > 0 && rp.nLights > 0) {
         // L += pathThroughput * UniformSampleOneLight(...) of the previous vertex (path_integrator.dart:56-68)
-        C3 Ld = resolve_nee<ENV, QUAD>(sc, lv, sr, flags, shOccIn, Ld1In);
-        C3 tot = cmulD(Ld, (double)rp.nLights);  // integrator.dart:113-116
-        L = cadd(L, cmul(betaNeeIn, tot));
+        if (flags & PF_RAW_NEE) {
+          C3 Ld = resolve_nee<ENV, QUAD>(sc, lv, sr, flags, shOccIn, Ld1In);
+          C3 tot = cmulD(Ld, (double)rp.nLights);  // integrator.dart:113-116
+          L = cadd(L, cmul(ldcf<F_BETANEE>(sr), tot));
+          Lchanged = true;
+        } else if ((flags & PF_HAS_SH) && shOccIn == 0) {
+          L = cadd(L, Ld1In);  // the finished term (setup_nee, PRE); an occluded or absent estimate adds pathThroughput * 0
+          Lchanged = true;
+        }
       }
       PROF(1);
       const int prim = (flags & PF_HAS_CONT) ? hprimIn : -1;
@@ -819,10 +844,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         // the camera ray escaped: Li = sum over lights of light.Le(ray) (sampler_renderer.dart:87-92); area
         // lights return 0 (light.dart:70-72), the infinite light its map
         L = cadd(L, env_Le_x<(ENV && !QUAD)>(sc.env, d));
+        Lchanged = true;
       }
       if (ENV && QUAD && bounce > 0 && prim < 0 && (flags & PF_HAS_CONT) && (flags & PF_SPECULAR) && sc.hasEnv) {
         // a ray that left the scene after a specular bounce still sees the lights (path_integrator.dart:107-111)
         L = cadd(L, cmul(beta, env_Le_x<(ENV && !QUAD)>(sc.env, d)));
+        Lchanged = true;
       }
       if (prim >= 0 && bounce <= rp.maxDepth) {
         Tri tr = load_tri(sc, (uint32_t)prim);
@@ -845,6 +872,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         if (bounce == 0 || (QUAD && (flags & PF_SPECULAR))) {  // bounces == 0 || specularBounce (path_integrator.dart:46)
           C3 Le = tr.light >= 0 ? light_L(lv.light(tr.light), dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
           L = cadd(L, cmul(beta, Le));
+          Lchanged = true;
         }
         Bsdf bsdf = make_bsdf<QUAD>(lv, dgs, tr.mat);
         bsdf.ng = dg.nn;  // BSDF(dgs, dgGeom.nn)
@@ -874,8 +902,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           int lightNum = (int)floor(lu * rp.nLights);
           lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
           PROF(3);
-          pf |= setup_nee<ENV, QUAD, (ENV && !QUAD)>(sc, lv, sr, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc);
-          stcf<F_BETANEE>(sr, beta);
+          pf |= setup_nee<ENV, QUAD, (ENV && !QUAD), true>(sc, lv, sr, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc, beta,
+                                                            (double)rp.nLights);
+          if (pf & PF_RAW_NEE) stcf<F_BETANEE>(sr, beta);
         }
         PROF(5);
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
@@ -914,7 +943,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         sr.f64<F_RTMIN>() = eps;
         vert = true;
       }
-      stcf<F_L>(sr, L);
+      if (Lchanged) stcf<F_L>(sr, L);
       sr.u32<F_FLAGS>() = pf;
       PROF(7);
     }
@@ -1012,7 +1041,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           double lsc = sv_one(rp, st, slot, cur.lc);
           double ls0 = l0, ls1 = l1, bs0 = b0, bs1 = b1;
           double bsc = QUAD ? (double)sv_one(rp, st, slot, cur.bc) : 0.0;
-          pf |= setup_nee<true, QUAD, false>(sc, lv, sr, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
+          pf |= setup_nee<true, QUAD, false, false>(sc, lv, sr, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
           again = true;
         } else {
           if (rp.nLights > 0) L = cadd(L, Lall);
