@@ -663,9 +663,8 @@ DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int boun
 // DrRenderStats.shade_items / shade_vertices: the per-wave vertex counts stage_push kept in LDS, one no-return atomic
 // per workgroup at the end of a shade kernel
 DR_DEV void shade_count_init(PushStage& sm) {
-  if (threadIdx.x < 16) sm.nVert[threadIdx.x] = 0;
   if (threadIdx.x < 256) sm.sobol[threadIdx.x] = c_sobol.lo[threadIdx.x];
-  __syncthreads();
+  stage_init(sm);
 }
 DR_DEV void shade_count(PushStage& sm, TraceCounters* ctr, uint32_t nIn) {
   if (threadIdx.x == 0) {
@@ -780,7 +779,7 @@ template <bool ENV, bool QUAD, bool LLDS>
 __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_shade_path(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
-  PushCtx pctx = {{0, 0, 0, 0}, 0};
+  PushCtx pctx = {{0, 0, 0, 0}, 0, 0};
   using LV = typename std::conditional<LLDS, LdsLights, GlobalLights>::type;
   LV lv;
   if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD)));
@@ -953,6 +952,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);
     PROF(9);
   }
+  stage_finish(s_push, pctx, q.closestQ, q.anyQ, q.activeOut);
   PROF_FLUSH;
   shade_count(s_push, q.ctr, nIn);
 }
@@ -965,7 +965,7 @@ template <bool QUAD, bool LLDS>
 __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_shade_direct(DScene sc, RenderParams rp, BatchState st, StageQueues q, int stage) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
-  PushCtx pctx = {{0, 0, 0, 0}, 0};
+  PushCtx pctx = {{0, 0, 0, 0}, 0, 0};
   using LV = typename std::conditional<LLDS, LdsLights, GlobalLights>::type;
   LV lv;
   if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD)));
@@ -1063,6 +1063,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
       stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);
   }
+  stage_finish(s_push, pctx, q.closestQ, q.anyQ, q.activeOut);
   shade_count(s_push, q.ctr, nIn);
 }
 
@@ -1080,7 +1081,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
 __global__ void __launch_bounds__(SHADE_BLOCK_OF(true), SHADE_WAVES_OF(true)) k_shade_spec(DScene sc, RenderParams rp, BatchState st, StageQueues q) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
-  PushCtx pctx = {{0, 0, 0, 0}, 0};
+  PushCtx pctx = {{0, 0, 0, 0}, 0, 0};
   const GlobalLights lv{sc.lights, sc.ltris, sc.lcdf, sc.mats};
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -1180,6 +1181,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(true), SHADE_WAVES_OF(true)) k_
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
       stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, nullptr);
   }
+  stage_finish(s_push, pctx, q.closestQ, q.anyQ, q.activeOut);
 }
 
 // ---------------------------------------------------------------------------
@@ -1292,19 +1294,25 @@ __global__ void k_film_resolve(const float* film, int64_t npix, float* rgb) {
   rgb[3 * p + 2] = (float)((double)b + 0.0);
 }
 
-// float4 copy: the measured HBM-bandwidth denominator of the roofline.  Four independent 16-byte loads per lane are
-// in flight before the first store (one load per lane leaves the memory pipeline half empty: 4.8 instead of ~6 TB/s).
+// float4 copy: the measured HBM-bandwidth denominator of the roofline.  The shape that reads fastest on MI355X
+// (tools/copy_bw.hip: 5.5 TB/s against 4.6-4.8 for a grid-stride loop): every workgroup owns one contiguous chunk,
+// four independent 16-byte non-temporal loads per lane are in flight before the first store.
+typedef float dr_v4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_copy(const float4* __restrict__ src, float4* __restrict__ dst, uint64_t n4) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a;
-    dst[i + stride] = b;
-    dst[i + 2 * stride] = c;
-    dst[i + 3 * stride] = d;
+  const dr_v4* s = (const dr_v4*)src;
+  dr_v4* d = (dr_v4*)dst;
+  const uint64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+  const uint64_t b0 = (uint64_t)blockIdx.x * per, b1 = b0 + per < n4 ? b0 + per : n4;
+  uint64_t i = b0 + threadIdx.x;
+  for (; i + 3 * 256 < b1; i += 4 * 256) {
+    const dr_v4 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + 256);
+    const dr_v4 c = __builtin_nontemporal_load(s + i + 512), e = __builtin_nontemporal_load(s + i + 768);
+    __builtin_nontemporal_store(a, d + i);
+    __builtin_nontemporal_store(b, d + i + 256);
+    __builtin_nontemporal_store(c, d + i + 512);
+    __builtin_nontemporal_store(e, d + i + 768);
   }
-  for (; i < n4; i += stride) dst[i] = src[i];
+  for (; i < b1; i += 256) d[i] = s[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -1417,5 +1425,5 @@ void launch_film_resolve(const float* film, int64_t npix, float* rgb, hipStream_
   hipLaunchKernelGGL(k_film_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, film, npix, rgb);
 }
 void launch_copy(const float4* src, float4* dst, uint64_t n4, hipStream_t s) {
-  hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, s, src, dst, n4);
+  hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, s, src, dst, n4);
 }
