@@ -60,11 +60,13 @@ def shade_alg_bytes(st):
     must read and write of the per-sample path state and the scene, from the device's own counts."""
     items, verts = st["shade_items"], st["shade_vertices"]
     later = max(0, items - st["camera_samples"])  # entries of stages > 0: they carry a pending light estimate
-    return (items * 40.0            # active entry, flags, hprim, L in; L, flags out
-            + later * (28.0 + 4.0)  # shOcc, Ld1, betaNee in; the active-list entry that brought it here
-            + st["shade_mis"] * (32.0 + 48.0 + 32.0)   # MIS resolve: misPrim, misLight, Ld2, misD + the hit's record; set-up writes
-            + verts * 129.0         # ht, ro, rd, beta, 48-B primitive record, sample indices in; ro, rtmin, betaNee out
-            + st["shade_cont"] * 28.0 + st["shade_shadow"] * 36.0)  # rd, beta | shD, shTmax, Ld1 + queue entries
+    return (items * 28.0                  # flags, hprim, L in; flags out (+ the entry of the active list, below)
+            + later * 20.0                # active-list entry, shOcc, the finished light term (Ld1)
+            + (st["camera_samples"] + st["shade_shadow"]) * 12.0   # L out: the camera stage initialises it, a light term changes it
+            + st["shade_mis"] * 136.0     # a MIS ray: misD, Ld2, misLight, betaNee out + queue entry; misPrim, misLight, Ld2, misD, betaNee, 48-B record in
+            + verts * 117.0               # ht, ro, rd, beta, 48-B primitive record, 5 sample-index bytes in; ro, rtmin out
+            + st["shade_cont"] * 28.0     # rd, beta + queue entry
+            + st["shade_shadow"] * 36.0)  # shD, shTmax, Ld1 + queue entry
 
 
 def roofline_objects(st, dt_total, copy_gbps):

@@ -1,0 +1,57 @@
+"""profiles/r02_<cfg>_traffic.json from the PMC summaries of tools/profile_r02.sh: HBM-side bytes per launch of the
+dominant traversal kernel and of k_shade_path, exactly as MI355X_MICROARCH.md prescribes (separate --pmc passes;
+reads = TCC_EA0_RDREQ_128B * 128 + _64B * 64 + _32B * 32 -- every wide read of these kernels is a 128-B request, so
+FETCH_SIZE would under-report 2x; writes = WRITE_SIZE KB * 1024)."""
+import csv, json, re, sys
+
+src, cfg, out = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def pmc(path):
+    d, k = {}, None
+    for line in open(path):
+        m = re.match(r"^(\S.*) dispatches=(\d+)", line)
+        if m:
+            k = m.group(1)
+            d[k] = {"dispatches": int(m.group(2))}
+            continue
+        m = re.match(r"^\s+(\S+)\s+(\S+)\s+per-dispatch\s+(\S+)", line)
+        if m and k:
+            d[k][m.group(1)] = float(m.group(3))
+    return d
+
+
+rd, wr, sq = pmc("%s/pmc_%s_rdreq.txt" % (src, cfg)), pmc("%s/pmc_%s_wrreq.txt" % (src, cfg)), pmc("%s/pmc_%s_sq.txt" % (src, cfg))
+stats = {r["Name"]: r for r in csv.DictReader(open("%s/%s_kernel_stats.csv" % (src, cfg)))}
+bench = json.load(open("%s/%s_bench.json" % (src, cfg)))
+res = {"workload": bench["config"]["workload"], "bench_value_under_rocprof": bench["value"], "kernels": {}}
+for name in rd:
+    if not (name.startswith("k_trace") or name.startswith("k_shade_path")):
+        continue
+    r, w, s = rd[name], wr.get(name, {}), sq.get(name, {})
+    reads = r.get("TCC_EA0_RDREQ_128B", 0) * 128 + r.get("TCC_EA0_RDREQ_64B", 0) * 64 + r.get("TCC_EA0_RDREQ_32B", 0) * 32
+    writes = w.get("WRITE_SIZE", 0) * 1024
+    full = [v for k, v in stats.items() if name in k]
+    avg_ms = float(full[0]["AverageNs"]) * 1e-6 if full else None
+    e = {"hbm_bytes_per_launch": reads + writes, "reads_bytes_per_launch": reads, "writes_bytes_per_launch": writes,
+         "avg_launch_ms_kernel_trace": avg_ms,
+         "hbm_side_GBps": (reads + writes) / (avg_ms * 1e-3) / 1e9 if avg_ms else None}
+    if s:
+        cycles = s["SQ_ACTIVE_INST_VALU"] * 4 / 1024.0  # quad-cycles -> cycles per SIMD
+        e["valu_busy"] = cycles / (avg_ms * 1e-3 * 2.4e9) if avg_ms else None
+        e["valu_lane_utilisation"] = s["SQ_THREAD_CYCLES_VALU"] / (s["SQ_INSTS_VALU"] * 64)
+        e["wait_any_share_of_wave_cycles"] = s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"]
+    res["kernels"][name] = e
+dom = "k_trace3<0>" if "k_trace3<0>" in res["kernels"] else "k_trace<0>"
+res["kernel"] = dom
+res["hbm_bytes_per_launch"] = res["kernels"][dom]["hbm_bytes_per_launch"]
+res["alg_bytes_per_launch"] = bench["roofline"]["alg_bytes_per_launch"]
+res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / bench["roofline"]["alg_bytes_per_launch"]
+res["method"] = ("tools/profile_r02.sh: rocprofv3 --pmc passes (counters only) on `DARTRAY_TRACE_IMPL=%s python3 bench.py %s--steps 1 --warmup 0 "
+                 "--no-cpu-baseline --no-extra` (two full renders, every launch full size); launch times from the --kernel-trace --stats "
+                 "run of the same script.  Counters sit on the L2's memory side, so Infinity-Cache hits are included: an upper bound on "
+                 "HBM bytes." % ("3" if dom.startswith("k_trace3") else "2", "" if cfg == "c2" else "--config %s " % cfg.upper()))
+res["sources"] = ["profiles/r02_pmc_%s_rdreq.txt" % cfg, "profiles/r02_pmc_%s_wrreq.txt" % cfg, "profiles/r02_pmc_%s_sq.txt" % cfg,
+                  "profiles/r02_%s_kernel_stats.csv" % cfg]
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1)[:1800])
