@@ -815,11 +815,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       C3 L = cur.L;
       C3 beta = cur.beta;
       const C3 Ld1In = cur.Ld1;
-#ifdef DR_L_ALWAYS
-      bool Lchanged = true;
-#else
       bool Lchanged = bounce == 0;  // L is stored when this stage changed it (the camera stage initialises it)
-#endif
       const F3 o = cur.o, d = cur.d;
       auto su = [&](int k) -> float {
         if (st.svFloat) return __uint_as_float(cur.raw[k]);

@@ -13,7 +13,11 @@
 // pins this file instead: (1) line-by-line fidelity to the cited reference
 // source, including its numerics contract (every arithmetic expression is
 // evaluated in f64; Vector/Point/Normal/Spectrum/Float32List stores round to
-// f32), (2) hand-derivable KATs in tests/, (3) BVH == brute force self checks.
+// f32), (2) hand-derivable KATs in tests/, (3) BVH == brute force self checks,
+// (4) a second restatement written independently from the Dart text in plain
+// Python (tests/golden/dart_restatement.py) that must agree with this file bit
+// for bit on per-sample Li, films and hit records (tests/test_restatement.py):
+// it removes the single-reader risk, it does not pin parity to the Dart VM.
 //
 // Numerics contract: compile with
 //   g++ -O2 -ffp-contract=off  (no fast-math)  -- Dart never fuses mul+add.
