@@ -225,18 +225,11 @@ void host_tri_normals(const float* a, const float* b, const float* c, bool rever
   for (int k = 0; k < 3; ++k) ns[k] = (float)(reverse ? n[k] * -1.0 : n[k]);
 }
 
-int traceGrid() {
-  // DR_LDS_STACK*256*4 bytes of LDS per workgroup (32 KiB at 32 entries => 5 workgroups = 20 waves per CU);
-  // at most 8 workgroups of 4 waves fit the 32-wave CU.
-  int perCU = 6;  // v2: 24 KiB per workgroup -> 6; v3: 32 KiB -> 5 resident, the sixth queues behind them
-  const char* e = getenv("DARTRAY_TRACE_WG_PER_CU");
-  if (e) perCU = atoi(e);
-  return g_numCU * std::max(1, std::min(perCU, 8));
-}
+int traceGrid() { return traceGridFor(DR_V2_WG_PER_CU); }  // the largest grid any variant launches (sizes the spill stacks)
 
 int ensureSpill(DrScene* sc, Workspace& w, int grid) {
   // deepest stack == tree depth; the v3 kernel keeps 16 (reference, E) pairs in LDS, v2 24 references
-  if (sc->bvhDepth != 0 && sc->bvhDepth <= 16) return DR_OK;
+  if (sc->bvhDepth != 0 && sc->bvhDepth <= DR_V2_LDS_STACK && sc->bvhDepth <= 16) return DR_OK;
   size_t need = (size_t)grid * DR_TRACE_BLOCK * (DR_MAX_STACK - 16) * 2;
   HIP_TRY(w.spill.alloc(need));
   w.spillGrid = grid;
@@ -364,6 +357,15 @@ void enumeratePixels(const RenderParams& rp, const DrRenderDesc* rd, std::vector
 
 }  // namespace
 
+int traceGridFor(int wgPerCU) {
+  // workgroups of the persistent traversal kernels: as many as are resident at once.  v2 (k_trace): 16 KiB of stack +
+  // 6 KiB of cold ray state in LDS and 72 VGPRs => 7 workgroups = 28 waves per CU; the other variants (v3: 32 KiB of
+  // LDS, the quadric and v1 kernels: more registers) 6, the sixth queueing behind five where only five fit.
+  const char* e = getenv("DARTRAY_TRACE_WG_PER_CU");
+  if (e) wgPerCU = atoi(e);
+  return g_numCU * std::max(1, std::min(wgPerCU, 8));
+}
+
 extern "C" {
 
 const char* dr_last_error(void) { return g_err.c_str(); }
@@ -410,6 +412,8 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   // the depth-first numbering of bvh_accel.dart:419-437), so every walk terminates, and one forward pass gives each
   // node's level: the height of the tree bounds the traversal stack (desc->bvh_depth == 0, "unknown", is measured here).
   uint32_t measuredDepth = 0;
+  // k_trace addresses node i at byte offset i * 32 from a scalar base, in 32 bits (dr_trace.hip)
+  if (desc->nnodes > (1ull << 27)) return fail(DR_ERR_UNSUPPORTED, "more than 2^27 BVH nodes");
   if (desc->nnodes) {
     const DrBvhNode* N = desc->nodes;
     std::vector<uint8_t> level(desc->nnodes, 0);
@@ -1420,6 +1424,7 @@ int dr_get_stats(DrScene* sc, DrRenderStats* out) {
     sc->foldEvents();
     sc->statsPending = false;
     shade_prof_dump();
+    trace_prof_dump();
   }
   *out = sc->stats;
   return DR_OK;

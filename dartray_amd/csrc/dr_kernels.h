@@ -195,6 +195,11 @@ struct StageQueues {
 #ifndef DR_LDS_STACK
 #define DR_LDS_STACK 24       // stack entries per lane kept in LDS: 24 KiB per workgroup => 6 workgroups (24 waves) per CU
 #endif
+#ifndef DR_V2_LDS_STACK
+#define DR_V2_LDS_STACK 16    // v2 kernels: 16 KiB of stack + 6 KiB of cold ray state per workgroup => 7 workgroups (28 waves) per CU
+#endif
+#define DR_V2_WG_PER_CU 7
+int traceGridFor(int wgPerCU);  // dr_api.hip: workgroups of a persistent traversal launch
 #define DR_MAX_STACK 128      // LDS + spill entries per lane (the reference uses 64, bvh_accel.dart:120)
 #define DR_TRACE_BLOCK 256
 
@@ -217,6 +222,7 @@ void launch_film(const RenderParams& rp, const BatchState& st, const float* filt
                  hipStream_t s);
 void launch_film_resolve(const float* film, int64_t npix, float* rgb, hipStream_t s);
 void launch_copy(const float4* src, float4* dst, uint64_t n4, hipStream_t s);
+void trace_prof_dump();  // -DDR_TRACE_PROF builds only: per-phase cycle sums of the v2 traversal loop
 void shade_prof_dump();  // -DDR_SHADE_PROF builds only: prints and clears the per-phase cycle sums of k_shade_path
 
 #endif

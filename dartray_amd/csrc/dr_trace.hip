@@ -31,8 +31,32 @@
 #ifndef DR_LEAF_TH
 #define DR_LEAF_TH 12
 #endif
+#ifndef DR_OPT_ABSMOD
+#define DR_OPT_ABSMOD 1
+#endif
+#ifndef DR_OPT_SCALAR_NODES
+#define DR_OPT_SCALAR_NODES 1
+#endif
+#ifndef DR_OPT_ADDR32
+#define DR_OPT_ADDR32 1
+#endif
+#ifndef DR_EXP_XLOAD
+#define DR_EXP_XLOAD 0
+#endif
+#ifndef DR_EXP_XVALU
+#define DR_EXP_XVALU 0
+#endif
+#ifndef DR_OPT_COLD
+#define DR_OPT_COLD 1
+#endif
+#ifndef DR_OPT_BOOLSLAB
+#define DR_OPT_BOOLSLAB 1
+#endif
+#ifndef DR_OPT_NEGBITS
+#define DR_OPT_NEGBITS 1
+#endif
 #ifndef DR_TRACE_WAVES
-#define DR_TRACE_WAVES 6  // __launch_bounds__ minimum waves per SIMD for k_trace: 80 VGPRs, measured best (7 and 8 spill)
+#define DR_TRACE_WAVES 7  // __launch_bounds__ minimum waves per SIMD for k_trace: 72 VGPRs (the loop is latency bound: DESIGN.md section 5, round 2)
 #endif
 #ifndef DR_NSHARD
 #define DR_NSHARD 1  // work-queue shards: 1 = one shared counter; 8 = one per XCD.  Measured on C2: 8 shards are 12 % SLOWER (each XCD walks its own eighth of the queue, so the chip-wide working set in the shared Infinity Cache is 8 regions instead of 1)
@@ -240,6 +264,7 @@ struct TraceRay {
   float tminLo, tminHi;        // f32 brackets: tminLo <= tmin <= tminHi
   float tmaxLo, tmaxHi;
   bool needF64;                // a zero direction component: 0*inf = NaN can occur, always take the literal test
+  uint32_t negBits;            // bit a: invDir[a] < 0 (the dirIsNeg table of bvh_accel.dart:112-116)
 };
 DR_DEV float f32_below(double v) {  // largest float <= v
   float f = (float)v;
@@ -267,6 +292,7 @@ DR_DEV void ray_init(TraceRay& r, F3 o, F3 d, double tmin, double tmax) {
   r.tminHi = f32_above(tmin);
   ray_set_tmax(r, tmax);
   r.needF64 = (d.x == 0.f) || (d.y == 0.f) || (d.z == 0.f);
+  r.negBits = (r.ivx < 0.f ? 1u : 0u) | (r.ivy < 0.f ? 2u : 0u) | (r.ivz < 0.f ? 4u : 0u);
 }
 
 // The literal slab test (bvh_accel.dart:439-472).
@@ -295,7 +321,7 @@ DR_DEV bool slab_f64(const TraceRay& r, float bminx, float bminy, float bminz, f
 // room for the rounding of the enclosure arithmetic itself and for f32 denormals.  Overflow to
 // +-inf makes an enclosure bound NaN or +-inf, every comparison below is then false and the box
 // is reported ambiguous.  Returns 1 = certain hit, 0 = certain miss, -1 = evaluate the f64 test.
-DR_DEV int slab_f32(const TraceRay& r, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz) {
+DR_DEV void slab_f32_sure(const TraceRay& r, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, bool* sureHit, bool* sureMiss) {
   const float ax = (bminx - r.o.x) * r.ivx, bx = (bmaxx - r.o.x) * r.ivx;
   const float ay = (bminy - r.o.y) * r.ivy, by = (bmaxy - r.o.y) * r.ivy;
   const float az = (bminz - r.o.z) * r.ivz, bz = (bmaxz - r.o.z) * r.ivz;
@@ -303,21 +329,33 @@ DR_DEV int slab_f32(const TraceRay& r, float bminx, float bminy, float bminz, fl
   const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
   const float R = 4.76837158203125e-07f;  // 2^-21
   const float A = 1.0e-37f;
+#if DR_OPT_ABSMOD
+  // |x| as a source modifier of the fma (left to itself the compiler packs the two fmas into one v_pk_fma_f32, which
+  // takes no modifiers, and pays two v_and and a v_mov for it)
+  float eLo, eHi;
+  asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(eLo) : "v"(lo), "v"(R), "v"(A));
+  asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(eHi) : "v"(hi), "v"(R), "v"(A));
+#else
   const float eLo = __fmaf_rn(fabsf(lo), R, A), eHi = __fmaf_rn(fabsf(hi), R, A);
+#endif
   const float loU = lo + eLo, loL = lo - eLo, hiU = hi + eHi, hiL = hi - eHi;
-  const bool sureHit = (loU <= hiL) && (loU < r.tmaxLo) && (hiL > r.tminHi);
-  const bool sureMiss = (loL > hiU) || (loL >= r.tmaxHi) || (hiU <= r.tminLo);
+  *sureHit = (loU <= hiL) && (loU < r.tmaxLo) && (hiL > r.tminHi);
+  *sureMiss = (loL > hiU) || (loL >= r.tmaxHi) || (hiU <= r.tminLo);
+}
+DR_DEV int slab_f32(const TraceRay& r, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz) {
+  bool sureHit, sureMiss;
+  slab_f32_sure(r, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, &sureHit, &sureMiss);
   return sureHit ? 1 : (sureMiss ? 0 : -1);
 }
 
 // Pop: the LDS read is issued unconditionally (ds_read, not a flat load through a selected pointer);
-// the global spill is only touched by lanes deeper than DR_LDS_STACK.
+// the global spill is only touched by lanes deeper than DR_V2_LDS_STACK.
 DR_DEV uint32_t stack_pop(const uint32_t* lds, const uint32_t* spill, uint32_t spillStride, int sp) {
   // (an explicit LDS-address-space load: left generic, the compiler merges the two loads into ONE flat load
   // through a selected pointer)
   typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-  uint32_t v = ((lds_u32*)lds)[(sp < DR_LDS_STACK ? sp : DR_LDS_STACK - 1) * DR_TRACE_BLOCK];
-  if (sp >= DR_LDS_STACK) v = spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
+  uint32_t v = ((lds_u32*)lds)[(sp < DR_V2_LDS_STACK ? sp : DR_V2_LDS_STACK - 1) * DR_TRACE_BLOCK];
+  if (sp >= DR_V2_LDS_STACK) v = spill[(size_t)(sp - DR_V2_LDS_STACK) * spillStride];
   return v;
 }
 
@@ -381,9 +419,63 @@ struct RayIO {
   }
 };
 
+// -DDR_TRACE_PROF: a diagnostic build that stamps s_memtime between the phases of the v2 loop and sums the cycles the
+// waves spent in each (printed and cleared by dr_get_stats through trace_prof_dump).  No stamp executes in the product build.
+#ifdef DR_TRACE_PROF
+__device__ unsigned long long g_traceProf[2][8];
+DR_DEV unsigned long long tprof_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define TPROF_DECL unsigned long long tpT = tprof_now(), tpAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TPROF(i)                              \
+  do {                                        \
+    const unsigned long long n_ = tprof_now(); \
+    tpAcc[i] += n_ - tpT;                     \
+    tpT = n_;                                 \
+  } while (0)
+#define TPROF_COUNT(i, v) tpAcc[i] += (v)
+#define TPROF_FLUSH                                                                  \
+  do {                                                                               \
+    if (lane_id() == 0)                                                              \
+      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_traceProf[ANY][i_], tpAcc[i_]);    \
+  } while (0)
+void trace_prof_dump() {
+  unsigned long long h[2][8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_traceProf), sizeof(h)) != hipSuccess) return;
+  static const char* names[8] = {"refill: queue entry + ray state + ray_init", "node visits", "leaf tests", "result stores + bookkeeping",
+                                 "(wave iterations)", "(refill events)", "(leaf phases)", "(leaf triangle rounds)"};
+  for (int a = 0; a < 2; ++a) {
+    double tot = 0;
+    for (int i = 0; i < 4; ++i) tot += (double)h[a][i];
+    if (tot == 0) continue;
+    for (int i = 0; i < 4; ++i) fprintf(stderr, "trace_prof %s %-44s %6.2f %%  (%.3g wave-cycles)\n", a ? "any    " : "closest", names[i], 100.0 * h[a][i] / tot, (double)h[a][i]);
+    for (int i = 4; i < 8; ++i) fprintf(stderr, "trace_prof %s %-44s %.4g\n", a ? "any    " : "closest", names[i], (double)h[a][i]);
+  }
+  for (int a = 0; a < 2; ++a) for (int i = 0; i < 8; ++i) h[a][i] = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_traceProf), h, sizeof(h));
+}
+#else
+#define TPROF_DECL
+#define TPROF(i)
+#define TPROF_COUNT(i, v)
+#define TPROF_FLUSH
+void trace_prof_dump() {}
+#endif
+
 template <int ANY, bool QUAD, class IO>
 DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_t* lds, uint32_t* spill,
-                             uint32_t spillStride, uint32_t* work, TraceCounters* ctr) {
+                             uint32_t spillStride, uint32_t* work, TraceCounters* ctr, uint32_t* cold) {
+#if DR_OPT_COLD
+  // Ray state the node loop never reads -- direction, minDistance, the queue handle -- lives in LDS (6 dwords per
+  // lane) between the refill and the leaf tests / the result store: 6 VGPRs fewer in the loop that sets the occupancy.
+  typedef __attribute__((address_space(3))) uint32_t cold_u32;
+#define COLD_ST(i, v) (((cold_u32*)cold)[(i) * DR_TRACE_BLOCK] = (v))
+#define COLD_LD(i) (((const cold_u32*)cold)[(i) * DR_TRACE_BLOCK])
+#define COLD_D() F3{__uint_as_float(COLD_LD(0)), __uint_as_float(COLD_LD(1)), __uint_as_float(COLD_LD(2))}
+#define COLD_TMIN() __hiloint2double((int)COLD_LD(4), (int)COLD_LD(3))
+#endif
   const int lane = lane_id();
   const unsigned long long ltMask = (1ull << lane) - 1ull;
   uint32_t nRays = 0, nNodes = 0, nTris = 0;
@@ -398,7 +490,10 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
   // read from HW_REG_XCC_ID and only affects speed, never results.
   uint32_t shard = ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (uint32_t)DR_NSHARD;  // XCC_ID[3:0]
   uint32_t tried = 0;
+  TPROF_DECL;
   for (;;) {
+    TPROF(3);
+    TPROF_COUNT(4, 1);
     // ---- refill idle lanes ----
     const unsigned long long idleMask = __ballot(mode == M_IDLE);
     const int nIdle = __popcll(idleMask);
@@ -425,12 +520,23 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
         }
       }
       const uint32_t take = min(resEnd - resNext, (uint32_t)nIdle);
+      TPROF_COUNT(5, 1);
       if (mode == M_IDLE) {
         const uint32_t j = (uint32_t)__popcll(idleMask & ltMask);
         if (j < take) {
           const uint32_t idx = resNext + j;
           io.load(idx, ray, handle);
+#if DR_OPT_COLD
+          COLD_ST(0, __float_as_uint(ray.d.x));
+          COLD_ST(1, __float_as_uint(ray.d.y));
+          COLD_ST(2, __float_as_uint(ray.d.z));
+          COLD_ST(3, (uint32_t)__double2loint(ray.tmin));
+          COLD_ST(4, (uint32_t)__double2hiint(ray.tmin));
+          COLD_ST(5, handle);
+#endif
+#if !DR_OPT_SCALAR_NODES
           ++nRays;
+#endif
           if (sc.nnodes == 0) {
             io.store(handle, ray, -1, sc);
           } else {
@@ -441,7 +547,14 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           }
         }
       }
+#if DR_OPT_SCALAR_NODES
+      nRays += take;
+#endif
       resNext += take;
+#ifdef DR_TRACE_PROF
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TPROF(0);
+#endif
     }
     const unsigned long long travMask = __ballot(mode == M_TRAV);
     unsigned long long leafMask = __ballot(mode == M_LEAF);
@@ -451,14 +564,62 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
     }
     bool finished = false;
     // ---- one node visit (bvh_accel.dart:122-160) ----
+#if DR_OPT_SCALAR_NODES
+    nNodes += (uint32_t)__popcll(travMask);  // wave-uniform: lane 0 carries the wave's count (flush_counters sums lanes)
+#endif
     if (mode == M_TRAV) {
+#if DR_OPT_ADDR32
+      // 32-bit byte offset from a scalar base (dr_scene_create refuses trees beyond 2^27 nodes): one shift instead of
+      // a 64-bit shift + add per visit
+      const uint4* np = (const uint4*)((const char*)sc.nodes + (size_t)(uint32_t)(node << 5));
+      const uint4 a = np[0];
+      const uint4 b = np[1];
+#else
       const uint4 a = sc.nodes[2 * (size_t)node];
       const uint4 b = sc.nodes[2 * (size_t)node + 1];
+#endif
+#if !DR_OPT_SCALAR_NODES
       ++nNodes;
+#endif
+#if DR_EXP_XLOAD
+      // experiment: one more 16-byte load per visit (1: same line, 2: another line), consumed after the box test
+      typedef uint32_t xu4 __attribute__((ext_vector_type(4)));
+      xu4 xl;
+      {
+        const uint4* xp = &sc.nodes[2 * (size_t)node + (DR_EXP_XLOAD == 2 ? 64 : 0)];
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xl) : "v"(xp) : "memory");
+      }
+#endif
+#if DR_EXP_XVALU
+      {
+        uint32_t x = node;
+#pragma unroll
+        for (int q = 0; q < DR_EXP_XVALU; ++q) asm volatile("v_add_u32 %0, %0, 1" : "+v"(x));
+        asm volatile("" :: "v"(x));
+      }
+#endif
       const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
       const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
+#if DR_OPT_BOOLSLAB
+      bool ok = false, amb = true;
+      if (!ray.needF64) {  // (two predicates instead of a three-valued int: they stay lane masks in SGPRs)
+        bool sureMiss;
+        slab_f32_sure(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, &ok, &sureMiss);
+        amb = !ok && !sureMiss;
+      }
+#if DR_OPT_COLD
+      if (amb) {
+        TraceRay rr = ray;
+        rr.tmin = COLD_TMIN();
+        ok = slab_f64(rr, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz);
+      }
+#else
+      if (amb) ok = slab_f64(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz);
+#endif
+#else
       int ok = ray.needF64 ? -1 : slab_f32(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz);
       if (ok < 0) ok = slab_f64(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz) ? 1 : 0;
+#endif
       bool pop = true;
       if (ok) {
         const uint32_t nprims = b.w & 0xffffu;
@@ -468,13 +629,17 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           leafN = nprims;
           pop = false;
         } else {
+#if DR_OPT_NEGBITS
+          const bool neg = ((ray.negBits >> ((b.w >> 16) & 0xffu)) & 1u) != 0u;
+#else
           const uint32_t axis = (b.w >> 16) & 0xffu;
           const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
           const bool neg = iv < 0.f;
+#endif
           const uint32_t far = neg ? node + 1 : b.z;  // bvh_accel.dart:147-153
           node = neg ? b.z : node + 1;
-          if (sp < DR_LDS_STACK) lds[sp * DR_TRACE_BLOCK] = far;
-          else if (sp < DR_MAX_STACK) spill[(size_t)(sp - DR_LDS_STACK) * spillStride] = far;
+          if (sp < DR_V2_LDS_STACK) lds[sp * DR_TRACE_BLOCK] = far;
+          else if (sp < DR_MAX_STACK) spill[(size_t)(sp - DR_V2_LDS_STACK) * spillStride] = far;
           ++sp;
           pop = false;
         }
@@ -487,13 +652,25 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           node = stack_pop(lds, spill, spillStride, sp);
         }
       }
+#if DR_EXP_XLOAD
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xl) :: "memory");
+#endif
     }
+    TPROF(1);
     // ---- batched leaf tests (bvh_accel.dart:126-143 / :189-204) ----
     leafMask = __ballot(mode == M_LEAF);
     const unsigned long long stillTrav = __ballot(mode == M_TRAV && !finished);
     if (leafMask != 0ull && (__popcll(leafMask) >= DR_LEAF_TH || stillTrav == 0ull)) {
+      TPROF_COUNT(6, 1);
       if (mode == M_LEAF) {
         bool occluded = false;
+#if DR_OPT_COLD
+        const F3 rayD = COLD_D();
+        const double rayTmin = COLD_TMIN();
+#else
+        const F3 rayD = ray.d;
+        const double rayTmin = ray.tmin;
+#endif
         for (uint32_t i = 0; i < leafN; ++i) {
           ++nTris;
           const float4* tp = sc.tris + 3 * (size_t)(leafOff + i);
@@ -501,7 +678,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           if (QUAD && PRIM_KIND(__float_as_uint(q2.w))) {  // GeometricPrimitive over a Sphere / Disk
             double t;
             F3 phit;
-            if (quadric_hit(sc.quads[__float_as_uint(q0.x)], ray.o, ray.d, ray.tmin, ray.tmax, &t, &phit)) {
+            if (quadric_hit(sc.quads[__float_as_uint(q0.x)], ray.o, rayD, rayTmin, ray.tmax, &t, &phit)) {
               if (ANY) {
                 occluded = true;
                 break;
@@ -513,13 +690,13 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           }
           const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
           if (ANY) {
-            if (tri_hitP(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax)) {  // return true (bvh_accel.dart:193-195)
+            if (tri_hitP(p1, p2, p3, ray.o, rayD, rayTmin, ray.tmax)) {  // return true (bvh_accel.dart:193-195)
               occluded = true;
               break;
             }
           } else {
             double t, b1, b2;
-            if (tri_hit(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax, &t, &b1, &b2)) {
+            if (tri_hit(p1, p2, p3, ray.o, rayD, rayTmin, ray.tmax, &t, &b1, &b2)) {
               ray_set_tmax(ray, t);  // r.maxDistance = thit (geometric_primitive.dart:59)
               hit = (int)(leafOff + i);
             }
@@ -536,46 +713,62 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           mode = M_TRAV;
         }
       }
+      TPROF(2);
     }
     if (finished) {
+#if DR_OPT_COLD
+      TraceRay rr = ray;
+      rr.d = COLD_D();
+      rr.tmin = COLD_TMIN();
+      io.store(COLD_LD(5), rr, hit, sc);
+#else
       io.store(handle, ray, hit, sc);
+#endif
       mode = M_IDLE;
     }
   }
+  TPROF_FLUSH;
+#if DR_OPT_SCALAR_NODES
+  flush_counters(ctr, ANY, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
+#else
   flush_counters(ctr, ANY, nRays, nNodes, nTris);
+#endif
 }
 
 template <int ANY>
 __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE_WAVES) k_trace(DScene sc, BatchState st, const uint32_t* queue,
                                                           const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
                                                           TraceCounters* ctr) {
-  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
+  __shared__ uint32_t s_stack[DR_V2_LDS_STACK * DR_TRACE_BLOCK];
+  __shared__ uint32_t s_cold[(DR_OPT_COLD ? 6 : 1) * DR_TRACE_BLOCK];  // DR_OPT_COLD: direction, minDistance, handle per lane
   StateIO<ANY> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
   trace_persistent<ANY, false>(sc, io, n, s_stack + threadIdx.x,
                         spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
-                        gridDim.x * DR_TRACE_BLOCK, work, ctr);
+                        gridDim.x * DR_TRACE_BLOCK, work, ctr, s_cold + threadIdx.x);
 }
 // scenes with sphere / disk primitives: the quadric tests cost registers, so they get their own instantiation
 template <int ANY>
 __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace_quad(DScene sc, BatchState st, const uint32_t* queue,
                                                                const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
                                                                TraceCounters* ctr) {
-  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
+  __shared__ uint32_t s_stack[DR_V2_LDS_STACK * DR_TRACE_BLOCK];
   StateIO<ANY> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
+  __shared__ uint32_t s_cold[(DR_OPT_COLD ? 6 : 1) * DR_TRACE_BLOCK];
   trace_persistent<ANY, true>(sc, io, n, s_stack + threadIdx.x,
                         spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
-                        gridDim.x * DR_TRACE_BLOCK, work, ctr);
+                        gridDim.x * DR_TRACE_BLOCK, work, ctr, s_cold + threadIdx.x);
 }
 template <int ANY>
 __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect(DScene sc, const DrRay* rays, uint32_t n, DrHit* out,
                                                               uint32_t* spill, uint32_t* work, TraceCounters* ctr) {
-  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
+  __shared__ uint32_t s_stack[DR_V2_LDS_STACK * DR_TRACE_BLOCK];
   RayIO<ANY> io{rays, out};
+  __shared__ uint32_t s_cold[(DR_OPT_COLD ? 6 : 1) * DR_TRACE_BLOCK];
   trace_persistent<ANY, true>(sc, io, n, s_stack + threadIdx.x,
                         spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
-                        gridDim.x * DR_TRACE_BLOCK, work, ctr);
+                        gridDim.x * DR_TRACE_BLOCK, work, ctr, s_cold + threadIdx.x);
 }
 
 // ===========================================================================
@@ -977,8 +1170,9 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
 }
 void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
-  const dim3 g(grid), b(DR_TRACE_BLOCK);
   const int impl = traceImpl(sc, anyHit);
+  if (!(impl == 2 && !sc.nquads)) grid = std::min(grid, traceGridFor(6));  // only k_trace fits 7 workgroups per CU
+  const dim3 g(grid), b(DR_TRACE_BLOCK);
   if (impl == 3) {
     if (anyHit) hipLaunchKernelGGL(k_trace3<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace3<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);

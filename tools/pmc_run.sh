@@ -12,7 +12,7 @@ while [ $# -ge 2 ]; do
   name="$1"; ctrs="$2"; shift 2
   d="$root/$out/$name"
   rm -rf "$d"; mkdir -p "$d"
-  (cd /tmp && rocprofv3 --pmc $ctrs --output-format csv -d "$d" -o run -- python3 "$root/bench.py" $bargs > "$d.log" 2>&1)
+  (cd /tmp && timeout -s KILL ${PMC_TIMEOUT:-240} rocprofv3 --pmc $ctrs --output-format csv -d "$d" -o run -- python3 "$root/bench.py" $bargs > "$d.log" 2>&1)
   python3 "$root/tools/pmc_summary.py" "$d" > "$root/$out/pmc_$name.txt" 2>&1
   rm -rf "$d"
   head -c 2500 "$root/$out/pmc_$name.txt"
