@@ -229,8 +229,8 @@ int traceGrid() { return traceGridFor(DR_V2_WG_PER_CU); }  // the largest grid a
 
 int ensureSpill(DrScene* sc, Workspace& w, int grid) {
   // deepest stack == tree depth; the v3 kernel keeps 16 (reference, E) pairs in LDS, v2 24 references
-  if (sc->bvhDepth != 0 && sc->bvhDepth <= DR_V2_LDS_STACK && sc->bvhDepth <= 16) return DR_OK;
-  size_t need = (size_t)grid * DR_TRACE_BLOCK * (DR_MAX_STACK - 16) * 2;
+  if (sc->bvhDepth != 0 && sc->bvhDepth <= 8) return DR_OK;
+  size_t need = (size_t)grid * DR_TRACE_BLOCK * (DR_MAX_STACK - 8) * 2;  // (room for any LDS stack depth >= 8 of either variant)
   HIP_TRY(w.spill.alloc(need));
   w.spillGrid = grid;
   return DR_OK;

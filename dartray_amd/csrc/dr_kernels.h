@@ -52,6 +52,7 @@ struct RenderParams {
                         // light, or a non-finite throughput); clear: Ld1 already is pathThroughput * (Ld1 * nLights)
 
 #define Q_MIS_BIT 0x80000000u
+#define Q_RESOLVE_BIT 0x40000000u  // active-list entry of k_shade_path: the slot has no vertex to shade, only a light estimate to fold in
 
 // State of one batch of camera samples.  Slot s belongs to batch pixel s >> sppShift, sample s & (spp-1).
 // Layout: array-of-structures-of-arrays in tiles of 64 slots (one wave).  A tile holds, for its 64 slots, every

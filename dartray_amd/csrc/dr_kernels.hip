@@ -627,13 +627,27 @@ struct ShadeIn {
   SlotRef sr;
 };
 template <bool QUAD>
-DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int bounce, uint32_t slot, bool valid, ShadeIn* in) {
+DR_DEV void load_shade_in(const BatchState& st, const RenderParams& rp, int bounce, uint32_t entry, bool valid, ShadeIn* in) {
+  const uint32_t slot = entry & ~Q_RESOLVE_BIT;
   in->valid = valid;
   in->slot = slot;
   if (!valid) return;
   const SlotRef sr = SlotRef::of(st, slot);
   in->sr = sr;
   in->flags = bounce == 0 ? PF_HAS_CONT : sr.u32<F_FLAGS>();
+  if (entry & Q_RESOLVE_BIT) {
+    // the path ended at the previous vertex (the entry says so, one iteration ahead of the state): only its light
+    // estimate is pending -- flags, the occlusion result, L and the estimate are all this item reads
+    in->hprim = -1;
+    in->t = 0.0;
+    in->shOcc = sr.i32<F_SHOCC>();
+    in->L = ldcf<F_L>(sr);
+    in->Ld1 = ldcf<F_LD1>(sr);
+    in->beta = C3{0.f, 0.f, 0.f};
+    in->o = in->d = F3{0.f, 0.f, 0.f};
+    for (int k = 0; k < 10; ++k) in->raw[k] = in->scr[k] = 0u;
+    return;
+  }
   in->hprim = sr.i32<F_HPRIM>();
   in->t = sr.f64<F_HT>();
   if (bounce == 0) {  // the camera vertex: nothing pending, pathThroughput = 1, L = 0 (k_raygen does not store them)
@@ -943,10 +957,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         vert = true;
       }
       if (Lchanged) stcf<F_L>(sr, L);
-      sr.u32<F_FLAGS>() = pf;
+      // (pf == 0: the slot is in no queue and no later stage visits it -- its flags are never read again)
+      if (pf) sr.u32<F_FLAGS>() = pf;
       PROF(7);
     }
-    stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT, vert);
+    stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT, vert,
+               pushCont ? 0u : Q_RESOLVE_BIT);
     PROF(8);
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
       stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);

@@ -18,9 +18,12 @@
 //    0*inf = NaN matters) is the literal f64 test of bvh_accel.dart:439-472 evaluated.  The
 //    decision is therefore always the f64 one;
 //  * todo stack: [depth][lane] u32 in LDS (bank == lane => conflict free) + global spill.
-// Measured: v2 is VALU-issue bound (93 % busy, 45 % of the lanes of an instruction active) on
-// cache-resident trees; k_trace3 (sibling pairs, further down) wins on big incoherent ones and is chosen per scene
-// and ray kind by the pilot in dr_render_device.  About 1 flop per byte: no MFMA.
+//  * what the node loop never reads -- direction, minDistance, the queue handle -- waits in LDS between the refill and
+//    the leaf tests / the result store => 72 VGPRs, 7 waves per SIMD.
+// Measured: the loop is bound by the latency of its dependent node fetches, not by VALU
+// issue (9 % fewer VALU instructions: no change; 3..6 workgroups per CU: t = 96 + 839 / w ms), so occupancy is what
+// pays; k_trace3 (sibling pairs, further down) wins on big incoherent trees and is chosen per scene and ray kind by
+// the pilot in dr_render_device.  About 1 flop per byte: no MFMA.
 #include "dr_kernels.h"
 #include "dr_wave.h"
 #include "dr_rng.h"
@@ -31,30 +34,6 @@
 #ifndef DR_LEAF_TH
 #define DR_LEAF_TH 12
 #endif
-#ifndef DR_OPT_ABSMOD
-#define DR_OPT_ABSMOD 1
-#endif
-#ifndef DR_OPT_SCALAR_NODES
-#define DR_OPT_SCALAR_NODES 1
-#endif
-#ifndef DR_OPT_ADDR32
-#define DR_OPT_ADDR32 1
-#endif
-#ifndef DR_EXP_XLOAD
-#define DR_EXP_XLOAD 0
-#endif
-#ifndef DR_EXP_XVALU
-#define DR_EXP_XVALU 0
-#endif
-#ifndef DR_OPT_COLD
-#define DR_OPT_COLD 1
-#endif
-#ifndef DR_OPT_BOOLSLAB
-#define DR_OPT_BOOLSLAB 1
-#endif
-#ifndef DR_OPT_NEGBITS
-#define DR_OPT_NEGBITS 1
-#endif
 #ifndef DR_TRACE_WAVES
 #define DR_TRACE_WAVES 7  // __launch_bounds__ minimum waves per SIMD for k_trace: 72 VGPRs (the loop is latency bound: DESIGN.md section 5, round 2)
 #endif
@@ -62,7 +41,7 @@
 #define DR_NSHARD 1  // work-queue shards: 1 = one shared counter; 8 = one per XCD.  Measured on C2: 8 shards are 12 % SLOWER (each XCD walks its own eighth of the queue, so the chip-wide working set in the shared Infinity Cache is 8 regions instead of 1)
 #endif
 #ifndef DR_TRACE3_WAVES
-#define DR_TRACE3_WAVES 5  // k_trace3: 32 KiB of LDS per workgroup => 5 workgroups per CU anyway
+#define DR_TRACE3_WAVES 5  // k_trace3: 30 KiB of LDS per workgroup => 5 workgroups per CU anyway
 #endif
 #ifndef DR_WORK_CHUNK
 #define DR_WORK_CHUNK 256  // queue entries a wave reserves per atomic on the work counter (256+ loses cache locality, 64 is atomic bound)
@@ -329,15 +308,11 @@ DR_DEV void slab_f32_sure(const TraceRay& r, float bminx, float bminy, float bmi
   const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
   const float R = 4.76837158203125e-07f;  // 2^-21
   const float A = 1.0e-37f;
-#if DR_OPT_ABSMOD
   // |x| as a source modifier of the fma (left to itself the compiler packs the two fmas into one v_pk_fma_f32, which
   // takes no modifiers, and pays two v_and and a v_mov for it)
   float eLo, eHi;
   asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(eLo) : "v"(lo), "v"(R), "v"(A));
   asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(eHi) : "v"(hi), "v"(R), "v"(A));
-#else
-  const float eLo = __fmaf_rn(fabsf(lo), R, A), eHi = __fmaf_rn(fabsf(hi), R, A);
-#endif
   const float loU = lo + eLo, loL = lo - eLo, hiU = hi + eHi, hiL = hi - eHi;
   *sureHit = (loU <= hiL) && (loU < r.tmaxLo) && (hiL > r.tminHi);
   *sureMiss = (loL > hiU) || (loL >= r.tmaxHi) || (hiU <= r.tminLo);
@@ -467,15 +442,15 @@ void trace_prof_dump() {}
 template <int ANY, bool QUAD, class IO>
 DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_t* lds, uint32_t* spill,
                              uint32_t spillStride, uint32_t* work, TraceCounters* ctr, uint32_t* cold) {
-#if DR_OPT_COLD
   // Ray state the node loop never reads -- direction, minDistance, the queue handle -- lives in LDS (6 dwords per
   // lane) between the refill and the leaf tests / the result store: 6 VGPRs fewer in the loop that sets the occupancy.
+  // (Keeping it in a global scratch row instead -- to make room for an eighth workgroup -- costs more than the extra
+  // waves return: every phase slows by 6..8 %)
   typedef __attribute__((address_space(3))) uint32_t cold_u32;
 #define COLD_ST(i, v) (((cold_u32*)cold)[(i) * DR_TRACE_BLOCK] = (v))
 #define COLD_LD(i) (((const cold_u32*)cold)[(i) * DR_TRACE_BLOCK])
 #define COLD_D() F3{__uint_as_float(COLD_LD(0)), __uint_as_float(COLD_LD(1)), __uint_as_float(COLD_LD(2))}
 #define COLD_TMIN() __hiloint2double((int)COLD_LD(4), (int)COLD_LD(3))
-#endif
   const int lane = lane_id();
   const unsigned long long ltMask = (1ull << lane) - 1ull;
   uint32_t nRays = 0, nNodes = 0, nTris = 0;
@@ -526,17 +501,12 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
         if (j < take) {
           const uint32_t idx = resNext + j;
           io.load(idx, ray, handle);
-#if DR_OPT_COLD
           COLD_ST(0, __float_as_uint(ray.d.x));
           COLD_ST(1, __float_as_uint(ray.d.y));
           COLD_ST(2, __float_as_uint(ray.d.z));
           COLD_ST(3, (uint32_t)__double2loint(ray.tmin));
           COLD_ST(4, (uint32_t)__double2hiint(ray.tmin));
           COLD_ST(5, handle);
-#endif
-#if !DR_OPT_SCALAR_NODES
-          ++nRays;
-#endif
           if (sc.nnodes == 0) {
             io.store(handle, ray, -1, sc);
           } else {
@@ -547,9 +517,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           }
         }
       }
-#if DR_OPT_SCALAR_NODES
       nRays += take;
-#endif
       resNext += take;
 #ifdef DR_TRACE_PROF
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -564,62 +532,26 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
     }
     bool finished = false;
     // ---- one node visit (bvh_accel.dart:122-160) ----
-#if DR_OPT_SCALAR_NODES
     nNodes += (uint32_t)__popcll(travMask);  // wave-uniform: lane 0 carries the wave's count (flush_counters sums lanes)
-#endif
     if (mode == M_TRAV) {
-#if DR_OPT_ADDR32
       // 32-bit byte offset from a scalar base (dr_scene_create refuses trees beyond 2^27 nodes): one shift instead of
       // a 64-bit shift + add per visit
       const uint4* np = (const uint4*)((const char*)sc.nodes + (size_t)(uint32_t)(node << 5));
       const uint4 a = np[0];
       const uint4 b = np[1];
-#else
-      const uint4 a = sc.nodes[2 * (size_t)node];
-      const uint4 b = sc.nodes[2 * (size_t)node + 1];
-#endif
-#if !DR_OPT_SCALAR_NODES
-      ++nNodes;
-#endif
-#if DR_EXP_XLOAD
-      // experiment: one more 16-byte load per visit (1: same line, 2: another line), consumed after the box test
-      typedef uint32_t xu4 __attribute__((ext_vector_type(4)));
-      xu4 xl;
-      {
-        const uint4* xp = &sc.nodes[2 * (size_t)node + (DR_EXP_XLOAD == 2 ? 64 : 0)];
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xl) : "v"(xp) : "memory");
-      }
-#endif
-#if DR_EXP_XVALU
-      {
-        uint32_t x = node;
-#pragma unroll
-        for (int q = 0; q < DR_EXP_XVALU; ++q) asm volatile("v_add_u32 %0, %0, 1" : "+v"(x));
-        asm volatile("" :: "v"(x));
-      }
-#endif
       const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
       const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
-#if DR_OPT_BOOLSLAB
       bool ok = false, amb = true;
       if (!ray.needF64) {  // (two predicates instead of a three-valued int: they stay lane masks in SGPRs)
         bool sureMiss;
         slab_f32_sure(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, &ok, &sureMiss);
         amb = !ok && !sureMiss;
       }
-#if DR_OPT_COLD
       if (amb) {
         TraceRay rr = ray;
         rr.tmin = COLD_TMIN();
         ok = slab_f64(rr, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz);
       }
-#else
-      if (amb) ok = slab_f64(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz);
-#endif
-#else
-      int ok = ray.needF64 ? -1 : slab_f32(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz);
-      if (ok < 0) ok = slab_f64(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz) ? 1 : 0;
-#endif
       bool pop = true;
       if (ok) {
         const uint32_t nprims = b.w & 0xffffu;
@@ -629,13 +561,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           leafN = nprims;
           pop = false;
         } else {
-#if DR_OPT_NEGBITS
           const bool neg = ((ray.negBits >> ((b.w >> 16) & 0xffu)) & 1u) != 0u;
-#else
-          const uint32_t axis = (b.w >> 16) & 0xffu;
-          const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
-          const bool neg = iv < 0.f;
-#endif
           const uint32_t far = neg ? node + 1 : b.z;  // bvh_accel.dart:147-153
           node = neg ? b.z : node + 1;
           if (sp < DR_V2_LDS_STACK) lds[sp * DR_TRACE_BLOCK] = far;
@@ -652,9 +578,6 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           node = stack_pop(lds, spill, spillStride, sp);
         }
       }
-#if DR_EXP_XLOAD
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xl) :: "memory");
-#endif
     }
     TPROF(1);
     // ---- batched leaf tests (bvh_accel.dart:126-143 / :189-204) ----
@@ -664,13 +587,8 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
       TPROF_COUNT(6, 1);
       if (mode == M_LEAF) {
         bool occluded = false;
-#if DR_OPT_COLD
         const F3 rayD = COLD_D();
         const double rayTmin = COLD_TMIN();
-#else
-        const F3 rayD = ray.d;
-        const double rayTmin = ray.tmin;
-#endif
         for (uint32_t i = 0; i < leafN; ++i) {
           ++nTris;
           const float4* tp = sc.tris + 3 * (size_t)(leafOff + i);
@@ -716,23 +634,15 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
       TPROF(2);
     }
     if (finished) {
-#if DR_OPT_COLD
       TraceRay rr = ray;
       rr.d = COLD_D();
       rr.tmin = COLD_TMIN();
       io.store(COLD_LD(5), rr, hit, sc);
-#else
-      io.store(handle, ray, hit, sc);
-#endif
       mode = M_IDLE;
     }
   }
   TPROF_FLUSH;
-#if DR_OPT_SCALAR_NODES
   flush_counters(ctr, ANY, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
-#else
-  flush_counters(ctr, ANY, nRays, nNodes, nTris);
-#endif
 }
 
 template <int ANY>
@@ -740,7 +650,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE_WAVES) k_trace(DScene
                                                           const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
                                                           TraceCounters* ctr) {
   __shared__ uint32_t s_stack[DR_V2_LDS_STACK * DR_TRACE_BLOCK];
-  __shared__ uint32_t s_cold[(DR_OPT_COLD ? 6 : 1) * DR_TRACE_BLOCK];  // DR_OPT_COLD: direction, minDistance, handle per lane
+  __shared__ uint32_t s_cold[6 * DR_TRACE_BLOCK];  // direction, minDistance, queue handle per lane
   StateIO<ANY> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
   trace_persistent<ANY, false>(sc, io, n, s_stack + threadIdx.x,
@@ -755,7 +665,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace_quad(DScene sc, BatchS
   __shared__ uint32_t s_stack[DR_V2_LDS_STACK * DR_TRACE_BLOCK];
   StateIO<ANY> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
-  __shared__ uint32_t s_cold[(DR_OPT_COLD ? 6 : 1) * DR_TRACE_BLOCK];
+  __shared__ uint32_t s_cold[6 * DR_TRACE_BLOCK];
   trace_persistent<ANY, true>(sc, io, n, s_stack + threadIdx.x,
                         spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
                         gridDim.x * DR_TRACE_BLOCK, work, ctr, s_cold + threadIdx.x);
@@ -765,7 +675,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect(DScene sc, const D
                                                               uint32_t* spill, uint32_t* work, TraceCounters* ctr) {
   __shared__ uint32_t s_stack[DR_V2_LDS_STACK * DR_TRACE_BLOCK];
   RayIO<ANY> io{rays, out};
-  __shared__ uint32_t s_cold[(DR_OPT_COLD ? 6 : 1) * DR_TRACE_BLOCK];
+  __shared__ uint32_t s_cold[6 * DR_TRACE_BLOCK];
   trace_persistent<ANY, true>(sc, io, n, s_stack + threadIdx.x,
                         spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
                         gridDim.x * DR_TRACE_BLOCK, work, ctr, s_cold + threadIdx.x);
@@ -797,7 +707,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect(DScene sc, const D
 // Packed child reference: 0xffffffff dead | leaf: 1<<31 | nprims<<26 | firstPrim | interior: axis<<29 | pair.
 // ===========================================================================
 #ifndef DR_PSTACK
-#define DR_PSTACK 16  // (reference, E) entries per lane kept in LDS: 8 B x 16 x 256 = 32 KiB per workgroup
+#define DR_PSTACK 15  // (reference, E) entries per lane kept in LDS: 8 B x 15 x 256 = 30 KiB per workgroup => 5 workgroups per CU (at 16 entries = 32 KiB only FOUR are resident: 5 x 32 KiB is the whole LDS and does not fit; measured on C4: +10 %)
 #endif
 
 struct SlabB {
@@ -1171,7 +1081,8 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
 void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
   const int impl = traceImpl(sc, anyHit);
-  if (!(impl == 2 && !sc.nquads)) grid = std::min(grid, traceGridFor(6));  // only k_trace fits 7 workgroups per CU
+  if (impl == 3) grid = std::min(grid, traceGridFor(5));                          // k_trace3: 30 KiB of LDS, 5 resident
+  else if (!(impl == 2 && !sc.nquads)) grid = std::min(grid, traceGridFor(6));  // only k_trace fits 7 workgroups per CU
   const dim3 g(grid), b(DR_TRACE_BLOCK);
   if (impl == 3) {
     if (anyHit) hipLaunchKernelGGL(k_trace3<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);

@@ -68,7 +68,7 @@ DR_DEV uint32_t* stage_region(PushStage& sm, uint32_t buffer) {
   return (uint32_t*)(&sm + 1) + ((size_t)buffer * nw + wave) * 4 * DR_PUSH_CAP;
 }
 DR_DEV void stage_push(PushStage& sm, PushCtx& c, bool pCont, bool pMis, bool pAny, bool pAct, uint32_t slot, uint32_t misBit,
-                       bool pVert = false) {
+                       bool pVert = false, uint32_t actBits = 0u) {
   const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
   uint32_t* buf = stage_region(sm, c.round & 1u);
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -78,7 +78,7 @@ DR_DEV void stage_push(PushStage& sm, PushCtx& c, bool pCont, bool pMis, bool pA
   if (pCont) buf[c.n[0] + (uint32_t)__popcll(m0 & lt)] = slot;
   if (pMis) buf[DR_PUSH_CAP + c.n[1] + (uint32_t)__popcll(m1 & lt)] = slot | misBit;
   if (pAny) buf[2 * DR_PUSH_CAP + c.n[2] + (uint32_t)__popcll(m2 & lt)] = slot;
-  if (pAct) buf[3 * DR_PUSH_CAP + c.n[3] + (uint32_t)__popcll(m3 & lt)] = slot;
+  if (pAct) buf[3 * DR_PUSH_CAP + c.n[3] + (uint32_t)__popcll(m3 & lt)] = slot | actBits;
   c.n[0] += (uint32_t)__popcll(m0);
   c.n[1] += (uint32_t)__popcll(m1);
   c.n[2] += (uint32_t)__popcll(m2);
