@@ -1050,6 +1050,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.dstages = sc->dlStages.p;
   rp.nDirectStages = direct ? sc->dlNStages : 0;
   rp.dlSpecular = dlSpec ? 1 : 0;
+  rp.deferredNee = rd->integrator == DR_INTEGRATOR_PATH ? 1 : 0;
   rp.samplerMode = rd->sampler_mode;
   rp.seed = (uint64_t)rd->seed;
   const int perNee = rp.nLights > 0 ? 7 : 0;

@@ -41,6 +41,7 @@ struct RenderParams {
   const DirectStage* dstages;  // DirectLighting: nDirectStages entries
   int32_t nDirectStages;
   int32_t dlSpecular;  // DirectLighting over mirror / glass: k_shade_spec adds SpecularReflect / SpecularTransmit after the last stage
+  int32_t deferredNee; // PathIntegrator: k_film adds the PF_DEFERRED light terms
 };
 
 // Flags of a path slot.
@@ -49,6 +50,8 @@ struct RenderParams {
 #define PF_HAS_CONT 4u  // continuation ray is pending
 #define PF_SPECULAR 8u  // the continuation ray was sampled from a specular lobe (specularBounce)
 #define PF_RAW_NEE 16u  // path kernel: Ld1 / Ld2 / betaNee hold the raw EstimateDirect terms (a MIS ray is pending, a delta
+#define PF_DEFERRED 32u  // path kernel: the path ended here and its last light term (finished, in Ld1) is added by k_film once the
+                         // shadow ray has been traced: the slot is in no later stage's list
                         // light, or a non-finite throughput); clear: Ld1 already is pathThroughput * (Ld1 * nLights)
 
 #define Q_MIS_BIT 0x80000000u

@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     PROF(4);
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
-    bool pushCont = false, vert = false;
+    bool pushCont = false, vert = false, deferred = false;
     if (valid) {
       const SlotRef sr = cur.sr;
       const uint32_t flags = cur.flags;
@@ -957,11 +957,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         vert = true;
       }
       if (Lchanged) stcf<F_L>(sr, L);
-      // (pf == 0: the slot is in no queue and no later stage visits it -- its flags are never read again)
-      if (pf) sr.u32<F_FLAGS>() = pf;
+      // The path ended here with a finished light term pending: nothing is added to L after it, so k_film adds it
+      // (L + Ld1 unless the shadow ray is blocked: the same f32 sum, one stage's round trip less).  Raw terms (a MIS
+      // ray to resolve) still take the next stage.
+      deferred = !pushCont && (pf & PF_HAS_SH) && !(pf & (PF_RAW_NEE | PF_HAS_MIS));
+      if (deferred) pf |= PF_DEFERRED;
+      // the camera stage initialises every slot's flags (k_film reads them); later stages need not store pf == 0:
+      // the slot is in no queue, no later stage visits it, and the flags it keeps carry no PF_DEFERRED
+      if (bounce == 0 || pf) sr.u32<F_FLAGS>() = pf;
       PROF(7);
     }
-    stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0, slot, Q_MIS_BIT, vert,
+    stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0 && !deferred, slot, Q_MIS_BIT, vert,
                pushCont ? 0u : Q_RESOLVE_BIT);
     PROF(8);
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
@@ -1225,6 +1231,15 @@ __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, co
         const uint32_t s = (uint32_t)s64;
         const int2 xy = st.pix[s >> rp.sppShift];
         C3 L = ldc(st.L(), cap, s);
+        if (rp.deferredNee) {
+          // the last light term of a path that ended (PF_DEFERRED, k_shade_path): L += pathThroughput * Ld unless the
+          // shadow ray found an occluder (path_integrator.dart:56-68); independent loads, no second round trip
+          const SlotRef sr = SlotRef::of(st, s);
+          const uint32_t flags = sr.u32<F_FLAGS>();
+          const int occ = sr.i32<F_SHOCC>();
+          const C3 Ld1 = ldcf<F_LD1>(sr);
+          if ((flags & PF_DEFERRED) && occ == 0) L = cadd(L, Ld1);
+        }
         // guards of sampler_renderer.dart:181-193
         double lum = clum(L);
         if (L.r != L.r || L.g != L.g || L.b != L.b) L = C3{0.f, 0.f, 0.f};
