@@ -200,7 +200,7 @@ struct StageQueues {
 #define DR_LDS_STACK 24       // stack entries per lane kept in LDS: 24 KiB per workgroup => 6 workgroups (24 waves) per CU
 #endif
 #ifndef DR_V2_LDS_STACK
-#define DR_V2_LDS_STACK 16    // v2 kernels: 16 KiB of stack + 6 KiB of cold ray state per workgroup => 7 workgroups (28 waves) per CU
+#define DR_V2_LDS_STACK 16    // k_trace: 16 KiB of stack + 6 KiB of cold ray state per workgroup => 7 workgroups (28 waves) per CU
 #endif
 #define DR_V2_WG_PER_CU 7
 int traceGridFor(int wgPerCU);  // dr_api.hip: workgroups of a persistent traversal launch

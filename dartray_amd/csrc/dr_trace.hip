@@ -34,9 +34,6 @@
 #ifndef DR_LEAF_TH
 #define DR_LEAF_TH 12
 #endif
-#ifndef DR_TRACE_WAVES
-#define DR_TRACE_WAVES 7  // __launch_bounds__ minimum waves per SIMD for k_trace: 72 VGPRs (the loop is latency bound: DESIGN.md section 5, round 2)
-#endif
 #ifndef DR_NSHARD
 #define DR_NSHARD 1  // work-queue shards: 1 = one shared counter; 8 = one per XCD.  Measured on C2: 8 shards are 12 % SLOWER (each XCD walks its own eighth of the queue, so the chip-wide working set in the shared Infinity Cache is 8 regions instead of 1)
 #endif
@@ -243,7 +240,6 @@ struct TraceRay {
   float tminLo, tminHi;        // f32 brackets: tminLo <= tmin <= tminHi
   float tmaxLo, tmaxHi;
   bool needF64;                // a zero direction component: 0*inf = NaN can occur, always take the literal test
-  uint32_t negBits;            // bit a: invDir[a] < 0 (the dirIsNeg table of bvh_accel.dart:112-116)
 };
 DR_DEV float f32_below(double v) {  // largest float <= v
   float f = (float)v;
@@ -271,7 +267,6 @@ DR_DEV void ray_init(TraceRay& r, F3 o, F3 d, double tmin, double tmax) {
   r.tminHi = f32_above(tmin);
   ray_set_tmax(r, tmax);
   r.needF64 = (d.x == 0.f) || (d.y == 0.f) || (d.z == 0.f);
-  r.negBits = (r.ivx < 0.f ? 1u : 0u) | (r.ivy < 0.f ? 2u : 0u) | (r.ivz < 0.f ? 4u : 0u);
 }
 
 // The literal slab test (bvh_accel.dart:439-472).
@@ -314,7 +309,11 @@ DR_DEV void slab_f32_sure(const TraceRay& r, float bminx, float bminy, float bmi
   asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(eLo) : "v"(lo), "v"(R), "v"(A));
   asm("v_fma_f32 %0, |%1|, %2, %3" : "=v"(eHi) : "v"(hi), "v"(R), "v"(A));
   const float loU = lo + eLo, loL = lo - eLo, hiU = hi + eHi, hiL = hi - eHi;
-  *sureHit = (loU <= hiL) && (loU < r.tmaxLo) && (hiL > r.tminHi);
+  // One bracket end per bound is enough.  tminLo / tminHi (and tmaxLo / tmaxHi) are equal or adjacent floats, so for the
+  // float hiL:  hiL > tminLo  =>  hiL >= tminHi >= minDistance, and the true exit parameter lies strictly above the real
+  // hi - eHi (eHi exceeds the rounding error of the products and of the enclosure arithmetic): exit > minDistance.
+  // Likewise loU < tmaxHi  =>  loU <= tmaxLo <= maxDistance with the true entry strictly below loU.
+  *sureHit = (loU <= hiL) && (loU < r.tmaxHi) && (hiL > r.tminLo);
   *sureMiss = (loL > hiU) || (loL >= r.tmaxHi) || (hiU <= r.tminLo);
 }
 DR_DEV int slab_f32(const TraceRay& r, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz) {
@@ -323,14 +322,23 @@ DR_DEV int slab_f32(const TraceRay& r, float bminx, float bminy, float bminz, fl
   return sureHit ? 1 : (sureMiss ? 0 : -1);
 }
 
+// The global part of the todo stack, [entry][launch thread]: a 32-bit byte offset from the wave-uniform base (the buffer
+// is < 4 GiB: ensureSpill).  The offset is rebuilt at every use and hidden from the optimiser -- left alone it keeps a
+// 64-bit per-lane pointer alive across the traversal loop.
+DR_DEV uint32_t* spill_at(uint32_t* spillBase, uint32_t spillStride, int entry) {
+  uint32_t o = blockIdx.x * DR_TRACE_BLOCK + threadIdx.x;
+  asm volatile("" : "+v"(o));
+  return (uint32_t*)((char*)spillBase + (size_t)(uint32_t)((o + (uint32_t)entry * spillStride) << 2));
+}
 // Pop: the LDS read is issued unconditionally (ds_read, not a flat load through a selected pointer);
-// the global spill is only touched by lanes deeper than DR_V2_LDS_STACK.
-DR_DEV uint32_t stack_pop(const uint32_t* lds, const uint32_t* spill, uint32_t spillStride, int sp) {
+// the global spill is only touched by lanes deeper than the STACK entries kept in LDS.
+template <int STACK>
+DR_DEV uint32_t stack_pop(const uint32_t* lds, uint32_t* spillBase, uint32_t spillStride, int sp) {
   // (an explicit LDS-address-space load: left generic, the compiler merges the two loads into ONE flat load
   // through a selected pointer)
   typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-  uint32_t v = ((lds_u32*)lds)[(sp < DR_V2_LDS_STACK ? sp : DR_V2_LDS_STACK - 1) * DR_TRACE_BLOCK];
-  if (sp >= DR_V2_LDS_STACK) v = spill[(size_t)(sp - DR_V2_LDS_STACK) * spillStride];
+  uint32_t v = ((lds_u32*)lds)[(sp < STACK ? sp : STACK - 1) * DR_TRACE_BLOCK];
+  if (sp >= STACK) v = *spill_at(spillBase, spillStride, sp - STACK);
   return v;
 }
 
@@ -439,7 +447,7 @@ void trace_prof_dump() {
 void trace_prof_dump() {}
 #endif
 
-template <int ANY, bool QUAD, class IO>
+template <int ANY, bool QUAD, int STACK, class IO>
 DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_t* lds, uint32_t* spill,
                              uint32_t spillStride, uint32_t* work, TraceCounters* ctr, uint32_t* cold) {
   // Ray state the node loop never reads -- direction, minDistance, the queue handle -- lives in LDS (6 dwords per
@@ -452,7 +460,6 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
 #define COLD_D() F3{__uint_as_float(COLD_LD(0)), __uint_as_float(COLD_LD(1)), __uint_as_float(COLD_LD(2))}
 #define COLD_TMIN() __hiloint2double((int)COLD_LD(4), (int)COLD_LD(3))
   const int lane = lane_id();
-  const unsigned long long ltMask = (1ull << lane) - 1ull;
   uint32_t nRays = 0, nNodes = 0, nTris = 0;
   TraceRay ray;
   ray.needF64 = false;
@@ -497,7 +504,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
       const uint32_t take = min(resEnd - resNext, (uint32_t)nIdle);
       TPROF_COUNT(5, 1);
       if (mode == M_IDLE) {
-        const uint32_t j = (uint32_t)__popcll(idleMask & ltMask);
+        const uint32_t j = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));  // rank among the idle lanes
         if (j < take) {
           const uint32_t idx = resNext + j;
           io.load(idx, ray, handle);
@@ -561,11 +568,12 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           leafN = nprims;
           pop = false;
         } else {
-          const bool neg = ((ray.negBits >> ((b.w >> 16) & 0xffu)) & 1u) != 0u;
+          const uint32_t axis = (b.w >> 16) & 0xffu;
+          const bool neg = (axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz)) < 0.f;  // dirIsNeg[axis]
           const uint32_t far = neg ? node + 1 : b.z;  // bvh_accel.dart:147-153
           node = neg ? b.z : node + 1;
-          if (sp < DR_V2_LDS_STACK) lds[sp * DR_TRACE_BLOCK] = far;
-          else if (sp < DR_MAX_STACK) spill[(size_t)(sp - DR_V2_LDS_STACK) * spillStride] = far;
+          if (sp < STACK) lds[sp * DR_TRACE_BLOCK] = far;
+          else if (sp < DR_MAX_STACK) *spill_at(spill, spillStride, sp - STACK) = far;
           ++sp;
           pop = false;
         }
@@ -575,7 +583,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           finished = true;
         } else {
           --sp;
-          node = stack_pop(lds, spill, spillStride, sp);
+          node = stack_pop<STACK>(lds, spill, spillStride, sp);
         }
       }
     }
@@ -627,7 +635,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           finished = true;
         } else {
           --sp;
-          node = stack_pop(lds, spill, spillStride, sp);
+          node = stack_pop<STACK>(lds, spill, spillStride, sp);
           mode = M_TRAV;
         }
       }
@@ -645,17 +653,20 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
   flush_counters(ctr, ANY, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
 }
 
+// Occupancy of k_trace (the loop is latency bound: every resident wave counts): 72 VGPRs => 7 waves per SIMD, 16 + 6
+// rows of LDS per lane = 22 KiB per workgroup => 7 workgroups per CU.  An eighth (any-hit rays fit 64 VGPRs) needs
+// <= 19 KiB, i.e. 13 stack rows: measured 9 % SLOWER -- the entries pushed past the LDS rows cost more than the waves
+// return (14 rows: +2 %, 12 rows: +19 %).
 template <int ANY>
-__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE_WAVES) k_trace(DScene sc, BatchState st, const uint32_t* queue,
+__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_V2_WG_PER_CU) k_trace(DScene sc, BatchState st, const uint32_t* queue,
                                                           const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
                                                           TraceCounters* ctr) {
   __shared__ uint32_t s_stack[DR_V2_LDS_STACK * DR_TRACE_BLOCK];
   __shared__ uint32_t s_cold[6 * DR_TRACE_BLOCK];  // direction, minDistance, queue handle per lane
   StateIO<ANY> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
-  trace_persistent<ANY, false>(sc, io, n, s_stack + threadIdx.x,
-                        spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
-                        gridDim.x * DR_TRACE_BLOCK, work, ctr, s_cold + threadIdx.x);
+  trace_persistent<ANY, false, DR_V2_LDS_STACK>(sc, io, n, s_stack + threadIdx.x, spill, gridDim.x * DR_TRACE_BLOCK, work, ctr,
+                                              s_cold + threadIdx.x);
 }
 // scenes with sphere / disk primitives: the quadric tests cost registers, so they get their own instantiation
 template <int ANY>
@@ -663,22 +674,20 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace_quad(DScene sc, BatchS
                                                                const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
                                                                TraceCounters* ctr) {
   __shared__ uint32_t s_stack[DR_V2_LDS_STACK * DR_TRACE_BLOCK];
+  __shared__ uint32_t s_cold[6 * DR_TRACE_BLOCK];
   StateIO<ANY> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
-  __shared__ uint32_t s_cold[6 * DR_TRACE_BLOCK];
-  trace_persistent<ANY, true>(sc, io, n, s_stack + threadIdx.x,
-                        spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
-                        gridDim.x * DR_TRACE_BLOCK, work, ctr, s_cold + threadIdx.x);
+  trace_persistent<ANY, true, DR_V2_LDS_STACK>(sc, io, n, s_stack + threadIdx.x, spill, gridDim.x * DR_TRACE_BLOCK, work, ctr,
+                                               s_cold + threadIdx.x);
 }
 template <int ANY>
 __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect(DScene sc, const DrRay* rays, uint32_t n, DrHit* out,
                                                               uint32_t* spill, uint32_t* work, TraceCounters* ctr) {
   __shared__ uint32_t s_stack[DR_V2_LDS_STACK * DR_TRACE_BLOCK];
-  RayIO<ANY> io{rays, out};
   __shared__ uint32_t s_cold[6 * DR_TRACE_BLOCK];
-  trace_persistent<ANY, true>(sc, io, n, s_stack + threadIdx.x,
-                        spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr,
-                        gridDim.x * DR_TRACE_BLOCK, work, ctr, s_cold + threadIdx.x);
+  RayIO<ANY> io{rays, out};
+  trace_persistent<ANY, true, DR_V2_LDS_STACK>(sc, io, n, s_stack + threadIdx.x, spill, gridDim.x * DR_TRACE_BLOCK, work, ctr,
+                                               s_cold + threadIdx.x);
 }
 
 // ===========================================================================
