@@ -69,12 +69,12 @@ def shade_alg_bytes(st):
             + st["shade_shadow"] * 36.0)  # shD, shTmax, Ld1 + queue entry
 
 
-def roofline_objects(st, dt_total, copy_gbps):
+def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>"):
     alg = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
     launches = max(1, st["closest_launches"])
     achieved = alg / max(st["closest_ms"] * 1e-3, 1e-12) / 1e9
     all_alg = alg + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
-    roof = {"bound": "hbm", "kernel": "k_trace<0> (closest-hit BVH traversal)",
+    roof = {"bound": "hbm", "kernel": "%s (closest-hit BVH traversal)" % closest_kernel,
             "achieved": round(achieved, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_GBPS, 4),
             "traffic": None,  # HBM-side bytes come from separate rocprofv3 --pmc passes: see "traffic_profiled"
             "hbm_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
@@ -242,7 +242,8 @@ class Run:
         _abi.check(self.lib.dr_copy_bandwidth(1 << 30, 10, C.byref(copy)))  # measured HBM denominator (float4 copy, 2 GiB moved per pass)
         samples_per_step = self.H * self.W * self.spp * (world if (self.mode == "samples" and world > 1) else 1)
         value = samples_per_step * steps / dt / 1e6
-        roof, shade, all_alg = roofline_objects(st, dt, copy.value)
+        picked = self.dev.trace_kernels()  # (closest, any): 2 = k_trace, 3 = k_trace3 (the pilot's choice for this scene)
+        roof, shade, all_alg = roofline_objects(st, dt, copy.value, "k_trace3<0>" if picked[0] == 3 else "k_trace<0>")
         agg = self.scene.aggregate
         if world == 1:
             par = "1 GPU"

@@ -9,7 +9,7 @@ mkdir -p "$root/$out"
 stats() {  # name, env assignment, bench args
   local name="$1" envs="$2" bargs="$3" d="$root/$out/$1"
   rm -rf "$d"; mkdir -p "$d"
-  (cd /tmp && export $envs && rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -o run -- python3 "$root/bench.py" $bargs > "$d/bench.json" 2> "$d/bench.err")
+  (cd /tmp && export $envs && timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -o run -- python3 "$root/bench.py" $bargs > "$d/bench.json" 2> "$d/bench.err")
   f=$(find "$d" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$root/$out/${name}_kernel_stats.csv"
   tail -1 "$d/bench.json" > "$root/$out/${name}_bench.json"
@@ -18,7 +18,7 @@ stats() {  # name, env assignment, bench args
 pmc() {  # name, env, bench args, counters
   local name="$1" envs="$2" bargs="$3" ctrs="$4" d="$root/$out/$1"
   rm -rf "$d"; mkdir -p "$d"
-  (cd /tmp && export $envs && rocprofv3 --pmc $ctrs --output-format csv -d "$d" -o run -- python3 "$root/bench.py" $bargs > "$d.log" 2>&1)
+  (cd /tmp && export $envs && timeout -s KILL 300 rocprofv3 --pmc $ctrs --output-format csv -d "$d" -o run -- python3 "$root/bench.py" $bargs > "$d.log" 2>&1)
   python3 "$root/tools/pmc_summary.py" "$d" > "$root/$out/pmc_$name.txt" 2>&1
   rm -rf "$d" "$d.log"
 }
