@@ -202,7 +202,9 @@ struct StageQueues {
 #ifndef DR_V2_LDS_STACK
 #define DR_V2_LDS_STACK 16    // k_trace: 16 KiB of stack + 6 KiB of cold ray state per workgroup => 7 workgroups (28 waves) per CU
 #endif
+#ifndef DR_V2_WG_PER_CU
 #define DR_V2_WG_PER_CU 7
+#endif
 int traceGridFor(int wgPerCU);  // dr_api.hip: workgroups of a persistent traversal launch
 #define DR_MAX_STACK 128      // LDS + spill entries per lane (the reference uses 64, bvh_accel.dart:120)
 #define DR_TRACE_BLOCK 256
