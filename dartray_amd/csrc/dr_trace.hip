@@ -338,13 +338,20 @@ DR_DEV uint32_t stack_pop(const uint32_t* lds, uint32_t* spillBase, uint32_t spi
   // through a selected pointer)
   typedef __attribute__((address_space(3))) const uint32_t lds_u32;
   uint32_t v = ((lds_u32*)lds)[(sp < STACK ? sp : STACK - 1) * DR_TRACE_BLOCK];
-  if (sp >= STACK) v = *spill_at(spillBase, spillStride, sp - STACK);
+  if (sp >= STACK) {
+    v = *spill_at(spillBase, spillStride, sp - STACK);
+    // consume the value HERE: the wait for this (rare) load then sits in this branch.  Left pending, it makes the
+    // compiler put `s_waitcnt vmcnt(0)` in front of every node fetch -- vmcnt retires in order, so that wait also
+    // covers the result stores and spill pushes issued before it, on every iteration of every lane.
+    asm volatile("" : "+v"(v));
+  }
   return v;
 }
 
 #define M_IDLE 0
 #define M_TRAV 1
 #define M_LEAF 2
+#define M_DONE 3  // finished, result not stored yet
 
 // IO policy of the path-state kernel: queue entries -> rays, results -> slot arrays.
 template <int ANY>
@@ -533,19 +540,33 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
     }
     const unsigned long long travMask = __ballot(mode == M_TRAV);
     unsigned long long leafMask = __ballot(mode == M_LEAF);
-    if ((travMask | leafMask) == 0ull) {
+    const unsigned long long doneMask = __ballot(mode == M_DONE);
+    if ((travMask | leafMask | doneMask) == 0ull) {
       if (exhausted) break;
       continue;
     }
     bool finished = false;
     // ---- one node visit (bvh_accel.dart:122-160) ----
     nNodes += (uint32_t)__popcll(travMask);  // wave-uniform: lane 0 carries the wave's count (flush_counters sums lanes)
+    uint4 a = uint4{0, 0, 0, 0}, b = uint4{0, 0, 0, 0};
     if (mode == M_TRAV) {
       // 32-bit byte offset from a scalar base (dr_scene_create refuses trees beyond 2^27 nodes): one shift instead of
       // a 64-bit shift + add per visit
       const uint4* np = (const uint4*)((const char*)sc.nodes + (size_t)(uint32_t)(node << 5));
-      const uint4 a = np[0];
-      const uint4 b = np[1];
+      a = np[0];
+      b = np[1];
+    }
+    // results of the rays that finished in the previous iteration: stored HERE, behind the node fetches.  vmcnt retires
+    // in order and stores count in it: issued before the fetches (at the end of the previous iteration) their
+    // acknowledgement is waited for before the fetches are even issued; issued behind them it overlaps the fetch.
+    if (mode == M_DONE) {
+      TraceRay rr = ray;
+      rr.d = COLD_D();
+      rr.tmin = COLD_TMIN();
+      io.store(COLD_LD(5), rr, hit, sc);
+      mode = M_IDLE;
+    }
+    if (mode == M_TRAV) {
       const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
       const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
       bool ok = false, amb = true;
@@ -641,13 +662,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
       }
       TPROF(2);
     }
-    if (finished) {
-      TraceRay rr = ray;
-      rr.d = COLD_D();
-      rr.tmin = COLD_TMIN();
-      io.store(COLD_LD(5), rr, hit, sc);
-      mode = M_IDLE;
-    }
+    if (finished) mode = M_DONE;  // stored at the head of the next iteration, behind that iteration's node fetches
   }
   TPROF_FLUSH;
   flush_counters(ctr, ANY, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
