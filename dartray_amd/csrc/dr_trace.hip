@@ -923,15 +923,24 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     }
     const unsigned long long expMask = __ballot(mode == M_EXPAND);
     unsigned long long leafMask = __ballot(mode == M_LEAF);
-    if ((expMask | leafMask) == 0ull) {
+    if ((expMask | leafMask | __ballot(mode == M_DONE)) == 0ull) {
       if (exhausted) break;
       continue;
     }
     bool finished = false;
     // ---- expand one interior node: ONE 64-byte fetch, two box tests ----
+    uint4 l0 = uint4{0, 0, 0, 0}, l1 = l0, r0 = l0, r1 = l0;
     if (mode == M_EXPAND) {
       const uint4* pp = sc.pairs + 4 * (size_t)(cur & 0x1fffffffu);
-      const uint4 l0 = pp[0], l1 = pp[1], r0 = pp[2], r1 = pp[3];
+      l0 = pp[0], l1 = pp[1], r0 = pp[2], r1 = pp[3];
+    }
+    // results of the rays that finished in the previous iteration, stored behind this iteration's fetches (vmcnt
+    // retires in order: see trace_persistent)
+    if (mode == M_DONE) {
+      io.store(handle, ray, hit, sc);
+      mode = M_IDLE;
+    }
+    if (mode == M_EXPAND) {
       bool alive = true;
       if (retest) {
         // own box = union of the children's (bvh_accel.dart:521): the literal test the reference does at this pop
@@ -1037,10 +1046,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
         }
       }
     }
-    if (finished) {
-      io.store(handle, ray, hit, sc);
-      mode = M_IDLE;
-    }
+    if (finished) mode = M_DONE;  // stored at the head of the next iteration
   }
   flush_counters(ctr, ANY, nRays, nNodes, nTris);
 }
