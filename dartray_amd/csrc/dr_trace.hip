@@ -521,13 +521,13 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           COLD_ST(3, (uint32_t)__double2loint(ray.tmin));
           COLD_ST(4, (uint32_t)__double2hiint(ray.tmin));
           COLD_ST(5, handle);
+          hit = -1;
           if (sc.nnodes == 0) {
-            io.store(handle, ray, -1, sc);
+            mode = M_DONE;  // an empty scene: a miss, stored like every other result
           } else {
             mode = M_TRAV;
             node = 0;
             sp = 0;
-            hit = -1;
           }
         }
       }
