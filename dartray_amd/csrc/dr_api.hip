@@ -1051,6 +1051,21 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.nDirectStages = direct ? sc->dlNStages : 0;
   rp.dlSpecular = dlSpec ? 1 : 0;
   rp.deferredNee = rd->integrator == DR_INTEGRATOR_PATH ? 1 : 0;
+  rp.genMask = 0ull;
+  if (rd->integrator == DR_INTEGRATOR_PATH && !rp.blocks) {
+    // What the path kernels read of a pixel sample (dr_kernels.hip: k_raygen, load_shade_in, k_film): the image sample,
+    // the lens sample of a thin-lens camera, and per SAMPLE_DEPTH level b <= maxDepth the light number, the light
+    // sample (component + position), the BSDF and path directions; the two uComponent slots only where a material has
+    // more than one lobe.  Never read: the time sample, the volume integrator's two slots, levels beyond maxDepth.
+    const bool general = sc->d.nquads || sc->d.hasSpec || sc->d.srec;
+    uint64_t m = 1ull | (rd->camera.lens_radius > 0.0 ? 2ull : 0ull);
+    for (int b = 0; b < 3 && b <= rd->max_depth; ++b) {
+      m |= 3ull << (3 + 4 * b);
+      if (general) m |= 12ull << (3 + 4 * b);
+      m |= 7ull << (3 + rp.n1D + 3 * b);
+    }
+    rp.genMask = m;
+  }
   rp.samplerMode = rd->sampler_mode;
   rp.seed = (uint64_t)rd->seed;
   const int perNee = rp.nLights > 0 ? 7 : 0;

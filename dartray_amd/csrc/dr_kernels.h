@@ -42,6 +42,7 @@ struct RenderParams {
   int32_t nDirectStages;
   int32_t dlSpecular;  // DirectLighting over mirror / glass: k_shade_spec adds SpecularReflect / SpecularTransmit after the last stage
   int32_t deferredNee; // PathIntegrator: k_film adds the PF_DEFERRED light terms
+  uint64_t genMask;    // LD blocks the device sampler must produce (bit = block index; 0 = all): blocks no kernel reads are skipped
 };
 
 // Flags of a path slot.

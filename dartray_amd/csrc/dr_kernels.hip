@@ -225,6 +225,14 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
 // The workgroup has LN = blockDim.x <= 64 lanes (pixels): what limits this kernel is the LDS footprint of a shuffle
 // (spp entries per pixel) and the latency of its dependent steps, so the 160 KB of a CU are better spent on many
 // narrow waves than on few full ones -- 64 lanes up to 128 spp, 32 at 256, 16 above (launch_gen_samples).
+// The LD block a workgroup row produces: blockIdx.y counts the blocks of rp.genMask (every (pixel, block) pair has its
+// own keyed stream, so a block nobody reads can be left out without touching the others).
+DR_DEV int gen_block(const RenderParams& rp) {
+  if (rp.genMask == 0ull) return (int)blockIdx.y;
+  unsigned long long m = rp.genMask;
+  for (uint32_t i = 0; i < blockIdx.y; ++i) m &= m - 1ull;
+  return __ffsll((long long)m) - 1;
+}
 template <class PT>
 __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchState st, uint32_t npix) {
   extern __shared__ __align__(16) unsigned char s_raw[];
@@ -234,7 +242,7 @@ __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchSta
   uint32_t* s_magic = (uint32_t*)(s_raw + (size_t)rp.spp * LN * sizeof(PT));  // [spp + 1]: floor(2^32 / m)
   const int lane = threadIdx.x;
   const uint32_t p = blockIdx.x * (uint32_t)LN + lane;
-  const int k = blockIdx.y;  // LD block: image, lens, time, 1-D slots, 2-D slots (montecarlo.dart:437-448)
+  const int k = gen_block(rp);  // LD block: image, lens, time, 1-D slots, 2-D slots (montecarlo.dart:437-448)
   const int spp = rp.spp;
   const bool is2D = k < 2 || k >= 3 + rp.n1D;
   auto at = [&](int i) -> PT& { return s_perm[(i / EPW) * (LN * EPW) + lane * EPW + (i % EPW)]; };
@@ -1364,10 +1372,11 @@ void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t*
 void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s) {
   const int nBlocks = rp.blocks ? rp.nBlocks : 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
   const dim3 grid((npix + 63) / 64, nBlocks);
-  if (!st.svFloat && rp.spp >= 64) {  // compact form (rp.blocks is null), whole index runs per pixel
+  if (!st.svFloat && rp.spp >= 64) {
+    const int nGen = rp.genMask ? __builtin_popcountll(rp.genMask) : nBlocks;  // compact form (rp.blocks is null), whole index runs per pixel
     static const int lanesEnv = getenv("DARTRAY_GEN_LANES") ? atoi(getenv("DARTRAY_GEN_LANES")) : 0;
     const int ln = lanesEnv ? lanesEnv : (rp.spp <= 128 ? 64 : (rp.spp <= 256 ? DR_GEN_LANES_256 : DR_GEN_LANES_BIG));
-    const dim3 g((npix + ln - 1) / ln, nBlocks);
+    const dim3 g((npix + ln - 1) / ln, nGen);
     const size_t lds = (size_t)rp.spp * ln * (rp.spp <= 256 ? 1 : 2) + ((size_t)rp.spp + 1) * 4;
     if (rp.spp <= 256) {
       hipLaunchKernelGGL(k_gen_samples_lm<uint8_t>, g, dim3(ln), lds, s, rp, st, npix);
