@@ -1052,7 +1052,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.dlSpecular = dlSpec ? 1 : 0;
   rp.deferredNee = rd->integrator == DR_INTEGRATOR_PATH ? 1 : 0;
   rp.genMask = 0ull;
-  if (rd->integrator == DR_INTEGRATOR_PATH && !rp.blocks) {
+  static const bool genAll = getenv("DARTRAY_GEN_ALL_BLOCKS") != nullptr;  // A/B and tests: generate every block
+  if (rd->integrator == DR_INTEGRATOR_PATH && !rp.blocks && !genAll) {
     // What the path kernels read of a pixel sample (dr_kernels.hip: k_raygen, load_shade_in, k_film): the image sample,
     // the lens sample of a thin-lens camera, and per SAMPLE_DEPTH level b <= maxDepth the light number, the light
     // sample (component + position), the BSDF and path directions; the two uComponent slots only where a material has

@@ -336,6 +336,43 @@ def test_two_pipelines_render_the_same_film():
     assert np.array_equal(films[0], films[1])
 
 
+def test_unread_sample_blocks_can_be_left_out():
+    """The device sampler only produces the LD blocks some kernel reads (RenderParams.genMask: no time sample, no
+    volume slots, no uComponents for single-lobe materials, no lens sample for a pinhole, no levels beyond maxDepth).
+    Every (pixel, block) has its own keyed stream, so generating ALL blocks (DARTRAY_GEN_ALL_BLOCKS=1) must give the same
+    film -- for a matte pinhole scene, a thin-lens camera, a mirror / glass scene and a depth-1 path."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from dartray_amd import core, scenes\n"
+        "films = []\n"
+        "prims, mk = scenes.config('C2', xres=96, yres=80, spp=64, blob=(60, 30))\n"
+        "films.append(mk().render(scenes.make_scene(prims)).film)\n"
+        "film = core.ImageFilm(96, 80)\n"
+        "cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film, lensradius=0.8, focaldistance=30.0)\n"
+        "for depth in (5, 1):\n"
+        "    r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 64), cam, core.PathIntegrator(depth), core.EmissionIntegrator())\n"
+        "    films.append(r.render(scenes.make_scene(prims)).film)\n"
+        "prims2 = scenes.cornell_walls() + [scenes.emitter_quad(), core.GeometricPrimitive(scenes.blob_mesh(16, 8), core.MirrorMaterial((0.9, 0.9, 0.9)))]\n"
+        "films.append(mk().render(scenes.make_scene(prims2)).film)\n"
+        "np.save(sys.argv[1], np.stack([f[:80, :96] for f in films]))\n" % ROOT)
+    out = []
+    for gen_all in (False, True):
+        path = os.path.join(ROOT, "gpurun_out", "film_gen%d.npy" % gen_all)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        env = dict(os.environ)
+        env.pop("DARTRAY_GEN_ALL_BLOCKS", None)
+        if gen_all:
+            env["DARTRAY_GEN_ALL_BLOCKS"] = "1"
+        res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=500)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out.append(np.load(path))
+        os.remove(path)
+    assert out[0].shape[0] == 4 and np.array_equal(out[0], out[1])
+    assert out[0][..., :3].max() > 0
+
+
 def test_invalid_arguments_raise(gpu):
     prims, mk = scenes.config("C1")
     scene = scenes.make_scene(prims)
