@@ -12,7 +12,8 @@ for bit.
 
 Scope (task 5): Triangle.intersect / intersectP, BVHAccel.intersect / intersectP + _intersectP,
 GeometricPrimitive.intersect, ShapeSet.sample / pdf, Shape.pdf2, DiffuseAreaLight, EstimateDirect,
-UniformSampleOneLight / AllLights, PathIntegrator.Li, DirectLightingIntegrator.Li, matte BSDF (Lambertian),
+UniformSampleOneLight / AllLights, PathIntegrator.Li, DirectLightingIntegrator.Li, BSDF with Lambertian /
+SpecularReflection / SpecularTransmission lobes and FresnelDielectric (matte, mirror, glass materials),
 PerspectiveCamera.generateRayDifferential, SamplerRenderer's guards, ImageFilm.addSample / writeImage.
 Inputs it does NOT derive: the flattened BVH node array and primitive order (built by the product's dr_bvh_build) and
 the recorded sample vectors / RNG draws.
@@ -105,10 +106,17 @@ class RGB:
     def __add__(self, s):
         return RGB(self.r + s.r, self.g + s.g, self.b + s.b)
 
+    def __sub__(self, s):
+        return RGB(self.r - s.r, self.g - s.g, self.b - s.b)
+
     def __mul__(self, s):
         if isinstance(s, RGB):
             return RGB(self.r * s.r, self.g * s.g, self.b * s.b)
         return RGB(self.r * s, self.g * s, self.b * s)
+
+    def clamp(self, low=0.0, high=INFINITY):                        # rgb_color.dart:189-192
+        c = lambda v: low if v < low else (high if v > high else v)
+        return RGB(c(self.r), c(self.g), c(self.b))
 
     def __truediv__(self, s):
         return RGB(self.r / s, self.g / s, self.b / s)
@@ -253,8 +261,11 @@ class Triangle:
 # accelerators/bvh_accel.dart
 # ---------------------------------------------------------------------------------------------------------------
 class Prim:                                                        # GeometricPrimitive (geometric_primitive.dart)
-    def __init__(self, shape, Kd, light=None):
-        self.shape, self.Kd, self.light = shape, Kd, light
+    def __init__(self, shape, material, light=None):
+        # material: a Kd triple (matte), or ("matte", Kd) / ("mirror", Kr) / ("glass", Kr, Kt, index)
+        if not isinstance(material[0], str):
+            material = ("matte", tuple(material))
+        self.shape, self.material, self.light = shape, material, light
 
 
 class Isect:
@@ -482,6 +493,9 @@ class DiffuseAreaLight:
     def pdf(self, p, w):
         return self.shapeSet.pdf(p, w)
 
+    def Le(self, ray):                                             # light.dart:70-72: an area light adds nothing to an escaped ray
+        return RGB(0.0)
+
     def sampleLAtPoint(self, p, pEpsilon, uPos, uComponent):
         """diffuse_area_light.dart:60-70 -> (Ls, wi, pdf, shadow ray)."""
         ps, ns = self.shapeSet.sample(uPos, uComponent, p)
@@ -493,18 +507,146 @@ class DiffuseAreaLight:
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# core/reflection/bsdf.dart with one Lambertian lobe (materials/matte_material.dart:41-65)
+# core/reflection/*.dart: BxDF, Lambertian, SpecularReflection, SpecularTransmission, Fresnel*, BSDF; and the three
+# materials that build them (materials/matte_material.dart, mirror_material.dart, glass_material.dart)
 # ---------------------------------------------------------------------------------------------------------------
-LAMBERT_TYPE = BSDF_REFLECTION | BSDF_DIFFUSE
+def CosTheta(w):                                                   # vector.dart:117
+    return w.z
+
+
+def AbsCosTheta(w):                                                # vector.dart:119
+    return abs(w.z)
+
+
+def SinTheta2(w):                                                  # vector.dart:121-122
+    return max(0.0, 1.0 - CosTheta(w) * CosTheta(w))
+
+
+class BxDF:                                                        # bxdf.dart:23-91
+    type = 0
+
+    def matchesFlags(self, flags):
+        return (self.type & flags) == self.type
+
+    def sample_f(self, wo, u1, u2):
+        """-> (f, wi, pdf): cosine-sample the hemisphere, flipping the direction if necessary (bxdf.dart:37-48)."""
+        wi = CosineSampleHemisphere(u1, u2)
+        if wo.z < 0.0:
+            wi = Vec(wi.x, wi.y, wi.z * -1.0)
+        return self.f(wo, wi), wi, self.pdf(wo, wi)
+
+    def pdf(self, wo, wi):                                         # bxdf.dart:84-88, Vector.SameHemisphere (vector.dart:194-196)
+        return AbsCosTheta(wi) * INV_PI if wo.z * wi.z > 0.0 else 0.0
+
+
+class Lambertian(BxDF):                                            # lambertian.dart:23-40
+    type = BSDF_REFLECTION | BSDF_DIFFUSE
+
+    def __init__(self, R):
+        self.R = R
+
+    def f(self, wo, wi):
+        return self.R * INV_PI
+
+
+class FresnelNoOp:                                                 # fresnel_no_op.dart:23-27
+    def evaluate(self, cosi):
+        return RGB(1.0)
+
+
+class FresnelDielectric:                                           # fresnel_dielectric.dart:30-68
+    def __init__(self, eta_i, eta_t):
+        self.eta_i, self.eta_t = eta_i, eta_t
+
+    def evaluate(self, cosi):
+        cosi = -1.0 if cosi < -1.0 else (1.0 if cosi > 1.0 else cosi)
+        entering = cosi > 0.0
+        ei, et = self.eta_i, self.eta_t
+        if not entering:
+            ei, et = et, ei
+        sint = ei / et * math.sqrt(max(0.0, 1.0 - cosi * cosi))    # Snell's law
+        if sint >= 1.0:
+            return RGB(1.0)                                        # total internal reflection
+        cost = math.sqrt(max(0.0, 1.0 - sint * sint))
+        cosi = abs(cosi)
+        Rparl = ((et * cosi) - (ei * cost)) / ((et * cosi) + (ei * cost))
+        Rperp = ((ei * cosi) - (et * cost)) / ((ei * cosi) + (et * cost))
+        return RGB((Rparl * Rparl + Rperp * Rperp) / 2.0)
+
+
+class SpecularReflection(BxDF):                                    # specular_reflection.dart:23-49
+    type = BSDF_REFLECTION | BSDF_SPECULAR
+
+    def __init__(self, R, fresnel):
+        self.R, self.fresnel = R, fresnel
+
+    def f(self, wo, wi):
+        return RGB(0.0)
+
+    def pdf(self, wo, wi):
+        return 0.0
+
+    def sample_f(self, wo, u1, u2):
+        wi = Vec(-wo.x, -wo.y, wo.z)                               # perfect specular reflection direction
+        return (self.fresnel.evaluate(CosTheta(wo)) * self.R) / AbsCosTheta(wi), wi, 1.0
+
+
+class SpecularTransmission(BxDF):                                  # specular_transmission.dart:23-79
+    type = BSDF_TRANSMISSION | BSDF_SPECULAR
+
+    def __init__(self, T, ei, et):
+        self.T, self.etai, self.etat = T, ei, et
+        self.fresnel = FresnelDielectric(ei, et)
+
+    def f(self, wo, wi):
+        return RGB(0.0)
+
+    def pdf(self, wo, wi):
+        return 0.0
+
+    def sample_f(self, wo, u1, u2):
+        entering = CosTheta(wo) > 0.0
+        ei, et = self.etai, self.etat
+        if not entering:
+            ei, et = et, ei
+        sini2 = SinTheta2(wo)
+        eta = ei / et
+        sint2 = eta * eta * sini2
+        if sint2 >= 1.0:                                           # total internal reflection: pdf stays 0 (bsdf.dart:84-95)
+            return RGB(0.0), Vec(), 0.0
+        cost = math.sqrt(max(0.0, 1.0 - sint2))
+        if entering:
+            cost = -cost
+        sintOverSini = eta
+        wi = Vec(sintOverSini * -wo.x, sintOverSini * -wo.y, cost)
+        F = self.fresnel.evaluate(CosTheta(wo))
+        return ((RGB(1.0) - F) * self.T) / AbsCosTheta(wi), wi, 1.0
 
 
 class BSDF:
-    def __init__(self, dgs, ngeom, Kd):
+    def __init__(self, dgs, ngeom, material):
         self.p, self.nn, self.ng = dgs.p, dgs.nn, ngeom             # bsdf.dart:45-51
         self.sn = Normalize(dgs.dpdu)
         self.tn = Cross(self.nn, self.sn)
-        r = RGB(*[min(max(c, 0.0), INFINITY) for c in Kd])          # Kd.evaluate(dgs).clamp()
-        self.R = None if r.isBlack() else r                         # matte_material.dart:54-60: no lobe for a black Kd
+        self.bxdfs = []
+        kind = material[0]
+        if kind == "matte":                                         # matte_material.dart:41-65 (sigma == 0)
+            r = RGB(*material[1]).clamp()
+            if not r.isBlack():
+                self.bxdfs.append(Lambertian(r))
+        elif kind == "mirror":                                      # mirror_material.dart:38-54
+            R = RGB(*material[1]).clamp()
+            if not R.isBlack():
+                self.bxdfs.append(SpecularReflection(R, FresnelNoOp()))
+        elif kind == "glass":                                       # glass_material.dart:44-68
+            ior = float(material[3])
+            R, T = RGB(*material[1]).clamp(), RGB(*material[2]).clamp()
+            if not R.isBlack():
+                self.bxdfs.append(SpecularReflection(R, FresnelDielectric(1.0, ior)))
+            if not T.isBlack():
+                self.bxdfs.append(SpecularTransmission(T, 1.0, ior))
+        else:
+            raise ValueError(kind)
 
     def worldToLocal(self, v):                                      # bsdf.dart:177-179
         return Vec(Dot(v, self.sn), Dot(v, self.tn), Dot(v, self.nn))
@@ -513,56 +655,66 @@ class BSDF:
         sn, tn, nn = self.sn, self.tn, self.nn
         return Vec(sn.x * v.x + tn.x * v.y + nn.x * v.z, sn.y * v.x + tn.y * v.y + nn.y * v.z, sn.z * v.x + tn.z * v.y + nn.z * v.z)
 
-    def _matches(self, flags):
-        return self.R is not None and (LAMBERT_TYPE & flags) == LAMBERT_TYPE
+    def numComponents(self, flags):                                 # bsdf.dart:162-175
+        return sum(1 for b in self.bxdfs if b.matchesFlags(flags))
 
     def f(self, woW, wiW, flags):                                   # bsdf.dart:187-211
+        wi, wo = self.worldToLocal(wiW), self.worldToLocal(woW)
         if Dot(wiW, self.ng) * Dot(woW, self.ng) > 0:
-            flags = flags & ~BSDF_TRANSMISSION
+            flags = flags & ~BSDF_TRANSMISSION                      # ignore BTDFs
         else:
-            flags = flags & ~BSDF_REFLECTION
+            flags = flags & ~BSDF_REFLECTION                        # ignore BRDFs
         f = RGB(0.0)
-        if self._matches(flags):
-            f = f + self.R * INV_PI                                 # lambertian.dart:35-37
+        for b in self.bxdfs:
+            if b.matchesFlags(flags):
+                f = f + b.f(wo, wi)
         return f
 
-    @staticmethod
-    def _lambert_pdf(wo, wi):                                       # bxdf.dart:84-88
-        return abs(wi.z) * INV_PI if wo.z * wi.z > 0.0 else 0.0
-
     def pdf(self, woW, wiW, flags):                                 # bsdf.dart:135-156
-        if self.R is None:
+        if not self.bxdfs:
             return 0.0
         wo, wi = self.worldToLocal(woW), self.worldToLocal(wiW)
         pdf, matching = 0.0, 0
-        if self._matches(flags):
-            matching += 1
-            pdf += self._lambert_pdf(wo, wi)
+        for b in self.bxdfs:
+            if b.matchesFlags(flags):
+                matching += 1
+                pdf += b.pdf(wo, wi)
         return pdf / matching if matching > 0 else 0.0
 
     def sample_f(self, woW, uDir, uComponent, flags):
         """bsdf.dart:53-133 -> (f, wiW, pdf, sampledType)."""
-        matching = 1 if self._matches(flags) else 0
+        matching = self.numComponents(flags)
         if matching == 0:
             return RGB(0.0), Vec(), 0.0, 0
         which = min(math.floor(uComponent * matching), matching - 1)
-        assert which == 0
+        bxdf, count = None, which
+        for b in self.bxdfs:
+            if b.matchesFlags(flags):
+                if count == 0:
+                    bxdf = b
+                    break
+                count -= 1
         wo = self.worldToLocal(woW)
-        wi = CosineSampleHemisphere(uDir[0], uDir[1])               # BxDF.sample_f (bxdf.dart:37-48)
-        if wo.z < 0.0:
-            wi = Vec(wi.x, wi.y, wi.z * -1.0)
-        pdf = self._lambert_pdf(wo, wi)
+        f, wi, pdf = bxdf.sample_f(wo, uDir[0], uDir[1])
         if pdf == 0.0:
             return RGB(0.0), Vec(), 0.0, 0
         wiW = self.localToWorld(wi)
-        f = RGB(0.0)                                                # not specular: re-evaluate over the matching lobes
-        if Dot(wiW, self.ng) * Dot(woW, self.ng) > 0:
-            flags = flags & ~BSDF_TRANSMISSION
-        else:
-            flags = flags & ~BSDF_REFLECTION
-        if self._matches(flags):
-            f = f + self.R * INV_PI
-        return f, wiW, pdf, LAMBERT_TYPE
+        if not (bxdf.type & BSDF_SPECULAR) and matching > 1:        # overall pdf with all matching lobes
+            for b in self.bxdfs:
+                if b is not bxdf and b.matchesFlags(flags):
+                    pdf += b.pdf(wo, wi)
+        if matching > 1:
+            pdf /= matching
+        if (bxdf.type & BSDF_SPECULAR) == 0:                        # value of the BSDF for the sampled direction
+            f = RGB(0.0)
+            if Dot(wiW, self.ng) * Dot(woW, self.ng) > 0:
+                flags = flags & ~BSDF_TRANSMISSION
+            else:
+                flags = flags & ~BSDF_REFLECTION
+            for b in self.bxdfs:
+                if b.matchesFlags(flags):
+                    f = f + b.f(wo, wi)
+        return f, wiW, pdf, bxdf.type
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -580,8 +732,8 @@ def isect_Le(isect, wo):                                            # intersecti
 
 def getBSDF(isect):
     """Intersection.getBSDF -> GeometricPrimitive.getBSDF -> Triangle.getShadingGeometry (a copy without per-vertex
-    N / S, triangle.dart:273-276) -> MatteMaterial.getBSDF."""
-    return BSDF(isect.dg, isect.dg.nn, isect.prim.Kd)
+    N / S, triangle.dart:273-276) -> Material.getBSDF (matte / mirror / glass)."""
+    return BSDF(isect.dg, isect.dg.nn, isect.prim.material)
 
 
 def EstimateDirect(scene, light, p, n, wo, rayEpsilon, bsdf, lightSample, bsdfSample, flags):
@@ -694,7 +846,10 @@ def PathLi(scene, r, isect, sv, rng, maxDepth):
             break
         localIsect = scene.bvh.intersect(ray)
         if localIsect is None:
-            break                                                   # (specularBounce never holds for matte surfaces)
+            if specularBounce:                                      # path_integrator.dart:106-110
+                for light in scene.lights:
+                    L = L + pathThroughput * light.Le(ray)
+            break
         pathThroughput = pathThroughput * RGB(1.0)                  # renderer.transmittance
         isectP = localIsect
         bounces += 1

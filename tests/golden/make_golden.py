@@ -13,6 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import oracle.binding as ob  # noqa: E402
 from dartray_amd import scenes  # noqa: E402
@@ -49,6 +50,15 @@ def main():
     # (4) counter-mode image (the device sampler's mode) of the same scene
     ref = osc.render(ob.render_desc(r, sampler_mode=1))
     np.savez_compressed(os.path.join(OUT, "c2small_path_counter.npz"), rgb=ref["rgb"], film=ref["film"])
+    # (5) mirror + glass under the path integrator, serial mode (the stream tests/golden/make_restatement_fixtures.py
+    #     replays through the independent Python restatement)
+    import make_restatement_fixtures as mrf
+    prims, mk = mrf.spec_case()
+    r = mk()
+    rec = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=0), record=17 * 17 * 8, max_tail=40)
+    np.savez_compressed(os.path.join(OUT, "cspec_path_serial.npz"), rgb=rec["rgb"], film=rec["film"],
+                        pixel_xy=rec["pixel_xy"][::8].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
+                        tail_count=rec["tail_count"], Ls=rec["Ls"])
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

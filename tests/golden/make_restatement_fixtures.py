@@ -3,6 +3,7 @@ Dart text) on the recorded serial sample streams of the golden cases and commits
 
   restatement_c1.npz       C1: Cornell floor + emitter, DirectLighting, 64 x 64, 4 spp (16 900 samples)
   restatement_c2small.npz  C2-small: Cornell box + 1024-triangle blob, PathIntegrator maxdepth 5, 16 x 16, 8 spp
+  restatement_cspec.npz    Cornell box + a mirror blob + a glass blob, PathIntegrator maxdepth 5, 16 x 16, 8 spp
 
 each with per-sample Li (`Ls`), the film (X, Y, Z, weightSum) and the written image (`rgb`), plus the number of RNG
 draws each sample consumed.  Inputs: the scene as the product's host code flattens it (BVH nodes from dr_bvh_build,
@@ -53,7 +54,15 @@ def build_scene(prims_in):
         mat = acc.materials[int(acc.tri_material[i])]
         li = int(acc.tri_light[i])
         light = lights[light_of[id(acc._lights[li])]] if li >= 0 else None
-        prims.append(dr.Prim(dr.Triangle(pt(a), pt(b), pt(c), bool(acc.tri_reverse[i])), tuple(float(v) for v in mat.Kd), light))
+        t3 = lambda v: tuple(float(x) for x in v)
+        if isinstance(mat, core.MirrorMaterial):
+            material = ("mirror", t3(mat.Kr))
+        elif isinstance(mat, core.GlassMaterial):
+            material = ("glass", t3(mat.Kr), t3(mat.Kt), float(mat.index))
+        else:
+            assert isinstance(mat, core.MatteMaterial) and mat.sigma == 0.0
+            material = ("matte", t3(mat.Kd))
+        prims.append(dr.Prim(dr.Triangle(pt(a), pt(b), pt(c), bool(acc.tri_reverse[i])), material, light))
     nodes = [((float(n["bmin"][0]), float(n["bmin"][1]), float(n["bmin"][2])),
               (float(n["bmax"][0]), float(n["bmax"][1]), float(n["bmax"][2])), int(n["offset"]), int(n["nprims"]), int(n["axis"]))
              for n in acc.nodes]
@@ -99,6 +108,20 @@ def cases():
     yield "restatement_c1.npz", prims, mk(), "c1_serial.npz", "direct", [1]
     prims, mk = scenes.config("C2", xres=16, yres=16, spp=8, blob=(32, 16))
     yield "restatement_c2small.npz", prims, mk(), "c2small_path_serial.npz", "path", None
+    prims, mk = spec_case()
+    yield "restatement_cspec.npz", prims, mk(), "cspec_path_serial.npz", "path", None
+
+
+def spec_case():
+    """Cornell box + emitter + a mirror blob and a glass blob, PathIntegrator maxdepth 5,
+    16 x 16, 8 spp: specular lobes, Fresnel, the specularBounce emission rule, two-lobe component selection."""
+    _, mk = scenes.config("C2", xres=16, yres=16, spp=8, blob=(8, 4))
+    prims = scenes.cornell_walls() + [
+        scenes.emitter_quad(),
+        core.GeometricPrimitive(scenes.blob_mesh(20, 10, radius=3.2, centre=(-4.2, -6.0, 2.5)), core.MirrorMaterial((0.9, 0.85, 0.8))),
+        core.GeometricPrimitive(scenes.blob_mesh(20, 10, radius=3.0, centre=(4.0, -4.5, -2.0)), core.GlassMaterial((1.0, 1.0, 1.0), (0.95, 1.0, 0.9), 1.5)),
+    ]
+    return prims, mk
 
 
 def main():

@@ -4,7 +4,9 @@ Python, from the Dart text) against the C++ oracle and the GPU.
 The reference is Dart, cannot run here and ships no golden vectors, so nothing in this image can pin the oracle to
 the reference itself ("parity unpinned").  What these tests remove is the single-reader risk: two readings of the
 same Dart functions, in different languages and with a different structure, must agree bit for bit -- per-sample
-radiance, film, written image, the number of RNG draws per sample, and hit records on 4000 stress rays.
+radiance, film, written image, the number of RNG draws per sample, and hit records on 4000 stress rays.  Three cases:
+C1 (DirectLighting), C2-small (PathIntegrator, matte) and a mirror + glass scene (specular lobes, FresnelDielectric,
+two-lobe component selection, the specularBounce rule: SURVEY section 8 row f4).
   CPU: oracle (live, serial mode) == committed restatement fixtures; the fixtures are reproducible from the script.
   GPU: the recorded serial streams replayed through DR_SAMPLER_HOST_BUFFER == the restatement's films."""
 import os
@@ -25,7 +27,8 @@ def _cases():
     return {c[0]: c for c in mrf.cases()}
 
 
-@pytest.mark.parametrize("name,spp,record", [("restatement_c1.npz", 4, 65 * 65 * 4), ("restatement_c2small.npz", 8, 17 * 17 * 8)])
+@pytest.mark.parametrize("name,spp,record", [("restatement_c1.npz", 4, 65 * 65 * 4), ("restatement_c2small.npz", 8, 17 * 17 * 8),
+                                             ("restatement_cspec.npz", 8, 17 * 17 * 8)])
 def test_oracle_equals_the_independent_restatement(ob, name, spp, record):
     """The oracle, run live in the reference's serial mode, against what the Python restatement computed from the
     same sample vectors and RNG draws."""
@@ -70,7 +73,7 @@ def test_restated_traversal_reproduces_the_golden_hit_records():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,spp", [("restatement_c1.npz", 4), ("restatement_c2small.npz", 8)])
+@pytest.mark.parametrize("name,spp", [("restatement_c1.npz", 4), ("restatement_c2small.npz", 8), ("restatement_cspec.npz", 8)])
 def test_gpu_replay_equals_the_independent_restatement(gpu, name, spp):
     _, prims, r, golden, integ, _ = _cases()[name]
     fx = np.load(os.path.join(GOLDEN, name))
