@@ -14,6 +14,7 @@ Scope (task 5): Triangle.intersect / intersectP, BVHAccel.inter
 GeometricPrimitive.intersect, ShapeSet.sample / pdf, Shape.pdf2, DiffuseAreaLight, EstimateDirect,
 UniformSampleOneLight / AllLights, PathIntegrator.Li, DirectLightingIntegrator.Li, BSDF with Lambertian /
 SpecularReflection / SpecularTransmission lobes and FresnelDielectric (matte, mirror, glass materials),
+InfiniteAreaLight with its MIPMap (pyramid, trilinear lookup) and Distribution2D (built from the texels here),
 PerspectiveCamera.generateRayDifferential, SamplerRenderer's guards, ImageFilm.addSample / writeImage.
 Inputs it does NOT derive: the flattened BVH node array and primitive order (built by the product's dr_bvh_build) and
 the recorded sample vectors / RNG draws.
@@ -411,6 +412,59 @@ class Distribution1D:
             ptr = first
         return max(0, ptr - 1)
 
+    def sampleContinuous(self, u):
+        """montecarlo.dart:54-80 -> (x, pdf, offset)."""
+        ptr = upper_bound(self.cdf, u, self.count + 1)
+        offset = max(0, ptr - 1)
+        if offset == self.count:
+            offset = self.count - 1
+        dc = self.cdf[offset + 1] - self.cdf[offset]
+        du = 0.0
+        if dc != 0.0:
+            du = (u - self.cdf[offset]) / dc
+        pdf = self.func[offset] / self.funcInt
+        return (offset + du) / self.count, pdf, offset
+
+
+def upper_bound(lst, value, last):                                 # common.dart:304-333 (first = 0, compare = less_than)
+    if len(lst) == 0:
+        return -1
+    if len(lst) == 1:
+        return 0
+    first, count = 0, last
+    while count > 0:
+        index = first
+        step = count >> 1
+        index += step
+        if not (value < lst[index]):
+            index += 1
+            first = index
+            count -= step + 1
+        else:
+            count = step
+    return first
+
+
+class Distribution2D:                                              # montecarlo.dart:222-268
+    def __init__(self, data, nu, nv):
+        self.pConditionalV = [Distribution1D(data[v * nu:v * nu + nu]) for v in range(nv)]
+        marginalFunc = [f32(c.funcInt) for c in self.pConditionalV]
+        self.pMarginal = Distribution1D(marginalFunc)
+
+    def sampleContinuous(self, u0, u1):
+        """-> (u, v, pdf)."""
+        v, pdfs1, iv = self.pMarginal.sampleContinuous(u1)
+        u, pdfs0, _ = self.pConditionalV[iv].sampleContinuous(u0)
+        return u, v, pdfs0 * pdfs1
+
+    def pdf(self, u, v):
+        nu, nv = self.pConditionalV[0].count, self.pMarginal.count
+        iu = min(max(int(u * nu), 0), nu - 1)                      # .toInt() truncates toward zero
+        iv = min(max(int(v * nv), 0), nv - 1)
+        if self.pConditionalV[iv].funcInt * self.pMarginal.funcInt == 0.0:
+            return 0.0
+        return (self.pConditionalV[iv].func[iu] * self.pMarginal.func[iv]) / (self.pConditionalV[iv].funcInt * self.pMarginal.funcInt)
+
 
 def ConcentricSampleDisk(u1, u2):                                  # montecarlo.dart:155-201
     sx = 2 * u1 - 1
@@ -504,6 +558,125 @@ class DiffuseAreaLight:
         dist = (ps - p).length()                                   # VisibilityTester.setSegment (visibility_tester.dart:26-29)
         shadow = Ray(p, (ps - p) / dist, pEpsilon, dist * (1.0 - 1.0e-3))
         return self.L(ns, -wo), wo, pdf, shadow
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# core/mipmap.dart (power-of-two RGB image, TEXTURE_REPEAT) and lights/infinite_area_light.dart
+# ---------------------------------------------------------------------------------------------------------------
+_invLog2 = 1.0 / math.log(2.0)                                     # common.dart:98
+
+
+def Log2(x):                                                       # common.dart:101-103
+    return math.log(x) * _invLog2
+
+
+class MIPMap:
+    def __init__(self, texels, width, height):
+        """MIPMap.texture (mipmap.dart:64-160) for a power-of-two image: `texels` = height rows of width (r, g, b)."""
+        assert width & (width - 1) == 0 and height & (height - 1) == 0
+        self.width, self.height = width, height
+        self.levels = 1 + int(Log2(max(width, height)))            # .toInt()
+        self.pyramid = [(width, height, [RGB(*t) for t in texels])]
+        for i in range(1, self.levels):
+            pw, ph, _ = self.pyramid[i - 1]
+            sRes, tRes = max(1, pw // 2), max(1, ph // 2)
+            lvl = []
+            for t in range(tRes):
+                for s_ in range(sRes):
+                    lvl.append((self.texel(i - 1, 2 * s_, 2 * t) + self.texel(i - 1, 2 * s_ + 1, 2 * t) +
+                                self.texel(i - 1, 2 * s_, 2 * t + 1) + self.texel(i - 1, 2 * s_ + 1, 2 * t + 1)) * 0.25)
+            self.pyramid.append((sRes, tRes, lvl))
+
+    def texel(self, level, s_, t):                                 # mipmap.dart:184-207 (TEXTURE_REPEAT; Dart % is non-negative)
+        w, h, l = self.pyramid[level]
+        return l[(t % h) * w + (s_ % w)]
+
+    def triangle(self, level, s_, t):                              # mipmap.dart:342-355
+        level = min(max(level, 0), self.levels - 1)
+        w, h, _ = self.pyramid[level]
+        s_ = s_ * w - 0.5
+        t = t * h - 0.5
+        s0, t0 = math.floor(s_), math.floor(t)
+        ds, dt = s_ - s0, t - t0
+        return (self.texel(level, s0, t0) * ((1.0 - ds) * (1.0 - dt)) + self.texel(level, s0, t0 + 1) * ((1.0 - ds) * dt) +
+                self.texel(level, s0 + 1, t0) * (ds * (1.0 - dt)) + self.texel(level, s0 + 1, t0 + 1) * (ds * dt))
+
+    def lookup(self, s_, t, width=0.0):                            # mipmap.dart:209-224
+        level = self.levels - 1 + Log2(max(width, 1.0e-8))
+        if level < 0:
+            return self.triangle(0, s_, t)
+        elif level >= self.levels - 1:
+            return self.texel(self.levels - 1, 0, 0)
+        iLevel = math.floor(level)
+        delta = level - iLevel
+        return self.triangle(iLevel, s_, t) * (1.0 - delta) + self.triangle(iLevel + 1, s_, t) * delta
+
+
+def transformVector(m, v):                                         # transform.dart:131-145 (m: 16 f32 values, row major)
+    return Vec(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z)
+
+
+def SphericalTheta(v):                                             # vector.dart:185-187
+    return math.acos(min(max(v.z, -1.0), 1.0))
+
+
+def SphericalPhi(v):                                               # vector.dart:189-192
+    p = math.atan2(v.y, v.x)
+    return p + 2.0 * math.pi if p < 0.0 else p
+
+
+INV_TWOPI = 0.15915494309189533577                                 # common.dart:24
+
+
+class InfiniteAreaLight:
+    """infinite_area_light.dart:37-68, 262-285: the radiance map, and the Distribution2D over luminance * sin(theta)
+    of the map filtered at 1 / max(width, height)."""
+
+    def __init__(self, lightToWorld, worldToLight, L, texels, width, height):
+        self.lightToWorld, self.worldToLight = [float(x) for x in lightToWorld], [float(x) for x in worldToLight]
+        self.L = RGB(*L)
+        self.radianceMap = MIPMap(texels, width, height)
+        filt = 1.0 / max(width, height)                            # _setRadianceMap
+        img = [0.0] * (width * height)
+        for v in range(height):
+            vp = v / height
+            sinTheta = math.sin(math.pi * (v + 0.5) / height)
+            for u in range(width):
+                up = u / width
+                x = f32(self._radiance(up, vp, filt).luminance())  # img is a Float32List: two stores
+                img[u + v * width] = f32(x * sinTheta)
+        self.img = img
+        self.distribution = Distribution2D(img, width, height)
+
+    def _radiance(self, u, v, width=0.0):                          # :180-182
+        return self.radianceMap.lookup(u, v, width) * self.L
+
+    def Le(self, ray):                                             # :84-90
+        wh = Normalize(transformVector(self.worldToLight, ray.d))
+        s_ = SphericalPhi(wh) * INV_TWOPI
+        t = SphericalTheta(wh) * INV_PI
+        return self._radiance(s_, t)
+
+    def sampleLAtPoint(self, p, pEpsilon, uPos, uComponent):
+        """:92-131 -> (Ls, wi, pdf, shadow ray)."""
+        u, v, mapPdf = self.distribution.sampleContinuous(uPos[0], uPos[1])
+        if mapPdf == 0.0:
+            return RGB(0.0), Vec(), 0.0, None
+        theta, phi = v * math.pi, u * 2.0 * math.pi
+        costheta, sintheta = math.cos(theta), math.sin(theta)
+        sinphi, cosphi = math.sin(phi), math.cos(phi)
+        wi = transformVector(self.lightToWorld, Vec(sintheta * cosphi, sintheta * sinphi, costheta))
+        pdf = 0.0 if sintheta == 0.0 else mapPdf / (2.0 * math.pi * math.pi * sintheta)
+        shadow = Ray(p, wi, pEpsilon, INFINITY)                    # visibility.setRay (visibility_tester.dart:31-33)
+        return self._radiance(u, v), wi, pdf, shadow
+
+    def pdf(self, p, w):                                           # :184-200
+        wi = transformVector(self.worldToLight, w)
+        theta, phi = SphericalTheta(wi), SphericalPhi(wi)
+        sintheta = math.sin(theta)
+        if sintheta == 0.0:
+            return 0.0
+        return self.distribution.pdf(phi * INV_TWOPI, theta * INV_PI) / (2.0 * math.pi * math.pi * sintheta)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -761,7 +934,8 @@ def EstimateDirect(scene, light, p, n, wo, rayEpsilon, bsdf, lightSample, bsdfSa
         if lightIsect is not None:
             if lightIsect.prim.light is light:
                 Li = isect_Le(lightIsect, -wi)
-        # else: Li = light.Le(ray) == 0 for an area light (light.dart:70-72)
+        else:
+            Li = light.Le(ray)                                      # 0 for an area light (light.dart:70-72)
         if not Li.isBlack():
             Li = Li * RGB(1.0)                                      # renderer.transmittance
             Ld = Ld + f * Li * (AbsDot(wi, n) * weight / bsdfPdf)
@@ -935,8 +1109,8 @@ def renderer_Li(scene, integrator, maxDepth, camera, px, py, sv, draws, nSamples
             Li = DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight)
     else:
         Li = RGB(0.0)
-        for _ in scene.lights:
-            Li = Li + RGB(0.0)                                      # light.Le(ray): 0 for area lights
+        for light in scene.lights:                                  # sampler_renderer.dart:87-92
+            Li = Li + light.Le(ray)
     Ls = (RGB(1.0) * Li + RGB(0.0)) * 1.0                           # T * Li + Lvi, then * rayWeight
     if Ls.hasNaNs():
         Ls = RGB(0.0)

@@ -59,6 +59,13 @@ def main():
     np.savez_compressed(os.path.join(OUT, "cspec_path_serial.npz"), rgb=rec["rgb"], film=rec["film"],
                         pixel_xy=rec["pixel_xy"][::8].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
                         tail_count=rec["tail_count"], Ls=rec["Ls"])
+    # (6) an InfiniteAreaLight scene, serial mode (same purpose as (5))
+    prims, mk = mrf.env_case()
+    r = mk()
+    rec = ob.OracleScene(prims, env=r.env).render(ob.render_desc(r, sampler_mode=0), record=17 * 17 * 8, max_tail=40)
+    np.savez_compressed(os.path.join(OUT, "cenv_path_serial.npz"), rgb=rec["rgb"], film=rec["film"],
+                        pixel_xy=rec["pixel_xy"][::8].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
+                        tail_count=rec["tail_count"], Ls=rec["Ls"])
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -4,6 +4,7 @@ Dart text) on the recorded serial sample streams of the golden cases and commits
   restatement_c1.npz       C1: Cornell floor + emitter, DirectLighting, 64 x 64, 4 spp (16 900 samples)
   restatement_c2small.npz  C2-small: Cornell box + 1024-triangle blob, PathIntegrator maxdepth 5, 16 x 16, 8 spp
   restatement_cspec.npz    Cornell box + a mirror blob + a glass blob, PathIntegrator maxdepth 5, 16 x 16, 8 spp
+  restatement_cenv.npz     floor + matte and mirror blobs + emitter under a 32 x 16 environment map, maxdepth 4, 16 x 16, 8 spp
 
 each with per-sample Li (`Ls`), the film (X, Y, Z, weightSum) and the written image (`rgb`), plus the number of RNG
 draws each sample consumed.  Inputs: the scene as the product's host code flattens it (BVH nodes from dr_bvh_build,
@@ -29,8 +30,10 @@ from dartray_amd import core, scenes  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
-def build_scene(prims_in):
-    """The flattened scene of core.BVHAccel -> restatement objects (no oracle involved)."""
+def build_scene(prims_in, env=None):
+    """The flattened scene of core.BVHAccel -> restatement objects (no oracle involved).  `env`: a core.InfiniteAreaLight,
+    appended to the lights like scenes.make_scene does; its MIP pyramid and sampling distribution are rebuilt by the
+    restatement from the level-0 texels."""
     acc = core.BVHAccel(prims_in)
     P = acc.verts
     pt = lambda i: dr.Vec(float(P[i, 0]), float(P[i, 1]), float(P[i, 2]))
@@ -66,12 +69,16 @@ def build_scene(prims_in):
     nodes = [((float(n["bmin"][0]), float(n["bmin"][1]), float(n["bmin"][2])),
               (float(n["bmax"][0]), float(n["bmax"][1]), float(n["bmax"][2])), int(n["offset"]), int(n["nprims"]), int(n["axis"]))
              for n in acc.nodes]
+    if env is not None:
+        h, w = env.texels.shape[:2]
+        texels = [tuple(float(c) for c in env.texels[y, x]) for y in range(h) for x in range(w)]
+        lights.append(dr.InfiniteAreaLight(env.lightToWorld.reshape(-1), env.worldToLight.reshape(-1), tuple(float(c) for c in env.L), texels, w, h))
     return dr.Scene(dr.BVH(nodes, prims), lights)
 
 
 def run(name, prims_in, renderer, golden, integrator, nspl=None, limit=None):
     g = np.load(os.path.join(OUT, golden))
-    scene = build_scene(prims_in)
+    scene = build_scene(prims_in, getattr(renderer, "env", None))
     cam = dr.PerspectiveCamera(renderer.camera.rasterToCamera.reshape(-1), renderer.camera.cameraToWorld.reshape(-1))
     film_desc = renderer.camera.film
     film = dr.ImageFilm(film_desc.xResolution, film_desc.yResolution, film_desc.filter.xWidth, film_desc.filter.yWidth, film_desc.filterTable)
@@ -110,6 +117,27 @@ def cases():
     yield "restatement_c2small.npz", prims, mk(), "c2small_path_serial.npz", "path", None
     prims, mk = spec_case()
     yield "restatement_cspec.npz", prims, mk(), "cspec_path_serial.npz", "path", None
+    prims, mk = env_case()
+    yield "restatement_cenv.npz", prims, mk(), "cenv_path_serial.npz", "path", None
+
+
+def env_case():
+    """An open scene under an InfiniteAreaLight (32 x 16 procedural sky with a sun lobe) plus the quad emitter: floor, a
+    matte blob and a mirror blob, PathIntegrator maxdepth 4, 16 x 16, 8 spp: Le of
+    escaped camera and specular rays, Distribution2D sampling, Light.pdf for the BSDF-sampled direction, two lights in
+    UniformSampleOneLight."""
+    film = core.ImageFilm(16, 16, core.BoxFilter(0.5, 0.5))
+    cam = core.PerspectiveCamera.lookAt((0.0, 2.0, -35.0), (0.0, -3.0, 0.0), (0.0, 1.0, 0.0), 40.0, film)
+    env = scenes.sky_env(32, 16)
+    prims = [scenes.floor_quad(), scenes.emitter_quad(),
+             core.GeometricPrimitive(scenes.blob_mesh(16, 8, radius=3.5, centre=(-3.5, -6.0, 1.0)), core.MatteMaterial((0.6, 0.5, 0.4))),
+             core.GeometricPrimitive(scenes.blob_mesh(16, 8, radius=3.0, centre=(4.5, -6.5, -1.5)), core.MirrorMaterial((0.9, 0.9, 0.9)))]
+
+    def mk():
+        r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 8, 5489), cam, core.PathIntegrator(4), core.EmissionIntegrator())
+        r.env = env
+        return r
+    return prims, mk
 
 
 def spec_case():

@@ -6,7 +6,9 @@ the reference itself ("parity unpinned").  What these tests remove is the single
 same Dart functions, in different languages and with a different structure, must agree bit for bit -- per-sample
 radiance, film, written image, the number of RNG draws per sample, and hit records on 4000 stress rays.  Three cases:
 C1 (DirectLighting), C2-small (PathIntegrator, matte) and a mirror + glass scene (specular lobes, FresnelDielectric,
-two-lobe component selection, the specularBounce rule: SURVEY section 8 row f4).
+two-lobe component selection, the specularBounce rule: SURVEY section 8 row f4) and an open scene under an
+InfiniteAreaLight (rows a25 / f2: the MIP pyramid, its trilinear lookup and the Distribution2D are rebuilt from the
+texels by the restatement, then Le / sampleL / pdf).
   CPU: oracle (live, serial mode) == committed restatement fixtures; the fixtures are reproducible from the script.
   GPU: the recorded serial streams replayed through DR_SAMPLER_HOST_BUFFER == the restatement's films."""
 import os
@@ -28,14 +30,16 @@ def _cases():
 
 
 @pytest.mark.parametrize("name,spp,record", [("restatement_c1.npz", 4, 65 * 65 * 4), ("restatement_c2small.npz", 8, 17 * 17 * 8),
-                                             ("restatement_cspec.npz", 8, 17 * 17 * 8)])
+                                             ("restatement_cspec.npz", 8, 17 * 17 * 8), ("restatement_cenv.npz", 8, 17 * 17 * 8)])
 def test_oracle_equals_the_independent_restatement(ob, name, spp, record):
     """The oracle, run live in the reference's serial mode, against what the Python restatement computed from the
     same sample vectors and RNG draws."""
     _, prims, r, golden, integ, _ = _cases()[name]
     fx = np.load(os.path.join(GOLDEN, name))
     g = np.load(os.path.join(GOLDEN, golden))
-    rec = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=0), record=record, max_tail=40 if integ == "path" else 8)
+    env = getattr(r, "env", None)
+    osc = ob.OracleScene(prims, env=env) if env is not None else ob.OracleScene(prims)
+    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=record, max_tail=40 if integ == "path" else 8)
     assert np.array_equal(rec["sample_vec"], g["sample_vec"])          # same inputs as the fixtures were made from
     assert np.array_equal(rec["Ls"], fx["Ls"])                          # per-sample Li
     assert np.array_equal(rec["film"], fx["film"])                      # ImageFilm.addSample, in reference order
@@ -73,11 +77,11 @@ def test_restated_traversal_reproduces_the_golden_hit_records():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,spp", [("restatement_c1.npz", 4), ("restatement_c2small.npz", 8), ("restatement_cspec.npz", 8)])
+@pytest.mark.parametrize("name,spp", [("restatement_c1.npz", 4), ("restatement_c2small.npz", 8), ("restatement_cspec.npz", 8), ("restatement_cenv.npz", 8)])
 def test_gpu_replay_equals_the_independent_restatement(gpu, name, spp):
     _, prims, r, golden, integ, _ = _cases()[name]
     fx = np.load(os.path.join(GOLDEN, name))
     g = np.load(os.path.join(GOLDEN, golden))
     r.sampler = core.HostBufferSampler(r.camera, spp, g["pixel_xy"], g["sample_vec"], g["tail"] if "tail" in g.files else None)
-    out = r.render(scenes.make_scene(prims))
+    out = r.render(scenes.make_scene(prims, getattr(r, "env", None)))
     assert np.array_equal(out.film, fx["film"]) and np.array_equal(out.rgb, fx["rgb"])
