@@ -16,8 +16,10 @@ UniformSampleOneLight / AllLights, PathIntegrator.Li, DirectLightingIntegrator.L
 SpecularReflection / SpecularTransmission lobes and FresnelDielectric (matte, mirror, glass materials),
 InfiniteAreaLight with its MIPMap (pyramid, trilinear lookup) and Distribution2D (built from the texels here),
 PerspectiveCamera.generateRayDifferential, SamplerRenderer's guards, ImageFilm.addSample / writeImage.
-Inputs it does NOT derive: the flattened BVH node array and primitive order (built by the product's dr_bvh_build) and
-the recorded sample vectors / RNG draws.
+The low-discrepancy pixel sample (LDPixelSample, the scrambled (0,2) sequences, Shuffle) and the RNG are restated too:
+run with a live RNG(taskNum) the module regenerates the serial sample streams themselves.
+Inputs it does NOT derive: the flattened BVH node array and primitive order (built by the product's dr_bvh_build)
+and the pixel order of the sampler window.
 
 TEST INFRASTRUCTURE ONLY.
 """
@@ -1100,7 +1102,8 @@ def renderer_Li(scene, integrator, maxDepth, camera, px, py, sv, draws, nSamples
     imageX = px + float(sv[0])                                      # montecarlo.dart:451-452
     imageY = py + float(sv[1])
     ray = camera.generateRay(imageX, imageY)
-    rng = Draws(draws)
+    rng = draws if hasattr(draws, "randomFloat") else Draws(draws)   # a live RNG (serial mode) or the recorded draws
+    pos0 = rng.pos
     isect = scene.bvh.intersect(ray)
     if isect is not None:
         if integrator == "path":
@@ -1118,7 +1121,143 @@ def renderer_Li(scene, integrator, maxDepth, camera, px, py, sv, draws, nSamples
         Ls = RGB(0.0)
     elif math.isinf(Ls.luminance()):
         Ls = RGB(0.0)
-    return Ls, imageX, imageY, rng.pos
+    return Ls, imageX, imageY, rng.pos - pos0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# core/rng.dart over dart:math Random (the Dart VM's generator: SURVEY.md Appendix E -- the SDK is not part of the
+# reference tree), core/montecarlo.dart:294-303, 407-551: the low-discrepancy pixel sample
+# ---------------------------------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+class DartRandom:
+    """dart:math Random(seed) on the VM: a 64-bit multiply-with-carry state, A = 0xffffda61, seeded through a 64-bit mix
+    (0 -> 0x5A17) and four warm-up steps."""
+
+    def __init__(self, seed):
+        n = seed & _M64
+        n = ((~n) + (n << 21)) & _M64
+        n ^= n >> 24
+        n = (n * 265) & _M64
+        n ^= n >> 14
+        n = (n * 21) & _M64
+        n ^= n >> 28
+        n = (n + (n << 31)) & _M64
+        if n == 0:
+            n = 0x5A17
+        self.lo, self.hi = n & 0xffffffff, n >> 32
+        for _ in range(4):
+            self._nextState()
+
+    def _nextState(self):
+        st = (0xffffda61 * self.lo + self.hi) & _M64
+        self.lo, self.hi = st & 0xffffffff, st >> 32
+
+    def nextInt(self, mx):
+        if mx & (mx - 1) == 0:                                     # power of two: mask
+            self._nextState()
+            return self.lo & (mx - 1)
+        while True:
+            self._nextState()
+            rnd32 = self.lo
+            result = rnd32 % mx
+            if not (rnd32 - result + mx > (1 << 32)):
+                return result
+
+    def nextDouble(self):
+        return (self.nextInt(1 << 26) * float(1 << 27) + self.nextInt(1 << 27)) / float(1 << 53)
+
+
+class RNG:                                                         # rng.dart:27-43
+    def __init__(self, seed=5489):
+        self.random = DartRandom(seed)
+        self.pos = 0                                               # randomFloat calls so far (bookkeeping for the tests)
+
+    def randomFloat(self):
+        self.pos += 1
+        return self.random.nextDouble()
+
+    def randomUint(self):
+        return self.random.nextInt(0xffffffff)
+
+
+ONE_MINUS_EPSILON = 0.9999999403953552                             # montecarlo.dart:23
+
+
+def Sobol2(n, scramble):                                           # montecarlo.dart:486-493 (64-bit ints: no wrap at bit 31)
+    v = 1 << 31
+    while n != 0:
+        if n & 0x1 != 0:
+            scramble ^= v
+        n >>= 1
+        v ^= v >> 1
+    return min(((scramble >> 8) & 0xffffff) / (1 << 24), ONE_MINUS_EPSILON)
+
+
+def VanDerCorput(n, scramble):                                     # montecarlo.dart:495-504
+    n = (n << 16) | (n >> 16)
+    n = ((n & 0x00ff00ff) << 8) | ((n & 0xff00ff00) >> 8)
+    n = ((n & 0x0f0f0f0f) << 4) | ((n & 0xf0f0f0f0) >> 4)
+    n = ((n & 0x33333333) << 2) | ((n & 0xcccccccc) >> 2)
+    n = ((n & 0x55555555) << 1) | ((n & 0xaaaaaaaa) >> 1)
+    n ^= scramble
+    return min(((n >> 8) & 0xffffff) / (1 << 24), ONE_MINUS_EPSILON)
+
+
+def Shuffle(samples, offset, count, dims, rng):                    # montecarlo.dart:294-303
+    for i in range(count):
+        other = i + (rng.randomUint() % (count - i))
+        for j in range(dims):
+            a, b = offset + dims * i + j, offset + dims * other + j
+            samples[a], samples[b] = samples[b], samples[a]
+
+
+def LDShuffleScrambled1D(nSamples, nPixel, samples, rng):         # montecarlo.dart:523-534 (`samples`: a Float32List view)
+    scramble = rng.randomUint()
+    for i in range(nSamples * nPixel):
+        samples[i] = f32(VanDerCorput(i, scramble))
+    for i in range(nPixel):
+        Shuffle(samples, i * nSamples, nSamples, 1, rng)
+    Shuffle(samples, 0, nPixel, nSamples, rng)
+
+
+def LDShuffleScrambled2D(nSamples, nPixel, samples, rng):         # montecarlo.dart:537-548
+    scramble = [rng.randomUint(), rng.randomUint()]
+    for i in range(nSamples * nPixel):
+        samples[2 * i] = f32(VanDerCorput(i, scramble[0]))         # Sample02 (:507-511)
+        samples[2 * i + 1] = f32(Sobol2(i, scramble[1]))
+    for i in range(nPixel):
+        Shuffle(samples, 2 * i * nSamples, nSamples, 2, rng)
+    Shuffle(samples, 0, nPixel, 2 * nSamples, rng)
+
+
+def LDPixelSample(shutterOpen, shutterClose, nPixelSamples, n1D, n2D, rng):
+    """montecarlo.dart:407-472 -> nPixelSamples flat sample vectors [image x, y offsets, lens u, v, time, the 1-D slots,
+    the 2-D slots] (the pixel position is added by the caller, like samples[i].imageX = xPos + ...)."""
+    imageSamples = [0.0] * (2 * nPixelSamples)
+    lensSamples = [0.0] * (2 * nPixelSamples)
+    timeSamples = [0.0] * nPixelSamples
+    oneD = [[0.0] * (n * nPixelSamples) for n in n1D]
+    twoD = [[0.0] * (2 * n * nPixelSamples) for n in n2D]
+    LDShuffleScrambled2D(1, nPixelSamples, imageSamples, rng)
+    LDShuffleScrambled2D(1, nPixelSamples, lensSamples, rng)
+    LDShuffleScrambled1D(1, nPixelSamples, timeSamples, rng)
+    for i in range(len(n1D)):
+        LDShuffleScrambled1D(n1D[i], nPixelSamples, oneD[i], rng)
+    for i in range(len(n2D)):
+        LDShuffleScrambled2D(n2D[i], nPixelSamples, twoD[i], rng)
+    out = []
+    for i in range(nPixelSamples):
+        t = timeSamples[i]
+        v = [imageSamples[2 * i], imageSamples[2 * i + 1], lensSamples[2 * i], lensSamples[2 * i + 1],
+             shutterOpen * (1.0 - t) + shutterClose * t]            # Lerp (common.dart:80-81): v1 * (1 - t) + v2 * t
+        for j in range(len(n1D)):
+            v.extend(oneD[j][n1D[j] * i:n1D[j] * (i + 1)])
+        for j in range(len(n2D)):
+            v.extend(twoD[j][2 * n2D[j] * i:2 * n2D[j] * (i + 1)])
+        out.append(v)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------

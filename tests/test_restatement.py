@@ -56,6 +56,29 @@ def test_fixtures_are_what_the_script_computes():
         assert np.array_equal(out["Ls"], fx["Ls"][:600]) and np.array_equal(out["draws_used"], fx["draws_used"][:600])
 
 
+def test_live_restatement_regenerates_the_serial_streams():
+    """Nothing recorded: the restatement's own port of the Dart VM generator, seeded RNG(taskNum = 0) like
+    sampler_renderer.dart:137, feeds its LDPixelSample and its Li in turn (one serial stream, as the reference consumes
+    it).  The sample vectors, the per-sample radiance and the number of in-Li draws it produces must equal the golden
+    serial streams (recorded from the C++ oracle) bit for bit -- sampler (a2 / a3), RNG (a22) and integrators read twice."""
+    for name, prims, r, golden, integ, nspl in mrf.cases():
+        g = np.load(os.path.join(GOLDEN, golden))
+        sv, pix, spp = g["sample_vec"], g["pixel_xy"], r.sampler.samplesPerPixel
+        n1D, n2D = ([1] * 14, [1] * 9) if integ == "path" else ([1] * 4, [1] * 2)  # requestSamples + the volume integrator's two slots
+        scene = mrf.build_scene(prims, getattr(r, "env", None))
+        cam = dr.PerspectiveCamera(r.camera.rasterToCamera.reshape(-1), r.camera.cameraToWorld.reshape(-1))
+        rng = dr.RNG(0)
+        k = 0
+        for px, py in pix[:400 if name == "restatement_c1.npz" else len(pix)]:
+            for v in dr.LDPixelSample(0.0, 1.0, spp, n1D, n2D, rng):
+                assert np.array_equal(np.array(v, np.float32), sv[k]), (name, k)
+                L, _, _, nd = dr.renderer_Li(scene, integ, r.surfaceIntegrator.maxDepth, cam, int(px), int(py), v, rng, nspl)
+                assert np.array_equal(np.array(L.tuple(), np.float32), g["Ls"][k]), (name, k)
+                assert nd == int(g["tail_count"][k]), (name, k)
+                k += 1
+        assert k >= 1600
+
+
 def test_restated_traversal_reproduces_the_golden_hit_records():
     """BVHAccel.intersect / intersectP + Triangle.intersect / intersectP restated in Python against the golden hit
     records of tests/golden/c2small_hits.npz (4000 AggregateTestRenderer-style rays: axis-parallel directions,
