@@ -18,8 +18,9 @@ InfiniteAreaLight with its MIPMap (pyramid, trilinear lookup) and Distribution2D
 PerspectiveCamera.generateRayDifferential, SamplerRenderer's guards, ImageFilm.addSample / writeImage.
 The low-discrepancy pixel sample (LDPixelSample, the scrambled (0,2) sequences, Shuffle) and the RNG are restated too:
 run with a live RNG(taskNum) the module regenerates the serial sample streams themselves.
-Inputs it does NOT derive: the flattened BVH node array and primitive order (built by the product's dr_bvh_build)
-and the pixel order of the sampler window.
+The SAH build and the flattening of BVHAccel are restated as well (build_bvh): tests compare its node array and
+primitive order with the product's dr_bvh_build byte for byte.
+Inputs it does NOT derive: the pixel order of the sampler window.
 
 TEST INFRASTRUCTURE ONLY.
 """
@@ -1122,6 +1123,183 @@ def renderer_Li(scene, integrator, maxDepth, camera, px, py, sv, draws, nSamples
     elif math.isinf(Ls.luminance()):
         Ls = RGB(0.0)
     return Ls, imageX, imageY, rng.pos - pos0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# accelerators/bvh_accel.dart:41-91, 228-437 (the SAH build and the depth-first flattening), core/bbox.dart,
+# core/common.dart:255-297 (partition, nth_element), core/primitive.dart:71-84 (fullyRefine)
+# ---------------------------------------------------------------------------------------------------------------
+class BBox:                                                        # bbox.dart:27-60: pMin / pMax are Points (f32)
+    __slots__ = ("mn", "mx")
+
+    def __init__(self, p1=None, p2=None):
+        if p1 is None:
+            self.mn, self.mx = Vec(INFINITY, INFINITY, INFINITY), Vec(-INFINITY, -INFINITY, -INFINITY)
+        else:
+            self.mn = Vec(min(p1.x, p2.x), min(p1.y, p2.y), min(p1.z, p2.z))
+            self.mx = Vec(max(p1.x, p2.x), max(p1.y, p2.y), max(p1.z, p2.z))
+
+    @staticmethod
+    def Union(b, b2):                                              # bbox.dart:146-155, 203-205
+        r = BBox()
+        r.mn = Vec(min(b.mn.x, b2.mn.x), min(b.mn.y, b2.mn.y), min(b.mn.z, b2.mn.z))
+        r.mx = Vec(max(b.mx.x, b2.mx.x), max(b.mx.y, b2.mx.y), max(b.mx.z, b2.mx.z))
+        return r
+
+    @staticmethod
+    def UnionPoint(b, q):                                          # bbox.dart:135-144, 199-201
+        r = BBox()
+        r.mn = Vec(min(b.mn.x, q.x), min(b.mn.y, q.y), min(b.mn.z, q.z))
+        r.mx = Vec(max(b.mx.x, q.x), max(b.mx.y, q.y), max(b.mx.z, q.z))
+        return r
+
+    def center(self):                                              # bbox.dart:71
+        return (self.mn * 0.5) + (self.mx * 0.5)
+
+    def surfaceArea(self):                                         # bbox.dart:166-169
+        d = self.mx - self.mn
+        return 2.0 * (d.x * d.y + d.x * d.z + d.y * d.z)
+
+    def maximumExtent(self):                                       # bbox.dart:176-185
+        d = self.mx - self.mn
+        if d.x > d.y and d.x > d.z:
+            return 0
+        return 1 if d.y > d.z else 2
+
+
+def _axis(v, dim):
+    return (v.x, v.y, v.z)[dim]
+
+
+def partition(lst, pred, first, last):                             # common.dart:255-283
+    while first < last:
+        while pred(lst[first]):
+            first += 1
+            if first == last:
+                return first
+        while True:
+            last -= 1
+            if first == last:
+                return first
+            if pred(lst[last]):
+                break
+        lst[first], lst[last] = lst[last], lst[first]
+        first += 1
+    return first
+
+
+def nth_element(lst, first, nth, last, pred):
+    """common.dart:286-294: the whole range is SORTED with the comparator (a, b) => pred(a, b) ? -1 : 1, which never
+    answers 0.  dart:core List.sort on at most 32 elements (all this path ever passes: nPrimitives <= 4) is the SDK's
+    insertion sort -- `while (j > left && compare(a[j - 1], el) > 0)` -- so an element moves in front of its equals."""
+    l = lst[first:last]
+    assert len(l) <= 32
+    compare = lambda a, b: -1 if pred(a, b) else 1
+    for i in range(1, len(l)):
+        el = l[i]
+        j = i
+        while j > 0 and compare(l[j - 1], el) > 0:
+            l[j] = l[j - 1]
+            j -= 1
+        l[j] = el
+    lst[first:last] = l
+
+
+def build_bvh(tris, maxPrims=4):
+    """BVHAccel(p, maxPrims, SPLIT_SAH) for already refined triangles `tris` = [(p1, p2, p3), ...] (Vec, world space)
+    -> (flattened nodes [(bmin, bmax, offset, nPrimitives, axis)], the primitive order as indices into `tris`)."""
+    maxPrimsInNode = min(255, maxPrims)
+    info = []                                                      # _BVHPrimitiveInfo: (primitiveNumber, centroid, bounds)
+    for i, (a, b, c) in enumerate(tris):
+        bounds = BBox.UnionPoint(BBox(a, b), c)                    # Triangle.worldBound (triangle.dart:39-42)
+        info.append((i, bounds.center(), bounds))
+    ordered, total = [], [0]
+
+    def leaf(start, end, bbox):
+        first = len(ordered)
+        for i in range(start, end):
+            ordered.append(info[i][0])
+        return {"bounds": bbox, "first": first, "n": end - start, "children": None, "axis": 0}
+
+    def recursiveBuild(start, end):                                # :228-418
+        total[0] += 1
+        bbox = BBox()
+        for i in range(start, end):
+            bbox = BBox.Union(bbox, info[i][2])
+        nPrimitives = end - start
+        if nPrimitives == 1:
+            return leaf(start, end, bbox)
+        centroidBounds = BBox()
+        for i in range(start, end):
+            centroidBounds = BBox.UnionPoint(centroidBounds, info[i][1])
+        dim = centroidBounds.maximumExtent()
+        mid = (start + end) // 2
+        cmin, cmax = _axis(centroidBounds.mn, dim), _axis(centroidBounds.mx, dim)
+        if cmax == cmin:
+            return leaf(start, end, bbox)
+        comparePoints = lambda a, b: _axis(a[1], dim) < _axis(b[1], dim)
+        if nPrimitives <= 4:
+            mid = (start + end) // 2
+            nth_element(info, start, mid, end, comparePoints)
+        else:
+            nBuckets = 12
+            count = [0] * nBuckets
+            bb = [BBox() for _ in range(nBuckets)]
+            for i in range(start, end):
+                b = int(nBuckets * ((_axis(info[i][1], dim) - cmin) / (cmax - cmin)))
+                if b == nBuckets:
+                    b = nBuckets - 1
+                count[b] += 1
+                bb[b] = BBox.Union(bb[b], info[i][2])
+            cost = [0.0] * (nBuckets - 1)                          # a Float32List
+            for i in range(nBuckets - 1):
+                b0, b1, count0, count1 = BBox(), BBox(), 0, 0
+                for j in range(i + 1):
+                    b0 = BBox.Union(b0, bb[j])
+                    count0 += count[j]
+                for j in range(i + 1, nBuckets):
+                    b1 = BBox.Union(b1, bb[j])
+                    count1 += count[j]
+                cost[i] = f32(0.125 + (count0 * b0.surfaceArea() + count1 * b1.surfaceArea()) / bbox.surfaceArea())
+            minCost, minCostSplit = cost[0], 0
+            for i in range(1, nBuckets - 1):
+                if cost[i] < minCost:
+                    minCost, minCostSplit = cost[i], i
+            if nPrimitives > maxPrimsInNode or minCost < nPrimitives:
+                def compareToBucket(q):
+                    b = math.floor(nBuckets * ((_axis(q[1], dim) - cmin) / (cmax - cmin)))
+                    if b == nBuckets:
+                        b = nBuckets - 1
+                    return b <= minCostSplit
+                mid = partition(info, compareToBucket, start, end)
+            else:
+                return leaf(start, end, bbox)
+        c2 = recursiveBuild(mid, end)                              # the SECOND child is built first (:411-415)
+        c1 = recursiveBuild(start, mid)
+        return {"bounds": BBox.Union(c1["bounds"], c2["bounds"]), "first": 0, "n": 0, "children": (c1, c2), "axis": dim}
+
+    if not tris:
+        return [], []
+    root = recursiveBuild(0, len(tris))
+    nodes = [None] * total[0]
+    offset = [0]
+
+    def flatten(node):                                             # :420-437
+        my = offset[0]
+        offset[0] += 1
+        bmin, bmax = node["bounds"].mn, node["bounds"].mx
+        if node["n"] > 0:
+            nodes[my] = ((bmin.x, bmin.y, bmin.z), (bmax.x, bmax.y, bmax.z), node["first"], node["n"], 0)
+        else:
+            flatten(node["children"][0])
+            second = flatten(node["children"][1])
+            nodes[my] = ((bmin.x, bmin.y, bmin.z), (bmax.x, bmax.y, bmax.z), second, 0, node["axis"])
+        return my
+
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
+    flatten(root)
+    return nodes, ordered
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -79,6 +79,39 @@ def test_live_restatement_regenerates_the_serial_streams():
         assert k >= 1600
 
 
+def _refined_triangles(prims):
+    """fullyRefine (primitive.dart:71-84): a mesh's triangles come off the todo stack in reverse order."""
+    tris, vid, base = [], [], 0
+    for gp in prims:
+        mesh = gp.shape
+        for t in range(len(mesh.vertexIndex) - 1, -1, -1):
+            a, b, c = (int(v) for v in mesh.vertexIndex[t])
+            tris.append(tuple(dr.Vec(*map(float, mesh.P[i])) for i in (a, b, c)))
+            vid.append((a + base, b + base, c + base))
+        base += len(mesh.P)
+    return tris, vid
+
+
+@pytest.mark.parametrize("case", ["c1", "c2small", "cspec", "cenv", "blob6k"])
+def test_restated_sah_build_equals_the_product_builder(hip, case):
+    """BVHAccel's SAH build + flattening (bvh_accel.dart:41-91, 228-437; partition / nth_element of common.dart) restated
+    in Python against dr_bvh_build (which the oracle's serial builder equals byte for byte,
+    test_host_bvh_builder_equals_oracle): node boxes, child offsets, leaf ranges, split axes and the primitive order."""
+    if case == "blob6k":
+        prims, _ = scenes.config("C2", xres=8, yres=8, spp=1, blob=(80, 40))
+    else:
+        prims = _cases()["restatement_%s.npz" % case][1]
+    acc = core.BVHAccel(prims)
+    tris, vid = _refined_triangles(prims)
+    nodes, order = dr.build_bvh(tris, 4)
+    assert len(nodes) == len(acc.nodes)
+    for i, n in enumerate(nodes):
+        m = acc.nodes[i]
+        assert tuple(np.float32(n[0])) == tuple(m["bmin"]) and tuple(np.float32(n[1])) == tuple(m["bmax"]), i
+        assert n[2] == int(m["offset"]) and n[3] == int(m["nprims"]) and (n[3] > 0 or n[4] == int(m["axis"])), i
+    assert np.array_equal(np.array([vid[i] for i in order], np.uint32), acc.tri_idx)
+
+
 def test_restated_traversal_reproduces_the_golden_hit_records():
     """BVHAccel.intersect / intersectP + Triangle.intersect / intersectP restated in Python against the golden hit
     records of tests/golden/c2small_hits.npz (4000 AggregateTestRenderer-style rays: axis-parallel directions,
