@@ -1060,13 +1060,43 @@ def DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight):
             Lall = Lall + Ld / float(ns)
         L = L + Lall
     if ray.depth + 1 < maxDepth:
-        # SpecularReflect / SpecularTransmit (integrator.dart:187-290): each draws a BSDFSample.random(rng); a matte
-        # BSDF has no specular lobe, so both return Spectrum(0)
-        for _ in range(6):
-            rng.randomFloat()
-        L = L + RGB(0.0)
-        L = L + RGB(0.0)
+        # trace rays for specular reflection and refraction (direct_lighting_integrator.dart:59-65)
+        li = lambda rd: RendererLi(scene, "direct", maxDepth, rd, sv, rng, nSamplesPerLight)
+        L = L + SpecularBounce(ray, bsdf, rng, isect, li, BSDF_REFLECTION | BSDF_SPECULAR)
+        L = L + SpecularBounce(ray, bsdf, rng, isect, li, BSDF_TRANSMISSION | BSDF_SPECULAR)
     return L
+
+
+def SpecularBounce(ray, bsdf, rng, isect, rendererLi, flags):
+    """Integrator.SpecularReflect / SpecularTransmit (integrator.dart:187-232 / :234-290); the two differ in `flags` and in
+    the ray differentials, which nothing on this path reads (no textures).  Each draws a BSDFSample.random(rng) whether
+    or not the BSDF has such a lobe."""
+    wo = -ray.d
+    p, n = bsdf.p, bsdf.nn
+    bs = (f32(rng.randomFloat()), f32(rng.randomFloat()), rng.randomFloat())   # BSDFSample.random (bsdf_sample.dart:37-42)
+    f, wi, pdf, _ = bsdf.sample_f(wo, (bs[0], bs[1]), bs[2], flags)
+    L = RGB(0.0)
+    if pdf > 0.0 and not f.isBlack() and AbsDot(wi, n) != 0.0:
+        rd = Ray(p, wi, isect.rayEpsilon, INFINITY, ray.depth + 1)            # RayDifferential.child
+        Li = rendererLi(rd)
+        L = f * Li * (AbsDot(wi, n) / pdf)
+    return L
+
+
+def RendererLi(scene, integrator, maxDepth, ray, sv, rng, nSamplesPerLight=None):
+    """SamplerRenderer.Li (sampler_renderer.dart:67-98) without the guards of the task loop: the surface integrator at the
+    hit, or the lights' Le along an escaped ray; the volume integrator adds 0 and transmits 1."""
+    isect = scene.bvh.intersect(ray)
+    if isect is not None:
+        if integrator == "path":
+            Li = PathLi(scene, ray, isect, sv, rng, maxDepth)
+        else:
+            Li = DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight)
+    else:
+        Li = RGB(0.0)
+        for light in scene.lights:
+            Li = Li + light.Le(ray)
+    return RGB(1.0) * Li + RGB(0.0)                                 # T * Li + Lvi
 
 
 class PerspectiveCamera:
@@ -1105,17 +1135,7 @@ def renderer_Li(scene, integrator, maxDepth, camera, px, py, sv, draws, nSamples
     ray = camera.generateRay(imageX, imageY)
     rng = draws if hasattr(draws, "randomFloat") else Draws(draws)   # a live RNG (serial mode) or the recorded draws
     pos0 = rng.pos
-    isect = scene.bvh.intersect(ray)
-    if isect is not None:
-        if integrator == "path":
-            Li = PathLi(scene, ray, isect, sv, rng, maxDepth)
-        else:
-            Li = DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight)
-    else:
-        Li = RGB(0.0)
-        for light in scene.lights:                                  # sampler_renderer.dart:87-92
-            Li = Li + light.Le(ray)
-    Ls = (RGB(1.0) * Li + RGB(0.0)) * 1.0                           # T * Li + Lvi, then * rayWeight
+    Ls = RendererLi(scene, integrator, maxDepth, ray, sv, rng, nSamplesPerLight) * 1.0   # Li, then * rayWeight (:170-172)
     if Ls.hasNaNs():
         Ls = RGB(0.0)
     elif Ls.luminance() < -1e-5:

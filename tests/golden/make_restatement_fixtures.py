@@ -5,6 +5,7 @@ Dart text) on the recorded serial sample streams of the golden cases and commits
   restatement_c2small.npz  C2-small: Cornell box + 1024-triangle blob, PathIntegrator maxdepth 5, 16 x 16, 8 spp
   restatement_cspec.npz    Cornell box + a mirror blob + a glass blob, PathIntegrator maxdepth 5, 16 x 16, 8 spp
   restatement_cenv.npz     floor + matte and mirror blobs + emitter under a 32 x 16 environment map, maxdepth 4, 16 x 16, 8 spp
+  restatement_cdlspec.npz  the mirror + glass scene under DirectLighting (maxdepth 5): specular recursion, 16 x 16, 4 spp
 
 each with per-sample Li (`Ls`), the film (X, Y, Z, weightSum) and the written image (`rgb`), plus the number of RNG
 draws each sample consumed.  Inputs: the scene as the product's host code flattens it (BVH nodes from dr_bvh_build,
@@ -119,6 +120,20 @@ def cases():
     yield "restatement_cspec.npz", prims, mk(), "cspec_path_serial.npz", "path", None
     prims, mk = env_case()
     yield "restatement_cenv.npz", prims, mk(), "cenv_path_serial.npz", "path", None
+    prims, mk = dlspec_case()
+    yield "restatement_cdlspec.npz", prims, mk(), "cdlspec_direct_serial.npz", "direct", [1]
+
+
+def dlspec_case():
+    """The mirror + glass Cornell scene under the reference's DEFAULT integrator, DirectLighting (maxdepth 5): the
+    SpecularReflect / SpecularTransmit recursion through Renderer.Li (integrator.dart:187-290), 16 x 16, 4 spp."""
+    prims, _ = spec_case()
+    film = core.ImageFilm(16, 16, core.BoxFilter(0.5, 0.5))
+    cam = core.PerspectiveCamera.lookAt((0.0, 0.0, -35.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 35.0, film)
+
+    def mk():
+        return core.SamplerRenderer(core.LowDiscrepancySampler(cam, 4, 5489), cam, core.DirectLightingIntegrator(0, 5), core.EmissionIntegrator())
+    return prims, mk
 
 
 def env_case():
