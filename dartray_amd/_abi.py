@@ -92,8 +92,8 @@ class DrHit(C.Structure):
 
 class DrCamera(C.Structure):
     _fields_ = [("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
-                ("lens_radius", C.c_float), ("focal_distance", C.c_float),
-                ("shutter_open", C.c_float), ("shutter_close", C.c_float), ("type", C.c_int32), ("pad", C.c_int32)]
+                ("lens_radius", C.c_double), ("focal_distance", C.c_double),
+                ("shutter_open", C.c_double), ("shutter_close", C.c_double), ("type", C.c_int32), ("pad", C.c_int32)]
 
 
 class DrFilm(C.Structure):

@@ -23,7 +23,7 @@ struct DirectStage {
 // Per-render constants (by-value kernel argument).
 struct RenderParams {
   float r2c[16], c2w[16];
-  float lensRadius, focalDistance, shutterOpen, shutterClose;
+  double lensRadius, focalDistance, shutterOpen, shutterClose;  // Dart doubles (projective_camera.dart:31-32)
   int32_t cameraType, padCam;  // DR_CAMERA_*
   // ImageFilm window (image_film.dart:61-65)
   int32_t xres, yres, left, top, width, height;

@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256) k_raygen(RenderParams rp, BatchState st) 
     } else {
       d = vnormalize(Pcamera);
     }
-    if (rp.lensRadius > 0.0f) {
+    if (rp.lensRadius > 0.0) {
       double lu, lv;
       sv_pair(rp, st, s, 2, &sx, &sy);
       ConcentricSampleDisk((double)sx, (double)sy, &lu, &lv);

@@ -193,10 +193,10 @@ typedef struct DrHit {
 typedef struct DrCamera {
   float raster_to_camera[16]; /* row-major, Matrix4x4.data order (matrix4x4.dart:170-176) */
   float camera_to_world[16];
-  float lens_radius;
-  float focal_distance;
-  float shutter_open;
-  float shutter_close;
+  double lens_radius;    /* ProjectiveCamera.lensRadius / focalDistance and Camera.shutterOpen / shutterClose are Dart */
+  double focal_distance; /* doubles (projective_camera.dart:31-32, camera.dart): a lens radius of 0.8 is 0.8, not its */
+  double shutter_open;   /* f32 neighbour                                                                          */
+  double shutter_close;
   int32_t type; /* DR_CAMERA_* */
   int32_t pad;
 } DrCamera;
@@ -415,25 +415,26 @@ DR_ABI_SIZE(DrRay, 40);
 DR_ABI_OFFSET(DrRay, tmin, 24);
 DR_ABI_SIZE(DrHit, 32);
 DR_ABI_OFFSET(DrHit, t, 8);
-DR_ABI_SIZE(DrCamera, 152);
+DR_ABI_SIZE(DrCamera, 168);
 DR_ABI_OFFSET(DrCamera, lens_radius, 128);
-DR_ABI_OFFSET(DrCamera, type, 144);
+DR_ABI_OFFSET(DrCamera, focal_distance, 136);
+DR_ABI_OFFSET(DrCamera, type, 160);
 DR_ABI_SIZE(DrFilm, 1080);
 DR_ABI_OFFSET(DrFilm, crop, 8);
 DR_ABI_OFFSET(DrFilm, filter_xw, 40);
 DR_ABI_OFFSET(DrFilm, filter_table, 56);
-DR_ABI_SIZE(DrRenderDesc, 1328);
-DR_ABI_OFFSET(DrRenderDesc, film, 152);
-DR_ABI_OFFSET(DrRenderDesc, integrator, 1232);
-DR_ABI_OFFSET(DrRenderDesc, seed, 1248);
-DR_ABI_OFFSET(DrRenderDesc, task_num, 1256);
-DR_ABI_OFFSET(DrRenderDesc, tile_rank, 1264);
-DR_ABI_OFFSET(DrRenderDesc, nsamples, 1280);
-DR_ABI_OFFSET(DrRenderDesc, pixel_xy, 1288);
-DR_ABI_OFFSET(DrRenderDesc, sample_vec, 1296);
-DR_ABI_OFFSET(DrRenderDesc, sample_stride, 1304);
-DR_ABI_OFFSET(DrRenderDesc, tail, 1312);
-DR_ABI_OFFSET(DrRenderDesc, max_tail, 1320);
+DR_ABI_SIZE(DrRenderDesc, 1344);
+DR_ABI_OFFSET(DrRenderDesc, film, 168);
+DR_ABI_OFFSET(DrRenderDesc, integrator, 1248);
+DR_ABI_OFFSET(DrRenderDesc, seed, 1264);
+DR_ABI_OFFSET(DrRenderDesc, task_num, 1272);
+DR_ABI_OFFSET(DrRenderDesc, tile_rank, 1280);
+DR_ABI_OFFSET(DrRenderDesc, nsamples, 1296);
+DR_ABI_OFFSET(DrRenderDesc, pixel_xy, 1304);
+DR_ABI_OFFSET(DrRenderDesc, sample_vec, 1312);
+DR_ABI_OFFSET(DrRenderDesc, sample_stride, 1320);
+DR_ABI_OFFSET(DrRenderDesc, tail, 1328);
+DR_ABI_OFFSET(DrRenderDesc, max_tail, 1336);
 DR_ABI_SIZE(DrRenderStats, 200);
 DR_ABI_OFFSET(DrRenderStats, trace_ms, 72);
 DR_ABI_OFFSET(DrRenderStats, film_ms, 144);

@@ -106,14 +106,14 @@ const int OFF_DrSceneDesc_env_maps = 120;
 const int OFF_DrSceneDesc_nenv_maps = 128;
 const int OFF_DrSceneDesc_quadrics = 136;
 const int OFF_DrSceneDesc_nquadrics = 144;
-const int SIZEOF_DrCamera = 152;
+const int SIZEOF_DrCamera = 168;
 const int OFF_DrCamera_raster_to_camera = 0;
 const int OFF_DrCamera_camera_to_world = 64;
 const int OFF_DrCamera_lens_radius = 128;
-const int OFF_DrCamera_focal_distance = 132;
-const int OFF_DrCamera_shutter_open = 136;
-const int OFF_DrCamera_shutter_close = 140;
-const int OFF_DrCamera_type = 144;
+const int OFF_DrCamera_focal_distance = 136;
+const int OFF_DrCamera_shutter_open = 144;
+const int OFF_DrCamera_shutter_close = 152;
+const int OFF_DrCamera_type = 160;
 const int SIZEOF_DrFilm = 1080;
 const int OFF_DrFilm_xres = 0;
 const int OFF_DrFilm_yres = 4;
@@ -121,25 +121,25 @@ const int OFF_DrFilm_crop = 8;
 const int OFF_DrFilm_filter_xw = 40;
 const int OFF_DrFilm_filter_yw = 48;
 const int OFF_DrFilm_filter_table = 56;
-const int SIZEOF_DrRenderDesc = 1328;
+const int SIZEOF_DrRenderDesc = 1344;
 const int OFF_DrRenderDesc_camera = 0;
-const int OFF_DrRenderDesc_film = 152;
-const int OFF_DrRenderDesc_integrator = 1232;
-const int OFF_DrRenderDesc_max_depth = 1236;
-const int OFF_DrRenderDesc_spp = 1240;
-const int OFF_DrRenderDesc_sampler_mode = 1244;
-const int OFF_DrRenderDesc_seed = 1248;
-const int OFF_DrRenderDesc_task_num = 1256;
-const int OFF_DrRenderDesc_task_count = 1260;
-const int OFF_DrRenderDesc_tile_rank = 1264;
-const int OFF_DrRenderDesc_tile_count = 1268;
-const int OFF_DrRenderDesc_tile_size = 1272;
-const int OFF_DrRenderDesc_nsamples = 1280;
-const int OFF_DrRenderDesc_pixel_xy = 1288;
-const int OFF_DrRenderDesc_sample_vec = 1296;
-const int OFF_DrRenderDesc_sample_stride = 1304;
-const int OFF_DrRenderDesc_tail = 1312;
-const int OFF_DrRenderDesc_max_tail = 1320;
+const int OFF_DrRenderDesc_film = 168;
+const int OFF_DrRenderDesc_integrator = 1248;
+const int OFF_DrRenderDesc_max_depth = 1252;
+const int OFF_DrRenderDesc_spp = 1256;
+const int OFF_DrRenderDesc_sampler_mode = 1260;
+const int OFF_DrRenderDesc_seed = 1264;
+const int OFF_DrRenderDesc_task_num = 1272;
+const int OFF_DrRenderDesc_task_count = 1276;
+const int OFF_DrRenderDesc_tile_rank = 1280;
+const int OFF_DrRenderDesc_tile_count = 1284;
+const int OFF_DrRenderDesc_tile_size = 1288;
+const int OFF_DrRenderDesc_nsamples = 1296;
+const int OFF_DrRenderDesc_pixel_xy = 1304;
+const int OFF_DrRenderDesc_sample_vec = 1312;
+const int OFF_DrRenderDesc_sample_stride = 1320;
+const int OFF_DrRenderDesc_tail = 1328;
+const int OFF_DrRenderDesc_max_tail = 1336;
 
 // enums of the header
 const int DR_MATERIAL_MATTE = 0, DR_MATERIAL_MIRROR = 1, DR_MATERIAL_GLASS = 2, DR_MATERIAL_PLASTIC = 3;
@@ -493,13 +493,13 @@ class HipSamplerRenderer extends Renderer {
       blobs.add(rd);
       int cam = OFF_DrRenderDesc_camera;
       rd.f32s(cam + OFF_DrCamera_camera_to_world, camera.cameraToWorld.startTransform.m.data);
-      rd.f32(cam + OFF_DrCamera_shutter_open, camera.shutterOpen);
-      rd.f32(cam + OFF_DrCamera_shutter_close, camera.shutterClose);
+      rd.f64(cam + OFF_DrCamera_shutter_open, camera.shutterOpen);
+      rd.f64(cam + OFF_DrCamera_shutter_close, camera.shutterClose);
       if (camera is PerspectiveCamera || camera is OrthographicCamera) {
         ProjectiveCamera pc = camera;
         rd.f32s(cam + OFF_DrCamera_raster_to_camera, pc.rasterToCamera.m.data);
-        rd.f32(cam + OFF_DrCamera_lens_radius, pc.lensRadius);
-        rd.f32(cam + OFF_DrCamera_focal_distance, pc.focalDistance);
+        rd.f64(cam + OFF_DrCamera_lens_radius, pc.lensRadius);
+        rd.f64(cam + OFF_DrCamera_focal_distance, pc.focalDistance);
         rd.i32(cam + OFF_DrCamera_type, camera is PerspectiveCamera ? DR_CAMERA_PERSPECTIVE : DR_CAMERA_ORTHOGRAPHIC);
       } else if (camera is EnvironmentCamera) {
         rd.i32(cam + OFF_DrCamera_type, DR_CAMERA_ENVIRONMENT);

@@ -44,8 +44,8 @@ class OrcRenderDesc(C.Structure):
     _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_double * 4),
                 ("filter_xw", C.c_double), ("filter_yw", C.c_double), ("filter_table", C.c_float * 256),
                 ("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
-                ("lens_radius", C.c_float), ("focal_distance", C.c_float),
-                ("shutter_open", C.c_float), ("shutter_close", C.c_float), ("camera_type", C.c_int32),
+                ("lens_radius", C.c_double), ("focal_distance", C.c_double),
+                ("shutter_open", C.c_double), ("shutter_close", C.c_double), ("camera_type", C.c_int32),
                 ("integrator", C.c_int32), ("max_depth", C.c_int32), ("spp", C.c_int32), ("sampler_mode", C.c_int32),
                 ("seed", C.c_int64), ("task_num", C.c_int32), ("task_count", C.c_int32),
                 ("npixels", C.c_int32), ("pixels", C.c_void_p),

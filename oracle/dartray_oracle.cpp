@@ -2258,7 +2258,7 @@ struct OrcRenderDesc {
   double filter_xw, filter_yw;
   float filter_table[256];
   float raster_to_camera[16], camera_to_world[16];
-  float lens_radius, focal_distance, shutter_open, shutter_close;
+  double lens_radius, focal_distance, shutter_open, shutter_close;
   int32_t camera_type;  // 0 perspective, 1 orthographic, 2 environment
   int32_t integrator;  // 0 direct(all), 1 path
   int32_t max_depth;

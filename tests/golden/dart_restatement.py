@@ -1100,9 +1100,10 @@ def RendererLi(scene, integrator, maxDepth, ray, sv, rng, nSamplesPerLight=None)
 
 
 class PerspectiveCamera:
-    def __init__(self, rasterToCamera, cameraToWorld):
+    def __init__(self, rasterToCamera, cameraToWorld, lensRadius=0.0, focalDistance=1.0e30):
         self.r2c = [float(v) for v in rasterToCamera]              # Matrix4x4.data: Float32List (row major)
         self.c2w = [float(v) for v in cameraToWorld]
+        self.lensRadius, self.focalDistance = float(lensRadius), float(focalDistance)
 
     @staticmethod
     def _point(m, p):                                               # transform.dart:110-129
@@ -1118,12 +1119,20 @@ class PerspectiveCamera:
         x, y, z = p.x, p.y, p.z
         return Vec(m[0] * x + m[1] * y + m[2] * z, m[4] * x + m[5] * y + m[6] * z, m[8] * x + m[9] * y + m[10] * z)
 
-    def generateRay(self, imageX, imageY):
-        """perspective_camera.dart:93-132 without depth of field."""
+    def generateRay(self, imageX, imageY, lensU=0.0, lensV=0.0):
+        """perspective_camera.dart:93-132 (the ray differentials are not computed: nothing on the path reads them)."""
         Pras = Vec(imageX, imageY, 0.0)
         Pcamera = self._point(self.r2c, Pras)
         d = Normalize(Pcamera)
         o = Vec(0.0, 0.0, 0.0)
+        if self.lensRadius > 0.0:                                  # depth of field (:104-119)
+            lu, lv = ConcentricSampleDisk(lensU, lensV)
+            lu *= self.lensRadius
+            lv *= self.lensRadius
+            ft = self.focalDistance / d.z
+            Pfocus = Ray(o, d).pointAt(ft)
+            o = Vec(lu, lv, 0.0)
+            d = Normalize(Pfocus - o)
         return Ray(self._point(self.c2w, o), self._vector(self.c2w, d), 0.0, INFINITY, 0)
 
 
@@ -1132,7 +1141,7 @@ def renderer_Li(scene, integrator, maxDepth, camera, px, py, sv, draws, nSamples
     -> (Ls, imageX, imageY)."""
     imageX = px + float(sv[0])                                      # montecarlo.dart:451-452
     imageY = py + float(sv[1])
-    ray = camera.generateRay(imageX, imageY)
+    ray = camera.generateRay(imageX, imageY, float(sv[2]), float(sv[3]))
     rng = draws if hasattr(draws, "randomFloat") else Draws(draws)   # a live RNG (serial mode) or the recorded draws
     pos0 = rng.pos
     Ls = RendererLi(scene, integrator, maxDepth, ray, sv, rng, nSamplesPerLight) * 1.0   # Li, then * rayWeight (:170-172)

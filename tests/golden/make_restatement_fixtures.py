@@ -6,6 +6,7 @@ Dart text) on the recorded serial sample streams of the golden cases and commits
   restatement_cspec.npz    Cornell box + a mirror blob + a glass blob, PathIntegrator maxdepth 5, 16 x 16, 8 spp
   restatement_cenv.npz     floor + matte and mirror blobs + emitter under a 32 x 16 environment map, maxdepth 4, 16 x 16, 8 spp
   restatement_cdlspec.npz  the mirror + glass scene under DirectLighting (maxdepth 5): specular recursion, 16 x 16, 4 spp
+  restatement_clens.npz    C2-small through a thin-lens camera, PathIntegrator maxdepth 3, 16 x 16, 4 spp
 
 each with per-sample Li (`Ls`), the film (X, Y, Z, weightSum) and the written image (`rgb`), plus the number of RNG
 draws each sample consumed.  Inputs: the scene as the product's host code flattens it (BVH nodes from dr_bvh_build,
@@ -77,10 +78,14 @@ def build_scene(prims_in, env=None):
     return dr.Scene(dr.BVH(nodes, prims), lights)
 
 
+def restated_camera(c):
+    return dr.PerspectiveCamera(c.rasterToCamera.reshape(-1), c.cameraToWorld.reshape(-1), c.lensRadius, c.focalDistance)
+
+
 def run(name, prims_in, renderer, golden, integrator, nspl=None, limit=None):
     g = np.load(os.path.join(OUT, golden))
     scene = build_scene(prims_in, getattr(renderer, "env", None))
-    cam = dr.PerspectiveCamera(renderer.camera.rasterToCamera.reshape(-1), renderer.camera.cameraToWorld.reshape(-1))
+    cam = restated_camera(renderer.camera)
     film_desc = renderer.camera.film
     film = dr.ImageFilm(film_desc.xResolution, film_desc.yResolution, film_desc.filter.xWidth, film_desc.filter.yWidth, film_desc.filterTable)
     spp = renderer.sampler.samplesPerPixel
@@ -122,6 +127,20 @@ def cases():
     yield "restatement_cenv.npz", prims, mk(), "cenv_path_serial.npz", "path", None
     prims, mk = dlspec_case()
     yield "restatement_cdlspec.npz", prims, mk(), "cdlspec_direct_serial.npz", "direct", [1]
+    prims, mk = lens_case()
+    yield "restatement_clens.npz", prims, mk(), "clens_path_serial.npz", "path", None
+
+
+def lens_case():
+    """C2-small through a thin lens (lensradius 0.8, focaldistance 33): the depth-of-field branch of
+    PerspectiveCamera.generateRayDifferential (perspective_camera.dart:104-119), PathIntegrator maxdepth 3, 16 x 16, 4 spp."""
+    prims, _ = scenes.config("C2", xres=16, yres=16, spp=4, blob=(32, 16))
+    film = core.ImageFilm(16, 16, core.BoxFilter(0.5, 0.5))
+    cam = core.PerspectiveCamera.lookAt((0.0, 0.0, -35.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 35.0, film, lensradius=0.8, focaldistance=33.0)
+
+    def mk():
+        return core.SamplerRenderer(core.LowDiscrepancySampler(cam, 4, 5489), cam, core.PathIntegrator(3), core.EmissionIntegrator())
+    return prims, mk
 
 
 def dlspec_case():

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hip):
 
 
 def test_abi_struct_sizes_match_the_header(hip):
-    assert C.sizeof(_abi.DrBvhNode) == 32 and C.sizeof(_abi.DrRay) == 40 and C.sizeof(_abi.DrHit) == 32 and C.sizeof(_abi.DrCamera) == 152
+    assert C.sizeof(_abi.DrBvhNode) == 32 and C.sizeof(_abi.DrRay) == 40 and C.sizeof(_abi.DrHit) == 32 and C.sizeof(_abi.DrCamera) == 168
     assert C.sizeof(_abi.DrMaterial) == 56 and C.sizeof(_abi.DrQuadric) == 168 and C.sizeof(_abi.DrAreaLight) == 128 and C.sizeof(_abi.DrMeshXform) == 128 and C.sizeof(_abi.DrEnvMap) == 144 and C.sizeof(_abi.DrLightTri) == 16
     assert core.NODE_DTYPE.itemsize == 32 and core.HIT_DTYPE.itemsize == 32
 
