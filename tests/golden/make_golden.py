@@ -80,6 +80,13 @@ def main():
     np.savez_compressed(os.path.join(OUT, "clens_path_serial.npz"), rgb=rec["rgb"], film=rec["film"],
                         pixel_xy=rec["pixel_xy"][::4].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
                         tail_count=rec["tail_count"], Ls=rec["Ls"])
+    # (9) DirectLighting, two lights with several samples each, serial mode
+    prims, mk = mrf.dl2_case()
+    r = mk()
+    rec = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=0), record=17 * 17 * 4, max_tail=8)
+    np.savez_compressed(os.path.join(OUT, "cdl2_direct_serial.npz"), rgb=rec["rgb"], film=rec["film"],
+                        pixel_xy=rec["pixel_xy"][::4].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
+                        tail_count=rec["tail_count"], Ls=rec["Ls"])
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -7,6 +7,7 @@ Dart text) on the recorded serial sample streams of the golden cases and commits
   restatement_cenv.npz     floor + matte and mirror blobs + emitter under a 32 x 16 environment map, maxdepth 4, 16 x 16, 8 spp
   restatement_cdlspec.npz  the mirror + glass scene under DirectLighting (maxdepth 5): specular recursion, 16 x 16, 4 spp
   restatement_clens.npz    C2-small through a thin-lens camera, PathIntegrator maxdepth 3, 16 x 16, 4 spp
+  restatement_cdl2.npz     DirectLighting over two area lights with 2 and 4 samples per light, 16 x 16, 4 spp
 
 each with per-sample Li (`Ls`), the film (X, Y, Z, weightSum) and the written image (`rgb`), plus the number of RNG
 draws each sample consumed.  Inputs: the scene as the product's host code flattens it (BVH nodes from dr_bvh_build,
@@ -129,6 +130,23 @@ def cases():
     yield "restatement_cdlspec.npz", prims, mk(), "cdlspec_direct_serial.npz", "direct", [1]
     prims, mk = lens_case()
     yield "restatement_clens.npz", prims, mk(), "clens_path_serial.npz", "path", None
+    prims, mk = dl2_case()
+    yield "restatement_cdl2.npz", prims, mk(), "cdl2_direct_serial.npz", "direct", [2, 4]
+
+
+def dl2_case():
+    """DirectLighting over TWO area lights with nsamples 2 and 3 (rounded up to 4 by the sampler, low_discrepancy_sampler.dart
+    roundSize): UniformSampleAllLights with several samples per light, LD slots holding more than one entry per pixel
+    sample (LDShuffleScrambled1D / 2D with nSamples > 1), 16 x 16, 4 spp."""
+    e2 = scenes._quad((-9.9, -2, -2), (-9.9, 2, -2), (-9.9, 2, 2), (-9.9, -2, 2), (0.5, 0.5, 0.5), core.DiffuseAreaLight((5.0, 9.0, 3.0), 3))
+    prims = scenes.cornell_prims(scenes.blob_prim(16, 8)) + [e2]
+    next(gp for gp in prims if gp.areaLight is not None).areaLight.nSamples = 2
+    film = core.ImageFilm(16, 16, core.BoxFilter(0.5, 0.5))
+    cam = core.PerspectiveCamera.lookAt((0.0, 0.0, -35.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 35.0, film)
+
+    def mk():
+        return core.SamplerRenderer(core.LowDiscrepancySampler(cam, 4, 5489), cam, core.DirectLightingIntegrator(0, 5), core.EmissionIntegrator())
+    return prims, mk
 
 
 def lens_case():

@@ -32,7 +32,8 @@ def _cases():
 
 @pytest.mark.parametrize("name,spp,record", [("restatement_c1.npz", 4, 65 * 65 * 4), ("restatement_c2small.npz", 8, 17 * 17 * 8),
                                              ("restatement_cspec.npz", 8, 17 * 17 * 8), ("restatement_cenv.npz", 8, 17 * 17 * 8),
-                                             ("restatement_cdlspec.npz", 4, 17 * 17 * 4), ("restatement_clens.npz", 4, 17 * 17 * 4)])
+                                             ("restatement_cdlspec.npz", 4, 17 * 17 * 4), ("restatement_clens.npz", 4, 17 * 17 * 4),
+                                             ("restatement_cdl2.npz", 4, 17 * 17 * 4)])
 def test_oracle_equals_the_independent_restatement(ob, name, spp, record):
     """The oracle, run live in the reference's serial mode, against what the Python restatement computed from the
     same sample vectors and RNG draws."""
@@ -66,7 +67,11 @@ def test_live_restatement_regenerates_the_serial_streams():
     for name, prims, r, golden, integ, nspl in mrf.cases():
         g = np.load(os.path.join(GOLDEN, golden))
         sv, pix, spp = g["sample_vec"], g["pixel_xy"], r.sampler.samplesPerPixel
-        n1D, n2D = ([1] * 14, [1] * 9) if integ == "path" else ([1] * 4, [1] * 2)  # requestSamples + the volume integrator's two slots
+        if integ == "path":
+            n1D, n2D = [1] * 14, [1] * 9                       # requestSamples (path_integrator.dart:124-131) + the volume integrator's two slots
+        else:
+            n2D = [k for ns in nspl for k in (ns, ns)]          # per light: LightSampleOffsets, BSDFSampleOffsets (add1D(n) + add2D(n) each)
+            n1D = n2D + [1, 1]
         scene = mrf.build_scene(prims, getattr(r, "env", None))
         cam = mrf.restated_camera(r.camera)
         rng = dr.RNG(0)
@@ -136,7 +141,7 @@ def test_restated_traversal_reproduces_the_golden_hit_records():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,spp", [("restatement_c1.npz", 4), ("restatement_c2small.npz", 8), ("restatement_cspec.npz", 8), ("restatement_cenv.npz", 8),
-                                      ("restatement_cdlspec.npz", 4), ("restatement_clens.npz", 4)])
+                                      ("restatement_cdlspec.npz", 4), ("restatement_clens.npz", 4), ("restatement_cdl2.npz", 4)])
 def test_gpu_replay_equals_the_independent_restatement(gpu, name, spp):
     _, prims, r, golden, integ, _ = _cases()[name]
     fx = np.load(os.path.join(GOLDEN, name))
