@@ -20,7 +20,7 @@ The low-discrepancy pixel sample (LDPixelSample, the scrambled (0,2) sequences, 
 run with a live RNG(taskNum) the module regenerates the serial sample streams themselves.
 The SAH build and the flattening of BVHAccel are restated as well (build_bvh): tests compare its node array and
 primitive order with the product's dr_bvh_build byte for byte.
-Inputs it does NOT derive: the pixel order of the sampler window.
+The sampler window (getSampleExtent, GetSubWindow, _makeSampler) and the linear / tile pixel orders are restated too.
 
 TEST INFRASTRUCTURE ONLY.
 """
@@ -1464,6 +1464,66 @@ def LDPixelSample(shutterOpen, shutterClose, nPixelSamples, n1D, n2D, rng):
         for j in range(len(n2D)):
             v.extend(twoD[j][2 * n2D[j] * i:2 * n2D[j] * (i + 1)])
         out.append(v)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The sampler window and the pixel order: film/image_film.dart:247-252, core/common.dart:52-73 (GetSubWindow),
+# dartray/dartray.dart:1009-1023 (_makeSampler), pixel_samplers/linear_pixel_sampler.dart, tile_pixel_sampler.dart
+# ---------------------------------------------------------------------------------------------------------------
+def getSampleExtent(left, top, width, height, xWidth, yWidth):     # image_film.dart:247-252
+    return [math.floor(left + 0.5 - xWidth), math.ceil(left + 0.5 + width + xWidth),
+            math.floor(top + 0.5 - yWidth), math.ceil(top + 0.5 + height + yWidth)]
+
+
+def GetSubWindow(w, h, num, count):                                # common.dart:52-73
+    nx, ny = count, 1
+    while (nx & 0x1) == 0 and 2 * w * ny < h * nx:
+        nx >>= 1
+        ny <<= 1
+    xo, yo = num % nx, num // nx
+    tx0, tx1 = xo / nx, (xo + 1) / nx
+    ty0, ty1 = yo / ny, (yo + 1) / ny
+    lerp = lambda t, v1, v2: v1 * (1.0 - t) + v2 * t
+    return [math.floor(lerp(tx0, 0, w)), min(math.floor(lerp(tx1, 0, w)), w), math.floor(lerp(ty0, 0, h)), min(math.floor(lerp(ty1, 0, h)), h)]
+
+
+def sampler_window(extent, taskNum, taskCount):
+    """_makeSampler (dartray.dart:1009-1023): GetSubWindow's extents -- computed from 0, not from the sample extent's own
+    origin -- go to the sampler unchanged -> (x, y, width, height)."""
+    e = GetSubWindow(extent[1] - extent[0], extent[3] - extent[2], taskNum, taskCount)
+    return e[0], e[2], e[1] - e[0], e[3] - e[2]
+
+
+def linear_pixels(x, y, width, height):                            # linear_pixel_sampler.dart:29-40
+    return [(px, py) for py in range(y, y + height) for px in range(x, x + width)]
+
+
+def tile_pixels(x, y, width, height, tileSize=32, randomize=True):
+    """tile_pixel_sampler.dart:36-100: tiles in row-major order, shuffled from tile 1 on by the sampler's own RNG()
+    (seed 5489), pixels row by row inside a tile."""
+    left, top, right, bottom = x, y, x + width - 1, y + height - 1
+    numXTiles = width // tileSize + (0 if width % tileSize == 0 else 1)
+    numYTiles = height // tileSize + (0 if height % tileSize == 0 else 1)
+    tiles = [[xi, yi] for yi in range(numYTiles) for xi in range(numXTiles)]
+    numTiles = len(tiles)
+    if randomize:
+        rng = RNG()
+        for ti in range(1, numTiles):
+            r = rng.randomUint() % numTiles
+            tiles[ti], tiles[r] = tiles[r], tiles[ti]
+    out = []
+    for tx, ty in tiles:
+        sx, sy = left + tx * tileSize, top + ty * tileSize
+        for yi in range(tileSize):
+            py = sy + yi
+            if py > bottom:
+                break
+            for xi in range(tileSize):
+                px = sx + xi
+                if px > right:
+                    break
+                out.append((px, py))
     return out
 
 

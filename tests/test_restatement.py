@@ -86,6 +86,29 @@ def test_live_restatement_regenerates_the_serial_streams():
         assert k >= 1100
 
 
+@pytest.mark.parametrize("res,fw,tasks", [((64, 64), 0.5, 1), ((100, 70), 0.5, 4), ((33, 95), 2.0, 8), ((16, 16), 0.5, 1)])
+def test_restated_sampler_window_and_pixel_orders(hip, res, fw, tasks):
+    """getSampleExtent + GetSubWindow + _makeSampler and the linear / tile pixel samplers (the tile sampler shuffles
+    its tiles with its own RNG(5489)) restated from the Dart against the product -- the C library's enumeration of a
+    task's pixels (dr_enumerate_pixels) and the host pixel-sampler classes -- and, for the fixtures' resolution, against
+    the pixel order recorded in the golden serial streams."""
+    film = core.ImageFilm(res[0], res[1], core.BoxFilter(fw, fw))
+    cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
+    ext = dr.getSampleExtent(0, 0, res[0], res[1], fw, fw)
+    assert tuple(ext) == tuple(film.getSampleExtent())
+    for num in range(tasks):
+        x, y, w, h = dr.sampler_window(ext, num, tasks)
+        r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 4, 5489), cam, core.PathIntegrator(5), core.EmissionIntegrator(),
+                                 taskNum=num, taskCount=tasks)
+        assert np.array_equal(np.array(dr.linear_pixels(x, y, w, h), np.int32).reshape(-1, 2), r.pixels()), num   # the task's window, linear order
+        for ts in (32, 7):   # the reference's default order (what the serial replay feeds through host buffers)
+            assert np.array_equal(np.array(dr.tile_pixels(x, y, w, h, ts), np.int32).reshape(-1, 2), core.TilePixelSampler(ts).setup(x, y, w, h)), (num, ts)
+    if res == (16, 16):
+        g = np.load(os.path.join(GOLDEN, "c2small_path_serial.npz"))
+        x, y, w, h = dr.sampler_window(ext, 0, 1)
+        assert np.array_equal(np.array(dr.linear_pixels(x, y, w, h), np.int32), g["pixel_xy"])
+
+
 def _refined_triangles(prims):
     """fullyRefine (primitive.dart:71-84): a mesh's triangles come off the todo stack in reverse order."""
     tris, vid, base = [], [], 0
