@@ -16,8 +16,10 @@
 // f32), (2) hand-derivable KATs in tests/, (3) BVH == brute force self checks,
 // (4) a second restatement written independently from the Dart text in plain
 // Python (tests/golden/dart_restatement.py) that must agree with this file bit
-// for bit on per-sample Li, films and hit records (tests/test_restatement.py):
-// it removes the single-reader risk, it does not pin parity to the Dart VM.
+// for bit on per-sample Li, films, hit records, sample vectors, RNG draws, BVH
+// node arrays and pixel orders over eight scenes (matte, mirror, glass, env
+// map, thin lens, both integrators; tests/test_restatement.py): it removes the
+// single-reader risk, it does not pin parity to the Dart VM.
 //
 // Numerics contract: compile with
 //   g++ -O2 -ffp-contract=off  (no fast-math)  -- Dart never fuses mul+add.
