@@ -246,7 +246,7 @@ class InfiniteAreaLight:
     def __init__(self, light2world=None, L=(1.0, 1.0, 1.0), nSamples=1, texels=None):
         m = np.eye(4, dtype=np.float32) if light2world is None else np.asarray(light2world, np.float32).reshape(4, 4)
         self.lightToWorld = m
-        self.worldToLight = np.linalg.inv(m.astype(np.float64)).astype(np.float32)  # Transform.Inverse (light.dart:30)
+        self.worldToLight = _inv(m)  # Transform.Inverse (light.dart:30) of a Transform made from the matrix alone (transform.dart:31-35)
         self.L = np.asarray(L, dtype=np.float32).reshape(3)
         self.Lemit = self.L
         self.nSamples = max(1, int(nSamples))
@@ -763,8 +763,43 @@ def _mul(a, b):  # Matrix4x4.Mul: left-to-right f64 sums, f32 store (matrix4x4.d
     return r.astype(np.float32)
 
 
-def _inv(a):  # Matrix4x4.Inverse (matrix4x4.dart:208-343) -- host logic, evaluated in f64, stored f32
-    return np.linalg.inv(a.astype(np.float64)).astype(np.float32)
+def _inv(a):
+    """Matrix4x4.Inverse (matrix4x4.dart:212-214, 242-354): the reference's own formula -- cofactors over the determinant,
+    every element ONE f64 expression in the reference's term order, stored f32; a singular matrix comes back unchanged.
+    (A general-purpose inverse such as numpy.linalg.inv differs in the last bits and leaves 1e-17 where this leaves 0.)"""
+    d = [float(v) for v in np.asarray(a, np.float32).reshape(-1)]
+    # the reference names the elements column-wise: nRC = data[4 * (C - 1) + (R - 1)]
+    n11, n12, n13, n14 = d[0], d[4], d[8], d[12]
+    n21, n22, n23, n24 = d[1], d[5], d[9], d[13]
+    n31, n32, n33, n34 = d[2], d[6], d[10], d[14]
+    n41, n42, n43, n44 = d[3], d[7], d[11], d[15]
+    det = ((n14 * n23 * n32 * n41) - (n13 * n24 * n32 * n41) - (n14 * n22 * n33 * n41) + (n12 * n24 * n33 * n41) +
+           (n13 * n22 * n34 * n41) - (n12 * n23 * n34 * n41) - (n14 * n23 * n31 * n42) + (n13 * n24 * n31 * n42) +
+           (n14 * n21 * n33 * n42) - (n11 * n24 * n33 * n42) - (n13 * n21 * n34 * n42) + (n11 * n23 * n34 * n42) +
+           (n14 * n22 * n31 * n43) - (n12 * n24 * n31 * n43) - (n14 * n21 * n32 * n43) + (n11 * n24 * n32 * n43) +
+           (n12 * n21 * n34 * n43) - (n11 * n22 * n34 * n43) - (n13 * n22 * n31 * n44) + (n12 * n23 * n31 * n44) +
+           (n13 * n21 * n32 * n44) - (n11 * n23 * n32 * n44) - (n12 * n21 * n33 * n44) + (n11 * n22 * n33 * n44))
+    if det == 0.0:
+        return np.asarray(a, np.float32).reshape(4, 4).copy()
+    i = 1.0 / det
+    r = [0.0] * 16
+    r[0] = (n23 * n34 * n42 - n24 * n33 * n42 + n24 * n32 * n43 - n22 * n34 * n43 - n23 * n32 * n44 + n22 * n33 * n44) * i
+    r[4] = (n14 * n33 * n42 - n13 * n34 * n42 - n14 * n32 * n43 + n12 * n34 * n43 + n13 * n32 * n44 - n12 * n33 * n44) * i
+    r[8] = (n13 * n24 * n42 - n14 * n23 * n42 + n14 * n22 * n43 - n12 * n24 * n43 - n13 * n22 * n44 + n12 * n23 * n44) * i
+    r[12] = (n14 * n23 * n32 - n13 * n24 * n32 - n14 * n22 * n33 + n12 * n24 * n33 + n13 * n22 * n34 - n12 * n23 * n34) * i
+    r[1] = (n24 * n33 * n41 - n23 * n34 * n41 - n24 * n31 * n43 + n21 * n34 * n43 + n23 * n31 * n44 - n21 * n33 * n44) * i
+    r[5] = (n13 * n34 * n41 - n14 * n33 * n41 + n14 * n31 * n43 - n11 * n34 * n43 - n13 * n31 * n44 + n11 * n33 * n44) * i
+    r[9] = (n14 * n23 * n41 - n13 * n24 * n41 - n14 * n21 * n43 + n11 * n24 * n43 + n13 * n21 * n44 - n11 * n23 * n44) * i
+    r[13] = (n13 * n24 * n31 - n14 * n23 * n31 + n14 * n21 * n33 - n11 * n24 * n33 - n13 * n21 * n34 + n11 * n23 * n34) * i
+    r[2] = (n22 * n34 * n41 - n24 * n32 * n41 + n24 * n31 * n42 - n21 * n34 * n42 - n22 * n31 * n44 + n21 * n32 * n44) * i
+    r[6] = (n14 * n32 * n41 - n12 * n34 * n41 - n14 * n31 * n42 + n11 * n34 * n42 + n12 * n31 * n44 - n11 * n32 * n44) * i
+    r[10] = (n12 * n24 * n41 - n14 * n22 * n41 + n14 * n21 * n42 - n11 * n24 * n42 - n12 * n21 * n44 + n11 * n22 * n44) * i
+    r[14] = (n14 * n22 * n31 - n12 * n24 * n31 - n14 * n21 * n32 + n11 * n24 * n32 + n12 * n21 * n34 - n11 * n22 * n34) * i
+    r[3] = (n23 * n32 * n41 - n22 * n33 * n41 - n23 * n31 * n42 + n21 * n33 * n42 + n22 * n31 * n43 - n21 * n32 * n43) * i
+    r[7] = (n12 * n33 * n41 - n13 * n32 * n41 + n13 * n31 * n42 - n11 * n33 * n42 - n12 * n31 * n43 + n11 * n32 * n43) * i
+    r[11] = (n13 * n22 * n41 - n12 * n23 * n41 - n13 * n21 * n42 + n11 * n23 * n42 + n12 * n21 * n43 - n11 * n22 * n43) * i
+    r[15] = (n12 * n23 * n31 - n13 * n22 * n31 + n13 * n21 * n32 - n11 * n23 * n32 - n12 * n21 * n33 + n11 * n22 * n33) * i
+    return np.asarray(r, dtype=np.float64).astype(np.float32).reshape(4, 4)
 
 
 def _normalize(v):

@@ -58,22 +58,7 @@ def _mat(rows):
 _mul = core._mul  # Matrix4x4.Mul (matrix4x4.dart:193-206): left-to-right f64 sums, f32 store
 
 
-def _inverse(m):
-    """Matrix4x4.invert (matrix4x4.dart:262-343): adjugate / determinant in f64, stored f32; a singular
-    matrix is returned unchanged (:264-266)."""
-    a = m.astype(np.float64)
-    cof = np.empty((4, 4), dtype=np.float64)
-    for i in range(4):
-        for j in range(4):
-            minor = np.delete(np.delete(a, i, axis=0), j, axis=1)
-            d = (minor[0, 0] * (minor[1, 1] * minor[2, 2] - minor[1, 2] * minor[2, 1])
-                 - minor[0, 1] * (minor[1, 0] * minor[2, 2] - minor[1, 2] * minor[2, 0])
-                 + minor[0, 2] * (minor[1, 0] * minor[2, 1] - minor[1, 1] * minor[2, 0]))
-            cof[i, j] = -d if (i + j) & 1 else d
-    det = float(a[0] @ cof[0])
-    if det == 0.0:
-        return m.copy()
-    return (cof.T * (1.0 / det)).astype(np.float32)
+_inverse = core._inv  # Matrix4x4.invert (matrix4x4.dart:242-354): the reference's cofactor formula, f32 stores
 
 
 class Transform:

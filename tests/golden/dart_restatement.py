@@ -1099,6 +1099,115 @@ def RendererLi(scene, integrator, maxDepth, ray, sv, rng, nSamplesPerLight=None)
     return RGB(1.0) * Li + RGB(0.0)                                 # T * Li + Lvi
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# core/matrix4x4.dart, core/transform.dart, core/projective_camera.dart:34-53, cameras/perspective_camera.dart:46-57,
+# 139-182: the camera matrices
+# ---------------------------------------------------------------------------------------------------------------
+def mat_values(*v):                                                # Matrix4x4.values: sixteen stores into a Float32List
+    return [f32(x) for x in v]
+
+
+def mat_mul(m1, m2):                                               # matrix4x4.dart:197-210 (row major)
+    r = [0.0] * 16
+    for i in range(4):
+        k = 4 * i
+        for j in range(4):
+            r[k + j] = f32(m1[k] * m2[j] + m1[k + 1] * m2[4 + j] + m1[k + 2] * m2[8 + j] + m1[k + 3] * m2[12 + j])
+    return r
+
+
+def mat_inverse(m):
+    """Matrix4x4.Inverse = copy + invert (matrix4x4.dart:212-214, 242-354): cofactors over the determinant, every
+    element one f64 expression stored as f32; the names nRC read the array COLUMN-wise (n12 = data[4])."""
+    n11, n12, n13, n14 = m[0], m[4], m[8], m[12]
+    n21, n22, n23, n24 = m[1], m[5], m[9], m[13]
+    n31, n32, n33, n34 = m[2], m[6], m[10], m[14]
+    n41, n42, n43, n44 = m[3], m[7], m[11], m[15]
+    det = ((n14 * n23 * n32 * n41) - (n13 * n24 * n32 * n41) - (n14 * n22 * n33 * n41) + (n12 * n24 * n33 * n41) +
+           (n13 * n22 * n34 * n41) - (n12 * n23 * n34 * n41) - (n14 * n23 * n31 * n42) + (n13 * n24 * n31 * n42) +
+           (n14 * n21 * n33 * n42) - (n11 * n24 * n33 * n42) - (n13 * n21 * n34 * n42) + (n11 * n23 * n34 * n42) +
+           (n14 * n22 * n31 * n43) - (n12 * n24 * n31 * n43) - (n14 * n21 * n32 * n43) + (n11 * n24 * n32 * n43) +
+           (n12 * n21 * n34 * n43) - (n11 * n22 * n34 * n43) - (n13 * n22 * n31 * n44) + (n12 * n23 * n31 * n44) +
+           (n13 * n21 * n32 * n44) - (n11 * n23 * n32 * n44) - (n12 * n21 * n33 * n44) + (n11 * n22 * n33 * n44))
+    if det == 0.0:
+        return list(m)
+    invDet = 1.0 / det
+    d = [0.0] * 16
+    d[0] = (n23 * n34 * n42 - n24 * n33 * n42 + n24 * n32 * n43 - n22 * n34 * n43 - n23 * n32 * n44 + n22 * n33 * n44) * invDet
+    d[4] = (n14 * n33 * n42 - n13 * n34 * n42 - n14 * n32 * n43 + n12 * n34 * n43 + n13 * n32 * n44 - n12 * n33 * n44) * invDet
+    d[8] = (n13 * n24 * n42 - n14 * n23 * n42 + n14 * n22 * n43 - n12 * n24 * n43 - n13 * n22 * n44 + n12 * n23 * n44) * invDet
+    d[12] = (n14 * n23 * n32 - n13 * n24 * n32 - n14 * n22 * n33 + n12 * n24 * n33 + n13 * n22 * n34 - n12 * n23 * n34) * invDet
+    d[1] = (n24 * n33 * n41 - n23 * n34 * n41 - n24 * n31 * n43 + n21 * n34 * n43 + n23 * n31 * n44 - n21 * n33 * n44) * invDet
+    d[5] = (n13 * n34 * n41 - n14 * n33 * n41 + n14 * n31 * n43 - n11 * n34 * n43 - n13 * n31 * n44 + n11 * n33 * n44) * invDet
+    d[9] = (n14 * n23 * n41 - n13 * n24 * n41 - n14 * n21 * n43 + n11 * n24 * n43 + n13 * n21 * n44 - n11 * n23 * n44) * invDet
+    d[13] = (n13 * n24 * n31 - n14 * n23 * n31 + n14 * n21 * n33 - n11 * n24 * n33 - n13 * n21 * n34 + n11 * n23 * n34) * invDet
+    d[2] = (n22 * n34 * n41 - n24 * n32 * n41 + n24 * n31 * n42 - n21 * n34 * n42 - n22 * n31 * n44 + n21 * n32 * n44) * invDet
+    d[6] = (n14 * n32 * n41 - n12 * n34 * n41 - n14 * n31 * n42 + n11 * n34 * n42 + n12 * n31 * n44 - n11 * n32 * n44) * invDet
+    d[10] = (n12 * n24 * n41 - n14 * n22 * n41 + n14 * n21 * n42 - n11 * n24 * n42 - n12 * n21 * n44 + n11 * n22 * n44) * invDet
+    d[14] = (n14 * n22 * n31 - n12 * n24 * n31 - n14 * n21 * n32 + n11 * n24 * n32 + n12 * n21 * n34 - n11 * n22 * n34) * invDet
+    d[3] = (n23 * n32 * n41 - n22 * n33 * n41 - n23 * n31 * n42 + n21 * n33 * n42 + n22 * n31 * n43 - n21 * n32 * n43) * invDet
+    d[7] = (n12 * n33 * n41 - n13 * n32 * n41 + n13 * n31 * n42 - n11 * n33 * n42 - n12 * n31 * n43 + n11 * n32 * n43) * invDet
+    d[11] = (n13 * n22 * n41 - n12 * n23 * n41 - n13 * n21 * n42 + n11 * n23 * n42 + n12 * n21 * n43 - n11 * n22 * n43) * invDet
+    d[15] = (n12 * n23 * n31 - n13 * n22 * n31 + n13 * n21 * n32 - n11 * n23 * n32 - n12 * n21 * n33 + n11 * n22 * n33) * invDet
+    return [f32(x) for x in d]
+
+
+class Transform:                                                   # transform.dart:31-35: m and mInv, both copied
+    def __init__(self, m, inv=None):
+        self.m = list(m)
+        self.mInv = mat_inverse(m) if inv is None else list(inv)
+
+    def __mul__(self, t2):                                         # :83-86
+        return Transform(mat_mul(self.m, t2.m), mat_mul(t2.mInv, self.mInv))
+
+    @staticmethod
+    def Inverse(t):                                                # :58-60
+        return Transform(t.mInv, t.m)
+
+    @staticmethod
+    def Translate(delta):                                          # :214-227
+        return Transform(mat_values(1.0, 0.0, 0.0, delta.x, 0.0, 1.0, 0.0, delta.y, 0.0, 0.0, 1.0, delta.z, 0.0, 0.0, 0.0, 1.0),
+                         mat_values(1.0, 0.0, 0.0, -delta.x, 0.0, 1.0, 0.0, -delta.y, 0.0, 0.0, 1.0, -delta.z, 0.0, 0.0, 0.0, 1.0))
+
+    @staticmethod
+    def Scale(x, y, z):                                            # :229-241
+        return Transform(mat_values(x, 0.0, 0.0, 0.0, 0.0, y, 0.0, 0.0, 0.0, 0.0, z, 0.0, 0.0, 0.0, 0.0, 1.0),
+                         mat_values(1.0 / x, 0.0, 0.0, 0.0, 0.0, 1.0 / y, 0.0, 0.0, 0.0, 0.0, 1.0 / z, 0.0, 0.0, 0.0, 0.0, 1.0))
+
+    @staticmethod
+    def LookAt(pos, look, up):                                     # :305-331 -> world-to-camera; its mInv is the matrix built here
+        m = [0.0] * 16
+        m[3], m[7], m[11], m[15] = pos.x, pos.y, pos.z, 1.0
+        d = Normalize(look - pos)
+        left = Normalize(Cross(Normalize(up), d))
+        newUp = Cross(d, left)
+        m[0], m[4], m[8], m[12] = left.x, left.y, left.z, 0.0
+        m[1], m[5], m[9], m[13] = newUp.x, newUp.y, newUp.z, 0.0
+        m[2], m[6], m[10], m[14] = d.x, d.y, d.z, 0.0
+        return Transform(mat_inverse(m), m)
+
+    @staticmethod
+    def Perspective(fov, znear, zfar):                             # :338-349
+        persp = mat_values(1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, zfar / (zfar - znear), -zfar * znear / (zfar - znear), 0.0, 0.0, 1.0, 0.0)
+        invTanAng = 1.0 / math.tan(((math.pi / 180.0) * fov) / 2.0)  # Radians (common.dart:87-88)
+        return Transform.Scale(invTanAng, invTanAng, 1.0) * Transform(persp)
+
+
+def perspective_camera_matrices(pos, look, up, fov, xres, yres):
+    """LookAt + Camera "perspective" with the default screen window (perspective_camera.dart:139-182) ->
+    (rasterToCamera.m, cameraToWorld.m): projective_camera.dart:34-53."""
+    cam2world = Transform.Inverse(Transform.LookAt(Vec(*pos), Vec(*look), Vec(*up)))
+    frame = xres / yres
+    screen = [-frame, frame, -1.0, 1.0] if frame > 1.0 else [-1.0, 1.0, -1.0 / frame, 1.0 / frame]
+    cameraToScreen = Transform.Perspective(fov, 1.0e-2, 1000.0)
+    screenToRaster = (Transform.Scale(float(xres), float(yres), 1.0) *
+                      Transform.Scale(1.0 / (screen[1] - screen[0]), 1.0 / (screen[2] - screen[3]), 1.0) *
+                      Transform.Translate(Vec(-screen[0], -screen[3], 0.0)))
+    rasterToScreen = Transform.Inverse(screenToRaster)
+    rasterToCamera = Transform.Inverse(cameraToScreen) * rasterToScreen
+    return rasterToCamera.m, cam2world.m
+
+
 class PerspectiveCamera:
     def __init__(self, rasterToCamera, cameraToWorld, lensRadius=0.0, focalDistance=1.0e30):
         self.r2c = [float(v) for v in rasterToCamera]              # Matrix4x4.data: Float32List (row major)

@@ -109,6 +109,21 @@ def test_restated_sampler_window_and_pixel_orders(hip, res, fw, tasks):
         assert np.array_equal(np.array(dr.linear_pixels(x, y, w, h), np.int32), g["pixel_xy"])
 
 
+@pytest.mark.parametrize("pos,look,up,fov,res", [((0.0, 0.0, -35.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 35.0, (16, 16)),
+                                                  ((0.0, 14.0, -72.0), (0.0, 3.0, 0.0), (0.0, 1.0, 0.0), 45.0, (2048, 2048)),
+                                                  ((3.5, 2.25, -9.0), (0.5, -1.0, 4.0), (0.1, 1.0, 0.2), 63.7, (100, 70)),
+                                                  ((-1.0, 8.0, 2.0), (4.0, 0.0, 3.0), (0.0, 0.0, 1.0), 20.0, (70, 100))])
+def test_restated_camera_matrices_equal_the_product(pos, look, up, fov, res):
+    """Transform.LookAt / Perspective / Scale / Translate, Matrix4x4.Mul / Inverse (f32 storage, f64 expressions) and the
+    ProjectiveCamera constructor restated from the Dart: rasterToCamera and cameraToWorld equal the product's host
+    camera (whose matrices test_camera_matrices_match_the_oracle ties to the oracle) bit for bit."""
+    film = core.ImageFilm(res[0], res[1], core.BoxFilter(0.5, 0.5))
+    cam = core.PerspectiveCamera.lookAt(pos, look, up, fov, film)
+    r2c, c2w = dr.perspective_camera_matrices(pos, look, up, fov, res[0], res[1])
+    assert np.array_equal(np.array(r2c, np.float32), cam.rasterToCamera.reshape(-1))
+    assert np.array_equal(np.array(c2w, np.float32), cam.cameraToWorld.reshape(-1))
+
+
 def _refined_triangles(prims):
     """fullyRefine (primitive.dart:71-84): a mesh's triangles come off the todo stack in reverse order."""
     tris, vid, base = [], [], 0
