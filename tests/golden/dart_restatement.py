@@ -242,6 +242,9 @@ class Triangle:
             Ns = Vec(Ns.x * -1.0, Ns.y * -1.0, Ns.z * -1.0)
         return p, Ns
 
+    def sample2(self, p, u1, u2):                                  # shape.dart:96-98
+        return self.sample(u1, u2)
+
     def pdf2(self, p, wi):
         """core/shape.dart:100-121."""
         ray = Ray(p, wi, 1.0e-3)
@@ -259,6 +262,297 @@ class Triangle:
         if math.isinf(pdf):
             pdf = 0.0
         return pdf
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# core/shape.dart, shapes/sphere.dart, shapes/disk.dart: quadrics keep objectToWorld / worldToObject and transform the ray
+# ---------------------------------------------------------------------------------------------------------------
+def transformPoint(m, p):                                          # transform.dart:110-129 (m: 16 f32 values, row major)
+    x, y, z = p.x, p.y, p.z
+    out = Vec(m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11])
+    w = m[12] * x + m[13] * y + m[14] * z + m[15]
+    if w != 1.0:
+        out = Vec(out.x / w, out.y / w, out.z / w)                  # Point.invScale
+    return out
+
+
+def transformNormal(mInv, n):                                      # transform.dart:147-161: the transpose of the inverse
+    x, y, z = n.x, n.y, n.z
+    return Vec(mInv[0] * x + mInv[4] * y + mInv[8] * z, mInv[1] * x + mInv[5] * y + mInv[9] * z, mInv[2] * x + mInv[6] * y + mInv[10] * z)
+
+
+def clamp(x, lo, hi):                                              # dart:core num.clamp
+    return lo if x < lo else (hi if x > hi else x)
+
+
+def Radians(deg):                                                  # common.dart:87-88
+    return (math.pi / 180.0) * deg
+
+
+def Quadratic(A, B, C):                                            # common.dart:140-167 -> (t0, t1) or None
+    discrim = B * B - 4.0 * A * C
+    if discrim < 0.0:
+        return None
+    rootDiscrim = math.sqrt(discrim)
+    if B < 0.0:
+        q = -0.5 * (B - rootDiscrim)
+    else:
+        q = -0.5 * (B + rootDiscrim)
+    t0 = _div(q, A)
+    t1 = _div(C, q)
+    if t0 > t1:
+        t0, t1 = t1, t0
+    return t0, t1
+
+
+def _div(a, b):
+    """A Dart double division: x / 0 is +-infinity or NaN, never an exception."""
+    try:
+        return a / b
+    except ZeroDivisionError:
+        if a == 0.0 or a != a:
+            return float("nan")
+        return math.copysign(INFINITY, a) * math.copysign(1.0, b)
+
+
+def CoordinateSystem(v1):                                          # vector.dart:198-214 -> (v2, v3)
+    if abs(v1.x) > abs(v1.y):
+        invLen = 1.0 / math.sqrt(v1.x * v1.x + v1.z * v1.z)
+        v2 = Vec(-v1.z * invLen, 0.0, v1.x * invLen)
+    else:
+        invLen = 1.0 / math.sqrt(v1.y * v1.y + v1.z * v1.z)
+        v2 = Vec(0.0, v1.z * invLen, -v1.y * invLen)
+    return v2, Cross(v1, v2)
+
+
+def UniformSampleSphere(u1, u2):                                   # montecarlo.dart:113-120
+    z = 1.0 - 2.0 * u1
+    r = math.sqrt(max(0.0, 1.0 - z * z))
+    phi = 2.0 * math.pi * u2
+    return Vec(r * math.cos(phi), r * math.sin(phi), z)
+
+
+def UniformSampleCone2(u1, u2, costhetamax, x, y, z):              # montecarlo.dart:135-142; Lerp(t, v1, v2) = v1 * (1 - t) + v2 * t
+    costheta = costhetamax * (1.0 - u1) + 1.0 * u1
+    sintheta = math.sqrt(1.0 - costheta * costheta)
+    phi = u2 * 2.0 * math.pi
+    return x * (math.cos(phi) * sintheta) + y * (math.sin(phi) * sintheta) + z * costheta
+
+
+def UniformConePdf(cosThetaMax):                                   # montecarlo.dart:144-146
+    return _div(1.0, 2.0 * math.pi * (1.0 - cosThetaMax))
+
+
+class Shape:
+    """core/shape.dart:26-124: the transforms (as the 16 f32 values of their matrices), the orientation flag and the
+    defaults a shape inherits.  transformSwapsHandedness stays false (shape.dart:30; nothing ever assigns it)."""
+
+    def __init__(self, o2w, w2o, ro):
+        self.o2w, self.w2o, self.reverse = [float(v) for v in o2w], [float(v) for v in w2o], bool(ro)
+
+    def _objectRay(self, r):                                       # Transform.transformRay (transform.dart:180-196) by worldToObject
+        return Ray(transformPoint(self.w2o, r.o), transformVector(self.w2o, r.d), r.mint, r.maxt, r.depth)
+
+    def worldBound(self):                                          # shape.dart:37-39, Transform.transformBBox (transform.dart:163-178)
+        b = self.objectBound()
+        lo, hi = b.mn, b.mx
+        out = BBox()
+        for q in (lo, Vec(hi.x, lo.y, lo.z), Vec(lo.x, hi.y, lo.z), Vec(lo.x, lo.y, hi.z), Vec(lo.x, hi.y, hi.z), Vec(hi.x, hi.y, lo.z),
+                  Vec(hi.x, lo.y, hi.z), hi):
+            out = BBox.UnionPoint(out, transformPoint(self.o2w, q))  # setPoint, then unionPoint
+        return out
+
+    def sample2(self, p, u1, u2):                                  # shape.dart:96-98
+        return self.sample(u1, u2)
+
+    def pdf2(self, p, wi):
+        """core/shape.dart:100-121."""
+        ray = Ray(p, wi, 1.0e-3)
+        hit = self.intersect(ray)
+        if hit is None:
+            return 0.0
+        thit, _, dgLight = hit
+        dist2 = (ray.pointAt(thit) - p).lengthSquared()            # Vector.DistanceSquared(a, b) = (b - a).lengthSquared()
+        pdf = _div(dist2, AbsDot(dgLight.nn, -wi) * self.area())
+        if math.isinf(pdf):
+            pdf = 0.0
+        return pdf
+
+
+class Sphere(Shape):
+    def __init__(self, o2w, w2o, ro, radius, z0, z1, pm):          # sphere.dart:24-32 (all members are Dart doubles)
+        super().__init__(o2w, w2o, ro)
+        self.radius = radius
+        self.zmin = clamp(min(z0, z1), -radius, radius)
+        self.zmax = clamp(max(z0, z1), -radius, radius)
+        self.thetaMin = math.acos(clamp(self.zmin / radius, -1.0, 1.0))
+        self.thetaMax = math.acos(clamp(self.zmax / radius, -1.0, 1.0))
+        self.phiMax = Radians(clamp(pm, 0.0, 360.0))
+
+    def objectBound(self):                                         # sphere.dart:33-36
+        return BBox(Vec(-self.radius, -self.radius, self.zmin), Vec(self.radius, self.radius, self.zmax))
+
+    def _hit(self, r):
+        """The part intersect (sphere.dart:38-116) and intersectP (:168-241) share: the object-space ray, the accepted
+        root and its point and azimuth, or None."""
+        radius, zmin, zmax, phiMax = self.radius, self.zmin, self.zmax, self.phiMax
+        ray = self._objectRay(r)
+        d, o = ray.d, ray.o
+        A = d.x * d.x + d.y * d.y + d.z * d.z
+        B = 2 * (d.x * o.x + d.y * o.y + d.z * o.z)
+        C = o.x * o.x + o.y * o.y + o.z * o.z - radius * radius
+        roots = Quadratic(A, B, C)
+        if roots is None:
+            return None
+        t0, t1 = roots
+        if t0 > ray.maxt or t1 < ray.mint:
+            return None
+        thit = t0
+        if thit < ray.mint:
+            thit = t1
+            if thit > ray.maxt:
+                return None
+
+        def at(t):
+            phit = ray.pointAt(t)
+            if phit.x == 0.0 and phit.y == 0.0:
+                phit.x = f32(1.0e-5 * radius)
+            phi = math.atan2(phit.y, phit.x)
+            if phi < 0.0:
+                phi += 2.0 * math.pi
+            return phit, phi
+
+        def clipped(phit, phi):
+            return (zmin > -radius and phit.z < zmin) or (zmax < radius and phit.z > zmax) or phi > phiMax
+
+        phit, phi = at(thit)
+        if clipped(phit, phi):
+            if thit == t1:
+                return None
+            if t1 > ray.maxt:
+                return None
+            thit = t1
+            phit, phi = at(thit)
+            if clipped(phit, phi):
+                return None
+        return thit, phit, phi
+
+    def intersect(self, r):
+        """sphere.dart:38-166 -> (t, rayEpsilon, dg) or None.  dndu / dndv (:137-155) are left out: they only feed the
+        ray differentials and bump mapping, which are not on the path."""
+        h = self._hit(r)
+        if h is None:
+            return None
+        thit, phit, phi = h
+        radius, phiMax, thetaMin, thetaMax = self.radius, self.phiMax, self.thetaMin, self.thetaMax
+        theta = math.acos(clamp(phit.z / radius, -1.0, 1.0))
+        zradius = math.sqrt(phit.x * phit.x + phit.y * phit.y)
+        invzradius = _div(1.0, zradius)
+        cosphi = phit.x * invzradius
+        sinphi = phit.y * invzradius
+        dpdu = Vec(-phiMax * phit.y, phiMax * phit.x, 0.0)
+        dpdv = Vec(phit.z * cosphi, phit.z * sinphi, -radius * math.sin(theta)) * (thetaMax - thetaMin)
+        dg = DG().set(transformPoint(self.o2w, phit), transformVector(self.o2w, dpdu), transformVector(self.o2w, dpdv), self.reverse)
+        return thit, 5.0e-4 * thit, dg
+
+    def intersectP(self, r):                                       # sphere.dart:168-241
+        return self._hit(r) is not None
+
+    def area(self):                                                # sphere.dart:243-245
+        return self.phiMax * self.radius * (self.zmax - self.zmin)
+
+    def sample(self, u1, u2):                                      # sphere.dart:247-260 -> (point, Ns)
+        p = Vec() + UniformSampleSphere(u1, u2) * self.radius
+        ns = NormalNormalize(transformNormal(self.w2o, Vec(p.x, p.y, p.z)))   # objectToWorld.mInv == worldToObject.m
+        if self.reverse:
+            ns = Vec(-ns.x, -ns.y, -ns.z)
+        return transformPoint(self.o2w, p), ns
+
+    def sample2(self, p, u1, u2):                                  # sphere.dart:262-299
+        Pcenter = transformPoint(self.o2w, Vec())
+        wc = Normalize(Pcenter - p)
+        wcX, wcY = CoordinateSystem(wc)
+        if (Pcenter - p).lengthSquared() - self.radius * self.radius < 1.0e-4:
+            return self.sample(u1, u2)
+        sinThetaMax2 = self.radius * self.radius / (Pcenter - p).lengthSquared()
+        cosThetaMax = math.sqrt(max(0.0, 1.0 - sinThetaMax2))
+        r = Ray(p, UniformSampleCone2(u1, u2, cosThetaMax, wcX, wcY, wc), 1.0e-3)
+        hit = self.intersect(r)
+        if hit is None:
+            thit = Dot(Pcenter - p, Normalize(r.d))
+        else:
+            thit = hit[0]
+        ps = r.pointAt(thit)
+        ns = Normalize(ps - Pcenter)
+        if self.reverse:
+            ns = Vec(-ns.x, -ns.y, -ns.z)
+        return ps, ns
+
+    def pdf2(self, p, wi):                                         # sphere.dart:301-312
+        Pcenter = transformPoint(self.o2w, Vec())
+        if (Pcenter - p).lengthSquared() - self.radius * self.radius < 1.0e-4:
+            return Shape.pdf2(self, p, wi)
+        sinThetaMax2 = self.radius * self.radius / (Pcenter - p).lengthSquared()
+        cosThetaMax = math.sqrt(max(0.0, 1.0 - sinThetaMax2))
+        return UniformConePdf(cosThetaMax)
+
+
+class Disk(Shape):
+    def __init__(self, o2w, w2o, ro, height, radius, innerRadius, phiMax):   # disk.dart:24-29
+        super().__init__(o2w, w2o, ro)
+        self.height, self.radius, self.innerRadius = height, radius, innerRadius
+        self.phiMax = Radians(clamp(phiMax, 0.0, 360.0))
+
+    def objectBound(self):                                         # disk.dart:31-34
+        return BBox(Vec(-self.radius, -self.radius, self.height), Vec(self.radius, self.radius, self.height))
+
+    def _hit(self, r):
+        """Shared by intersect (disk.dart:38-68) and intersectP (:103-137)."""
+        ray = self._objectRay(r)
+        if abs(ray.d.z) < 1.0e-7:
+            return None
+        thit = (self.height - ray.o.z) / ray.d.z
+        if thit < ray.mint or thit > ray.maxt:
+            return None
+        phit = ray.pointAt(thit)
+        dist2 = phit.x * phit.x + phit.y * phit.y
+        if dist2 > self.radius * self.radius or dist2 < self.innerRadius * self.innerRadius:
+            return None
+        phi = math.atan2(phit.y, phit.x)
+        if phi < 0.0:
+            phi += 2.0 * math.pi
+        if phi > self.phiMax:
+            return None
+        return thit, phit, dist2, phi
+
+    def intersect(self, r):                                        # disk.dart:38-101
+        h = self._hit(r)
+        if h is None:
+            return None
+        thit, phit, dist2, phi = h
+        radius, innerRadius, phiMax = self.radius, self.innerRadius, self.phiMax
+        oneMinusV = (math.sqrt(dist2) - innerRadius) / (radius - innerRadius)
+        invOneMinusV = (1.0 / oneMinusV) if oneMinusV > 0.0 else 0.0
+        dpdu = Vec(-phiMax * phit.y, phiMax * phit.x, 0.0)
+        dpdv = Vec(-phit.x * invOneMinusV, -phit.y * invOneMinusV, 0.0)
+        dpdu = dpdu * (phiMax * INV_TWOPI)
+        dpdv = dpdv * ((radius - innerRadius) / radius)
+        dg = DG().set(transformPoint(self.o2w, phit), transformVector(self.o2w, dpdu), transformVector(self.o2w, dpdv), self.reverse)
+        return thit, 5.0e-4 * thit, dg
+
+    def intersectP(self, r):                                       # disk.dart:103-137
+        return self._hit(r) is not None
+
+    def area(self):                                                # disk.dart:139-142
+        return self.phiMax * 0.5 * (self.radius * self.radius - self.innerRadius * self.innerRadius)
+
+    def sample(self, u1, u2):                                      # disk.dart:144-155 -> (point, Ns)
+        dx, dy = ConcentricSampleDisk(u1, u2)
+        p = Vec(dx * self.radius, dy * self.radius, self.height)
+        ns = NormalNormalize(transformNormal(self.w2o, Vec(0.0, 0.0, 1.0)))
+        if self.reverse:
+            ns = ns * -1.0                                         # Normal.scale(-1.0)
+        return transformPoint(self.o2w, p), ns
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -519,7 +813,7 @@ class ShapeSet:
     def sample(self, uPos, uComponent, p):
         """shape_set.dart:53-80 (the overload with a reference point) -> (point, Ns)."""
         sn = self.areaDistribution.sampleDiscrete(uComponent) % len(self.shapes)
-        pt, Ns = self.shapes[sn].sample(uPos[0], uPos[1])          # Shape.sample2 defaults to sample (shape.dart:96-98)
+        pt, Ns = self.shapes[sn].sample2(p, uPos[0], uPos[1])      # Shape.sample2 defaults to sample (shape.dart:96-98)
         r = Ray(p, pt - p, 1.0e-3, INFINITY)
         thit = 1.0
         anyHit, dgn = False, None
@@ -1175,6 +1469,17 @@ class Transform:                                                   # transform.d
                          mat_values(1.0 / x, 0.0, 0.0, 0.0, 0.0, 1.0 / y, 0.0, 0.0, 0.0, 0.0, 1.0 / z, 0.0, 0.0, 0.0, 0.0, 1.0))
 
     @staticmethod
+    def Rotate(angle, axis):                                       # :276-303 (the inverse is Matrix4x4.Transpose(m))
+        a = Normalize(axis)
+        s_ = math.sin(Radians(angle))
+        c = math.cos(Radians(angle))
+        m = mat_values(a.x * a.x + (1.0 - a.x * a.x) * c, a.x * a.y * (1.0 - c) - a.z * s_, a.x * a.z * (1.0 - c) + a.y * s_, 0.0,
+                       a.x * a.y * (1.0 - c) + a.z * s_, a.y * a.y + (1.0 - a.y * a.y) * c, a.y * a.z * (1.0 - c) - a.x * s_, 0.0,
+                       a.x * a.z * (1.0 - c) - a.y * s_, a.y * a.z * (1.0 - c) + a.x * s_, a.z * a.z + (1.0 - a.z * a.z) * c, 0.0,
+                       0.0, 0.0, 0.0, 1.0)
+        return Transform(m, [m[4 * (i % 4) + i // 4] for i in range(16)])
+
+    @staticmethod
     def LookAt(pos, look, up):                                     # :305-331 -> world-to-camera; its mInv is the matrix built here
         m = [0.0] * 16
         m[3], m[7], m[11], m[15] = pos.x, pos.y, pos.z, 1.0
@@ -1344,12 +1649,16 @@ def nth_element(lst, first, nth, last, pred):
 
 
 def build_bvh(tris, maxPrims=4):
-    """BVHAccel(p, maxPrims, SPLIT_SAH) for already refined triangles `tris` = [(p1, p2, p3), ...] (Vec, world space)
+    """BVHAccel(p, maxPrims, SPLIT_SAH) for already refined primitives `tris` = [(p1, p2, p3) | BBox, ...] (Vec, world space)
     -> (flattened nodes [(bmin, bmax, offset, nPrimitives, axis)], the primitive order as indices into `tris`)."""
     maxPrimsInNode = min(255, maxPrims)
     info = []                                                      # _BVHPrimitiveInfo: (primitiveNumber, centroid, bounds)
-    for i, (a, b, c) in enumerate(tris):
-        bounds = BBox.UnionPoint(BBox(a, b), c)                    # Triangle.worldBound (triangle.dart:39-42)
+    for i, t in enumerate(tris):
+        if isinstance(t, BBox):                                    # an intersectable shape kept whole: its Shape.worldBound
+            bounds = t
+        else:
+            a, b, c = t
+            bounds = BBox.UnionPoint(BBox(a, b), c)                # Triangle.worldBound (triangle.dart:39-42)
         info.append((i, bounds.center(), bounds))
     ordered, total = [], [0]
 

@@ -87,6 +87,14 @@ def main():
     np.savez_compressed(os.path.join(OUT, "cdl2_direct_serial.npz"), rgb=rec["rgb"], film=rec["film"],
                         pixel_xy=rec["pixel_xy"][::4].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
                         tail_count=rec["tail_count"], Ls=rec["Ls"])
+    # (10) spheres and disks (BVH primitives and emitters), path and direct, serial mode
+    for direct, name, spp, mt in ((False, "cquad_path_serial.npz", 8, 40), (True, "cquaddl_direct_serial.npz", 4, 200)):
+        prims, mk = mrf.quad_case(direct=direct)
+        r = mk()
+        rec = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=0), record=17 * 17 * spp, max_tail=mt)
+        np.savez_compressed(os.path.join(OUT, name), rgb=rec["rgb"], film=rec["film"],
+                            pixel_xy=rec["pixel_xy"][::spp].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
+                            tail_count=rec["tail_count"], Ls=rec["Ls"])
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -8,6 +8,8 @@ Dart text) on the recorded serial sample streams of the golden cases and commits
   restatement_cdlspec.npz  the mirror + glass scene under DirectLighting (maxdepth 5): specular recursion, 16 x 16, 4 spp
   restatement_clens.npz    C2-small through a thin-lens camera, PathIntegrator maxdepth 3, 16 x 16, 4 spp
   restatement_cdl2.npz     DirectLighting over two area lights with 2 and 4 samples per light, 16 x 16, 4 spp
+  restatement_cquad.npz    spheres and disks (matte / mirror / glass; a disk and a sphere emitter), PathIntegrator maxdepth 5, 16 x 16, 8 spp
+  restatement_cquaddl.npz  the same scene under DirectLighting (maxdepth 5), 16 x 16, 4 spp
 
 each with per-sample Li (`Ls`), the film (X, Y, Z, weightSum) and the written image (`rgb`), plus the number of RNG
 draws each sample consumed.  Inputs: the scene as the product's host code flattens it (BVH nodes from dr_bvh_build,
@@ -28,7 +30,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import dart_restatement as dr  # noqa: E402
-from dartray_amd import core, scenes  # noqa: E402
+from dartray_amd import _abi, core, pbrt, scenes  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -44,8 +46,22 @@ def build_scene(prims_in, env=None):
     # (shape_set.dart:25-35, triangle_mesh.dart:83-89)
     lights, light_of = [], {}
     base = 0
+    quadric = {}
+
+    def restated_quadric(q):
+        """core.Sphere / core.Disk keep the constructor arguments (`params`, Dart doubles) and the two matrices."""
+        if id(q) not in quadric:
+            cls = dr.Sphere if isinstance(q, core.Sphere) else dr.Disk
+            quadric[id(q)] = cls(q.objectToWorld.reshape(-1), q.worldToObject.reshape(-1), q.reverseOrientation, *q.params)
+        return quadric[id(q)]
+
     for gp in prims_in:
         mesh = gp.shape
+        if isinstance(mesh, (core.Sphere, core.Disk)):
+            if gp.areaLight is not None:                            # ShapeSet keeps an intersectable shape whole (shape_set.dart:25-35)
+                light_of[id(gp.areaLight)] = len(lights)
+                lights.append(dr.DiffuseAreaLight(tuple(float(v) for v in gp.areaLight.Lemit), [restated_quadric(mesh)]))
+            continue
         if gp.areaLight is not None:
             tris = []
             for t in range(len(mesh.vertexIndex) - 1, -1, -1):
@@ -68,6 +84,9 @@ def build_scene(prims_in, env=None):
         else:
             assert isinstance(mat, core.MatteMaterial) and mat.sigma == 0.0
             material = ("matte", t3(mat.Kd))
+        if a == _abi.DR_PRIM_QUADRIC:
+            prims.append(dr.Prim(restated_quadric(acc.quadrics[b]), material, light))
+            continue
         prims.append(dr.Prim(dr.Triangle(pt(a), pt(b), pt(c), bool(acc.tri_reverse[i])), material, light))
     nodes = [((float(n["bmin"][0]), float(n["bmin"][1]), float(n["bmin"][2])),
               (float(n["bmax"][0]), float(n["bmax"][1]), float(n["bmax"][2])), int(n["offset"]), int(n["nprims"]), int(n["axis"]))
@@ -132,6 +151,39 @@ def cases():
     yield "restatement_clens.npz", prims, mk(), "clens_path_serial.npz", "path", None
     prims, mk = dl2_case()
     yield "restatement_cdl2.npz", prims, mk(), "cdl2_direct_serial.npz", "direct", [2, 4]
+    prims, mk = quad_case()
+    yield "restatement_cquad.npz", prims, mk(), "cquad_path_serial.npz", "path", None
+    prims, mk = quad_case(direct=True)
+    yield "restatement_cquaddl.npz", prims, mk(), "cquaddl_direct_serial.npz", "direct", [1, 1]
+
+
+def quad_case(direct=False):
+    """Cornell walls lit by a DISK emitter under the ceiling and a small SPHERE emitter, with a matte sphere, a mirror
+    sphere clipped in z and phi (the second-root and clipping branches of Sphere.intersect), a glass sphere and an annular
+    matte disk: quadrics as BVH primitives, Disk.sample / Shape.pdf2, Sphere.sample2 / pdf2
+    (cone sampling), 16 x 16; PathIntegrator maxdepth 5 at 8 spp, or DirectLighting (maxdepth 5) at 4 spp."""
+    T = pbrt.Transform
+    at = lambda x, y, z: T.Translate(x, y, z)
+    down = at(0.0, 9.9, 0.0) * T.Rotate(90.0, 1.0, 0.0, 0.0)        # object +z -> world -y
+    tilt = at(4.5, -5.5, -3.0) * T.Rotate(-60.0, 1.0, 0.0, 0.0) * T.Rotate(30.0, 0.0, 0.0, 1.0)
+    ring = at(-5.0, -9.0, -4.0) * T.Rotate(-90.0, 1.0, 0.0, 0.0)
+    gp = core.GeometricPrimitive
+    prims = scenes.cornell_walls() + [
+        gp(core.Disk(down.m, down.mInv, False, 0.0, 3.0), core.MatteMaterial((0.5, 0.5, 0.5)), core.DiffuseAreaLight((30.0, 30.0, 30.0), 1)),
+        gp(core.Sphere(at(6.0, 4.0, 3.0).m, at(6.0, 4.0, 3.0).mInv, False, 0.8), core.MatteMaterial((0.5, 0.5, 0.5)), core.DiffuseAreaLight((12.0, 20.0, 40.0), 1)),
+        gp(core.Sphere(at(-4.5, -6.5, 2.5).m, at(-4.5, -6.5, 2.5).mInv, False, 3.3), core.MatteMaterial((0.7, 0.6, 0.3))),
+        gp(core.Sphere(tilt.m, tilt.mInv, False, 3.0, -1.2, 2.4, 250.0), core.MirrorMaterial((0.9, 0.9, 0.85))),
+        gp(core.Sphere(at(0.5, -2.0, -5.0).m, at(0.5, -2.0, -5.0).mInv, True, 2.2), core.GlassMaterial((1.0, 1.0, 1.0), (0.95, 1.0, 0.9), 1.5)),
+        gp(core.Disk(ring.m, ring.mInv, False, 0.5, 3.0, 1.0, 300.0), core.MatteMaterial((0.3, 0.6, 0.7))),
+    ]
+    film = core.ImageFilm(16, 16, core.BoxFilter(0.5, 0.5))
+    cam = core.PerspectiveCamera.lookAt((0.0, 0.0, -35.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 35.0, film)
+
+    def mk():
+        if direct:
+            return core.SamplerRenderer(core.LowDiscrepancySampler(cam, 4, 5489), cam, core.DirectLightingIntegrator(0, 5), core.EmissionIntegrator())
+        return core.SamplerRenderer(core.LowDiscrepancySampler(cam, 8, 5489), cam, core.PathIntegrator(5), core.EmissionIntegrator())
+    return prims, mk
 
 
 def dl2_case():

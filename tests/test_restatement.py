@@ -4,12 +4,14 @@ Python, from the Dart text) against the C++ oracle and the GPU.
 The reference is Dart, cannot run here and ships no golden vectors, so nothing in this image can pin the oracle to
 the reference itself ("parity unpinned").  What these tests remove is the single-reader risk: two readings of the
 same Dart functions, in different languages and with a different structure, must agree bit for bit -- per-sample
-radiance, film, written image, the number of RNG draws per sample, and hit records on 4000 stress rays.  Three cases:
+radiance, film, written image, the number of RNG draws per sample, and hit records on 4000 stress rays.  The cases:
 C1 (DirectLighting), C2-small (PathIntegrator, matte) and a mirror + glass scene (specular lobes, FresnelDielectric,
 two-lobe component selection, the specularBounce rule: SURVEY section 8 row f4) and an open scene under an
 InfiniteAreaLight (rows a25 / f2: the MIP pyramid, its trilinear lookup and the Distribution2D are rebuilt from the
 texels by the restatement, then Le / sampleL / pdf); and the mirror + glass scene under the reference's default
-integrator, DirectLighting, whose SpecularReflect / SpecularTransmit recurse through Renderer.Li.
+integrator, DirectLighting, whose SpecularReflect / SpecularTransmit recurse through Renderer.Li; a thin-lens camera;
+DirectLighting with several samples per light; and a box of spheres and disks (Shape / Sphere / Disk / Quadratic and the
+Transform methods they use, as BVH primitives and as emitters) under both integrators.
   CPU: oracle (live, serial mode) == committed restatement fixtures; the fixtures are reproducible from the script.
   GPU: the recorded serial streams replayed through DR_SAMPLER_HOST_BUFFER == the restatement's films."""
 import os
@@ -19,7 +21,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from dartray_amd import core, scenes
+from dartray_amd import _abi, core, pbrt, scenes
 
 sys.path.insert(0, GOLDEN)
 import dart_restatement as dr  # noqa: E402
@@ -33,7 +35,8 @@ def _cases():
 @pytest.mark.parametrize("name,spp,record", [("restatement_c1.npz", 4, 65 * 65 * 4), ("restatement_c2small.npz", 8, 17 * 17 * 8),
                                              ("restatement_cspec.npz", 8, 17 * 17 * 8), ("restatement_cenv.npz", 8, 17 * 17 * 8),
                                              ("restatement_cdlspec.npz", 4, 17 * 17 * 4), ("restatement_clens.npz", 4, 17 * 17 * 4),
-                                             ("restatement_cdl2.npz", 4, 17 * 17 * 4)])
+                                             ("restatement_cdl2.npz", 4, 17 * 17 * 4), ("restatement_cquad.npz", 8, 17 * 17 * 8),
+                                             ("restatement_cquaddl.npz", 4, 17 * 17 * 4)])
 def test_oracle_equals_the_independent_restatement(ob, name, spp, record):
     """The oracle, run live in the reference's serial mode, against what the Python restatement computed from the
     same sample vectors and RNG draws."""
@@ -42,7 +45,7 @@ def test_oracle_equals_the_independent_restatement(ob, name, spp, record):
     g = np.load(os.path.join(GOLDEN, golden))
     env = getattr(r, "env", None)
     osc = ob.OracleScene(prims, env=env) if env is not None else ob.OracleScene(prims)
-    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=record, max_tail=40 if integ == "path" else (200 if "dlspec" in name else 8))
+    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=record, max_tail=40 if integ == "path" else (200 if ("dlspec" in name or "quaddl" in name) else 8))
     assert np.array_equal(rec["sample_vec"], g["sample_vec"])          # same inputs as the fixtures were made from
     assert np.array_equal(rec["Ls"], fx["Ls"])                          # per-sample Li
     assert np.array_equal(rec["film"], fx["film"])                      # ImageFilm.addSample, in reference order
@@ -124,11 +127,28 @@ def test_restated_camera_matrices_equal_the_product(pos, look, up, fov, res):
     assert np.array_equal(np.array(c2w, np.float32), cam.cameraToWorld.reshape(-1))
 
 
+@pytest.mark.parametrize("angle,axis", [(90.0, (1.0, 0.0, 0.0)), (-60.0, (1.0, 0.0, 0.0)), (30.0, (0.0, 0.0, 1.0)), (137.5, (0.3, -2.0, 0.7))])
+def test_restated_rotate_and_transform_products(angle, axis):
+    """Transform.Rotate (transform.dart:276-303: f32 normalised axis, inverse = transpose) and products with Translate,
+    as the quadric cases place their shapes, against the scene-file front end's Transform (bit for bit, m and mInv)."""
+    a = dr.Transform.Translate(dr.Vec(4.5, -5.5, -3.0)) * dr.Transform.Rotate(angle, dr.Vec(*axis)) * dr.Transform.Rotate(30.0, dr.Vec(0.0, 0.0, 1.0))
+    b = pbrt.Transform.Translate(4.5, -5.5, -3.0) * pbrt.Transform.Rotate(angle, *axis) * pbrt.Transform.Rotate(30.0, 0.0, 0.0, 1.0)
+    assert np.array_equal(np.array(a.m, np.float32), np.asarray(b.m, np.float32).reshape(-1))
+    assert np.array_equal(np.array(a.mInv, np.float32), np.asarray(b.mInv, np.float32).reshape(-1))
+
+
 def _refined_triangles(prims):
     """fullyRefine (primitive.dart:71-84): a mesh's triangles come off the todo stack in reverse order."""
-    tris, vid, base = [], [], 0
+    tris, vid, base, nq = [], [], 0, 0
     for gp in prims:
         mesh = gp.shape
+        if isinstance(mesh, (core.Sphere, core.Disk)):   # canIntersect: kept whole, bounded by Shape.worldBound
+            cls = dr.Sphere if isinstance(mesh, core.Sphere) else dr.Disk
+            q = cls(mesh.objectToWorld.reshape(-1), mesh.worldToObject.reshape(-1), mesh.reverseOrientation, *mesh.params)
+            tris.append(q.worldBound())
+            vid.append((_abi.DR_PRIM_QUADRIC, nq, 0))
+            nq += 1
+            continue
         for t in range(len(mesh.vertexIndex) - 1, -1, -1):
             a, b, c = (int(v) for v in mesh.vertexIndex[t])
             tris.append(tuple(dr.Vec(*map(float, mesh.P[i])) for i in (a, b, c)))
@@ -137,7 +157,7 @@ def _refined_triangles(prims):
     return tris, vid
 
 
-@pytest.mark.parametrize("case", ["c1", "c2small", "cspec", "cenv", "blob6k"])  # (cdlspec is cspec's scene)
+@pytest.mark.parametrize("case", ["c1", "c2small", "cspec", "cenv", "cquad", "blob6k"])  # (cdlspec is cspec's scene)
 def test_restated_sah_build_equals_the_product_builder(hip, case):
     """BVHAccel's SAH build + flattening (bvh_accel.dart:41-91, 228-437; partition / nth_element of common.dart) restated
     in Python against dr_bvh_build (which the oracle's serial builder equals byte for byte,
@@ -179,7 +199,8 @@ def test_restated_traversal_reproduces_the_golden_hit_records():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,spp", [("restatement_c1.npz", 4), ("restatement_c2small.npz", 8), ("restatement_cspec.npz", 8), ("restatement_cenv.npz", 8),
-                                      ("restatement_cdlspec.npz", 4), ("restatement_clens.npz", 4), ("restatement_cdl2.npz", 4)])
+                                      ("restatement_cdlspec.npz", 4), ("restatement_clens.npz", 4), ("restatement_cdl2.npz", 4),
+                                      ("restatement_cquad.npz", 8), ("restatement_cquaddl.npz", 4)])
 def test_gpu_replay_equals_the_independent_restatement(gpu, name, spp):
     _, prims, r, golden, integ, _ = _cases()[name]
     fx = np.load(os.path.join(GOLDEN, name))
