@@ -71,7 +71,7 @@ struct Workspace {
 };
 
 #define DR_STATE_WORDS F_SAMPLES  // 41 4-byte words of fixed path state per slot: 3 f64 + 10 3-vectors + 5 i32
-#define N_COUNTERS 4096  // [0,1024): stage queue counts; [1024,4096): 8 per-XCD work counters per trace launch
+#define N_COUNTERS (1024 + 8 * DR_WORK_STRIDE * 400)  // [0,1024): stage queue counts; then 8 per-XCD work counters per trace launch, DR_WORK_STRIDE words apart
 
 }  // namespace
 
@@ -989,9 +989,9 @@ int dr_intersect(DrScene* sc, const DrRay* rays, int64_t n, DrHit* out, int32_t 
   DevBuf<uint32_t> work;
   HIP_TRY(dR.alloc(n));
   HIP_TRY(dH.alloc(n));
-  HIP_TRY(work.alloc(8));
+  HIP_TRY(work.alloc(8 * DR_WORK_STRIDE));
   HIP_TRY(hipMemcpy(dR.p, rays, n * sizeof(DrRay), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(work.p, 0, 8 * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(work.p, 0, 8 * DR_WORK_STRIDE * sizeof(uint32_t)));
   HIP_TRY(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
   launch_intersect(sc->d, dR.p, n, dH.p, any_hit, sc->ws.spill.p, work.p, sc->ctr.p, grid, 0);
   HIP_TRY(hipGetLastError());
@@ -1219,7 +1219,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   size_t batchIndex = 0;
   const int sgrid = g_numCU;  // the shade launchers size their grid per CU (DR_SHADE_GRID), grid-stride over the active list
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
-  if (4 * nStages + 8 > 1000 || 8 * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
+  if (nStages > 248 || 8 * DR_WORK_STRIDE * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
 
   // One batch through the stage loop.  pilot != null: a calibration batch -- a normal batch whose traversal launches are
   // also collected into pilot->ev[kind] (see above).
@@ -1255,7 +1255,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any) {
       hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
       (void)hipEventRecord(e0, s);
-      launch_trace(sc->d, st, queue, nQ, any, w.spill.p, C + 1024 + 8 * (wc++), sc->ctr.p, tgrid, s);
+      launch_trace(sc->d, st, queue, nQ, any, w.spill.p, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, s);
       (void)hipEventRecord(e1, s);
       if (pilot) pilot->ev[any].push_back({e0, e1});
       sc->traceEvents.push_back({e0, e1, any});
@@ -1276,13 +1276,17 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     for (int b = 0; b < nStages; ++b) {
       StageQueues q;
       q.activeIn = b == 0 ? roundQ : ((b - 1) & 1 ? w.activeB.p : w.activeA.p);
-      q.nActiveIn = b == 0 ? nRound : C + 4 * (b - 1);
+      // a stage's four counters sit ~1 KB apart: every wave adds to all four in one round trip (stage_flush), and
+      // same-line atomics serialise
+      auto cnt = [&](int j, int stage) { return C + 248 * j + stage; };
+      q.nActiveIn = b == 0 ? nRound : cnt(0, b - 1);
       q.activeOut = (b & 1) ? w.activeB.p : w.activeA.p;
-      q.nActiveOut = C + 4 * b;
+      q.nActiveOut = cnt(0, b);
       q.closestQ = w.closestQ.p;
-      q.nClosest = C + 4 * b + 1;
+      q.nClosest = cnt(1, b);
       q.anyQ = w.anyQ.p;
-      q.nAny = C + 4 * b + 2;
+      q.nAny = cnt(2, b);
+      q.work = cnt(3, b);
       q.ctr = sc->ctr.p;
       hipEvent_t evS = sc->getEvent();
       (void)hipEventRecord(evS, s);

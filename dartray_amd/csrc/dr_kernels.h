@@ -195,8 +195,13 @@ struct StageQueues {
   uint32_t* anyQ;
   uint32_t* nAny;
   TraceCounters* ctr;  // shade_* totals (one no-return atomic per counter, workgroup and flush)
+  uint32_t* work;      // k_shade_path's chunk counter (zero at launch): waves take chunks of 64 * DR_PUSH_ITERS entries
 };
 
+// k_trace's per-XCD work counters of one launch sit this many words apart (same-line atomics serialise)
+#ifndef DR_WORK_STRIDE
+#define DR_WORK_STRIDE 64
+#endif
 #ifndef DR_LDS_STACK
 #define DR_LDS_STACK 24       // stack entries per lane kept in LDS: 24 KiB per workgroup => 6 workgroups (24 waves) per CU
 #endif

@@ -740,8 +740,8 @@ void shade_prof_dump() {}
 #endif
 
 // One vertex of PathIntegrator.Li (path_integrator.dart:44-119).
-// Launch shape (measured): ONE 768-thread workgroup per CU = 3 waves per SIMD (168 VGPRs each).
-// Smaller workgroups pay more same-address queue atomics (one per workgroup, counter and iteration), 4 waves per
+// Launch shape (measured): ONE 768-thread workgroup per CU = 3 waves per SIMD (168 VGPRs each);
+// the waves are independent of each other (own staging region, own reservations, work taken in chunks), 4 waves per
 // SIMD spill.
 #ifndef DR_SHADE_WAVES
 #define DR_SHADE_WAVES 3
@@ -807,23 +807,30 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD)));
   else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf, sc.mats};
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t nIter = (nIn + stride - 1) / stride;
   // Every iteration fetches its active-list entry, then the whole slot state with independent loads.  Prefetching the
   // next item's state did not pay (DESIGN.md section 5 row i: vmcnt retires in order, so a prefetch issued before the
   // shading code is waited for at its first load; issued after it, it costs 16 spilled registers).
-  const uint32_t tid0 = blockIdx.x * blockDim.x + threadIdx.x;
   auto slotOf = [&](uint32_t i) -> uint32_t { return i < nIn ? (q.activeIn ? q.activeIn[i] : i) : 0u; };
   shade_count_init(s_push);
-  // the NEXT iteration's active-list entry is fetched one iteration ahead (one register): the entry -> slot state ->
-  // primitive record chain of dependent round trips loses its first link
-  uint32_t slotNext = slotOf(tid0);
+  // Work is handed out dynamically: a wave takes CHUNKS of 64 * DR_PUSH_ITERS consecutive active-list entries from the
+  // launch's counter (q.work), one staging round each; the next chunk's number comes back with the round's queue
+  // reservations (stage_flush), one round ahead of its use, so that a wave always knows its next entry.
+  const uint32_t CH = 64u * DR_PUSH_ITERS;
+  const uint32_t nChunks = (nIn + CH - 1u) / CH;
+  const uint32_t lane = (uint32_t)lane_id();
+  uint32_t cCur = 0u;
+  if (lane == 0u) cCur = atomicAdd(q.work, 2u);
+  cCur = wave_bcast_first(cCur);
+  uint32_t cNext = cCur + 1u;
+  uint32_t slotNext = slotOf(cCur * CH + lane);
   PROF_DECL;
-  for (uint32_t it = 0; it < nIter; ++it) {
+  while (cCur < nChunks) {
     ShadeIn cur;
     const uint32_t slotCur = slotNext;
-    slotNext = slotOf((it + 1) * stride + tid0);
-    load_shade_in<QUAD>(st, rp, bounce, slotCur, it * stride + tid0 < nIn, &cur);
+    const uint32_t idx = cCur * CH + pctx.iters * 64u + lane;
+    const bool lastOfChunk = pctx.iters + 1u == DR_PUSH_ITERS;
+    slotNext = slotOf(lastOfChunk ? cNext * CH + lane : idx + 64u);
+    load_shade_in<QUAD>(st, rp, bounce, slotCur, idx < nIn, &cur);
     PROF(4);
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
@@ -978,11 +985,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0 && !deferred, slot, Q_MIS_BIT, vert,
                pushCont ? 0u : Q_RESOLVE_BIT);
     PROF(8);
-    if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
-      stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);
+    if (pctx.iters == DR_PUSH_ITERS) {
+      const uint32_t g = stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont, q.work);
+      cCur = cNext;
+      cNext = g;
+    }
     PROF(9);
   }
-  stage_finish(s_push, pctx, q.closestQ, q.anyQ, q.activeOut);
+  stage_finish(s_push, pctx, q.closestQ, q.anyQ, q.activeOut, &q.ctr->shade_cont);
   PROF_FLUSH;
   shade_count(s_push, q.ctr, nIn);
 }
@@ -1093,7 +1103,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
       stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);
   }
-  stage_finish(s_push, pctx, q.closestQ, q.anyQ, q.activeOut);
+  stage_finish(s_push, pctx, q.closestQ, q.anyQ, q.activeOut, &q.ctr->shade_cont);
   shade_count(s_push, q.ctr, nIn);
 }
 

@@ -497,7 +497,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           const uint32_t s0 = (uint32_t)(((unsigned long long)n * shard) / DR_NSHARD);
           const uint32_t s1 = (uint32_t)(((unsigned long long)n * (shard + 1u)) / DR_NSHARD);
           uint32_t fresh = 0;
-          if (lane == 0) fresh = atomicAdd(work + shard, (uint32_t)DR_WORK_CHUNK);
+          if (lane == 0) fresh = atomicAdd(work + shard * (uint32_t)DR_WORK_STRIDE, (uint32_t)DR_WORK_CHUNK);
           fresh = wave_bcast_first(fresh);
           if (fresh < s1 - s0) {
             resNext = s0 + fresh;

@@ -19,31 +19,25 @@ DR_DEV void wave_push(uint32_t* q, uint32_t* count, bool pred, uint32_t val) {
   base = (uint32_t)__shfl((int)base, leader);
   if (pred) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = val;
 }
-// Staged append to the three stage queues.  Same-address atomics run at ~90-130 per microsecond chip-wide and a
-// returning atomic takes microseconds under that load, so a shade workgroup (the only one on its CU) must neither
-// issue many nor wait for them: every WAVE compacts its entries into its own LDS region (ballot + popcount,
-// wave-uniform counts, no barrier, no global traffic) for one ROUND of DR_PUSH_ITERS iterations of the grid-stride
-// loop.  Rounds are double buffered and nobody waits at a round's end: each wave publishes its counts and takes an LDS
-// ticket; the wave that arrives LAST reserves the workgroup's ranges (one global atomic per queue) and marks the round
-// ready; every wave then copies out its region of the PREVIOUS round -- whose ranges were reserved a whole round ago --
-// with coalesced stores and starts the next round in the other buffer.  A wave can run up to two rounds ahead of the
-// slowest one before it has to wait (a buffer's counts must have been consumed before they are overwritten).
-// History: round 1 staged per workgroup with two barriers in EVERY iteration (the 12 waves of the CU ran in lock
-// step: VALU 40 % busy); the first version of this round met at a barrier once per flush, where the in-kernel
-// profile (-DDR_SHADE_PROF) still showed 12 % of the waves' time.
-// closestQ receives the continuation entries of a round first, then its MIS entries.  Every spin is bounded: a
-// protocol error traps instead of hanging the GPU.
+// Staged append to the three stage queues.  Every WAVE compacts its entries into its own LDS region (ballot +
+// popcount, wave-uniform counts, no barrier, no global traffic) for one ROUND of DR_PUSH_ITERS iterations, then reserves
+// its own ranges -- one atomic per queue counter, all in flight together, one wait -- and copies the region out with
+// coalesced stores.  No word is shared between waves and nobody waits for anybody.
+// What the numbers said on the way here (C2, shade ms per step): one atomic per wave, queue and ITERATION on adjacent
+// counters: 726 (same-line atomics are a chip-wide serial resource, ~100 per microsecond); per-workgroup staging with two
+// barriers per iteration: 153; per-wave regions, one workgroup-level reservation per 4 iterations by the last wave to
+// arrive, double buffered: 114 -- with 14 % of the waves' time (-DDR_SHADE_PROF) spent waiting for the slowest wave of
+// the workgroup, because a buffer can only be reused once EVERY wave has copied it out; per-wave reservations every 8
+// iterations with the four counters of a stage in ONE cache line: 130 (4 iterations: 204); the same with the counters
+// ~1 KB apart (dr_api.hip) and work handed out in chunks from a counter: 100.
+// closestQ receives the continuation entries of a wave's round first, then its MIS entries.
 #ifndef DR_PUSH_ITERS
-#define DR_PUSH_ITERS 4
+#define DR_PUSH_ITERS 8
 #endif
 struct TraceCounters;
-struct PushStage {  // head of the dynamic LDS block; followed by [2 buffers][wave] regions: 4 arrays (cont, mis, any, active) of 64 * DR_PUSH_ITERS entries
-  uint32_t cnt[2][4][16];  // per buffer, queue, wave: entries staged in the round that last used the buffer
-  uint32_t arrived[2];     // tickets taken on the buffer (monotonic: nw per round)
-  uint32_t ready[2];       // round + 1 of the round whose base[] is valid
-  uint32_t copied[2];      // copy-outs finished on the buffer (monotonic: nw per round)
-  uint32_t base[2][3];     // reserved ranges of the round: closestQ, anyQ, activeQ
-  uint32_t nVert[16];      // per wave: path vertices set up so far (statistics; kept in LDS, not in a register)
+struct PushStage {  // head of the dynamic LDS block; followed by one region per wave: 4 arrays (cont, mis, any, active) of 64 * DR_PUSH_ITERS entries
+  uint32_t nVert[16];  // per wave: path vertices set up so far (statistics; kept in LDS, not in a register)
+  unsigned long long nStat[16][3];  // per wave: continuation, MIS and shadow rays queued so far (statistics)
 #ifdef DR_SHADE_PROF
   unsigned long long prof[16][10];
 #endif
@@ -54,23 +48,24 @@ struct PushCtx {  // wave-uniform registers
   uint32_t iters;
   uint32_t round;
 };
-#define DR_PUSH_CAP (64 * DR_PUSH_ITERS)  // entries per queue, wave and buffer
+#define DR_PUSH_CAP (64 * DR_PUSH_ITERS)  // entries per queue and wave
 __host__ __device__ inline size_t push_stage_bytes(uint32_t blockDimX) {
-  return sizeof(PushStage) + 2 * 4 * (size_t)blockDimX * DR_PUSH_ITERS * sizeof(uint32_t);
+  return sizeof(PushStage) + 4 * (size_t)blockDimX * DR_PUSH_ITERS * sizeof(uint32_t);
 }
 DR_DEV void stage_init(PushStage& sm) {  // once per kernel, by every thread, before the first stage_push
-  if (threadIdx.x < 2) sm.arrived[threadIdx.x] = sm.ready[threadIdx.x] = sm.copied[threadIdx.x] = 0u;
-  if (threadIdx.x < 16) sm.nVert[threadIdx.x] = 0u;
+  if (threadIdx.x < 16) {
+    sm.nVert[threadIdx.x] = 0u;
+    sm.nStat[threadIdx.x][0] = sm.nStat[threadIdx.x][1] = sm.nStat[threadIdx.x][2] = 0ull;
+  }
   __syncthreads();
 }
-DR_DEV uint32_t* stage_region(PushStage& sm, uint32_t buffer) {
-  const uint32_t nw = (blockDim.x + 63u) >> 6, wave = threadIdx.x >> 6;
-  return (uint32_t*)(&sm + 1) + ((size_t)buffer * nw + wave) * 4 * DR_PUSH_CAP;
+DR_DEV uint32_t* stage_region(PushStage& sm) {
+  return (uint32_t*)(&sm + 1) + (size_t)(threadIdx.x >> 6) * 4 * DR_PUSH_CAP;
 }
 DR_DEV void stage_push(PushStage& sm, PushCtx& c, bool pCont, bool pMis, bool pAny, bool pAct, uint32_t slot, uint32_t misBit,
                        bool pVert = false, uint32_t actBits = 0u) {
   const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-  uint32_t* buf = stage_region(sm, c.round & 1u);
+  uint32_t* buf = stage_region(sm);
   const unsigned long long lt = (1ull << lane) - 1ull;
   const unsigned long long m0 = __ballot(pCont), m1 = __ballot(pMis), m2 = __ballot(pAny), m3 = __ballot(pAct);
   const unsigned long long m4 = __ballot(pVert);
@@ -85,77 +80,74 @@ DR_DEV void stage_push(PushStage& sm, PushCtx& c, bool pCont, bool pMis, bool pA
   c.n[3] += (uint32_t)__popcll(m3);
   ++c.iters;
 }
-// wait (bounded) until the LDS word reaches `want`; acquire at workgroup scope
-DR_DEV void stage_wait(uint32_t* word, uint32_t want) {
-  for (uint32_t spin = 0; spin < (1u << 24); ++spin) {
-    if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) return;
-    __builtin_amdgcn_s_sleep(2);
+// End of a wave's round (every DR_PUSH_ITERS iterations, and after its last iteration).  closestQ receives the round's
+// continuation entries first, then its MIS entries.
+// `work` (optional): the kernel's chunk counter; the wave's next chunk of work is taken in the same round trip and
+// returned (dynamic distribution: a wave that runs ahead simply takes more chunks).
+DR_DEV uint32_t stage_flush(PushStage& sm, PushCtx& c, uint32_t* closestQ, uint32_t* nClosest, uint32_t* anyQ, uint32_t* nAny,
+                            uint32_t* activeQ, uint32_t* nActive, unsigned long long* stats = nullptr, uint32_t* work = nullptr) {
+  const int lane = lane_id();
+  const uint32_t n0 = c.n[0], n1 = c.n[1], n2 = c.n[2], n3 = c.n[3];
+  uint32_t grabbed = 0u;
+  if (work && (n0 | n1 | n2 | n3) == 0u) {
+    if (lane == 0) grabbed = atomicAdd(work, 1u);
+    grabbed = wave_bcast_first(grabbed);
   }
-  __builtin_trap();  // a protocol error must fail loudly, not hang the GPU
-}
-// this wave's region of round q goes to the ranges the round's last arriver reserved
-DR_DEV void stage_copy_out(PushStage& sm, uint32_t q, uint32_t* closestQ, uint32_t* anyQ, uint32_t* activeQ) {
-  const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = (int)((blockDim.x + 63) >> 6);
-  const uint32_t b = q & 1u;
-  stage_wait(&sm.ready[b], q + 1u);
-  uint32_t pre[4] = {0, 0, 0, 0}, mine[4] = {0, 0, 0, 0}, tot0 = 0;
-  for (int w = 0; w < nw; ++w)
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t v = sm.cnt[b][j][w];
-      if (w < wave) pre[j] += v;
-      if (w == wave) mine[j] = v;
-      if (j == 0) tot0 += v;
-    }
-  const uint32_t* buf = stage_region(sm, b);
-  const uint32_t b0 = sm.base[b][0], b1 = sm.base[b][1], b2 = sm.base[b][2];
-  for (uint32_t i = (uint32_t)lane; i < mine[0]; i += 64u) closestQ[b0 + pre[0] + i] = buf[i];
-  for (uint32_t i = (uint32_t)lane; i < mine[1]; i += 64u) closestQ[b0 + tot0 + pre[1] + i] = buf[DR_PUSH_CAP + i];
-  for (uint32_t i = (uint32_t)lane; i < mine[2]; i += 64u) anyQ[b1 + pre[2] + i] = buf[2 * DR_PUSH_CAP + i];
-  for (uint32_t i = (uint32_t)lane; i < mine[3]; i += 64u) activeQ[b2 + pre[3] + i] = buf[3 * DR_PUSH_CAP + i];
-  // the region and the round's counts have been consumed by this wave (release: the reads above come first)
-  if (lane == 0) __hip_atomic_fetch_add(&sm.copied[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// End of a round (every DR_PUSH_ITERS iterations, and after the last iteration): reached by every wave of the workgroup.
-DR_DEV void stage_flush(PushStage& sm, PushCtx& c, uint32_t* closestQ, uint32_t* nClosest, uint32_t* anyQ, uint32_t* nAny,
-                        uint32_t* activeQ, uint32_t* nActive, unsigned long long* stats = nullptr) {
-  const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = (int)((blockDim.x + 63) >> 6);
-  const uint32_t r = c.round, b = r & 1u, k = r >> 1;  // the k-th use of buffer b
-  // the previous use of this buffer (round r - 2) must have been copied out by every wave before its counts go
-  if (k > 0) stage_wait(&sm.copied[b], (uint32_t)nw * k);
-  uint32_t ticket = 0;
-  if (lane == 0) {
-    sm.cnt[b][0][wave] = c.n[0];
-    sm.cnt[b][1][wave] = c.n[1];
-    sm.cnt[b][2][wave] = c.n[2];
-    sm.cnt[b][3][wave] = c.n[3];
-    ticket = __hip_atomic_fetch_add(&sm.arrived[b], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  ticket = wave_bcast_first(ticket);
-  if (ticket == (uint32_t)nw * (k + 1u) - 1u) {  // the last wave to arrive reserves the round's ranges
-    uint32_t tot[4] = {0, 0, 0, 0};
-    for (int w = 0; w < nw; ++w)
-      for (int j = 0; j < 4; ++j) tot[j] += sm.cnt[b][j][w];
+  if ((n0 | n1 | n2 | n3) != 0u) {
+    // three independent round trips in flight together, ONE wait.  Written out because the compiler's atomic optimizer
+    // wraps every atomicAdd in its own readfirstlane and so waits for each before it issues the next.  Every lane gets
+    // the same values back from lane 0 through readfirstlane (adding 0 returns the counter and costs the same).
+    uint32_t a0 = 0u, a1 = 0u, a2 = 0u;
     if (lane == 0) {
-      sm.base[b][0] = (tot[0] + tot[1]) ? atomicAdd(nClosest, tot[0] + tot[1]) : 0u;
-      sm.base[b][1] = tot[2] ? atomicAdd(nAny, tot[2]) : 0u;
-      sm.base[b][2] = tot[3] ? atomicAdd(nActive, tot[3]) : 0u;
-      if (stats) {  // statistics only (shade_cont, shade_mis, shade_shadow): no-return atomics
-        if (tot[0]) atomicAdd(stats + 0, (unsigned long long)tot[0]);
-        if (tot[1]) atomicAdd(stats + 1, (unsigned long long)tot[1]);
-        if (tot[2]) atomicAdd(stats + 2, (unsigned long long)tot[2]);
+      const uint32_t zero = 0u;
+      if (work) {
+        const uint32_t one = 1u;
+        asm volatile(
+            "global_atomic_add %0, %4, %5, %9 sc0\n\t"
+            "global_atomic_add %1, %4, %6, %10 sc0\n\t"
+            "global_atomic_add %2, %4, %7, %11 sc0\n\t"
+            "global_atomic_add %3, %4, %8, %12 sc0\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(grabbed)
+            : "v"(zero), "v"(n0 + n1), "v"(n2), "v"(n3), "v"(one), "s"(nClosest), "s"(nAny), "s"(nActive), "s"(work)
+            : "memory");
+      } else {
+        asm volatile(
+            "global_atomic_add %0, %3, %4, %7 sc0\n\t"
+            "global_atomic_add %1, %3, %5, %8 sc0\n\t"
+            "global_atomic_add %2, %3, %6, %9 sc0\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(a0), "=&v"(a1), "=&v"(a2)
+            : "v"(zero), "v"(n0 + n1), "v"(n2), "v"(n3), "s"(nClosest), "s"(nAny), "s"(nActive)
+            : "memory");
       }
-      __hip_atomic_store(&sm.ready[b], r + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int wave = (int)(threadIdx.x >> 6);  // statistics (shade_cont, shade_mis, shade_shadow): summed at the end
+      sm.nStat[wave][0] += n0;
+      sm.nStat[wave][1] += n1;
+      sm.nStat[wave][2] += n2;
     }
+    const uint32_t b0 = wave_bcast_first(a0), b1 = wave_bcast_first(a1), b2 = wave_bcast_first(a2);
+    const uint32_t* buf = stage_region(sm);
+    for (uint32_t i = (uint32_t)lane; i < n0; i += 64u) closestQ[b0 + i] = buf[i];
+    for (uint32_t i = (uint32_t)lane; i < n1; i += 64u) closestQ[b0 + n0 + i] = buf[DR_PUSH_CAP + i];
+    for (uint32_t i = (uint32_t)lane; i < n2; i += 64u) anyQ[b1 + i] = buf[2 * DR_PUSH_CAP + i];
+    for (uint32_t i = (uint32_t)lane; i < n3; i += 64u) activeQ[b2 + i] = buf[3 * DR_PUSH_CAP + i];
+    if (work) grabbed = wave_bcast_first(grabbed);
   }
-  if (r > 0) stage_copy_out(sm, r - 1u, closestQ, anyQ, activeQ);
   c.n[0] = c.n[1] = c.n[2] = c.n[3] = 0;
   c.iters = 0;
-  c.round = r + 1u;
+  c.round += 1u;
+  return grabbed;
 }
-// After the loop: the last round is still in its buffer.
-DR_DEV void stage_finish(PushStage& sm, PushCtx& c, uint32_t* closestQ, uint32_t* anyQ, uint32_t* activeQ) {
-  if (c.round > 0) stage_copy_out(sm, c.round - 1u, closestQ, anyQ, activeQ);
-  __syncthreads();  // (the statistics below read every wave's LDS counters)
+// After the loop: every round has been flushed (the loop flushes after its last iteration).
+DR_DEV void stage_finish(PushStage& sm, PushCtx& c, uint32_t* closestQ, uint32_t* anyQ, uint32_t* activeQ,
+                         unsigned long long* stats = nullptr) {
+  __syncthreads();  // (the statistics read every wave's LDS counters)
+  if (stats && threadIdx.x < 3) {  // one no-return atomic per workgroup and counter
+    unsigned long long v = 0;
+    for (int w = 0; w < 16; ++w) v += sm.nStat[w][threadIdx.x];
+    if (v) atomicAdd(stats + threadIdx.x, v);
+  }
 }
 DR_DEV unsigned long long wave_sum(uint32_t v) {
   unsigned long long x = v;
