@@ -62,6 +62,7 @@ struct Workspace {
   DevBuf<uint32_t> scr;  // compact samples: scramble words [2 * nBlocks][pixCap]
   DevBuf<double> tail;
   DevBuf<uint32_t> activeA, activeB, closestQ, anyQ, counters, spill;
+  size_t spillHalf = 0;
   DevBuf<uint32_t> roundA, roundB;  // DirectLighting over mirror / glass: the slots whose child ray is traced next round
   DevBuf<float> specFrames;         //   [maxDepth][cap] SpecFrame
   DevBuf<int32_t> specSp;           //   [cap]
@@ -106,9 +107,12 @@ struct DrScene {
   // one batch's kernel tails / memory-bound shading overlap the other's ALU-bound traversal
   Workspace ws2;
   hipStream_t s2 = nullptr;
+  hipStream_t s3 = nullptr;  // the any-hit launches of a stage, beside the closest-hit ones
   // stats of the last render
   DrRenderStats stats;
-  struct TraceEv { hipEvent_t e0, e1; int any; };  // any: 0 closest, 1 any-hit, 2 shade, 3 sample gen + raygen, 4 film
+  // any: 0 closest, 1 any-hit, 2 shade, 3 sample gen + raygen, 4 film.  after: set for an any-hit launch that ran beside
+  // the stage's closest-hit launch (its end): only the time AFTER that counts as any-hit time
+  struct TraceEv { hipEvent_t e0, e1; int any; hipEvent_t after = nullptr; };
   std::vector<TraceEv> traceEvents;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> renderEvents;
   std::vector<hipEvent_t> eventPool;
@@ -120,7 +124,8 @@ struct DrScene {
   void foldEvents() {
     for (auto& ev : traceEvents) {
       float t = 0.f;
-      if (hipEventElapsedTime(&t, ev.e0, ev.e1) != hipSuccess) continue;
+      if (hipEventElapsedTime(&t, ev.after ? ev.after : ev.e0, ev.e1) != hipSuccess) continue;
+      if (t < 0.f) t = 0.f;  // (an any-hit launch that ended before the closest-hit one beside it)
       if (ev.any == 1) { stats.any_ms += t; stats.any_launches++; }
       else if (ev.any == 0) { stats.closest_ms += t; stats.closest_launches++; }
       else if (ev.any == 2) stats.shade_ms += t;
@@ -150,6 +155,7 @@ struct DrScene {
     (void)hipDeviceSynchronize();  // nothing of this scene may still be in flight when its buffers and events go away
     for (auto e : eventPool) (void)hipEventDestroy(e);
     if (s2) (void)hipStreamDestroy(s2);
+    if (s3) (void)hipStreamDestroy(s3);
   }
 };
 
@@ -231,7 +237,8 @@ int ensureSpill(DrScene* sc, Workspace& w, int grid) {
   // deepest stack == tree depth; the v3 kernel keeps 16 (reference, E) pairs in LDS, v2 24 references
   if (sc->bvhDepth != 0 && sc->bvhDepth <= 8) return DR_OK;
   size_t need = (size_t)grid * DR_TRACE_BLOCK * (DR_MAX_STACK - 8) * 2;  // (room for any LDS stack depth >= 8 of either variant)
-  HIP_TRY(w.spill.alloc(need));
+  w.spillHalf = need;
+  HIP_TRY(w.spill.alloc(2 * need));  // second half: the any-hit launch of a stage when it runs beside the closest-hit one
   w.spillGrid = grid;
   return DR_OK;
 }
@@ -1161,6 +1168,9 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const int tgrid = traceGrid();
   rc = ensureSpill(sc, sc->ws, tgrid);
   if (rc) return rc;
+  static const bool overlapEnv = !(getenv("DARTRAY_OVERLAP_ANY") && atoi(getenv("DARTRAY_OVERLAP_ANY")) == 0);  // default: on
+  const bool overlapAny = overlapEnv && !dlSpec && !(nPipesEnv >= 2);
+  if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
   const bool twoPipes = nPipesEnv >= 2 && !hostBuf && !dlSpec && npixTotal > pixPerBatch;
   if (twoPipes) {
     rc = allocWorkspace(sc, sc->ws2, cap, sf, pixPerBatch, rd->max_tail, false);
@@ -1252,14 +1262,19 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     timed(3, evGen);
     uint32_t* C = w.counters.p;
     int wc = 0;  // work counters live at C[1024..], 8 per launch
-    auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any) {
+    auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr) {
       hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
-      (void)hipEventRecord(e0, s);
-      launch_trace(sc->d, st, queue, nQ, any, w.spill.p, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, s);
-      (void)hipEventRecord(e1, s);
+      (void)hipEventRecord(e0, ts);
+      launch_trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
+      (void)hipEventRecord(e1, ts);
       if (pilot) pilot->ev[any].push_back({e0, e1});
-      sc->traceEvents.push_back({e0, e1, any});
+      sc->traceEvents.push_back({e0, e1, any, after});
+      return e1;
     };
+    // A stage's two traversals are independent (closest hit of the continuation / MIS rays, occlusion of the shadow
+    // rays).  Side by side on two streams the any-hit workgroups take the CU slots the closest-hit launch frees as its
+    // queue runs dry (a persistent launch ends with its longest rays).  Calibration batches time each launch alone.
+    const bool sideBySide = overlapAny && !pilot;
     // DirectLighting over mirror / glass: one round of the stage loop per vertex of a slot's ray tree; `roundQ` lists
     // the slots whose (camera or child) ray this round traces.  Everything else: one round.
     const uint32_t* roundQ = nullptr;
@@ -1272,7 +1287,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       HIP_TRY(hipMemsetAsync(C + 1024, 0, (N_COUNTERS - 1024) * sizeof(uint32_t), s));
       wc = 0;
     }
-    trace(roundQ, nRound, 0);  // camera rays (or this round's child rays)
+    trace(roundQ, nRound, 0, s, w.spill.p);  // camera rays (or this round's child rays)
     for (int b = 0; b < nStages; ++b) {
       StageQueues q;
       q.activeIn = b == 0 ? roundQ : ((b - 1) & 1 ? w.activeB.p : w.activeA.p);
@@ -1294,8 +1309,18 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       else launch_shade_direct(sc->d, rp, st, q, b, sgrid, s);
       timed(2, evS);
       if (b + 1 < nStages) {
-        trace(q.closestQ, q.nClosest, 0);
-        trace(q.anyQ, q.nAny, 1);
+        if (sideBySide) {
+          hipEvent_t eS = sc->getEvent(), eA = sc->getEvent();
+          (void)hipEventRecord(eS, s);
+          (void)hipStreamWaitEvent(sc->s3, eS, 0);
+          hipEvent_t closestEnd = trace(q.closestQ, q.nClosest, 0, s, w.spill.p);
+          trace(q.anyQ, q.nAny, 1, sc->s3, w.spill.p + w.spillHalf, closestEnd);
+          (void)hipEventRecord(eA, sc->s3);
+          (void)hipStreamWaitEvent(s, eA, 0);
+        } else {
+          trace(q.closestQ, q.nClosest, 0, s, w.spill.p);
+          trace(q.anyQ, q.nAny, 1, s, w.spill.p);
+        }
       }
     }
     if (!dlSpec) break;

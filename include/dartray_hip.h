@@ -255,7 +255,8 @@ typedef struct DrRenderStats {
   double total_ms;                   /* device time of the render calls (HIP events) */
   uint64_t batches;
   uint64_t closest_launches, any_launches; /* per kernel: k_trace<0> (closest hit), k_trace<1> (any hit) */
-  double closest_ms, any_ms;
+  double closest_ms, any_ms; /* a stage's any-hit launch runs beside its closest-hit launch (second stream; DARTRAY_OVERLAP_ANY=0
+                              * serialises them): any_ms counts its time AFTER the closest-hit launch ended */
   double shade_ms;  /* k_shade_path / k_shade_direct */
   double gen_ms;    /* k_gen_samples (+ host-buffer transpose) and k_raygen */
   double film_ms;   /* k_film */
