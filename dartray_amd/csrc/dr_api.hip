@@ -1059,6 +1059,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.dlSpecular = dlSpec ? 1 : 0;
   rp.deferredNee = rd->integrator == DR_INTEGRATOR_PATH ? 1 : 0;
   rp.genMask = 0ull;
+  static const bool genSlow = getenv("DARTRAY_GEN_SLOW_DRAWS") != nullptr;
+  rp.genSlowDraws = genSlow ? 1 : 0;
   static const bool genAll = getenv("DARTRAY_GEN_ALL_BLOCKS") != nullptr;  // A/B and tests: generate every block
   if (rd->integrator == DR_INTEGRATOR_PATH && !rp.blocks && !genAll) {
     // What the path kernels read of a pixel sample (dr_kernels.hip: k_raygen, load_shade_in, k_film): the image sample,

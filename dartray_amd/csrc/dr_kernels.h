@@ -42,6 +42,7 @@ struct RenderParams {
   int32_t nDirectStages;
   int32_t dlSpecular;  // DirectLighting over mirror / glass: k_shade_spec adds SpecularReflect / SpecularTransmit after the last stage
   int32_t deferredNee; // PathIntegrator: k_film adds the PF_DEFERRED light terms
+  int32_t genSlowDraws;  // tests: k_gen_samples_lm redoes every group of draws the slow way (the path a rare generator value takes)
   uint64_t genMask;    // LD blocks the device sampler must produce (bit = block index; 0 = all): blocks no kernel reads are skipped
 };
 

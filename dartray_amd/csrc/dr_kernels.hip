@@ -256,19 +256,74 @@ __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchSta
   // LDShuffleScrambled1D/2D with nSamples == 1 (montecarlo.dart:524-551)
   st.svScr[(size_t)(2 * k) * st.pixCap + p] = rng.randomUint();
   st.svScr[(size_t)(2 * k + 1) * st.pixCap + p] = is2D ? rng.randomUint() : 0u;
-  for (int i = 0; i < spp; ++i) (void)rng.randomUint();  // Shuffle of ONE entry: other = i + r % 1 (:294-303)
+  // randomUint() is one generator step unless the step lands on 0xffffffff (it then steps again: once in 2^32).  A loop
+  // around every step is a branch per step in a serial chain; instead a GROUP of draws is made with plain steps and
+  // redone the slow way from the saved state if any lane of the wave saw the rare value.
+  auto draws = [&](uint32_t* r, int n) {  // r == nullptr: the draws are discarded
+    const DartRandom saved = rng;
+    bool rare = rp.genSlowDraws != 0;  // (tests: DARTRAY_GEN_SLOW_DRAWS=1 takes the slow path everywhere; same streams)
+    for (int j = 0; j < n; ++j) {
+      rng.step();
+      rare |= rng.lo == 0xffffffffu;
+      if (r) r[j] = rng.lo;
+    }
+    if (__ballot(rare) != 0ull) {
+      rng = saved;
+      for (int j = 0; j < n; ++j) {
+        const uint32_t v = rng.randomUint();
+        if (r) r[j] = v;
+      }
+    }
+  };
+  for (int i = 0; i < spp; i += 16) draws(nullptr, 16);  // Shuffle of ONE entry: other = i + r % 1 (:294-303), spp times
   for (int i = 0; i < spp; ++i) at(i) = (PT)i;
-  PT a = at(0);
-  for (int i = 0; i < spp; ++i) {  // Fisher-Yates (montecarlo.dart:294-303), as in k_gen_samples
-    const uint32_t r = rng.randomUint(), m = (uint32_t)(spp - i);
-    uint32_t rem = r - __umulhi(r, s_magic[m]) * m;
-    if (rem >= m) rem -= m;
-    const int other = i + (int)rem;
-    const PT ahead = at(i + 1 < spp ? i + 1 : i);
-    const PT b = at(other);
-    at(i) = b;
-    at(other) = a;
-    a = (other == i + 1) ? a : ahead;
+  // Fisher-Yates (montecarlo.dart:294-303), FOUR steps at a time.  One lane's shuffle is a serial chain (generator ->
+  // partner -> LDS read -> LDS writes) and at 512 / 1024 spp only one or two waves fit a CU's LDS, so nothing hides the
+  // chain's latency.  Per group: the four partners (the only truly serial part: four generator steps) are computed one
+  // group AHEAD, beside the LDS round trip of the current group; ALL the group's reads are issued together, the four
+  // swaps replayed in registers -- a position a previous step of the group wrote is patched from that step's value,
+  // newest first -- then the eight writes go out in step order (LDS executes a wave's accesses in order, so aliasing
+  // writes end up right).
+  auto partners = [&](int i, int* o) {
+    uint32_t r[4];
+    draws(r, 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t m = (uint32_t)(spp - i - j);
+      uint32_t rem = r[j] - __umulhi(r[j], s_magic[m]) * m;  // r % m for the wave-uniform divisor: mulhi(r, floor(2^32 / m)) is r / m or one less
+      if (rem >= m) rem -= m;
+      o[j] = i + j + (int)rem;
+    }
+  };
+  int oNext[4];
+  partners(0, oNext);
+  for (int i = 0; i < spp; i += 4) {
+    int o[4];
+    PT R[4], A[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = oNext[j];
+      R[j] = at(o[j]);
+      A[j] = at(i + j);
+    }
+    if (i + 4 < spp) partners(i + 4, oNext);
+    PT av[4], bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      PT aj = A[j], bj = R[j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) {  // oldest first: the newest write wins
+        if (o[k] == i + j) aj = av[k];
+        if (o[k] == o[j]) bj = av[k];
+      }
+      av[j] = aj;
+      bv[j] = bj;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      at(i + j) = bv[j];
+      at(o[j]) = av[j];
+    }
   }
   // this lane's spp entries are spp / 64 whole index runs: slot p * spp + i is entry i & 63 of tile (p * spp + i) >> 6
   const uint32_t* cols = (const uint32_t*)s_raw + lane;  // dword d of this lane's column is cols[d * LN]
@@ -1235,6 +1290,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(true), SHADE_WAVES_OF(true)) k_
 __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, const float* table, uint32_t npix, float* film) {
   __shared__ float s_X[DR_FILM_CHUNK], s_Y[DR_FILM_CHUNK], s_Z[DR_FILM_CHUNK], s_W[DR_FILM_CHUNK];
   __shared__ uint8_t s_own[DR_FILM_CHUNK];
+  __shared__ float s_one[1];
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t spp = (uint32_t)rp.spp;
   const uint64_t base = (uint64_t)blockIdx.x * DR_FILM_CHUNK;
@@ -1242,6 +1298,7 @@ __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, co
   const uint32_t perPix = spp;                      // samples of one pixel
   const uint32_t nPixChunk = DR_FILM_CHUNK / spp;   // pixels of this block
   {
+    if (threadIdx.x == 0) s_one[0] = 1.0f;
     for (uint32_t e = threadIdx.x; e < DR_FILM_CHUNK; e += 256u) {
       const uint64_t s64 = base + e;
       uint8_t own = 0;
@@ -1300,18 +1357,37 @@ __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, co
       s_own[e] = own;
     }
     __syncthreads();
-    // lane = (pixel, channel): X, Y, Z and the weight sum are four independent f32 chains
+    // lane = (pixel, channel): X, Y, Z and the weight sum are four independent f32 chains, each in the reference's
+    // sample order.  Branch-free and eight samples per trip, every load unconditional (the weight lane reads its factor
+    // 1.0 from LDS with stride 0), so that a group's LDS reads are in flight together and only the additions are serial:
+    // a branch on s_own and three dependent reads per sample took ~200 cycles per sample (43 of the kernel's 52 ms at
+    // 1024 spp).  One wave per block does this (more waves with one busy lane each only compete for the SIMDs: 67 ms).
     for (uint32_t w = threadIdx.x; w < 4u * nPixChunk; w += 256u) {
       const uint32_t pl = w >> 2, c = w & 3u;
       const uint32_t e0 = pl * perPix;
-      const float* val = c == 0 ? s_X : (c == 1 ? s_Y : s_Z);
+      const float* src = c == 0 ? s_X : (c == 1 ? s_Y : (c == 2 ? s_Z : s_one));
+      const uint32_t step = c == 3u ? 0u : 1u, first = c == 3u ? 0u : e0;
       float acc = 0.f;
-      for (uint32_t i = 0; i < perPix; ++i) {
-        const uint32_t e = e0 + i;
-        if (s_own[e]) {
-          const double wt = s_W[e];
-          acc = (float)((double)acc + wt * (c == 3 ? 1.0 : (double)val[e]));  // weightSum += wt (wt * 1.0 is exact)
+      auto add = [&](uint8_t own, float wt, float v) {
+        const float t = (float)((double)acc + (double)wt * (double)v);  // _Lxyz += wt * xyz; weightSum += wt (wt * 1.0 is exact)
+        acc = own ? t : acc;
+      };
+      if (perPix >= 8u) {
+        for (uint32_t i = 0; i < perPix; i += 8u) {
+          const uint32_t e = e0 + i;
+          float v[8], wv[8];
+          uint8_t ow[8];
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; ++j) {
+            wv[j] = s_W[e + j];
+            ow[j] = s_own[e + j];
+            v[j] = src[first + (i + j) * step];
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; ++j) add(ow[j], wv[j], v[j]);
         }
+      } else {
+        for (uint32_t i = 0; i < perPix; ++i) add(s_own[e0 + i], s_W[e0 + i], src[first + i * step]);
       }
       const uint64_t s64 = base + e0;  // the first slot of this lane's pixel
       if (s64 < nslots) {

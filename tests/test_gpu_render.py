@@ -358,18 +358,24 @@ def test_unread_sample_blocks_can_be_left_out():
         "films.append(mk().render(scenes.make_scene(prims2)).film)\n"
         "np.save(sys.argv[1], np.stack([f[:80, :96] for f in films]))\n" % ROOT)
     out = []
-    for gen_all in (False, True):
-        path = os.path.join(ROOT, "gpurun_out", "film_gen%d.npy" % gen_all)
+    # third run: the device sampler draws its generator values in groups of plain steps and redoes a group the slow way
+    # (Random.nextInt's retry loop) when a lane saw the one value in 2^32 that is redrawn; DARTRAY_GEN_SLOW_DRAWS=1 takes
+    # that path for every group -- the streams must not change
+    for gen_all, slow in ((False, False), (True, False), (False, True)):
+        path = os.path.join(ROOT, "gpurun_out", "film_gen%d%d.npy" % (gen_all, slow))
         os.makedirs(os.path.dirname(path), exist_ok=True)
         env = dict(os.environ)
         env.pop("DARTRAY_GEN_ALL_BLOCKS", None)
+        env.pop("DARTRAY_GEN_SLOW_DRAWS", None)
         if gen_all:
             env["DARTRAY_GEN_ALL_BLOCKS"] = "1"
+        if slow:
+            env["DARTRAY_GEN_SLOW_DRAWS"] = "1"
         res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=500)
         assert res.returncode == 0, res.stderr[-2000:]
         out.append(np.load(path))
         os.remove(path)
-    assert out[0].shape[0] == 4 and np.array_equal(out[0], out[1])
+    assert out[0].shape[0] == 4 and np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
     assert out[0][..., :3].max() > 0
 
 
