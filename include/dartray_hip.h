@@ -319,7 +319,11 @@ int dr_render(DrScene* scene, const DrRenderDesc* desc, float* film_out, float* 
 
 /* Same, with the film left in device memory (accumulated into film_dev, which
  * the caller zero-initialises) on the given hipStream_t; used by bench.py and
- * by the multi-GPU path, which reduces film_dev over RCCL before resolving. */
+ * by the multi-GPU path, which reduces film_dev over RCCL before resolving.
+ * Everything the call enqueues is ordered behind earlier work of hip_stream and
+ * in front of later work of it; internally a stage's any-hit launch runs on a
+ * stream of the scene's own, beside the closest-hit launch, tied to hip_stream
+ * by events (DARTRAY_OVERLAP_ANY=0: everything on hip_stream). */
 int dr_render_device(DrScene* scene, const DrRenderDesc* desc, void* film_dev, void* hip_stream);
 
 /* The raster pixels a DR_SAMPLER_COUNTER render of `desc` traces, in trace
