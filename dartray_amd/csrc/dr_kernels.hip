@@ -338,6 +338,131 @@ __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchSta
   }
 }
 
+// 512 / 1024 spp: the same shuffle by TWO waves per 64 pixels.  A table of spp 16-bit entries per pixel lets one
+// (1024 spp) or two (512 spp) groups of 64 pixels fit a CU's LDS, so a single wave per group leaves three SIMDs idle and
+// pays every instruction of the serial chain in full.  Wave 0 runs the generator side (seed, scrambles, the burn-in
+// draws, then the partners of every step, four steps per group) and hands the partners over through a small LDS ring;
+// wave 1 initialises the table meanwhile and performs the swaps; both write the result out.  The two instruction
+// streams run on different SIMDs side by side: the time per step is the longer of the two instead of their sum.
+// Hand-over: `prod` / `cons` count finished groups (published every 4 groups, bounded spins, a protocol error traps).
+#define DR_GEN_RING 16  // groups of 4 partners per lane in the ring
+DR_DEV void gen_wait(uint32_t* word, uint32_t want) {
+  for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+    if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_trap();
+}
+__global__ void __launch_bounds__(128) k_gen_samples_pc(RenderParams rp, BatchState st, uint32_t npix) {
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  typedef uint16_t PT;
+  const int spp = rp.spp, G = spp / 4;
+  PT* s_perm = (PT*)s_raw;                                                   // [spp / 2][64][2]
+  uint32_t* s_magic = (uint32_t*)(s_raw + (size_t)spp * 64 * sizeof(PT));   // [spp + 1]: floor(2^32 / m)
+  uint2* s_ring = (uint2*)(s_magic + ((spp + 2) & ~1));                      // [DR_GEN_RING][64]: four 16-bit partners
+  uint32_t* s_flag = (uint32_t*)(s_ring + DR_GEN_RING * 64);                // prod, cons
+  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+  const uint32_t p = blockIdx.x * 64u + (uint32_t)lane;
+  const bool valid = p < npix;
+  const int k = gen_block(rp);
+  const bool is2D = k < 2 || k >= 3 + rp.n1D;
+  auto at = [&](int i) -> PT& { return s_perm[(i >> 1) * 128 + lane * 2 + (i & 1)]; };
+  for (int m = 1 + (int)threadIdx.x; m <= spp; m += 128) s_magic[m] = m == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)m);
+  if (threadIdx.x < 2) s_flag[threadIdx.x] = 0u;
+  __syncthreads();
+  if (role == 0) {
+    // ---- generator side ----
+    const int2 xy = st.pix[valid ? p : npix - 1u];
+    const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
+    DartRandom rng;
+    rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
+    const uint32_t scr0 = rng.randomUint(), scr1 = is2D ? rng.randomUint() : 0u;  // LDShuffleScrambled1D/2D (montecarlo.dart:524-551)
+    if (valid) {
+      st.svScr[(size_t)(2 * k) * st.pixCap + p] = scr0;
+      st.svScr[(size_t)(2 * k + 1) * st.pixCap + p] = scr1;
+    }
+    auto draws = [&](uint32_t* r, int n) {  // as in k_gen_samples_lm: plain steps, redone the slow way after a rare value
+      const DartRandom saved = rng;
+      bool rare = rp.genSlowDraws != 0;
+      for (int j = 0; j < n; ++j) {
+        rng.step();
+        rare |= rng.lo == 0xffffffffu;
+        if (r) r[j] = rng.lo;
+      }
+      if (__ballot(rare) != 0ull) {
+        rng = saved;
+        for (int j = 0; j < n; ++j) {
+          const uint32_t v = rng.randomUint();
+          if (r) r[j] = v;
+        }
+      }
+    };
+    for (int i = 0; i < spp; i += 16) draws(nullptr, 16);  // Shuffle of ONE entry, spp times (:294-303)
+    for (int g = 0; g < G; ++g) {
+      if ((g & 3) == 0 && g + 4 > DR_GEN_RING) gen_wait(&s_flag[1], (uint32_t)(g + 4 - DR_GEN_RING));  // room for four more groups
+      uint32_t r[4];
+      draws(r, 4);
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t m = (uint32_t)(spp - 4 * g - j);
+        uint32_t rem = r[j] - __umulhi(r[j], s_magic[m]) * m;
+        if (rem >= m) rem -= m;
+        o[j] = (uint32_t)(4 * g + j) + rem;
+      }
+      s_ring[(g % DR_GEN_RING) * 64 + lane] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+      if ((g & 3) == 3 && lane == 0) __hip_atomic_store(&s_flag[0], (uint32_t)(g + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  } else {
+    // ---- table side ----
+    uint32_t* cols = (uint32_t*)s_raw + lane;
+    for (int d = 0; d < spp / 2; ++d) cols[d * 64] = (uint32_t)(2 * d) | ((uint32_t)(2 * d + 1) << 16);  // at(i) = i
+    for (int g = 0; g < G; ++g) {
+      if ((g & 3) == 0) gen_wait(&s_flag[0], (uint32_t)(g + 4));
+      const uint2 q = s_ring[(g % DR_GEN_RING) * 64 + lane];
+      const int i = 4 * g;
+      int o[4] = {(int)(q.x & 0xffffu), (int)(q.x >> 16), (int)(q.y & 0xffffu), (int)(q.y >> 16)};
+      PT R[4], A[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        R[j] = at(o[j]);
+        A[j] = at(i + j);
+      }
+      PT av[4], bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        PT aj = A[j], bj = R[j];
+#pragma unroll
+        for (int kk = 0; kk < j; ++kk) {  // oldest first: the newest write wins
+          if (o[kk] == i + j) aj = av[kk];
+          if (o[kk] == o[j]) bj = av[kk];
+        }
+        av[j] = aj;
+        bv[j] = bj;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        at(i + j) = bv[j];
+        at(o[j]) = av[j];
+      }
+      if ((g & 3) == 3 && lane == 0) __hip_atomic_store(&s_flag[1], (uint32_t)(g + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();
+  // write-out: a lane's spp entries are spp / 64 whole 64-entry index runs (128 B each); the two waves take alternate runs
+  if (valid) {
+    const uint32_t* cols = (const uint32_t*)s_raw + lane;
+    const size_t tile0 = ((size_t)p * (size_t)spp) >> 6;
+    for (int t = role; t < spp / 64; t += 2) {
+      uint4* o = (uint4*)(st.svIdx() + (tile0 + t) * (size_t)st.tileStride * 4 + (size_t)k * 64 * sizeof(PT));
+      for (int q = 0; q < 8; ++q) {
+        const int d = t * 32 + 4 * q;
+        o[q] = make_uint4(cols[(d + 0) * 64], cols[(d + 1) * 64], cols[(d + 2) * 64], cols[(d + 3) * 64]);
+      }
+    }
+  }
+}
+
 // Blocks with n > 1 entries per pixel sample (DirectLighting with light nsamples > 1): lane = pixel, the
 // n*spp values are generated and shuffled in place in the sample-vector arrays.  Element (sample i, entry j,
 // dim d) lives at sv[(dst + dims*j + d)][p*spp + i].  Rare configuration: correctness over speed.
@@ -1467,12 +1592,19 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t n
     if (rp.spp <= 256) {
       hipLaunchKernelGGL(k_gen_samples_lm<uint8_t>, g, dim3(ln), lds, s, rp, st, npix);
     } else {
+      static const bool onePerGroup = getenv("DARTRAY_GEN_ONE_WAVE") != nullptr;  // A/B: the single-wave kernel
       static bool attrSet = false;
       if (!attrSet) {
         (void)hipFuncSetAttribute((const void*)k_gen_samples_lm<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_gen_samples_pc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrSet = true;
       }
-      hipLaunchKernelGGL(k_gen_samples_lm<uint16_t>, g, dim3(ln), lds, s, rp, st, npix);
+      if (!onePerGroup && !lanesEnv) {
+        const size_t ldsPc = (size_t)rp.spp * 64 * 2 + (((size_t)rp.spp + 2) & ~(size_t)1) * 4 + (size_t)DR_GEN_RING * 64 * 8 + 16;
+        hipLaunchKernelGGL(k_gen_samples_pc, dim3((npix + 63) / 64, nGen), dim3(128), ldsPc, s, rp, st, npix);
+      } else {
+        hipLaunchKernelGGL(k_gen_samples_lm<uint16_t>, g, dim3(ln), lds, s, rp, st, npix);
+      }
     }
     return;
   }
