@@ -356,6 +356,9 @@ def test_unread_sample_blocks_can_be_left_out():
         "    films.append(r.render(scenes.make_scene(prims)).film)\n"
         "prims2 = scenes.cornell_walls() + [scenes.emitter_quad(), core.GeometricPrimitive(scenes.blob_mesh(16, 8), core.MirrorMaterial((0.9, 0.9, 0.9)))]\n"
         "films.append(mk().render(scenes.make_scene(prims2)).film)\n"
+        "prims3, mk3 = scenes.config('C2', xres=96, yres=80, spp=512, blob=(20, 10))\n"   # 512 spp: the two-wave sampler kernel
+        "r3 = mk3(); r3.taskNum, r3.taskCount = 5, 60\n"
+        "films.append(r3.render(scenes.make_scene(prims3)).film)\n"
         "np.save(sys.argv[1], np.stack([f[:80, :96] for f in films]))\n" % ROOT)
     out = []
     # third run: the device sampler draws its generator values in groups of plain steps and redoes a group the slow way
@@ -375,7 +378,7 @@ def test_unread_sample_blocks_can_be_left_out():
         assert res.returncode == 0, res.stderr[-2000:]
         out.append(np.load(path))
         os.remove(path)
-    assert out[0].shape[0] == 4 and np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+    assert out[0].shape[0] == 5 and np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
     assert out[0][..., :3].max() > 0
 
 

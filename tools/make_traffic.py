@@ -22,7 +22,9 @@ def pmc(path):
 
 
 rd, wr, sq = pmc("%s/pmc_%s_rdreq.txt" % (src, cfg)), pmc("%s/pmc_%s_wrreq.txt" % (src, cfg)), pmc("%s/pmc_%s_sq.txt" % (src, cfg))
-stats = {r["Name"]: r for r in csv.DictReader(open("%s/%s_kernel_stats.csv" % (src, cfg)))}
+import os
+_serial = "%s/%s_kernel_stats_serial.csv" % (src, cfg)  # one kernel at a time (profile_r02.sh): per-kernel durations
+stats = {r["Name"]: r for r in csv.DictReader(open(_serial if os.path.exists(_serial) else "%s/%s_kernel_stats.csv" % (src, cfg)))}
 bench = json.load(open("%s/%s_bench.json" % (src, cfg)))
 res = {"workload": bench["config"]["workload"], "bench_value_under_rocprof": bench["value"], "kernels": {}}
 for name in rd:

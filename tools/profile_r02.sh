@@ -29,6 +29,21 @@ SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CY
 stats c2 "DARTRAY_TRACE_IMPL=2" "$B"
 stats c4 "DARTRAY_TRACE_IMPL=3" "--config C4 $B"
 stats c5 "DARTRAY_TRACE_IMPL=2" "--config C5 --steps 2 --warmup 1 --no-cpu-baseline --no-extra"
+# the same commands with one kernel at a time (a stage's any-hit launch otherwise runs beside its closest-hit launch and
+# its entry in the table is the span from submission to end): per-kernel durations for the traffic files
+for cfg in c2 c4 c5; do
+  for f in kernel_stats bench; do [ -f "$root/$out/${cfg}_$f.csv" ] && mv "$root/$out/${cfg}_$f.csv" "$root/$out/${cfg}_${f}_sbs.csv"; done
+  mv "$root/$out/${cfg}_bench.json" "$root/$out/${cfg}_bench_sbs.json"
+done
+stats c2 "DARTRAY_TRACE_IMPL=2 DARTRAY_OVERLAP_ANY=0" "$B"
+stats c4 "DARTRAY_TRACE_IMPL=3 DARTRAY_OVERLAP_ANY=0" "--config C4 $B"
+stats c5 "DARTRAY_TRACE_IMPL=2 DARTRAY_OVERLAP_ANY=0" "--config C5 --steps 2 --warmup 1 --no-cpu-baseline --no-extra"
+for cfg in c2 c4 c5; do
+  mv "$root/$out/${cfg}_kernel_stats.csv" "$root/$out/${cfg}_kernel_stats_serial.csv"
+  mv "$root/$out/${cfg}_bench.json" "$root/$out/${cfg}_bench_serial.json"
+  mv "$root/$out/${cfg}_kernel_stats_sbs.csv" "$root/$out/${cfg}_kernel_stats.csv"
+  mv "$root/$out/${cfg}_bench_sbs.json" "$root/$out/${cfg}_bench.json"
+done
 for cfg in c2 c4; do
   if [ $cfg = c2 ]; then e="DARTRAY_TRACE_IMPL=2"; a="$P"; else e="DARTRAY_TRACE_IMPL=3"; a="--config C4 $P"; fi
   pmc ${cfg}_rdreq "$e" "$a" "$RD"
