@@ -2,12 +2,12 @@
 //   k_shade_path     PathIntegrator.Li vertex step      (surface_integrators/path_integrator.dart:29-122,
 //                                                        core/integrator.dart:79-185)
 //   k_shade_direct   DirectLightingIntegrator.Li         (surface_integrators/direct_lighting_integrator.dart:30-68)
-//   k_gen_samples(_lm / _multi)  LDPixelSample           (core/montecarlo.dart:407-551)
+//   k_gen_samples(_lm / _pc / _multi)  LDPixelSample     (core/montecarlo.dart:407-551; _pc: two waves per 64 pixels, 512+ spp)
 //   k_raygen         Perspective / Orthographic / EnvironmentCamera.generateRay (cameras/*.dart)
 //   k_film / k_film_resolve  ImageFilm.addSample / writeImage (film/image_film.dart:99-185,268-299)
 //
 // One path per lane, 64-lane waves, path state in 64-slot tiles (BatchState, dr_kernels.h).  The shade kernels run
-// one large workgroup per CU, grid-stride over the active list, and stage their queue entries in LDS; what bounds
+// one large workgroup per CU whose waves take chunks of the active list and stage their queue entries in LDS; what bounds
 // each kernel is in DESIGN.md section 3 / 5.  The path is about 1 flop per byte: no MFMA.
 //
 // Compiled with -ffp-contract=off: the Dart VM never fuses a*b+c.
