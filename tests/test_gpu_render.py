@@ -364,21 +364,26 @@ def test_unread_sample_blocks_can_be_left_out():
     # third run: the device sampler draws its generator values in groups of plain steps and redoes a group the slow way
     # (Random.nextInt's retry loop) when a lane saw the one value in 2^32 that is redrawn; DARTRAY_GEN_SLOW_DRAWS=1 takes
     # that path for every group -- the streams must not change
-    for gen_all, slow in ((False, False), (True, False), (False, True)):
-        path = os.path.join(ROOT, "gpurun_out", "film_gen%d%d.npy" % (gen_all, slow))
+    # fourth run: a stage's any-hit launch after its closest-hit launch instead of beside it (DARTRAY_OVERLAP_ANY=0) and
+    # the single-wave sampler kernel at 512 spp (DARTRAY_GEN_ONE_WAVE=1)
+    for gen_all, slow, serial in ((False, False, False), (True, False, False), (False, True, False), (False, False, True)):
+        path = os.path.join(ROOT, "gpurun_out", "film_gen%d%d%d.npy" % (gen_all, slow, serial))
         os.makedirs(os.path.dirname(path), exist_ok=True)
         env = dict(os.environ)
-        env.pop("DARTRAY_GEN_ALL_BLOCKS", None)
-        env.pop("DARTRAY_GEN_SLOW_DRAWS", None)
+        for k in ("DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_GEN_SLOW_DRAWS", "DARTRAY_OVERLAP_ANY", "DARTRAY_GEN_ONE_WAVE"):
+            env.pop(k, None)
         if gen_all:
             env["DARTRAY_GEN_ALL_BLOCKS"] = "1"
         if slow:
             env["DARTRAY_GEN_SLOW_DRAWS"] = "1"
+        if serial:
+            env["DARTRAY_OVERLAP_ANY"] = "0"
+            env["DARTRAY_GEN_ONE_WAVE"] = "1"
         res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=500)
         assert res.returncode == 0, res.stderr[-2000:]
         out.append(np.load(path))
         os.remove(path)
-    assert out[0].shape[0] == 5 and np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+    assert out[0].shape[0] == 5 and all(np.array_equal(out[0], o) for o in out[1:])
     assert out[0][..., :3].max() > 0
 
 
