@@ -272,7 +272,9 @@ class Run:
                                        "tests but is not a throughput mode (one serial stream; 148 B + RNG tail per sample over PCIe)"},
             "roofline": roof,
             "roofline_shade": shade,
-            "kernel_ms_per_step": {k: round(st[k] / steps, 2) for k in ("closest_ms", "any_ms", "shade_ms", "gen_ms", "film_ms", "total_ms")},
+            "kernel_ms_per_step": dict({k: round(st[k] / steps, 2) for k in ("closest_ms", "any_ms", "shade_ms", "gen_ms", "film_ms", "total_ms")},
+                                       note="a stage's any-hit launch runs beside its closest-hit launch (second stream): any_ms is its time "
+                                            "after the closest-hit launch ended" if os.environ.get("DARTRAY_OVERLAP_ANY", "1") != "0" else "one kernel at a time"),
             "per_sample": {"rays": round((st["closest_rays"] + st["any_rays"]) / max(1, st["camera_samples"]), 3),
                            "nodes": round((st["closest_nodes"] + st["any_nodes"]) / max(1, st["camera_samples"]), 2),
                            "tris": round((st["closest_tris"] + st["any_tris"]) / max(1, st["camera_samples"]), 3),
