@@ -1111,7 +1111,7 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
 void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
   const int impl = traceImpl(sc, anyHit);
-  if (impl == 3) grid = std::min(grid, traceGridFor(5));                          // k_trace3: 30 KiB of LDS, 5 resident
+  if (impl == 3) grid = std::min(grid, traceGridFor(DR_TRACE3_WAVES));                        // k_trace3: 30 KiB of LDS, 5 resident
   else if (!(impl == 2 && !sc.nquads)) grid = std::min(grid, traceGridFor(6));  // only k_trace fits 7 workgroups per CU
   const dim3 g(grid), b(DR_TRACE_BLOCK);
   if (impl == 3) {
