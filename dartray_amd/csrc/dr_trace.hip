@@ -31,6 +31,19 @@
 #ifndef DR_REFILL_TH
 #define DR_REFILL_TH 16
 #endif
+// k_trace's own thresholds per ray kind (closest hit, any hit); the other kernels use the two above
+#ifndef DR_REFILL_TH_C
+#define DR_REFILL_TH_C DR_REFILL_TH
+#endif
+#ifndef DR_REFILL_TH_A
+#define DR_REFILL_TH_A DR_REFILL_TH
+#endif
+#ifndef DR_LEAF_TH_C
+#define DR_LEAF_TH_C 14  // (end of round 2, queue in 512-entry runs: 14 is 0.3 % better than 12 for closest hits; 16 / 20 / 24 any-hit lanes: no gain)
+#endif
+#ifndef DR_LEAF_TH_A
+#define DR_LEAF_TH_A 12
+#endif
 #ifndef DR_LEAF_TH
 #define DR_LEAF_TH 12
 #endif
@@ -486,7 +499,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
     // ---- refill idle lanes ----
     const unsigned long long idleMask = __ballot(mode == M_IDLE);
     const int nIdle = __popcll(idleMask);
-    if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
+    if (!exhausted && (nIdle >= (ANY ? DR_REFILL_TH_A : DR_REFILL_TH_C) || nIdle == 64)) {
       if (resNext == resEnd) {
         // Reserve DR_WORK_CHUNK entries per atomic: same-address atomics are a chip-wide serial resource.
         for (;;) {
@@ -612,7 +625,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
     // ---- batched leaf tests (bvh_accel.dart:126-143 / :189-204) ----
     leafMask = __ballot(mode == M_LEAF);
     const unsigned long long stillTrav = __ballot(mode == M_TRAV && !finished);
-    if (leafMask != 0ull && (__popcll(leafMask) >= DR_LEAF_TH || stillTrav == 0ull)) {
+    if (leafMask != 0ull && (__popcll(leafMask) >= (ANY ? DR_LEAF_TH_A : DR_LEAF_TH_C) || stillTrav == 0ull)) {
       TPROF_COUNT(6, 1);
       if (mode == M_LEAF) {
         bool occluded = false;
