@@ -1405,31 +1405,76 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(true), SHADE_WAVES_OF(true)) k_
 }
 
 // ---------------------------------------------------------------------------
-// film (image_film.dart:99-185).  A block owns 1024 consecutive slots (whole pixels: spp is a power of
-// two <= 1024, dr_render refuses more): first lane = sample (coalesced reads of L and the image
-// sample; XYZ conversion and filter weight; the sample's contribution to its OWN pixel parked in LDS,
-// contributions to other pixels -- wide filters, or imageX exactly integral -- sent through float atomics),
-// then lane = pixel adds the parked contributions in the reference's sample order.
+// film (image_film.dart:99-185).  First lane = sample (coalesced reads of L and the image sample; XYZ conversion
+// and filter weight; the sample's contribution to its OWN pixel parked in LDS, contributions to other pixels -- wide
+// filters, or imageX exactly integral -- sent through float atomics), then lane = (pixel, channel) adds the parked
+// contributions in the reference's sample order: one serial f32 chain per lane.
+// spp >= 64: a block owns 16 pixels and walks their samples 64 at a time (one 64-slot tile per pixel and pass: 1024
+// samples in LDS), so that all 64 lanes of the adding wave carry a chain (16 pixels x X, Y, Z, weight) whatever spp is;
+// with one 1024-slot chunk per block only 4096 / spp lanes did (4 at 1024 spp: 22 of the kernel's 32 ms).
+// spp < 64: a block owns 1024 consecutive slots = 1024 / spp whole pixels, one pass.
 // ---------------------------------------------------------------------------
 #define DR_FILM_CHUNK 1024
 __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, const float* table, uint32_t npix, float* film) {
-  __shared__ float s_X[DR_FILM_CHUNK], s_Y[DR_FILM_CHUNK], s_Z[DR_FILM_CHUNK], s_W[DR_FILM_CHUNK];
-  __shared__ uint8_t s_own[DR_FILM_CHUNK];
+  __shared__ float s_X[DR_FILM_CHUNK + 16], s_Y[DR_FILM_CHUNK + 16], s_Z[DR_FILM_CHUNK + 16], s_W[DR_FILM_CHUNK + 16];
+  __shared__ uint8_t s_own[DR_FILM_CHUNK + 16];
   __shared__ float s_one[1];
   const uint32_t cap = st.tileStride;  // words per 64-slot tile
   const uint32_t spp = (uint32_t)rp.spp;
-  const uint64_t base = (uint64_t)blockIdx.x * DR_FILM_CHUNK;
   const uint32_t nslots = st.nslots;
-  const uint32_t perPix = spp;                      // samples of one pixel
-  const uint32_t nPixChunk = DR_FILM_CHUNK / spp;   // pixels of this block
-  {
-    if (threadIdx.x == 0) s_one[0] = 1.0f;
+  const bool tiled = spp >= 64u;                              // 16 pixels x 64 samples per pass
+  const uint32_t seg = tiled ? 64u : spp;                     // samples of one pixel per pass
+  const uint32_t segShift = tiled ? 6u : (uint32_t)rp.sppShift;
+  const uint32_t str = tiled ? 65u : spp;                     // LDS row pitch (65: the 16 rows start in 16 different banks)
+  const uint32_t nPixBlk = DR_FILM_CHUNK >> segShift;         // pixels of this block
+  const uint32_t p0 = blockIdx.x * nPixBlk;                   // its first batch pixel
+  const uint32_t nPass = tiled ? spp >> 6 : 1u;
+  if (threadIdx.x == 0) s_one[0] = 1.0f;
+  float acc = 0.f;  // tiled: lane (pixel, channel) of wave 0 keeps its chain across the passes
+  auto add = [&](float& a, uint8_t own, float wt, float v) {
+    const float t = (float)((double)a + (double)wt * (double)v);  // _Lxyz += wt * xyz; weightSum += wt (wt * 1.0 is exact)
+    a = own ? t : a;
+  };
+  // Eight samples per trip, branch-free, every load unconditional (the weight lane reads its factor 1.0 from LDS with
+  // stride 0): a group's LDS reads are in flight together and only the additions are serial.
+  auto chain = [&](float& a, uint32_t row, uint32_t c, uint32_t n) {
+    const float* src = c == 0 ? s_X : (c == 1 ? s_Y : (c == 2 ? s_Z : s_one));
+    const uint32_t step = c == 3u ? 0u : 1u, first = c == 3u ? 0u : row;
+    if (n >= 8u) {
+      for (uint32_t i = 0; i < n; i += 8u) {
+        float v[8], wv[8];
+        uint8_t ow[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+          wv[j] = s_W[row + i + j];
+          ow[j] = s_own[row + i + j];
+          v[j] = src[first + (i + j) * step];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) add(a, ow[j], wv[j], v[j]);
+      }
+    } else {
+      for (uint32_t i = 0; i < n; ++i) add(a, s_own[row + i], s_W[row + i], src[first + i * step]);
+    }
+  };
+  auto flush = [&](uint32_t pl, uint32_t c, float a) {
+    const uint32_t p = p0 + pl;
+    if (p < npix) {
+      const int2 xy = st.pix[p];
+      if (xy.x >= rp.left && xy.x < rp.left + rp.width && xy.y >= rp.top && xy.y < rp.top + rp.height)
+        atomicAdd(film + 4 * ((size_t)(xy.y - rp.top) * rp.width + (size_t)(xy.x - rp.left)) + c, a);
+    }
+  };
+  for (uint32_t pass = 0; pass < nPass; ++pass) {
+    if (pass) __syncthreads();  // the previous pass's rows have been added
     for (uint32_t e = threadIdx.x; e < DR_FILM_CHUNK; e += 256u) {
-      const uint64_t s64 = base + e;
+      const uint32_t pl = e >> segShift, j = e & (seg - 1u);
+      const uint32_t le = pl * str + j;  // where this sample parks
+      const uint64_t s64 = (uint64_t)(p0 + pl) * spp + (uint64_t)pass * seg + j;
       uint8_t own = 0;
-      if (s64 < nslots) {
+      if (p0 + pl < npix && s64 < nslots) {
         const uint32_t s = (uint32_t)s64;
-        const int2 xy = st.pix[s >> rp.sppShift];
+        const int2 xy = st.pix[p0 + pl];
         C3 L = ldc(st.L(), cap, s);
         if (rp.deferredNee) {
           // the last light term of a path that ended (PF_DEFERRED, k_shade_path): L += pathThroughput * Ld unless the
@@ -1466,7 +1511,7 @@ __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, co
               const int ix = min((int)floor(fx), 15);
               const float wt = table[iy * 16 + ix];
               if (x == xy.x && y == xy.y) {
-                s_X[e] = X; s_Y[e] = Y; s_Z[e] = Z; s_W[e] = wt;
+                s_X[le] = X; s_Y[le] = Y; s_Z[le] = Z; s_W[le] = wt;
                 own = 1;
               } else {
                 float* px = film + 4 * ((size_t)(y - rp.top) * rp.width + (size_t)(x - rp.left));
@@ -1479,49 +1524,20 @@ __global__ void __launch_bounds__(256) k_film(RenderParams rp, BatchState st, co
           }
         }
       }
-      s_own[e] = own;
+      s_own[le] = own;
     }
     __syncthreads();
-    // lane = (pixel, channel): X, Y, Z and the weight sum are four independent f32 chains, each in the reference's
-    // sample order.  Branch-free and eight samples per trip, every load unconditional (the weight lane reads its factor
-    // 1.0 from LDS with stride 0), so that a group's LDS reads are in flight together and only the additions are serial:
-    // a branch on s_own and three dependent reads per sample took ~200 cycles per sample (43 of the kernel's 52 ms at
-    // 1024 spp).  One wave per block does this (more waves with one busy lane each only compete for the SIMDs: 67 ms).
-    for (uint32_t w = threadIdx.x; w < 4u * nPixChunk; w += 256u) {
-      const uint32_t pl = w >> 2, c = w & 3u;
-      const uint32_t e0 = pl * perPix;
-      const float* src = c == 0 ? s_X : (c == 1 ? s_Y : (c == 2 ? s_Z : s_one));
-      const uint32_t step = c == 3u ? 0u : 1u, first = c == 3u ? 0u : e0;
-      float acc = 0.f;
-      auto add = [&](uint8_t own, float wt, float v) {
-        const float t = (float)((double)acc + (double)wt * (double)v);  // _Lxyz += wt * xyz; weightSum += wt (wt * 1.0 is exact)
-        acc = own ? t : acc;
-      };
-      if (perPix >= 8u) {
-        for (uint32_t i = 0; i < perPix; i += 8u) {
-          const uint32_t e = e0 + i;
-          float v[8], wv[8];
-          uint8_t ow[8];
-#pragma unroll
-          for (uint32_t j = 0; j < 8u; ++j) {
-            wv[j] = s_W[e + j];
-            ow[j] = s_own[e + j];
-            v[j] = src[first + (i + j) * step];
-          }
-#pragma unroll
-          for (uint32_t j = 0; j < 8u; ++j) add(ow[j], wv[j], v[j]);
-        }
-      } else {
-        for (uint32_t i = 0; i < perPix; ++i) add(s_own[e0 + i], s_W[e0 + i], src[first + i * step]);
-      }
-      const uint64_t s64 = base + e0;  // the first slot of this lane's pixel
-      if (s64 < nslots) {
-        const int2 xy = st.pix[(uint32_t)s64 >> rp.sppShift];
-        if (xy.x >= rp.left && xy.x < rp.left + rp.width && xy.y >= rp.top && xy.y < rp.top + rp.height)
-          atomicAdd(film + 4 * ((size_t)(xy.y - rp.top) * rp.width + (size_t)(xy.x - rp.left)) + c, acc);
+    if (tiled) {
+      if (threadIdx.x < 64u) chain(acc, (threadIdx.x >> 2) * str, threadIdx.x & 3u, 64u);  // 16 pixels x 4 channels
+    } else {
+      for (uint32_t w = threadIdx.x; w < 4u * nPixBlk; w += 256u) {
+        float a = 0.f;
+        chain(a, (w >> 2) * str, w & 3u, spp);
+        flush(w >> 2, w & 3u, a);
       }
     }
   }
+  if (tiled && threadIdx.x < 64u) flush(threadIdx.x >> 2, threadIdx.x & 3u, acc);
 }
 
 // ImageFilm.writeImage (image_film.dart:268-299), splat == 0.
@@ -1675,7 +1691,8 @@ void launch_shade_spec(const DScene& sc, const RenderParams& rp, const BatchStat
 }
 void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
                  hipStream_t s) {
-  const uint64_t nblk = ((uint64_t)npix * (uint64_t)rp.spp + DR_FILM_CHUNK - 1) / DR_FILM_CHUNK;
+  const uint64_t nblk = rp.spp >= 64 ? ((uint64_t)npix + 15) / 16  // 16 pixels per block, 64 samples of each per pass
+                                     : ((uint64_t)npix * (uint64_t)rp.spp + DR_FILM_CHUNK - 1) / DR_FILM_CHUNK;
   if (nblk == 0) return;
   hipLaunchKernelGGL(k_film, dim3((unsigned)nblk), dim3(256), 0, s, rp, st, filterTable, npix, film);
 }
