@@ -62,6 +62,7 @@ struct Workspace {
   DevBuf<uint32_t> scr;  // compact samples: scramble words [2 * nBlocks][pixCap]
   DevBuf<double> tail;
   DevBuf<uint32_t> activeA, activeB, closestQ, anyQ, counters, spill;
+  DevBuf<uint32_t> envQ;  // plain-triangle scenes under an environment map: k_env's list of a stage (cap entries)
   size_t spillHalf = 0;
   DevBuf<uint32_t> roundA, roundB;  // DirectLighting over mirror / glass: the slots whose child ray is traced next round
   DevBuf<float> specFrames;         //   [maxDepth][cap] SpecFrame
@@ -72,7 +73,8 @@ struct Workspace {
 };
 
 #define DR_STATE_WORDS F_SAMPLES  // 41 4-byte words of fixed path state per slot: 3 f64 + 10 3-vectors + 5 i32
-#define N_COUNTERS (1024 + 8 * DR_WORK_STRIDE * 400)  // [0,1024): stage queue counts; then 8 per-XCD work counters per trace launch, DR_WORK_STRIDE words apart
+#define N_COUNTERS_TRACE (1024 + 8 * DR_WORK_STRIDE * 400)
+#define N_COUNTERS (N_COUNTERS_TRACE + 64 * 256)  // ... then the counts of k_env's lists, one cache line per stage  // [0,1024): stage queue counts; then 8 per-XCD work counters per trace launch, DR_WORK_STRIDE words apart
 
 }  // namespace
 
@@ -81,7 +83,7 @@ int dr_fail(int code, const std::string& msg) { return fail(code, msg); }  // fo
 struct DrScene {
   DScene d;
   DevBuf<uint4> nodes, pairs;
-  DevBuf<float4> tris, mats;
+  DevBuf<float4> tris, mats, shtris;
   DevBuf<DLight> lights;
   DevBuf<DLightTri> ltris;
   DevBuf<DQuadric> quads;
@@ -907,6 +909,14 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   sc->d.nmats = desc->nmaterials;
   sc->d.nltris = desc->nlight_tris;
   sc->d.ncdf = (uint32_t)sc->lcdf.n;
+  // plain triangles + matte materials (the !QUAD shade kernels): the 32-byte shading records (ShTri in dr_device.h)
+  sc->d.shtris = nullptr;
+  if (!(sc->d.nquads || sc->d.hasSpec || sc->d.srec) && desc->ntris) {
+    TRY_SC(sc->shtris.alloc(2 * desc->ntris));
+    launch_make_shtris(sc->d, sc->shtris.p, desc->ntris, 0);
+    TRY_SC(hipDeviceSynchronize());
+    sc->d.shtris = sc->shtris.p;
+  }
   {  // DirectLighting: one 1-D + one 2-D slot pair per light for the light sample and one for the BSDF sample, each
      // with roundSize(nSamples) entries (low_discrepancy_sampler.dart:43-49), then the two 1-D volume slots
     auto rp2 = [](int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; };
@@ -1231,7 +1241,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   size_t batchIndex = 0;
   const int sgrid = g_numCU;  // the shade launchers size their grid per CU (DR_SHADE_GRID), grid-stride over the active list
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
-  if (nStages > 248 || 8 * DR_WORK_STRIDE * (1 + 2 * nStages) > N_COUNTERS - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
+  if (nStages > 248 || 8 * DR_WORK_STRIDE * (1 + 2 * nStages) > N_COUNTERS_TRACE - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
+  // k_env (dr_kernels.hip): the environment-map work of a plain-triangle scene's path stages runs in its own kernel
+  const bool envStage = rd->integrator == DR_INTEGRATOR_PATH && sc->d.hasEnv && !(sc->d.nquads || sc->d.hasSpec || sc->d.srec);
+  if (envStage) {
+    HIP_TRY(sc->ws.envQ.alloc(sc->ws.cap));
+    if (twoPipes) HIP_TRY(sc->ws2.envQ.alloc(sc->ws2.cap));
+  }
 
   // One batch through the stage loop.  pilot != null: a calibration batch -- a normal batch whose traversal launches are
   // also collected into pilot->ev[kind] (see above).
@@ -1286,7 +1302,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     for (int round = 0; round < maxRounds; ++round) {
     if (round > 0) {  // the stage counters are reused every round; the round lists' counts live behind them
       HIP_TRY(hipMemsetAsync(C, 0, 1000 * sizeof(uint32_t), s));
-      HIP_TRY(hipMemsetAsync(C + 1024, 0, (N_COUNTERS - 1024) * sizeof(uint32_t), s));
+      HIP_TRY(hipMemsetAsync(C + 1024, 0, (N_COUNTERS - 1024) * sizeof(uint32_t), s));  // (work counters and k_env's counts)
       wc = 0;
     }
     trace(roundQ, nRound, 0, s, w.spill.p);  // camera rays (or this round's child rays)
@@ -1305,10 +1321,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       q.nAny = cnt(2, b);
       q.work = cnt(3, b);
       q.ctr = sc->ctr.p;
+      q.envQ = envStage ? w.envQ.p : nullptr;
+      q.nEnv = C + N_COUNTERS_TRACE + 64 * b;
       hipEvent_t evS = sc->getEvent();
       (void)hipEventRecord(evS, s);
       if (rd->integrator == DR_INTEGRATOR_PATH) launch_shade_path(sc->d, rp, st, q, b, sgrid, s);
       else launch_shade_direct(sc->d, rp, st, q, b, sgrid, s);
+      if (envStage) launch_env(sc->d, rp, st, q, b, sgrid, s);
       timed(2, evS);
       if (b + 1 < nStages) {
         if (sideBySide) {
@@ -1359,6 +1378,15 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       launch_film(rp, st, sc->ws.filterTable.p, np, (float*)film_dev, s);
       timed(4, evF);
       sc->stats.batches++;
+    }
+    static const bool stageCounts = getenv("DARTRAY_STAGE_COUNTS") != nullptr;  // diagnostics: the batch's list lengths per stage
+    if (stageCounts) {
+      std::vector<uint32_t> hc(N_COUNTERS);
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipMemcpy(hc.data(), C, N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      for (int b = 0; b < nStages; ++b)
+        fprintf(stderr, "stage_counts batch %zu stage %d: in %u active_out %u closest %u any %u env %u\n", (size_t)sc->stats.batches, b,
+                b == 0 ? nslots : hc[248 * 0 + b - 1], hc[248 * 0 + b], hc[248 * 1 + b], hc[248 * 2 + b], hc[N_COUNTERS_TRACE + 64 * b]);
     }
     HIP_TRY(hipGetLastError());
     if (hostBuf) HIP_TRY(hipStreamSynchronize(s));  // host buffers of the next batch reuse the staging area

@@ -132,6 +132,15 @@ struct DScene {
   uint32_t npairs;
   const uint4* nodes;   // 2 x uint4 per node (DrBvhNode)
   const float4* tris;   // 3 x float4 per primitive
+  // Shading record of a triangle, 32 B (2 x float4), for scenes of plain triangles with matte materials (the !QUAD
+  // shade kernels; null otherwise): everything PathIntegrator.Li needs of a hit primitive that does not depend on the
+  // ray -- dg.nn (differential_geometry.dart:84-99, reverseOrientation applied), sn = normalize(dg.dpdu) of the BSDF
+  // frame (bsdf.dart:45-51), material and light ids -- evaluated once at upload by the same device functions the
+  // shade kernels used per vertex (tri_dg, vnormalize), so the bits are the same.  A 32-byte aligned record never
+  // straddles a cache line (the 48-byte vertex record does for a quarter of the primitives) and a path vertex no longer
+  // pays two normalisations (6 f64 divisions, 2 square roots) for values that are constants of the triangle.
+  //   s0 = (nn.x, nn.y, nn.z, sn.x)  s1 = (sn.y, sn.z, material, light(int))
+  const float4* shtris;
   const float4* mats;   // kd.rgb, sigma
   const DLight* lights;
   const DLightTri* ltris;
@@ -174,6 +183,22 @@ DR_DEV Tri load_tri(const DScene& sc, uint32_t prim) {
   t.reverse = w & 1u;
   t.kind = PRIM_KIND(w);
   t.quad = __float_as_uint(q0.x);
+  return t;
+}
+
+struct ShTri {
+  F3 nn, sn;
+  uint32_t mat;
+  int32_t light;
+};
+DR_DEV ShTri load_shtri(const DScene& sc, uint32_t prim) {
+  const float4* tp = sc.shtris + 2 * (size_t)prim;
+  const float4 s0 = tp[0], s1 = tp[1];
+  ShTri t;
+  t.nn = F3{s0.x, s0.y, s0.z};
+  t.sn = F3{s0.w, s1.x, s1.y};
+  t.mat = __float_as_uint(s1.z);
+  t.light = (int32_t)__float_as_uint(s1.w);
   return t;
 }
 
@@ -972,6 +997,24 @@ DR_DEV Bsdf make_bsdf(const LV& lv, const DGeo& dg, uint32_t mat) {
       b.ior = __hiloint2double((int)__float_as_uint(m3.y), (int)__float_as_uint(m3.x));
     }
   }
+  return b;
+}
+// The matte BSDF of a plain-triangle hit from its shading record (ShTri): the same values make_bsdf<false> derives
+// from the DifferentialGeometry, with nn and sn = normalize(dpdu) read instead of recomputed.
+template <class LV>
+DR_DEV Bsdf make_bsdf_pre(const LV& lv, F3 p, F3 nn, F3 sn, uint32_t mat) {
+  Bsdf b;
+  b.p = p;
+  b.nn = nn;
+  b.ng = nn;
+  b.sn = sn;
+  b.tn = vcross(b.nn, b.sn);
+  C3 r = clamp0(lv.mat(mat, 0));
+  b.R = r;
+  b.nBxDFs = cblack(r) ? 0 : 1;
+  b.mtype = DR_MATERIAL_MATTE;
+  b.on = false;
+  b.glossy = false;
   return b;
 }
 DR_DEV F3 bsdf_w2l(const Bsdf& b, F3 v) { return f3(vdot(v, b.sn), vdot(v, b.tn), vdot(v, b.nn)); }  // bsdf.dart:177-179

@@ -57,6 +57,7 @@ struct RenderParams {
                         // light, or a non-finite throughput); clear: Ld1 already is pathThroughput * (Ld1 * nLights)
 
 #define Q_MIS_BIT 0x80000000u
+#define Q_ENV_MISS_BIT 0x80000000u  // entry of the environment-map list: an escaped camera ray (else: a parked light estimate)
 #define Q_RESOLVE_BIT 0x40000000u  // active-list entry of k_shade_path: the slot has no vertex to shade, only a light estimate to fold in
 
 // State of one batch of camera samples.  Slot s belongs to batch pixel s >> sppShift, sample s & (spp-1).
@@ -66,8 +67,19 @@ struct RenderParams {
 // contiguous ~tileStride*4-byte region (a handful of DRAM rows) instead of 80 arrays a gigabyte apart.
 // Field pointers below already include the field's offset inside the tile: element (field, slot) is
 // ptr[TI(tileStride, slot)]; component c of a 3-vector is 64 words further per component; the f64 arrays use TD.
-#define TI(ts, s) ((size_t)((s) >> 6) * (size_t)(ts) + (size_t)((s) & 63u))
-#define TD(ts, s) ((size_t)((s) >> 6) * (size_t)((ts) >> 1) + (size_t)((s) & 63u))
+// Inside a tile the 41 state words of the 64 slots are laid out in SUB-TILES of DR_SUB slots (a power of two <= 64):
+// sub-tile j holds, for slots 64 t + DR_SUB j ... + DR_SUB - 1, every field as one run of DR_SUB words -- 164 * DR_SUB
+// contiguous bytes per sub-tile.  DR_SUB = 64 is the plain tile (every field one 256-byte run).  A smaller sub-tile
+// keeps a wave's dense accesses whole (a 128-byte line still only holds data of the wave's own slots) and lets a
+// SPARSE stage -- 3 % of C2's slots are alive at bounce 5, a quarter of C5's at bounce 2 -- touch 164 * DR_SUB / 128
+// lines per surviving slot instead of one line per field (~35).  The sample region keeps whole-tile runs (TI64).
+#ifndef DR_SUB
+#define DR_SUB 64
+#endif
+#define DR_SUB_WORDS (DR_STATE_WORDS_K * DR_SUB)  // words of one sub-tile
+#define TI64(ts, s) ((size_t)((s) >> 6) * (size_t)(ts) + (size_t)((s) & 63u))
+#define TI(ts, s) ((size_t)((s) >> 6) * (size_t)(ts) + (size_t)(((s) & 63u) / DR_SUB) * DR_SUB_WORDS + (size_t)((s) & (DR_SUB - 1u)))
+#define TD(ts, s) ((size_t)((s) >> 6) * (size_t)((ts) >> 1) + (size_t)(((s) & 63u) / DR_SUB) * (DR_SUB_WORDS / 2) + (size_t)((s) & (DR_SUB - 1u)))
 // Field offsets inside a tile, in 64-word (256-byte) runs: the three f64 fields first (8-byte aligned), then the
 // 3-vectors, the i32 fields and the sample region.  Every field address is ONE base pointer + a constant: the shade
 // kernels touch ~25 fields, and 25 separate pointers (50 SGPRs) pushed them into SGPR spilling -- two v_readlane
@@ -79,10 +91,11 @@ enum {
   F_RO0 = 38,     // (DirectLighting with quadrics / shading records only: outside the window below)
   F_SAMPLES = 41  // == DR_STATE_WORDS
 };
+#define DR_STATE_WORDS_K 41
 // The 32 runs F_RO .. F_FLAGS are exactly 8 KiB: the whole signed 13-bit immediate-offset window of a global_load /
 // global_store around ONE per-lane base address (SlotRef below), so the shade kernels reach every hot field of a slot
 // without any per-access address arithmetic.
-#define SLOT_BIAS (F_RO * 256 + 4096)
+#define SLOT_BIAS (DR_SUB == 64 ? F_RO * 256 + 4096 : 0)
 struct BatchState {
   uint32_t cap;     // slots allocated (a multiple of 64)
   uint32_t nslots;  // slots used by the current batch
@@ -105,7 +118,7 @@ struct BatchState {
   float* specFrames;
   int32_t* specSp;
 #define DR_FIELD(T, name, F) \
-  __host__ __device__ T* name() const { return (T*)(tiles + 64 * (F)); }
+  __host__ __device__ T* name() const { return (T*)(tiles + ((F) >= F_SAMPLES ? 64 : DR_SUB) * (F)); }
   DR_FIELD(double, rtmin, F_RTMIN)      // Ray.minDistance (isect.rayEpsilon after the first vertex)
   DR_FIELD(double, ht, F_HT)            // closest-hit parameter of the camera / continuation ray
   DR_FIELD(double, shTmax, F_SHTMAX)
@@ -144,16 +157,16 @@ struct SlotRef {
   char* a;
   char* b;
   DR_DEV static SlotRef of(const BatchState& st, uint32_t slot) {
-    char* tile = (char*)st.tiles + (size_t)(slot >> 6) * ((size_t)st.tileStride * 4);
+    char* tile = (char*)st.tiles + (size_t)(slot >> 6) * ((size_t)st.tileStride * 4) + ((slot & 63u) / DR_SUB) * (DR_SUB_WORDS * 4);
     SlotRef r;
-    r.a = tile + (slot & 63u) * 4 + SLOT_BIAS;
-    r.b = tile + (slot & 63u) * 8;
+    r.a = tile + (slot & (DR_SUB - 1u)) * 4 + SLOT_BIAS;
+    r.b = tile + (slot & (DR_SUB - 1u)) * 8;
     return r;
   }
-  template <int F> DR_DEV float& f32(int comp = 0) const { return *(float*)(a + ((F + comp) * 256 - SLOT_BIAS)); }
-  template <int F> DR_DEV int32_t& i32() const { return *(int32_t*)(a + (F * 256 - SLOT_BIAS)); }
-  template <int F> DR_DEV uint32_t& u32() const { return *(uint32_t*)(a + (F * 256 - SLOT_BIAS)); }
-  template <int F> DR_DEV double& f64() const { return *(double*)(b + F * 256); }
+  template <int F> DR_DEV float& f32(int comp = 0) const { return *(float*)(a + ((F + comp) * (DR_SUB * 4) - SLOT_BIAS)); }
+  template <int F> DR_DEV int32_t& i32() const { return *(int32_t*)(a + (F * (DR_SUB * 4) - SLOT_BIAS)); }
+  template <int F> DR_DEV uint32_t& u32() const { return *(uint32_t*)(a + (F * (DR_SUB * 4) - SLOT_BIAS)); }
+  template <int F> DR_DEV double& f64() const { return *(double*)(b + F * (DR_SUB * 4)); }
 };
 template <int F> DR_DEV F3 ld3f(const SlotRef& r) { return F3{LDS_STREAM(&r.f32<F>(0)), LDS_STREAM(&r.f32<F>(1)), LDS_STREAM(&r.f32<F>(2))}; }
 template <int F> DR_DEV C3 ldcf(const SlotRef& r) { return C3{LDS_STREAM(&r.f32<F>(0)), LDS_STREAM(&r.f32<F>(1)), LDS_STREAM(&r.f32<F>(2))}; }
@@ -197,6 +210,10 @@ struct StageQueues {
   uint32_t* nAny;
   TraceCounters* ctr;  // shade_* totals (one no-return atomic per counter, workgroup and flush)
   uint32_t* work;      // k_shade_path's chunk counter (zero at launch): waves take chunks of 64 * DR_PUSH_ITERS entries
+  // plain-triangle scenes under an environment map: the slots whose light estimate picked the infinite light and the
+  // escaped camera rays (| Q_ENV_MISS_BIT), written by k_shade_path, worked off by k_env before the stage's traversals
+  uint32_t* envQ;
+  uint32_t* nEnv;
 };
 
 // k_trace's per-XCD work counters of one launch sit this many words apart (same-line atomics serialise)
@@ -219,6 +236,7 @@ int traceGridFor(int wgPerCU);  // dr_api.hip: workgroups of a persistent traver
 // ---- launchers (dr_kernels.hip) ----
 void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t* mat, const int32_t* light,
                         const uint8_t* rev, float4* out, uint64_t ntris, hipStream_t s);
+void launch_make_shtris(const DScene& sc, float4* out, uint64_t ntris, hipStream_t s);
 void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
                       uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s, int forceImpl = 0);
 void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
@@ -228,6 +246,7 @@ void launch_transpose_samples(const float* aos, int stride, const BatchState& st
 void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s);
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s);
+void launch_env(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce, int grid, hipStream_t s);
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s);
 void launch_shade_spec(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int grid, hipStream_t s);

@@ -43,6 +43,19 @@ __global__ void k_gather_tris(const float* verts, const uint32_t* idx, const uin
   out[3 * i + 2] = q2;
 }
 
+// Shading records (ShTri, dr_device.h) of a plain-triangle scene: dg.nn and the BSDF frame's sn of every primitive,
+// with the functions the shade kernels would otherwise run per path vertex.
+__global__ void k_make_shtris(DScene sc, float4* out, uint64_t ntris) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntris) return;
+  const Tri tr = load_tri(sc, (uint32_t)i);
+  DGeo dg;
+  tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, F3{0, 0, 0}, 0.0, &dg);
+  const F3 sn = vnormalize(dg.dpdu);  // bsdf.dart:45-51
+  out[2 * i] = make_float4(dg.nn.x, dg.nn.y, dg.nn.z, sn.x);
+  out[2 * i + 1] = make_float4(sn.y, sn.z, __uint_as_float(tr.mat), __uint_as_float((uint32_t)tr.light));
+}
+
 // ---------------------------------------------------------------------------
 // LD sampler (montecarlo.dart:407-551), counter mode: lane = (pixel, LD block)
 // ---------------------------------------------------------------------------
@@ -96,7 +109,7 @@ DR_DEV int sv_block(const RenderParams& rp, int f) {
 // raw fetch of 1-D field f: float bits, or the permuted index + its scramble
 DR_DEV void sv_fetch1(const RenderParams& rp, const BatchState& st, uint32_t slot, int f, uint32_t* raw, uint32_t* scr) {
   if (st.svFloat) {
-    *raw = __float_as_uint(LDS_STREAM(st.sv() + TI(st.tileStride, slot) + (size_t)f * 64));
+    *raw = __float_as_uint(LDS_STREAM(st.sv() + TI64(st.tileStride, slot) + (size_t)f * 64));
     *scr = 0u;
     return;
   }
@@ -108,8 +121,8 @@ DR_DEV void sv_fetch1(const RenderParams& rp, const BatchState& st, uint32_t slo
 // raw fetch of the 2-D entry whose first float is field f
 DR_DEV void sv_fetch2(const RenderParams& rp, const BatchState& st, uint32_t slot, int f, uint32_t* raw, uint32_t* scr) {
   if (st.svFloat) {
-    raw[0] = __float_as_uint(LDS_STREAM(st.sv() + TI(st.tileStride, slot) + (size_t)f * 64));
-    raw[1] = __float_as_uint(LDS_STREAM(st.sv() + TI(st.tileStride, slot) + (size_t)(f + 1) * 64));
+    raw[0] = __float_as_uint(LDS_STREAM(st.sv() + TI64(st.tileStride, slot) + (size_t)f * 64));
+    raw[1] = __float_as_uint(LDS_STREAM(st.sv() + TI64(st.tileStride, slot) + (size_t)(f + 1) * 64));
     scr[0] = scr[1] = 0u;
     return;
   }
@@ -212,7 +225,7 @@ __global__ void __launch_bounds__(64) k_gen_samples(RenderParams rp, BatchState 
   for (uint32_t e = lane; e < nOut; e += 64u) {
     const uint32_t pl = e >> rp.sppShift, j = e & (uint32_t)(spp - 1);
     const uint32_t idx = s_perm[j * ROW + pl];
-    float* o = out0 + TI(st.tileStride, slot0 + e);
+    float* o = out0 + TI64(st.tileStride, slot0 + e);
     o[0] = VanDerCorput(idx, s_scr[pl]);
     if (is2D) o[64] = Sobol2(idx, s_scr[64 + pl]);
   }
@@ -480,7 +493,7 @@ __global__ void __launch_bounds__(64) k_gen_samples_multi(RenderParams rp, Batch
   const uint32_t s1 = b.is2D ? rng.randomUint() : 0u;
   float* base = st.sv() + (size_t)b.dst * 64;
   const uint32_t slot0 = p * (uint32_t)spp;
-  auto at = [&](int i, int j, int d) -> float& { return base[TI(st.tileStride, slot0 + (uint32_t)i) + (size_t)(dims * j + d) * 64]; };
+  auto at = [&](int i, int j, int d) -> float& { return base[TI64(st.tileStride, slot0 + (uint32_t)i) + (size_t)(dims * j + d) * 64]; };
   for (int i = 0; i < spp; ++i)
     for (int j = 0; j < n; ++j) {
       const uint32_t e = (uint32_t)(i * n + j);
@@ -511,29 +524,29 @@ __global__ void __launch_bounds__(64) k_gen_samples_multi(RenderParams rp, Batch
 __global__ void k_transpose_samples(const float* aos, int stride, BatchState st, int nFloats) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= st.nslots) return;
-  for (int k = 0; k < nFloats; ++k) st.sv()[TI(st.tileStride, s) + (size_t)k * 64] = aos[(size_t)s * stride + k];
+  for (int k = 0; k < nFloats; ++k) st.sv()[TI64(st.tileStride, s) + (size_t)k * 64] = aos[(size_t)s * stride + k];
 }
 
 // 3-vector / colour fields: `cap` in the callers below is the tile stride (see BatchState)
 DR_DEV F3 ld3(const float* a, uint32_t cap, uint32_t s) {
   a += TI(cap, s);
-  return F3{LDS_STREAM(a), LDS_STREAM(a + 64), LDS_STREAM(a + 128)};
+  return F3{LDS_STREAM(a), LDS_STREAM(a + DR_SUB), LDS_STREAM(a + 2 * DR_SUB)};
 }
 DR_DEV void st3(float* a, uint32_t cap, uint32_t s, F3 v) {
   a += TI(cap, s);
   STS_STREAM(a, v.x);
-  STS_STREAM(a + 64, v.y);
-  STS_STREAM(a + 128, v.z);
+  STS_STREAM(a + DR_SUB, v.y);
+  STS_STREAM(a + 2 * DR_SUB, v.z);
 }
 DR_DEV C3 ldc(const float* a, uint32_t cap, uint32_t s) {
   a += TI(cap, s);
-  return C3{LDS_STREAM(a), LDS_STREAM(a + 64), LDS_STREAM(a + 128)};
+  return C3{LDS_STREAM(a), LDS_STREAM(a + DR_SUB), LDS_STREAM(a + 2 * DR_SUB)};
 }
 DR_DEV void stc(float* a, uint32_t cap, uint32_t s, C3 v) {
   a += TI(cap, s);
   STS_STREAM(a, v.r);
-  STS_STREAM(a + 64, v.g);
-  STS_STREAM(a + 128, v.b);
+  STS_STREAM(a + DR_SUB, v.g);
+  STS_STREAM(a + 2 * DR_SUB, v.b);
 }
 
 // ---------------------------------------------------------------------------
@@ -616,6 +629,12 @@ DR_DEV C3 resolve_nee(const DScene& sc, const LV& lv, const SlotRef& sr, uint32_
     if (ENV && lv.light(li).kind == DR_LIGHT_INFINITE) {
       // the MIS ray escaped: Li = light.Le(ray) (integrator.dart:173-175), folded into Ld2 at set-up
       if (prim < 0) Ld = cadd(Ld, ldcf<F_LD2>(sr));
+    } else if (!QUAD && prim >= 0) {
+      const ShTri tr = load_shtri(sc, (uint32_t)prim);
+      if (tr.light == li) {  // lightIsect.primitive.getAreaLight() == light (integrator.dart:170-172)
+        C3 Li = light_L(lv.light(li), tr.nn, vneg(ld3f<F_MISD>(sr)));
+        if (!cblack(Li)) Ld = cadd(Ld, ldcf<F_LD2>(sr));
+      }
     } else if (prim >= 0) {
       Tri tr = load_tri(sc, (uint32_t)prim);
       if (tr.light == li) {  // lightIsect.primitive.getAreaLight() == light (integrator.dart:170-172)
@@ -649,14 +668,16 @@ DR_DEV C3 resolve_nee(const DScene& sc, const LV& lv, const SlotRef& sr, uint32_
 // that, integrator.dart:113-116 / path_integrator.dart:56-68), so that the next stage reads 12 bytes instead of 24 and
 // nobody writes betaNee; the two halves are evaluated BSDF half first (they are independent) so that the light half
 // knows whether a MIS ray is pending.  Every other outcome keeps the raw terms and sets PF_RAW_NEE.
-template <bool ENV, bool QUAD, bool NI, bool PRE, class LV>
+// ENVONLY (k_env): the light is known to be the infinite one -- only that branch is compiled.
+template <bool ENV, bool QUAD, bool NI, bool PRE, class LV, bool ENVONLY = false>
 DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const SlotRef& sr, int lightNum, const Bsdf& bsdf, F3 p, F3 n,
                           F3 wo, double ls0, double ls1, double lsc, double bs0, double bs1, double bsc,
                           C3 beta = C3{0.f, 0.f, 0.f}, double nLights = 0.0) {
-  const DLight light = lv.light(lightNum);
+  DLight light;
+  if constexpr (!ENVONLY) light = lv.light(lightNum);
   const int flags = BSDF_ALL & ~BSDF_SPECULAR;
   uint32_t pf = 0;
-  const bool infinite = ENV && light.kind == DR_LIGHT_INFINITE;
+  const bool infinite = ENVONLY || (ENV && light.kind == DR_LIGHT_INFINITE);
   F3 wi = F3{0, 0, 0}, ps = F3{0, 0, 0};
   double lightPdf = 0.0;
   C3 Li;
@@ -710,12 +731,16 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const SlotRef& sr, int
     double bsdfPdf = 0.0;
     C3 f = bsdf_sample_f(bsdf, wo, &wi2, bs0, bs1, bsc, &bsdfPdf, flags);
     if (!cblack(f) && bsdfPdf > 0.0) {
-      double lightPdf2 = infinite ? env_pdf_x<NI>(sc.env, wi2) : shapeset_pdf<QUAD>(sc, lv, light, p, wi2);
+      double lightPdf2;
+      if constexpr (ENVONLY) lightPdf2 = env_pdf(sc.env, wi2);
+      else lightPdf2 = infinite ? env_pdf_x<NI>(sc.env, wi2) : shapeset_pdf<QUAD>(sc, lv, light, p, wi2);
       if (lightPdf2 != 0.0) {
         double weight = PowerHeuristic(bsdfPdf, lightPdf2);
         // the radiance the MIS ray returns IF it reaches the light: Lemit of the sampled area light (its
         // front face is checked at resolve), or the map along wi2 if the ray escapes (light.Le(ray))
-        C3 Lhit = infinite ? env_Le_x<NI>(sc.env, wi2) : C3{light.L[0], light.L[1], light.L[2]};
+        C3 Lhit;
+        if constexpr (ENVONLY) Lhit = env_Le(sc.env, wi2);
+        else Lhit = infinite ? env_Le_x<NI>(sc.env, wi2) : C3{light.L[0], light.L[1], light.L[2]};
         st3f<F_MISD>(sr, wi2);
         stcf<F_LD2>(sr, cmulD(cmul(f, Lhit), (fabs(vdot(wi2, n)) * weight / bsdfPdf)));
         sr.i32<F_MISLIGHT>() = lightNum;
@@ -725,7 +750,9 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const SlotRef& sr, int
   };
   // the light-sampling half (integrator.dart:128-150)
   auto lightHalf = [&](bool raw) {
-    if (!infinite) {
+    if constexpr (ENVONLY) {
+      Li = env_sample(sc.env, ls0, ls1, &wi, &lightPdf);
+    } else if (!infinite) {
       // DiffuseAreaLight.sampleLAtPoint (diffuse_area_light.dart:60-70)
       F3 ns;
       ps = shapeset_sample<QUAD>(sc, lv, light, ls0, ls1, lsc, &ns, p);
@@ -982,9 +1009,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
   PushCtx pctx = {{0, 0, 0, 0}, 0, 0};
+  // ENVQ (plain-triangle scenes under an environment map): nothing that touches the map is evaluated here.  A lane
+  // whose light estimate picked the infinite light, or whose camera ray escaped, parks its inputs in the slot and
+  // appends the slot to a fifth list (q.envQ); k_env works that list off at full lane width before the stage's rays
+  // are traced.  One lane in nLights picks the map, so inline the wave paid the map's two dependent CDF searches, four
+  // sin / cos and an acos / atan2 pair with ~1/9 of its lanes active, and the kernel carried ~110 spilled registers
+  // per lane for them (C5: shade 776 ms per step, 34 % of the waves' time waiting behind the spill traffic).
+  constexpr bool ENVQ = ENV && !QUAD;
+  constexpr int NQ = ENVQ ? 5 : 4;
   using LV = typename std::conditional<LLDS, LdsLights, GlobalLights>::type;
   LV lv;
-  if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD)));
+  if constexpr (LLDS) lv = stage_lights(sc, s_dyn, push_stage_bytes(SHADE_BLOCK_OF(QUAD), NQ));
   else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf, sc.mats};
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   // Every iteration fetches its active-list entry, then the whole slot state with independent loads.  Prefetching the
@@ -1015,6 +1050,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
     bool pushCont = false, vert = false, deferred = false;
+    bool envNee = false, envMiss = false;  // ENVQ: this lane's light estimate / escaped camera ray goes to k_env
     if (valid) {
       const SlotRef sr = cur.sr;
       const uint32_t flags = cur.flags;
@@ -1051,39 +1087,58 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       if (ENV && bounce == 0 && prim < 0 && sc.hasEnv) {
         // the camera ray escaped: Li = sum over lights of light.Le(ray) (sampler_renderer.dart:87-92); area
         // lights return 0 (light.dart:70-72), the infinite light its map
-        L = cadd(L, env_Le_x<(ENV && !QUAD)>(sc.env, d));
-        Lchanged = true;
+        if constexpr (ENVQ) {
+          envMiss = true;      // k_env stores L = 0 + Le(ray); rd is still the camera ray's direction
+          Lchanged = false;
+        } else {
+          L = cadd(L, env_Le(sc.env, d));
+          Lchanged = true;
+        }
       }
       if (ENV && QUAD && bounce > 0 && prim < 0 && (flags & PF_HAS_CONT) && (flags & PF_SPECULAR) && sc.hasEnv) {
         // a ray that left the scene after a specular bounce still sees the lights (path_integrator.dart:107-111)
-        L = cadd(L, cmul(beta, env_Le_x<(ENV && !QUAD)>(sc.env, d)));
+        L = cadd(L, cmul(beta, env_Le(sc.env, d)));
         Lchanged = true;
       }
       if (prim >= 0 && bounce <= rp.maxDepth) {
-        Tri tr = load_tri(sc, (uint32_t)prim);
-        DGeo dg;
-        const bool isQuad = QUAD && tr.kind != 0;
-        DGeo dgs;  // shading geometry (GeometricPrimitive.getBSDF -> Shape.getShadingGeometry)
-        if (isQuad) {
-          quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
-          dgs = dg;
-        } else if (QUAD && sc.srec && __float_as_uint(sc.srec[7 * (size_t)prim + 6].x) != 0u) {
-          const ShadeRec sr = load_srec(sc, (uint32_t)prim);
-          tri_dg_srec(tr, sr, o, d, t, &dg);
-          if (sr.flags & (DR_SHADING_N | DR_SHADING_S)) shading_geometry(sc, sr, tr.reverse, dg, &dgs);
-          else dgs = dg;
-        } else {
-          tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
-          dgs = dg;
-        }
+        Bsdf bsdf;
+        bool isQuad = false;
         const F3 wo = vneg(d);
-        if (bounce == 0 || (QUAD && (flags & PF_SPECULAR))) {  // bounces == 0 || specularBounce (path_integrator.dart:46)
-          C3 Le = tr.light >= 0 ? light_L(lv.light(tr.light), dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
-          L = cadd(L, cmul(beta, Le));
-          Lchanged = true;
+        if constexpr (!QUAD) {
+          // plain triangles, matte materials: the ray-independent part of the vertex comes from the 32-byte shading
+          // record (dg.nn, the frame's sn, material, light), the rest is pointAt(t) and one cross product
+          const ShTri tr = load_shtri(sc, (uint32_t)prim);
+          if (bounce == 0) {  // bounces == 0 (path_integrator.dart:46)
+            C3 Le = tr.light >= 0 ? light_L(lv.light(tr.light), tr.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
+            L = cadd(L, cmul(beta, Le));
+            Lchanged = true;
+          }
+          bsdf = make_bsdf_pre(lv, vadd(o, vmul(d, t)), tr.nn, tr.sn, tr.mat);  // Ray.pointAt ray.dart:66-67
+        } else {
+          Tri tr = load_tri(sc, (uint32_t)prim);
+          DGeo dg;
+          isQuad = tr.kind != 0;
+          DGeo dgs;  // shading geometry (GeometricPrimitive.getBSDF -> Shape.getShadingGeometry)
+          if (isQuad) {
+            quadric_dg_at(sc.quads[tr.quad], o, d, t, &dg);
+            dgs = dg;
+          } else if (sc.srec && __float_as_uint(sc.srec[7 * (size_t)prim + 6].x) != 0u) {
+            const ShadeRec sr = load_srec(sc, (uint32_t)prim);
+            tri_dg_srec(tr, sr, o, d, t, &dg);
+            if (sr.flags & (DR_SHADING_N | DR_SHADING_S)) shading_geometry(sc, sr, tr.reverse, dg, &dgs);
+            else dgs = dg;
+          } else {
+            tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, o, d, t, &dg);
+            dgs = dg;
+          }
+          if (bounce == 0 || (flags & PF_SPECULAR)) {  // bounces == 0 || specularBounce (path_integrator.dart:46)
+            C3 Le = tr.light >= 0 ? light_L(lv.light(tr.light), dg.nn, wo) : C3{0.f, 0.f, 0.f};  // intersection.dart:60-63
+            L = cadd(L, cmul(beta, Le));
+            Lchanged = true;
+          }
+          bsdf = make_bsdf<QUAD>(lv, dgs, tr.mat);
+          bsdf.ng = dg.nn;  // BSDF(dgs, dgGeom.nn)
         }
-        Bsdf bsdf = make_bsdf<QUAD>(lv, dgs, tr.mat);
-        bsdf.ng = dg.nn;  // BSDF(dgs, dgGeom.nn)
         const F3 p = bsdf.p, n = bsdf.nn;
         const double eps = (isQuad ? 5.0e-4 : 1.0e-3) * t;  // triangle.dart:157; sphere.dart:169, disk.dart:98
         PROF(2);
@@ -1110,9 +1165,22 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           int lightNum = (int)floor(lu * rp.nLights);
           lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
           PROF(3);
-          pf |= setup_nee<ENV, QUAD, (ENV && !QUAD), true>(sc, lv, sr, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc, beta,
-                                                            (double)rp.nLights);
-          if (pf & PF_RAW_NEE) stcf<F_BETANEE>(sr, beta);
+          if (ENVQ && lv.light(lightNum).kind == DR_LIGHT_INFINITE) {
+            // parked for k_env (fields it overwrites with the estimate's results, or that only a raw estimate reads):
+            // wo, the throughput the estimate is weighted with, the light and BSDF samples, the light's number
+            envNee = true;
+            st3f<F_MISD>(sr, wo);
+            stcf<F_BETANEE>(sr, beta);
+            sr.f32<F_LD1>(0) = (float)ls0;
+            sr.f32<F_LD1>(1) = (float)ls1;
+            sr.f32<F_LD2>(0) = (float)bs0;
+            sr.f32<F_LD2>(1) = (float)bs1;
+            sr.i32<F_MISLIGHT>() = lightNum;
+          } else {
+            pf |= setup_nee<(ENV && !ENVQ), QUAD, false, true>(sc, lv, sr, lightNum, bsdf, p, n, wo, ls0, ls1, lsc, bs0, bs1, bsc, beta,
+                                                                (double)rp.nLights);
+            if (pf & PF_RAW_NEE) stcf<F_BETANEE>(sr, beta);
+          }
         }
         PROF(5);
         // Sample BSDF to get the new path direction (path_integrator.dart:70-90)
@@ -1158,15 +1226,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       deferred = !pushCont && (pf & PF_HAS_SH) && !(pf & (PF_RAW_NEE | PF_HAS_MIS));
       if (deferred) pf |= PF_DEFERRED;
       // the camera stage initialises every slot's flags (k_film reads them); later stages need not store pf == 0:
-      // the slot is in no queue, no later stage visits it, and the flags it keeps carry no PF_DEFERRED
-      if (bounce == 0 || pf) sr.u32<F_FLAGS>() = pf;
+      // the slot is in no queue, no later stage visits it, and the flags it keeps carry no PF_DEFERRED.  (A parked
+      // estimate: k_env reads the continuation bit here and writes the finished flags.)
+      if (bounce == 0 || pf || envNee) sr.u32<F_FLAGS>() = pf;
       PROF(7);
     }
-    stage_push(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0 && !deferred, slot, Q_MIS_BIT, vert,
-               pushCont ? 0u : Q_RESOLVE_BIT);
+    // (a slot with a parked estimate enters the next stage's list in k_env, once its flags are known)
+    stage_push<NQ>(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0 && !deferred && !envNee, slot, Q_MIS_BIT,
+                   vert, pushCont ? 0u : Q_RESOLVE_BIT, envNee || envMiss, envMiss ? Q_ENV_MISS_BIT : 0u);
     PROF(8);
     if (pctx.iters == DR_PUSH_ITERS) {
-      const uint32_t g = stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont, q.work);
+      const uint32_t g = stage_flush<NQ>(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont,
+                                         q.work, q.envQ, q.nEnv);
       cCur = cNext;
       cNext = g;
     }
@@ -1175,6 +1246,69 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   stage_finish(s_push, pctx, q.closestQ, q.anyQ, q.activeOut, &q.ctr->shade_cont);
   PROF_FLUSH;
   shade_count(s_push, q.ctr, nIn);
+}
+
+// Everything of PathIntegrator.Li that touches the InfiniteAreaLight's map, for plain-triangle scenes (the ENVQ
+// instantiations of k_shade_path leave it here): a stage's list q.envQ holds
+//   slot                    a vertex whose UniformSampleOneLight picked the infinite light: EstimateDirect's set-up
+//                           (integrator.dart:119-185 with infinite_area_light.dart:92-131,190-205) from the inputs
+//                           k_shade_path parked in the slot -- wo in misD, the throughput in betaNee, the light sample
+//                           in Ld1[0..1], the BSDF sample in Ld2[0..1], the light's number in misLight; the vertex is
+//                           ro, its frame and material the hit primitive's shading record.  Writes what setup_nee
+//                           writes, finishes the slot's flags and queues its shadow / MIS rays and its entry of the
+//                           next stage's list;
+//   slot | Q_ENV_MISS_BIT   an escaped camera ray: L = 0 + light.Le(ray) (sampler_renderer.dart:87-92).
+// Lane = list entry: every lane runs the map's CDF searches and trigonometry, where the inline form ran them with the
+// one lane in nLights that picked the map.  Runs between a stage's shade launch and its traversals.
+#ifndef DR_ENV_BLOCK
+#define DR_ENV_BLOCK 256
+#endif
+struct MatsOnly {  // the BSDF functions' view of the scene tables: only the material table is read here
+  const float4* mats;
+  DR_DEV float4 mat(uint32_t m, int k) const { return mats[4 * (size_t)m + k]; }
+};
+__global__ void __launch_bounds__(DR_ENV_BLOCK) k_env(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  PushStage& s_push = *(PushStage*)s_dyn;
+  PushCtx pctx = {{0, 0, 0, 0}, 0, 0};
+  const MatsOnly lv{sc.mats};
+  const uint32_t nIn = *q.nEnv;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t nIter = (nIn + stride - 1) / stride;
+  stage_init(s_push);
+  for (uint32_t it = 0; it < nIter; ++it) {
+    const uint32_t idx = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t slot = 0, pf = 0;
+    bool active = false, cont = false;
+    if (idx < nIn) {
+      const uint32_t entry = q.envQ[idx];
+      slot = entry & ~Q_ENV_MISS_BIT;
+      const SlotRef sr = SlotRef::of(st, slot);
+      if (entry & Q_ENV_MISS_BIT) {
+        stcf<F_L>(sr, cadd(C3{0.f, 0.f, 0.f}, env_Le(sc.env, ld3f<F_RD>(sr))));
+      } else {
+        const uint32_t flags = sr.u32<F_FLAGS>();  // the continuation bit(s) k_shade_path stored
+        const ShTri tr = load_shtri(sc, (uint32_t)sr.i32<F_HPRIM>());
+        const F3 p = ld3f<F_RO>(sr), wo = ld3f<F_MISD>(sr);
+        const C3 beta = ldcf<F_BETANEE>(sr);
+        const double ls0 = sr.f32<F_LD1>(0), ls1 = sr.f32<F_LD1>(1), bs0 = sr.f32<F_LD2>(0), bs1 = sr.f32<F_LD2>(1);
+        const int lightNum = sr.i32<F_MISLIGHT>();
+        const Bsdf bsdf = make_bsdf_pre(lv, p, tr.nn, tr.sn, tr.mat);
+        pf = flags | setup_nee<true, false, false, true, MatsOnly, true>(sc, lv, sr, lightNum, bsdf, p, bsdf.nn, wo, ls0, ls1, 0.0, bs0, bs1, 0.0,
+                                                                         beta, (double)rp.nLights);
+        // (a raw estimate reads the throughput from betaNee: it is there already)
+        cont = (flags & PF_HAS_CONT) != 0;
+        const bool deferred = !cont && (pf & PF_HAS_SH) && !(pf & (PF_RAW_NEE | PF_HAS_MIS));
+        if (deferred) pf |= PF_DEFERRED;
+        sr.u32<F_FLAGS>() = pf;
+        active = pf != 0 && !deferred;
+      }
+    }
+    stage_push(s_push, pctx, false, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, active, slot, Q_MIS_BIT, false, cont ? 0u : Q_RESOLVE_BIT);
+    if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
+      stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);
+  }
+  stage_finish(s_push, pctx, q.closestQ, q.anyQ, q.activeOut, &q.ctr->shade_cont);
 }
 
 // DirectLightingIntegrator.Li with strategy "all" (direct_lighting_integrator.dart:30-68;
@@ -1590,6 +1724,10 @@ void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t*
   hipLaunchKernelGGL(k_gather_tris, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, verts, idx, mat, light, rev, out,
                      ntris);
 }
+void launch_make_shtris(const DScene& sc, float4* out, uint64_t ntris, hipStream_t s) {
+  if (ntris == 0) return;
+  hipLaunchKernelGGL(k_make_shtris, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, sc, out, ntris);
+}
 #ifndef DR_GEN_LANES_256
 #define DR_GEN_LANES_256 64
 #endif
@@ -1646,9 +1784,9 @@ void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s) 
 }
 // The shade kernels stage their queue entries in dynamic LDS (PushStage, dr_wave.h): ~96 KB of the CU's 160 KB; the
 // light tables follow when they are small (LLDS instantiations).
-template <auto kernel, int BLOCK, class... A>
+template <auto kernel, int BLOCK, int NQ = 4, class... A>
 static void launch_shade(int grid, size_t extraLds, hipStream_t s, A... args) {
-  const size_t lds = push_stage_bytes(BLOCK) + extraLds;
+  const size_t lds = push_stage_bytes(BLOCK, NQ) + extraLds;
   static size_t attrSet = 0;  // one instance of this template, hence one value, per kernel
   if (attrSet < lds) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1663,16 +1801,25 @@ static bool lightsInLds(const DScene& sc) {
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {
   const bool gen = sc.nquads || sc.hasSpec || sc.srec;
-  if (lightsInLds(sc)) {
-    const size_t x = light_table_bytes(sc) + mat_table_bytes(sc);
+  const size_t x = light_table_bytes(sc) + mat_table_bytes(sc);
+  // (the env-map variant stages a fifth list: its tables only go to LDS when the 160 KB still hold both)
+  const bool envq = !gen && sc.hasEnv;
+  if (lightsInLds(sc) && (!envq || push_stage_bytes(SHADE_BLOCK_OF(false), 5) + x <= 160 * 1024)) {
     if (gen) launch_shade<k_shade_path<true, true, true>, SHADE_BLOCK_OF(true)>(grid, x, s, sc, rp, st, q, bounce);
-    else if (sc.hasEnv) launch_shade<k_shade_path<true, false, true>, SHADE_BLOCK_OF(false)>(grid, x, s, sc, rp, st, q, bounce);
+    else if (sc.hasEnv) launch_shade<k_shade_path<true, false, true>, SHADE_BLOCK_OF(false), 5>(grid, x, s, sc, rp, st, q, bounce);
     else launch_shade<k_shade_path<false, false, true>, SHADE_BLOCK_OF(false)>(grid, x, s, sc, rp, st, q, bounce);
   } else {
     if (gen) launch_shade<k_shade_path<true, true, false>, SHADE_BLOCK_OF(true)>(grid, 0, s, sc, rp, st, q, bounce);
-    else if (sc.hasEnv) launch_shade<k_shade_path<true, false, false>, SHADE_BLOCK_OF(false)>(grid, 0, s, sc, rp, st, q, bounce);
+    else if (sc.hasEnv) launch_shade<k_shade_path<true, false, false>, SHADE_BLOCK_OF(false), 5>(grid, 0, s, sc, rp, st, q, bounce);
     else launch_shade<k_shade_path<false, false, false>, SHADE_BLOCK_OF(false)>(grid, 0, s, sc, rp, st, q, bounce);
   }
+}
+// k_env: DR_ENV_GRID_PER_CU workgroups of 256 threads per CU, a grid-stride loop over the stage's environment-map list
+#ifndef DR_ENV_GRID_PER_CU
+#define DR_ENV_GRID_PER_CU 4
+#endif
+void launch_env(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_env, dim3(grid * DR_ENV_GRID_PER_CU), dim3(DR_ENV_BLOCK), push_stage_bytes(DR_ENV_BLOCK), s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {

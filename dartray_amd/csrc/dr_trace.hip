@@ -179,20 +179,20 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace_v1(DScene sc, BatchSta
       const uint32_t e = queue ? queue[idx] : idx;
       const uint32_t slot = e & ~Q_MIS_BIT;
       const size_t ti = TI(cap, slot);
-      const F3 o = F3{st.ro()[ti], st.ro()[ti + 64], st.ro()[ti + 128]};
+      const F3 o = F3{st.ro()[ti], st.ro()[ti + DR_SUB], st.ro()[ti + 2 * DR_SUB]};
       const double tmin = st.rtmin()[TD(cap, slot)];
       ++rays;
       if (ANY) {
-        const F3 d = F3{st.shD()[ti], st.shD()[ti + 64], st.shD()[ti + 128]};
+        const F3 d = F3{st.shD()[ti], st.shD()[ti + DR_SUB], st.shD()[ti + 2 * DR_SUB]};
         double t;
         int r = traverse<1>(sc, o, d, tmin, st.shTmax()[TD(cap, slot)], lds, mySpill, spillStride, &t, &nodes, &tris);
         st.shOcc()[ti] = (r >= 0) ? 1 : 0;
       } else if (e & Q_MIS_BIT) {
-        const F3 d = F3{st.misD()[ti], st.misD()[ti + 64], st.misD()[ti + 128]};
+        const F3 d = F3{st.misD()[ti], st.misD()[ti + DR_SUB], st.misD()[ti + 2 * DR_SUB]};
         double t;
         st.misPrim()[ti] = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
       } else {
-        const F3 d = F3{st.rd()[ti], st.rd()[ti + 64], st.rd()[ti + 128]};
+        const F3 d = F3{st.rd()[ti], st.rd()[ti + DR_SUB], st.rd()[ti + 2 * DR_SUB]};
         double t;
         int r = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
         st.hprim()[ti] = r;
@@ -377,9 +377,9 @@ struct StateIO {
     const uint32_t cap = st.tileStride;  // words per 64-slot tile
     handle = e;
     const size_t ti = TI(cap, slot), td = TD(cap, slot);
-    const F3 o = F3{LDS_STREAM(st.ro() + ti), LDS_STREAM(st.ro() + ti + 64), LDS_STREAM(st.ro() + ti + 128)};
+    const F3 o = F3{LDS_STREAM(st.ro() + ti), LDS_STREAM(st.ro() + ti + DR_SUB), LDS_STREAM(st.ro() + ti + 2 * DR_SUB)};
     const float* dir = (ANY ? st.shD() : ((e & Q_MIS_BIT) ? st.misD() : st.rd())) + ti;
-    const F3 d = F3{LDS_STREAM(dir), LDS_STREAM(dir + 64), LDS_STREAM(dir + 128)};
+    const F3 d = F3{LDS_STREAM(dir), LDS_STREAM(dir + DR_SUB), LDS_STREAM(dir + 2 * DR_SUB)};
     ray_init(r, o, d, LDS_STREAM(st.rtmin() + td), ANY ? LDS_STREAM(st.shTmax() + td) : DR_INF);
   }
   DR_DEV void store(uint32_t handle, const TraceRay& r, int prim, const DScene&) const {

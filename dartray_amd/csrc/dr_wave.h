@@ -47,10 +47,12 @@ struct PushCtx {  // wave-uniform registers
   uint32_t n[4];
   uint32_t iters;
   uint32_t round;
+  uint32_t nEnv;  // NQ == 5: entries of the fifth (environment-map) list
 };
 #define DR_PUSH_CAP (64 * DR_PUSH_ITERS)  // entries per queue and wave
-__host__ __device__ inline size_t push_stage_bytes(uint32_t blockDimX) {
-  return sizeof(PushStage) + 4 * (size_t)blockDimX * DR_PUSH_ITERS * sizeof(uint32_t);
+// NQ = lists per wave: 4 (continuation, MIS, shadow, active) or 5 (+ the environment-map items of k_shade_path, k_env's input)
+__host__ __device__ inline size_t push_stage_bytes(uint32_t blockDimX, int nq = 4) {
+  return sizeof(PushStage) + (size_t)nq * (size_t)blockDimX * DR_PUSH_ITERS * sizeof(uint32_t);
 }
 DR_DEV void stage_init(PushStage& sm) {  // once per kernel, by every thread, before the first stage_push
   if (threadIdx.x < 16) {
@@ -59,13 +61,15 @@ DR_DEV void stage_init(PushStage& sm) {  // once per kernel, by every thread, be
   }
   __syncthreads();
 }
+template <int NQ = 4>
 DR_DEV uint32_t* stage_region(PushStage& sm) {
-  return (uint32_t*)(&sm + 1) + (size_t)(threadIdx.x >> 6) * 4 * DR_PUSH_CAP;
+  return (uint32_t*)(&sm + 1) + (size_t)(threadIdx.x >> 6) * NQ * DR_PUSH_CAP;
 }
+template <int NQ = 4>
 DR_DEV void stage_push(PushStage& sm, PushCtx& c, bool pCont, bool pMis, bool pAny, bool pAct, uint32_t slot, uint32_t misBit,
-                       bool pVert = false, uint32_t actBits = 0u) {
+                       bool pVert = false, uint32_t actBits = 0u, bool pEnv = false, uint32_t envBits = 0u) {
   const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-  uint32_t* buf = stage_region(sm);
+  uint32_t* buf = stage_region<NQ>(sm);
   const unsigned long long lt = (1ull << lane) - 1ull;
   const unsigned long long m0 = __ballot(pCont), m1 = __ballot(pMis), m2 = __ballot(pAny), m3 = __ballot(pAct);
   const unsigned long long m4 = __ballot(pVert);
@@ -78,17 +82,36 @@ DR_DEV void stage_push(PushStage& sm, PushCtx& c, bool pCont, bool pMis, bool pA
   c.n[1] += (uint32_t)__popcll(m1);
   c.n[2] += (uint32_t)__popcll(m2);
   c.n[3] += (uint32_t)__popcll(m3);
+  if constexpr (NQ == 5) {
+    const unsigned long long m5 = __ballot(pEnv);
+    if (pEnv) buf[4 * DR_PUSH_CAP + c.nEnv + (uint32_t)__popcll(m5 & lt)] = slot | envBits;
+    c.nEnv += (uint32_t)__popcll(m5);
+  }
   ++c.iters;
 }
 // End of a wave's round (every DR_PUSH_ITERS iterations, and after its last iteration).  closestQ receives the round's
 // continuation entries first, then its MIS entries.
 // `work` (optional): the kernel's chunk counter; the wave's next chunk of work is taken in the same round trip and
 // returned (dynamic distribution: a wave that runs ahead simply takes more chunks).
+template <int NQ = 4>
 DR_DEV uint32_t stage_flush(PushStage& sm, PushCtx& c, uint32_t* closestQ, uint32_t* nClosest, uint32_t* anyQ, uint32_t* nAny,
-                            uint32_t* activeQ, uint32_t* nActive, unsigned long long* stats = nullptr, uint32_t* work = nullptr) {
+                            uint32_t* activeQ, uint32_t* nActive, unsigned long long* stats = nullptr, uint32_t* work = nullptr,
+                            uint32_t* envQ = nullptr, uint32_t* nEnvQ = nullptr) {
   const int lane = lane_id();
   const uint32_t n0 = c.n[0], n1 = c.n[1], n2 = c.n[2], n3 = c.n[3];
   uint32_t grabbed = 0u;
+  if constexpr (NQ == 5) {
+    // the environment-map list: its own reservation (a fifth counter, in its own cache line), copied out first
+    const uint32_t n4 = c.nEnv;
+    if (n4) {
+      uint32_t a4 = 0u;
+      if (lane == 0) a4 = atomicAdd(nEnvQ, n4);
+      a4 = wave_bcast_first(a4);
+      const uint32_t* buf = stage_region<NQ>(sm);
+      for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) envQ[a4 + i] = buf[4 * DR_PUSH_CAP + i];
+    }
+    c.nEnv = 0u;
+  }
   if (work && (n0 | n1 | n2 | n3) == 0u) {
     if (lane == 0) grabbed = atomicAdd(work, 1u);
     grabbed = wave_bcast_first(grabbed);
@@ -127,7 +150,7 @@ DR_DEV uint32_t stage_flush(PushStage& sm, PushCtx& c, uint32_t* closestQ, uint3
       sm.nStat[wave][2] += n2;
     }
     const uint32_t b0 = wave_bcast_first(a0), b1 = wave_bcast_first(a1), b2 = wave_bcast_first(a2);
-    const uint32_t* buf = stage_region(sm);
+    const uint32_t* buf = stage_region<NQ>(sm);
     for (uint32_t i = (uint32_t)lane; i < n0; i += 64u) closestQ[b0 + i] = buf[i];
     for (uint32_t i = (uint32_t)lane; i < n1; i += 64u) closestQ[b0 + n0 + i] = buf[DR_PUSH_CAP + i];
     for (uint32_t i = (uint32_t)lane; i < n2; i += 64u) anyQ[b1 + i] = buf[2 * DR_PUSH_CAP + i];
