@@ -73,6 +73,7 @@ struct Workspace {
 };
 
 #define DR_STATE_WORDS F_SAMPLES  // 41 4-byte words of fixed path state per slot: 3 f64 + 10 3-vectors + 5 i32
+#define DR_ENV_MARG_MAX_ROWS 8192  // k_env keeps the map's marginal distribution in LDS (dr_kernels.hip)
 #define N_COUNTERS_TRACE (1024 + 8 * DR_WORK_STRIDE * 400)
 #define N_COUNTERS (N_COUNTERS_TRACE + 64 * 256)  // ... then the counts of k_env's lists, one cache line per stage  // [0,1024): stage queue counts; then 8 per-XCD work counters per trace launch, DR_WORK_STRIDE words apart
 
@@ -92,6 +93,7 @@ struct DrScene {
   DevBuf<float> xforms;
   DevBuf<float> lcdf;
   DevBuf<float> envTexels, envCondFunc, envCondCdf, envCondInt, envMargFunc, envMargCdf;
+  DevBuf<uint16_t> envCondGuide;
   DevBuf<TraceCounters> ctr;
   uint32_t bvhDepth = 0;
   bool traceCalibrated = false;
@@ -858,6 +860,26 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       TRY_SC(sc->envMargCdf.alloc(mc.size()));
       TRY_SC(hipMemcpy(sc->envMargCdf.p, mc.data(), mc.size() * sizeof(float), hipMemcpyHostToDevice));
       DEnv& e = sc->d.env;
+      // guide rows of the conditional CDFs (DEnv::condGuide): upper_bound at u = k / G, G = w / 4 (a power of two)
+      e.condGuide = nullptr;
+      e.guideN = 0;
+      if (w >= 16 && w + 1 <= 65535) {
+        const int G = w / 4;
+        std::vector<uint16_t> guide((size_t)h * (G + 1));
+        for (int v = 0; v < h; ++v) {
+          const float* c = &cc[(size_t)v * (w + 1)];
+          int i = 0;  // upper_bound is monotone in u: one sweep per row
+          for (int k = 0; k <= G; ++k) {
+            const double u = (double)k / (double)G;
+            while (i < w + 1 && !(u < (double)c[i])) ++i;
+            guide[(size_t)v * (G + 1) + k] = (uint16_t)i;
+          }
+        }
+        TRY_SC(sc->envCondGuide.alloc(guide.size()));
+        TRY_SC(hipMemcpy(sc->envCondGuide.p, guide.data(), guide.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        e.condGuide = sc->envCondGuide.p;
+        e.guideN = G;
+      }
       e.texels = sc->envTexels.p;
       e.condFunc = sc->envCondFunc.p;
       e.condCdf = sc->envCondCdf.p;
@@ -1244,6 +1266,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (nStages > 248 || 8 * DR_WORK_STRIDE * (1 + 2 * nStages) > N_COUNTERS_TRACE - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
   // k_env (dr_kernels.hip): the environment-map work of a plain-triangle scene's path stages runs in its own kernel
   const bool envStage = rd->integrator == DR_INTEGRATOR_PATH && sc->d.hasEnv && !(sc->d.nquads || sc->d.hasSpec || sc->d.srec);
+  if (envStage && sc->d.env.h > DR_ENV_MARG_MAX_ROWS) return fail(DR_ERR_UNSUPPORTED, "radiance map taller than 8192 rows");
   if (envStage) {
     HIP_TRY(sc->ws.envQ.alloc(sc->ws.cap));
     if (twoPipes) HIP_TRY(sc->ws2.envQ.alloc(sc->ws2.cap));

@@ -95,6 +95,12 @@ struct DEnv {
   const float* condInt;   // [h]         pConditionalV[v].funcInt (an f32 value)
   const float* margFunc;  // [h]
   const float* margCdf;   // [h+1]
+  // Guide table in front of the conditional CDFs' upper_bound (common.dart:304-333): condGuide[v][k] = upper_bound of
+  // row v for u = k / guideN, k = 0 .. guideN (guideN a power of two, so k / guideN and floor(u * guideN) are exact):
+  // the bound for any u of bucket k lies in [guide[k], guide[k + 1]], a handful of entries instead of w + 1 -- the
+  // search returns the same index after ~2 dependent fetches instead of log2(w + 1) = 11.
+  const uint16_t* condGuide;  // [h][guideN + 1]
+  int32_t guideN;
   float margInt;
   int32_t w, h;
   float L[3];
@@ -842,9 +848,9 @@ DR_DEV C3 env_Le(const DEnv& e, F3 dir) {  // infinite_area_light.dart:84-90
   const double t = SphericalTheta(wh) * DR_INV_PI;
   return env_radiance(e, s, t);
 }
-// upper_bound over cdf[0..count] (common.dart:304-333) then Distribution1D.sampleContinuous (montecarlo.dart:50-80)
-DR_DEV double dist1d_sample(const float* func, const float* cdf, double funcInt, int count, double u, double* pdf, int* off) {
-  int first = 0, cnt = count + 1;
+// upper_bound over cdf[first .. first + cnt) (common.dart:304-333): the first index whose entry is > u
+template <class CDF>
+DR_DEV int cdf_upper_bound(const CDF& cdf, int first, int cnt, double u) {
   while (cnt > 0) {
     int step = cnt >> 1;
     int index = first + step;
@@ -855,22 +861,61 @@ DR_DEV double dist1d_sample(const float* func, const float* cdf, double funcInt,
       cnt = step;
     }
   }
+  return first;
+}
+// Distribution1D.sampleContinuous (montecarlo.dart:50-80) once upper_bound's result `first` is known
+template <class FUNC, class CDF>
+DR_DEV double dist1d_finish(const FUNC& func, const CDF& cdf, double funcInt, int count, double u, int first, double* pdf, int* off) {
   int offset = first - 1 < 0 ? 0 : first - 1;
   if (offset == count) offset = count - 1;
   if (off) *off = offset;
-  const double dc = ((double)cdf[offset + 1] - (double)cdf[offset]);
+  const double c0 = (double)cdf[offset];
+  const double dc = ((double)cdf[offset + 1] - c0);
   double du = 0.0;
-  if (dc != 0.0) du = (u - (double)cdf[offset]) / dc;
+  if (dc != 0.0) du = (u - c0) / dc;
   *pdf = (double)func[offset] / funcInt;
   return (offset + du) / count;
 }
+template <class FUNC, class CDF>
+DR_DEV double dist1d_sample(const FUNC& func, const CDF& cdf, double funcInt, int count, double u, double* pdf, int* off) {
+  return dist1d_finish(func, cdf, funcInt, count, u, cdf_upper_bound(cdf, 0, count + 1, u), pdf, off);
+}
+// The same through a guide row (DEnv::condGuide): identical index, found in the bucket's few entries.  Up to four
+// candidates are fetched together (one round trip) before any bisection.
+DR_DEV double dist1d_sample_guided(const float* func, const float* cdf, double funcInt, int count, double u, const uint16_t* guide, int guideN,
+                                   double* pdf) {
+  int k = (int)(u * (double)guideN);
+  k = k < 0 ? 0 : (k > guideN - 1 ? guideN - 1 : k);
+  int lo = guide[k], hi = guide[k + 1];  // upper_bound(u) is in [lo, hi] for every u of bucket k ...
+  if (!(u < (double)(k + 1) / (double)guideN)) hi = count + 1;  // ... and a u outside [0, 1) searches to the end
+  if (!(u >= (double)k / (double)guideN)) lo = 0;
+  int first;
+  if (hi - lo <= 4) {
+    const int last = count;  // cdf has count + 1 entries
+    const float c0 = cdf[lo <= last ? lo : last], c1 = cdf[lo + 1 <= last ? lo + 1 : last], c2 = cdf[lo + 2 <= last ? lo + 2 : last],
+                c3 = cdf[lo + 3 <= last ? lo + 3 : last];
+    first = hi;
+    if (hi - lo > 3 && u < (double)c3) first = lo + 3;
+    if (hi - lo > 2 && u < (double)c2) first = lo + 2;
+    if (hi - lo > 1 && u < (double)c1) first = lo + 1;
+    if (hi - lo > 0 && u < (double)c0) first = lo;
+  } else {
+    first = cdf_upper_bound(cdf, lo, hi - lo, u);
+  }
+  return dist1d_finish(func, cdf, funcInt, count, u, first, pdf, nullptr);
+}
 // sampleLAtPoint (infinite_area_light.dart:92-131): wi, pdf and the radiance; the shadow ray is p + t wi, t < inf.
-DR_DEV C3 env_sample(const DEnv& e, double u0, double u1, F3* wi, double* pdf) {
+// MF / MC: the marginal distribution's func and cdf (global pointers, or k_env's LDS copies)
+template <class MF, class MC>
+DR_DEV C3 env_sample_m(const DEnv& e, const MF& margFunc, const MC& margCdf, double u0, double u1, F3* wi, double* pdf) {
   double pdfs1, pdfs0;
   int voff;
-  const double v = dist1d_sample(e.margFunc, e.margCdf, (double)e.margInt, e.h, u1, &pdfs1, &voff);
-  const double u = dist1d_sample(e.condFunc + (size_t)voff * e.w, e.condCdf + (size_t)voff * (e.w + 1),
-                                 (double)e.condInt[voff], e.w, u0, &pdfs0, nullptr);
+  const double v = dist1d_sample(margFunc, margCdf, (double)e.margInt, e.h, u1, &pdfs1, &voff);
+  const float* cf = e.condFunc + (size_t)voff * e.w;
+  const float* cc = e.condCdf + (size_t)voff * (e.w + 1);
+  const double ci = (double)e.condInt[voff];
+  const double u = e.condGuide ? dist1d_sample_guided(cf, cc, ci, e.w, u0, e.condGuide + (size_t)voff * (e.guideN + 1), e.guideN, &pdfs0)
+                               : dist1d_sample(cf, cc, ci, e.w, u0, &pdfs0, nullptr);
   const double mapPdf = pdfs0 * pdfs1;
   if (mapPdf == 0.0) {
     *pdf = 0.0;
@@ -883,6 +928,9 @@ DR_DEV C3 env_sample(const DEnv& e, double u0, double u1, F3* wi, double* pdf) {
   if (sintheta == 0.0) *pdf = 0.0;
   else *pdf = mapPdf / (2.0 * DR_PI * DR_PI * sintheta);
   return env_radiance(e, u, v);
+}
+DR_DEV C3 env_sample(const DEnv& e, double u0, double u1, F3* wi, double* pdf) {
+  return env_sample_m(e, e.margFunc, e.margCdf, u0, u1, wi, pdf);
 }
 DR_DEV double env_pdf(const DEnv& e, F3 w) {  // infinite_area_light.dart:190-205 + Distribution2D.pdf (montecarlo.dart:250-263)
   F3 wi = xf3(e.w2l, w);
@@ -899,27 +947,12 @@ DR_DEV double env_pdf(const DEnv& e, F3 w) {  // infinite_area_light.dart:190-20
   else p2 = ((double)e.condFunc[(size_t)iv * e.w + iu] * (double)e.margFunc[iv]) / (ci * mi);
   return p2 / (2.0 * DR_PI * DR_PI * sintheta);
 }
-// Out-of-line copies for the env-map path kernel (ENV && !QUAD): called, not inlined, these three keep their ~90
-// registers out of the caller's live set -- that variant then fits 3 waves per SIMD without spilling (C5 shade
-// 1047 -> 883 ms).  The DirectLighting and general kernels measured slower with them and keep the inline forms.
-__device__ __noinline__ C3 env_Le_ni(const DEnv& e, F3 dir) { return env_Le(e, dir); }
-__device__ __noinline__ C3 env_sample_ni(const DEnv& e, double u0, double u1, F3* wi, double* pdf) { return env_sample(e, u0, u1, wi, pdf); }
-__device__ __noinline__ double env_pdf_ni(const DEnv& e, F3 w) { return env_pdf(e, w); }
 template <bool NI>
-DR_DEV C3 env_Le_x(const DEnv& e, F3 dir) {
-  if constexpr (NI) return env_Le_ni(e, dir);
-  else return env_Le(e, dir);
-}
+DR_DEV C3 env_Le_x(const DEnv& e, F3 dir) { return env_Le(e, dir); }
 template <bool NI>
-DR_DEV C3 env_sample_x(const DEnv& e, double u0, double u1, F3* wi, double* pdf) {
-  if constexpr (NI) return env_sample_ni(e, u0, u1, wi, pdf);
-  else return env_sample(e, u0, u1, wi, pdf);
-}
+DR_DEV C3 env_sample_x(const DEnv& e, double u0, double u1, F3* wi, double* pdf) { return env_sample(e, u0, u1, wi, pdf); }
 template <bool NI>
-DR_DEV double env_pdf_x(const DEnv& e, F3 w) {
-  if constexpr (NI) return env_pdf_ni(e, w);
-  else return env_pdf(e, w);
-}
+DR_DEV double env_pdf_x(const DEnv& e, F3 w) { return env_pdf(e, w); }
 
 // ---- BSDF with one Lambertian lobe -------------------------------------------
 // (matte_material.dart:41-65; reflection/bsdf.dart:45-211; bxdf.dart:31-48,84-88;

@@ -751,7 +751,7 @@ DR_DEV uint32_t setup_nee(const DScene& sc, const LV& lv, const SlotRef& sr, int
   // the light-sampling half (integrator.dart:128-150)
   auto lightHalf = [&](bool raw) {
     if constexpr (ENVONLY) {
-      Li = env_sample(sc.env, ls0, ls1, &wi, &lightPdf);
+      Li = env_sample_m(sc.env, lv.margFunc, lv.margCdf, ls0, ls1, &wi, &lightPdf);  // (k_env: the marginal distribution from LDS)
     } else if (!infinite) {
       // DiffuseAreaLight.sampleLAtPoint (diffuse_area_light.dart:60-70)
       F3 ns;
@@ -1263,15 +1263,27 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
 #ifndef DR_ENV_BLOCK
 #define DR_ENV_BLOCK 256
 #endif
-struct MatsOnly {  // the BSDF functions' view of the scene tables: only the material table is read here
+struct LdsFloats {
+  lds_cu32* p;
+  DR_DEV float operator[](int i) const { return __uint_as_float(p[i]); }
+};
+struct MatsOnly {  // k_env's view of the scene tables: the material table and the map's marginal distribution (LDS copies)
   const float4* mats;
+  LdsFloats margFunc, margCdf;
   DR_DEV float4 mat(uint32_t m, int k) const { return mats[4 * (size_t)m + k]; }
 };
 __global__ void __launch_bounds__(DR_ENV_BLOCK) k_env(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
   PushCtx pctx = {{0, 0, 0, 0}, 0, 0};
-  const MatsOnly lv{sc.mats};
+  // the marginal distribution (h func + h + 1 cdf entries) behind the staging lists: its 10-step search runs on LDS
+  uint32_t* const sMarg = (uint32_t*)(s_dyn + push_stage_bytes(DR_ENV_BLOCK));
+  {
+    const uint32_t h = (uint32_t)sc.env.h;
+    for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) sMarg[i] = __float_as_uint(sc.env.margFunc[i]);
+    for (uint32_t i = threadIdx.x; i < h + 1u; i += blockDim.x) sMarg[h + i] = __float_as_uint(sc.env.margCdf[i]);
+  }
+  const MatsOnly lv{sc.mats, LdsFloats{(lds_cu32*)sMarg}, LdsFloats{(lds_cu32*)(sMarg + sc.env.h)}};
   const uint32_t nIn = *q.nEnv;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
@@ -1819,7 +1831,13 @@ void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchStat
 #define DR_ENV_GRID_PER_CU 4
 #endif
 void launch_env(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_env, dim3(grid * DR_ENV_GRID_PER_CU), dim3(DR_ENV_BLOCK), push_stage_bytes(DR_ENV_BLOCK), s, sc, rp, st, q, bounce);
+  const size_t lds = push_stage_bytes(DR_ENV_BLOCK) + (2 * (size_t)sc.env.h + 1) * 4;
+  static size_t attrSet = 0;
+  if (attrSet < lds) {
+    (void)hipFuncSetAttribute((const void*)k_env, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attrSet = lds;
+  }
+  hipLaunchKernelGGL(k_env, dim3(grid * DR_ENV_GRID_PER_CU), dim3(DR_ENV_BLOCK), lds, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
