@@ -6,13 +6,14 @@
 metric  : Msamples/s (primary + path rays), film pixels x spp per second, whole job over N GPUs
 workload: N = 1 -- configs[1] (C2): Cornell box + 1M-triangle displaced blob, PathIntegrator maxdepth 5,
           1024x1024, 256 spp (2.68e8 camera samples per step).
-          N > 1 -- configs[2] (C3) verbatim: the same scene at 4096x4096, 1024 spp (1.72e10 samples per step), the
-          image's 32x32 tiles dealt round-robin over the ranks (north_star; the reference's task split,
-          render_manager.dart:100-141), every rank accumulating a full-frame (X, Y, Z, weight) film and ONE RCCL
-          reduce per step (dr_film_reduce of the C ABI: ncclReduce over xGMI) summing them on rank 0.  Total work is
-          fixed for every N > 1 ("scaling": "strong").  Options: --scaling weak (the C2 image with N x the pixels,
-          per-GPU work fixed), --scaling strong-c2 (the 1024x1024 image itself split), --scaling samples (no tiles:
-          every rank adds its own 256 spp of the C2 image, seed + rank).
+          N > 1 -- the SAME workload per GPU ("scaling": "weak"): the C2 scene and view at 256 spp with N x the pixels
+          (a square image of side 1024 sqrt(N), rounded to whole 32-pixel tiles), its 32x32 tiles dealt round-robin
+          over the ranks (north_star; the reference's task split, render_manager.dart:100-141), every rank
+          accumulating a full-frame (X, Y, Z, weight) film and ONE RCCL reduce per step (dr_film_reduce of the C ABI:
+          ncclReduce over xGMI) summing them on rank 0 -- so value(N) / value(1) compares like with like and a step stays
+          ~0.45 s at every N.  Options: --scaling c3 (configs[2] verbatim: 4096x4096, 1024 spp, 1.72e10 samples per
+          step, total work fixed: ~14 s per step at N = 2), --scaling strong-c2 (the 1024x1024 image itself split),
+          --scaling samples (no tiles: every rank adds its own 256 spp of the C2 image, seed + rank).
           One "step" = one full pass of the hot path over the image.  Launch: `python bench.py --gpus N` starts
           the N ranks itself (torch.distributed.run, one process per GPU) unless it already runs under torchrun.
 Inputs (scene, BVH) are resident in HBM before the timed region; samples are generated on the device.  Synthetic
@@ -20,9 +21,12 @@ procedural scene, no files.  The FIRST render of a scene allocates the path-stat
 traversal-kernel pilot: it is timed separately ("first_render_ms", "pilot_ms") and is not one of the W + K steps.
 
 Extra objects on the JSON line: "roofline" for the dominant kernel k_trace<0> (closest-hit BVH traversal):
-algorithmic bytes (32 B per node visit + 48 B per triangle test, counted on the device) / the kernel's summed
-HIP-event time, against the 8 TB/s spec ("frac") and against this run's measured float4-copy rate
-("frac_of_measured"); "roofline_shade" likewise for k_shade_path; "cpu_baseline": the CPU oracle (a C++ port of
+"achieved" = ALGORITHMIC bytes (32 B per node visit + 48 B per triangle test, counted on the device) / the kernel's
+summed HIP-event time, "frac" = that against the 8 TB/s spec.  Algorithmic bytes are mostly served by L1 / L2 / the
+Infinity Cache, so this figure can exceed what HBM could deliver ("alg_over_measured_copy" > 1 on the cache-resident
+scenes): the physical picture is next to it, from the committed rocprofv3 --pmc passes of the same command and
+labelled as such -- "physical_GBps" (L2-memory-side bytes per launch / launch time), "physical_frac_of_measured"
+(against this run's float4-copy rate) and "bound_observed"; "roofline_shade" likewise for k_shade_path; "cpu_baseline": the CPU oracle (a C++ port of
 the reference path) on one host core on a strided pixel subset; "cpu_baseline_threads": the same oracle, one OS thread
 per GetSubWindow task rectangle (the reference's isolate-per-task model); "extra_configs": short C4 and C5 runs
 (2 steps each, N = 1 only, after the headline's timed region) with their own roofline objects.
@@ -43,6 +47,12 @@ NAMES = {"C2": "Cornell box + 1M-triangle displaced blob", "C3": "Cornell box + 
 PEAK_GBPS = 8000.0  # HBM3E spec (MI355X_MICROARCH.md chip table)
 
 
+def rank_command(gpus, argv, port):
+    """The command line that starts one rank per GPU (the driver's own form: torch.distributed.run on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` outside torchrun: start the N ranks as a child job (before anything touches the GPU)
     and exit with its code."""
@@ -50,9 +60,22 @@ def launch_ranks(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd))
+    raise SystemExit(subprocess.call(rank_command(args.gpus, sys.argv[1:], port)))
+
+
+def weak_resolution(res, world):
+    """Side of the square image with `world` x the pixels of a res x res one, in whole 32-pixel tiles."""
+    return int(round(res * world ** 0.5 / 32.0)) * 32
+
+
+def check_world(gpus, world_env):
+    """The launch contract: one rank per GPU.  Returns "launch" when `python bench.py --gpus N` has to start the ranks
+    itself, None when this process is a rank (or the single-GPU run); anything else is refused."""
+    if gpus > 1 and world_env == 0:
+        return "launch"
+    if world_env not in (0, gpus) or (world_env == 0 and gpus != 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s: launch one rank per GPU" % (gpus, os.environ.get("WORLD_SIZE")))
+    return None
 
 
 def shade_alg_bytes(st):
@@ -63,40 +86,77 @@ def shade_alg_bytes(st):
     return (items * 28.0                  # flags, hprim, L in; flags out (+ the entry of the active list, below)
             + later * 20.0                # active-list entry, shOcc, the finished light term (Ld1)
             + (st["camera_samples"] + st["shade_shadow"]) * 12.0   # L out: the camera stage initialises it, a light term changes it
-            + st["shade_mis"] * 136.0     # a MIS ray: misD, Ld2, misLight, betaNee out + queue entry; misPrim, misLight, Ld2, misD, betaNee, 48-B record in
-            + verts * 117.0               # ht, ro, rd, beta, 48-B primitive record, 5 sample-index bytes in; ro, rtmin out
+            + st["shade_mis"] * 120.0     # a MIS ray: misD, Ld2, misLight, betaNee out + queue entry; misPrim, misLight, Ld2, misD, betaNee, 32-B shading record in
+            + verts * 101.0               # ht, ro, rd, beta, 32-B shading record (round 3; 48-B vertex record before), 5 sample-index bytes in; ro, rtmin out
             + st["shade_cont"] * 28.0     # rd, beta + queue entry
             + st["shade_shadow"] * 36.0)  # shD, shTmax, Ld1 + queue entry
 
 
-def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>"):
+def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="C2"):
     alg = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
     launches = max(1, st["closest_launches"])
     achieved = alg / max(st["closest_ms"] * 1e-3, 1e-12) / 1e9
     all_alg = alg + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
     roof = {"bound": "hbm", "kernel": "%s (closest-hit BVH traversal)" % closest_kernel,
             "achieved": round(achieved, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_GBPS, 4),
-            "traffic": None,  # HBM-side bytes come from separate rocprofv3 --pmc passes: see "traffic_profiled"
+            "traffic": None,  # HBM-side bytes come from separate rocprofv3 --pmc passes: see "traffic_profiled" / "physical_*"
+            "achieved_is": "algorithmic bytes per second (cache hits included), not HBM traffic",
             "hbm_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
-            "frac_of_measured": round(achieved / copy_gbps, 4) if copy_gbps else None,
+            "alg_over_measured_copy": round(achieved / copy_gbps, 4) if copy_gbps else None,
             "alg_bytes_per_launch": round(alg / launches, 1),
             "avg_launch_ms": round(st["closest_ms"] / launches, 4), "launches": int(st["closest_launches"]),
             "rank0_job_alg_GBps": round(all_alg / dt_total / 1e9, 2),
             "rank0_trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt_total, 4)}
     sb = shade_alg_bytes(st)
     sa = sb / max(st["shade_ms"] * 1e-3, 1e-12) / 1e9
-    shade = {"bound": "hbm", "kernel": "k_shade_path (vertex step of PathIntegrator.Li)", "achieved": round(sa, 2),
-             "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(sa / PEAK_GBPS, 4), "traffic": None,
-             "frac_of_measured": round(sa / copy_gbps, 4) if copy_gbps else None,
+    shade = {"bound": "hbm", "kernel": "k_shade_path (vertex step of PathIntegrator.Li; + k_env on scenes with an environment map)",
+             "achieved": round(sa, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(sa / PEAK_GBPS, 4), "traffic": None,
+             "achieved_is": "algorithmic bytes per second, not HBM traffic",
+             "alg_over_measured_copy": round(sa / copy_gbps, 4) if copy_gbps else None,
              "alg_bytes_per_item": round(sb / max(1, st["shade_items"]), 1),
              "items": int(st["shade_items"]), "vertices": int(st["shade_vertices"])}
+    # the physical picture, from the committed PMC passes of the same command (never presented as this run's measurement)
+    prof = profiled_kernels(tag)
+    if prof:
+        for obj, prefix in ((roof, closest_kernel), (shade, "k_shade_path")):
+            k = next((v for n, v in prof["kernels"].items() if n.startswith(prefix)), None)
+            if not k or not k.get("hbm_side_GBps"):
+                continue
+            obj["physical_GBps"] = round(k["hbm_side_GBps"], 1)
+            obj["physical_frac_of_spec"] = round(k["hbm_side_GBps"] / PEAK_GBPS, 4)
+            obj["physical_frac_of_measured"] = round(k["hbm_side_GBps"] / copy_gbps, 4) if copy_gbps else None
+            obj["physical_source"] = prof["source"] + " (rocprofv3 --pmc: TCC_EA0_RDREQ 32/64/128 B + WRITE_SIZE per launch / kernel-trace launch time; not this run)"
+        roof["bound_observed"] = BOUND_OBSERVED.get(tag, {}).get("trace")
+        shade["bound_observed"] = BOUND_OBSERVED.get(tag, {}).get("shade")
     return roof, shade, all_alg
+
+
+# What the PMC passes say bounds each kernel (profiles/r0*_traffic.json)
+BOUND_OBSERVED = {
+    "C2": {"trace": "dependent-fetch latency, scene cache resident (L2 / Infinity Cache serve ~half the algorithmic bytes); t = 96 + 839 / workgroups-per-CU ms",
+           "shade": "f64 VALU issue (~0.7 busy) and state-access latency at 3 waves per SIMD; 1.5x the algorithmic bytes at the memory side"},
+    "C3": {"trace": "as C2 (same scene)", "shade": "as C2"},
+    "C4": {"trace": "HBM / Infinity Cache (tree beyond every cache: 640 MB nodes + 480 MB triangles), dependent fetches", "shade": "as C2"},
+    "C5": {"trace": "dependent-fetch latency, upper tree cache resident",
+           "shade": "sparse state access: a surviving slot of a thinned-out stage list touches one 128-B line per field (2.7x the algorithmic bytes)"},
+}
+
+
+def profiled_kernels(tag):
+    """Per-kernel entries of the newest committed traffic file of this config."""
+    for name in ("r03_%s_traffic.json" % tag.lower(), "r02_%s_traffic.json" % tag.lower()):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            if "kernels" in d:
+                return {"kernels": d["kernels"], "source": "profiles/" + name}
+    return None
 
 
 def profiled_traffic(tag):
     """HBM-side bytes per launch from committed rocprofv3 --pmc passes of the same command, labelled with the file
     they come from (never presented as this run's measurement)."""
-    for name in ("r02_%s_traffic.json" % tag.lower(), "r01_k_traffic.json" if tag == "C2" else None):
+    for name in ("r03_%s_traffic.json" % tag.lower(), "r02_%s_traffic.json" % tag.lower(), "r01_k_traffic.json" if tag == "C2" else None):
         if not name:
             continue
         path = os.path.join(ROOT, "profiles", name)
@@ -122,17 +182,14 @@ def main():
                          "the ALU-bound traversal) -- per-kernel event times then overlap, so the roofline "
                          "object is only meaningful with 1")
     ap.add_argument("--scaling", default=None, choices=["c3", "weak", "strong-c2", "samples"],
-                    help="N > 1: c3 (default) = configs[2] verbatim, tiles of the 4096^2 x 1024 spp image; weak = tiles of the C2 "
-                         "image with N x the pixels; strong-c2 = tiles of the 1024^2 image; samples = every rank renders "
-                         "256 spp of the whole C2 image with its own seed, films summed")
+                    help="N > 1: weak (default) = tiles of the C2 image with N x the pixels (the N = 1 workload per GPU); c3 = configs[2] "
+                         "verbatim, tiles of the 4096^2 x 1024 spp image; strong-c2 = tiles of the 1024^2 image; samples = every rank "
+                         "renders 256 spp of the whole C2 image with its own seed, films summed")
     ap.add_argument("--cpu-pixels", type=int, default=96, help="cpu baseline: side of the strided pixel grid")
     args = ap.parse_args()
 
-    world_env = int(os.environ.get("WORLD_SIZE", "0"))
-    if args.gpus > 1 and world_env == 0:
+    if check_world(args.gpus, int(os.environ.get("WORLD_SIZE", "0"))) == "launch":
         launch_ranks(args)
-    if world_env not in (0, args.gpus) or (world_env == 0 and args.gpus != 1):
-        raise SystemExit("--gpus %d but WORLD_SIZE=%s: launch one rank per GPU" % (args.gpus, os.environ.get("WORLD_SIZE")))
 
     os.environ["DARTRAY_PIPELINES"] = str(args.pipelines)  # read once by the library
     import torch
@@ -145,12 +202,12 @@ def main():
     rank, world, local = drdist.init_process_group()  # gloo control plane + dr_comm_init (RCCL) on every rank
     lib = _abi.lib()
 
-    mode = args.scaling or "c3"
+    mode = args.scaling or "weak"
     cfg = args.config or ("C2" if world == 1 or mode != "c3" else "C3")
     spp = args.spp or {"C2": 256, "C3": 1024, "C4": 64, "C5": 512}[cfg]
     res = args.res or {"C2": 1024, "C3": 4096, "C4": 1024, "C5": 2048}[cfg]
     if mode == "weak" and world > 1:
-        res = int(round(res * world ** 0.5 / 32.0)) * 32  # N x the pixels, whole tiles
+        res = weak_resolution(res, world)
     run = Run(cfg, res, spp, rank, world, mode, args)
     out = run.headline(args.steps, args.warmup)
 
@@ -234,8 +291,19 @@ class Run:
         torch.cuda.synchronize()
         drdist.barrier()
         torch.cuda.synchronize()
-        dt = drdist.max_over_ranks(time.perf_counter() - t0)
+        dt_rank = time.perf_counter() - t0
+        dt = drdist.max_over_ranks(dt_rank)
+        dt_min = -drdist.max_over_ranks(-dt_rank)
         st = self.dev.stats()
+        reduce_ms = None
+        if world > 1:  # the collective alone (after the timed region): three reduces of this film, barrier-bracketed
+            torch.cuda.synchronize()
+            drdist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                drdist.reduce_film(self.film, 0, self.stream)
+            torch.cuda.synchronize()
+            reduce_ms = drdist.max_over_ranks(time.perf_counter() - t1) / 3 * 1e3
         if rank != 0:
             return None
         copy = C.c_double(0.0)
@@ -243,7 +311,7 @@ class Run:
         samples_per_step = self.H * self.W * self.spp * (world if (self.mode == "samples" and world > 1) else 1)
         value = samples_per_step * steps / dt / 1e6
         picked = self.dev.trace_kernels()  # (closest, any): 2 = k_trace, 3 = k_trace3 (the pilot's choice for this scene)
-        roof, shade, all_alg = roofline_objects(st, dt, copy.value, "k_trace3<0>" if picked[0] == 3 else "k_trace<0>")
+        roof, shade, all_alg = roofline_objects(st, dt, copy.value, "k_trace3<0>" if picked[0] == 3 else "k_trace<0>", self.cfg)
         agg = self.scene.aggregate
         if world == 1:
             par = "1 GPU"
@@ -284,10 +352,34 @@ class Run:
         }
         if world > 1:
             out["scaling"] = {"c3": "strong", "strong-c2": "strong", "weak": "weak", "samples": "weak"}[self.mode]
+            out["rccl_world"] = int(self.lib.dr_comm_world())
+            out["per_rank_step_ms"] = {"min": round(dt_min / steps * 1e3, 3), "max": round(dt / steps * 1e3, 3)}
+            out["reduce_ms"] = round(reduce_ms, 3)
+            out["film_bytes_reduced_per_step"] = int(self.H * self.W * 16)
+            out["one_gpu_same_workload"] = one_gpu_reference(self.mode, self.cfg)
         tp = profiled_traffic(self.cfg)
         if tp and world == 1 and args.pipelines == 1 and not os.environ.get("DARTRAY_BATCH_BITS"):
             out["traffic_profiled"] = tp
         return out
+
+
+def one_gpu_reference(mode, cfg):
+    """The single-GPU rate a scaling figure of this N-rank line should be read against, from a committed single-GPU run
+    of the same per-GPU (weak) or the same total (strong) workload -- labelled with its source, not measured now."""
+    if mode in ("weak", "samples", "strong-c2"):
+        src, key = "profiles/r02_bench_final.json", "C2, 1024x1024, 256 spp on one GPU: the per-GPU workload of the weak modes, the total one of strong-c2"
+    else:
+        src, key = None, "C3 (4096x4096, 1024 spp) on one GPU: 602 Msamples/s, 28.5 s per step (DESIGN.md section 5, round 2: `bench.py --config C3 --steps 1`)"
+    ref = {"workload": key, "source": src}
+    if src and os.path.exists(os.path.join(ROOT, src)):
+        try:
+            ref["value"] = json.loads(open(os.path.join(ROOT, src)).read().strip().splitlines()[-1])["value"]
+            ref["unit"] = "Msamples/s"
+        except (ValueError, KeyError):
+            pass
+    elif not src:
+        ref["value"], ref["unit"], ref["source"] = 602.0, "Msamples/s", "DESIGN.md section 5 (round 2)"
+    return ref
 
 
 def cpu_baseline(prims, renderer, grid, H, W, spp):

@@ -136,6 +136,8 @@ EXPORTS = {
                                C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint32)]),
     "dr_bvh_build_mixed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32,
                                      C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint32)]),
+    "dr_bvh_build_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32,
+                                      C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint32)]),
     "dr_scene_create": (C.c_int, [C.POINTER(DrSceneDesc), C.POINTER(C.c_void_p)]),
     "dr_scene_destroy": (None, [C.c_void_p]),
     "dr_scene_get_trace_kernels": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32 * 2)]),

@@ -16,6 +16,7 @@ compute itself happens in libdartray_hip.so.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -307,6 +308,27 @@ NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<u4")
 # ---------------------------------------------------------------------------
 # BVHAccel (lib/accelerators/bvh_accel.dart) -- the Aggregate of the scene
 # ---------------------------------------------------------------------------
+def build_bvh_arrays(verts, refined, quadric_bounds, nquadrics, max_prims, builder=None):
+    """BVHAccel's constructor (bvh_accel.dart:41-91,228-437) through the C ABI: (nodes, order, nnodes, depth).
+    builder: "device" = dr_bvh_build_device (HIP; needs an initialised GPU), "host" = dr_bvh_build_mixed (C++ threads);
+    None = the environment's DARTRAY_BVH_BUILDER, else the device builder whenever a GPU has been selected.  Both write
+    the same bytes (tests/test_gpu_bvh_device.py)."""
+    n = len(refined)
+    lib = _abi.lib()
+    if builder is None:
+        builder = os.environ.get("DARTRAY_BVH_BUILDER") or ("device" if _abi._initialised is not None else "host")
+    if builder not in ("device", "host"):
+        raise ValueError("builder must be 'device' or 'host'")
+    nodes = np.zeros(max(2 * n - 1, 1), dtype=NODE_DTYPE)
+    order = np.zeros(max(n, 1), dtype=np.uint32)
+    nn = C.c_uint64(0)
+    depth = C.c_uint32(0)
+    fn = lib.dr_bvh_build_device if builder == "device" else lib.dr_bvh_build_mixed
+    _abi.check(fn(verts.ctypes.data, len(verts), refined.ctypes.data, n, quadric_bounds.ctypes.data, nquadrics, max_prims,
+                  nodes.ctypes.data, C.byref(nn), order.ctypes.data, C.byref(depth)))
+    return nodes, order, int(nn.value), int(depth.value)
+
+
 class BVHAccel:
     """Aggregate 'bvh' (accelerators/bvh_accel.dart:36-91).
 
@@ -315,7 +337,7 @@ class BVHAccel:
     `nodes` (32-byte _LinearBVHNode records) and the per-primitive tables in
     `primitives` order."""
 
-    def __init__(self, p, maxPrims=4, splitMethod="sah"):
+    def __init__(self, p, maxPrims=4, splitMethod="sah", builder=None):
         if splitMethod != "sah":
             raise NotImplementedError("only the default 'sah' split method is on the path")
         self.maxPrimsInNode = min(255, int(maxPrims))
@@ -374,21 +396,14 @@ class BVHAccel:
             self.vert_tangents = np.ascontiguousarray(np.concatenate(vs), np.float32)
             self.vert_uvs = np.ascontiguousarray(np.concatenate(vuv), np.float32)
         n = len(refined)
-        lib = _abi.lib()
-        nodes = np.zeros(max(2 * n - 1, 1), dtype=NODE_DTYPE)
-        order = np.zeros(max(n, 1), dtype=np.uint32)
-        nn = C.c_uint64(0)
-        depth = C.c_uint32(0)
         qb = np.zeros((max(len(self.quadrics), 1), 6), dtype=np.float32)
         for i, q in enumerate(self.quadrics):
             lo, hi = q.worldBound()
             qb[i, :3], qb[i, 3:] = lo, hi
-        _abi.check(lib.dr_bvh_build_mixed(self.verts.ctypes.data, len(self.verts), refined.ctypes.data, n,
-                                          qb.ctypes.data, len(self.quadrics), self.maxPrimsInNode, nodes.ctypes.data,
-                                          C.byref(nn), order.ctypes.data, C.byref(depth)))
+        nodes, order, nn, depth = build_bvh_arrays(self.verts, refined, qb, len(self.quadrics), self.maxPrimsInNode, builder)
         order = order[:n]
-        self.nodes = nodes[:nn.value] if n else None  # bvh_accel.dart:50-53
-        self.depth = int(depth.value)
+        self.nodes = nodes[:nn] if n else None  # bvh_accel.dart:50-53
+        self.depth = int(depth)
         self.order = order
         # BVHAccel.primitives (orderedPrims, bvh_accel.dart:69-76)
         self.tri_idx = np.ascontiguousarray(refined[order])
@@ -427,10 +442,11 @@ class BVHAccel:
         lists differ (e.g. with and without an InfiniteAreaLight): the cache is keyed on the list's identity."""
         want = self._lights if lights is None else lights
         key = tuple(id(l) for l in want)
-        if self._scene is None or self._scene_key != key:
-            self._scene = _DeviceScene(self, want)
-            self._scene_key = key
-        return self._scene
+        cache = self.__dict__.setdefault("_scenes", {})
+        if key not in cache:  # every light list keeps its own upload: alternating callers do not evict each other
+            cache[key] = _DeviceScene(self, want)
+        self._scene, self._scene_key = cache[key], key
+        return cache[key]
 
     def intersect(self, ray):
         """Aggregate.intersect (bvh_accel.dart:101-165) on a batch: returns a
@@ -625,11 +641,11 @@ class Scene:
     def _device(self):
         return self.aggregate._device_scene(self.lights)
 
-    def intersect(self, ray):  # scene.dart:51-56
-        return self.aggregate.intersect(ray)
+    def intersect(self, ray):  # scene.dart:51-56 (through this Scene's own device scene: one upload per Scene)
+        return self._device().intersect(ray, any_hit=False)
 
     def intersectP(self, ray):  # scene.dart:63-68
-        return self.aggregate.intersectP(ray)
+        return self._device().intersect(ray, any_hit=True)["prim"] >= 0
 
 
 # ---------------------------------------------------------------------------

@@ -1427,17 +1427,23 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       HIP_TRY(hipMemcpy(c, sc->ctr.p, sizeof(TraceCounters), hipMemcpyDeviceToHost));
       return DR_OK;
     };
+    const uint32_t keepKernel[2] = {sc->d.traceKernel[0], sc->d.traceKernel[1]};
+    auto abandon = [&](int code) {  // an error in the middle: the scene keeps the choice it had, not a forced one
+      sc->d.traceKernel[0] = keepKernel[0];
+      sc->d.traceKernel[1] = keepKernel[1];
+      return code;
+    };
     for (int set = 0; set < 3; ++set) {  // warm-up (v2), v2 timed, v3 timed
       const int impl = set == 2 ? 3 : 2;
       sc->d.traceKernel[0] = sc->d.traceKernel[1] = (uint32_t)impl;
       TraceCounters c0, c1;
       int prc = readCtr(&c0);
-      if (prc) return prc;
+      if (prc) return abandon(prc);
       PilotTimes pt;
       prc = runBatch(sc->ws, sc->ws.pix.p + set * calibPix, set * calibPix, (uint32_t)calibPix, &pt);
-      if (prc) return prc;
+      if (prc) return abandon(prc);
       prc = readCtr(&c1);
-      if (prc) return prc;
+      if (prc) return abandon(prc);
       if (set == 0) continue;
       const double bytes[2] = {32.0 * (double)(c1.closest_nodes - c0.closest_nodes) + 48.0 * (double)(c1.closest_tris - c0.closest_tris),
                                32.0 * (double)(c1.any_nodes - c0.any_nodes) + 48.0 * (double)(c1.any_tris - c0.any_tris)};

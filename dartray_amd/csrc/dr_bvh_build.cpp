@@ -22,6 +22,21 @@
 
 namespace {
 
+// dart:math min / max (BBox.union / unionPoint, bbox.dart:135-155): the lesser / greater value, -0.0 below +0.0 --
+// std::min / std::max would keep whichever zero came first, and the result would depend on the order of the items
+static inline float dartMin(float a, float b) {
+  if (a > b) return b;
+  if (a < b) return a;
+  if (a == 0.0f) return (float)(((double)a + (double)b) * (double)a * (double)b);
+  return b != b ? b : a;
+}
+static inline float dartMax(float a, float b) {
+  if (a > b) return a;
+  if (a < b) return b;
+  if (a == 0.0f) return a + b;
+  return b != b ? b : a;
+}
+
 struct Box {
   float lo[3], hi[3];
   void reset() {
@@ -32,14 +47,14 @@ struct Box {
   }
   void grow(const Box& b) {
     for (int k = 0; k < 3; ++k) {
-      lo[k] = std::min(lo[k], b.lo[k]);
-      hi[k] = std::max(hi[k], b.hi[k]);
+      lo[k] = dartMin(lo[k], b.lo[k]);
+      hi[k] = dartMax(hi[k], b.hi[k]);
     }
   }
   void growPoint(const float* p) {
     for (int k = 0; k < 3; ++k) {
-      lo[k] = std::min(lo[k], p[k]);
-      hi[k] = std::max(hi[k], p[k]);
+      lo[k] = dartMin(lo[k], p[k]);
+      hi[k] = dartMax(hi[k], p[k]);
     }
   }
   // BBox.surfaceArea (bbox.dart:163-166): d = pMax - pMin is a Vector (f32)

@@ -30,6 +30,22 @@ struct NcclUniqueId {
 typedef void* NcclComm;
 enum { kNcclFloat32 = 7, kNcclFloat64 = 8 };  // ncclDataType_t
 enum { kNcclSum = 0, kNcclMax = 2 };          // ncclRedOp_t
+}  // namespace
+
+// The hand-declared subset above is checked against the installed header at BUILD time (declarations only: nothing of
+// librccl is linked), and the library bound at run time must be the same major version.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+static_assert((int)ncclFloat32 == kNcclFloat32 && (int)ncclFloat64 == kNcclFloat64, "ncclDataType_t values changed");
+static_assert((int)ncclSum == kNcclSum && (int)ncclMax == kNcclMax, "ncclRedOp_t values changed");
+static_assert(sizeof(ncclUniqueId) == DR_COMM_ID_BYTES && NCCL_UNIQUE_ID_BYTES == DR_COMM_ID_BYTES, "ncclUniqueId is not DR_COMM_ID_BYTES long");
+static_assert(sizeof(ncclComm_t) == sizeof(void*), "ncclComm_t is not a pointer");
+#define DR_RCCL_BUILD_MAJOR NCCL_MAJOR
+#else
+#define DR_RCCL_BUILD_MAJOR 2
+#endif
+
+namespace {
 
 struct Rccl {
   void* handle = nullptr;
@@ -39,6 +55,7 @@ struct Rccl {
   int (*Reduce)(const void*, void*, size_t, int, int, int, NcclComm, hipStream_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
 };
 
 Rccl g_rccl;
@@ -79,7 +96,16 @@ int loadRccl() {
   BIND(Reduce, "ncclReduce");
   BIND(AllReduce, "ncclAllReduce");
   BIND(GetErrorString, "ncclGetErrorString");
+  BIND(GetVersion, "ncclGetVersion");
 #undef BIND
+  {  // NCCL_VERSION_CODE = major * 10000 + minor * 100 + patch since 2.9 (major * 1000 + ... before): same major as the header
+    int v = 0;
+    if (r.GetVersion(&v) != 0) return dr_fail(DR_ERR_UNSUPPORTED, "ncclGetVersion failed");
+    const int major = v >= 10000 ? v / 10000 : v / 1000;
+    if (major != DR_RCCL_BUILD_MAJOR)
+      return dr_fail(DR_ERR_UNSUPPORTED, "librccl major version " + std::to_string(major) + " differs from the ABI subset this library declares (" +
+                                             std::to_string(DR_RCCL_BUILD_MAJOR) + ")");
+  }
   g_rccl = r;
   return DR_OK;
 }

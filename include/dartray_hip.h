@@ -23,6 +23,7 @@
 #ifndef DARTRAY_HIP_H
 #define DARTRAY_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -286,6 +287,16 @@ int dr_bvh_build_mixed(const float* verts, uint64_t nverts, const uint32_t* tri_
                        const float* quadric_bounds, uint64_t nquadrics, int32_t max_prims_in_node,
                        DrBvhNode* nodes_out, uint64_t* nnodes_out, uint32_t* order_out, uint32_t* depth_out);
 
+/* The same constructor ON THE GPU (dr_bvh_device.hip): identical arguments (host
+ * pointers) and byte-identical nodes_out / order_out -- the bounds, the centroid bounds and the 12 SAH buckets are
+ * device-wide reductions, the reference's two-pointer `partition` (common.dart:256-287) is the swap of the k-th
+ * misplaced item of the left part with the k-th from the end (ranks from one prefix sum), sub-trees of at most 64
+ * items are finished by one thread each with the reference's recursion as it stands.  Needs dr_init.  The host
+ * builder above stays as the fallback (no GPU) and as this one's checker. */
+int dr_bvh_build_device(const float* verts, uint64_t nverts, const uint32_t* tri_idx, uint64_t ntris,
+                        const float* quadric_bounds, uint64_t nquadrics, int32_t max_prims_in_node,
+                        DrBvhNode* nodes_out, uint64_t* nnodes_out, uint32_t* order_out, uint32_t* depth_out);
+
 /* Scene upload (replaces the construction of lib/core/scene.dart Scene). */
 int dr_scene_create(const DrSceneDesc* desc, DrScene** out);
 void dr_scene_destroy(DrScene* scene);
@@ -323,7 +334,11 @@ int dr_render(DrScene* scene, const DrRenderDesc* desc, float* film_out, float* 
  * Everything the call enqueues is ordered behind earlier work of hip_stream and
  * in front of later work of it; internally a stage's any-hit launch runs on a
  * stream of the scene's own, beside the closest-hit launch, tied to hip_stream
- * by events (DARTRAY_OVERLAP_ANY=0: everything on hip_stream). */
+ * by events (DARTRAY_OVERLAP_ANY=0: everything on hip_stream).
+ * The call returns with its kernels enqueued, except in three cases where it waits for hip_stream itself: the
+ * first big render of a big scene (the traversal-kernel pilot reads its counters back between its three batches),
+ * DR_SAMPLER_HOST_BUFFER (the host sample buffers of a batch are staged before the next batch reuses the area), and
+ * DirectLighting over mirror / glass materials (one count is read back per round of the specular recursion). */
 int dr_render_device(DrScene* scene, const DrRenderDesc* desc, void* film_dev, void* hip_stream);
 
 /* The raster pixels a DR_SAMPLER_COUNTER render of `desc` traces, in trace
@@ -370,7 +385,6 @@ const char* dr_version(void);
 
 /* ---- layout checks: a foreign host (dart:ffi Struct classes, ctypes, a C program) must see exactly these
  * sizes and offsets (LP64, little endian, natural alignment) ---- */
-#include <stddef.h>
 #ifdef __cplusplus
 #define DR_ABI_ASSERT(c, m) static_assert(c, m)
 #else

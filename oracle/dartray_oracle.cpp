@@ -864,16 +864,34 @@ static V sphere_sample2(const Quadric& q, const V& p, D u1, D u2, V* ns) {
 struct BBox {
   V pMin{kInf, kInf, kInf}, pMax{-kInf, -kInf, -kInf};  // bbox.dart:31-34
 };
+// dart:math min / max on doubles (sdk/lib/math/math.dart, restated from memory of the SDK source like the generator in
+// dr_rng.h): the lesser / greater argument, and for two zeros of different sign min is -0.0 ((a + b) * a * b) and max is
+// +0.0 (a + b) -- std::min / std::max keep whichever zero came first.  Only a box whose extreme coordinate is a zero
+// of both signs can tell the difference (the union of vertices at -0.0 and +0.0).
+static inline D dartMin(D a, D b) {
+  if (a > b) return b;
+  if (a < b) return a;
+  if (a == 0.0) return (a + b) * a * b;
+  if (b != b) return b;
+  return a;
+}
+static inline D dartMax(D a, D b) {
+  if (a > b) return a;
+  if (a < b) return b;
+  if (a == 0.0) return a + b;
+  if (b != b) return b;
+  return a;
+}
 static inline BBox bunion(const BBox& a, const BBox& b) {  // bbox.dart:152-161,203-205
   BBox r;
-  r.pMin = V{std::min(a.pMin.x, b.pMin.x), std::min(a.pMin.y, b.pMin.y), std::min(a.pMin.z, b.pMin.z)};
-  r.pMax = V{std::max(a.pMax.x, b.pMax.x), std::max(a.pMax.y, b.pMax.y), std::max(a.pMax.z, b.pMax.z)};
+  r.pMin = V{dartMin(a.pMin.x, b.pMin.x), dartMin(a.pMin.y, b.pMin.y), dartMin(a.pMin.z, b.pMin.z)};
+  r.pMax = V{dartMax(a.pMax.x, b.pMax.x), dartMax(a.pMax.y, b.pMax.y), dartMax(a.pMax.z, b.pMax.z)};
   return r;
 }
 static inline BBox bunionP(const BBox& a, const V& p) {  // bbox.dart:141-150,199-201
   BBox r;
-  r.pMin = V{std::min(a.pMin.x, p.x), std::min(a.pMin.y, p.y), std::min(a.pMin.z, p.z)};
-  r.pMax = V{std::max(a.pMax.x, p.x), std::max(a.pMax.y, p.y), std::max(a.pMax.z, p.z)};
+  r.pMin = V{dartMin(a.pMin.x, p.x), dartMin(a.pMin.y, p.y), dartMin(a.pMin.z, p.z)};
+  r.pMax = V{dartMax(a.pMax.x, p.x), dartMax(a.pMax.y, p.y), dartMax(a.pMax.z, p.z)};
   return r;
 }
 static inline D bsurfaceArea(const BBox& b) {  // bbox.dart:163-166
@@ -1066,8 +1084,8 @@ struct Builder {
         V lo = q.kind == 1 ? vec(-q.radius, -q.radius, q.zmin) : vec(-q.radius, -q.radius, q.height);
         V hi = q.kind == 1 ? vec(q.radius, q.radius, q.zmax) : vec(q.radius, q.radius, q.height);
         BBox ob;  // BBox(p1, p2) bbox.dart:36-40
-        ob.pMin = V{std::min(lo.x, hi.x), std::min(lo.y, hi.y), std::min(lo.z, hi.z)};
-        ob.pMax = V{std::max(lo.x, hi.x), std::max(lo.y, hi.y), std::max(lo.z, hi.z)};
+        ob.pMin = V{dartMin(lo.x, hi.x), dartMin(lo.y, hi.y), dartMin(lo.z, hi.z)};
+        ob.pMax = V{dartMax(lo.x, hi.x), dartMax(lo.y, hi.y), dartMax(lo.z, hi.z)};
         const V c8[8] = {ob.pMin, V{ob.pMax.x, ob.pMin.y, ob.pMin.z}, V{ob.pMin.x, ob.pMax.y, ob.pMin.z},
                          V{ob.pMin.x, ob.pMin.y, ob.pMax.z}, V{ob.pMin.x, ob.pMax.y, ob.pMax.z},
                          V{ob.pMax.x, ob.pMax.y, ob.pMin.z}, V{ob.pMax.x, ob.pMin.y, ob.pMax.z}, ob.pMax};
@@ -1075,8 +1093,8 @@ struct Builder {
       } else {
         V a = sc->vert(pr.v[0]), b = sc->vert(pr.v[1]), c = sc->vert(pr.v[2]);
         // Triangle.worldBound triangle.dart:39-42
-        bb.pMin = V{std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)};
-        bb.pMax = V{std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)};
+        bb.pMin = V{dartMin(a.x, b.x), dartMin(a.y, b.y), dartMin(a.z, b.z)};
+        bb.pMax = V{dartMax(a.x, b.x), dartMax(a.y, b.y), dartMax(a.z, b.z)};
         bb = bunionP(bb, c);
       }
       buildData[i].primitiveNumber = i;

@@ -1572,6 +1572,27 @@ def renderer_Li(scene, integrator, maxDepth, camera, px, py, sv, draws, nSamples
 # accelerators/bvh_accel.dart:41-91, 228-437 (the SAH build and the depth-first flattening), core/bbox.dart,
 # core/common.dart:255-297 (partition, nth_element), core/primitive.dart:71-84 (fullyRefine)
 # ---------------------------------------------------------------------------------------------------------------
+def dart_min(a, b):
+    """dart:math min on doubles (from memory of sdk/lib/math/math.dart): for zeros of different sign the result is -0.0."""
+    if a > b:
+        return b
+    if a < b:
+        return a
+    if a == 0.0:
+        return (a + b) * a * b
+    return b if b != b else a
+
+
+def dart_max(a, b):
+    if a > b:
+        return a
+    if a < b:
+        return b
+    if a == 0.0:
+        return a + b
+    return b if b != b else a
+
+
 class BBox:                                                        # bbox.dart:27-60: pMin / pMax are Points (f32)
     __slots__ = ("mn", "mx")
 
@@ -1579,21 +1600,21 @@ class BBox:                                                        # bbox.dart:2
         if p1 is None:
             self.mn, self.mx = Vec(INFINITY, INFINITY, INFINITY), Vec(-INFINITY, -INFINITY, -INFINITY)
         else:
-            self.mn = Vec(min(p1.x, p2.x), min(p1.y, p2.y), min(p1.z, p2.z))
-            self.mx = Vec(max(p1.x, p2.x), max(p1.y, p2.y), max(p1.z, p2.z))
+            self.mn = Vec(dart_min(p1.x, p2.x), dart_min(p1.y, p2.y), dart_min(p1.z, p2.z))
+            self.mx = Vec(dart_max(p1.x, p2.x), dart_max(p1.y, p2.y), dart_max(p1.z, p2.z))
 
     @staticmethod
     def Union(b, b2):                                              # bbox.dart:146-155, 203-205
         r = BBox()
-        r.mn = Vec(min(b.mn.x, b2.mn.x), min(b.mn.y, b2.mn.y), min(b.mn.z, b2.mn.z))
-        r.mx = Vec(max(b.mx.x, b2.mx.x), max(b.mx.y, b2.mx.y), max(b.mx.z, b2.mx.z))
+        r.mn = Vec(dart_min(b.mn.x, b2.mn.x), dart_min(b.mn.y, b2.mn.y), dart_min(b.mn.z, b2.mn.z))
+        r.mx = Vec(dart_max(b.mx.x, b2.mx.x), dart_max(b.mx.y, b2.mx.y), dart_max(b.mx.z, b2.mx.z))
         return r
 
     @staticmethod
     def UnionPoint(b, q):                                          # bbox.dart:135-144, 199-201
         r = BBox()
-        r.mn = Vec(min(b.mn.x, q.x), min(b.mn.y, q.y), min(b.mn.z, q.z))
-        r.mx = Vec(max(b.mx.x, q.x), max(b.mx.y, q.y), max(b.mx.z, q.z))
+        r.mn = Vec(dart_min(b.mn.x, q.x), dart_min(b.mn.y, q.y), dart_min(b.mn.z, q.z))
+        r.mx = Vec(dart_max(b.mx.x, q.x), dart_max(b.mx.y, q.y), dart_max(b.mx.z, q.z))
         return r
 
     def center(self):                                              # bbox.dart:71

@@ -1,10 +1,11 @@
-"""profiles/r02_<cfg>_traffic.json from the PMC summaries of tools/profile_r02.sh: HBM-side bytes per launch of the
+"""profiles/r0N_<cfg>_traffic.json from the PMC summaries of tools/profile_r0N.sh (usage: make_traffic.py SRC cfg OUT [round]): HBM-side bytes per launch of the
 dominant traversal kernel and of k_shade_path, exactly as MI355X_MICROARCH.md prescribes (separate --pmc passes;
 reads = TCC_EA0_RDREQ_128B * 128 + _64B * 64 + _32B * 32 -- every wide read of these kernels is a 128-B request, so
 FETCH_SIZE would under-report 2x; writes = WRITE_SIZE KB * 1024)."""
 import csv, json, re, sys
 
 src, cfg, out = sys.argv[1], sys.argv[2], sys.argv[3]
+rnd = sys.argv[4] if len(sys.argv) > 4 else "r02"
 
 
 def pmc(path):
@@ -28,7 +29,7 @@ stats = {r["Name"]: r for r in csv.DictReader(open(_serial if os.path.exists(_se
 bench = json.load(open("%s/%s_bench.json" % (src, cfg)))
 res = {"workload": bench["config"]["workload"], "bench_value_under_rocprof": bench["value"], "kernels": {}}
 for name in rd:
-    if not (name.startswith("k_trace") or name.startswith("k_shade_path")):
+    if not (name.startswith("k_trace") or name.startswith("k_shade_path") or name.startswith("k_env")):
         continue
     r, w, s = rd[name], wr.get(name, {}), sq.get(name, {})
     reads = r.get("TCC_EA0_RDREQ_128B", 0) * 128 + r.get("TCC_EA0_RDREQ_64B", 0) * 64 + r.get("TCC_EA0_RDREQ_32B", 0) * 32
@@ -53,11 +54,11 @@ res["kernel"] = dom
 res["hbm_bytes_per_launch"] = res["kernels"][dom]["hbm_bytes_per_launch"]
 res["alg_bytes_per_launch"] = bench["roofline"]["alg_bytes_per_launch"]
 res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / bench["roofline"]["alg_bytes_per_launch"]
-res["method"] = ("tools/profile_r02.sh: rocprofv3 --pmc passes (counters only) on `DARTRAY_TRACE_IMPL=%s python3 bench.py %s--steps 1 --warmup 0 "
+res["method"] = ("tools/profile_%s.sh: rocprofv3 --pmc passes (counters only) on `DARTRAY_TRACE_IMPL=%s python3 bench.py %s--steps 1 --warmup 0 "
                  "--no-cpu-baseline --no-extra` (two full renders, every launch full size); launch times from the --kernel-trace --stats "
                  "run of the same script.  Counters sit on the L2's memory side, so Infinity-Cache hits are included: an upper bound on "
-                 "HBM bytes." % ("3" if dom.startswith("k_trace3") else "2", "" if cfg == "c2" else "--config %s " % cfg.upper()))
-res["sources"] = ["profiles/r02_pmc_%s_rdreq.txt" % cfg, "profiles/r02_pmc_%s_wrreq.txt" % cfg, "profiles/r02_pmc_%s_sq.txt" % cfg,
-                  "profiles/r02_%s_kernel_stats.csv" % cfg]
+                 "HBM bytes." % (rnd, "3" if dom.startswith("k_trace3") else "2", "" if cfg == "c2" else "--config %s " % cfg.upper()))
+res["sources"] = ["profiles/%s_pmc_%s_rdreq.txt" % (rnd, cfg), "profiles/%s_pmc_%s_wrreq.txt" % (rnd, cfg), "profiles/%s_pmc_%s_sq.txt" % (rnd, cfg),
+                  "profiles/%s_%s_kernel_stats_serial.csv" % (rnd, cfg)]
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1)[:1800])
