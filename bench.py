@@ -201,6 +201,7 @@ def main():
     torch.cuda.set_device(local)
     rank, world, local = drdist.init_process_group()  # gloo control plane + dr_comm_init (RCCL) on every rank
     lib = _abi.lib()
+    _abi.init(local)  # before the scenes are built: BVHAccel then takes the device builder (dr_bvh_build_device)
 
     mode = args.scaling or "weak"
     cfg = args.config or ("C2" if world == 1 or mode != "c3" else "C3")
@@ -334,6 +335,7 @@ class Run:
             "config": {"workload": "%s: %s, PathIntegrator maxdepth=%d, %dx%d, %d spp, LD sampler (device, counter streams), box filter"
                        % (self.cfg, NAMES[self.cfg], self.renderer.surfaceIntegrator.maxDepth, self.res, self.res, self.spp),
                        "triangles": int(len(agg.tri_idx)), "bvh_nodes": int(len(agg.nodes)),
+                       "bvh_builder": "%s (dr_bvh_build_%s), %.0f ms" % (agg.builder, "device" if agg.builder == "device" else "mixed", agg.build_ms),
                        "samples_per_step": samples_per_step, "parallelism": par, "pipelines": args.pipelines,
                        "sampler_mode": "DR_SAMPLER_COUNTER (keyed per-pixel streams, bit-exact vs the oracle's same mode); the reference's "
                                        "single serial Random(taskNum) stream is replayed bit-exactly through DR_SAMPLER_HOST_BUFFER in the "

@@ -20,6 +20,7 @@ DR_LIGHT_INFINITE = 1
 DR_LIGHT_POINT = 2
 DR_LIGHT_SPOT = 3
 DR_LIGHT_DISTANT = 4
+DR_LIGHT_SPOT_COS = 5
 
 
 class DrBvhNode(C.Structure):
@@ -147,6 +148,7 @@ EXPORTS = {
     "dr_scene_sample_floats": (C.c_int32, [C.c_void_p, C.c_int32]),
     "dr_render": (C.c_int, [C.c_void_p, C.POINTER(DrRenderDesc), C.c_void_p, C.c_void_p]),
     "dr_render_device": (C.c_int, [C.c_void_p, C.POINTER(DrRenderDesc), C.c_void_p, C.c_void_p]),
+    "dr_render_sharded": (C.c_int, [C.c_void_p, C.POINTER(DrRenderDesc), C.c_int32, C.c_void_p, C.c_void_p]),
     "dr_film_resolve_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "dr_enumerate_pixels": (C.c_int, [C.POINTER(DrRenderDesc), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "dr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(DrRenderStats)]),

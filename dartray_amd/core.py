@@ -400,7 +400,11 @@ class BVHAccel:
         for i, q in enumerate(self.quadrics):
             lo, hi = q.worldBound()
             qb[i, :3], qb[i, 3:] = lo, hi
+        import time as _time
+        _t0 = _time.perf_counter()
         nodes, order, nn, depth = build_bvh_arrays(self.verts, refined, qb, len(self.quadrics), self.maxPrimsInNode, builder)
+        self.build_ms = (_time.perf_counter() - _t0) * 1e3  # the constructor proper (host pointers in and out)
+        self.builder = builder or os.environ.get("DARTRAY_BVH_BUILDER") or ("device" if _abi._initialised is not None else "host")
         order = order[:n]
         self.nodes = nodes[:nn] if n else None  # bvh_accel.dart:50-53
         self.depth = int(depth)
@@ -508,7 +512,13 @@ class _DeviceScene:
                 dl[i].position[:] = [float(x) for x in L.lightPos]
                 if isinstance(L, SpotLight):
                     dl[i].world_to_light[:] = [float(x) for x in L.worldToLight.reshape(-1)]
-                    dl[i].cone_width, dl[i].cone_falloff_start = L.width, L.fall
+                    if getattr(L, "marshal_cosines", False):
+                        # what a host that only holds the constructed SpotLight has (spot_light.dart:46-47): the two cosines
+                        dl[i].kind = _abi.DR_LIGHT_SPOT_COS
+                        dl[i].cone_width = math.cos(math.radians(L.width))
+                        dl[i].cone_falloff_start = math.cos(math.radians(L.fall))
+                    else:
+                        dl[i].cone_width, dl[i].cone_falloff_start = L.width, L.fall
                 continue
             if isinstance(L, InfiniteAreaLight):
                 e = _abi.DrEnvMap()
@@ -1173,6 +1183,22 @@ class SamplerRenderer:
         del keep
         self.last_stats = dev.stats()
         return OutputImage(film.left, film.top, film.width, film.height, out_rgb, out_film)
+
+    def render_sharded(self, scene, root=0):
+        """One rank's part of a sharded render (dr_render_sharded): this renderer's tile / task share, ONE film reduce over
+        the communicator of dr_comm_init, and on the root rank the OutputImage; other ranks return None.  What
+        RenderManager's fan-out and rectangle merge do in the host (render_manager.dart:100-141), as one C call."""
+        film = self.camera.film
+        d, keep = self.describe()
+        lib = _abi.lib()
+        is_root = lib.dr_comm_world() <= 1 or lib.dr_comm_rank() == root
+        out_film = np.zeros((film.height, film.width, 4), dtype=np.float32) if is_root else None
+        out_rgb = np.zeros((film.height, film.width, 3), dtype=np.float32) if is_root else None
+        dev = scene._device()
+        _abi.check(lib.dr_render_sharded(dev.handle, C.byref(d), root, out_film.ctypes.data if is_root else None,
+                                         out_rgb.ctypes.data if is_root else None))
+        del keep
+        return OutputImage(film.left, film.top, film.width, film.height, out_rgb, out_film) if is_root else None
 
     def pixels(self):
         """Raster pixels this renderer's task / tile share traces, in trace order (host-only)."""

@@ -702,17 +702,21 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         sc->lightNSamples.push_back(d.nsamples);
         continue;
       }
-      if (a.kind == DR_LIGHT_POINT || a.kind == DR_LIGHT_SPOT || a.kind == DR_LIGHT_DISTANT) {
+      if (a.kind == DR_LIGHT_POINT || a.kind == DR_LIGHT_SPOT || a.kind == DR_LIGHT_SPOT_COS || a.kind == DR_LIGHT_DISTANT) {
         DLight& d = L[i];
         memset(&d, 0, sizeof(d));
         d.L[0] = a.L[0]; d.L[1] = a.L[1]; d.L[2] = a.L[2];
         d.nsamples = 1;
-        d.kind = a.kind;
+        d.kind = a.kind == DR_LIGHT_SPOT_COS ? DR_LIGHT_SPOT : a.kind;
         d.pos[0] = a.position[0]; d.pos[1] = a.position[1]; d.pos[2] = a.position[2];
         if (a.kind == DR_LIGHT_SPOT) {  // spot_light.dart:42-48
           for (int k = 0; k < 12; ++k) d.w2l[k] = a.world_to_light[k];
           d.cosTotalWidth = std::cos((3.141592653589793 / 180.0) * a.cone_width);
           d.cosFalloffStart = std::cos((3.141592653589793 / 180.0) * a.cone_falloff_start);
+        } else if (a.kind == DR_LIGHT_SPOT_COS) {  // the cosines a constructed SpotLight keeps (spot_light.dart:46-47)
+          for (int k = 0; k < 12; ++k) d.w2l[k] = a.world_to_light[k];
+          d.cosTotalWidth = a.cone_width;
+          d.cosFalloffStart = a.cone_falloff_start;
         }
         sc->lightNSamples.push_back(1);
         sc->hasDeltaLight = true;
@@ -1575,6 +1579,35 @@ int dr_render(DrScene* sc, const DrRenderDesc* rd, float* film_out, float* rgb_o
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(film_out, film.p, 4 * npix * sizeof(float), hipMemcpyDeviceToHost));
   if (rgb_out) HIP_TRY(hipMemcpy(rgb_out, rgb.p, 3 * npix * sizeof(float), hipMemcpyDeviceToHost));
+  return DR_OK;
+}
+
+int dr_render_sharded(DrScene* sc, const DrRenderDesc* rd, int32_t root, float* film_out, float* rgb_out) {
+  if (!sc || !rd) return fail(DR_ERR_INVALID, "null argument");
+  const int world = dr_comm_world(), rank = dr_comm_rank();
+  if (world > 1 ? (root < 0 || root >= world) : root != 0) return fail(DR_ERR_INVALID, "dr_render_sharded: root out of range");
+  RenderParams rp;
+  memset(&rp, 0, sizeof(rp));
+  rp_film(rp, rd->film);
+  const int64_t npix = (int64_t)rp.width * rp.height;
+  DevBuf<float> film, rgb;
+  HIP_TRY(film.alloc(4 * npix));
+  HIP_TRY(hipMemset(film.p, 0, 4 * npix * sizeof(float)));
+  int rc = dr_render_device(sc, rd, film.p, nullptr);
+  if (rc) return rc;
+  if (world > 1) {
+    rc = dr_film_reduce(film.p, npix, root, nullptr);
+    if (rc) return rc;
+  }
+  const bool isRoot = world > 1 ? rank == root : true;
+  if (isRoot && rgb_out) {
+    HIP_TRY(rgb.alloc(3 * npix));
+    rc = dr_film_resolve_device(film.p, npix, rgb.p, nullptr);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  if (isRoot && film_out) HIP_TRY(hipMemcpy(film_out, film.p, 4 * npix * sizeof(float), hipMemcpyDeviceToHost));
+  if (isRoot && rgb_out) HIP_TRY(hipMemcpy(rgb_out, rgb.p, 3 * npix * sizeof(float), hipMemcpyDeviceToHost));
   return DR_OK;
 }
 

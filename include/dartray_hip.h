@@ -67,6 +67,12 @@ typedef struct DrMaterial {
 #define DR_LIGHT_POINT 2        /* PointLight (lib/lights/point_light.dart): a delta light */
 #define DR_LIGHT_SPOT 3         /* SpotLight (lib/lights/spot_light.dart): a delta light */
 #define DR_LIGHT_DISTANT 4      /* DistantLight (lib/lights/distant_light.dart): a delta light */
+#define DR_LIGHT_SPOT_COS 5     /* DR_LIGHT_SPOT whose cone_width / cone_falloff_start hold the two COSINES a constructed SpotLight
+                                 * keeps (cosTotalWidth, cosFalloffStart: spot_light.dart:46-47) instead of the constructor's
+                                 * degrees -- what a host that only sees the Light object can marshal bit for bit */
+#define DR_LIGHT_SPOT_COS 5     /* DR_LIGHT_SPOT whose cone_width / cone_falloff_start hold the two COSINES a constructed SpotLight
+                                 * keeps (cosTotalWidth, cosFalloffStart: spot_light.dart:46-47) instead of the constructor's
+                                 * degrees -- what a host that only sees the Light object can marshal bit for bit */
 
 /* One entry of Scene.lights.  kind DR_LIGHT_DIFFUSE_AREA: DiffuseAreaLight + its
  * ShapeSet (diffuse_area_light.dart:36-43, lib/core/light/shape_set.dart:24-51);
@@ -375,6 +381,13 @@ int dr_comm_init(int32_t rank, int32_t world, const void* unique_id, uint64_t id
 int dr_film_reduce(void* film_dev, int64_t npixels, int32_t root, void* hip_stream);
 /* in-place ncclAllReduce(max / sum) of n doubles on the stream: the barrier + max-over-ranks of a timed region */
 int dr_comm_allreduce_f64(void* buf_dev, int64_t n, int32_t op_max, void* hip_stream);
+/* One rank's part of a sharded render and the merge, in one call (the fan-out of RenderManager,
+ * lib/dartray_web/render_manager.dart:100-141, with the rectangle copies replaced by ONE reduce): renders desc's share
+ * (tile_rank / tile_count / tile_size, or task_num / task_count) into a zero-initialised full-frame device film,
+ * sums the ranks' films on `root` through the communicator of dr_comm_init (skipped when none exists or its world
+ * is 1), and on the root rank resolves the film and copies it out.  film_out / rgb_out ([h*w*4] / [h*w*3] f32) may be
+ * NULL; on ranks other than root nothing is written.  A foreign host needs no device-memory calls of its own. */
+int dr_render_sharded(DrScene* scene, const DrRenderDesc* desc, int32_t root, float* film_out, float* rgb_out);
 int dr_comm_rank(void);  /* -1 before dr_comm_init */
 int dr_comm_world(void); /* 0 before dr_comm_init */
 int dr_comm_destroy(void);

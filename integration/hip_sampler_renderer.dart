@@ -22,6 +22,10 @@
  * not executed.  tests/abi/c1_from_c.c is the same call sequence from C and
  * IS executed on the GPU.
  *
+ * SDK window: the reference is pre-null-safety Dart (no `environment` in its pubspec.yaml) and dart:ffi with
+ * package:ffi's `calloc` / `Utf8.toDartString` needs Dart >= 2.12: Dart 2.12 ... 2.19 with `// @dart=2.9`-style
+ * unsound null safety (`dart --no-sound-null-safety`), package:ffi ^1.0.0.  Dart 3 rejects the reference itself.
+ *
  * Scope: what the device path covers (SURVEY.md section 8): BVHAccel over
  * TriangleMesh / Sphere / Disk shapes, matte / mirror / glass / plastic
  * materials with constant textures, DiffuseAreaLight / InfiniteAreaLight /
@@ -80,6 +84,11 @@ const int OFF_DrEnvMap_height = 12;
 const int OFF_DrEnvMap_light_to_world = 16;
 const int OFF_DrEnvMap_world_to_light = 80;
 const int SIZEOF_DrLightTri = 16;
+const int OFF_DrLightTri_v = 0;
+const int OFF_DrLightTri_reverse_orientation = 12;
+const int SIZEOF_DrMeshXform = 128;
+const int OFF_DrMeshXform_object_to_world = 0;
+const int OFF_DrMeshXform_world_to_object = 64;
 const int SIZEOF_DrQuadric = 168;
 const int OFF_DrQuadric_kind = 0;
 const int OFF_DrQuadric_object_to_world = 8;
@@ -106,6 +115,13 @@ const int OFF_DrSceneDesc_env_maps = 120;
 const int OFF_DrSceneDesc_nenv_maps = 128;
 const int OFF_DrSceneDesc_quadrics = 136;
 const int OFF_DrSceneDesc_nquadrics = 144;
+const int OFF_DrSceneDesc_vert_normals = 152;
+const int OFF_DrSceneDesc_vert_tangents = 160;
+const int OFF_DrSceneDesc_vert_uvs = 168;
+const int OFF_DrSceneDesc_tri_shading = 176;
+const int OFF_DrSceneDesc_tri_xform = 184;
+const int OFF_DrSceneDesc_mesh_xforms = 192;
+const int OFF_DrSceneDesc_nmesh_xforms = 200;
 const int SIZEOF_DrCamera = 168;
 const int OFF_DrCamera_raster_to_camera = 0;
 const int OFF_DrCamera_camera_to_world = 64;
@@ -144,6 +160,9 @@ const int OFF_DrRenderDesc_max_tail = 1336;
 // enums of the header
 const int DR_MATERIAL_MATTE = 0, DR_MATERIAL_MIRROR = 1, DR_MATERIAL_GLASS = 2, DR_MATERIAL_PLASTIC = 3;
 const int DR_LIGHT_DIFFUSE_AREA = 0, DR_LIGHT_INFINITE = 1, DR_LIGHT_POINT = 2, DR_LIGHT_SPOT = 3, DR_LIGHT_DISTANT = 4;
+const int DR_LIGHT_SPOT_COS = 5;
+const int DR_SHADING_N = 1, DR_SHADING_S = 2, DR_SHADING_UV = 4;
+const int DR_COMM_ID_BYTES = 128;
 const int DR_PRIM_QUADRIC = 0xFFFFFFFF, DR_QUADRIC_SPHERE = 1, DR_QUADRIC_DISK = 2;
 const int DR_CAMERA_PERSPECTIVE = 0, DR_CAMERA_ORTHOGRAPHIC = 1, DR_CAMERA_ENVIRONMENT = 2;
 const int DR_INTEGRATOR_DIRECT_ALL = 0, DR_INTEGRATOR_PATH = 1;
@@ -155,6 +174,20 @@ typedef _SceneCreateC = Int32 Function(Pointer<Uint8>, Pointer<Pointer<Void>>);
 typedef _SceneCreateD = int Function(Pointer<Uint8>, Pointer<Pointer<Void>>);
 typedef _RenderC = Int32 Function(Pointer<Void>, Pointer<Uint8>, Pointer<Float>, Pointer<Float>);
 typedef _RenderD = int Function(Pointer<Void>, Pointer<Uint8>, Pointer<Float>, Pointer<Float>);
+typedef _RenderShardedC = Int32 Function(Pointer<Void>, Pointer<Uint8>, Int32, Pointer<Float>, Pointer<Float>);
+typedef _RenderShardedD = int Function(Pointer<Void>, Pointer<Uint8>, int, Pointer<Float>, Pointer<Float>);
+typedef _RenderDeviceC = Int32 Function(Pointer<Void>, Pointer<Uint8>, Pointer<Void>, Pointer<Void>);
+typedef _RenderDeviceD = int Function(Pointer<Void>, Pointer<Uint8>, Pointer<Void>, Pointer<Void>);
+typedef _FilmReduceC = Int32 Function(Pointer<Void>, Int64, Int32, Pointer<Void>);
+typedef _FilmReduceD = int Function(Pointer<Void>, int, int, Pointer<Void>);
+typedef _FilmResolveC = Int32 Function(Pointer<Void>, Int64, Pointer<Void>, Pointer<Void>);
+typedef _FilmResolveD = int Function(Pointer<Void>, int, Pointer<Void>, Pointer<Void>);
+typedef _CommIdC = Int32 Function(Pointer<Uint8>, Uint64);
+typedef _CommIdD = int Function(Pointer<Uint8>, int);
+typedef _CommInitC = Int32 Function(Int32, Int32, Pointer<Uint8>, Uint64);
+typedef _CommInitD = int Function(int, int, Pointer<Uint8>, int);
+typedef _CommVoidC = Int32 Function();
+typedef _CommVoidD = int Function();
 typedef _DestroyC = Void Function(Pointer<Void>);
 typedef _DestroyD = void Function(Pointer<Void>);
 typedef _ErrC = Pointer<Utf8> Function();
@@ -196,10 +229,57 @@ class HipSamplerRenderer extends Renderer {
   static final _SceneCreateD _sceneCreate = _lib.lookupFunction<_SceneCreateC, _SceneCreateD>('dr_scene_create');
   static final _RenderD _render = _lib.lookupFunction<_RenderC, _RenderD>('dr_render');
   static final _DestroyD _destroy = _lib.lookupFunction<_DestroyC, _DestroyD>('dr_scene_destroy');
+  // the multi-GPU half (include/dartray_hip.h): one process per GPU, ONE film reduce per render
+  static final _RenderShardedD _renderSharded = _lib.lookupFunction<_RenderShardedC, _RenderShardedD>('dr_render_sharded');
+  static final _CommIdD _commUniqueId = _lib.lookupFunction<_CommIdC, _CommIdD>('dr_comm_unique_id');
+  static final _CommInitD _commInit = _lib.lookupFunction<_CommInitC, _CommInitD>('dr_comm_init');
+  static final _CommVoidD _commDestroy = _lib.lookupFunction<_CommVoidC, _CommVoidD>('dr_comm_destroy');
+  static final _CommVoidD _commWorld = _lib.lookupFunction<_CommVoidC, _CommVoidD>('dr_comm_world');
+  static final _CommVoidD _commRank = _lib.lookupFunction<_CommVoidC, _CommVoidD>('dr_comm_rank');
+  // for hosts that keep the film on the device themselves (device pointers come from their own HIP binding)
+  static final _RenderDeviceD renderDevice = _lib.lookupFunction<_RenderDeviceC, _RenderDeviceD>('dr_render_device');
+  static final _FilmReduceD filmReduce = _lib.lookupFunction<_FilmReduceC, _FilmReduceD>('dr_film_reduce');
+  static final _FilmResolveD filmResolveDevice = _lib.lookupFunction<_FilmResolveC, _FilmResolveD>('dr_film_resolve_device');
+
+  /// Rank 0 of a multi-GPU render: the 128 opaque bytes every other rank needs for [commInit] (carried by the host:
+  /// a file, a pipe, a socket -- hip_render_manager.dart uses a file).
+  static Uint8List commUniqueId(int device) {
+    _checkStatic(_init(device));
+    Pointer<Uint8> id = calloc<Uint8>(DR_COMM_ID_BYTES);
+    try {
+      _checkStatic(_commUniqueId(id, DR_COMM_ID_BYTES));
+      return new Uint8List.fromList(id.asTypedList(DR_COMM_ID_BYTES));
+    } finally {
+      calloc.free(id);
+    }
+  }
+
+  /// Every rank, once, after dr_init(device): joins the RCCL communicator of `world` ranks.
+  static void commInit(int device, int rank, int world, Uint8List id) {
+    _checkStatic(_init(device));
+    Pointer<Uint8> p = calloc<Uint8>(DR_COMM_ID_BYTES);
+    try {
+      p.asTypedList(DR_COMM_ID_BYTES).setAll(0, id);
+      _checkStatic(_commInit(rank, world, p, DR_COMM_ID_BYTES));
+    } finally {
+      calloc.free(p);
+    }
+  }
+
+  static void commDestroy() => _checkStatic(_commDestroy());
+
+  static void _checkStatic(int rc) {
+    if (rc != 0) {
+      LogSevere('dartray_hip error $rc: ${_err().toDartString()}');
+    }
+  }
   static final _ErrD _err = _lib.lookupFunction<_ErrC, _ErrD>('dr_last_error');
 
+  /// tileRank / tileCount: this process's share of the image's 32 x 32 tiles (round-robin) when a render is spread
+  /// over several GPUs (one process each, see hip_render_manager.dart); the default is the whole image.
   HipSamplerRenderer(this.sampler, this.camera, this.surfaceIntegrator, this.volumeIntegrator,
-                     [this.taskNum = 0, this.taskCount = 1, this.device = 0, this.seed = 5489]);
+                     [this.taskNum = 0, this.taskCount = 1, this.device = 0, this.seed = 5489,
+                      this.tileRank = 0, this.tileCount = 1]);
 
   /// Every failure of the library becomes a LogSevere, i.e. an Exception (log.dart:42-47), which
   /// DartRay.worldEnd turns into completeError (dartray.dart:573-583).
@@ -285,7 +365,12 @@ class HipSamplerRenderer extends Renderer {
       _Blob triMaterial = new _Blob(nprims * 4);
       _Blob triLight = new _Blob(nprims * 4);
       _Blob triReverse = new _Blob(nprims);
-      blobs.addAll([triIdx, triMaterial, triLight, triReverse]);
+      _Blob triShading = new _Blob(nprims);
+      _Blob triXform = new _Blob(nprims * 4);
+      bool anyShading = false;
+      List<TriangleMesh> xformMeshes = [];
+      Map<TriangleMesh, int> xformIndex = {};
+      blobs.addAll([triIdx, triMaterial, triLight, triReverse, triShading, triXform]);
       for (int i = 0; i < nprims; ++i) {
         if (bvh.primitives[i] is! GeometricPrimitive) {
           _unsupported('primitive ${bvh.primitives[i].runtimeType} (instancing)');
@@ -296,12 +381,22 @@ class HipSamplerRenderer extends Renderer {
           if (sh.mesh.alphaTexture != null) {
             _unsupported('an alpha texture');
           }
-          if (sh.mesh.n != null || sh.mesh.s != null || sh.mesh.uvs != null) {
-            // per-vertex N / S / uv go through vert_normals / vert_tangents / vert_uvs + tri_shading + mesh_xforms
-            // (include/dartray_hip.h: DrSceneDesc); left to the maintainer who needs them
-            _unsupported('per-vertex normals / tangents / uvs in this binding');
-          }
           int b = baseOf(sh.mesh);
+          // per-vertex N / S / uv (triangle_mesh.dart:195-203): which attributes the primitive's mesh has, and the
+          // mesh transform that takes N / S to world space at shading time (triangle.dart:303-317)
+          int bits = (sh.mesh.n != null ? DR_SHADING_N : 0) | (sh.mesh.s != null ? DR_SHADING_S : 0) |
+                     (sh.mesh.uvs != null ? DR_SHADING_UV : 0);
+          triShading.u8(i, bits);
+          if (bits != 0) {
+            anyShading = true;
+          }
+          if ((bits & (DR_SHADING_N | DR_SHADING_S)) != 0) {
+            if (!xformIndex.containsKey(sh.mesh)) {
+              xformIndex[sh.mesh] = xformMeshes.length;
+              xformMeshes.add(sh.mesh);
+            }
+            triXform.u32(4 * i, xformIndex[sh.mesh]);
+          }
           for (int k = 0; k < 3; ++k) {
             triIdx.u32(12 * i + 4 * k, b + sh.mesh.vertexIndex[sh.index + k]);   // Triangle.v(k) (triangle.dart:241)
           }
@@ -328,6 +423,34 @@ class HipSamplerRenderer extends Renderer {
         for (int i = 0; i < m.nverts; ++i) {
           Point p = m.point(i);
           verts.f32s(12 * (b + i), [p.x, p.y, p.z]);
+        }
+      }
+
+      // per-vertex normals / tangents (OBJECT space: TriangleMesh keeps them as given) and uvs, indexed like verts
+      _Blob vertN, vertS, vertUV, meshXforms;
+      if (anyShading) {
+        vertN = new _Blob(nverts * 12);
+        vertS = new _Blob(nverts * 12);
+        vertUV = new _Blob(nverts * 8);
+        meshXforms = new _Blob(xformMeshes.length * SIZEOF_DrMeshXform);
+        blobs.addAll([vertN, vertS, vertUV, meshXforms]);
+        for (TriangleMesh m in meshes) {
+          int b = meshBase[m];
+          for (int i = 0; i < m.nverts; ++i) {
+            if (m.n != null) {
+              vertN.f32s(12 * (b + i), [m.n[i].x, m.n[i].y, m.n[i].z]);
+            }
+            if (m.s != null) {
+              vertS.f32s(12 * (b + i), [m.s[i].x, m.s[i].y, m.s[i].z]);
+            }
+            if (m.uvs != null) {
+              vertUV.f32s(8 * (b + i), [m.uvs[2 * i], m.uvs[2 * i + 1]]);
+            }
+          }
+        }
+        for (int i = 0; i < xformMeshes.length; ++i) {
+          meshXforms.f32s(i * SIZEOF_DrMeshXform + OFF_DrMeshXform_object_to_world, xformMeshes[i].objectToWorld.m.data);
+          meshXforms.f32s(i * SIZEOF_DrMeshXform + OFF_DrMeshXform_world_to_object, xformMeshes[i].worldToObject.m.data);
         }
       }
 
@@ -404,8 +527,10 @@ class HipSamplerRenderer extends Renderer {
           for (Shape s in l.shapeSet.shapes) {            // ShapeSet order: the LIFO refine order (shape_set.dart:27-35)
             if (s is Triangle) {
               int b = baseOf(s.mesh);                     // (an emitter's mesh is also a primitive's mesh: already placed)
+              // bit 1: the mesh has uvs -- they decide dpdu x dpdv, i.e. the side the emitter shines from
               lightTris.add([b + s.mesh.vertexIndex[s.index], b + s.mesh.vertexIndex[s.index + 1],
-                             b + s.mesh.vertexIndex[s.index + 2], s.reverseOrientation ? 1 : 0]);
+                             b + s.mesh.vertexIndex[s.index + 2],
+                             (s.reverseOrientation ? 1 : 0) | (s.mesh.uvs != null ? 2 : 0)]);
             } else if (s is Sphere || s is Disk) {
               lightTris.add([DR_PRIM_QUADRIC, quadricOf(s), 0, s.reverseOrientation ? 1 : 0]);
             } else {
@@ -437,10 +562,16 @@ class HipSamplerRenderer extends Renderer {
           envMaps.f32s(OFF_DrEnvMap_world_to_light, l.worldToLight.m.data);
           blobs.addAll([envTexels, envMaps]);
         } else if (l is SpotLight) {
-          // DrAreaLight takes the cone's total width and falloff start in degrees (the constructor arguments,
-          // spot_light.dart:42-48); SpotLight only keeps their cosines, and degrees -> cosine does not round-trip
-          // bit for bit.  Extend the binding with the angles kept at construction if spot lights are needed.
-          _unsupported('SpotLight in this binding');
+          // A constructed SpotLight only keeps the two cosines (spot_light.dart:46-47); DR_LIGHT_SPOT_COS takes
+          // exactly those doubles (DR_LIGHT_SPOT takes the constructor's degrees).  SpotLight extends Light, not
+          // PointLight: this branch precedes the PointLight one only for readability.
+          lights.u32(o + OFF_DrAreaLight_kind, DR_LIGHT_SPOT_COS);
+          lights.f32s(o + OFF_DrAreaLight_L, _rgb(l.intensity));
+          lights.i32(o + OFF_DrAreaLight_nsamples, 1);
+          lights.f32s(o + OFF_DrAreaLight_position, [l.lightPos.x, l.lightPos.y, l.lightPos.z]);
+          lights.f32s(o + OFF_DrAreaLight_world_to_light, l.worldToLight.m.data);
+          lights.f64(o + OFF_DrAreaLight_cone_width, l.cosTotalWidth);
+          lights.f64(o + OFF_DrAreaLight_cone_falloff_start, l.cosFalloffStart);
         } else if (l is PointLight) {                     // point_light.dart:36-39
           lights.u32(o + OFF_DrAreaLight_kind, DR_LIGHT_POINT);
           lights.f32s(o + OFF_DrAreaLight_L, _rgb(l.intensity));
@@ -486,6 +617,15 @@ class HipSamplerRenderer extends Renderer {
       sd.u32(OFF_DrSceneDesc_nenv_maps, envMaps == null ? 0 : 1);
       sd.addr(OFF_DrSceneDesc_quadrics, quads);
       sd.u32(OFF_DrSceneDesc_nquadrics, quadrics.length);
+      if (anyShading) {
+        sd.addr(OFF_DrSceneDesc_vert_normals, vertN);
+        sd.addr(OFF_DrSceneDesc_vert_tangents, vertS);
+        sd.addr(OFF_DrSceneDesc_vert_uvs, vertUV);
+        sd.addr(OFF_DrSceneDesc_tri_shading, triShading);
+        sd.addr(OFF_DrSceneDesc_tri_xform, triXform);
+        sd.addr(OFF_DrSceneDesc_mesh_xforms, meshXforms);
+        sd.u32(OFF_DrSceneDesc_nmesh_xforms, xformMeshes.length);
+      }
       _check(_sceneCreate(sd.ptr, handle));
 
       // ---- DrRenderDesc: camera, film, integrator, sampler, task (sampler_renderer.dart:29-31,36-65) ----
@@ -552,15 +692,26 @@ class HipSamplerRenderer extends Renderer {
       rd.i64(OFF_DrRenderDesc_seed, seed);
       rd.i32(OFF_DrRenderDesc_task_num, taskNum);         // GetSubWindow rectangle (common.dart:52-73)
       rd.i32(OFF_DrRenderDesc_task_count, taskCount);
-      rd.i32(OFF_DrRenderDesc_tile_rank, 0);
-      rd.i32(OFF_DrRenderDesc_tile_count, 1);
+      rd.i32(OFF_DrRenderDesc_tile_rank, tileRank);       // this process's share of the 32 x 32 tiles (round-robin)
+      rd.i32(OFF_DrRenderDesc_tile_count, tileCount);
       rd.i32(OFF_DrRenderDesc_tile_size, 32);
 
       // ---- Renderer.render ----
       final int npix = film.width * film.height;
       lxyzw = calloc<Float>(4 * npix);
       rgb = calloc<Float>(3 * npix);
-      _check(_render(handle.value, rd.ptr, lxyzw, rgb));
+      if (tileCount > 1) {
+        // one rank of a multi-GPU render: its tiles, ONE ncclReduce(sum) of the full-frame film onto rank 0, which
+        // resolves it (dr_render_sharded; commInit has been called by the process).  Ranks > 0 complete with null,
+        // like a RenderTask whose output the manager does not merge (render_manager.dart:108-125).
+        _check(_renderSharded(handle.value, rd.ptr, 0, lxyzw, rgb));
+        if (_commRank() > 0) {
+          completer.complete(null);
+          return completer.future;
+        }
+      } else {
+        _check(_render(handle.value, rd.ptr, lxyzw, rgb));
+      }
       OutputImage out = new OutputImage(film.left, film.top, film.width, film.height,
                                         film.xResolution, film.yResolution,
                                         new Float32List.fromList(rgb.asTypedList(3 * npix)));
@@ -597,6 +748,8 @@ class HipSamplerRenderer extends Renderer {
   int taskCount;
   int device;
   int seed;
+  int tileRank;
+  int tileCount;
   Sampler sampler;
   Camera camera;
   SurfaceIntegrator surfaceIntegrator;

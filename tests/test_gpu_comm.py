@@ -39,6 +39,21 @@ def test_world_one_film_reduce_is_the_identity_through_rccl(gpu):
     assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
 
 
+def test_render_sharded_without_a_communicator_is_dr_render(gpu):
+    """dr_render_sharded: no communicator (or a world of 1) => this rank is the root and the merge is skipped."""
+    from dartray_amd import scenes
+    prims, mk = scenes.config("C2", xres=48, yres=40, spp=8, blob=(24, 12))
+    scene = scenes.make_scene(prims)
+    a = mk().render(scene)
+    b = mk().render_sharded(scene)
+    assert np.array_equal(a.film, b.film) and np.array_equal(a.rgb, b.rgb)
+    r = mk()
+    d, keep = r.describe()
+    import ctypes as C
+    assert gpu.lib().dr_render_sharded(scene._device().handle, C.byref(d), 1, None, None) == -1  # root out of range
+    assert b"root" in gpu.lib().dr_last_error()
+
+
 _WORKER = r"""
 import os, sys
 import numpy as np
@@ -61,6 +76,10 @@ torch.cuda.synchronize()
 assert t == float(world), t
 if rank == 0:
     np.save(sys.argv[1], film.cpu().numpy())
+out = r.render_sharded(scene, 0)   # the same through the one-call entry point of the C ABI
+assert (out is not None) == (rank == 0)
+if rank == 0:
+    assert np.array_equal(out.film, film.cpu().numpy())
 drdist.barrier()
 drdist.comm_destroy()
 torch.distributed.destroy_process_group()

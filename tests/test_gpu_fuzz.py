@@ -74,6 +74,7 @@ def random_scene(seed):
         elif k == 1:
             t = pbrt.Transform.Translate(u(-8, 8), u(4, 9), u(-8, 8)) * pbrt.Transform.Rotate(u(60, 120), 1, 0, u(-0.3, 0.3))
             pl = core.SpotLight(t.m, tuple(100 + 300 * rng.random(3)), u(20, 50), u(5, 19), t.mInv)
+            pl.marshal_cosines = bool(seed & 1)  # DR_LIGHT_SPOT_COS: the two cosines a constructed SpotLight keeps
         else:
             pl = core.DistantLight(None, tuple(0.3 + rng.random(3)), (u(-1, 1), u(0.2, 1), u(-1, 1)))
         lights.append(pl)
