@@ -519,6 +519,69 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         ok = false;  // packed references carry at most 31 primitives per leaf; fall back to the v2 kernel
       }
     }
+    // Memory order of the pair records (experiments; results never depend on it -- the
+    // references are explicit).  Default: depth-first (a node's left child next to it).  DARTRAY_PAIR_ORDER=
+    //   pad:K    depth-first with K - 1 empty records behind every pair (footprint experiment)
+    //   sib      the two child records of a node side by side in ONE 128-byte line (holes where a child is a leaf)
+    //   veb:T:S  treelets: the top T levels breadth-first, below them sub-trees of height S breadth-first each,
+    //            treelet after treelet in depth-first order (van Emde Boas style; veb:1:1 is the default order)
+    if (const char* po = getenv("DARTRAY_PAIR_ORDER")) {
+      const std::string mode(po);
+      std::vector<uint32_t> slotOf(desc->nnodes, 0);
+      uint32_t slots = 0;
+      if (mode == "sib") {
+        std::vector<uint32_t> st;
+        st.push_back(0);
+        slotOf[0] = 0;
+        slots = 2;
+        while (!st.empty()) {
+          const uint32_t i = st.back();
+          st.pop_back();
+          const uint32_t c[2] = {i + 1, N[i].offset};
+          for (int k = 0; k < 2; ++k)
+            if (N[c[k]].nprims == 0) slotOf[c[k]] = slots + (uint32_t)k;
+          if (N[c[0]].nprims == 0 || N[c[1]].nprims == 0) slots += 2;
+          if (N[c[1]].nprims == 0) st.push_back(c[1]);
+          if (N[c[0]].nprims == 0) st.push_back(c[0]);
+        }
+      } else if (mode.rfind("pad:", 0) == 0) {
+        // depth-first order with K - 1 empty records behind every pair: K times the footprint and 2 / K pairs per
+        // 128-byte line -- what a record of 64 / K bytes would GAIN is at most what this loses per halving
+        const uint32_t K = (uint32_t)std::max(1, atoi(po + 4));
+        for (uint64_t i = 0; i < desc->nnodes; ++i)
+          if (N[i].nprims == 0) slotOf[i] = pairIndex[i] * K;
+        slots = np * K;
+      } else if (mode.rfind("veb:", 0) == 0) {
+        int T = 1, S = 1;
+        if (sscanf(po + 4, "%d:%d", &T, &S) < 1) T = 1;
+        T = std::max(1, T);
+        S = std::max(1, S);
+        std::vector<std::pair<uint32_t, int>> st;  // (treelet root, height)
+        st.push_back({0u, T});
+        std::vector<uint32_t> cur, nxt, frontier;
+        while (!st.empty()) {
+          const auto top = st.back();
+          st.pop_back();
+          cur.assign(1, top.first);
+          frontier.clear();
+          for (int lev = 0; lev < top.second && !cur.empty(); ++lev) {
+            nxt.clear();
+            for (uint32_t i : cur) {
+              slotOf[i] = slots++;
+              const uint32_t c[2] = {i + 1, N[i].offset};
+              for (int k = 0; k < 2; ++k)
+                if (N[c[k]].nprims == 0) nxt.push_back(c[k]);
+            }
+            cur.swap(nxt);
+          }
+          for (size_t k = cur.size(); k-- > 0;) st.push_back({cur[k], S});  // the next treelets, leftmost first
+        }
+      }
+      if (slots) {
+        pairIndex.swap(slotOf);
+        np = slots;
+      }
+    }
     if (np >= (1u << 29)) ok = false;
     // The v3 kernel re-derives a node's own box when it needs the literal test: an interior node's bounds
     // must be the union of its children's (initInterior, bvh_accel.dart:518-524) and a leaf's the union of

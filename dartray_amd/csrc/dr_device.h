@@ -255,6 +255,30 @@ DR_DEV bool tri_hit(F3 p1, F3 p2, F3 p3, F3 o, F3 d, double tmin, double tmax, d
   *b2Out = b2;
   return true;
 }
+// The same test with the triangle's edges e1 = p2 - p1, e2 = p3 - p1 handed in as the f64 differences the test forms
+// first (triangle.dart:52-57): for the few triangles of an emitter they are constants of the light table.
+DR_DEV bool tri_hit_e(F3 p1, const double* e, F3 o, F3 d, double tmin, double tmax, double* tOut) {
+  const double e1x = e[0], e1y = e[1], e1z = e[2], e2x = e[3], e2y = e[4], e2z = e[5];
+  double dx = d.x, dy = d.y, dz = d.z;
+  double s1x = (dy * e2z) - (dz * e2y);
+  double s1y = (dz * e2x) - (dx * e2z);
+  double s1z = (dx * e2y) - (dy * e2x);
+  double divisor = (s1x * e1x) + (s1y * e1y) + (s1z * e1z);
+  if (divisor == 0.0) return false;
+  double invDivisor = 1.0 / divisor;
+  double sx = (double)o.x - (double)p1.x, sy = (double)o.y - (double)p1.y, sz = (double)o.z - (double)p1.z;
+  double b1 = (sx * s1x + sy * s1y + sz * s1z) * invDivisor;
+  if (b1 < 0.0 || b1 > 1.0) return false;
+  double s2x = (sy * e1z) - (sz * e1y);
+  double s2y = (sz * e1x) - (sx * e1z);
+  double s2z = (sx * e1y) - (sy * e1x);
+  double b2 = ((dx * s2x) + (dy * s2y) + (dz * s2z)) * invDivisor;
+  if (b2 < 0.0 || b1 + b2 > 1.0) return false;
+  double t = (e2x * s2x + e2y * s2y + e2z * s2z) * invDivisor;
+  if (t < tmin || t > tmax) return false;
+  *tOut = t;
+  return true;
+}
 // Triangle.intersectP (triangle.dart:162-194): Vector temporaries rounded to f32.
 DR_DEV bool tri_hitP(F3 p1, F3 p2, F3 p3, F3 o, F3 d, double tmin, double tmax) {
 #ifdef DR_EXP_TRI_F32
@@ -653,6 +677,12 @@ struct GlobalLights {
   DR_DEV DLight light(int i) const { return lights[i]; }
   DR_DEV DLightTri ltri(uint32_t i) const { return ltris[i]; }
   DR_DEV float cdf(uint32_t i) const { return lcdf[i]; }
+  DR_DEV void edges(uint32_t, const DLightTri& t, double* e) const {  // e1 = p2 - p1, e2 = p3 - p1 (triangle.dart:52-57)
+    for (int k = 0; k < 3; ++k) {
+      e[k] = (double)t.p[3 + k] - (double)t.p[k];
+      e[3 + k] = (double)t.p[6 + k] - (double)t.p[k];
+    }
+  }
 };
 template <class T>
 DR_DEV T lds_read_struct(lds_cu32* base, uint32_t index) {
@@ -678,8 +708,13 @@ struct LdsLights {
     return make_float4(__uint_as_float(p[0]), __uint_as_float(p[1]), __uint_as_float(p[2]), __uint_as_float(p[3]));
   }
   DR_DEV DLight light(int i) const { return lds_read_struct<DLight>(lights, (uint32_t)i); }
+  lds_cu32* ledges;        // 12 words per light triangle: the six f64 edge components, evaluated once per workgroup
   DR_DEV DLightTri ltri(uint32_t i) const { return lds_read_struct<DLightTri>(ltris, i); }
   DR_DEV float cdf(uint32_t i) const { return __uint_as_float(lcdf[i]); }
+  DR_DEV void edges(uint32_t i, const DLightTri&, double* e) const {
+    lds_cu32* p = ledges + 12 * (size_t)i;
+    for (int k = 0; k < 6; ++k) e[k] = __hiloint2double((int)p[2 * k + 1], (int)p[2 * k]);
+  }
 };
 
 // ---- ShapeSet / DiffuseAreaLight ---------------------------------------------
@@ -750,8 +785,9 @@ DR_DEV F3 shapeset_sample(const DScene& sc, const LV& lv, const DLight& L, doubl
       }
       continue;
     }
-    ltri_verts(t, &a, &b, &c);
-    if (tri_hit(a, b, c, p, rd, 1.0e-3, DR_INF, &th, &bb1, &bb2)) {
+    double e[6];
+    lv.edges(L.first_tri + i, t, e);
+    if (tri_hit_e(F3{t.p[0], t.p[1], t.p[2]}, e, p, rd, 1.0e-3, DR_INF, &th)) {
       thit = th;
       *Ns = F3{t.nn[0], t.nn[1], t.nn[2]};  // dg.nn of the last hitting shape (shape_set.dart:71-77)
     }
@@ -787,8 +823,9 @@ DR_DEV double shapeset_pdf(const DScene& sc, const LV& lv, const DLight& L, F3 p
         nn = dg.nn;
       }
     } else {
-      ltri_verts(t, &a, &b, &c);
-      h = tri_hit(a, b, c, p, wi, 1.0e-3, DR_INF, &th, &bb1, &bb2);
+      double e[6];
+      lv.edges(L.first_tri + i, t, e);
+      h = tri_hit_e(F3{t.p[0], t.p[1], t.p[2]}, e, p, wi, 1.0e-3, DR_INF, &th);
       nn = F3{t.nn[0], t.nn[1], t.nn[2]};
     }
     if (!h) {

@@ -975,8 +975,8 @@ void shade_prof_dump() {}
 // dynamic LDS; a workgroup-wide copy + barrier.
 #define DR_LDS_LIGHT_BYTES (24 * 1024)  // light tables up to this size are staged in LDS (the queue staging takes ~96 KB of the 160)
 #define DR_LDS_MAT_BYTES (24 * 1024)    // likewise the material table (64 B per material)
-__host__ __device__ inline size_t light_table_bytes(const DScene& sc) {
-  return (size_t)sc.nlights * sizeof(DLight) + (size_t)sc.nltris * sizeof(DLightTri) + (size_t)sc.ncdf * 4;
+__host__ __device__ inline size_t light_table_bytes(const DScene& sc) {  // (+ 48 B per triangle: its f64 edges, LdsLights::ledges)
+  return (size_t)sc.nlights * sizeof(DLight) + (size_t)sc.nltris * (sizeof(DLightTri) + 48) + (size_t)sc.ncdf * 4;
 }
 __host__ __device__ inline size_t mat_table_bytes(const DScene& sc) {
   const size_t b = (size_t)sc.nmats * 64;
@@ -985,6 +985,7 @@ __host__ __device__ inline size_t mat_table_bytes(const DScene& sc) {
 DR_DEV LdsLights stage_lights(const DScene& sc, unsigned char* dyn, size_t pushBytes) {
   uint32_t* dst = (uint32_t*)(dyn + pushBytes);
   const uint32_t nL = sc.nlights * (uint32_t)(sizeof(DLight) / 4), nT = sc.nltris * (uint32_t)(sizeof(DLightTri) / 4), nC = sc.ncdf;
+  const uint32_t nE = sc.nltris * 12u;  // f64 edges; nL and nT are even (8-byte multiples), so they start 8-byte aligned
   const uint32_t nM = (uint32_t)(mat_table_bytes(sc) / 4);
   const uint32_t* srcL = (const uint32_t*)sc.lights;
   const uint32_t* srcT = (const uint32_t*)sc.ltris;
@@ -992,14 +993,23 @@ DR_DEV LdsLights stage_lights(const DScene& sc, unsigned char* dyn, size_t pushB
   const uint32_t* srcM = (const uint32_t*)sc.mats;
   for (uint32_t i = threadIdx.x; i < nL; i += blockDim.x) dst[i] = srcL[i];
   for (uint32_t i = threadIdx.x; i < nT; i += blockDim.x) dst[nL + i] = srcT[i];
-  for (uint32_t i = threadIdx.x; i < nC; i += blockDim.x) dst[nL + nT + i] = srcC[i];
-  for (uint32_t i = threadIdx.x; i < nM; i += blockDim.x) dst[nL + nT + nC + i] = srcM[i];
+  for (uint32_t i = threadIdx.x; i < sc.nltris * 6u; i += blockDim.x) {
+    // e1 = p2 - p1, e2 = p3 - p1 as Triangle.intersect forms them (triangle.dart:52-57): f64 differences of f32 values
+    const uint32_t t = i / 6u, k = i % 6u;
+    const float* p = sc.ltris[t].p;
+    const double e = (double)p[3 + k] - (double)p[k % 3u];
+    dst[nL + nT + 2u * i] = (uint32_t)__double2loint(e);
+    dst[nL + nT + 2u * i + 1u] = (uint32_t)__double2hiint(e);
+  }
+  for (uint32_t i = threadIdx.x; i < nC; i += blockDim.x) dst[nL + nT + nE + i] = srcC[i];
+  for (uint32_t i = threadIdx.x; i < nM; i += blockDim.x) dst[nL + nT + nE + nC + i] = srcM[i];
   __syncthreads();
   LdsLights lv;
   lv.lights = (lds_cu32*)dst;
   lv.ltris = (lds_cu32*)(dst + nL);
-  lv.lcdf = (lds_cu32*)(dst + nL + nT);
-  lv.mats = nM ? (lds_cu32*)(dst + nL + nT + nC) : (lds_cu32*)nullptr;
+  lv.ledges = (lds_cu32*)(dst + nL + nT);
+  lv.lcdf = (lds_cu32*)(dst + nL + nT + nE);
+  lv.mats = nM ? (lds_cu32*)(dst + nL + nT + nE + nC) : (lds_cu32*)nullptr;
   lv.gmats = sc.mats;
   return lv;
 }
@@ -1050,6 +1060,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
     bool pushCont = false, vert = false, deferred = false;
+    uint32_t contKey = 0u;  // DR_SORT_CONT: octant of the continuation ray's direction
     bool envNee = false, envMiss = false;  // ENVQ: this lane's light estimate / escaped camera ray goes to k_env
     if (valid) {
       const SlotRef sr = cur.sr;
@@ -1210,6 +1221,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         if (alive && bounce != rp.maxDepth) {
           st3f<F_RD>(sr, wi);
           stcf<F_BETA>(sr, beta);
+          contKey = (wi.x < 0.f ? 1u : 0u) | (wi.y < 0.f ? 2u : 0u) | (wi.z < 0.f ? 4u : 0u);
           pf |= PF_HAS_CONT;
           if (specular) pf |= PF_SPECULAR;  // specularBounce (path_integrator.dart:87)
           pushCont = true;
@@ -1233,7 +1245,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     }
     // (a slot with a parked estimate enters the next stage's list in k_env, once its flags are known)
     stage_push<NQ>(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0 && !deferred && !envNee, slot, Q_MIS_BIT,
-                   vert, pushCont ? 0u : Q_RESOLVE_BIT, envNee || envMiss, envMiss ? Q_ENV_MISS_BIT : 0u);
+                   vert, pushCont ? 0u : Q_RESOLVE_BIT, envNee || envMiss, envMiss ? Q_ENV_MISS_BIT : 0u, contKey);
     PROF(8);
     if (pctx.iters == DR_PUSH_ITERS) {
       const uint32_t g = stage_flush<NQ>(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont,

@@ -144,7 +144,9 @@ DR_DEV int traverse(const DScene& sc, F3 o, F3 d, double tmin, double tmax, uint
 
 DR_DEV void flush_counters(TraceCounters* ctr, int any, uint32_t rays, uint32_t nodes, uint32_t tris) {
   unsigned long long r = wave_sum(rays), n = wave_sum(nodes), t = wave_sum(tris);
-  if (lane_id() == 0 && ctr) {
+  // (a wave that traced nothing reports nothing: the ~7000 waves of a persistent launch otherwise queue 21 000 atomics
+  // on three addresses -- ~0.2 ms, the floor of the small launches at the end of a path's stage loop)
+  if (lane_id() == 0 && ctr && (r | n | t) != 0ull) {
     if (any) {
       atomicAdd(&ctr->any_rays, r);
       atomicAdd(&ctr->any_nodes, n);
@@ -510,7 +512,14 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           const uint32_t s0 = (uint32_t)(((unsigned long long)n * shard) / DR_NSHARD);
           const uint32_t s1 = (uint32_t)(((unsigned long long)n * (shard + 1u)) / DR_NSHARD);
           uint32_t fresh = 0;
-          if (lane == 0) fresh = atomicAdd(work + shard * (uint32_t)DR_WORK_STRIDE, (uint32_t)DR_WORK_CHUNK);
+          // (the counter only grows: once a plain load sees it past the shard's end nothing is left to reserve -- a wave
+          // that arrives late does not join the queue of same-address atomics)
+          if (lane == 0) {
+            uint32_t* const wc = work + shard * (uint32_t)DR_WORK_STRIDE;
+            // (only before a wave's first reservation: later ones go straight to the atomic)
+            fresh = nRays == 0u ? __hip_atomic_load(wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (fresh < s1 - s0) fresh = atomicAdd(wc, (uint32_t)DR_WORK_CHUNK);
+          }
           fresh = wave_bcast_first(fresh);
           if (fresh < s1 - s0) {
             resNext = s0 + fresh;
@@ -898,7 +907,10 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
       if (resNext == resEnd) {
         uint32_t fresh = 0;
-        if (lane == 0) fresh = atomicAdd(work, (uint32_t)DR_WORK_CHUNK);
+        if (lane == 0) {
+          fresh = nRays == 0u ? __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // (see trace_persistent)
+          if (fresh < n) fresh = atomicAdd(work, (uint32_t)DR_WORK_CHUNK);
+        }
         fresh = wave_bcast_first(fresh);
         if (fresh < n) {
           resNext = fresh;
