@@ -1122,14 +1122,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   hipStream_t s = (hipStream_t)hip_stream;
   const int spp = rd->spp;
   if (spp <= 0 || (spp & (spp - 1)) != 0) return fail(DR_ERR_INVALID, "spp must be a power of two (low_discrepancy_sampler.dart:43-49)");
-  if (spp > 1024) return fail(DR_ERR_UNSUPPORTED, "spp > 1024");
+  if (spp > 4096) return fail(DR_ERR_UNSUPPORTED, "spp > 4096 (one pixel's shuffle table of a 16-pixel sampler group would not fit the LDS)");
   if (rd->integrator != DR_INTEGRATOR_PATH && rd->integrator != DR_INTEGRATOR_DIRECT_ALL)
     return fail(DR_ERR_INVALID, "unknown integrator");
   if (rd->max_depth < 0 || rd->max_depth > 64) return fail(DR_ERR_INVALID, "max_depth out of range");
   // DirectLighting over mirror / glass recurses through SpecularReflect / SpecularTransmit (integrator.dart:187-290):
   // an explicit per-slot stack and one round of the stage loop per vertex of the ray tree (k_shade_spec)
   const bool dlSpec = rd->integrator == DR_INTEGRATOR_DIRECT_ALL && sc->hasSpecular;
-  if (dlSpec && rd->max_depth > 16) return fail(DR_ERR_UNSUPPORTED, "DirectLighting over mirror / glass: max_depth > 16");
 
   RenderParams rp;
   memset(&rp, 0, sizeof(rp));
@@ -1226,6 +1225,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // has one entry per pixel sample; host buffers and multi-entry blocks (DirectLighting with nsamples > 1) use floats.
   SampleForm sf;
   sf.compact = !hostBuf && rp.blocks == nullptr && !getenv("DARTRAY_FLOAT_SAMPLES");
+  if (!sf.compact && !hostBuf && spp > 1024)
+    return fail(DR_ERR_UNSUPPORTED, "spp > 1024 with LD blocks of several entries per sample (DirectLighting with nsamples > 1): the float-form sampler's table exceeds the LDS");
   sf.nFloats = rp.nFloats;
   sf.nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
   sf.idxShift = spp > 256 ? 1 : 0;
@@ -1387,7 +1388,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // the slots whose (camera or child) ray this round traces.  Everything else: one round.
     const uint32_t* roundQ = nullptr;
     const uint32_t* nRound = nullptr;
-    const int maxRounds = dlSpec ? (1 << std::min(16, std::max(1, rd->max_depth))) : 1;
+    // (one round per vertex of a slot's ray tree, until no slot launched a child: at most 2^maxDepth like the recursion itself)
+    const int maxRounds = dlSpec ? 0x7fffffff : 1;
     if (dlSpec) HIP_TRY(hipMemsetAsync(w.specSp.p, 0, (size_t)w.cap * sizeof(int32_t), s));
     for (int round = 0; round < maxRounds; ++round) {
     if (round > 0) {  // the stage counters are reused every round; the round lists' counts live behind them

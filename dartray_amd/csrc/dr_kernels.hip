@@ -1764,7 +1764,8 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t n
   if (!st.svFloat && rp.spp >= 64) {
     const int nGen = rp.genMask ? __builtin_popcountll(rp.genMask) : nBlocks;  // compact form (rp.blocks is null), whole index runs per pixel
     static const int lanesEnv = getenv("DARTRAY_GEN_LANES") ? atoi(getenv("DARTRAY_GEN_LANES")) : 0;
-    const int ln = lanesEnv ? lanesEnv : (rp.spp <= 128 ? 64 : (rp.spp <= 256 ? DR_GEN_LANES_256 : DR_GEN_LANES_BIG));
+    // (above 1024 spp a pixel's table is 4 / 8 KB: 32 / 16 pixels per group keep the group's tables within 128 KB)
+    const int ln = lanesEnv ? lanesEnv : (rp.spp <= 128 ? 64 : (rp.spp <= 256 ? DR_GEN_LANES_256 : (rp.spp <= 1024 ? DR_GEN_LANES_BIG : (rp.spp <= 2048 ? 32 : 16))));
     const dim3 g((npix + ln - 1) / ln, nGen);
     const size_t lds = (size_t)rp.spp * ln * (rp.spp <= 256 ? 1 : 2) + ((size_t)rp.spp + 1) * 4;
     if (rp.spp <= 256) {
@@ -1777,7 +1778,7 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t n
         (void)hipFuncSetAttribute((const void*)k_gen_samples_pc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrSet = true;
       }
-      if (!onePerGroup && !lanesEnv) {
+      if (!onePerGroup && !lanesEnv && rp.spp <= 1024) {
         const size_t ldsPc = (size_t)rp.spp * 64 * 2 + (((size_t)rp.spp + 2) & ~(size_t)1) * 4 + (size_t)DR_GEN_RING * 64 * 8 + 16;
         hipLaunchKernelGGL(k_gen_samples_pc, dim3((npix + 63) / 64, nGen), dim3(128), ldsPc, s, rp, st, npix);
       } else {

@@ -103,9 +103,10 @@ def test_path_counter_mode_vs_oracle(ob, gpu, cfg):
         assert st[k] == c[k], k
 
 
-@pytest.mark.parametrize("spp", [1, 2, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("spp", [1, 2, 64, 128, 256, 512, 1024, 2048, 4096])
 def test_sample_counts_at_the_ends_of_the_range(ob, gpu, spp):
-    """spp 1 / 2 (degenerate LD blocks, row-major k_gen_samples), 64..256 (k_gen_samples_lm, u8) and 512 / 1024 (u16)."""
+    """spp 1 / 2 (degenerate LD blocks, row-major k_gen_samples), 64..256 (k_gen_samples_lm, u8), 512 / 1024 (u16, the
+    two-wave kernel) and 2048 / 4096 (u16, 32 / 16 pixels per sampler group)."""
     prims, mk = scenes.config("C2", xres=8, yres=6, spp=spp, blob=(16, 8))
     r = mk()
     out = r.render(scenes.make_scene(prims))

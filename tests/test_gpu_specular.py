@@ -112,6 +112,20 @@ def test_direct_lighting_recurses_through_mirror_and_glass_like_the_oracle(ob, g
         assert not np.array_equal(path.film, out.film)
 
 
+def test_direct_lighting_recursion_deeper_than_sixteen(ob, gpu):
+    """maxdepth 20 over mirrors only (one child per vertex: the walk has at most maxdepth rounds per slot; with glass it is
+    the reference's own 2^maxdepth).  Rounds 17 and deeper were refused before round 3."""
+    txt = SCENE.format(depth=20, env=ENV, ceiling=CEILING).replace('SurfaceIntegrator "path"', 'SurfaceIntegrator "directlighting"')
+    txt = txt.replace('Material "glass" "float index" [1.5] "color Kr" [0.1 0.8 0.8] "color Kt" [0.1 0.8 0.8]', 'Material "mirror" "color Kr" [0.95 0.95 0.95]')
+    txt = txt.replace('Material "glass" "float index" [1.33]', 'Material "mirror" "color Kr" [0.9 0.9 0.9]')
+    txt = txt.replace('[48]', '[24]').replace('[36]', '[18]').replace('"integer pixelsamples" [16]', '"integer pixelsamples" [4]')
+    api = pbrt.loads(txt, render=True)
+    out, r = api.outputImage, api.rendererObject
+    e, before = api.envLight()
+    ref = ob.OracleScene(api.scenePrimitives, env=e, env_before=before).render(ob.render_desc(r, sampler_mode=1))
+    assert np.array_equal(out.film, ref["film"])
+
+
 def test_direct_lighting_serial_reference_stream_with_specular_materials(ob, gpu):
     """The serial reference stream: every SpecularReflect / SpecularTransmit call burns three RNG floats, which shifts
     the LD scrambles of all later pixels; the oracle records the sample vectors it drew and the device replays them."""
