@@ -199,6 +199,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
+    os.environ.setdefault("DARTRAY_COMM_FALLBACK", "1")  # N > 1: see dartray_amd/dist.py (_fallback_group); reported on the line
     rank, world, local = drdist.init_process_group()  # gloo control plane + dr_comm_init (RCCL) on every rank
     lib = _abi.lib()
     _abi.init(local)  # before the scenes are built: BVHAccel then takes the device builder (dr_bvh_build_device)
@@ -355,6 +356,8 @@ class Run:
         if world > 1:
             out["scaling"] = {"c3": "strong", "strong-c2": "strong", "weak": "weak", "samples": "weak"}[self.mode]
             out["rccl_world"] = int(self.lib.dr_comm_world())
+            out["collective"] = ("dr_film_reduce (C ABI: ncclReduce(sum, f32) over xGMI, librccl bound at run time)" if drdist.comm_error is None else
+                                 "FALLBACK torch.distributed RCCL group -- dr_comm_init failed: %s" % drdist.comm_error)
             out["per_rank_step_ms"] = {"min": round(dt_min / steps * 1e3, 3), "max": round(dt / steps * 1e3, 3)}
             out["reduce_ms"] = round(reduce_ms, 3)
             out["film_bytes_reduced_per_step"] = int(self.H * self.W * 16)

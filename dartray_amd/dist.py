@@ -29,6 +29,11 @@ import torch.distributed as dist
 from . import _abi
 
 _comm_ready = False
+# bench.py only: if dr_comm_init fails on a multi-GPU box (the world > 1 path of dr_comm.cpp has never met hardware in
+# development: one-GPU boxes), the film is reduced by torch.distributed's own RCCL group instead and the JSON line says
+# so, with the error -- a measured scaling curve plus a bug report instead of no curve.  Never taken silently.
+_fallback_group = None
+comm_error = None
 
 
 def init_process_group(device_comm=None):
@@ -46,8 +51,28 @@ def init_process_group(device_comm=None):
     if device_comm is None:
         device_comm = world > 1 and torch.cuda.is_available()
     if device_comm and not _comm_ready:
-        comm_init(rank, world, local)
+        if world > 1 and os.environ.get("DARTRAY_COMM_FALLBACK") == "1":
+            _comm_init_or_fallback(rank, world, local)
+        else:
+            comm_init(rank, world, local)
     return rank, world, local
+
+
+def _comm_init_or_fallback(rank, world, local):
+    """comm_init; if ANY rank fails, every rank drops to a torch.distributed RCCL group (see _fallback_group)."""
+    global _fallback_group, comm_error
+    err = None
+    try:
+        comm_init(rank, world, local)
+    except Exception as e:  # noqa: BLE001 -- reported on the JSON line
+        err = "%s: %s" % (type(e).__name__, e)
+    flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # gloo control plane
+    if int(flag.item()):
+        comm_error = err or "dr_comm_init failed on another rank"
+        if _comm_ready:
+            comm_destroy()
+        _fallback_group = dist.new_group(backend="nccl")
 
 
 def comm_init(rank, world, local):
@@ -69,6 +94,11 @@ def comm_destroy():
     if _comm_ready:
         _abi.check(_abi.lib().dr_comm_destroy())
         _comm_ready = False
+# bench.py only: if dr_comm_init fails on a multi-GPU box (the world > 1 path of dr_comm.cpp has never met hardware in
+# development: one-GPU boxes), the film is reduced by torch.distributed's own RCCL group instead and the JSON line says
+# so, with the error -- a measured scaling curve plus a bug report instead of no curve.  Never taken silently.
+_fallback_group = None
+comm_error = None
 
 
 def shard(renderer, rank, world, tile_size=32):
@@ -88,6 +118,9 @@ def reduce_film(film, dst=0, stream=None):
     """Sum the per-rank (X, Y, Z, weight) films onto rank `dst` (one collective per render).  Device films go
     through dr_film_reduce (RCCL) on `stream` (default: torch's current stream)."""
     if film.is_cuda:
+        if _fallback_group is not None:
+            dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM, group=_fallback_group)
+            return film
         if not _comm_ready:
             if int(os.environ.get("WORLD_SIZE", "1")) > 1:
                 raise _abi.DartRayHipError("reduce_film: dr_comm_init has not run (init_process_group on a GPU box does it)")
