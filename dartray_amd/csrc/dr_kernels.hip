@@ -1060,7 +1060,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
     bool pushCont = false, vert = false, deferred = false;
-    uint32_t contKey = 0u;  // DR_SORT_CONT: octant of the continuation ray's direction
+    uint32_t contKey = 0u, anyKey = 0u;  // DR_SORT_CONT: octants of the continuation / shadow ray's direction
     bool envNee = false, envMiss = false;  // ENVQ: this lane's light estimate / escaped camera ray goes to k_env
     if (valid) {
       const SlotRef sr = cur.sr;
@@ -1231,6 +1231,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         sr.f64<F_RTMIN>() = eps;
         vert = true;
       }
+      if (DR_SORT_CONT > 1 && (pf & PF_HAS_SH)) {
+        const F3 sd = ld3f<F_SHD>(sr);  // (experiment only: read back what setup_nee stored)
+        anyKey = (sd.x < 0.f ? 1u : 0u) | (sd.y < 0.f ? 2u : 0u) | (sd.z < 0.f ? 4u : 0u);
+      }
       if (Lchanged) stcf<F_L>(sr, L);
       // The path ended here with a finished light term pending: nothing is added to L after it, so k_film adds it
       // (L + Ld1 unless the shadow ray is blocked: the same f32 sum, one stage's round trip less).  Raw terms (a MIS
@@ -1245,7 +1249,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     }
     // (a slot with a parked estimate enters the next stage's list in k_env, once its flags are known)
     stage_push<NQ>(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0 && !deferred && !envNee, slot, Q_MIS_BIT,
-                   vert, pushCont ? 0u : Q_RESOLVE_BIT, envNee || envMiss, envMiss ? Q_ENV_MISS_BIT : 0u, contKey);
+                   vert, pushCont ? 0u : Q_RESOLVE_BIT, envNee || envMiss, envMiss ? Q_ENV_MISS_BIT : 0u, contKey, anyKey);
     PROF(8);
     if (pctx.iters == DR_PUSH_ITERS) {
       const uint32_t g = stage_flush<NQ>(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont,
