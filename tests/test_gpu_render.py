@@ -337,6 +337,33 @@ def test_two_pipelines_render_the_same_film():
     assert np.array_equal(films[0], films[1])
 
 
+def test_env_map_kernel_over_several_batches_and_two_pipelines():
+    """k_env (the environment-map work of a plain-triangle scene's path stages, with its own list per stage and batch) when
+    a render needs several batches, on one and on two pipelines (the second workspace has its own list): same film, and
+    the same as the single-batch render."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from dartray_amd import scenes\n"
+        "prims, mk = scenes.config('C5', xres=320, yres=256, spp=64, yard=(6, 12), env_res=(128, 64))\n"   # 5.2e6 samples
+        "r = mk(); out = r.render(scenes.make_scene(prims, r.env))\n"
+        "print('batches', r.last_stats['batches'])\n"
+        "np.save(sys.argv[1], out.film)\n" % ROOT)
+    films = []
+    for pipes, bits in (("1", "28"), ("1", "20"), ("2", "20")):
+        path = os.path.join(ROOT, "gpurun_out", "film_env_p%s_%s.npy" % (pipes, bits))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        env = dict(os.environ, DARTRAY_PIPELINES=pipes, DARTRAY_BATCH_BITS=bits)
+        res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=500)
+        assert res.returncode == 0, res.stderr[-2000:]
+        if bits == "20":
+            assert int(res.stdout.split("batches")[1].split()[0]) >= 4, res.stdout
+        films.append(np.load(path))
+        os.remove(path)
+    assert np.array_equal(films[0], films[1]) and np.array_equal(films[0], films[2])
+
+
 def test_unread_sample_blocks_can_be_left_out():
     """The device sampler only produces the LD blocks some kernel reads (RenderParams.genMask: no time sample, no
     volume slots, no uComponents for single-lobe materials, no lens sample for a pinhole, no levels beyond maxDepth).
