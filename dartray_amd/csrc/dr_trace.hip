@@ -427,13 +427,13 @@ struct RayIO {
 // -DDR_TRACE_PROF: a diagnostic build that stamps s_memtime between the phases of the v2 loop and sums the cycles the
 // waves spent in each (printed and cleared by dr_get_stats through trace_prof_dump).  No stamp executes in the product build.
 #ifdef DR_TRACE_PROF
-__device__ unsigned long long g_traceProf[2][8];
+__device__ unsigned long long g_traceProf[2][12];
 DR_DEV unsigned long long tprof_now() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
-#define TPROF_DECL unsigned long long tpT = tprof_now(), tpAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TPROF_DECL unsigned long long tpT = tprof_now(), tpAcc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define TPROF(i)                              \
   do {                                        \
     const unsigned long long n_ = tprof_now(); \
@@ -444,21 +444,23 @@ DR_DEV unsigned long long tprof_now() {
 #define TPROF_FLUSH                                                                  \
   do {                                                                               \
     if (lane_id() == 0)                                                              \
-      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_traceProf[ANY][i_], tpAcc[i_]);    \
+      for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_traceProf[ANY][i_], tpAcc[i_]);   \
   } while (0)
 void trace_prof_dump() {
-  unsigned long long h[2][8];
+  unsigned long long h[2][12];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_traceProf), sizeof(h)) != hipSuccess) return;
-  static const char* names[8] = {"refill: queue entry + ray state + ray_init", "node visits", "leaf tests", "result stores + bookkeeping",
-                                 "(wave iterations)", "(refill events)", "(leaf phases)", "(leaf triangle rounds)"};
+  static const char* names[12] = {"refill: queue entry + ray state + ray_init", "node visits", "leaf tests", "result stores + bookkeeping",
+                                  "(wave iterations)", "(refill events)", "(leaf phases)", "(leaf triangle rounds)",
+                                  "(lanes visiting a node, summed over iterations)", "(lanes waiting at a leaf, summed over iterations)",
+                                  "(idle lanes, summed over iterations)", "(lanes in the leaf phases that ran)"};
   for (int a = 0; a < 2; ++a) {
     double tot = 0;
     for (int i = 0; i < 4; ++i) tot += (double)h[a][i];
     if (tot == 0) continue;
     for (int i = 0; i < 4; ++i) fprintf(stderr, "trace_prof %s %-44s %6.2f %%  (%.3g wave-cycles)\n", a ? "any    " : "closest", names[i], 100.0 * h[a][i] / tot, (double)h[a][i]);
-    for (int i = 4; i < 8; ++i) fprintf(stderr, "trace_prof %s %-44s %.4g\n", a ? "any    " : "closest", names[i], (double)h[a][i]);
+    for (int i = 4; i < 12; ++i) fprintf(stderr, "trace_prof %s %-44s %.4g\n", a ? "any    " : "closest", names[i], (double)h[a][i]);
   }
-  for (int a = 0; a < 2; ++a) for (int i = 0; i < 8; ++i) h[a][i] = 0;
+  for (int a = 0; a < 2; ++a) for (int i = 0; i < 12; ++i) h[a][i] = 0;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_traceProf), h, sizeof(h));
 }
 #else
@@ -568,6 +570,9 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
       continue;
     }
     bool finished = false;
+    TPROF_COUNT(8, __popcll(travMask));
+    TPROF_COUNT(9, __popcll(leafMask));
+    TPROF_COUNT(10, 64 - __popcll(travMask | leafMask | doneMask));
     // ---- one node visit (bvh_accel.dart:122-160) ----
     nNodes += (uint32_t)__popcll(travMask);  // wave-uniform: lane 0 carries the wave's count (flush_counters sums lanes)
     uint4 a = uint4{0, 0, 0, 0}, b = uint4{0, 0, 0, 0};
@@ -636,6 +641,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
     const unsigned long long stillTrav = __ballot(mode == M_TRAV && !finished);
     if (leafMask != 0ull && (__popcll(leafMask) >= (ANY ? DR_LEAF_TH_A : DR_LEAF_TH_C) || stillTrav == 0ull)) {
       TPROF_COUNT(6, 1);
+      TPROF_COUNT(11, __popcll(leafMask));
       if (mode == M_LEAF) {
         bool occluded = false;
         const F3 rayD = COLD_D();
