@@ -372,7 +372,7 @@ def one_gpu_reference(mode, cfg):
     """The single-GPU rate a scaling figure of this N-rank line should be read against, from a committed single-GPU run
     of the same per-GPU (weak) or the same total (strong) workload -- labelled with its source, not measured now."""
     if mode in ("weak", "samples", "strong-c2"):
-        src, key = "profiles/r02_bench_final.json", "C2, 1024x1024, 256 spp on one GPU: the per-GPU workload of the weak modes, the total one of strong-c2"
+        src, key = "profiles/r03_bench_final.json", "C2, 1024x1024, 256 spp on one GPU: the per-GPU workload of the weak modes, the total one of strong-c2"
     else:
         src, key = None, "C3 (4096x4096, 1024 spp) on one GPU: 602 Msamples/s, 28.5 s per step (DESIGN.md section 5, round 2: `bench.py --config C3 --steps 1`)"
     ref = {"workload": key, "source": src}

@@ -54,6 +54,6 @@ def test_weak_scaling_keeps_the_per_gpu_pixel_count():
 
 def test_the_n_rank_line_names_its_single_gpu_reference():
     ref = bench.one_gpu_reference("weak", "C2")
-    assert ref["source"] == "profiles/r02_bench_final.json" and ref["value"] > 100 and ref["unit"] == "Msamples/s"
+    assert ref["source"] == "profiles/r03_bench_final.json" and ref["value"] > 100 and ref["unit"] == "Msamples/s"
     ref = bench.one_gpu_reference("c3", "C3")
     assert "4096x4096" in ref["workload"] and ref["value"] == 602.0
