@@ -105,6 +105,9 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
             "alg_over_measured_copy": round(achieved / copy_gbps, 4) if copy_gbps else None,
             "alg_bytes_per_launch": round(alg / launches, 1),
             "avg_launch_ms": round(st["closest_ms"] / launches, 4), "launches": int(st["closest_launches"]),
+            "avg_launch_ms_note": ("HIP events around each k_trace<0> launch on its own stream; the stage's any-hit launch runs beside it on a second "
+                                   "stream (DARTRAY_OVERLAP_ANY=0 serialises them: profiles/r03_*_kernel_stats_serial.csv, within 1 % of this figure)"
+                                   if os.environ.get("DARTRAY_OVERLAP_ANY", "1") != "0" else "one kernel at a time"),
             "rank0_job_alg_GBps": round(all_alg / dt_total / 1e9, 2),
             "rank0_trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt_total, 4)}
     sb = shade_alg_bytes(st)
