@@ -87,6 +87,37 @@ def test_coincident_centroids_and_signed_zeros(gpu):
     assert len(zeros) and np.signbit(zeros).any()  # a box that reaches a zero plane from both sides starts at -0.0
 
 
+@pytest.mark.parametrize("n,kind,seed", [(1, "soup", 1), (2, "soup", 2), (3, "soup", 3), (4, "soup", 4), (5, "soup", 5), (63, "soup", 6), (64, "soup", 7),
+                                         (65, "soup", 8), (128, "clusters", 9), (129, "soup", 10), (1000, "clusters", 11), (4097, "soup", 12),
+                                         (20000, "line", 13), (100003, "clusters", 14), (300000, "soup", 15), (50000, "grid", 16)])
+def test_random_triangle_soups(gpu, n, kind, seed):
+    """Sizes around the single-thread threshold (64), the wave and tile sizes of the reduction kernels, and distributions
+    that stress the split logic: uniform soups, tight clusters far apart (empty SAH buckets, huge coordinate ranges), points
+    on a line (two degenerate axes), a regular grid (many equal centroids: ties in the bucket index and in the 4-element sort)."""
+    rng = np.random.default_rng(seed)
+    if kind == "soup":
+        c = rng.uniform(-100, 100, (n, 1, 3))
+        v = c + rng.normal(0, 1.5, (n, 3, 3))
+    elif kind == "clusters":
+        centres = rng.uniform(-1e4, 1e4, (7, 3))
+        c = centres[rng.integers(0, 7, n)][:, None, :] + rng.normal(0, 0.01, (n, 1, 3))
+        v = c + rng.normal(0, 0.001, (n, 3, 3))
+    elif kind == "line":
+        t = rng.uniform(-50, 50, (n, 1, 1))
+        v = np.concatenate([t + rng.normal(0, 0.01, (n, 3, 1)), np.zeros((n, 3, 1)), np.full((n, 3, 1), 2.0)], axis=2)
+    else:  # grid: integer lattice, many coincident and equal centroids
+        g = rng.integers(0, 12, (n, 1, 3)).astype(np.float64)
+        v = g + np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float64)[None]
+    verts = np.ascontiguousarray(v.reshape(-1, 3), np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    qb = np.zeros((1, 6), np.float32)
+    for max_prims in ((4,) if n > 5000 else (4, 1, 8)):
+        hn, ho, hnn, hd = core.build_bvh_arrays(verts, idx, qb, 0, max_prims, "host")
+        dn, do, dnn, dd = core.build_bvh_arrays(verts, idx, qb, 0, max_prims, "device")
+        assert dnn == hnn and dd == hd, (n, kind, max_prims)
+        assert np.array_equal(do[:n], ho[:n]) and dn[:dnn].tobytes() == hn[:hnn].tobytes(), (n, kind, max_prims)
+
+
 @pytest.mark.parametrize("cfg,budget_s", [("C2", 0.25), ("C5", 0.6), ("C4", 0.6)])
 def test_full_size_configs_equal_the_host_builder(gpu, cfg, budget_s):
     """BASELINE.json's scenes at full size: 1 000 012, ~8 M and 10 000 012 triangles."""
