@@ -773,7 +773,7 @@ DR_DEV F3 shapeset_sample(const DScene& sc, const LV& lv, const DLight& L, doubl
   double thit = 1.0;
   for (uint32_t i = 0; i < L.ntris; ++i) {
     const DLightTri t = lv.ltri(L.first_tri + i);
-    double th, bb1, bb2;
+    double th;
     if (QUAD && PRIM_KIND(t.reverse)) {
       const DQuadric& q = sc.quads[__float_as_uint(t.p[0])];
       F3 phit;
@@ -800,9 +800,8 @@ DR_DEV double shapeset_pdf(const DScene& sc, const LV& lv, const DLight& L, F3 p
   double pdf = 0.0;
   for (uint32_t i = 0; i < L.ntris; ++i) {
     const DLightTri t = lv.ltri(L.first_tri + i);
-    F3 a, b, c;
     double pdf2;
-    double th, bb1, bb2;
+    double th;
     bool h;
     F3 nn;
     if (QUAD && PRIM_KIND(t.reverse)) {
