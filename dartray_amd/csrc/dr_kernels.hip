@@ -1831,9 +1831,9 @@ void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchStat
                        int grid, hipStream_t s) {
   const bool gen = sc.nquads || sc.hasSpec || sc.srec;
   const size_t x = light_table_bytes(sc) + mat_table_bytes(sc);
-  // (the env-map variant stages a fifth list: its tables only go to LDS when the 160 KB still hold both)
+  // (the tables only go to LDS when the 160 KB hold them next to the staging lists: five per wave in the env-map variant)
   const bool envq = !gen && sc.hasEnv;
-  if (lightsInLds(sc) && (!envq || push_stage_bytes(SHADE_BLOCK_OF(false), 5) + x <= 160 * 1024)) {
+  if (lightsInLds(sc) && push_stage_bytes(SHADE_BLOCK_OF(gen), envq ? 5 : 4) + x <= 160 * 1024) {
     if (gen) launch_shade<k_shade_path<true, true, true>, SHADE_BLOCK_OF(true)>(grid, x, s, sc, rp, st, q, bounce);
     else if (sc.hasEnv) launch_shade<k_shade_path<true, false, true>, SHADE_BLOCK_OF(false), 5>(grid, x, s, sc, rp, st, q, bounce);
     else launch_shade<k_shade_path<false, false, true>, SHADE_BLOCK_OF(false)>(grid, x, s, sc, rp, st, q, bounce);
@@ -1859,7 +1859,7 @@ void launch_env(const DScene& sc, const RenderParams& rp, const BatchState& st, 
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
   const bool gen = sc.nquads || sc.hasSpec || sc.srec;
-  if (lightsInLds(sc)) {
+  if (lightsInLds(sc) && push_stage_bytes(SHADE_BLOCK_OF(gen)) + light_table_bytes(sc) + mat_table_bytes(sc) <= 160 * 1024) {
     const size_t x = light_table_bytes(sc) + mat_table_bytes(sc);
     if (gen) launch_shade<k_shade_direct<true, true>, SHADE_BLOCK_OF(true)>(grid, x, s, sc, rp, st, q, stage);
     else launch_shade<k_shade_direct<false, true>, SHADE_BLOCK_OF(false)>(grid, x, s, sc, rp, st, q, stage);
