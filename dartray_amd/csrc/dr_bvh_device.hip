@@ -747,7 +747,11 @@ extern "C" int dr_bvh_build_device(const float* verts, uint64_t nverts, const ui
   Buf<uint3> dSmall;
   BT(dSmall.alloc(n));
   // the per-level lists are kept: sizes run bottom-up, numbering top-down
-  std::vector<Seg*> levels;
+  struct LevelLists : std::vector<Seg*> {  // freed on every return path
+    ~LevelLists() {
+      for (Seg* p : *this) (void)hipFree(p);
+    }
+  } levels;
   std::vector<uint32_t> levelCount;
   auto freeLevels = [&]() {
     for (Seg* p : levels) (void)hipFree(p);
