@@ -107,30 +107,43 @@ DR_DEV uint32_t stage_flush(PushStage& sm, PushCtx& c, uint32_t* closestQ, uint3
   const int lane = lane_id();
   const uint32_t n0 = c.n[0], n1 = c.n[1], n2 = c.n[2], n3 = c.n[3];
   uint32_t grabbed = 0u;
-  if constexpr (NQ == 5) {
-    // the environment-map list: its own reservation (a fifth counter, in its own cache line), copied out first
-    const uint32_t n4 = c.nEnv;
-    if (n4) {
-      uint32_t a4 = 0u;
-      if (lane == 0) a4 = atomicAdd(nEnvQ, n4);
-      a4 = wave_bcast_first(a4);
-      const uint32_t* buf = stage_region<NQ>(sm);
-      for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) envQ[a4 + i] = buf[4 * DR_PUSH_CAP + i];
-    }
-    c.nEnv = 0u;
-  }
-  if (work && (n0 | n1 | n2 | n3) == 0u) {
+  uint32_t n4 = 0u;
+  if constexpr (NQ == 5) n4 = c.nEnv;  // the environment-map list: a fifth counter, in its own cache line
+  if (work && (n0 | n1 | n2 | n3 | n4) == 0u) {
     if (lane == 0) grabbed = atomicAdd(work, 1u);
     grabbed = wave_bcast_first(grabbed);
+  }
+  if (NQ == 5 && n4 != 0u && (n0 | n1 | n2 | n3) == 0u) {  // only environment-map entries this round (e.g. a chunk of sky)
+    uint32_t a4 = 0u;
+    if (lane == 0) {
+      a4 = atomicAdd(nEnvQ, n4);
+      if (work) grabbed = atomicAdd(work, 1u);
+    }
+    a4 = wave_bcast_first(a4);
+    if (work) grabbed = wave_bcast_first(grabbed);
+    const uint32_t* buf = stage_region<NQ>(sm);
+    for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) envQ[a4 + i] = buf[4 * DR_PUSH_CAP + i];
   }
   if ((n0 | n1 | n2 | n3) != 0u) {
     // three independent round trips in flight together, ONE wait.  Written out because the compiler's atomic optimizer
     // wraps every atomicAdd in its own readfirstlane and so waits for each before it issues the next.  Every lane gets
     // the same values back from lane 0 through readfirstlane (adding 0 returns the counter and costs the same).
-    uint32_t a0 = 0u, a1 = 0u, a2 = 0u;
+    uint32_t a0 = 0u, a1 = 0u, a2 = 0u, a4 = 0u;
     if (lane == 0) {
       const uint32_t zero = 0u;
-      if (work) {
+      if (NQ == 5 && work) {  // five round trips in flight together (k_shade_path's ENVQ instantiations)
+        const uint32_t one = 1u;
+        asm volatile(
+            "global_atomic_add %0, %5, %6, %11 sc0\n\t"
+            "global_atomic_add %1, %5, %7, %12 sc0\n\t"
+            "global_atomic_add %2, %5, %8, %13 sc0\n\t"
+            "global_atomic_add %3, %5, %9, %14 sc0\n\t"
+            "global_atomic_add %4, %5, %10, %15 sc0\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(grabbed), "=&v"(a4)
+            : "v"(zero), "v"(n0 + n1), "v"(n2), "v"(n3), "v"(one), "v"(n4), "s"(nClosest), "s"(nAny), "s"(nActive), "s"(work), "s"(nEnvQ)
+            : "memory");
+      } else if (work) {
         const uint32_t one = 1u;
         asm volatile(
             "global_atomic_add %0, %4, %5, %9 sc0\n\t"
@@ -198,9 +211,19 @@ DR_DEV uint32_t stage_flush(PushStage& sm, PushCtx& c, uint32_t* closestQ, uint3
     else
       for (uint32_t i = (uint32_t)lane; i < n2; i += 64u) anyQ[b1 + i] = buf[2 * DR_PUSH_CAP + i];
     for (uint32_t i = (uint32_t)lane; i < n3; i += 64u) activeQ[b2 + i] = buf[3 * DR_PUSH_CAP + i];
+    if constexpr (NQ == 5) {
+      if (n4 != 0u) {
+        if (!work) {  // (no caller: the five-list form is k_shade_path's, which always hands its work counter in)
+          if (lane == 0) a4 = atomicAdd(nEnvQ, n4);
+        }
+        const uint32_t b4 = wave_bcast_first(a4);
+        for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) envQ[b4 + i] = buf[4 * DR_PUSH_CAP + i];
+      }
+    }
     if (work) grabbed = wave_bcast_first(grabbed);
   }
   c.n[0] = c.n[1] = c.n[2] = c.n[3] = 0;
+  c.nEnv = 0u;
   c.iters = 0;
   c.round += 1u;
   return grabbed;
