@@ -77,6 +77,7 @@ struct RenderParams {
 #define DR_SUB 64
 #endif
 #define DR_SUB_WORDS (DR_STATE_WORDS_K * DR_SUB)  // words of one sub-tile
+static_assert(DR_SUB >= 2 && DR_SUB <= 64 && (DR_SUB & (DR_SUB - 1)) == 0, "DR_SUB: a power of two in 2 .. 64 (the f64 fields need an even number of words per sub-tile)");
 #define TI64(ts, s) ((size_t)((s) >> 6) * (size_t)(ts) + (size_t)((s) & 63u))
 #define TI(ts, s) ((size_t)((s) >> 6) * (size_t)(ts) + (size_t)(((s) & 63u) / DR_SUB) * DR_SUB_WORDS + (size_t)((s) & (DR_SUB - 1u)))
 #define TD(ts, s) ((size_t)((s) >> 6) * (size_t)((ts) >> 1) + (size_t)(((s) & 63u) / DR_SUB) * (DR_SUB_WORDS / 2) + (size_t)((s) & (DR_SUB - 1u)))
