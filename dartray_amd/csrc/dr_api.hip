@@ -368,6 +368,28 @@ void enumeratePixels(const RenderParams& rp, const DrRenderDesc* rd, std::vector
 
 }  // namespace
 
+// The kernels that read or write the path state exist twice: the default layout (every field of a tile's 64 slots one
+// 256-byte run) and sp4 (sub-tiles of four slots: a slot's 41 words within 656 contiguous bytes; the same sources compiled
+// with -DDR_SUB=4 -DDR_NS=sp4).  Dense stage lists are faster in the first; lists that thin out early -- open scenes under an
+// environment map, where most bounce rays leave -- in the second (C5: shade 711 -> 536 ms).
+// A render picks one (dr_render_device); results do not depend on it.
+struct LayoutOps {
+  decltype(&launch_trace) trace;
+  decltype(&launch_gen_samples) gen_samples;
+  decltype(&launch_transpose_samples) transpose_samples;
+  decltype(&launch_raygen) raygen;
+  decltype(&launch_shade_path) shade_path;
+  decltype(&launch_env) env;
+  decltype(&launch_shade_direct) shade_direct;
+  decltype(&launch_shade_spec) shade_spec;
+  decltype(&launch_film) film;
+};
+static const LayoutOps kLayout64 = {&launch_trace, &launch_gen_samples, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
+                                    &launch_env, &launch_shade_direct, &launch_shade_spec, &launch_film};
+static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_gen_samples, &sp4::launch_transpose_samples, &sp4::launch_raygen,
+                                     &sp4::launch_shade_path, &sp4::launch_env, &sp4::launch_shade_direct, &sp4::launch_shade_spec,
+                                     &sp4::launch_film};
+
 int traceGridFor(int wgPerCU) {
   // workgroups of the persistent traversal kernels: as many as are resident at once.  v2 (k_trace): 16 KiB of stack +
   // 6 KiB of cold ray state in LDS and 72 VGPRs => 7 workgroups = 28 waves per CU; the other variants (v3: 32 KiB of
@@ -1335,6 +1357,10 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // k_env (dr_kernels.hip): the environment-map work of a plain-triangle scene's path stages runs in its own kernel
   const bool envStage = rd->integrator == DR_INTEGRATOR_PATH && sc->d.hasEnv && !(sc->d.nquads || sc->d.hasSpec || sc->d.srec);
   if (envStage && sc->d.env.h > DR_ENV_MARG_MAX_ROWS) return fail(DR_ERR_UNSUPPORTED, "radiance map taller than 8192 rows");
+  // state layout of this render (see LayoutOps): the four-slot sub-tiles for the renders whose lists thin out early
+  static const char* layoutEnv = getenv("DARTRAY_STATE_LAYOUT");  // 64 | 4: A/B runs and tests
+  const bool sparseLayout = layoutEnv ? atoi(layoutEnv) == 4 : envStage;
+  const LayoutOps& L = sparseLayout ? kLayoutSp4 : kLayout64;
   if (envStage) {
     HIP_TRY(sc->ws.envQ.alloc(sc->ws.cap));
     if (twoPipes) HIP_TRY(sc->ws2.envQ.alloc(sc->ws2.cap));
@@ -1360,21 +1386,21 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       HIP_TRY(w.aosSamples.alloc((size_t)w.cap * rd->sample_stride));
       HIP_TRY(hipMemcpyAsync(w.aosSamples.p, rd->sample_vec + (size_t)p0 * spp * rd->sample_stride,
                              (size_t)nslots * rd->sample_stride * sizeof(float), hipMemcpyHostToDevice, s));
-      launch_transpose_samples(w.aosSamples.p, rd->sample_stride, st, rp.nFloats, s);
+      L.transpose_samples(w.aosSamples.p, rd->sample_stride, st, rp.nFloats, s);
       if (needTail > 0)
         HIP_TRY(hipMemcpyAsync(w.tail.p, rd->tail + (size_t)p0 * spp * rd->max_tail,
                                (size_t)nslots * rd->max_tail * sizeof(double), hipMemcpyHostToDevice, s));
     } else {
-      launch_gen_samples(rp, st, np, s);
+      L.gen_samples(rp, st, np, s);
     }
-    launch_raygen(rp, st, s);
+    L.raygen(rp, st, s);
     timed(3, evGen);
     uint32_t* C = w.counters.p;
     int wc = 0;  // work counters live at C[1024..], 8 per launch
     auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr) {
       hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
       (void)hipEventRecord(e0, ts);
-      launch_trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
+      L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
       (void)hipEventRecord(e1, ts);
       if (pilot) pilot->ev[any].push_back({e0, e1});
       sc->traceEvents.push_back({e0, e1, any, after});
@@ -1417,9 +1443,9 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       q.nEnv = C + N_COUNTERS_TRACE + 64 * b;
       hipEvent_t evS = sc->getEvent();
       (void)hipEventRecord(evS, s);
-      if (rd->integrator == DR_INTEGRATOR_PATH) launch_shade_path(sc->d, rp, st, q, b, sgrid, s);
-      else launch_shade_direct(sc->d, rp, st, q, b, sgrid, s);
-      if (envStage) launch_env(sc->d, rp, st, q, b, sgrid, s);
+      if (rd->integrator == DR_INTEGRATOR_PATH) L.shade_path(sc->d, rp, st, q, b, sgrid, s);
+      else L.shade_direct(sc->d, rp, st, q, b, sgrid, s);
+      if (envStage) L.env(sc->d, rp, st, q, b, sgrid, s);
       timed(2, evS);
       if (b + 1 < nStages) {
         if (sideBySide) {
@@ -1454,7 +1480,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       q.ctr = sc->ctr.p;
       hipEvent_t evS = sc->getEvent();
       (void)hipEventRecord(evS, s);
-      launch_shade_spec(sc->d, rp, st, q, sgrid, s);
+      L.shade_spec(sc->d, rp, st, q, sgrid, s);
       timed(2, evS);
       uint32_t live = 0;  // (a synchronous read-back per round: this is not the throughput path)
       HIP_TRY(hipMemcpyAsync(&live, nNext, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1467,7 +1493,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     {
       hipEvent_t evF = sc->getEvent();
       (void)hipEventRecord(evF, s);
-      launch_film(rp, st, sc->ws.filterTable.p, np, (float*)film_dev, s);
+      L.film(rp, st, sc->ws.filterTable.p, np, (float*)film_dev, s);
       timed(4, evF);
       sc->stats.batches++;
     }
@@ -1599,6 +1625,8 @@ int dr_get_stats(DrScene* sc, DrRenderStats* out) {
     sc->statsPending = false;
     shade_prof_dump();
     trace_prof_dump();
+    sp4::shade_prof_dump();
+    sp4::trace_prof_dump();
   }
   *out = sc->stats;
   return DR_OK;

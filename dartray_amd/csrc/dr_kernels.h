@@ -234,28 +234,10 @@ int traceGridFor(int wgPerCU);  // dr_api.hip: workgroups of a persistent traver
 #define DR_MAX_STACK 128      // LDS + spill entries per lane (the reference uses 64, bvh_accel.dart:120)
 #define DR_TRACE_BLOCK 256
 
-// ---- launchers (dr_kernels.hip) ----
-void launch_gather_tris(const float* verts, const uint32_t* idx, const uint32_t* mat, const int32_t* light,
-                        const uint8_t* rev, float4* out, uint64_t ntris, hipStream_t s);
-void launch_make_shtris(const DScene& sc, float4* out, uint64_t ntris, hipStream_t s);
-void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
-                      uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s, int forceImpl = 0);
-void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
-                  uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s);
-void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s);
-void launch_transpose_samples(const float* aos, int stride, const BatchState& st, int nFloats, hipStream_t s);
-void launch_raygen(const RenderParams& rp, const BatchState& st, hipStream_t s);
-void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
-                       int grid, hipStream_t s);
-void launch_env(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce, int grid, hipStream_t s);
-void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
-                         int grid, hipStream_t s);
-void launch_shade_spec(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int grid, hipStream_t s);
-void launch_film(const RenderParams& rp, const BatchState& st, const float* filterTable, uint32_t npix, float* film,
-                 hipStream_t s);
-void launch_film_resolve(const float* film, int64_t npix, float* rgb, hipStream_t s);
-void launch_copy(const float4* src, float4* dst, uint64_t n4, hipStream_t s);
-void trace_prof_dump();  // -DDR_TRACE_PROF builds only: per-phase cycle sums of the v2 traversal loop
-void shade_prof_dump();  // -DDR_SHADE_PROF builds only: prints and clears the per-phase cycle sums of k_shade_path
+// ---- launchers (dr_kernels.hip, dr_trace.hip): one set per state layout ----
+#include "dr_launchers.inc"
+namespace sp4 {
+#include "dr_launchers.inc"
+}
 
 #endif

@@ -17,6 +17,10 @@
 #include "dr_rng.h"
 #include "dr_wave.h"
 
+#ifdef DR_NS  // a second instantiation of this file (another state layout, -DDR_SUB=...): every symbol in its own namespace
+namespace DR_NS {
+#endif
+
 // ---------------------------------------------------------------------------
 // scene upload: gather each primitive's vertices into its 48-byte record
 // ---------------------------------------------------------------------------
@@ -1884,3 +1888,7 @@ void launch_film_resolve(const float* film, int64_t npix, float* rgb, hipStream_
 void launch_copy(const float4* src, float4* dst, uint64_t n4, hipStream_t s) {
   hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, s, src, dst, n4);
 }
+
+#ifdef DR_NS
+}  // namespace DR_NS
+#endif

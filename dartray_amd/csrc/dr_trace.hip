@@ -28,6 +28,10 @@
 #include "dr_wave.h"
 #include "dr_rng.h"
 
+#ifdef DR_NS  // a second instantiation of this file (another state layout, -DDR_SUB=...): every symbol in its own namespace
+namespace DR_NS {
+#endif
+
 #ifndef DR_REFILL_TH
 #define DR_REFILL_TH 16
 #endif
@@ -1159,3 +1163,7 @@ void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue,
     else hipLaunchKernelGGL(k_trace<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
   }
 }
+
+#ifdef DR_NS
+}  // namespace DR_NS
+#endif

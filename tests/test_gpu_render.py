@@ -337,6 +337,35 @@ def test_two_pipelines_render_the_same_film():
     assert np.array_equal(films[0], films[1])
 
 
+def test_both_state_layouts_render_the_same_film():
+    """The kernels that touch the path state are built twice (LayoutOps, dr_api.hip): 64-slot runs, and sub-tiles of four slots
+    (namespace sp4, picked by itself for plain-triangle scenes under an environment map).  DARTRAY_STATE_LAYOUT forces one: a
+    closed scene, an open scene under a map, DirectLighting and a host-buffer replay give the same films either way."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from dartray_amd import core, scenes\n"
+        "films = []\n"
+        "prims, mk = scenes.config('C2', xres=96, yres=80, spp=64, blob=(40, 20))\n"
+        "films.append(mk().render(scenes.make_scene(prims)).film)\n"
+        "prims5, mk5 = scenes.config('C5', xres=96, yres=80, spp=64, yard=(6, 12), env_res=(128, 64))\n"
+        "r5 = mk5(); films.append(r5.render(scenes.make_scene(prims5, r5.env)).film)\n"
+        "prims1, mk1 = scenes.config('C1')\n"
+        "r1 = mk1(); films.append(np.pad(r1.render(scenes.make_scene(prims1)).film, ((0, 16), (0, 32), (0, 0))))\n"
+        "np.save(sys.argv[1], np.stack([f[:80, :96] for f in films]))\n" % ROOT)
+    out = []
+    for layout in ("64", "4"):
+        path = os.path.join(ROOT, "gpurun_out", "film_layout%s.npy" % layout)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, DARTRAY_STATE_LAYOUT=layout), capture_output=True,
+                             text=True, timeout=500)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out.append(np.load(path))
+        os.remove(path)
+    assert np.array_equal(out[0], out[1]) and out[0].any()
+
+
 def test_env_map_kernel_over_several_batches_and_two_pipelines():
     """k_env (the environment-map work of a plain-triangle scene's path stages, with its own list per stage and batch) when
     a render needs several batches, on one and on two pipelines (the second workspace has its own list): same film, and

@@ -14,7 +14,7 @@ for spec in "$@"; do
     for s in dr_kernels.hip dr_trace.hip dr_api.hip dr_bvh_build.cpp dr_comm.cpp dr_bvh_device.hip; do
       if [ "$s" = "$src" ]; then objs="$objs _obj/var_$name.o"; else objs="$objs _obj/$s.o"; fi
     done
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o "../libdartray_hip_$name.so" $objs -ldl
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o "../libdartray_hip_$name.so" $objs _obj/dr_kernels.hip.sp4.o _obj/dr_trace.hip.sp4.o -ldl
     rm -f "_obj/var_$name.o"; echo "built $name" ) &
 done
 wait
