@@ -76,8 +76,12 @@ struct RenderParams {
 #ifndef DR_SUB
 #define DR_SUB 64
 #endif
+#ifndef DR_STATE_WORDS_K
+#define DR_STATE_WORDS_K 41  // words of fixed path state per slot (42 pads a slot to 168 B: the experiment with DR_SUB = 1, one slot's words contiguous)
+#endif
 #define DR_SUB_WORDS (DR_STATE_WORDS_K * DR_SUB)  // words of one sub-tile
-static_assert(DR_SUB >= 2 && DR_SUB <= 64 && (DR_SUB & (DR_SUB - 1)) == 0, "DR_SUB: a power of two in 2 .. 64 (the f64 fields need an even number of words per sub-tile)");
+static_assert(DR_SUB >= 1 && DR_SUB <= 64 && (DR_SUB & (DR_SUB - 1)) == 0 && (DR_SUB * DR_STATE_WORDS_K) % 2 == 0,
+              "DR_SUB: a power of two in 1 .. 64 with an even number of words per sub-tile (the f64 fields)");
 #define TI64(ts, s) ((size_t)((s) >> 6) * (size_t)(ts) + (size_t)((s) & 63u))
 #define TI(ts, s) ((size_t)((s) >> 6) * (size_t)(ts) + (size_t)(((s) & 63u) / DR_SUB) * DR_SUB_WORDS + (size_t)((s) & (DR_SUB - 1u)))
 #define TD(ts, s) ((size_t)((s) >> 6) * (size_t)((ts) >> 1) + (size_t)(((s) & 63u) / DR_SUB) * (DR_SUB_WORDS / 2) + (size_t)((s) & (DR_SUB - 1u)))
@@ -90,9 +94,8 @@ enum {
   F_RO = 6, F_RD = 9, F_BETA = 12, F_L = 15, F_BETANEE = 18, F_SHD = 21, F_LD1 = 24, F_MISD = 27, F_LD2 = 30,
   F_HPRIM = 33, F_SHOCC = 34, F_MISLIGHT = 35, F_MISPRIM = 36, F_FLAGS = 37,
   F_RO0 = 38,     // (DirectLighting with quadrics / shading records only: outside the window below)
-  F_SAMPLES = 41  // == DR_STATE_WORDS
+  F_SAMPLES = DR_STATE_WORDS_K  // == DR_STATE_WORDS: where a tile's sample region starts, in 64-word runs
 };
-#define DR_STATE_WORDS_K 41
 // The 32 runs F_RO .. F_FLAGS are exactly 8 KiB: the whole signed 13-bit immediate-offset window of a global_load /
 // global_store around ONE per-lane base address (SlotRef below), so the shade kernels reach every hot field of a slot
 // without any per-access address arithmetic.
