@@ -122,7 +122,7 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
     prof = profiled_kernels(tag)
     if prof:
         for obj, prefix in ((roof, closest_kernel), (shade, "k_shade_path")):
-            k = next((v for n, v in prof["kernels"].items() if n.startswith(prefix)), None)
+            k = next((v for n, v in prof["kernels"].items() if n.split("::")[-1].startswith(prefix)), None)
             if not k or not k.get("hbm_side_GBps"):
                 continue
             obj["physical_GBps"] = round(k["hbm_side_GBps"], 1)

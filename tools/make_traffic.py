@@ -29,7 +29,8 @@ stats = {r["Name"]: r for r in csv.DictReader(open(_serial if os.path.exists(_se
 bench = json.load(open("%s/%s_bench.json" % (src, cfg)))
 res = {"workload": bench["config"]["workload"], "bench_value_under_rocprof": bench["value"], "kernels": {}}
 for name in rd:
-    if not (name.startswith("k_trace") or name.startswith("k_shade_path") or name.startswith("k_env")):
+    base = name.split("::")[-1]  # (kernels of the four-slot state layout live in namespace sp4)
+    if not (base.startswith("k_trace") or base.startswith("k_shade_path") or base.startswith("k_env")):
         continue
     r, w, s = rd[name], wr.get(name, {}), sq.get(name, {})
     reads = r.get("TCC_EA0_RDREQ_128B", 0) * 128 + r.get("TCC_EA0_RDREQ_64B", 0) * 64 + r.get("TCC_EA0_RDREQ_32B", 0) * 32
@@ -49,7 +50,7 @@ for name in rd:
         e["valu_lane_utilisation"] = s["SQ_THREAD_CYCLES_VALU"] / (s["SQ_INSTS_VALU"] * 64)
         e["wait_any_share_of_wave_cycles"] = s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"]
     res["kernels"][name] = e
-dom = "k_trace3<0>" if "k_trace3<0>" in res["kernels"] else "k_trace<0>"
+dom = next((k for k in res["kernels"] if k.split("::")[-1] == "k_trace3<0>"), None) or next(k for k in res["kernels"] if k.split("::")[-1] == "k_trace<0>")
 res["kernel"] = dom
 res["hbm_bytes_per_launch"] = res["kernels"][dom]["hbm_bytes_per_launch"]
 res["alg_bytes_per_launch"] = bench["roofline"]["alg_bytes_per_launch"]
@@ -57,7 +58,7 @@ res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / bench["roofline"
 res["method"] = ("tools/profile_%s.sh: rocprofv3 --pmc passes (counters only) on `DARTRAY_TRACE_IMPL=%s python3 bench.py %s--steps 1 --warmup 0 "
                  "--no-cpu-baseline --no-extra` (two full renders, every launch full size); launch times from the --kernel-trace --stats "
                  "run of the same script.  Counters sit on the L2's memory side, so Infinity-Cache hits are included: an upper bound on "
-                 "HBM bytes." % (rnd, "3" if dom.startswith("k_trace3") else "2", "" if cfg == "c2" else "--config %s " % cfg.upper()))
+                 "HBM bytes." % (rnd, "3" if "k_trace3" in dom else "2", "" if cfg == "c2" else "--config %s " % cfg.upper()))
 res["sources"] = ["profiles/%s_pmc_%s_rdreq.txt" % (rnd, cfg), "profiles/%s_pmc_%s_wrreq.txt" % (rnd, cfg), "profiles/%s_pmc_%s_sq.txt" % (rnd, cfg),
                   "profiles/%s_%s_kernel_stats_serial.csv" % (rnd, cfg)]
 json.dump(res, open(out, "w"), indent=1)
