@@ -56,6 +56,7 @@ struct DevBuf {
 
 struct Workspace {
   uint32_t cap = 0;
+  int stateWords = 0;  // words per slot the tiles were sized for
   int svWords = 0, maxTail = 0;  // svWords: 4-byte words of the sample region of one tile
   uint32_t pixCap = 0;
   DevBuf<float> tiles;  // the tiled path state (see BatchState in dr_kernels.h): cap/64 tiles of 64*41+svWords words
@@ -294,12 +295,13 @@ struct SampleForm {
   int svWords() const { return compact ? ((nBlocks * 64) << idxShift) / 4 : 64 * nFloats; }
 };
 
-int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, const SampleForm& sf, uint32_t pixCap, int maxTail, bool needTail) {
+int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, const SampleForm& sf, uint32_t pixCap, int maxTail, bool needTail, int stateWords) {
   cap = (cap + 63u) & ~63u;  // whole tiles
-  if (cap > w.cap || sf.svWords() > w.svWords) {
+  if (cap > w.cap || sf.svWords() > w.svWords || stateWords > w.stateWords) {
     uint32_t c = std::max(cap, w.cap);
     int sw = std::max(sf.svWords(), w.svWords);
-    HIP_TRY(w.tiles.alloc((size_t)(c / 64) * (64 * (size_t)DR_STATE_WORDS + (size_t)sw)));
+    w.stateWords = std::max(stateWords, w.stateWords);
+    HIP_TRY(w.tiles.alloc((size_t)(c / 64) * (64 * (size_t)w.stateWords + (size_t)sw)));
     HIP_TRY(w.activeA.alloc(c));
     HIP_TRY(w.activeB.alloc(c));
     HIP_TRY(w.closestQ.alloc(2 * (size_t)c));
@@ -318,11 +320,11 @@ int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, const SampleForm& sf
   return DR_OK;
 }
 
-BatchState makeState(Workspace& w, const SampleForm& sf, const int2* pix, uint32_t nslots, bool useTail) {
+BatchState makeState(Workspace& w, const SampleForm& sf, const int2* pix, uint32_t nslots, bool useTail, int stateWords) {
   BatchState st;
   st.cap = w.cap;
   st.nslots = nslots;
-  st.tileStride = 64u * (uint32_t)DR_STATE_WORDS + (uint32_t)w.svWords;
+  st.tileStride = 64u * (uint32_t)stateWords + (uint32_t)w.svWords;  // (the layout's own words per slot: its sample region starts behind them)
   st.idxShift = (uint32_t)sf.idxShift;
   st.pix = pix;
   st.tail = useTail ? w.tail.p : nullptr;
@@ -383,12 +385,13 @@ struct LayoutOps {
   decltype(&launch_shade_direct) shade_direct;
   decltype(&launch_shade_spec) shade_spec;
   decltype(&launch_film) film;
+  int stateWords;  // 4-byte words of fixed path state per slot in this layout (a tile is 64 of them + the sample region)
 };
 static const LayoutOps kLayout64 = {&launch_trace, &launch_gen_samples, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
-                                    &launch_env, &launch_shade_direct, &launch_shade_spec, &launch_film};
+                                    &launch_env, &launch_shade_direct, &launch_shade_spec, &launch_film, DR_STATE_WORDS};
 static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_gen_samples, &sp4::launch_transpose_samples, &sp4::launch_raygen,
                                      &sp4::launch_shade_path, &sp4::launch_env, &sp4::launch_shade_direct, &sp4::launch_shade_spec,
-                                     &sp4::launch_film};
+                                     &sp4::launch_film, 48};
 
 int traceGridFor(int wgPerCU) {
   // workgroups of the persistent traversal kernels: as many as are resident at once.  v2 (k_trace): 16 KiB of stack +
@@ -1151,6 +1154,12 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // DirectLighting over mirror / glass recurses through SpecularReflect / SpecularTransmit (integrator.dart:187-290):
   // an explicit per-slot stack and one round of the stage loop per vertex of the ray tree (k_shade_spec)
   const bool dlSpec = rd->integrator == DR_INTEGRATOR_DIRECT_ALL && sc->hasSpecular;
+  // k_env (dr_kernels.hip): the environment-map work of a plain-triangle scene's path stages runs in its own kernel
+  const bool envStage = rd->integrator == DR_INTEGRATOR_PATH && sc->d.hasEnv && !(sc->d.nquads || sc->d.hasSpec || sc->d.srec);
+  // state layout of this render (see LayoutOps): the four-slot sub-tiles for the renders whose lists thin out early
+  static const char* layoutEnv = getenv("DARTRAY_STATE_LAYOUT");  // 64 | 4: A/B runs and tests
+  const bool sparseLayout = layoutEnv ? atoi(layoutEnv) == 4 : envStage;
+  const LayoutOps& L = sparseLayout ? kLayoutSp4 : kLayout64;
 
   RenderParams rp;
   memset(&rp, 0, sizeof(rp));
@@ -1260,14 +1269,14 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // permuted indices in the compact form, 4 B per float otherwise; + the RNG tail in host-buffer mode).  The
     // default batch (2^28) takes 56 GB of a 288 GB MI355X; on a device with less free
     // memory the batch shrinks instead of failing (results do not depend on the batch size).
-    const uint64_t perSlot = (uint64_t)DR_STATE_WORDS * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 +
+    const uint64_t perSlot = (uint64_t)L.stateWords * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 +
                              (hostBuf && needTail > 0 ? (uint64_t)rd->max_tail * 8 : 0) + (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0) +
                              (sf.compact ? (uint64_t)(8 * sf.nBlocks + spp - 1) / spp : 0) +
                              (dlSpec ? (uint64_t)std::max(1, rd->max_depth) * sizeof(SpecFrame) + 12 : 0);
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)DR_STATE_WORDS * 4 + sc->ws.svWords / 16 + 20) +
-                            (uint64_t)sc->ws2.cap * ((uint64_t)DR_STATE_WORDS * 4 + sc->ws2.svWords / 16 + 20);
+      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)sc->ws.stateWords * 4 + sc->ws.svWords / 16 + 20) +
+                            (uint64_t)sc->ws2.cap * ((uint64_t)sc->ws2.stateWords * 4 + sc->ws2.svWords / 16 + 20);
       const uint64_t budget = (uint64_t)(0.9 * (double)freeB) + have;
       const uint64_t pipes = nPipesEnv >= 2 && !hostBuf ? 2 : 1;
       // (+ 1/4: the slack that lets a slightly larger window still go as one batch, below)
@@ -1281,7 +1290,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (nBatches > 1 && npixTotal <= pixCapBatch + pixCapBatch / 4 && !(nPipesEnv >= 2 && !hostBuf)) nBatches = 1;
   const uint32_t pixPerBatch = (uint32_t)((npixTotal + nBatches - 1) / nBatches);
   const uint32_t cap = pixPerBatch * (uint32_t)spp;
-  int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0);
+  int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0, L.stateWords);
   if (rc) return rc;
   if (dlSpec) {
     HIP_TRY(sc->ws.specFrames.alloc((size_t)sc->ws.cap * std::max(1, rd->max_depth) * DR_SPEC_FRAME_WORDS));
@@ -1297,7 +1306,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
   const bool twoPipes = nPipesEnv >= 2 && !hostBuf && !dlSpec && npixTotal > pixPerBatch;
   if (twoPipes) {
-    rc = allocWorkspace(sc, sc->ws2, cap, sf, pixPerBatch, rd->max_tail, false);
+    rc = allocWorkspace(sc, sc->ws2, cap, sf, pixPerBatch, rd->max_tail, false, L.stateWords);
     if (rc) return rc;
     rc = ensureSpill(sc, sc->ws2, tgrid);
     if (rc) return rc;
@@ -1354,13 +1363,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const int sgrid = g_numCU;  // the shade launchers size their grid per CU (DR_SHADE_GRID), grid-stride over the active list
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
   if (nStages > 248 || 8 * DR_WORK_STRIDE * (1 + 2 * nStages) > N_COUNTERS_TRACE - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
-  // k_env (dr_kernels.hip): the environment-map work of a plain-triangle scene's path stages runs in its own kernel
-  const bool envStage = rd->integrator == DR_INTEGRATOR_PATH && sc->d.hasEnv && !(sc->d.nquads || sc->d.hasSpec || sc->d.srec);
   if (envStage && sc->d.env.h > DR_ENV_MARG_MAX_ROWS) return fail(DR_ERR_UNSUPPORTED, "radiance map taller than 8192 rows");
-  // state layout of this render (see LayoutOps): the four-slot sub-tiles for the renders whose lists thin out early
-  static const char* layoutEnv = getenv("DARTRAY_STATE_LAYOUT");  // 64 | 4: A/B runs and tests
-  const bool sparseLayout = layoutEnv ? atoi(layoutEnv) == 4 : envStage;
-  const LayoutOps& L = sparseLayout ? kLayoutSp4 : kLayout64;
   if (envStage) {
     HIP_TRY(sc->ws.envQ.alloc(sc->ws.cap));
     if (twoPipes) HIP_TRY(sc->ws2.envQ.alloc(sc->ws2.cap));
@@ -1373,7 +1376,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   };
   auto runBatch = [&](Workspace& w, const int2* pixDev, size_t p0, uint32_t np, PilotTimes* pilot) -> int {
     const uint32_t nslots = np * (uint32_t)spp;
-    BatchState st = makeState(w, sf, pixDev, nslots, hostBuf && needTail > 0);
+    BatchState st = makeState(w, sf, pixDev, nslots, hostBuf && needTail > 0, L.stateWords);
     HIP_TRY(hipMemsetAsync(w.counters.p, 0, N_COUNTERS * sizeof(uint32_t), s));
     auto timed = [&](int kind, hipEvent_t e0) {
       hipEvent_t e1 = sc->getEvent();

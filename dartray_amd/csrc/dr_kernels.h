@@ -89,6 +89,22 @@ static_assert(DR_SUB >= 1 && DR_SUB <= 64 && (DR_SUB & (DR_SUB - 1)) == 0 && (DR
 // 3-vectors, the i32 fields and the sample region.  Every field address is ONE base pointer + a constant: the shade
 // kernels touch ~25 fields, and 25 separate pointers (50 SGPRs) pushed them into SGPR spilling -- two v_readlane
 // per memory access.
+#if defined(DR_GROUPED) && DR_GROUPED
+// The line-grouped order of the four-slot layout (namespace sp4: -DDR_SUB=4 -DDR_STATE_WORDS_K=48 -DDR_GROUPED=1).  A field's run
+// is DR_SUB * 4 = 16 bytes, so eight words are one 128-byte line of the sub-tile, and the words one kernel touches together share a
+// line: the ray generator writes line 0 whole, a traversal reads line 0 (and line 2 for a shadow ray), the film kernel reads line 1
+// whole.  48 words per slot (768-byte sub-tiles: six whole lines; 7 words of padding).
+enum {
+  F_RTMIN = 0, F_RO = 2, F_RD = 5,                          // line 0: the ray (written by k_raygen / the shade kernels, read by the traversals)
+  F_L = 8, F_LD1 = 11, F_FLAGS = 14, F_SHOCC = 15,          // line 1: what k_film reads
+  F_HT = 16, F_SHTMAX = 18, F_SHD = 20, F_HPRIM = 23,       // line 2: hit record + shadow ray
+  F_BETA = 24, F_BETANEE = 27, F_MISLIGHT = 30, F_MISPRIM = 31,  // line 3
+  F_MISD = 32, F_LD2 = 35,                                  // line 4 (+ 2 words of padding)
+  F_RO0 = 40,                                               // line 5 (DirectLighting with quadrics / shading records only)
+  F_SAMPLES = DR_STATE_WORDS_K
+};
+static_assert(DR_SUB == 4 && DR_STATE_WORDS_K == 48, "the line-grouped field order is the four-slot layout's");
+#else
 enum {
   F_RTMIN = 0, F_HT = 2, F_SHTMAX = 4,
   F_RO = 6, F_RD = 9, F_BETA = 12, F_L = 15, F_BETANEE = 18, F_SHD = 21, F_LD1 = 24, F_MISD = 27, F_LD2 = 30,
@@ -96,6 +112,7 @@ enum {
   F_RO0 = 38,     // (DirectLighting with quadrics / shading records only: outside the window below)
   F_SAMPLES = DR_STATE_WORDS_K  // == DR_STATE_WORDS: where a tile's sample region starts, in 64-word runs
 };
+#endif
 // The 32 runs F_RO .. F_FLAGS are exactly 8 KiB: the whole signed 13-bit immediate-offset window of a global_load /
 // global_store around ONE per-lane base address (SlotRef below), so the shade kernels reach every hot field of a slot
 // without any per-access address arithmetic.
