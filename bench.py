@@ -141,7 +141,8 @@ BOUND_OBSERVED = {
     "C3": {"trace": "as C2 (same scene)", "shade": "as C2"},
     "C4": {"trace": "HBM / Infinity Cache (tree beyond every cache: 640 MB nodes + 480 MB triangles), dependent fetches", "shade": "as C2"},
     "C5": {"trace": "dependent-fetch latency, upper tree cache resident",
-           "shade": "sparse state access: a surviving slot of a thinned-out stage list touches one 128-B line per field (2.7x the algorithmic bytes)"},
+           "shade": "sparse state access: the stage lists thin out at the first bounce (four-slot line-grouped state layout picked for this scene; "
+                    "~2x the algorithmic bytes at the memory side, half the list entries carry no vertex)"},
 }
 
 
