@@ -92,12 +92,37 @@ def shade_alg_bytes(st):
             + st["shade_shadow"] * 36.0)  # shD, shTmax, Ld1 + queue entry
 
 
-def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="C2"):
+def gen_blocks(renderer, scene):
+    """LD blocks of a pixel sample the device sampler generates for a path render (dr_api.hip: rp.genMask): the image
+    sample, the lens sample of a thin-lens camera and, per SAMPLE_DEPTH level b <= min(2, maxDepth), the light number, the
+    light component, the light position, the BSDF and path directions (+ the two uComponent slots where a material has
+    more than one lobe).  Never generated: the time sample, the volume integrator's slots."""
+    d = scene._device()
+    general = bool(getattr(d, "general", False))
+    n = 1 + (1 if getattr(renderer.camera, "lensRadius", 0.0) > 0.0 else 0)
+    for b in range(3):
+        if b <= renderer.surfaceIntegrator.maxDepth:
+            n += 2 + (2 if general else 0) + 3
+    return n
+
+
+def gen_alg_bytes_per_sample(nblocks, spp):
+    """What the sampler and the ray generator must move per camera sample (compact sample form): one
+    permuted-index entry per generated LD block (1 byte up to 256 spp, 2 above) + the block's two scramble words once per
+    pixel, written by k_gen_samples_*; k_raygen reads the image (+ lens) entries back and writes origin, direction and
+    minDistance (32 B)."""
+    idx = 1 if spp <= 256 else 2
+    return nblocks * idx + 8.0 * nblocks / spp + 2 * idx + 32.0
+
+
+def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="C2", gen_bytes_per_sample=None):
     alg = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
     launches = max(1, st["closest_launches"])
     achieved = alg / max(st["closest_ms"] * 1e-3, 1e-12) / 1e9
     all_alg = alg + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
-    roof = {"bound": "hbm", "kernel": "%s (closest-hit BVH traversal)" % closest_kernel,
+    bo = BOUND_OBSERVED.get(tag, {})
+    roof = {"bound": bo.get("trace_bound", "hbm"), "bound_priced_against": "hbm",
+            "kernel": "%s (closest-hit BVH traversal)" % closest_kernel,
             "achieved": round(achieved, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_GBPS, 4),
             "traffic": None,  # HBM-side bytes come from separate rocprofv3 --pmc passes: see "traffic_profiled" / "physical_*"
             "achieved_is": "algorithmic bytes per second (cache hits included), not HBM traffic",
@@ -106,22 +131,36 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
             "alg_bytes_per_launch": round(alg / launches, 1),
             "avg_launch_ms": round(st["closest_ms"] / launches, 4), "launches": int(st["closest_launches"]),
             "avg_launch_ms_note": ("HIP events around each k_trace<0> launch on its own stream; the stage's any-hit launch runs beside it on a second "
-                                   "stream (DARTRAY_OVERLAP_ANY=0 serialises them: profiles/r03_*_kernel_stats_serial.csv, within 1 % of this figure)"
+                                   "stream (DARTRAY_OVERLAP_ANY=0 serialises them: profiles/r0*_kernel_stats_serial.csv, within 1 % of this figure)"
                                    if os.environ.get("DARTRAY_OVERLAP_ANY", "1") != "0" else "one kernel at a time"),
             "rank0_job_alg_GBps": round(all_alg / dt_total / 1e9, 2),
             "rank0_trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt_total, 4)}
     sb = shade_alg_bytes(st)
     sa = sb / max(st["shade_ms"] * 1e-3, 1e-12) / 1e9
-    shade = {"bound": "hbm", "kernel": "k_shade_path (vertex step of PathIntegrator.Li; + k_env on scenes with an environment map)",
+    shade = {"bound": bo.get("shade_bound", "hbm"), "bound_priced_against": "hbm",
+             "kernel": "k_shade_path (vertex step of PathIntegrator.Li; + k_env on scenes with an environment map)",
              "achieved": round(sa, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(sa / PEAK_GBPS, 4), "traffic": None,
              "achieved_is": "algorithmic bytes per second, not HBM traffic",
              "alg_over_measured_copy": round(sa / copy_gbps, 4) if copy_gbps else None,
              "alg_bytes_per_item": round(sb / max(1, st["shade_items"]), 1),
              "items": int(st["shade_items"]), "vertices": int(st["shade_vertices"])}
+    gen = None
+    if gen_bytes_per_sample and st.get("gen_ms"):
+        gb = gen_bytes_per_sample * st["camera_samples"]
+        ga = gb / max(st["gen_ms"] * 1e-3, 1e-12) / 1e9
+        gen = {"bound": "lds-latency", "bound_priced_against": "hbm",
+               "kernel": "k_gen_samples_* + k_raygen (LDPixelSample: per (pixel, LD block) a seeded generator, burn-in draws and a Fisher-Yates shuffle in LDS; then the camera rays)",
+               "achieved": round(ga, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(ga / PEAK_GBPS, 4), "traffic": None,
+               "achieved_is": "algorithmic bytes per second: permuted-index bytes + scrambles written, camera rays written",
+               "alg_bytes_per_sample": round(gen_bytes_per_sample, 2),
+               "bound_observed": "the serial chain of a pixel's shuffle (generator step -> partner -> LDS swap, spp steps per block) at the "
+                                 "occupancy its LDS table allows (one 64-pixel group per CU at 1024 spp); bytes are not the limit"}
     # the physical picture, from the committed PMC passes of the same command (never presented as this run's measurement)
     prof = profiled_kernels(tag)
     if prof:
-        for obj, prefix in ((roof, closest_kernel), (shade, "k_shade_path")):
+        for obj, prefix in ((roof, closest_kernel), (shade, "k_shade_path"), (gen, "k_gen_samples")):
+            if obj is None:
+                continue
             k = next((v for n, v in prof["kernels"].items() if n.split("::")[-1].startswith(prefix)), None)
             if not k or not k.get("hbm_side_GBps"):
                 continue
@@ -129,38 +168,51 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
             obj["physical_frac_of_spec"] = round(k["hbm_side_GBps"] / PEAK_GBPS, 4)
             obj["physical_frac_of_measured"] = round(k["hbm_side_GBps"] / copy_gbps, 4) if copy_gbps else None
             obj["physical_source"] = prof["source"] + " (rocprofv3 --pmc: TCC_EA0_RDREQ 32/64/128 B + WRITE_SIZE per launch / kernel-trace launch time; not this run)"
-        roof["bound_observed"] = BOUND_OBSERVED.get(tag, {}).get("trace")
-        shade["bound_observed"] = BOUND_OBSERVED.get(tag, {}).get("shade")
-    return roof, shade, all_alg
+        # memory-side bytes over algorithmic bytes, per kernel, both from the profiled run (1 = every byte fetched once;
+        # below: caches absorb re-reads; above: partial lines / re-reads -- the first thing to fix)
+        if prof.get("trace_ratio"):
+            roof["traffic_over_algorithmic"] = round(prof["trace_ratio"], 3)
+        if prof.get("shade_ratio"):
+            shade["traffic_over_algorithmic"] = round(prof["shade_ratio"], 3)
+        roof["bound_observed"] = bo.get("trace")
+        shade["bound_observed"] = bo.get("shade")
+    return roof, shade, gen, all_alg
 
 
-# What the PMC passes say bounds each kernel (profiles/r0*_traffic.json)
+# What the PMC passes say bounds each kernel (profiles/r0*_traffic.json).  "bound" on the line is
+# the observed one; the fraction is priced against the HBM roofline either way ("bound_priced_against").
 BOUND_OBSERVED = {
-    "C2": {"trace": "dependent-fetch latency, scene cache resident (L2 / Infinity Cache serve ~half the algorithmic bytes); t = 96 + 839 / workgroups-per-CU ms",
-           "shade": "f64 VALU issue (~0.7 busy) and state-access latency at 3 waves per SIMD; 1.5x the algorithmic bytes at the memory side"},
-    "C3": {"trace": "as C2 (same scene)", "shade": "as C2"},
-    "C4": {"trace": "HBM / Infinity Cache (tree beyond every cache: 640 MB nodes + 480 MB triangles), dependent fetches", "shade": "as C2"},
-    "C5": {"trace": "dependent-fetch latency, upper tree cache resident",
-           "shade": "sparse state access: the stage lists thin out at the first bounce (four-slot line-grouped state layout picked for this scene; "
-                    "~2x the algorithmic bytes at the memory side, half the list entries carry no vertex)"},
+    "C2": {"trace_bound": "latency", "shade_bound": "valu-f64+latency",
+           "trace": "dependent-fetch latency, scene cache resident (L2 / Infinity Cache serve ~half the algorithmic bytes); t = 96 + 839 / workgroups-per-CU ms",
+           "shade": "f64 VALU issue (~0.7 busy) and state-access latency at 3 waves per SIMD; 1.6x the algorithmic bytes at the memory side"},
+    "C3": {"trace_bound": "latency", "shade_bound": "valu-f64+latency", "trace": "as C2 (same scene)", "shade": "as C2"},
+    "C4": {"trace_bound": "hbm", "shade_bound": "valu-f64+latency",
+           "trace": "HBM / Infinity Cache (tree beyond every cache: 640 MB nodes + 480 MB triangles): 0.7 of the measured copy rate at the memory "
+                    "side, the rest is the length of a ray's chain of dependent fetches", "shade": "as C2"},
+    "C5": {"trace_bound": "latency", "shade_bound": "latency (sparse state access)",
+           "trace": "dependent-fetch latency, upper tree cache resident",
+           "shade": "sparse state access: the stage lists thin out at the first bounce (four-slot line-grouped state layout picked for this render); "
+                    "3.2x the algorithmic bytes at the memory side (k_shade_path + k_env), half the list entries carry no vertex"},
 }
 
 
 def profiled_kernels(tag):
     """Per-kernel entries of the newest committed traffic file of this config."""
-    for name in ("r03_%s_traffic.json" % tag.lower(), "r02_%s_traffic.json" % tag.lower()):
+    for name in ("r04_%s_traffic.json" % tag.lower(), "r03_%s_traffic.json" % tag.lower(), "r02_%s_traffic.json" % tag.lower()):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             d = json.load(open(path))
             if "kernels" in d:
-                return {"kernels": d["kernels"], "source": "profiles/" + name}
+                return {"kernels": d["kernels"], "source": "profiles/" + name, "trace_ratio": d.get("traffic_over_algorithmic"),
+                        "shade_ratio": (d.get("shade") or {}).get("traffic_over_algorithmic")}
     return None
 
 
 def profiled_traffic(tag):
     """HBM-side bytes per launch from committed rocprofv3 --pmc passes of the same command, labelled with the file
     they come from (never presented as this run's measurement)."""
-    for name in ("r03_%s_traffic.json" % tag.lower(), "r02_%s_traffic.json" % tag.lower(), "r01_k_traffic.json" if tag == "C2" else None):
+    for name in ("r04_%s_traffic.json" % tag.lower(), "r03_%s_traffic.json" % tag.lower(), "r02_%s_traffic.json" % tag.lower(),
+                 "r01_k_traffic.json" if tag == "C2" else None):
         if not name:
             continue
         path = os.path.join(ROOT, "profiles", name)
@@ -229,7 +281,7 @@ def main():
                 r = Run(c, {"C4": 1024, "C5": 2048}[c], {"C4": 64, "C5": 512}[c], 0, 1, mode, args)
                 e = r.headline(2, 1)
                 extra.append({k: e[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
-                                                "roofline_shade", "kernel_ms_per_step", "per_sample", "first_render_ms",
+                                                "roofline_shade", "roofline_gen", "kernel_ms_per_step", "per_sample", "first_render_ms",
                                                 "pilot_ms", "traffic_profiled") if k in e})
                 del r
                 torch.cuda.empty_cache()
@@ -317,7 +369,8 @@ class Run:
         samples_per_step = self.H * self.W * self.spp * (world if (self.mode == "samples" and world > 1) else 1)
         value = samples_per_step * steps / dt / 1e6
         picked = self.dev.trace_kernels()  # (closest, any): 2 = k_trace, 3 = k_trace3 (the pilot's choice for this scene)
-        roof, shade, all_alg = roofline_objects(st, dt, copy.value, "k_trace3<0>" if picked[0] == 3 else "k_trace<0>", self.cfg)
+        gbs = gen_alg_bytes_per_sample(gen_blocks(self.renderer, self.scene), self.spp)
+        roof, shade, gen, all_alg = roofline_objects(st, dt, copy.value, "k_trace3<0>" if picked[0] == 3 else "k_trace<0>", self.cfg, gbs)
         agg = self.scene.aggregate
         if world == 1:
             par = "1 GPU"
@@ -347,6 +400,7 @@ class Run:
                                        "tests but is not a throughput mode (one serial stream; 148 B + RNG tail per sample over PCIe)"},
             "roofline": roof,
             "roofline_shade": shade,
+            "roofline_gen": gen,
             "kernel_ms_per_step": dict({k: round(st[k] / steps, 2) for k in ("closest_ms", "any_ms", "shade_ms", "gen_ms", "film_ms", "total_ms")},
                                        note="a stage's any-hit launch runs beside its closest-hit launch (second stream): any_ms is its time "
                                             "after the closest-hit launch ended" if os.environ.get("DARTRAY_OVERLAP_ANY", "1") != "0" else "one kernel at a time"),

@@ -15,6 +15,7 @@ compute itself happens in libdartray_hip.so.
     out     = SamplerRenderer(sampler, camera, PathIntegrator(5), EmissionIntegrator()).render(scene)
 """
 import ctypes as C
+import collections
 import math
 import os
 
@@ -309,7 +310,7 @@ NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<u4")
 # BVHAccel (lib/accelerators/bvh_accel.dart) -- the Aggregate of the scene
 # ---------------------------------------------------------------------------
 def build_bvh_arrays(verts, refined, quadric_bounds, nquadrics, max_prims, builder=None):
-    """BVHAccel's constructor (bvh_accel.dart:41-91,228-437) through the C ABI: (nodes, order, nnodes, depth).
+    """BVHAccel's constructor (bvh_accel.dart:41-91,228-437) through the C ABI: (nodes, order, nnodes, depth, builder that ran).
     builder: "device" = dr_bvh_build_device (HIP; needs an initialised GPU), "host" = dr_bvh_build_mixed (C++ threads);
     None = the environment's DARTRAY_BVH_BUILDER, else the device builder whenever a GPU has been selected.  Both write
     the same bytes (tests/test_gpu_bvh_device.py)."""
@@ -326,7 +327,7 @@ def build_bvh_arrays(verts, refined, quadric_bounds, nquadrics, max_prims, build
     fn = lib.dr_bvh_build_device if builder == "device" else lib.dr_bvh_build_mixed
     _abi.check(fn(verts.ctypes.data, len(verts), refined.ctypes.data, n, quadric_bounds.ctypes.data, nquadrics, max_prims,
                   nodes.ctypes.data, C.byref(nn), order.ctypes.data, C.byref(depth)))
-    return nodes, order, int(nn.value), int(depth.value)
+    return nodes, order, int(nn.value), int(depth.value), builder
 
 
 class BVHAccel:
@@ -402,9 +403,8 @@ class BVHAccel:
             qb[i, :3], qb[i, 3:] = lo, hi
         import time as _time
         _t0 = _time.perf_counter()
-        nodes, order, nn, depth = build_bvh_arrays(self.verts, refined, qb, len(self.quadrics), self.maxPrimsInNode, builder)
+        nodes, order, nn, depth, self.builder = build_bvh_arrays(self.verts, refined, qb, len(self.quadrics), self.maxPrimsInNode, builder)
         self.build_ms = (_time.perf_counter() - _t0) * 1e3  # the constructor proper (host pointers in and out)
-        self.builder = builder or os.environ.get("DARTRAY_BVH_BUILDER") or ("device" if _abi._initialised is not None else "host")
         order = order[:n]
         self.nodes = nodes[:nn] if n else None  # bvh_accel.dart:50-53
         self.depth = int(depth)
@@ -446,11 +446,19 @@ class BVHAccel:
         lists differ (e.g. with and without an InfiniteAreaLight): the cache is keyed on the list's identity."""
         want = self._lights if lights is None else lights
         key = tuple(id(l) for l in want)
-        cache = self.__dict__.setdefault("_scenes", {})
-        if key not in cache:  # every light list keeps its own upload: alternating callers do not evict each other
+        cache = self.__dict__.setdefault("_scenes", collections.OrderedDict())
+        if key in cache:
+            cache.move_to_end(key)
+        else:
+            # a few light lists keep their own upload (alternating callers do not evict each other), but not without
+            # bound: every entry holds the whole geometry in HBM (C4: 1.1 GB), so the least recently used one goes first
+            while len(cache) >= self._SCENE_CACHE:
+                cache.popitem(last=False)[1].destroy()
             cache[key] = _DeviceScene(self, want)
         self._scene, self._scene_key = cache[key], key
         return cache[key]
+
+    _SCENE_CACHE = 3
 
     def intersect(self, ray):
         """Aggregate.intersect (bvh_accel.dart:101-165) on a batch: returns a
@@ -475,8 +483,10 @@ class _DeviceScene:
     def __init__(self, accel, lights):
         _abi.init(_abi._initialised if _abi._initialised is not None else 0)
         lib = _abi.lib()
-        self.accel = accel
-        self.lights = list(lights)
+        self.lights = list(lights)  # (no reference back to the aggregate: the cache there would make it a cycle)
+        # the general shading kernels (not the plain-triangle matte ones) run this scene: dr_api.hip's `general`
+        self.general = bool(accel.quadrics) or accel.has_shading or any(isinstance(L, (PointLight, DistantLight)) for L in self.lights) or \
+            any(getattr(m, "kind", _abi.DR_MATERIAL_MATTE) != _abi.DR_MATERIAL_MATTE or float(getattr(m, "sigma", 0.0)) != 0.0 for m in accel.materials)
         mats = (_abi.DrMaterial * max(len(accel.materials), 1))()
         for i, m in enumerate(accel.materials):
             mats[i].type = getattr(m, "kind", _abi.DR_MATERIAL_MATTE)
@@ -603,11 +613,15 @@ class _DeviceScene:
         _abi.check(lib.dr_scene_create(C.byref(d), C.byref(h)))
         self.handle = h
 
+    def destroy(self):
+        """dr_scene_destroy now (an evicted cache entry must not wait for a garbage collection)."""
+        if getattr(self, "handle", None):
+            _abi.lib().dr_scene_destroy(self.handle)
+            self.handle = None
+
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
-                _abi.lib().dr_scene_destroy(self.handle)
-                self.handle = None
+            self.destroy()
         except Exception:
             pass
 

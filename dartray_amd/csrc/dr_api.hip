@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -74,13 +76,38 @@ struct Workspace {
 };
 
 #define DR_STATE_WORDS F_SAMPLES  // 41 4-byte words of fixed path state per slot: 3 f64 + 10 3-vectors + 5 i32
-#define DR_ENV_MARG_MAX_ROWS 8192  // k_env keeps the map's marginal distribution in LDS (dr_kernels.hip)
 #define N_COUNTERS_TRACE (1024 + 8 * DR_WORK_STRIDE * 400)
 #define N_COUNTERS (N_COUNTERS_TRACE + 64 * 256)  // ... then the counts of k_env's lists, one cache line per stage  // [0,1024): stage queue counts; then 8 per-XCD work counters per trace launch, DR_WORK_STRIDE words apart
 
 }  // namespace
 
 int dr_fail(int code, const std::string& msg) { return fail(code, msg); }  // for dr_comm.cpp
+
+// ---- tuning / diagnostic switches: dr_set_option, else the environment ----
+namespace {
+std::mutex g_optMutex;
+std::map<std::string, std::string> g_options;  // name -> value; an empty value = "unset for this process" (hides the environment's)
+const char* const kOptionNames[] = {
+    "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
+    "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
+    "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_TREELET", "DARTRAY_TREELET_TOP",
+    "DARTRAY_TREELET_ROUNDS", "DARTRAY_WORKSPACE", "DARTRAY_LAYOUT_PILOT"};
+}  // namespace
+
+const char* dr_option(const char* name) {
+  thread_local std::string held;
+  {
+    std::lock_guard<std::mutex> lock(g_optMutex);
+    auto it = g_options.find(name);
+    if (it != g_options.end()) {
+      if (it->second.empty()) return nullptr;
+      held = it->second;
+      return held.c_str();
+    }
+  }
+  return getenv(name);
+}
 
 struct DrScene {
   DScene d;
@@ -385,19 +412,20 @@ struct LayoutOps {
   decltype(&launch_shade_direct) shade_direct;
   decltype(&launch_shade_spec) shade_spec;
   decltype(&launch_film) film;
-  int stateWords;  // 4-byte words of fixed path state per slot in this layout (a tile is 64 of them + the sample region)
+  int stateWords;  // 4-byte words of fixed path state per slot in this layout (a tile is 64 of them + the sample region):
+                   // what the kernels' own translation unit was compiled with (layout_state_words), not a constant repeated here
 };
 static const LayoutOps kLayout64 = {&launch_trace, &launch_gen_samples, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
-                                    &launch_env, &launch_shade_direct, &launch_shade_spec, &launch_film, DR_STATE_WORDS};
+                                    &launch_env, &launch_shade_direct, &launch_shade_spec, &launch_film, layout_state_words()};
 static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_gen_samples, &sp4::launch_transpose_samples, &sp4::launch_raygen,
                                      &sp4::launch_shade_path, &sp4::launch_env, &sp4::launch_shade_direct, &sp4::launch_shade_spec,
-                                     &sp4::launch_film, 48};
+                                     &sp4::launch_film, sp4::layout_state_words()};
 
 int traceGridFor(int wgPerCU) {
   // workgroups of the persistent traversal kernels: as many as are resident at once.  v2 (k_trace): 16 KiB of stack +
   // 6 KiB of cold ray state in LDS and 72 VGPRs => 7 workgroups = 28 waves per CU; the other variants (v3: 32 KiB of
   // LDS, the quadric and v1 kernels: more registers) 6, the sixth queueing behind five where only five fit.
-  const char* e = getenv("DARTRAY_TRACE_WG_PER_CU");
+  const char* e = dr_option("DARTRAY_TRACE_WG_PER_CU");
   if (e) wgPerCU = atoi(e);
   return g_numCU * std::max(1, std::min(wgPerCU, 8));
 }
@@ -405,6 +433,20 @@ int traceGridFor(int wgPerCU) {
 extern "C" {
 
 const char* dr_last_error(void) { return g_err.c_str(); }
+
+int dr_set_option(const char* name, const char* value) {
+  if (!name || !*name) return fail(DR_ERR_INVALID, "dr_set_option: null name");
+  std::string n(name);
+  for (char& c : n) c = (char)toupper((unsigned char)c);
+  if (n.rfind("DARTRAY_", 0) != 0) n = "DARTRAY_" + n;
+  bool known = false;
+  for (const char* k : kOptionNames) known = known || n == k;
+  if (!known) return fail(DR_ERR_INVALID, "dr_set_option: unknown option " + n);
+  std::lock_guard<std::mutex> lock(g_optMutex);
+  if (value) g_options[n] = value;  // "" hides the environment's value
+  else g_options.erase(n);          // null: back to the environment's value
+  return DR_OK;
+}
 const char* dr_version(void) { return "dartray_amd 0.1 (gfx950)"; }
 
 int dr_init(int device) {
@@ -416,6 +458,11 @@ int dr_init(int device) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   g_numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  // the two sets of state-touching kernels must be the two layouts this file hands out (dr_kernels.hip / dr_trace.hip are
+  // compiled twice: as they are, and with -DDR_SUB=4 -DDR_NS=sp4 -DDR_STATE_WORDS_K=48 -DDR_GROUPED=1)
+  if (layout_sub() != 64 || layout_state_words() != DR_STATE_WORDS || sp4::layout_sub() != 4 || sp4::layout_state_words() < DR_STATE_WORDS ||
+      kLayout64.stateWords != layout_state_words() || kLayoutSp4.stateWords != sp4::layout_state_words())
+    return fail(DR_ERR_UNSUPPORTED, "libdartray_hip was linked from kernel objects of unexpected state layouts");
   g_device = device;
   return DR_OK;
 }
@@ -550,7 +597,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     //   sib      the two child records of a node side by side in ONE 128-byte line (holes where a child is a leaf)
     //   veb:T:S  treelets: the top T levels breadth-first, below them sub-trees of height S breadth-first each,
     //            treelet after treelet in depth-first order (van Emde Boas style; veb:1:1 is the default order)
-    if (const char* po = getenv("DARTRAY_PAIR_ORDER")) {
+    if (const char* po = dr_option("DARTRAY_PAIR_ORDER")) {
       const std::string mode(po);
       std::vector<uint32_t> slotOf(desc->nnodes, 0);
       uint32_t slots = 0;
@@ -1157,7 +1204,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // k_env (dr_kernels.hip): the environment-map work of a plain-triangle scene's path stages runs in its own kernel
   const bool envStage = rd->integrator == DR_INTEGRATOR_PATH && sc->d.hasEnv && !(sc->d.nquads || sc->d.hasSpec || sc->d.srec);
   // state layout of this render (see LayoutOps): the four-slot sub-tiles for the renders whose lists thin out early
-  static const char* layoutEnv = getenv("DARTRAY_STATE_LAYOUT");  // 64 | 4: A/B runs and tests
+  const char* layoutEnv = dr_option("DARTRAY_STATE_LAYOUT");  // 64 | 4: A/B runs and tests
   const bool sparseLayout = layoutEnv ? atoi(layoutEnv) == 4 : envStage;
   const LayoutOps& L = sparseLayout ? kLayoutSp4 : kLayout64;
 
@@ -1188,9 +1235,9 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.dlSpecular = dlSpec ? 1 : 0;
   rp.deferredNee = rd->integrator == DR_INTEGRATOR_PATH ? 1 : 0;
   rp.genMask = 0ull;
-  static const bool genSlow = getenv("DARTRAY_GEN_SLOW_DRAWS") != nullptr;
+  const bool genSlow = dr_option("DARTRAY_GEN_SLOW_DRAWS") != nullptr;
   rp.genSlowDraws = genSlow ? 1 : 0;
-  static const bool genAll = getenv("DARTRAY_GEN_ALL_BLOCKS") != nullptr;  // A/B and tests: generate every block
+  const bool genAll = dr_option("DARTRAY_GEN_ALL_BLOCKS") != nullptr;  // A/B and tests: generate every block
   if (rd->integrator == DR_INTEGRATOR_PATH && !rp.blocks && !genAll) {
     // What the path kernels read of a pixel sample (dr_kernels.hip: k_raygen, load_shade_in, k_film): the image sample,
     // the lens sample of a thin-lens camera, and per SAMPLE_DEPTH level b <= maxDepth the light number, the light
@@ -1255,14 +1302,14 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // Sample vectors: the on-device LD sampler stores permuted indices + scrambles (compact form) whenever every LD block
   // has one entry per pixel sample; host buffers and multi-entry blocks (DirectLighting with nsamples > 1) use floats.
   SampleForm sf;
-  sf.compact = !hostBuf && rp.blocks == nullptr && !getenv("DARTRAY_FLOAT_SAMPLES");
+  sf.compact = !hostBuf && rp.blocks == nullptr && !dr_option("DARTRAY_FLOAT_SAMPLES");
   if (!sf.compact && !hostBuf && spp > 1024)
     return fail(DR_ERR_UNSUPPORTED, "spp > 1024 with LD blocks of several entries per sample (DirectLighting with nsamples > 1): the float-form sampler's table exceeds the LDS");
   sf.nFloats = rp.nFloats;
   sf.nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
   sf.idxShift = spp > 256 ? 1 : 0;
-  static const int slotBits = getenv("DARTRAY_BATCH_BITS") ? std::min(28, std::max(16, atoi(getenv("DARTRAY_BATCH_BITS")))) : 28;
-  static const int nPipesEnv = getenv("DARTRAY_PIPELINES") ? atoi(getenv("DARTRAY_PIPELINES")) : 1;
+  const int slotBits = dr_option("DARTRAY_BATCH_BITS") ? std::min(28, std::max(16, atoi(dr_option("DARTRAY_BATCH_BITS")))) : 28;
+  const int nPipesEnv = dr_option("DARTRAY_PIPELINES") ? atoi(dr_option("DARTRAY_PIPELINES")) : 1;
   uint64_t maxSlots = 1ull << slotBits;  // camera samples in flight per batch
   {
     // path state per camera sample: 164 B of ray / hit / NEE state, 20 B of queues and the sample vector (24 B of
@@ -1301,7 +1348,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const int tgrid = traceGrid();
   rc = ensureSpill(sc, sc->ws, tgrid);
   if (rc) return rc;
-  static const bool overlapEnv = !(getenv("DARTRAY_OVERLAP_ANY") && atoi(getenv("DARTRAY_OVERLAP_ANY")) == 0);  // default: on
+  const bool overlapEnv = !(dr_option("DARTRAY_OVERLAP_ANY") && atoi(dr_option("DARTRAY_OVERLAP_ANY")) == 0);  // default: on
   const bool overlapAny = overlapEnv && !dlSpec && !(nPipesEnv >= 2);
   if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
   const bool twoPipes = nPipesEnv >= 2 && !hostBuf && !dlSpec && npixTotal > pixPerBatch;
@@ -1322,14 +1369,14 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // Nothing is traced twice: the calibration costs only what three small launches lose against one big one (round 1
   // ran up to six extra passes over pilot rays that never reached the film: 19 % of a C2 render, 64 % of C4's).
   // Both kernels are bit-exact, so results do not depend on the choice; dr_scene_set_trace_kernels / DARTRAY_TRACE_IMPL fix it.
-  static const bool pilotOff = getenv("DARTRAY_PILOT") && atoi(getenv("DARTRAY_PILOT")) == 0;
-  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || getenv("DARTRAY_PILOT_FORCE");
-  const bool calibrate = !sc->traceCalibrated && !pilotOff && !hostBuf && !dlSpec && !getenv("DARTRAY_TRACE_IMPL") && sc->d.pairs &&
+  const bool pilotOff = dr_option("DARTRAY_PILOT") && atoi(dr_option("DARTRAY_PILOT")) == 0;
+  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || dr_option("DARTRAY_PILOT_FORCE");
+  const bool calibrate = !sc->traceCalibrated && !pilotOff && !hostBuf && !dlSpec && !dr_option("DARTRAY_TRACE_IMPL") && sc->d.pairs &&
                          !sc->d.nquads && bigJob && npixTotal >= 3 * 64 * 4 && !(nPipesEnv >= 2);
   size_t calibPix = 0;  // pixels per calibration batch; the three batches are the first 3 * calibPix entries of `pixels`
   if (calibrate) {
     uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 22, (uint64_t)npixTotal * spp / 64));
-    if (getenv("DARTRAY_PILOT_BITS")) pilotSamples = 1ull << atoi(getenv("DARTRAY_PILOT_BITS"));
+    if (dr_option("DARTRAY_PILOT_BITS")) pilotSamples = 1ull << atoi(dr_option("DARTRAY_PILOT_BITS"));
     pilotSamples = std::min<uint64_t>(pilotSamples, (uint64_t)(pixPerBatch / 64 * 64) * spp);
     const size_t totalGroups = npixTotal / 64;
     const size_t groups = std::min<size_t>(std::max<size_t>(1, (size_t)(pilotSamples / spp) / 64), totalGroups / 4);
@@ -1363,7 +1410,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const int sgrid = g_numCU;  // the shade launchers size their grid per CU (DR_SHADE_GRID), grid-stride over the active list
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
   if (nStages > 248 || 8 * DR_WORK_STRIDE * (1 + 2 * nStages) > N_COUNTERS_TRACE - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
-  if (envStage && sc->d.env.h > DR_ENV_MARG_MAX_ROWS) return fail(DR_ERR_UNSUPPORTED, "radiance map taller than 8192 rows");
   if (envStage) {
     HIP_TRY(sc->ws.envQ.alloc(sc->ws.cap));
     if (twoPipes) HIP_TRY(sc->ws2.envQ.alloc(sc->ws2.cap));
@@ -1500,7 +1546,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       timed(4, evF);
       sc->stats.batches++;
     }
-    static const bool stageCounts = getenv("DARTRAY_STAGE_COUNTS") != nullptr;  // diagnostics: the batch's list lengths per stage
+    const bool stageCounts = dr_option("DARTRAY_STAGE_COUNTS") != nullptr;  // diagnostics: the batch's list lengths per stage
     if (stageCounts) {
       std::vector<uint32_t> hc(N_COUNTERS);
       HIP_TRY(hipStreamSynchronize(s));
@@ -1570,7 +1616,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     sc->traceEvents.push_back({evP0, evP1, 5});  // DrRenderStats.pilot_ms: the time of the three calibration batches
     firstPix = 3 * calibPix;
     batchIndex = 3;
-    if (getenv("DARTRAY_VERBOSE"))
+    if (dr_option("DARTRAY_VERBOSE"))
       fprintf(stderr, "dartray_hip: traversal pilot (3 x %zu samples, rendered into the film), ms per algorithmic GB: closest v2 %.4f / v3 %.4f -> v%u; "
               "any hit v2 %.4f / v3 %.4f -> v%u\n", calibPix * (size_t)spp, perByte[0][0], perByte[0][1], sc->d.traceKernel[0],
               perByte[1][0], perByte[1][1], sc->d.traceKernel[1]);

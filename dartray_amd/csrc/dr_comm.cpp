@@ -19,6 +19,8 @@
 
 #include "../../include/dartray_hip.h"
 
+const char* dr_option(const char* name);  // dr_api.hip: dr_set_option's value, else the environment's
+
 int dr_fail(int code, const std::string& msg);  // dr_api.hip: sets dr_last_error()
 
 namespace {
@@ -66,7 +68,7 @@ int loadRccl() {
   if (g_rccl.handle) return DR_OK;
   void* h = nullptr;
   std::string tried;
-  const char* env = getenv("DARTRAY_RCCL_LIB");
+  const char* env = dr_option("DARTRAY_RCCL_LIB");
   if (env && *env) {
     h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
     if (!h) return dr_fail(DR_ERR_UNSUPPORTED, std::string("DARTRAY_RCCL_LIB: ") + dlerror());
@@ -117,6 +119,8 @@ int ncclFail(const char* what, int rc) {
 }  // namespace
 
 extern "C" {
+
+int dr_comm_available(void) { return loadRccl(); }
 
 int dr_comm_unique_id(void* id_out, uint64_t cap) {
   if (!id_out || cap < DR_COMM_ID_BYTES) return dr_fail(DR_ERR_INVALID, "id buffer smaller than DR_COMM_ID_BYTES");

@@ -138,8 +138,10 @@ struct BatchState {
   // per-slot stack of suspended vertices, [level][cap] SpecFrame records, and its depth per slot; null otherwise
   float* specFrames;
   int32_t* specSp;
+  // (device-only: their bodies depend on the layout this translation unit was compiled for -- as host functions the two
+  // layouts' copies would be ONE weak symbol and the linker would keep either)
 #define DR_FIELD(T, name, F) \
-  __host__ __device__ T* name() const { return (T*)(tiles + ((F) >= F_SAMPLES ? 64 : DR_SUB) * (F)); }
+  DR_DEV T* name() const { return (T*)(tiles + ((F) >= F_SAMPLES ? 64 : DR_SUB) * (F)); }
   DR_FIELD(double, rtmin, F_RTMIN)      // Ray.minDistance (isect.rayEpsilon after the first vertex)
   DR_FIELD(double, ht, F_HT)            // closest-hit parameter of the camera / continuation ray
   DR_FIELD(double, shTmax, F_SHTMAX)
@@ -251,6 +253,10 @@ struct StageQueues {
 #define DR_V2_WG_PER_CU 7
 #endif
 int traceGridFor(int wgPerCU);  // dr_api.hip: workgroups of a persistent traversal launch
+// A tuning / diagnostic switch of the library (DARTRAY_*): the value given to dr_set_option, else the environment's; null
+// when unset.  Read at every use -- nothing is latched at first use -- so a long-lived foreign host can change a switch
+// between two renders without setenv.  The pointer is valid until the calling thread's next dr_option call.
+const char* dr_option(const char* name);
 #define DR_MAX_STACK 128      // LDS + spill entries per lane (the reference uses 64, bvh_accel.dart:120)
 #define DR_TRACE_BLOCK 256
 

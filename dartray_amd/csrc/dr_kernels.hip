@@ -1280,6 +1280,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
 //   slot | Q_ENV_MISS_BIT   an escaped camera ray: L = 0 + light.Le(ray) (sampler_renderer.dart:87-92).
 // Lane = list entry: every lane runs the map's CDF searches and trigonometry, where the inline form ran them with the
 // one lane in nLights that picked the map.  Runs between a stage's shade launch and its traversals.
+#ifndef DR_ENV_MARG_LDS_ROWS
+#define DR_ENV_MARG_LDS_ROWS 8192  // tallest map whose marginal distribution k_env copies into LDS (64 KiB + the staging lists)
+#endif
 #ifndef DR_ENV_BLOCK
 #define DR_ENV_BLOCK 256
 #endif
@@ -1287,23 +1290,39 @@ struct LdsFloats {
   lds_cu32* p;
   DR_DEV float operator[](int i) const { return __uint_as_float(p[i]); }
 };
-struct MatsOnly {  // k_env's view of the scene tables: the material table and the map's marginal distribution (LDS copies)
+struct GlobalFloats {
+  const float* p;
+  DR_DEV float operator[](int i) const { return p[i]; }
+};
+template <class MF>
+struct MatsOnlyT {  // k_env's view of the scene tables: the material table and the map's marginal distribution
   const float4* mats;
-  LdsFloats margFunc, margCdf;
+  MF margFunc, margCdf;
   DR_DEV float4 mat(uint32_t m, int k) const { return mats[4 * (size_t)m + k]; }
 };
+// MLDS: the marginal distribution in LDS (maps of up to DR_ENV_MARG_LDS_ROWS rows: the usual case); taller maps search
+// the global-memory arrays -- the same indices, a dozen cold round trips more per light sample.
+template <bool MLDS>
 __global__ void __launch_bounds__(DR_ENV_BLOCK) k_env(DScene sc, RenderParams rp, BatchState st, StageQueues q, int bounce) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   PushStage& s_push = *(PushStage*)s_dyn;
   PushCtx pctx = {{0, 0, 0, 0}, 0, 0};
-  // the marginal distribution (h func + h + 1 cdf entries) behind the staging lists: its 10-step search runs on LDS
-  uint32_t* const sMarg = (uint32_t*)(s_dyn + push_stage_bytes(DR_ENV_BLOCK));
-  {
+  using MF = typename std::conditional<MLDS, LdsFloats, GlobalFloats>::type;
+  using MatsOnly = MatsOnlyT<MF>;
+  MatsOnly lv;
+  lv.mats = sc.mats;
+  if constexpr (MLDS) {
+    // the marginal distribution (h func + h + 1 cdf entries) behind the staging lists: its 10-step search runs on LDS
+    uint32_t* const sMarg = (uint32_t*)(s_dyn + push_stage_bytes(DR_ENV_BLOCK));
     const uint32_t h = (uint32_t)sc.env.h;
     for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) sMarg[i] = __float_as_uint(sc.env.margFunc[i]);
     for (uint32_t i = threadIdx.x; i < h + 1u; i += blockDim.x) sMarg[h + i] = __float_as_uint(sc.env.margCdf[i]);
+    lv.margFunc = LdsFloats{(lds_cu32*)sMarg};
+    lv.margCdf = LdsFloats{(lds_cu32*)(sMarg + sc.env.h)};
+  } else {
+    lv.margFunc = GlobalFloats{sc.env.margFunc};
+    lv.margCdf = GlobalFloats{sc.env.margCdf};
   }
-  const MatsOnly lv{sc.mats, LdsFloats{(lds_cu32*)sMarg}, LdsFloats{(lds_cu32*)(sMarg + sc.env.h)}};
   const uint32_t nIn = *q.nEnv;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t nIter = (nIn + stride - 1) / stride;
@@ -1771,7 +1790,7 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t n
   const dim3 grid((npix + 63) / 64, nBlocks);
   if (!st.svFloat && rp.spp >= 64) {
     const int nGen = rp.genMask ? __builtin_popcountll(rp.genMask) : nBlocks;  // compact form (rp.blocks is null), whole index runs per pixel
-    static const int lanesEnv = getenv("DARTRAY_GEN_LANES") ? atoi(getenv("DARTRAY_GEN_LANES")) : 0;
+    const int lanesEnv = dr_option("DARTRAY_GEN_LANES") ? atoi(dr_option("DARTRAY_GEN_LANES")) : 0;
     // (above 1024 spp a pixel's table is 4 / 8 KB: 32 / 16 pixels per group keep the group's tables within 128 KB)
     const int ln = lanesEnv ? lanesEnv : (rp.spp <= 128 ? 64 : (rp.spp <= 256 ? DR_GEN_LANES_256 : (rp.spp <= 1024 ? DR_GEN_LANES_BIG : (rp.spp <= 2048 ? 32 : 16))));
     const dim3 g((npix + ln - 1) / ln, nGen);
@@ -1779,7 +1798,7 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t n
     if (rp.spp <= 256) {
       hipLaunchKernelGGL(k_gen_samples_lm<uint8_t>, g, dim3(ln), lds, s, rp, st, npix);
     } else {
-      static const bool onePerGroup = getenv("DARTRAY_GEN_ONE_WAVE") != nullptr;  // A/B: the single-wave kernel
+      const bool onePerGroup = dr_option("DARTRAY_GEN_ONE_WAVE") != nullptr;  // A/B: the single-wave kernel
       static bool attrSet = false;
       if (!attrSet) {
         (void)hipFuncSetAttribute((const void*)k_gen_samples_lm<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1828,7 +1847,7 @@ static void launch_shade(int grid, size_t extraLds, hipStream_t s, A... args) {
   hipLaunchKernelGGL(kernel, dim3(DR_SHADE_GRID(grid)), dim3(BLOCK), lds, s, args...);
 }
 static bool lightsInLds(const DScene& sc) {
-  static const bool off = getenv("DARTRAY_LDS_LIGHTS") && atoi(getenv("DARTRAY_LDS_LIGHTS")) == 0;  // A/B runs
+  const bool off = dr_option("DARTRAY_LDS_LIGHTS") && atoi(dr_option("DARTRAY_LDS_LIGHTS")) == 0;  // A/B runs
   return !off && sc.nlights > 0 && light_table_bytes(sc) <= DR_LDS_LIGHT_BYTES;
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
@@ -1852,13 +1871,17 @@ void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchStat
 #define DR_ENV_GRID_PER_CU 4
 #endif
 void launch_env(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce, int grid, hipStream_t s) {
+  if ((size_t)sc.env.h > DR_ENV_MARG_LDS_ROWS) {  // a map too tall for the LDS copy: the global-memory marginal (any height)
+    hipLaunchKernelGGL(k_env<false>, dim3(grid * DR_ENV_GRID_PER_CU), dim3(DR_ENV_BLOCK), push_stage_bytes(DR_ENV_BLOCK), s, sc, rp, st, q, bounce);
+    return;
+  }
   const size_t lds = push_stage_bytes(DR_ENV_BLOCK) + (2 * (size_t)sc.env.h + 1) * 4;
   static size_t attrSet = 0;
   if (attrSet < lds) {
-    (void)hipFuncSetAttribute((const void*)k_env, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_env<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attrSet = lds;
   }
-  hipLaunchKernelGGL(k_env, dim3(grid * DR_ENV_GRID_PER_CU), dim3(DR_ENV_BLOCK), lds, s, sc, rp, st, q, bounce);
+  hipLaunchKernelGGL(k_env<true>, dim3(grid * DR_ENV_GRID_PER_CU), dim3(DR_ENV_BLOCK), lds, s, sc, rp, st, q, bounce);
 }
 void launch_shade_direct(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int stage,
                          int grid, hipStream_t s) {
@@ -1888,6 +1911,8 @@ void launch_film_resolve(const float* film, int64_t npix, float* rgb, hipStream_
 void launch_copy(const float4* src, float4* dst, uint64_t n4, hipStream_t s) {
   hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, s, src, dst, n4);
 }
+int layout_state_words() { return DR_STATE_WORDS_K; }
+int layout_sub() { return DR_SUB; }
 
 #ifdef DR_NS
 }  // namespace DR_NS

@@ -1116,11 +1116,8 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_intersect3(
 // launchers.  DARTRAY_TRACE_IMPL selects the kernel for A/B runs: 1 = first version, 2 = default, 3 = sibling pairs.
 // ---------------------------------------------------------------------------
 static int traceImpl(const DScene& sc, int anyHit, int force = 0) {
-  static int env = -1;
-  if (env < 0) {
-    const char* e = getenv("DARTRAY_TRACE_IMPL");
-    env = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
-  }
+  const char* e = dr_option("DARTRAY_TRACE_IMPL");  // (read per launch: dr_set_option may change it between renders)
+  const int env = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
   // v2 is the fastest on cache-resident trees, v3 (sibling pairs) on big incoherent ones:
   // unless DARTRAY_TRACE_IMPL fixes it, the choice is the one measured for this scene (sc.traceKernel, set by the
   // pilot of dr_render_device)

@@ -58,21 +58,69 @@ def init_process_group(device_comm=None):
     return rank, world, local
 
 
+def _any_rank(flag):
+    """gloo all-reduce(MAX) of a host flag: did ANY rank raise it?  Every rank calls this at the same point."""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
 def _comm_init_or_fallback(rank, world, local):
-    """comm_init; if ANY rank fails, every rank drops to a torch.distributed RCCL group (see _fallback_group)."""
-    global _fallback_group, comm_error
+    """dr_comm_init on every rank -- or, if ANY rank cannot, every rank together on a torch.distributed RCCL group (see
+    _fallback_group).  The handshake is symmetric phase by phase: each phase is a LOCAL attempt on the ranks it
+    concerns, then one gloo all-reduce of an error flag that every rank joins, and only a clean phase is followed by the
+    next collective -- so no rank is ever left waiting in a broadcast or in ncclCommInitRank for a peer that has given up:
+      1. every rank: dr_init + dr_comm_available (binds librccl, checks its version; talks to nobody)   -> agree
+      2. rank 0: dr_comm_unique_id                                                                    -> agree
+      3. every rank: broadcast of the 128-byte id (gloo), then dr_comm_init (ncclCommInitRank)         -> agree
+    A failure INSIDE ncclCommInitRank on a subset of ranks can still block the others in RCCL: nothing on the host can
+    undo that, and the launcher's timeout ends the job non-zero -- this process never re-executes itself."""
+    global _fallback_group, comm_error, _comm_ready
+    lib = None
     err = None
-    try:
-        comm_init(rank, world, local)
-    except Exception as e:  # noqa: BLE001 -- reported on the JSON line
-        err = "%s: %s" % (type(e).__name__, e)
-    flag = torch.tensor([1 if err else 0], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # gloo control plane
-    if int(flag.item()):
-        comm_error = err or "dr_comm_init failed on another rank"
+
+    def attempt(fn):
+        nonlocal err
+        if err is None:
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001 -- reported on the JSON line
+                err = "%s: %s" % (type(e).__name__, e)
+
+    def fall_back(stage):
+        global _fallback_group, comm_error
+        comm_error = err or "%s failed on another rank" % stage
         if _comm_ready:
             comm_destroy()
-        _fallback_group = dist.new_group(backend="nccl")
+        _fallback_group = dist.new_group(backend=_FALLBACK_BACKEND)
+
+    def phase1():
+        nonlocal lib
+        lib = _abi.lib()
+        _abi.init(local)
+        _abi.check(lib.dr_comm_available())
+
+    attempt(phase1)
+    if _any_rank(err):
+        return fall_back("dr_comm_available")
+    ident = torch.zeros(_abi.DR_COMM_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        attempt(lambda: _abi.check(lib.dr_comm_unique_id(ident.data_ptr(), ident.numel())))
+    if _any_rank(err):
+        return fall_back("dr_comm_unique_id")
+    dist.broadcast(ident, src=0)
+
+    def phase3():
+        global _comm_ready
+        _abi.check(lib.dr_comm_init(rank, world, ident.data_ptr(), ident.numel()))
+        _comm_ready = True
+
+    attempt(phase3)
+    if _any_rank(err):
+        return fall_back("dr_comm_init")
+
+
+_FALLBACK_BACKEND = "nccl"  # (the CPU test of the handshake swaps in gloo)
 
 
 def comm_init(rank, world, local):
@@ -94,11 +142,6 @@ def comm_destroy():
     if _comm_ready:
         _abi.check(_abi.lib().dr_comm_destroy())
         _comm_ready = False
-# bench.py only: if dr_comm_init fails on a multi-GPU box (the world > 1 path of dr_comm.cpp has never met hardware in
-# development: one-GPU boxes), the film is reduced by torch.distributed's own RCCL group instead and the JSON line says
-# so, with the error -- a measured scaling curve plus a bug report instead of no curve.  Never taken silently.
-_fallback_group = None
-comm_error = None
 
 
 def shard(renderer, rank, world, tile_size=32):

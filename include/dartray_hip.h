@@ -70,9 +70,6 @@ typedef struct DrMaterial {
 #define DR_LIGHT_SPOT_COS 5     /* DR_LIGHT_SPOT whose cone_width / cone_falloff_start hold the two COSINES a constructed SpotLight
                                  * keeps (cosTotalWidth, cosFalloffStart: spot_light.dart:46-47) instead of the constructor's
                                  * degrees -- what a host that only sees the Light object can marshal bit for bit */
-#define DR_LIGHT_SPOT_COS 5     /* DR_LIGHT_SPOT whose cone_width / cone_falloff_start hold the two COSINES a constructed SpotLight
-                                 * keeps (cosTotalWidth, cosFalloffStart: spot_light.dart:46-47) instead of the constructor's
-                                 * degrees -- what a host that only sees the Light object can marshal bit for bit */
 
 /* One entry of Scene.lights.  kind DR_LIGHT_DIFFUSE_AREA: DiffuseAreaLight + its
  * ShapeSet (diffuse_area_light.dart:36-43, lib/core/light/shape_set.dart:24-51);
@@ -371,6 +368,9 @@ int dr_copy_bandwidth(uint64_t bytes, int32_t iters, double* gbps_out);
  * store).  librccl is loaded on the first dr_comm_* call (DARTRAY_RCCL_LIB overrides the search), so
  * single-GPU hosts need not have it.  One communicator per process. */
 #define DR_COMM_ID_BYTES 128 /* == NCCL_UNIQUE_ID_BYTES */
+/* every rank, local: binds librccl and checks its version against the ABI subset this library declares -- DR_OK or the
+ * reason, without talking to any other rank (so a host can agree on "every rank can" BEFORE anyone blocks in dr_comm_init) */
+int dr_comm_available(void);
 /* rank 0: ncclGetUniqueId into id_out[DR_COMM_ID_BYTES] */
 int dr_comm_unique_id(void* id_out, uint64_t cap);
 /* every rank, after dr_init: ncclCommInitRank(world, id, rank); blocks until all ranks have called it */
@@ -394,6 +394,24 @@ int dr_comm_destroy(void);
 
 const char* dr_last_error(void);
 const char* dr_version(void);
+
+/* Tuning / diagnostic switches.  Every switch is also an environment variable of the same name (DARTRAY_<NAME>); a
+ * value set here takes precedence, is read at every use (nothing is latched at first use: the next render sees it) and
+ * needs no setenv in a long-lived foreign host.  name: with or without the DARTRAY_ prefix, any case; value NULL: back
+ * to the environment's value; "": unset for this process.  Unknown names are DR_ERR_INVALID.  Results never depend on a
+ * switch (all of them pick between bit-exact variants or print diagnostics).  The switches:
+ *   TRACE_IMPL 1|2|3|4    traversal kernel for both ray kinds (default: the scene's measured choice; 4 = treelet-parked)
+ *   TRACE_WG_PER_CU n     workgroups of a persistent traversal launch per CU
+ *   STATE_LAYOUT 64|4     path-state layout (default: picked per render from the pilot's stage-list densities)
+ *   LAYOUT_PILOT 0        do not measure list densities; take the layout from the scene's lights as round 3 did
+ *   BATCH_BITS b          at most 2^b camera samples per batch (16..28)
+ *   WORKSPACE job|max     size the path-state workspace to this render (default) or to 2^BATCH_BITS slots at once
+ *   PIPELINES 1|2, OVERLAP_ANY 0|1, PILOT 0|1, PILOT_FORCE, PILOT_BITS b   scheduling of a render's launches
+ *   PAIR_ORDER ...        memory order of the sibling-pair records (read by dr_scene_create)
+ *   TREELET, TREELET_TOP n, TREELET_ROUNDS n   the treelet-parked traversal
+ *   GEN_SLOW_DRAWS, GEN_ALL_BLOCKS, GEN_LANES n, GEN_ONE_WAVE, FLOAT_SAMPLES, LDS_LIGHTS 0   A/B variants of the sampler / shade kernels
+ *   BUILD_THREADS n, BUILD_DEBUG   the BVH builders;  RCCL_LIB path   librccl to bind;  STAGE_COUNTS, VERBOSE   diagnostics */
+int dr_set_option(const char* name, const char* value);
 
 
 /* ---- layout checks: a foreign host (dart:ffi Struct classes, ctypes, a C program) must see exactly these

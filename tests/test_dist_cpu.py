@@ -80,3 +80,81 @@ def test_init_process_group_single_rank_is_a_noop(monkeypatch):
     import torch
     t = torch.ones(3)
     assert drdist.reduce_film(t) is t
+
+
+class _FakeLib:
+    """Stands in for libdartray_hip in the handshake test: every dr_comm_* call returns what the scenario says for this
+    rank (0 = DR_OK) and records that it was made."""
+
+    def __init__(self, rank, fail_at):
+        self.rank, self.fail_at, self.calls = rank, fail_at, []
+
+    def _rc(self, name):
+        self.calls.append(name)
+        return 7 if self.fail_at == (self.rank, name) else 0
+
+    def dr_comm_available(self):
+        return self._rc("dr_comm_available")
+
+    def dr_comm_unique_id(self, ptr, n):
+        return self._rc("dr_comm_unique_id")
+
+    def dr_comm_init(self, rank, world, ptr, n):
+        return self._rc("dr_comm_init")
+
+    def dr_comm_destroy(self):
+        return self._rc("dr_comm_destroy")
+
+
+def _handshake_worker(rank, world, init_file, out_dir, fail_rank, fail_call):
+    sys.path.insert(0, ROOT)
+    import json
+    import torch
+    import torch.distributed as dist
+    from dartray_amd import _abi, dist as drdist
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    fake = _FakeLib(rank, (fail_rank, fail_call))
+
+    def check(rc):
+        if rc != 0:
+            raise _abi.DartRayHipError("fake error %d" % rc)
+
+    _abi.lib, _abi.init, _abi.check = (lambda: fake), (lambda dev: None), check
+    drdist._FALLBACK_BACKEND = "gloo"
+    drdist._comm_init_or_fallback(rank, world, rank)
+    ok = None
+    if drdist._fallback_group is not None:  # the group every rank dropped to works, on every rank
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t, group=drdist._fallback_group)
+        ok = float(t.item())
+    json.dump({"calls": fake.calls, "fallback": drdist._fallback_group is not None, "error": drdist.comm_error,
+               "ready": drdist._comm_ready, "sum": ok}, open(os.path.join(out_dir, "r%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("fail_rank,fail_call", [(0, "dr_comm_unique_id"), (1, "dr_comm_available"), (1, "dr_comm_init"), (0, "dr_comm_init"),
+                                                 (None, None)])
+def test_comm_init_or_fallback_is_symmetric_when_one_rank_fails(fail_rank, fail_call):
+    """whichever rank fails, and in whichever phase, BOTH ranks end in the fallback group with
+    comm_error set -- nobody waits in a broadcast or a collective for a peer that has given up (this test would hang) --
+    and a clean handshake leaves both with the RCCL communicator and no fallback."""
+    import json
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_handshake_worker, args=(2, os.path.join(tmp, "init"), tmp, fail_rank, fail_call), nprocs=2, join=True)
+        res = [json.load(open(os.path.join(tmp, "r%d.json" % r))) for r in range(2)]
+    if fail_call is None:
+        assert all(not r["fallback"] and r["ready"] and r["error"] is None for r in res)
+        assert res[0]["calls"] == ["dr_comm_available", "dr_comm_unique_id", "dr_comm_init"]
+        assert res[1]["calls"] == ["dr_comm_available", "dr_comm_init"]
+        return
+    assert all(r["fallback"] and not r["ready"] and r["error"] for r in res), res
+    assert all(r["sum"] == 3.0 for r in res)
+    assert "fake error" in res[fail_rank]["error"] and "another rank" in res[1 - fail_rank]["error"]
+    if fail_call == "dr_comm_init":  # the rank whose init succeeded gives its communicator back before falling back
+        assert res[1 - fail_rank]["calls"][-1] == "dr_comm_destroy"
+        assert "dr_comm_destroy" not in res[fail_rank]["calls"]
+    else:  # nobody reached ncclCommInitRank
+        assert all("dr_comm_init" not in r["calls"] for r in res)

@@ -29,9 +29,10 @@ def _inputs(prims):
 
 def _same(acc, refined, qb, max_prims=4):
     t0 = time.time()
-    nodes, order, nn, depth = core.build_bvh_arrays(acc.verts, refined, qb, len(acc.quadrics), max_prims, "device")
+    nodes, order, nn, depth, ran = core.build_bvh_arrays(acc.verts, refined, qb, len(acc.quadrics), max_prims, "device")
     dt = time.time() - t0
-    hn, ho, hnn, hdepth = core.build_bvh_arrays(acc.verts, refined, qb, len(acc.quadrics), max_prims, "host")
+    assert ran == "device"
+    hn, ho, hnn, hdepth, _ = core.build_bvh_arrays(acc.verts, refined, qb, len(acc.quadrics), max_prims, "host")
     assert nn == hnn and depth == hdepth
     assert np.array_equal(order[:len(refined)], ho[:len(refined)])
     assert nodes[:nn].tobytes() == hn[:hnn].tobytes()
@@ -49,7 +50,14 @@ def test_device_builder_equals_the_host_builder_on_the_restatement_scenes(gpu, c
     _same(acc, refined, qb)
     # and through the host class: the aggregate the renderer uses
     dev = core.BVHAccel(prims, builder="device")
+    assert dev.builder == "device"
     assert dev.nodes.tobytes() == acc.nodes.tobytes() and np.array_equal(dev.tri_idx, acc.tri_idx)
+    # and DIRECTLY against the oracle's serial restatement of bvh_accel.dart:228-437 (not only through the host builder)
+    import oracle.binding as ob
+    onodes, otri, _, _ = ob.OracleScene(prims).bvh()
+    assert dev.nodes.tobytes() == onodes.tobytes()
+    if case != "cquad":  # (a quadric's row of tri_idx is a tag + its index: the product's own encoding)
+        assert np.array_equal(dev.tri_idx, otri)
 
 
 @pytest.mark.parametrize("blob,max_prims", [((200, 100), 4), ((200, 100), 1), ((200, 100), 16), ((200, 100), 255), ((333, 77), 4)])
@@ -79,8 +87,8 @@ def test_coincident_centroids_and_signed_zeros(gpu):
     verts = np.ascontiguousarray(np.concatenate(tris), np.float32)
     idx = np.arange(len(verts), dtype=np.uint32).reshape(-1, 3)
     qb = np.zeros((1, 6), np.float32)
-    hn, ho, hnn, hd = core.build_bvh_arrays(verts, idx, qb, 0, 4, "host")
-    dn, do, dnn, dd = core.build_bvh_arrays(verts, idx, qb, 0, 4, "device")
+    hn, ho, hnn, hd, _ = core.build_bvh_arrays(verts, idx, qb, 0, 4, "host")
+    dn, do, dnn, dd, _ = core.build_bvh_arrays(verts, idx, qb, 0, 4, "device")
     assert dnn == hnn and dd == hd and np.array_equal(do, ho) and dn[:dnn].tobytes() == hn[:hnn].tobytes()
     assert (hn[:hnn]["nprims"] > 1).any()
     zeros = hn[:hnn]["bmin"][hn[:hnn]["bmin"] == 0]
@@ -112,13 +120,13 @@ def test_random_triangle_soups(gpu, n, kind, seed):
     idx = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
     qb = np.zeros((1, 6), np.float32)
     for max_prims in ((4,) if n > 5000 else (4, 1, 8)):
-        hn, ho, hnn, hd = core.build_bvh_arrays(verts, idx, qb, 0, max_prims, "host")
-        dn, do, dnn, dd = core.build_bvh_arrays(verts, idx, qb, 0, max_prims, "device")
+        hn, ho, hnn, hd, _ = core.build_bvh_arrays(verts, idx, qb, 0, max_prims, "host")
+        dn, do, dnn, dd, _ = core.build_bvh_arrays(verts, idx, qb, 0, max_prims, "device")
         assert dnn == hnn and dd == hd, (n, kind, max_prims)
         assert np.array_equal(do[:n], ho[:n]) and dn[:dnn].tobytes() == hn[:hnn].tobytes(), (n, kind, max_prims)
 
 
-@pytest.mark.parametrize("cfg,budget_s", [("C2", 0.25), ("C5", 0.6), ("C4", 0.6)])
+@pytest.mark.parametrize("cfg,budget_s", [("C2", 0.1), ("C5", 0.25), ("C4", 0.25)])
 def test_full_size_configs_equal_the_host_builder(gpu, cfg, budget_s):
     """BASELINE.json's scenes at full size: 1 000 012, ~8 M and 10 000 012 triangles."""
     prims, _ = scenes.config(cfg)
@@ -126,4 +134,4 @@ def test_full_size_configs_equal_the_host_builder(gpu, cfg, budget_s):
     _same(acc, refined, qb)            # first call: includes one-off allocation effects
     dt, nn, depth = _same(acc, refined, qb)
     print("%s: %d triangles, %d nodes, depth %d: dr_bvh_build_device %.3f s (host pointers in and out)" % (cfg, len(refined), nn, depth, dt))
-    assert dt < 4 * budget_s
+    assert dt < 1.5 * budget_s  # (measured: C2 0.03 s, C5 0.09 s, C4 0.14 s)
