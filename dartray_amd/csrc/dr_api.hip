@@ -73,6 +73,11 @@ struct Workspace {
   DevBuf<int2> pix;
   DevBuf<float> filterTable, aosSamples;
   int spillGrid = 0;
+  // treelet-parked traversal (DARTRAY_TRACE_IMPL=4): parked records, keys, sort buffers
+  DevBuf<uint4> tlRec[2];
+  DevBuf<uint32_t> tlKeys[2], tlKeysSorted, tlIota, tlOrder, tlCounts;
+  DevBuf<unsigned char> tlSortTmp;
+  TLWork tl = {};
 };
 
 #define DR_STATE_WORDS F_SAMPLES  // 41 4-byte words of fixed path state per slot: 3 f64 + 10 3-vectors + 5 i32
@@ -91,8 +96,8 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_TREELET", "DARTRAY_TREELET_TOP",
-    "DARTRAY_TREELET_ROUNDS", "DARTRAY_WORKSPACE", "DARTRAY_LAYOUT_PILOT"};
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_TREELET", "DARTRAY_TREELET_TOP",
+    "DARTRAY_TREELET_ROUNDS", "DARTRAY_TREELET_MIN", "DARTRAY_TREELET_SHARDS", "DARTRAY_WORKSPACE", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
 const char* dr_option(const char* name) {
@@ -404,6 +409,7 @@ void enumeratePixels(const RenderParams& rp, const DrRenderDesc* rd, std::vector
 // A render picks one (dr_render_device); results do not depend on it.
 struct LayoutOps {
   decltype(&launch_trace) trace;
+  decltype(&launch_trace_treelets) trace_treelets;
   decltype(&launch_gen_samples) gen_samples;
   decltype(&launch_transpose_samples) transpose_samples;
   decltype(&launch_raygen) raygen;
@@ -415,9 +421,9 @@ struct LayoutOps {
   int stateWords;  // 4-byte words of fixed path state per slot in this layout (a tile is 64 of them + the sample region):
                    // what the kernels' own translation unit was compiled with (layout_state_words), not a constant repeated here
 };
-static const LayoutOps kLayout64 = {&launch_trace, &launch_gen_samples, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
+static const LayoutOps kLayout64 = {&launch_trace, &launch_trace_treelets, &launch_gen_samples, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
                                     &launch_env, &launch_shade_direct, &launch_shade_spec, &launch_film, layout_state_words()};
-static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_gen_samples, &sp4::launch_transpose_samples, &sp4::launch_raygen,
+static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_trace_treelets, &sp4::launch_gen_samples, &sp4::launch_transpose_samples, &sp4::launch_raygen,
                                      &sp4::launch_shade_path, &sp4::launch_env, &sp4::launch_shade_direct, &sp4::launch_shade_spec,
                                      &sp4::launch_film, sp4::layout_state_words()};
 
@@ -497,9 +503,9 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   uint32_t measuredDepth = 0;
   // k_trace addresses node i at byte offset i * 32 from a scalar base, in 32 bits (dr_trace.hip)
   if (desc->nnodes > (1ull << 27)) return fail(DR_ERR_UNSUPPORTED, "more than 2^27 BVH nodes");
+  std::vector<uint8_t> level(desc->nnodes, 0);
   if (desc->nnodes) {
     const DrBvhNode* N = desc->nodes;
-    std::vector<uint8_t> level(desc->nnodes, 0);
     for (uint64_t i = 0; i < desc->nnodes; ++i) {
       if (N[i].nprims == 0) {
         if (N[i].offset <= i + 1 || N[i].offset >= desc->nnodes || N[i].axis > 2)
@@ -577,6 +583,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   // sibling-pair layout for the v3 traversal (see dr_device.h): children of the k-th interior node side by side
   sc->d.pairs = nullptr;
   sc->d.npairs = 0;
+  sc->d.topPairs = 0;
   sc->d.rootRef = PREF_DEAD;
   if (desc->nnodes) {
     const DrBvhNode* N = desc->nodes;
@@ -597,7 +604,10 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     //   sib      the two child records of a node side by side in ONE 128-byte line (holes where a child is a leaf)
     //   veb:T:S  treelets: the top T levels breadth-first, below them sub-trees of height S breadth-first each,
     //            treelet after treelet in depth-first order (van Emde Boas style; veb:1:1 is the default order)
-    if (const char* po = dr_option("DARTRAY_PAIR_ORDER")) {
+    // (default since round 4: top:12 -- the top twelve levels breadth-first, 3 774 records = 236 KiB on C4, every sub-tree below
+    // them contiguous and depth-first: C4 closest-hit -1 %, any-hit -3.5 % against plain depth-first; "dfs" restores that)
+    const char* poOpt = dr_option("DARTRAY_PAIR_ORDER");
+    if (const char* po = poOpt ? poOpt : "top:12") {
       const std::string mode(po);
       std::vector<uint32_t> slotOf(desc->nnodes, 0);
       uint32_t slots = 0;
@@ -623,6 +633,18 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         for (uint64_t i = 0; i < desc->nnodes; ++i)
           if (N[i].nprims == 0) slotOf[i] = pairIndex[i] * K;
         slots = np * K;
+      } else if (mode.rfind("top:", 0) == 0) {
+        // the top T levels breadth-first (the top treelet of the treelet-parked traversal, DScene.topPairs records), then
+        // every other interior node in depth-first (= node index) order: a sub-tree below the top is one contiguous run
+        const int T = std::max(1, atoi(po + 4));
+        std::vector<uint32_t> top;
+        for (uint64_t i = 0; i < desc->nnodes; ++i)
+          if (N[i].nprims == 0 && level[i] < T) top.push_back((uint32_t)i);
+        std::stable_sort(top.begin(), top.end(), [&](uint32_t a, uint32_t b) { return level[a] < level[b]; });
+        for (uint32_t i : top) slotOf[i] = slots++;
+        sc->d.topPairs = slots;
+        for (uint64_t i = 0; i < desc->nnodes; ++i)
+          if (N[i].nprims == 0 && level[i] >= T) slotOf[i] = slots++;
       } else if (mode.rfind("veb:", 0) == 0) {
         int T = 1, S = 1;
         if (sscanf(po + 4, "%d:%d", &T, &S) < 1) T = 1;
@@ -1348,6 +1370,40 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const int tgrid = traceGrid();
   rc = ensureSpill(sc, sc->ws, tgrid);
   if (rc) return rc;
+  // DARTRAY_TRACE_IMPL=4: the treelet-parked traversal (a prototype) for the stage queues of a scene
+  // whose pair records were laid out with DARTRAY_PAIR_ORDER=top:T
+  const char* implOpt = dr_option("DARTRAY_TRACE_IMPL");
+  const bool treelets = implOpt && implOpt[0] == '4' && sc->d.pairs && sc->d.topPairs > 0 && !sc->d.nquads && !dlSpec && nPipesEnv < 2;
+  if (treelets) {
+    Workspace& w = sc->ws;
+    const uint32_t outCap = w.cap + (uint32_t)tgrid * (DR_TRACE_BLOCK / 64) * 256u + 1024u;
+    if (w.tl.outCap < outCap) {
+      for (int k = 0; k < 2; ++k) {
+        HIP_TRY(w.tlRec[k].alloc((size_t)outCap * DR_TL_REC_U4));
+        HIP_TRY(w.tlKeys[k].alloc(outCap));
+        w.tl.rec[k] = w.tlRec[k].p;
+        w.tl.keys[k] = w.tlKeys[k].p;
+      }
+      HIP_TRY(w.tlKeysSorted.alloc(outCap));
+      HIP_TRY(w.tlIota.alloc(outCap));
+      HIP_TRY(w.tlOrder.alloc(outCap));
+      HIP_TRY(w.tlCounts.alloc(64));
+      w.tl.sortTmpBytes = (sp4::treelet_sort_bytes(outCap) + 255) & ~(size_t)255;
+      HIP_TRY(w.tlSortTmp.alloc(w.tl.sortTmpBytes));
+      w.tl.keysSorted = w.tlKeysSorted.p;
+      w.tl.iota = w.tlIota.p;
+      w.tl.order = w.tlOrder.p;
+      w.tl.counts = w.tlCounts.p;
+      w.tl.sortTmp = w.tlSortTmp.p;
+      w.tl.outCap = outCap;
+      w.tl.iotaReady = 0;
+    }
+    w.tl.topPairs = sc->d.topPairs;
+    w.tl.rounds = dr_option("DARTRAY_TREELET_ROUNDS") ? std::max(0, std::min(3, atoi(dr_option("DARTRAY_TREELET_ROUNDS")))) : 1;
+    w.tl.shards = dr_option("DARTRAY_TREELET_SHARDS") ? std::max(1, std::min(8, atoi(dr_option("DARTRAY_TREELET_SHARDS")))) : 8;
+    w.tl.minPark = dr_option("DARTRAY_TREELET_MIN") ? (uint32_t)atoi(dr_option("DARTRAY_TREELET_MIN")) : (1u << 18);
+    w.tl.verbose = dr_option("DARTRAY_VERBOSE") ? atoi(dr_option("DARTRAY_VERBOSE")) : 0;
+  }
   const bool overlapEnv = !(dr_option("DARTRAY_OVERLAP_ANY") && atoi(dr_option("DARTRAY_OVERLAP_ANY")) == 0);  // default: on
   const bool overlapAny = overlapEnv && !dlSpec && !(nPipesEnv >= 2);
   if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
@@ -1449,7 +1505,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr) {
       hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
       (void)hipEventRecord(e0, ts);
-      L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
+      if (treelets) (void)L.trace_treelets(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts, w.tl);
+      else L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
       (void)hipEventRecord(e1, ts);
       if (pilot) pilot->ev[any].push_back({e0, e1});
       sc->traceEvents.push_back({e0, e1, any, after});
@@ -1458,7 +1515,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // A stage's two traversals are independent (closest hit of the continuation / MIS rays, occlusion of the shadow
     // rays).  Side by side on two streams the any-hit workgroups take the CU slots the closest-hit launch frees as its
     // queue runs dry (a persistent launch ends with its longest rays).  Calibration batches time each launch alone.
-    const bool sideBySide = overlapAny && !pilot;
+    const bool sideBySide = overlapAny && !pilot && !treelets;
     // DirectLighting over mirror / glass: one round of the stage loop per vertex of a slot's ray tree; `roundQ` lists
     // the slots whose (camera or child) ray this round traces.  Everything else: one round.
     const uint32_t* roundQ = nullptr;
@@ -1636,6 +1693,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     HIP_TRY(hipStreamWaitEvent(callerStream, ev, 0));
   }
   HIP_TRY(hipEventRecord(evStop, s));
+  if (treelets && sc->ws.tl.verbose) {
+    TLWork& t = sc->ws.tl;
+    for (int k = 0; k < 2; ++k)
+      fprintf(stderr, "dartray_hip: treelet-parked traversal (top %u pairs, %d parking round%s), %s rays: launches %.2f ms, sorts %.2f ms, %.2f M records parked\n",
+              t.topPairs, t.rounds, t.rounds == 1 ? "" : "s", k ? "any-hit" : "closest-hit", t.ms[k][0], t.ms[k][1], t.ms[k][3]);
+    memset(t.ms, 0, sizeof(t.ms));
+  }
   sc->stats.camera_samples += (uint64_t)npixTotal * spp;
   sc->stats.film_samples += filmSamples;
   return DR_OK;

@@ -136,6 +136,9 @@ struct DScene {
   float rootBox[6];     // bounds of node 0
   uint32_t rootRef;     // packed reference of node 0 (see pack_ref)
   uint32_t npairs;
+  uint32_t topPairs;    // pair order "top:T" (dr_scene_create): pairs [0, topPairs) are the top T levels of the tree, breadth-first;
+                        // every sub-tree below them is one contiguous, depth-first run of records.  0: another order
+  uint32_t padTop;
   const uint4* nodes;   // 2 x uint4 per node (DrBvhNode)
   const float4* tris;   // 3 x float4 per primitive
   // Shading record of a triangle, 32 B (2 x float4), for scenes of plain triangles with matte materials (the !QUAD

@@ -27,6 +27,7 @@
 #include "dr_kernels.h"
 #include "dr_wave.h"
 #include "dr_rng.h"
+#include <hipcub/hipcub.hpp>
 
 #ifdef DR_NS  // a second instantiation of this file (another state layout, -DDR_SUB=...): every symbol in its own namespace
 namespace DR_NS {
@@ -811,10 +812,13 @@ DR_DEV uint32_t pack_ref(uint32_t ref, uint32_t meta) {
 }
 
 #define M_EXPAND 1  // `cur` is an interior node whose box is hit (or must be re-tested): fetch its pair
+#ifndef DR_PARK_TH
+#define DR_PARK_TH 16  // treelet-parked traversal: lanes that park together
+#endif
 
-template <int ANY, class IO>
+template <int ANY, class IO, bool TL = false>
 DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ldsRef, float* ldsE, uint32_t* spill,
-                        uint32_t spillStride, uint32_t spillHalf, uint32_t* work, TraceCounters* ctr) {
+                        uint32_t spillStride, uint32_t spillHalf, uint32_t* work, TraceCounters* ctr, const TLArgs& tl = TLArgs()) {
   const int lane = lane_id();
   const unsigned long long ltMask = (1ull << lane) - 1ull;
   uint32_t nRays = 0, nNodes = 0, nTris = 0;
@@ -825,6 +829,15 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
   bool retest = false;  // cur was popped inside the ambiguous band: evaluate the literal test on its own box
   bool exhausted = false;
   uint32_t resNext = 0, resEnd = 0;
+  // treelet-parked mode (TL): inBottom = the ray is inside a bottom sub-tree, entered when its stack held spEnter entries
+  // (depth first: it has left the sub-tree exactly when the stack is lower than that again)
+  bool inBottom = false;
+  int spEnter = 0;
+  uint32_t outNext = 0, outEnd = 0;  // wave-uniform: this wave's reservation of parked-record positions
+  uint32_t tlShard = TL ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (tl.shards ? tl.shards : 1u) : 0u, tlTried = 0;  // XCC_ID
+  if constexpr (TL) {
+    if (tl.order) n = *tl.nIn;
+  }
 
   auto stackGet = [&](int i, uint32_t* ref, float* e) {
     *ref = ldsRef[(i < DR_PSTACK ? i : DR_PSTACK - 1) * DR_TRACE_BLOCK];
@@ -871,7 +884,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
   // the stack survives its pop (up to the ambiguous band), so pops never turn into long chains.
   auto pruneStack = [&]() {
     const float R = 4.76837158203125e-07f, A = 1.0e-37f;
-    int j = 0;
+    int j = 0, below = 0;
     for (int i = 0; i < sp; ++i) {
       uint32_t r;
       float e;
@@ -879,12 +892,14 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       const float eb = __fmaf_rn(fabsf(e), R, A);
       if (e - eb >= ray.tmaxHi) {
         ++nNodes;
+        if (TL && i < spEnter) ++below;  // an entry from before the current bottom sub-tree was entered
         continue;
       }
       if (j != i) stackSet(j, r, e);
       ++j;
     }
     sp = j;
+    if constexpr (TL) spEnter -= below;
   };
   // Pop until an entry survives (bvh_accel.dart:139-143,156-159); every popped entry is one node visit.
   // Returns false when the stack is empty (the ray is finished).
@@ -915,7 +930,29 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     const unsigned long long idleMask = __ballot(mode == M_IDLE);
     const int nIdle = __popcll(idleMask);
     if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
-      if (resNext == resEnd) {
+      if (TL && tl.order && tl.shards > 1u) {
+        // resumed records are sorted by sub-tree: the list is cut into one contiguous shard per XCD (each XCD has its own
+        // 4 MiB L2), a wave drains its own XCD's shard and then helps with the others -- the sub-trees an XCD's waves
+        // walk at one time are then a window of ONE region of the tree instead of one window per XCD of the same region
+        while (resNext == resEnd && !exhausted) {
+          if (tlTried == tl.shards) {
+            exhausted = true;
+            break;
+          }
+          const uint32_t s0 = (uint32_t)(((unsigned long long)n * tlShard) / tl.shards);
+          const uint32_t s1 = (uint32_t)(((unsigned long long)n * (tlShard + 1u)) / tl.shards);
+          uint32_t fresh = 0;
+          if (lane == 0) fresh = atomicAdd(work + tlShard * 16u, (uint32_t)DR_WORK_CHUNK);
+          fresh = wave_bcast_first(fresh);
+          if (fresh < s1 - s0) {
+            resNext = s0 + fresh;
+            resEnd = min(s0 + fresh + (uint32_t)DR_WORK_CHUNK, s1);
+          } else {
+            tlShard = (tlShard + 1u) % tl.shards;
+            ++tlTried;
+          }
+        }
+      } else if (resNext == resEnd) {
         uint32_t fresh = 0;
         if (lane == 0) {
           fresh = nRays == 0u ? __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // (see trace_persistent)
@@ -932,12 +969,42 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       const uint32_t take = min(resEnd - resNext, (uint32_t)nIdle);
       if (mode == M_IDLE) {
         const uint32_t j = (uint32_t)__popcll(idleMask & ltMask);
-        if (j < take) {
+        if (TL && tl.order && j < take) {
+          // resume a parked ray: its record carries the ray, the node it was about to expand and its stack
+          const uint4* rec = tl.in + (size_t)tl.order[resNext + j] * DR_TL_REC_U4;
+          const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+          ray_init(ray, F3{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)},
+                   F3{__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)}, __hiloint2double((int)q1.w, (int)q1.z),
+                   __hiloint2double((int)q2.y, (int)q2.x));
+          hit = (int)q2.z;
+          handle = q2.w;
+          cur = q3.x;
+          sp = (int)(q3.y & 0xffffu);
+          retest = ((q3.y >> 16) & 1u) != 0;
+          {  // the rest of the record's first line in one go (8 entries: most stacks), the second line only when needed
+            const uint4 v0 = rec[4], v1 = rec[5], v2 = rec[6], v3 = rec[7];
+            const uint4 vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (2 * k < sp) stackSet(2 * k, vv[k].x, __uint_as_float(vv[k].y));
+              if (2 * k + 1 < sp) stackSet(2 * k + 1, vv[k].z, __uint_as_float(vv[k].w));
+            }
+          }
+          for (int i = 8; i < sp; i += 2) {
+            const uint4 v = rec[4 + (i >> 1)];
+            stackSet(i, v.x, __uint_as_float(v.y));
+            if (i + 1 < sp) stackSet(i + 1, v.z, __uint_as_float(v.w));
+          }
+          mode = M_EXPAND;
+          inBottom = true;
+          spEnter = sp;
+        } else if (j < take) {
           io.load(resNext + j, ray, handle);
           ++nRays;
           sp = 0;
           hit = -1;
           retest = false;
+          inBottom = false;
           // visit node 0 (its box and packed reference live in kernel arguments)
           bool ok = false;
           if (sc.rootRef != PREF_DEAD) {
@@ -956,6 +1023,62 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       }
       resNext += take;
     }
+    bool hold = false;  // (TL) this lane waits for a batch of lanes to park with
+    if constexpr (TL) {
+      // ---- entering a bottom sub-tree: park the ray for the next round, or mark where it entered ----
+      if (inBottom && sp < spEnter) inBottom = false;
+      const bool enter = mode == M_EXPAND && !inBottom && (cur & 0x1fffffffu) >= tl.topPairs;
+      bool park = enter && tl.out != nullptr && sp <= DR_TL_MAX_SP;
+      // writing a record is ~100 instructions and a dozen stores: like the leaf tests it is done for a batch of lanes --
+      // a lane that wants to park holds until DR_PARK_TH do or nobody else in the wave has anything to do
+      unsigned long long parkMask = __ballot(park);
+      if (parkMask != 0ull && __popcll(parkMask) < DR_PARK_TH &&
+          __ballot((mode == M_EXPAND && !park) || mode == M_LEAF || mode == M_DONE) != 0ull) {
+        hold = park;
+        parkMask = 0ull;
+      }
+      if (parkMask != 0ull) {
+        const uint32_t np = (uint32_t)__popcll(parkMask), rem = outEnd - outNext;
+        uint32_t fresh = 0;
+        if (rem < np) {  // the rest of this wave's reservation first, then a new one (positions are never left unused here)
+          if (lane == 0) fresh = atomicAdd(&tl.outCount[0], (uint32_t)DR_WORK_CHUNK);
+          fresh = wave_bcast_first(fresh);
+        }
+        if (park) {
+          const uint32_t rank = (uint32_t)__popcll(parkMask & ltMask);
+          const uint32_t pos = rank < rem ? outNext + rank : fresh + (rank - rem);
+          if (pos < tl.outCap) {
+            uint4* rec = tl.out + (size_t)pos * DR_TL_REC_U4;
+            rec[0] = uint4{__float_as_uint(ray.o.x), __float_as_uint(ray.o.y), __float_as_uint(ray.o.z), __float_as_uint(ray.d.x)};
+            rec[1] = uint4{__float_as_uint(ray.d.y), __float_as_uint(ray.d.z), (uint32_t)__double2loint(ray.tmin), (uint32_t)__double2hiint(ray.tmin)};
+            rec[2] = uint4{(uint32_t)__double2loint(ray.tmax), (uint32_t)__double2hiint(ray.tmax), (uint32_t)hit, handle};
+            rec[3] = uint4{cur, (uint32_t)sp | (retest ? 0x10000u : 0u), 0u, 0u};
+            for (int i = 0; i < sp; i += 2) {
+              uint32_t ra, rb = 0u;
+              float ea, eb = 0.f;
+              stackGet(i, &ra, &ea);
+              if (i + 1 < sp) stackGet(i + 1, &rb, &eb);
+              rec[4 + (i >> 1)] = uint4{ra, __float_as_uint(ea), rb, __float_as_uint(eb)};
+            }
+            tl.outKeys[pos] = cur & 0x1fffffffu;
+            mode = M_IDLE;
+          } else {  // the record buffer is full: the position stays unused and the ray walks on
+            atomicAdd(&tl.outCount[1], 1u);
+            park = false;
+          }
+        }
+        if (rem < np) {
+          outNext = fresh + (np - rem);
+          outEnd = fresh + (uint32_t)DR_WORK_CHUNK;
+        } else {
+          outNext += np;
+        }
+      }
+      if (enter && !park) {
+        inBottom = true;
+        spEnter = sp;
+      }
+    }
     const unsigned long long expMask = __ballot(mode == M_EXPAND);
     unsigned long long leafMask = __ballot(mode == M_LEAF);
     if ((expMask | leafMask | __ballot(mode == M_DONE)) == 0ull) {
@@ -965,7 +1088,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     bool finished = false;
     // ---- expand one interior node: ONE 64-byte fetch, two box tests ----
     uint4 l0 = uint4{0, 0, 0, 0}, l1 = l0, r0 = l0, r1 = l0;
-    if (mode == M_EXPAND) {
+    if (mode == M_EXPAND && !hold) {
       const uint4* pp = sc.pairs + 4 * (size_t)(cur & 0x1fffffffu);
       l0 = pp[0], l1 = pp[1], r0 = pp[2], r1 = pp[3];
     }
@@ -975,7 +1098,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       io.store(handle, ray, hit, sc);
       mode = M_IDLE;
     }
-    if (mode == M_EXPAND) {
+    if (mode == M_EXPAND && !hold) {
       bool alive = true;
       if (retest) {
         // own box = union of the children's (bvh_accel.dart:521): the literal test the reference does at this pop
@@ -1032,7 +1155,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     }
     // ---- batched leaf tests ----
     leafMask = __ballot(mode == M_LEAF);
-    const unsigned long long stillExp = __ballot(mode == M_EXPAND && !finished);
+    const unsigned long long stillExp = __ballot(mode == M_EXPAND && !finished && !hold);
     if (leafMask != 0ull && (__popcll(leafMask) >= DR_LEAF_TH || stillExp == 0ull)) {
       if (mode == M_LEAF) {
         const uint32_t leafN = (cur >> 26) & 31u, leafOff = cur & 0x3ffffffu;
@@ -1083,6 +1206,9 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     }
     if (finished) mode = M_DONE;  // stored at the head of the next iteration
   }
+  if constexpr (TL) {
+    if (lane == 0 && outEnd > outNext && tl.out) atomicAdd(&tl.outCount[1], outEnd - outNext);
+  }
   flush_counters(ctr, ANY, nRays, nNodes, nTris);
 }
 
@@ -1112,12 +1238,257 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_intersect3(
                    stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
 }
 
+// Treelet-parked traversal (DARTRAY_TRACE_IMPL=4; TLArgs in dr_kernels.h): trace_pairs with its TL blocks compiled in.
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_trace_tl(DScene sc, BatchState st, const uint32_t* queue,
+                                                                              const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
+                                                                              TraceCounters* ctr, TLArgs tl) {
+  __shared__ uint32_t s_ref[DR_PSTACK * DR_TRACE_BLOCK];
+  __shared__ float s_e[DR_PSTACK * DR_TRACE_BLOCK];
+  StateIO<ANY> io{st, queue};
+  const uint32_t n = nQueue ? *nQueue : st.nslots;
+  const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
+  trace_pairs<ANY, StateIO<ANY>, true>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x,
+                                       spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr, stride,
+                                       stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr, tl);
+}
+__global__ void k_tl_iota(uint32_t* v, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i;
+}
+
+// ===========================================================================
+// v3 for any-hit rays (k_trace3a): 4-byte stack entries.
+// intersectP never shrinks maxDistance (bvh_accel.dart:167-226), so everything the reference decides about a far child
+// when it POPS it is already decided when it PUSHES it.  The far child's whole slab test -- the near child's: f32
+// filter, literal f64 fallback -- is therefore evaluated at push time; a child that fails is a DEAD entry (one node
+// visit if the ray ever gets to pop it, like the reference; a run of them is a count in a register / one merged entry),
+// a child that passes is pushed as a bare reference and expanded when popped with no further test.  No entry parameter
+// next to the reference, no re-test, no pruning pass: 4 bytes per entry instead of 8, and direction / minDistance /
+// maxDistance / the queue handle wait in LDS between refill and leaf test as in k_trace -- 16 + 8 rows = 24 KiB per
+// workgroup and <= 80 VGPRs: six workgroups per CU where k_trace3<1> had five.
+// ===========================================================================
+#ifndef DR_PSTACK_A
+#define DR_PSTACK_A 16
+#endif
+#ifndef DR_TRACE3A_WAVES
+#define DR_TRACE3A_WAVES 6
+#endif
+#define PREF_DEADN 0x60000000u  // (axis bits == 3: no interior reference carries them) | number of merged dead entries
+
+template <class IO>
+DR_DEV void trace_pairs_any(const DScene& sc, const IO& io, uint32_t n, uint32_t* ldsRef, uint32_t* cold, uint32_t* spill,
+                            uint32_t spillStride, uint32_t* work, TraceCounters* ctr) {
+  typedef __attribute__((address_space(3))) uint32_t cold_u32;
+#define COLD_TMAX() __hiloint2double((int)COLD_LD(7), (int)COLD_LD(6))
+  const int lane = lane_id();
+  uint32_t nRays = 0, nNodes = 0, nTris = 0;
+  TraceRay ray;
+  ray.needF64 = false;
+  uint32_t cur = 0, deadTop = 0;  // deadTop: dead entries on top of the stack that have not been written yet
+  int sp = 0, hit = -1, mode = M_IDLE;
+  bool exhausted = false;
+  uint32_t resNext = 0, resEnd = 0;
+
+  auto stackGet = [&](int i) -> uint32_t { return stack_pop<DR_PSTACK_A>(ldsRef, spill, spillStride, i); };
+  auto stackSet = [&](int i, uint32_t ref) {
+    if (i < DR_PSTACK_A) ldsRef[i * DR_TRACE_BLOCK] = ref;
+    else if (i < DR_MAX_STACK) *spill_at(spill, spillStride, i - DR_PSTACK_A) = ref;
+  };
+  auto push = [&](uint32_t ref) {
+    if (deadTop) {
+      stackSet(sp, PREF_DEADN | deadTop);
+      ++sp;
+      deadTop = 0;
+    }
+    stackSet(sp, ref);
+    ++sp;
+  };
+  // the literal test needs the f64 bounds of the ray: they wait in LDS
+  auto boxHit = [&](float x0, float y0, float z0, float x1, float y1, float z1) -> bool {
+    bool ok = false, amb = true;
+    if (!ray.needF64) {
+      bool sureMiss;
+      slab_f32_sure(ray, x0, y0, z0, x1, y1, z1, &ok, &sureMiss);
+      amb = !ok && !sureMiss;
+    }
+    if (amb) {
+      TraceRay rr = ray;
+      rr.tmin = COLD_TMIN();
+      rr.tmax = COLD_TMAX();
+      ok = slab_f64(rr, x0, y0, z0, x1, y1, z1);
+    }
+    return ok;
+  };
+  // Pop the next live entry (bvh_accel.dart:206-210); every popped entry is one node visit.  False: the stack is empty.
+  auto popNext = [&]() -> bool {
+    for (;;) {
+      nNodes += deadTop;
+      deadTop = 0;
+      if (sp == 0) return false;
+      --sp;
+      const uint32_t ref = stackGet(sp);
+      if ((ref & 0xe0000000u) == PREF_DEADN) {
+        nNodes += ref & 0x1fffffffu;
+        continue;
+      }
+      ++nNodes;
+      cur = ref;
+      mode = (ref & PREF_LEAF) ? M_LEAF : M_EXPAND;
+      return true;
+    }
+  };
+
+  for (;;) {
+    // ---- refill idle lanes (as in trace_persistent) ----
+    const unsigned long long idleMask = __ballot(mode == M_IDLE);
+    const int nIdle = __popcll(idleMask);
+    if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
+      if (resNext == resEnd) {
+        uint32_t fresh = 0;
+        if (lane == 0) {
+          fresh = nRays == 0u ? __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // (see trace_persistent)
+          if (fresh < n) fresh = atomicAdd(work, (uint32_t)DR_WORK_CHUNK);
+        }
+        fresh = wave_bcast_first(fresh);
+        if (fresh < n) {
+          resNext = fresh;
+          resEnd = min(fresh + (uint32_t)DR_WORK_CHUNK, n);
+        } else {
+          exhausted = true;
+        }
+      }
+      const uint32_t take = min(resEnd - resNext, (uint32_t)nIdle);
+      if (mode == M_IDLE) {
+        const uint32_t j = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
+        if (j < take) {
+          uint32_t handle;
+          io.load(resNext + j, ray, handle);
+          COLD_ST(0, __float_as_uint(ray.d.x));
+          COLD_ST(1, __float_as_uint(ray.d.y));
+          COLD_ST(2, __float_as_uint(ray.d.z));
+          COLD_ST(3, (uint32_t)__double2loint(ray.tmin));
+          COLD_ST(4, (uint32_t)__double2hiint(ray.tmin));
+          COLD_ST(5, handle);
+          COLD_ST(6, (uint32_t)__double2loint(ray.tmax));
+          COLD_ST(7, (uint32_t)__double2hiint(ray.tmax));
+          sp = 0;
+          deadTop = 0;
+          hit = -1;
+          mode = M_DONE;  // a ray that misses the root box: a miss, stored like every other result
+          // visit node 0 (its box and packed reference live in kernel arguments)
+          if (sc.rootRef != PREF_DEAD) {
+            ++nNodes;
+            if (boxHit(sc.rootBox[0], sc.rootBox[1], sc.rootBox[2], sc.rootBox[3], sc.rootBox[4], sc.rootBox[5])) {
+              cur = sc.rootRef;
+              mode = (cur & PREF_LEAF) ? M_LEAF : M_EXPAND;
+            }
+          }
+        }
+      }
+      if (lane == 0) nRays += take;  // (lane 0 carries the wave's count: flush_counters sums the lanes)
+      resNext += take;
+    }
+    const unsigned long long expMask = __ballot(mode == M_EXPAND);
+    unsigned long long leafMask = __ballot(mode == M_LEAF);
+    if ((expMask | leafMask | __ballot(mode == M_DONE)) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+    bool finished = false;
+    // ---- expand one interior node: ONE 64-byte fetch, two box tests ----
+    uint4 l0 = uint4{0, 0, 0, 0}, l1 = l0, r0 = l0, r1 = l0;
+    if (mode == M_EXPAND) {
+      const uint4* pp = (const uint4*)((const char*)sc.pairs + ((size_t)(cur & 0x1fffffffu) << 6));
+      l0 = pp[0], l1 = pp[1], r0 = pp[2], r1 = pp[3];
+    }
+    // results of the rays that finished in the previous iteration, stored behind this iteration's fetches (vmcnt
+    // retires in order: see trace_persistent)
+    if (mode == M_DONE) {
+      io.store(COLD_LD(5), ray, hit, sc);
+      mode = M_IDLE;
+    }
+    if (mode == M_EXPAND) {
+      const uint32_t axis = (cur >> 29) & 3u;
+      const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
+      const bool neg = iv < 0.f;  // near = second child when the ray runs against the split axis (:147-153)
+      const uint4 n0 = neg ? r0 : l0, n1 = neg ? r1 : l1, f0 = neg ? l0 : r0, f1 = neg ? l1 : r1;
+      // far child: what the reference pushes; its test cannot change before it is popped, so it is decided now
+      if (boxHit(__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w), __uint_as_float(f1.x),
+                 __uint_as_float(f1.y)))
+        push(pack_ref(f1.z, f1.w));
+      else
+        ++deadTop;
+      // near child: visited now
+      ++nNodes;
+      if (boxHit(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z), __uint_as_float(n0.w), __uint_as_float(n1.x),
+                 __uint_as_float(n1.y))) {
+        cur = pack_ref(n1.z, n1.w);
+        mode = (cur & PREF_LEAF) ? M_LEAF : M_EXPAND;
+      } else if (!popNext()) {
+        finished = true;
+      }
+    }
+    // ---- batched leaf tests (bvh_accel.dart:189-204) ----
+    leafMask = __ballot(mode == M_LEAF);
+    const unsigned long long stillExp = __ballot(mode == M_EXPAND && !finished);
+    if (leafMask != 0ull && (__popcll(leafMask) >= DR_LEAF_TH || stillExp == 0ull)) {
+      if (mode == M_LEAF) {
+        const uint32_t leafN = (cur >> 26) & 31u, leafOff = cur & 0x3ffffffu;
+        const F3 rayD = COLD_D();
+        const double rayTmin = COLD_TMIN(), rayTmax = COLD_TMAX();
+        bool occluded = false;
+        for (uint32_t i = 0; i < leafN; ++i) {
+          ++nTris;
+          const float4* tp = sc.tris + 3 * (size_t)(leafOff + i);
+          const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+          const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
+          if (tri_hitP(p1, p2, p3, ray.o, rayD, rayTmin, rayTmax)) {  // return true (bvh_accel.dart:193-195)
+            occluded = true;
+            break;
+          }
+        }
+        if (occluded) {
+          hit = 0;
+          finished = true;
+        } else if (!popNext()) {
+          finished = true;
+        }
+      }
+    }
+    if (finished) mode = M_DONE;  // stored at the head of the next iteration
+  }
+  flush_counters(ctr, 1, nRays, nNodes, nTris);
+#undef COLD_TMAX
+}
+
+__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3A_WAVES) k_trace3a(DScene sc, BatchState st, const uint32_t* queue,
+                                                                              const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
+                                                                              TraceCounters* ctr) {
+  __shared__ uint32_t s_ref[DR_PSTACK_A * DR_TRACE_BLOCK];
+  __shared__ uint32_t s_cold[8 * DR_TRACE_BLOCK];  // direction, minDistance, queue handle, maxDistance per lane
+  StateIO<1> io{st, queue};
+  const uint32_t n = nQueue ? *nQueue : st.nslots;
+  trace_pairs_any(sc, io, n, s_ref + threadIdx.x, s_cold + threadIdx.x, spill, gridDim.x * DR_TRACE_BLOCK, work, ctr);
+}
+__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3A_WAVES) k_intersect3a(DScene sc, const DrRay* rays, uint32_t n, DrHit* out,
+                                                                                  uint32_t* spill, uint32_t* work, TraceCounters* ctr) {
+  __shared__ uint32_t s_ref[DR_PSTACK_A * DR_TRACE_BLOCK];
+  __shared__ uint32_t s_cold[8 * DR_TRACE_BLOCK];
+  RayIO<1> io{rays, out};
+  trace_pairs_any(sc, io, n, s_ref + threadIdx.x, s_cold + threadIdx.x, spill, gridDim.x * DR_TRACE_BLOCK, work, ctr);
+}
+
 // ---------------------------------------------------------------------------
 // launchers.  DARTRAY_TRACE_IMPL selects the kernel for A/B runs: 1 = first version, 2 = default, 3 = sibling pairs.
 // ---------------------------------------------------------------------------
+// A/B: DARTRAY_ANY8=1 keeps the 8-byte (reference, entry parameter) any-hit kernel of round 3 (k_trace3<1>)
+static bool any8() {
+  const char* e = dr_option("DARTRAY_ANY8");
+  return e && atoi(e) != 0;
+}
 static int traceImpl(const DScene& sc, int anyHit, int force = 0) {
   const char* e = dr_option("DARTRAY_TRACE_IMPL");  // (read per launch: dr_set_option may change it between renders)
-  const int env = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
+  const int env = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : ((e && e[0] == '4') ? 3 : 0);  // 4: treelet-parked stage traversals (dr_api.hip); everything else v3
   // v2 is the fastest on cache-resident trees, v3 (sibling pairs) on big incoherent ones:
   // unless DARTRAY_TRACE_IMPL fixes it, the choice is the one measured for this scene (sc.traceKernel, set by the
   // pilot of dr_render_device)
@@ -1130,7 +1501,8 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
   const dim3 g(grid), b(DR_TRACE_BLOCK);
   const int impl = traceImpl(sc, anyHit, forceImpl);
   if (impl == 3) {
-    if (anyHit) hipLaunchKernelGGL(k_intersect3<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+    if (anyHit && any8()) hipLaunchKernelGGL(k_intersect3<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+    else if (anyHit) hipLaunchKernelGGL(k_intersect3a, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_intersect3<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
   } else if (impl == 1) {
     if (anyHit) hipLaunchKernelGGL(k_intersect_v1<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
@@ -1143,11 +1515,12 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
 void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
   const int impl = traceImpl(sc, anyHit);
-  if (impl == 3) grid = std::min(grid, traceGridFor(DR_TRACE3_WAVES));                        // k_trace3: 30 KiB of LDS, 5 resident
+  if (impl == 3) grid = std::min(grid, traceGridFor(anyHit && !any8() ? DR_TRACE3A_WAVES : DR_TRACE3_WAVES));  // k_trace3: 30 KiB of LDS, 5 resident; k_trace3a: 24 KiB, 6
   else if (!(impl == 2 && !sc.nquads)) grid = std::min(grid, traceGridFor(6));  // only k_trace fits 7 workgroups per CU
   const dim3 g(grid), b(DR_TRACE_BLOCK);
   if (impl == 3) {
-    if (anyHit) hipLaunchKernelGGL(k_trace3<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+    if (anyHit && any8()) hipLaunchKernelGGL(k_trace3<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+    else if (anyHit) hipLaunchKernelGGL(k_trace3a, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace3<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
   } else if (impl == 1) {
     if (anyHit) hipLaunchKernelGGL(k_trace_v1<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
@@ -1159,6 +1532,99 @@ void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue,
     if (anyHit) hipLaunchKernelGGL(k_trace<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
   }
+}
+
+size_t treelet_sort_bytes(uint32_t n) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, (int)n, 0, 32, (hipStream_t)0);
+  return bytes;
+}
+
+// The treelet-parked traversal of one stage queue: launch 0 walks every ray through the top treelet and parks it where it
+// enters its first bottom sub-tree; the records are sorted by sub-tree (hipcub radix sort of (key, position)); the next
+// launch resumes them in that order -- parking them again at their NEXT bottom sub-tree while parking rounds are left
+// (w.rounds), finishing them otherwise.  The host reads two counters back per round (a prototype: the stage loop of
+// dr_render_device otherwise never waits for the device).
+int launch_trace_treelets(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
+                          uint32_t* spill, uint32_t* workCounters, TraceCounters* ctr, int grid, hipStream_t s, TLWork& w) {
+  grid = std::min(grid, traceGridFor(DR_TRACE3_WAVES));
+  const dim3 g(grid), b(DR_TRACE_BLOCK);
+  int keyBits = 1;
+  while ((1ull << keyBits) < (unsigned long long)sc.npairs + 1ull && keyBits < 32) ++keyBits;
+  hipEvent_t e[4];
+  for (auto& x : e) (void)hipEventCreate(&x);
+  (void)hipMemsetAsync(w.counts, 0, 64 * sizeof(uint32_t), s);
+  if (!w.iotaReady) {
+    hipLaunchKernelGGL(k_tl_iota, dim3(4096), dim3(256), 0, s, w.iota, w.outCap);
+    w.iotaReady = 1;
+  }
+  uint32_t nResume = 0;
+  for (int round = 0; round < 4; ++round) {
+    const bool parks = round < w.rounds && (round == 0 || nResume >= w.minPark) && round < 3;
+    const int ob = round & 1;  // records written by this launch
+    TLArgs tl;
+    tl.order = round ? w.order : nullptr;
+    tl.nIn = w.counts + 32 + round;
+    tl.in = round ? w.rec[ob ^ 1] : nullptr;
+    tl.out = parks ? w.rec[ob] : nullptr;
+    tl.outKeys = w.keys[ob];
+    tl.outCount = w.counts + 2 * round;
+    tl.outCap = w.outCap;
+    tl.topPairs = w.topPairs;
+    if (parks) (void)hipMemsetAsync(w.keys[ob], 0xff, (size_t)w.outCap * sizeof(uint32_t), s);
+    (void)hipEventRecord(e[0], s);
+    uint32_t* wc = workCounters + (size_t)round * 128;  // (the launch's 8 x DR_WORK_STRIDE = 512 words: 8 shard counters, 64 B apart, per round)
+    tl.shards = round ? (uint32_t)w.shards : 1u;
+    if (round >= 4) break;  // (never reached: rounds <= 3)
+    if (anyHit) hipLaunchKernelGGL(k_trace_tl<1>, g, b, 0, s, sc, st, queue, nQueue, spill, wc, ctr, tl);
+    else hipLaunchKernelGGL(k_trace_tl<0>, g, b, 0, s, sc, st, queue, nQueue, spill, wc, ctr, tl);
+    (void)hipEventRecord(e[1], s);
+    if (!parks) {
+      if (w.verbose) {
+        (void)hipEventSynchronize(e[1]);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e[0], e[1]);
+        w.ms[anyHit][0] += t;
+        if (w.verbose > 1) fprintf(stderr, "treelets %s round %d: %u resumed, finished in %.3f ms\n", anyHit ? "any" : "closest", round, nResume, t);
+      }
+      break;
+    }
+    uint32_t cnt[2] = {0, 0};
+    if (hipMemcpyAsync(cnt, w.counts + 2 * round, sizeof(cnt), hipMemcpyDeviceToHost, s) != hipSuccess) return DR_ERR_HIP;
+    if (hipStreamSynchronize(s) != hipSuccess) return DR_ERR_HIP;
+    const uint32_t reserved = std::min(cnt[0], w.outCap);
+    const uint32_t overflowed = cnt[0] > w.outCap ? cnt[0] - w.outCap : 0u;  // positions past the buffer: reserved by waves, never written (their rays walked on)
+    const uint32_t unusedInBuf = cnt[1] > overflowed ? cnt[1] - overflowed : 0u;
+    nResume = reserved > unusedInBuf ? reserved - unusedInBuf : 0u;
+    float tTrace = 0.f, tSort = 0.f;
+    (void)hipEventElapsedTime(&tTrace, e[0], e[1]);
+    if (nResume == 0) {
+      w.ms[anyHit][0] += tTrace;
+      break;
+    }
+    (void)hipEventRecord(e[2], s);
+    size_t tmpBytes = w.sortTmpBytes;
+    if (hipcub::DeviceRadixSort::SortPairs(w.sortTmp, tmpBytes, (const uint32_t*)w.keys[ob], w.keysSorted, (const uint32_t*)w.iota, w.order,
+                                           (int)reserved, 0, keyBits, s) != hipSuccess)
+      return DR_ERR_HIP;
+    (void)hipMemcpyAsync(w.counts + 32 + round + 1, &nResume, sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    (void)hipEventRecord(e[3], s);
+    if (w.verbose) {
+      (void)hipEventSynchronize(e[3]);
+      (void)hipEventElapsedTime(&tSort, e[2], e[3]);
+      w.ms[anyHit][0] += tTrace;
+      w.ms[anyHit][1] += tSort;
+      w.ms[anyHit][3] += (float)nResume * 1.0e-6f;
+      if (w.verbose > 1)
+        fprintf(stderr, "treelets %s round %d: traced in %.3f ms, %u rays parked (%u positions reserved), sorted in %.3f ms\n", anyHit ? "any" : "closest",
+                round, tTrace, nResume, cnt[0], tSort);
+    } else {
+      (void)hipStreamSynchronize(s);  // (nResume is a host local the copy above reads)
+    }
+  }
+  for (auto& x : e) (void)hipEventDestroy(x);
+  return DR_OK;
 }
 
 #ifdef DR_NS

@@ -263,10 +263,18 @@ def test_render_is_deterministic_and_device_film_accumulates(gpu):
     assert np.array_equal(film.cpu().numpy(), a.film) and np.array_equal(rgb.cpu().numpy(), a.rgb)
 
 
-@pytest.mark.parametrize("impl", ["1", "3"])
+@pytest.mark.parametrize("impl", ["1", "3", "3:any8", "4:top3:r1", "4:top3:r3", "4:top6:r2", "4:top1:r3"])
 def test_alternative_traversal_kernels_are_bit_exact_too(impl):
-    """DARTRAY_TRACE_IMPL selects the first traversal kernel (1) or the sibling-pair experiment (3) for A/B
-    runs; both must reproduce the oracle's hits, visit counts and image exactly, like the default (2)."""
+    """DARTRAY_TRACE_IMPL selects the first traversal kernel (1), the sibling-pair kernels (3: k_trace3<0> + the 4-byte-entry
+    any-hit kernel k_trace3a; any8: round 3's 8-byte any-hit kernel) or the treelet-parked traversal (4: pair records laid
+    out top:T, every ray parked at each bottom sub-tree it enters for r rounds, sorted, resumed) for A/B runs; all must
+    reproduce the oracle's hits, visit counts and image exactly, like the default (2)."""
+    extra = {}
+    if impl == "3:any8":
+        impl, extra = "3", {"DARTRAY_ANY8": "1"}
+    elif impl.startswith("4:"):
+        _, top, rounds = impl.split(":")
+        impl, extra = "4", {"DARTRAY_PAIR_ORDER": "top:" + top[3:], "DARTRAY_TREELET_ROUNDS": rounds[1:], "DARTRAY_TREELET_MIN": "0"}
     import subprocess
     import sys
     code = (
@@ -282,7 +290,7 @@ def test_alternative_traversal_kernels_are_bit_exact_too(impl):
         "assert np.array_equal(out.film, ref['film'])\n"
         "assert all(st[k] == c[k] for k in ('closest_nodes', 'any_nodes', 'closest_tris', 'any_tris', 'closest_rays', 'any_rays'))\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
-    env = dict(os.environ, DARTRAY_TRACE_IMPL=impl)
+    env = dict(os.environ, DARTRAY_TRACE_IMPL=impl, **extra)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)
     assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
 
