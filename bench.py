@@ -14,6 +14,10 @@ workload: N = 1 -- configs[1] (C2): Cornell box + 1M-triangle displaced blob, Pa
           ~0.45 s at every N.  Options: --scaling c3 (configs[2] verbatim: 4096x4096, 1024 spp, 1.72e10 samples per
           step, total work fixed: ~14 s per step at N = 2), --scaling strong-c2 (the 1024x1024 image itself split),
           --scaling samples (no tiles: every rank adds its own 256 spp of the C2 image, seed + rank).
+          At N > 1 the default run also appends, after the headline's timed region, BASELINE configs[2] itself as
+          "extra_configs"[0]: the 4096x4096 x 1024 spp image over the N ranks ("scaling": "strong"), first render +
+          ONE timed step with its own per_rank_step_ms / reduce_ms / one_gpu_same_workload (602 Msamples/s) -- about
+          57 s / N of rendering on top of the headline (--no-extra skips it).
           One "step" = one full pass of the hot path over the image.  Launch: `python bench.py --gpus N` starts
           the N ranks itself (torch.distributed.run, one process per GPU) unless it already runs under torchrun.
 Inputs (scene, BVH) are resident in HBM before the timed region; samples are generated on the device.  Synthetic
@@ -282,10 +286,25 @@ def main():
                 e = r.headline(2, 1)
                 extra.append({k: e[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
                                                 "roofline_shade", "roofline_gen", "kernel_ms_per_step", "per_sample", "first_render_ms",
-                                                "pilot_ms", "traffic_profiled") if k in e})
+                                                "pilot_ms", "one_shot_ms", "traffic_profiled") if k in e})
                 del r
                 torch.cuda.empty_cache()
             out["extra_configs"] = extra
+    if world > 1 and mode == "weak" and not args.no_extra and not args.config and not args.res and not args.spp:
+        # BASELINE configs[2] on the N-rank line (every rank takes part; after the headline's timed region, like C4 / C5 at
+        # N = 1): the C2 scene at 4096 x 4096, 1024 spp, its 32 x 32 tiles over the N ranks, ONE reduce of the 268 MB film per
+        # step -- total work fixed ("strong").  The first render is the warm-up, then ONE timed step: 2 x 28.5 s / N of
+        # rendering (N = 2: ~30 s, N = 8: ~8 s) + the scene build.
+        del run
+        torch.cuda.empty_cache()
+        r3 = Run("C3", 4096, 1024, rank, world, "c3", args)
+        e = r3.headline(1, 0)
+        if rank == 0:
+            out["extra_configs"] = [{k: e[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "scaling", "rccl_world", "collective",
+                                                       "per_rank_step_ms", "reduce_ms", "film_bytes_reduced_per_step", "one_gpu_same_workload",
+                                                       "roofline", "kernel_ms_per_step", "first_render_ms") if k in e}]
+        del r3
+    if rank == 0:
         print(json.dumps(out))
     drdist.barrier()
     drdist.comm_destroy()
@@ -313,7 +332,9 @@ class Run:
         self.film = torch.zeros((self.H, self.W, 4), dtype=torch.float32, device="cuda")
         self.rgb = torch.zeros((self.H, self.W, 3), dtype=torch.float32, device="cuda")
         self.stream = torch.cuda.current_stream().cuda_stream
-        self.dev = self.scene._device()
+        t0 = time.perf_counter()
+        self.dev = self.scene._device()  # dr_scene_create: validation, pair records, uploads (host pointers in)
+        self.create_ms = (time.perf_counter() - t0) * 1e3
         self.lib = _abi.lib()
 
     def step(self):
@@ -336,6 +357,9 @@ class Run:
         self.step()
         torch.cuda.synchronize()
         first_ms = (time.perf_counter() - t0) * 1e3
+        if rank == 0:
+            self.rgb.cpu()  # the image back on the host: what Renderer.render hands to its caller
+        one_shot_render_ms = (time.perf_counter() - t0) * 1e3
         pilot_ms = self.dev.stats()["pilot_ms"]
         for _ in range(warmup):
             self.step()
@@ -347,21 +371,25 @@ class Run:
         for _ in range(steps):
             self.step()
         torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0  # this rank's own share (BEFORE the barrier: after it every rank reads the same clock)
         drdist.barrier()
         torch.cuda.synchronize()
         dt_rank = time.perf_counter() - t0
         dt = drdist.max_over_ranks(dt_rank)
-        dt_min = -drdist.max_over_ranks(-dt_rank)
+        own_max = drdist.max_over_ranks(dt_own)
+        own_min = -drdist.max_over_ranks(-dt_own)
         st = self.dev.stats()
         reduce_ms = None
-        if world > 1:  # the collective alone (after the timed region): three reduces of this film, barrier-bracketed
+        if world > 1:  # the collective alone (after the timed region): three reduces of a scratch film, barrier-bracketed
+            scratch = torch.zeros_like(self.film)
             torch.cuda.synchronize()
             drdist.barrier()
             t1 = time.perf_counter()
             for _ in range(3):
-                drdist.reduce_film(self.film, 0, self.stream)
+                drdist.reduce_film(scratch, 0, self.stream)
             torch.cuda.synchronize()
             reduce_ms = drdist.max_over_ranks(time.perf_counter() - t1) / 3 * 1e3
+            del scratch
         if rank != 0:
             return None
         copy = C.c_double(0.0)
@@ -410,13 +438,23 @@ class Run:
                            "alg_bytes": round(all_alg / max(1, st["camera_samples"]) + 148 + 32, 1)},
             "first_render_ms": round(first_ms, 1),
             "pilot_ms": round(pilot_ms, 1),
+            # what a one-shot host pays from host pointers to the image on the host (Renderer.render once per task,
+            # lib/dartray/dartray.dart:574): the BVHAccel constructor, the scene upload, the first render incl. resolve and copy out
+            "one_shot_ms": {"bvh_build": round(agg.build_ms, 1), "scene_create": round(self.create_ms, 1),
+                            "first_render_resolve_copy_out": round(one_shot_render_ms, 1),
+                            "total": round(agg.build_ms + self.create_ms + one_shot_render_ms, 1),
+                            "steady_step": round(dt / steps * 1e3, 1)},
         }
+        lay, dens = self.dev.state_layout()
+        out["config"]["state_layout"] = ("%s, picked from the first pilot batch: %.2f of its slots alive at the second bounce" % (
+            "four-slot line-grouped sub-tiles (sp4)" if lay == 4 else "64-slot runs", dens)) if lay else "64-slot runs (no pilot: small render)"
         if world > 1:
             out["scaling"] = {"c3": "strong", "strong-c2": "strong", "weak": "weak", "samples": "weak"}[self.mode]
             out["rccl_world"] = int(self.lib.dr_comm_world())
             out["collective"] = ("dr_film_reduce (C ABI: ncclReduce(sum, f32) over xGMI, librccl bound at run time)" if drdist.comm_error is None else
                                  "FALLBACK torch.distributed RCCL group -- dr_comm_init failed: %s" % drdist.comm_error)
-            out["per_rank_step_ms"] = {"min": round(dt_min / steps * 1e3, 3), "max": round(dt / steps * 1e3, 3)}
+            out["per_rank_step_ms"] = {"min": round(own_min / steps * 1e3, 3), "max": round(own_max / steps * 1e3, 3),
+                                       "note": "each rank's own clock before the closing barrier (rank 0's includes waiting for the reduce)"}
             out["reduce_ms"] = round(reduce_ms, 3)
             out["film_bytes_reduced_per_step"] = int(self.H * self.W * 16)
             out["one_gpu_same_workload"] = one_gpu_reference(self.mode, self.cfg)

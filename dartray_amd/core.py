@@ -641,6 +641,15 @@ class _DeviceScene:
     def reset_stats(self):
         _abi.check(_abi.lib().dr_reset_stats(self.handle))
 
+    def state_layout(self, layout=None):
+        """Get (layout, alive share at the second bounce) of this scene's path renders (0 = not measured yet), or store a
+        layout (64 / 4; 0 makes the next big render measure again)."""
+        if layout is not None:
+            _abi.check(_abi.lib().dr_scene_set_state_layout(self.handle, int(layout)))
+        lay, dens = C.c_int32(0), C.c_float(0.0)
+        _abi.check(_abi.lib().dr_scene_get_state_layout(self.handle, C.byref(lay), C.byref(dens)))
+        return int(lay.value), float(dens.value)
+
     def trace_kernels(self, kernels=None):
         """Get (closest, any-hit) traversal kernels of this scene (0 = not measured yet), or set them (2 / 3; (0, 0)
         makes the next big render measure again)."""

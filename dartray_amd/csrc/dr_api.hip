@@ -130,6 +130,8 @@ struct DrScene {
   DevBuf<TraceCounters> ctr;
   uint32_t bvhDepth = 0;
   bool traceCalibrated = false;
+  int stateLayout = 0;          // path-state layout of this scene's path renders: 0 = not measured yet, 64 / 4 (LayoutOps)
+  float layoutDensity = -1.f;   //   what decided it: the share of a pilot batch's slots still alive at the second bounce
   float calibMs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // pilot of dr_render_device: [closest / any][v2 / v3] ms
   std::vector<int32_t> lightNSamples;
   bool hasSpecular = false;  // some material is a mirror / glass
@@ -1177,6 +1179,21 @@ int dr_scene_set_trace_kernels(DrScene* sc, const uint32_t in[2]) {
   return DR_OK;
 }
 
+int dr_scene_get_state_layout(const DrScene* sc, int32_t* layout_out, float* density_out) {
+  if (!sc || !layout_out) return fail(DR_ERR_INVALID, "null argument");
+  *layout_out = sc->stateLayout;
+  if (density_out) *density_out = sc->layoutDensity;
+  return DR_OK;
+}
+
+int dr_scene_set_state_layout(DrScene* sc, int32_t layout) {
+  if (!sc) return fail(DR_ERR_INVALID, "null argument");
+  if (layout != 0 && layout != 4 && layout != 64) return fail(DR_ERR_INVALID, "state layout must be 64 or 4 (or 0 to measure again)");
+  sc->stateLayout = layout;
+  if (layout == 0) sc->layoutDensity = -1.f;
+  return DR_OK;
+}
+
 int dr_intersect(DrScene* sc, const DrRay* rays, int64_t n, DrHit* out, int32_t any_hit) {
   if (!sc || (n > 0 && (!rays || !out))) return fail(DR_ERR_INVALID, "null argument");
   if (n <= 0) return DR_OK;
@@ -1226,9 +1243,19 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // k_env (dr_kernels.hip): the environment-map work of a plain-triangle scene's path stages runs in its own kernel
   const bool envStage = rd->integrator == DR_INTEGRATOR_PATH && sc->d.hasEnv && !(sc->d.nquads || sc->d.hasSpec || sc->d.srec);
   // state layout of this render (see LayoutOps): the four-slot sub-tiles for the renders whose lists thin out early
+  // Which one is MEASURED on the render's own work (round 4; round 3 took the four-slot layout for every plain-triangle
+  // scene under an environment map): the first pilot batch -- the calibration batches below, rendered into the film like any
+  // other -- runs in the 64-slot layout and its stage lists say how fast the paths die; when less than half of the slots
+  // are still alive at the second bounce the rest of the render, and every later render of the scene, uses the four-slot
+  // sub-tiles (C5: 0.38 -> sp4; C2 0.80, C4: 64-slot).  DARTRAY_STATE_LAYOUT=64|4 forces one, dr_scene_set_state_layout
+  // stores one; renders too small for a pilot keep round 3's rule.
   const char* layoutEnv = dr_option("DARTRAY_STATE_LAYOUT");  // 64 | 4: A/B runs and tests
-  const bool sparseLayout = layoutEnv ? atoi(layoutEnv) == 4 : envStage;
-  const LayoutOps& L = sparseLayout ? kLayoutSp4 : kLayout64;
+  const bool layoutPilotOff = dr_option("DARTRAY_LAYOUT_PILOT") && atoi(dr_option("DARTRAY_LAYOUT_PILOT")) == 0;
+  const bool layoutKnown = layoutEnv || sc->stateLayout != 0 || rd->integrator != DR_INTEGRATOR_PATH || layoutPilotOff;
+  const bool sparseLayout = layoutEnv ? atoi(layoutEnv) == 4 : (sc->stateLayout ? sc->stateLayout == 4 : envStage);
+  const LayoutOps* Lp = sparseLayout ? &kLayoutSp4 : &kLayout64;
+  const int maxStateWords = layoutKnown ? Lp->stateWords : std::max(kLayout64.stateWords, kLayoutSp4.stateWords);
+#define L (*Lp)
 
   RenderParams rp;
   memset(&rp, 0, sizeof(rp));
@@ -1338,7 +1365,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // permuted indices in the compact form, 4 B per float otherwise; + the RNG tail in host-buffer mode).  The
     // default batch (2^28) takes 56 GB of a 288 GB MI355X; on a device with less free
     // memory the batch shrinks instead of failing (results do not depend on the batch size).
-    const uint64_t perSlot = (uint64_t)L.stateWords * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 +
+    const uint64_t perSlot = (uint64_t)maxStateWords * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 +
                              (hostBuf && needTail > 0 ? (uint64_t)rd->max_tail * 8 : 0) + (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0) +
                              (sf.compact ? (uint64_t)(8 * sf.nBlocks + spp - 1) / spp : 0) +
                              (dlSpec ? (uint64_t)std::max(1, rd->max_depth) * sizeof(SpecFrame) + 12 : 0);
@@ -1359,7 +1386,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (nBatches > 1 && npixTotal <= pixCapBatch + pixCapBatch / 4 && !(nPipesEnv >= 2 && !hostBuf)) nBatches = 1;
   const uint32_t pixPerBatch = (uint32_t)((npixTotal + nBatches - 1) / nBatches);
   const uint32_t cap = pixPerBatch * (uint32_t)spp;
-  int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0, L.stateWords);
+  int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0, maxStateWords);
   if (rc) return rc;
   if (dlSpec) {
     HIP_TRY(sc->ws.specFrames.alloc((size_t)sc->ws.cap * std::max(1, rd->max_depth) * DR_SPEC_FRAME_WORDS));
@@ -1409,7 +1436,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
   const bool twoPipes = nPipesEnv >= 2 && !hostBuf && !dlSpec && npixTotal > pixPerBatch;
   if (twoPipes) {
-    rc = allocWorkspace(sc, sc->ws2, cap, sf, pixPerBatch, rd->max_tail, false, L.stateWords);
+    rc = allocWorkspace(sc, sc->ws2, cap, sf, pixPerBatch, rd->max_tail, false, maxStateWords);
     if (rc) return rc;
     rc = ensureSpill(sc, sc->ws2, tgrid);
     if (rc) return rc;
@@ -1427,8 +1454,11 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // Both kernels are bit-exact, so results do not depend on the choice; dr_scene_set_trace_kernels / DARTRAY_TRACE_IMPL fix it.
   const bool pilotOff = dr_option("DARTRAY_PILOT") && atoi(dr_option("DARTRAY_PILOT")) == 0;
   const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || dr_option("DARTRAY_PILOT_FORCE");
-  const bool calibrate = !sc->traceCalibrated && !pilotOff && !hostBuf && !dlSpec && !dr_option("DARTRAY_TRACE_IMPL") && sc->d.pairs &&
-                         !sc->d.nquads && bigJob && npixTotal >= 3 * 64 * 4 && !(nPipesEnv >= 2);
+  const bool pilotOk = !pilotOff && !hostBuf && !dlSpec && bigJob && npixTotal >= 3 * 64 * 4 && !(nPipesEnv >= 2);
+  const bool calibrateTrace = !sc->traceCalibrated && pilotOk && !dr_option("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads;
+  const bool measureLayout = !layoutKnown && pilotOk;
+  const bool calibrate = calibrateTrace || measureLayout;
+  const int pilotSets = calibrateTrace ? 3 : 1;  // traversal kernels: warm-up, v2 timed, v3 timed; the layout alone: one batch
   size_t calibPix = 0;  // pixels per calibration batch; the three batches are the first 3 * calibPix entries of `pixels`
   if (calibrate) {
     uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 22, (uint64_t)npixTotal * spp / 64));
@@ -1440,9 +1470,9 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     std::vector<int2> ordered;
     ordered.reserve(npixTotal);
     std::vector<uint8_t> taken(totalGroups, 0);
-    for (int set = 0; set < 3; ++set)
+    for (int set = 0; set < pilotSets; ++set)
       for (size_t g = 0; g < groups; ++g) {
-        const size_t grp = ((3 * g + set) * totalGroups) / (3 * groups);  // interleaved: the three sets see the same regions
+        const size_t grp = (((size_t)pilotSets * g + set) * totalGroups) / ((size_t)pilotSets * groups);  // interleaved: the sets see the same regions
         taken[grp] = 1;
         ordered.insert(ordered.end(), pixels.begin() + grp * 64, pixels.begin() + grp * 64 + 64);
       }
@@ -1634,9 +1664,9 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       sc->d.traceKernel[1] = keepKernel[1];
       return code;
     };
-    for (int set = 0; set < 3; ++set) {  // warm-up (v2), v2 timed, v3 timed
+    for (int set = 0; set < pilotSets; ++set) {  // warm-up (v2), v2 timed, v3 timed
       const int impl = set == 2 ? 3 : 2;
-      sc->d.traceKernel[0] = sc->d.traceKernel[1] = (uint32_t)impl;
+      if (calibrateTrace) sc->d.traceKernel[0] = sc->d.traceKernel[1] = (uint32_t)impl;
       TraceCounters c0, c1;
       int prc = readCtr(&c0);
       if (prc) return abandon(prc);
@@ -1645,7 +1675,18 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       if (prc) return abandon(prc);
       prc = readCtr(&c1);
       if (prc) return abandon(prc);
-      if (set == 0) continue;
+      if (set == 0 && measureLayout) {
+        // the batch's stage lists (still in the counters): how many of its slots are alive at the second bounce?
+        uint32_t alive2 = 0;
+        HIP_TRY(hipMemcpy(&alive2, sc->ws.counters.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));  // entries of stage 1's output list
+        sc->layoutDensity = (float)((double)alive2 / ((double)calibPix * spp));
+        sc->stateLayout = sc->layoutDensity < 0.5f ? 4 : 64;
+        Lp = sc->stateLayout == 4 ? &kLayoutSp4 : &kLayout64;
+        if (dr_option("DARTRAY_VERBOSE"))
+          fprintf(stderr, "dartray_hip: state-layout pilot: %.3f of a batch's slots alive at the second bounce -> %s\n", sc->layoutDensity,
+                  sc->stateLayout == 4 ? "four-slot line-grouped sub-tiles (sp4)" : "64-slot runs");
+      }
+      if (set == 0 || !calibrateTrace) continue;
       const double bytes[2] = {32.0 * (double)(c1.closest_nodes - c0.closest_nodes) + 48.0 * (double)(c1.closest_tris - c0.closest_tris),
                                32.0 * (double)(c1.any_nodes - c0.any_nodes) + 48.0 * (double)(c1.any_tris - c0.any_tris)};
       for (int kind = 0; kind < 2; ++kind) {
@@ -1659,6 +1700,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
         perByte[kind][impl - 2] = bytes[kind] > 0.0 ? (double)sum / (bytes[kind] * 1.0e-9) : 0.0;
       }
     }
+    if (calibrateTrace) {
     for (int kind = 0; kind < 2; ++kind) {
       sc->d.traceKernel[kind] = perByte[kind][1] < 0.95 * perByte[kind][0] ? 3u : 2u;
       sc->calibMs[kind][0] = ms[kind][0];
@@ -1669,11 +1711,12 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // it unless the calibration batch found it more than 5 % slower (C2 / C5, where v3 loses, are 30 - 40 % slower)
     if (perByte[0][1] < 0.90 * perByte[0][0] && perByte[1][1] <= 1.05 * perByte[1][0]) sc->d.traceKernel[1] = 3u;
     sc->traceCalibrated = true;
+    }
     HIP_TRY(hipEventRecord(evP1, s));
-    sc->traceEvents.push_back({evP0, evP1, 5});  // DrRenderStats.pilot_ms: the time of the three calibration batches
-    firstPix = 3 * calibPix;
-    batchIndex = 3;
-    if (dr_option("DARTRAY_VERBOSE"))
+    sc->traceEvents.push_back({evP0, evP1, 5});  // DrRenderStats.pilot_ms: the time of the calibration batches
+    firstPix = (size_t)pilotSets * calibPix;
+    batchIndex = (size_t)pilotSets;
+    if (calibrateTrace && dr_option("DARTRAY_VERBOSE"))
       fprintf(stderr, "dartray_hip: traversal pilot (3 x %zu samples, rendered into the film), ms per algorithmic GB: closest v2 %.4f / v3 %.4f -> v%u; "
               "any hit v2 %.4f / v3 %.4f -> v%u\n", calibPix * (size_t)spp, perByte[0][0], perByte[0][1], sc->d.traceKernel[0],
               perByte[1][0], perByte[1][1], sc->d.traceKernel[1]);
@@ -1703,6 +1746,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   sc->stats.camera_samples += (uint64_t)npixTotal * spp;
   sc->stats.film_samples += filmSamples;
   return DR_OK;
+#undef L
 }
 
 int dr_enumerate_pixels(const DrRenderDesc* rd, int32_t* out_xy, uint64_t cap, uint64_t* n_out) {

@@ -311,6 +311,13 @@ void dr_scene_destroy(DrScene* scene);
  * skipped.  Setting 0 makes the next big render measure again. */
 int dr_scene_get_trace_kernels(const DrScene* scene, uint32_t kernels_out[2]);
 int dr_scene_set_trace_kernels(DrScene* scene, const uint32_t kernels[2]);
+/* The path-state layout of this scene's path-traced renders, next to the traversal kernels and measured the same way: the
+ * first big render's first pilot batch counts how many of its slots are still alive at the second bounce (density_out;
+ * -1 before); below one half the renders use four-slot, line-grouped sub-tiles (layout 4: stage lists that thin out touch
+ * few lines per surviving slot), otherwise 64-slot runs (layout 64).  Results never depend on it.  A host can store the
+ * choice with the scene and hand it back (0 = measure again at the next big render). */
+int dr_scene_get_state_layout(const DrScene* scene, int32_t* layout_out, float* density_out);
+int dr_scene_set_state_layout(DrScene* scene, int32_t layout);
 
 /* Aggregate.intersect / Aggregate.intersectP (lib/core/primitive.dart:33-55 ->
  * bvh_accel.dart:101-226) on a batch of rays; host buffers. */

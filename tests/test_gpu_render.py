@@ -502,3 +502,42 @@ def test_full_size_c2_properties_and_sparse_parity(ob, gpu):
         err = rel_err_image(out.rgb[y, x][None], ref["rgb"][y, x][None]).max()
         assert err <= REL_TOL, (x, y, out.rgb[y, x], ref["rgb"][y, x])
         assert np.array_equal(out.film[y, x], ref["film"][y, x])
+
+
+def test_state_layout_is_chosen_from_the_pilot_batch_densities():
+    """the path-state layout of a scene comes from what its first pilot batch measured -- the share of
+    slots still alive at the second bounce -- not from a property of its lights.  C2-like box: dense lists -> 64-slot runs; the
+    same box with black surfaces (every path dies at its first vertex): four-slot sub-tiles; an open scene under an environment
+    map: what its own density says.  The film is the same whichever layout runs (both forced through dr_set_option)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "from dartray_amd import _abi, scenes, core\n"
+        "_abi.init(0)\n"
+        "lib = _abi.lib()\n"
+        "def run(prims, mk, env=False):\n"
+        "    r = mk(); scene = scenes.make_scene(prims, r.env if env else None)\n"
+        "    out = r.render(scene); dev = scene._device(); lay, dens = dev.state_layout()\n"
+        "    films = {}\n"
+        "    for forced in (b'64', b'4'):\n"
+        "        _abi.check(lib.dr_set_option(b'STATE_LAYOUT', forced)); films[forced] = r.render(scene).film\n"
+        "    _abi.check(lib.dr_set_option(b'STATE_LAYOUT', None))\n"
+        "    assert np.array_equal(films[b'64'], films[b'4']) and np.array_equal(out.film, films[b'4'])\n"
+        "    assert dev.state_layout(64)[0] == 64 and dev.state_layout(0) == (0, -1.0)\n"
+        "    return lay, dens\n"
+        "prims, mk = scenes.config('C2', xres=48, yres=40, spp=16, blob=(60, 30))\n"
+        "lay, dens = run(prims, mk); print('box', lay, dens); assert lay == 64 and dens > 0.5\n"
+        "black = [core.GeometricPrimitive(p.shape, core.MatteMaterial((0.0, 0.0, 0.0)), p.areaLight) for p in prims]\n"
+        "lay, dens = run(black, mk); print('black', lay, dens); assert lay == 4 and dens < 0.05\n"
+        "prims, mk = scenes.config('C5', xres=48, yres=40, spp=16, yard=(4, 12), env_res=(64, 32))\n"
+        "lay, dens = run(prims, mk, env=True); print('yard', lay, dens); assert lay == (4 if dens < 0.5 else 64) and 0.0 < dens < 1.0\n"
+        "assert lib.dr_set_option(b'NO_SUCH_SWITCH', b'1') != 0\n"
+        "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ, DARTRAY_PILOT_FORCE="1", DARTRAY_VERBOSE="1")
+    for k in ("DARTRAY_TRACE_IMPL", "DARTRAY_STATE_LAYOUT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)
+    assert res.returncode == 0 and "OK" in res.stdout, (res.stdout[-1000:], res.stderr[-2000:])
+    assert res.stderr.count("state-layout pilot") == 3, res.stderr[-2000:]   # once per scene
