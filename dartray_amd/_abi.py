@@ -154,6 +154,7 @@ EXPORTS = {
     "dr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(DrRenderStats)]),
     "dr_reset_stats": (C.c_int, [C.c_void_p]),
     "dr_copy_bandwidth": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
+    "dr_scene_get_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "dr_scene_get_state_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "dr_scene_set_state_layout": (C.c_int, [C.c_void_p, C.c_int32]),
     "dr_comm_available": (C.c_int, []),

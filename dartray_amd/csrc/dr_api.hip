@@ -19,6 +19,8 @@
 #include <vector>
 
 #include "dr_kernels.h"
+#include "dr_scene_prep.h"
+static_assert(DR_PREP_MAX_STACK == DR_MAX_STACK, "dr_scene_prep.h");
 
 namespace {
 
@@ -96,7 +98,7 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_TREELET", "DARTRAY_TREELET_TOP",
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_SCENE_PREP", "DARTRAY_TREELET", "DARTRAY_TREELET_TOP",
     "DARTRAY_TREELET_ROUNDS", "DARTRAY_TREELET_MIN", "DARTRAY_TREELET_SHARDS", "DARTRAY_WORKSPACE", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
@@ -505,8 +507,15 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   uint32_t measuredDepth = 0;
   // k_trace addresses node i at byte offset i * 32 from a scalar base, in 32 bits (dr_trace.hip)
   if (desc->nnodes > (1ull << 27)) return fail(DR_ERR_UNSUPPORTED, "more than 2^27 BVH nodes");
-  std::vector<uint8_t> level(desc->nnodes, 0);
-  if (desc->nnodes) {
+  // Round 4: validation, height, pair records and the union check run on the device (dr_scene_prep.hip: C4 0.6 s -> 0.1 s).  The
+  // serial host loops below remain for the experimental pair orders (DARTRAY_PAIR_ORDER=sib | pad:K | veb:T:S) and as the
+  // reference the device results are tested against (DARTRAY_SCENE_PREP=host).
+  const char* pairOrderOpt = dr_option("DARTRAY_PAIR_ORDER");
+  const std::string pairOrder = pairOrderOpt ? pairOrderOpt : "top:12";
+  const char* prepOpt = dr_option("DARTRAY_SCENE_PREP");
+  const bool hostPrep = (prepOpt && std::string(prepOpt) == "host") || !(pairOrder == "dfs" || pairOrder.rfind("top:", 0) == 0);
+  std::vector<uint8_t> level(hostPrep ? desc->nnodes : 0, 0);
+  if (desc->nnodes && hostPrep) {
     const DrBvhNode* N = desc->nodes;
     for (uint64_t i = 0; i < desc->nnodes; ++i) {
       if (N[i].nprims == 0) {
@@ -525,7 +534,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   if (desc->bvh_depth > DR_MAX_STACK) return fail(DR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
   if (desc->bvh_depth != 0 && desc->bvh_depth < measuredDepth)
     return fail(DR_ERR_INVALID, "bvh_depth is smaller than the tree's height (pass 0 to have it measured)");
-  for (uint64_t i = 0; i < 3 * desc->ntris; i += 3) {
+  for (uint64_t i = 0; hostPrep && i < 3 * desc->ntris; i += 3) {
     if (desc->tri_idx[i] == DR_PRIM_QUADRIC) continue;
     for (int k = 0; k < 3; ++k)
       if (desc->tri_idx[i + k] >= desc->nverts) return fail(DR_ERR_INVALID, "vertex index out of range");
@@ -577,17 +586,75 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     sc->hostQuads.push_back(q);
   }
 
-  sc->bvhDepth = std::max(desc->bvh_depth, measuredDepth);  // (a caller may pass a bound larger than the height)
-  if (desc->nnodes && sc->bvhDepth == 0) sc->bvhDepth = 1;  // a single leaf: "known, no stack needed"
   // nodes: the 32-byte marshalled node is consumed as two 16-byte loads
   TRY_SC(sc->nodes.alloc(2 * desc->nnodes));
   if (desc->nnodes) TRY_SC(hipMemcpy(sc->nodes.p, desc->nodes, desc->nnodes * sizeof(DrBvhNode), hipMemcpyHostToDevice));
+  // the primitive tables (gathered into 48-byte records further down; the device-side validation reads them too)
+  DevBuf<float> dV;
+  DevBuf<uint32_t> dI, dM;
+  DevBuf<int32_t> dL;
+  DevBuf<uint8_t> dR;
+  if (desc->ntris) {
+    TRY_SC(dV.alloc(3 * std::max<uint64_t>(desc->nverts, 1)));
+    TRY_SC(dI.alloc(3 * desc->ntris));
+    TRY_SC(dM.alloc(desc->ntris));
+    TRY_SC(dL.alloc(desc->ntris));
+    TRY_SC(dR.alloc(desc->ntris));
+    if (desc->nverts) TRY_SC(hipMemcpy(dV.p, desc->verts, 3 * desc->nverts * sizeof(float), hipMemcpyHostToDevice));
+    TRY_SC(hipMemcpy(dI.p, desc->tri_idx, 3 * desc->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
+    TRY_SC(hipMemcpy(dM.p, desc->tri_material, desc->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
+    TRY_SC(hipMemcpy(dL.p, desc->tri_light, desc->ntris * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   // sibling-pair layout for the v3 traversal (see dr_device.h): children of the k-th interior node side by side
   sc->d.pairs = nullptr;
   sc->d.npairs = 0;
   sc->d.topPairs = 0;
   sc->d.rootRef = PREF_DEAD;
-  if (desc->nnodes) {
+  if (!hostPrep) {
+    ScenePrepIn pin;
+    memset(&pin, 0, sizeof(pin));
+    pin.nodes = sc->nodes.p;
+    pin.hostNodes = desc->nodes;
+    pin.nnodes = desc->nnodes;
+    pin.verts = dV.p;
+    pin.nverts = desc->nverts;
+    pin.triIdx = dI.p;
+    pin.triMaterial = dM.p;
+    pin.triLight = dL.p;
+    pin.ntris = desc->ntris;
+    pin.nquadrics = desc->nquadrics;
+    pin.nmaterials = desc->nmaterials;
+    pin.nlights = desc->nlights;
+    pin.wantPairs = desc->nnodes && desc->ntris < (1ull << 26) && desc->nquadrics == 0;  // only the v2 kernel tests quadrics
+    pin.topLevels = pairOrder.rfind("top:", 0) == 0 ? std::max(1, atoi(pairOrder.c_str() + 4)) : 0;
+    if (pin.wantPairs) {
+      pin.pairsCap = desc->nnodes / 2 + 1;  // a binary tree of n nodes has (n - 1) / 2 interior ones
+      TRY_SC(sc->pairs.alloc(4 * pin.pairsCap));
+      pin.pairsOut = sc->pairs.p;
+    }
+    ScenePrepOut pout;
+    const int prc = scene_prepare_device(pin, &pout);
+    if (prc != DR_OK) return bail(prc, pout.message);
+    measuredDepth = pout.depth;
+    if (desc->bvh_depth != 0 && desc->bvh_depth < measuredDepth)
+      return bail(DR_ERR_INVALID, "bvh_depth is smaller than the tree's height (pass 0 to have it measured)");
+    if (pout.pairsOk) {
+      const DrBvhNode& r = desc->nodes[0];
+      sc->d.pairs = sc->pairs.p;
+      sc->d.npairs = pout.npairs;
+      sc->d.topPairs = pout.topPairs;
+      sc->d.rootRef = r.nprims ? (PREF_LEAF | ((uint32_t)r.nprims << 26) | r.offset) : ((uint32_t)r.axis << 29);  // (the root's pair is slot 0 in either order)
+      for (int k = 0; k < 3; ++k) {
+        sc->d.rootBox[k] = r.bmin[k];
+        sc->d.rootBox[3 + k] = r.bmax[k];
+      }
+    } else {
+      sc->pairs.release();
+    }
+  }
+  sc->bvhDepth = std::max(desc->bvh_depth, measuredDepth);  // (a caller may pass a bound larger than the height)
+  if (desc->nnodes && sc->bvhDepth == 0) sc->bvhDepth = 1;  // a single leaf: "known, no stack needed"
+  if (desc->nnodes && hostPrep) {
     const DrBvhNode* N = desc->nodes;
     bool ok = desc->ntris < (1ull << 26) && desc->nquadrics == 0;  // only the v2 kernel tests quadrics
     std::vector<uint32_t> pairIndex(desc->nnodes, 0);
@@ -608,8 +675,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     //            treelet after treelet in depth-first order (van Emde Boas style; veb:1:1 is the default order)
     // (default since round 4: top:12 -- the top twelve levels breadth-first, 3 774 records = 236 KiB on C4, every sub-tree below
     // them contiguous and depth-first: C4 closest-hit -1 %, any-hit -3.5 % against plain depth-first; "dfs" restores that)
-    const char* poOpt = dr_option("DARTRAY_PAIR_ORDER");
-    if (const char* po = poOpt ? poOpt : "top:12") {
+    if (const char* po = pairOrder.c_str()) {
       const std::string mode(po);
       std::vector<uint32_t> slotOf(desc->nnodes, 0);
       uint32_t slots = 0;
@@ -737,18 +803,11 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   // primitives: gather vertices on the device
   TRY_SC(sc->tris.alloc(3 * desc->ntris));
   if (desc->ntris) {
-    DevBuf<float> dV;
-    DevBuf<uint32_t> dI, dM;
-    DevBuf<int32_t> dL;
-    DevBuf<uint8_t> dR;
-    TRY_SC(dV.alloc(3 * std::max<uint64_t>(desc->nverts, 1)));
-    TRY_SC(dI.alloc(3 * desc->ntris));
-    TRY_SC(dM.alloc(desc->ntris));
-    TRY_SC(dL.alloc(desc->ntris));
-    TRY_SC(dR.alloc(desc->ntris));
+    // per-primitive flag byte: bit 0 = Shape.reverseOrientation, bits 1.. = the quadric kind (the device-side validation has
+    // checked every index when the host loops did not)
     std::vector<uint8_t> flags(desc->ntris);
-    for (uint64_t i = 0; i < desc->ntris; ++i) {
-      flags[i] = desc->tri_reverse[i] ? 1 : 0;
+    for (uint64_t i = 0; i < desc->ntris; ++i) flags[i] = desc->tri_reverse[i] ? 1 : 0;
+    for (uint64_t i = 0; (desc->nquadrics || hostPrep) && i < desc->ntris; ++i) {
       if (desc->tri_idx[3 * i] == DR_PRIM_QUADRIC) {
         const uint32_t qi = desc->tri_idx[3 * i + 1];
         if (qi >= desc->nquadrics) return bail(DR_ERR_INVALID, "quadric index out of range");
@@ -759,14 +818,10 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       for (int k = 0; k < 3; ++k)
         if (desc->tri_idx[3 * i + k] >= desc->nverts) return bail(DR_ERR_INVALID, "vertex index out of range");
     }
-    for (uint64_t i = 0; i < desc->ntris; ++i) {
+    for (uint64_t i = 0; hostPrep && i < desc->ntris; ++i) {
       if (desc->tri_material[i] >= desc->nmaterials) return bail(DR_ERR_INVALID, "material index out of range");
       if (desc->tri_light[i] >= (int32_t)desc->nlights) return bail(DR_ERR_INVALID, "light index out of range");
     }
-    if (desc->nverts) TRY_SC(hipMemcpy(dV.p, desc->verts, 3 * desc->nverts * sizeof(float), hipMemcpyHostToDevice));
-    TRY_SC(hipMemcpy(dI.p, desc->tri_idx, 3 * desc->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
-    TRY_SC(hipMemcpy(dM.p, desc->tri_material, desc->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
-    TRY_SC(hipMemcpy(dL.p, desc->tri_light, desc->ntris * sizeof(int32_t), hipMemcpyHostToDevice));
     TRY_SC(hipMemcpy(dR.p, flags.data(), desc->ntris, hipMemcpyHostToDevice));
     launch_gather_tris(dV.p, dI.p, dM.p, dL.p, dR.p, sc->tris.p, desc->ntris, 0);
     TRY_SC(hipDeviceSynchronize());
@@ -1176,6 +1231,18 @@ int dr_scene_set_trace_kernels(DrScene* sc, const uint32_t in[2]) {
   sc->d.traceKernel[0] = in[0];
   sc->d.traceKernel[1] = in[1];
   sc->traceCalibrated = true;
+  return DR_OK;
+}
+
+int dr_scene_get_pairs(const DrScene* sc, void* out, uint64_t cap_bytes, uint64_t* npairs_out, uint32_t* top_pairs_out, uint32_t* depth_out) {
+  if (!sc || !npairs_out) return fail(DR_ERR_INVALID, "null argument");
+  *npairs_out = sc->d.pairs ? sc->d.npairs : 0;
+  if (top_pairs_out) *top_pairs_out = sc->d.topPairs;
+  if (depth_out) *depth_out = sc->bvhDepth;
+  if (out && sc->d.pairs) {
+    if (cap_bytes < (uint64_t)sc->d.npairs * 64) return fail(DR_ERR_INVALID, "pair buffer too small");
+    HIP_TRY(hipMemcpy(out, sc->d.pairs, (size_t)sc->d.npairs * 64, hipMemcpyDeviceToHost));
+  }
   return DR_OK;
 }
 

@@ -317,6 +317,11 @@ int dr_scene_set_trace_kernels(DrScene* scene, const uint32_t kernels[2]);
  * few lines per surviving slot), otherwise 64-slot runs (layout 64).  Results never depend on it.  A host can store the
  * choice with the scene and hand it back (0 = measure again at the next big render). */
 int dr_scene_get_state_layout(const DrScene* scene, int32_t* layout_out, float* density_out);
+/* Diagnostics: what dr_scene_create derived from the marshalled tree -- the sibling-pair records of the v3 traversal kernels
+ * (64 bytes each: the two child nodes of an interior node side by side, a child's `offset` naming its own pair record; 0 records
+ * when the tree cannot use them), how many of them form the breadth-first top of the tree, and the height it measured.  out may
+ * be NULL to query the counts. */
+int dr_scene_get_pairs(const DrScene* scene, void* out, uint64_t cap_bytes, uint64_t* npairs_out, uint32_t* top_pairs_out, uint32_t* depth_out);
 int dr_scene_set_state_layout(DrScene* scene, int32_t layout);
 
 /* Aggregate.intersect / Aggregate.intersectP (lib/core/primitive.dart:33-55 ->

@@ -13,7 +13,7 @@ for spec in "$@"; do
       objs="$objs _obj/va_${name}_$s.o"
     done
     wait
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o "../libdartray_hip_$name.so" $objs _obj/dr_bvh_build.cpp.o _obj/dr_comm.cpp.o _obj/dr_bvh_device.hip.o _obj/dr_kernels.hip.sp4.o _obj/dr_trace.hip.sp4.o -ldl
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o "../libdartray_hip_$name.so" $objs _obj/dr_bvh_build.cpp.o _obj/dr_comm.cpp.o _obj/dr_bvh_device.hip.o _obj/dr_scene_prep.hip.o _obj/dr_kernels.hip.sp4.o _obj/dr_trace.hip.sp4.o -ldl
     rm -f $objs; echo "built $name" ) &
 done
 wait
