@@ -277,6 +277,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(run.prims, run.renderer, args.cpu_pixels, run.H, run.W, spp)
             out["cpu_baseline_threads"] = cpu_baseline_threads(run.prims, run.renderer, run.H, run.W, spp)
+            if cfg == "C2":
+                out["replay"] = replay_leg(run)
+                out["replay_Msamples_s"] = out["replay"]["value"]
         if world == 1 and not args.no_extra and cfg == "C2" and not args.res and not args.spp:
             del run
             torch.cuda.empty_cache()
@@ -481,6 +484,43 @@ def one_gpu_reference(mode, cfg):
     elif not src:
         ref["value"], ref["unit"], ref["source"] = 602.0, "Msamples/s", "DESIGN.md section 5 (round 2)"
     return ref
+
+
+def replay_leg(run, res=128, spp=64):
+    """The reference-exact sampler mode as a number.  The reference draws every sample of a task from ONE serial generator
+    threaded through the sampler and the integrator (lib/renderers/sampler_renderer.dart:137,
+    lib/samplers/low_discrepancy_sampler.dart:64-88, lib/core/montecarlo.dart:407-473), so "identical Sampler RNG seeds" means
+    replaying that stream: the CPU oracle renders a res x res x spp window of the bench scene in its serial mode (timed: a CPU
+    baseline in the reference's own mode) and records every sample's inputs; the device renders the recording through
+    DR_SAMPLER_HOST_BUFFER from host pointers (dr_render: sample vectors and the RNG tail over PCIe in, film and image out)
+    and must return the oracle's film bit for bit."""
+    import numpy as np
+    import oracle.binding as ob
+    from dartray_amd import core, scenes
+    _, mk = scenes.config("C2", xres=res, yres=res, spp=spp, blob=(2, 2))  # (the renderer only: same camera, a res x res film)
+    r = mk()
+    n = (res + 1) * (res + 1) * spp
+    osc = ob.OracleScene(run.prims)
+    t0 = time.perf_counter()
+    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=n, max_tail=40)
+    t_cpu = time.perf_counter() - t0
+    r.sampler = core.HostBufferSampler(r.camera, spp, rec["pixel_xy"][::spp], rec["sample_vec"], rec["tail"])
+    out = r.render(run.scene)  # warm-up: the workspace of this shape
+    exact = bool(np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"]))
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = r.render(run.scene)
+    dt = (time.perf_counter() - t0) / reps
+    film_samples = res * res * spp
+    bytes_in = rec["sample_vec"].nbytes + rec["tail"].nbytes + rec["pixel_xy"][::spp].nbytes
+    return {"value": round(film_samples / dt / 1e6, 3), "unit": "Msamples/s", "bit_exact_vs_serial_oracle": exact,
+            "samples_traced": n, "ms_per_render": round(dt * 1e3, 2), "host_bytes_in_per_render": int(bytes_in),
+            "cpu_serial_oracle_Msamples_s": round(film_samples / t_cpu / 1e6, 4),
+            "what": "DR_SAMPLER_HOST_BUFFER replay of the reference's ONE serial Random(taskNum) stream (recorded by the CPU oracle in its "
+                    "serial mode): %dx%d film window of the bench scene x %d spp, dr_render from host pointers -- %d B of sample vector + "
+                    "%d B of RNG tail per sample over PCIe in, film + image out; the price of 'identical Sampler RNG seeds' against the "
+                    "keyed per-pixel streams of the headline" % (res, res, spp, rec["sample_vec"].shape[1] * 4, rec["tail"].shape[1] * 8)}
 
 
 def cpu_baseline(prims, renderer, grid, H, W, spp):

@@ -349,7 +349,9 @@ int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, const SampleForm& sf
     w.pixCap = std::max(w.pixCap, pixCap);
     HIP_TRY(w.scr.alloc(2 * (size_t)sf.nBlocks * w.pixCap));
   }
-  if (needTail && ((size_t)w.cap * maxTail > w.tail.n)) HIP_TRY(w.tail.alloc((size_t)w.cap * maxTail));
+  // (sized for THIS render's batches, not for the largest batch the workspace has ever held: a small replay after a big
+  // counter-mode render would otherwise allocate cap x maxTail doubles -- 86 GB behind a C2 batch)
+  if (needTail && ((size_t)cap * maxTail > w.tail.n)) HIP_TRY(w.tail.alloc((size_t)cap * maxTail));
   w.maxTail = maxTail;
   HIP_TRY(w.counters.alloc(N_COUNTERS));
   HIP_TRY(w.filterTable.alloc(256));
@@ -1585,7 +1587,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     hipEvent_t evGen = sc->getEvent();
     (void)hipEventRecord(evGen, s);
     if (hostBuf) {
-      HIP_TRY(w.aosSamples.alloc((size_t)w.cap * rd->sample_stride));
+      HIP_TRY(w.aosSamples.alloc((size_t)((cap + 63u) & ~63u) * rd->sample_stride));
       HIP_TRY(hipMemcpyAsync(w.aosSamples.p, rd->sample_vec + (size_t)p0 * spp * rd->sample_stride,
                              (size_t)nslots * rd->sample_stride * sizeof(float), hipMemcpyHostToDevice, s));
       L.transpose_samples(w.aosSamples.p, rd->sample_stride, st, rp.nFloats, s);

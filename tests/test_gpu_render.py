@@ -541,3 +541,60 @@ def test_state_layout_is_chosen_from_the_pilot_batch_densities():
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)
     assert res.returncode == 0 and "OK" in res.stdout, (res.stdout[-1000:], res.stderr[-2000:])
     assert res.stderr.count("state-layout pilot") == 3, res.stderr[-2000:]   # once per scene
+
+
+def _serial_recording(ob, prims, r, spp, max_tail=40):
+    """The reference's own sample sequence: ONE serial Random(taskNum) stream through the sampler and the integrator
+    (sampler_renderer.dart:137), recorded by the oracle in tile order (the reference's default pixel order)."""
+    r.sampler.pixelSampler = core.TilePixelSampler()
+    fd = r.camera.film
+    n = (fd.width + 1) * (fd.height + 1) * spp
+    rec = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=0), record=n, max_tail=max_tail)
+    return rec, n
+
+
+@pytest.mark.parametrize("pipelines", [b"1", b"2"])
+def test_serial_stream_replay_across_several_batches(ob, gpu, pipelines):
+    """the host-buffer staging hand-over between batches (include/dartray_hip.h: the sample buffers of
+    a batch are staged before the next batch reuses the area).  A recorded serial stream of 129 x 129 x 16 = 266 256 samples
+    replayed with at most 2^16 slots per batch -- five batches -- equals the recording; DARTRAY_PIPELINES=2 is accepted (host
+    buffers always run on one pipeline)."""
+    prims, mk = scenes.config("C2", xres=128, yres=128, spp=16, blob=(40, 20))
+    r = mk()
+    rec, n = _serial_recording(ob, prims, r, 16)
+    assert n == 129 * 129 * 16
+    lib = _abi.lib()
+    r.sampler = core.HostBufferSampler(r.camera, 16, rec["pixel_xy"][::16], rec["sample_vec"], rec["tail"])
+    scene = scenes.make_scene(prims)
+    whole = r.render(scene)
+    assert r.last_stats["batches"] == 1
+    try:
+        _abi.check(lib.dr_set_option(b"BATCH_BITS", b"16"))
+        _abi.check(lib.dr_set_option(b"PIPELINES", pipelines))
+        out = r.render(scene)
+        assert r.last_stats["batches"] == 5
+    finally:
+        _abi.check(lib.dr_set_option(b"BATCH_BITS", None))
+        _abi.check(lib.dr_set_option(b"PIPELINES", None))
+    assert np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"])
+    assert np.array_equal(whole.film, rec["film"])
+
+
+def test_serial_stream_replay_of_a_million_samples(ob, gpu):
+    """"identical Sampler RNG seeds" at scale -- 129 x 129 x 64 = 1 065 024 samples of the C2-type
+    scene (3 600-triangle blob) drawn from the reference's one serial generator, replayed through DR_SAMPLER_HOST_BUFFER in
+    batches of 2^18: the film and the image equal the serial recording bit for bit."""
+    prims, mk = scenes.config("C2", xres=128, yres=128, spp=64, blob=(60, 30))
+    r = mk()
+    rec, n = _serial_recording(ob, prims, r, 64)
+    assert n == 1065024
+    lib = _abi.lib()
+    r.sampler = core.HostBufferSampler(r.camera, 64, rec["pixel_xy"][::64], rec["sample_vec"], rec["tail"])
+    try:
+        _abi.check(lib.dr_set_option(b"BATCH_BITS", b"18"))
+        out = r.render(scenes.make_scene(prims))
+        assert r.last_stats["batches"] == 5
+    finally:
+        _abi.check(lib.dr_set_option(b"BATCH_BITS", None))
+    assert np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"])
+    assert (rec["tail_count"] > 0).mean() > 0.2  # bounces >= 3 and Russian roulette draw from the recorded tail
