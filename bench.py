@@ -246,6 +246,7 @@ def main():
                          "verbatim, tiles of the 4096^2 x 1024 spp image; strong-c2 = tiles of the 1024^2 image; samples = every rank "
                          "renders 256 spp of the whole C2 image with its own seed, films summed")
     ap.add_argument("--cpu-pixels", type=int, default=96, help="cpu baseline: side of the strided pixel grid")
+    ap.add_argument("--trace-kernels", default=None, help="A/B runs: force the traversal kernels (closest,any), e.g. 2,3 (default: the scene's pilot)")
     args = ap.parse_args()
 
     if check_world(args.gpus, int(os.environ.get("WORLD_SIZE", "0"))) == "launch":
@@ -339,6 +340,8 @@ class Run:
         self.dev = self.scene._device()  # dr_scene_create: validation, pair records, uploads (host pointers in)
         self.create_ms = (time.perf_counter() - t0) * 1e3
         self.lib = _abi.lib()
+        if getattr(args, "trace_kernels", None):
+            self.dev.trace_kernels(tuple(int(x) for x in args.trace_kernels.split(",")))
 
     def step(self):
         from dartray_amd import _abi, dist as drdist

@@ -1264,14 +1264,18 @@ __global__ void k_tl_iota(uint32_t* v, uint32_t n) {
 // visit if the ray ever gets to pop it, like the reference; a run of them is a count in a register / one merged entry),
 // a child that passes is pushed as a bare reference and expanded when popped with no further test.  No entry parameter
 // next to the reference, no re-test, no pruning pass: 4 bytes per entry instead of 8, and direction / minDistance /
-// maxDistance / the queue handle wait in LDS between refill and leaf test as in k_trace -- 16 + 8 rows = 24 KiB per
-// workgroup and <= 80 VGPRs: six workgroups per CU where k_trace3<1> had five.
+// maxDistance / the queue handle wait in LDS between refill and leaf test as in k_trace -- 14 + 8 rows = 22 KiB per
+// workgroup and 70 VGPRs: seven workgroups per CU where k_trace3<1> had five.
 // ===========================================================================
+// 14 stack rows + 8 rows of cold ray state = 22 KiB per workgroup and 70 VGPRs => SEVEN workgroups per CU, like k_trace.  Measured:
+// C4 any-hit 113.3 (k_trace3<1>, 5 workgroups) -> 103.6 ms with 16 rows / 6 workgroups, 104.6 with 14 / 7; on the cache-resident C2
+// 16 / 6 loses to k_trace<1> (114 against 96 ms) and 14 / 7 equals it (96.0): the seventh workgroup matters more than two stack rows.
+// 12 rows / 8 workgroups spill (64 VGPRs): C4 117 ms.
 #ifndef DR_PSTACK_A
-#define DR_PSTACK_A 16
+#define DR_PSTACK_A 14
 #endif
 #ifndef DR_TRACE3A_WAVES
-#define DR_TRACE3A_WAVES 6
+#define DR_TRACE3A_WAVES 7
 #endif
 #define PREF_DEADN 0x60000000u  // (axis bits == 3: no interior reference carries them) | number of merged dead entries
 
