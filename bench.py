@@ -147,7 +147,12 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
              "achieved_is": "algorithmic bytes per second, not HBM traffic",
              "alg_over_measured_copy": round(sa / copy_gbps, 4) if copy_gbps else None,
              "alg_bytes_per_item": round(sb / max(1, st["shade_items"]), 1),
-             "items": int(st["shade_items"]), "vertices": int(st["shade_vertices"])}
+             "items": int(st["shade_items"]), "vertices": int(st["shade_vertices"]),
+             # rays the shading stages queued: continuation, MIS (BSDF-sampled direction towards the light) and shadow rays.  List entries
+             # without a vertex = items - vertices; of those, the ones known at push time (a path that ended with a MIS ray pending:
+             # Q_RESOLVE_BIT) = items - camera_samples - cont (every later entry either continues or is resolve-only)
+             "cont_rays": int(st["shade_cont"]), "mis_rays": int(st["shade_mis"]), "shadow_rays": int(st["shade_shadow"]),
+             "resolve_only_entries": int(st["shade_items"] - st["camera_samples"] - st["shade_cont"])}
     gen = None
     if gen_bytes_per_sample and st.get("gen_ms"):
         gb = gen_bytes_per_sample * st["camera_samples"]

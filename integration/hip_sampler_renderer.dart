@@ -187,6 +187,10 @@ typedef _CommIdD = int Function(Pointer<Uint8>, int);
 typedef _CommInitC = Int32 Function(Int32, Int32, Pointer<Uint8>, Uint64);
 typedef _CommInitD = int Function(int, int, Pointer<Uint8>, int);
 typedef _CommVoidC = Int32 Function();
+typedef _SetOptionC = Int32 Function(Pointer<Utf8>, Pointer<Utf8>);
+typedef _SetOptionD = int Function(Pointer<Utf8>, Pointer<Utf8>);
+typedef _SetLayoutC = Int32 Function(Pointer<Void>, Int32);
+typedef _SetLayoutD = int Function(Pointer<Void>, int);
 typedef _CommVoidD = int Function();
 typedef _DestroyC = Void Function(Pointer<Void>);
 typedef _DestroyD = void Function(Pointer<Void>);
@@ -236,6 +240,29 @@ class HipSamplerRenderer extends Renderer {
   static final _CommVoidD _commDestroy = _lib.lookupFunction<_CommVoidC, _CommVoidD>('dr_comm_destroy');
   static final _CommVoidD _commWorld = _lib.lookupFunction<_CommVoidC, _CommVoidD>('dr_comm_world');
   static final _CommVoidD _commRank = _lib.lookupFunction<_CommVoidC, _CommVoidD>('dr_comm_rank');
+  static final _CommVoidD _commAvailable = _lib.lookupFunction<_CommVoidC, _CommVoidD>('dr_comm_available');
+  static final _SetOptionD _setOption = _lib.lookupFunction<_SetOptionC, _SetOptionD>('dr_set_option');
+  static final _SetLayoutD _setStateLayout = _lib.lookupFunction<_SetLayoutC, _SetLayoutD>('dr_scene_set_state_layout');
+
+  /// Can this process join a multi-GPU render?  Binds librccl and checks its version WITHOUT talking to another rank, so
+  /// that the workers can agree on it before anyone blocks in [commInit] (hip_render_manager.dart).
+  static bool commAvailable(int device) {
+    _checkStatic(_init(device));
+    return _commAvailable() == 0;
+  }
+
+  /// A tuning / diagnostic switch of the library (the DARTRAY_* names of include/dartray_hip.h, without setenv): read
+  /// at every use, so it applies from the next render on; value null returns the switch to the environment's value.
+  static void setOption(String name, String value) {
+    Pointer<Utf8> n = name.toNativeUtf8();
+    Pointer<Utf8> v = value == null ? nullptr : value.toNativeUtf8();
+    try {
+      _checkStatic(_setOption(n, v));
+    } finally {
+      calloc.free(n);
+      if (v != nullptr) calloc.free(v);
+    }
+  }
   // for hosts that keep the film on the device themselves (device pointers come from their own HIP binding)
   static final _RenderDeviceD renderDevice = _lib.lookupFunction<_RenderDeviceC, _RenderDeviceD>('dr_render_device');
   static final _FilmReduceD filmReduce = _lib.lookupFunction<_FilmReduceC, _FilmReduceD>('dr_film_reduce');
