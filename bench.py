@@ -407,9 +407,9 @@ class Run:
         _abi.check(self.lib.dr_copy_bandwidth(1 << 30, 10, C.byref(copy)))  # measured HBM denominator (float4 copy, 2 GiB moved per pass)
         samples_per_step = self.H * self.W * self.spp * (world if (self.mode == "samples" and world > 1) else 1)
         value = samples_per_step * steps / dt / 1e6
-        picked = self.dev.trace_kernels()  # (closest, any): 2 = k_trace, 3 = k_trace3 (the pilot's choice for this scene)
+        picked = self.dev.trace_kernels()  # (closest, any): 2 = k_trace, 3 = k_trace3 / k_trace3a, 5 = k_trace3c (the pilot's choice for this scene)
         gbs = gen_alg_bytes_per_sample(gen_blocks(self.renderer, self.scene), self.spp)
-        roof, shade, gen, all_alg = roofline_objects(st, dt, copy.value, "k_trace3<0>" if picked[0] == 3 else "k_trace<0>", self.cfg, gbs)
+        roof, shade, gen, all_alg = roofline_objects(st, dt, copy.value, {3: "k_trace3<0>", 5: "k_trace3c"}.get(picked[0], "k_trace<0>"), self.cfg, gbs)
         agg = self.scene.aggregate
         if world == 1:
             par = "1 GPU"
@@ -433,6 +433,9 @@ class Run:
                        % (self.cfg, NAMES[self.cfg], self.renderer.surfaceIntegrator.maxDepth, self.res, self.res, self.spp),
                        "triangles": int(len(agg.tri_idx)), "bvh_nodes": int(len(agg.nodes)),
                        "bvh_builder": "%s (dr_bvh_build_%s), %.0f ms" % (agg.builder, "device" if agg.builder == "device" else "mixed", agg.build_ms),
+                       "trace_kernels": {"closest": {2: "k_trace<0>", 3: "k_trace3<0>", 5: "k_trace3c"}.get(picked[0], str(picked[0])),
+                                         "any_hit": {2: "k_trace<1>", 3: "k_trace3a"}.get(picked[1], str(picked[1])),
+                                         "picked_by": "--trace-kernels" if getattr(args, "trace_kernels", None) else "the scene's pilot batches"},
                        "samples_per_step": samples_per_step, "parallelism": par, "pipelines": args.pipelines,
                        "sampler_mode": "DR_SAMPLER_COUNTER (keyed per-pixel streams, bit-exact vs the oracle's same mode); the reference's "
                                        "single serial Random(taskNum) stream is replayed bit-exactly through DR_SAMPLER_HOST_BUFFER in the "

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -98,7 +99,7 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_SCENE_PREP", "DARTRAY_TREELET", "DARTRAY_TREELET_TOP",
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP", "DARTRAY_TREELET", "DARTRAY_TREELET_TOP",
     "DARTRAY_TREELET_ROUNDS", "DARTRAY_TREELET_MIN", "DARTRAY_TREELET_SHARDS", "DARTRAY_WORKSPACE", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
@@ -134,7 +135,7 @@ struct DrScene {
   bool traceCalibrated = false;
   int stateLayout = 0;          // path-state layout of this scene's path renders: 0 = not measured yet, 64 / 4 (LayoutOps)
   float layoutDensity = -1.f;   //   what decided it: the share of a pilot batch's slots still alive at the second bounce
-  float calibMs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // pilot of dr_render_device: [closest / any][v2 / v3] ms
+  float calibMs[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // pilot of dr_render_device: [closest / any][v2 / v3 / v3c] ms
   std::vector<int32_t> lightNSamples;
   bool hasSpecular = false;  // some material is a mirror / glass
   bool hasDeltaLight = false;
@@ -1227,8 +1228,9 @@ int dr_scene_set_trace_kernels(DrScene* sc, const uint32_t in[2]) {
     return DR_OK;
   }
   for (int k = 0; k < 2; ++k) {
-    if (in[k] != 2u && in[k] != 3u) return fail(DR_ERR_INVALID, "trace kernel must be 2 or 3 (or 0, 0 to measure again)");
-    if (in[k] == 3u && (!sc->d.pairs || sc->d.nquads)) return fail(DR_ERR_UNSUPPORTED, "this scene cannot use the sibling-pair kernel");
+    if (in[k] != 2u && in[k] != 3u && !(k == 0 && in[k] == 5u))
+      return fail(DR_ERR_INVALID, "trace kernel must be 2 or 3 (closest-hit rays also 5; or 0, 0 to measure again)");
+    if (in[k] != 2u && (!sc->d.pairs || sc->d.nquads)) return fail(DR_ERR_UNSUPPORTED, "this scene cannot use the sibling-pair kernels");
   }
   sc->d.traceKernel[0] = in[0];
   sc->d.traceKernel[1] = in[1];
@@ -1455,8 +1457,16 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (nBatches > 1 && npixTotal <= pixCapBatch + pixCapBatch / 4 && !(nPipesEnv >= 2 && !hostBuf)) nBatches = 1;
   const uint32_t pixPerBatch = (uint32_t)((npixTotal + nBatches - 1) / nBatches);
   const uint32_t cap = pixPerBatch * (uint32_t)spp;
+  const auto tAlloc0 = std::chrono::steady_clock::now();
+  const uint32_t capBefore = sc->ws.cap;
   int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0, maxStateWords);
   if (rc) return rc;
+  if (dr_option("DARTRAY_VERBOSE") && sc->ws.cap != capBefore) {
+    (void)hipDeviceSynchronize();
+    fprintf(stderr, "dartray_hip: path-state workspace for %u slots (%.1f GB) allocated in %.1f ms\n", sc->ws.cap,
+            (double)sc->ws.tiles.n * 4.0e-9 + (double)sc->ws.cap * 20.0e-9,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tAlloc0).count());
+  }
   if (dlSpec) {
     HIP_TRY(sc->ws.specFrames.alloc((size_t)sc->ws.cap * std::max(1, rd->max_depth) * DR_SPEC_FRAME_WORDS));
     HIP_TRY(sc->ws.specSp.alloc(sc->ws.cap));
@@ -1527,10 +1537,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const bool calibrateTrace = !sc->traceCalibrated && pilotOk && !dr_option("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads;
   const bool measureLayout = !layoutKnown && pilotOk;
   const bool calibrate = calibrateTrace || measureLayout;
-  const int pilotSets = calibrateTrace ? 3 : 1;  // traversal kernels: warm-up, v2 timed, v3 timed; the layout alone: one batch
+  const int pilotSets = calibrateTrace ? 4 : 1;  // traversal kernels: warm-up, v2 timed, v3 timed, v3c timed; the layout alone: one batch
   size_t calibPix = 0;  // pixels per calibration batch; the three batches are the first 3 * calibPix entries of `pixels`
   if (calibrate) {
-    uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 22, (uint64_t)npixTotal * spp / 64));
+    // (round 4: at least 2^24 samples per calibration batch.  With 2^22 -- 1 / 64 of C2 -- the launches are so short that their tails
+    // decide: the pair kernel, whose rays are half as many fetches long, looked 10 % FASTER than k_trace<0> on C2 and is 12 % slower in
+    // the full-size launches; at 2^24 and above the calibration batches rank the kernels as the full-size launches do.)
+    uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 24, (uint64_t)npixTotal * spp / 16));
     if (dr_option("DARTRAY_PILOT_BITS")) pilotSamples = 1ull << atoi(dr_option("DARTRAY_PILOT_BITS"));
     pilotSamples = std::min<uint64_t>(pilotSamples, (uint64_t)(pixPerBatch / 64 * 64) * spp);
     const size_t totalGroups = npixTotal / 64;
@@ -1720,8 +1733,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (calibrate) {
     hipEvent_t evP0 = sc->getEvent(), evP1 = sc->getEvent();
     HIP_TRY(hipEventRecord(evP0, s));
-    double perByte[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // [closest / any][v2 / v3]: ms per algorithmic GB
-    float ms[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    double perByte[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};  // [closest / any][v2 / v3 / v3c]: ms per algorithmic GB
+    float ms[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto readCtr = [&](TraceCounters* c) -> int {
       HIP_TRY(hipStreamSynchronize(s));
       HIP_TRY(hipMemcpy(c, sc->ctr.p, sizeof(TraceCounters), hipMemcpyDeviceToHost));
@@ -1733,9 +1746,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       sc->d.traceKernel[1] = keepKernel[1];
       return code;
     };
-    for (int set = 0; set < pilotSets; ++set) {  // warm-up (v2), v2 timed, v3 timed
-      const int impl = set == 2 ? 3 : 2;
-      if (calibrateTrace) sc->d.traceKernel[0] = sc->d.traceKernel[1] = (uint32_t)impl;
+    for (int set = 0; set < pilotSets; ++set) {  // warm-up (v2), v2 timed, v3 timed, v3c timed (its any-hit rays: v3 again)
+      const int impl = set == 2 ? 3 : (set == 3 ? 5 : 2);
+      const int col = set == 2 ? 1 : (set == 3 ? 2 : 0);
+      if (calibrateTrace) {
+        sc->d.traceKernel[0] = (uint32_t)impl;
+        sc->d.traceKernel[1] = impl == 5 ? 3u : (uint32_t)impl;
+      }
       TraceCounters c0, c1;
       int prc = readCtr(&c0);
       if (prc) return abandon(prc);
@@ -1765,20 +1782,28 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
           (void)hipEventElapsedTime(&t, e.first, e.second);
           sum += t;
         }
-        ms[kind][impl - 2] = sum;
-        perByte[kind][impl - 2] = bytes[kind] > 0.0 ? (double)sum / (bytes[kind] * 1.0e-9) : 0.0;
+        ms[kind][col] = sum;
+        perByte[kind][col] = bytes[kind] > 0.0 ? (double)sum / (bytes[kind] * 1.0e-9) : 0.0;
       }
     }
     if (calibrateTrace) {
     for (int kind = 0; kind < 2; ++kind) {
       sc->d.traceKernel[kind] = perByte[kind][1] < 0.95 * perByte[kind][0] ? 3u : 2u;
-      sc->calibMs[kind][0] = ms[kind][0];
-      sc->calibMs[kind][1] = ms[kind][1];
+      for (int c = 0; c < 3; ++c) sc->calibMs[kind][c] = ms[kind][c];
+    }
+    // the closest-hit rays have a third candidate (round 4): the pair kernel with its cold state in LDS, six workgroups per CU --
+    // 5 % ahead of k_trace3<0> on the cache-resident C5 (and there, with it, ahead of k_trace<0>), level with it on C4
+    // -- 5 % ahead of k_trace3<0> in C5's full-size launches and level with it in C5's calibration batches (eight times
+    // smaller: they understate what a sixth workgroup returns, as they do for the shadow rays below), 1.4 % behind on C4 at
+    // full size and 3.5 % behind in its calibration batches: so it takes the tie, and k_trace3<0> stays where it is 2 % ahead
+    {
+      const double best3 = std::min(perByte[0][1], perByte[0][2]);
+      if (best3 < 0.95 * perByte[0][0]) sc->d.traceKernel[0] = perByte[0][2] < 1.02 * perByte[0][1] ? 5u : 3u;
     }
     // small launches understate v3's advantage on shadow rays (C4: -2 ... +6 % in a calibration batch, +25 % in the
     // full-size launches of the render): where the closest-hit rays prefer v3 clearly (10 %), the any-hit rays take
     // it unless the calibration batch found it more than 5 % slower (C2 / C5, where v3 loses, are 30 - 40 % slower)
-    if (perByte[0][1] < 0.90 * perByte[0][0] && perByte[1][1] <= 1.05 * perByte[1][0]) sc->d.traceKernel[1] = 3u;
+    if (std::min(perByte[0][1], perByte[0][2]) < 0.90 * perByte[0][0] && perByte[1][1] <= 1.05 * perByte[1][0]) sc->d.traceKernel[1] = 3u;
     sc->traceCalibrated = true;
     }
     HIP_TRY(hipEventRecord(evP1, s));
@@ -1786,8 +1811,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     firstPix = (size_t)pilotSets * calibPix;
     batchIndex = (size_t)pilotSets;
     if (calibrateTrace && dr_option("DARTRAY_VERBOSE"))
-      fprintf(stderr, "dartray_hip: traversal pilot (3 x %zu samples, rendered into the film), ms per algorithmic GB: closest v2 %.4f / v3 %.4f -> v%u; "
-              "any hit v2 %.4f / v3 %.4f -> v%u\n", calibPix * (size_t)spp, perByte[0][0], perByte[0][1], sc->d.traceKernel[0],
+      fprintf(stderr, "dartray_hip: traversal pilot (4 x %zu samples, rendered into the film), ms per algorithmic GB: closest v2 %.4f / v3 %.4f / v3c %.4f -> v%u; "
+              "any hit v2 %.4f / v3 %.4f -> v%u\n", calibPix * (size_t)spp, perByte[0][0], perByte[0][1], perByte[0][2], sc->d.traceKernel[0],
               perByte[1][0], perByte[1][1], sc->d.traceKernel[1]);
   }
 

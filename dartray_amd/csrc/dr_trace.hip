@@ -473,7 +473,42 @@ void trace_prof_dump() {
 #define TPROF(i)
 #define TPROF_COUNT(i, v)
 #define TPROF_FLUSH
+#ifndef DR_STACK_PROF
 void trace_prof_dump() {}
+#endif
+#endif
+// -DDR_STACK_PROF: a diagnostic build of the sibling-pair kernels that histograms, per ray, the deepest its todo stack got
+// (printed and cleared by dr_get_stats): how many LDS rows does a scene's traversal need before entries go to the global rows?
+#ifdef DR_STACK_PROF
+__device__ unsigned long long g_stackHist[2][40];
+#define SPROF_DECL int spMax = 0
+#define SPROF_PUSH() (spMax = sp > spMax ? sp : spMax)
+#define SPROF_RAY(any)                                                   \
+  do {                                                                   \
+    atomicAdd(&g_stackHist[any][spMax < 39 ? spMax : 39], 1ull);         \
+    spMax = 0;                                                           \
+  } while (0)
+void trace_prof_dump() {
+  unsigned long long h[2][40];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stackHist), sizeof(h)) != hipSuccess) return;
+  for (int a = 0; a < 2; ++a) {
+    double tot = 0, acc = 0;
+    for (int i = 0; i < 40; ++i) tot += (double)h[a][i];
+    if (tot == 0) continue;
+    fprintf(stderr, "stack_prof %s: rays %.4g; share of rays whose stack never exceeded d entries:", a ? "any-hit" : "closest", tot);
+    for (int i = 0; i < 40; ++i) {
+      acc += (double)h[a][i];
+      if (i >= 4 && i <= 32) fprintf(stderr, " %d:%.4f", i, acc / tot);
+    }
+    fprintf(stderr, "\n");
+  }
+  memset(h, 0, sizeof(h));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stackHist), h, sizeof(h));
+}
+#else
+#define SPROF_DECL
+#define SPROF_PUSH()
+#define SPROF_RAY(any)
 #endif
 
 template <int ANY, bool QUAD, int STACK, class IO>
@@ -816,19 +851,38 @@ DR_DEV uint32_t pack_ref(uint32_t ref, uint32_t meta) {
 #define DR_PARK_TH 16  // treelet-parked traversal: lanes that park together
 #endif
 
-template <int ANY, class IO, bool TL = false>
+// COLD (k_trace3c): direction, minDistance, maxDistance and the queue handle wait in 8 LDS rows per lane (`cold`) between the refill,
+// the leaf tests, the rare literal slab tests and the result store, as in k_trace / k_trace3a: they are re-read in front of every use
+// (reloadCold), so the loop that sets the occupancy does not hold them in registers.
+template <int ANY, class IO, bool TL = false, bool COLD = false, int PSTACK = DR_PSTACK>
 DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ldsRef, float* ldsE, uint32_t* spill,
-                        uint32_t spillStride, uint32_t spillHalf, uint32_t* work, TraceCounters* ctr, const TLArgs& tl = TLArgs()) {
-  const int lane = lane_id();
-  const unsigned long long ltMask = (1ull << lane) - 1ull;
+                        uint32_t spillStride, uint32_t spillHalf, uint32_t* work, TraceCounters* ctr, const TLArgs& tl = TLArgs(),
+                        uint32_t* cold = nullptr) {
+  static_assert(!(TL && COLD), "the treelet build keeps the ray in registers");
+  typedef __attribute__((address_space(3))) uint32_t cold_u32;
+#define COLD_TMAX() __hiloint2double((int)COLD_LD(7), (int)COLD_LD(6))
+#define lane lane_id()  /* (recomputed where it is needed: one mbcnt pair instead of a live register) */
+  // (rank of this lane among the set lanes of a mask: mbcnt, no 64-bit lane mask held in registers)
+  auto rankIn = [](unsigned long long m) -> uint32_t {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  };
   uint32_t nRays = 0, nNodes = 0, nTris = 0;
   TraceRay ray;
   ray.needF64 = false;
   uint32_t handle = 0, cur = 0;
-  int sp = 0, hit = -1, mode = M_IDLE;
-  bool retest = false;  // cur was popped inside the ambiguous band: evaluate the literal test on its own box
+  int sp = 0, hit = -1, mode = M_IDLE;  // mode: M_* in bits 0..1; bit 2 (M_RETEST): cur was popped inside the ambiguous band --
+                                        // evaluate the literal test on its own box (one register for both)
+#define M_RETEST 4
+#define MODE_IS(m) ((mode & 3) == (m))
   bool exhausted = false;
   uint32_t resNext = 0, resEnd = 0;
+  auto reloadCold = [&]() {
+    if constexpr (COLD) {
+      ray.d = COLD_D();
+      ray.tmin = COLD_TMIN();
+      ray.tmax = COLD_TMAX();
+    }
+  };
   // treelet-parked mode (TL): inBottom = the ray is inside a bottom sub-tree, entered when its stack held spEnter entries
   // (depth first: it has left the sub-tree exactly when the stack is lower than that again)
   bool inBottom = false;
@@ -840,25 +894,27 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
   }
 
   auto stackGet = [&](int i, uint32_t* ref, float* e) {
-    *ref = ldsRef[(i < DR_PSTACK ? i : DR_PSTACK - 1) * DR_TRACE_BLOCK];
-    *e = ldsE[(i < DR_PSTACK ? i : DR_PSTACK - 1) * DR_TRACE_BLOCK];
-    if (i >= DR_PSTACK) {
-      *ref = spill[(size_t)(i - DR_PSTACK) * spillStride];
-      *e = __uint_as_float(spill[spillHalf + (size_t)(i - DR_PSTACK) * spillStride]);
+    *ref = ldsRef[(i < PSTACK ? i : PSTACK - 1) * DR_TRACE_BLOCK];
+    *e = ldsE[(i < PSTACK ? i : PSTACK - 1) * DR_TRACE_BLOCK];
+    if (i >= PSTACK) {
+      *ref = *spill_at(spill, spillStride, i - PSTACK);
+      *e = __uint_as_float(*spill_at(spill + spillHalf, spillStride, i - PSTACK));
     }
   };
   auto stackSet = [&](int i, uint32_t ref, float e) {
-    if (i < DR_PSTACK) {
+    if (i < PSTACK) {
       ldsRef[i * DR_TRACE_BLOCK] = ref;
       ldsE[i * DR_TRACE_BLOCK] = e;
     } else if (i < DR_MAX_STACK) {
-      spill[(size_t)(i - DR_PSTACK) * spillStride] = ref;
-      spill[spillHalf + (size_t)(i - DR_PSTACK) * spillStride] = __float_as_uint(e);
+      *spill_at(spill, spillStride, i - PSTACK) = ref;
+      *spill_at(spill + spillHalf, spillStride, i - PSTACK) = __float_as_uint(e);
     }
   };
+  SPROF_DECL;
   auto push = [&](uint32_t ref, float e) {
     stackSet(sp, ref, e);
     ++sp;
+    SPROF_PUSH();
   };
   // A far child that can never be hit still is ONE visit when the reference pops it.  Closest-hit rays pop
   // every entry sooner or later, so the visit is counted right away and nothing is pushed; any-hit rays may
@@ -918,16 +974,16 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       const float R = 4.76837158203125e-07f, A = 1.0e-37f;
       const float eb = __fmaf_rn(fabsf(e), R, A);
       if (e - eb >= ray.tmaxHi) continue;  // entry >= maxDistance for certain: pruned, nothing fetched
-      retest = !(e + eb < ray.tmaxLo);     // not certainly before maxDistance (also NaN: needF64 rays)
+      const float tmaxLo = COLD ? __uint_as_float(__float_as_uint(ray.tmaxHi) - (ray.tmaxHi < 0.f ? 0xffffffffu : 1u)) : ray.tmaxLo;
       cur = ref;
-      mode = (ref & PREF_LEAF) ? M_LEAF : M_EXPAND;
+      mode = ((ref & PREF_LEAF) ? M_LEAF : M_EXPAND) | (!(e + eb < tmaxLo) ? M_RETEST : 0);  // retest: not certainly before maxDistance (also NaN: needF64 rays)
       return true;
     }
   };
 
   for (;;) {
     // ---- refill idle lanes (as in v2) ----
-    const unsigned long long idleMask = __ballot(mode == M_IDLE);
+    const unsigned long long idleMask = __ballot(MODE_IS(M_IDLE));
     const int nIdle = __popcll(idleMask);
     if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
       if (TL && tl.order && tl.shards > 1u) {
@@ -967,8 +1023,8 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
         }
       }
       const uint32_t take = min(resEnd - resNext, (uint32_t)nIdle);
-      if (mode == M_IDLE) {
-        const uint32_t j = (uint32_t)__popcll(idleMask & ltMask);
+      if (MODE_IS(M_IDLE)) {
+        const uint32_t j = rankIn(idleMask);
         if (TL && tl.order && j < take) {
           // resume a parked ray: its record carries the ray, the node it was about to expand and its stack
           const uint4* rec = tl.in + (size_t)tl.order[resNext + j] * DR_TL_REC_U4;
@@ -980,7 +1036,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
           handle = q2.w;
           cur = q3.x;
           sp = (int)(q3.y & 0xffffu);
-          retest = ((q3.y >> 16) & 1u) != 0;
+          const bool retestRec = ((q3.y >> 16) & 1u) != 0;
           {  // the rest of the record's first line in one go (8 entries: most stacks), the second line only when needed
             const uint4 v0 = rec[4], v1 = rec[5], v2 = rec[6], v3 = rec[7];
             const uint4 vv[4] = {v0, v1, v2, v3};
@@ -995,15 +1051,13 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
             stackSet(i, v.x, __uint_as_float(v.y));
             if (i + 1 < sp) stackSet(i + 1, v.z, __uint_as_float(v.w));
           }
-          mode = M_EXPAND;
+          mode = M_EXPAND | (retestRec ? M_RETEST : 0);
           inBottom = true;
           spEnter = sp;
         } else if (j < take) {
           io.load(resNext + j, ray, handle);
-          ++nRays;
           sp = 0;
           hit = -1;
-          retest = false;
           inBottom = false;
           // visit node 0 (its box and packed reference live in kernel arguments)
           bool ok = false;
@@ -1016,24 +1070,35 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
           if (ok) {
             cur = sc.rootRef;
             mode = (cur & PREF_LEAF) ? M_LEAF : M_EXPAND;
+            if constexpr (COLD) {
+              COLD_ST(0, __float_as_uint(ray.d.x));
+              COLD_ST(1, __float_as_uint(ray.d.y));
+              COLD_ST(2, __float_as_uint(ray.d.z));
+              COLD_ST(3, (uint32_t)__double2loint(ray.tmin));
+              COLD_ST(4, (uint32_t)__double2hiint(ray.tmin));
+              COLD_ST(5, handle);
+              COLD_ST(6, (uint32_t)__double2loint(ray.tmax));
+              COLD_ST(7, (uint32_t)__double2hiint(ray.tmax));
+            }
           } else {
             io.store(handle, ray, -1, sc);
           }
         }
       }
+      if (!(TL && tl.order)) nRays += take;  // wave-uniform: lane 0 reports it (a resumed record is no new ray)
       resNext += take;
     }
     bool hold = false;  // (TL) this lane waits for a batch of lanes to park with
     if constexpr (TL) {
       // ---- entering a bottom sub-tree: park the ray for the next round, or mark where it entered ----
       if (inBottom && sp < spEnter) inBottom = false;
-      const bool enter = mode == M_EXPAND && !inBottom && (cur & 0x1fffffffu) >= tl.topPairs;
+      const bool enter = MODE_IS(M_EXPAND) && !inBottom && (cur & 0x1fffffffu) >= tl.topPairs;
       bool park = enter && tl.out != nullptr && sp <= DR_TL_MAX_SP;
       // writing a record is ~100 instructions and a dozen stores: like the leaf tests it is done for a batch of lanes --
       // a lane that wants to park holds until DR_PARK_TH do or nobody else in the wave has anything to do
       unsigned long long parkMask = __ballot(park);
       if (parkMask != 0ull && __popcll(parkMask) < DR_PARK_TH &&
-          __ballot((mode == M_EXPAND && !park) || mode == M_LEAF || mode == M_DONE) != 0ull) {
+          __ballot((MODE_IS(M_EXPAND) && !park) || MODE_IS(M_LEAF) || MODE_IS(M_DONE)) != 0ull) {
         hold = park;
         parkMask = 0ull;
       }
@@ -1045,14 +1110,14 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
           fresh = wave_bcast_first(fresh);
         }
         if (park) {
-          const uint32_t rank = (uint32_t)__popcll(parkMask & ltMask);
+          const uint32_t rank = rankIn(parkMask);
           const uint32_t pos = rank < rem ? outNext + rank : fresh + (rank - rem);
           if (pos < tl.outCap) {
             uint4* rec = tl.out + (size_t)pos * DR_TL_REC_U4;
             rec[0] = uint4{__float_as_uint(ray.o.x), __float_as_uint(ray.o.y), __float_as_uint(ray.o.z), __float_as_uint(ray.d.x)};
             rec[1] = uint4{__float_as_uint(ray.d.y), __float_as_uint(ray.d.z), (uint32_t)__double2loint(ray.tmin), (uint32_t)__double2hiint(ray.tmin)};
             rec[2] = uint4{(uint32_t)__double2loint(ray.tmax), (uint32_t)__double2hiint(ray.tmax), (uint32_t)hit, handle};
-            rec[3] = uint4{cur, (uint32_t)sp | (retest ? 0x10000u : 0u), 0u, 0u};
+            rec[3] = uint4{cur, (uint32_t)sp | ((mode & M_RETEST) ? 0x10000u : 0u), 0u, 0u};
             for (int i = 0; i < sp; i += 2) {
               uint32_t ra, rb = 0u;
               float ea, eb = 0.f;
@@ -1079,40 +1144,46 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
         spEnter = sp;
       }
     }
-    const unsigned long long expMask = __ballot(mode == M_EXPAND);
-    unsigned long long leafMask = __ballot(mode == M_LEAF);
-    if ((expMask | leafMask | __ballot(mode == M_DONE)) == 0ull) {
+    const unsigned long long expMask = __ballot(MODE_IS(M_EXPAND));
+    unsigned long long leafMask = __ballot(MODE_IS(M_LEAF));
+    if ((expMask | leafMask | __ballot(MODE_IS(M_DONE))) == 0ull) {
       if (exhausted) break;
       continue;
     }
     bool finished = false;
     // ---- expand one interior node: ONE 64-byte fetch, two box tests ----
-    uint4 l0 = uint4{0, 0, 0, 0}, l1 = l0, r0 = l0, r1 = l0;
-    if (mode == M_EXPAND && !hold) {
+    // (the near child is the second record when the ray runs against the split axis, bvh_accel.dart:147-153: known from the
+    // reference's axis bits before the fetch, so the two halves are LOADED as near / far instead of being selected
+    // component by component afterwards -- 16 v_cndmask and their registers less per step)
+    uint4 n0 = uint4{0, 0, 0, 0}, n1 = n0, f0 = n0, f1 = n0;
+    if (MODE_IS(M_EXPAND) && !hold) {
+      const uint32_t axis = (cur >> 29) & 3u;
+      const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
+      const uint32_t nearHalf = iv < 0.f ? 2u : 0u;
       const uint4* pp = sc.pairs + 4 * (size_t)(cur & 0x1fffffffu);
-      l0 = pp[0], l1 = pp[1], r0 = pp[2], r1 = pp[3];
+      n0 = pp[nearHalf], n1 = pp[nearHalf + 1u], f0 = pp[2u - nearHalf], f1 = pp[3u - nearHalf];
     }
     // results of the rays that finished in the previous iteration, stored behind this iteration's fetches (vmcnt
     // retires in order: see trace_persistent)
-    if (mode == M_DONE) {
+    if (MODE_IS(M_DONE)) {
+      reloadCold();
+      if constexpr (COLD) handle = COLD_LD(5);
       io.store(handle, ray, hit, sc);
+      SPROF_RAY(ANY);
       mode = M_IDLE;
     }
-    if (mode == M_EXPAND && !hold) {
+    if (MODE_IS(M_EXPAND) && !hold) {
       bool alive = true;
-      if (retest) {
+      if (mode & M_RETEST) {
         // own box = union of the children's (bvh_accel.dart:521): the literal test the reference does at this pop
-        const float ux0 = fminf(__uint_as_float(l0.x), __uint_as_float(r0.x)), uy0 = fminf(__uint_as_float(l0.y), __uint_as_float(r0.y));
-        const float uz0 = fminf(__uint_as_float(l0.z), __uint_as_float(r0.z)), ux1 = fmaxf(__uint_as_float(l0.w), __uint_as_float(r0.w));
-        const float uy1 = fmaxf(__uint_as_float(l1.x), __uint_as_float(r1.x)), uz1 = fmaxf(__uint_as_float(l1.y), __uint_as_float(r1.y));
+        const float ux0 = fminf(__uint_as_float(n0.x), __uint_as_float(f0.x)), uy0 = fminf(__uint_as_float(n0.y), __uint_as_float(f0.y));
+        const float uz0 = fminf(__uint_as_float(n0.z), __uint_as_float(f0.z)), ux1 = fmaxf(__uint_as_float(n0.w), __uint_as_float(f0.w));
+        const float uy1 = fmaxf(__uint_as_float(n1.x), __uint_as_float(f1.x)), uz1 = fmaxf(__uint_as_float(n1.y), __uint_as_float(f1.y));
+        reloadCold();
         alive = slab_f64(ray, ux0, uy0, uz0, ux1, uy1, uz1);
-        retest = false;
+        mode &= 3;
       }
       if (alive) {
-        const uint32_t axis = (cur >> 29) & 3u;
-        const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
-        const bool neg = iv < 0.f;  // near = second child when the ray runs against the split axis (:147-153)
-        const uint4 n0 = neg ? r0 : l0, n1 = neg ? r1 : l1, f0 = neg ? l0 : r0, f1 = neg ? l1 : r1;
         const float nbx0 = __uint_as_float(n0.x), nby0 = __uint_as_float(n0.y), nbz0 = __uint_as_float(n0.z);
         const float nbx1 = __uint_as_float(n0.w), nby1 = __uint_as_float(n1.x), nbz1 = __uint_as_float(n1.y);
         const float fbx0 = __uint_as_float(f0.x), fby0 = __uint_as_float(f0.y), fbz0 = __uint_as_float(f0.z);
@@ -1124,13 +1195,17 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
           farE = __uint_as_float(0x7fc00000u);  // NaN: always evaluated literally when popped
         } else {
           const SlabB fb = slab_bounds(ray, fbx0, fby0, fbz0, fbx1, fby1, fbz1);
-          const bool sureIn = (fb.loU <= fb.hiL) && (fb.hiL > ray.tminHi);
+          // (COLD: one bracket end per bound is kept; the other is its neighbour or itself -- taking the neighbour only sends a
+          // few more boxes to the literal test)
+          const float tminHi = COLD ? __uint_as_float(__float_as_uint(ray.tminLo) + (ray.tminLo < 0.f ? 0xffffffffu : 1u)) : ray.tminHi;
+          const bool sureIn = (fb.loU <= fb.hiL) && (fb.hiL > tminHi);
           const bool sureOut = (fb.loL > fb.hiU) || (fb.hiU <= ray.tminLo);
           farE = fb.lo;
           if (sureOut) {
             farRef = PREF_DEAD;
           } else if (!sureIn) {
             double E;
+            reloadCold();
             if (slab_geom_f64(ray, fbx0, fby0, fbz0, fbx1, fby1, fbz1, &E)) farE = (float)E;
             else farRef = PREF_DEAD;
           }
@@ -1142,7 +1217,10 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
         // near child: visited now
         ++nNodes;
         int d = ray.needF64 ? -1 : slab_f32(ray, nbx0, nby0, nbz0, nbx1, nby1, nbz1);
-        if (d < 0) d = slab_f64(ray, nbx0, nby0, nbz0, nbx1, nby1, nbz1) ? 1 : 0;
+        if (d < 0) {
+          reloadCold();
+          d = slab_f64(ray, nbx0, nby0, nbz0, nbx1, nby1, nbz1) ? 1 : 0;
+        }
         if (d) {
           cur = pack_ref(n1.z, n1.w);
           mode = (cur & PREF_LEAF) ? M_LEAF : M_EXPAND;
@@ -1154,13 +1232,14 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       }
     }
     // ---- batched leaf tests ----
-    leafMask = __ballot(mode == M_LEAF);
-    const unsigned long long stillExp = __ballot(mode == M_EXPAND && !finished && !hold);
+    leafMask = __ballot(MODE_IS(M_LEAF));
+    const unsigned long long stillExp = __ballot(MODE_IS(M_EXPAND) && !finished && !hold);
     if (leafMask != 0ull && (__popcll(leafMask) >= DR_LEAF_TH || stillExp == 0ull)) {
-      if (mode == M_LEAF) {
+      if (MODE_IS(M_LEAF)) {
         const uint32_t leafN = (cur >> 26) & 31u, leafOff = cur & 0x3ffffffu;
         bool alive = true;
-        if (retest) {
+        reloadCold();
+        if (mode & M_RETEST) {
           // own box = union of the triangles' vertices (Triangle.worldBound, :238-241)
           float x0 = __uint_as_float(0x7f800000u), y0 = x0, z0 = x0, x1 = -x0, y1 = -x0, z1 = -x0;
           for (uint32_t i = 0; i < leafN; ++i) {
@@ -1171,7 +1250,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
             z0 = fminf(z0, fminf(q0.z, fminf(q1.y, q2.x))); z1 = fmaxf(z1, fmaxf(q0.z, fmaxf(q1.y, q2.x)));
           }
           alive = slab_f64(ray, x0, y0, z0, x1, y1, z1);
-          retest = false;
+          mode &= 3;
         }
         bool occluded = false, shrunk = false;
         if (alive) {
@@ -1195,7 +1274,13 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
             }
           }
         }
-        if (shrunk) pruneStack();
+        if (shrunk) {
+          if constexpr (COLD) {
+            COLD_ST(6, (uint32_t)__double2loint(ray.tmax));
+            COLD_ST(7, (uint32_t)__double2hiint(ray.tmax));
+          }
+          pruneStack();
+        }
         if (occluded) {
           hit = 0;
           finished = true;
@@ -1209,7 +1294,10 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
   if constexpr (TL) {
     if (lane == 0 && outEnd > outNext && tl.out) atomicAdd(&tl.outCount[1], outEnd - outNext);
   }
-  flush_counters(ctr, ANY, nRays, nNodes, nTris);
+  flush_counters(ctr, ANY, lane_id() == 0 ? nRays : 0u, nNodes, nTris);
+#undef lane
+#undef MODE_IS
+#undef M_RETEST
 }
 
 template <int ANY>
@@ -1221,9 +1309,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_trace3(DSce
   StateIO<ANY> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
   const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
-  trace_pairs<ANY>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x,
-                   spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr, stride,
-                   stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
+  trace_pairs<ANY>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride, stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
 }
 template <int ANY>
 __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_intersect3(DScene sc, const DrRay* rays, uint32_t n,
@@ -1233,9 +1319,29 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_intersect3(
   __shared__ float s_e[DR_PSTACK * DR_TRACE_BLOCK];
   RayIO<ANY> io{rays, out};
   const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
-  trace_pairs<ANY>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x,
-                   spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr, stride,
-                   stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
+  trace_pairs<ANY>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride, stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
+}
+
+// k_trace3c: the closest-hit pair traversal with its cold ray state in LDS.  Stacks are shallow -- on C4 98.8 % of the closest-hit
+// rays never hold more than 10 entries (the far children that fail are not pushed, and every hit prunes the stack), 99.96 % not more
+// than 13 (-DDR_STACK_PROF) -- so DR_PSTACK_C rows of 8-byte entries + 8 cold rows fit SIX workgroups per CU where k_trace3<0> runs five.
+#ifndef DR_PSTACK_C
+#define DR_PSTACK_C 9
+#endif
+#ifndef DR_TRACE3C_WAVES
+#define DR_TRACE3C_WAVES 6
+#endif
+__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3C_WAVES) k_trace3c(DScene sc, BatchState st, const uint32_t* queue,
+                                                                              const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
+                                                                              TraceCounters* ctr) {
+  __shared__ uint32_t s_ref[DR_PSTACK_C * DR_TRACE_BLOCK];
+  __shared__ float s_e[DR_PSTACK_C * DR_TRACE_BLOCK];
+  __shared__ uint32_t s_cold[8 * DR_TRACE_BLOCK];
+  StateIO<0> io{st, queue};
+  const uint32_t n = nQueue ? *nQueue : st.nslots;
+  const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
+  trace_pairs<0, StateIO<0>, false, true, DR_PSTACK_C>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride,
+                                                      stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK_C), work, ctr, TLArgs(), s_cold + threadIdx.x);
 }
 
 // Treelet-parked traversal (DARTRAY_TRACE_IMPL=4; TLArgs in dr_kernels.h): trace_pairs with its TL blocks compiled in.
@@ -1248,8 +1354,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_trace_tl(DS
   StateIO<ANY> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
   const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
-  trace_pairs<ANY, StateIO<ANY>, true>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x,
-                                       spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr, stride,
+  trace_pairs<ANY, StateIO<ANY>, true>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride,
                                        stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr, tl);
 }
 __global__ void k_tl_iota(uint32_t* v, uint32_t n) {
@@ -1298,6 +1403,7 @@ DR_DEV void trace_pairs_any(const DScene& sc, const IO& io, uint32_t n, uint32_t
     if (i < DR_PSTACK_A) ldsRef[i * DR_TRACE_BLOCK] = ref;
     else if (i < DR_MAX_STACK) *spill_at(spill, spillStride, i - DR_PSTACK_A) = ref;
   };
+  SPROF_DECL;
   auto push = [&](uint32_t ref) {
     if (deadTop) {
       stackSet(sp, PREF_DEADN | deadTop);
@@ -1306,6 +1412,7 @@ DR_DEV void trace_pairs_any(const DScene& sc, const IO& io, uint32_t n, uint32_t
     }
     stackSet(sp, ref);
     ++sp;
+    SPROF_PUSH();
   };
   // the literal test needs the f64 bounds of the ray: they wait in LDS
   auto boxHit = [&](float x0, float y0, float z0, float x1, float y1, float z1) -> bool {
@@ -1400,22 +1507,22 @@ DR_DEV void trace_pairs_any(const DScene& sc, const IO& io, uint32_t n, uint32_t
     }
     bool finished = false;
     // ---- expand one interior node: ONE 64-byte fetch, two box tests ----
-    uint4 l0 = uint4{0, 0, 0, 0}, l1 = l0, r0 = l0, r1 = l0;
+    uint4 n0 = uint4{0, 0, 0, 0}, n1 = n0, f0 = n0, f1 = n0;  // (loaded as near / far: see trace_pairs)
     if (mode == M_EXPAND) {
+      const uint32_t axis = (cur >> 29) & 3u;
+      const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
+      const uint32_t nearHalf = iv < 0.f ? 2u : 0u;
       const uint4* pp = (const uint4*)((const char*)sc.pairs + ((size_t)(cur & 0x1fffffffu) << 6));
-      l0 = pp[0], l1 = pp[1], r0 = pp[2], r1 = pp[3];
+      n0 = pp[nearHalf], n1 = pp[nearHalf + 1u], f0 = pp[2u - nearHalf], f1 = pp[3u - nearHalf];
     }
     // results of the rays that finished in the previous iteration, stored behind this iteration's fetches (vmcnt
     // retires in order: see trace_persistent)
     if (mode == M_DONE) {
       io.store(COLD_LD(5), ray, hit, sc);
+      SPROF_RAY(1);
       mode = M_IDLE;
     }
     if (mode == M_EXPAND) {
-      const uint32_t axis = (cur >> 29) & 3u;
-      const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
-      const bool neg = iv < 0.f;  // near = second child when the ray runs against the split axis (:147-153)
-      const uint4 n0 = neg ? r0 : l0, n1 = neg ? r1 : l1, f0 = neg ? l0 : r0, f1 = neg ? l1 : r1;
       // far child: what the reference pushes; its test cannot change before it is popped, so it is decided now
       if (boxHit(__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w), __uint_as_float(f1.x),
                  __uint_as_float(f1.y)))
@@ -1490,13 +1597,23 @@ static bool any8() {
   const char* e = dr_option("DARTRAY_ANY8");
   return e && atoi(e) != 0;
 }
-static int traceImpl(const DScene& sc, int anyHit, int force = 0) {
+// A/B: DARTRAY_CLOSEST_COLD=1 runs the closest-hit pair traversal with its cold ray state in LDS (k_trace3c)
+static bool coldClosest() {
+  const char* e = dr_option("DARTRAY_CLOSEST_COLD");
+  return e && atoi(e) != 0;
+}
+// Kernel ids (DScene.traceKernel, DARTRAY_TRACE_IMPL, dr_scene_set_trace_kernels): 1 first version, 2 k_trace, 3 sibling pairs (k_trace3<0> /
+// k_trace3a), 5 sibling pairs with the closest-hit rays' cold state in LDS (k_trace3c; the any-hit rays: k_trace3a as with 3).  Returned
+// here: 1 / 2 / 3, with `*cold` set for id 5 on closest-hit rays.
+static int traceImpl(const DScene& sc, int anyHit, int force = 0, bool* cold = nullptr) {
   const char* e = dr_option("DARTRAY_TRACE_IMPL");  // (read per launch: dr_set_option may change it between renders)
-  const int env = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : ((e && e[0] == '4') ? 3 : 0);  // 4: treelet-parked stage traversals (dr_api.hip); everything else v3
+  const int env = (e && ((e[0] >= '1' && e[0] <= '3') || e[0] == '5')) ? e[0] - '0' : ((e && e[0] == '4') ? 3 : 0);  // 4: treelet-parked stage traversals (dr_api.hip); everything else v3
   // v2 is the fastest on cache-resident trees, v3 (sibling pairs) on big incoherent ones:
   // unless DARTRAY_TRACE_IMPL fixes it, the choice is the one measured for this scene (sc.traceKernel, set by the
   // pilot of dr_render_device)
   int impl = force ? force : (env ? env : (sc.traceKernel[anyHit ? 1 : 0] ? (int)sc.traceKernel[anyHit ? 1 : 0] : 2));
+  if (cold) *cold = !anyHit && (impl == 5 || (impl == 3 && coldClosest()));
+  if (impl == 5) impl = 3;
   if (sc.nquads) return 2;                     // only v2 tests quadric primitives
   return (impl == 3 && !sc.pairs) ? 2 : impl;  // scenes the pair layout cannot encode use v2
 }
@@ -1518,13 +1635,15 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
 }
 void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
-  const int impl = traceImpl(sc, anyHit);
-  if (impl == 3) grid = std::min(grid, traceGridFor(anyHit && !any8() ? DR_TRACE3A_WAVES : DR_TRACE3_WAVES));  // k_trace3: 30 KiB of LDS, 5 resident; k_trace3a: 24 KiB, 6
+  bool cold = false;
+  const int impl = traceImpl(sc, anyHit, 0, &cold);
+  if (impl == 3) grid = std::min(grid, traceGridFor(anyHit ? (any8() ? DR_TRACE3_WAVES : DR_TRACE3A_WAVES) : (cold ? DR_TRACE3C_WAVES : DR_TRACE3_WAVES)));  // k_trace3: 30 KiB of LDS, 5 resident; k_trace3a: 22 KiB, 7; k_trace3c: 26 KiB, 6
   else if (!(impl == 2 && !sc.nquads)) grid = std::min(grid, traceGridFor(6));  // only k_trace fits 7 workgroups per CU
   const dim3 g(grid), b(DR_TRACE_BLOCK);
   if (impl == 3) {
     if (anyHit && any8()) hipLaunchKernelGGL(k_trace3<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else if (anyHit) hipLaunchKernelGGL(k_trace3a, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+    else if (cold) hipLaunchKernelGGL(k_trace3c, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace3<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
   } else if (impl == 1) {
     if (anyHit) hipLaunchKernelGGL(k_trace_v1<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);

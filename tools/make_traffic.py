@@ -90,7 +90,7 @@ def build(src, cfg, rnd):
             e["l2_hit_rate"] = t["TCC_HIT_sum"] / max(1.0, t["TCC_HIT_sum"] + t["TCC_MISS_sum"])
         res["kernels"][name] = e
     base = lambda k: k.split("::")[-1]
-    dom = next((k for k in res["kernels"] if base(k) == "k_trace3<0>"), None) or next(k for k in res["kernels"] if base(k) == "k_trace<0>")
+    dom = next((k for k in res["kernels"] if base(k) in ("k_trace3<0>", "k_trace3c")), None) or next(k for k in res["kernels"] if base(k) == "k_trace<0>")
     res["kernel"] = dom
     res["hbm_bytes_per_launch"] = res["kernels"][dom]["hbm_bytes_per_launch"]
     res["alg_bytes_per_launch"] = bench["roofline"]["alg_bytes_per_launch"]
