@@ -305,8 +305,9 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out);
 void dr_scene_destroy(DrScene* scene);
 
 /* Which traversal kernel each ray kind ([0] closest hit, [1] any hit) uses on this scene: 0 = not decided yet (the
- * first big render of a big scene measures both on ~1.5 % of its own samples: DrRenderStats.pilot_ms), 2 = one node
- * per step, 3 = sibling pairs.  Both are bit-exact; only speed depends on the choice.  A host that renders the same
+ * first big render of a big scene measures the candidates on calibration batches of its own samples, rendered into the
+ * film like any other: DrRenderStats.pilot_ms), 2 = one node per step, 3 = sibling pairs, 5 (closest-hit rays only) =
+ * sibling pairs with the ray's cold state in LDS, six workgroups per CU.  All are bit-exact; only speed depends on the choice.  A host that renders the same
  * scene again (another frame, another process) can store the measured choice and hand it back: the pilot is then
  * skipped.  Setting 0 makes the next big render measure again. */
 int dr_scene_get_trace_kernels(const DrScene* scene, uint32_t kernels_out[2]);
@@ -412,7 +413,8 @@ const char* dr_version(void);
  * needs no setenv in a long-lived foreign host.  name: with or without the DARTRAY_ prefix, any case; value NULL: back
  * to the environment's value; "": unset for this process.  Unknown names are DR_ERR_INVALID.  Results never depend on a
  * switch (all of them pick between bit-exact variants or print diagnostics).  The switches:
- *   TRACE_IMPL 1|2|3|4    traversal kernel for both ray kinds (default: the scene's measured choice; 4 = treelet-parked)
+ *   TRACE_IMPL 1|2|3|5|4  traversal kernel for both ray kinds (default: the scene's measured choice; 5 = the pair kernels with the
+ *                         closest-hit rays' cold state in LDS; 4 = treelet-parked); ANY8, CLOSEST_COLD: A/B variants of the pair kernels
  *   TRACE_WG_PER_CU n     workgroups of a persistent traversal launch per CU
  *   STATE_LAYOUT 64|4     path-state layout (default: picked per render from the pilot's stage-list densities)
  *   LAYOUT_PILOT 0        do not measure list densities; take the layout from the scene's lights as round 3 did

@@ -37,7 +37,7 @@ for cfg in $cfgs; do
     # 64-slot runs for C2 / C4, what the density pilot chooses too -- so that every launch of a pass is a full-size one)
     c2) e="DARTRAY_TRACE_IMPL=2 DARTRAY_LAYOUT_PILOT=0"; a=""; s="--steps 3 --warmup 1";;
     c4) e="DARTRAY_TRACE_IMPL=3 DARTRAY_LAYOUT_PILOT=0"; a="--config C4"; s="--steps 3 --warmup 1";;
-    c5) e="DARTRAY_TRACE_IMPL=2 DARTRAY_LAYOUT_PILOT=0"; a="--config C5"; s="--steps 2 --warmup 1";;
+    c5) e="DARTRAY_PILOT=0 DARTRAY_LAYOUT_PILOT=0"; a="--config C5 --trace-kernels 5,3"; s="--steps 2 --warmup 1";;  # (what C5's pilot picks since k_trace3c)
   esac
   X="--no-cpu-baseline --no-extra"
   if [ "$what" != pmc ]; then
