@@ -66,6 +66,7 @@ struct Workspace {
   uint32_t pixCap = 0;
   DevBuf<float> tiles;  // the tiled path state (see BatchState in dr_kernels.h): cap/64 tiles of 64*41+svWords words
   DevBuf<uint32_t> scr;  // compact samples: scramble words [2 * nBlocks][pixCap]
+  DevBuf<uint2> genState;  //   and the streams' generator states behind their burn-in draws [nBlocks][pixCap] (k_gen_burnin)
   DevBuf<double> tail;
   DevBuf<uint32_t> activeA, activeB, closestQ, anyQ, counters, spill;
   DevBuf<uint32_t> envQ;  // plain-triangle scenes under an environment map: k_env's list of a stage (cap entries)
@@ -99,7 +100,7 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP", "DARTRAY_TREELET", "DARTRAY_TREELET_TOP",
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP", "DARTRAY_TREELET", "DARTRAY_TREELET_TOP",
     "DARTRAY_TREELET_ROUNDS", "DARTRAY_TREELET_MIN", "DARTRAY_TREELET_SHARDS", "DARTRAY_WORKSPACE", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
@@ -349,6 +350,7 @@ int allocWorkspace(DrScene* sc, Workspace& w, uint32_t cap, const SampleForm& sf
   if (sf.compact) {
     w.pixCap = std::max(w.pixCap, pixCap);
     HIP_TRY(w.scr.alloc(2 * (size_t)sf.nBlocks * w.pixCap));
+    HIP_TRY(w.genState.alloc((size_t)sf.nBlocks * w.pixCap));
   }
   // (sized for THIS render's batches, not for the largest batch the workspace has ever held: a small replay after a big
   // counter-mode render would otherwise allocate cap x maxTail doubles -- 86 GB behind a C2 batch)
@@ -370,6 +372,10 @@ BatchState makeState(Workspace& w, const SampleForm& sf, const int2* pix, uint32
   st.tiles = w.tiles.p;  // field offsets inside a tile: the F_* constants of dr_kernels.h
   st.svFloat = sf.compact ? 0u : 1u;
   st.svScr = sf.compact ? w.scr.p : nullptr;
+  {  // DARTRAY_GEN_PREPASS=0 (A/B, tests): the shuffle kernels seed and burn in their streams themselves
+    const char* pp = dr_option("DARTRAY_GEN_PREPASS");
+    st.genState = sf.compact && !(pp && atoi(pp) == 0) ? w.genState.p : nullptr;
+  }
   st.pixCap = w.pixCap;
   st.specFrames = w.specFrames.p;
   st.specSp = w.specSp.p;

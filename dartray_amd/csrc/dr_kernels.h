@@ -134,6 +134,9 @@ struct BatchState {
   uint32_t svFloat;
   uint32_t pixCap;
   uint32_t* svScr;    // [2 * nBlocks][pixCap]
+  // device sampler, compact form: the generator state of every (LD block, batch pixel) stream behind its scramble words and
+  // its burn-in draws (k_gen_burnin), [nBlocks][pixCap] (lo, hi); null: the shuffle kernels seed and burn in themselves
+  uint2* genState;
   // DirectLighting over mirror / glass (Integrator.SpecularReflect / SpecularTransmit, integrator.dart:187-290): the
   // per-slot stack of suspended vertices, [level][cap] SpecFrame records, and its depth per slot; null otherwise
   float* specFrames;

@@ -250,6 +250,35 @@ DR_DEV int gen_block(const RenderParams& rp) {
   for (uint32_t i = 0; i < blockIdx.y; ++i) m &= m - 1ull;
   return __ffsll((long long)m) - 1;
 }
+// The part of a (pixel, LD block) stream in front of its shuffle -- seeding, the one or two scramble words, and the spp draws of
+// the one-entry Shuffles (montecarlo.dart:294-303,524-551: `other = i + r % 1`, values that only advance the generator) -- needs no
+// table.  In the shuffle kernels it ran at the occupancy a CU's LDS leaves them (one wave per SIMD at 512 spp) and was half of
+// their generator steps; here it runs one thread per stream at full occupancy and leaves the generator state behind.
+__global__ void __launch_bounds__(256) k_gen_burnin(RenderParams rp, BatchState st, uint32_t npix) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const int k = gen_block(rp);
+  const bool is2D = k < 2 || k >= 3 + rp.n1D;
+  const int2 xy = st.pix[p];
+  const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
+  DartRandom rng;
+  rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
+  st.svScr[(size_t)(2 * k) * st.pixCap + p] = rng.randomUint();
+  st.svScr[(size_t)(2 * k + 1) * st.pixCap + p] = is2D ? rng.randomUint() : 0u;
+  // spp draws: plain steps; a lane that met the one value in 2^32 that Random.nextInt redraws does them again the slow way
+  const DartRandom saved = rng;
+  bool rare = rp.genSlowDraws != 0;
+  for (int i = 0; i < rp.spp; ++i) {
+    rng.step();
+    rare |= rng.lo == 0xffffffffu;
+  }
+  if (rare) {
+    rng = saved;
+    for (int i = 0; i < rp.spp; ++i) (void)rng.randomUint();
+  }
+  st.genState[(size_t)k * st.pixCap + p] = make_uint2(rng.lo, rng.hi);
+}
+
 template <class PT>
 __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchState st, uint32_t npix) {
   extern __shared__ __align__(16) unsigned char s_raw[];
@@ -269,10 +298,16 @@ __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchSta
   const int2 xy = st.pix[p];
   const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
   DartRandom rng;
-  rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
-  // LDShuffleScrambled1D/2D with nSamples == 1 (montecarlo.dart:524-551)
-  st.svScr[(size_t)(2 * k) * st.pixCap + p] = rng.randomUint();
-  st.svScr[(size_t)(2 * k + 1) * st.pixCap + p] = is2D ? rng.randomUint() : 0u;
+  if (st.genState) {  // k_gen_burnin has seeded the stream, drawn its scrambles and made its burn-in draws
+    const uint2 gs = st.genState[(size_t)k * st.pixCap + p];
+    rng.lo = gs.x;
+    rng.hi = gs.y;
+  } else {
+    rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
+    // LDShuffleScrambled1D/2D with nSamples == 1 (montecarlo.dart:524-551)
+    st.svScr[(size_t)(2 * k) * st.pixCap + p] = rng.randomUint();
+    st.svScr[(size_t)(2 * k + 1) * st.pixCap + p] = is2D ? rng.randomUint() : 0u;
+  }
   // randomUint() is one generator step unless the step lands on 0xffffffff (it then steps again: once in 2^32).  A loop
   // around every step is a branch per step in a serial chain; instead a GROUP of draws is made with plain steps and
   // redone the slow way from the saved state if any lane of the wave saw the rare value.
@@ -292,7 +327,8 @@ __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchSta
       }
     }
   };
-  for (int i = 0; i < spp; i += 16) draws(nullptr, 16);  // Shuffle of ONE entry: other = i + r % 1 (:294-303), spp times
+  if (!st.genState)
+    for (int i = 0; i < spp; i += 16) draws(nullptr, 16);  // Shuffle of ONE entry: other = i + r % 1 (:294-303), spp times
   for (int i = 0; i < spp; ++i) at(i) = (PT)i;
   // Fisher-Yates (montecarlo.dart:294-303), FOUR steps at a time.  One lane's shuffle is a serial chain (generator ->
   // partner -> LDS read -> LDS writes) and at 512 / 1024 spp only one or two waves fit a CU's LDS, so nothing hides the
@@ -392,11 +428,17 @@ __global__ void __launch_bounds__(128) k_gen_samples_pc(RenderParams rp, BatchSt
     const int2 xy = st.pix[valid ? p : npix - 1u];
     const uint64_t pixelIndex = (uint64_t)(xy.y - rp.extY0) * (uint64_t)rp.extW + (uint64_t)(xy.x - rp.extX0);
     DartRandom rng;
-    rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
-    const uint32_t scr0 = rng.randomUint(), scr1 = is2D ? rng.randomUint() : 0u;  // LDShuffleScrambled1D/2D (montecarlo.dart:524-551)
-    if (valid) {
-      st.svScr[(size_t)(2 * k) * st.pixCap + p] = scr0;
-      st.svScr[(size_t)(2 * k + 1) * st.pixCap + p] = scr1;
+    if (st.genState) {  // (k_gen_burnin: seed, scrambles and burn-in draws done)
+      const uint2 gs = st.genState[(size_t)k * st.pixCap + (valid ? p : npix - 1u)];
+      rng.lo = gs.x;
+      rng.hi = gs.y;
+    } else {
+      rng.seed(dr_counter_key(rp.seed, pixelIndex, (uint64_t)k, 1));
+      const uint32_t scr0 = rng.randomUint(), scr1 = is2D ? rng.randomUint() : 0u;  // LDShuffleScrambled1D/2D (montecarlo.dart:524-551)
+      if (valid) {
+        st.svScr[(size_t)(2 * k) * st.pixCap + p] = scr0;
+        st.svScr[(size_t)(2 * k + 1) * st.pixCap + p] = scr1;
+      }
     }
     auto draws = [&](uint32_t* r, int n) {  // as in k_gen_samples_lm: plain steps, redone the slow way after a rare value
       const DartRandom saved = rng;
@@ -414,7 +456,8 @@ __global__ void __launch_bounds__(128) k_gen_samples_pc(RenderParams rp, BatchSt
         }
       }
     };
-    for (int i = 0; i < spp; i += 16) draws(nullptr, 16);  // Shuffle of ONE entry, spp times (:294-303)
+    if (!st.genState)
+      for (int i = 0; i < spp; i += 16) draws(nullptr, 16);  // Shuffle of ONE entry, spp times (:294-303)
     for (int g = 0; g < G; ++g) {
       if ((g & 3) == 0 && g + 4 > DR_GEN_RING) gen_wait(&s_flag[1], (uint32_t)(g + 4 - DR_GEN_RING));  // room for four more groups
       uint32_t r[4];
@@ -1785,7 +1828,11 @@ void launch_make_shtris(const DScene& sc, float4* out, uint64_t ntris, hipStream
 #ifndef DR_GEN_LANES_BIG
 #define DR_GEN_LANES_BIG 64
 #endif
-void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t npix, hipStream_t s) {
+void launch_gen_samples(const RenderParams& rp, const BatchState& stIn, uint32_t npix, hipStream_t s) {
+  // the pre-pass (k_gen_burnin) pays where the shuffle kernels run at one wave per SIMD -- above 256 spp: C5 151 -> 141.5 ms, the 1024-spp
+  // image 119 -> 112 -- and costs a launch where nine waves per CU hide the burn-in anyway (C2, 256 spp: 9.1 -> 9.4 ms)
+  BatchState st = stIn;
+  if (rp.spp <= 256) st.genState = nullptr;
   const int nBlocks = rp.blocks ? rp.nBlocks : 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
   const dim3 grid((npix + 63) / 64, nBlocks);
   if (!st.svFloat && rp.spp >= 64) {
@@ -1794,6 +1841,7 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& st, uint32_t n
     // (above 1024 spp a pixel's table is 4 / 8 KB: 32 / 16 pixels per group keep the group's tables within 128 KB)
     const int ln = lanesEnv ? lanesEnv : (rp.spp <= 128 ? 64 : (rp.spp <= 256 ? DR_GEN_LANES_256 : (rp.spp <= 1024 ? DR_GEN_LANES_BIG : (rp.spp <= 2048 ? 32 : 16))));
     const dim3 g((npix + ln - 1) / ln, nGen);
+    if (st.genState) hipLaunchKernelGGL(k_gen_burnin, dim3((npix + 255) / 256, nGen), dim3(256), 0, s, rp, st, npix);
     const size_t lds = (size_t)rp.spp * ln * (rp.spp <= 256 ? 1 : 2) + ((size_t)rp.spp + 1) * 4;
     if (rp.spp <= 256) {
       hipLaunchKernelGGL(k_gen_samples_lm<uint8_t>, g, dim3(ln), lds, s, rp, st, npix);

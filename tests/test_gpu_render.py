@@ -433,12 +433,17 @@ def test_unread_sample_blocks_can_be_left_out():
     # that path for every group -- the streams must not change
     # fourth run: a stage's any-hit launch after its closest-hit launch instead of beside it (DARTRAY_OVERLAP_ANY=0) and
     # the single-wave sampler kernel at 512 spp (DARTRAY_GEN_ONE_WAVE=1)
-    for gen_all, slow, serial in ((False, False, False), (True, False, False), (False, True, False), (False, False, True)):
-        path = os.path.join(ROOT, "gpurun_out", "film_gen%d%d%d.npy" % (gen_all, slow, serial))
+    # fifth / sixth run: without the sampler's pre-pass (DARTRAY_GEN_PREPASS=0: the shuffle kernels seed their streams, draw the
+    # scrambles and make the burn-in draws themselves, as before round 4), plain and with the slow draws
+    for gen_all, slow, serial, prepass in ((False, False, False, True), (True, False, False, True), (False, True, False, True),
+                                           (False, False, True, True), (False, False, False, False), (False, True, True, False)):
+        path = os.path.join(ROOT, "gpurun_out", "film_gen%d%d%d%d.npy" % (gen_all, slow, serial, prepass))
         os.makedirs(os.path.dirname(path), exist_ok=True)
         env = dict(os.environ)
-        for k in ("DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_GEN_SLOW_DRAWS", "DARTRAY_OVERLAP_ANY", "DARTRAY_GEN_ONE_WAVE"):
+        for k in ("DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_GEN_SLOW_DRAWS", "DARTRAY_OVERLAP_ANY", "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS"):
             env.pop(k, None)
+        if not prepass:
+            env["DARTRAY_GEN_PREPASS"] = "0"
         if gen_all:
             env["DARTRAY_GEN_ALL_BLOCKS"] = "1"
         if slow:
