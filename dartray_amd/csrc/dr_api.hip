@@ -1620,11 +1620,14 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     timed(3, evGen);
     uint32_t* C = w.counters.p;
     int wc = 0;  // work counters live at C[1024..], 8 per launch
+    int treeletErr = DR_OK;
     auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr) {
       hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
       (void)hipEventRecord(e0, ts);
-      if (treelets) (void)L.trace_treelets(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts, w.tl);
-      else L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
+      if (treelets) {
+        const int trc = L.trace_treelets(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts, w.tl);
+        if (trc != DR_OK && treeletErr == DR_OK) treeletErr = trc;
+      } else L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
       (void)hipEventRecord(e1, ts);
       if (pilot) pilot->ev[any].push_back({e0, e1});
       sc->traceEvents.push_back({e0, e1, any, after});
@@ -1731,6 +1734,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
                 b == 0 ? nslots : hc[248 * 0 + b - 1], hc[248 * 0 + b], hc[248 * 1 + b], hc[248 * 2 + b], hc[N_COUNTERS_TRACE + 64 * b]);
     }
     HIP_TRY(hipGetLastError());
+    if (treeletErr != DR_OK) return fail(treeletErr, "treelet-parked traversal: a device call failed (sort / counter read-back)");
     if (hostBuf) HIP_TRY(hipStreamSynchronize(s));  // host buffers of the next batch reuse the staging area
     return DR_OK;
   };

@@ -22,8 +22,6 @@
 
 namespace {
 
-#define PREF_LEAF_P 0x80000000u
-
 enum { ST_FIRST_BAD = 0, ST_BAD_KIND = 1, ST_BIG_LEAF = 2, ST_NOT_UNION = 3, ST_OVERFLOW = 4, ST_BAD_TRI = 5, ST_WORDS = 8 };
 enum { BAD_INTERIOR = 1, BAD_LEAF_RANGE = 2 };
 

@@ -861,7 +861,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
   static_assert(!(TL && COLD), "the treelet build keeps the ray in registers");
   typedef __attribute__((address_space(3))) uint32_t cold_u32;
 #define COLD_TMAX() __hiloint2double((int)COLD_LD(7), (int)COLD_LD(6))
-#define lane lane_id()  /* (recomputed where it is needed: one mbcnt pair instead of a live register) */
+  // (the lane number is recomputed where it is needed -- lane_id(): one mbcnt pair -- instead of living in a register)
   // (rank of this lane among the set lanes of a mask: mbcnt, no 64-bit lane mask held in registers)
   auto rankIn = [](unsigned long long m) -> uint32_t {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -998,7 +998,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
           const uint32_t s0 = (uint32_t)(((unsigned long long)n * tlShard) / tl.shards);
           const uint32_t s1 = (uint32_t)(((unsigned long long)n * (tlShard + 1u)) / tl.shards);
           uint32_t fresh = 0;
-          if (lane == 0) fresh = atomicAdd(work + tlShard * 16u, (uint32_t)DR_WORK_CHUNK);
+          if (lane_id() == 0) fresh = atomicAdd(work + tlShard * 16u, (uint32_t)DR_WORK_CHUNK);
           fresh = wave_bcast_first(fresh);
           if (fresh < s1 - s0) {
             resNext = s0 + fresh;
@@ -1010,7 +1010,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
         }
       } else if (resNext == resEnd) {
         uint32_t fresh = 0;
-        if (lane == 0) {
+        if (lane_id() == 0) {
           fresh = nRays == 0u ? __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // (see trace_persistent)
           if (fresh < n) fresh = atomicAdd(work, (uint32_t)DR_WORK_CHUNK);
         }
@@ -1106,7 +1106,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
         const uint32_t np = (uint32_t)__popcll(parkMask), rem = outEnd - outNext;
         uint32_t fresh = 0;
         if (rem < np) {  // the rest of this wave's reservation first, then a new one (positions are never left unused here)
-          if (lane == 0) fresh = atomicAdd(&tl.outCount[0], (uint32_t)DR_WORK_CHUNK);
+          if (lane_id() == 0) fresh = atomicAdd(&tl.outCount[0], (uint32_t)DR_WORK_CHUNK);
           fresh = wave_bcast_first(fresh);
         }
         if (park) {
@@ -1292,10 +1292,9 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     if (finished) mode = M_DONE;  // stored at the head of the next iteration
   }
   if constexpr (TL) {
-    if (lane == 0 && outEnd > outNext && tl.out) atomicAdd(&tl.outCount[1], outEnd - outNext);
+    if (lane_id() == 0 && outEnd > outNext && tl.out) atomicAdd(&tl.outCount[1], outEnd - outNext);
   }
   flush_counters(ctr, ANY, lane_id() == 0 ? nRays : 0u, nNodes, nTris);
-#undef lane
 #undef MODE_IS
 #undef M_RETEST
 }
@@ -1675,8 +1674,12 @@ int launch_trace_treelets(const DScene& sc, const BatchState& st, const uint32_t
   const dim3 g(grid), b(DR_TRACE_BLOCK);
   int keyBits = 1;
   while ((1ull << keyBits) < (unsigned long long)sc.npairs + 1ull && keyBits < 32) ++keyBits;
-  hipEvent_t e[4];
-  for (auto& x : e) (void)hipEventCreate(&x);
+  struct Events {  // (destroyed on every return path)
+    hipEvent_t v[4];
+    Events() { for (auto& x : v) (void)hipEventCreate(&x); }
+    ~Events() { for (auto& x : v) (void)hipEventDestroy(x); }
+    hipEvent_t operator[](int i) const { return v[i]; }
+  } e;
   (void)hipMemsetAsync(w.counts, 0, 64 * sizeof(uint32_t), s);
   if (!w.iotaReady) {
     hipLaunchKernelGGL(k_tl_iota, dim3(4096), dim3(256), 0, s, w.iota, w.outCap);
@@ -1746,7 +1749,6 @@ int launch_trace_treelets(const DScene& sc, const BatchState& st, const uint32_t
       (void)hipStreamSynchronize(s);  // (nResume is a host local the copy above reads)
     }
   }
-  for (auto& x : e) (void)hipEventDestroy(x);
   return DR_OK;
 }
 
