@@ -1381,6 +1381,9 @@ __global__ void k_tl_iota(uint32_t* v, uint32_t n) {
 #ifndef DR_TRACE3A_WAVES
 #define DR_TRACE3A_WAVES 7
 #endif
+#ifndef DR_REFILL_TH_3A
+#define DR_REFILL_TH_3A 24  // idle lanes before a refill (C4 any-hit: 8 / 16 / 24 idle lanes 111.2 / 105.1 / 101.8 ms; C5 indifferent)
+#endif
 #define PREF_DEADN 0x60000000u  // (axis bits == 3: no interior reference carries them) | number of merged dead entries
 
 template <class IO>
@@ -1452,7 +1455,7 @@ DR_DEV void trace_pairs_any(const DScene& sc, const IO& io, uint32_t n, uint32_t
     // ---- refill idle lanes (as in trace_persistent) ----
     const unsigned long long idleMask = __ballot(mode == M_IDLE);
     const int nIdle = __popcll(idleMask);
-    if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
+    if (!exhausted && (nIdle >= DR_REFILL_TH_3A || nIdle == 64)) {
       if (resNext == resEnd) {
         uint32_t fresh = 0;
         if (lane == 0) {
