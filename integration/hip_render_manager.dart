@@ -9,8 +9,9 @@
  *
  *   manager (this file, `HipRenderManager.render`)
  *     |- starts N workers:  dart hip_render_manager.dart --worker <scene.pbrt> <rank> <N> <dir>
- *     |     worker r: dr_init(r); rank 0 draws the RCCL unique id (HipSamplerRenderer.commUniqueId) and writes it to
- *     |     <dir>/id; the others wait for that file; all join the communicator (commInit);
+ *     |     worker r: dr_init(r); every rank says whether it can join (commAvailable) and all agree through files in <dir>;
+ *     |     rank 0 draws the RCCL unique id (HipSamplerRenderer.commUniqueId), writes it to <dir>/id, all agree again;
+ *     |     the others read the id; all join the communicator (commInit);
  *     |     every worker loads the scene with the 'hipsampler' renderer, tile share r of N (round-robin 32 x 32
  *     |     tiles: balanced even when the geometry sits in one corner of the image);
  *     |     HipSamplerRenderer.render -> dr_render_sharded: the tiles, ONE ncclReduce(sum, f32) of the full-frame
@@ -65,17 +66,31 @@ class HipRenderManager {
 
   // ---- worker side ----
   static Future<void> worker(String scenePath, int rank, int world, String dirPath) async {
+    // The handshake is symmetric phase by phase (as dartray_amd/dist.py's): every phase ends with a file per rank that says
+    // "ok" or "fail", and nobody enters the next phase -- in particular nobody blocks in ncclCommInitRank -- unless every
+    // rank said ok.  Phase 1: can this process join at all (dr_comm_available: binds librccl, talks to nobody)?
+    bool ok = true;
+    try {
+      ok = HipSamplerRenderer.commAvailable(rank);
+    } catch (e) {
+      ok = false;
+    }
+    await _agree(dirPath, 'available', rank, world, ok);
+    // Phase 2: rank 0 draws the unique id.
     File idFile = new File('$dirPath/id');
     Uint8List id;
     if (rank == 0) {
-      id = HipSamplerRenderer.commUniqueId(rank);
-      File tmp = new File('$dirPath/id.tmp');
-      await tmp.writeAsBytes(id, flush: true);
-      await tmp.rename(idFile.path);  // atomic: the others never see a half-written id
-    } else {
-      while (!await idFile.exists()) {
-        await new Future.delayed(const Duration(milliseconds: 5));
+      try {
+        id = HipSamplerRenderer.commUniqueId(rank);
+        File tmp = new File('$dirPath/id.tmp');
+        await tmp.writeAsBytes(id, flush: true);
+        await tmp.rename(idFile.path);  // atomic: the others never see a half-written id
+      } catch (e) {
+        ok = false;
       }
+    }
+    await _agree(dirPath, 'id', rank, world, ok);
+    if (rank != 0) {
       id = await idFile.readAsBytes();
     }
     HipSamplerRenderer.commInit(rank, rank, world, id);   // device == rank: one GPU per process
@@ -86,6 +101,29 @@ class HipRenderManager {
       }
     } finally {
       HipSamplerRenderer.commDestroy();
+    }
+  }
+
+  /// One phase of the workers' handshake: publish this rank's verdict, wait (bounded) for every rank's, and leave the job -- all
+  /// ranks alike, exit code 3 -- if anyone failed or never answered.
+  static Future<void> _agree(String dirPath, String phase, int rank, int world, bool ok) async {
+    File mine = new File('$dirPath/$phase.$rank.tmp');
+    await mine.writeAsString(ok ? 'ok' : 'fail', flush: true);
+    await mine.rename('$dirPath/$phase.$rank');
+    DateTime deadline = new DateTime.now().add(const Duration(seconds: 120));
+    for (int r = 0; r < world; ++r) {
+      File f = new File('$dirPath/$phase.$r');
+      while (!await f.exists()) {
+        if (new DateTime.now().isAfter(deadline)) {
+          LogSevere('HipRenderManager: rank $r never reached phase "$phase"');
+          exit(3);
+        }
+        await new Future.delayed(const Duration(milliseconds: 5));
+      }
+      if ((await f.readAsString()) != 'ok') {
+        LogSevere('HipRenderManager: rank $r failed in phase "$phase"');
+        exit(3);
+      }
     }
   }
 

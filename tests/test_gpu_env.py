@@ -62,3 +62,15 @@ def test_rotated_light_to_world(ob, gpu):
     cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
     r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 16), cam, core.PathIntegrator(4), core.EmissionIntegrator())
     _parity(ob, prims, r, env)
+
+
+def test_environment_map_taller_than_the_lds_copy(ob, gpu):
+    """k_env keeps the map's marginal distribution in LDS up to 8192 rows; a taller map (here 16 384 x 2 texels) searches the
+    global-memory arrays instead (k_env<false>) -- round 3 refused such a render with DR_ERR_UNSUPPORTED.  Same indices, same film."""
+    sky = scenes.sky_env(2, 16384)
+    assert sky.texels.shape[0] == 16384
+    floor = scenes._quad((-50, 0, -50), (50, 0, -50), (50, 0, 50), (-50, 0, 50), (0.6, 0.6, 0.6))
+    film = core.ImageFilm(20, 20)
+    cam = core.PerspectiveCamera.lookAt((0, 10, -30), (0, 0, 0), (0, 1, 0), 40.0, film)
+    r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 16), cam, core.PathIntegrator(4), core.EmissionIntegrator())
+    _parity(ob, [floor] + scenes.cornell_walls()[3:], r, sky)
