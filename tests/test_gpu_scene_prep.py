@@ -125,3 +125,30 @@ def test_malformed_trees_and_tables_are_refused_like_before(gpu):
     for prep in (None, b"host"):
         d = _create(a, prep)
         assert len(_pairs(d)[0]) == 0
+
+
+@pytest.mark.parametrize("order", [b"sib", b"veb:2:3", b"pad:2", b"dfs", b"top:5"])
+def test_experimental_pair_orders_trace_the_same_hits(gpu, ob, order):
+    """Every memory order of the pair records (the experimental ones are laid out by the host loops) gives the hits and the visit
+    counters of the oracle: the references inside the records are explicit."""
+    prims, _ = scenes.config("C2", xres=8, yres=8, spp=1, blob=(40, 20))
+    acc = core.BVHAccel(prims)
+    lib = _abi.lib()
+    rng = np.random.default_rng(3)
+    n = 20000
+    o = rng.uniform(-9, 9, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ray = core.Ray(o, d, 1e-3, np.inf)
+    osc = ob.OracleScene(prims)
+    rays = np.zeros(n, dtype=ob.RAY_DTYPE)
+    rays["o"], rays["d"], rays["tmin"], rays["tmax"] = o, d, 1e-3, np.inf
+    ref = osc.intersect(rays, any_hit=False)
+    try:
+        _abi.check(lib.dr_set_option(b"TRACE_IMPL", b"3"))
+        dev = _create(acc, None, order)
+        out = dev.intersect(ray, any_hit=False)
+    finally:
+        _abi.check(lib.dr_set_option(b"TRACE_IMPL", None))
+    assert len(_pairs(dev)[0]) > 0
+    assert np.array_equal(out["prim"], ref["prim"]) and np.array_equal(out["t"], ref["t"])
