@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 4, GPU run 4: treelet-parked traversal -- batched parking, control without the sort
+# round 4: treelet-parked traversal -- batched parking, and the control without the sort (DARTRAY_TREELET_SORT=0: that build's 1-bit radix-sort path faulted
+# after a few stages and the switch was removed again; profiles/r04_tl_c4_timings.txt keeps the lines it printed before)
 cd "$(dirname "$0")/.."
 out=gpurun_out/r04d; mkdir -p $out
 timeout 600 python -m pytest tests/test_gpu_render.py -m gpu -x -q -k "alternative_traversal" > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log; tail -3 $out/pytest.log
