@@ -6,18 +6,19 @@
 metric  : Msamples/s (primary + path rays), film pixels x spp per second, whole job over N GPUs
 workload: N = 1 -- configs[1] (C2): Cornell box + 1M-triangle displaced blob, PathIntegrator maxdepth 5,
           1024x1024, 256 spp (2.68e8 camera samples per step).
-          N > 1 -- the SAME workload per GPU ("scaling": "weak"): the C2 scene and view at 256 spp with N x the pixels
-          (a square image of side 1024 sqrt(N), rounded to whole 32-pixel tiles), its 32x32 tiles dealt round-robin
-          over the ranks (north_star; the reference's task split, render_manager.dart:100-141), every rank
-          accumulating a full-frame (X, Y, Z, weight) film and ONE RCCL reduce per step (dr_film_reduce of the C ABI:
-          ncclReduce over xGMI) summing them on rank 0 -- so value(N) / value(1) compares like with like and a step stays
-          ~0.45 s at every N.  Options: --scaling c3 (configs[2] verbatim: 4096x4096, 1024 spp, 1.72e10 samples per
-          step, total work fixed: ~14 s per step at N = 2), --scaling strong-c2 (the 1024x1024 image itself split),
-          --scaling samples (no tiles: every rank adds its own 256 spp of the C2 image, seed + rank).
-          At N > 1 the default run also appends, after the headline's timed region, BASELINE configs[2] itself as
-          "extra_configs"[0]: the 4096x4096 x 1024 spp image over the N ranks ("scaling": "strong"), first render +
-          ONE timed step with its own per_rank_step_ms / reduce_ms / one_gpu_same_workload (602 Msamples/s) -- about
-          57 s / N of rendering on top of the headline (--no-extra skips it).
+          N > 1 -- BASELINE configs[2] verbatim (C3; round 5: the N-rank HEADLINE, it used to be an extra): the C2 scene at
+          4096x4096, 1024 spp (1.72e10 samples per step), its 32x32 tiles dealt round-robin over the N ranks (north_star;
+          the reference's task split, render_manager.dart:100-141), every rank accumulating a full-frame (X, Y, Z,
+          weight) film and ONE RCCL reduce of the 268 MB film per step (dr_film_reduce of the C ABI: ncclReduce over
+          xGMI) summing them on rank 0; total work is the same for every N ("scaling": "strong"), --steps / --warmup are
+          honoured as given.  Expected run time (one GPU renders C3 in 28.5 s per step, 602 Msamples/s): a step is
+          ~28.5 s / N -- N = 8: 3.6 s, N = 4: 7.1 s, N = 2: 14.3 s -- so the driver's `--steps 20 --warmup 5` (+ the first
+          render) is ~1.6 min at N = 8, ~3.1 min at N = 4 and ~6.2 min at N = 2, plus ~15 s of scene build per process.
+          The same C2 scene per GPU as the N = 1 line is appended as "extra_configs"[0] ("scaling": "weak": the C2 view at
+          256 spp on a square image with N x the pixels, side 1024 sqrt(N) in whole 32-pixel tiles, 2 timed steps of
+          ~0.45 s; --no-extra skips it), so that a per-GPU-like-for-like figure sits next to the N = 1 line's.
+          Options: --scaling weak (that image as the headline), --scaling strong-c2 (the 1024x1024 image itself
+          split), --scaling samples (no tiles: every rank adds its own 256 spp of the C2 image, seed + rank).
           One "step" = one full pass of the hot path over the image.  Launch: `python bench.py --gpus N` starts
           the N ranks itself (torch.distributed.run, one process per GPU) unless it already runs under torchrun.
 Inputs (scene, BVH) are resident in HBM before the timed region; samples are generated on the device.  Synthetic
@@ -38,6 +39,7 @@ per GetSubWindow task rectangle (the reference's isolate-per-task model); "extra
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -70,6 +72,26 @@ def launch_ranks(args):
 def weak_resolution(res, world):
     """Side of the square image with `world` x the pixels of a res x res one, in whole 32-pixel tiles."""
     return int(round(res * world ** 0.5 / 32.0)) * 32
+
+
+def plan(world, scaling=None, config=None, res=0, spp=0, no_extra=False):
+    """What a run renders, as data (tested on the CPU: tests/test_bench_launch.py): the headline Run's (config, resolution,
+    spp, mode) and the extra runs appended after its timed region as (config, resolution, spp, mode, steps, warmup).
+    N = 1: configs[1] (C2) + short C4 / C5 runs.  N > 1: configs[2] (C3: 4096^2, 1024 spp, tiles over the N ranks, total
+    work fixed) + the weak C2 image (the N = 1 workload per GPU), short."""
+    mode = scaling or ("c3" if world > 1 else "weak")
+    cfg = config or ("C3" if world > 1 and mode == "c3" else "C2")
+    spp_ = spp or {"C2": 256, "C3": 1024, "C4": 64, "C5": 512}[cfg]
+    res_ = res or {"C2": 1024, "C3": 4096, "C4": 1024, "C5": 2048}[cfg]
+    if mode == "weak" and world > 1:
+        res_ = weak_resolution(res_, world)
+    extras = []
+    default_shape = not (no_extra or config or res or spp)
+    if world == 1 and default_shape:
+        extras = [("C4", 1024, 64, mode, 2, 1), ("C5", 2048, 512, mode, 2, 1)]
+    elif world > 1 and default_shape and mode == "c3":
+        extras = [("C2", weak_resolution(1024, world), 256, "weak", 2, 1)]
+    return {"headline": (cfg, res_, spp_, mode), "extras": extras}
 
 
 def check_world(gpus, world_env):
@@ -119,24 +141,29 @@ def gen_alg_bytes_per_sample(nblocks, spp):
     return nblocks * idx + 8.0 * nblocks / spp + 2 * idx + 32.0
 
 
-def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="C2", gen_bytes_per_sample=None):
+def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="C2", gen_bytes_per_sample=None, kernels_forced=False):
     alg = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
     launches = max(1, st["closest_launches"])
     achieved = alg / max(st["closest_ms"] * 1e-3, 1e-12) / 1e9
     all_alg = alg + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
-    bo = BOUND_OBSERVED.get(tag, {})
+    # (the observed bounds were read off the committed profiles of the kernels the pilots pick: not claimed for forced kernels)
+    bo = {} if kernels_forced else BOUND_OBSERVED.get(tag, {})
     roof = {"bound": bo.get("trace_bound", "hbm"), "bound_priced_against": "hbm",
+            "bound_source": "profiles/ (committed PMC passes of the pilots' kernels), not this run" if bo else "not profiled for these kernels",
             "kernel": "%s (closest-hit BVH traversal)" % closest_kernel,
             "achieved": round(achieved, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_GBPS, 4),
+            # an algorithmic-byte fraction at or above 1 has left the range where it discriminates (the bytes are served by caches):
+            # read frac_physical_of_copy / lane_utilisation / wait_share below instead
+            "saturated": bool(achieved / PEAK_GBPS > 1.0),
             "traffic": None,  # HBM-side bytes come from separate rocprofv3 --pmc passes: see "traffic_profiled" / "physical_*"
             "achieved_is": "algorithmic bytes per second (cache hits included), not HBM traffic",
             "hbm_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
             "alg_over_measured_copy": round(achieved / copy_gbps, 4) if copy_gbps else None,
             "alg_bytes_per_launch": round(alg / launches, 1),
             "avg_launch_ms": round(st["closest_ms"] / launches, 4), "launches": int(st["closest_launches"]),
-            "avg_launch_ms_note": ("HIP events around each k_trace<0> launch on its own stream; the stage's any-hit launch runs beside it on a second "
-                                   "stream (DARTRAY_OVERLAP_ANY=0 serialises them: profiles/r0*_kernel_stats_serial.csv, within 1 % of this figure)"
-                                   if os.environ.get("DARTRAY_OVERLAP_ANY", "1") != "0" else "one kernel at a time"),
+            "avg_launch_ms_note": ("HIP events around each %s launch on its own stream; the stage's any-hit launch runs beside it on a second "
+                                   "stream (DARTRAY_OVERLAP_ANY=0 serialises them: profiles/r0*_kernel_stats_serial.csv, within 1 %% of this figure)"
+                                   % closest_kernel if os.environ.get("DARTRAY_OVERLAP_ANY", "1") != "0" else "%s, one kernel at a time" % closest_kernel),
             "rank0_job_alg_GBps": round(all_alg / dt_total / 1e9, 2),
             "rank0_trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt_total, 4)}
     sb = shade_alg_bytes(st)
@@ -176,6 +203,12 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
             obj["physical_GBps"] = round(k["hbm_side_GBps"], 1)
             obj["physical_frac_of_spec"] = round(k["hbm_side_GBps"] / PEAK_GBPS, 4)
             obj["physical_frac_of_measured"] = round(k["hbm_side_GBps"] / copy_gbps, 4) if copy_gbps else None
+            # the figure to read next to `frac`: memory-side bytes per second against the copy rate this run measured
+            obj["frac_physical_of_copy"] = obj["physical_frac_of_measured"]
+            for src_key, dst_key in (("valu_lane_utilisation", "lane_utilisation"), ("wait_any_share_of_wave_cycles", "wait_share"),
+                                     ("l2_hit_rate", "l2_hit_rate")):
+                if k.get(src_key) is not None:
+                    obj[dst_key] = round(k[src_key], 4)
             obj["physical_source"] = prof["source"] + " (rocprofv3 --pmc: TCC_EA0_RDREQ 32/64/128 B + WRITE_SIZE per launch / kernel-trace launch time; not this run)"
         # memory-side bytes over algorithmic bytes, per kernel, both from the profiled run (1 = every byte fetched once;
         # below: caches absorb re-reads; above: partial lines / re-reads -- the first thing to fix)
@@ -205,9 +238,43 @@ BOUND_OBSERVED = {
 }
 
 
+def traffic_files(tag):
+    """The committed traffic files of this config, newest round first."""
+    pat = re.compile(r"r\d\d_%s_traffic\.json$" % tag.lower())
+    try:
+        return sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if pat.match(n)), reverse=True)
+    except OSError:
+        return []
+
+
+def kernel_profile(tag, names):
+    """What the committed PMC passes say about each named traversal kernel of this config (lane utilisation, wait share,
+    L2 hit rate, memory-side rate): the newest traffic file that has the kernel; {"profiled": False} when none has."""
+    out = {}
+    for role, kname in names.items():
+        hit = None
+        for fname in traffic_files(tag):
+            d = json.load(open(os.path.join(ROOT, "profiles", fname)))
+            k = next((v for n, v in d.get("kernels", {}).items() if n.split("::")[-1] == kname or n.split("::")[-1].startswith(kname + "(")), None)
+            if k:
+                hit = (fname, k)
+                break
+        if not hit:
+            out[role] = {"kernel": kname, "profiled": False}
+            continue
+        fname, k = hit
+        out[role] = {"kernel": kname, "profiled": True, "source": "profiles/" + fname,
+                     "lane_utilisation": round(k["valu_lane_utilisation"], 4) if k.get("valu_lane_utilisation") is not None else None,
+                     "wait_share": round(k["wait_any_share_of_wave_cycles"], 4) if k.get("wait_any_share_of_wave_cycles") is not None else None,
+                     "l2_hit_rate": round(k["l2_hit_rate"], 4) if k.get("l2_hit_rate") is not None else None,
+                     "physical_GBps": round(k["hbm_side_GBps"], 1) if k.get("hbm_side_GBps") else None,
+                     "avg_launch_ms_serial": round(k["avg_launch_ms_kernel_trace"], 3) if k.get("avg_launch_ms_kernel_trace") else None}
+    return out
+
+
 def profiled_kernels(tag):
     """Per-kernel entries of the newest committed traffic file of this config."""
-    for name in ("r04_%s_traffic.json" % tag.lower(), "r03_%s_traffic.json" % tag.lower(), "r02_%s_traffic.json" % tag.lower()):
+    for name in traffic_files(tag):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             d = json.load(open(path))
@@ -220,10 +287,7 @@ def profiled_kernels(tag):
 def profiled_traffic(tag):
     """HBM-side bytes per launch from committed rocprofv3 --pmc passes of the same command, labelled with the file
     they come from (never presented as this run's measurement)."""
-    for name in ("r04_%s_traffic.json" % tag.lower(), "r03_%s_traffic.json" % tag.lower(), "r02_%s_traffic.json" % tag.lower(),
-                 "r01_k_traffic.json" if tag == "C2" else None):
-        if not name:
-            continue
+    for name in traffic_files(tag) + (["r01_k_traffic.json"] if tag == "C2" else []):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             d = json.load(open(path))
@@ -247,9 +311,9 @@ def main():
                          "the ALU-bound traversal) -- per-kernel event times then overlap, so the roofline "
                          "object is only meaningful with 1")
     ap.add_argument("--scaling", default=None, choices=["c3", "weak", "strong-c2", "samples"],
-                    help="N > 1: weak (default) = tiles of the C2 image with N x the pixels (the N = 1 workload per GPU); c3 = configs[2] "
-                         "verbatim, tiles of the 4096^2 x 1024 spp image; strong-c2 = tiles of the 1024^2 image; samples = every rank "
-                         "renders 256 spp of the whole C2 image with its own seed, films summed")
+                    help="N > 1: c3 (default) = BASELINE configs[2] verbatim, tiles of the 4096^2 x 1024 spp image over the N ranks; weak = "
+                         "tiles of the C2 image with N x the pixels (the N = 1 workload per GPU); strong-c2 = tiles of the 1024^2 image; "
+                         "samples = every rank renders 256 spp of the whole C2 image with its own seed, films summed")
     ap.add_argument("--cpu-pixels", type=int, default=96, help="cpu baseline: side of the strided pixel grid")
     ap.add_argument("--trace-kernels", default=None, help="A/B runs: force the traversal kernels (closest,any), e.g. 2,3 (default: the scene's pilot)")
     args = ap.parse_args()
@@ -270,12 +334,8 @@ def main():
     lib = _abi.lib()
     _abi.init(local)  # before the scenes are built: BVHAccel then takes the device builder (dr_bvh_build_device)
 
-    mode = args.scaling or "weak"
-    cfg = args.config or ("C2" if world == 1 or mode != "c3" else "C3")
-    spp = args.spp or {"C2": 256, "C3": 1024, "C4": 64, "C5": 512}[cfg]
-    res = args.res or {"C2": 1024, "C3": 4096, "C4": 1024, "C5": 2048}[cfg]
-    if mode == "weak" and world > 1:
-        res = weak_resolution(res, world)
+    pl = plan(world, args.scaling, args.config, args.res, args.spp, args.no_extra)
+    cfg, res, spp, mode = pl["headline"]
     run = Run(cfg, res, spp, rank, world, mode, args)
     out = run.headline(args.steps, args.warmup)
 
@@ -286,33 +346,37 @@ def main():
             if cfg == "C2":
                 out["replay"] = replay_leg(run)
                 out["replay_Msamples_s"] = out["replay"]["value"]
-        if world == 1 and not args.no_extra and cfg == "C2" and not args.res and not args.spp:
+        if world == 1 and pl["extras"]:
             del run
             torch.cuda.empty_cache()
             extra = []
-            for c in ("C4", "C5"):
-                r = Run(c, {"C4": 1024, "C5": 2048}[c], {"C4": 64, "C5": 512}[c], 0, 1, mode, args)
-                e = r.headline(2, 1)
+            for (c, eres, espp, emode, esteps, ewarm) in pl["extras"]:
+                r = Run(c, eres, espp, 0, 1, emode, args)
+                e = r.headline(esteps, ewarm)
                 extra.append({k: e[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
-                                                "roofline_shade", "roofline_gen", "kernel_ms_per_step", "per_sample", "first_render_ms",
-                                                "pilot_ms", "one_shot_ms", "traffic_profiled") if k in e})
+                                                "roofline_shade", "roofline_gen", "trace_kernels_profiled", "kernel_ms_per_step", "per_sample",
+                                                "first_render_ms", "pilot_ms", "one_shot_ms", "traffic_profiled") if k in e})
                 del r
                 torch.cuda.empty_cache()
             out["extra_configs"] = extra
-    if world > 1 and mode == "weak" and not args.no_extra and not args.config and not args.res and not args.spp:
-        # BASELINE configs[2] on the N-rank line (every rank takes part; after the headline's timed region, like C4 / C5 at
-        # N = 1): the C2 scene at 4096 x 4096, 1024 spp, its 32 x 32 tiles over the N ranks, ONE reduce of the 268 MB film per
-        # step -- total work fixed ("strong").  The first render is the warm-up, then ONE timed step: 2 x 28.5 s / N of
-        # rendering (N = 2: ~30 s, N = 8: ~8 s) + the scene build.
+    if world > 1 and pl["extras"]:
+        # next to the N-rank headline (configs[2]): the N = 1 line's workload per GPU -- the C2 view at 256 spp on a square image
+        # with N x the pixels, tiles over the N ranks, one reduce per step ("weak") -- every rank takes part; after the
+        # headline's timed region, like C4 / C5 at N = 1; first render + one warm-up + 2 timed steps of ~0.45 s.
         del run
         torch.cuda.empty_cache()
-        r3 = Run("C3", 4096, 1024, rank, world, "c3", args)
-        e = r3.headline(1, 0)
+        extra = []
+        for (c, eres, espp, emode, esteps, ewarm) in pl["extras"]:
+            rx = Run(c, eres, espp, rank, world, emode, args)
+            e = rx.headline(esteps, ewarm)
+            if rank == 0:
+                extra.append({k: e[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "scaling", "rccl_world", "collective",
+                                                "per_rank_step_ms", "reduce_ms", "film_bytes_reduced_per_step", "one_gpu_same_workload",
+                                                "roofline", "kernel_ms_per_step", "first_render_ms") if k in e})
+            del rx
+            torch.cuda.empty_cache()
         if rank == 0:
-            out["extra_configs"] = [{k: e[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "scaling", "rccl_world", "collective",
-                                                       "per_rank_step_ms", "reduce_ms", "film_bytes_reduced_per_step", "one_gpu_same_workload",
-                                                       "roofline", "kernel_ms_per_step", "first_render_ms") if k in e}]
-        del r3
+            out["extra_configs"] = extra
     if rank == 0:
         print(json.dumps(out))
     drdist.barrier()
@@ -409,7 +473,19 @@ class Run:
         value = samples_per_step * steps / dt / 1e6
         picked = self.dev.trace_kernels()  # (closest, any): 2 = k_trace, 3 = k_trace3 / k_trace3a, 5 = k_trace3c (the pilot's choice for this scene)
         gbs = gen_alg_bytes_per_sample(gen_blocks(self.renderer, self.scene), self.spp)
-        roof, shade, gen, all_alg = roofline_objects(st, dt, copy.value, {3: "k_trace3<0>", 5: "k_trace3c"}.get(picked[0], "k_trace<0>"), self.cfg, gbs)
+        forced = bool(getattr(args, "trace_kernels", None)) or bool(os.environ.get("DARTRAY_TRACE_IMPL"))
+        knames = {"closest": {2: "k_trace<0>", 3: "k_trace3<0>", 5: "k_trace3c"}.get(picked[0], str(picked[0])),
+                  "any_hit": {2: "k_trace<1>", 3: "k_trace3a"}.get(picked[1], str(picked[1]))}
+        roof, shade, gen, all_alg = roofline_objects(st, dt, copy.value, knames["closest"], self.cfg, gbs, kernels_forced=forced)
+        pilot = self.dev.pilot()
+        near = []  # picks the calibration batches decided by less than 2 %
+        pc, pa = pilot["closest"], pilot["any_hit"]
+        if not forced and pc[2] > 0 and pc[3] > 0:
+            cands = {k: v for k, v in pc.items() if v > 0}
+            best = min(cands.values())
+            near += ["closest: kernel %d within 2 %% of kernel %d" % (k, picked[0]) for k, v in cands.items() if k != picked[0] and v < 1.02 * best]
+            if pa[2] > 0 and pa[3] > 0 and abs(pa[2] - pa[3]) < 0.02 * min(pa[2], pa[3]):
+                near.append("any_hit: kernels 2 and 3 within 2 %")
         agg = self.scene.aggregate
         if world == 1:
             par = "1 GPU"
@@ -433,9 +509,13 @@ class Run:
                        % (self.cfg, NAMES[self.cfg], self.renderer.surfaceIntegrator.maxDepth, self.res, self.res, self.spp),
                        "triangles": int(len(agg.tri_idx)), "bvh_nodes": int(len(agg.nodes)),
                        "bvh_builder": "%s (dr_bvh_build_%s), %.0f ms" % (agg.builder, "device" if agg.builder == "device" else "mixed", agg.build_ms),
-                       "trace_kernels": {"closest": {2: "k_trace<0>", 3: "k_trace3<0>", 5: "k_trace3c"}.get(picked[0], str(picked[0])),
-                                         "any_hit": {2: "k_trace<1>", 3: "k_trace3a"}.get(picked[1], str(picked[1])),
-                                         "picked_by": "--trace-kernels" if getattr(args, "trace_kernels", None) else "the scene's pilot batches"},
+                       "trace_kernels": {"closest": knames["closest"], "any_hit": knames["any_hit"],
+                                         "picked_by": ("--trace-kernels / DARTRAY_TRACE_IMPL" if forced else
+                                                       "the scene's pilot batches (closest-hit: best time per algorithmic byte, a pair kernel needs 5 %; any-hit: "
+                                                       "the closest-hit kernel's family unless the other wins its own batch by more than 10 %)"),
+                                         "pilot_ms_per_alg_GB": {"closest": {str(k): round(v, 4) for k, v in pc.items()},
+                                                                 "any_hit": {str(k): round(v, 4) for k, v in pa.items()}},
+                                         "near_ties": near},
                        "samples_per_step": samples_per_step, "parallelism": par, "pipelines": args.pipelines,
                        "sampler_mode": "DR_SAMPLER_COUNTER (keyed per-pixel streams, bit-exact vs the oracle's same mode); the reference's "
                                        "single serial Random(taskNum) stream is replayed bit-exactly through DR_SAMPLER_HOST_BUFFER in the "
@@ -443,6 +523,9 @@ class Run:
             "roofline": roof,
             "roofline_shade": shade,
             "roofline_gen": gen,
+            # per traversal kernel of this line, from the committed PMC passes of the same command (not this run): where the lanes and
+            # the wave-cycles go -- the figures that move when a traversal kernel gets better or worse
+            "trace_kernels_profiled": kernel_profile(self.cfg, knames),
             "kernel_ms_per_step": dict({k: round(st[k] / steps, 2) for k in ("closest_ms", "any_ms", "shade_ms", "gen_ms", "film_ms", "total_ms")},
                                        note="a stage's any-hit launch runs beside its closest-hit launch (second stream): any_ms is its time "
                                             "after the closest-hit launch ended" if os.environ.get("DARTRAY_OVERLAP_ANY", "1") != "0" else "one kernel at a time"),
@@ -482,9 +565,11 @@ def one_gpu_reference(mode, cfg):
     """The single-GPU rate a scaling figure of this N-rank line should be read against, from a committed single-GPU run
     of the same per-GPU (weak) or the same total (strong) workload -- labelled with its source, not measured now."""
     if mode in ("weak", "samples", "strong-c2"):
-        src, key = "profiles/r03_bench_final.json", "C2, 1024x1024, 256 spp on one GPU: the per-GPU workload of the weak modes, the total one of strong-c2"
+        finals = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.startswith("r") and n.endswith("_bench_final.json"))
+        src = "profiles/" + finals[-1] if finals else None  # the newest committed single-GPU line
+        key = "C2, 1024x1024, 256 spp on one GPU: the per-GPU workload of the weak modes, the total one of strong-c2"
     else:
-        src, key = None, "C3 (4096x4096, 1024 spp) on one GPU: 602 Msamples/s, 28.5 s per step (DESIGN.md section 5, round 2: `bench.py --config C3 --steps 1`)"
+        src, key = None, "C3 (4096x4096, 1024 spp) on one GPU: 602 Msamples/s, 28.5 s per step (MEASUREMENTS.md, round 2: `bench.py --config C3 --steps 1`)"
     ref = {"workload": key, "source": src}
     if src and os.path.exists(os.path.join(ROOT, src)):
         try:
@@ -492,8 +577,8 @@ def one_gpu_reference(mode, cfg):
             ref["unit"] = "Msamples/s"
         except (ValueError, KeyError):
             pass
-    elif not src:
-        ref["value"], ref["unit"], ref["source"] = 602.0, "Msamples/s", "DESIGN.md section 5 (round 2)"
+    elif mode == "c3":
+        ref["value"], ref["unit"], ref["source"] = 602.0, "Msamples/s", "MEASUREMENTS.md (round 2)"
     return ref
 
 

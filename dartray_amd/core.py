@@ -659,6 +659,20 @@ class _DeviceScene:
         _abi.check(_abi.lib().dr_scene_get_trace_kernels(self.handle, C.byref(arr)))
         return int(arr[0]), int(arr[1])
 
+    def last_render_info(self):
+        """What the last render_device call ran with (dr_scene_last_render_info)."""
+        arr = (C.c_int32 * 8)()
+        _abi.check(_abi.lib().dr_scene_last_render_info(self.handle, C.byref(arr)))
+        return {"state_layout": int(arr[0]), "closest_kernel": int(arr[1]), "any_hit_kernel": int(arr[2]), "treelet_rounds": int(arr[3]),
+                "pilot_batches": int(arr[4]), "batches": int(arr[5]), "trace_wg_per_cu": int(arr[6]), "overlap_any": int(arr[7])}
+
+    def pilot(self):
+        """What the traversal pilot measured, ms per algorithmic GB: {"closest": {2: .., 3: .., 5: ..}, "any_hit": {2: .., 3: ..}}
+        (0.0 = that candidate was not timed)."""
+        arr = (C.c_float * 6)()
+        _abi.check(_abi.lib().dr_scene_get_pilot(self.handle, C.byref(arr)))
+        return {"closest": {2: float(arr[0]), 3: float(arr[1]), 5: float(arr[2])}, "any_hit": {2: float(arr[3]), 3: float(arr[4])}}
+
 
 class Scene:
     """core/scene.dart:26-45."""

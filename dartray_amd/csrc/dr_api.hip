@@ -100,22 +100,26 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP", "DARTRAY_TREELET", "DARTRAY_TREELET_TOP",
-    "DARTRAY_TREELET_ROUNDS", "DARTRAY_TREELET_MIN", "DARTRAY_TREELET_SHARDS", "DARTRAY_WORKSPACE", "DARTRAY_LAYOUT_PILOT"};
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP",
+    "DARTRAY_TREELET_ROUNDS", "DARTRAY_TREELET_MIN", "DARTRAY_TREELET_SHARDS", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
-const char* dr_option(const char* name) {
-  thread_local std::string held;
+DrOpt dr_opt(const char* name) {
+  DrOpt o;
   {
     std::lock_guard<std::mutex> lock(g_optMutex);
     auto it = g_options.find(name);
     if (it != g_options.end()) {
-      if (it->second.empty()) return nullptr;
-      held = it->second;
-      return held.c_str();
+      o.set = !it->second.empty();  // "" hides the environment's value
+      o.value = it->second;
+      return o;
     }
   }
-  return getenv(name);
+  if (const char* e = getenv(name)) {
+    o.set = true;
+    o.value = e;
+  }
+  return o;
 }
 
 struct DrScene {
@@ -137,6 +141,10 @@ struct DrScene {
   int stateLayout = 0;          // path-state layout of this scene's path renders: 0 = not measured yet, 64 / 4 (LayoutOps)
   float layoutDensity = -1.f;   //   what decided it: the share of a pilot batch's slots still alive at the second bounce
   float calibMs[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // pilot of dr_render_device: [closest / any][v2 / v3 / v3c] ms
+  float calibPerGB[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  //   the same as ms per algorithmic GB (what the choice compares; 0 = not measured)
+  // what the last dr_render_device call actually ran with (dr_scene_last_render_info): state layout, the traversal kernels of
+  // its last batch, treelet parking rounds (-1: not the treelet-parked traversal), calibration batches, workgroups per CU
+  int32_t lastInfo[8] = {0, 0, 0, -1, 0, 0, 0, 0};
   std::vector<int32_t> lightNSamples;
   bool hasSpecular = false;  // some material is a mirror / glass
   bool hasDeltaLight = false;
@@ -373,8 +381,7 @@ BatchState makeState(Workspace& w, const SampleForm& sf, const int2* pix, uint32
   st.svFloat = sf.compact ? 0u : 1u;
   st.svScr = sf.compact ? w.scr.p : nullptr;
   {  // DARTRAY_GEN_PREPASS=0 (A/B, tests): the shuffle kernels seed and burn in their streams themselves
-    const char* pp = dr_option("DARTRAY_GEN_PREPASS");
-    st.genState = sf.compact && !(pp && atoi(pp) == 0) ? w.genState.p : nullptr;
+    st.genState = sf.compact && !dr_opt("DARTRAY_GEN_PREPASS").isZero() ? w.genState.p : nullptr;
   }
   st.pixCap = w.pixCap;
   st.specFrames = w.specFrames.p;
@@ -422,6 +429,7 @@ void enumeratePixels(const RenderParams& rp, const DrRenderDesc* rd, std::vector
 // A render picks one (dr_render_device); results do not depend on it.
 struct LayoutOps {
   decltype(&launch_trace) trace;
+  decltype(&trace_kernel_id) trace_kernel_id;
   decltype(&launch_trace_treelets) trace_treelets;
   decltype(&launch_gen_samples) gen_samples;
   decltype(&launch_transpose_samples) transpose_samples;
@@ -434,9 +442,9 @@ struct LayoutOps {
   int stateWords;  // 4-byte words of fixed path state per slot in this layout (a tile is 64 of them + the sample region):
                    // what the kernels' own translation unit was compiled with (layout_state_words), not a constant repeated here
 };
-static const LayoutOps kLayout64 = {&launch_trace, &launch_trace_treelets, &launch_gen_samples, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
+static const LayoutOps kLayout64 = {&launch_trace, &trace_kernel_id, &launch_trace_treelets, &launch_gen_samples, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
                                     &launch_env, &launch_shade_direct, &launch_shade_spec, &launch_film, layout_state_words()};
-static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_trace_treelets, &sp4::launch_gen_samples, &sp4::launch_transpose_samples, &sp4::launch_raygen,
+static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::trace_kernel_id, &sp4::launch_trace_treelets, &sp4::launch_gen_samples, &sp4::launch_transpose_samples, &sp4::launch_raygen,
                                      &sp4::launch_shade_path, &sp4::launch_env, &sp4::launch_shade_direct, &sp4::launch_shade_spec,
                                      &sp4::launch_film, sp4::layout_state_words()};
 
@@ -444,8 +452,7 @@ int traceGridFor(int wgPerCU) {
   // workgroups of the persistent traversal kernels: as many as are resident at once.  v2 (k_trace): 16 KiB of stack +
   // 6 KiB of cold ray state in LDS and 72 VGPRs => 7 workgroups = 28 waves per CU; the other variants (v3: 32 KiB of
   // LDS, the quadric and v1 kernels: more registers) 6, the sixth queueing behind five where only five fit.
-  const char* e = dr_option("DARTRAY_TRACE_WG_PER_CU");
-  if (e) wgPerCU = atoi(e);
+  wgPerCU = dr_opt("DARTRAY_TRACE_WG_PER_CU").toInt(wgPerCU);
   return g_numCU * std::max(1, std::min(wgPerCU, 8));
 }
 
@@ -519,10 +526,9 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   // Round 4: validation, height, pair records and the union check run on the device (dr_scene_prep.hip: C4 0.6 s -> 0.1 s).  The
   // serial host loops below remain for the experimental pair orders (DARTRAY_PAIR_ORDER=sib | pad:K | veb:T:S) and as the
   // reference the device results are tested against (DARTRAY_SCENE_PREP=host).
-  const char* pairOrderOpt = dr_option("DARTRAY_PAIR_ORDER");
-  const std::string pairOrder = pairOrderOpt ? pairOrderOpt : "top:12";
-  const char* prepOpt = dr_option("DARTRAY_SCENE_PREP");
-  const bool hostPrep = (prepOpt && std::string(prepOpt) == "host") || !(pairOrder == "dfs" || pairOrder.rfind("top:", 0) == 0);
+  const DrOpt pairOrderOpt = dr_opt("DARTRAY_PAIR_ORDER");
+  const std::string pairOrder = pairOrderOpt ? pairOrderOpt.value : "top:12";
+  const bool hostPrep = dr_opt("DARTRAY_SCENE_PREP").is("host") || !(pairOrder == "dfs" || pairOrder.rfind("top:", 0) == 0);
   std::vector<uint8_t> level(hostPrep ? desc->nnodes : 0, 0);
   if (desc->nnodes && hostPrep) {
     const DrBvhNode* N = desc->nodes;
@@ -1226,6 +1232,21 @@ int dr_scene_get_trace_kernels(const DrScene* sc, uint32_t out[2]) {
   return DR_OK;
 }
 
+int dr_scene_last_render_info(const DrScene* sc, int32_t out[8]) {
+  if (!sc || !out) return fail(DR_ERR_INVALID, "null argument");
+  for (int i = 0; i < 8; ++i) out[i] = sc->lastInfo[i];
+  return DR_OK;
+}
+
+int dr_scene_get_pilot(const DrScene* sc, float out[6]) {
+  if (!sc || !out) return fail(DR_ERR_INVALID, "null argument");
+  for (int c = 0; c < 3; ++c) out[c] = sc->calibPerGB[0][c];
+  out[3] = sc->calibPerGB[1][0];
+  out[4] = sc->calibPerGB[1][1];
+  out[5] = 0.f;
+  return DR_OK;
+}
+
 int dr_scene_set_trace_kernels(DrScene* sc, const uint32_t in[2]) {
   if (!sc || !in) return fail(DR_ERR_INVALID, "null argument");
   if (in[0] == 0u && in[1] == 0u) {
@@ -1326,10 +1347,10 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // are still alive at the second bounce the rest of the render, and every later render of the scene, uses the four-slot
   // sub-tiles (C5: 0.38 -> sp4; C2 0.80, C4: 64-slot).  DARTRAY_STATE_LAYOUT=64|4 forces one, dr_scene_set_state_layout
   // stores one; renders too small for a pilot keep round 3's rule.
-  const char* layoutEnv = dr_option("DARTRAY_STATE_LAYOUT");  // 64 | 4: A/B runs and tests
-  const bool layoutPilotOff = dr_option("DARTRAY_LAYOUT_PILOT") && atoi(dr_option("DARTRAY_LAYOUT_PILOT")) == 0;
+  const DrOpt layoutEnv = dr_opt("DARTRAY_STATE_LAYOUT");  // 64 | 4: A/B runs and tests (a copy: later look-ups cannot change it)
+  const bool layoutPilotOff = dr_opt("DARTRAY_LAYOUT_PILOT").isZero();
   const bool layoutKnown = layoutEnv || sc->stateLayout != 0 || rd->integrator != DR_INTEGRATOR_PATH || layoutPilotOff;
-  const bool sparseLayout = layoutEnv ? atoi(layoutEnv) == 4 : (sc->stateLayout ? sc->stateLayout == 4 : envStage);
+  const bool sparseLayout = layoutEnv ? layoutEnv.toInt(0) == 4 : (sc->stateLayout ? sc->stateLayout == 4 : envStage);
   const LayoutOps* Lp = sparseLayout ? &kLayoutSp4 : &kLayout64;
   const int maxStateWords = layoutKnown ? Lp->stateWords : std::max(kLayout64.stateWords, kLayoutSp4.stateWords);
 #define L (*Lp)
@@ -1361,9 +1382,9 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.dlSpecular = dlSpec ? 1 : 0;
   rp.deferredNee = rd->integrator == DR_INTEGRATOR_PATH ? 1 : 0;
   rp.genMask = 0ull;
-  const bool genSlow = dr_option("DARTRAY_GEN_SLOW_DRAWS") != nullptr;
+  const bool genSlow = dr_opt("DARTRAY_GEN_SLOW_DRAWS").set;
   rp.genSlowDraws = genSlow ? 1 : 0;
-  const bool genAll = dr_option("DARTRAY_GEN_ALL_BLOCKS") != nullptr;  // A/B and tests: generate every block
+  const bool genAll = dr_opt("DARTRAY_GEN_ALL_BLOCKS").set;  // A/B and tests: generate every block
   if (rd->integrator == DR_INTEGRATOR_PATH && !rp.blocks && !genAll) {
     // What the path kernels read of a pixel sample (dr_kernels.hip: k_raygen, load_shade_in, k_film): the image sample,
     // the lens sample of a thin-lens camera, and per SAMPLE_DEPTH level b <= maxDepth the light number, the light
@@ -1428,14 +1449,14 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // Sample vectors: the on-device LD sampler stores permuted indices + scrambles (compact form) whenever every LD block
   // has one entry per pixel sample; host buffers and multi-entry blocks (DirectLighting with nsamples > 1) use floats.
   SampleForm sf;
-  sf.compact = !hostBuf && rp.blocks == nullptr && !dr_option("DARTRAY_FLOAT_SAMPLES");
+  sf.compact = !hostBuf && rp.blocks == nullptr && !dr_opt("DARTRAY_FLOAT_SAMPLES");
   if (!sf.compact && !hostBuf && spp > 1024)
     return fail(DR_ERR_UNSUPPORTED, "spp > 1024 with LD blocks of several entries per sample (DirectLighting with nsamples > 1): the float-form sampler's table exceeds the LDS");
   sf.nFloats = rp.nFloats;
   sf.nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
   sf.idxShift = spp > 256 ? 1 : 0;
-  const int slotBits = dr_option("DARTRAY_BATCH_BITS") ? std::min(28, std::max(16, atoi(dr_option("DARTRAY_BATCH_BITS")))) : 28;
-  const int nPipesEnv = dr_option("DARTRAY_PIPELINES") ? atoi(dr_option("DARTRAY_PIPELINES")) : 1;
+  const int slotBits = std::min(28, std::max(16, dr_opt("DARTRAY_BATCH_BITS").toInt(28)));
+  const int nPipesEnv = dr_opt("DARTRAY_PIPELINES").toInt(1);
   uint64_t maxSlots = 1ull << slotBits;  // camera samples in flight per batch
   {
     // path state per camera sample: 164 B of ray / hit / NEE state, 20 B of queues and the sample vector (24 B of
@@ -1444,7 +1465,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // memory the batch shrinks instead of failing (results do not depend on the batch size).
     const uint64_t perSlot = (uint64_t)maxStateWords * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 +
                              (hostBuf && needTail > 0 ? (uint64_t)rd->max_tail * 8 : 0) + (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0) +
-                             (sf.compact ? (uint64_t)(8 * sf.nBlocks + spp - 1) / spp : 0) +
+                             (sf.compact ? (uint64_t)(16 * sf.nBlocks + spp - 1) / spp : 0) +  // scramble words + generator states, per (block, pixel)
                              (dlSpec ? (uint64_t)std::max(1, rd->max_depth) * sizeof(SpecFrame) + 12 : 0);
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
@@ -1467,7 +1488,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const uint32_t capBefore = sc->ws.cap;
   int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0, maxStateWords);
   if (rc) return rc;
-  if (dr_option("DARTRAY_VERBOSE") && sc->ws.cap != capBefore) {
+  if (dr_opt("DARTRAY_VERBOSE") && sc->ws.cap != capBefore) {
     (void)hipDeviceSynchronize();
     fprintf(stderr, "dartray_hip: path-state workspace for %u slots (%.1f GB) allocated in %.1f ms\n", sc->ws.cap,
             (double)sc->ws.tiles.n * 4.0e-9 + (double)sc->ws.cap * 20.0e-9,
@@ -1484,8 +1505,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (rc) return rc;
   // DARTRAY_TRACE_IMPL=4: the treelet-parked traversal (a prototype) for the stage queues of a scene
   // whose pair records were laid out with DARTRAY_PAIR_ORDER=top:T
-  const char* implOpt = dr_option("DARTRAY_TRACE_IMPL");
-  const bool treelets = implOpt && implOpt[0] == '4' && sc->d.pairs && sc->d.topPairs > 0 && !sc->d.nquads && !dlSpec && nPipesEnv < 2;
+  const bool treelets = dr_opt("DARTRAY_TRACE_IMPL").first() == '4' && sc->d.pairs && sc->d.topPairs > 0 && !sc->d.nquads && !dlSpec && nPipesEnv < 2;
   if (treelets) {
     Workspace& w = sc->ws;
     const uint32_t outCap = w.cap + (uint32_t)tgrid * (DR_TRACE_BLOCK / 64) * 256u + 1024u;
@@ -1511,12 +1531,12 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       w.tl.iotaReady = 0;
     }
     w.tl.topPairs = sc->d.topPairs;
-    w.tl.rounds = dr_option("DARTRAY_TREELET_ROUNDS") ? std::max(0, std::min(3, atoi(dr_option("DARTRAY_TREELET_ROUNDS")))) : 1;
-    w.tl.shards = dr_option("DARTRAY_TREELET_SHARDS") ? std::max(1, std::min(8, atoi(dr_option("DARTRAY_TREELET_SHARDS")))) : 8;
-    w.tl.minPark = dr_option("DARTRAY_TREELET_MIN") ? (uint32_t)atoi(dr_option("DARTRAY_TREELET_MIN")) : (1u << 18);
-    w.tl.verbose = dr_option("DARTRAY_VERBOSE") ? atoi(dr_option("DARTRAY_VERBOSE")) : 0;
+    w.tl.rounds = std::max(0, std::min(3, dr_opt("DARTRAY_TREELET_ROUNDS").toInt(1)));
+    w.tl.shards = std::max(1, std::min(8, dr_opt("DARTRAY_TREELET_SHARDS").toInt(8)));
+    w.tl.minPark = (uint32_t)dr_opt("DARTRAY_TREELET_MIN").toInt(1 << 18);
+    w.tl.verbose = dr_opt("DARTRAY_VERBOSE").toInt(0);
   }
-  const bool overlapEnv = !(dr_option("DARTRAY_OVERLAP_ANY") && atoi(dr_option("DARTRAY_OVERLAP_ANY")) == 0);  // default: on
+  const bool overlapEnv = !(dr_opt("DARTRAY_OVERLAP_ANY").isZero());  // default: on
   const bool overlapAny = overlapEnv && !dlSpec && !(nPipesEnv >= 2);
   if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
   const bool twoPipes = nPipesEnv >= 2 && !hostBuf && !dlSpec && npixTotal > pixPerBatch;
@@ -1537,11 +1557,12 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // Nothing is traced twice: the calibration costs only what three small launches lose against one big one (round 1
   // ran up to six extra passes over pilot rays that never reached the film: 19 % of a C2 render, 64 % of C4's).
   // Both kernels are bit-exact, so results do not depend on the choice; dr_scene_set_trace_kernels / DARTRAY_TRACE_IMPL fix it.
-  const bool pilotOff = dr_option("DARTRAY_PILOT") && atoi(dr_option("DARTRAY_PILOT")) == 0;
-  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || dr_option("DARTRAY_PILOT_FORCE");
+  const bool pilotOff = dr_opt("DARTRAY_PILOT").isZero();
+  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || dr_opt("DARTRAY_PILOT_FORCE").set;
   const bool pilotOk = !pilotOff && !hostBuf && !dlSpec && bigJob && npixTotal >= 3 * 64 * 4 && !(nPipesEnv >= 2);
-  const bool calibrateTrace = !sc->traceCalibrated && pilotOk && !dr_option("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads;
+  const bool calibrateTrace = !sc->traceCalibrated && pilotOk && !dr_opt("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads;
   const bool measureLayout = !layoutKnown && pilotOk;
+  if (measureLayout) Lp = &kLayout64;  // the batch whose stage lists are measured runs in the 64-slot layout (the header's and the comment's claim)
   const bool calibrate = calibrateTrace || measureLayout;
   const int pilotSets = calibrateTrace ? 4 : 1;  // traversal kernels: warm-up, v2 timed, v3 timed, v3c timed; the layout alone: one batch
   size_t calibPix = 0;  // pixels per calibration batch; the three batches are the first 3 * calibPix entries of `pixels`
@@ -1550,7 +1571,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // decide: the pair kernel, whose rays are half as many fetches long, looked 10 % FASTER than k_trace<0> on C2 and is 12 % slower in
     // the full-size launches; at 2^24 and above the calibration batches rank the kernels as the full-size launches do.)
     uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 24, (uint64_t)npixTotal * spp / 16));
-    if (dr_option("DARTRAY_PILOT_BITS")) pilotSamples = 1ull << atoi(dr_option("DARTRAY_PILOT_BITS"));
+    if (const DrOpt pb = dr_opt("DARTRAY_PILOT_BITS")) pilotSamples = 1ull << std::max(0, std::min(40, pb.toInt(24)));
     pilotSamples = std::min<uint64_t>(pilotSamples, (uint64_t)(pixPerBatch / 64 * 64) * spp);
     const size_t totalGroups = npixTotal / 64;
     const size_t groups = std::min<size_t>(std::max<size_t>(1, (size_t)(pilotSamples / spp) / 64), totalGroups / 4);
@@ -1724,7 +1745,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       timed(4, evF);
       sc->stats.batches++;
     }
-    const bool stageCounts = dr_option("DARTRAY_STAGE_COUNTS") != nullptr;  // diagnostics: the batch's list lengths per stage
+    const bool stageCounts = dr_opt("DARTRAY_STAGE_COUNTS").set;  // diagnostics: the batch's list lengths per stage
     if (stageCounts) {
       std::vector<uint32_t> hc(N_COUNTERS);
       HIP_TRY(hipStreamSynchronize(s));
@@ -1740,6 +1761,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   };
 
   size_t firstPix = 0;
+  int pilotBatchesRun = 0;
   if (calibrate) {
     hipEvent_t evP0 = sc->getEvent(), evP1 = sc->getEvent();
     HIP_TRY(hipEventRecord(evP0, s));
@@ -1756,7 +1778,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       sc->d.traceKernel[1] = keepKernel[1];
       return code;
     };
+    int setsRun = 0;
     for (int set = 0; set < pilotSets; ++set) {  // warm-up (v2), v2 timed, v3 timed, v3c timed (its any-hit rays: v3 again)
+      // (round 5) where the pair kernel has just lost clearly to k_trace<0> (C2: 8 - 10 % behind) its cold-state sibling is not
+      // timed: k_trace3c is never more than a few per cent from k_trace3<0>, and the batch is a quarter of the pilot's cost.
+      // Its pixels simply stay in the render's ordinary batches.
+      if (set == 3 && calibrateTrace && perByte[0][1] > 1.05 * perByte[0][0]) break;
+      ++setsRun;
       const int impl = set == 2 ? 3 : (set == 3 ? 5 : 2);
       const int col = set == 2 ? 1 : (set == 3 ? 2 : 0);
       if (calibrateTrace) {
@@ -1774,11 +1802,12 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       if (set == 0 && measureLayout) {
         // the batch's stage lists (still in the counters): how many of its slots are alive at the second bounce?
         uint32_t alive2 = 0;
-        HIP_TRY(hipMemcpy(&alive2, sc->ws.counters.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));  // entries of stage 1's output list
+        if (hipMemcpy(&alive2, sc->ws.counters.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)  // entries of stage 1's output list
+          return abandon(fail(DR_ERR_HIP, "layout pilot: counter read-back failed"));
         sc->layoutDensity = (float)((double)alive2 / ((double)calibPix * spp));
         sc->stateLayout = sc->layoutDensity < 0.5f ? 4 : 64;
         Lp = sc->stateLayout == 4 ? &kLayoutSp4 : &kLayout64;
-        if (dr_option("DARTRAY_VERBOSE"))
+        if (dr_opt("DARTRAY_VERBOSE"))
           fprintf(stderr, "dartray_hip: state-layout pilot: %.3f of a batch's slots alive at the second bounce -> %s\n", sc->layoutDensity,
                   sc->stateLayout == 4 ? "four-slot line-grouped sub-tiles (sp4)" : "64-slot runs");
       }
@@ -1797,32 +1826,44 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       }
     }
     if (calibrateTrace) {
-    for (int kind = 0; kind < 2; ++kind) {
-      sc->d.traceKernel[kind] = perByte[kind][1] < 0.95 * perByte[kind][0] ? 3u : 2u;
-      for (int c = 0; c < 3; ++c) sc->calibMs[kind][c] = ms[kind][c];
-    }
+    for (int kind = 0; kind < 2; ++kind)
+      for (int c = 0; c < 3; ++c) {
+        sc->calibMs[kind][c] = ms[kind][c];
+        sc->calibPerGB[kind][c] = (float)perByte[kind][c];
+      }
+    sc->d.traceKernel[0] = perByte[0][1] < 0.95 * perByte[0][0] ? 3u : 2u;
     // the closest-hit rays have a third candidate (round 4): the pair kernel with its cold state in LDS, six workgroups per CU --
     // 5 % ahead of k_trace3<0> on the cache-resident C5 (and there, with it, ahead of k_trace<0>), level with it on C4
     // -- 5 % ahead of k_trace3<0> in C5's full-size launches and level with it in C5's calibration batches (eight times
     // smaller: they understate what a sixth workgroup returns, as they do for the shadow rays below), 1.4 % behind on C4 at
     // full size and 3.5 % behind in its calibration batches: so it takes the tie, and k_trace3<0> stays where it is 2 % ahead
-    {
+    if (perByte[0][2] > 0.0) {
       const double best3 = std::min(perByte[0][1], perByte[0][2]);
       if (best3 < 0.95 * perByte[0][0]) sc->d.traceKernel[0] = perByte[0][2] < 1.02 * perByte[0][1] ? 5u : 3u;
     }
-    // small launches understate v3's advantage on shadow rays (C4: -2 ... +6 % in a calibration batch, +25 % in the
-    // full-size launches of the render): where the closest-hit rays prefer v3 clearly (10 %), the any-hit rays take
-    // it unless the calibration batch found it more than 5 % slower (C2 / C5, where v3 loses, are 30 - 40 % slower)
-    if (std::min(perByte[0][1], perByte[0][2]) < 0.90 * perByte[0][0] && perByte[1][1] <= 1.05 * perByte[1][0]) sc->d.traceKernel[1] = 3u;
+    // The any-hit rays (round 5: a rule without a coin in it).  Their calibration launches are the least reliable of the
+    // pilot -- shadow rays are short, a small launch is mostly ramp-up and tail, and the two families come out within a few
+    // per cent of each other on the cache-resident scenes (C2: k_trace3a 6 - 8 % ahead in the calibration batches of three
+    // boxes, level at full size: 96.0 against 96.5 ms per step; round 4's 5 % threshold let the box decide) while small launches
+    // understate the pair kernel on the big incoherent tree (C4: -2 ... +6 % in a calibration batch, +25 % at full size).  So the
+    // any-hit rays stay in the FAMILY the closest-hit rays chose -- k_trace<1> beside k_trace<0>, k_trace3a beside k_trace3<0> /
+    // k_trace3c -- and cross over only when their own calibration batch says so by more than 10 %.
+    {
+      const bool pairFamily = sc->d.traceKernel[0] != 2u;
+      const double own = pairFamily ? perByte[1][1] : perByte[1][0], other = pairFamily ? perByte[1][0] : perByte[1][1];
+      const bool cross = other > 0.0 && own > 0.0 && other < 0.90 * own;
+      sc->d.traceKernel[1] = (pairFamily != cross) ? 3u : 2u;
+    }
     sc->traceCalibrated = true;
     }
     HIP_TRY(hipEventRecord(evP1, s));
     sc->traceEvents.push_back({evP0, evP1, 5});  // DrRenderStats.pilot_ms: the time of the calibration batches
-    firstPix = (size_t)pilotSets * calibPix;
-    batchIndex = (size_t)pilotSets;
-    if (calibrateTrace && dr_option("DARTRAY_VERBOSE"))
-      fprintf(stderr, "dartray_hip: traversal pilot (4 x %zu samples, rendered into the film), ms per algorithmic GB: closest v2 %.4f / v3 %.4f / v3c %.4f -> v%u; "
-              "any hit v2 %.4f / v3 %.4f -> v%u\n", calibPix * (size_t)spp, perByte[0][0], perByte[0][1], perByte[0][2], sc->d.traceKernel[0],
+    firstPix = (size_t)setsRun * calibPix;  // (a set that was skipped left its pixels to the ordinary batches)
+    batchIndex = (size_t)setsRun;
+    pilotBatchesRun = setsRun;
+    if (calibrateTrace && dr_opt("DARTRAY_VERBOSE"))
+      fprintf(stderr, "dartray_hip: traversal pilot (%d x %zu samples, rendered into the film), ms per algorithmic GB: closest v2 %.4f / v3 %.4f / v3c %.4f -> v%u; "
+              "any hit v2 %.4f / v3 %.4f -> v%u\n", setsRun, calibPix * (size_t)spp, perByte[0][0], perByte[0][1], perByte[0][2], sc->d.traceKernel[0],
               perByte[1][0], perByte[1][1], sc->d.traceKernel[1]);
   }
 
@@ -1849,6 +1890,14 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   }
   sc->stats.camera_samples += (uint64_t)npixTotal * spp;
   sc->stats.film_samples += filmSamples;
+  sc->lastInfo[0] = Lp == &kLayoutSp4 ? 4 : 64;
+  sc->lastInfo[1] = treelets ? 4 : L.trace_kernel_id(sc->d, 0);
+  sc->lastInfo[2] = treelets ? 4 : L.trace_kernel_id(sc->d, 1);
+  sc->lastInfo[3] = treelets ? sc->ws.tl.rounds : -1;
+  sc->lastInfo[4] = pilotBatchesRun;
+  sc->lastInfo[5] = (int32_t)std::min<uint64_t>(0x7fffffff, nBatches);
+  sc->lastInfo[6] = tgrid / std::max(1, g_numCU);
+  sc->lastInfo[7] = overlapAny ? 1 : 0;
   return DR_OK;
 #undef L
 }

@@ -20,7 +20,7 @@
 
 #include "../../include/dartray_hip.h"
 
-const char* dr_option(const char* name);  // dr_api.hip: dr_set_option's value, else the environment's
+#include "dr_options.h"  // dr_opt: dr_set_option's value, else the environment's (by value)
 
 namespace {
 
@@ -387,10 +387,10 @@ extern "C" int dr_bvh_build_mixed(const float* verts, uint64_t nverts, const uin
   }
   SahBuilder b;
   b.maxPrims = std::min(255, max_prims_in_node > 0 ? max_prims_in_node : 4);  // bvh_accel.dart:44
-  const char* env = dr_option("DARTRAY_BUILD_THREADS");
+  const DrOpt env = dr_opt("DARTRAY_BUILD_THREADS");
   int hw = (int)std::thread::hardware_concurrency();
-  b.maxThreads = env ? std::max(1, atoi(env)) : std::max(1, std::min(hw, 64));
-  const bool dbg = dr_option("DARTRAY_BUILD_DEBUG") != nullptr;
+  b.maxThreads = env ? std::max(1, env.toInt(1)) : std::max(1, std::min(hw, 64));
+  const bool dbg = dr_opt("DARTRAY_BUILD_DEBUG").set;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   b.items.resize(ntris);

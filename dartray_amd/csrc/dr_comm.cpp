@@ -19,7 +19,7 @@
 
 #include "../../include/dartray_hip.h"
 
-const char* dr_option(const char* name);  // dr_api.hip: dr_set_option's value, else the environment's
+#include "dr_options.h"  // dr_opt: dr_set_option's value, else the environment's (by value)
 
 int dr_fail(int code, const std::string& msg);  // dr_api.hip: sets dr_last_error()
 
@@ -68,9 +68,9 @@ int loadRccl() {
   if (g_rccl.handle) return DR_OK;
   void* h = nullptr;
   std::string tried;
-  const char* env = dr_option("DARTRAY_RCCL_LIB");
-  if (env && *env) {
-    h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+  const DrOpt env = dr_opt("DARTRAY_RCCL_LIB");
+  if (env && !env.value.empty()) {
+    h = dlopen(env.value.c_str(), RTLD_NOW | RTLD_GLOBAL);
     if (!h) return dr_fail(DR_ERR_UNSUPPORTED, std::string("DARTRAY_RCCL_LIB: ") + dlerror());
   }
   // a copy that is already mapped (torch's) first, then the system one

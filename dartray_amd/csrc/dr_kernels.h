@@ -256,10 +256,7 @@ struct StageQueues {
 #define DR_V2_WG_PER_CU 7
 #endif
 int traceGridFor(int wgPerCU);  // dr_api.hip: workgroups of a persistent traversal launch
-// A tuning / diagnostic switch of the library (DARTRAY_*): the value given to dr_set_option, else the environment's; null
-// when unset.  Read at every use -- nothing is latched at first use -- so a long-lived foreign host can change a switch
-// between two renders without setenv.  The pointer is valid until the calling thread's next dr_option call.
-const char* dr_option(const char* name);
+#include "dr_options.h"  // dr_opt(name): a tuning / diagnostic switch of the library (DARTRAY_*), by value
 #define DR_MAX_STACK 128      // LDS + spill entries per lane (the reference uses 64, bvh_accel.dart:120)
 #define DR_TRACE_BLOCK 256
 

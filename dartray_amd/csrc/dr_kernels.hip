@@ -1837,7 +1837,7 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& stIn, uint32_t
   const dim3 grid((npix + 63) / 64, nBlocks);
   if (!st.svFloat && rp.spp >= 64) {
     const int nGen = rp.genMask ? __builtin_popcountll(rp.genMask) : nBlocks;  // compact form (rp.blocks is null), whole index runs per pixel
-    const int lanesEnv = dr_option("DARTRAY_GEN_LANES") ? atoi(dr_option("DARTRAY_GEN_LANES")) : 0;
+    const int lanesEnv = dr_opt("DARTRAY_GEN_LANES").toInt(0);
     // (above 1024 spp a pixel's table is 4 / 8 KB: 32 / 16 pixels per group keep the group's tables within 128 KB)
     const int ln = lanesEnv ? lanesEnv : (rp.spp <= 128 ? 64 : (rp.spp <= 256 ? DR_GEN_LANES_256 : (rp.spp <= 1024 ? DR_GEN_LANES_BIG : (rp.spp <= 2048 ? 32 : 16))));
     const dim3 g((npix + ln - 1) / ln, nGen);
@@ -1846,7 +1846,7 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& stIn, uint32_t
     if (rp.spp <= 256) {
       hipLaunchKernelGGL(k_gen_samples_lm<uint8_t>, g, dim3(ln), lds, s, rp, st, npix);
     } else {
-      const bool onePerGroup = dr_option("DARTRAY_GEN_ONE_WAVE") != nullptr;  // A/B: the single-wave kernel
+      const bool onePerGroup = dr_opt("DARTRAY_GEN_ONE_WAVE").set;  // A/B: the single-wave kernel
       static bool attrSet = false;
       if (!attrSet) {
         (void)hipFuncSetAttribute((const void*)k_gen_samples_lm<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1895,7 +1895,7 @@ static void launch_shade(int grid, size_t extraLds, hipStream_t s, A... args) {
   hipLaunchKernelGGL(kernel, dim3(DR_SHADE_GRID(grid)), dim3(BLOCK), lds, s, args...);
 }
 static bool lightsInLds(const DScene& sc) {
-  const bool off = dr_option("DARTRAY_LDS_LIGHTS") && atoi(dr_option("DARTRAY_LDS_LIGHTS")) == 0;  // A/B runs
+  const bool off = dr_opt("DARTRAY_LDS_LIGHTS").isZero();  // A/B runs
   return !off && sc.nlights > 0 && light_table_bytes(sc) <= DR_LDS_LIGHT_BYTES;
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,

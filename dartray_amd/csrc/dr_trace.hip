@@ -1196,8 +1196,12 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
         } else {
           const SlabB fb = slab_bounds(ray, fbx0, fby0, fbz0, fbx1, fby1, fbz1);
           // (COLD: one bracket end per bound is kept; the other is its neighbour or itself -- taking the neighbour only sends a
-          // few more boxes to the literal test)
-          const float tminHi = COLD ? __uint_as_float(__float_as_uint(ray.tminLo) + (ray.tminLo < 0.f ? 0xffffffffu : 1u)) : ray.tminHi;
+          // few more boxes to the literal test).  The neighbour is chosen by the SIGN BIT, not by `< 0`: minDistance == -0.0 has
+          // tminLo == -0.0, for which `< 0` is false and bits + 1 would be the negative denormal BELOW it (a bracket end under
+          // the value it must bound: sureIn could skip a literal test); by the sign bit -0.0 steps to 0x7fffffff, a NaN, and
+          // every comparison with it fails -- the box goes to the literal test.  (pred(tmaxHi) at the pops yields NaN at both
+          // zeros already: conservative.)  Render rays have minDistance 0 or an epsilon > 0; dr_intersect takes any ray.
+          const float tminHi = COLD ? __uint_as_float(__float_as_uint(ray.tminLo) + ((int32_t)__float_as_uint(ray.tminLo) < 0 ? 0xffffffffu : 1u)) : ray.tminHi;
           const bool sureIn = (fb.loU <= fb.hiL) && (fb.hiL > tminHi);
           const bool sureOut = (fb.loL > fb.hiU) || (fb.hiU <= ray.tminLo);
           farE = fb.lo;
@@ -1596,20 +1600,18 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3A_WAVES) k_intersect3
 // ---------------------------------------------------------------------------
 // A/B: DARTRAY_ANY8=1 keeps the 8-byte (reference, entry parameter) any-hit kernel of round 3 (k_trace3<1>)
 static bool any8() {
-  const char* e = dr_option("DARTRAY_ANY8");
-  return e && atoi(e) != 0;
+  return dr_opt("DARTRAY_ANY8").nonZero();
 }
 // A/B: DARTRAY_CLOSEST_COLD=1 runs the closest-hit pair traversal with its cold ray state in LDS (k_trace3c)
 static bool coldClosest() {
-  const char* e = dr_option("DARTRAY_CLOSEST_COLD");
-  return e && atoi(e) != 0;
+  return dr_opt("DARTRAY_CLOSEST_COLD").nonZero();
 }
 // Kernel ids (DScene.traceKernel, DARTRAY_TRACE_IMPL, dr_scene_set_trace_kernels): 1 first version, 2 k_trace, 3 sibling pairs (k_trace3<0> /
 // k_trace3a), 5 sibling pairs with the closest-hit rays' cold state in LDS (k_trace3c; the any-hit rays: k_trace3a as with 3).  Returned
 // here: 1 / 2 / 3, with `*cold` set for id 5 on closest-hit rays.
 static int traceImpl(const DScene& sc, int anyHit, int force = 0, bool* cold = nullptr) {
-  const char* e = dr_option("DARTRAY_TRACE_IMPL");  // (read per launch: dr_set_option may change it between renders)
-  const int env = (e && ((e[0] >= '1' && e[0] <= '3') || e[0] == '5')) ? e[0] - '0' : ((e && e[0] == '4') ? 3 : 0);  // 4: treelet-parked stage traversals (dr_api.hip); everything else v3
+  const char e = dr_opt("DARTRAY_TRACE_IMPL").first();  // (read per launch: dr_set_option may change it between renders)
+  const int env = ((e >= '1' && e <= '3') || e == '5') ? e - '0' : (e == '4' ? 3 : 0);  // 4: treelet-parked stage traversals (dr_api.hip); everything else v3
   // v2 is the fastest on cache-resident trees, v3 (sibling pairs) on big incoherent ones:
   // unless DARTRAY_TRACE_IMPL fixes it, the choice is the one measured for this scene (sc.traceKernel, set by the
   // pilot of dr_render_device)
@@ -1634,6 +1636,11 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
     if (anyHit) hipLaunchKernelGGL(k_intersect<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_intersect<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
   }
+}
+int trace_kernel_id(const DScene& sc, int anyHit) {
+  bool cold = false;
+  const int impl = traceImpl(sc, anyHit, 0, &cold);
+  return impl == 3 && cold ? 5 : impl;
 }
 void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {

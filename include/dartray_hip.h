@@ -312,6 +312,17 @@ void dr_scene_destroy(DrScene* scene);
  * skipped.  Setting 0 makes the next big render measure again. */
 int dr_scene_get_trace_kernels(const DrScene* scene, uint32_t kernels_out[2]);
 int dr_scene_set_trace_kernels(DrScene* scene, const uint32_t kernels[2]);
+/* What the pilot measured, in ms per algorithmic GB (32 B per node visit + 48 B per triangle test of the calibration
+ * batch's own counters): out[0..2] closest-hit rays with kernel 2 / 3 / 5, out[3..4] any-hit rays with kernel 2 / 3,
+ * out[5] reserved (0).  0 = not measured (no pilot has run, the kernels were set by the host, or that candidate was
+ * skipped: kernel 5 is not timed where kernel 3 lost to kernel 2 by more than 5 %).  Diagnostics: how close a choice was. */
+int dr_scene_get_pilot(const DrScene* scene, float ms_per_gb_out[6]);
+/* Diagnostics: what the scene's LAST dr_render_device call actually ran with, switches (dr_set_option / environment)
+ * included -- out[0] path-state layout (64 / 4), out[1] / out[2] the traversal kernel of its closest-hit / any-hit launches
+ * (1, 2, 3, 5 as above; 4 = the treelet-parked traversal), out[3] the treelet parking rounds (-1 otherwise), out[4] the
+ * calibration batches it ran (0: no pilot), out[5] its batches, out[6] workgroups per CU of a persistent traversal
+ * launch, out[7] 1 when a stage's any-hit launch ran beside its closest-hit launch.  All 0 / -1 before the first render. */
+int dr_scene_last_render_info(const DrScene* scene, int32_t info_out[8]);
 /* The path-state layout of this scene's path-traced renders, next to the traversal kernels and measured the same way: the
  * first big render's first pilot batch counts how many of its slots are still alive at the second bounce (density_out;
  * -1 before); below one half the renders use four-slot, line-grouped sub-tiles (layout 4: stage lists that thin out touch
@@ -411,18 +422,21 @@ const char* dr_version(void);
 /* Tuning / diagnostic switches.  Every switch is also an environment variable of the same name (DARTRAY_<NAME>); a
  * value set here takes precedence, is read at every use (nothing is latched at first use: the next render sees it) and
  * needs no setenv in a long-lived foreign host.  name: with or without the DARTRAY_ prefix, any case; value NULL: back
- * to the environment's value; "": unset for this process.  Unknown names are DR_ERR_INVALID.  Results never depend on a
- * switch (all of them pick between bit-exact variants or print diagnostics).  The switches:
+ * to the environment's value; "": unset for this process.  Unknown names are DR_ERR_INVALID.  The film never depends on a
+ * switch, with one stated exception: the switches pick between bit-exact variants of a kernel, a layout or a schedule, or
+ * print diagnostics.  The exception is the sampler FORM: FLOAT_SAMPLES and the GEN_* switches choose how the device LD
+ * sampler stores / draws the same keyed streams -- bit-exact by test (tests/test_gpu_render.py), but they are variants of
+ * the sampler, not of a schedule.  The switches:
  *   TRACE_IMPL 1|2|3|5|4  traversal kernel for both ray kinds (default: the scene's measured choice; 5 = the pair kernels with the
  *                         closest-hit rays' cold state in LDS; 4 = treelet-parked); ANY8, CLOSEST_COLD: A/B variants of the pair kernels
  *   TRACE_WG_PER_CU n     workgroups of a persistent traversal launch per CU
  *   STATE_LAYOUT 64|4     path-state layout (default: picked per render from the pilot's stage-list densities)
  *   LAYOUT_PILOT 0        do not measure list densities; take the layout from the scene's lights as round 3 did
  *   BATCH_BITS b          at most 2^b camera samples per batch (16..28)
- *   WORKSPACE job|max     size the path-state workspace to this render (default) or to 2^BATCH_BITS slots at once
  *   PIPELINES 1|2, OVERLAP_ANY 0|1, PILOT 0|1, PILOT_FORCE, PILOT_BITS b   scheduling of a render's launches
  *   PAIR_ORDER ...        memory order of the sibling-pair records (read by dr_scene_create)
- *   TREELET, TREELET_TOP n, TREELET_ROUNDS n   the treelet-parked traversal
+ *   TREELET_ROUNDS n, TREELET_SHARDS n, TREELET_MIN n   the treelet-parked traversal (TRACE_IMPL=4; MEASUREMENTS.md, round 4)
+ *   SCENE_PREP host, GEN_PREPASS 0   dr_scene_create's checks on the host; no burn-in pre-pass above 256 spp
  *   GEN_SLOW_DRAWS, GEN_ALL_BLOCKS, GEN_LANES n, GEN_ONE_WAVE, FLOAT_SAMPLES, LDS_LIGHTS 0   A/B variants of the sampler / shade kernels
  *   BUILD_THREADS n, BUILD_DEBUG   the BVH builders;  RCCL_LIB path   librccl to bind;  STAGE_COUNTS, VERBOSE   diagnostics */
 int dr_set_option(const char* name, const char* value);

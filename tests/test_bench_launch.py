@@ -1,6 +1,7 @@
 """bench.py's launch contract, without a GPU: `python bench.py --gpus N` starts one rank per GPU itself (the driver's
 own command line: torch.distributed.run on 127.0.0.1) unless it already runs under torchrun, and refuses a world size
-that differs from --gpus.  The N-rank workload is the N = 1 workload per GPU (weak scaling over whole 32-pixel tiles).
+that differs from --gpus.  The N-rank HEADLINE is BASELINE configs[2] (C3: the C2 scene at 4096 x 4096, 1024 spp, its 32 x 32
+tiles over the N ranks -- round 5; it used to be the N = 1 workload per GPU, which now follows as extra_configs[0]).
 Mirrors the fan-out of lib/dartray_web/render_manager.dart:100-141 (N workers, one sub-image each)."""
 import os
 import subprocess
@@ -52,8 +53,29 @@ def test_weak_scaling_keeps_the_per_gpu_pixel_count():
     assert bench.weak_resolution(1024, 4) == 2048
 
 
+def test_the_n_rank_headline_is_baseline_configs_2():
+    """`--gpus N` with N > 1 and nothing else: the headline Run is C3 = (4096, 1024 spp, tiles over the ranks, total work
+    fixed), whatever --steps / --warmup the driver passes; the N = 1 workload per GPU follows as a short extra.  N = 1 keeps
+    configs[1] with the short C4 / C5 runs."""
+    for n in (2, 4, 8):
+        pl = bench.plan(n)
+        assert pl["headline"] == ("C3", 4096, 1024, "c3")
+        assert pl["extras"] == [("C2", bench.weak_resolution(1024, n), 256, "weak", 2, 1)]
+    assert bench.plan(8, no_extra=True)["extras"] == []
+    assert bench.plan(8, scaling="weak") == {"headline": ("C2", bench.weak_resolution(1024, 8), 256, "weak"), "extras": []}
+    assert bench.plan(2, scaling="strong-c2")["headline"] == ("C2", 1024, 256, "strong-c2")
+    pl = bench.plan(1)
+    assert pl["headline"] == ("C2", 1024, 256, "weak") and [e[0] for e in pl["extras"]] == ["C4", "C5"]
+    assert bench.plan(1, config="C5") == {"headline": ("C5", 2048, 512, "weak"), "extras": []}
+    # the argument path of the driver's N = 2 command line ends in that plan
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "pl = plan(world, args.scaling, args.config, args.res, args.spp, args.no_extra)" in src
+    assert 'cfg, res, spp, mode = pl["headline"]' in src and "Run(cfg, res, spp, rank, world, mode, args)" in src
+
+
 def test_the_n_rank_line_names_its_single_gpu_reference():
     ref = bench.one_gpu_reference("weak", "C2")
-    assert ref["source"] == "profiles/r03_bench_final.json" and ref["value"] > 100 and ref["unit"] == "Msamples/s"
+    finals = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_bench_final.json"))
+    assert ref["source"] == "profiles/" + finals[-1] and ref["value"] > 100 and ref["unit"] == "Msamples/s"
     ref = bench.one_gpu_reference("c3", "C3")
     assert "4096x4096" in ref["workload"] and ref["value"] == 602.0

@@ -3,7 +3,8 @@
 merges them on rank 0.  The per-rank compute is done by the CPU oracle here (test infrastructure
 standing in for the GPU), so what is tested is the product's sharding logic and the call sequence of
 dartray_amd.dist; on GPUs the same reduce_film goes through dr_film_reduce (RCCL, tests/test_gpu_comm.py).
-bench.py --gpus N runs exactly this split (on configs[2]'s 4096 x 4096 x 1024 spp image by default)."""
+bench.py --gpus N runs exactly this split -- by default on BASELINE configs[2]'s 4096 x 4096 x 1024 spp image (the N-rank
+headline since round 5: bench.plan, tests/test_bench_launch.py), followed by the N = 1 workload per GPU as a short extra."""
 import os
 import sys
 import tempfile

@@ -1,0 +1,126 @@
+"""The switches of the library through the C ABI (dr_set_option), and one process that renders several scenes in turn.
+
+Round 4's dr_option handed out a pointer into ONE thread-local buffer: with STATE_LAYOUT and LAYOUT_PILOT both set through
+dr_set_option the forced layout was read from the pilot switch's value.  Environment variables hid it (getenv pointers are
+stable), and every earlier test that combined switches used the environment.  These set them through the ABI only and ask
+the library what the render actually ran with (dr_scene_last_render_info)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(code, timeout=600, **env_extra):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DARTRAY_") or k in ("DARTRAY_LIB", "DARTRAY_RCCL_LIB")}
+    env.update(env_extra)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0 and "OK" in res.stdout, (res.stdout[-1500:], res.stderr[-3000:])
+    return res
+
+
+def test_switches_set_through_the_c_abi_do_not_clobber_each_other():
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "from dartray_amd import _abi, scenes\n"
+        "_abi.init(0)\n"
+        "lib = _abi.lib()\n"
+        "def opt(name, value):\n"
+        "    _abi.check(lib.dr_set_option(name.encode(), None if value is None else str(value).encode()))\n"
+        "prims, mk = scenes.config('C2', xres=40, yres=40, spp=16, blob=(60, 30))\n"
+        "r = mk(); scene = scenes.make_scene(prims); dev = scene._device()\n"
+        "ref = r.render(scene).film\n"
+        "info = dev.last_render_info(); assert info['state_layout'] == 64 and info['treelet_rounds'] == -1, info\n"
+        # the round-4 failure: the layout switch first, then two more look-ups of other names (one with a LONGER value)
+        "opt('STATE_LAYOUT', 4); opt('LAYOUT_PILOT', 0); opt('VERBOSE', '0000000000000000000000000000000000000001')\n"
+        "f = r.render(scene).film; info = dev.last_render_info()\n"
+        "assert info['state_layout'] == 4, info\n"
+        "assert np.array_equal(f, ref)\n"
+        "opt('STATE_LAYOUT', 64); f = r.render(scene).film; assert dev.last_render_info()['state_layout'] == 64\n"
+        "opt('STATE_LAYOUT', None); opt('LAYOUT_PILOT', None); opt('VERBOSE', None)\n"
+        # kernel switches: the pair kernels with the cold-state closest-hit variant, then round 3's 8-byte any-hit kernel beside it
+        "opt('TRACE_IMPL', 3); opt('CLOSEST_COLD', 1); opt('OVERLAP_ANY', 0)\n"
+        "f = r.render(scene).film; info = dev.last_render_info()\n"
+        "assert (info['closest_kernel'], info['any_hit_kernel'], info['overlap_any']) == (5, 3, 0), info\n"
+        "assert np.array_equal(f, ref)\n"
+        "opt('CLOSEST_COLD', None); opt('OVERLAP_ANY', None); opt('TRACE_IMPL', 2); opt('TRACE_WG_PER_CU', 5)\n"
+        "f = r.render(scene).film; info = dev.last_render_info()\n"
+        "assert (info['closest_kernel'], info['any_hit_kernel'], info['trace_wg_per_cu'], info['overlap_any']) == (2, 2, 5, 1), info\n"
+        "assert np.array_equal(f, ref)\n"
+        "opt('TRACE_WG_PER_CU', None)\n"
+        # the treelet-parked traversal needs its pair order at dr_scene_create: a second device scene of the same primitives
+        "opt('TRACE_IMPL', 4); opt('TREELET_ROUNDS', 2); opt('PAIR_ORDER', 'top:3'); opt('TREELET_MIN', 0)\n"
+        "scene2 = scenes.make_scene(prims); f = r.render(scene2).film; info = scene2._device().last_render_info()\n"
+        "assert (info['closest_kernel'], info['any_hit_kernel'], info['treelet_rounds']) == (4, 4, 2), info\n"
+        "assert np.array_equal(f, ref)\n"
+        "for n in ('TRACE_IMPL', 'TREELET_ROUNDS', 'PAIR_ORDER', 'TREELET_MIN'): opt(n, None)\n"
+        # names the header no longer lists are refused, like any unknown name
+        "for n in (b'WORKSPACE', b'TREELET', b'TREELET_TOP', b'NO_SUCH_SWITCH'): assert lib.dr_set_option(n, b'1') != 0\n"
+        "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    _run(code)
+
+
+def test_one_process_renders_several_scenes_in_turn():
+    """One long-lived host, several scenes: four device scenes of ONE aggregate with different light lists go through its
+    3-entry cache (eviction destroys a device scene at once), two aggregates of different sizes share nothing but the
+    process; every scene keeps its own workspace, pilot choice and state layout.  Rendered alternately -- small, large,
+    another integrator, the evicted one again -- every film equals the film of that scene rendered alone in a fresh
+    process."""
+    body = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "from dartray_amd import _abi, core, scenes\n"
+        "_abi.init(0)\n"
+        "def scene_a():\n"
+        "    prims, mk = scenes.config('C2', xres=64, yres=48, spp=32, blob=(60, 30)); return prims, mk(), None\n"
+        "def scene_b():\n"
+        "    prims, mk = scenes.config('C5', xres=80, yres=64, spp=64, yard=(6, 12), env_res=(128, 64)); r = mk(); return prims, r, r.env\n"
+        "def scene_c():\n"
+        "    prims, mk = scenes.config('C1'); return prims, mk(), None\n"
+        "def scene_d():\n"
+        "    prims, mk = scenes.config('C4', xres=56, yres=40, spp=16, hair=(40, 24)); return prims, mk(), None\n"
+        "makers = {'a': scene_a, 'b': scene_b, 'c': scene_c, 'd': scene_d}\n" % (ROOT, os.path.join(ROOT, "tests")))
+    alone = body + (
+        "prims, r, env = makers[sys.argv[1]]()\n"
+        "np.save(sys.argv[2], r.render(scenes.make_scene(prims, env)).film)\n"
+        "print('OK')\n")
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    paths = {}
+    for k in "abcd":
+        paths[k] = os.path.join(out, "film_alone_%s.npy" % k)
+        env = {kk: v for kk, v in os.environ.items() if not kk.startswith("DARTRAY_")}
+        env["DARTRAY_PILOT_FORCE"] = "1"
+        res = subprocess.run([sys.executable, "-c", alone, k, paths[k]], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+    together = body + (
+        "built = {k: makers[k]() for k in 'abcd'}\n"
+        "sc = {k: scenes.make_scene(built[k][0], built[k][2]) for k in 'abcd'}\n"
+        "films = {}\n"
+        "order = 'abcdabdcbadcc'\n"
+        "for k in order:\n"
+        "    f = built[k][1].render(sc[k]).film\n"
+        "    if k in films: assert np.array_equal(films[k], f), k\n"
+        "    films[k] = f\n"
+        # the aggregate-level cache: four more light lists on scene b's aggregate (its area lights + an equal environment light
+        # of their own each: the cache is keyed on the light objects), three entries -- the least recently used device scene is
+        # destroyed at once, and a list that was evicted is uploaded and piloted again
+        "agg = sc['b'].aggregate\n"
+        "lists = [agg.lights() + [scenes.sky_env(128, 64)] for _ in range(4)]\n"
+        "for l in lists + [lists[0], sc['b'].lights]:\n"
+        "    f = built['b'][1].render(core.Scene(agg, l)).film; assert np.array_equal(f, films['b'])\n"
+        "    assert len(agg._scenes) <= 3\n"
+        "for k in 'abcd': assert np.array_equal(films[k], np.load(sys.argv[1] %% k)), k\n"
+        "info = {k: sc[k]._device().last_render_info() for k in 'abcd'}\n"
+        "assert info['b']['state_layout'] in (4, 64) and info['a']['state_layout'] == 64, info\n"
+        "print('OK')\n")
+    res = subprocess.run([sys.executable, "-c", together, os.path.join(out, "film_alone_%s.npy")],
+                         env=dict({kk: v for kk, v in os.environ.items() if not kk.startswith("DARTRAY_")}, DARTRAY_PILOT_FORCE="1"),
+                         capture_output=True, text=True, timeout=900)
+    for p in paths.values():
+        os.remove(p)
+    assert res.returncode == 0 and "OK" in res.stdout, (res.stdout[-1500:], res.stderr[-3000:])

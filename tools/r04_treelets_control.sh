@@ -1,6 +1,8 @@
 #!/bin/bash
-# round 4: treelet-parked traversal -- batched parking, and the control without the sort (DARTRAY_TREELET_SORT=0: that build's 1-bit radix-sort path faulted
-# after a few stages and the switch was removed again; profiles/r04_tl_c4_timings.txt keeps the lines it printed before)
+# round 4: treelet-parked traversal -- batched parking, T = 12 / 6, per-round timings.
+# (The "unsorted" control legs were removed in round 5: DARTRAY_TREELET_SORT never shipped -- that build's 1-bit radix-sort path
+# faulted after a few stages and the switch was taken out again -- so those legs ran the sorted path a second time.  The control
+# figures quoted in MEASUREMENTS.md come from profiles/r04_tl_c4_timings.txt, printed by the build that still had the switch.)
 cd "$(dirname "$0")/.."
 out=gpurun_out/r04d; mkdir -p $out
 timeout 600 python -m pytest tests/test_gpu_render.py -m gpu -x -q -k "alternative_traversal" > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log; tail -3 $out/pytest.log
@@ -17,9 +19,6 @@ PY
 }
 B="DARTRAY_OVERLAP_ANY=0 DARTRAY_VERBOSE=1"
 run tl_T12 $B DARTRAY_TRACE_IMPL=4 DARTRAY_PAIR_ORDER=top:12
-run tl_T12_unsorted $B DARTRAY_TRACE_IMPL=4 DARTRAY_PAIR_ORDER=top:12 DARTRAY_TREELET_SORT=0
 run tl_T6 $B DARTRAY_TRACE_IMPL=4 DARTRAY_PAIR_ORDER=top:6
 ( export DARTRAY_OVERLAP_ANY=0 DARTRAY_VERBOSE=2 DARTRAY_TRACE_IMPL=4 DARTRAY_PAIR_ORDER=top:12; timeout 400 python bench.py --config C4 --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> $out/rounds_T12.err )
 grep "treelets" $out/rounds_T12.err | tail -26 | head -12
-( export DARTRAY_OVERLAP_ANY=0 DARTRAY_VERBOSE=2 DARTRAY_TRACE_IMPL=4 DARTRAY_PAIR_ORDER=top:12 DARTRAY_TREELET_SORT=0; timeout 400 python bench.py --config C4 --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> $out/rounds_T12_unsorted.err )
-grep "treelets" $out/rounds_T12_unsorted.err | tail -26 | head -12
