@@ -315,6 +315,8 @@ def main():
                          "tiles of the C2 image with N x the pixels (the N = 1 workload per GPU); strong-c2 = tiles of the 1024^2 image; "
                          "samples = every rank renders 256 spp of the whole C2 image with its own seed, films summed")
     ap.add_argument("--cpu-pixels", type=int, default=96, help="cpu baseline: side of the strided pixel grid")
+    ap.add_argument("--blob", default=None, help="diagnostics only (NOT a BASELINE config): C2 / C3 with a blob of SEGMENTS,ROWS (2 x SEGMENTS x ROWS triangles) "
+                                                 "instead of 1000,500 -- e.g. 180,90 = 32 400 triangles, a tree that fits one XCD's L2; the line says so")
     ap.add_argument("--trace-kernels", default=None, help="A/B runs: force the traversal kernels (closest,any), e.g. 2,3 (default: the scene's pilot)")
     args = ap.parse_args()
 
@@ -392,7 +394,8 @@ class Run:
         import torch
         from dartray_amd import _abi, scenes, dist as drdist
         self.cfg, self.res, self.spp, self.rank, self.world, self.mode, self.args = cfg, res, spp, rank, world, mode, args
-        self.prims, mk = scenes.config("C2" if cfg == "C3" else cfg, xres=res, yres=res, spp=spp)
+        skw = {"blob": tuple(int(x) for x in args.blob.split(","))} if getattr(args, "blob", None) and cfg in ("C2", "C3") else {}
+        self.prims, mk = scenes.config("C2" if cfg == "C3" else cfg, xres=res, yres=res, spp=spp, **skw)
         r = mk()
         if mode == "samples" and world > 1:
             r = drdist.sample_set(r, rank)  # independent sample sets of the same image
@@ -506,7 +509,8 @@ class Run:
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "%s: %s, PathIntegrator maxdepth=%d, %dx%d, %d spp, LD sampler (device, counter streams), box filter"
-                       % (self.cfg, NAMES[self.cfg], self.renderer.surfaceIntegrator.maxDepth, self.res, self.res, self.spp),
+                       % (self.cfg + (" VARIANT (--blob %s: not a BASELINE config)" % args.blob if getattr(args, "blob", None) else ""),
+                          NAMES[self.cfg], self.renderer.surfaceIntegrator.maxDepth, self.res, self.res, self.spp),
                        "triangles": int(len(agg.tri_idx)), "bvh_nodes": int(len(agg.nodes)),
                        "bvh_builder": "%s (dr_bvh_build_%s), %.0f ms" % (agg.builder, "device" if agg.builder == "device" else "mixed", agg.build_ms),
                        "trace_kernels": {"closest": knames["closest"], "any_hit": knames["any_hit"],

@@ -1623,6 +1623,22 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       hipEvent_t e1 = sc->getEvent();
       (void)hipEventRecord(e1, s);
       sc->traceEvents.push_back({e0, e1, kind});
+      return e1;
+    };
+    // DARTRAY_STAGE_COUNTS=1 (diagnostics): per stage the list lengths, the kernel times (this batch's own events) and -- with
+    // DARTRAY_STAGE_COUNTS=2, which waits for the device after every stage -- the node visits / triangle tests of its traversals
+    const int stageCounts = dr_opt("DARTRAY_STAGE_COUNTS").toInt(0) > 0 ? dr_opt("DARTRAY_STAGE_COUNTS").toInt(0) : (dr_opt("DARTRAY_STAGE_COUNTS").set ? 1 : 0);
+    struct StageLog {
+      hipEvent_t s0 = nullptr, sMid = nullptr, s1 = nullptr, c0 = nullptr, c1 = nullptr, a0 = nullptr, a1 = nullptr;
+      TraceCounters ctr;
+    };
+    std::vector<StageLog> slog(stageCounts ? (size_t)nStages + 1 : 0);  // [0] = the camera rays' traversal, [b + 1] = stage b
+    TraceCounters ctrBase = {};
+    auto readCtrNow = [&](TraceCounters* c) {
+      if (stageCounts < 2) return;
+      (void)hipStreamSynchronize(s);
+      if (sc->s3) (void)hipStreamSynchronize(sc->s3);
+      (void)hipMemcpy(c, sc->ctr.p, sizeof(TraceCounters), hipMemcpyDeviceToHost);
     };
     hipEvent_t evGen = sc->getEvent();
     (void)hipEventRecord(evGen, s);
@@ -1671,7 +1687,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       HIP_TRY(hipMemsetAsync(C + 1024, 0, (N_COUNTERS - 1024) * sizeof(uint32_t), s));  // (work counters and k_env's counts)
       wc = 0;
     }
+    if (stageCounts && round == 0) readCtrNow(&ctrBase);
     trace(roundQ, nRound, 0, s, w.spill.p);  // camera rays (or this round's child rays)
+    if (stageCounts && round == 0) {
+      slog[0].c0 = sc->traceEvents.back().e0;
+      slog[0].c1 = sc->traceEvents.back().e1;
+      readCtrNow(&slog[0].ctr);
+    }
     for (int b = 0; b < nStages; ++b) {
       StageQueues q;
       q.activeIn = b == 0 ? roundQ : ((b - 1) & 1 ? w.activeB.p : w.activeA.p);
@@ -1693,21 +1715,48 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       (void)hipEventRecord(evS, s);
       if (rd->integrator == DR_INTEGRATOR_PATH) L.shade_path(sc->d, rp, st, q, b, sgrid, s);
       else L.shade_direct(sc->d, rp, st, q, b, sgrid, s);
+      hipEvent_t evMid = nullptr;
+      if (stageCounts && envStage) {
+        evMid = sc->getEvent();
+        (void)hipEventRecord(evMid, s);
+      }
       if (envStage) L.env(sc->d, rp, st, q, b, sgrid, s);
-      timed(2, evS);
+      hipEvent_t evS1 = timed(2, evS);
+      if (stageCounts && round == 0) {
+        slog[b + 1].s0 = evS;
+        slog[b + 1].sMid = evMid;
+        slog[b + 1].s1 = evS1;
+      }
       if (b + 1 < nStages) {
         if (sideBySide) {
           hipEvent_t eS = sc->getEvent(), eA = sc->getEvent();
           (void)hipEventRecord(eS, s);
           (void)hipStreamWaitEvent(sc->s3, eS, 0);
           hipEvent_t closestEnd = trace(q.closestQ, q.nClosest, 0, s, w.spill.p);
+          if (stageCounts && round == 0) {
+            slog[b + 1].c0 = sc->traceEvents.back().e0;
+            slog[b + 1].c1 = sc->traceEvents.back().e1;
+          }
           trace(q.anyQ, q.nAny, 1, sc->s3, w.spill.p + w.spillHalf, closestEnd);
+          if (stageCounts && round == 0) {
+            slog[b + 1].a0 = sc->traceEvents.back().e0;
+            slog[b + 1].a1 = sc->traceEvents.back().e1;
+          }
           (void)hipEventRecord(eA, sc->s3);
           (void)hipStreamWaitEvent(s, eA, 0);
         } else {
           trace(q.closestQ, q.nClosest, 0, s, w.spill.p);
+          if (stageCounts && round == 0) {
+            slog[b + 1].c0 = sc->traceEvents.back().e0;
+            slog[b + 1].c1 = sc->traceEvents.back().e1;
+          }
           trace(q.anyQ, q.nAny, 1, s, w.spill.p);
+          if (stageCounts && round == 0) {
+            slog[b + 1].a0 = sc->traceEvents.back().e0;
+            slog[b + 1].a1 = sc->traceEvents.back().e1;
+          }
         }
+        if (stageCounts && round == 0) readCtrNow(&slog[b + 1].ctr);
       }
     }
     if (!dlSpec) break;
@@ -1745,14 +1794,34 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       timed(4, evF);
       sc->stats.batches++;
     }
-    const bool stageCounts = dr_opt("DARTRAY_STAGE_COUNTS").set;  // diagnostics: the batch's list lengths per stage
     if (stageCounts) {
       std::vector<uint32_t> hc(N_COUNTERS);
       HIP_TRY(hipStreamSynchronize(s));
+      if (sc->s3) HIP_TRY(hipStreamSynchronize(sc->s3));
       HIP_TRY(hipMemcpy(hc.data(), C, N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost));
       for (int b = 0; b < nStages; ++b)
         fprintf(stderr, "stage_counts batch %zu stage %d: in %u active_out %u closest %u any %u env %u\n", (size_t)sc->stats.batches, b,
                 b == 0 ? nslots : hc[248 * 0 + b - 1], hc[248 * 0 + b], hc[248 * 1 + b], hc[248 * 2 + b], hc[N_COUNTERS_TRACE + 64 * b]);
+      // the kernel times of the same stages (HIP events of this batch; side-by-side any-hit launches overlap the closest-hit ones:
+      // DARTRAY_OVERLAP_ANY=0 gives each its own time) and, with DARTRAY_STAGE_COUNTS=2, the traversal work of each stage
+      auto ms = [](hipEvent_t a, hipEvent_t b) {
+        float t = 0.f;
+        return a && b && hipEventElapsedTime(&t, a, b) == hipSuccess ? (double)t : 0.0;
+      };
+      for (int i = 0; i <= nStages; ++i) {
+        const StageLog& g = slog[i];
+        const double shade = g.sMid ? ms(g.s0, g.sMid) : ms(g.s0, g.s1), env = g.sMid ? ms(g.sMid, g.s1) : 0.0;
+        fprintf(stderr, "stage_times batch %zu stage %d: shade %.4f env %.4f closest %.4f any %.4f ms", (size_t)sc->stats.batches, i - 1, shade, env,
+                ms(g.c0, g.c1), ms(g.a0, g.a1));
+        if (stageCounts >= 2) {
+          const TraceCounters& p = i ? slog[i - 1].ctr : ctrBase;
+          if (i == 0 || (g.c0 || g.a0))
+            fprintf(stderr, "; closest rays %llu nodes %llu tris %llu any rays %llu nodes %llu tris %llu", g.ctr.closest_rays - p.closest_rays,
+                    g.ctr.closest_nodes - p.closest_nodes, g.ctr.closest_tris - p.closest_tris, g.ctr.any_rays - p.any_rays,
+                    g.ctr.any_nodes - p.any_nodes, g.ctr.any_tris - p.any_tris);
+        }
+        fprintf(stderr, "\n");
+      }
     }
     HIP_TRY(hipGetLastError());
     if (treeletErr != DR_OK) return fail(treeletErr, "treelet-parked traversal: a device call failed (sort / counter read-back)");
