@@ -221,7 +221,7 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
     return roof, shade, gen, all_alg
 
 
-# What the PMC passes say bounds each kernel (profiles/r0*_traffic.json).  "bound" on the line is
+# What the PMC passes say bounds each kernel (MEASUREMENTS.md; profiles/r0*_traffic.json).  "bound" on the line is
 # the observed one; the fraction is priced against the HBM roofline either way ("bound_priced_against").
 BOUND_OBSERVED = {
     "C2": {"trace_bound": "latency", "shade_bound": "valu-f64+latency",
@@ -428,7 +428,7 @@ class Run:
         import torch
         from dartray_amd import _abi, dist as drdist
         args, world, rank = self.args, self.world, self.rank
-        # The first render of a scene: workspace allocation + the traversal-kernel pilot -- what a
+        # The first render of a scene: workspace allocation + the traversal-kernel pilot (MEASUREMENTS.md) -- what a
         # one-shot render pays on top of a steady-state step; timed on its own, not one of the W + K steps.
         torch.cuda.synchronize()
         t0 = time.perf_counter()

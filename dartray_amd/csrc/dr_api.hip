@@ -425,7 +425,7 @@ void enumeratePixels(const RenderParams& rp, const DrRenderDesc* rd, std::vector
 // The kernels that read or write the path state exist twice: the default layout (every field of a tile's 64 slots one
 // 256-byte run) and sp4 (sub-tiles of four slots: a slot's 41 words within 656 contiguous bytes; the same sources compiled
 // with -DDR_SUB=4 -DDR_NS=sp4).  Dense stage lists are faster in the first; lists that thin out early -- open scenes under an
-// environment map, where most bounce rays leave -- in the second (C5: shade 711 -> 536 ms).
+// environment map, where most bounce rays leave -- in the second (C5: shade 711 -> 536 ms, MEASUREMENTS.md round 3).
 // A render picks one (dr_render_device); results do not depend on it.
 struct LayoutOps {
   decltype(&launch_trace) trace;
@@ -682,7 +682,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         ok = false;  // packed references carry at most 31 primitives per leaf; fall back to the v2 kernel
       }
     }
-    // Memory order of the pair records (experiments; results never depend on it -- the
+    // Memory order of the pair records (experiments, MEASUREMENTS.md round 3; results never depend on it -- the
     // references are explicit).  Default: depth-first (a node's left child next to it).  DARTRAY_PAIR_ORDER=
     //   pad:K    depth-first with K - 1 empty records behind every pair (footprint experiment)
     //   sib      the two child records of a node side by side in ONE 128-byte line (holes where a child is a leaf)
@@ -1503,7 +1503,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const int tgrid = traceGrid();
   rc = ensureSpill(sc, sc->ws, tgrid);
   if (rc) return rc;
-  // DARTRAY_TRACE_IMPL=4: the treelet-parked traversal (a prototype) for the stage queues of a scene
+  // DARTRAY_TRACE_IMPL=4: the treelet-parked traversal (a prototype, MEASUREMENTS.md round 4) for the stage queues of a scene
   // whose pair records were laid out with DARTRAY_PAIR_ORDER=top:T
   const bool treelets = dr_opt("DARTRAY_TRACE_IMPL").first() == '4' && sc->d.pairs && sc->d.topPairs > 0 && !sc->d.nquads && !dlSpec && nPipesEnv < 2;
   if (treelets) {

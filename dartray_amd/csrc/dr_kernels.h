@@ -260,7 +260,7 @@ int traceGridFor(int wgPerCU);  // dr_api.hip: workgroups of a persistent traver
 #define DR_MAX_STACK 128      // LDS + spill entries per lane (the reference uses 64, bvh_accel.dart:120)
 #define DR_TRACE_BLOCK 256
 
-// Treelet-parked traversal (k_trace_tl).  A ray that is about to ENTER a bottom sub-tree -- to
+// Treelet-parked traversal (k_trace_tl; MEASUREMENTS.md, round 4).  A ray that is about to ENTER a bottom sub-tree -- to
 // expand an interior node outside the top treelet (pair index >= DScene.topPairs) while it is not inside a bottom
 // sub-tree already -- is written out as a parked record keyed by that sub-tree's root; the records of a round are sorted
 // by key (= memory order of the sub-trees) and the next round's launch resumes them in that order, so that the rays a

@@ -8,7 +8,7 @@
 //
 // One path per lane, 64-lane waves, path state in 64-slot tiles (BatchState, dr_kernels.h).  The shade kernels run
 // one large workgroup per CU whose waves take chunks of the active list and stage their queue entries in LDS; what bounds
-// each kernel is in DESIGN.md section 3 / 5.  The path is about 1 flop per byte: no MFMA.
+// each kernel is in DESIGN.md section 3 and MEASUREMENTS.md.  The path is about 1 flop per byte: no MFMA.
 //
 // Compiled with -ffp-contract=off: the Dart VM never fuses a*b+c.
 #include <type_traits>
@@ -994,7 +994,7 @@ void shade_prof_dump() {}
 #endif
 
 // One vertex of PathIntegrator.Li (path_integrator.dart:44-119).
-// Launch shape (measured): ONE 768-thread workgroup per CU = 3 waves per SIMD (168 VGPRs each);
+// Launch shape (measured, MEASUREMENTS.md): ONE 768-thread workgroup per CU = 3 waves per SIMD (168 VGPRs each);
 // the waves are independent of each other (own staging region, own reservations, work taken in chunks), 4 waves per
 // SIMD spill.
 #ifndef DR_SHADE_WAVES
@@ -1080,7 +1080,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   else lv = GlobalLights{sc.lights, sc.ltris, sc.lcdf, sc.mats};
   const uint32_t nIn = q.nActiveIn ? *q.nActiveIn : st.nslots;
   // Every iteration fetches its active-list entry, then the whole slot state with independent loads.  Prefetching the
-  // next item's state did not pay (DESIGN.md section 5 row i: vmcnt retires in order, so a prefetch issued before the
+  // next item's state did not pay (MEASUREMENTS.md row i: vmcnt retires in order, so a prefetch issued before the
   // shading code is waited for at its first load; issued after it, it costs 16 spilled registers).
   auto slotOf = [&](uint32_t i) -> uint32_t { return i < nIn ? (q.activeIn ? q.activeIn[i] : i) : 0u; };
   shade_count_init(s_push);

@@ -20,7 +20,7 @@
 //  * todo stack: [depth][lane] u32 in LDS (bank == lane => conflict free) + global spill.
 //  * what the node loop never reads -- direction, minDistance, the queue handle -- waits in LDS between the refill and
 //    the leaf tests / the result store => 72 VGPRs, 7 waves per SIMD.
-// Measured: the loop is bound by the latency of its dependent node fetches, not by VALU
+// Measured (MEASUREMENTS.md, round 2): the loop is bound by the latency of its dependent node fetches, not by VALU
 // issue (9 % fewer VALU instructions: no change; 3..6 workgroups per CU: t = 96 + 839 / w ms), so occupancy is what
 // pays; k_trace3 (sibling pairs, further down) wins on big incoherent trees and is chosen per scene and ray kind by
 // the pilot in dr_render_device.  About 1 flop per byte: no MFMA.
@@ -517,7 +517,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
   // Ray state the node loop never reads -- direction, minDistance, the queue handle -- lives in LDS (6 dwords per
   // lane) between the refill and the leaf tests / the result store: 6 VGPRs fewer in the loop that sets the occupancy.
   // (Keeping it in a global scratch row instead -- to make room for an eighth workgroup -- costs more than the extra
-  // waves return: every phase slows by 6..8 %)
+  // waves return: every phase slows by 6..8 %, MEASUREMENTS.md.)
   typedef __attribute__((address_space(3))) uint32_t cold_u32;
 #define COLD_ST(i, v) (((cold_u32*)cold)[(i) * DR_TRACE_BLOCK] = (v))
 #define COLD_LD(i) (((const cold_u32*)cold)[(i) * DR_TRACE_BLOCK])
@@ -1373,7 +1373,7 @@ __global__ void k_tl_iota(uint32_t* v, uint32_t n) {
 // a child that passes is pushed as a bare reference and expanded when popped with no further test.  No entry parameter
 // next to the reference, no re-test, no pruning pass: 4 bytes per entry instead of 8, and direction / minDistance /
 // maxDistance / the queue handle wait in LDS between refill and leaf test as in k_trace -- 14 + 8 rows = 22 KiB per
-// workgroup and 70 VGPRs: seven workgroups per CU where k_trace3<1> had five.
+// workgroup and 70 VGPRs: seven workgroups per CU where k_trace3<1> had five (MEASUREMENTS.md, round 4).
 // ===========================================================================
 // 14 stack rows + 8 rows of cold ray state = 22 KiB per workgroup and 70 VGPRs => SEVEN workgroups per CU, like k_trace.  Measured:
 // C4 any-hit 113.3 (k_trace3<1>, 5 workgroups) -> 103.6 ms with 16 rows / 6 workgroups, 104.6 with 14 / 7; on the cache-resident C2
@@ -1612,7 +1612,7 @@ static bool coldClosest() {
 static int traceImpl(const DScene& sc, int anyHit, int force = 0, bool* cold = nullptr) {
   const char e = dr_opt("DARTRAY_TRACE_IMPL").first();  // (read per launch: dr_set_option may change it between renders)
   const int env = ((e >= '1' && e <= '3') || e == '5') ? e - '0' : (e == '4' ? 3 : 0);  // 4: treelet-parked stage traversals (dr_api.hip); everything else v3
-  // v2 is the fastest on cache-resident trees, v3 (sibling pairs) on big incoherent ones:
+  // v2 is the fastest on cache-resident trees, v3 (sibling pairs) on big incoherent ones (MEASUREMENTS.md):
   // unless DARTRAY_TRACE_IMPL fixes it, the choice is the one measured for this scene (sc.traceKernel, set by the
   // pilot of dr_render_device)
   int impl = force ? force : (env ? env : (sc.traceKernel[anyHit ? 1 : 0] ? (int)sc.traceKernel[anyHit ? 1 : 0] : 2));

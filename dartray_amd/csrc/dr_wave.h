@@ -65,7 +65,7 @@ template <int NQ = 4>
 DR_DEV uint32_t* stage_region(PushStage& sm) {
   return (uint32_t*)(&sm + 1) + (size_t)(threadIdx.x >> 6) * NQ * DR_PUSH_CAP;
 }
-// DR_SORT_CONT (experiment; 2: the shadow rays too): a wave's round of continuation rays leaves for the queue
+// DR_SORT_CONT (experiment, MEASUREMENTS.md round 3; 2: the shadow rays too): a wave's round of continuation rays leaves for the queue
 // grouped by the octant of its direction (3 sign bits, carried in bits 29..31 of the staged entry; slots stay below
 // 2^29): rays of one octant take the same near / far decisions at every node (bvh_accel.dart:147-153).
 #ifndef DR_SORT_CONT

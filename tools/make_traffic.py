@@ -80,7 +80,7 @@ def build(src, cfg, rnd):
         if s and "SQ_INSTS_VALU" in s and s["SQ_INSTS_VALU"] > 0:
             # SQ_ACTIVE_INST_VALU counts quad-cycles per wave instruction (4 cycles each, the cost of a wave issuing ALONE);
             # with other waves interleaved a wave64 instruction occupies the SIMD for 2 cycles (MI355X_MICROARCH.md), so the
-            # pipe's real occupancy is about half of this figure (A/B runs: DESIGN.md section 5, round 2).
+            # pipe's real occupancy is about half of this figure (A/B runs: MEASUREMENTS.md, round 2).
             cycles = s["SQ_ACTIVE_INST_VALU"] * 4 / 1024.0  # quad-cycles -> cycles per SIMD
             e["valu_issue_share_at_4_cycles_per_instruction"] = cycles / (avg_ms * 1e-3 * 2.4e9) if avg_ms else None
             e["valu_lane_utilisation"] = s["SQ_THREAD_CYCLES_VALU"] / (s["SQ_INSTS_VALU"] * 64)
@@ -110,6 +110,15 @@ def build(src, cfg, rnd):
                      "--no-cpu-baseline --no-extra` (two full renders, every launch full size); launch times from the --kernel-trace --stats "
                      "run of the same script.  Counters sit on the L2's memory side, so Infinity-Cache hits are included: an upper bound on "
                      "HBM bytes." % (rnd, "3" if "k_trace3" in dom else "2", "" if cfg == "c2" else "--config %s " % cfg.upper()))
+    tk = bench.get("config", {}).get("trace_kernels")
+    if rnd >= "r05" and tk:
+        res["trace_kernels"] = {"closest": tk["closest"], "any_hit": tk["any_hit"]}
+        res["method"] = ("tools/profile_%s.sh: a dry run of the bench command reads what this config's pilot picks on the box (closest-hit %s, any-hit %s), "
+                         "then rocprofv3 --pmc passes (counters only, one group per pass) on `DARTRAY_PILOT=0 DARTRAY_STATE_LAYOUT=<picked> python3 bench.py %s"
+                         "--trace-kernels <picked> --steps 1 --warmup 0 --no-cpu-baseline --no-extra` (two full renders, every launch a full-size launch of "
+                         "those kernels); launch times from the --kernel-trace --stats run of the same script (DARTRAY_OVERLAP_ANY=0).  Counters sit on the "
+                         "L2's memory side, so Infinity-Cache hits are included: an upper bound on HBM bytes."
+                         % (rnd, tk["closest"], tk["any_hit"], "" if cfg == "c2" else "--config %s " % cfg.upper()))
     res["sources"] = ["profiles/%s_pmc_%s_%s.txt" % (rnd, cfg, k) for k, p in (("rdreq", rdp), ("wrreq", wrp), ("sq", sqp), ("tcc", tccp)) if p] + \
                      ["profiles/%s_%s" % (rnd, os.path.basename(statsp).replace(rnd + "_", ""))]
     return res
