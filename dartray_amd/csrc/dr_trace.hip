@@ -636,6 +636,32 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
     if (mode == M_TRAV) {
       const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
       const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
+#if defined(DR_EXP_PAD_VALU) || defined(DR_EXP_PAD_LDS)
+      // Timing experiments only (tools/variants.sh; never in the product build): what does ONE more instruction per node visit
+      // cost at today's occupancy?  DR_EXP_PAD_VALU=N: N plain f32 VALU instructions (two independent chains, results unused);
+      // DR_EXP_PAD_LDS=N: N more reads of the lane's own stack row.  (MEASUREMENTS.md round 5: which resource the
+      // occupancy-independent part of the kernel's time belongs to.)
+      {
+        float p0 = bminx, p1 = bmaxx;
+#ifdef DR_EXP_PAD_VALU
+#pragma unroll
+        for (int k_ = 0; k_ < DR_EXP_PAD_VALU; k_ += 2) {
+          asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(p0));
+          asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(p1));
+        }
+#endif
+#ifdef DR_EXP_PAD_LDS
+        typedef __attribute__((address_space(3))) const uint32_t lds_u32p;
+#pragma unroll
+        for (int k_ = 0; k_ < DR_EXP_PAD_LDS; ++k_) {
+          uint32_t v_ = ((lds_u32p*)lds)[(k_ & 7) * DR_TRACE_BLOCK];
+          asm volatile("" : "+v"(v_));
+          p0 += __uint_as_float(v_ & 0u);
+        }
+#endif
+        asm volatile("" ::"v"(p0), "v"(p1));
+      }
+#endif
       bool ok = false, amb = true;
       if (!ray.needF64) {  // (two predicates instead of a three-valued int: they stay lane masks in SGPRs)
         bool sureMiss;

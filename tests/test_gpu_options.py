@@ -114,7 +114,7 @@ def test_one_process_renders_several_scenes_in_turn():
         "for l in lists + [lists[0], sc['b'].lights]:\n"
         "    f = built['b'][1].render(core.Scene(agg, l)).film; assert np.array_equal(f, films['b'])\n"
         "    assert len(agg._scenes) <= 3\n"
-        "for k in 'abcd': assert np.array_equal(films[k], np.load(sys.argv[1] %% k)), k\n"
+        "for k in 'abcd': assert np.array_equal(films[k], np.load(sys.argv[1] % k)), k\n"
         "info = {k: sc[k]._device().last_render_info() for k in 'abcd'}\n"
         "assert info['b']['state_layout'] in (4, 64) and info['a']['state_layout'] == 64, info\n"
         "print('OK')\n")
