@@ -272,6 +272,70 @@ def kernel_profile(tag, names):
     return out
 
 
+def trace_ceilings(tag, kname, st, steps):
+    """Throughput ceilings of the closest-hit traversal kernel, per step, from what the kernel asks of each shared resource:
+    the time each resource alone would need for this run's work at its MEASURED peak rate (tools/gather_rate.hip:
+    profiles/r05_gather_rates.json) -- VALU issue (2 cycles per wave64 instruction on a SIMD-32 with several waves resident), the
+    per-CU L1's divergent-address path (16-byte lane loads of different lines), L2 requests, and random 128-byte lines from beyond
+    L2 (Infinity Cache / HBM) -- with the per-byte demands (instructions, L2 requests, lines beyond L2 per algorithmic byte) taken
+    from the committed PMC passes of the same kernel on the same config.  The kernel is UNDER each of them; `binding` is the largest,
+    `frac_of_binding_ceiling` = that over the measured time: what a perfectly overlapped, latency-free version would reach."""
+    try:
+        rates = json.load(open(os.path.join(ROOT, "profiles", "r05_gather_rates.json")))
+    except (OSError, ValueError):
+        return None
+    prof = None
+    for fname in traffic_files(tag):
+        d = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        k = next((v for n, v in d.get("kernels", {}).items() if n.split("::")[-1] == kname), None)
+        if k and d.get("alg_bytes_per_launch") and d.get("kernel", "").split("::")[-1] == kname:
+            prof = (fname, d, k)
+            break
+    if not prof or not st["closest_ms"]:
+        return None
+    fname, d, k = prof
+    alg_prof = d["alg_bytes_per_launch"]
+    alg_run = (32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]) / steps
+    clk, simds, cus = 2.4e9, 1024, 256
+    out = {"kernel": kname, "per": "step", "measured_ms": round(st["closest_ms"] / steps, 2),
+           "demand_source": "profiles/" + fname + " (per algorithmic byte)", "rate_source": "profiles/r05_gather_rates.json (tools/gather_rate.hip)"}
+    c = {}
+    if k.get("valu_issue_share_at_4_cycles_per_instruction") and k.get("avg_launch_ms_kernel_trace"):
+        instr = k["valu_issue_share_at_4_cycles_per_instruction"] * k["avg_launch_ms_kernel_trace"] * 1e-3 * clk / 4.0 * simds
+        c["valu_issue_ms"] = instr / alg_prof * alg_run * 2.0 / (simds * clk) * 1e3
+    c["l1_divergent_loads_ms"] = (2.0 * st["closest_nodes"] + 3.0 * st["closest_tris"]) / steps / (rates["l1_hit_lane_loads_per_cu_cycle"] * cus * clk) * 1e3
+    if k.get("l2_requests_per_launch"):
+        c["l2_requests_ms"] = k["l2_requests_per_launch"] / alg_prof * alg_run / rates["l2_hit_records_per_s"] * 1e3
+    if k.get("read_requests_per_launch"):
+        c["lines_beyond_l2_ms"] = k["read_requests_per_launch"] / alg_prof * alg_run / rates["infinity_cache_lines_per_s"] * 1e3
+    out["ceilings_ms"] = {n: round(v, 1) for n, v in c.items()}
+    binding = max(c, key=c.get)
+    out["binding"] = binding
+    out["frac_of_binding_ceiling"] = round(c[binding] / (st["closest_ms"] / steps), 3)
+    out["reading"] = ("each shared resource alone would need this long for the step's closest-hit traversal; the kernel takes `measured_ms` because the "
+                      "resources overlap imperfectly behind dependent fetches at the occupancy its registers allow (7 workgroups per CU)")
+    return out
+
+
+def occupancy_model(tag, kname):
+    """The fitted occupancy model of C2's k_trace<0> (profiles/r05_c2_occupancy_model.json: closest-hit ms per step against
+    workgroups per CU, w = 3..7): the additive form the earlier rounds quoted, its residual, and the two forms that fit better."""
+    if tag not in ("C2", "C3") or kname != "k_trace<0>":
+        return None
+    try:
+        m = json.load(open(os.path.join(ROOT, "profiles", "r05_c2_occupancy_model.json")))["scenes"]["big"]["closest"]
+    except (OSError, ValueError, KeyError):
+        return None
+    a = m["additive"]
+    return {"form": "closest_ms_per_step = a + b / w  (w = workgroups per CU; a: not hidden by more resident waves, b / w: exposed latency)",
+            "a_ms": a["a_ms"], "b_ms": a["b_ms"], "rms_ms": a["rms_ms"], "w": 7, "predicted_ms": round(a["a_ms"] + a["b_ms"] / 7.0, 1),
+            "better_fits": {"soft_max sqrt(a^2 + (b/w)^2)": m["soft_max"], "closed_queue (MVA: one server C, delay M)": m["closed_queue"]},
+            "what_a_is": "NOT Infinity-Cache bandwidth: a tree that fits one XCD's L2 (0.19x the bytes beyond L2) keeps 0.93x the intercept, which follows the node "
+                         "visits (0.87x); numerically it coincides with three separate ceilings of ~105 ms each (roofline.ceilings) -- VALU issue, the L1's "
+                         "divergent-load path and random lines beyond L2 -- none of which binds alone (MEASUREMENTS.md, round 5)",
+            "source": "profiles/r05_c2_occupancy_model.json (tools/r05_c2_intercept.sh, tools/fit_occupancy.py)"}
+
+
 def profiled_kernels(tag):
     """Per-kernel entries of the newest committed traffic file of this config."""
     for name in traffic_files(tag):
@@ -480,6 +544,8 @@ class Run:
         knames = {"closest": {2: "k_trace<0>", 3: "k_trace3<0>", 5: "k_trace3c"}.get(picked[0], str(picked[0])),
                   "any_hit": {2: "k_trace<1>", 3: "k_trace3a"}.get(picked[1], str(picked[1]))}
         roof, shade, gen, all_alg = roofline_objects(st, dt, copy.value, knames["closest"], self.cfg, gbs, kernels_forced=forced)
+        roof["ceilings"] = trace_ceilings(self.cfg, knames["closest"], st, steps)
+        roof["model"] = occupancy_model(self.cfg, knames["closest"])
         pilot = self.dev.pilot()
         near = []  # picks the calibration batches decided by less than 2 %
         pc, pa = pilot["closest"], pilot["any_hit"]
