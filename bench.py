@@ -225,7 +225,9 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
 # the observed one; the fraction is priced against the HBM roofline either way ("bound_priced_against").
 BOUND_OBSERVED = {
     "C2": {"trace_bound": "latency", "shade_bound": "valu-f64+latency",
-           "trace": "dependent-fetch latency, scene cache resident (L2 / Infinity Cache serve ~half the algorithmic bytes); t = 96 + 839 / workgroups-per-CU ms",
+           "trace": "dependent-fetch latency at seven workgroups per CU on top of three half-loaded throughput ceilings of ~108 ms each per step -- VALU issue, "
+                    "the L1's divergent-load path, random lines beyond L2 (roofline.ceilings; MEASUREMENTS.md round 5: the occupancy-independent part is NOT "
+                    "Infinity-Cache bandwidth); the scene is cache resident (L2 / Infinity Cache serve ~half the algorithmic bytes)",
            "shade": "f64 VALU issue (~0.7 busy) and state-access latency at 3 waves per SIMD; 1.6x the algorithmic bytes at the memory side"},
     "C3": {"trace_bound": "latency", "shade_bound": "valu-f64+latency", "trace": "as C2 (same scene)", "shade": "as C2"},
     "C4": {"trace_bound": "hbm", "shade_bound": "valu-f64+latency",
@@ -670,7 +672,9 @@ def replay_leg(run, res=128, spp=64):
     t0 = time.perf_counter()
     rec = osc.render(ob.render_desc(r, sampler_mode=0), record=n, max_tail=40)
     t_cpu = time.perf_counter() - t0
-    r.sampler = core.HostBufferSampler(r.camera, spp, rec["pixel_xy"][::spp], rec["sample_vec"], rec["tail"])
+    # (round 5: the PACKED tail -- DrRenderDesc.tail_offsets -- only the values a sample drew cross the host link)
+    r.sampler = core.HostBufferSampler(r.camera, spp, rec["pixel_xy"][::spp], rec["sample_vec"], rec["tail"], rec["tail_count"])
+    fixed_tail_bytes = rec["tail"].nbytes
     out = r.render(run.scene)  # warm-up: the workspace of this shape
     exact = bool(np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"]))
     reps = 3
@@ -679,14 +683,16 @@ def replay_leg(run, res=128, spp=64):
         out = r.render(run.scene)
     dt = (time.perf_counter() - t0) / reps
     film_samples = res * res * spp
-    bytes_in = rec["sample_vec"].nbytes + rec["tail"].nbytes + rec["pixel_xy"][::spp].nbytes
+    bytes_in = rec["sample_vec"].nbytes + r.sampler.tail.nbytes + r.sampler.tail_offsets.nbytes + rec["pixel_xy"][::spp].nbytes
     return {"value": round(film_samples / dt / 1e6, 3), "unit": "Msamples/s", "bit_exact_vs_serial_oracle": exact,
             "samples_traced": n, "ms_per_render": round(dt * 1e3, 2), "host_bytes_in_per_render": int(bytes_in),
             "cpu_serial_oracle_Msamples_s": round(film_samples / t_cpu / 1e6, 4),
+            "host_bytes_in_with_the_fixed_tail_form": int(bytes_in - r.sampler.tail.nbytes - r.sampler.tail_offsets.nbytes + fixed_tail_bytes),
             "what": "DR_SAMPLER_HOST_BUFFER replay of the reference's ONE serial Random(taskNum) stream (recorded by the CPU oracle in its "
                     "serial mode): %dx%d film window of the bench scene x %d spp, dr_render from host pointers -- %d B of sample vector + "
-                    "%d B of RNG tail per sample over PCIe in, film + image out; the price of 'identical Sampler RNG seeds' against the "
-                    "keyed per-pixel streams of the headline" % (res, res, spp, rec["sample_vec"].shape[1] * 4, rec["tail"].shape[1] * 8)}
+                    "%.0f B of RNG tail per sample (packed: the values a sample drew + one 8-byte offset; the fixed form is %d B) over PCIe in, "
+                    "film + image out; the price of 'identical Sampler RNG seeds' against the keyed per-pixel streams of the headline"
+                    % (res, res, spp, rec["sample_vec"].shape[1] * 4, (r.sampler.tail.nbytes + r.sampler.tail_offsets.nbytes) / n, rec["tail"].shape[1] * 8)}
 
 
 def cpu_baseline(prims, renderer, grid, H, W, spp):

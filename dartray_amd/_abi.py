@@ -110,7 +110,7 @@ class DrRenderDesc(C.Structure):
                 ("tile_rank", C.c_int32), ("tile_count", C.c_int32), ("tile_size", C.c_int32),
                 ("nsamples", C.c_int64),
                 ("pixel_xy", C.c_void_p), ("sample_vec", C.c_void_p), ("sample_stride", C.c_int32),
-                ("tail", C.c_void_p), ("max_tail", C.c_int32)]
+                ("tail", C.c_void_p), ("max_tail", C.c_int32), ("tail_offsets", C.c_void_p)]
 
 
 class DrRenderStats(C.Structure):

@@ -1116,16 +1116,28 @@ class LowDiscrepancySampler:
 class HostBufferSampler:
     """Explicit camera samples: pixel_xy [npix,2] int32, sample_vec [npix*spp, nfloats] f32
     (imageU, imageV, lensU, lensV, time, oneD..., twoD...), tail [npix*spp, max_tail] f64 =
-    the RNG.randomFloat() values PathIntegrator.Li draws for bounces >= 3."""
+    the RNG.randomFloat() values PathIntegrator.Li draws for bounces >= 3.  tail_count [npix*spp] (how many of its
+    max_tail slots each sample actually drew: the oracle's recording has it) selects the PACKED form of the C ABI
+    (DrRenderDesc.tail_offsets): only the drawn values cross the host link."""
 
-    def __init__(self, camera, spp, pixel_xy, sample_vec, tail=None):
+    def __init__(self, camera, spp, pixel_xy, sample_vec, tail=None, tail_count=None):
         self.camera = camera
         self.samplesPerPixel = int(spp)
         self.pixel_xy = np.ascontiguousarray(pixel_xy, dtype=np.int32).reshape(-1, 2)
         self.sample_vec = np.ascontiguousarray(sample_vec, dtype=np.float32)
         self.tail = None if tail is None else np.ascontiguousarray(tail, dtype=np.float64)
+        self.tail_offsets = None
         if len(self.sample_vec) != len(self.pixel_xy) * self.samplesPerPixel:
             raise ValueError("sample_vec must hold spp vectors per pixel")
+        if tail_count is not None and self.tail is not None:
+            cnt = np.minimum(np.asarray(tail_count, dtype=np.int64), self.tail.shape[1])
+            if len(cnt) != len(self.sample_vec):
+                raise ValueError("tail_count must hold one entry per sample")
+            self.max_tail = int(self.tail.shape[1])
+            self.tail_offsets = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+            self.tail = np.ascontiguousarray(self.tail[np.arange(self.tail.shape[1])[None, :] < cnt[:, None]])  # row-major: draw order per sample
+            if len(self.tail) == 0:
+                self.tail = np.zeros(1, np.float64)
 
 
 class PathIntegrator:
@@ -1202,8 +1214,12 @@ class SamplerRenderer:
             d.sample_stride = s.sample_vec.shape[1]
             if s.tail is not None:
                 d.tail = s.tail.ctypes.data
-                d.max_tail = s.tail.shape[1]
-            keep = [s.pixel_xy, s.sample_vec, s.tail]
+                if s.tail_offsets is not None:
+                    d.max_tail = s.max_tail
+                    d.tail_offsets = s.tail_offsets.ctypes.data
+                else:
+                    d.max_tail = s.tail.shape[1]
+            keep = [s.pixel_xy, s.sample_vec, s.tail, s.tail_offsets]
         else:
             d.sampler_mode = _abi.DR_SAMPLER_COUNTER
             d.seed = self.sampler.seed

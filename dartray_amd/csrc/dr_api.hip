@@ -68,6 +68,7 @@ struct Workspace {
   DevBuf<uint32_t> scr;  // compact samples: scramble words [2 * nBlocks][pixCap]
   DevBuf<uint2> genState;  //   and the streams' generator states behind their burn-in draws [nBlocks][pixCap] (k_gen_burnin)
   DevBuf<double> tail;
+  DevBuf<unsigned long long> tailOff;  // packed tail (DrRenderDesc.tail_offsets): the batch's nslots + 1 offsets
   DevBuf<uint32_t> activeA, activeB, closestQ, anyQ, counters, spill;
   DevBuf<uint32_t> envQ;  // plain-triangle scenes under an environment map: k_env's list of a stage (cap entries)
   size_t spillHalf = 0;
@@ -377,6 +378,8 @@ BatchState makeState(Workspace& w, const SampleForm& sf, const int2* pix, uint32
   st.idxShift = (uint32_t)sf.idxShift;
   st.pix = pix;
   st.tail = useTail ? w.tail.p : nullptr;
+  st.tailOff = nullptr;  // (the packed form: set per batch by dr_render_device)
+  st.tailBase = 0ull;
   st.tiles = w.tiles.p;  // field offsets inside a tile: the F_* constants of dr_kernels.h
   st.svFloat = sf.compact ? 0u : 1u;
   st.svScr = sf.compact ? w.scr.p : nullptr;
@@ -1416,6 +1419,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     if (rd->sample_stride < rp.nFloats) return fail(DR_ERR_INVALID, "sample_stride smaller than the sample vector");
     if (needTail > 0 && (!rd->tail || rd->max_tail < needTail))
       return fail(DR_ERR_INVALID, "host-buffer sampler: tail buffer missing or max_tail too small for max_depth");
+    if (needTail > 0 && rd->tail_offsets && rd->tail_offsets[rd->nsamples] < rd->tail_offsets[0])
+      return fail(DR_ERR_INVALID, "host-buffer sampler: tail_offsets must be non-decreasing");
     int64_t np = rd->nsamples / spp;
     pixels.resize(np);
     for (int64_t i = 0; i < np; ++i) pixels[i] = make_int2(rd->pixel_xy[2 * i], rd->pixel_xy[2 * i + 1]);
@@ -1463,8 +1468,11 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // permuted indices in the compact form, 4 B per float otherwise; + the RNG tail in host-buffer mode).  The
     // default batch (2^28) takes 56 GB of a 288 GB MI355X; on a device with less free
     // memory the batch shrinks instead of failing (results do not depend on the batch size).
-    const uint64_t perSlot = (uint64_t)maxStateWords * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 +
-                             (hostBuf && needTail > 0 ? (uint64_t)rd->max_tail * 8 : 0) + (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0) +
+    const bool packedTail = hostBuf && needTail > 0 && rd->tail_offsets != nullptr;
+    const uint64_t tailPerSlot = !(hostBuf && needTail > 0) ? 0ull
+                                 : (packedTail ? 16ull + 8ull * ((rd->tail_offsets[rd->nsamples] - rd->tail_offsets[0]) / (uint64_t)rd->nsamples + 1ull)
+                                               : (uint64_t)rd->max_tail * 8);
+    const uint64_t perSlot = (uint64_t)maxStateWords * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 + tailPerSlot + (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0) +
                              (sf.compact ? (uint64_t)(16 * sf.nBlocks + spp - 1) / spp : 0) +  // scramble words + generator states, per (block, pixel)
                              (dlSpec ? (uint64_t)std::max(1, rd->max_depth) * sizeof(SpecFrame) + 12 : 0);
     size_t freeB = 0, totalB = 0;
@@ -1486,7 +1494,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const uint32_t cap = pixPerBatch * (uint32_t)spp;
   const auto tAlloc0 = std::chrono::steady_clock::now();
   const uint32_t capBefore = sc->ws.cap;
-  int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0, maxStateWords);
+  const bool packedTailForm = hostBuf && needTail > 0 && rd->tail_offsets != nullptr;  // (its buffers are sized per batch, in runBatch)
+  int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0 && !packedTailForm, maxStateWords);
   if (rc) return rc;
   if (dr_opt("DARTRAY_VERBOSE") && sc->ws.cap != capBefore) {
     (void)hipDeviceSynchronize();
@@ -1647,7 +1656,19 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       HIP_TRY(hipMemcpyAsync(w.aosSamples.p, rd->sample_vec + (size_t)p0 * spp * rd->sample_stride,
                              (size_t)nslots * rd->sample_stride * sizeof(float), hipMemcpyHostToDevice, s));
       L.transpose_samples(w.aosSamples.p, rd->sample_stride, st, rp.nFloats, s);
-      if (needTail > 0)
+      if (needTail > 0 && packedTailForm) {
+        // the batch's runs are one contiguous piece of the packed array: [off[first], off[first + nslots])
+        const uint64_t* off = rd->tail_offsets + (size_t)p0 * spp;
+        const uint64_t o0 = off[0], o1 = off[nslots];
+        if (o1 < o0) return fail(DR_ERR_INVALID, "host-buffer sampler: tail_offsets must be non-decreasing");
+        HIP_TRY(w.tail.alloc((size_t)(o1 - o0) + (size_t)rd->max_tail + 1));  // (+ max_tail: a lane reads rec[pos] only inside its run, the slack is belt and braces)
+        HIP_TRY(w.tailOff.alloc((size_t)nslots + 1));
+        if (o1 > o0) HIP_TRY(hipMemcpyAsync(w.tail.p, rd->tail + o0, (size_t)(o1 - o0) * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w.tailOff.p, off, ((size_t)nslots + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        st.tail = w.tail.p;
+        st.tailOff = w.tailOff.p;
+        st.tailBase = o0;
+      } else if (needTail > 0)
         HIP_TRY(hipMemcpyAsync(w.tail.p, rd->tail + (size_t)p0 * spp * rd->max_tail,
                                (size_t)nslots * rd->max_tail * sizeof(double), hipMemcpyHostToDevice, s));
     } else {

@@ -125,6 +125,9 @@ struct BatchState {
   const int2* pix;  // raster pixel of each batch pixel
   float* tiles;     // the tiled state
   const double* tail;  // [cap][maxTail] host-buffer mode, else null
+  // packed form of the tail (DrRenderDesc.tail_offsets): slot s owns tail[tailOff[s] - tailBase .. tailOff[s + 1] - tailBase); null: fixed form
+  const unsigned long long* tailOff;
+  unsigned long long tailBase;
   // The camera-sample vectors (Sample, montecarlo.dart:437-452) live in the sample region of each tile, in one of two forms:
   //  float (svFloat != 0) -- nFloats 64-word runs per tile (host-buffer sampler, multi-entry LD blocks);
   //  compact              -- the on-device LD sampler only stores what cannot be recomputed: per (LD block, slot)

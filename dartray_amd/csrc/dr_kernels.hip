@@ -854,7 +854,7 @@ struct TailSrc {
   DR_DEV void init(const RenderParams& rp, const BatchState& st, uint32_t slot, int startPos) {
     pos = startPos;
     if (st.tail) {
-      rec = st.tail + (size_t)slot * rp.maxTail;
+      rec = st.tailOff ? st.tail + (size_t)(st.tailOff[slot] - st.tailBase) : st.tail + (size_t)slot * rp.maxTail;
     } else {
       rec = nullptr;
       const int2 xy = st.pix[slot >> rp.sppShift];
@@ -863,9 +863,12 @@ struct TailSrc {
       for (int i = 0; i < 2 * startPos; ++i) rng.step();
     }
   }
-  DR_DEV double next(const RenderParams& rp) {
+  // (the packed form's run length is re-read from the offsets instead of being held in a register: host-buffer replays only)
+  DR_DEV double next(const RenderParams& rp, const BatchState& st, uint32_t slot) {
     if (rec) {
-      double v = pos < rp.maxTail ? rec[pos] : 0.0;
+      bool in = pos < rp.maxTail;
+      if (in && st.tailOff) in = (unsigned long long)pos < st.tailOff[slot + 1u] - st.tailOff[slot];
+      double v = in ? rec[pos] : 0.0;
       ++pos;
       return v;
     }
@@ -1214,11 +1217,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
             bs1 = su(5);
             if (QUAD) bsc = su(9);
           } else {
-            lu = ts.next(rp);                                   // integrator.dart:96
-            ls0 = (float)ts.next(rp); ls1 = (float)ts.next(rp); // LightSample.random light_sample.dart:46-51
-            lsc = ts.next(rp);
-            bs0 = (float)ts.next(rp); bs1 = (float)ts.next(rp); // BSDFSample.random bsdf_sample.dart:37-42
-            bsc = ts.next(rp);                                  // uComponent
+            lu = ts.next(rp, st, slot);                                   // integrator.dart:96
+            ls0 = (float)ts.next(rp, st, slot); ls1 = (float)ts.next(rp, st, slot); // LightSample.random light_sample.dart:46-51
+            lsc = ts.next(rp, st, slot);
+            bs0 = (float)ts.next(rp, st, slot); bs1 = (float)ts.next(rp, st, slot); // BSDFSample.random bsdf_sample.dart:37-42
+            bsc = ts.next(rp, st, slot);                                  // uComponent
           }
           int lightNum = (int)floor(lu * rp.nLights);
           lightNum = lightNum < rp.nLights - 1 ? lightNum : rp.nLights - 1;
@@ -1248,8 +1251,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           o1 = su(7);
           if (QUAD) oc = su(8);
         } else {
-          o0 = (float)ts.next(rp); o1 = (float)ts.next(rp);
-          oc = ts.next(rp);
+          o0 = (float)ts.next(rp, st, slot); o1 = (float)ts.next(rp, st, slot);
+          oc = ts.next(rp, st, slot);
         }
         F3 wi = F3{0, 0, 0};
         double pdf = 0.0;
@@ -1261,7 +1264,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           if (bounce > 3) {  // Russian roulette, drawn BEFORE the maxDepth test (path_integrator.dart:93-103)
             double lum = clum(beta);
             double cp = (lum != lum) ? lum : (lum < 0.5 ? lum : 0.5);  // Math.min(0.5, lum) propagates NaN
-            if (ts.next(rp) > cp) alive = false;
+            if (ts.next(rp, st, slot) > cp) alive = false;
             else beta = cdivD(beta, cp);
           }
         }

@@ -243,6 +243,13 @@ typedef struct DrRenderDesc {
   int32_t sample_stride;
   const double* tail;       /* [nsamples][max_tail] RNG.randomFloat() values drawn inside Li, or NULL */
   int32_t max_tail;
+  /* Optional packed form of `tail` (round 5): tail_offsets[nsamples + 1], non-decreasing; sample s owns
+   * tail[tail_offsets[s] .. tail_offsets[s + 1]) -- the values it actually drew, in draw order (position p of the fixed
+   * form = element p of the run; a read past the run yields 0.0 like the zero fill of the fixed form); max_tail stays the
+   * bound on a run's length.  NULL: the fixed [nsamples][max_tail] form.  A path draws nothing before its fourth vertex
+   * and most paths end early, so a recorded C2 stream holds ~5 of its 40 slots per sample: the replay moves 0.4 x the
+   * bytes over PCIe. */
+  const uint64_t* tail_offsets;
 } DrRenderDesc;
 
 /* Counters and timings accumulated over the dr_render* calls on a scene since
@@ -501,7 +508,7 @@ DR_ABI_SIZE(DrFilm, 1080);
 DR_ABI_OFFSET(DrFilm, crop, 8);
 DR_ABI_OFFSET(DrFilm, filter_xw, 40);
 DR_ABI_OFFSET(DrFilm, filter_table, 56);
-DR_ABI_SIZE(DrRenderDesc, 1344);
+DR_ABI_SIZE(DrRenderDesc, 1352);
 DR_ABI_OFFSET(DrRenderDesc, film, 168);
 DR_ABI_OFFSET(DrRenderDesc, integrator, 1248);
 DR_ABI_OFFSET(DrRenderDesc, seed, 1264);
@@ -513,6 +520,7 @@ DR_ABI_OFFSET(DrRenderDesc, sample_vec, 1312);
 DR_ABI_OFFSET(DrRenderDesc, sample_stride, 1320);
 DR_ABI_OFFSET(DrRenderDesc, tail, 1328);
 DR_ABI_OFFSET(DrRenderDesc, max_tail, 1336);
+DR_ABI_OFFSET(DrRenderDesc, tail_offsets, 1344);
 DR_ABI_SIZE(DrRenderStats, 200);
 DR_ABI_OFFSET(DrRenderStats, trace_ms, 72);
 DR_ABI_OFFSET(DrRenderStats, film_ms, 144);

@@ -137,7 +137,7 @@ const int OFF_DrFilm_crop = 8;
 const int OFF_DrFilm_filter_xw = 40;
 const int OFF_DrFilm_filter_yw = 48;
 const int OFF_DrFilm_filter_table = 56;
-const int SIZEOF_DrRenderDesc = 1344;
+const int SIZEOF_DrRenderDesc = 1352;
 const int OFF_DrRenderDesc_camera = 0;
 const int OFF_DrRenderDesc_film = 168;
 const int OFF_DrRenderDesc_integrator = 1248;
@@ -156,6 +156,7 @@ const int OFF_DrRenderDesc_sample_vec = 1312;
 const int OFF_DrRenderDesc_sample_stride = 1320;
 const int OFF_DrRenderDesc_tail = 1328;
 const int OFF_DrRenderDesc_max_tail = 1336;
+const int OFF_DrRenderDesc_tail_offsets = 1344;  // host-buffer sampler only: stays NULL here (calloc'd descriptor)
 
 // enums of the header
 const int DR_MATERIAL_MATTE = 0, DR_MATERIAL_MIRROR = 1, DR_MATERIAL_GLASS = 2, DR_MATERIAL_PLASTIC = 3;

@@ -585,6 +585,27 @@ def test_serial_stream_replay_across_several_batches(ob, gpu, pipelines):
         _abi.check(lib.dr_set_option(b"PIPELINES", None))
     assert np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"])
     assert np.array_equal(whole.film, rec["film"])
+    # the PACKED form of the tail (DrRenderDesc.tail_offsets: only the values a sample drew cross the host link), whole and
+    # across the same five batches -- a batch's runs are one contiguous piece of the packed array
+    packed = core.HostBufferSampler(r.camera, 16, rec["pixel_xy"][::16], rec["sample_vec"], rec["tail"], rec["tail_count"])
+    assert packed.tail.size == int(rec["tail_count"].sum()) < rec["tail"].size // 3 and packed.tail_offsets[-1] == packed.tail.size
+    r.sampler = packed
+    assert np.array_equal(r.render(scene).film, rec["film"])
+    try:
+        _abi.check(lib.dr_set_option(b"BATCH_BITS", b"16"))
+        out = r.render(scene)
+        assert r.last_stats["batches"] == 5
+    finally:
+        _abi.check(lib.dr_set_option(b"BATCH_BITS", None))
+    assert np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"])
+    # a run that is shorter than what the path draws reads 0.0 past its end, exactly like the zero fill of the fixed form
+    cut = np.maximum(rec["tail_count"] - 3, 0)
+    fixed = rec["tail"].copy()
+    fixed[np.arange(fixed.shape[1])[None, :] >= cut[:, None]] = 0.0
+    r.sampler = core.HostBufferSampler(r.camera, 16, rec["pixel_xy"][::16], rec["sample_vec"], fixed)
+    a = r.render(scene).film
+    r.sampler = core.HostBufferSampler(r.camera, 16, rec["pixel_xy"][::16], rec["sample_vec"], rec["tail"], cut)
+    assert np.array_equal(r.render(scene).film, a) and not np.array_equal(a, rec["film"])
 
 
 def test_serial_stream_replay_of_a_million_samples(ob, gpu):
@@ -596,7 +617,7 @@ def test_serial_stream_replay_of_a_million_samples(ob, gpu):
     rec, n = _serial_recording(ob, prims, r, 64)
     assert n == 1065024
     lib = _abi.lib()
-    r.sampler = core.HostBufferSampler(r.camera, 64, rec["pixel_xy"][::64], rec["sample_vec"], rec["tail"])
+    r.sampler = core.HostBufferSampler(r.camera, 64, rec["pixel_xy"][::64], rec["sample_vec"], rec["tail"], rec["tail_count"])  # packed tail
     try:
         _abi.check(lib.dr_set_option(b"BATCH_BITS", b"18"))
         out = r.render(scenes.make_scene(prims))
