@@ -1090,7 +1090,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
   // Work is handed out dynamically: a wave takes CHUNKS of 64 * DR_PUSH_ITERS consecutive active-list entries from the
   // launch's counter (q.work), one staging round each; the next chunk's number comes back with the round's queue
   // reservations (stage_flush), one round ahead of its use, so that a wave always knows its next entry.
-  const uint32_t CH = 64u * DR_PUSH_ITERS;
+  // (round 5) a THIN list -- fewer than a full chunk per resident wave -- is cut into shorter chunks, so that every wave takes one
+  // and walks it in `ipc` iterations instead of a few waves walking DR_PUSH_ITERS iterations each while the others idle
+  // (C5's stage 6: 26 K entries = 52 chunks of 512 for 3 072 waves)
+  const uint32_t nWavesAll = gridDim.x * (blockDim.x >> 6);
+  const uint32_t ipc = nIn >= nWavesAll * 64u * DR_PUSH_ITERS ? (uint32_t)DR_PUSH_ITERS
+                                                              : max(1u, min((uint32_t)DR_PUSH_ITERS, (nIn + nWavesAll * 64u - 1u) / (nWavesAll * 64u)));
+  const uint32_t CH = 64u * ipc;
   const uint32_t nChunks = (nIn + CH - 1u) / CH;
   const uint32_t lane = (uint32_t)lane_id();
   uint32_t cCur = 0u;
@@ -1103,7 +1109,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     ShadeIn cur;
     const uint32_t slotCur = slotNext;
     const uint32_t idx = cCur * CH + pctx.iters * 64u + lane;
-    const bool lastOfChunk = pctx.iters + 1u == DR_PUSH_ITERS;
+    const bool lastOfChunk = pctx.iters + 1u == ipc;
     slotNext = slotOf(lastOfChunk ? cNext * CH + lane : idx + 64u);
     load_shade_in<QUAD>(st, rp, bounce, slotCur, idx < nIn, &cur);
     PROF(4);
@@ -1301,7 +1307,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     stage_push<NQ>(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0 && !deferred && !envNee, slot, Q_MIS_BIT,
                    vert, pushCont ? 0u : Q_RESOLVE_BIT, envNee || envMiss, envMiss ? Q_ENV_MISS_BIT : 0u, contKey, anyKey);
     PROF(8);
-    if (pctx.iters == DR_PUSH_ITERS) {
+    if (pctx.iters == ipc) {
       const uint32_t g = stage_flush<NQ>(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont,
                                          q.work, q.envQ, q.nEnv);
       cCur = cNext;

@@ -61,6 +61,22 @@ namespace DR_NS {
 #ifndef DR_WORK_CHUNK
 #define DR_WORK_CHUNK 256  // queue entries a wave reserves per atomic on the work counter (256+ loses cache locality, 64 is atomic bound)
 #endif
+// A THIN launch (round 5): with fewer than 256 entries per resident wave the first n / 256 waves would each walk four generations of
+// rays one after the other while the rest of the chip idles (C5: 262 922 closest-hit rays = 1 027 busy waves of 7 168, 0.43 ms for what is
+// one ray chain deep).  The reservation then shrinks to the queue's share per wave, in whole 64-ray generations -- never below 64 (one
+// atomic per wave generation is what the work counter sustains) -- and every wave that finds work walks one generation.
+#ifndef DR_WORK_CHUNK_DYNAMIC
+#define DR_WORK_CHUNK_DYNAMIC 1
+#endif
+__device__ __forceinline__ uint32_t work_chunk(uint32_t n) {
+#if DR_WORK_CHUNK_DYNAMIC
+  const uint32_t waves = gridDim.x * (DR_TRACE_BLOCK / 64);
+  const uint32_t share = ((n + waves - 1u) / waves + 63u) & ~63u;
+  return share < (uint32_t)DR_WORK_CHUNK ? (share < 64u ? 64u : share) : (uint32_t)DR_WORK_CHUNK;
+#else
+  return (uint32_t)DR_WORK_CHUNK;
+#endif
+}
 
 // ===========================================================================
 // v1: the first correct version (kept for A/B runs, DARTRAY_TRACE_IMPL=1): 64 queue entries per
@@ -536,6 +552,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
   // read from HW_REG_XCC_ID and only affects speed, never results.
   uint32_t shard = ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (uint32_t)DR_NSHARD;  // XCC_ID[3:0]
   uint32_t tried = 0;
+  const uint32_t chunk = work_chunk(n);  // wave-uniform
   TPROF_DECL;
   for (;;) {
     TPROF(3);
@@ -560,12 +577,12 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
             uint32_t* const wc = work + shard * (uint32_t)DR_WORK_STRIDE;
             // (only before a wave's first reservation: later ones go straight to the atomic)
             fresh = nRays == 0u ? __hip_atomic_load(wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            if (fresh < s1 - s0) fresh = atomicAdd(wc, (uint32_t)DR_WORK_CHUNK);
+            if (fresh < s1 - s0) fresh = atomicAdd(wc, chunk);
           }
           fresh = wave_bcast_first(fresh);
           if (fresh < s1 - s0) {
             resNext = s0 + fresh;
-            resEnd = min(s0 + fresh + (uint32_t)DR_WORK_CHUNK, s1);
+            resEnd = min(s0 + fresh + chunk, s1);
             break;
           }
           shard = (shard + 1u) % (uint32_t)DR_NSHARD;  // this shard is drained (its counter only grows)
@@ -1038,12 +1055,12 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
         uint32_t fresh = 0;
         if (lane_id() == 0) {
           fresh = nRays == 0u ? __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // (see trace_persistent)
-          if (fresh < n) fresh = atomicAdd(work, (uint32_t)DR_WORK_CHUNK);
+          if (fresh < n) fresh = atomicAdd(work, work_chunk(n));
         }
         fresh = wave_bcast_first(fresh);
         if (fresh < n) {
           resNext = fresh;
-          resEnd = min(fresh + (uint32_t)DR_WORK_CHUNK, n);
+          resEnd = min(fresh + work_chunk(n), n);
         } else {
           exhausted = true;
         }
@@ -1490,12 +1507,12 @@ DR_DEV void trace_pairs_any(const DScene& sc, const IO& io, uint32_t n, uint32_t
         uint32_t fresh = 0;
         if (lane == 0) {
           fresh = nRays == 0u ? __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // (see trace_persistent)
-          if (fresh < n) fresh = atomicAdd(work, (uint32_t)DR_WORK_CHUNK);
+          if (fresh < n) fresh = atomicAdd(work, work_chunk(n));
         }
         fresh = wave_bcast_first(fresh);
         if (fresh < n) {
           resNext = fresh;
-          resEnd = min(fresh + (uint32_t)DR_WORK_CHUNK, n);
+          resEnd = min(fresh + work_chunk(n), n);
         } else {
           exhausted = true;
         }
