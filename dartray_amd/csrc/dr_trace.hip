@@ -448,13 +448,19 @@ struct RayIO {
 // -DDR_TRACE_PROF: a diagnostic build that stamps s_memtime between the phases of the v2 loop and sums the cycles the
 // waves spent in each (printed and cleared by dr_get_stats through trace_prof_dump).  No stamp executes in the product build.
 #ifdef DR_TRACE_PROF
-__device__ unsigned long long g_traceProf[2][12];
+__device__ unsigned long long g_traceProf[2][16];  // [0..3] phases, [4..11] counts, [12..14] parts of the node-visit phase (round 5)
 DR_DEV unsigned long long tprof_now() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
-#define TPROF_DECL unsigned long long tpT = tprof_now(), tpAcc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define TPROF_DECL unsigned long long tpT = tprof_now(), tpAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+// (round 5) inside the node-visit phase: wait until the loads issued so far have arrived, then stamp
+#define TPROF_ARRIVED(i)                                  \
+  do {                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
+    TPROF(i);                                             \
+  } while (0)
 #define TPROF(i)                              \
   do {                                        \
     const unsigned long long n_ = tprof_now(); \
@@ -465,10 +471,10 @@ DR_DEV unsigned long long tprof_now() {
 #define TPROF_FLUSH                                                                  \
   do {                                                                               \
     if (lane_id() == 0)                                                              \
-      for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_traceProf[ANY][i_], tpAcc[i_]);   \
+      for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_traceProf[ANY][i_], tpAcc[i_]);   \
   } while (0)
 void trace_prof_dump() {
-  unsigned long long h[2][12];
+  unsigned long long h[2][16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_traceProf), sizeof(h)) != hipSuccess) return;
   static const char* names[12] = {"refill: queue entry + ray state + ray_init", "node visits", "leaf tests", "result stores + bookkeeping",
                                   "(wave iterations)", "(refill events)", "(leaf phases)", "(leaf triangle rounds)",
@@ -480,13 +486,22 @@ void trace_prof_dump() {
     if (tot == 0) continue;
     for (int i = 0; i < 4; ++i) fprintf(stderr, "trace_prof %s %-44s %6.2f %%  (%.3g wave-cycles)\n", a ? "any    " : "closest", names[i], 100.0 * h[a][i] / tot, (double)h[a][i]);
     for (int i = 4; i < 12; ++i) fprintf(stderr, "trace_prof %s %-44s %.4g\n", a ? "any    " : "closest", names[i], (double)h[a][i]);
+    // parts of the node-visit phase, in wave-cycles per wave iteration (they were taken out of names[1]'s sum above)
+    static const char* sub[3] = {"node visit: ballots + fetch issue + result stores -> node data arrived", "node visit: slab filter -> decision",
+                                 "node visit: push / pop (LDS, rare global spill)"};
+    for (int i = 0; i < 3; ++i)
+      fprintf(stderr, "trace_prof %s %-72s %8.1f cycles per wave iteration (%5.2f %% of all phases)\n", a ? "any    " : "closest", sub[i],
+              (double)h[a][12 + i] / (double)(h[a][4] ? h[a][4] : 1), 100.0 * (double)h[a][12 + i] / (tot + (double)h[a][12] + (double)h[a][13] + (double)h[a][14]));
+    fprintf(stderr, "trace_prof %s %-72s %8.1f cycles\n", a ? "any    " : "closest", "a whole wave iteration",
+            (tot + (double)h[a][12] + (double)h[a][13] + (double)h[a][14]) / (double)(h[a][4] ? h[a][4] : 1));
   }
-  for (int a = 0; a < 2; ++a) for (int i = 0; i < 12; ++i) h[a][i] = 0;
+  for (int a = 0; a < 2; ++a) for (int i = 0; i < 16; ++i) h[a][i] = 0;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_traceProf), h, sizeof(h));
 }
 #else
 #define TPROF_DECL
 #define TPROF(i)
+#define TPROF_ARRIVED(i)
 #define TPROF_COUNT(i, v)
 #define TPROF_FLUSH
 #ifndef DR_STACK_PROF
@@ -639,17 +654,46 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
       const uint4* np = (const uint4*)((const char*)sc.nodes + (size_t)(uint32_t)(node << 5));
       a = np[0];
       b = np[1];
+#ifdef DR_EXP_PAD_VMEM
+      // timing experiment only: N more 16-byte lane loads of the SAME node line per visit (what does a lane load cost the L1's
+      // divergent-address path at today's occupancy?)
+#pragma unroll
+      for (int k_ = 0; k_ < DR_EXP_PAD_VMEM; ++k_) {
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        u32x4_ x_;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x_) : "v"(np + (k_ & 1)) : "memory");
+        asm volatile("" ::"v"(x_));
+      }
+#endif
     }
     // results of the rays that finished in the previous iteration: stored HERE, behind the node fetches.  vmcnt retires
     // in order and stores count in it: issued before the fetches (at the end of the previous iteration) their
     // acknowledgement is waited for before the fetches are even issued; issued behind them it overlaps the fetch.
-    if (mode == M_DONE) {
-      TraceRay rr = ray;
-      rr.d = COLD_D();
-      rr.tmin = COLD_TMIN();
-      io.store(COLD_LD(5), rr, hit, sc);
-      mode = M_IDLE;
-    }
+#define STORE_DONE_RAYS()               \
+  if (mode == M_DONE) {                 \
+    TraceRay rr = ray;                  \
+    rr.d = COLD_D();                    \
+    rr.tmin = COLD_TMIN();              \
+    io.store(COLD_LD(5), rr, hit, sc);  \
+    mode = M_IDLE;                      \
+  }
+#ifndef DR_TRACE_PROF
+    STORE_DONE_RAYS()
+#else
+    // (the profiling build waits for the node data FIRST and stamps, then issues the stores: stamped behind them, the wait would
+    // include the stores' acknowledgements -- vmcnt counts loads and stores together, in order; issued here their acknowledgements
+    // still overlap the next iteration's fetches)
+    TPROF_ARRIVED(12);
+    STORE_DONE_RAYS()
+#endif
+#undef STORE_DONE_RAYS
+    bool ok = false;
+#ifdef DR_TRACE_PROF
+    const bool trav_ = mode == M_TRAV;  // (the profiling build closes and re-opens the block below around a wave-uniform stamp)
+#define TPROF_SPLIT(i) } TPROF(i); if (trav_) {
+#else
+#define TPROF_SPLIT(i)
+#endif
     if (mode == M_TRAV) {
       const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
       const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
@@ -679,7 +723,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
         asm volatile("" ::"v"(p0), "v"(p1));
       }
 #endif
-      bool ok = false, amb = true;
+      bool amb = true;
       if (!ray.needF64) {  // (two predicates instead of a three-valued int: they stay lane masks in SGPRs)
         bool sureMiss;
         slab_f32_sure(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, &ok, &sureMiss);
@@ -690,6 +734,7 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
         rr.tmin = COLD_TMIN();
         ok = slab_f64(rr, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz);
       }
+      TPROF_SPLIT(13)
       bool pop = true;
       if (ok) {
         const uint32_t nprims = b.w & 0xffffu;
@@ -718,7 +763,10 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
         }
       }
     }
-    TPROF(1);
+#ifdef DR_TRACE_PROF
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the popped entry has arrived from LDS)
+#endif
+    TPROF(14);
     // ---- batched leaf tests (bvh_accel.dart:126-143 / :189-204) ----
     leafMask = __ballot(mode == M_LEAF);
     const unsigned long long stillTrav = __ballot(mode == M_TRAV && !finished);
