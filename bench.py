@@ -584,7 +584,7 @@ class Run:
                        "trace_kernels": {"closest": knames["closest"], "any_hit": knames["any_hit"],
                                          "picked_by": ("--trace-kernels / DARTRAY_TRACE_IMPL" if forced else
                                                        "the scene's pilot batches (closest-hit: best time per algorithmic byte, a pair kernel needs 5 %; any-hit: "
-                                                       "the closest-hit kernel's family unless the other wins its own batch by more than 10 %)"),
+                                                       "the closest-hit kernel's family unless the other wins its own batch by more than 15 %)"),
                                          "pilot_ms_per_alg_GB": {"closest": {str(k): round(v, 4) for k, v in pc.items()},
                                                                  "any_hit": {str(k): round(v, 4) for k, v in pa.items()}},
                                          "near_ties": near},

@@ -1937,11 +1937,12 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // boxes, level at full size: 96.0 against 96.5 ms per step; round 4's 5 % threshold let the box decide) while small launches
     // understate the pair kernel on the big incoherent tree (C4: -2 ... +6 % in a calibration batch, +25 % at full size).  So the
     // any-hit rays stay in the FAMILY the closest-hit rays chose -- k_trace<1> beside k_trace<0>, k_trace3a beside k_trace3<0> /
-    // k_trace3c -- and cross over only when their own calibration batch says so by more than 10 %.
+    // k_trace3c -- and cross over only when their own calibration batch says so by more than 15 % (C2's k_trace3a: 6 - 12 % ahead in the
+    // calibration batches of five boxes, level at full size).
     {
       const bool pairFamily = sc->d.traceKernel[0] != 2u;
       const double own = pairFamily ? perByte[1][1] : perByte[1][0], other = pairFamily ? perByte[1][0] : perByte[1][1];
-      const bool cross = other > 0.0 && own > 0.0 && other < 0.90 * own;
+      const bool cross = other > 0.0 && own > 0.0 && other < 0.85 * own;
       sc->d.traceKernel[1] = (pairFamily != cross) ? 3u : 2u;
     }
     sc->traceCalibrated = true;

@@ -129,7 +129,7 @@ def test_one_process_renders_several_scenes_in_turn():
 def test_pilot_reports_what_it_measured_and_any_hit_follows_the_closest_hit_family():
     """dr_scene_get_pilot / dr_scene_last_render_info after a forced pilot on a small scene: the candidates' ms per algorithmic GB are
     there (kernel 5 only when kernel 3 did not lose clearly), the calibration batches are counted, and the any-hit kernel is the
-    closest-hit kernel's family (2 beside 2, 3 beside 3 / 5) unless its own batch disagreed by more than 10 %.  A second render of the
+    closest-hit kernel's family (2 beside 2, 3 beside 3 / 5) unless its own batch disagreed by more than 15 %.  A second render of the
     scene runs no pilot.  Films are the oracle's either way (tests/test_gpu_render.py::test_traversal_pilot_*)."""
     code = (
         "import sys; sys.path[:0] = [%r, %r]\n"
@@ -146,7 +146,7 @@ def test_pilot_reports_what_it_measured_and_any_hit_follows_the_closest_hit_fami
         "assert info['pilot_batches'] == 4 or p['closest'][3] > 1.05 * p['closest'][2]\n"
         "own, other = (p['any_hit'][3], p['any_hit'][2]) if k[0] != 2 else (p['any_hit'][2], p['any_hit'][3])\n"
         "family = 3 if k[0] != 2 else 2\n"
-        "assert k[1] == (family if not other < 0.9 * own else 5 - family), (k, p)\n"
+        "assert k[1] == (family if not other < 0.85 * own else 5 - family), (k, p)\n"
         "assert (info['closest_kernel'], info['any_hit_kernel']) == k\n"
         "b = r.render(scene).film; assert dev.last_render_info()['pilot_batches'] == 0 and np.array_equal(a, b)\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
