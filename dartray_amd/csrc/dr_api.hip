@@ -1732,6 +1732,18 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       q.ctr = sc->ctr.p;
       q.envQ = envStage ? w.envQ.p : nullptr;
       q.nEnv = C + N_COUNTERS_TRACE + 64 * b;
+#ifdef DR_EXP_SORT_LISTS
+      if (b > 0 && rd->integrator == DR_INTEGRATOR_PATH) {  // timing experiment: the stage's list in slot order (outside the shade events)
+        static DevBuf<uint32_t> sorted;
+        static DevBuf<unsigned char> tmp;
+        uint32_t nIn = 0;
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(&nIn, q.nActiveIn, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(sorted.alloc(w.cap));
+        HIP_TRY(tmp.alloc((size_t)w.cap * 12 + (1u << 20)));
+        if (nIn > 1 && exp_sort_list(q.activeIn, sorted.p, nIn, tmp.p, tmp.n, s) == 0) q.activeIn = sorted.p;
+      }
+#endif
       hipEvent_t evS = sc->getEvent();
       (void)hipEventRecord(evS, s);
       if (rd->integrator == DR_INTEGRATOR_PATH) L.shade_path(sc->d, rp, st, q, b, sgrid, s);

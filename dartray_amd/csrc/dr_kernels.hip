@@ -1303,8 +1303,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
       if (bounce == 0 || pf || envNee) sr.u32<F_FLAGS>() = pf;
       PROF(7);
     }
-    // (a slot with a parked estimate enters the next stage's list in k_env, once its flags are known)
-    stage_push<NQ>(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, pf != 0 && !deferred && !envNee, slot, Q_MIS_BIT,
+    // A slot with a parked estimate: when its path CONTINUES it is in the next stage's list whatever the estimate turns out to be, so
+    // its entry is pushed here, in place among its neighbours (round 5: pushed by k_env, these entries -- one vertex in nLights --
+    // formed a second, nine times thinner sequence behind the list, and the stage after that split both again: a dense list cost
+    // 100 -> 290 ps per entry over four stages in the 64-slot layout, MEASUREMENTS.md 5.8).  Only a parked slot whose path ENDS here
+    // still enters the list in k_env, once its flags say whether a light term is left to fold in.
+    stage_push<NQ>(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, (pf != 0 && !deferred && !envNee) || (envNee && pushCont), slot, Q_MIS_BIT,
                    vert, pushCont ? 0u : Q_RESOLVE_BIT, envNee || envMiss, envMiss ? Q_ENV_MISS_BIT : 0u, contKey, anyKey);
     PROF(8);
     if (pctx.iters == ipc) {
@@ -1407,7 +1411,8 @@ __global__ void __launch_bounds__(DR_ENV_BLOCK) k_env(DScene sc, RenderParams rp
         active = pf != 0 && !deferred;
       }
     }
-    stage_push(s_push, pctx, false, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, active, slot, Q_MIS_BIT, false, cont ? 0u : Q_RESOLVE_BIT);
+    // (a continuing path's entry of the next stage's list was pushed by k_shade_path, in place: see there)
+    stage_push(s_push, pctx, false, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, active && !cont, slot, Q_MIS_BIT, false, Q_RESOLVE_BIT);
     if (pctx.iters == DR_PUSH_ITERS || it + 1 == nIter)
       stage_flush(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont);
   }

@@ -1757,6 +1757,16 @@ void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue,
   }
 }
 
+#ifdef DR_EXP_SORT_LISTS
+// Timing experiment only (tools/variants_all.sh "sortl:-DDR_EXP_SORT_LISTS"): a stage's active list sorted by slot before k_shade_path
+// reads it -- what would an order-preserving compaction of the stage lists return?  (MEASUREMENTS.md round 5)
+int exp_sort_list(const uint32_t* in, uint32_t* out, uint32_t n, void* tmp, size_t tmpBytes, hipStream_t s) {
+  size_t need = 0;
+  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, need, in, out, (int)n, 0, 30, s);
+  if (need > tmpBytes) return -1;
+  return hipcub::DeviceRadixSort::SortKeys(tmp, need, in, out, (int)n, 0, 30, s) == hipSuccess ? 0 : -2;
+}
+#endif
 size_t treelet_sort_bytes(uint32_t n) {
   size_t bytes = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
