@@ -1760,6 +1760,21 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
         slog[b + 1].sMid = evMid;
         slog[b + 1].s1 = evS1;
       }
+#if defined(DR_EXP_SORT_LISTS) && DR_EXP_SORT_LISTS >= 2
+      if (b + 1 < nStages) {  // timing experiment: the stage's two ray queues in slot order too (outside the traversal events)
+        static DevBuf<uint32_t> sortedQ[2];
+        static DevBuf<unsigned char> tmpQ;
+        uint32_t nQ[2] = {0, 0};
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(&nQ[0], q.nClosest, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&nQ[1], q.nAny, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(sortedQ[0].alloc(2 * (size_t)w.cap));
+        HIP_TRY(sortedQ[1].alloc(w.cap));
+        HIP_TRY(tmpQ.alloc((size_t)w.cap * 24 + (1u << 20)));
+        if (nQ[0] > 1 && exp_sort_list(q.closestQ, sortedQ[0].p, nQ[0], tmpQ.p, tmpQ.n, s) == 0) q.closestQ = sortedQ[0].p;
+        if (nQ[1] > 1 && exp_sort_list(q.anyQ, sortedQ[1].p, nQ[1], tmpQ.p, tmpQ.n, s) == 0) q.anyQ = sortedQ[1].p;
+      }
+#endif
       if (b + 1 < nStages) {
         if (sideBySide) {
           hipEvent_t eS = sc->getEvent(), eA = sc->getEvent();
