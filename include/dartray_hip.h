@@ -445,7 +445,8 @@ const char* dr_version(void);
  *   TREELET_ROUNDS n, TREELET_SHARDS n, TREELET_MIN n   the treelet-parked traversal (TRACE_IMPL=4; MEASUREMENTS.md, round 4)
  *   SCENE_PREP host, GEN_PREPASS 0   dr_scene_create's checks on the host; no burn-in pre-pass above 256 spp
  *   GEN_SLOW_DRAWS, GEN_ALL_BLOCKS, GEN_LANES n, GEN_ONE_WAVE, FLOAT_SAMPLES, LDS_LIGHTS 0   A/B variants of the sampler / shade kernels
- *   BUILD_THREADS n, BUILD_DEBUG   the BVH builders;  RCCL_LIB path   librccl to bind;  STAGE_COUNTS, VERBOSE   diagnostics */
+ *   BUILD_THREADS n, BUILD_DEBUG   the BVH builders;  RCCL_LIB path   librccl to bind;  STAGE_COUNTS 1|2 (per stage: list lengths and kernel times; 2: also
+ *                         the node visits / triangle tests of each stage's traversals, waiting for the device after every stage), VERBOSE   diagnostics */
 int dr_set_option(const char* name, const char* value);
 
 
