@@ -101,7 +101,7 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP",
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP",
     "DARTRAY_TREELET_ROUNDS", "DARTRAY_TREELET_MIN", "DARTRAY_TREELET_SHARDS", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
@@ -432,6 +432,7 @@ void enumeratePixels(const RenderParams& rp, const DrRenderDesc* rd, std::vector
 // A render picks one (dr_render_device); results do not depend on it.
 struct LayoutOps {
   decltype(&launch_trace) trace;
+  decltype(&launch_trace_coherent) trace_coherent;
   decltype(&trace_kernel_id) trace_kernel_id;
   decltype(&launch_trace_treelets) trace_treelets;
   decltype(&launch_gen_samples) gen_samples;
@@ -445,9 +446,9 @@ struct LayoutOps {
   int stateWords;  // 4-byte words of fixed path state per slot in this layout (a tile is 64 of them + the sample region):
                    // what the kernels' own translation unit was compiled with (layout_state_words), not a constant repeated here
 };
-static const LayoutOps kLayout64 = {&launch_trace, &trace_kernel_id, &launch_trace_treelets, &launch_gen_samples, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
+static const LayoutOps kLayout64 = {&launch_trace, &launch_trace_coherent, &trace_kernel_id, &launch_trace_treelets, &launch_gen_samples, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
                                     &launch_env, &launch_shade_direct, &launch_shade_spec, &launch_film, layout_state_words()};
-static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::trace_kernel_id, &sp4::launch_trace_treelets, &sp4::launch_gen_samples, &sp4::launch_transpose_samples, &sp4::launch_raygen,
+static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_trace_coherent, &sp4::trace_kernel_id, &sp4::launch_trace_treelets, &sp4::launch_gen_samples, &sp4::launch_transpose_samples, &sp4::launch_raygen,
                                      &sp4::launch_shade_path, &sp4::launch_env, &sp4::launch_shade_direct, &sp4::launch_shade_spec,
                                      &sp4::launch_film, sp4::layout_state_words()};
 
@@ -1545,6 +1546,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     w.tl.minPark = (uint32_t)dr_opt("DARTRAY_TREELET_MIN").toInt(1 << 18);
     w.tl.verbose = dr_opt("DARTRAY_VERBOSE").toInt(0);
   }
+  // the camera rays (a tile = 64 samples of one pixel) through the wave-coherent kernel k_trace_pk (DARTRAY_COHERENT_CAMERA=0: k_trace & co.)
+  const bool coherentCamera = !dr_opt("DARTRAY_COHERENT_CAMERA").isZero() && !dlSpec;
   const bool overlapEnv = !(dr_opt("DARTRAY_OVERLAP_ANY").isZero());  // default: on
   const bool overlapAny = overlapEnv && !dlSpec && !(nPipesEnv >= 2);
   if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
@@ -1685,7 +1688,12 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       if (treelets) {
         const int trc = L.trace_treelets(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts, w.tl);
         if (trc != DR_OK && treeletErr == DR_OK) treeletErr = trc;
-      } else L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
+      } else if (!(coherentCamera && queue == nullptr && !any &&
+                   L.trace_coherent(sc->d, st, C + 1024 + 8 * DR_WORK_STRIDE * wc, sc->ctr.p, tgrid, ts))) {
+        L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
+      } else {
+        ++wc;  // (the coherent kernel took the camera rays: the identity queue of the batch's slots)
+      }
       (void)hipEventRecord(e1, ts);
       if (pilot) pilot->ev[any].push_back({e0, e1});
       sc->traceEvents.push_back({e0, e1, any, after});
@@ -2015,7 +2023,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   sc->lastInfo[4] = pilotBatchesRun;
   sc->lastInfo[5] = (int32_t)std::min<uint64_t>(0x7fffffff, nBatches);
   sc->lastInfo[6] = tgrid / std::max(1, g_numCU);
-  sc->lastInfo[7] = overlapAny ? 1 : 0;
+  sc->lastInfo[7] = (overlapAny ? 1 : 0) | (coherentCamera && !treelets && !sc->d.nquads ? 2 : 0);
   return DR_OK;
 #undef L
 }

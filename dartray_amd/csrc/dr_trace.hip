@@ -1686,6 +1686,148 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3A_WAVES) k_intersect3
   trace_pairs_any(sc, io, n, s_ref + threadIdx.x, s_cold + threadIdx.x, spill, gridDim.x * DR_TRACE_BLOCK, work, ctr);
 }
 
+// ===========================================================================
+// k_trace_pk (round 5): closest-hit traversal of COHERENT waves -- the camera rays.  A tile's 64 slots are samples of ONE pixel
+// (spp >= 64; below that, of neighbouring pixels), i.e. 64 nearly identical rays.  In k_trace each lane still fetches its own
+// node with two divergent 16-byte loads, and MEASUREMENTS.md 5.2 (f) finds what a ray waits for there: the queue in front of the
+// CU's L1 address path, 61 cycles per wave and node visit.  Here the WAVE walks the tree with one stack: the node (and, at a
+// leaf, every triangle) is loaded once for the wave from a wave-uniform address, and every lane tests ITS ray against it.
+//
+// Same visits, same order, same decisions per ray as bvh_accel.dart:101-163:
+//  * rays are grouped by the sign pattern of their inverse direction (dirIsNeg, :111-113): within a group every ray takes the
+//    same near / far order at every node (:147-153), so one shared order is every ray's own order.  The groups of a tile are
+//    walked one after the other (same-pixel rays: almost always one group);
+//  * a stack entry is (node, mask of the lanes that pushed it): exactly the lanes whose own traversal holds that far child on
+//    its own stack; when the entry is popped those lanes test the node's box with THEIR current maxDistance, as the reference
+//    does at its pop (:139-143).  A lane's entries are a sub-sequence of the wave's, so its pops come in its own LIFO order;
+//  * a node is visited (and counted) by the lanes of the mask only; lanes whose box test fails simply leave the mask.
+// Box and triangle tests are the functions k_trace uses (f32 enclosure, literal f64 fallback; tri_hit), so hits, hit
+// parameters and the visit counters equal k_trace's and the oracle's.
+// ===========================================================================
+#ifndef DR_PK_WG_PER_CU
+#define DR_PK_WG_PER_CU 6  // 80 VGPRs (the f64 triangle test at full lane width is the peak); C2's camera rays: 17.2 ms at six, 17.6 at five (94 VGPRs, no scratch), 18.8 at seven
+#endif
+// A load from a WAVE-UNIFORM address of data that no kernel writes while this one runs (the scene's nodes and triangles), through the
+// constant address space: the compiler then uses a scalar load -- one request of the scalar cache for the wave, the data in SGPRs
+// (operands of the lanes' VALU instructions) instead of 4 VGPRs per lane and 64 lane requests of the vector L1.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t pk_u32x4 __attribute__((ext_vector_type(4)));
+typedef float pk_f32x4 __attribute__((ext_vector_type(4)));
+DR_DEV uint4 ld_uniform(const uint4* p) {
+  const pk_u32x4 v = *(__attribute__((address_space(4))) const pk_u32x4*)(uintptr_t)p;
+  return uint4{v.x, v.y, v.z, v.w};
+}
+DR_DEV float4 ld_uniform(const float4* p) {
+  const pk_f32x4 v = *(__attribute__((address_space(4))) const pk_f32x4*)(uintptr_t)p;
+  return float4{v.x, v.y, v.z, v.w};
+}
+#else
+DR_DEV uint4 ld_uniform(const uint4* p) { return *p; }
+DR_DEV float4 ld_uniform(const float4* p) { return *p; }
+#endif
+__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DScene sc, BatchState st, uint32_t n, uint32_t* work, TraceCounters* ctr) {
+  __shared__ uint32_t s_pk[(DR_TRACE_BLOCK / 64) * DR_MAX_STACK * 3];
+  typedef __attribute__((address_space(3))) uint32_t pk_u32;
+  pk_u32* const stk = (pk_u32*)(s_pk + (threadIdx.x >> 6) * (DR_MAX_STACK * 3));
+  StateIO<0> io{st, nullptr};
+  const int lane = lane_id();
+  uint32_t nRays = 0, nNodes = 0, nTris = 0;  // nRays / nNodes: wave-uniform, lane 0 reports them; nTris: per lane
+  const uint32_t nTiles = (n + 63u) >> 6;
+  for (;;) {
+    uint32_t t0 = 0;
+    if (lane == 0) t0 = atomicAdd(work, 4u);  // four tiles (256 rays) per atomic, as k_trace's reservations
+    t0 = wave_bcast_first(t0);
+    if (t0 >= nTiles) break;
+    const uint32_t t1 = min(t0 + 4u, nTiles);
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+      const uint32_t idx = (tile << 6) + (uint32_t)lane;
+      const bool have = idx < n;
+      TraceRay ray;
+      int hit = -1;
+      {
+        uint32_t handle;
+        io.load(have ? idx : n - 1u, ray, handle);  // (a lane beyond the end loads the last ray and takes no part; the handle of an identity queue is idx)
+      }
+      const unsigned long long haveMask = __ballot(have);
+      nRays += (uint32_t)__popcll(haveMask);
+      if (sc.nnodes != 0u) {
+        // dirIsNeg (bvh_accel.dart:111-113) as three bits, rebuilt where it is read instead of living in a register
+        auto octant = [&]() -> uint32_t { return (ray.ivx < 0.f ? 1u : 0u) | (ray.ivy < 0.f ? 2u : 0u) | (ray.ivz < 0.f ? 4u : 0u); };
+        unsigned long long remaining = haveMask;
+        while (remaining != 0ull) {
+          const uint32_t oct = (uint32_t)__builtin_amdgcn_readlane((int)octant(), __ffsll((long long)remaining) - 1);
+          const unsigned long long pmask = __ballot(have && octant() == oct) & remaining;
+          remaining &= ~pmask;
+          int sp = 0;
+          uint32_t cur = 0u;
+          unsigned long long curMask = pmask;
+          for (;;) {
+            const uint4* np = (const uint4*)((const char*)sc.nodes + (size_t)(cur << 5));  // wave-uniform address
+            const uint4 a = ld_uniform(np), b = ld_uniform(np + 1);
+            nNodes += (uint32_t)__popcll(curMask);
+            bool ok = false;
+            if ((curMask >> lane) & 1ull) {
+              const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
+              const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
+              bool amb = true;
+              if (!ray.needF64) {
+                bool sureMiss;
+                slab_f32_sure(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, &ok, &sureMiss);
+                amb = !ok && !sureMiss;
+              }
+              if (amb) ok = slab_f64(ray, bminx, bminy, bminz, bmaxx, bmaxy, bmaxz);
+            }
+            const unsigned long long hitMask = __ballot(ok);
+            bool descend = false;
+            if (hitMask != 0ull) {
+              const uint32_t nprims = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b.w & 0xffffu));
+              if (nprims > 0u) {  // a leaf: every lane of hitMask tests every triangle (bvh_accel.dart:126-138)
+                const uint32_t leafOff = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.z);
+                for (uint32_t i = 0; i < nprims; ++i) {
+                  const float4* tp = sc.tris + 3 * (size_t)(leafOff + i);
+                  const float4 q0 = ld_uniform(tp), q1 = ld_uniform(tp + 1), q2 = ld_uniform(tp + 2);
+                  if (ok) {
+                    ++nTris;
+                    const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
+                    double t, b1, b2;
+                    if (tri_hit(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax, &t, &b1, &b2)) {
+                      ray_set_tmax(ray, t);  // r.maxDistance = thit (geometric_primitive.dart:59)
+                      hit = (int)(leafOff + i);
+                    }
+                  }
+                }
+              } else {  // interior: near child now, far child pushed for the lanes that are here (bvh_accel.dart:145-155)
+                const uint32_t axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)((b.w >> 16) & 0xffu));
+                const uint32_t second = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.z);
+                const bool neg = ((oct >> axis) & 1u) != 0u;
+                if (lane == 0 && sp < DR_MAX_STACK) {
+                  stk[3 * sp] = neg ? cur + 1u : second;
+                  stk[3 * sp + 1] = (uint32_t)hitMask;
+                  stk[3 * sp + 2] = (uint32_t)(hitMask >> 32);
+                }
+                ++sp;
+                cur = neg ? second : cur + 1u;
+                curMask = hitMask;
+                descend = true;
+              }
+            }
+            if (!descend) {
+              if (sp == 0) break;
+              --sp;
+              cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[3 * sp]);
+              const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[3 * sp + 1]);
+              const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[3 * sp + 2]);
+              curMask = (unsigned long long)mlo | ((unsigned long long)mhi << 32);
+            }
+          }
+        }
+      }
+      if (have) io.store(idx, ray, hit, sc);
+    }
+  }
+  flush_counters(ctr, 0, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
+}
+
 // ---------------------------------------------------------------------------
 // launchers.  DARTRAY_TRACE_IMPL selects the kernel for A/B runs: 1 = first version, 2 = default, 3 = sibling pairs.
 // ---------------------------------------------------------------------------
@@ -1727,6 +1869,14 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
     if (anyHit) hipLaunchKernelGGL(k_intersect<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_intersect<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
   }
+}
+// The camera rays of a batch (identity queue: tile t = slots 64 t .. 64 t + 63, samples of one pixel at spp >= 64) through the
+// wave-coherent kernel.  Returns false when this scene / build cannot use it (quadric primitives: k_trace_quad's tests).
+bool launch_trace_coherent(const DScene& sc, const BatchState& st, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
+  if (sc.nquads) return false;
+  grid = std::min(grid, traceGridFor(DR_PK_WG_PER_CU));
+  hipLaunchKernelGGL(k_trace_pk, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, st.nslots, workCounter, ctr);
+  return true;
 }
 int trace_kernel_id(const DScene& sc, int anyHit) {
   bool cold = false;

@@ -151,3 +151,43 @@ def test_pilot_reports_what_it_measured_and_any_hit_follows_the_closest_hit_fami
         "b = r.render(scene).film; assert dev.last_render_info()['pilot_batches'] == 0 and np.array_equal(a, b)\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
     _run(code, DARTRAY_PILOT_FORCE="1")
+
+
+def test_coherent_camera_kernel_equals_the_per_lane_kernels():
+    """k_trace_pk walks a tile's 64 camera rays with ONE stack (node and triangles loaded once per wave, every lane testing its own
+    ray; stack entries carry the mask of the lanes that pushed them).  Hits, films and the visit counters must equal what the per-lane
+    kernels give (DARTRAY_COHERENT_CAMERA=0) and the oracle's -- also where the rays of a tile do NOT share their direction signs (a
+    camera looking straight down an axis: every tile around the image centre mixes four sign patterns; spp 4: a tile spans 16
+    pixels), where every ray has zero direction components (orthographic camera: all lanes take the literal f64 slab test), and on a
+    deep tree."""
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "import oracle.binding as ob\n"
+        "from dartray_amd import _abi, core, scenes\n"
+        "_abi.init(0)\n"
+        "lib = _abi.lib()\n"
+        "def both(prims, r, env=None):\n"
+        "    scene = scenes.make_scene(prims, env); dev = scene._device(); films = []; stats = []\n"
+        "    for on in (b'1', b'0'):\n"
+        "        _abi.check(lib.dr_set_option(b'COHERENT_CAMERA', on)); out = r.render(scene); films.append(out.film); stats.append(r.last_stats)\n"
+        "        assert dev.last_render_info()['coherent_camera'] == int(on)\n"
+        "    _abi.check(lib.dr_set_option(b'COHERENT_CAMERA', None))\n"
+        "    assert np.array_equal(films[0], films[1])\n"
+        "    keys = ('closest_nodes', 'any_nodes', 'closest_tris', 'any_tris', 'closest_rays', 'any_rays')\n"
+        "    assert all(stats[0][k] == stats[1][k] for k in keys), (stats[0], stats[1])\n"
+        "    osc = ob.OracleScene(prims, env=env) if env is not None else ob.OracleScene(prims); osc.counters(reset=True)\n"
+        "    ref = osc.render(ob.render_desc(r, sampler_mode=1)); c = osc.counters()\n"
+        "    assert np.array_equal(films[0], ref['film']) and all(stats[0][k] == c[k] for k in keys), (stats[0], c)\n"
+        "for spp, blob in ((64, (60, 30)), (4, (24, 12)), (128, (90, 45))):\n"
+        "    prims, mk = scenes.config('C2', xres=24, yres=20, spp=spp, blob=blob); both(prims, mk())\n"
+        # the camera on the z axis looking at the origin: direction signs change in the middle of the image, inside tiles
+        "prims, mk = scenes.config('C2', xres=9, yres=9, spp=8, blob=(40, 20)); both(prims, mk())\n"
+        "prims, mk = scenes.config('C4', xres=20, yres=16, spp=64, hair=(60, 30)); both(prims, mk())\n"
+        "prims5, mk5 = scenes.config('C5', xres=24, yres=16, spp=64, yard=(4, 12), env_res=(64, 32)); r5 = mk5(); both(prims5, r5, r5.env)\n"
+        # orthographic camera: every ray is (0, 0, 1) in camera space -> zero components -> the literal test for every box
+        "prims = scenes.cornell_prims(scenes.blob_prim(40, 20)); film = core.ImageFilm(20, 16)\n"
+        "cam = core.OrthographicCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), film, screenWindow=[-11, 11, -8, 8])\n"
+        "both(prims, core.SamplerRenderer(core.LowDiscrepancySampler(cam, 64), cam, core.PathIntegrator(3), core.EmissionIntegrator()))\n"
+        "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    _run(code, timeout=900)
