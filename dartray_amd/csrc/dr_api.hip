@@ -101,7 +101,7 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP",
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_COHERENT_SHADOW", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP",
     "DARTRAY_TREELET_ROUNDS", "DARTRAY_TREELET_MIN", "DARTRAY_TREELET_SHARDS", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
@@ -1548,6 +1548,11 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   }
   // the camera rays (a tile = 64 samples of one pixel) through the wave-coherent kernel k_trace_pk (DARTRAY_COHERENT_CAMERA=0: k_trace & co.)
   const bool coherentCamera = !dr_opt("DARTRAY_COHERENT_CAMERA").isZero() && !dlSpec;
+  // DARTRAY_COHERENT_SHADOW=1 (A/B; a measured negative, MEASUREMENTS.md 5.9): the shadow rays that leave the CAMERA vertices (a path
+  // render's first stage; every stage of DirectLighting) through k_trace_pk<1> as well.  64 consecutive queue entries are neighbouring
+  // hit points looking at the lights -- but they start on different pieces of surface and fan out over the emitter: the wave's union
+  // of visited nodes is several rays' worth (C2 any-hit 95 -> 136 ms, C4 102 -> 326).
+  const bool coherentShadow = !dlSpec && !sc->d.nquads && dr_opt("DARTRAY_COHERENT_SHADOW").nonZero();
   const bool overlapEnv = !(dr_opt("DARTRAY_OVERLAP_ANY").isZero());  // default: on
   const bool overlapAny = overlapEnv && !dlSpec && !(nPipesEnv >= 2);
   if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
@@ -1682,17 +1687,16 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     uint32_t* C = w.counters.p;
     int wc = 0;  // work counters live at C[1024..], 8 per launch
     int treeletErr = DR_OK;
-    auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr) {
+    auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr, bool coherent = false) {
       hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
       (void)hipEventRecord(e0, ts);
       if (treelets) {
         const int trc = L.trace_treelets(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts, w.tl);
         if (trc != DR_OK && treeletErr == DR_OK) treeletErr = trc;
-      } else if (!(coherentCamera && queue == nullptr && !any &&
-                   L.trace_coherent(sc->d, st, C + 1024 + 8 * DR_WORK_STRIDE * wc, sc->ctr.p, tgrid, ts))) {
+      } else if (!(coherent && L.trace_coherent(sc->d, st, queue, nQ, any, C + 1024 + 8 * DR_WORK_STRIDE * wc, sc->ctr.p, tgrid, ts))) {
         L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
       } else {
-        ++wc;  // (the coherent kernel took the camera rays: the identity queue of the batch's slots)
+        ++wc;  // (k_trace_pk took this queue: the camera rays, or the camera vertices' shadow rays towards one light)
       }
       (void)hipEventRecord(e1, ts);
       if (pilot) pilot->ev[any].push_back({e0, e1});
@@ -1717,7 +1721,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       wc = 0;
     }
     if (stageCounts && round == 0) readCtrNow(&ctrBase);
-    trace(roundQ, nRound, 0, s, w.spill.p);  // camera rays (or this round's child rays)
+    trace(roundQ, nRound, 0, s, w.spill.p, nullptr, coherentCamera && roundQ == nullptr);  // camera rays (or this round's child rays)
     if (stageCounts && round == 0) {
       slog[0].c0 = sc->traceEvents.back().e0;
       slog[0].c1 = sc->traceEvents.back().e1;
@@ -1793,7 +1797,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
             slog[b + 1].c0 = sc->traceEvents.back().e0;
             slog[b + 1].c1 = sc->traceEvents.back().e1;
           }
-          trace(q.anyQ, q.nAny, 1, sc->s3, w.spill.p + w.spillHalf, closestEnd);
+          trace(q.anyQ, q.nAny, 1, sc->s3, w.spill.p + w.spillHalf, closestEnd, coherentShadow && (direct || b == 0));
           if (stageCounts && round == 0) {
             slog[b + 1].a0 = sc->traceEvents.back().e0;
             slog[b + 1].a1 = sc->traceEvents.back().e1;
@@ -1806,7 +1810,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
             slog[b + 1].c0 = sc->traceEvents.back().e0;
             slog[b + 1].c1 = sc->traceEvents.back().e1;
           }
-          trace(q.anyQ, q.nAny, 1, s, w.spill.p);
+          trace(q.anyQ, q.nAny, 1, s, w.spill.p, nullptr, coherentShadow && (direct || b == 0));
           if (stageCounts && round == 0) {
             slog[b + 1].a0 = sc->traceEvents.back().e0;
             slog[b + 1].a1 = sc->traceEvents.back().e1;
@@ -2023,7 +2027,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   sc->lastInfo[4] = pilotBatchesRun;
   sc->lastInfo[5] = (int32_t)std::min<uint64_t>(0x7fffffff, nBatches);
   sc->lastInfo[6] = tgrid / std::max(1, g_numCU);
-  sc->lastInfo[7] = (overlapAny ? 1 : 0) | (coherentCamera && !treelets && !sc->d.nquads ? 2 : 0);
+  sc->lastInfo[7] = (overlapAny ? 1 : 0) | (coherentCamera && !treelets && !sc->d.nquads ? 2 : 0) | (coherentShadow && !treelets ? 4 : 0);
   return DR_OK;
 #undef L
 }

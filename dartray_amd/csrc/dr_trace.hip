@@ -1725,11 +1725,17 @@ DR_DEV float4 ld_uniform(const float4* p) {
 DR_DEV uint4 ld_uniform(const uint4* p) { return *p; }
 DR_DEV float4 ld_uniform(const float4* p) { return *p; }
 #endif
-__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DScene sc, BatchState st, uint32_t n, uint32_t* work, TraceCounters* ctr) {
+// ANY = 1 (BVHAccel.intersectP, bvh_accel.dart:167-226) for the shadow rays of the CAMERA vertices of a scene with one light: 64
+// consecutive entries of the stage's any-hit queue leave neighbouring hit points towards the same emitter.  A lane whose ray has
+// found an occluder has returned (:193-195): it leaves every mask (`done`), the others walk on.
+template <int ANY>
+__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DScene sc, BatchState st, const uint32_t* queue, const uint32_t* nQueue,
+                                                                             uint32_t* work, TraceCounters* ctr) {
   __shared__ uint32_t s_pk[(DR_TRACE_BLOCK / 64) * DR_MAX_STACK * 3];
   typedef __attribute__((address_space(3))) uint32_t pk_u32;
   pk_u32* const stk = (pk_u32*)(s_pk + (threadIdx.x >> 6) * (DR_MAX_STACK * 3));
-  StateIO<0> io{st, nullptr};
+  StateIO<ANY> io{st, queue};
+  const uint32_t n = nQueue ? *nQueue : st.nslots;
   const int lane = lane_id();
   uint32_t nRays = 0, nNodes = 0, nTris = 0;  // nRays / nNodes: wave-uniform, lane 0 reports them; nTris: per lane
   const uint32_t nTiles = (n + 63u) >> 6;
@@ -1745,9 +1751,10 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
       TraceRay ray;
       int hit = -1;
       {
-        uint32_t handle;
-        io.load(have ? idx : n - 1u, ray, handle);  // (a lane beyond the end loads the last ray and takes no part; the handle of an identity queue is idx)
+        uint32_t handle;  // (re-read from the queue at the store: not held in a register across the walk)
+        io.load(have ? idx : n - 1u, ray, handle);  // (a lane beyond the end loads the last ray and takes no part)
       }
+      unsigned long long done = 0ull;  // ANY: the lanes whose ray has returned
       const unsigned long long haveMask = __ballot(have);
       nRays += (uint32_t)__popcll(haveMask);
       if (sc.nnodes != 0u) {
@@ -1762,6 +1769,18 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
           uint32_t cur = 0u;
           unsigned long long curMask = pmask;
           for (;;) {
+            if (ANY) {
+              curMask &= ~done;
+              if (curMask == 0ull) {  // every ray that would have visited this node has returned: not a visit
+                if (sp == 0) break;
+                --sp;
+                cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[3 * sp]);
+                const uint32_t mlo_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[3 * sp + 1]);
+                const uint32_t mhi_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[3 * sp + 2]);
+                curMask = (unsigned long long)mlo_ | ((unsigned long long)mhi_ << 32);
+                continue;
+              }
+            }
             const uint4* np = (const uint4*)((const char*)sc.nodes + (size_t)(cur << 5));  // wave-uniform address
             const uint4 a = ld_uniform(np), b = ld_uniform(np + 1);
             nNodes += (uint32_t)__popcll(curMask);
@@ -1789,13 +1808,22 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
                   if (ok) {
                     ++nTris;
                     const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
-                    double t, b1, b2;
-                    if (tri_hit(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax, &t, &b1, &b2)) {
-                      ray_set_tmax(ray, t);  // r.maxDistance = thit (geometric_primitive.dart:59)
-                      hit = (int)(leafOff + i);
+                    if (ANY) {
+                      if (tri_hitP(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax)) {  // return true (bvh_accel.dart:193-195)
+                        hit = 0;
+                        ok = false;  // no further triangle of this leaf for this ray
+                      }
+                    } else {
+                      double t, b1, b2;
+                      if (tri_hit(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax, &t, &b1, &b2)) {
+                        ray_set_tmax(ray, t);  // r.maxDistance = thit (geometric_primitive.dart:59)
+                        hit = (int)(leafOff + i);
+                      }
                     }
                   }
+                  if (ANY && __ballot(ok) == 0ull) break;  // every ray at this leaf has returned
                 }
+                if (ANY) done |= __ballot(hit == 0);
               } else {  // interior: near child now, far child pushed for the lanes that are here (bvh_accel.dart:145-155)
                 const uint32_t axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)((b.w >> 16) & 0xffu));
                 const uint32_t second = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.z);
@@ -1822,10 +1850,10 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
           }
         }
       }
-      if (have) io.store(idx, ray, hit, sc);
+      if (have) io.store(queue ? queue[idx] : idx, ray, hit, sc);
     }
   }
-  flush_counters(ctr, 0, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
+  flush_counters(ctr, ANY, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
 }
 
 // ---------------------------------------------------------------------------
@@ -1872,10 +1900,12 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
 }
 // The camera rays of a batch (identity queue: tile t = slots 64 t .. 64 t + 63, samples of one pixel at spp >= 64) through the
 // wave-coherent kernel.  Returns false when this scene / build cannot use it (quadric primitives: k_trace_quad's tests).
-bool launch_trace_coherent(const DScene& sc, const BatchState& st, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
+bool launch_trace_coherent(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit, uint32_t* workCounter,
+                           TraceCounters* ctr, int grid, hipStream_t s) {
   if (sc.nquads) return false;
   grid = std::min(grid, traceGridFor(DR_PK_WG_PER_CU));
-  hipLaunchKernelGGL(k_trace_pk, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, st.nslots, workCounter, ctr);
+  if (anyHit) hipLaunchKernelGGL(k_trace_pk<1>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, queue, nQueue, workCounter, ctr);
+  else hipLaunchKernelGGL(k_trace_pk<0>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, queue, nQueue, workCounter, ctr);
   return true;
 }
 int trace_kernel_id(const DScene& sc, int anyHit) {

@@ -329,7 +329,7 @@ int dr_scene_get_pilot(const DrScene* scene, float ms_per_gb_out[6]);
  * (1, 2, 3, 5 as above; 4 = the treelet-parked traversal), out[3] the treelet parking rounds (-1 otherwise), out[4] the
  * calibration batches it ran (0: no pilot), out[5] its batches, out[6] workgroups per CU of a persistent traversal
  * launch, out[7] bit 0: a stage's any-hit launch ran beside its closest-hit launch, bit 1: the camera rays went through the
- * wave-coherent kernel (k_trace_pk).  All 0 / -1 before the first render. */
+ * wave-coherent kernel (k_trace_pk), bit 2: so did the camera vertices' shadow rays.  All 0 / -1 before the first render. */
 int dr_scene_last_render_info(const DrScene* scene, int32_t info_out[8]);
 /* The path-state layout of this scene's path-traced renders, next to the traversal kernels and measured the same way: the
  * first big render's first pilot batch counts how many of its slots are still alive at the second bounce (density_out;
@@ -446,6 +446,7 @@ const char* dr_version(void);
  *   TREELET_ROUNDS n, TREELET_SHARDS n, TREELET_MIN n   the treelet-parked traversal (TRACE_IMPL=4; MEASUREMENTS.md, round 4)
  *   SCENE_PREP host, GEN_PREPASS 0   dr_scene_create's checks on the host; no burn-in pre-pass above 256 spp
  *   COHERENT_CAMERA 0     the camera rays through the per-lane traversal kernels like every other ray (default: the wave-coherent k_trace_pk)
+ *   COHERENT_SHADOW 1     the camera vertices' shadow rays through k_trace_pk too (a measured negative, kept for A/B: default off)
  *   GEN_SLOW_DRAWS, GEN_ALL_BLOCKS, GEN_LANES n, GEN_ONE_WAVE, FLOAT_SAMPLES, LDS_LIGHTS 0   A/B variants of the sampler / shade kernels
  *   BUILD_THREADS n, BUILD_DEBUG   the BVH builders;  RCCL_LIB path   librccl to bind;  STAGE_COUNTS 1|2 (per stage: list lengths and kernel times; 2: also
  *                         the node visits / triangle tests of each stage's traversals, waiting for the device after every stage), VERBOSE   diagnostics */
