@@ -141,11 +141,17 @@ def gen_alg_bytes_per_sample(nblocks, spp):
     return nblocks * idx + 8.0 * nblocks / spp + 2 * idx + 32.0
 
 
-def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="C2", gen_bytes_per_sample=None, kernels_forced=False):
-    alg = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
-    launches = max(1, st["closest_launches"])
-    achieved = alg / max(st["closest_ms"] * 1e-3, 1e-12) / 1e9
-    all_alg = alg + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
+def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="C2", gen_bytes_per_sample=None, kernels_forced=False, pk=None):
+    # (round 5) the camera rays are traced by k_trace_pk (coherent waves); `pk` = its share of the closest-hit totals
+    # (dr_scene_get_coherent_stats): the dominant kernel's object below is the PER-LANE kernel alone, k_trace_pk gets its own
+    pk = pk or {"rays": 0, "nodes": 0, "tris": 0, "launches": 0, "ms": 0.0}
+    alg_all_closest = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
+    alg_pk = 32.0 * pk["nodes"] + 48.0 * pk["tris"]
+    alg = alg_all_closest - alg_pk
+    launches = max(1, st["closest_launches"] - pk["launches"])
+    lane_ms = st["closest_ms"] - pk["ms"]
+    achieved = alg / max(lane_ms * 1e-3, 1e-12) / 1e9
+    all_alg = alg_all_closest + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
     # (the observed bounds were read off the committed profiles of the kernels the pilots pick: not claimed for forced kernels)
     bo = {} if kernels_forced else BOUND_OBSERVED.get(tag, {})
     roof = {"bound": bo.get("trace_bound", "hbm"), "bound_priced_against": "hbm",
@@ -160,7 +166,9 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
             "hbm_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
             "alg_over_measured_copy": round(achieved / copy_gbps, 4) if copy_gbps else None,
             "alg_bytes_per_launch": round(alg / launches, 1),
-            "avg_launch_ms": round(st["closest_ms"] / launches, 4), "launches": int(st["closest_launches"]),
+            "avg_launch_ms": round(lane_ms / launches, 4), "launches": int(launches),
+            "camera_rays_by": ("k_trace_pk (coherent waves): %d launches, %.2f ms and %.1f GB of algorithmic bytes per launch -- not in this object: see roofline_camera"
+                               % (pk["launches"], pk["ms"] / max(1, pk["launches"]), alg_pk / max(1, pk["launches"]) / 1e9)) if pk["launches"] else None,
             "avg_launch_ms_note": ("HIP events around each %s launch on its own stream; the stage's any-hit launch runs beside it on a second "
                                    "stream (DARTRAY_OVERLAP_ANY=0 serialises them: profiles/r0*_kernel_stats_serial.csv, within 1 %% of this figure)"
                                    % closest_kernel if os.environ.get("DARTRAY_OVERLAP_ANY", "1") != "0" else "%s, one kernel at a time" % closest_kernel),
@@ -218,7 +226,17 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
             shade["traffic_over_algorithmic"] = round(prof["shade_ratio"], 3)
         roof["bound_observed"] = bo.get("trace")
         shade["bound_observed"] = bo.get("shade")
-    return roof, shade, gen, all_alg
+    cam = None
+    if pk["launches"]:
+        ca = alg_pk / max(pk["ms"] * 1e-3, 1e-12) / 1e9
+        cam = {"bound": "scalar-load latency + VALU at full lane width", "bound_priced_against": "hbm",
+               "kernel": "k_trace_pk<0> (closest-hit traversal of the camera rays by coherent waves: one stack per wave, node and triangles loaded once per wave)",
+               "achieved": round(ca, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(ca / PEAK_GBPS, 4), "saturated": bool(ca / PEAK_GBPS > 1.0),
+               "traffic": None, "achieved_is": "algorithmic bytes per second (32 B per ray and node visit: the reference's per-ray count), not HBM traffic -- "
+                                               "the wave loads a node ONCE for its 64 rays, so this figure exceeds any memory rate by construction",
+               "alg_bytes_per_launch": round(alg_pk / pk["launches"], 1), "avg_launch_ms": round(pk["ms"] / pk["launches"], 4), "launches": int(pk["launches"]),
+               "rays": int(pk["rays"]), "node_visits_per_ray": round(pk["nodes"] / max(1, pk["rays"]), 2)}
+    return roof, shade, gen, all_alg, cam
 
 
 # What the PMC passes say bounds each kernel (MEASUREMENTS.md; profiles/r0*_traffic.json).  "bound" on the line is
@@ -274,7 +292,7 @@ def kernel_profile(tag, names):
     return out
 
 
-def trace_ceilings(tag, kname, st, steps):
+def trace_ceilings(tag, kname, st, steps, pk=None):
     """Throughput ceilings of the closest-hit traversal kernel, per step, from what the kernel asks of each shared resource:
     the time each resource alone would need for this run's work at its MEASURED peak rate (tools/gather_rate.hip:
     profiles/r05_gather_rates.json) -- VALU issue (2 cycles per wave64 instruction on a SIMD-32 with several waves resident), the
@@ -297,15 +315,17 @@ def trace_ceilings(tag, kname, st, steps):
         return None
     fname, d, k = prof
     alg_prof = d["alg_bytes_per_launch"]
-    alg_run = (32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]) / steps
+    pk = pk or {"nodes": 0, "tris": 0, "ms": 0.0}
+    nodes, tris, ms = st["closest_nodes"] - pk["nodes"], st["closest_tris"] - pk["tris"], st["closest_ms"] - pk["ms"]  # the per-lane kernel's share
+    alg_run = (32.0 * nodes + 48.0 * tris) / steps
     clk, simds, cus = 2.4e9, 1024, 256
-    out = {"kernel": kname, "per": "step", "measured_ms": round(st["closest_ms"] / steps, 2),
+    out = {"kernel": kname, "per": "step", "measured_ms": round(ms / steps, 2),
            "demand_source": "profiles/" + fname + " (per algorithmic byte)", "rate_source": "profiles/r05_gather_rates.json (tools/gather_rate.hip)"}
     c = {}
     if k.get("valu_issue_share_at_4_cycles_per_instruction") and k.get("avg_launch_ms_kernel_trace"):
         instr = k["valu_issue_share_at_4_cycles_per_instruction"] * k["avg_launch_ms_kernel_trace"] * 1e-3 * clk / 4.0 * simds
         c["valu_issue_ms"] = instr / alg_prof * alg_run * 2.0 / (simds * clk) * 1e3
-    c["l1_divergent_loads_ms"] = (2.0 * st["closest_nodes"] + 3.0 * st["closest_tris"]) / steps / (rates["l1_hit_lane_loads_per_cu_cycle"] * cus * clk) * 1e3
+    c["l1_divergent_loads_ms"] = (2.0 * nodes + 3.0 * tris) / steps / (rates["l1_hit_lane_loads_per_cu_cycle"] * cus * clk) * 1e3
     if k.get("l2_requests_per_launch"):
         c["l2_requests_ms"] = k["l2_requests_per_launch"] / alg_prof * alg_run / rates["l2_hit_records_per_s"] * 1e3
     if k.get("read_requests_per_launch"):
@@ -313,7 +333,7 @@ def trace_ceilings(tag, kname, st, steps):
     out["ceilings_ms"] = {n: round(v, 1) for n, v in c.items()}
     binding = max(c, key=c.get)
     out["binding"] = binding
-    out["frac_of_binding_ceiling"] = round(c[binding] / (st["closest_ms"] / steps), 3)
+    out["frac_of_binding_ceiling"] = round(c[binding] / (ms / steps), 3)
     out["reading"] = ("each shared resource alone would need this long for the step's closest-hit traversal; the kernel takes `measured_ms` because the "
                       "resources overlap imperfectly behind dependent fetches at the occupancy its registers allow (7 workgroups per CU)")
     return out
@@ -422,7 +442,7 @@ def main():
                 r = Run(c, eres, espp, 0, 1, emode, args)
                 e = r.headline(esteps, ewarm)
                 extra.append({k: e[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
-                                                "roofline_shade", "roofline_gen", "trace_kernels_profiled", "kernel_ms_per_step", "per_sample",
+                                                "roofline_shade", "roofline_gen", "roofline_camera", "trace_kernels_profiled", "kernel_ms_per_step", "per_sample",
                                                 "first_render_ms", "pilot_ms", "one_shot_ms", "traffic_profiled") if k in e})
                 del r
                 torch.cuda.empty_cache()
@@ -545,8 +565,9 @@ class Run:
         forced = bool(getattr(args, "trace_kernels", None)) or bool(os.environ.get("DARTRAY_TRACE_IMPL"))
         knames = {"closest": {2: "k_trace<0>", 3: "k_trace3<0>", 5: "k_trace3c"}.get(picked[0], str(picked[0])),
                   "any_hit": {2: "k_trace<1>", 3: "k_trace3a"}.get(picked[1], str(picked[1]))}
-        roof, shade, gen, all_alg = roofline_objects(st, dt, copy.value, knames["closest"], self.cfg, gbs, kernels_forced=forced)
-        roof["ceilings"] = trace_ceilings(self.cfg, knames["closest"], st, steps)
+        pk = self.dev.coherent_stats()
+        roof, shade, gen, all_alg, cam = roofline_objects(st, dt, copy.value, knames["closest"], self.cfg, gbs, kernels_forced=forced, pk=pk)
+        roof["ceilings"] = trace_ceilings(self.cfg, knames["closest"], st, steps, pk)
         roof["model"] = occupancy_model(self.cfg, knames["closest"])
         pilot = self.dev.pilot()
         near = []  # picks the calibration batches decided by less than 2 %
@@ -582,6 +603,7 @@ class Run:
                        "triangles": int(len(agg.tri_idx)), "bvh_nodes": int(len(agg.nodes)),
                        "bvh_builder": "%s (dr_bvh_build_%s), %.0f ms" % (agg.builder, "device" if agg.builder == "device" else "mixed", agg.build_ms),
                        "trace_kernels": {"closest": knames["closest"], "any_hit": knames["any_hit"],
+                                         "camera_rays": "k_trace_pk<0>" if pk["launches"] else knames["closest"],
                                          "picked_by": ("--trace-kernels / DARTRAY_TRACE_IMPL" if forced else
                                                        "the scene's pilot batches (closest-hit: best time per algorithmic byte, a pair kernel needs 5 %; any-hit: "
                                                        "the closest-hit kernel's family unless the other wins its own batch by more than 15 %)"),
@@ -595,6 +617,7 @@ class Run:
             "roofline": roof,
             "roofline_shade": shade,
             "roofline_gen": gen,
+            "roofline_camera": cam,
             # per traversal kernel of this line, from the committed PMC passes of the same command (not this run): where the lanes and
             # the wave-cycles go -- the figures that move when a traversal kernel gets better or worse
             "trace_kernels_profiled": kernel_profile(self.cfg, knames),

@@ -667,6 +667,12 @@ class _DeviceScene:
                 "pilot_batches": int(arr[4]), "batches": int(arr[5]), "trace_wg_per_cu": int(arr[6]), "overlap_any": int(arr[7]) & 1,
                 "coherent_camera": (int(arr[7]) >> 1) & 1, "coherent_shadow": (int(arr[7]) >> 2) & 1}
 
+    def coherent_stats(self):
+        """The part of stats()' closest-hit totals that k_trace_pk (coherent waves: the camera rays) traced."""
+        arr = (C.c_double * 5)()
+        _abi.check(_abi.lib().dr_scene_get_coherent_stats(self.handle, C.byref(arr)))
+        return {"rays": int(arr[0]), "nodes": int(arr[1]), "tris": int(arr[2]), "launches": int(arr[3]), "ms": float(arr[4])}
+
     def pilot(self):
         """What the traversal pilot measured, ms per algorithmic GB: {"closest": {2: .., 3: .., 5: ..}, "any_hit": {2: .., 3: ..}}
         (0.0 = that candidate was not timed)."""

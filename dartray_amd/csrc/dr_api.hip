@@ -171,6 +171,10 @@ struct DrScene {
   size_t eventsUsed = 0;
   bool statsPending = false;
   hipEvent_t lastEvent = nullptr;
+  // dr_scene_get_coherent_stats: what k_trace_pk traced of the closest-hit totals since the last dr_reset_stats
+  double pkMs = 0.0;
+  uint64_t pkLaunches = 0;
+  unsigned long long pkRays = 0, pkNodes = 0, pkTris = 0;
   // Timings of finished launches are folded into `stats` and their events recycled, so a long-lived scene (a frame
   // loop calling dr_render_device) does not grow the pool or the lists without bound.
   void foldEvents() {
@@ -180,6 +184,7 @@ struct DrScene {
       if (t < 0.f) t = 0.f;  // (an any-hit launch that ended before the closest-hit one beside it)
       if (ev.any == 1) { stats.any_ms += t; stats.any_launches++; }
       else if (ev.any == 0) { stats.closest_ms += t; stats.closest_launches++; }
+      else if (ev.any == 6) { stats.closest_ms += t; stats.closest_launches++; pkMs += t; pkLaunches++; }  // k_trace_pk: part of the closest-hit time
       else if (ev.any == 2) stats.shade_ms += t;
       else if (ev.any == 3) stats.gen_ms += t;
       else if (ev.any == 5) stats.pilot_ms += t;
@@ -1690,6 +1695,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr, bool coherent = false) {
       hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
       (void)hipEventRecord(e0, ts);
+      bool tookCoherent = false;
       if (treelets) {
         const int trc = L.trace_treelets(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts, w.tl);
         if (trc != DR_OK && treeletErr == DR_OK) treeletErr = trc;
@@ -1697,10 +1703,11 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
         L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
       } else {
         ++wc;  // (k_trace_pk took this queue: the camera rays, or the camera vertices' shadow rays towards one light)
+        tookCoherent = true;
       }
       (void)hipEventRecord(e1, ts);
       if (pilot) pilot->ev[any].push_back({e0, e1});
-      sc->traceEvents.push_back({e0, e1, any, after});
+      sc->traceEvents.push_back({e0, e1, tookCoherent && !any ? 6 : any, after});
       return e1;
     };
     // A stage's two traversals are independent (closest hit of the continuation / MIS rays, occlusion of the shadow
@@ -2064,6 +2071,9 @@ int dr_get_stats(DrScene* sc, DrRenderStats* out) {
     sc->stats.closest_tris = c.closest_tris; sc->stats.any_tris = c.any_tris;
     sc->stats.shade_items = c.shade_items; sc->stats.shade_vertices = c.shade_vertices;
     sc->stats.shade_cont = c.shade_cont; sc->stats.shade_mis = c.shade_mis; sc->stats.shade_shadow = c.shade_shadow;
+    sc->pkRays = c.pk_rays[0];
+    sc->pkNodes = c.pk_nodes[0];
+    sc->pkTris = c.pk_tris[0];
     sc->foldEvents();
     sc->statsPending = false;
     shade_prof_dump();
@@ -2084,7 +2094,23 @@ int dr_reset_stats(DrScene* sc) {
   sc->eventsUsed = 0;
   sc->lastEvent = nullptr;
   sc->statsPending = false;
+  sc->pkMs = 0.0;
+  sc->pkLaunches = 0;
+  sc->pkRays = sc->pkNodes = sc->pkTris = 0;
   HIP_TRY(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
+  return DR_OK;
+}
+
+int dr_scene_get_coherent_stats(DrScene* sc, double out[5]) {
+  if (!sc || !out) return fail(DR_ERR_INVALID, "null argument");
+  DrRenderStats st;
+  const int rc = dr_get_stats(sc, &st);  // (waits for the renders in flight and folds their events, like dr_get_stats)
+  if (rc) return rc;
+  out[0] = (double)sc->pkRays;
+  out[1] = (double)sc->pkNodes;
+  out[2] = (double)sc->pkTris;
+  out[3] = (double)sc->pkLaunches;
+  out[4] = sc->pkMs;
   return DR_OK;
 }
 

@@ -175,6 +175,8 @@ struct TraceCounters {  // device-side totals (Stats probes of bvh_accel.dart:10
   unsigned long long closest_rays, any_rays, closest_nodes, any_nodes, closest_tris, any_tris;
   // shading stages: active-list entries processed, path vertices set up, rays queued (DrRenderStats.shade_*)
   unsigned long long shade_items, shade_vertices, shade_cont, shade_mis, shade_shadow;
+  // the part of the closest_* / any_* totals above that k_trace_pk (coherent waves: the camera rays) traced, [0] closest [1] any hit
+  unsigned long long pk_rays[2], pk_nodes[2], pk_tris[2];
 };
 
 // A slot's place in the tiled state: `a` addresses its element of the 4-byte fields (biased by SLOT_BIAS so that

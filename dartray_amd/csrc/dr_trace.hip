@@ -1853,6 +1853,14 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
       if (have) io.store(queue ? queue[idx] : idx, ray, hit, sc);
     }
   }
+  {  // (what THIS kernel traced, next to the totals: the bench line prices k_trace<0> and k_trace_pk separately)
+    const unsigned long long r = wave_sum(lane == 0 ? nRays : 0u), nn = wave_sum(lane == 0 ? nNodes : 0u), t = wave_sum(nTris);
+    if (lane == 0 && ctr && (r | nn | t) != 0ull) {
+      atomicAdd(&ctr->pk_rays[ANY], r);
+      atomicAdd(&ctr->pk_nodes[ANY], nn);
+      atomicAdd(&ctr->pk_tris[ANY], t);
+    }
+  }
   flush_counters(ctr, ANY, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
 }
 

@@ -331,6 +331,11 @@ int dr_scene_get_pilot(const DrScene* scene, float ms_per_gb_out[6]);
  * launch, out[7] bit 0: a stage's any-hit launch ran beside its closest-hit launch, bit 1: the camera rays went through the
  * wave-coherent kernel (k_trace_pk), bit 2: so did the camera vertices' shadow rays.  All 0 / -1 before the first render. */
 int dr_scene_last_render_info(const DrScene* scene, int32_t info_out[8]);
+/* Diagnostics: the part of DrRenderStats' closest-hit totals (closest_rays / _nodes / _tris / _launches / _ms, accumulated since the last
+ * dr_reset_stats) that the wave-coherent kernel k_trace_pk traced -- the camera rays -- as out[0] rays, out[1] node visits, out[2]
+ * triangle tests, out[3] launches, out[4] ms.  Waits for the renders in flight like dr_get_stats.  What is left after subtracting them
+ * belongs to the per-lane closest-hit kernel (k_trace<0> / k_trace3<0> / k_trace3c): how bench.py prices the two separately. */
+int dr_scene_get_coherent_stats(DrScene* scene, double out[5]);
 /* The path-state layout of this scene's path-traced renders, next to the traversal kernels and measured the same way: the
  * first big render's first pilot batch counts how many of its slots are still alive at the second bounce (density_out;
  * -1 before); below one half the renders use four-slot, line-grouped sub-tiles (layout 4: stage lists that thin out touch

@@ -173,6 +173,9 @@ def test_coherent_camera_kernel_equals_the_per_lane_kernels():
         "        _abi.check(lib.dr_set_option(b'COHERENT_CAMERA', on)); _abi.check(lib.dr_set_option(b'COHERENT_SHADOW', shadow))\n"
         "        out = r.render(scene); films.append(out.film); stats.append(r.last_stats)\n"
         "        info = dev.last_render_info(); assert (info['coherent_camera'], info['coherent_shadow']) == (int(on), int(shadow)), info\n"
+        "        cs = dev.coherent_stats(); st_ = r.last_stats\n"   # the coherent kernel's share of the closest-hit totals: the camera rays, one launch per batch
+        "        assert (cs['rays'], cs['launches']) == ((st_['camera_samples'], st_['batches']) if on == b'1' else (0, 0)), (cs, st_)\n"
+        "        assert 0 <= cs['nodes'] <= st_['closest_nodes'] and 0 <= cs['tris'] <= st_['closest_tris'] and cs['ms'] <= st_['closest_ms'] + 1e-6\n"
         "    _abi.check(lib.dr_set_option(b'COHERENT_CAMERA', None)); _abi.check(lib.dr_set_option(b'COHERENT_SHADOW', None))\n"
         "    assert np.array_equal(films[0], films[1]) and np.array_equal(films[0], films[2])\n"
         "    keys = ('closest_nodes', 'any_nodes', 'closest_tris', 'any_tris', 'closest_rays', 'any_rays')\n"
