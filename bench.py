@@ -561,12 +561,17 @@ class Run:
         samples_per_step = self.H * self.W * self.spp * (world if (self.mode == "samples" and world > 1) else 1)
         value = samples_per_step * steps / dt / 1e6
         picked = self.dev.trace_kernels()  # (closest, any): 2 = k_trace, 3 = k_trace3 / k_trace3a, 5 = k_trace3c (the pilot's choice for this scene)
-        gbs = gen_alg_bytes_per_sample(gen_blocks(self.renderer, self.scene), self.spp)
+        # (lazy generation shuffles bounce b's blocks only for pixel groups alive at bounce b: the blocks that count are the ones generated)
+        ss = self.dev.sampler_stats()
+        gen_share = ss["generated"] / ss["named"] if ss["named"] else 1.0
+        gbs = gen_alg_bytes_per_sample(gen_blocks(self.renderer, self.scene) * gen_share, self.spp)
         forced = bool(getattr(args, "trace_kernels", None)) or bool(os.environ.get("DARTRAY_TRACE_IMPL"))
         knames = {"closest": {2: "k_trace<0>", 3: "k_trace3<0>", 5: "k_trace3c"}.get(picked[0], str(picked[0])),
                   "any_hit": {2: "k_trace<1>", 3: "k_trace3a"}.get(picked[1], str(picked[1]))}
         pk = self.dev.coherent_stats()
         roof, shade, gen, all_alg, cam = roofline_objects(st, dt, copy.value, knames["closest"], self.cfg, gbs, kernels_forced=forced, pk=pk)
+        if gen:
+            gen["blocks_generated_of_named"] = round(gen_share, 4)
         roof["ceilings"] = trace_ceilings(self.cfg, knames["closest"], st, steps, pk)
         roof["model"] = occupancy_model(self.cfg, knames["closest"])
         pilot = self.dev.pilot()

@@ -146,6 +146,7 @@ EXPORTS = {
     "dr_scene_get_pilot": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 6)]),
     "dr_scene_last_render_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32 * 8)]),
     "dr_scene_get_coherent_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double * 5)]),
+    "dr_scene_get_sampler_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double * 2)]),
     "dr_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "dr_sample_floats": (C.c_int32, [C.c_int32, C.c_uint32]),
     "dr_scene_sample_floats": (C.c_int32, [C.c_void_p, C.c_int32]),

@@ -665,13 +665,19 @@ class _DeviceScene:
         _abi.check(_abi.lib().dr_scene_last_render_info(self.handle, C.byref(arr)))
         return {"state_layout": int(arr[0]), "closest_kernel": int(arr[1]), "any_hit_kernel": int(arr[2]), "treelet_rounds": int(arr[3]),
                 "pilot_batches": int(arr[4]), "batches": int(arr[5]), "trace_wg_per_cu": int(arr[6]), "overlap_any": int(arr[7]) & 1,
-                "coherent_camera": (int(arr[7]) >> 1) & 1, "coherent_shadow": (int(arr[7]) >> 2) & 1}
+                "coherent_camera": (int(arr[7]) >> 1) & 1, "coherent_shadow": (int(arr[7]) >> 2) & 1, "lazy_gen": (int(arr[7]) >> 3) & 1}
 
     def coherent_stats(self):
         """The part of stats()' closest-hit totals that k_trace_pk (coherent waves: the camera rays) traced."""
         arr = (C.c_double * 5)()
         _abi.check(_abi.lib().dr_scene_get_coherent_stats(self.handle, C.byref(arr)))
         return {"rays": int(arr[0]), "nodes": int(arr[1]), "tris": int(arr[2]), "launches": int(arr[3]), "ms": float(arr[4])}
+
+    def sampler_stats(self):
+        """(pixel, LD block) pairs the device sampler generated / that the integrator's reads name (lazy generation: fewer where paths end early)."""
+        arr = (C.c_double * 2)()
+        _abi.check(_abi.lib().dr_scene_get_sampler_stats(self.handle, C.byref(arr)))
+        return {"generated": int(arr[0]), "named": int(arr[1])}
 
     def pilot(self):
         """What the traversal pilot measured, ms per algorithmic GB: {"closest": {2: .., 3: .., 5: ..}, "any_hit": {2: .., 3: ..}}

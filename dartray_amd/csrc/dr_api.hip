@@ -71,6 +71,7 @@ struct Workspace {
   DevBuf<unsigned long long> tailOff;  // packed tail (DrRenderDesc.tail_offsets): the batch's nslots + 1 offsets
   DevBuf<uint32_t> activeA, activeB, closestQ, anyQ, counters, spill;
   DevBuf<uint32_t> envQ;  // plain-triangle scenes under an environment map: k_env's list of a stage (cap entries)
+  DevBuf<uint8_t> alive;  // lazy sample generation: [3][groups of 64 batch pixels] = a path of the group is alive at bounce 0 / 1 / 2
   size_t spillHalf = 0;
   DevBuf<uint32_t> roundA, roundB;  // DirectLighting over mirror / glass: the slots whose child ray is traced next round
   DevBuf<float> specFrames;         //   [maxDepth][cap] SpecFrame
@@ -101,7 +102,7 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_COHERENT_SHADOW", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP",
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_COHERENT_SHADOW", "DARTRAY_LAZY_GEN", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP",
     "DARTRAY_TREELET_ROUNDS", "DARTRAY_TREELET_MIN", "DARTRAY_TREELET_SHARDS", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
@@ -175,6 +176,9 @@ struct DrScene {
   double pkMs = 0.0;
   uint64_t pkLaunches = 0;
   unsigned long long pkRays = 0, pkNodes = 0, pkTris = 0;
+  // dr_scene_get_sampler_stats: (pixel, LD block) pairs the device sampler shuffled / that the path's reads name (rp.genMask), since the
+  // last dr_reset_stats (lazy generation: the first is smaller where paths end early -- sky pixels)
+  unsigned long long genDone = 0, genDoneHost = 0, genNamed = 0;
   // Timings of finished launches are folded into `stats` and their events recycled, so a long-lived scene (a frame
   // loop calling dr_render_device) does not grow the pool or the lists without bound.
   void foldEvents() {
@@ -390,6 +394,10 @@ BatchState makeState(Workspace& w, const SampleForm& sf, const int2* pix, uint32
   st.svScr = sf.compact ? w.scr.p : nullptr;
   {  // DARTRAY_GEN_PREPASS=0 (A/B, tests): the shuffle kernels seed and burn in their streams themselves
     st.genState = sf.compact && !dr_opt("DARTRAY_GEN_PREPASS").isZero() ? w.genState.p : nullptr;
+    st.genAlive = nullptr;
+    st.markAlive = nullptr;
+    st.markShift = 0;
+    st.padMark = 0;
   }
   st.pixCap = w.pixCap;
   st.specFrames = w.specFrames.p;
@@ -441,6 +449,8 @@ struct LayoutOps {
   decltype(&trace_kernel_id) trace_kernel_id;
   decltype(&launch_trace_treelets) trace_treelets;
   decltype(&launch_gen_samples) gen_samples;
+  decltype(&launch_mark_alive) mark_alive;
+  decltype(&launch_sum_alive) sum_alive;
   decltype(&launch_transpose_samples) transpose_samples;
   decltype(&launch_raygen) raygen;
   decltype(&launch_shade_path) shade_path;
@@ -451,9 +461,9 @@ struct LayoutOps {
   int stateWords;  // 4-byte words of fixed path state per slot in this layout (a tile is 64 of them + the sample region):
                    // what the kernels' own translation unit was compiled with (layout_state_words), not a constant repeated here
 };
-static const LayoutOps kLayout64 = {&launch_trace, &launch_trace_coherent, &trace_kernel_id, &launch_trace_treelets, &launch_gen_samples, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
+static const LayoutOps kLayout64 = {&launch_trace, &launch_trace_coherent, &trace_kernel_id, &launch_trace_treelets, &launch_gen_samples, &launch_mark_alive, &launch_sum_alive, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
                                     &launch_env, &launch_shade_direct, &launch_shade_spec, &launch_film, layout_state_words()};
-static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_trace_coherent, &sp4::trace_kernel_id, &sp4::launch_trace_treelets, &sp4::launch_gen_samples, &sp4::launch_transpose_samples, &sp4::launch_raygen,
+static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_trace_coherent, &sp4::trace_kernel_id, &sp4::launch_trace_treelets, &sp4::launch_gen_samples, &sp4::launch_mark_alive, &sp4::launch_sum_alive, &sp4::launch_transpose_samples, &sp4::launch_raygen,
                                      &sp4::launch_shade_path, &sp4::launch_env, &sp4::launch_shade_direct, &sp4::launch_shade_spec,
                                      &sp4::launch_film, sp4::layout_state_words()};
 
@@ -1559,6 +1569,10 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // of visited nodes is several rays' worth (C2 any-hit 95 -> 136 ms, C4 102 -> 326).
   const bool coherentShadow = !dlSpec && !sc->d.nquads && dr_opt("DARTRAY_COHERENT_SHADOW").nonZero();
   const bool overlapEnv = !(dr_opt("DARTRAY_OVERLAP_ANY").isZero());  // default: on
+  // lazy sample generation (DARTRAY_LAZY_GEN=0: every block for every pixel up front): needs the device sampler's compact form, the keyed
+  // per-(pixel, block) streams (a block that is left out disturbs no other) and k_trace_pk's marks of the camera rays that hit
+  const bool lazyGen = !hostBuf && sf.compact && rp.genMask != 0ull && rd->integrator == DR_INTEGRATOR_PATH && coherentCamera && !treelets &&
+                       !sc->d.nquads && spp >= 64 && !dr_opt("DARTRAY_LAZY_GEN").isZero();
   const bool overlapAny = overlapEnv && !dlSpec && !(nPipesEnv >= 2);
   if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
   const bool twoPipes = nPipesEnv >= 2 && !hostBuf && !dlSpec && npixTotal > pixPerBatch;
@@ -1641,6 +1655,24 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     const uint32_t nslots = np * (uint32_t)spp;
     BatchState st = makeState(w, sf, pixDev, nslots, hostBuf && needTail > 0, L.stateWords);
     HIP_TRY(hipMemsetAsync(w.counters.p, 0, N_COUNTERS * sizeof(uint32_t), s));
+    uint32_t nGroups = 0;
+    // lazy sample generation: the LD blocks of bounce b (light number, light component, light position, BSDF direction, path direction:
+    // the bits genMask gives the level, above) for the 64-pixel groups marked in alive[b]
+    auto genBounce = [&](int b) {
+      uint64_t m = (15ull << (3 + 4 * b)) | (7ull << (3 + rp.n1D + 3 * b));
+      m &= rp.genMask;
+      if (!m) return;
+      hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
+      (void)hipEventRecord(e0, s);
+      RenderParams rpB = rp;
+      rpB.genMask = m;
+      BatchState stB = st;
+      stB.genAlive = w.alive.p + (size_t)b * nGroups;
+      stB.markAlive = nullptr;
+      L.gen_samples(rpB, stB, np, s);
+      (void)hipEventRecord(e1, s);
+      sc->traceEvents.push_back({e0, e1, 3});
+    };
     auto timed = [&](int kind, hipEvent_t e0) {
       hipEvent_t e1 = sc->getEvent();
       (void)hipEventRecord(e1, s);
@@ -1684,8 +1716,24 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       } else if (needTail > 0)
         HIP_TRY(hipMemcpyAsync(w.tail.p, rd->tail + (size_t)p0 * spp * rd->max_tail,
                                (size_t)nslots * rd->max_tail * sizeof(double), hipMemcpyHostToDevice, s));
+    } else if (lazyGen) {
+      // the image (+ lens) blocks for every pixel now; the blocks of bounce b once it is known which 64-pixel groups still have a path there
+      RenderParams rpA = rp;
+      rpA.genMask = rp.genMask & 3ull;
+      L.gen_samples(rpA, st, np, s);
+      nGroups = (np + 63u) / 64u;
+      HIP_TRY(w.alive.alloc(3 * (size_t)nGroups));
+      HIP_TRY(hipMemsetAsync(w.alive.p, 0, 3 * (size_t)nGroups, s));
+      sc->genDoneHost += (unsigned long long)np * (unsigned)__builtin_popcountll(rpA.genMask);
+      sc->genNamed += (unsigned long long)np * (unsigned)__builtin_popcountll(rp.genMask);
+      st.markAlive = w.alive.p;  // k_trace_pk: the groups whose camera rays hit something
+      st.markShift = (uint32_t)rp.sppShift + 6u;
     } else {
       L.gen_samples(rp, st, np, s);
+      if (sf.compact && rp.genMask) {
+        sc->genDoneHost += (unsigned long long)np * (unsigned)__builtin_popcountll(rp.genMask);
+        sc->genNamed += (unsigned long long)np * (unsigned)__builtin_popcountll(rp.genMask);
+      }
     }
     L.raygen(rp, st, s);
     timed(3, evGen);
@@ -1729,6 +1777,10 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     }
     if (stageCounts && round == 0) readCtrNow(&ctrBase);
     trace(roundQ, nRound, 0, s, w.spill.p, nullptr, coherentCamera && roundQ == nullptr);  // camera rays (or this round's child rays)
+    if (lazyGen && round == 0) {
+      st.markAlive = nullptr;
+      genBounce(0);
+    }
     if (stageCounts && round == 0) {
       slog[0].c0 = sc->traceEvents.back().e0;
       slog[0].c1 = sc->traceEvents.back().e1;
@@ -1774,6 +1826,10 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       }
       if (envStage) L.env(sc->d, rp, st, q, b, sgrid, s);
       hipEvent_t evS1 = timed(2, evS);
+      if (lazyGen && round == 0 && b < 2 && b + 1 <= rd->max_depth) {  // bounce b + 1's blocks for the groups in this stage's output list
+        L.mark_alive(q.activeOut, q.nActiveOut, (uint32_t)rp.sppShift + 6u, w.alive.p + (size_t)(b + 1) * nGroups, s);
+        genBounce(b + 1);
+      }
       if (stageCounts && round == 0) {
         slog[b + 1].s0 = evS;
         slog[b + 1].sMid = evMid;
@@ -1853,6 +1909,11 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       roundQ = nextQ;
       nRound = nNext;
     }
+    }
+    if (lazyGen) {  // statistics: the (pixel, block) pairs the three genBounce calls came to
+      uint32_t nb[3];
+      for (int b = 0; b < 3; ++b) nb[b] = (uint32_t)__builtin_popcountll(((15ull << (3 + 4 * b)) | (7ull << (3 + rp.n1D + 3 * b))) & rp.genMask);
+      L.sum_alive(w.alive.p, nGroups, np, nb, sc->ctr.p, s);
     }
     {
       hipEvent_t evF = sc->getEvent();
@@ -2037,7 +2098,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   sc->lastInfo[4] = pilotBatchesRun;
   sc->lastInfo[5] = (int32_t)std::min<uint64_t>(0x7fffffff, nBatches);
   sc->lastInfo[6] = tgrid / std::max(1, g_numCU);
-  sc->lastInfo[7] = (overlapAny ? 1 : 0) | (coherentCamera && !treelets && !sc->d.nquads ? 2 : 0) | (coherentShadow && !treelets ? 4 : 0);
+  sc->lastInfo[7] = (overlapAny ? 1 : 0) | (coherentCamera && !treelets && !sc->d.nquads ? 2 : 0) | (coherentShadow && !treelets ? 4 : 0) | (lazyGen ? 8 : 0);
   return DR_OK;
 #undef L
 }
@@ -2074,6 +2135,7 @@ int dr_get_stats(DrScene* sc, DrRenderStats* out) {
     sc->pkRays = c.pk_rays[0];
     sc->pkNodes = c.pk_nodes[0];
     sc->pkTris = c.pk_tris[0];
+    sc->genDone = sc->genDoneHost + c.gen_pixel_blocks;
     sc->foldEvents();
     sc->statsPending = false;
     shade_prof_dump();
@@ -2097,7 +2159,18 @@ int dr_reset_stats(DrScene* sc) {
   sc->pkMs = 0.0;
   sc->pkLaunches = 0;
   sc->pkRays = sc->pkNodes = sc->pkTris = 0;
+  sc->genDone = sc->genDoneHost = sc->genNamed = 0;
   HIP_TRY(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
+  return DR_OK;
+}
+
+int dr_scene_get_sampler_stats(DrScene* sc, double out[2]) {
+  if (!sc || !out) return fail(DR_ERR_INVALID, "null argument");
+  DrRenderStats st;
+  const int rc = dr_get_stats(sc, &st);
+  if (rc) return rc;
+  out[0] = (double)sc->genDone;
+  out[1] = (double)sc->genNamed;
   return DR_OK;
 }
 

@@ -140,6 +140,13 @@ struct BatchState {
   // device sampler, compact form: the generator state of every (LD block, batch pixel) stream behind its scramble words and
   // its burn-in draws (k_gen_burnin), [nBlocks][pixCap] (lo, hi); null: the shuffle kernels seed and burn in themselves
   uint2* genState;
+  // Lazy sample generation (round 5): the LD blocks of bounce b are only shuffled for the 64-pixel groups that still have a path
+  // alive at bounce b.  genAlive: one byte per group of 64 batch pixels, read by the shuffle kernels (null: every group);
+  // markAlive: where k_trace_pk marks the groups of the camera rays that hit something (null: nothing is marked);
+  // markShift = sppShift + 6: slot -> group.
+  const uint8_t* genAlive;
+  uint8_t* markAlive;
+  uint32_t markShift, padMark;
   // DirectLighting over mirror / glass (Integrator.SpecularReflect / SpecularTransmit, integrator.dart:187-290): the
   // per-slot stack of suspended vertices, [level][cap] SpecFrame records, and its depth per slot; null otherwise
   float* specFrames;
@@ -177,6 +184,8 @@ struct TraceCounters {  // device-side totals (Stats probes of bvh_accel.dart:10
   unsigned long long shade_items, shade_vertices, shade_cont, shade_mis, shade_shadow;
   // the part of the closest_* / any_* totals above that k_trace_pk (coherent waves: the camera rays) traced, [0] closest [1] any hit
   unsigned long long pk_rays[2], pk_nodes[2], pk_tris[2];
+  // lazy sample generation: (pixel, LD block) pairs the shuffle kernels generated for bounces 0..2 (k_sum_alive, once per batch)
+  unsigned long long gen_pixel_blocks;
 };
 
 // A slot's place in the tiled state: `a` addresses its element of the 4-byte fields (biased by SLOT_BIAS so that

@@ -257,6 +257,7 @@ DR_DEV int gen_block(const RenderParams& rp) {
 __global__ void __launch_bounds__(256) k_gen_burnin(RenderParams rp, BatchState st, uint32_t npix) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npix) return;
+  if (st.genAlive && !st.genAlive[p >> 6]) return;  // no path of this 64-pixel group reads this bounce's blocks
   const int k = gen_block(rp);
   const bool is2D = k < 2 || k >= 3 + rp.n1D;
   const int2 xy = st.pix[p];
@@ -284,6 +285,7 @@ __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchSta
   extern __shared__ __align__(16) unsigned char s_raw[];
   constexpr int EPW = 4 / (int)sizeof(PT);  // entries per dword
   const int LN = (int)blockDim.x;
+  if (st.genAlive && !st.genAlive[(blockIdx.x * (uint32_t)LN) >> 6]) return;  // (LN divides 64: the workgroup's pixels are in one group; uniform exit)
   PT* s_perm = (PT*)s_raw;                  // [spp / EPW][LN][EPW]
   uint32_t* s_magic = (uint32_t*)(s_raw + (size_t)rp.spp * LN * sizeof(PT));  // [spp + 1]: floor(2^32 / m)
   const int lane = threadIdx.x;
@@ -409,6 +411,7 @@ DR_DEV void gen_wait(uint32_t* word, uint32_t want) {
 __global__ void __launch_bounds__(128) k_gen_samples_pc(RenderParams rp, BatchState st, uint32_t npix) {
   extern __shared__ __align__(16) unsigned char s_raw[];
   typedef uint16_t PT;
+  if (st.genAlive && !st.genAlive[blockIdx.x]) return;  // (the workgroup is one 64-pixel group; uniform exit)
   const int spp = rp.spp, G = spp / 4;
   PT* s_perm = (PT*)s_raw;                                                   // [spp / 2][64][2]
   uint32_t* s_magic = (uint32_t*)(s_raw + (size_t)spp * 64 * sizeof(PT));   // [spp + 1]: floor(2^32 / m)
@@ -567,6 +570,22 @@ __global__ void __launch_bounds__(64) k_gen_samples_multi(RenderParams rp, Batch
   }
 }
 
+// Lazy sample generation: the 64-pixel groups that have an entry in a stage's active list
+__global__ void __launch_bounds__(256) k_mark_alive(const uint32_t* list, const uint32_t* nList, uint32_t shift, uint8_t* alive) {
+  const uint32_t n = *nList;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) alive[(list[i] & 0x3fffffffu) >> shift] = 1;
+}
+// ... and what that came to: pixels of the marked groups x the blocks of each bounce (DrScene's sampler statistics)
+__global__ void __launch_bounds__(256) k_sum_alive(const uint8_t* alive, uint32_t nGroups, uint32_t npix, uint32_t nb0, uint32_t nb1, uint32_t nb2,
+                                                   TraceCounters* ctr) {
+  uint32_t mine = 0u;  // (a lane sees a few hundred groups at most: 64 pixels x <= 7 blocks each)
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 3u * nGroups; i += gridDim.x * blockDim.x) {
+    const uint32_t b = i / nGroups, g = i - b * nGroups;
+    if (alive[i]) mine += min(64u, npix - 64u * g) * (b == 0 ? nb0 : (b == 1 ? nb1 : nb2));
+  }
+  const unsigned long long sum = wave_sum(mine);
+  if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&ctr->gen_pixel_blocks, sum);
+}
 // Host-buffer mode: [n][stride] -> [nFloats][cap]
 __global__ void k_transpose_samples(const float* aos, int stride, BatchState st, int nFloats) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1889,6 +1908,12 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& stIn, uint32_t
     }
     hipLaunchKernelGGL((k_gen_samples<uint16_t, 66>), grid, dim3(64), lds, s, rp, st, npix);
   }
+}
+void launch_mark_alive(const uint32_t* list, const uint32_t* nList, uint32_t shift, uint8_t* alive, hipStream_t s) {
+  hipLaunchKernelGGL(k_mark_alive, dim3(2048), dim3(256), 0, s, list, nList, shift, alive);
+}
+void launch_sum_alive(const uint8_t* alive, uint32_t nGroups, uint32_t npix, const uint32_t nb[3], TraceCounters* ctr, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_alive, dim3(std::max(1u, std::min(256u, (3u * nGroups + 255u) / 256u))), dim3(256), 0, s, alive, nGroups, npix, nb[0], nb[1], nb[2], ctr);
 }
 void launch_transpose_samples(const float* aos, int stride, const BatchState& st, int nFloats, hipStream_t s) {
   hipLaunchKernelGGL(k_transpose_samples, dim3((st.nslots + 255) / 256), dim3(256), 0, s, aos, stride, st, nFloats);

@@ -1851,6 +1851,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
         }
       }
       if (have) io.store(queue ? queue[idx] : idx, ray, hit, sc);
+      if (!ANY && st.markAlive && have && hit >= 0) st.markAlive[idx >> st.markShift] = 1;  // lazy sample generation: this 64-pixel group has a vertex
     }
   }
   {  // (what THIS kernel traced, next to the totals: the bench line prices k_trace<0> and k_trace_pk separately)

@@ -329,13 +329,20 @@ int dr_scene_get_pilot(const DrScene* scene, float ms_per_gb_out[6]);
  * (1, 2, 3, 5 as above; 4 = the treelet-parked traversal), out[3] the treelet parking rounds (-1 otherwise), out[4] the
  * calibration batches it ran (0: no pilot), out[5] its batches, out[6] workgroups per CU of a persistent traversal
  * launch, out[7] bit 0: a stage's any-hit launch ran beside its closest-hit launch, bit 1: the camera rays went through the
- * wave-coherent kernel (k_trace_pk), bit 2: so did the camera vertices' shadow rays.  All 0 / -1 before the first render. */
+ * wave-coherent kernel (k_trace_pk), bit 2: so did the camera vertices' shadow rays, bit 3: the device sampler generated bounce b's blocks only for the pixel
+ * groups alive at bounce b (DARTRAY_LAZY_GEN).  All 0 / -1 before the first render. */
 int dr_scene_last_render_info(const DrScene* scene, int32_t info_out[8]);
 /* Diagnostics: the part of DrRenderStats' closest-hit totals (closest_rays / _nodes / _tris / _launches / _ms, accumulated since the last
  * dr_reset_stats) that the wave-coherent kernel k_trace_pk traced -- the camera rays -- as out[0] rays, out[1] node visits, out[2]
  * triangle tests, out[3] launches, out[4] ms.  Waits for the renders in flight like dr_get_stats.  What is left after subtracting them
  * belongs to the per-lane closest-hit kernel (k_trace<0> / k_trace3<0> / k_trace3c): how bench.py prices the two separately. */
 int dr_scene_get_coherent_stats(DrScene* scene, double out[5]);
+/* Diagnostics: the device sampler's work since the last dr_reset_stats, in (pixel, LD block) pairs -- one pair = one shuffled run of
+ * spp indices.  out[0]: pairs generated; out[1]: pairs the integrator's reads name (every block a path of maximal length would read,
+ * for every pixel).  Equal unless generation is lazy (DARTRAY_LAZY_GEN, the default for path renders at >= 64 spp) and paths end
+ * early: bounce b's blocks are shuffled only for 64-pixel groups with a path alive at bounce b.  Both 0 for the host-buffer sampler
+ * and the full-float sample form.  Waits for the renders in flight like dr_get_stats. */
+int dr_scene_get_sampler_stats(DrScene* scene, double out[2]);
 /* The path-state layout of this scene's path-traced renders, next to the traversal kernels and measured the same way: the
  * first big render's first pilot batch counts how many of its slots are still alive at the second bounce (density_out;
  * -1 before); below one half the renders use four-slot, line-grouped sub-tiles (layout 4: stage lists that thin out touch
@@ -452,6 +459,8 @@ const char* dr_version(void);
  *   SCENE_PREP host, GEN_PREPASS 0   dr_scene_create's checks on the host; no burn-in pre-pass above 256 spp
  *   COHERENT_CAMERA 0     the camera rays through the per-lane traversal kernels like every other ray (default: the wave-coherent k_trace_pk)
  *   COHERENT_SHADOW 1     the camera vertices' shadow rays through k_trace_pk too (a measured negative, kept for A/B: default off)
+ *   LAZY_GEN 0            the device sampler shuffles every LD block for every pixel up front (default: bounce b's blocks only for the
+ *                         64-pixel groups that still have a path alive at bounce b)
  *   GEN_SLOW_DRAWS, GEN_ALL_BLOCKS, GEN_LANES n, GEN_ONE_WAVE, FLOAT_SAMPLES, LDS_LIGHTS 0   A/B variants of the sampler / shade kernels
  *   BUILD_THREADS n, BUILD_DEBUG   the BVH builders;  RCCL_LIB path   librccl to bind;  STAGE_COUNTS 1|2 (per stage: list lengths and kernel times; 2: also
  *                         the node visits / triangle tests of each stage's traversals, waiting for the device after every stage), VERBOSE   diagnostics */

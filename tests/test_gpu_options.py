@@ -153,6 +153,41 @@ def test_pilot_reports_what_it_measured_and_any_hit_follows_the_closest_hit_fami
     _run(code, DARTRAY_PILOT_FORCE="1")
 
 
+def test_lazy_sample_generation_leaves_the_film_alone():
+    """The device sampler shuffles bounce b's LD blocks only for the 64-pixel groups that still have a path alive at bounce b (the camera
+    rays' hits marked by k_trace_pk, then each stage's output list): a view that is mostly sky, a view with no sky at all, 64 / 256 / 512
+    samples per pixel (the three shuffle kernels), depth 1 (only bounce 0 and 1 exist) and depth 5 -- films equal DARTRAY_LAZY_GEN=0's and
+    the oracle's."""
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "import oracle.binding as ob\n"
+        "from dartray_amd import _abi, core, scenes\n"
+        "_abi.init(0)\n"
+        "lib = _abi.lib()\n"
+        "frac = []\n"
+        "def both(prims, r, env=None, oracle=True):\n"
+        "    scene = scenes.make_scene(prims, env); dev = scene._device(); films = []; dev.reset_stats()\n"
+        "    for on in (None, b'0'):\n"
+        "        _abi.check(lib.dr_set_option(b'LAZY_GEN', on)); films.append(r.render(scene).film)\n"
+        "        assert dev.last_render_info()['lazy_gen'] == (1 if on is None else 0), dev.last_render_info()\n"
+        "        ss = dev.sampler_stats(); assert 0 < ss['generated'] <= ss['named'] and (on is None or ss['generated'] == ss['named']), ss\n"
+        "        frac.append(ss['generated'] / ss['named']); dev.reset_stats()\n"
+        "    _abi.check(lib.dr_set_option(b'LAZY_GEN', None))\n"
+        "    assert np.array_equal(films[0], films[1])\n"
+        "    if oracle:\n"
+        "        osc = ob.OracleScene(prims, env=env) if env is not None else ob.OracleScene(prims)\n"
+        "        assert np.array_equal(films[0], osc.render(ob.render_desc(r, sampler_mode=1))['film'])\n"
+        "for spp, res, depth, oracle in ((64, (64, 48), 5, True), (256, (40, 32), 1, True), (512, (64, 40), 3, False)):\n"
+        "    prims5, mk5 = scenes.config('C5', xres=res[0], yres=res[1], spp=spp, yard=(4, 12), env_res=(64, 32)); r5 = mk5()\n"
+        "    r5.surfaceIntegrator.maxDepth = depth; both(prims5, r5, r5.env, oracle)\n"
+        "prims, mk = scenes.config('C2', xres=40, yres=32, spp=64, blob=(40, 20)); both(prims, mk())\n"
+        # the courtyard under the sky: whole groups of pixels see only sky (no bounce-0 blocks) and fewer still reach bounce 2
+        "assert frac[0] < 0.9 and frac[1] == 1.0, frac\n"
+        "print('OK', frac)\n" % (ROOT, os.path.join(ROOT, "tests")))
+    _run(code, timeout=900)
+
+
 def test_coherent_camera_kernel_equals_the_per_lane_kernels():
     """k_trace_pk walks a tile's 64 camera rays with ONE stack (node and triangles loaded once per wave, every lane testing its own
     ray; stack entries carry the mask of the lanes that pushed them).  Hits, films and the visit counters must equal what the per-lane
