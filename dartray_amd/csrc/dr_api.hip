@@ -2136,6 +2136,9 @@ int dr_get_stats(DrScene* sc, DrRenderStats* out) {
     sc->pkNodes = c.pk_nodes[0];
     sc->pkTris = c.pk_tris[0];
     sc->genDone = sc->genDoneHost + c.gen_pixel_blocks;
+#ifdef DR_EXP_PK_STATS
+    fprintf(stderr, "pk_stats: rays %llu lane-visits %llu packet iterations %llu all-miss %llu leaf %llu\n", c.pk_rays[0], c.pk_nodes[0], c.pk_rays[1], c.pk_nodes[1], c.pk_tris[1]);
+#endif
     sc->foldEvents();
     sc->statsPending = false;
     shade_prof_dump();

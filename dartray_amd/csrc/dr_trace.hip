@@ -1738,6 +1738,9 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
   const uint32_t n = nQueue ? *nQueue : st.nslots;
   const int lane = lane_id();
   uint32_t nRays = 0, nNodes = 0, nTris = 0;  // nRays / nNodes: wave-uniform, lane 0 reports them; nTris: per lane
+#ifdef DR_EXP_PK_STATS
+  uint32_t xIter = 0, xMiss = 0, xLeaf = 0;  // timing-free experiment: packet iterations, those in which no lane hit the box, leaf iterations
+#endif
   const uint32_t nTiles = (n + 63u) >> 6;
   for (;;) {
     uint32_t t0 = 0;
@@ -1798,6 +1801,9 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
             }
             const unsigned long long hitMask = __ballot(ok);
             bool descend = false;
+#ifdef DR_EXP_PK_STATS
+            if (lane == 0) { ++xIter; if (hitMask == 0ull) ++xMiss; else if ((b.w & 0xffffu) != 0u) ++xLeaf; }
+#endif
             if (hitMask != 0ull) {
               const uint32_t nprims = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b.w & 0xffffu));
               if (nprims > 0u) {  // a leaf: every lane of hitMask tests every triangle (bvh_accel.dart:126-138)
@@ -1861,6 +1867,13 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
       atomicAdd(&ctr->pk_nodes[ANY], nn);
       atomicAdd(&ctr->pk_tris[ANY], t);
     }
+#ifdef DR_EXP_PK_STATS
+    if (lane == 0 && ctr && !ANY) {
+      atomicAdd(&ctr->pk_rays[1], (unsigned long long)xIter);
+      atomicAdd(&ctr->pk_nodes[1], (unsigned long long)xMiss);
+      atomicAdd(&ctr->pk_tris[1], (unsigned long long)xLeaf);
+    }
+#endif
   }
   flush_counters(ctr, ANY, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
 }
