@@ -178,10 +178,18 @@ def test_lazy_sample_generation_leaves_the_film_alone():
         "    if oracle:\n"
         "        osc = ob.OracleScene(prims, env=env) if env is not None else ob.OracleScene(prims)\n"
         "        assert np.array_equal(films[0], osc.render(ob.render_desc(r, sampler_mode=1))['film'])\n"
+        "    return dev.last_render_info()\n"
         "for spp, res, depth, oracle in ((64, (64, 48), 5, True), (256, (40, 32), 1, True), (512, (64, 40), 3, False)):\n"
         "    prims5, mk5 = scenes.config('C5', xres=res[0], yres=res[1], spp=spp, yard=(4, 12), env_res=(64, 32)); r5 = mk5()\n"
         "    r5.surfaceIntegrator.maxDepth = depth; both(prims5, r5, r5.env, oracle)\n"
         "prims, mk = scenes.config('C2', xres=40, yres=32, spp=64, blob=(40, 20)); both(prims, mk())\n"
+        # several batches whose pixel counts are no multiples of 64 (the last group of a batch is partial), on one and on two pipelines
+        # (the second has its own workspace and its own marks)
+        "prims5, mk5 = scenes.config('C5', xres=70, yres=50, spp=64, yard=(4, 12), env_res=(64, 32)); r5 = mk5()\n"
+        "for pipes in (b'1', b'2'):\n"
+        "    _abi.check(lib.dr_set_option(b'BATCH_BITS', b'16')); _abi.check(lib.dr_set_option(b'PIPELINES', pipes))\n"
+        "    info = both(prims5, r5, r5.env, pipes == b'1'); assert info['batches'] > 2, info\n"
+        "_abi.check(lib.dr_set_option(b'BATCH_BITS', None)); _abi.check(lib.dr_set_option(b'PIPELINES', None))\n"
         # the courtyard under the sky: whole groups of pixels see only sky (no bounce-0 blocks) and fewer still reach bounce 2
         "assert frac[0] < 0.9 and frac[1] == 1.0, frac\n"
         "print('OK', frac)\n" % (ROOT, os.path.join(ROOT, "tests")))
