@@ -4,6 +4,8 @@ pixel's weightSum == spp up to the rare integral-imageX splats, exactly 0 on pix
 non-negative radiance, plausible traversal counters -- and (b) sparse parity: a handful of pixels spread over the
 image are rendered by the oracle with the same keyed sample streams and must equal the GPU's film entries bit for bit.
 Plus the renderer's NaN / negative / infinite radiance guards (sampler_renderer.dart:181-193)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -64,8 +66,9 @@ def test_full_size_c4_hairball_both_traversal_kernels(ob, gpu):
     out = r.render(scene)
     dev = scene._device()
     picked = dev.trace_kernels()
-    assert picked[0] in (2, 3, 5) and picked[1] in (2, 3)
-    assert r.last_stats["pilot_ms"] > 0
+    if not any(os.environ.get(k) for k in ("DARTRAY_PIPELINES", "DARTRAY_PILOT", "DARTRAY_TRACE_IMPL")):  # (two pipelines run no pilot)
+        assert picked[0] in (2, 3, 5) and picked[1] in (2, 3)
+        assert r.last_stats["pilot_ms"] > 0
     w = out.film[..., 3]
     assert abs(float(w.sum()) - 1024 * 1024 * 64) <= 512 and np.mean(w == 64) > 0.9999
     assert np.isfinite(out.rgb).all() and out.rgb.min() >= 0

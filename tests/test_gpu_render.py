@@ -573,6 +573,7 @@ def test_serial_stream_replay_across_several_batches(ob, gpu, pipelines):
     lib = _abi.lib()
     r.sampler = core.HostBufferSampler(r.camera, 16, rec["pixel_xy"][::16], rec["sample_vec"], rec["tail"])
     scene = scenes.make_scene(prims)
+    _abi.check(lib.dr_set_option(b"BATCH_BITS", b""))  # ("" hides the environment's value: the suite is also run with DARTRAY_BATCH_BITS=16)
     whole = r.render(scene)
     assert r.last_stats["batches"] == 1
     try:
