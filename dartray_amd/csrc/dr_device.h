@@ -517,8 +517,15 @@ DR_DEV void ConcentricSampleDisk(double u1, double u2, double* dx, double* dy) {
     }
   }
   theta *= DR_PI / 4.0;
+#ifdef DR_EXP_SINCOS  // timing experiment (bit-exact, a measured negative: MEASUREMENTS.md 5.6): one argument reduction for the pair
+  double sn_, cs_;
+  sincos(theta, &sn_, &cs_);
+  *dx = r * cs_;
+  *dy = r * sn_;
+#else
   *dx = r * cos(theta);
   *dy = r * sin(theta);
+#endif
 }
 DR_DEV F3 CosineSampleHemisphere(double u1, double u2) {  // montecarlo.dart:203-209
   double dx, dy;
