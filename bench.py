@@ -415,10 +415,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = drdist.local_device(int(os.environ.get("LOCAL_RANK", "0")))  # (= LOCAL_RANK; DARTRAY_COMM_REHEARSAL shares GPUs between ranks)
     torch.cuda.set_device(local)
     os.environ.setdefault("DARTRAY_COMM_FALLBACK", "1")  # N > 1: see dartray_amd/dist.py (_fallback_group); reported on the line
     rank, world, local = drdist.init_process_group()  # gloo control plane + dr_comm_init (RCCL) on every rank
+    local = drdist.local_device(local)
     lib = _abi.lib()
     _abi.init(local)  # before the scenes are built: BVHAccel then takes the device builder (dr_bvh_build_device)
 
@@ -649,7 +650,9 @@ class Run:
             out["scaling"] = {"c3": "strong", "strong-c2": "strong", "weak": "weak", "samples": "weak"}[self.mode]
             out["rccl_world"] = int(self.lib.dr_comm_world())
             out["collective"] = ("dr_film_reduce (C ABI: ncclReduce(sum, f32) over xGMI, librccl bound at run time)" if drdist.comm_error is None else
-                                 "FALLBACK torch.distributed RCCL group -- dr_comm_init failed: %s" % drdist.comm_error)
+                                 (drdist.comm_error if drdist.rehearsal() else "FALLBACK torch.distributed RCCL group -- dr_comm_init failed: %s" % drdist.comm_error))
+            if drdist.rehearsal():
+                out["rehearsal"] = "NOT a measurement: %d ranks on %d GPU(s)" % (world, torch.cuda.device_count())
             out["per_rank_step_ms"] = {"min": round(own_min / steps * 1e3, 3), "max": round(own_max / steps * 1e3, 3),
                                        "note": "each rank's own clock before the closing barrier (rank 0's includes waiting for the reduce)"}
             out["reduce_ms"] = round(reduce_ms, 3)

@@ -34,6 +34,22 @@ _comm_ready = False
 # so, with the error -- a measured scaling curve plus a bug report instead of no curve.  Never taken silently.
 _fallback_group = None
 comm_error = None
+# DARTRAY_COMM_REHEARSAL=1 (development only, never a measurement): the N ranks SHARE the visible GPUs (rank r on device r mod
+# count -- RCCL refuses two ranks on one device) and the film is summed through host memory by gloo.  It exists so that the
+# N-rank code of bench.py and of this module -- tile split, per-rank renders, the reduce's call sites, the JSON line -- can
+# run on a one-GPU box; the collective itself is NOT the product's and the line says so.
+_rehearsal = False
+
+
+def rehearsal():
+    return os.environ.get("DARTRAY_COMM_REHEARSAL") == "1"
+
+
+def local_device(local):
+    """The device index of local rank `local` (identity, except under DARTRAY_COMM_REHEARSAL)."""
+    if rehearsal():
+        return local % max(1, torch.cuda.device_count())
+    return local
 
 
 def init_process_group(device_comm=None):
@@ -50,7 +66,13 @@ def init_process_group(device_comm=None):
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if device_comm is None:
         device_comm = world > 1 and torch.cuda.is_available()
-    if device_comm and not _comm_ready:
+    if device_comm and not _comm_ready and world > 1 and rehearsal():
+        global _fallback_group, comm_error, _rehearsal
+        _abi.init(local_device(local))
+        comm_error = "REHEARSAL (DARTRAY_COMM_REHEARSAL=1): ranks share a GPU, the film is summed through host memory by gloo"
+        _fallback_group = dist.new_group(backend="gloo")
+        _rehearsal = True
+    elif device_comm and not _comm_ready:
         if world > 1 and os.environ.get("DARTRAY_COMM_FALLBACK") == "1":
             _comm_init_or_fallback(rank, world, local)
         else:
@@ -161,6 +183,12 @@ def reduce_film(film, dst=0, stream=None):
     """Sum the per-rank (X, Y, Z, weight) films onto rank `dst` (one collective per render).  Device films go
     through dr_film_reduce (RCCL) on `stream` (default: torch's current stream)."""
     if film.is_cuda:
+        if _fallback_group is not None and _rehearsal:  # (gloo reduces host tensors only)
+            host = film.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=_fallback_group)
+            if dist.get_rank() == dst:
+                film.copy_(host)
+            return film
         if _fallback_group is not None:
             dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM, group=_fallback_group)
             return film

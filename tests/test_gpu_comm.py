@@ -60,9 +60,9 @@ import numpy as np
 sys.path.insert(0, %(root)r)
 import torch
 from dartray_amd import _abi, scenes, dist as drdist
-local = int(os.environ["LOCAL_RANK"])
+local = drdist.local_device(int(os.environ["LOCAL_RANK"]))
 torch.cuda.set_device(local)
-rank, world, local = drdist.init_process_group()
+rank, world, _ = drdist.init_process_group()
 prims, mk = scenes.config("C2", xres=160, yres=128, spp=16, blob=(60, 30))
 r = drdist.shard(mk(), rank, world)
 scene = scenes.make_scene(prims)
@@ -76,28 +76,36 @@ torch.cuda.synchronize()
 assert t == float(world), t
 if rank == 0:
     np.save(sys.argv[1], film.cpu().numpy())
-out = r.render_sharded(scene, 0)   # the same through the one-call entry point of the C ABI
-assert (out is not None) == (rank == 0)
-if rank == 0:
-    assert np.array_equal(out.film, film.cpu().numpy())
+if not drdist.rehearsal():
+    out = r.render_sharded(scene, 0)   # the same through the one-call entry point of the C ABI
+    assert (out is not None) == (rank == 0)
+    if rank == 0:
+        assert np.array_equal(out.film, film.cpu().numpy())
 drdist.barrier()
 drdist.comm_destroy()
 torch.distributed.destroy_process_group()
 """
 
 
-def test_two_ranks_tile_shards_merged_by_dr_film_reduce(gpu):
+@pytest.mark.parametrize("rehearsal", [False, True])
+def test_two_ranks_tile_shards_merged_by_dr_film_reduce(gpu, rehearsal):
+    """rehearsal=True (any box): the two ranks SHARE a GPU and gloo sums the film through host memory (DARTRAY_COMM_REHEARSAL,
+    dartray_amd/dist.py) -- everything of the world-2 path but the RCCL calls runs on hardware: the tile split, each rank's device
+    render into a full-frame film, the reduce's call sites, the max over ranks."""
     import torch
-    if torch.cuda.device_count() < 2:
+    if not rehearsal and torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs (the driver's multi-GPU tier); the world-2 logic is covered on CPU by tests/test_dist_cpu.py")
     from dartray_amd import scenes
     with tempfile.TemporaryDirectory() as tmp:
         script = os.path.join(tmp, "worker.py")
         out = os.path.join(tmp, "film.npy")
         open(script, "w").write(_WORKER % {"root": ROOT})
+        env = dict(os.environ)
+        if rehearsal:
+            env["DARTRAY_COMM_REHEARSAL"] = "1"
         res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                              "--master-addr", "127.0.0.1", "--master-port", "29531", script, out],
-                             capture_output=True, text=True, timeout=900)
+                              "--master-addr", "127.0.0.1", "--master-port", "29532" if rehearsal else "29531", script, out],
+                             capture_output=True, text=True, timeout=900, env=env)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         merged = np.load(out)
     prims, mk = scenes.config("C2", xres=160, yres=128, spp=16, blob=(60, 30))
