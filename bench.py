@@ -377,7 +377,7 @@ def profiled_traffic(tag):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             d = json.load(open(path))
-            return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "source": "profiles/" + name,
+            return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "kernel": d.get("kernel"), "source": "profiles/" + name,
                     "note": "separate rocprofv3 --pmc passes (TCC_EA0_RDREQ 32/64/128 B + WRITE_SIZE), not this run"}
     return None
 
@@ -661,6 +661,11 @@ class Run:
         tp = profiled_traffic(self.cfg)
         if tp and world == 1 and args.pipelines == 1 and not os.environ.get("DARTRAY_BATCH_BITS"):
             out["traffic_profiled"] = tp
+            # roofline.traffic: the memory-side bytes per launch of the SAME kernel from the committed --pmc passes of this command (counters
+            # cannot be read inside a timed run: the guide's separate passes) -- null when the passes profiled another kernel than this run ran
+            if tp.get("kernel") and tp.get("hbm_bytes_per_launch") and out["roofline"].get("kernel", "").startswith(tp["kernel"].split("::")[-1] + " "):
+                out["roofline"]["traffic"] = float(tp["hbm_bytes_per_launch"])
+                out["roofline"]["traffic_source"] = "%s (%s)" % (tp["source"], tp["note"])
         return out
 
 
