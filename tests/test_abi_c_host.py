@@ -125,3 +125,81 @@ def test_dart_binding_offsets_equal_the_c_layout(tmp_path):
     header = open(HEADER).read()
     for sym in re.findall(r"lookupFunction<\w+, \w+>\('(dr_\w+)'\)", dart):
         assert re.search(r"\b%s\s*\(" % sym, header), sym
+
+
+def _dart_brackets(text):
+    """A lexer's view of a Dart file: comments and string literals (single / double / triple quoted, raw, with nested
+    ${...} interpolation) skipped, every bracket matched.  Returns the number of top-level declarations' closing braces."""
+    stack, i, n, closed_top = [], 0, len(text), 0
+    pairs = {")": "(", "]": "[", "}": "{"}
+
+    def skip_string(i, raw):
+        q = text[i]
+        triple = text[i:i + 3] == q * 3
+        i += 3 if triple else 1
+        while i < n:
+            c = text[i]
+            if not raw and c == "\\":
+                i += 2
+                continue
+            if not raw and c == "$" and i + 1 < n and text[i + 1] == "{":
+                depth, i = 1, i + 2
+                while i < n and depth:
+                    if text[i] in "'\"":
+                        i = skip_string(i, False)
+                        continue
+                    depth += {"{": 1, "}": -1}.get(text[i], 0)
+                    i += 1
+                continue
+            if triple and text[i:i + 3] == q * 3:
+                return i + 3
+            if not triple and c == q:
+                return i + 1
+            assert triple or c != "\n", "unterminated string literal near offset %d" % i
+            i += 1
+        raise AssertionError("unterminated string literal")
+
+    while i < n:
+        c = text[i]
+        if text[i:i + 2] == "//":
+            i = text.find("\n", i)
+            i = n if i < 0 else i
+        elif text[i:i + 2] == "/*":
+            depth, i = 1, i + 2
+            while depth:  # Dart block comments nest
+                a, b = text.find("/*", i), text.find("*/", i)
+                assert b >= 0, "unterminated block comment"
+                if 0 <= a < b:
+                    depth, i = depth + 1, a + 2
+                else:
+                    depth, i = depth - 1, b + 2
+        elif c in "'\"":
+            i = skip_string(i, i > 0 and text[i - 1] == "r" and (i < 2 or not (text[i - 2].isalnum() or text[i - 2] == "_")))
+        elif c in "([{":
+            stack.append((c, text.count("\n", 0, i) + 1))
+            i += 1
+        elif c in ")]}":
+            assert stack and stack[-1][0] == pairs[c], "line %d: '%s' closes %s" % (text.count("\n", 0, i) + 1, c, stack[-1] if stack else "nothing")
+            stack.pop()
+            closed_top += (c == "}" and not stack)
+            i += 1
+        else:
+            i += 1
+    assert not stack, "unclosed %s" % (stack[-1],)
+    return closed_top
+
+
+@pytest.mark.parametrize("name", ["hip_sampler_renderer.dart", "hip_render_manager.dart"])
+def test_dart_sources_are_lexically_well_formed(name):
+    """No Dart SDK in the image: the least a reader without one can check of integration/*.dart beyond offsets and symbol names --
+    strings and comments terminate, every bracket closes the bracket it should, statements end (no line of code ends in an operator
+    followed by a closing brace), and the file declares what INTEGRATION.md says it does."""
+    text = open(os.path.join(ROOT, "integration", name)).read()
+    assert _dart_brackets(text) >= 2
+    assert _dart_brackets("void f() { var s = 'a${g('}')}b'; /* x /* y */ } */ }") == 1
+    with pytest.raises(AssertionError):
+        _dart_brackets("void f() { g(1]; }")
+    if name == "hip_sampler_renderer.dart":
+        assert re.search(r"class\s+HipSamplerRenderer\s+extends\s+Renderer", text)
+    else:
+        assert "dr_render_sharded" in text or "HipSamplerRenderer" in text
