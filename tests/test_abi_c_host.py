@@ -203,3 +203,35 @@ def test_dart_sources_are_lexically_well_formed(name):
         assert re.search(r"class\s+HipSamplerRenderer\s+extends\s+Renderer", text)
     else:
         assert "dr_render_sharded" in text or "HipSamplerRenderer" in text
+
+
+_DART_SDK_NAMES = set("""String List Map Set Object Future Stream Uint8List Float32List Float64List Int32List Uint32List Int64List Uint64List
+Pointer Void Int32 Int64 Uint8 Uint32 Uint64 Float Double DynamicLibrary Struct NativeFunction NativeType Process ProcessResult File
+Directory Platform Duration Stopwatch Exception StateError ArgumentError Utf8 Allocator Completer Endian ByteData Isolate Random Int8
+Uint16 Int16 Char Opaque Abi FileMode IOSink Iterable Function Type Null DateTime RangeError UnsupportedError FormatException Float32
+Float64 addAll addr address asTypedList getUint32 little lookupFunction setAll setFloat32 setFloat64 setInt32 setInt64 setUint16
+setUint32 setUint64 setUint8 toNativeUtf8 addStream asFloat32List asUint8List createTemp delayed delete exists exitCode getInt32 isAfter
+lengthInBytes openWrite readAsString rename resolvedExecutable stderr systemTemp toFilePath writeAsBytes writeAsString""".split())
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib"), reason="the reference is only present in the build container")
+def test_dart_integration_uses_only_names_the_reference_declares():
+    """Without an SDK nothing can type-check integration/*.dart; this is the check a text search allows: every capitalised name
+    the two files use is a class / function of the reference, of the Dart SDK, or their own, and every `.member` they access is a
+    word of the reference's sources, an SDK member, or their own -- a misspelt field of Scene / BVHAccel / Camera would show here."""
+    import glob
+    ref = "\n".join(open(f, errors="ignore").read() for f in glob.glob("/root/reference/lib/**/*.dart", recursive=True))
+    ref_words = set(re.findall(r"\b[A-Za-z_]\w*\b", ref))
+    texts, own = {}, set()
+    for name in ("hip_sampler_renderer.dart", "hip_render_manager.dart"):
+        t = open(os.path.join(ROOT, "integration", name)).read()
+        t = re.sub(r"//[^\n]*", "", t)
+        t = re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+        t = re.sub(r"'(?:\\.|[^'\\\n])*'", "''", t)
+        texts[name] = t
+        own |= set(re.findall(r"\b(?:class|typedef)\s+(\w+)", t)) | set(re.findall(r"\b(?:final|var|int|double|bool|String)\s+(\w+)\s*[;=,)]", t))
+        own |= set(re.findall(r"\bthis\.(\w+)", t)) | set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*(?:async\s*)?(?:=>|\{)", t)) | {"HipSamplerRenderer", "HipRenderManager"}
+    for name, t in texts.items():
+        used = set(re.findall(r"\b([A-Z][a-z]\w*)\b", t)) | set(re.findall(r"\.([a-z]\w+)\b", t))
+        unknown = sorted(w for w in used if w not in ref_words and w not in _DART_SDK_NAMES and w not in own)
+        assert not unknown, (name, unknown)
