@@ -11,7 +11,7 @@ workload: N = 1 -- configs[1] (C2): Cornell box + 1M-triangle displaced blob, Pa
           the reference's task split, render_manager.dart:100-141), every rank accumulating a full-frame (X, Y, Z,
           weight) film and ONE RCCL reduce of the 268 MB film per step (dr_film_reduce of the C ABI: ncclReduce over
           xGMI) summing them on rank 0; total work is the same for every N ("scaling": "strong"), --steps / --warmup are
-          honoured as given.  Expected run time (one GPU renders C3 in 28.5 s per step, 602 Msamples/s): a step is
+          honoured as given.  Expected run time (one GPU renders C3 in 27.8 s per step, 617 Msamples/s: profiles/r05_c3_one_gpu.json): a step is
           ~28.5 s / N -- N = 8: 3.6 s, N = 4: 7.1 s, N = 2: 14.3 s -- so the driver's `--steps 20 --warmup 5` (+ the first
           render) is ~1.6 min at N = 8, ~3.1 min at N = 4 and ~6.2 min at N = 2, plus ~15 s of scene build per process.
           The same C2 scene per GPU as the N = 1 line is appended as "extra_configs"[0] ("scaling": "weak": the C2 view at
@@ -676,8 +676,10 @@ def one_gpu_reference(mode, cfg):
         finals = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.startswith("r") and n.endswith("_bench_final.json"))
         src = "profiles/" + finals[-1] if finals else None  # the newest committed single-GPU line
         key = "C2, 1024x1024, 256 spp on one GPU: the per-GPU workload of the weak modes, the total one of strong-c2"
-    else:
-        src, key = None, "C3 (4096x4096, 1024 spp) on one GPU: 602 Msamples/s, 28.5 s per step (MEASUREMENTS.md, round 2: `bench.py --config C3 --steps 1`)"
+    else:  # the newest committed whole-C3-on-one-GPU line (`bench.py --config C3 --steps 1 --warmup 0 --no-extra --no-cpu-baseline`)
+        c3 = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.startswith("r") and n.endswith("_c3_one_gpu.json"))
+        src = "profiles/" + c3[-1] if c3 else None
+        key = "C3 (4096x4096, 1024 spp, the whole image) on one GPU" + ("" if src else ": 602 Msamples/s, 28.5 s per step (MEASUREMENTS.md, round 2)")
     ref = {"workload": key, "source": src}
     if src and os.path.exists(os.path.join(ROOT, src)):
         try:

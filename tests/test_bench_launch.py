@@ -78,4 +78,5 @@ def test_the_n_rank_line_names_its_single_gpu_reference():
     finals = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_bench_final.json"))
     assert ref["source"] == "profiles/" + finals[-1] and ref["value"] > 100 and ref["unit"] == "Msamples/s"
     ref = bench.one_gpu_reference("c3", "C3")
-    assert "4096x4096" in ref["workload"] and ref["value"] == 602.0
+    c3 = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_c3_one_gpu.json"))
+    assert "4096x4096" in ref["workload"] and ref["source"] == "profiles/" + c3[-1] and 500 < ref["value"] < 1000  # (the committed whole-C3 line)
