@@ -1749,6 +1749,9 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
         if (trc != DR_OK && treeletErr == DR_OK) treeletErr = trc;
       } else if (!(coherent && L.trace_coherent(sc->d, st, queue, nQ, any, C + 1024 + 8 * DR_WORK_STRIDE * wc, sc->ctr.p, tgrid, ts))) {
         L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
+        // (lazy sample generation counts on k_trace_pk's marks: should the coherent kernel ever decline a launch that was to leave
+        // them, every group counts as alive -- all blocks are generated, nothing is skipped)
+        if (coherent && !any && st.markAlive) (void)hipMemsetAsync(st.markAlive, 1, nGroups, ts);
       } else {
         ++wc;  // (k_trace_pk took this queue: the camera rays, or the camera vertices' shadow rays towards one light)
         tookCoherent = true;
