@@ -585,12 +585,14 @@ class Run:
             if pa[2] > 0 and pa[3] > 0 and abs(pa[2] - pa[3]) < 0.02 * min(pa[2], pa[3]):
                 near.append("any_hit: kernels 2 and 3 within 2 %")
         agg = self.scene.aggregate
+        red = ("film summed through host memory by gloo (REHEARSAL on shared GPUs)" if drdist.rehearsal() else
+               "RCCL film reduce (world %d)" % self.lib.dr_comm_world())
         if world == 1:
             par = "1 GPU"
         elif self.mode == "samples":
-            par = "spp-sets x%d, RCCL film reduce (world %d)" % (world, self.lib.dr_comm_world())
+            par = "spp-sets x%d, %s" % (world, red)
         else:
-            par = "tiles32 x%d, RCCL film reduce (world %d)" % (world, self.lib.dr_comm_world())
+            par = "tiles32 x%d, %s" % (world, red)
         out = {
             "metric": "Msamples/sec (primary+path rays)",
             "value": round(value, 3),
