@@ -459,6 +459,7 @@ const char* dr_version(void);
  *   SCENE_PREP host, GEN_PREPASS 0   dr_scene_create's checks on the host; no burn-in pre-pass above 256 spp
  *   COHERENT_CAMERA 0     the camera rays through the per-lane traversal kernels like every other ray (default: the wave-coherent k_trace_pk)
  *   COHERENT_SHADOW 1     the camera vertices' shadow rays through k_trace_pk too (a measured negative, kept for A/B: default off)
+ *   SPLIT_WG a,b          a stage's closest-hit / any-hit launches with a / b workgroups per CU from the start (a measured negative)
  *   LAZY_GEN 0            the device sampler shuffles every LD block for every pixel up front (default: bounce b's blocks only for the
  *                         64-pixel groups that still have a path alive at bounce b)
  *   GEN_SLOW_DRAWS, GEN_ALL_BLOCKS, GEN_LANES n, GEN_ONE_WAVE, FLOAT_SAMPLES, LDS_LIGHTS 0   A/B variants of the sampler / shade kernels
