@@ -382,6 +382,144 @@ def profiled_traffic(tag):
     return None
 
 
+LINE_LIMIT = 8000  # bytes: the driver keeps a bounded window of stdout (round 5's 26 KB line was not parsed)
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "saturated", "traffic", "traffic_over_algorithmic", "frac_physical_of_copy",
+                 "frac_of_binding_ceiling", "binding", "avg_launch_ms", "launches", "alg_bytes_per_launch", "hbm_copy_GBps", "lane_utilisation", "stale_profile")
+
+
+def _short_kernel(name):
+    """`k_trace<0> (closest-hit BVH traversal)` -> `k_trace<0>`."""
+    return name.split(" (")[0] if isinstance(name, str) else name
+
+
+def _roofline_numbers(r):
+    """The numbers of one roofline object (glossary: profiles/README.md); prose stays in the sidecar."""
+    if not r:
+        return None
+    o = {k: r[k] for k in ROOFLINE_KEYS if k in r}
+    if "kernel" in o:
+        o["kernel"] = _short_kernel(o["kernel"])
+    c = r.get("ceilings")
+    if c:
+        o["binding"] = c.get("binding")
+        o["frac_of_binding_ceiling"] = c.get("frac_of_binding_ceiling")
+    for k in ("traffic", "traffic_over_algorithmic", "frac_physical_of_copy", "frac_of_binding_ceiling"):
+        o.setdefault(k, None)
+    return o
+
+
+def _workload_tag(workload):
+    return workload.split(":")[0].strip()
+
+
+def compact_line(d, detail_path=None):
+    """The ONE JSON line of a run, numbers only and under LINE_LIMIT bytes, from the full result `d` (which goes to the sidecar
+    file the line names).  Pure function of `d`: tests/test_bench_line.py builds it from canned results without a GPU."""
+    line = {k: d[k] for k in HEADLINE_KEYS if k in d}
+    c = d.get("config", {})
+    tk = c.get("trace_kernels", {})
+    lay = c.get("state_layout", "")
+    line["config"] = {"workload": c.get("workload"), "triangles": c.get("triangles"), "bvh_nodes": c.get("bvh_nodes"),
+                      "samples_per_step": c.get("samples_per_step"), "parallelism": c.get("parallelism"),
+                      "kernels": {k: tk.get(k) for k in ("closest", "any_hit", "camera_rays")},
+                      "kernels_forced": bool(str(tk.get("picked_by", "")).startswith("--trace-kernels")),
+                      "state_layout": 4 if str(lay).startswith("four-slot") else 64,
+                      "sampler": str(c.get("sampler_mode", "")).split(" ")[0] or None}
+    line["roofline"] = _roofline_numbers(d.get("roofline"))
+    others = {}
+    for key, tag in (("roofline_camera", "camera"), ("roofline_shade", "shade"), ("roofline_gen", "gen")):
+        r = _roofline_numbers(d.get(key))
+        if r:
+            others[tag] = {k: r.get(k) for k in ("kernel", "bound", "frac", "saturated", "frac_physical_of_copy", "binding", "frac_of_binding_ceiling") if r.get(k) is not None}
+    if others:
+        line["roofline_others"] = others
+    cb = d.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "host_cores")}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:120]
+    ct = d.get("cpu_baseline_threads")
+    if ct:
+        line["cpu_baseline_threads"] = {k: ct.get(k) for k in ("value", "unit", "cores", "kind")}
+    if d.get("kernel_ms_per_step"):
+        line["kernel_ms_per_step"] = {k: v for k, v in d["kernel_ms_per_step"].items() if not isinstance(v, str)}
+    if d.get("per_sample"):
+        line["per_sample"] = d["per_sample"]
+    for k in ("first_render_ms", "pilot_ms", "workspace_bytes", "replay_Msamples_s", "rccl_world", "reduce_ms", "film_bytes_reduced_per_step"):
+        if d.get(k) is not None:
+            line[k] = d[k]
+    if d.get("one_shot_ms"):
+        line["one_shot_ms"] = d["one_shot_ms"].get("total")
+    if d.get("replay"):
+        line["replay_bit_exact"] = d["replay"].get("bit_exact_vs_serial_oracle")
+    if d.get("n_gpus", 1) > 1:
+        col = str(d.get("collective", ""))
+        line["collective"] = ("gloo-rehearsal" if d.get("rehearsal") else "torch-rccl-fallback" if col.startswith("FALLBACK") else "ncclReduce")
+        line["rehearsal"] = bool(d.get("rehearsal"))
+        prs = d.get("per_rank_step_ms") or {}
+        line["per_rank_step_ms"] = {k: prs.get(k) for k in ("min", "max")}
+        ref = d.get("one_gpu_same_workload") or {}
+        line["one_gpu_same_workload"] = {"value": ref.get("value"), "source": ref.get("source")}
+        if d.get("trace_kernels_per_rank"):
+            line["trace_kernels_per_rank"] = d["trace_kernels_per_rank"]
+    ex = []
+    for e in d.get("extra_configs") or []:
+        r = e.get("roofline") or {}
+        ex.append({"workload": _workload_tag(e.get("config", {}).get("workload", "?")), "value": e.get("value"), "ms_per_step": e.get("ms_per_step"),
+                   "steps": e.get("steps"), "kernel": _short_kernel(r.get("kernel")), "roofline_frac": r.get("frac"),
+                   "frac_physical_of_copy": r.get("frac_physical_of_copy"),
+                   "frac_of_binding_ceiling": (r.get("ceilings") or {}).get("frac_of_binding_ceiling")})
+        if e.get("scaling"):
+            ex[-1]["scaling"] = e["scaling"]
+    if ex:
+        line["extra_configs"] = ex
+    line["detail"] = detail_path
+    line["glossary"] = "profiles/README.md"
+    # the size is enforced, not hoped for: drop the optional objects, largest first, until the line fits
+    for k in ("roofline_others", "per_sample", "cpu_baseline_threads", "extra_configs", "kernel_ms_per_step"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(k, None)
+    if len(json.dumps(line)) >= LINE_LIMIT:
+        raise AssertionError("bench line is %d bytes (limit %d)" % (len(json.dumps(line)), LINE_LIMIT))
+    return line
+
+
+def write_detail(d):
+    """The full result (every roofline object, ceilings, the occupancy model, the pilot table, replay, one-shot costs, all prose)
+    as a sidecar file; returns its path relative to the repo (None when no directory is writable)."""
+    tag = _workload_tag(d.get("config", {}).get("workload", "run")).split(" ")[0].lower()
+    name = "bench_detail_%s_n%d.json" % (tag, d.get("n_gpus", 1))
+    for base in (os.environ.get("DARTRAY_BENCH_DETAIL_DIR"), os.path.join(ROOT, "gpurun_out"), ROOT, "/tmp"):
+        if not base:
+            continue
+        try:
+            os.makedirs(base, exist_ok=True)
+            path = os.path.join(base, name)
+            with open(path, "w") as fh:
+                json.dump(d, fh, indent=1)
+            return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+        except OSError:
+            continue
+    return None
+
+
+def load_detail(path):
+    """A full result: a sidecar file (one JSON document) or a log whose last line is one (the round 1-5 lines under profiles/)."""
+    text = open(path).read().strip()
+    try:
+        return json.loads(text)
+    except ValueError:
+        return json.loads(text.splitlines()[-1])
+
+
+def emit(d):
+    """Sidecar first, then the line -- the LAST thing this process writes to stdout."""
+    path = write_detail(d)
+    sys.stdout.flush()
+    print(json.dumps(compact_line(d, path)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -403,8 +541,13 @@ def main():
     ap.add_argument("--cpu-pixels", type=int, default=96, help="cpu baseline: side of the strided pixel grid")
     ap.add_argument("--blob", default=None, help="diagnostics only (NOT a BASELINE config): C2 / C3 with a blob of SEGMENTS,ROWS (2 x SEGMENTS x ROWS triangles) "
                                                  "instead of 1000,500 -- e.g. 180,90 = 32 400 triangles, a tree that fits one XCD's L2; the line says so")
+    ap.add_argument("--from-detail", default=None, help="no run: print the line of a committed / sidecar detail file (CPU)")
     ap.add_argument("--trace-kernels", default=None, help="A/B runs: force the traversal kernels (closest,any), e.g. 2,3 (default: the scene's pilot)")
     args = ap.parse_args()
+
+    if args.from_detail:
+        print(json.dumps(compact_line(load_detail(args.from_detail), os.path.relpath(os.path.abspath(args.from_detail), ROOT))), flush=True)
+        return
 
     if check_world(args.gpus, int(os.environ.get("WORLD_SIZE", "0"))) == "launch":
         launch_ranks(args)
@@ -442,9 +585,7 @@ def main():
             for (c, eres, espp, emode, esteps, ewarm) in pl["extras"]:
                 r = Run(c, eres, espp, 0, 1, emode, args)
                 e = r.headline(esteps, ewarm)
-                extra.append({k: e[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
-                                                "roofline_shade", "roofline_gen", "roofline_camera", "trace_kernels_profiled", "kernel_ms_per_step", "per_sample",
-                                                "first_render_ms", "pilot_ms", "one_shot_ms", "traffic_profiled") if k in e})
+                extra.append(e)
                 del r
                 torch.cuda.empty_cache()
             out["extra_configs"] = extra
@@ -459,19 +600,17 @@ def main():
             rx = Run(c, eres, espp, rank, world, emode, args)
             e = rx.headline(esteps, ewarm)
             if rank == 0:
-                extra.append({k: e[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "scaling", "rccl_world", "collective",
-                                                "per_rank_step_ms", "reduce_ms", "film_bytes_reduced_per_step", "one_gpu_same_workload",
-                                                "roofline", "kernel_ms_per_step", "first_render_ms") if k in e})
+                extra.append(e)
             del rx
             torch.cuda.empty_cache()
         if rank == 0:
             out["extra_configs"] = extra
-    if rank == 0:
-        print(json.dumps(out))
     drdist.barrier()
     drdist.comm_destroy()
     if world > 1:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        emit(out)
 
 
 class Run:
@@ -602,6 +741,7 @@ class Run:
             "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 3),
             "higher_is_better": True,
+            "scaling": "weak",  # (N = 1, and the per-GPU-fixed modes; the N-rank C3 / strong-c2 lines overwrite it below)
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -750,9 +890,7 @@ def cpu_baseline(prims, renderer, grid, H, W, spp):
     dt = time.perf_counter() - t0
     n = len(px) * spp
     return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "%dx%d pixels on a stride-%d grid of the %dx%d image x %d spp = %d samples in %.1f s; "
-                      "C++ restatement of the Dart reference path (oracle/), single thread"
-                      % (grid, grid, H // grid, W, H, spp, n, dt),
+            "sample": "%dx%d px, stride %d, of %dx%d x %d spp = %d samples, %.1f s (oracle/, 1 thread)" % (grid, grid, H // grid, W, H, spp, n, dt),
             "host_cores": os.cpu_count()}
 
 
@@ -796,9 +934,7 @@ def cpu_baseline_threads(prims, renderer, H, W, spp, budget_samples=3.0e7):
     dt = time.perf_counter() - t0
     n = sum(len(p) for p in parts) * spp
     return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": len(parts), "kind": "port",
-            "sample": "%d GetSubWindow task rectangles of the %dx%d image (one OS thread each), every %d-th pixel per axis x %d spp = %d "
-                      "samples in %.1f s; C++ restatement of the Dart reference path (oracle/), shared read-only scene"
-                      % (len(parts), W, H, stride, spp, n, dt),
+            "sample": "%d GetSubWindow tasks of %dx%d (one thread each), stride %d x %d spp = %d samples, %.1f s (oracle/)" % (len(parts), W, H, stride, spp, n, dt),
             "host_cores": os.cpu_count()}
 
 
