@@ -663,7 +663,7 @@ class _DeviceScene:
         """What the last render_device call ran with (dr_scene_last_render_info)."""
         arr = (C.c_int32 * 8)()
         _abi.check(_abi.lib().dr_scene_last_render_info(self.handle, C.byref(arr)))
-        return {"state_layout": int(arr[0]), "closest_kernel": int(arr[1]), "any_hit_kernel": int(arr[2]), "treelet_rounds": int(arr[3]),
+        return {"state_layout": int(arr[0]), "closest_kernel": int(arr[1]), "any_hit_kernel": int(arr[2]),
                 "pilot_batches": int(arr[4]), "batches": int(arr[5]), "trace_wg_per_cu": int(arr[6]), "overlap_any": int(arr[7]) & 1,
                 "coherent_camera": (int(arr[7]) >> 1) & 1, "coherent_shadow": (int(arr[7]) >> 2) & 1, "lazy_gen": (int(arr[7]) >> 3) & 1}
 

@@ -79,11 +79,6 @@ struct Workspace {
   DevBuf<int2> pix;
   DevBuf<float> filterTable, aosSamples;
   int spillGrid = 0;
-  // treelet-parked traversal (DARTRAY_TRACE_IMPL=4): parked records, keys, sort buffers
-  DevBuf<uint4> tlRec[2];
-  DevBuf<uint32_t> tlKeys[2], tlKeysSorted, tlIota, tlOrder, tlCounts;
-  DevBuf<unsigned char> tlSortTmp;
-  TLWork tl = {};
 };
 
 #define DR_STATE_WORDS F_SAMPLES  // 41 4-byte words of fixed path state per slot: 3 f64 + 10 3-vectors + 5 i32
@@ -102,8 +97,7 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_COHERENT_SHADOW", "DARTRAY_LAZY_GEN", "DARTRAY_SPLIT_WG", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP",
-    "DARTRAY_TREELET_ROUNDS", "DARTRAY_TREELET_MIN", "DARTRAY_TREELET_SHARDS", "DARTRAY_LAYOUT_PILOT"};
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_COHERENT_SHADOW", "DARTRAY_LAZY_GEN", "DARTRAY_SPLIT_WG", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
 DrOpt dr_opt(const char* name) {
@@ -145,7 +139,7 @@ struct DrScene {
   float calibMs[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // pilot of dr_render_device: [closest / any][v2 / v3 / v3c] ms
   float calibPerGB[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  //   the same as ms per algorithmic GB (what the choice compares; 0 = not measured)
   // what the last dr_render_device call actually ran with (dr_scene_last_render_info): state layout, the traversal kernels of
-  // its last batch, treelet parking rounds (-1: not the treelet-parked traversal), calibration batches, workgroups per CU
+  // its last batch, a reserved word (-1), calibration batches, workgroups per CU
   int32_t lastInfo[8] = {0, 0, 0, -1, 0, 0, 0, 0};
   std::vector<int32_t> lightNSamples;
   bool hasSpecular = false;  // some material is a mirror / glass
@@ -447,7 +441,6 @@ struct LayoutOps {
   decltype(&launch_trace) trace;
   decltype(&launch_trace_coherent) trace_coherent;
   decltype(&trace_kernel_id) trace_kernel_id;
-  decltype(&launch_trace_treelets) trace_treelets;
   decltype(&launch_gen_samples) gen_samples;
   decltype(&launch_mark_alive) mark_alive;
   decltype(&launch_sum_alive) sum_alive;
@@ -461,9 +454,9 @@ struct LayoutOps {
   int stateWords;  // 4-byte words of fixed path state per slot in this layout (a tile is 64 of them + the sample region):
                    // what the kernels' own translation unit was compiled with (layout_state_words), not a constant repeated here
 };
-static const LayoutOps kLayout64 = {&launch_trace, &launch_trace_coherent, &trace_kernel_id, &launch_trace_treelets, &launch_gen_samples, &launch_mark_alive, &launch_sum_alive, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
+static const LayoutOps kLayout64 = {&launch_trace, &launch_trace_coherent, &trace_kernel_id, &launch_gen_samples, &launch_mark_alive, &launch_sum_alive, &launch_transpose_samples, &launch_raygen, &launch_shade_path,
                                     &launch_env, &launch_shade_direct, &launch_shade_spec, &launch_film, layout_state_words()};
-static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_trace_coherent, &sp4::trace_kernel_id, &sp4::launch_trace_treelets, &sp4::launch_gen_samples, &sp4::launch_mark_alive, &sp4::launch_sum_alive, &sp4::launch_transpose_samples, &sp4::launch_raygen,
+static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_trace_coherent, &sp4::trace_kernel_id, &sp4::launch_gen_samples, &sp4::launch_mark_alive, &sp4::launch_sum_alive, &sp4::launch_transpose_samples, &sp4::launch_raygen,
                                      &sp4::launch_shade_path, &sp4::launch_env, &sp4::launch_shade_direct, &sp4::launch_shade_spec,
                                      &sp4::launch_film, sp4::layout_state_words()};
 
@@ -1529,39 +1522,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const int tgrid = tgridFull;
   rc = ensureSpill(sc, sc->ws, tgrid);
   if (rc) return rc;
-  // DARTRAY_TRACE_IMPL=4: the treelet-parked traversal (a prototype, MEASUREMENTS.md round 4) for the stage queues of a scene
-  // whose pair records were laid out with DARTRAY_PAIR_ORDER=top:T
-  const bool treelets = dr_opt("DARTRAY_TRACE_IMPL").first() == '4' && sc->d.pairs && sc->d.topPairs > 0 && !sc->d.nquads && !dlSpec && nPipesEnv < 2;
-  if (treelets) {
-    Workspace& w = sc->ws;
-    const uint32_t outCap = w.cap + (uint32_t)tgrid * (DR_TRACE_BLOCK / 64) * 256u + 1024u;
-    if (w.tl.outCap < outCap) {
-      for (int k = 0; k < 2; ++k) {
-        HIP_TRY(w.tlRec[k].alloc((size_t)outCap * DR_TL_REC_U4));
-        HIP_TRY(w.tlKeys[k].alloc(outCap));
-        w.tl.rec[k] = w.tlRec[k].p;
-        w.tl.keys[k] = w.tlKeys[k].p;
-      }
-      HIP_TRY(w.tlKeysSorted.alloc(outCap));
-      HIP_TRY(w.tlIota.alloc(outCap));
-      HIP_TRY(w.tlOrder.alloc(outCap));
-      HIP_TRY(w.tlCounts.alloc(64));
-      w.tl.sortTmpBytes = (sp4::treelet_sort_bytes(outCap) + 255) & ~(size_t)255;
-      HIP_TRY(w.tlSortTmp.alloc(w.tl.sortTmpBytes));
-      w.tl.keysSorted = w.tlKeysSorted.p;
-      w.tl.iota = w.tlIota.p;
-      w.tl.order = w.tlOrder.p;
-      w.tl.counts = w.tlCounts.p;
-      w.tl.sortTmp = w.tlSortTmp.p;
-      w.tl.outCap = outCap;
-      w.tl.iotaReady = 0;
-    }
-    w.tl.topPairs = sc->d.topPairs;
-    w.tl.rounds = std::max(0, std::min(3, dr_opt("DARTRAY_TREELET_ROUNDS").toInt(1)));
-    w.tl.shards = std::max(1, std::min(8, dr_opt("DARTRAY_TREELET_SHARDS").toInt(8)));
-    w.tl.minPark = (uint32_t)dr_opt("DARTRAY_TREELET_MIN").toInt(1 << 18);
-    w.tl.verbose = dr_opt("DARTRAY_VERBOSE").toInt(0);
-  }
   // the camera rays (a tile = 64 samples of one pixel) through the wave-coherent kernel k_trace_pk (DARTRAY_COHERENT_CAMERA=0: k_trace & co.)
   const bool coherentCamera = !dr_opt("DARTRAY_COHERENT_CAMERA").isZero() && !dlSpec;
   // DARTRAY_COHERENT_SHADOW=1 (A/B; a measured negative, MEASUREMENTS.md 5.9): the shadow rays that leave the CAMERA vertices (a path
@@ -1572,7 +1532,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   const bool overlapEnv = !(dr_opt("DARTRAY_OVERLAP_ANY").isZero());  // default: on
   // lazy sample generation (DARTRAY_LAZY_GEN=0: every block for every pixel up front): needs the device sampler's compact form, the keyed
   // per-(pixel, block) streams (a block that is left out disturbs no other) and k_trace_pk's marks of the camera rays that hit
-  const bool lazyGen = !hostBuf && sf.compact && rp.genMask != 0ull && rd->integrator == DR_INTEGRATOR_PATH && coherentCamera && !treelets &&
+  const bool lazyGen = !hostBuf && sf.compact && rp.genMask != 0ull && rd->integrator == DR_INTEGRATOR_PATH && coherentCamera &&
                        !sc->d.nquads && spp >= 64 && !dr_opt("DARTRAY_LAZY_GEN").isZero();
   const bool overlapAny = overlapEnv && !dlSpec && !(nPipesEnv >= 2);
   if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
@@ -1740,17 +1700,13 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     timed(3, evGen);
     uint32_t* C = w.counters.p;
     int wc = 0;  // work counters live at C[1024..], 8 per launch
-    int treeletErr = DR_OK;
     auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr, bool coherent = false,
                      int gridOverride = 0) {
       const int tgrid = gridOverride > 0 ? std::min(gridOverride, tgridFull) : tgridFull;  // (shadows the render's grid for this launch)
       hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
       (void)hipEventRecord(e0, ts);
       bool tookCoherent = false;
-      if (treelets) {
-        const int trc = L.trace_treelets(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts, w.tl);
-        if (trc != DR_OK && treeletErr == DR_OK) treeletErr = trc;
-      } else if (!(coherent && L.trace_coherent(sc->d, st, queue, nQ, any, C + 1024 + 8 * DR_WORK_STRIDE * wc, sc->ctr.p, tgrid, ts))) {
+      if (!(coherent && L.trace_coherent(sc->d, st, queue, nQ, any, C + 1024 + 8 * DR_WORK_STRIDE * wc, sc->ctr.p, tgrid, ts))) {
         L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
         // (lazy sample generation counts on k_trace_pk's marks: should the coherent kernel ever decline a launch that was to leave
         // them, every group counts as alive -- all blocks are generated, nothing is skipped)
@@ -1767,7 +1723,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // A stage's two traversals are independent (closest hit of the continuation / MIS rays, occlusion of the shadow
     // rays).  Side by side on two streams the any-hit workgroups take the CU slots the closest-hit launch frees as its
     // queue runs dry (a persistent launch ends with its longest rays).  Calibration batches time each launch alone.
-    const bool sideBySide = overlapAny && !pilot && !treelets;
+    const bool sideBySide = overlapAny && !pilot;
     // DARTRAY_SPLIT_WG=a,b (experiment): side by side, the closest-hit launch takes a and the any-hit launch b workgroups per CU from the
     // start, instead of the any-hit workgroups waiting for the slots a full closest-hit grid frees at its end
     int splitClosest = 0, splitAny = 0;
@@ -1969,7 +1925,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       }
     }
     HIP_TRY(hipGetLastError());
-    if (treeletErr != DR_OK) return fail(treeletErr, "treelet-parked traversal: a device call failed (sort / counter read-back)");
     if (hostBuf) HIP_TRY(hipStreamSynchronize(s));  // host buffers of the next batch reuse the staging area
     return DR_OK;
   };
@@ -2099,23 +2054,16 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     HIP_TRY(hipStreamWaitEvent(callerStream, ev, 0));
   }
   HIP_TRY(hipEventRecord(evStop, s));
-  if (treelets && sc->ws.tl.verbose) {
-    TLWork& t = sc->ws.tl;
-    for (int k = 0; k < 2; ++k)
-      fprintf(stderr, "dartray_hip: treelet-parked traversal (top %u pairs, %d parking round%s), %s rays: launches %.2f ms, sorts %.2f ms, %.2f M records parked\n",
-              t.topPairs, t.rounds, t.rounds == 1 ? "" : "s", k ? "any-hit" : "closest-hit", t.ms[k][0], t.ms[k][1], t.ms[k][3]);
-    memset(t.ms, 0, sizeof(t.ms));
-  }
   sc->stats.camera_samples += (uint64_t)npixTotal * spp;
   sc->stats.film_samples += filmSamples;
   sc->lastInfo[0] = Lp == &kLayoutSp4 ? 4 : 64;
-  sc->lastInfo[1] = treelets ? 4 : L.trace_kernel_id(sc->d, 0);
-  sc->lastInfo[2] = treelets ? 4 : L.trace_kernel_id(sc->d, 1);
-  sc->lastInfo[3] = treelets ? sc->ws.tl.rounds : -1;
+  sc->lastInfo[1] = L.trace_kernel_id(sc->d, 0);
+  sc->lastInfo[2] = L.trace_kernel_id(sc->d, 1);
+  sc->lastInfo[3] = -1;  // (reserved: rounds 4-5 reported the treelet-parked traversal's parking rounds here)
   sc->lastInfo[4] = pilotBatchesRun;
   sc->lastInfo[5] = (int32_t)std::min<uint64_t>(0x7fffffff, nBatches);
   sc->lastInfo[6] = tgrid / std::max(1, g_numCU);
-  sc->lastInfo[7] = (overlapAny ? 1 : 0) | (coherentCamera && !treelets && !sc->d.nquads ? 2 : 0) | (coherentShadow && !treelets ? 4 : 0) | (lazyGen ? 8 : 0);
+  sc->lastInfo[7] = (overlapAny ? 1 : 0) | (coherentCamera && !sc->d.nquads ? 2 : 0) | (coherentShadow ? 4 : 0) | (lazyGen ? 8 : 0);
   return DR_OK;
 #undef L
 }

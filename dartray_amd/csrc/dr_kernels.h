@@ -274,42 +274,6 @@ int traceGridFor(int wgPerCU);  // dr_api.hip: workgroups of a persistent traver
 #define DR_MAX_STACK 128      // LDS + spill entries per lane (the reference uses 64, bvh_accel.dart:120)
 #define DR_TRACE_BLOCK 256
 
-// Treelet-parked traversal (k_trace_tl; MEASUREMENTS.md, round 4).  A ray that is about to ENTER a bottom sub-tree -- to
-// expand an interior node outside the top treelet (pair index >= DScene.topPairs) while it is not inside a bottom
-// sub-tree already -- is written out as a parked record keyed by that sub-tree's root; the records of a round are sorted
-// by key (= memory order of the sub-trees) and the next round's launch resumes them in that order, so that the rays a
-// wave, a CU and an XCD work on at the same time walk the same few sub-trees.  A ray keeps its own stack and its own
-// near / far order: the sequence of nodes it visits, its hits and its counters are the untouched reference's
-// (bvh_accel.dart:101-226); parking only changes WHEN the next node of that sequence is visited, and by which lane.
-struct TLArgs {
-  const uint32_t* order;  // round > 0: indices into `in`, sorted by key; null: fresh rays from the stage's queue
-  const uint32_t* nIn;    // round > 0: number of records to resume (device word)
-  const uint4* in;        // parked records of the previous round, DR_TL_REC_U4 uint4 each
-  uint4* out;             // this round's parked records; null: never park (the last round finishes every ray)
-  uint32_t* outKeys;      //   their sort keys, preset to 0xffffffff (positions a wave reserved and did not use keep that)
-  uint32_t* outCount;     //   [0] positions reserved, [1] of them not used
-  uint32_t outCap;
-  uint32_t topPairs;
-  uint32_t shards;        // round > 0: the sorted list is worked off in this many contiguous shards, one per XCD (1: one shared counter)
-};
-#define DR_TL_REC_U4 16   // a parked record: 64 B of ray state + up to 24 stack entries of 8 B = 256 B (the second line only when needed)
-#define DR_TL_MAX_SP 24   // a ray with a deeper stack is not parked (it walks on: parking is never needed for correctness)
-// Device buffers of the treelet-parked traversal (allocated by dr_api.hip when DARTRAY_TRACE_IMPL=4)
-struct TLWork {
-  uint4* rec[2];
-  uint32_t* keys[2];
-  uint32_t *keysSorted, *iota, *order, *counts;  // counts: [2 * round] reserved / unused, [32 + round] records to resume
-  void* sortTmp;
-  size_t sortTmpBytes;
-  uint32_t outCap, topPairs;
-  int rounds;        // parking rounds (DARTRAY_TREELET_ROUNDS, default 1): launches 0 .. rounds - 1 park, the last one does not
-  uint32_t minPark;  // fewer records than this: the next launch finishes them without parking
-  int verbose;
-  int iotaReady;
-  int shards;        // DARTRAY_TREELET_SHARDS (default 8)
-  float ms[2][4];    // accumulated per ray kind: traversal launches, sorts, (unused), records parked (count / 1e6)
-};
-
 // ---- launchers (dr_kernels.hip, dr_trace.hip): one set per state layout ----
 #include "dr_launchers.inc"
 namespace sp4 {

@@ -938,18 +938,13 @@ DR_DEV uint32_t pack_ref(uint32_t ref, uint32_t meta) {
 }
 
 #define M_EXPAND 1  // `cur` is an interior node whose box is hit (or must be re-tested): fetch its pair
-#ifndef DR_PARK_TH
-#define DR_PARK_TH 16  // treelet-parked traversal: lanes that park together
-#endif
 
 // COLD (k_trace3c): direction, minDistance, maxDistance and the queue handle wait in 8 LDS rows per lane (`cold`) between the refill,
 // the leaf tests, the rare literal slab tests and the result store, as in k_trace / k_trace3a: they are re-read in front of every use
 // (reloadCold), so the loop that sets the occupancy does not hold them in registers.
-template <int ANY, class IO, bool TL = false, bool COLD = false, int PSTACK = DR_PSTACK>
+template <int ANY, class IO, bool COLD = false, int PSTACK = DR_PSTACK>
 DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ldsRef, float* ldsE, uint32_t* spill,
-                        uint32_t spillStride, uint32_t spillHalf, uint32_t* work, TraceCounters* ctr, const TLArgs& tl = TLArgs(),
-                        uint32_t* cold = nullptr) {
-  static_assert(!(TL && COLD), "the treelet build keeps the ray in registers");
+                        uint32_t spillStride, uint32_t spillHalf, uint32_t* work, TraceCounters* ctr, uint32_t* cold = nullptr) {
   typedef __attribute__((address_space(3))) uint32_t cold_u32;
 #define COLD_TMAX() __hiloint2double((int)COLD_LD(7), (int)COLD_LD(6))
   // (the lane number is recomputed where it is needed -- lane_id(): one mbcnt pair -- instead of living in a register)
@@ -974,16 +969,6 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       ray.tmax = COLD_TMAX();
     }
   };
-  // treelet-parked mode (TL): inBottom = the ray is inside a bottom sub-tree, entered when its stack held spEnter entries
-  // (depth first: it has left the sub-tree exactly when the stack is lower than that again)
-  bool inBottom = false;
-  int spEnter = 0;
-  uint32_t outNext = 0, outEnd = 0;  // wave-uniform: this wave's reservation of parked-record positions
-  uint32_t tlShard = TL ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (tl.shards ? tl.shards : 1u) : 0u, tlTried = 0;  // XCC_ID
-  if constexpr (TL) {
-    if (tl.order) n = *tl.nIn;
-  }
-
   auto stackGet = [&](int i, uint32_t* ref, float* e) {
     *ref = ldsRef[(i < PSTACK ? i : PSTACK - 1) * DR_TRACE_BLOCK];
     *e = ldsE[(i < PSTACK ? i : PSTACK - 1) * DR_TRACE_BLOCK];
@@ -1031,7 +1016,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
   // the stack survives its pop (up to the ambiguous band), so pops never turn into long chains.
   auto pruneStack = [&]() {
     const float R = 4.76837158203125e-07f, A = 1.0e-37f;
-    int j = 0, below = 0;
+    int j = 0;
     for (int i = 0; i < sp; ++i) {
       uint32_t r;
       float e;
@@ -1039,14 +1024,12 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       const float eb = __fmaf_rn(fabsf(e), R, A);
       if (e - eb >= ray.tmaxHi) {
         ++nNodes;
-        if (TL && i < spEnter) ++below;  // an entry from before the current bottom sub-tree was entered
         continue;
       }
       if (j != i) stackSet(j, r, e);
       ++j;
     }
     sp = j;
-    if constexpr (TL) spEnter -= below;
   };
   // Pop until an entry survives (bvh_accel.dart:139-143,156-159); every popped entry is one node visit.
   // Returns false when the stack is empty (the ray is finished).
@@ -1077,29 +1060,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     const unsigned long long idleMask = __ballot(MODE_IS(M_IDLE));
     const int nIdle = __popcll(idleMask);
     if (!exhausted && (nIdle >= DR_REFILL_TH || nIdle == 64)) {
-      if (TL && tl.order && tl.shards > 1u) {
-        // resumed records are sorted by sub-tree: the list is cut into one contiguous shard per XCD (each XCD has its own
-        // 4 MiB L2), a wave drains its own XCD's shard and then helps with the others -- the sub-trees an XCD's waves
-        // walk at one time are then a window of ONE region of the tree instead of one window per XCD of the same region
-        while (resNext == resEnd && !exhausted) {
-          if (tlTried == tl.shards) {
-            exhausted = true;
-            break;
-          }
-          const uint32_t s0 = (uint32_t)(((unsigned long long)n * tlShard) / tl.shards);
-          const uint32_t s1 = (uint32_t)(((unsigned long long)n * (tlShard + 1u)) / tl.shards);
-          uint32_t fresh = 0;
-          if (lane_id() == 0) fresh = atomicAdd(work + tlShard * 16u, (uint32_t)DR_WORK_CHUNK);
-          fresh = wave_bcast_first(fresh);
-          if (fresh < s1 - s0) {
-            resNext = s0 + fresh;
-            resEnd = min(s0 + fresh + (uint32_t)DR_WORK_CHUNK, s1);
-          } else {
-            tlShard = (tlShard + 1u) % tl.shards;
-            ++tlTried;
-          }
-        }
-      } else if (resNext == resEnd) {
+      if (resNext == resEnd) {
         uint32_t fresh = 0;
         if (lane_id() == 0) {
           fresh = nRays == 0u ? __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // (see trace_persistent)
@@ -1116,40 +1077,10 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       const uint32_t take = min(resEnd - resNext, (uint32_t)nIdle);
       if (MODE_IS(M_IDLE)) {
         const uint32_t j = rankIn(idleMask);
-        if (TL && tl.order && j < take) {
-          // resume a parked ray: its record carries the ray, the node it was about to expand and its stack
-          const uint4* rec = tl.in + (size_t)tl.order[resNext + j] * DR_TL_REC_U4;
-          const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-          ray_init(ray, F3{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)},
-                   F3{__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)}, __hiloint2double((int)q1.w, (int)q1.z),
-                   __hiloint2double((int)q2.y, (int)q2.x));
-          hit = (int)q2.z;
-          handle = q2.w;
-          cur = q3.x;
-          sp = (int)(q3.y & 0xffffu);
-          const bool retestRec = ((q3.y >> 16) & 1u) != 0;
-          {  // the rest of the record's first line in one go (8 entries: most stacks), the second line only when needed
-            const uint4 v0 = rec[4], v1 = rec[5], v2 = rec[6], v3 = rec[7];
-            const uint4 vv[4] = {v0, v1, v2, v3};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              if (2 * k < sp) stackSet(2 * k, vv[k].x, __uint_as_float(vv[k].y));
-              if (2 * k + 1 < sp) stackSet(2 * k + 1, vv[k].z, __uint_as_float(vv[k].w));
-            }
-          }
-          for (int i = 8; i < sp; i += 2) {
-            const uint4 v = rec[4 + (i >> 1)];
-            stackSet(i, v.x, __uint_as_float(v.y));
-            if (i + 1 < sp) stackSet(i + 1, v.z, __uint_as_float(v.w));
-          }
-          mode = M_EXPAND | (retestRec ? M_RETEST : 0);
-          inBottom = true;
-          spEnter = sp;
-        } else if (j < take) {
+        if (j < take) {
           io.load(resNext + j, ray, handle);
           sp = 0;
           hit = -1;
-          inBottom = false;
           // visit node 0 (its box and packed reference live in kernel arguments)
           bool ok = false;
           if (sc.rootRef != PREF_DEAD) {
@@ -1176,64 +1107,8 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
           }
         }
       }
-      if (!(TL && tl.order)) nRays += take;  // wave-uniform: lane 0 reports it (a resumed record is no new ray)
+      nRays += take;  // wave-uniform: lane 0 reports it
       resNext += take;
-    }
-    bool hold = false;  // (TL) this lane waits for a batch of lanes to park with
-    if constexpr (TL) {
-      // ---- entering a bottom sub-tree: park the ray for the next round, or mark where it entered ----
-      if (inBottom && sp < spEnter) inBottom = false;
-      const bool enter = MODE_IS(M_EXPAND) && !inBottom && (cur & 0x1fffffffu) >= tl.topPairs;
-      bool park = enter && tl.out != nullptr && sp <= DR_TL_MAX_SP;
-      // writing a record is ~100 instructions and a dozen stores: like the leaf tests it is done for a batch of lanes --
-      // a lane that wants to park holds until DR_PARK_TH do or nobody else in the wave has anything to do
-      unsigned long long parkMask = __ballot(park);
-      if (parkMask != 0ull && __popcll(parkMask) < DR_PARK_TH &&
-          __ballot((MODE_IS(M_EXPAND) && !park) || MODE_IS(M_LEAF) || MODE_IS(M_DONE)) != 0ull) {
-        hold = park;
-        parkMask = 0ull;
-      }
-      if (parkMask != 0ull) {
-        const uint32_t np = (uint32_t)__popcll(parkMask), rem = outEnd - outNext;
-        uint32_t fresh = 0;
-        if (rem < np) {  // the rest of this wave's reservation first, then a new one (positions are never left unused here)
-          if (lane_id() == 0) fresh = atomicAdd(&tl.outCount[0], (uint32_t)DR_WORK_CHUNK);
-          fresh = wave_bcast_first(fresh);
-        }
-        if (park) {
-          const uint32_t rank = rankIn(parkMask);
-          const uint32_t pos = rank < rem ? outNext + rank : fresh + (rank - rem);
-          if (pos < tl.outCap) {
-            uint4* rec = tl.out + (size_t)pos * DR_TL_REC_U4;
-            rec[0] = uint4{__float_as_uint(ray.o.x), __float_as_uint(ray.o.y), __float_as_uint(ray.o.z), __float_as_uint(ray.d.x)};
-            rec[1] = uint4{__float_as_uint(ray.d.y), __float_as_uint(ray.d.z), (uint32_t)__double2loint(ray.tmin), (uint32_t)__double2hiint(ray.tmin)};
-            rec[2] = uint4{(uint32_t)__double2loint(ray.tmax), (uint32_t)__double2hiint(ray.tmax), (uint32_t)hit, handle};
-            rec[3] = uint4{cur, (uint32_t)sp | ((mode & M_RETEST) ? 0x10000u : 0u), 0u, 0u};
-            for (int i = 0; i < sp; i += 2) {
-              uint32_t ra, rb = 0u;
-              float ea, eb = 0.f;
-              stackGet(i, &ra, &ea);
-              if (i + 1 < sp) stackGet(i + 1, &rb, &eb);
-              rec[4 + (i >> 1)] = uint4{ra, __float_as_uint(ea), rb, __float_as_uint(eb)};
-            }
-            tl.outKeys[pos] = cur & 0x1fffffffu;
-            mode = M_IDLE;
-          } else {  // the record buffer is full: the position stays unused and the ray walks on
-            atomicAdd(&tl.outCount[1], 1u);
-            park = false;
-          }
-        }
-        if (rem < np) {
-          outNext = fresh + (np - rem);
-          outEnd = fresh + (uint32_t)DR_WORK_CHUNK;
-        } else {
-          outNext += np;
-        }
-      }
-      if (enter && !park) {
-        inBottom = true;
-        spEnter = sp;
-      }
     }
     const unsigned long long expMask = __ballot(MODE_IS(M_EXPAND));
     unsigned long long leafMask = __ballot(MODE_IS(M_LEAF));
@@ -1247,7 +1122,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     // reference's axis bits before the fetch, so the two halves are LOADED as near / far instead of being selected
     // component by component afterwards -- 16 v_cndmask and their registers less per step)
     uint4 n0 = uint4{0, 0, 0, 0}, n1 = n0, f0 = n0, f1 = n0;
-    if (MODE_IS(M_EXPAND) && !hold) {
+    if (MODE_IS(M_EXPAND)) {
       const uint32_t axis = (cur >> 29) & 3u;
       const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
       const uint32_t nearHalf = iv < 0.f ? 2u : 0u;
@@ -1263,7 +1138,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       SPROF_RAY(ANY);
       mode = M_IDLE;
     }
-    if (MODE_IS(M_EXPAND) && !hold) {
+    if (MODE_IS(M_EXPAND)) {
       bool alive = true;
       if (mode & M_RETEST) {
         // own box = union of the children's (bvh_accel.dart:521): the literal test the reference does at this pop
@@ -1328,7 +1203,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     }
     // ---- batched leaf tests ----
     leafMask = __ballot(MODE_IS(M_LEAF));
-    const unsigned long long stillExp = __ballot(MODE_IS(M_EXPAND) && !finished && !hold);
+    const unsigned long long stillExp = __ballot(MODE_IS(M_EXPAND) && !finished);
     if (leafMask != 0ull && (__popcll(leafMask) >= DR_LEAF_TH || stillExp == 0ull)) {
       if (MODE_IS(M_LEAF)) {
         const uint32_t leafN = (cur >> 26) & 31u, leafOff = cur & 0x3ffffffu;
@@ -1386,9 +1261,6 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     }
     if (finished) mode = M_DONE;  // stored at the head of the next iteration
   }
-  if constexpr (TL) {
-    if (lane_id() == 0 && outEnd > outNext && tl.out) atomicAdd(&tl.outCount[1], outEnd - outNext);
-  }
   flush_counters(ctr, ANY, lane_id() == 0 ? nRays : 0u, nNodes, nTris);
 #undef MODE_IS
 #undef M_RETEST
@@ -1434,25 +1306,8 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3C_WAVES) k_trace3c(DS
   StateIO<0> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
   const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
-  trace_pairs<0, StateIO<0>, false, true, DR_PSTACK_C>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride,
-                                                      stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK_C), work, ctr, TLArgs(), s_cold + threadIdx.x);
-}
-
-// Treelet-parked traversal (DARTRAY_TRACE_IMPL=4; TLArgs in dr_kernels.h): trace_pairs with its TL blocks compiled in.
-template <int ANY>
-__global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_trace_tl(DScene sc, BatchState st, const uint32_t* queue,
-                                                                              const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
-                                                                              TraceCounters* ctr, TLArgs tl) {
-  __shared__ uint32_t s_ref[DR_PSTACK * DR_TRACE_BLOCK];
-  __shared__ float s_e[DR_PSTACK * DR_TRACE_BLOCK];
-  StateIO<ANY> io{st, queue};
-  const uint32_t n = nQueue ? *nQueue : st.nslots;
-  const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
-  trace_pairs<ANY, StateIO<ANY>, true>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride,
-                                       stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr, tl);
-}
-__global__ void k_tl_iota(uint32_t* v, uint32_t n) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i;
+  trace_pairs<0, StateIO<0>, true, DR_PSTACK_C>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride,
+                                               stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK_C), work, ctr, s_cold + threadIdx.x);
 }
 
 // ===========================================================================
@@ -1894,7 +1749,7 @@ static bool coldClosest() {
 // here: 1 / 2 / 3, with `*cold` set for id 5 on closest-hit rays.
 static int traceImpl(const DScene& sc, int anyHit, int force = 0, bool* cold = nullptr) {
   const char e = dr_opt("DARTRAY_TRACE_IMPL").first();  // (read per launch: dr_set_option may change it between renders)
-  const int env = ((e >= '1' && e <= '3') || e == '5') ? e - '0' : (e == '4' ? 3 : 0);  // 4: treelet-parked stage traversals (dr_api.hip); everything else v3
+  const int env = ((e >= '1' && e <= '3') || e == '5') ? e - '0' : 0;
   // v2 is the fastest on cache-resident trees, v3 (sibling pairs) on big incoherent ones (MEASUREMENTS.md):
   // unless DARTRAY_TRACE_IMPL fixes it, the choice is the one measured for this scene (sc.traceKernel, set by the
   // pilot of dr_render_device)
@@ -1969,102 +1824,6 @@ int exp_sort_list(const uint32_t* in, uint32_t* out, uint32_t n, void* tmp, size
   return hipcub::DeviceRadixSort::SortKeys(tmp, need, in, out, (int)n, 0, 30, s) == hipSuccess ? 0 : -2;
 }
 #endif
-size_t treelet_sort_bytes(uint32_t n) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                           (uint32_t*)nullptr, (int)n, 0, 32, (hipStream_t)0);
-  return bytes;
-}
-
-// The treelet-parked traversal of one stage queue: launch 0 walks every ray through the top treelet and parks it where it
-// enters its first bottom sub-tree; the records are sorted by sub-tree (hipcub radix sort of (key, position)); the next
-// launch resumes them in that order -- parking them again at their NEXT bottom sub-tree while parking rounds are left
-// (w.rounds), finishing them otherwise.  The host reads two counters back per round (a prototype: the stage loop of
-// dr_render_device otherwise never waits for the device).
-int launch_trace_treelets(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
-                          uint32_t* spill, uint32_t* workCounters, TraceCounters* ctr, int grid, hipStream_t s, TLWork& w) {
-  grid = std::min(grid, traceGridFor(DR_TRACE3_WAVES));
-  const dim3 g(grid), b(DR_TRACE_BLOCK);
-  int keyBits = 1;
-  while ((1ull << keyBits) < (unsigned long long)sc.npairs + 1ull && keyBits < 32) ++keyBits;
-  struct Events {  // (destroyed on every return path)
-    hipEvent_t v[4];
-    Events() { for (auto& x : v) (void)hipEventCreate(&x); }
-    ~Events() { for (auto& x : v) (void)hipEventDestroy(x); }
-    hipEvent_t operator[](int i) const { return v[i]; }
-  } e;
-  (void)hipMemsetAsync(w.counts, 0, 64 * sizeof(uint32_t), s);
-  if (!w.iotaReady) {
-    hipLaunchKernelGGL(k_tl_iota, dim3(4096), dim3(256), 0, s, w.iota, w.outCap);
-    w.iotaReady = 1;
-  }
-  uint32_t nResume = 0;
-  for (int round = 0; round < 4; ++round) {
-    const bool parks = round < w.rounds && (round == 0 || nResume >= w.minPark) && round < 3;
-    const int ob = round & 1;  // records written by this launch
-    TLArgs tl;
-    tl.order = round ? w.order : nullptr;
-    tl.nIn = w.counts + 32 + round;
-    tl.in = round ? w.rec[ob ^ 1] : nullptr;
-    tl.out = parks ? w.rec[ob] : nullptr;
-    tl.outKeys = w.keys[ob];
-    tl.outCount = w.counts + 2 * round;
-    tl.outCap = w.outCap;
-    tl.topPairs = w.topPairs;
-    if (parks) (void)hipMemsetAsync(w.keys[ob], 0xff, (size_t)w.outCap * sizeof(uint32_t), s);
-    (void)hipEventRecord(e[0], s);
-    uint32_t* wc = workCounters + (size_t)round * 128;  // (the launch's 8 x DR_WORK_STRIDE = 512 words: 8 shard counters, 64 B apart, per round)
-    tl.shards = round ? (uint32_t)w.shards : 1u;
-    if (round >= 4) break;  // (never reached: rounds <= 3)
-    if (anyHit) hipLaunchKernelGGL(k_trace_tl<1>, g, b, 0, s, sc, st, queue, nQueue, spill, wc, ctr, tl);
-    else hipLaunchKernelGGL(k_trace_tl<0>, g, b, 0, s, sc, st, queue, nQueue, spill, wc, ctr, tl);
-    (void)hipEventRecord(e[1], s);
-    if (!parks) {
-      if (w.verbose) {
-        (void)hipEventSynchronize(e[1]);
-        float t = 0.f;
-        (void)hipEventElapsedTime(&t, e[0], e[1]);
-        w.ms[anyHit][0] += t;
-        if (w.verbose > 1) fprintf(stderr, "treelets %s round %d: %u resumed, finished in %.3f ms\n", anyHit ? "any" : "closest", round, nResume, t);
-      }
-      break;
-    }
-    uint32_t cnt[2] = {0, 0};
-    if (hipMemcpyAsync(cnt, w.counts + 2 * round, sizeof(cnt), hipMemcpyDeviceToHost, s) != hipSuccess) return DR_ERR_HIP;
-    if (hipStreamSynchronize(s) != hipSuccess) return DR_ERR_HIP;
-    const uint32_t reserved = std::min(cnt[0], w.outCap);
-    const uint32_t overflowed = cnt[0] > w.outCap ? cnt[0] - w.outCap : 0u;  // positions past the buffer: reserved by waves, never written (their rays walked on)
-    const uint32_t unusedInBuf = cnt[1] > overflowed ? cnt[1] - overflowed : 0u;
-    nResume = reserved > unusedInBuf ? reserved - unusedInBuf : 0u;
-    float tTrace = 0.f, tSort = 0.f;
-    (void)hipEventElapsedTime(&tTrace, e[0], e[1]);
-    if (nResume == 0) {
-      w.ms[anyHit][0] += tTrace;
-      break;
-    }
-    (void)hipEventRecord(e[2], s);
-    size_t tmpBytes = w.sortTmpBytes;
-    if (hipcub::DeviceRadixSort::SortPairs(w.sortTmp, tmpBytes, (const uint32_t*)w.keys[ob], w.keysSorted, (const uint32_t*)w.iota, w.order,
-                                           (int)reserved, 0, keyBits, s) != hipSuccess)
-      return DR_ERR_HIP;
-    (void)hipMemcpyAsync(w.counts + 32 + round + 1, &nResume, sizeof(uint32_t), hipMemcpyHostToDevice, s);
-    (void)hipEventRecord(e[3], s);
-    if (w.verbose) {
-      (void)hipEventSynchronize(e[3]);
-      (void)hipEventElapsedTime(&tSort, e[2], e[3]);
-      w.ms[anyHit][0] += tTrace;
-      w.ms[anyHit][1] += tSort;
-      w.ms[anyHit][3] += (float)nResume * 1.0e-6f;
-      if (w.verbose > 1)
-        fprintf(stderr, "treelets %s round %d: traced in %.3f ms, %u rays parked (%u positions reserved), sorted in %.3f ms\n", anyHit ? "any" : "closest",
-                round, tTrace, nResume, cnt[0], tSort);
-    } else {
-      (void)hipStreamSynchronize(s);  // (nResume is a host local the copy above reads)
-    }
-  }
-  return DR_OK;
-}
-
 #ifdef DR_NS
 }  // namespace DR_NS
 #endif

@@ -34,7 +34,7 @@ def test_switches_set_through_the_c_abi_do_not_clobber_each_other():
         "prims, mk = scenes.config('C2', xres=40, yres=40, spp=16, blob=(60, 30))\n"
         "r = mk(); scene = scenes.make_scene(prims); dev = scene._device()\n"
         "ref = r.render(scene).film\n"
-        "info = dev.last_render_info(); assert info['state_layout'] == 64 and info['treelet_rounds'] == -1, info\n"
+        "info = dev.last_render_info(); assert info['state_layout'] == 64, info\n"
         # the round-4 failure: the layout switch first, then two more look-ups of other names (one with a LONGER value)
         "opt('STATE_LAYOUT', 4); opt('LAYOUT_PILOT', 0); opt('VERBOSE', '0000000000000000000000000000000000000001')\n"
         "f = r.render(scene).film; info = dev.last_render_info()\n"
@@ -52,14 +52,8 @@ def test_switches_set_through_the_c_abi_do_not_clobber_each_other():
         "assert (info['closest_kernel'], info['any_hit_kernel'], info['trace_wg_per_cu'], info['overlap_any']) == (2, 2, 5, 1), info\n"
         "assert np.array_equal(f, ref)\n"
         "opt('TRACE_WG_PER_CU', None)\n"
-        # the treelet-parked traversal needs its pair order at dr_scene_create: a second device scene of the same primitives
-        "opt('TRACE_IMPL', 4); opt('TREELET_ROUNDS', 2); opt('PAIR_ORDER', 'top:3'); opt('TREELET_MIN', 0)\n"
-        "scene2 = scenes.make_scene(prims); f = r.render(scene2).film; info = scene2._device().last_render_info()\n"
-        "assert (info['closest_kernel'], info['any_hit_kernel'], info['treelet_rounds']) == (4, 4, 2), info\n"
-        "assert np.array_equal(f, ref)\n"
-        "for n in ('TRACE_IMPL', 'TREELET_ROUNDS', 'PAIR_ORDER', 'TREELET_MIN'): opt(n, None)\n"
         # names the header no longer lists are refused, like any unknown name
-        "for n in (b'WORKSPACE', b'TREELET', b'TREELET_TOP', b'NO_SUCH_SWITCH'): assert lib.dr_set_option(n, b'1') != 0\n"
+        "for n in (b'WORKSPACE', b'TREELET', b'TREELET_TOP', b'TREELET_ROUNDS', b'NO_SUCH_SWITCH'): assert lib.dr_set_option(n, b'1') != 0\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
     _run(code)
 

@@ -263,20 +263,17 @@ def test_render_is_deterministic_and_device_film_accumulates(gpu):
     assert np.array_equal(film.cpu().numpy(), a.film) and np.array_equal(rgb.cpu().numpy(), a.rgb)
 
 
-@pytest.mark.parametrize("impl", ["1", "3", "3:any8", "3:cold", "4:top3:r1", "4:top3:r3", "4:top6:r2", "4:top1:r3"])
+@pytest.mark.parametrize("impl", ["1", "3", "3:any8", "3:cold"])
 def test_alternative_traversal_kernels_are_bit_exact_too(impl):
     """DARTRAY_TRACE_IMPL selects the first traversal kernel (1), the sibling-pair kernels (3: k_trace3<0> + the 4-byte-entry
-    any-hit kernel k_trace3a; any8: round 3's 8-byte any-hit kernel) or the treelet-parked traversal (4: pair records laid
-    out top:T, every ray parked at each bottom sub-tree it enters for r rounds, sorted, resumed) for A/B runs; all must
-    reproduce the oracle's hits, visit counts and image exactly, like the default (2)."""
+    any-hit kernel k_trace3a; any8: round 3's 8-byte any-hit kernel) for A/B runs; all must reproduce the oracle's hits,
+    visit counts and image exactly, like the default (2).  (The treelet-parked traversal of round 4 -- a measured negative --
+    lives in experiments/r06_treelet_parked_traversal.diff.)"""
     extra = {}
     if impl == "3:any8":
         impl, extra = "3", {"DARTRAY_ANY8": "1"}
     elif impl == "3:cold":  # k_trace3c: the closest-hit pair kernel with its cold ray state in LDS
         impl, extra = "3", {"DARTRAY_CLOSEST_COLD": "1"}
-    elif impl.startswith("4:"):
-        _, top, rounds = impl.split(":")
-        impl, extra = "4", {"DARTRAY_PAIR_ORDER": "top:" + top[3:], "DARTRAY_TREELET_ROUNDS": rounds[1:], "DARTRAY_TREELET_MIN": "0"}
     import subprocess
     import sys
     code = (
