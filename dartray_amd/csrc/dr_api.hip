@@ -463,7 +463,7 @@ static const LayoutOps kLayoutSp4 = {&sp4::launch_trace, &sp4::launch_trace_cohe
 int traceGridFor(int wgPerCU) {
   // workgroups of the persistent traversal kernels: as many as are resident at once.  v2 (k_trace): 16 KiB of stack +
   // 6 KiB of cold ray state in LDS and 72 VGPRs => 7 workgroups = 28 waves per CU; the other variants (v3: 32 KiB of
-  // LDS, the quadric and v1 kernels: more registers) 6, the sixth queueing behind five where only five fit.
+  // LDS, the quadric kernel: more registers) 6, the sixth queueing behind five where only five fit.
   wgPerCU = dr_opt("DARTRAY_TRACE_WG_PER_CU").toInt(wgPerCU);
   return g_numCU * std::max(1, std::min(wgPerCU, 8));
 }

@@ -260,9 +260,6 @@ struct StageQueues {
 #ifndef DR_WORK_STRIDE
 #define DR_WORK_STRIDE 64
 #endif
-#ifndef DR_LDS_STACK
-#define DR_LDS_STACK 24       // stack entries per lane kept in LDS: 24 KiB per workgroup => 6 workgroups (24 waves) per CU
-#endif
 #ifndef DR_V2_LDS_STACK
 #define DR_V2_LDS_STACK 16    // k_trace: 16 KiB of stack + 6 KiB of cold ray state per workgroup => 7 workgroups (28 waves) per CU
 #endif

@@ -78,91 +78,6 @@ __device__ __forceinline__ uint32_t work_chunk(uint32_t n) {
 #endif
 }
 
-// ===========================================================================
-// v1: the first correct version (kept for A/B runs, DARTRAY_TRACE_IMPL=1): 64 queue entries per
-// wave at a time, one node visit OR leaf per iteration for every lane.
-// ===========================================================================
-// ---------------------------------------------------------------------------
-// BVH traversal (bvh_accel.dart:101-226).  Returns the hit primitive (closest)
-// or 0 / -1 (any-hit: occluded / free).
-// ---------------------------------------------------------------------------
-template <int ANY>
-DR_DEV int traverse(const DScene& sc, F3 o, F3 d, double tmin, double tmax, uint32_t* lds, uint32_t* spill,
-                    uint32_t spillStride, double* tOut, uint32_t* nNodes, uint32_t* nTris) {
-  if (sc.nnodes == 0) return -1;
-  // invDir is a Vector: rounded to f32 (bvh_accel.dart:109-111)
-  const float ivx = (float)(1.0 / (double)d.x), ivy = (float)(1.0 / (double)d.y), ivz = (float)(1.0 / (double)d.z);
-  const bool n0 = ivx < 0.f, n1 = ivy < 0.f, n2 = ivz < 0.f;
-  const double ox = o.x, oy = o.y, oz = o.z;
-  const double dix = ivx, diy = ivy, diz = ivz;
-  int sp = 0;
-  uint32_t node = 0;
-  int hit = -1;
-  for (;;) {
-    const uint4 a = sc.nodes[2 * (size_t)node];
-    const uint4 b = sc.nodes[2 * (size_t)node + 1];
-    ++*nNodes;
-    const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
-    const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
-    const uint32_t offset = b.z, meta = b.w;
-    // _intersectP slab test (bvh_accel.dart:439-472), f64 products of f32 values
-    double t0 = ((double)(n0 ? bmaxx : bminx) - ox) * dix;
-    double t1 = ((double)(n0 ? bminx : bmaxx) - ox) * dix;
-    const double ty0 = ((double)(n1 ? bmaxy : bminy) - oy) * diy;
-    const double ty1 = ((double)(n1 ? bminy : bmaxy) - oy) * diy;
-    bool ok = !((t0 > ty1) || (ty0 > t1));
-    if (ok) {
-      if (ty0 > t0) t0 = ty0;
-      if (ty1 < t1) t1 = ty1;
-      const double tz0 = ((double)(n2 ? bmaxz : bminz) - oz) * diz;
-      const double tz1 = ((double)(n2 ? bminz : bmaxz) - oz) * diz;
-      ok = !((t0 > tz1) || (tz0 > t1));
-      if (ok) {
-        if (tz0 > t0) t0 = tz0;
-        if (tz1 < t1) t1 = tz1;
-        ok = (t0 < tmax) && (t1 > tmin);
-      }
-    }
-    bool pop = true;
-    if (ok) {
-      const uint32_t nprims = meta & 0xffffu;
-      if (nprims > 0) {
-        for (uint32_t i = 0; i < nprims; ++i) {
-          ++*nTris;
-          const float4* tp = sc.tris + 3 * (size_t)(offset + i);
-          const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-          const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
-          if (ANY) {
-            if (tri_hitP(p1, p2, p3, o, d, tmin, tmax)) return 0;  // bvh_accel.dart:193-195
-          } else {
-            double t, b1, b2;
-            if (tri_hit(p1, p2, p3, o, d, tmin, tmax, &t, &b1, &b2)) {
-              tmax = t;  // r.maxDistance = thit (geometric_primitive.dart:59)
-              hit = (int)(offset + i);
-            }
-          }
-        }
-      } else {
-        const uint32_t axis = (meta >> 16) & 0xffu;
-        const bool neg = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
-        const uint32_t far = neg ? node + 1 : offset;  // bvh_accel.dart:147-153
-        node = neg ? offset : node + 1;
-        if (sp < DR_LDS_STACK) lds[sp * DR_TRACE_BLOCK] = far;
-        else if (sp < DR_MAX_STACK) spill[(size_t)(sp - DR_LDS_STACK) * spillStride] = far;
-        ++sp;
-        pop = false;
-      }
-    }
-    if (pop) {
-      if (sp == 0) break;
-      --sp;
-      node = sp < DR_LDS_STACK ? lds[sp * DR_TRACE_BLOCK] : spill[(size_t)(sp - DR_LDS_STACK) * spillStride];
-    }
-  }
-  if (!ANY) *tOut = tmax;
-  return hit;
-}
-
 DR_DEV void flush_counters(TraceCounters* ctr, int any, uint32_t rays, uint32_t nodes, uint32_t tris) {
   unsigned long long r = wave_sum(rays), n = wave_sum(nodes), t = wave_sum(tris);
   // (a wave that traced nothing reports nothing: the ~7000 waves of a persistent launch otherwise queue 21 000 atomics
@@ -180,90 +95,6 @@ DR_DEV void flush_counters(TraceCounters* ctr, int any, uint32_t rays, uint32_t 
   }
 }
 
-// Persistent traversal kernel over a queue of path slots.
-template <int ANY>
-__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_trace_v1(DScene sc, BatchState st, const uint32_t* queue,
-                                                          const uint32_t* nQueue, uint32_t* spill, uint32_t* work,
-                                                          TraceCounters* ctr) {
-  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
-  uint32_t* lds = s_stack + threadIdx.x;
-  const uint32_t spillStride = gridDim.x * DR_TRACE_BLOCK;
-  uint32_t* mySpill = spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr;
-  const uint32_t n = nQueue ? *nQueue : st.nslots;
-  const uint32_t cap = st.tileStride;  // words per 64-slot tile
-  uint32_t rays = 0, nodes = 0, tris = 0;
-  for (;;) {
-    uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(work, 64u);
-    base = wave_bcast_first(base);
-    if (base >= n) break;
-    const uint32_t idx = base + (uint32_t)lane_id();
-    if (idx < n) {
-      const uint32_t e = queue ? queue[idx] : idx;
-      const uint32_t slot = e & ~Q_MIS_BIT;
-      const size_t ti = TI(cap, slot);
-      const F3 o = F3{st.ro()[ti], st.ro()[ti + DR_SUB], st.ro()[ti + 2 * DR_SUB]};
-      const double tmin = st.rtmin()[TD(cap, slot)];
-      ++rays;
-      if (ANY) {
-        const F3 d = F3{st.shD()[ti], st.shD()[ti + DR_SUB], st.shD()[ti + 2 * DR_SUB]};
-        double t;
-        int r = traverse<1>(sc, o, d, tmin, st.shTmax()[TD(cap, slot)], lds, mySpill, spillStride, &t, &nodes, &tris);
-        st.shOcc()[ti] = (r >= 0) ? 1 : 0;
-      } else if (e & Q_MIS_BIT) {
-        const F3 d = F3{st.misD()[ti], st.misD()[ti + DR_SUB], st.misD()[ti + 2 * DR_SUB]};
-        double t;
-        st.misPrim()[ti] = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
-      } else {
-        const F3 d = F3{st.rd()[ti], st.rd()[ti + DR_SUB], st.rd()[ti + 2 * DR_SUB]};
-        double t;
-        int r = traverse<0>(sc, o, d, tmin, DR_INF, lds, mySpill, spillStride, &t, &nodes, &tris);
-        st.hprim()[ti] = r;
-        st.ht()[TD(cap, slot)] = t;
-      }
-    }
-  }
-  flush_counters(ctr, ANY, rays, nodes, tris);
-}
-
-// Aggregate.intersect / intersectP on caller-supplied rays (dr_intersect).
-template <int ANY>
-__global__ void __launch_bounds__(DR_TRACE_BLOCK) k_intersect_v1(DScene sc, const DrRay* rays, uint32_t n, DrHit* out,
-                                                              uint32_t* spill, uint32_t* work, TraceCounters* ctr) {
-  __shared__ uint32_t s_stack[DR_LDS_STACK * DR_TRACE_BLOCK];
-  uint32_t* lds = s_stack + threadIdx.x;
-  const uint32_t spillStride = gridDim.x * DR_TRACE_BLOCK;
-  uint32_t* mySpill = spill ? spill + (size_t)blockIdx.x * DR_TRACE_BLOCK + threadIdx.x : nullptr;
-  uint32_t nr = 0, nodes = 0, tris = 0;
-  for (;;) {
-    uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(work, 64u);
-    base = wave_bcast_first(base);
-    if (base >= n) break;
-    const uint32_t idx = base + (uint32_t)lane_id();
-    if (idx < n) {
-      const DrRay r = rays[idx];
-      const F3 o = F3{r.o[0], r.o[1], r.o[2]}, d = F3{r.d[0], r.d[1], r.d[2]};
-      ++nr;
-      DrHit h;
-      h.pad = 0;
-      h.t = h.b1 = h.b2 = 0.0;
-      double t = 0.0;
-      h.prim = traverse<ANY>(sc, o, d, r.tmin, r.tmax, lds, mySpill, spillStride, &t, &nodes, &tris);
-      if (!ANY && h.prim >= 0) {
-        Tri tr = load_tri(sc, (uint32_t)h.prim);
-        double tt, b1, b2;
-        // same arithmetic as the accepting test; only the [tmin,tmax] gate differs
-        tri_hit(tr.p1, tr.p2, tr.p3, o, d, r.tmin, DR_INF, &tt, &b1, &b2);
-        h.t = t;
-        h.b1 = b1;
-        h.b2 = b2;
-      }
-      out[idx] = h;
-    }
-  }
-  flush_counters(ctr, ANY, nr, nodes, tris);
-}
 
 
 // ===========================================================================
@@ -1734,7 +1565,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
 }
 
 // ---------------------------------------------------------------------------
-// launchers.  DARTRAY_TRACE_IMPL selects the kernel for A/B runs: 1 = first version, 2 = default, 3 = sibling pairs.
+// launchers.  DARTRAY_TRACE_IMPL selects the kernel for A/B runs: 2 = k_trace, 3 = sibling pairs, 5 = 3 with k_trace3c.
 // ---------------------------------------------------------------------------
 // A/B: DARTRAY_ANY8=1 keeps the 8-byte (reference, entry parameter) any-hit kernel of round 3 (k_trace3<1>)
 static bool any8() {
@@ -1744,12 +1575,12 @@ static bool any8() {
 static bool coldClosest() {
   return dr_opt("DARTRAY_CLOSEST_COLD").nonZero();
 }
-// Kernel ids (DScene.traceKernel, DARTRAY_TRACE_IMPL, dr_scene_set_trace_kernels): 1 first version, 2 k_trace, 3 sibling pairs (k_trace3<0> /
+// Kernel ids (DScene.traceKernel, DARTRAY_TRACE_IMPL, dr_scene_set_trace_kernels): 2 k_trace, 3 sibling pairs (k_trace3<0> /
 // k_trace3a), 5 sibling pairs with the closest-hit rays' cold state in LDS (k_trace3c; the any-hit rays: k_trace3a as with 3).  Returned
-// here: 1 / 2 / 3, with `*cold` set for id 5 on closest-hit rays.
+// here: 2 / 3, with `*cold` set for id 5 on closest-hit rays.
 static int traceImpl(const DScene& sc, int anyHit, int force = 0, bool* cold = nullptr) {
   const char e = dr_opt("DARTRAY_TRACE_IMPL").first();  // (read per launch: dr_set_option may change it between renders)
-  const int env = ((e >= '1' && e <= '3') || e == '5') ? e - '0' : 0;
+  const int env = (e == '2' || e == '3' || e == '5') ? e - '0' : 0;
   // v2 is the fastest on cache-resident trees, v3 (sibling pairs) on big incoherent ones (MEASUREMENTS.md):
   // unless DARTRAY_TRACE_IMPL fixes it, the choice is the one measured for this scene (sc.traceKernel, set by the
   // pilot of dr_render_device)
@@ -1767,9 +1598,6 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
     if (anyHit && any8()) hipLaunchKernelGGL(k_intersect3<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
     else if (anyHit) hipLaunchKernelGGL(k_intersect3a, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_intersect3<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
-  } else if (impl == 1) {
-    if (anyHit) hipLaunchKernelGGL(k_intersect_v1<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
-    else hipLaunchKernelGGL(k_intersect_v1<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
   } else {
     if (anyHit) hipLaunchKernelGGL(k_intersect<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_intersect<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
@@ -1802,9 +1630,6 @@ void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue,
     else if (anyHit) hipLaunchKernelGGL(k_trace3a, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else if (cold) hipLaunchKernelGGL(k_trace3c, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace3<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
-  } else if (impl == 1) {
-    if (anyHit) hipLaunchKernelGGL(k_trace_v1<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
-    else hipLaunchKernelGGL(k_trace_v1<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
   } else if (sc.nquads) {
     if (anyHit) hipLaunchKernelGGL(k_trace_quad<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace_quad<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
