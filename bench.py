@@ -230,7 +230,7 @@ def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="
     if pk["launches"]:
         ca = alg_pk / max(pk["ms"] * 1e-3, 1e-12) / 1e9
         cam = {"bound": "scalar-load latency + VALU at full lane width", "bound_priced_against": "hbm",
-               "kernel": "k_trace_pk<0> (closest-hit traversal of the camera rays by coherent waves: one stack per wave, node and triangles loaded once per wave)",
+               "kernel": "k_trace_pk (closest-hit traversal of the camera rays by coherent waves: one stack per wave, node and triangles loaded once per wave)",
                "achieved": round(ca, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(ca / PEAK_GBPS, 4), "saturated": bool(ca / PEAK_GBPS > 1.0),
                "traffic": None, "achieved_is": "algorithmic bytes per second (32 B per ray and node visit: the reference's per-ray count), not HBM traffic -- "
                                                "the wave loads a node ONCE for its 64 rays, so this figure exceeds any memory rate by construction",
@@ -751,7 +751,7 @@ class Run:
                        "triangles": int(len(agg.tri_idx)), "bvh_nodes": int(len(agg.nodes)),
                        "bvh_builder": "%s (dr_bvh_build_%s), %.0f ms" % (agg.builder, "device" if agg.builder == "device" else "mixed", agg.build_ms),
                        "trace_kernels": {"closest": knames["closest"], "any_hit": knames["any_hit"],
-                                         "camera_rays": "k_trace_pk<0>" if pk["launches"] else knames["closest"],
+                                         "camera_rays": "k_trace_pk" if pk["launches"] else knames["closest"],
                                          "picked_by": ("--trace-kernels / DARTRAY_TRACE_IMPL" if forced else
                                                        "the scene's pilot batches (closest-hit: best time per algorithmic byte, a pair kernel needs 5 %; any-hit: "
                                                        "the closest-hit kernel's family unless the other wins its own batch by more than 15 %)"),

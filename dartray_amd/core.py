@@ -665,7 +665,7 @@ class _DeviceScene:
         _abi.check(_abi.lib().dr_scene_last_render_info(self.handle, C.byref(arr)))
         return {"state_layout": int(arr[0]), "closest_kernel": int(arr[1]), "any_hit_kernel": int(arr[2]),
                 "pilot_batches": int(arr[4]), "batches": int(arr[5]), "trace_wg_per_cu": int(arr[6]), "overlap_any": int(arr[7]) & 1,
-                "coherent_camera": (int(arr[7]) >> 1) & 1, "coherent_shadow": (int(arr[7]) >> 2) & 1, "lazy_gen": (int(arr[7]) >> 3) & 1}
+                "coherent_camera": (int(arr[7]) >> 1) & 1, "lazy_gen": (int(arr[7]) >> 3) & 1}
 
     def coherent_stats(self):
         """The part of stats()' closest-hit totals that k_trace_pk (coherent waves: the camera rays) traced."""

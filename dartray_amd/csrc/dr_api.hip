@@ -97,7 +97,7 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_COHERENT_SHADOW", "DARTRAY_LAZY_GEN", "DARTRAY_SPLIT_WG", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP", "DARTRAY_LAYOUT_PILOT"};
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_LAZY_GEN", "DARTRAY_SPLIT_WG", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
 DrOpt dr_opt(const char* name) {
@@ -1524,11 +1524,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   if (rc) return rc;
   // the camera rays (a tile = 64 samples of one pixel) through the wave-coherent kernel k_trace_pk (DARTRAY_COHERENT_CAMERA=0: k_trace & co.)
   const bool coherentCamera = !dr_opt("DARTRAY_COHERENT_CAMERA").isZero() && !dlSpec;
-  // DARTRAY_COHERENT_SHADOW=1 (A/B; a measured negative, MEASUREMENTS.md 5.9): the shadow rays that leave the CAMERA vertices (a path
-  // render's first stage; every stage of DirectLighting) through k_trace_pk<1> as well.  64 consecutive queue entries are neighbouring
-  // hit points looking at the lights -- but they start on different pieces of surface and fan out over the emitter: the wave's union
-  // of visited nodes is several rays' worth (C2 any-hit 95 -> 136 ms, C4 102 -> 326).
-  const bool coherentShadow = !dlSpec && !sc->d.nquads && dr_opt("DARTRAY_COHERENT_SHADOW").nonZero();
   const bool overlapEnv = !(dr_opt("DARTRAY_OVERLAP_ANY").isZero());  // default: on
   // lazy sample generation (DARTRAY_LAZY_GEN=0: every block for every pixel up front): needs the device sampler's compact form, the keyed
   // per-(pixel, block) streams (a block that is left out disturbs no other) and k_trace_pk's marks of the camera rays that hit
@@ -1712,7 +1707,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
         // them, every group counts as alive -- all blocks are generated, nothing is skipped)
         if (coherent && !any && st.markAlive) (void)hipMemsetAsync(st.markAlive, 1, nGroups, ts);
       } else {
-        ++wc;  // (k_trace_pk took this queue: the camera rays, or the camera vertices' shadow rays towards one light)
+        ++wc;  // (k_trace_pk took this queue: the camera rays)
         tookCoherent = true;
       }
       (void)hipEventRecord(e1, ts);
@@ -1833,7 +1828,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
             slog[b + 1].c0 = sc->traceEvents.back().e0;
             slog[b + 1].c1 = sc->traceEvents.back().e1;
           }
-          trace(q.anyQ, q.nAny, 1, sc->s3, w.spill.p + w.spillHalf, closestEnd, coherentShadow && (direct || b == 0), splitAny);
+          trace(q.anyQ, q.nAny, 1, sc->s3, w.spill.p + w.spillHalf, closestEnd, false, splitAny);
           if (stageCounts && round == 0) {
             slog[b + 1].a0 = sc->traceEvents.back().e0;
             slog[b + 1].a1 = sc->traceEvents.back().e1;
@@ -1846,7 +1841,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
             slog[b + 1].c0 = sc->traceEvents.back().e0;
             slog[b + 1].c1 = sc->traceEvents.back().e1;
           }
-          trace(q.anyQ, q.nAny, 1, s, w.spill.p, nullptr, coherentShadow && (direct || b == 0));
+          trace(q.anyQ, q.nAny, 1, s, w.spill.p);
           if (stageCounts && round == 0) {
             slog[b + 1].a0 = sc->traceEvents.back().e0;
             slog[b + 1].a1 = sc->traceEvents.back().e1;
@@ -2063,7 +2058,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   sc->lastInfo[4] = pilotBatchesRun;
   sc->lastInfo[5] = (int32_t)std::min<uint64_t>(0x7fffffff, nBatches);
   sc->lastInfo[6] = tgrid / std::max(1, g_numCU);
-  sc->lastInfo[7] = (overlapAny ? 1 : 0) | (coherentCamera && !sc->d.nquads ? 2 : 0) | (coherentShadow ? 4 : 0) | (lazyGen ? 8 : 0);
+  sc->lastInfo[7] = (overlapAny ? 1 : 0) | (coherentCamera && !sc->d.nquads ? 2 : 0) | (lazyGen ? 8 : 0);
   return DR_OK;
 #undef L
 }

@@ -1411,16 +1411,14 @@ DR_DEV float4 ld_uniform(const float4* p) {
 DR_DEV uint4 ld_uniform(const uint4* p) { return *p; }
 DR_DEV float4 ld_uniform(const float4* p) { return *p; }
 #endif
-// ANY = 1 (BVHAccel.intersectP, bvh_accel.dart:167-226) for the shadow rays of the CAMERA vertices of a scene with one light: 64
-// consecutive entries of the stage's any-hit queue leave neighbouring hit points towards the same emitter.  A lane whose ray has
-// found an occluder has returned (:193-195): it leaves every mask (`done`), the others walk on.
-template <int ANY>
+// (An any-hit instantiation for the camera vertices' shadow rays was measured in round 5 and lost -- C2 any-hit 95 -> 136 ms, the wave's
+// union of visited nodes is several rays' worth: experiments/r06_coherent_shadow_rays.diff.)
 __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DScene sc, BatchState st, const uint32_t* queue, const uint32_t* nQueue,
                                                                              uint32_t* work, TraceCounters* ctr) {
   __shared__ uint32_t s_pk[(DR_TRACE_BLOCK / 64) * DR_MAX_STACK * 3];
   typedef __attribute__((address_space(3))) uint32_t pk_u32;
   pk_u32* const stk = (pk_u32*)(s_pk + (threadIdx.x >> 6) * (DR_MAX_STACK * 3));
-  StateIO<ANY> io{st, queue};
+  StateIO<0> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
   const int lane = lane_id();
   uint32_t nRays = 0, nNodes = 0, nTris = 0;  // nRays / nNodes: wave-uniform, lane 0 reports them; nTris: per lane
@@ -1443,7 +1441,6 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
         uint32_t handle;  // (re-read from the queue at the store: not held in a register across the walk)
         io.load(have ? idx : n - 1u, ray, handle);  // (a lane beyond the end loads the last ray and takes no part)
       }
-      unsigned long long done = 0ull;  // ANY: the lanes whose ray has returned
       const unsigned long long haveMask = __ballot(have);
       nRays += (uint32_t)__popcll(haveMask);
       if (sc.nnodes != 0u) {
@@ -1458,18 +1455,6 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
           uint32_t cur = 0u;
           unsigned long long curMask = pmask;
           for (;;) {
-            if (ANY) {
-              curMask &= ~done;
-              if (curMask == 0ull) {  // every ray that would have visited this node has returned: not a visit
-                if (sp == 0) break;
-                --sp;
-                cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[3 * sp]);
-                const uint32_t mlo_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[3 * sp + 1]);
-                const uint32_t mhi_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[3 * sp + 2]);
-                curMask = (unsigned long long)mlo_ | ((unsigned long long)mhi_ << 32);
-                continue;
-              }
-            }
             const uint4* np = (const uint4*)((const char*)sc.nodes + (size_t)(cur << 5));  // wave-uniform address
             const uint4 a = ld_uniform(np), b = ld_uniform(np + 1);
             nNodes += (uint32_t)__popcll(curMask);
@@ -1500,22 +1485,13 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
                   if (ok) {
                     ++nTris;
                     const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
-                    if (ANY) {
-                      if (tri_hitP(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax)) {  // return true (bvh_accel.dart:193-195)
-                        hit = 0;
-                        ok = false;  // no further triangle of this leaf for this ray
-                      }
-                    } else {
-                      double t, b1, b2;
-                      if (tri_hit(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax, &t, &b1, &b2)) {
-                        ray_set_tmax(ray, t);  // r.maxDistance = thit (geometric_primitive.dart:59)
-                        hit = (int)(leafOff + i);
-                      }
+                    double t, b1, b2;
+                    if (tri_hit(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax, &t, &b1, &b2)) {
+                      ray_set_tmax(ray, t);  // r.maxDistance = thit (geometric_primitive.dart:59)
+                      hit = (int)(leafOff + i);
                     }
                   }
-                  if (ANY && __ballot(ok) == 0ull) break;  // every ray at this leaf has returned
                 }
-                if (ANY) done |= __ballot(hit == 0);
               } else {  // interior: near child now, far child pushed for the lanes that are here (bvh_accel.dart:145-155)
                 const uint32_t axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)((b.w >> 16) & 0xffu));
                 const uint32_t second = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.z);
@@ -1543,25 +1519,25 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
         }
       }
       if (have) io.store(queue ? queue[idx] : idx, ray, hit, sc);
-      if (!ANY && st.markAlive && have && hit >= 0) st.markAlive[idx >> st.markShift] = 1;  // lazy sample generation: this 64-pixel group has a vertex
+      if (st.markAlive && have && hit >= 0) st.markAlive[idx >> st.markShift] = 1;  // lazy sample generation: this 64-pixel group has a vertex
     }
   }
   {  // (what THIS kernel traced, next to the totals: the bench line prices k_trace<0> and k_trace_pk separately)
     const unsigned long long r = wave_sum(lane == 0 ? nRays : 0u), nn = wave_sum(lane == 0 ? nNodes : 0u), t = wave_sum(nTris);
     if (lane == 0 && ctr && (r | nn | t) != 0ull) {
-      atomicAdd(&ctr->pk_rays[ANY], r);
-      atomicAdd(&ctr->pk_nodes[ANY], nn);
-      atomicAdd(&ctr->pk_tris[ANY], t);
+      atomicAdd(&ctr->pk_rays[0], r);
+      atomicAdd(&ctr->pk_nodes[0], nn);
+      atomicAdd(&ctr->pk_tris[0], t);
     }
 #ifdef DR_EXP_PK_STATS
-    if (lane == 0 && ctr && !ANY) {
+    if (lane == 0 && ctr) {
       atomicAdd(&ctr->pk_rays[1], (unsigned long long)xIter);
       atomicAdd(&ctr->pk_nodes[1], (unsigned long long)xMiss);
       atomicAdd(&ctr->pk_tris[1], (unsigned long long)xLeaf);
     }
 #endif
   }
-  flush_counters(ctr, ANY, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
+  flush_counters(ctr, 0, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
 }
 
 // ---------------------------------------------------------------------------
@@ -1607,10 +1583,9 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
 // wave-coherent kernel.  Returns false when this scene / build cannot use it (quadric primitives: k_trace_quad's tests).
 bool launch_trace_coherent(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit, uint32_t* workCounter,
                            TraceCounters* ctr, int grid, hipStream_t s) {
-  if (sc.nquads) return false;
+  if (sc.nquads || anyHit) return false;
   grid = std::min(grid, traceGridFor(DR_PK_WG_PER_CU));
-  if (anyHit) hipLaunchKernelGGL(k_trace_pk<1>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, queue, nQueue, workCounter, ctr);
-  else hipLaunchKernelGGL(k_trace_pk<0>, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, queue, nQueue, workCounter, ctr);
+  hipLaunchKernelGGL(k_trace_pk, dim3(grid), dim3(DR_TRACE_BLOCK), 0, s, sc, st, queue, nQueue, workCounter, ctr);
   return true;
 }
 int trace_kernel_id(const DScene& sc, int anyHit) {

@@ -212,17 +212,17 @@ def test_coherent_camera_kernel_equals_the_per_lane_kernels():
         "lib = _abi.lib()\n"
         "def both(prims, r, env=None):\n"
         "    scene = scenes.make_scene(prims, env); dev = scene._device(); films = []; stats = []\n"
-        "    for on, shadow in ((b'1', b'0'), (b'0', b'0'), (b'1', b'1')):\n"   # the last: the any-hit form (k_trace_pk<1>: a measured negative, kept for A/B)
-        "        _abi.check(lib.dr_set_option(b'COHERENT_CAMERA', on)); _abi.check(lib.dr_set_option(b'COHERENT_SHADOW', shadow))\n"
+        "    for on in (b'1', b'0'):\n"
+        "        _abi.check(lib.dr_set_option(b'COHERENT_CAMERA', on))\n"
         "        out = r.render(scene); films.append(out.film); stats.append(r.last_stats)\n"
-        "        info = dev.last_render_info(); assert (info['coherent_camera'], info['coherent_shadow']) == (int(on), int(shadow)), info\n"
+        "        info = dev.last_render_info(); assert info['coherent_camera'] == int(on), info\n"
         "        cs = dev.coherent_stats(); st_ = r.last_stats\n"   # the coherent kernel's share of the closest-hit totals: the camera rays, one launch per batch
         "        assert (cs['rays'], cs['launches']) == ((st_['camera_samples'], st_['batches']) if on == b'1' else (0, 0)), (cs, st_)\n"
         "        assert 0 <= cs['nodes'] <= st_['closest_nodes'] and 0 <= cs['tris'] <= st_['closest_tris'] and cs['ms'] <= st_['closest_ms'] + 1e-6\n"
-        "    _abi.check(lib.dr_set_option(b'COHERENT_CAMERA', None)); _abi.check(lib.dr_set_option(b'COHERENT_SHADOW', None))\n"
-        "    assert np.array_equal(films[0], films[1]) and np.array_equal(films[0], films[2])\n"
+        "    _abi.check(lib.dr_set_option(b'COHERENT_CAMERA', None))\n"
+        "    assert np.array_equal(films[0], films[1])\n"
         "    keys = ('closest_nodes', 'any_nodes', 'closest_tris', 'any_tris', 'closest_rays', 'any_rays')\n"
-        "    assert all(stats[0][k] == stats[1][k] == stats[2][k] for k in keys), (stats[0], stats[1], stats[2])\n"
+        "    assert all(stats[0][k] == stats[1][k] for k in keys), (stats[0], stats[1])\n"
         "    osc = ob.OracleScene(prims, env=env) if env is not None else ob.OracleScene(prims); osc.counters(reset=True)\n"
         "    ref = osc.render(ob.render_desc(r, sampler_mode=1)); c = osc.counters()\n"
         "    assert np.array_equal(films[0], ref['film']) and all(stats[0][k] == c[k] for k in keys), (stats[0], c)\n"
