@@ -97,7 +97,7 @@ const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
     "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_LAZY_GEN", "DARTRAY_SPLIT_WG", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP", "DARTRAY_LAYOUT_PILOT"};
+    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_LAZY_GEN", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_ANY8", "DARTRAY_CLOSEST_COLD", "DARTRAY_SCENE_PREP", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
 
 DrOpt dr_opt(const char* name) {
@@ -1518,8 +1518,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     HIP_TRY(sc->ws.roundA.alloc(sc->ws.cap));
     HIP_TRY(sc->ws.roundB.alloc(sc->ws.cap));
   }
-  const int tgridFull = traceGrid();
-  const int tgrid = tgridFull;
+  const int tgrid = traceGrid();
   rc = ensureSpill(sc, sc->ws, tgrid);
   if (rc) return rc;
   // the camera rays (a tile = 64 samples of one pixel) through the wave-coherent kernel k_trace_pk (DARTRAY_COHERENT_CAMERA=0: k_trace & co.)
@@ -1695,9 +1694,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     timed(3, evGen);
     uint32_t* C = w.counters.p;
     int wc = 0;  // work counters live at C[1024..], 8 per launch
-    auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr, bool coherent = false,
-                     int gridOverride = 0) {
-      const int tgrid = gridOverride > 0 ? std::min(gridOverride, tgridFull) : tgridFull;  // (shadows the render's grid for this launch)
+    auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr, bool coherent = false) {
       hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
       (void)hipEventRecord(e0, ts);
       bool tookCoherent = false;
@@ -1719,17 +1716,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // rays).  Side by side on two streams the any-hit workgroups take the CU slots the closest-hit launch frees as its
     // queue runs dry (a persistent launch ends with its longest rays).  Calibration batches time each launch alone.
     const bool sideBySide = overlapAny && !pilot;
-    // DARTRAY_SPLIT_WG=a,b (experiment): side by side, the closest-hit launch takes a and the any-hit launch b workgroups per CU from the
-    // start, instead of the any-hit workgroups waiting for the slots a full closest-hit grid frees at its end
-    int splitClosest = 0, splitAny = 0;
-    {
-      const DrOpt sw = dr_opt("DARTRAY_SPLIT_WG");
-      if (sw && sideBySide) {
-        const size_t comma = sw.value.find(',');
-        splitClosest = g_numCU * std::max(1, atoi(sw.value.c_str()));
-        splitAny = g_numCU * std::max(1, comma == std::string::npos ? 1 : atoi(sw.value.c_str() + comma + 1));
-      }
-    }
     // DirectLighting over mirror / glass: one round of the stage loop per vertex of a slot's ray tree; `roundQ` lists
     // the slots whose (camera or child) ray this round traces.  Everything else: one round.
     const uint32_t* roundQ = nullptr;
@@ -1823,12 +1809,12 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
           hipEvent_t eS = sc->getEvent(), eA = sc->getEvent();
           (void)hipEventRecord(eS, s);
           (void)hipStreamWaitEvent(sc->s3, eS, 0);
-          hipEvent_t closestEnd = trace(q.closestQ, q.nClosest, 0, s, w.spill.p, nullptr, false, splitClosest);
+          hipEvent_t closestEnd = trace(q.closestQ, q.nClosest, 0, s, w.spill.p);
           if (stageCounts && round == 0) {
             slog[b + 1].c0 = sc->traceEvents.back().e0;
             slog[b + 1].c1 = sc->traceEvents.back().e1;
           }
-          trace(q.anyQ, q.nAny, 1, sc->s3, w.spill.p + w.spillHalf, closestEnd, false, splitAny);
+          trace(q.anyQ, q.nAny, 1, sc->s3, w.spill.p + w.spillHalf, closestEnd);
           if (stageCounts && round == 0) {
             slog[b + 1].a0 = sc->traceEvents.back().e0;
             slog[b + 1].a1 = sc->traceEvents.back().e1;
