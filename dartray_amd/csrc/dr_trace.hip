@@ -773,7 +773,9 @@ DR_DEV uint32_t pack_ref(uint32_t ref, uint32_t meta) {
 // COLD (k_trace3c): direction, minDistance, maxDistance and the queue handle wait in 8 LDS rows per lane (`cold`) between the refill,
 // the leaf tests, the rare literal slab tests and the result store, as in k_trace / k_trace3a: they are re-read in front of every use
 // (reloadCold), so the loop that sets the occupancy does not hold them in registers.
-template <int ANY, class IO, bool COLD = false, int PSTACK = DR_PSTACK>
+// Closest-hit rays only (BVHAccel.intersect); the any-hit rays have their own 4-byte-entry form, trace_pairs_any below.  (Round 3's
+// any-hit instantiation of this function -- k_trace3<1>, DARTRAY_ANY8 -- is experiments/r06_pair_kernel_any8.diff.)
+template <class IO, bool COLD = false, int PSTACK = DR_PSTACK>
 DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ldsRef, float* ldsE, uint32_t* spill,
                         uint32_t spillStride, uint32_t spillHalf, uint32_t* work, TraceCounters* ctr, uint32_t* cold = nullptr) {
   typedef __attribute__((address_space(3))) uint32_t cold_u32;
@@ -823,25 +825,9 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
     ++sp;
     SPROF_PUSH();
   };
-  // A far child that can never be hit still is ONE visit when the reference pops it.  Closest-hit rays pop
-  // every entry sooner or later, so the visit is counted right away and nothing is pushed; any-hit rays may
-  // stop early, so they push a DEAD entry -- consecutive ones merged into one entry whose E field is a count.
-  auto pushDead = [&]() {
-    if (!ANY) {
-      ++nNodes;
-      return;
-    }
-    if (sp > 0) {
-      uint32_t r;
-      float c;
-      stackGet(sp - 1, &r, &c);
-      if (r == PREF_DEAD) {
-        stackSet(sp - 1, PREF_DEAD, __uint_as_float(__float_as_uint(c) + 1u));
-        return;
-      }
-    }
-    push(PREF_DEAD, __uint_as_float(1u));
-  };
+  // A far child that can never be hit still is ONE visit when the reference pops it.  Closest-hit rays pop every entry
+  // sooner or later, so the visit is counted right away and nothing is pushed.
+  auto pushDead = [&]() { ++nNodes; };
   // maxDistance just shrank (closest hit only): drop every entry that is now certainly beyond it and count
   // its visit -- the reference would pop and reject each of them later, with no other effect.  What stays on
   // the stack survives its pop (up to the ambiguous band), so pops never turn into long chains.
@@ -871,10 +857,6 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       uint32_t ref;
       float e;
       stackGet(sp, &ref, &e);
-      if (ref == PREF_DEAD) {
-        nNodes += __float_as_uint(e);  // merged dead entries (any-hit rays only)
-        continue;
-      }
       ++nNodes;
       const float R = 4.76837158203125e-07f, A = 1.0e-37f;
       const float eb = __fmaf_rn(fabsf(e), R, A);
@@ -966,7 +948,7 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
       reloadCold();
       if constexpr (COLD) handle = COLD_LD(5);
       io.store(handle, ray, hit, sc);
-      SPROF_RAY(ANY);
+      SPROF_RAY(0);
       mode = M_IDLE;
     }
     if (MODE_IS(M_EXPAND)) {
@@ -1053,25 +1035,18 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
           alive = slab_f64(ray, x0, y0, z0, x1, y1, z1);
           mode &= 3;
         }
-        bool occluded = false, shrunk = false;
+        bool shrunk = false;
         if (alive) {
           for (uint32_t i = 0; i < leafN; ++i) {
             ++nTris;
             const float4* tp = sc.tris + 3 * (size_t)(leafOff + i);
             const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
             const F3 p1 = F3{q0.x, q0.y, q0.z}, p2 = F3{q0.w, q1.x, q1.y}, p3 = F3{q1.z, q1.w, q2.x};
-            if (ANY) {
-              if (tri_hitP(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax)) {
-                occluded = true;
-                break;
-              }
-            } else {
-              double t, b1, b2;
-              if (tri_hit(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax, &t, &b1, &b2)) {
-                ray_set_tmax(ray, t);
-                hit = (int)(leafOff + i);
-                shrunk = true;
-              }
+            double t, b1, b2;
+            if (tri_hit(p1, p2, p3, ray.o, ray.d, ray.tmin, ray.tmax, &t, &b1, &b2)) {
+              ray_set_tmax(ray, t);
+              hit = (int)(leafOff + i);
+              shrunk = true;
             }
           }
         }
@@ -1082,17 +1057,12 @@ DR_DEV void trace_pairs(const DScene& sc, const IO& io, uint32_t n, uint32_t* ld
           }
           pruneStack();
         }
-        if (occluded) {
-          hit = 0;
-          finished = true;
-        } else if (!popNext()) {
-          finished = true;
-        }
+        if (!popNext()) finished = true;
       }
     }
     if (finished) mode = M_DONE;  // stored at the head of the next iteration
   }
-  flush_counters(ctr, ANY, lane_id() == 0 ? nRays : 0u, nNodes, nTris);
+  flush_counters(ctr, 0, lane_id() == 0 ? nRays : 0u, nNodes, nTris);
 #undef MODE_IS
 #undef M_RETEST
 }
@@ -1103,10 +1073,11 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_trace3(DSce
                                                                             uint32_t* work, TraceCounters* ctr) {
   __shared__ uint32_t s_ref[DR_PSTACK * DR_TRACE_BLOCK];
   __shared__ float s_e[DR_PSTACK * DR_TRACE_BLOCK];
-  StateIO<ANY> io{st, queue};
+  static_assert(ANY == 0, "closest-hit rays only: the any-hit pair kernel is k_trace3a");
+  StateIO<0> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
   const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
-  trace_pairs<ANY>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride, stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
+  trace_pairs(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride, stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
 }
 template <int ANY>
 __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_intersect3(DScene sc, const DrRay* rays, uint32_t n,
@@ -1114,9 +1085,10 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3_WAVES) k_intersect3(
                                                                                 TraceCounters* ctr) {
   __shared__ uint32_t s_ref[DR_PSTACK * DR_TRACE_BLOCK];
   __shared__ float s_e[DR_PSTACK * DR_TRACE_BLOCK];
-  RayIO<ANY> io{rays, out};
+  static_assert(ANY == 0, "closest-hit rays only: the any-hit pair kernel is k_intersect3a");
+  RayIO<0> io{rays, out};
   const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
-  trace_pairs<ANY>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride, stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
+  trace_pairs(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride, stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK), work, ctr);
 }
 
 // k_trace3c: the closest-hit pair traversal with its cold ray state in LDS.  Stacks are shallow -- on C4 98.8 % of the closest-hit
@@ -1137,7 +1109,7 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_TRACE3C_WAVES) k_trace3c(DS
   StateIO<0> io{st, queue};
   const uint32_t n = nQueue ? *nQueue : st.nslots;
   const uint32_t stride = gridDim.x * DR_TRACE_BLOCK;
-  trace_pairs<0, StateIO<0>, true, DR_PSTACK_C>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride,
+  trace_pairs<StateIO<0>, true, DR_PSTACK_C>(sc, io, n, s_ref + threadIdx.x, s_e + threadIdx.x, spill, stride,
                                                stride * (uint32_t)(DR_MAX_STACK - DR_PSTACK_C), work, ctr, s_cold + threadIdx.x);
 }
 
@@ -1543,14 +1515,6 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
 // ---------------------------------------------------------------------------
 // launchers.  DARTRAY_TRACE_IMPL selects the kernel for A/B runs: 2 = k_trace, 3 = sibling pairs, 5 = 3 with k_trace3c.
 // ---------------------------------------------------------------------------
-// A/B: DARTRAY_ANY8=1 keeps the 8-byte (reference, entry parameter) any-hit kernel of round 3 (k_trace3<1>)
-static bool any8() {
-  return dr_opt("DARTRAY_ANY8").nonZero();
-}
-// A/B: DARTRAY_CLOSEST_COLD=1 runs the closest-hit pair traversal with its cold ray state in LDS (k_trace3c)
-static bool coldClosest() {
-  return dr_opt("DARTRAY_CLOSEST_COLD").nonZero();
-}
 // Kernel ids (DScene.traceKernel, DARTRAY_TRACE_IMPL, dr_scene_set_trace_kernels): 2 k_trace, 3 sibling pairs (k_trace3<0> /
 // k_trace3a), 5 sibling pairs with the closest-hit rays' cold state in LDS (k_trace3c; the any-hit rays: k_trace3a as with 3).  Returned
 // here: 2 / 3, with `*cold` set for id 5 on closest-hit rays.
@@ -1561,7 +1525,7 @@ static int traceImpl(const DScene& sc, int anyHit, int force = 0, bool* cold = n
   // unless DARTRAY_TRACE_IMPL fixes it, the choice is the one measured for this scene (sc.traceKernel, set by the
   // pilot of dr_render_device)
   int impl = force ? force : (env ? env : (sc.traceKernel[anyHit ? 1 : 0] ? (int)sc.traceKernel[anyHit ? 1 : 0] : 2));
-  if (cold) *cold = !anyHit && (impl == 5 || (impl == 3 && coldClosest()));
+  if (cold) *cold = !anyHit && impl == 5;
   if (impl == 5) impl = 3;
   if (sc.nquads) return 2;                     // only v2 tests quadric primitives
   return (impl == 3 && !sc.pairs) ? 2 : impl;  // scenes the pair layout cannot encode use v2
@@ -1571,8 +1535,7 @@ void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out
   const dim3 g(grid), b(DR_TRACE_BLOCK);
   const int impl = traceImpl(sc, anyHit, forceImpl);
   if (impl == 3) {
-    if (anyHit && any8()) hipLaunchKernelGGL(k_intersect3<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
-    else if (anyHit) hipLaunchKernelGGL(k_intersect3a, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
+    if (anyHit) hipLaunchKernelGGL(k_intersect3a, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_intersect3<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
   } else {
     if (anyHit) hipLaunchKernelGGL(k_intersect<1>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
@@ -1597,12 +1560,11 @@ void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
   bool cold = false;
   const int impl = traceImpl(sc, anyHit, 0, &cold);
-  if (impl == 3) grid = std::min(grid, traceGridFor(anyHit ? (any8() ? DR_TRACE3_WAVES : DR_TRACE3A_WAVES) : (cold ? DR_TRACE3C_WAVES : DR_TRACE3_WAVES)));  // k_trace3: 30 KiB of LDS, 5 resident; k_trace3a: 22 KiB, 7; k_trace3c: 26 KiB, 6
+  if (impl == 3) grid = std::min(grid, traceGridFor(anyHit ? DR_TRACE3A_WAVES : (cold ? DR_TRACE3C_WAVES : DR_TRACE3_WAVES)));  // k_trace3: 30 KiB of LDS, 5 resident; k_trace3a: 22 KiB, 7; k_trace3c: 26 KiB, 6
   else if (!(impl == 2 && !sc.nquads)) grid = std::min(grid, traceGridFor(6));  // only k_trace fits 7 workgroups per CU
   const dim3 g(grid), b(DR_TRACE_BLOCK);
   if (impl == 3) {
-    if (anyHit && any8()) hipLaunchKernelGGL(k_trace3<1>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
-    else if (anyHit) hipLaunchKernelGGL(k_trace3a, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
+    if (anyHit) hipLaunchKernelGGL(k_trace3a, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else if (cold) hipLaunchKernelGGL(k_trace3c, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_trace3<0>, g, b, 0, s, sc, st, queue, nQueue, spill, workCounter, ctr);
   } else if (sc.nquads) {

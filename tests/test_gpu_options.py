@@ -42,12 +42,12 @@ def test_switches_set_through_the_c_abi_do_not_clobber_each_other():
         "assert np.array_equal(f, ref)\n"
         "opt('STATE_LAYOUT', 64); f = r.render(scene).film; assert dev.last_render_info()['state_layout'] == 64\n"
         "opt('STATE_LAYOUT', None); opt('LAYOUT_PILOT', None); opt('VERBOSE', None)\n"
-        # kernel switches: the pair kernels with the cold-state closest-hit variant, then round 3's 8-byte any-hit kernel beside it
-        "opt('TRACE_IMPL', 3); opt('CLOSEST_COLD', 1); opt('OVERLAP_ANY', 0)\n"
+        # kernel switches: the pair kernels with the cold-state closest-hit variant
+        "opt('TRACE_IMPL', 5); opt('OVERLAP_ANY', 0)\n"
         "f = r.render(scene).film; info = dev.last_render_info()\n"
         "assert (info['closest_kernel'], info['any_hit_kernel'], info['overlap_any']) == (5, 3, 0), info\n"
         "assert np.array_equal(f, ref)\n"
-        "opt('CLOSEST_COLD', None); opt('OVERLAP_ANY', None); opt('TRACE_IMPL', 2); opt('TRACE_WG_PER_CU', 5)\n"
+        "opt('OVERLAP_ANY', None); opt('TRACE_IMPL', 2); opt('TRACE_WG_PER_CU', 5)\n"
         "f = r.render(scene).film; info = dev.last_render_info()\n"
         "assert (info['closest_kernel'], info['any_hit_kernel'], info['trace_wg_per_cu'], info['overlap_any']) == (2, 2, 5, 1), info\n"
         "assert np.array_equal(f, ref)\n"

@@ -263,17 +263,13 @@ def test_render_is_deterministic_and_device_film_accumulates(gpu):
     assert np.array_equal(film.cpu().numpy(), a.film) and np.array_equal(rgb.cpu().numpy(), a.rgb)
 
 
-@pytest.mark.parametrize("impl", ["3", "3:any8", "3:cold"])
+@pytest.mark.parametrize("impl", ["3", "5"])
 def test_alternative_traversal_kernels_are_bit_exact_too(impl):
-    """DARTRAY_TRACE_IMPL selects the sibling-pair kernels (3: k_trace3<0> + the 4-byte-entry
-    any-hit kernel k_trace3a; any8: round 3's 8-byte any-hit kernel) for A/B runs; all must reproduce the oracle's hits,
-    visit counts and image exactly, like the default (2).  (The treelet-parked traversal of round 4 -- a measured negative --
-    lives in experiments/r06_treelet_parked_traversal.diff.)"""
+    """DARTRAY_TRACE_IMPL selects the sibling-pair kernels (3: k_trace3<0> + the 4-byte-entry any-hit kernel k_trace3a; 5: the
+    closest-hit rays through k_trace3c, cold ray state in LDS) for A/B runs; all must reproduce the oracle's hits, visit counts
+    and image exactly, like the default (2).  (Round 1's first kernels, round 3's 8-byte any-hit pair kernel and round 4's
+    treelet-parked traversal -- measured negatives -- live in experiments/r06_*.diff.)"""
     extra = {}
-    if impl == "3:any8":
-        impl, extra = "3", {"DARTRAY_ANY8": "1"}
-    elif impl == "3:cold":  # k_trace3c: the closest-hit pair kernel with its cold ray state in LDS
-        impl, extra = "3", {"DARTRAY_CLOSEST_COLD": "1"}
     import subprocess
     import sys
     code = (
