@@ -530,10 +530,6 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short C4 / C5 runs appended at N = 1")
-    ap.add_argument("--pipelines", type=int, default=1, choices=[1, 2],
-                    help="2: odd batches run on a second stream / workspace (kernel tails and memory-bound shading overlap "
-                         "the ALU-bound traversal) -- per-kernel event times then overlap, so the roofline "
-                         "object is only meaningful with 1")
     ap.add_argument("--scaling", default=None, choices=["c3", "weak", "strong-c2", "samples"],
                     help="N > 1: c3 (default) = BASELINE configs[2] verbatim, tiles of the 4096^2 x 1024 spp image over the N ranks; weak = "
                          "tiles of the C2 image with N x the pixels (the N = 1 workload per GPU); strong-c2 = tiles of the 1024^2 image; "
@@ -552,7 +548,6 @@ def main():
     if check_world(args.gpus, int(os.environ.get("WORLD_SIZE", "0"))) == "launch":
         launch_ranks(args)
 
-    os.environ["DARTRAY_PIPELINES"] = str(args.pipelines)  # read once by the library
     import torch
     from dartray_amd import _abi, scenes, dist as drdist
 
@@ -758,7 +753,7 @@ class Run:
                                          "pilot_ms_per_alg_GB": {"closest": {str(k): round(v, 4) for k, v in pc.items()},
                                                                  "any_hit": {str(k): round(v, 4) for k, v in pa.items()}},
                                          "near_ties": near},
-                       "samples_per_step": samples_per_step, "parallelism": par, "pipelines": args.pipelines,
+                       "samples_per_step": samples_per_step, "parallelism": par,
                        "sampler_mode": "DR_SAMPLER_COUNTER (keyed per-pixel streams, bit-exact vs the oracle's same mode); the reference's "
                                        "single serial Random(taskNum) stream is replayed bit-exactly through DR_SAMPLER_HOST_BUFFER in the "
                                        "tests but is not a throughput mode (one serial stream; 148 B + RNG tail per sample over PCIe)"},
@@ -801,7 +796,7 @@ class Run:
             out["film_bytes_reduced_per_step"] = int(self.H * self.W * 16)
             out["one_gpu_same_workload"] = one_gpu_reference(self.mode, self.cfg)
         tp = profiled_traffic(self.cfg)
-        if tp and world == 1 and args.pipelines == 1 and not os.environ.get("DARTRAY_BATCH_BITS"):
+        if tp and world == 1 and not os.environ.get("DARTRAY_BATCH_BITS"):
             out["traffic_profiled"] = tp
             # roofline.traffic: the memory-side bytes per launch of the SAME kernel from the committed --pmc passes of this command (counters
             # cannot be read inside a timed run: the guide's separate passes) -- null when the passes profiled another kernel than this run ran

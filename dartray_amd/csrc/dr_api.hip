@@ -95,7 +95,7 @@ std::mutex g_optMutex;
 std::map<std::string, std::string> g_options;  // name -> value; an empty value = "unset for this process" (hides the environment's)
 const char* const kOptionNames[] = {
     "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
-    "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_PIPELINES", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
+    "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
     "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
     "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_LAZY_GEN", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_SCENE_PREP", "DARTRAY_LAYOUT_PILOT"};
 }  // namespace
@@ -150,10 +150,6 @@ struct DrScene {
   int dlNBlocks = 0, dlNStages = 0, dlNFloats = 0, dlN1D = 0;
   bool dlMulti = false;
   Workspace ws;
-  // optional second pipeline (DARTRAY_PIPELINES=2): odd batches run on their own stream and workspace so that
-  // one batch's kernel tails / memory-bound shading overlap the other's ALU-bound traversal
-  Workspace ws2;
-  hipStream_t s2 = nullptr;
   hipStream_t s3 = nullptr;  // the any-hit launches of a stage, beside the closest-hit ones
   // stats of the last render
   DrRenderStats stats;
@@ -209,7 +205,6 @@ struct DrScene {
   ~DrScene() {
     (void)hipDeviceSynchronize();  // nothing of this scene may still be in flight when its buffers and events go away
     for (auto e : eventPool) (void)hipEventDestroy(e);
-    if (s2) (void)hipStreamDestroy(s2);
     if (s3) (void)hipStreamDestroy(s3);
   }
 };
@@ -1470,7 +1465,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   sf.nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
   sf.idxShift = spp > 256 ? 1 : 0;
   const int slotBits = std::min(28, std::max(16, dr_opt("DARTRAY_BATCH_BITS").toInt(28)));
-  const int nPipesEnv = dr_opt("DARTRAY_PIPELINES").toInt(1);
   uint64_t maxSlots = 1ull << slotBits;  // camera samples in flight per batch
   {
     // path state per camera sample: 164 B of ray / hit / NEE state, 20 B of queues and the sample vector (24 B of
@@ -1486,19 +1480,17 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
                              (dlSpec ? (uint64_t)std::max(1, rd->max_depth) * sizeof(SpecFrame) + 12 : 0);
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)sc->ws.stateWords * 4 + sc->ws.svWords / 16 + 20) +
-                            (uint64_t)sc->ws2.cap * ((uint64_t)sc->ws2.stateWords * 4 + sc->ws2.svWords / 16 + 20);
+      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)sc->ws.stateWords * 4 + sc->ws.svWords / 16 + 20);
       const uint64_t budget = (uint64_t)(0.9 * (double)freeB) + have;
-      const uint64_t pipes = nPipesEnv >= 2 && !hostBuf ? 2 : 1;
       // (+ 1/4: the slack that lets a slightly larger window still go as one batch, below)
-      while (maxSlots > (1ull << 16) && std::min<uint64_t>(maxSlots + maxSlots / 4, (uint64_t)npixTotal * spp) * perSlot * pipes > budget) maxSlots >>= 1;
+      while (maxSlots > (1ull << 16) && std::min<uint64_t>(maxSlots + maxSlots / 4, (uint64_t)npixTotal * spp) * perSlot > budget) maxSlots >>= 1;
     }
   }
   // Equal batches, and no tiny tail batch: every stage launch costs ~0.4 ms of ramp-up and tail however small it is
   // (the sampler window of a 1024 x 1024 film is 1025 x 1025 pixels -- 2^20 + 2049).
   uint64_t pixCapBatch = std::max<uint64_t>(1, maxSlots / spp);
   uint64_t nBatches = (npixTotal + pixCapBatch - 1) / pixCapBatch;
-  if (nBatches > 1 && npixTotal <= pixCapBatch + pixCapBatch / 4 && !(nPipesEnv >= 2 && !hostBuf)) nBatches = 1;
+  if (nBatches > 1 && npixTotal <= pixCapBatch + pixCapBatch / 4) nBatches = 1;
   const uint32_t pixPerBatch = (uint32_t)((npixTotal + nBatches - 1) / nBatches);
   const uint32_t cap = pixPerBatch * (uint32_t)spp;
   const auto tAlloc0 = std::chrono::steady_clock::now();
@@ -1528,16 +1520,8 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // per-(pixel, block) streams (a block that is left out disturbs no other) and k_trace_pk's marks of the camera rays that hit
   const bool lazyGen = !hostBuf && sf.compact && rp.genMask != 0ull && rd->integrator == DR_INTEGRATOR_PATH && coherentCamera &&
                        !sc->d.nquads && spp >= 64 && !dr_opt("DARTRAY_LAZY_GEN").isZero();
-  const bool overlapAny = overlapEnv && !dlSpec && !(nPipesEnv >= 2);
+  const bool overlapAny = overlapEnv && !dlSpec;
   if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
-  const bool twoPipes = nPipesEnv >= 2 && !hostBuf && !dlSpec && npixTotal > pixPerBatch;
-  if (twoPipes) {
-    rc = allocWorkspace(sc, sc->ws2, cap, sf, pixPerBatch, rd->max_tail, false, maxStateWords);
-    if (rc) return rc;
-    rc = ensureSpill(sc, sc->ws2, tgrid);
-    if (rc) return rc;
-    if (!sc->s2) HIP_TRY(hipStreamCreateWithFlags(&sc->s2, hipStreamNonBlocking));
-  }
   // Which traversal kernel?  v2 (one node per step, f32 filter) is issue bound and wins while the hot part of the tree
   // stays in cache; v3 (sibling pairs, half the dependent fetches) wins on big incoherent trees (C4 hairball +26 %)
   // and loses on others of the same size (C5 courtyard: closest -8 %, any hit -33 %); random probe rays mispredict
@@ -1550,7 +1534,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // Both kernels are bit-exact, so results do not depend on the choice; dr_scene_set_trace_kernels / DARTRAY_TRACE_IMPL fix it.
   const bool pilotOff = dr_opt("DARTRAY_PILOT").isZero();
   const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || dr_opt("DARTRAY_PILOT_FORCE").set;
-  const bool pilotOk = !pilotOff && !hostBuf && !dlSpec && bigJob && npixTotal >= 3 * 64 * 4 && !(nPipesEnv >= 2);
+  const bool pilotOk = !pilotOff && !hostBuf && !dlSpec && bigJob && npixTotal >= 3 * 64 * 4;
   const bool calibrateTrace = !sc->traceCalibrated && pilotOk && !dr_opt("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads;
   const bool measureLayout = !layoutKnown && pilotOk;
   if (measureLayout) Lp = &kLayout64;  // the batch whose stage lists are measured runs in the 64-slot layout (the header's and the comment's claim)
@@ -1586,19 +1570,11 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   HIP_TRY(hipMemcpyAsync(sc->ws.filterTable.p, rd->film.filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s));
   // pixels is a local: the async copy above must complete before it goes out of scope
   HIP_TRY(hipStreamSynchronize(s));
-  hipStream_t const callerStream = s;
-  if (twoPipes) {  // everything enqueued on the caller's stream so far (e.g. the film clear) precedes the second pipeline
-    hipEvent_t ev = sc->getEvent();
-    HIP_TRY(hipEventRecord(ev, callerStream));
-    HIP_TRY(hipStreamWaitEvent(sc->s2, ev, 0));
-  }
-  size_t batchIndex = 0;
   const int sgrid = g_numCU;  // the shade launchers size their grid per CU (DR_SHADE_GRID), grid-stride over the active list
   const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
   if (nStages > 248 || 8 * DR_WORK_STRIDE * (1 + 2 * nStages) > N_COUNTERS_TRACE - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
   if (envStage) {
     HIP_TRY(sc->ws.envQ.alloc(sc->ws.cap));
-    if (twoPipes) HIP_TRY(sc->ws2.envQ.alloc(sc->ws2.cap));
   }
 
   // One batch through the stage loop.  pilot != null: a calibration batch -- a normal batch whose traversal launches are
@@ -2013,7 +1989,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     HIP_TRY(hipEventRecord(evP1, s));
     sc->traceEvents.push_back({evP0, evP1, 5});  // DrRenderStats.pilot_ms: the time of the calibration batches
     firstPix = (size_t)setsRun * calibPix;  // (a set that was skipped left its pixels to the ordinary batches)
-    batchIndex = (size_t)setsRun;
     pilotBatchesRun = setsRun;
     if (calibrateTrace && dr_opt("DARTRAY_VERBOSE"))
       fprintf(stderr, "dartray_hip: traversal pilot (%d x %zu samples, rendered into the film), ms per algorithmic GB: closest v2 %.4f / v3 %.4f / v3c %.4f -> v%u; "
@@ -2021,18 +1996,10 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
               perByte[1][0], perByte[1][1], sc->d.traceKernel[1]);
   }
 
-  for (size_t p0 = firstPix; p0 < npixTotal; p0 += pixPerBatch, ++batchIndex) {
-    const bool second = twoPipes && (batchIndex & 1);
-    s = second ? sc->s2 : callerStream;
+  for (size_t p0 = firstPix; p0 < npixTotal; p0 += pixPerBatch) {
     const uint32_t np = (uint32_t)std::min<size_t>(pixPerBatch, npixTotal - p0);
-    int brc = runBatch(second ? sc->ws2 : sc->ws, sc->ws.pix.p + p0, p0, np, nullptr);
+    int brc = runBatch(sc->ws, sc->ws.pix.p + p0, p0, np, nullptr);
     if (brc) return brc;
-  }
-  s = callerStream;
-  if (twoPipes) {  // the caller's stream continues after both pipelines
-    hipEvent_t ev = sc->getEvent();
-    HIP_TRY(hipEventRecord(ev, sc->s2));
-    HIP_TRY(hipStreamWaitEvent(callerStream, ev, 0));
   }
   HIP_TRY(hipEventRecord(evStop, s));
   sc->stats.camera_samples += (uint64_t)npixTotal * spp;

@@ -66,7 +66,7 @@ def test_full_size_c4_hairball_both_traversal_kernels(ob, gpu):
     out = r.render(scene)
     dev = scene._device()
     picked = dev.trace_kernels()
-    if not any(os.environ.get(k) for k in ("DARTRAY_PIPELINES", "DARTRAY_PILOT", "DARTRAY_TRACE_IMPL")):  # (two pipelines run no pilot)
+    if not any(os.environ.get(k) for k in ("DARTRAY_PILOT", "DARTRAY_TRACE_IMPL")):
         assert picked[0] in (2, 3, 5) and picked[1] in (2, 3)
         assert r.last_stats["pilot_ms"] > 0
     w = out.film[..., 3]

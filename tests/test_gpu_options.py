@@ -183,13 +183,11 @@ def test_lazy_sample_generation_leaves_the_film_alone():
         "    spp = int(rng.choice([64, 128, 256])); res = (int(rng.integers(17, 50)), int(rng.integers(9, 40)))\n"
         "    prims5, mk5 = scenes.config('C5', xres=res[0], yres=res[1], spp=spp, yard=(int(rng.integers(2, 6)), int(rng.integers(4, 14))), env_res=(64, 32))\n"
         "    r5 = mk5(); r5.surfaceIntegrator.maxDepth = int(rng.integers(1, 9)); both(prims5, r5, r5.env, True)\n"
-        # several batches whose pixel counts are no multiples of 64 (the last group of a batch is partial), on one and on two pipelines
-        # (the second has its own workspace and its own marks)
+        # several batches whose pixel counts are no multiples of 64 (the last group of a batch is partial)
         "prims5, mk5 = scenes.config('C5', xres=70, yres=50, spp=64, yard=(4, 12), env_res=(64, 32)); r5 = mk5()\n"
-        "for pipes in (b'1', b'2'):\n"
-        "    _abi.check(lib.dr_set_option(b'BATCH_BITS', b'16')); _abi.check(lib.dr_set_option(b'PIPELINES', pipes))\n"
-        "    info = both(prims5, r5, r5.env, pipes == b'1'); assert info['batches'] > 2, info\n"
-        "_abi.check(lib.dr_set_option(b'BATCH_BITS', None)); _abi.check(lib.dr_set_option(b'PIPELINES', None))\n"
+        "_abi.check(lib.dr_set_option(b'BATCH_BITS', b'16'))\n"
+        "info = both(prims5, r5, r5.env, True); assert info['batches'] > 2, info\n"
+        "_abi.check(lib.dr_set_option(b'BATCH_BITS', None))\n"
         # the courtyard under the sky: whole groups of pixels see only sky (no bounce-0 blocks) and fewer still reach bounce 2
         "assert frac[0] < 0.9 and frac[1] == 1.0 and all(f == 1.0 for f in frac[1::2]), frac\n"
         "print('OK', frac)\n" % (ROOT, os.path.join(ROOT, "tests")))

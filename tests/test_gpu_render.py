@@ -290,7 +290,6 @@ def test_alternative_traversal_kernels_are_bit_exact_too(impl):
     assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
 
 
-@pytest.mark.skipif(os.environ.get("DARTRAY_PIPELINES", "1") not in ("", "1"), reason="two pipelines run no pilot (by design)")
 def test_traversal_pilot_leaves_results_and_counters_untouched():
     """The first big render of a big scene times both traversal kernels on a sample of its own rays
     (dr_render_device's pilot) before rendering; forced here on a small scene: film and visit counters must equal
@@ -315,30 +314,6 @@ def test_traversal_pilot_leaves_results_and_counters_untouched():
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)
     assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
     assert res.stderr.count("traversal pilot") == 1, res.stderr[-2000:]   # once per scene
-
-
-def test_two_pipelines_render_the_same_film():
-    """DARTRAY_PIPELINES=2 (odd batches on a second stream and workspace) only changes scheduling: a render that
-    needs several batches gives the same film as the single-pipeline run."""
-    import subprocess
-    import sys
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "from dartray_amd import scenes\n"
-        "prims, mk = scenes.config('C2', xres=600, yres=500, spp=128, blob=(60, 30))\n"   # 3e5 pixels x 128 spp: 3 batches
-        "r = mk(); out = r.render(scenes.make_scene(prims))\n"
-        "assert r.last_stats['batches'] >= 3, r.last_stats['batches']\n"
-        "np.save(sys.argv[1], out.film)\n" % ROOT)
-    films = []
-    for pipes in ("1", "2"):
-        path = os.path.join(ROOT, "gpurun_out", "film_p%s.npy" % pipes)
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        env = dict(os.environ, DARTRAY_PIPELINES=pipes, DARTRAY_BATCH_BITS="24")  # 2^24 samples per batch => 3 batches
-        res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=500)
-        assert res.returncode == 0, res.stderr[-2000:]
-        films.append(np.load(path))
-        os.remove(path)
-    assert np.array_equal(films[0], films[1])
 
 
 def test_both_state_layouts_render_the_same_film():
@@ -370,10 +345,9 @@ def test_both_state_layouts_render_the_same_film():
     assert np.array_equal(out[0], out[1]) and out[0].any()
 
 
-def test_env_map_kernel_over_several_batches_and_two_pipelines():
+def test_env_map_kernel_over_several_batches():
     """k_env (the environment-map work of a plain-triangle scene's path stages, with its own list per stage and batch) when
-    a render needs several batches, on one and on two pipelines (the second workspace has its own list): same film, and
-    the same as the single-batch render."""
+    a render needs several batches: the same film as the single-batch render."""
     import subprocess
     import sys
     code = (
@@ -384,17 +358,17 @@ def test_env_map_kernel_over_several_batches_and_two_pipelines():
         "print('batches', r.last_stats['batches'])\n"
         "np.save(sys.argv[1], out.film)\n" % ROOT)
     films = []
-    for pipes, bits in (("1", "28"), ("1", "20"), ("2", "20")):
-        path = os.path.join(ROOT, "gpurun_out", "film_env_p%s_%s.npy" % (pipes, bits))
+    for bits in ("28", "20"):
+        path = os.path.join(ROOT, "gpurun_out", "film_env_%s.npy" % bits)
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        env = dict(os.environ, DARTRAY_PIPELINES=pipes, DARTRAY_BATCH_BITS=bits)
+        env = dict(os.environ, DARTRAY_BATCH_BITS=bits)
         res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=500)
         assert res.returncode == 0, res.stderr[-2000:]
         if bits == "20":
             assert int(res.stdout.split("batches")[1].split()[0]) >= 4, res.stdout
         films.append(np.load(path))
         os.remove(path)
-    assert np.array_equal(films[0], films[1]) and np.array_equal(films[0], films[2])
+    assert np.array_equal(films[0], films[1])
 
 
 def test_unread_sample_blocks_can_be_left_out():
@@ -505,7 +479,6 @@ def test_full_size_c2_properties_and_sparse_parity(ob, gpu):
         assert np.array_equal(out.film[y, x], ref["film"][y, x])
 
 
-@pytest.mark.skipif(os.environ.get("DARTRAY_PIPELINES", "1") not in ("", "1"), reason="two pipelines run no pilot (by design)")
 def test_state_layout_is_chosen_from_the_pilot_batch_densities():
     """the path-state layout of a scene comes from what its first pilot batch measured -- the share of
     slots still alive at the second bounce -- not from a property of its lights.  C2-like box: dense lists -> 64-slot runs; the
@@ -555,12 +528,10 @@ def _serial_recording(ob, prims, r, spp, max_tail=40):
     return rec, n
 
 
-@pytest.mark.parametrize("pipelines", [b"1", b"2"])
-def test_serial_stream_replay_across_several_batches(ob, gpu, pipelines):
+def test_serial_stream_replay_across_several_batches(ob, gpu):
     """the host-buffer staging hand-over between batches (include/dartray_hip.h: the sample buffers of
     a batch are staged before the next batch reuses the area).  A recorded serial stream of 129 x 129 x 16 = 266 256 samples
-    replayed with at most 2^16 slots per batch -- five batches -- equals the recording; DARTRAY_PIPELINES=2 is accepted (host
-    buffers always run on one pipeline)."""
+    replayed with at most 2^16 slots per batch -- five batches -- equals the recording."""
     prims, mk = scenes.config("C2", xres=128, yres=128, spp=16, blob=(40, 20))
     r = mk()
     rec, n = _serial_recording(ob, prims, r, 16)
@@ -573,12 +544,10 @@ def test_serial_stream_replay_across_several_batches(ob, gpu, pipelines):
     assert r.last_stats["batches"] == 1
     try:
         _abi.check(lib.dr_set_option(b"BATCH_BITS", b"16"))
-        _abi.check(lib.dr_set_option(b"PIPELINES", pipelines))
         out = r.render(scene)
         assert r.last_stats["batches"] == 5
     finally:
         _abi.check(lib.dr_set_option(b"BATCH_BITS", None))
-        _abi.check(lib.dr_set_option(b"PIPELINES", None))
     assert np.array_equal(out.film, rec["film"]) and np.array_equal(out.rgb, rec["rgb"])
     assert np.array_equal(whole.film, rec["film"])
     # the PACKED form of the tail (DrRenderDesc.tail_offsets: only the values a sample drew cross the host link), whole and
