@@ -1733,18 +1733,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
       q.ctr = sc->ctr.p;
       q.envQ = envStage ? w.envQ.p : nullptr;
       q.nEnv = C + N_COUNTERS_TRACE + 64 * b;
-#ifdef DR_EXP_SORT_LISTS
-      if (b > 0 && rd->integrator == DR_INTEGRATOR_PATH) {  // timing experiment: the stage's list in slot order (outside the shade events)
-        static DevBuf<uint32_t> sorted;
-        static DevBuf<unsigned char> tmp;
-        uint32_t nIn = 0;
-        HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipMemcpy(&nIn, q.nActiveIn, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(sorted.alloc(w.cap));
-        HIP_TRY(tmp.alloc((size_t)w.cap * 12 + (1u << 20)));
-        if (nIn > 1 && exp_sort_list(q.activeIn, sorted.p, nIn, tmp.p, tmp.n, s) == 0) q.activeIn = sorted.p;
-      }
-#endif
       hipEvent_t evS = sc->getEvent();
       (void)hipEventRecord(evS, s);
       if (rd->integrator == DR_INTEGRATOR_PATH) L.shade_path(sc->d, rp, st, q, b, sgrid, s);
@@ -1765,21 +1753,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
         slog[b + 1].sMid = evMid;
         slog[b + 1].s1 = evS1;
       }
-#if defined(DR_EXP_SORT_LISTS) && DR_EXP_SORT_LISTS >= 2
-      if (b + 1 < nStages) {  // timing experiment: the stage's two ray queues in slot order too (outside the traversal events)
-        static DevBuf<uint32_t> sortedQ[2];
-        static DevBuf<unsigned char> tmpQ;
-        uint32_t nQ[2] = {0, 0};
-        HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipMemcpy(&nQ[0], q.nClosest, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&nQ[1], q.nAny, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(sortedQ[0].alloc(2 * (size_t)w.cap));
-        HIP_TRY(sortedQ[1].alloc(w.cap));
-        HIP_TRY(tmpQ.alloc((size_t)w.cap * 24 + (1u << 20)));
-        if (nQ[0] > 1 && exp_sort_list(q.closestQ, sortedQ[0].p, nQ[0], tmpQ.p, tmpQ.n, s) == 0) q.closestQ = sortedQ[0].p;
-        if (nQ[1] > 1 && exp_sort_list(q.anyQ, sortedQ[1].p, nQ[1], tmpQ.p, tmpQ.n, s) == 0) q.anyQ = sortedQ[1].p;
-      }
-#endif
       if (b + 1 < nStages) {
         if (sideBySide) {
           hipEvent_t eS = sc->getEvent(), eA = sc->getEvent();
@@ -2049,9 +2022,6 @@ int dr_get_stats(DrScene* sc, DrRenderStats* out) {
     sc->pkNodes = c.pk_nodes[0];
     sc->pkTris = c.pk_tris[0];
     sc->genDone = sc->genDoneHost + c.gen_pixel_blocks;
-#ifdef DR_EXP_PK_STATS
-    fprintf(stderr, "pk_stats: rays %llu lane-visits %llu packet iterations %llu all-miss %llu leaf %llu\n", c.pk_rays[0], c.pk_nodes[0], c.pk_rays[1], c.pk_nodes[1], c.pk_tris[1]);
-#endif
     sc->foldEvents();
     sc->statsPending = false;
     shade_prof_dump();

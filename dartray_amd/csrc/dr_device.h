@@ -18,18 +18,10 @@
 
 #define DR_DEV __device__ __forceinline__
 
-// Streaming accesses to the per-sample path state (read or written once per stage, ~5 GB per batch)
-// can be made non-temporal with -DDR_NT=1 (an experiment to keep the BVH resident in L2 / Infinity Cache).
-#ifndef DR_NT
-#define DR_NT 0  // measured on C2: no gain for k_trace / k_shade_path, and scattered nt stores defeat L2 write combining
-#endif
-#if DR_NT
-#define LDS_STREAM(p) __builtin_nontemporal_load(p)
-#define STS_STREAM(p, v) __builtin_nontemporal_store((v), (p))
-#else
+// Streaming accesses to the per-sample path state (read or written once per stage, ~5 GB per batch).  Plain accesses: non-temporal
+// ones were measured on C2 (no gain for k_trace / k_shade_path; scattered nt stores defeat L2 write combining).
 #define LDS_STREAM(p) (*(p))
 #define STS_STREAM(p, v) (*(p) = (v))
-#endif
 
 #define DR_INV_PI 0.31830988618379067154  // core/common.dart:23
 #define DR_PI 3.141592653589793
@@ -215,25 +207,6 @@ DR_DEV ShTri load_shtri(const DScene& sc, uint32_t prim) {
 // Triangle.intersect's hit test (triangle.dart:52-98): f64 scalars on f32 inputs.
 DR_DEV bool tri_hit(F3 p1, F3 p2, F3 p3, F3 o, F3 d, double tmin, double tmax, double* tOut, double* b1Out,
                     double* b2Out) {
-#ifdef DR_EXP_TRI_F32  // timing experiment only (results differ): the whole test in f32 = what an f32 front filter could save at most
-  {
-    float e1x = p2.x - p1.x, e1y = p2.y - p1.y, e1z = p2.z - p1.z, e2x = p3.x - p1.x, e2y = p3.y - p1.y, e2z = p3.z - p1.z;
-    float s1x = d.y * e2z - d.z * e2y, s1y = d.z * e2x - d.x * e2z, s1z = d.x * e2y - d.y * e2x;
-    float divisor = s1x * e1x + s1y * e1y + s1z * e1z;
-    if (divisor == 0.f) return false;
-    float inv = 1.0f / divisor;
-    float sx = o.x - p1.x, sy = o.y - p1.y, sz = o.z - p1.z;
-    float b1 = (sx * s1x + sy * s1y + sz * s1z) * inv;
-    if (b1 < 0.f || b1 > 1.f) return false;
-    float s2x = sy * e1z - sz * e1y, s2y = sz * e1x - sx * e1z, s2z = sx * e1y - sy * e1x;
-    float b2 = (d.x * s2x + d.y * s2y + d.z * s2z) * inv;
-    if (b2 < 0.f || b1 + b2 > 1.f) return false;
-    float t = (e2x * s2x + e2y * s2y + e2z * s2z) * inv;
-    if ((double)t < tmin || (double)t > tmax) return false;
-    *tOut = t; *b1Out = b1; *b2Out = b2;
-    return true;
-  }
-#endif
   double e1x = (double)p2.x - (double)p1.x, e1y = (double)p2.y - (double)p1.y, e1z = (double)p2.z - (double)p1.z;
   double e2x = (double)p3.x - (double)p1.x, e2y = (double)p3.y - (double)p1.y, e2z = (double)p3.z - (double)p1.z;
   double dx = d.x, dy = d.y, dz = d.z;
@@ -284,12 +257,6 @@ DR_DEV bool tri_hit_e(F3 p1, const double* e, F3 o, F3 d, double tmin, double tm
 }
 // Triangle.intersectP (triangle.dart:162-194): Vector temporaries rounded to f32.
 DR_DEV bool tri_hitP(F3 p1, F3 p2, F3 p3, F3 o, F3 d, double tmin, double tmax) {
-#ifdef DR_EXP_TRI_F32
-  {
-    double t, b1, b2;
-    return tri_hit(p1, p2, p3, o, d, tmin, tmax, &t, &b1, &b2);
-  }
-#endif
   F3 e1 = vsub(p2, p1);
   F3 e2 = vsub(p3, p1);
   F3 s1 = vcross(d, e2);
@@ -517,15 +484,8 @@ DR_DEV void ConcentricSampleDisk(double u1, double u2, double* dx, double* dy) {
     }
   }
   theta *= DR_PI / 4.0;
-#ifdef DR_EXP_SINCOS  // timing experiment (bit-exact, a measured negative: MEASUREMENTS.md 5.6): one argument reduction for the pair
-  double sn_, cs_;
-  sincos(theta, &sn_, &cs_);
-  *dx = r * cs_;
-  *dy = r * sn_;
-#else
   *dx = r * cos(theta);
   *dy = r * sin(theta);
-#endif
 }
 DR_DEV F3 CosineSampleHemisphere(double u1, double u2) {  // montecarlo.dart:203-209
   double dx, dy;

@@ -401,14 +401,8 @@ __global__ void __launch_bounds__(64) k_gen_samples_lm(RenderParams rp, BatchSta
 // streams run on different SIMDs side by side: the time per step is the longer of the two instead of their sum.
 // Hand-over: `prod` / `cons` count finished groups (published every 4 groups, bounded spins, a protocol error traps).
 #define DR_GEN_RING 16  // groups of 4 partners per lane in the ring
-#ifndef DR_GEN_PIPE
-// bits (MEASUREMENTS.md 5.6; the table wave is busy 95 % of its loop, the generator wave 90 %: both pay every instruction's latency alone on
-// their SIMD): 1 = the group's magic numbers requested before the draws; 4 = table rows of 64 entries per index (one shift-add per
-// address instead of five instructions); 8 = the four partners in whole registers (no sub-dword compares with wait states behind
-// them) -- together 228 -> 211 K cycles per 64 pixels and block at 1024 spp; 2 = the next ring entry requested a group ahead: SLOWER
-// (248 K), off
-#define DR_GEN_PIPE 13
-#endif
+// (MEASUREMENTS.md 5.6, what the loop keeps of round 5's variants: the group's magic numbers requested before the draws; table rows of 64
+// entries per index -- one shift-add per address; the four partners in whole registers.  Requesting the next ring entry a group ahead was slower.)
 DR_DEV void gen_wait(uint32_t* word, uint32_t want) {
   for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
     if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) return;
@@ -430,18 +424,10 @@ __global__ void __launch_bounds__(128) k_gen_samples_pc(RenderParams rp, BatchSt
   const bool valid = p < npix;
   const int k = gen_block(rp);
   const bool is2D = k < 2 || k >= 3 + rp.n1D;
-#if DR_GEN_PIPE & 4  // rows of 64 entries, one per index: an entry's address is one shift-add (two lanes share a bank: the loop is not LDS-rate bound)
   auto at = [&](int i) -> PT& { return s_perm[i * 64 + lane]; };
-#else
-  auto at = [&](int i) -> PT& { return s_perm[(i >> 1) * 128 + lane * 2 + (i & 1)]; };
-#endif
   for (int m = 1 + (int)threadIdx.x; m <= spp; m += 128) s_magic[m] = m == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)m);
   if (threadIdx.x < 2) s_flag[threadIdx.x] = 0u;
   __syncthreads();
-#ifdef DR_EXP_GEN_PROF
-  unsigned long long waited = 0ull;
-  const unsigned long long tStart = __builtin_readcyclecounter();
-#endif
   if (role == 0) {
     // ---- generator side ----
     const int2 xy = st.pix[valid ? p : npix - 1u];
@@ -479,28 +465,15 @@ __global__ void __launch_bounds__(128) k_gen_samples_pc(RenderParams rp, BatchSt
       for (int i = 0; i < spp; i += 16) draws(nullptr, 16);  // Shuffle of ONE entry, spp times (:294-303)
     for (int g = 0; g < G; ++g) {
       if ((g & 3) == 0 && g + 4 > DR_GEN_RING) {  // room for four more groups
-#ifdef DR_EXP_GEN_PROF
-        const unsigned long long t0_ = __builtin_readcyclecounter();
         gen_wait(&s_flag[1], (uint32_t)(g + 4 - DR_GEN_RING));
-        waited += __builtin_readcyclecounter() - t0_;
-#else
-        gen_wait(&s_flag[1], (uint32_t)(g + 4 - DR_GEN_RING));
-#endif
       }
       // (the group's four magic numbers are requested BEFORE the draws: a single wave per SIMD pays every LDS round trip in full,
       // this one now runs under the generator steps)
-#if DR_GEN_PIPE & 1
       uint32_t mg[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) mg[j] = s_magic[spp - 4 * g - j];
-#endif
       uint32_t r[4];
       draws(r, 4);
-#if !(DR_GEN_PIPE & 1)
-      uint32_t mg[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) mg[j] = s_magic[spp - 4 * g - j];
-#endif
       uint32_t o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -514,45 +487,20 @@ __global__ void __launch_bounds__(128) k_gen_samples_pc(RenderParams rp, BatchSt
     }
   } else {
     // ---- table side ----
-#if DR_GEN_PIPE & 4
     for (int d = 0; d < spp; ++d) at(d) = (PT)d;
-#else
-    uint32_t* cols = (uint32_t*)s_raw + lane;
-    for (int d = 0; d < spp / 2; ++d) cols[d * 64] = (uint32_t)(2 * d) | ((uint32_t)(2 * d + 1) << 16);  // at(i) = i
-#endif
     auto waitProd = [&](uint32_t want) {
-#ifdef DR_EXP_GEN_PROF
-      const unsigned long long t0_ = __builtin_readcyclecounter();
       gen_wait(&s_flag[0], want);
-      waited += __builtin_readcyclecounter() - t0_;
-#else
-      gen_wait(&s_flag[0], want);
-#endif
     };
     // The ring entry of group g + 1 is requested at the top of group g, so that its LDS round trip runs under g's table reads
     // (LDS operations of a wave complete in order: the wait for g's reads covers it).  The producer publishes every four groups:
     // before the last group of a quad the next quad is waited for (it is at most 8 of the ring's 16 groups ahead of `cons`).
-#if DR_GEN_PIPE & 2
-    waitProd(4u);
-    uint2 qNext = s_ring[lane];
-#endif
     for (int g = 0; g < G; ++g) {
-#if DR_GEN_PIPE & 2
-      const uint2 q = qNext;
-      if (g + 1 < G) {
-        if ((g & 3) == 3) waitProd((uint32_t)(g + 5));
-        qNext = s_ring[((g + 1) % DR_GEN_RING) * 64 + lane];
-      }
-#else
       if ((g & 3) == 0) waitProd((uint32_t)(g + 4));
       const uint2 q = s_ring[(g % DR_GEN_RING) * 64 + lane];
-#endif
       const int i = 4 * g;
       int o[4] = {(int)(q.x & 0xffffu), (int)(q.x >> 16), (int)(q.y & 0xffffu), (int)(q.y >> 16)};
-#if DR_GEN_PIPE & 8  // whole registers for the four partners: compares through sub-dword selects write VCC with wait states behind them
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(o[j]));
-#endif
       PT R[4], A[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -579,15 +527,6 @@ __global__ void __launch_bounds__(128) k_gen_samples_pc(RenderParams rp, BatchSt
       if ((g & 3) == 3 && lane == 0) __hip_atomic_store(&s_flag[1], (uint32_t)(g + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-#ifdef DR_EXP_GEN_PROF
-  {
-    const unsigned long long tLoop = __builtin_readcyclecounter() - tStart;
-    __syncthreads();
-    const unsigned long long tAll = __builtin_readcyclecounter() - tStart;
-    if (blockIdx.x == 7 && blockIdx.y == 1 && lane == 0)
-      printf("gen_prof role %d: loop %llu cycles, of which waiting %llu; both done after %llu (spp %d)\n", role, tLoop, waited, tAll, spp);
-  }
-#endif
   __syncthreads();
   // write-out: a lane's spp entries are spp / 64 whole 64-entry index runs (128 B each); the two waves take alternate runs
   if (valid) {
@@ -596,14 +535,9 @@ __global__ void __launch_bounds__(128) k_gen_samples_pc(RenderParams rp, BatchSt
     for (int t = role; t < spp / 64; t += 2) {
       uint4* o = (uint4*)(st.svIdx() + (tile0 + t) * (size_t)st.tileStride * 4 + (size_t)k * 64 * sizeof(PT));
       for (int q = 0; q < 8; ++q) {
-#if DR_GEN_PIPE & 4
         const int e = t * 64 + 8 * q;
         auto two = [&](int i) { return (uint32_t)s_perm[i * 64 + lane] | ((uint32_t)s_perm[(i + 1) * 64 + lane] << 16); };
         o[q] = make_uint4(two(e), two(e + 2), two(e + 4), two(e + 6));
-#else
-        const int d = t * 32 + 4 * q;
-        o[q] = make_uint4(cols[(d + 0) * 64], cols[(d + 1) * 64], cols[(d + 2) * 64], cols[(d + 3) * 64]);
-#endif
       }
     }
   }
@@ -1218,7 +1152,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     const bool valid = cur.valid;
     uint32_t slot = cur.slot, pf = 0;
     bool pushCont = false, vert = false, deferred = false;
-    uint32_t contKey = 0u, anyKey = 0u;  // DR_SORT_CONT: octants of the continuation / shadow ray's direction
     bool envNee = false, envMiss = false;  // ENVQ: this lane's light estimate / escaped camera ray goes to k_env
     if (valid) {
       const SlotRef sr = cur.sr;
@@ -1379,7 +1312,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         if (alive && bounce != rp.maxDepth) {
           st3f<F_RD>(sr, wi);
           stcf<F_BETA>(sr, beta);
-          contKey = (wi.x < 0.f ? 1u : 0u) | (wi.y < 0.f ? 2u : 0u) | (wi.z < 0.f ? 4u : 0u);
           pf |= PF_HAS_CONT;
           if (specular) pf |= PF_SPECULAR;  // specularBounce (path_integrator.dart:87)
           pushCont = true;
@@ -1388,10 +1320,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
         st3f<F_RO>(sr, p);
         sr.f64<F_RTMIN>() = eps;
         vert = true;
-      }
-      if (DR_SORT_CONT > 1 && (pf & PF_HAS_SH)) {
-        const F3 sd = ld3f<F_SHD>(sr);  // (experiment only: read back what setup_nee stored)
-        anyKey = (sd.x < 0.f ? 1u : 0u) | (sd.y < 0.f ? 2u : 0u) | (sd.z < 0.f ? 4u : 0u);
       }
       if (Lchanged) stcf<F_L>(sr, L);
       // The path ended here with a finished light term pending: nothing is added to L after it, so k_film adds it
@@ -1411,7 +1339,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
     // 100 -> 290 ps per entry over four stages in the 64-slot layout, MEASUREMENTS.md 5.8).  Only a parked slot whose path ENDS here
     // still enters the list in k_env, once its flags say whether a light term is left to fold in.
     stage_push<NQ>(s_push, pctx, pushCont, (pf & PF_HAS_MIS) != 0, (pf & PF_HAS_SH) != 0, (pf != 0 && !deferred && !envNee) || (envNee && pushCont), slot, Q_MIS_BIT,
-                   vert, pushCont ? 0u : Q_RESOLVE_BIT, envNee || envMiss, envMiss ? Q_ENV_MISS_BIT : 0u, contKey, anyKey);
+                   vert, pushCont ? 0u : Q_RESOLVE_BIT, envNee || envMiss, envMiss ? Q_ENV_MISS_BIT : 0u);
     PROF(8);
     if (pctx.iters == ipc) {
       const uint32_t g = stage_flush<NQ>(s_push, pctx, q.closestQ, q.nClosest, q.anyQ, q.nAny, q.activeOut, q.nActiveOut, &q.ctr->shade_cont,

@@ -27,7 +27,6 @@
 #include "dr_kernels.h"
 #include "dr_wave.h"
 #include "dr_rng.h"
-#include <hipcub/hipcub.hpp>
 
 #ifdef DR_NS  // a second instantiation of this file (another state layout, -DDR_SUB=...): every symbol in its own namespace
 namespace DR_NS {
@@ -485,17 +484,6 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
       const uint4* np = (const uint4*)((const char*)sc.nodes + (size_t)(uint32_t)(node << 5));
       a = np[0];
       b = np[1];
-#ifdef DR_EXP_PAD_VMEM
-      // timing experiment only: N more 16-byte lane loads of the SAME node line per visit (what does a lane load cost the L1's
-      // divergent-address path at today's occupancy?)
-#pragma unroll
-      for (int k_ = 0; k_ < DR_EXP_PAD_VMEM; ++k_) {
-        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-        u32x4_ x_;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x_) : "v"(np + (k_ & 1)) : "memory");
-        asm volatile("" ::"v"(x_));
-      }
-#endif
     }
     // results of the rays that finished in the previous iteration: stored HERE, behind the node fetches.  vmcnt retires
     // in order and stores count in it: issued before the fetches (at the end of the previous iteration) their
@@ -528,32 +516,6 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
     if (mode == M_TRAV) {
       const float bminx = __uint_as_float(a.x), bminy = __uint_as_float(a.y), bminz = __uint_as_float(a.z);
       const float bmaxx = __uint_as_float(a.w), bmaxy = __uint_as_float(b.x), bmaxz = __uint_as_float(b.y);
-#if defined(DR_EXP_PAD_VALU) || defined(DR_EXP_PAD_LDS)
-      // Timing experiments only (tools/variants.sh; never in the product build): what does ONE more instruction per node visit
-      // cost at today's occupancy?  DR_EXP_PAD_VALU=N: N plain f32 VALU instructions (two independent chains, results unused);
-      // DR_EXP_PAD_LDS=N: N more reads of the lane's own stack row.  (MEASUREMENTS.md round 5: which resource the
-      // occupancy-independent part of the kernel's time belongs to.)
-      {
-        float p0 = bminx, p1 = bmaxx;
-#ifdef DR_EXP_PAD_VALU
-#pragma unroll
-        for (int k_ = 0; k_ < DR_EXP_PAD_VALU; k_ += 2) {
-          asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(p0));
-          asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(p1));
-        }
-#endif
-#ifdef DR_EXP_PAD_LDS
-        typedef __attribute__((address_space(3))) const uint32_t lds_u32p;
-#pragma unroll
-        for (int k_ = 0; k_ < DR_EXP_PAD_LDS; ++k_) {
-          uint32_t v_ = ((lds_u32p*)lds)[(k_ & 7) * DR_TRACE_BLOCK];
-          asm volatile("" : "+v"(v_));
-          p0 += __uint_as_float(v_ & 0u);
-        }
-#endif
-        asm volatile("" ::"v"(p0), "v"(p1));
-      }
-#endif
       bool amb = true;
       if (!ray.needF64) {  // (two predicates instead of a three-valued int: they stay lane masks in SGPRs)
         bool sureMiss;
@@ -1394,9 +1356,6 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
   const uint32_t n = nQueue ? *nQueue : st.nslots;
   const int lane = lane_id();
   uint32_t nRays = 0, nNodes = 0, nTris = 0;  // nRays / nNodes: wave-uniform, lane 0 reports them; nTris: per lane
-#ifdef DR_EXP_PK_STATS
-  uint32_t xIter = 0, xMiss = 0, xLeaf = 0;  // timing-free experiment: packet iterations, those in which no lane hit the box, leaf iterations
-#endif
   const uint32_t nTiles = (n + 63u) >> 6;
   for (;;) {
     uint32_t t0 = 0;
@@ -1444,9 +1403,6 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
             }
             const unsigned long long hitMask = __ballot(ok);
             bool descend = false;
-#ifdef DR_EXP_PK_STATS
-            if (lane == 0) { ++xIter; if (hitMask == 0ull) ++xMiss; else if ((b.w & 0xffffu) != 0u) ++xLeaf; }
-#endif
             if (hitMask != 0ull) {
               const uint32_t nprims = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b.w & 0xffffu));
               if (nprims > 0u) {  // a leaf: every lane of hitMask tests every triangle (bvh_accel.dart:126-138)
@@ -1501,13 +1457,6 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
       atomicAdd(&ctr->pk_nodes[0], nn);
       atomicAdd(&ctr->pk_tris[0], t);
     }
-#ifdef DR_EXP_PK_STATS
-    if (lane == 0 && ctr) {
-      atomicAdd(&ctr->pk_rays[1], (unsigned long long)xIter);
-      atomicAdd(&ctr->pk_nodes[1], (unsigned long long)xMiss);
-      atomicAdd(&ctr->pk_tris[1], (unsigned long long)xLeaf);
-    }
-#endif
   }
   flush_counters(ctr, 0, lane == 0 ? nRays : 0u, lane == 0 ? nNodes : 0u, nTris);
 }
@@ -1576,16 +1525,6 @@ void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue,
   }
 }
 
-#ifdef DR_EXP_SORT_LISTS
-// Timing experiment only (tools/variants_all.sh "sortl:-DDR_EXP_SORT_LISTS"): a stage's active list sorted by slot before k_shade_path
-// reads it -- what would an order-preserving compaction of the stage lists return?  (MEASUREMENTS.md round 5)
-int exp_sort_list(const uint32_t* in, uint32_t* out, uint32_t n, void* tmp, size_t tmpBytes, hipStream_t s) {
-  size_t need = 0;
-  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, need, in, out, (int)n, 0, 30, s);
-  if (need > tmpBytes) return -1;
-  return hipcub::DeviceRadixSort::SortKeys(tmp, need, in, out, (int)n, 0, 30, s) == hipSuccess ? 0 : -2;
-}
-#endif
 #ifdef DR_NS
 }  // namespace DR_NS
 #endif

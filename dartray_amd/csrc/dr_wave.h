@@ -65,25 +65,18 @@ template <int NQ = 4>
 DR_DEV uint32_t* stage_region(PushStage& sm) {
   return (uint32_t*)(&sm + 1) + (size_t)(threadIdx.x >> 6) * NQ * DR_PUSH_CAP;
 }
-// DR_SORT_CONT (experiment, MEASUREMENTS.md round 3; 2: the shadow rays too): a wave's round of continuation rays leaves for the queue
-// grouped by the octant of its direction (3 sign bits, carried in bits 29..31 of the staged entry; slots stay below
-// 2^29): rays of one octant take the same near / far decisions at every node (bvh_accel.dart:147-153).
-#ifndef DR_SORT_CONT
-#define DR_SORT_CONT 0
-#endif
 template <int NQ = 4>
 DR_DEV void stage_push(PushStage& sm, PushCtx& c, bool pCont, bool pMis, bool pAny, bool pAct, uint32_t slot, uint32_t misBit,
-                       bool pVert = false, uint32_t actBits = 0u, bool pEnv = false, uint32_t envBits = 0u, uint32_t contKey = 0u,
-                       uint32_t anyKey = 0u) {
+                       bool pVert = false, uint32_t actBits = 0u, bool pEnv = false, uint32_t envBits = 0u) {
   const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
   uint32_t* buf = stage_region<NQ>(sm);
   const unsigned long long lt = (1ull << lane) - 1ull;
   const unsigned long long m0 = __ballot(pCont), m1 = __ballot(pMis), m2 = __ballot(pAny), m3 = __ballot(pAct);
   const unsigned long long m4 = __ballot(pVert);
   if (lane == 0) sm.nVert[wave] += (uint32_t)__popcll(m4);
-  if (pCont) buf[c.n[0] + (uint32_t)__popcll(m0 & lt)] = DR_SORT_CONT ? (slot | (contKey << 29)) : slot;
+  if (pCont) buf[c.n[0] + (uint32_t)__popcll(m0 & lt)] = slot;
   if (pMis) buf[DR_PUSH_CAP + c.n[1] + (uint32_t)__popcll(m1 & lt)] = slot | misBit;
-  if (pAny) buf[2 * DR_PUSH_CAP + c.n[2] + (uint32_t)__popcll(m2 & lt)] = DR_SORT_CONT > 1 ? (slot | (anyKey << 29)) : slot;
+  if (pAny) buf[2 * DR_PUSH_CAP + c.n[2] + (uint32_t)__popcll(m2 & lt)] = slot;
   if (pAct) buf[3 * DR_PUSH_CAP + c.n[3] + (uint32_t)__popcll(m3 & lt)] = slot | actBits;
   c.n[0] += (uint32_t)__popcll(m0);
   c.n[1] += (uint32_t)__popcll(m1);
@@ -171,45 +164,9 @@ DR_DEV uint32_t stage_flush(PushStage& sm, PushCtx& c, uint32_t* closestQ, uint3
     }
     const uint32_t b0 = wave_bcast_first(a0), b1 = wave_bcast_first(a1), b2 = wave_bcast_first(a2);
     const uint32_t* buf = stage_region<NQ>(sm);
-    auto sortedOut = [&](const uint32_t* src, uint32_t n, uint32_t* dst) {  // grouped by the 3-bit key in bits 29..31
-      uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (uint32_t r = 0; r < n; r += 64u) {
-        const uint32_t i = r + (uint32_t)lane;
-        const uint32_t key = i < n ? src[i] >> 29 : 8u;
-#pragma unroll
-        for (uint32_t b = 0; b < 8u; ++b) cnt[b] += (uint32_t)__popcll(__ballot(key == b));
-      }
-      uint32_t base[8];
-      uint32_t acc = 0;
-#pragma unroll
-      for (uint32_t b = 0; b < 8u; ++b) {
-        base[b] = acc;
-        acc += cnt[b];
-      }
-      const unsigned long long ltm = (1ull << lane) - 1ull;
-      for (uint32_t r = 0; r < n; r += 64u) {
-        const uint32_t i = r + (uint32_t)lane;
-        const uint32_t e = i < n ? src[i] : 0u;
-        const uint32_t key = i < n ? e >> 29 : 8u;
-        uint32_t dest = 0;
-#pragma unroll
-        for (uint32_t b = 0; b < 8u; ++b) {
-          const unsigned long long m = __ballot(key == b);
-          if (key == b) dest = base[b] + (uint32_t)__popcll(m & ltm);
-          base[b] += (uint32_t)__popcll(m);
-        }
-        if (i < n) dst[dest] = e & 0x1fffffffu;
-      }
-    };
-    if (DR_SORT_CONT) {
-      sortedOut(buf, n0, closestQ + b0);
-    } else {
-      for (uint32_t i = (uint32_t)lane; i < n0; i += 64u) closestQ[b0 + i] = buf[i];
-    }
+    for (uint32_t i = (uint32_t)lane; i < n0; i += 64u) closestQ[b0 + i] = buf[i];
     for (uint32_t i = (uint32_t)lane; i < n1; i += 64u) closestQ[b0 + n0 + i] = buf[DR_PUSH_CAP + i];
-    if (DR_SORT_CONT > 1) sortedOut(buf + 2 * DR_PUSH_CAP, n2, anyQ + b1);
-    else
-      for (uint32_t i = (uint32_t)lane; i < n2; i += 64u) anyQ[b1 + i] = buf[2 * DR_PUSH_CAP + i];
+    for (uint32_t i = (uint32_t)lane; i < n2; i += 64u) anyQ[b1 + i] = buf[2 * DR_PUSH_CAP + i];
     for (uint32_t i = (uint32_t)lane; i < n3; i += 64u) activeQ[b2 + i] = buf[3 * DR_PUSH_CAP + i];
     if constexpr (NQ == 5) {
       if (n4 != 0u) {
