@@ -81,6 +81,7 @@ struct Workspace {
   int spillGrid = 0;
 };
 
+#define DR_PAIR_TOP_LEVELS 12  // sibling-pair records: this many levels of the tree breadth-first in front (dr_scene_create)
 #define DR_STATE_WORDS F_SAMPLES  // 41 4-byte words of fixed path state per slot: 3 f64 + 10 3-vectors + 5 i32
 #define N_COUNTERS_TRACE (1024 + 8 * DR_WORK_STRIDE * 400)
 #define N_COUNTERS (N_COUNTERS_TRACE + 64 * 256)  // ... then the counts of k_env's lists, one cache line per stage  // [0,1024): stage queue counts; then 8 per-XCD work counters per trace launch, DR_WORK_STRIDE words apart
@@ -94,10 +95,15 @@ namespace {
 std::mutex g_optMutex;
 std::map<std::string, std::string> g_options;  // name -> value; an empty value = "unset for this process" (hides the environment's)
 const char* const kOptionNames[] = {
-    "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_PAIR_ORDER", "DARTRAY_STATE_LAYOUT", "DARTRAY_GEN_SLOW_DRAWS",
-    "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_FLOAT_SAMPLES", "DARTRAY_BATCH_BITS", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
-    "DARTRAY_PILOT_FORCE", "DARTRAY_PILOT_BITS", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE", "DARTRAY_BUILD_DEBUG", "DARTRAY_GEN_LANES",
-    "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS", "DARTRAY_COHERENT_CAMERA", "DARTRAY_LAZY_GEN", "DARTRAY_LDS_LIGHTS", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_SCENE_PREP", "DARTRAY_LAYOUT_PILOT"};
+    // what a render runs: traversal kernels, state layout, batch size, schedule, the pilot
+    "DARTRAY_TRACE_IMPL", "DARTRAY_TRACE_WG_PER_CU", "DARTRAY_STATE_LAYOUT", "DARTRAY_BATCH_BITS", "DARTRAY_OVERLAP_ANY", "DARTRAY_PILOT",
+    "DARTRAY_COHERENT_CAMERA",
+    // the device sampler (bit-exact variants, tests)
+    "DARTRAY_LAZY_GEN", "DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_GEN_SLOW_DRAWS",
+    // scene set-up, the collective's library, diagnostics
+    "DARTRAY_SCENE_PREP", "DARTRAY_BUILD_THREADS", "DARTRAY_RCCL_LIB", "DARTRAY_STAGE_COUNTS", "DARTRAY_VERBOSE"};
+static_assert(sizeof(kOptionNames) / sizeof(kOptionNames[0]) <= 15, "a new switch replaces one: measured negatives go to experiments/");
+
 }  // namespace
 
 DrOpt dr_opt(const char* name) {
@@ -381,8 +387,8 @@ BatchState makeState(Workspace& w, const SampleForm& sf, const int2* pix, uint32
   st.tiles = w.tiles.p;  // field offsets inside a tile: the F_* constants of dr_kernels.h
   st.svFloat = sf.compact ? 0u : 1u;
   st.svScr = sf.compact ? w.scr.p : nullptr;
-  {  // DARTRAY_GEN_PREPASS=0 (A/B, tests): the shuffle kernels seed and burn in their streams themselves
-    st.genState = sf.compact && !dr_opt("DARTRAY_GEN_PREPASS").isZero() ? w.genState.p : nullptr;
+  {  // (the pre-pass k_gen_burnin fills genState above 256 spp; at and below, the shuffle kernels seed and burn in their streams themselves)
+    st.genState = sf.compact ? w.genState.p : nullptr;
     st.genAlive = nullptr;
     st.markAlive = nullptr;
     st.markShift = 0;
@@ -531,11 +537,8 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   // k_trace addresses node i at byte offset i * 32 from a scalar base, in 32 bits (dr_trace.hip)
   if (desc->nnodes > (1ull << 27)) return fail(DR_ERR_UNSUPPORTED, "more than 2^27 BVH nodes");
   // Round 4: validation, height, pair records and the union check run on the device (dr_scene_prep.hip: C4 0.6 s -> 0.1 s).  The
-  // serial host loops below remain for the experimental pair orders (DARTRAY_PAIR_ORDER=sib | pad:K | veb:T:S) and as the
-  // reference the device results are tested against (DARTRAY_SCENE_PREP=host).
-  const DrOpt pairOrderOpt = dr_opt("DARTRAY_PAIR_ORDER");
-  const std::string pairOrder = pairOrderOpt ? pairOrderOpt.value : "top:12";
-  const bool hostPrep = dr_opt("DARTRAY_SCENE_PREP").is("host") || !(pairOrder == "dfs" || pairOrder.rfind("top:", 0) == 0);
+  // serial host loops below remain as the reference the device results are tested against (DARTRAY_SCENE_PREP=host).
+  const bool hostPrep = dr_opt("DARTRAY_SCENE_PREP").is("host");
   std::vector<uint8_t> level(hostPrep ? desc->nnodes : 0, 0);
   if (desc->nnodes && hostPrep) {
     const DrBvhNode* N = desc->nodes;
@@ -648,7 +651,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     pin.nmaterials = desc->nmaterials;
     pin.nlights = desc->nlights;
     pin.wantPairs = desc->nnodes && desc->ntris < (1ull << 26) && desc->nquadrics == 0;  // only the v2 kernel tests quadrics
-    pin.topLevels = pairOrder.rfind("top:", 0) == 0 ? std::max(1, atoi(pairOrder.c_str() + 4)) : 0;
+    pin.topLevels = DR_PAIR_TOP_LEVELS;
     if (pin.wantPairs) {
       pin.pairsCap = desc->nnodes / 2 + 1;  // a binary tree of n nodes has (n - 1) / 2 interior ones
       TRY_SC(sc->pairs.alloc(4 * pin.pairsCap));
@@ -689,78 +692,21 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         ok = false;  // packed references carry at most 31 primitives per leaf; fall back to the v2 kernel
       }
     }
-    // Memory order of the pair records (experiments, MEASUREMENTS.md round 3; results never depend on it -- the
-    // references are explicit).  Default: depth-first (a node's left child next to it).  DARTRAY_PAIR_ORDER=
-    //   pad:K    depth-first with K - 1 empty records behind every pair (footprint experiment)
-    //   sib      the two child records of a node side by side in ONE 128-byte line (holes where a child is a leaf)
-    //   veb:T:S  treelets: the top T levels breadth-first, below them sub-trees of height S breadth-first each,
-    //            treelet after treelet in depth-first order (van Emde Boas style; veb:1:1 is the default order)
-    // (default since round 4: top:12 -- the top twelve levels breadth-first, 3 774 records = 236 KiB on C4, every sub-tree below
-    // them contiguous and depth-first: C4 closest-hit -1 %, any-hit -3.5 % against plain depth-first; "dfs" restores that)
-    if (const char* po = pairOrder.c_str()) {
-      const std::string mode(po);
+    // Memory order of the pair records (results never depend on it -- the references are explicit): the top DR_PAIR_TOP_LEVELS levels
+    // breadth-first (3 774 records = 236 KiB on C4), then every other interior node in depth-first (= node index) order, so a sub-tree
+    // below the top is one contiguous run (round 4: C4 closest-hit -1 %, any-hit -3.5 % against plain depth-first; the other orders
+    // that were tried -- sibling lines, padded records, van Emde Boas treelets -- are experiments/r06_runtime_switches.diff).
+    {
       std::vector<uint32_t> slotOf(desc->nnodes, 0);
       uint32_t slots = 0;
-      if (mode == "sib") {
-        std::vector<uint32_t> st;
-        st.push_back(0);
-        slotOf[0] = 0;
-        slots = 2;
-        while (!st.empty()) {
-          const uint32_t i = st.back();
-          st.pop_back();
-          const uint32_t c[2] = {i + 1, N[i].offset};
-          for (int k = 0; k < 2; ++k)
-            if (N[c[k]].nprims == 0) slotOf[c[k]] = slots + (uint32_t)k;
-          if (N[c[0]].nprims == 0 || N[c[1]].nprims == 0) slots += 2;
-          if (N[c[1]].nprims == 0) st.push_back(c[1]);
-          if (N[c[0]].nprims == 0) st.push_back(c[0]);
-        }
-      } else if (mode.rfind("pad:", 0) == 0) {
-        // depth-first order with K - 1 empty records behind every pair: K times the footprint and 2 / K pairs per
-        // 128-byte line -- what a record of 64 / K bytes would GAIN is at most what this loses per halving
-        const uint32_t K = (uint32_t)std::max(1, atoi(po + 4));
-        for (uint64_t i = 0; i < desc->nnodes; ++i)
-          if (N[i].nprims == 0) slotOf[i] = pairIndex[i] * K;
-        slots = np * K;
-      } else if (mode.rfind("top:", 0) == 0) {
-        // the top T levels breadth-first (the top treelet of the treelet-parked traversal, DScene.topPairs records), then
-        // every other interior node in depth-first (= node index) order: a sub-tree below the top is one contiguous run
-        const int T = std::max(1, atoi(po + 4));
-        std::vector<uint32_t> top;
-        for (uint64_t i = 0; i < desc->nnodes; ++i)
-          if (N[i].nprims == 0 && level[i] < T) top.push_back((uint32_t)i);
-        std::stable_sort(top.begin(), top.end(), [&](uint32_t a, uint32_t b) { return level[a] < level[b]; });
-        for (uint32_t i : top) slotOf[i] = slots++;
-        sc->d.topPairs = slots;
-        for (uint64_t i = 0; i < desc->nnodes; ++i)
-          if (N[i].nprims == 0 && level[i] >= T) slotOf[i] = slots++;
-      } else if (mode.rfind("veb:", 0) == 0) {
-        int T = 1, S = 1;
-        if (sscanf(po + 4, "%d:%d", &T, &S) < 1) T = 1;
-        T = std::max(1, T);
-        S = std::max(1, S);
-        std::vector<std::pair<uint32_t, int>> st;  // (treelet root, height)
-        st.push_back({0u, T});
-        std::vector<uint32_t> cur, nxt, frontier;
-        while (!st.empty()) {
-          const auto top = st.back();
-          st.pop_back();
-          cur.assign(1, top.first);
-          frontier.clear();
-          for (int lev = 0; lev < top.second && !cur.empty(); ++lev) {
-            nxt.clear();
-            for (uint32_t i : cur) {
-              slotOf[i] = slots++;
-              const uint32_t c[2] = {i + 1, N[i].offset};
-              for (int k = 0; k < 2; ++k)
-                if (N[c[k]].nprims == 0) nxt.push_back(c[k]);
-            }
-            cur.swap(nxt);
-          }
-          for (size_t k = cur.size(); k-- > 0;) st.push_back({cur[k], S});  // the next treelets, leftmost first
-        }
-      }
+      std::vector<uint32_t> top;
+      for (uint64_t i = 0; i < desc->nnodes; ++i)
+        if (N[i].nprims == 0 && level[i] < DR_PAIR_TOP_LEVELS) top.push_back((uint32_t)i);
+      std::stable_sort(top.begin(), top.end(), [&](uint32_t a, uint32_t b) { return level[a] < level[b]; });
+      for (uint32_t i : top) slotOf[i] = slots++;
+      sc->d.topPairs = slots;
+      for (uint64_t i = 0; i < desc->nnodes; ++i)
+        if (N[i].nprims == 0 && level[i] >= DR_PAIR_TOP_LEVELS) slotOf[i] = slots++;
       if (slots) {
         pairIndex.swap(slotOf);
         np = slots;
@@ -1355,8 +1301,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // sub-tiles (C5: 0.38 -> sp4; C2 0.80, C4: 64-slot).  DARTRAY_STATE_LAYOUT=64|4 forces one, dr_scene_set_state_layout
   // stores one; renders too small for a pilot keep round 3's rule.
   const DrOpt layoutEnv = dr_opt("DARTRAY_STATE_LAYOUT");  // 64 | 4: A/B runs and tests (a copy: later look-ups cannot change it)
-  const bool layoutPilotOff = dr_opt("DARTRAY_LAYOUT_PILOT").isZero();
-  const bool layoutKnown = layoutEnv || sc->stateLayout != 0 || rd->integrator != DR_INTEGRATOR_PATH || layoutPilotOff;
+  const bool layoutKnown = layoutEnv || sc->stateLayout != 0 || rd->integrator != DR_INTEGRATOR_PATH;
   const bool sparseLayout = layoutEnv ? layoutEnv.toInt(0) == 4 : (sc->stateLayout ? sc->stateLayout == 4 : envStage);
   const LayoutOps* Lp = sparseLayout ? &kLayoutSp4 : &kLayout64;
   const int maxStateWords = layoutKnown ? Lp->stateWords : std::max(kLayout64.stateWords, kLayoutSp4.stateWords);
@@ -1458,7 +1403,7 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // Sample vectors: the on-device LD sampler stores permuted indices + scrambles (compact form) whenever every LD block
   // has one entry per pixel sample; host buffers and multi-entry blocks (DirectLighting with nsamples > 1) use floats.
   SampleForm sf;
-  sf.compact = !hostBuf && rp.blocks == nullptr && !dr_opt("DARTRAY_FLOAT_SAMPLES");
+  sf.compact = !hostBuf && rp.blocks == nullptr;
   if (!sf.compact && !hostBuf && spp > 1024)
     return fail(DR_ERR_UNSUPPORTED, "spp > 1024 with LD blocks of several entries per sample (DirectLighting with nsamples > 1): the float-form sampler's table exceeds the LDS");
   sf.nFloats = rp.nFloats;
@@ -1532,8 +1477,9 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   // Nothing is traced twice: the calibration costs only what three small launches lose against one big one (round 1
   // ran up to six extra passes over pilot rays that never reached the film: 19 % of a C2 render, 64 % of C4's).
   // Both kernels are bit-exact, so results do not depend on the choice; dr_scene_set_trace_kernels / DARTRAY_TRACE_IMPL fix it.
-  const bool pilotOff = dr_opt("DARTRAY_PILOT").isZero();
-  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || dr_opt("DARTRAY_PILOT_FORCE").set;
+  const DrOpt pilotOpt = dr_opt("DARTRAY_PILOT");  // 0: never; force: also on renders too small to need one (tests)
+  const bool pilotOff = pilotOpt.is("0");
+  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || pilotOpt.is("force");
   const bool pilotOk = !pilotOff && !hostBuf && !dlSpec && bigJob && npixTotal >= 3 * 64 * 4;
   const bool calibrateTrace = !sc->traceCalibrated && pilotOk && !dr_opt("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads;
   const bool measureLayout = !layoutKnown && pilotOk;
@@ -1546,7 +1492,6 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
     // decide: the pair kernel, whose rays are half as many fetches long, looked 10 % FASTER than k_trace<0> on C2 and is 12 % slower in
     // the full-size launches; at 2^24 and above the calibration batches rank the kernels as the full-size launches do.)
     uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 24, (uint64_t)npixTotal * spp / 16));
-    if (const DrOpt pb = dr_opt("DARTRAY_PILOT_BITS")) pilotSamples = 1ull << std::max(0, std::min(40, pb.toInt(24)));
     pilotSamples = std::min<uint64_t>(pilotSamples, (uint64_t)(pixPerBatch / 64 * 64) * spp);
     const size_t totalGroups = npixTotal / 64;
     const size_t groups = std::min<size_t>(std::max<size_t>(1, (size_t)(pilotSamples / spp) / 64), totalGroups / 4);

@@ -390,7 +390,7 @@ extern "C" int dr_bvh_build_mixed(const float* verts, uint64_t nverts, const uin
   const DrOpt env = dr_opt("DARTRAY_BUILD_THREADS");
   int hw = (int)std::thread::hardware_concurrency();
   b.maxThreads = env ? std::max(1, env.toInt(1)) : std::max(1, std::min(hw, 64));
-  const bool dbg = dr_opt("DARTRAY_BUILD_DEBUG").set;
+  const bool dbg = dr_opt("DARTRAY_VERBOSE").toInt(0) >= 2;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   b.items.resize(ntris);

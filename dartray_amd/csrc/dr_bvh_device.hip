@@ -708,7 +708,7 @@ extern "C" int dr_bvh_build_device(const float* verts, uint64_t nverts, const ui
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) return dr_fail(DR_ERR_NO_DEVICE, "dr_bvh_build_device before dr_init");
   const int maxPrims = std::min(255, max_prims_in_node > 0 ? max_prims_in_node : 4);  // bvh_accel.dart:44
-  const bool dbg = dr_opt("DARTRAY_BUILD_DEBUG").set;
+  const bool dbg = dr_opt("DARTRAY_VERBOSE").toInt(0) >= 2;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   const uint32_t n = (uint32_t)ntris;

@@ -1866,12 +1866,6 @@ void launch_make_shtris(const DScene& sc, float4* out, uint64_t ntris, hipStream
   if (ntris == 0) return;
   hipLaunchKernelGGL(k_make_shtris, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, sc, out, ntris);
 }
-#ifndef DR_GEN_LANES_256
-#define DR_GEN_LANES_256 64
-#endif
-#ifndef DR_GEN_LANES_BIG
-#define DR_GEN_LANES_BIG 64
-#endif
 void launch_gen_samples(const RenderParams& rp, const BatchState& stIn, uint32_t npix, hipStream_t s) {
   // the pre-pass (k_gen_burnin) pays where the shuffle kernels run at one wave per SIMD -- above 256 spp: C5 151 -> 141.5 ms, the 1024-spp
   // image 119 -> 112 -- and costs a launch where nine waves per CU hide the burn-in anyway (C2, 256 spp: 9.1 -> 9.4 ms)
@@ -1881,23 +1875,22 @@ void launch_gen_samples(const RenderParams& rp, const BatchState& stIn, uint32_t
   const dim3 grid((npix + 63) / 64, nBlocks);
   if (!st.svFloat && rp.spp >= 64) {
     const int nGen = rp.genMask ? __builtin_popcountll(rp.genMask) : nBlocks;  // compact form (rp.blocks is null), whole index runs per pixel
-    const int lanesEnv = dr_opt("DARTRAY_GEN_LANES").toInt(0);
-    // (above 1024 spp a pixel's table is 4 / 8 KB: 32 / 16 pixels per group keep the group's tables within 128 KB)
-    const int ln = lanesEnv ? lanesEnv : (rp.spp <= 128 ? 64 : (rp.spp <= 256 ? DR_GEN_LANES_256 : (rp.spp <= 1024 ? DR_GEN_LANES_BIG : (rp.spp <= 2048 ? 32 : 16))));
+    // (above 1024 spp a pixel's table is 4 / 8 KB: 32 / 16 pixels per group keep the group's tables within 128 KB; the lazy-generation
+    // exit of k_gen_samples_lm tests ONE 64-pixel group per workgroup: the group size must divide 64)
+    const int ln = rp.spp <= 1024 ? 64 : (rp.spp <= 2048 ? 32 : 16);
     const dim3 g((npix + ln - 1) / ln, nGen);
     if (st.genState) hipLaunchKernelGGL(k_gen_burnin, dim3((npix + 255) / 256, nGen), dim3(256), 0, s, rp, st, npix);
     const size_t lds = (size_t)rp.spp * ln * (rp.spp <= 256 ? 1 : 2) + ((size_t)rp.spp + 1) * 4;
     if (rp.spp <= 256) {
       hipLaunchKernelGGL(k_gen_samples_lm<uint8_t>, g, dim3(ln), lds, s, rp, st, npix);
     } else {
-      const bool onePerGroup = dr_opt("DARTRAY_GEN_ONE_WAVE").set;  // A/B: the single-wave kernel
       static bool attrSet = false;
       if (!attrSet) {
         (void)hipFuncSetAttribute((const void*)k_gen_samples_lm<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_gen_samples_pc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrSet = true;
       }
-      if (!onePerGroup && !lanesEnv && rp.spp <= 1024) {
+      if (rp.spp <= 1024) {  // two waves per 64 pixels (generator / table); above, a group's tables leave no room for the ring: one wave
         const size_t ldsPc = (size_t)rp.spp * 64 * 2 + (((size_t)rp.spp + 2) & ~(size_t)1) * 4 + (size_t)DR_GEN_RING * 64 * 8 + 16;
         hipLaunchKernelGGL(k_gen_samples_pc, dim3((npix + 63) / 64, nGen), dim3(128), ldsPc, s, rp, st, npix);
       } else {
@@ -1945,8 +1938,7 @@ static void launch_shade(int grid, size_t extraLds, hipStream_t s, A... args) {
   hipLaunchKernelGGL(kernel, dim3(DR_SHADE_GRID(grid)), dim3(BLOCK), lds, s, args...);
 }
 static bool lightsInLds(const DScene& sc) {
-  const bool off = dr_opt("DARTRAY_LDS_LIGHTS").isZero();  // A/B runs
-  return !off && sc.nlights > 0 && light_table_bytes(sc) <= DR_LDS_LIGHT_BYTES;
+  return sc.nlights > 0 && light_table_bytes(sc) <= DR_LDS_LIGHT_BYTES;
 }
 void launch_shade_path(const DScene& sc, const RenderParams& rp, const BatchState& st, const StageQueues& q, int bounce,
                        int grid, hipStream_t s) {

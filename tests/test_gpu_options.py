@@ -1,6 +1,6 @@
 """The switches of the library through the C ABI (dr_set_option), and one process that renders several scenes in turn.
 
-Round 4's dr_option handed out a pointer into ONE thread-local buffer: with STATE_LAYOUT and LAYOUT_PILOT both set through
+Round 4's dr_option handed out a pointer into ONE thread-local buffer: with STATE_LAYOUT and a second switch both set through
 dr_set_option the forced layout was read from the pilot switch's value.  Environment variables hid it (getenv pointers are
 stable), and every earlier test that combined switches used the environment.  These set them through the ABI only and ask
 the library what the render actually ran with (dr_scene_last_render_info)."""
@@ -36,12 +36,12 @@ def test_switches_set_through_the_c_abi_do_not_clobber_each_other():
         "ref = r.render(scene).film\n"
         "info = dev.last_render_info(); assert info['state_layout'] == 64, info\n"
         # the round-4 failure: the layout switch first, then two more look-ups of other names (one with a LONGER value)
-        "opt('STATE_LAYOUT', 4); opt('LAYOUT_PILOT', 0); opt('VERBOSE', '0000000000000000000000000000000000000001')\n"
+        "opt('STATE_LAYOUT', 4); opt('BATCH_BITS', 28); opt('VERBOSE', '0000000000000000000000000000000000000001')\n"
         "f = r.render(scene).film; info = dev.last_render_info()\n"
         "assert info['state_layout'] == 4, info\n"
         "assert np.array_equal(f, ref)\n"
         "opt('STATE_LAYOUT', 64); f = r.render(scene).film; assert dev.last_render_info()['state_layout'] == 64\n"
-        "opt('STATE_LAYOUT', None); opt('LAYOUT_PILOT', None); opt('VERBOSE', None)\n"
+        "opt('STATE_LAYOUT', None); opt('BATCH_BITS', None); opt('VERBOSE', None)\n"
         # kernel switches: the pair kernels with the cold-state closest-hit variant
         "opt('TRACE_IMPL', 5); opt('OVERLAP_ANY', 0)\n"
         "f = r.render(scene).film; info = dev.last_render_info()\n"
@@ -53,7 +53,7 @@ def test_switches_set_through_the_c_abi_do_not_clobber_each_other():
         "assert np.array_equal(f, ref)\n"
         "opt('TRACE_WG_PER_CU', None)\n"
         # names the header no longer lists are refused, like any unknown name
-        "for n in (b'WORKSPACE', b'TREELET', b'TREELET_TOP', b'TREELET_ROUNDS', b'NO_SUCH_SWITCH'): assert lib.dr_set_option(n, b'1') != 0\n"
+        "for n in (b'WORKSPACE', b'TREELET', b'TREELET_TOP', b'TREELET_ROUNDS', b'PIPELINES', b'ANY8', b'LAYOUT_PILOT', b'NO_SUCH_SWITCH'): assert lib.dr_set_option(n, b'1') != 0\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
     _run(code)
 
@@ -88,7 +88,7 @@ def test_one_process_renders_several_scenes_in_turn():
     for k in "abcd":
         paths[k] = os.path.join(out, "film_alone_%s.npy" % k)
         env = {kk: v for kk, v in os.environ.items() if not kk.startswith("DARTRAY_")}
-        env["DARTRAY_PILOT_FORCE"] = "1"
+        env["DARTRAY_PILOT"] = "force"
         res = subprocess.run([sys.executable, "-c", alone, k, paths[k]], env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
     together = body + (
@@ -113,7 +113,7 @@ def test_one_process_renders_several_scenes_in_turn():
         "assert info['b']['state_layout'] in (4, 64) and info['a']['state_layout'] == 64, info\n"
         "print('OK')\n")
     res = subprocess.run([sys.executable, "-c", together, os.path.join(out, "film_alone_%s.npy")],
-                         env=dict({kk: v for kk, v in os.environ.items() if not kk.startswith("DARTRAY_")}, DARTRAY_PILOT_FORCE="1"),
+                         env=dict({kk: v for kk, v in os.environ.items() if not kk.startswith("DARTRAY_")}, DARTRAY_PILOT="force"),
                          capture_output=True, text=True, timeout=900)
     for p in paths.values():
         os.remove(p)
@@ -144,7 +144,7 @@ def test_pilot_reports_what_it_measured_and_any_hit_follows_the_closest_hit_fami
         "assert (info['closest_kernel'], info['any_hit_kernel']) == k\n"
         "b = r.render(scene).film; assert dev.last_render_info()['pilot_batches'] == 0 and np.array_equal(a, b)\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
-    _run(code, DARTRAY_PILOT_FORCE="1")
+    _run(code, DARTRAY_PILOT="force")
 
 
 def test_lazy_sample_generation_leaves_the_film_alone():

@@ -309,7 +309,7 @@ def test_traversal_pilot_leaves_results_and_counters_untouched():
         "assert np.array_equal(out.film, ref['film']) and np.array_equal(out2.film, ref['film'])\n"
         "assert all(st[k] == c[k] for k in ('closest_nodes', 'any_nodes', 'closest_tris', 'any_tris', 'closest_rays', 'any_rays')), (st, c)\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
-    env = dict(os.environ, DARTRAY_PILOT_FORCE="1", DARTRAY_VERBOSE="1")
+    env = dict(os.environ, DARTRAY_PILOT="force", DARTRAY_VERBOSE="1")
     env.pop("DARTRAY_TRACE_IMPL", None)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)
     assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
@@ -399,26 +399,19 @@ def test_unread_sample_blocks_can_be_left_out():
     # third run: the device sampler draws its generator values in groups of plain steps and redoes a group the slow way
     # (Random.nextInt's retry loop) when a lane saw the one value in 2^32 that is redrawn; DARTRAY_GEN_SLOW_DRAWS=1 takes
     # that path for every group -- the streams must not change
-    # fourth run: a stage's any-hit launch after its closest-hit launch instead of beside it (DARTRAY_OVERLAP_ANY=0) and
-    # the single-wave sampler kernel at 512 spp (DARTRAY_GEN_ONE_WAVE=1)
-    # fifth / sixth run: without the sampler's pre-pass (DARTRAY_GEN_PREPASS=0: the shuffle kernels seed their streams, draw the
-    # scrambles and make the burn-in draws themselves, as before round 4), plain and with the slow draws
-    for gen_all, slow, serial, prepass in ((False, False, False, True), (True, False, False, True), (False, True, False, True),
-                                           (False, False, True, True), (False, False, False, False), (False, True, True, False)):
-        path = os.path.join(ROOT, "gpurun_out", "film_gen%d%d%d%d.npy" % (gen_all, slow, serial, prepass))
+    # fourth run: a stage's any-hit launch after its closest-hit launch instead of beside it (DARTRAY_OVERLAP_ANY=0); fifth: that and the slow draws
+    for gen_all, slow, serial in ((False, False, False), (True, False, False), (False, True, False), (False, False, True), (False, True, True)):
+        path = os.path.join(ROOT, "gpurun_out", "film_gen%d%d%d.npy" % (gen_all, slow, serial))
         os.makedirs(os.path.dirname(path), exist_ok=True)
         env = dict(os.environ)
-        for k in ("DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_GEN_SLOW_DRAWS", "DARTRAY_OVERLAP_ANY", "DARTRAY_GEN_ONE_WAVE", "DARTRAY_GEN_PREPASS"):
+        for k in ("DARTRAY_GEN_ALL_BLOCKS", "DARTRAY_GEN_SLOW_DRAWS", "DARTRAY_OVERLAP_ANY"):
             env.pop(k, None)
-        if not prepass:
-            env["DARTRAY_GEN_PREPASS"] = "0"
         if gen_all:
             env["DARTRAY_GEN_ALL_BLOCKS"] = "1"
         if slow:
             env["DARTRAY_GEN_SLOW_DRAWS"] = "1"
         if serial:
             env["DARTRAY_OVERLAP_ANY"] = "0"
-            env["DARTRAY_GEN_ONE_WAVE"] = "1"
         res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=500)
         assert res.returncode == 0, res.stderr[-2000:]
         out.append(np.load(path))
@@ -510,7 +503,7 @@ def test_state_layout_is_chosen_from_the_pilot_batch_densities():
         "lay, dens = run(prims, mk, env=True); print('yard', lay, dens); assert lay == (4 if dens < 0.5 else 64) and 0.0 < dens < 1.0\n"
         "assert lib.dr_set_option(b'NO_SUCH_SWITCH', b'1') != 0\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
-    env = dict(os.environ, DARTRAY_PILOT_FORCE="1", DARTRAY_VERBOSE="1")
+    env = dict(os.environ, DARTRAY_PILOT="force", DARTRAY_VERBOSE="1")
     for k in ("DARTRAY_TRACE_IMPL", "DARTRAY_STATE_LAYOUT"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)

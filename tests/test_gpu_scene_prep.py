@@ -1,7 +1,7 @@
 """dr_scene_create's work on the marshalled tree, on the device (dartray_amd/csrc/dr_scene_prep.hip): validation of every node
 and primitive, the tree's height, the sibling-pair records in their memory order, the union check.  The serial host loops of
 round 3 (DARTRAY_SCENE_PREP=host through dr_set_option) are the reference: same errors, same height, the same pair records byte
-for byte, for the depth-first and the top:T orders."""
+for byte."""
 import ctypes as C
 
 import numpy as np
@@ -22,29 +22,25 @@ def _pairs(dev):
     return out, int(top.value), int(depth.value)
 
 
-def _create(acc, prep, order=None):
+def _create(acc, prep):
     lib = _abi.lib()
     _abi.check(lib.dr_set_option(b"SCENE_PREP", prep))
-    _abi.check(lib.dr_set_option(b"PAIR_ORDER", order))
     try:
         return core._DeviceScene(acc, acc.lights())
     finally:
         _abi.check(lib.dr_set_option(b"SCENE_PREP", None))
-        _abi.check(lib.dr_set_option(b"PAIR_ORDER", None))
 
 
-@pytest.mark.parametrize("order", [None, b"dfs", b"top:1", b"top:3", b"top:7", b"top:40"])
-@pytest.mark.parametrize("blob", [(8, 4), (60, 30), (333, 77)])
-def test_device_prep_equals_the_host_loops(gpu, blob, order):
+@pytest.mark.parametrize("blob", [(2, 2), (8, 4), (60, 30), (333, 77)])   # trees lower and higher than the breadth-first top (12 levels)
+def test_device_prep_equals_the_host_loops(gpu, blob):
     prims, _ = scenes.config("C2", xres=8, yres=8, spp=1, blob=blob)
     acc = core.BVHAccel(prims)
-    dev, host = _create(acc, None, order), _create(acc, b"host", order)
+    dev, host = _create(acc, None), _create(acc, b"host")
     pd, topd, depthd = _pairs(dev)
     ph, toph, depthh = _pairs(host)
     assert len(pd) == (len(acc.nodes) - 1) // 2 and depthd == depthh == acc.depth and topd == toph
     assert pd.tobytes() == ph.tobytes()
-    if order in (None, b"top:40") or (order or b"").startswith(b"top:"):
-        assert topd > 0
+    assert topd > 0
     # the height is measured when the host passes none, and a bound below it is refused
     acc2 = core.BVHAccel(prims)
     acc2.depth = 0
@@ -127,10 +123,10 @@ def test_malformed_trees_and_tables_are_refused_like_before(gpu):
         assert len(_pairs(d)[0]) == 0
 
 
-@pytest.mark.parametrize("order", [b"sib", b"veb:2:3", b"pad:2", b"dfs", b"top:5"])
-def test_experimental_pair_orders_trace_the_same_hits(gpu, ob, order):
-    """Every memory order of the pair records (the experimental ones are laid out by the host loops) gives the hits and the visit
-    counters of the oracle: the references inside the records are explicit."""
+@pytest.mark.parametrize("prep", [None, b"host"])
+def test_pair_records_of_either_prep_trace_the_oracles_hits(gpu, ob, prep):
+    """The pair records as the device lays them out, and as the host loops do, give the oracle's hits (dr_intersect through the
+    pair kernels).  (Round 3's other memory orders of the records: experiments/r06_runtime_switches.diff.)"""
     prims, _ = scenes.config("C2", xres=8, yres=8, spp=1, blob=(40, 20))
     acc = core.BVHAccel(prims)
     lib = _abi.lib()
@@ -146,7 +142,7 @@ def test_experimental_pair_orders_trace_the_same_hits(gpu, ob, order):
     ref = osc.intersect(rays, any_hit=False)
     try:
         _abi.check(lib.dr_set_option(b"TRACE_IMPL", b"3"))
-        dev = _create(acc, None, order)
+        dev = _create(acc, prep)
         out = dev.intersect(ray, any_hit=False)
     finally:
         _abi.check(lib.dr_set_option(b"TRACE_IMPL", None))
