@@ -445,7 +445,7 @@ def compact_line(d, detail_path=None):
         line["kernel_ms_per_step"] = {k: v for k, v in d["kernel_ms_per_step"].items() if not isinstance(v, str)}
     if d.get("per_sample"):
         line["per_sample"] = d["per_sample"]
-    for k in ("first_render_ms", "pilot_ms", "workspace_bytes", "replay_Msamples_s", "rccl_world", "reduce_ms", "film_bytes_reduced_per_step"):
+    for k in ("first_render_ms", "second_render_ms", "pilot_ms", "workspace_bytes", "first_render_workspace_bytes", "replay_Msamples_s", "rccl_world", "reduce_ms", "film_bytes_reduced_per_step"):
         if d.get(k) is not None:
             line[k] = d[k]
     if d.get("one_shot_ms"):
@@ -660,6 +660,13 @@ class Run:
             self.rgb.cpu()  # the image back on the host: what Renderer.render hands to its caller
         one_shot_render_ms = (time.perf_counter() - t0) * 1e3
         pilot_ms = self.dev.stats()["pilot_ms"]
+        first_workspace = self.dev.workspace_bytes()
+        # the SECOND render of a scene: the library kept the first one's batches at 2^27 slots (what a one-shot host pays for) and now grows the
+        # workspace to one batch per image -- the steady state of a frame loop; timed on its own, not one of the W + K steps either
+        t0 = time.perf_counter()
+        self.step()
+        torch.cuda.synchronize()
+        second_ms = (time.perf_counter() - t0) * 1e3
         for _ in range(warmup):
             self.step()
         torch.cuda.synchronize()
@@ -772,7 +779,9 @@ class Run:
                            "tris": round((st["closest_tris"] + st["any_tris"]) / max(1, st["camera_samples"]), 3),
                            "alg_bytes": round(all_alg / max(1, st["camera_samples"]) + 148 + 32, 1)},
             "first_render_ms": round(first_ms, 1),
+            "second_render_ms": round(second_ms, 1),
             "pilot_ms": round(pilot_ms, 1),
+            "workspace_bytes": int(self.dev.workspace_bytes()), "first_render_workspace_bytes": int(first_workspace),
             # what a one-shot host pays from host pointers to the image on the host (Renderer.render once per task,
             # lib/dartray/dartray.dart:574): the BVHAccel constructor, the scene upload, the first render incl. resolve and copy out
             "one_shot_ms": {"bvh_build": round(agg.build_ms, 1), "scene_create": round(self.create_ms, 1),

@@ -128,6 +128,7 @@ class DrRenderStats(C.Structure):
 
 
 DR_COMM_ID_BYTES = 128
+DR_ABI_VERSION = 7  # include/dartray_hip.h (tests/test_host_logic.py compares the two); lib() refuses a library of another version
 
 
 # name -> (restype, argtypes): every symbol include/dartray_hip.h declares.
@@ -172,6 +173,8 @@ EXPORTS = {
     "dr_comm_destroy": (C.c_int, []),
     "dr_last_error": (C.c_char_p, []),
     "dr_version": (C.c_char_p, []),
+    "dr_abi_version": (C.c_int32, []),
+    "dr_scene_workspace_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None
@@ -242,6 +245,8 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        if l.dr_abi_version() != DR_ABI_VERSION:
+            raise DartRayHipError("libdartray_hip.so has ABI version %d, this binding was written against %d" % (l.dr_abi_version(), DR_ABI_VERSION))
         _lib = l
     return _lib
 

@@ -667,6 +667,12 @@ class _DeviceScene:
                 "pilot_batches": int(arr[4]), "batches": int(arr[5]), "trace_wg_per_cu": int(arr[6]), "overlap_any": int(arr[7]) & 1,
                 "coherent_camera": (int(arr[7]) >> 1) & 1, "lazy_gen": (int(arr[7]) >> 3) & 1}
 
+    def workspace_bytes(self):
+        """Device memory the scene's path-state workspace holds right now (dr_scene_workspace_bytes)."""
+        n = C.c_uint64(0)
+        _abi.check(_abi.lib().dr_scene_workspace_bytes(self.handle, C.byref(n)))
+        return int(n.value)
+
     def coherent_stats(self):
         """The part of stats()' closest-hit totals that k_trace_pk (coherent waves: the camera rays) traced."""
         arr = (C.c_double * 5)()

@@ -56,6 +56,7 @@ struct DevBuf {
     p = nullptr;
     n = 0;
   }
+  size_t bytes() const { return p ? std::max<size_t>(n, 1) * sizeof(T) : 0; }
   ~DevBuf() { release(); }
 };
 
@@ -140,6 +141,7 @@ struct DrScene {
   DevBuf<TraceCounters> ctr;
   uint32_t bvhDepth = 0;
   bool traceCalibrated = false;
+  uint32_t bigRenders = 0;      // big renders this scene has finished (planBatches: the first one keeps its batches at 2^27 slots)
   int stateLayout = 0;          // path-state layout of this scene's path renders: 0 = not measured yet, 64 / 4 (LayoutOps)
   float layoutDensity = -1.f;   //   what decided it: the share of a pilot batch's slots still alive at the second bounce
   float calibMs[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // pilot of dr_render_device: [closest / any][v2 / v3 / v3c] ms
@@ -486,7 +488,8 @@ int dr_set_option(const char* name, const char* value) {
   else g_options.erase(n);          // null: back to the environment's value
   return DR_OK;
 }
-const char* dr_version(void) { return "dartray_amd 0.1 (gfx950)"; }
+const char* dr_version(void) { return "dartray_amd 0.6 (gfx950, abi 7)"; }
+int32_t dr_abi_version(void) { return DR_ABI_VERSION; }
 
 int dr_init(int device) {
   int n = 0;
@@ -1230,6 +1233,15 @@ int dr_scene_get_pairs(const DrScene* sc, void* out, uint64_t cap_bytes, uint64_
   return DR_OK;
 }
 
+int dr_scene_workspace_bytes(const DrScene* sc, uint64_t* bytes_out) {
+  if (!sc || !bytes_out) return fail(DR_ERR_INVALID, "null argument");
+  const Workspace& w = sc->ws;
+  *bytes_out = w.tiles.bytes() + w.scr.bytes() + w.genState.bytes() + w.tail.bytes() + w.tailOff.bytes() + w.activeA.bytes() + w.activeB.bytes() +
+               w.closestQ.bytes() + w.anyQ.bytes() + w.counters.bytes() + w.spill.bytes() + w.envQ.bytes() + w.alive.bytes() + w.roundA.bytes() +
+               w.roundB.bytes() + w.specFrames.bytes() + w.specSp.bytes() + w.pix.bytes() + w.filterTable.bytes() + w.aosSamples.bytes();
+  return DR_OK;
+}
+
 int dr_scene_get_state_layout(const DrScene* sc, int32_t* layout_out, float* density_out) {
   if (!sc || !layout_out) return fail(DR_ERR_INVALID, "null argument");
   *layout_out = sc->stateLayout;
@@ -1279,35 +1291,69 @@ int dr_intersect(DrScene* sc, const DrRay* rays, int64_t n, DrHit* out, int32_t 
   return DR_OK;
 }
 
-int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* hip_stream) {
-  if (!sc || !rd || !film_dev) return fail(DR_ERR_INVALID, "null argument");
-  hipStream_t s = (hipStream_t)hip_stream;
-  const int spp = rd->spp;
+}  // extern "C"
+
+// ===========================================================================
+// dr_render_device, in units: RenderPlan (what this call runs: planRender, planBatches), prepareRender (workspace, pilot
+// decision, uploads), BatchRunner (one batch through the stage loop), runPilot (the calibration batches) and the entry
+// point, which strings them together and records what ran.
+// ===========================================================================
+namespace {
+
+struct RenderPlan {
+  DrScene* sc = nullptr;
+  const DrRenderDesc* rd = nullptr;
+  float* film = nullptr;
+  hipStream_t s = nullptr;
+  RenderParams rp;
+  SampleForm sf;
+  const LayoutOps* L = nullptr;  // state layout of the NEXT batch (the layout pilot decides it after the first calibration batch)
+  int spp = 0;
+  bool direct = false, dlSpec = false, envStage = false, hostBuf = false, packedTail = false;
+  int needTail = 0;       // RNG draws a path can make beyond the sample vector (host-buffer mode: the recorded tail)
+  bool layoutKnown = false;
+  int maxStateWords = 0;  // words per slot the workspace is sized for (both layouts while the layout is not known)
+  bool coherentCamera = false, lazyGen = false, overlapAny = false;
+  bool calibrateTrace = false, measureLayout = false;
+  int pilotSets = 0;      // calibration batches: warm-up, k_trace timed, k_trace3 timed, k_trace3c timed; the layout alone: one
+  size_t calibPix = 0;    // pixels per calibration batch: the first pilotSets * calibPix entries of `pixels`
+  std::vector<int2> pixels;
+  size_t npixTotal = 0;
+  uint64_t filmSamples = 0;
+  uint32_t pixPerBatch = 0, cap = 0;
+  uint64_t nBatches = 0;
+  int tgrid = 0, sgrid = 0, nStages = 0;
+  bool calibrate() const { return calibrateTrace || measureLayout; }
+};
+
+// What the call asks for, checked, as RenderParams + the flags every later unit reads; which pixels it traces.
+int planRender(RenderPlan& P) {
+  DrScene* sc = P.sc;
+  const DrRenderDesc* rd = P.rd;
+  const int spp = P.spp = rd->spp;
   if (spp <= 0 || (spp & (spp - 1)) != 0) return fail(DR_ERR_INVALID, "spp must be a power of two (low_discrepancy_sampler.dart:43-49)");
   if (spp > 4096) return fail(DR_ERR_UNSUPPORTED, "spp > 4096 (one pixel's shuffle table of a 16-pixel sampler group would not fit the LDS)");
-  if (rd->integrator != DR_INTEGRATOR_PATH && rd->integrator != DR_INTEGRATOR_DIRECT_ALL)
-    return fail(DR_ERR_INVALID, "unknown integrator");
+  if (rd->integrator != DR_INTEGRATOR_PATH && rd->integrator != DR_INTEGRATOR_DIRECT_ALL) return fail(DR_ERR_INVALID, "unknown integrator");
   if (rd->max_depth < 0 || rd->max_depth > 64) return fail(DR_ERR_INVALID, "max_depth out of range");
+  P.direct = rd->integrator == DR_INTEGRATOR_DIRECT_ALL;
   // DirectLighting over mirror / glass recurses through SpecularReflect / SpecularTransmit (integrator.dart:187-290):
   // an explicit per-slot stack and one round of the stage loop per vertex of the ray tree (k_shade_spec)
-  const bool dlSpec = rd->integrator == DR_INTEGRATOR_DIRECT_ALL && sc->hasSpecular;
+  P.dlSpec = P.direct && sc->hasSpecular;
   // k_env (dr_kernels.hip): the environment-map work of a plain-triangle scene's path stages runs in its own kernel
-  const bool envStage = rd->integrator == DR_INTEGRATOR_PATH && sc->d.hasEnv && !(sc->d.nquads || sc->d.hasSpec || sc->d.srec);
-  // state layout of this render (see LayoutOps): the four-slot sub-tiles for the renders whose lists thin out early
-  // Which one is MEASURED on the render's own work (round 4; round 3 took the four-slot layout for every plain-triangle
-  // scene under an environment map): the first pilot batch -- the calibration batches below, rendered into the film like any
-  // other -- runs in the 64-slot layout and its stage lists say how fast the paths die; when less than half of the slots
-  // are still alive at the second bounce the rest of the render, and every later render of the scene, uses the four-slot
-  // sub-tiles (C5: 0.38 -> sp4; C2 0.80, C4: 64-slot).  DARTRAY_STATE_LAYOUT=64|4 forces one, dr_scene_set_state_layout
-  // stores one; renders too small for a pilot keep round 3's rule.
-  const DrOpt layoutEnv = dr_opt("DARTRAY_STATE_LAYOUT");  // 64 | 4: A/B runs and tests (a copy: later look-ups cannot change it)
-  const bool layoutKnown = layoutEnv || sc->stateLayout != 0 || rd->integrator != DR_INTEGRATOR_PATH;
-  const bool sparseLayout = layoutEnv ? layoutEnv.toInt(0) == 4 : (sc->stateLayout ? sc->stateLayout == 4 : envStage);
-  const LayoutOps* Lp = sparseLayout ? &kLayoutSp4 : &kLayout64;
-  const int maxStateWords = layoutKnown ? Lp->stateWords : std::max(kLayout64.stateWords, kLayoutSp4.stateWords);
-#define L (*Lp)
+  P.envStage = rd->integrator == DR_INTEGRATOR_PATH && sc->d.hasEnv && !(sc->d.nquads || sc->d.hasSpec || sc->d.srec);
+  // State layout (see LayoutOps): the four-slot sub-tiles for the renders whose lists thin out early.  Which one is MEASURED on
+  // the render's own work: the first calibration batch -- rendered into the film like any other -- runs in the 64-slot layout
+  // and its stage lists say how fast the paths die; when less than half of the slots are still alive at the second bounce the
+  // rest of the render, and every later render of the scene, uses the four-slot sub-tiles (C5: 0.38 -> sp4; C2 0.80, C4: 64-slot).
+  // DARTRAY_STATE_LAYOUT=64|4 forces one, dr_scene_set_state_layout stores one; renders too small for a pilot keep round 3's
+  // rule (plain-triangle scenes under an environment map: sp4).
+  const DrOpt layoutEnv = dr_opt("DARTRAY_STATE_LAYOUT");
+  P.layoutKnown = layoutEnv || sc->stateLayout != 0 || rd->integrator != DR_INTEGRATOR_PATH;
+  const bool sparseLayout = layoutEnv ? layoutEnv.toInt(0) == 4 : (sc->stateLayout ? sc->stateLayout == 4 : P.envStage);
+  P.L = sparseLayout ? &kLayoutSp4 : &kLayout64;
+  P.maxStateWords = P.layoutKnown ? P.L->stateWords : std::max(kLayout64.stateWords, kLayoutSp4.stateWords);
 
-  RenderParams rp;
+  RenderParams& rp = P.rp;
   memset(&rp, 0, sizeof(rp));
   memcpy(rp.r2c, rd->camera.raster_to_camera, sizeof(rp.r2c));
   memcpy(rp.c2w, rd->camera.camera_to_world, sizeof(rp.c2w));
@@ -1324,20 +1370,17 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.sppShift = 0;
   while ((1 << rp.sppShift) < spp) ++rp.sppShift;
   rp.nLights = (int)sc->d.nlights;
-  const bool direct = rd->integrator == DR_INTEGRATOR_DIRECT_ALL;
-  rp.nFloats = direct ? sc->dlNFloats : dr_sample_floats(rd->integrator, sc->d.nlights);
-  rp.n1D = direct ? sc->dlN1D : 14;
-  rp.blocks = direct && sc->dlMulti ? sc->dlBlocks.p : nullptr;
+  rp.nFloats = P.direct ? sc->dlNFloats : dr_sample_floats(rd->integrator, sc->d.nlights);
+  rp.n1D = P.direct ? sc->dlN1D : 14;
+  rp.blocks = P.direct && sc->dlMulti ? sc->dlBlocks.p : nullptr;
   rp.nBlocks = sc->dlNBlocks;
   rp.dstages = sc->dlStages.p;
-  rp.nDirectStages = direct ? sc->dlNStages : 0;
-  rp.dlSpecular = dlSpec ? 1 : 0;
+  rp.nDirectStages = P.direct ? sc->dlNStages : 0;
+  rp.dlSpecular = P.dlSpec ? 1 : 0;
   rp.deferredNee = rd->integrator == DR_INTEGRATOR_PATH ? 1 : 0;
   rp.genMask = 0ull;
-  const bool genSlow = dr_opt("DARTRAY_GEN_SLOW_DRAWS").set;
-  rp.genSlowDraws = genSlow ? 1 : 0;
-  const bool genAll = dr_opt("DARTRAY_GEN_ALL_BLOCKS").set;  // A/B and tests: generate every block
-  if (rd->integrator == DR_INTEGRATOR_PATH && !rp.blocks && !genAll) {
+  rp.genSlowDraws = dr_opt("DARTRAY_GEN_SLOW_DRAWS").set ? 1 : 0;
+  if (rd->integrator == DR_INTEGRATOR_PATH && !rp.blocks && !dr_opt("DARTRAY_GEN_ALL_BLOCKS").set) {
     // What the path kernels read of a pixel sample (dr_kernels.hip: k_raygen, load_shade_in, k_film): the image sample,
     // the lens sample of a thin-lens camera, and per SAMPLE_DEPTH level b <= maxDepth the light number, the light
     // sample (component + position), the BSDF and path directions; the two uComponent slots only where a material has
@@ -1354,31 +1397,656 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   rp.samplerMode = rd->sampler_mode;
   rp.seed = (uint64_t)rd->seed;
   const int perNee = rp.nLights > 0 ? 7 : 0;
-  const int needTail = rd->integrator == DR_INTEGRATOR_PATH && rd->max_depth >= 3
-                           ? (rd->max_depth - 2) * (perNee + 3) + std::max(0, rd->max_depth - 3)
-                           : 0;
+  P.needTail = rd->integrator == DR_INTEGRATOR_PATH && rd->max_depth >= 3 ? (rd->max_depth - 2) * (perNee + 3) + std::max(0, rd->max_depth - 3) : 0;
   rp.maxTail = rd->max_tail;
 
   // ---- which pixels does this call trace? ----
-  std::vector<int2> pixels;
-  const bool hostBuf = rd->sampler_mode == DR_SAMPLER_HOST_BUFFER;
-  if (hostBuf) {
+  P.hostBuf = rd->sampler_mode == DR_SAMPLER_HOST_BUFFER;
+  if (P.hostBuf) {
     if (rd->nsamples <= 0 || rd->nsamples % spp != 0 || !rd->pixel_xy || !rd->sample_vec)
       return fail(DR_ERR_INVALID, "host-buffer sampler: nsamples must be a positive multiple of spp with pixel_xy and sample_vec set");
     if (rd->sample_stride < rp.nFloats) return fail(DR_ERR_INVALID, "sample_stride smaller than the sample vector");
-    if (needTail > 0 && (!rd->tail || rd->max_tail < needTail))
+    if (P.needTail > 0 && (!rd->tail || rd->max_tail < P.needTail))
       return fail(DR_ERR_INVALID, "host-buffer sampler: tail buffer missing or max_tail too small for max_depth");
-    if (needTail > 0 && rd->tail_offsets && rd->tail_offsets[rd->nsamples] < rd->tail_offsets[0])
+    P.packedTail = P.needTail > 0 && rd->tail_offsets != nullptr;  // (its device buffers are sized per batch: BatchRunner::loadSamples)
+    if (P.packedTail && rd->tail_offsets[rd->nsamples] < rd->tail_offsets[0])
       return fail(DR_ERR_INVALID, "host-buffer sampler: tail_offsets must be non-decreasing");
-    int64_t np = rd->nsamples / spp;
-    pixels.resize(np);
-    for (int64_t i = 0; i < np; ++i) pixels[i] = make_int2(rd->pixel_xy[2 * i], rd->pixel_xy[2 * i + 1]);
+    const int64_t np = rd->nsamples / spp;
+    P.pixels.resize(np);
+    for (int64_t i = 0; i < np; ++i) P.pixels[i] = make_int2(rd->pixel_xy[2 * i], rd->pixel_xy[2 * i + 1]);
   } else if (rd->sampler_mode == DR_SAMPLER_COUNTER) {
-    enumeratePixels(rp, rd, pixels);
+    enumeratePixels(rp, rd, P.pixels);
   } else {
     return fail(DR_ERR_INVALID, "unknown sampler mode");
   }
-  const size_t npixTotal = pixels.size();
+  P.npixTotal = P.pixels.size();
+  P.filmSamples = 0;
+  for (const int2& p : P.pixels)
+    if (p.x >= rp.left && p.x < rp.left + rp.width && p.y >= rp.top && p.y < rp.top + rp.height) P.filmSamples += spp;
+  P.sgrid = g_numCU;  // the shade launchers size their grid per CU (DR_SHADE_GRID), grid-stride over the active list
+  P.nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
+  if (P.nStages > 248 || 8 * DR_WORK_STRIDE * (1 + 2 * P.nStages) > N_COUNTERS_TRACE - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
+  return DR_OK;
+}
+
+// The sample form and the batches: how many camera samples are in flight at once.
+int planBatches(RenderPlan& P) {
+  DrScene* sc = P.sc;
+  const DrRenderDesc* rd = P.rd;
+  const RenderParams& rp = P.rp;
+  const int spp = P.spp;
+  // Sample vectors: the on-device LD sampler stores permuted indices + scrambles (compact form) whenever every LD block
+  // has one entry per pixel sample; host buffers and multi-entry blocks (DirectLighting with nsamples > 1) use floats.
+  SampleForm& sf = P.sf;
+  sf.compact = !P.hostBuf && rp.blocks == nullptr;
+  if (!sf.compact && !P.hostBuf && spp > 1024)
+    return fail(DR_ERR_UNSUPPORTED, "spp > 1024 with LD blocks of several entries per sample (DirectLighting with nsamples > 1): the float-form sampler's table exceeds the LDS");
+  sf.nFloats = rp.nFloats;
+  sf.nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
+  sf.idxShift = spp > 256 ? 1 : 0;
+  // Camera samples in flight per batch.  The throughput end is one batch per image (2^28 slots: C2's whole sampler window, 64 GB of a
+  // 288 GB MI355X); a scene's FIRST big render -- all a one-shot host ever does (Renderer.render once per task, dartray.dart:574) --
+  // stays at 2^27 (C2: three batches, 21 GB, whose hipMalloc does not wait for the driver to scrub 64 GB: profiles/r05_alloc_probe.txt)
+  // and the workspace grows to the image when the same scene is rendered again (a frame loop, bench.py's steps: + 3 % steady state).
+  const DrOpt bitsOpt = dr_opt("DARTRAY_BATCH_BITS");
+  const int slotBits = std::min(28, std::max(16, bitsOpt ? bitsOpt.toInt(28) : (sc->bigRenders == 0 ? 27 : 28)));
+  uint64_t maxSlots = 1ull << slotBits;
+  {
+    // path state per camera sample: 164 B of ray / hit / NEE state, 20 B of queues and the sample vector (24 B of permuted
+    // indices in the compact form, 4 B per float otherwise; + the RNG tail in host-buffer mode).  On a device with less free
+    // memory the batch shrinks instead of failing (results do not depend on the batch size).
+    const uint64_t tailPerSlot = !(P.hostBuf && P.needTail > 0) ? 0ull
+                                 : (P.packedTail ? 16ull + 8ull * ((rd->tail_offsets[rd->nsamples] - rd->tail_offsets[0]) / (uint64_t)rd->nsamples + 1ull)
+                                                 : (uint64_t)rd->max_tail * 8);
+    const uint64_t perSlot = (uint64_t)P.maxStateWords * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 + tailPerSlot + (P.hostBuf ? (uint64_t)rd->sample_stride * 4 : 0) +
+                             (sf.compact ? (uint64_t)(16 * sf.nBlocks + spp - 1) / spp : 0) +  // scramble words + generator states, per (block, pixel)
+                             (P.dlSpec ? (uint64_t)std::max(1, rd->max_depth) * sizeof(SpecFrame) + 12 : 0);
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)sc->ws.stateWords * 4 + sc->ws.svWords / 16 + 20);
+      const uint64_t budget = (uint64_t)(0.9 * (double)freeB) + have;
+      // (+ 1/4: the slack that lets a slightly larger window still go as one batch, below)
+      while (maxSlots > (1ull << 16) && std::min<uint64_t>(maxSlots + maxSlots / 4, (uint64_t)P.npixTotal * spp) * perSlot > budget) maxSlots >>= 1;
+    }
+  }
+  // Equal batches, and no tiny tail batch: every stage launch costs ~0.4 ms of ramp-up and tail however small it is
+  // (the sampler window of a 1024 x 1024 film is 1025 x 1025 pixels -- 2^20 + 2049).
+  const uint64_t pixCapBatch = std::max<uint64_t>(1, maxSlots / spp);
+  P.nBatches = (P.npixTotal + pixCapBatch - 1) / pixCapBatch;
+  if (P.nBatches > 1 && P.npixTotal <= pixCapBatch + pixCapBatch / 4) P.nBatches = 1;
+  P.pixPerBatch = (uint32_t)((P.npixTotal + P.nBatches - 1) / P.nBatches);
+  P.cap = P.pixPerBatch * (uint32_t)spp;
+  return DR_OK;
+}
+
+// Workspace, streams, the pilot decision (which reorders the pixels), and the uploads every batch reads.
+int prepareRender(RenderPlan& P) {
+  DrScene* sc = P.sc;
+  const DrRenderDesc* rd = P.rd;
+  const int spp = P.spp;
+  const auto tAlloc0 = std::chrono::steady_clock::now();
+  const uint32_t capBefore = sc->ws.cap;
+  int rc = allocWorkspace(sc, sc->ws, P.cap, P.sf, P.pixPerBatch, rd->max_tail, P.hostBuf && P.needTail > 0 && !P.packedTail, P.maxStateWords);
+  if (rc) return rc;
+  if (dr_opt("DARTRAY_VERBOSE") && sc->ws.cap != capBefore) {
+    (void)hipDeviceSynchronize();
+    fprintf(stderr, "dartray_hip: path-state workspace for %u slots (%.1f GB) allocated in %.1f ms\n", sc->ws.cap,
+            (double)sc->ws.tiles.n * 4.0e-9 + (double)sc->ws.cap * 20.0e-9,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tAlloc0).count());
+  }
+  if (P.dlSpec) {
+    HIP_TRY(sc->ws.specFrames.alloc((size_t)sc->ws.cap * std::max(1, rd->max_depth) * DR_SPEC_FRAME_WORDS));
+    HIP_TRY(sc->ws.specSp.alloc(sc->ws.cap));
+    HIP_TRY(sc->ws.roundA.alloc(sc->ws.cap));
+    HIP_TRY(sc->ws.roundB.alloc(sc->ws.cap));
+  }
+  if (P.envStage) HIP_TRY(sc->ws.envQ.alloc(sc->ws.cap));
+  P.tgrid = traceGrid();
+  rc = ensureSpill(sc, sc->ws, P.tgrid);
+  if (rc) return rc;
+  // the camera rays (a tile = 64 samples of one pixel) through the wave-coherent kernel k_trace_pk (DARTRAY_COHERENT_CAMERA=0: k_trace & co.)
+  P.coherentCamera = !dr_opt("DARTRAY_COHERENT_CAMERA").isZero() && !P.dlSpec;
+  // lazy sample generation (DARTRAY_LAZY_GEN=0: every block for every pixel up front): needs the device sampler's compact form, the keyed
+  // per-(pixel, block) streams (a block that is left out disturbs no other) and k_trace_pk's marks of the camera rays that hit
+  P.lazyGen = !P.hostBuf && P.sf.compact && P.rp.genMask != 0ull && rd->integrator == DR_INTEGRATOR_PATH && P.coherentCamera && !sc->d.nquads && spp >= 64 &&
+              !dr_opt("DARTRAY_LAZY_GEN").isZero();
+  // a stage's any-hit launch beside its closest-hit launch, on a second stream (DARTRAY_OVERLAP_ANY=0: one after the other)
+  P.overlapAny = !dr_opt("DARTRAY_OVERLAP_ANY").isZero() && !P.dlSpec;
+  if (P.overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
+  // Which traversal kernel?  k_trace (one node per step, f32 filter) is issue bound and wins while the hot part of the tree stays in
+  // cache; the pair kernels (half the dependent fetches) win on big incoherent trees (C4 hairball +26 %) and lose on others of the same
+  // size; random probe rays mispredict both.  So the first big render of a big scene measures it ON ITS OWN WORK: small calibration
+  // batches -- 64-pixel groups spread over the image -- are rendered first, into the film like every other batch: one with k_trace to
+  // warm the caches, then one per candidate, timed; each ray kind keeps the kernel with the better time per algorithmic byte (the
+  // device's own node / triangle counters of that batch).  Nothing is traced twice.  All kernels are bit-exact, so results do not depend
+  // on the choice; dr_scene_set_trace_kernels / DARTRAY_TRACE_IMPL fix it (an N-rank host measures on rank 0 and hands the choice on).
+  const DrOpt pilotOpt = dr_opt("DARTRAY_PILOT");  // 0: never; force: also on renders too small to need one (tests)
+  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)P.npixTotal * spp >= (1ull << 25)) || pilotOpt.is("force");
+  const bool pilotOk = !pilotOpt.is("0") && !P.hostBuf && !P.dlSpec && bigJob && P.npixTotal >= 3 * 64 * 4;
+  P.calibrateTrace = !sc->traceCalibrated && pilotOk && !dr_opt("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads;
+  P.measureLayout = !P.layoutKnown && pilotOk;
+  if (P.measureLayout) P.L = &kLayout64;  // the batch whose stage lists are measured runs in the 64-slot layout
+  P.pilotSets = P.calibrateTrace ? 4 : 1;
+  P.calibPix = 0;
+  if (P.calibrate()) {
+    // (at least 2^24 samples per calibration batch: with 2^22 the launches are so short that their tails decide -- the pair kernel,
+    // whose rays are half as many fetches long, looked 10 % faster than k_trace<0> on C2 and is 12 % slower at full size)
+    uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 24, (uint64_t)P.npixTotal * spp / 16));
+    pilotSamples = std::min<uint64_t>(pilotSamples, (uint64_t)(P.pixPerBatch / 64 * 64) * spp);
+    const size_t totalGroups = P.npixTotal / 64;
+    const size_t groups = std::min<size_t>(std::max<size_t>(1, (size_t)(pilotSamples / spp) / 64), totalGroups / 4);
+    P.calibPix = groups * 64;
+    std::vector<int2> ordered;
+    ordered.reserve(P.npixTotal);
+    std::vector<uint8_t> taken(totalGroups, 0);
+    for (int set = 0; set < P.pilotSets; ++set)
+      for (size_t g = 0; g < groups; ++g) {
+        const size_t grp = (((size_t)P.pilotSets * g + set) * totalGroups) / ((size_t)P.pilotSets * groups);  // interleaved: the sets see the same regions
+        taken[grp] = 1;
+        ordered.insert(ordered.end(), P.pixels.begin() + grp * 64, P.pixels.begin() + grp * 64 + 64);
+      }
+    for (size_t grp = 0; grp < totalGroups; ++grp)
+      if (!taken[grp]) ordered.insert(ordered.end(), P.pixels.begin() + grp * 64, P.pixels.begin() + grp * 64 + 64);
+    ordered.insert(ordered.end(), P.pixels.begin() + totalGroups * 64, P.pixels.end());
+    P.pixels.swap(ordered);
+  }
+  HIP_TRY(sc->ws.pix.alloc(P.npixTotal));
+  HIP_TRY(hipMemcpyAsync(sc->ws.pix.p, P.pixels.data(), P.npixTotal * sizeof(int2), hipMemcpyHostToDevice, P.s));
+  HIP_TRY(hipMemcpyAsync(sc->ws.filterTable.p, rd->film.filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, P.s));
+  HIP_TRY(hipStreamSynchronize(P.s));  // (the copies read host memory the caller and this plan own)
+  return DR_OK;
+}
+
+// The traversal launches of one calibration batch, per ray kind (the coherent camera launch is every candidate's and is left out).
+struct PilotTimes {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+};
+
+// One batch through the stage loop: gen_samples -> raygen -> trace(camera) -> [shade(b) -> (env) -> trace_closest || trace_any] -> film,
+// no host round trips (DirectLighting over mirror / glass: one round of the loop per vertex of a slot's ray tree, one count read back
+// per round).  pilot != null: a calibration batch -- a normal batch whose per-lane traversal launches are also collected in pilot->ev.
+class BatchRunner {
+ public:
+  BatchRunner(RenderPlan& plan, Workspace& ws, const int2* pixDev, size_t firstPixel, uint32_t npixels, PilotTimes* pilotTimes)
+      : P(plan), sc(plan.sc), rd(plan.rd), rp(plan.rp), L(*plan.L), w(ws), s(plan.s), p0(firstPixel), np(npixels), nslots(npixels * (uint32_t)plan.spp),
+        pilot(pilotTimes), C(ws.counters.p) {
+    st = makeState(w, P.sf, pixDev, nslots, P.hostBuf && P.needTail > 0, L.stateWords);
+    const DrOpt scOpt = dr_opt("DARTRAY_STAGE_COUNTS");
+    stageCounts = scOpt.toInt(0) > 0 ? scOpt.toInt(0) : (scOpt.set ? 1 : 0);
+    slog.resize(stageCounts ? (size_t)P.nStages + 1 : 0);  // [0] = the camera rays' traversal, [b + 1] = stage b
+    // A stage's two traversals are independent (closest hit of the continuation / MIS rays, occlusion of the shadow rays).  Side by
+    // side on two streams the any-hit workgroups take the CU slots the closest-hit launch frees as its queue runs dry (a persistent
+    // launch ends with its longest rays).  Calibration batches time each launch alone.
+    sideBySide = P.overlapAny && !pilot;
+  }
+  int run();
+
+ private:
+  // DARTRAY_STAGE_COUNTS=1 (diagnostics): per stage the list lengths, the kernel times (this batch's own events) and -- with
+  // DARTRAY_STAGE_COUNTS=2, which waits for the device after every stage -- the node visits / triangle tests of its traversals
+  struct StageLog {
+    hipEvent_t s0 = nullptr, sMid = nullptr, s1 = nullptr, c0 = nullptr, c1 = nullptr, a0 = nullptr, a1 = nullptr;
+    TraceCounters ctr;
+  };
+  int loadSamples();
+  int loadHostSamples();
+  void genBounce(int b);
+  hipEvent_t timed(int kind, hipEvent_t e0);
+  hipEvent_t trace(const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr, bool coherent = false);
+  void logTrace(StageLog& g, int any);
+  void readCtrNow(TraceCounters* c);
+  StageQueues stageQueues(int b, const uint32_t* roundQ, const uint32_t* nRound);
+  int stage(int b, int round, const uint32_t* roundQ, const uint32_t* nRound);
+  int specRound(int round, const uint32_t*& roundQ, const uint32_t*& nRound, bool& done);
+  int finish();
+  int printStageLog();
+
+  RenderPlan& P;
+  DrScene* sc;
+  const DrRenderDesc* rd;
+  const RenderParams& rp;
+  const LayoutOps& L;
+  Workspace& w;
+  hipStream_t s;
+  size_t p0;
+  uint32_t np, nslots;
+  PilotTimes* pilot;
+  uint32_t* C;  // [0, 1024): stage queue counts; then 8 per-XCD work counters per trace launch; then k_env's counts
+  BatchState st;
+  uint32_t nGroups = 0;  // lazy generation: 64-pixel groups of this batch
+  int wc = 0;            // work counters live at C[1024..], 8 per launch
+  int stageCounts = 0;
+  bool sideBySide = false;
+  std::vector<StageLog> slog;
+  TraceCounters ctrBase = {};
+};
+
+hipEvent_t BatchRunner::timed(int kind, hipEvent_t e0) {
+  hipEvent_t e1 = sc->getEvent();
+  (void)hipEventRecord(e1, s);
+  sc->traceEvents.push_back({e0, e1, kind});
+  return e1;
+}
+
+void BatchRunner::readCtrNow(TraceCounters* c) {
+  if (stageCounts < 2) return;
+  (void)hipStreamSynchronize(s);
+  if (sc->s3) (void)hipStreamSynchronize(sc->s3);
+  (void)hipMemcpy(c, sc->ctr.p, sizeof(TraceCounters), hipMemcpyDeviceToHost);
+}
+
+// lazy sample generation: the LD blocks of bounce b (light number, light component, light position, BSDF direction, path direction:
+// the bits genMask gives the level) for the 64-pixel groups marked in alive[b]
+void BatchRunner::genBounce(int b) {
+  uint64_t m = (15ull << (3 + 4 * b)) | (7ull << (3 + rp.n1D + 3 * b));
+  m &= rp.genMask;
+  if (!m) return;
+  hipEvent_t e0 = sc->getEvent();
+  (void)hipEventRecord(e0, s);
+  RenderParams rpB = rp;
+  rpB.genMask = m;
+  BatchState stB = st;
+  stB.genAlive = w.alive.p + (size_t)b * nGroups;
+  stB.markAlive = nullptr;
+  L.gen_samples(rpB, stB, np, s);
+  timed(3, e0);
+}
+
+// Host-buffer sampler: this batch's sample vectors (and the RNG tail) from the caller's memory.
+int BatchRunner::loadHostSamples() {
+  const int spp = P.spp;
+  HIP_TRY(w.aosSamples.alloc((size_t)((P.cap + 63u) & ~63u) * rd->sample_stride));
+  HIP_TRY(hipMemcpyAsync(w.aosSamples.p, rd->sample_vec + (size_t)p0 * spp * rd->sample_stride, (size_t)nslots * rd->sample_stride * sizeof(float),
+                         hipMemcpyHostToDevice, s));
+  L.transpose_samples(w.aosSamples.p, rd->sample_stride, st, rp.nFloats, s);
+  if (P.needTail > 0 && P.packedTail) {
+    // the batch's runs are one contiguous piece of the packed array: [off[first], off[first + nslots]).  The header promises
+    // non-decreasing offsets and runs of at most max_tail values; a host that breaks the promise gets DR_ERR_INVALID here, not a
+    // device read outside the piece that is copied (tailOff[slot + 1] - tailOff[slot] as a huge unsigned run).
+    const uint64_t* off = rd->tail_offsets + (size_t)p0 * spp;
+    for (uint32_t i = 0; i < nslots; ++i)
+      if (off[i + 1] < off[i] || off[i + 1] - off[i] > (uint64_t)rd->max_tail)
+        return fail(DR_ERR_INVALID, "host-buffer sampler: tail_offsets must be non-decreasing with runs of at most max_tail values");
+    const uint64_t o0 = off[0], o1 = off[nslots];
+    HIP_TRY(w.tail.alloc((size_t)(o1 - o0) + (size_t)rd->max_tail + 1));
+    HIP_TRY(w.tailOff.alloc((size_t)nslots + 1));
+    if (o1 > o0) HIP_TRY(hipMemcpyAsync(w.tail.p, rd->tail + o0, (size_t)(o1 - o0) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.tailOff.p, off, ((size_t)nslots + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    st.tail = w.tail.p;
+    st.tailOff = w.tailOff.p;
+    st.tailBase = o0;
+  } else if (P.needTail > 0) {
+    HIP_TRY(hipMemcpyAsync(w.tail.p, rd->tail + (size_t)p0 * spp * rd->max_tail, (size_t)nslots * rd->max_tail * sizeof(double), hipMemcpyHostToDevice, s));
+  }
+  return DR_OK;
+}
+
+// The batch's pixel samples (host buffers, or the device LD sampler: everything now, or lazily) and its camera rays.
+int BatchRunner::loadSamples() {
+  hipEvent_t evGen = sc->getEvent();
+  (void)hipEventRecord(evGen, s);
+  if (P.hostBuf) {
+    const int rc = loadHostSamples();
+    if (rc) return rc;
+  } else if (P.lazyGen) {
+    // the image (+ lens) blocks for every pixel now; the blocks of bounce b once it is known which 64-pixel groups still have a path there
+    RenderParams rpA = rp;
+    rpA.genMask = rp.genMask & 3ull;
+    L.gen_samples(rpA, st, np, s);
+    nGroups = (np + 63u) / 64u;
+    HIP_TRY(w.alive.alloc(3 * (size_t)nGroups));
+    HIP_TRY(hipMemsetAsync(w.alive.p, 0, 3 * (size_t)nGroups, s));
+    sc->genDoneHost += (unsigned long long)np * (unsigned)__builtin_popcountll(rpA.genMask);
+    sc->genNamed += (unsigned long long)np * (unsigned)__builtin_popcountll(rp.genMask);
+    st.markAlive = w.alive.p;  // k_trace_pk: the groups whose camera rays hit something
+    st.markShift = (uint32_t)rp.sppShift + 6u;
+  } else {
+    L.gen_samples(rp, st, np, s);
+    if (P.sf.compact && rp.genMask) {
+      sc->genDoneHost += (unsigned long long)np * (unsigned)__builtin_popcountll(rp.genMask);
+      sc->genNamed += (unsigned long long)np * (unsigned)__builtin_popcountll(rp.genMask);
+    }
+  }
+  L.raygen(rp, st, s);
+  timed(3, evGen);
+  return DR_OK;
+}
+
+// One traversal launch over a queue (null: the batch's slots in order = the camera rays).  Returns its end event.
+hipEvent_t BatchRunner::trace(const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after, bool coherent) {
+  hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
+  (void)hipEventRecord(e0, ts);
+  bool tookCoherent = false;
+  if (!(coherent && L.trace_coherent(sc->d, st, queue, nQ, any, C + 1024 + 8 * DR_WORK_STRIDE * wc, sc->ctr.p, P.tgrid, ts))) {
+    L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, P.tgrid, ts);
+    // (lazy sample generation counts on k_trace_pk's marks: should the coherent kernel ever decline a launch that was to leave
+    // them, every group counts as alive -- all blocks are generated, nothing is skipped)
+    if (coherent && !any && st.markAlive) (void)hipMemsetAsync(st.markAlive, 1, nGroups, ts);
+  } else {
+    ++wc;  // (k_trace_pk took this queue: the camera rays)
+    tookCoherent = true;
+  }
+  (void)hipEventRecord(e1, ts);
+  // (the pilot compares the per-lane kernels: the coherent camera launch is the same kernel for every candidate and would only
+  // compress the ratios its thresholds look at)
+  if (pilot && !tookCoherent) pilot->ev[any].push_back({e0, e1});
+  sc->traceEvents.push_back({e0, e1, tookCoherent && !any ? 6 : any, after});
+  return e1;
+}
+
+void BatchRunner::logTrace(StageLog& g, int any) {
+  (any ? g.a0 : g.c0) = sc->traceEvents.back().e0;
+  (any ? g.a1 : g.c1) = sc->traceEvents.back().e1;
+}
+
+StageQueues BatchRunner::stageQueues(int b, const uint32_t* roundQ, const uint32_t* nRound) {
+  StageQueues q;
+  // a stage's four counters sit ~1 KB apart: every wave adds to all four in one round trip (stage_flush), and same-line atomics serialise
+  auto cnt = [&](int j, int stg) { return C + 248 * j + stg; };
+  q.activeIn = b == 0 ? roundQ : ((b - 1) & 1 ? w.activeB.p : w.activeA.p);
+  q.nActiveIn = b == 0 ? nRound : cnt(0, b - 1);
+  q.activeOut = (b & 1) ? w.activeB.p : w.activeA.p;
+  q.nActiveOut = cnt(0, b);
+  q.closestQ = w.closestQ.p;
+  q.nClosest = cnt(1, b);
+  q.anyQ = w.anyQ.p;
+  q.nAny = cnt(2, b);
+  q.work = cnt(3, b);
+  q.ctr = sc->ctr.p;
+  q.envQ = P.envStage ? w.envQ.p : nullptr;
+  q.nEnv = C + N_COUNTERS_TRACE + 64 * b;
+  return q;
+}
+
+// Stage b: shade the active list (+ the environment-map kernel), generate the next bounce's sample blocks where paths are alive,
+// trace the continuation / MIS rays and the shadow rays the stage queued.
+int BatchRunner::stage(int b, int round, const uint32_t* roundQ, const uint32_t* nRound) {
+  const StageQueues q = stageQueues(b, roundQ, nRound);
+  const bool log = stageCounts && round == 0;
+  hipEvent_t evS = sc->getEvent();
+  (void)hipEventRecord(evS, s);
+  if (rd->integrator == DR_INTEGRATOR_PATH) L.shade_path(sc->d, rp, st, q, b, P.sgrid, s);
+  else L.shade_direct(sc->d, rp, st, q, b, P.sgrid, s);
+  hipEvent_t evMid = nullptr;
+  if (stageCounts && P.envStage) {
+    evMid = sc->getEvent();
+    (void)hipEventRecord(evMid, s);
+  }
+  if (P.envStage) L.env(sc->d, rp, st, q, b, P.sgrid, s);
+  hipEvent_t evS1 = timed(2, evS);
+  if (P.lazyGen && round == 0 && b < 2 && b + 1 <= rd->max_depth) {  // bounce b + 1's blocks for the groups in this stage's output list
+    L.mark_alive(q.activeOut, q.nActiveOut, (uint32_t)rp.sppShift + 6u, w.alive.p + (size_t)(b + 1) * nGroups, s);
+    genBounce(b + 1);
+  }
+  if (log) {
+    slog[b + 1].s0 = evS;
+    slog[b + 1].sMid = evMid;
+    slog[b + 1].s1 = evS1;
+  }
+  if (b + 1 >= P.nStages) return DR_OK;
+  if (sideBySide) {
+    hipEvent_t eS = sc->getEvent(), eA = sc->getEvent();
+    (void)hipEventRecord(eS, s);
+    (void)hipStreamWaitEvent(sc->s3, eS, 0);
+    hipEvent_t closestEnd = trace(q.closestQ, q.nClosest, 0, s, w.spill.p);
+    if (log) logTrace(slog[b + 1], 0);
+    trace(q.anyQ, q.nAny, 1, sc->s3, w.spill.p + w.spillHalf, closestEnd);
+    if (log) logTrace(slog[b + 1], 1);
+    (void)hipEventRecord(eA, sc->s3);
+    (void)hipStreamWaitEvent(s, eA, 0);
+  } else {
+    trace(q.closestQ, q.nClosest, 0, s, w.spill.p);
+    if (log) logTrace(slog[b + 1], 0);
+    trace(q.anyQ, q.nAny, 1, s, w.spill.p);
+    if (log) logTrace(slog[b + 1], 1);
+  }
+  if (log) readCtrNow(&slog[b + 1].ctr);
+  return DR_OK;
+}
+
+// DirectLighting over mirror / glass, the end of a round: k_shade_spec pops / pushes every slot's frame stack and lists the slots
+// whose child ray the next round traces.  done: no slot launched a child.
+int BatchRunner::specRound(int round, const uint32_t*& roundQ, const uint32_t*& nRound, bool& done) {
+  StageQueues q;
+  memset(&q, 0, sizeof(q));
+  q.activeIn = roundQ;
+  q.nActiveIn = nRound;
+  uint32_t* nextQ = (round & 1) ? w.roundB.p : w.roundA.p;
+  uint32_t* nNext = C + 1008 + (round & 1);
+  HIP_TRY(hipMemsetAsync(nNext, 0, sizeof(uint32_t), s));
+  q.activeOut = nextQ;
+  q.nActiveOut = nNext;
+  q.closestQ = w.closestQ.p;  // unused: the child rays are the next round's list
+  q.nClosest = C + 1010;
+  q.anyQ = w.anyQ.p;
+  q.nAny = C + 1011;
+  q.ctr = sc->ctr.p;
+  hipEvent_t evS = sc->getEvent();
+  (void)hipEventRecord(evS, s);
+  L.shade_spec(sc->d, rp, st, q, P.sgrid, s);
+  timed(2, evS);
+  uint32_t live = 0;  // (a synchronous read-back per round: this is not the throughput path)
+  HIP_TRY(hipMemcpyAsync(&live, nNext, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  done = live == 0;
+  roundQ = nextQ;
+  nRound = nNext;
+  return DR_OK;
+}
+
+int BatchRunner::printStageLog() {
+  std::vector<uint32_t> hc(N_COUNTERS);
+  HIP_TRY(hipStreamSynchronize(s));
+  if (sc->s3) HIP_TRY(hipStreamSynchronize(sc->s3));
+  HIP_TRY(hipMemcpy(hc.data(), C, N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  const size_t batch = (size_t)sc->stats.batches;
+  for (int b = 0; b < P.nStages; ++b)
+    fprintf(stderr, "stage_counts batch %zu stage %d: in %u active_out %u closest %u any %u env %u\n", batch, b, b == 0 ? nslots : hc[248 * 0 + b - 1],
+            hc[248 * 0 + b], hc[248 * 1 + b], hc[248 * 2 + b], hc[N_COUNTERS_TRACE + 64 * b]);
+  // the kernel times of the same stages (side-by-side any-hit launches overlap the closest-hit ones: DARTRAY_OVERLAP_ANY=0 gives each its
+  // own time) and, with DARTRAY_STAGE_COUNTS=2, the traversal work of each stage
+  auto ms = [](hipEvent_t a, hipEvent_t b) {
+    float t = 0.f;
+    return a && b && hipEventElapsedTime(&t, a, b) == hipSuccess ? (double)t : 0.0;
+  };
+  for (int i = 0; i <= P.nStages; ++i) {
+    const StageLog& g = slog[i];
+    const double shade = g.sMid ? ms(g.s0, g.sMid) : ms(g.s0, g.s1), env = g.sMid ? ms(g.sMid, g.s1) : 0.0;
+    fprintf(stderr, "stage_times batch %zu stage %d: shade %.4f env %.4f closest %.4f any %.4f ms", batch, i - 1, shade, env, ms(g.c0, g.c1), ms(g.a0, g.a1));
+    if (stageCounts >= 2 && (i == 0 || g.c0 || g.a0)) {
+      const TraceCounters& p = i ? slog[i - 1].ctr : ctrBase;
+      fprintf(stderr, "; closest rays %llu nodes %llu tris %llu any rays %llu nodes %llu tris %llu", g.ctr.closest_rays - p.closest_rays,
+              g.ctr.closest_nodes - p.closest_nodes, g.ctr.closest_tris - p.closest_tris, g.ctr.any_rays - p.any_rays, g.ctr.any_nodes - p.any_nodes,
+              g.ctr.any_tris - p.any_tris);
+    }
+    fprintf(stderr, "\n");
+  }
+  return DR_OK;
+}
+
+// After the last stage: the sampler statistics, the film, the diagnostics.
+int BatchRunner::finish() {
+  if (P.lazyGen) {  // statistics: the (pixel, block) pairs the three genBounce calls came to
+    uint32_t nb[3];
+    for (int b = 0; b < 3; ++b) nb[b] = (uint32_t)__builtin_popcountll(((15ull << (3 + 4 * b)) | (7ull << (3 + rp.n1D + 3 * b))) & rp.genMask);
+    L.sum_alive(w.alive.p, nGroups, np, nb, sc->ctr.p, s);
+  }
+  hipEvent_t evF = sc->getEvent();
+  (void)hipEventRecord(evF, s);
+  L.film(rp, st, sc->ws.filterTable.p, np, P.film, s);
+  timed(4, evF);
+  sc->stats.batches++;
+  if (stageCounts) {
+    const int rc = printStageLog();
+    if (rc) return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  if (P.hostBuf) HIP_TRY(hipStreamSynchronize(s));  // host buffers of the next batch reuse the staging area
+  return DR_OK;
+}
+
+int BatchRunner::run() {
+  HIP_TRY(hipMemsetAsync(C, 0, N_COUNTERS * sizeof(uint32_t), s));
+  int rc = loadSamples();
+  if (rc) return rc;
+  // DirectLighting over mirror / glass: one round of the stage loop per vertex of a slot's ray tree (at most 2^maxDepth rounds, like the
+  // recursion itself); `roundQ` lists the slots whose (camera or child) ray this round traces.  Everything else: one round.
+  const uint32_t* roundQ = nullptr;
+  const uint32_t* nRound = nullptr;
+  if (P.dlSpec) HIP_TRY(hipMemsetAsync(w.specSp.p, 0, (size_t)w.cap * sizeof(int32_t), s));
+  for (int round = 0;; ++round) {
+    if (round > 0) {  // the stage counters are reused every round; the round lists' counts live behind them
+      HIP_TRY(hipMemsetAsync(C, 0, 1000 * sizeof(uint32_t), s));
+      HIP_TRY(hipMemsetAsync(C + 1024, 0, (N_COUNTERS - 1024) * sizeof(uint32_t), s));  // (work counters and k_env's counts)
+      wc = 0;
+    }
+    if (stageCounts && round == 0) readCtrNow(&ctrBase);
+    trace(roundQ, nRound, 0, s, w.spill.p, nullptr, P.coherentCamera && roundQ == nullptr);  // camera rays (or this round's child rays)
+    if (stageCounts && round == 0) {  // (before genBounce pushes its own event)
+      logTrace(slog[0], 0);
+      readCtrNow(&slog[0].ctr);
+    }
+    if (P.lazyGen && round == 0) {
+      st.markAlive = nullptr;
+      genBounce(0);
+    }
+    for (int b = 0; b < P.nStages; ++b) {
+      rc = stage(b, round, roundQ, nRound);
+      if (rc) return rc;
+    }
+    if (!P.dlSpec) break;
+    bool done = false;
+    rc = specRound(round, roundQ, nRound, done);
+    if (rc) return rc;
+    if (done) break;
+  }
+  return finish();
+}
+
+// The calibration batches of a scene's first big render (prepareRender decided that there are some): part of the render -- nothing is
+// traced twice -- and the measurement that picks the state layout and, per ray kind, the traversal kernel.
+struct PilotResult {
+  int setsRun = 0;
+  double perByte[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};  // [closest / any][k_trace / k_trace3 / k_trace3c]: ms per algorithmic GB
+  float ms[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+};
+
+// The choice, from the calibration batches' times per algorithmic byte.
+void pickTraceKernels(DrScene* sc, const PilotResult& R) {
+  const double(&perByte)[2][3] = R.perByte;
+  for (int kind = 0; kind < 2; ++kind)
+    for (int c = 0; c < 3; ++c) {
+      sc->calibMs[kind][c] = R.ms[kind][c];
+      sc->calibPerGB[kind][c] = (float)perByte[kind][c];
+    }
+  // closest-hit rays: a pair kernel needs 5 % on k_trace<0>
+  sc->d.traceKernel[0] = perByte[0][1] < 0.95 * perByte[0][0] ? 3u : 2u;
+  // ... and has a second form (round 4): the cold ray state in LDS, six workgroups per CU -- at full size 2.5 - 3 % ahead of k_trace3<0>
+  // on C5 (728 against 762 - 786 ms) and level on C4 (123.2 / 123.5), while the calibration batches put it anywhere from 2 % behind to
+  // 1 % ahead: it keeps the pair family's place unless k_trace3<0> beats it by 5 % there
+  if (perByte[0][2] > 0.0) {
+    const double best3 = std::min(perByte[0][1], perByte[0][2]);
+    if (best3 < 0.95 * perByte[0][0]) sc->d.traceKernel[0] = perByte[0][2] < 1.05 * perByte[0][1] ? 5u : 3u;
+  }
+  // The any-hit rays.  Their calibration launches are the least reliable of the pilot -- shadow rays are short, a small launch is
+  // mostly ramp-up and tail, and the two families come out within a few per cent of each other on the cache-resident scenes (C2:
+  // k_trace3a 6 - 12 % ahead in the calibration batches of five boxes, level at full size) while small launches understate the pair
+  // kernel on the big incoherent tree (C4: -2 ... +6 % in a calibration batch, +25 % at full size).  So they stay in the FAMILY the
+  // closest-hit rays chose -- k_trace<1> beside k_trace<0>, k_trace3a beside k_trace3<0> / k_trace3c -- and cross over only when
+  // their own calibration batch says so by more than 15 %.
+  const bool pairFamily = sc->d.traceKernel[0] != 2u;
+  const double own = pairFamily ? perByte[1][1] : perByte[1][0], other = pairFamily ? perByte[1][0] : perByte[1][1];
+  const bool cross = other > 0.0 && own > 0.0 && other < 0.85 * own;
+  sc->d.traceKernel[1] = (pairFamily != cross) ? 3u : 2u;
+  sc->traceCalibrated = true;
+}
+
+int runPilot(RenderPlan& P, PilotResult& R) {
+  DrScene* sc = P.sc;
+  hipStream_t s = P.s;
+  hipEvent_t evP0 = sc->getEvent(), evP1 = sc->getEvent();
+  HIP_TRY(hipEventRecord(evP0, s));
+  auto readCtr = [&](TraceCounters* c) -> int {
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(c, sc->ctr.p, sizeof(TraceCounters), hipMemcpyDeviceToHost));
+    return DR_OK;
+  };
+  const uint32_t keepKernel[2] = {sc->d.traceKernel[0], sc->d.traceKernel[1]};
+  auto abandon = [&](int code) {  // an error in the middle: the scene keeps the choice it had, not a forced one
+    sc->d.traceKernel[0] = keepKernel[0];
+    sc->d.traceKernel[1] = keepKernel[1];
+    return code;
+  };
+  for (int set = 0; set < P.pilotSets; ++set) {  // warm-up (k_trace), k_trace timed, k_trace3 timed, k_trace3c timed (its any-hit rays: k_trace3a again)
+    // where the pair kernel has just lost clearly to k_trace<0> (C2: 8 - 10 % behind) its cold-state sibling is not timed: k_trace3c is
+    // never more than a few per cent from k_trace3<0>, and the batch is a quarter of the pilot's cost.  Its pixels stay in the ordinary batches.
+    if (set == 3 && P.calibrateTrace && R.perByte[0][1] > 1.05 * R.perByte[0][0]) break;
+    ++R.setsRun;
+    const int impl = set == 2 ? 3 : (set == 3 ? 5 : 2);
+    const int col = set == 2 ? 1 : (set == 3 ? 2 : 0);
+    if (P.calibrateTrace) {
+      sc->d.traceKernel[0] = (uint32_t)impl;
+      sc->d.traceKernel[1] = impl == 5 ? 3u : (uint32_t)impl;
+    }
+    TraceCounters c0, c1;
+    int prc = readCtr(&c0);
+    if (prc) return abandon(prc);
+    PilotTimes pt;
+    prc = BatchRunner(P, sc->ws, sc->ws.pix.p + set * P.calibPix, set * P.calibPix, (uint32_t)P.calibPix, &pt).run();
+    if (prc) return abandon(prc);
+    prc = readCtr(&c1);
+    if (prc) return abandon(prc);
+    if (set == 0 && P.measureLayout) {
+      // the batch's stage lists (still in the counters): how many of its slots are alive at the second bounce?
+      uint32_t alive2 = 0;
+      if (hipMemcpy(&alive2, sc->ws.counters.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)  // entries of stage 1's output list
+        return abandon(fail(DR_ERR_HIP, "layout pilot: counter read-back failed"));
+      sc->layoutDensity = (float)((double)alive2 / ((double)P.calibPix * P.spp));
+      sc->stateLayout = sc->layoutDensity < 0.5f ? 4 : 64;
+      P.L = sc->stateLayout == 4 ? &kLayoutSp4 : &kLayout64;
+      if (dr_opt("DARTRAY_VERBOSE"))
+        fprintf(stderr, "dartray_hip: state-layout pilot: %.3f of a batch's slots alive at the second bounce -> %s\n", sc->layoutDensity,
+                sc->stateLayout == 4 ? "four-slot line-grouped sub-tiles (sp4)" : "64-slot runs");
+    }
+    if (set == 0 || !P.calibrateTrace) continue;
+    // the per-lane kernels' own work: the batch's totals without what k_trace_pk traced of them (the camera rays)
+    const double bytes[2] = {32.0 * (double)((c1.closest_nodes - c0.closest_nodes) - (c1.pk_nodes[0] - c0.pk_nodes[0])) +
+                                 48.0 * (double)((c1.closest_tris - c0.closest_tris) - (c1.pk_tris[0] - c0.pk_tris[0])),
+                             32.0 * (double)(c1.any_nodes - c0.any_nodes) + 48.0 * (double)(c1.any_tris - c0.any_tris)};
+    for (int kind = 0; kind < 2; ++kind) {
+      float sum = 0.f;
+      for (auto& e : pt.ev[kind]) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e.first, e.second);
+        sum += t;
+      }
+      R.ms[kind][col] = sum;
+      R.perByte[kind][col] = bytes[kind] > 0.0 ? (double)sum / (bytes[kind] * 1.0e-9) : 0.0;
+    }
+  }
+  if (P.calibrateTrace) pickTraceKernels(sc, R);
+  HIP_TRY(hipEventRecord(evP1, s));
+  sc->traceEvents.push_back({evP0, evP1, 5});  // DrRenderStats.pilot_ms: the time of the calibration batches
+  if (P.calibrateTrace && dr_opt("DARTRAY_VERBOSE"))
+    fprintf(stderr, "dartray_hip: traversal pilot (%d x %zu samples, rendered into the film), ms per algorithmic GB of the per-lane kernels: closest v2 %.4f / v3 %.4f / v3c %.4f -> v%u; "
+            "any hit v2 %.4f / v3 %.4f -> v%u\n", R.setsRun, P.calibPix * (size_t)P.spp, R.perByte[0][0], R.perByte[0][1], R.perByte[0][2], sc->d.traceKernel[0],
+            R.perByte[1][0], R.perByte[1][1], sc->d.traceKernel[1]);
+  return DR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* hip_stream) {
+  if (!sc || !rd || !film_dev) return fail(DR_ERR_INVALID, "null argument");
+  RenderPlan P;
+  P.sc = sc;
+  P.rd = rd;
+  P.film = (float*)film_dev;
+  P.s = (hipStream_t)hip_stream;
+  int rc = planRender(P);
+  if (rc) return rc;
   // recycle the events of earlier renders once they have completed (or when too many are pending)
   if (sc->lastEvent && !sc->traceEvents.empty()) {
     hipError_t q = hipEventQuery(sc->lastEvent);
@@ -1390,548 +2058,39 @@ int dr_render_device(DrScene* sc, const DrRenderDesc* rd, void* film_dev, void* 
   hipEvent_t evStart = sc->getEvent(), evStop = sc->getEvent();
   sc->renderEvents.push_back({evStart, evStop});
   sc->lastEvent = evStop;
-  HIP_TRY(hipEventRecord(evStart, s));
-  if (npixTotal == 0) {
-    HIP_TRY(hipEventRecord(evStop, s));
+  HIP_TRY(hipEventRecord(evStart, P.s));
+  if (P.npixTotal == 0) {
+    HIP_TRY(hipEventRecord(evStop, P.s));
     return DR_OK;
   }
-  uint64_t filmSamples = 0;
-  for (const int2& p : pixels)
-    if (p.x >= rp.left && p.x < rp.left + rp.width && p.y >= rp.top && p.y < rp.top + rp.height) filmSamples += spp;
-
-  // ---- workspace ----
-  // Sample vectors: the on-device LD sampler stores permuted indices + scrambles (compact form) whenever every LD block
-  // has one entry per pixel sample; host buffers and multi-entry blocks (DirectLighting with nsamples > 1) use floats.
-  SampleForm sf;
-  sf.compact = !hostBuf && rp.blocks == nullptr;
-  if (!sf.compact && !hostBuf && spp > 1024)
-    return fail(DR_ERR_UNSUPPORTED, "spp > 1024 with LD blocks of several entries per sample (DirectLighting with nsamples > 1): the float-form sampler's table exceeds the LDS");
-  sf.nFloats = rp.nFloats;
-  sf.nBlocks = 3 + rp.n1D + (rp.nFloats - 5 - rp.n1D) / 2;
-  sf.idxShift = spp > 256 ? 1 : 0;
-  const int slotBits = std::min(28, std::max(16, dr_opt("DARTRAY_BATCH_BITS").toInt(28)));
-  uint64_t maxSlots = 1ull << slotBits;  // camera samples in flight per batch
-  {
-    // path state per camera sample: 164 B of ray / hit / NEE state, 20 B of queues and the sample vector (24 B of
-    // permuted indices in the compact form, 4 B per float otherwise; + the RNG tail in host-buffer mode).  The
-    // default batch (2^28) takes 56 GB of a 288 GB MI355X; on a device with less free
-    // memory the batch shrinks instead of failing (results do not depend on the batch size).
-    const bool packedTail = hostBuf && needTail > 0 && rd->tail_offsets != nullptr;
-    const uint64_t tailPerSlot = !(hostBuf && needTail > 0) ? 0ull
-                                 : (packedTail ? 16ull + 8ull * ((rd->tail_offsets[rd->nsamples] - rd->tail_offsets[0]) / (uint64_t)rd->nsamples + 1ull)
-                                               : (uint64_t)rd->max_tail * 8);
-    const uint64_t perSlot = (uint64_t)maxStateWords * 4 + (uint64_t)(sf.svWords() + 15) / 16 + 20 + tailPerSlot + (hostBuf ? (uint64_t)rd->sample_stride * 4 : 0) +
-                             (sf.compact ? (uint64_t)(16 * sf.nBlocks + spp - 1) / spp : 0) +  // scramble words + generator states, per (block, pixel)
-                             (dlSpec ? (uint64_t)std::max(1, rd->max_depth) * sizeof(SpecFrame) + 12 : 0);
-    size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-      const uint64_t have = (uint64_t)sc->ws.cap * ((uint64_t)sc->ws.stateWords * 4 + sc->ws.svWords / 16 + 20);
-      const uint64_t budget = (uint64_t)(0.9 * (double)freeB) + have;
-      // (+ 1/4: the slack that lets a slightly larger window still go as one batch, below)
-      while (maxSlots > (1ull << 16) && std::min<uint64_t>(maxSlots + maxSlots / 4, (uint64_t)npixTotal * spp) * perSlot > budget) maxSlots >>= 1;
-    }
-  }
-  // Equal batches, and no tiny tail batch: every stage launch costs ~0.4 ms of ramp-up and tail however small it is
-  // (the sampler window of a 1024 x 1024 film is 1025 x 1025 pixels -- 2^20 + 2049).
-  uint64_t pixCapBatch = std::max<uint64_t>(1, maxSlots / spp);
-  uint64_t nBatches = (npixTotal + pixCapBatch - 1) / pixCapBatch;
-  if (nBatches > 1 && npixTotal <= pixCapBatch + pixCapBatch / 4) nBatches = 1;
-  const uint32_t pixPerBatch = (uint32_t)((npixTotal + nBatches - 1) / nBatches);
-  const uint32_t cap = pixPerBatch * (uint32_t)spp;
-  const auto tAlloc0 = std::chrono::steady_clock::now();
-  const uint32_t capBefore = sc->ws.cap;
-  const bool packedTailForm = hostBuf && needTail > 0 && rd->tail_offsets != nullptr;  // (its buffers are sized per batch, in runBatch)
-  int rc = allocWorkspace(sc, sc->ws, cap, sf, pixPerBatch, rd->max_tail, hostBuf && needTail > 0 && !packedTailForm, maxStateWords);
+  rc = planBatches(P);
   if (rc) return rc;
-  if (dr_opt("DARTRAY_VERBOSE") && sc->ws.cap != capBefore) {
-    (void)hipDeviceSynchronize();
-    fprintf(stderr, "dartray_hip: path-state workspace for %u slots (%.1f GB) allocated in %.1f ms\n", sc->ws.cap,
-            (double)sc->ws.tiles.n * 4.0e-9 + (double)sc->ws.cap * 20.0e-9,
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tAlloc0).count());
-  }
-  if (dlSpec) {
-    HIP_TRY(sc->ws.specFrames.alloc((size_t)sc->ws.cap * std::max(1, rd->max_depth) * DR_SPEC_FRAME_WORDS));
-    HIP_TRY(sc->ws.specSp.alloc(sc->ws.cap));
-    HIP_TRY(sc->ws.roundA.alloc(sc->ws.cap));
-    HIP_TRY(sc->ws.roundB.alloc(sc->ws.cap));
-  }
-  const int tgrid = traceGrid();
-  rc = ensureSpill(sc, sc->ws, tgrid);
+  rc = prepareRender(P);
   if (rc) return rc;
-  // the camera rays (a tile = 64 samples of one pixel) through the wave-coherent kernel k_trace_pk (DARTRAY_COHERENT_CAMERA=0: k_trace & co.)
-  const bool coherentCamera = !dr_opt("DARTRAY_COHERENT_CAMERA").isZero() && !dlSpec;
-  const bool overlapEnv = !(dr_opt("DARTRAY_OVERLAP_ANY").isZero());  // default: on
-  // lazy sample generation (DARTRAY_LAZY_GEN=0: every block for every pixel up front): needs the device sampler's compact form, the keyed
-  // per-(pixel, block) streams (a block that is left out disturbs no other) and k_trace_pk's marks of the camera rays that hit
-  const bool lazyGen = !hostBuf && sf.compact && rp.genMask != 0ull && rd->integrator == DR_INTEGRATOR_PATH && coherentCamera &&
-                       !sc->d.nquads && spp >= 64 && !dr_opt("DARTRAY_LAZY_GEN").isZero();
-  const bool overlapAny = overlapEnv && !dlSpec;
-  if (overlapAny && !sc->s3) HIP_TRY(hipStreamCreateWithFlags(&sc->s3, hipStreamNonBlocking));
-  // Which traversal kernel?  v2 (one node per step, f32 filter) is issue bound and wins while the hot part of the tree
-  // stays in cache; v3 (sibling pairs, half the dependent fetches) wins on big incoherent trees (C4 hairball +26 %)
-  // and loses on others of the same size (C5 courtyard: closest -8 %, any hit -33 %); random probe rays mispredict
-  // both.  So the first big render of a big scene measures it ON ITS OWN WORK: three small calibration batches -- 64-pixel
-  // groups spread over the image, ~1.5 % of the camera samples each -- are rendered first, into the film like every
-  // other batch: one with v2 to warm the caches, one with v2 and one with v3 that are timed; each ray kind then keeps
-  // the kernel with the better time per algorithmic byte (the device's own node / triangle counters of that batch).
-  // Nothing is traced twice: the calibration costs only what three small launches lose against one big one (round 1
-  // ran up to six extra passes over pilot rays that never reached the film: 19 % of a C2 render, 64 % of C4's).
-  // Both kernels are bit-exact, so results do not depend on the choice; dr_scene_set_trace_kernels / DARTRAY_TRACE_IMPL fix it.
-  const DrOpt pilotOpt = dr_opt("DARTRAY_PILOT");  // 0: never; force: also on renders too small to need one (tests)
-  const bool pilotOff = pilotOpt.is("0");
-  const bool bigJob = (sc->d.nnodes >= (1u << 20) && (uint64_t)npixTotal * spp >= (1ull << 25)) || pilotOpt.is("force");
-  const bool pilotOk = !pilotOff && !hostBuf && !dlSpec && bigJob && npixTotal >= 3 * 64 * 4;
-  const bool calibrateTrace = !sc->traceCalibrated && pilotOk && !dr_opt("DARTRAY_TRACE_IMPL") && sc->d.pairs && !sc->d.nquads;
-  const bool measureLayout = !layoutKnown && pilotOk;
-  if (measureLayout) Lp = &kLayout64;  // the batch whose stage lists are measured runs in the 64-slot layout (the header's and the comment's claim)
-  const bool calibrate = calibrateTrace || measureLayout;
-  const int pilotSets = calibrateTrace ? 4 : 1;  // traversal kernels: warm-up, v2 timed, v3 timed, v3c timed; the layout alone: one batch
-  size_t calibPix = 0;  // pixels per calibration batch; the three batches are the first 3 * calibPix entries of `pixels`
-  if (calibrate) {
-    // (round 4: at least 2^24 samples per calibration batch.  With 2^22 -- 1 / 64 of C2 -- the launches are so short that their tails
-    // decide: the pair kernel, whose rays are half as many fetches long, looked 10 % FASTER than k_trace<0> on C2 and is 12 % slower in
-    // the full-size launches; at 2^24 and above the calibration batches rank the kernels as the full-size launches do.)
-    uint64_t pilotSamples = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 24, (uint64_t)npixTotal * spp / 16));
-    pilotSamples = std::min<uint64_t>(pilotSamples, (uint64_t)(pixPerBatch / 64 * 64) * spp);
-    const size_t totalGroups = npixTotal / 64;
-    const size_t groups = std::min<size_t>(std::max<size_t>(1, (size_t)(pilotSamples / spp) / 64), totalGroups / 4);
-    calibPix = groups * 64;
-    std::vector<int2> ordered;
-    ordered.reserve(npixTotal);
-    std::vector<uint8_t> taken(totalGroups, 0);
-    for (int set = 0; set < pilotSets; ++set)
-      for (size_t g = 0; g < groups; ++g) {
-        const size_t grp = (((size_t)pilotSets * g + set) * totalGroups) / ((size_t)pilotSets * groups);  // interleaved: the sets see the same regions
-        taken[grp] = 1;
-        ordered.insert(ordered.end(), pixels.begin() + grp * 64, pixels.begin() + grp * 64 + 64);
-      }
-    for (size_t grp = 0; grp < totalGroups; ++grp)
-      if (!taken[grp]) ordered.insert(ordered.end(), pixels.begin() + grp * 64, pixels.begin() + grp * 64 + 64);
-    ordered.insert(ordered.end(), pixels.begin() + totalGroups * 64, pixels.end());
-    pixels.swap(ordered);
+  PilotResult pilot;
+  if (P.calibrate()) {
+    rc = runPilot(P, pilot);
+    if (rc) return rc;
   }
-  HIP_TRY(sc->ws.pix.alloc(npixTotal));
-  HIP_TRY(hipMemcpyAsync(sc->ws.pix.p, pixels.data(), npixTotal * sizeof(int2), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(sc->ws.filterTable.p, rd->film.filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s));
-  // pixels is a local: the async copy above must complete before it goes out of scope
-  HIP_TRY(hipStreamSynchronize(s));
-  const int sgrid = g_numCU;  // the shade launchers size their grid per CU (DR_SHADE_GRID), grid-stride over the active list
-  const int nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
-  if (nStages > 248 || 8 * DR_WORK_STRIDE * (1 + 2 * nStages) > N_COUNTERS_TRACE - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
-  if (envStage) {
-    HIP_TRY(sc->ws.envQ.alloc(sc->ws.cap));
+  // (a calibration set that was skipped left its pixels to the ordinary batches)
+  for (size_t p0 = (size_t)pilot.setsRun * P.calibPix; p0 < P.npixTotal; p0 += P.pixPerBatch) {
+    const uint32_t np = (uint32_t)std::min<size_t>(P.pixPerBatch, P.npixTotal - p0);
+    rc = BatchRunner(P, sc->ws, sc->ws.pix.p + p0, p0, np, nullptr).run();
+    if (rc) return rc;
   }
-
-  // One batch through the stage loop.  pilot != null: a calibration batch -- a normal batch whose traversal launches are
-  // also collected into pilot->ev[kind] (see above).
-  struct PilotTimes {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
-  };
-  auto runBatch = [&](Workspace& w, const int2* pixDev, size_t p0, uint32_t np, PilotTimes* pilot) -> int {
-    const uint32_t nslots = np * (uint32_t)spp;
-    BatchState st = makeState(w, sf, pixDev, nslots, hostBuf && needTail > 0, L.stateWords);
-    HIP_TRY(hipMemsetAsync(w.counters.p, 0, N_COUNTERS * sizeof(uint32_t), s));
-    uint32_t nGroups = 0;
-    // lazy sample generation: the LD blocks of bounce b (light number, light component, light position, BSDF direction, path direction:
-    // the bits genMask gives the level, above) for the 64-pixel groups marked in alive[b]
-    auto genBounce = [&](int b) {
-      uint64_t m = (15ull << (3 + 4 * b)) | (7ull << (3 + rp.n1D + 3 * b));
-      m &= rp.genMask;
-      if (!m) return;
-      hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
-      (void)hipEventRecord(e0, s);
-      RenderParams rpB = rp;
-      rpB.genMask = m;
-      BatchState stB = st;
-      stB.genAlive = w.alive.p + (size_t)b * nGroups;
-      stB.markAlive = nullptr;
-      L.gen_samples(rpB, stB, np, s);
-      (void)hipEventRecord(e1, s);
-      sc->traceEvents.push_back({e0, e1, 3});
-    };
-    auto timed = [&](int kind, hipEvent_t e0) {
-      hipEvent_t e1 = sc->getEvent();
-      (void)hipEventRecord(e1, s);
-      sc->traceEvents.push_back({e0, e1, kind});
-      return e1;
-    };
-    // DARTRAY_STAGE_COUNTS=1 (diagnostics): per stage the list lengths, the kernel times (this batch's own events) and -- with
-    // DARTRAY_STAGE_COUNTS=2, which waits for the device after every stage -- the node visits / triangle tests of its traversals
-    const int stageCounts = dr_opt("DARTRAY_STAGE_COUNTS").toInt(0) > 0 ? dr_opt("DARTRAY_STAGE_COUNTS").toInt(0) : (dr_opt("DARTRAY_STAGE_COUNTS").set ? 1 : 0);
-    struct StageLog {
-      hipEvent_t s0 = nullptr, sMid = nullptr, s1 = nullptr, c0 = nullptr, c1 = nullptr, a0 = nullptr, a1 = nullptr;
-      TraceCounters ctr;
-    };
-    std::vector<StageLog> slog(stageCounts ? (size_t)nStages + 1 : 0);  // [0] = the camera rays' traversal, [b + 1] = stage b
-    TraceCounters ctrBase = {};
-    auto readCtrNow = [&](TraceCounters* c) {
-      if (stageCounts < 2) return;
-      (void)hipStreamSynchronize(s);
-      if (sc->s3) (void)hipStreamSynchronize(sc->s3);
-      (void)hipMemcpy(c, sc->ctr.p, sizeof(TraceCounters), hipMemcpyDeviceToHost);
-    };
-    hipEvent_t evGen = sc->getEvent();
-    (void)hipEventRecord(evGen, s);
-    if (hostBuf) {
-      HIP_TRY(w.aosSamples.alloc((size_t)((cap + 63u) & ~63u) * rd->sample_stride));
-      HIP_TRY(hipMemcpyAsync(w.aosSamples.p, rd->sample_vec + (size_t)p0 * spp * rd->sample_stride,
-                             (size_t)nslots * rd->sample_stride * sizeof(float), hipMemcpyHostToDevice, s));
-      L.transpose_samples(w.aosSamples.p, rd->sample_stride, st, rp.nFloats, s);
-      if (needTail > 0 && packedTailForm) {
-        // the batch's runs are one contiguous piece of the packed array: [off[first], off[first + nslots])
-        const uint64_t* off = rd->tail_offsets + (size_t)p0 * spp;
-        const uint64_t o0 = off[0], o1 = off[nslots];
-        if (o1 < o0) return fail(DR_ERR_INVALID, "host-buffer sampler: tail_offsets must be non-decreasing");
-        HIP_TRY(w.tail.alloc((size_t)(o1 - o0) + (size_t)rd->max_tail + 1));  // (+ max_tail: a lane reads rec[pos] only inside its run, the slack is belt and braces)
-        HIP_TRY(w.tailOff.alloc((size_t)nslots + 1));
-        if (o1 > o0) HIP_TRY(hipMemcpyAsync(w.tail.p, rd->tail + o0, (size_t)(o1 - o0) * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(w.tailOff.p, off, ((size_t)nslots + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-        st.tail = w.tail.p;
-        st.tailOff = w.tailOff.p;
-        st.tailBase = o0;
-      } else if (needTail > 0)
-        HIP_TRY(hipMemcpyAsync(w.tail.p, rd->tail + (size_t)p0 * spp * rd->max_tail,
-                               (size_t)nslots * rd->max_tail * sizeof(double), hipMemcpyHostToDevice, s));
-    } else if (lazyGen) {
-      // the image (+ lens) blocks for every pixel now; the blocks of bounce b once it is known which 64-pixel groups still have a path there
-      RenderParams rpA = rp;
-      rpA.genMask = rp.genMask & 3ull;
-      L.gen_samples(rpA, st, np, s);
-      nGroups = (np + 63u) / 64u;
-      HIP_TRY(w.alive.alloc(3 * (size_t)nGroups));
-      HIP_TRY(hipMemsetAsync(w.alive.p, 0, 3 * (size_t)nGroups, s));
-      sc->genDoneHost += (unsigned long long)np * (unsigned)__builtin_popcountll(rpA.genMask);
-      sc->genNamed += (unsigned long long)np * (unsigned)__builtin_popcountll(rp.genMask);
-      st.markAlive = w.alive.p;  // k_trace_pk: the groups whose camera rays hit something
-      st.markShift = (uint32_t)rp.sppShift + 6u;
-    } else {
-      L.gen_samples(rp, st, np, s);
-      if (sf.compact && rp.genMask) {
-        sc->genDoneHost += (unsigned long long)np * (unsigned)__builtin_popcountll(rp.genMask);
-        sc->genNamed += (unsigned long long)np * (unsigned)__builtin_popcountll(rp.genMask);
-      }
-    }
-    L.raygen(rp, st, s);
-    timed(3, evGen);
-    uint32_t* C = w.counters.p;
-    int wc = 0;  // work counters live at C[1024..], 8 per launch
-    auto trace = [&](const uint32_t* queue, const uint32_t* nQ, int any, hipStream_t ts, uint32_t* spill, hipEvent_t after = nullptr, bool coherent = false) {
-      hipEvent_t e0 = sc->getEvent(), e1 = sc->getEvent();
-      (void)hipEventRecord(e0, ts);
-      bool tookCoherent = false;
-      if (!(coherent && L.trace_coherent(sc->d, st, queue, nQ, any, C + 1024 + 8 * DR_WORK_STRIDE * wc, sc->ctr.p, tgrid, ts))) {
-        L.trace(sc->d, st, queue, nQ, any, spill, C + 1024 + 8 * DR_WORK_STRIDE * (wc++), sc->ctr.p, tgrid, ts);
-        // (lazy sample generation counts on k_trace_pk's marks: should the coherent kernel ever decline a launch that was to leave
-        // them, every group counts as alive -- all blocks are generated, nothing is skipped)
-        if (coherent && !any && st.markAlive) (void)hipMemsetAsync(st.markAlive, 1, nGroups, ts);
-      } else {
-        ++wc;  // (k_trace_pk took this queue: the camera rays)
-        tookCoherent = true;
-      }
-      (void)hipEventRecord(e1, ts);
-      if (pilot) pilot->ev[any].push_back({e0, e1});
-      sc->traceEvents.push_back({e0, e1, tookCoherent && !any ? 6 : any, after});
-      return e1;
-    };
-    // A stage's two traversals are independent (closest hit of the continuation / MIS rays, occlusion of the shadow
-    // rays).  Side by side on two streams the any-hit workgroups take the CU slots the closest-hit launch frees as its
-    // queue runs dry (a persistent launch ends with its longest rays).  Calibration batches time each launch alone.
-    const bool sideBySide = overlapAny && !pilot;
-    // DirectLighting over mirror / glass: one round of the stage loop per vertex of a slot's ray tree; `roundQ` lists
-    // the slots whose (camera or child) ray this round traces.  Everything else: one round.
-    const uint32_t* roundQ = nullptr;
-    const uint32_t* nRound = nullptr;
-    // (one round per vertex of a slot's ray tree, until no slot launched a child: at most 2^maxDepth like the recursion itself)
-    const int maxRounds = dlSpec ? 0x7fffffff : 1;
-    if (dlSpec) HIP_TRY(hipMemsetAsync(w.specSp.p, 0, (size_t)w.cap * sizeof(int32_t), s));
-    for (int round = 0; round < maxRounds; ++round) {
-    if (round > 0) {  // the stage counters are reused every round; the round lists' counts live behind them
-      HIP_TRY(hipMemsetAsync(C, 0, 1000 * sizeof(uint32_t), s));
-      HIP_TRY(hipMemsetAsync(C + 1024, 0, (N_COUNTERS - 1024) * sizeof(uint32_t), s));  // (work counters and k_env's counts)
-      wc = 0;
-    }
-    if (stageCounts && round == 0) readCtrNow(&ctrBase);
-    trace(roundQ, nRound, 0, s, w.spill.p, nullptr, coherentCamera && roundQ == nullptr);  // camera rays (or this round's child rays)
-    if (lazyGen && round == 0) {
-      st.markAlive = nullptr;
-      genBounce(0);
-    }
-    if (stageCounts && round == 0) {
-      slog[0].c0 = sc->traceEvents.back().e0;
-      slog[0].c1 = sc->traceEvents.back().e1;
-      readCtrNow(&slog[0].ctr);
-    }
-    for (int b = 0; b < nStages; ++b) {
-      StageQueues q;
-      q.activeIn = b == 0 ? roundQ : ((b - 1) & 1 ? w.activeB.p : w.activeA.p);
-      // a stage's four counters sit ~1 KB apart: every wave adds to all four in one round trip (stage_flush), and
-      // same-line atomics serialise
-      auto cnt = [&](int j, int stage) { return C + 248 * j + stage; };
-      q.nActiveIn = b == 0 ? nRound : cnt(0, b - 1);
-      q.activeOut = (b & 1) ? w.activeB.p : w.activeA.p;
-      q.nActiveOut = cnt(0, b);
-      q.closestQ = w.closestQ.p;
-      q.nClosest = cnt(1, b);
-      q.anyQ = w.anyQ.p;
-      q.nAny = cnt(2, b);
-      q.work = cnt(3, b);
-      q.ctr = sc->ctr.p;
-      q.envQ = envStage ? w.envQ.p : nullptr;
-      q.nEnv = C + N_COUNTERS_TRACE + 64 * b;
-      hipEvent_t evS = sc->getEvent();
-      (void)hipEventRecord(evS, s);
-      if (rd->integrator == DR_INTEGRATOR_PATH) L.shade_path(sc->d, rp, st, q, b, sgrid, s);
-      else L.shade_direct(sc->d, rp, st, q, b, sgrid, s);
-      hipEvent_t evMid = nullptr;
-      if (stageCounts && envStage) {
-        evMid = sc->getEvent();
-        (void)hipEventRecord(evMid, s);
-      }
-      if (envStage) L.env(sc->d, rp, st, q, b, sgrid, s);
-      hipEvent_t evS1 = timed(2, evS);
-      if (lazyGen && round == 0 && b < 2 && b + 1 <= rd->max_depth) {  // bounce b + 1's blocks for the groups in this stage's output list
-        L.mark_alive(q.activeOut, q.nActiveOut, (uint32_t)rp.sppShift + 6u, w.alive.p + (size_t)(b + 1) * nGroups, s);
-        genBounce(b + 1);
-      }
-      if (stageCounts && round == 0) {
-        slog[b + 1].s0 = evS;
-        slog[b + 1].sMid = evMid;
-        slog[b + 1].s1 = evS1;
-      }
-      if (b + 1 < nStages) {
-        if (sideBySide) {
-          hipEvent_t eS = sc->getEvent(), eA = sc->getEvent();
-          (void)hipEventRecord(eS, s);
-          (void)hipStreamWaitEvent(sc->s3, eS, 0);
-          hipEvent_t closestEnd = trace(q.closestQ, q.nClosest, 0, s, w.spill.p);
-          if (stageCounts && round == 0) {
-            slog[b + 1].c0 = sc->traceEvents.back().e0;
-            slog[b + 1].c1 = sc->traceEvents.back().e1;
-          }
-          trace(q.anyQ, q.nAny, 1, sc->s3, w.spill.p + w.spillHalf, closestEnd);
-          if (stageCounts && round == 0) {
-            slog[b + 1].a0 = sc->traceEvents.back().e0;
-            slog[b + 1].a1 = sc->traceEvents.back().e1;
-          }
-          (void)hipEventRecord(eA, sc->s3);
-          (void)hipStreamWaitEvent(s, eA, 0);
-        } else {
-          trace(q.closestQ, q.nClosest, 0, s, w.spill.p);
-          if (stageCounts && round == 0) {
-            slog[b + 1].c0 = sc->traceEvents.back().e0;
-            slog[b + 1].c1 = sc->traceEvents.back().e1;
-          }
-          trace(q.anyQ, q.nAny, 1, s, w.spill.p);
-          if (stageCounts && round == 0) {
-            slog[b + 1].a0 = sc->traceEvents.back().e0;
-            slog[b + 1].a1 = sc->traceEvents.back().e1;
-          }
-        }
-        if (stageCounts && round == 0) readCtrNow(&slog[b + 1].ctr);
-      }
-    }
-    if (!dlSpec) break;
-    {
-      StageQueues q;
-      memset(&q, 0, sizeof(q));
-      q.activeIn = roundQ;
-      q.nActiveIn = nRound;
-      uint32_t* nextQ = (round & 1) ? w.roundB.p : w.roundA.p;
-      uint32_t* nNext = C + 1008 + (round & 1);
-      HIP_TRY(hipMemsetAsync(nNext, 0, sizeof(uint32_t), s));
-      q.activeOut = nextQ;
-      q.nActiveOut = nNext;
-      q.closestQ = w.closestQ.p;  // unused: the child rays are the next round's list
-      q.nClosest = C + 1010;
-      q.anyQ = w.anyQ.p;
-      q.nAny = C + 1011;
-      q.ctr = sc->ctr.p;
-      hipEvent_t evS = sc->getEvent();
-      (void)hipEventRecord(evS, s);
-      L.shade_spec(sc->d, rp, st, q, sgrid, s);
-      timed(2, evS);
-      uint32_t live = 0;  // (a synchronous read-back per round: this is not the throughput path)
-      HIP_TRY(hipMemcpyAsync(&live, nNext, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      if (live == 0) break;
-      roundQ = nextQ;
-      nRound = nNext;
-    }
-    }
-    if (lazyGen) {  // statistics: the (pixel, block) pairs the three genBounce calls came to
-      uint32_t nb[3];
-      for (int b = 0; b < 3; ++b) nb[b] = (uint32_t)__builtin_popcountll(((15ull << (3 + 4 * b)) | (7ull << (3 + rp.n1D + 3 * b))) & rp.genMask);
-      L.sum_alive(w.alive.p, nGroups, np, nb, sc->ctr.p, s);
-    }
-    {
-      hipEvent_t evF = sc->getEvent();
-      (void)hipEventRecord(evF, s);
-      L.film(rp, st, sc->ws.filterTable.p, np, (float*)film_dev, s);
-      timed(4, evF);
-      sc->stats.batches++;
-    }
-    if (stageCounts) {
-      std::vector<uint32_t> hc(N_COUNTERS);
-      HIP_TRY(hipStreamSynchronize(s));
-      if (sc->s3) HIP_TRY(hipStreamSynchronize(sc->s3));
-      HIP_TRY(hipMemcpy(hc.data(), C, N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost));
-      for (int b = 0; b < nStages; ++b)
-        fprintf(stderr, "stage_counts batch %zu stage %d: in %u active_out %u closest %u any %u env %u\n", (size_t)sc->stats.batches, b,
-                b == 0 ? nslots : hc[248 * 0 + b - 1], hc[248 * 0 + b], hc[248 * 1 + b], hc[248 * 2 + b], hc[N_COUNTERS_TRACE + 64 * b]);
-      // the kernel times of the same stages (HIP events of this batch; side-by-side any-hit launches overlap the closest-hit ones:
-      // DARTRAY_OVERLAP_ANY=0 gives each its own time) and, with DARTRAY_STAGE_COUNTS=2, the traversal work of each stage
-      auto ms = [](hipEvent_t a, hipEvent_t b) {
-        float t = 0.f;
-        return a && b && hipEventElapsedTime(&t, a, b) == hipSuccess ? (double)t : 0.0;
-      };
-      for (int i = 0; i <= nStages; ++i) {
-        const StageLog& g = slog[i];
-        const double shade = g.sMid ? ms(g.s0, g.sMid) : ms(g.s0, g.s1), env = g.sMid ? ms(g.sMid, g.s1) : 0.0;
-        fprintf(stderr, "stage_times batch %zu stage %d: shade %.4f env %.4f closest %.4f any %.4f ms", (size_t)sc->stats.batches, i - 1, shade, env,
-                ms(g.c0, g.c1), ms(g.a0, g.a1));
-        if (stageCounts >= 2) {
-          const TraceCounters& p = i ? slog[i - 1].ctr : ctrBase;
-          if (i == 0 || (g.c0 || g.a0))
-            fprintf(stderr, "; closest rays %llu nodes %llu tris %llu any rays %llu nodes %llu tris %llu", g.ctr.closest_rays - p.closest_rays,
-                    g.ctr.closest_nodes - p.closest_nodes, g.ctr.closest_tris - p.closest_tris, g.ctr.any_rays - p.any_rays,
-                    g.ctr.any_nodes - p.any_nodes, g.ctr.any_tris - p.any_tris);
-        }
-        fprintf(stderr, "\n");
-      }
-    }
-    HIP_TRY(hipGetLastError());
-    if (hostBuf) HIP_TRY(hipStreamSynchronize(s));  // host buffers of the next batch reuse the staging area
-    return DR_OK;
-  };
-
-  size_t firstPix = 0;
-  int pilotBatchesRun = 0;
-  if (calibrate) {
-    hipEvent_t evP0 = sc->getEvent(), evP1 = sc->getEvent();
-    HIP_TRY(hipEventRecord(evP0, s));
-    double perByte[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};  // [closest / any][v2 / v3 / v3c]: ms per algorithmic GB
-    float ms[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    auto readCtr = [&](TraceCounters* c) -> int {
-      HIP_TRY(hipStreamSynchronize(s));
-      HIP_TRY(hipMemcpy(c, sc->ctr.p, sizeof(TraceCounters), hipMemcpyDeviceToHost));
-      return DR_OK;
-    };
-    const uint32_t keepKernel[2] = {sc->d.traceKernel[0], sc->d.traceKernel[1]};
-    auto abandon = [&](int code) {  // an error in the middle: the scene keeps the choice it had, not a forced one
-      sc->d.traceKernel[0] = keepKernel[0];
-      sc->d.traceKernel[1] = keepKernel[1];
-      return code;
-    };
-    int setsRun = 0;
-    for (int set = 0; set < pilotSets; ++set) {  // warm-up (v2), v2 timed, v3 timed, v3c timed (its any-hit rays: v3 again)
-      // (round 5) where the pair kernel has just lost clearly to k_trace<0> (C2: 8 - 10 % behind) its cold-state sibling is not
-      // timed: k_trace3c is never more than a few per cent from k_trace3<0>, and the batch is a quarter of the pilot's cost.
-      // Its pixels simply stay in the render's ordinary batches.
-      if (set == 3 && calibrateTrace && perByte[0][1] > 1.05 * perByte[0][0]) break;
-      ++setsRun;
-      const int impl = set == 2 ? 3 : (set == 3 ? 5 : 2);
-      const int col = set == 2 ? 1 : (set == 3 ? 2 : 0);
-      if (calibrateTrace) {
-        sc->d.traceKernel[0] = (uint32_t)impl;
-        sc->d.traceKernel[1] = impl == 5 ? 3u : (uint32_t)impl;
-      }
-      TraceCounters c0, c1;
-      int prc = readCtr(&c0);
-      if (prc) return abandon(prc);
-      PilotTimes pt;
-      prc = runBatch(sc->ws, sc->ws.pix.p + set * calibPix, set * calibPix, (uint32_t)calibPix, &pt);
-      if (prc) return abandon(prc);
-      prc = readCtr(&c1);
-      if (prc) return abandon(prc);
-      if (set == 0 && measureLayout) {
-        // the batch's stage lists (still in the counters): how many of its slots are alive at the second bounce?
-        uint32_t alive2 = 0;
-        if (hipMemcpy(&alive2, sc->ws.counters.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)  // entries of stage 1's output list
-          return abandon(fail(DR_ERR_HIP, "layout pilot: counter read-back failed"));
-        sc->layoutDensity = (float)((double)alive2 / ((double)calibPix * spp));
-        sc->stateLayout = sc->layoutDensity < 0.5f ? 4 : 64;
-        Lp = sc->stateLayout == 4 ? &kLayoutSp4 : &kLayout64;
-        if (dr_opt("DARTRAY_VERBOSE"))
-          fprintf(stderr, "dartray_hip: state-layout pilot: %.3f of a batch's slots alive at the second bounce -> %s\n", sc->layoutDensity,
-                  sc->stateLayout == 4 ? "four-slot line-grouped sub-tiles (sp4)" : "64-slot runs");
-      }
-      if (set == 0 || !calibrateTrace) continue;
-      const double bytes[2] = {32.0 * (double)(c1.closest_nodes - c0.closest_nodes) + 48.0 * (double)(c1.closest_tris - c0.closest_tris),
-                               32.0 * (double)(c1.any_nodes - c0.any_nodes) + 48.0 * (double)(c1.any_tris - c0.any_tris)};
-      for (int kind = 0; kind < 2; ++kind) {
-        float sum = 0.f;
-        for (auto& e : pt.ev[kind]) {
-          float t = 0.f;
-          (void)hipEventElapsedTime(&t, e.first, e.second);
-          sum += t;
-        }
-        ms[kind][col] = sum;
-        perByte[kind][col] = bytes[kind] > 0.0 ? (double)sum / (bytes[kind] * 1.0e-9) : 0.0;
-      }
-    }
-    if (calibrateTrace) {
-    for (int kind = 0; kind < 2; ++kind)
-      for (int c = 0; c < 3; ++c) {
-        sc->calibMs[kind][c] = ms[kind][c];
-        sc->calibPerGB[kind][c] = (float)perByte[kind][c];
-      }
-    sc->d.traceKernel[0] = perByte[0][1] < 0.95 * perByte[0][0] ? 3u : 2u;
-    // the closest-hit rays have a third candidate (round 4): the pair kernel with its cold state in LDS, six workgroups per CU --
-    // 5 % ahead of k_trace3<0> on the cache-resident C5 (and there, with it, ahead of k_trace<0>), level with it on C4
-    // -- 5 % ahead of k_trace3<0> in C5's full-size launches and level with it in C5's calibration batches (eight times
-    // smaller: they understate what a sixth workgroup returns, as they do for the shadow rays below), 1.4 % behind on C4 at
-    // full size and 3.5 % behind in its calibration batches: so it takes the tie, and k_trace3<0> stays where it is 2 % ahead
-    if (perByte[0][2] > 0.0) {
-      const double best3 = std::min(perByte[0][1], perByte[0][2]);
-      // (round 5, the camera rays no longer in these kernels: at full size k_trace3c is 2.5 - 3 % ahead on C5 -- 728 against 762 - 786 ms --
-      // and level on C4 -- 123.2 / 123.5 --, while the calibration batches put it anywhere from 2 % behind to 1 % ahead: it keeps the
-      // pair family's place unless k_trace3<0> beats it by 5 % there)
-      if (best3 < 0.95 * perByte[0][0]) sc->d.traceKernel[0] = perByte[0][2] < 1.05 * perByte[0][1] ? 5u : 3u;
-    }
-    // The any-hit rays (round 5: a rule without a coin in it).  Their calibration launches are the least reliable of the
-    // pilot -- shadow rays are short, a small launch is mostly ramp-up and tail, and the two families come out within a few
-    // per cent of each other on the cache-resident scenes (C2: k_trace3a 6 - 8 % ahead in the calibration batches of three
-    // boxes, level at full size: 96.0 against 96.5 ms per step; round 4's 5 % threshold let the box decide) while small launches
-    // understate the pair kernel on the big incoherent tree (C4: -2 ... +6 % in a calibration batch, +25 % at full size).  So the
-    // any-hit rays stay in the FAMILY the closest-hit rays chose -- k_trace<1> beside k_trace<0>, k_trace3a beside k_trace3<0> /
-    // k_trace3c -- and cross over only when their own calibration batch says so by more than 15 % (C2's k_trace3a: 6 - 12 % ahead in the
-    // calibration batches of five boxes, level at full size).
-    {
-      const bool pairFamily = sc->d.traceKernel[0] != 2u;
-      const double own = pairFamily ? perByte[1][1] : perByte[1][0], other = pairFamily ? perByte[1][0] : perByte[1][1];
-      const bool cross = other > 0.0 && own > 0.0 && other < 0.85 * own;
-      sc->d.traceKernel[1] = (pairFamily != cross) ? 3u : 2u;
-    }
-    sc->traceCalibrated = true;
-    }
-    HIP_TRY(hipEventRecord(evP1, s));
-    sc->traceEvents.push_back({evP0, evP1, 5});  // DrRenderStats.pilot_ms: the time of the calibration batches
-    firstPix = (size_t)setsRun * calibPix;  // (a set that was skipped left its pixels to the ordinary batches)
-    pilotBatchesRun = setsRun;
-    if (calibrateTrace && dr_opt("DARTRAY_VERBOSE"))
-      fprintf(stderr, "dartray_hip: traversal pilot (%d x %zu samples, rendered into the film), ms per algorithmic GB: closest v2 %.4f / v3 %.4f / v3c %.4f -> v%u; "
-              "any hit v2 %.4f / v3 %.4f -> v%u\n", setsRun, calibPix * (size_t)spp, perByte[0][0], perByte[0][1], perByte[0][2], sc->d.traceKernel[0],
-              perByte[1][0], perByte[1][1], sc->d.traceKernel[1]);
-  }
-
-  for (size_t p0 = firstPix; p0 < npixTotal; p0 += pixPerBatch) {
-    const uint32_t np = (uint32_t)std::min<size_t>(pixPerBatch, npixTotal - p0);
-    int brc = runBatch(sc->ws, sc->ws.pix.p + p0, p0, np, nullptr);
-    if (brc) return brc;
-  }
-  HIP_TRY(hipEventRecord(evStop, s));
-  sc->stats.camera_samples += (uint64_t)npixTotal * spp;
-  sc->stats.film_samples += filmSamples;
-  sc->lastInfo[0] = Lp == &kLayoutSp4 ? 4 : 64;
-  sc->lastInfo[1] = L.trace_kernel_id(sc->d, 0);
-  sc->lastInfo[2] = L.trace_kernel_id(sc->d, 1);
+  HIP_TRY(hipEventRecord(evStop, P.s));
+  sc->stats.camera_samples += (uint64_t)P.npixTotal * P.spp;
+  sc->stats.film_samples += P.filmSamples;
+  if ((uint64_t)P.npixTotal * P.spp >= (1ull << 25)) sc->bigRenders++;  // (planBatches: the next render of this scene may take the whole image as one batch)
+  sc->lastInfo[0] = P.L == &kLayoutSp4 ? 4 : 64;
+  sc->lastInfo[1] = P.L->trace_kernel_id(sc->d, 0);
+  sc->lastInfo[2] = P.L->trace_kernel_id(sc->d, 1);
   sc->lastInfo[3] = -1;  // (reserved: rounds 4-5 reported the treelet-parked traversal's parking rounds here)
-  sc->lastInfo[4] = pilotBatchesRun;
-  sc->lastInfo[5] = (int32_t)std::min<uint64_t>(0x7fffffff, nBatches);
-  sc->lastInfo[6] = tgrid / std::max(1, g_numCU);
-  sc->lastInfo[7] = (overlapAny ? 1 : 0) | (coherentCamera && !sc->d.nquads ? 2 : 0) | (lazyGen ? 8 : 0);
+  sc->lastInfo[4] = pilot.setsRun;
+  sc->lastInfo[5] = (int32_t)std::min<uint64_t>(0x7fffffff, P.nBatches);
+  sc->lastInfo[6] = P.tgrid / std::max(1, g_numCU);
+  sc->lastInfo[7] = (P.overlapAny ? 1 : 0) | (P.coherentCamera && !sc->d.nquads ? 2 : 0) | (P.lazyGen ? 8 : 0);
   return DR_OK;
-#undef L
 }
 
 int dr_enumerate_pixels(const DrRenderDesc* rd, int32_t* out_xy, uint64_t cap, uint64_t* n_out) {

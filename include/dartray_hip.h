@@ -343,6 +343,9 @@ int dr_scene_get_coherent_stats(DrScene* scene, double out[5]);
  * early: bounce b's blocks are shuffled only for 64-pixel groups with a path alive at bounce b.  Both 0 for the host-buffer sampler
  * and the full-float sample form.  Waits for the renders in flight like dr_get_stats. */
 int dr_scene_get_sampler_stats(DrScene* scene, double out[2]);
+/* Device memory the scene's path-state workspace holds right now (tiles, queues, sample storage; it is allocated by the first render,
+ * grows when a later render needs more and is freed with the scene): what a host budgets next to its own allocations. */
+int dr_scene_workspace_bytes(const DrScene* scene, uint64_t* bytes_out);
 /* The path-state layout of this scene's path-traced renders, next to the traversal kernels and measured the same way: the
  * first big render's first pilot batch counts how many of its slots are still alive at the second bounce (density_out;
  * -1 before); below one half the renders use four-slot, line-grouped sub-tiles (layout 4: stage lists that thin out touch
@@ -438,6 +441,12 @@ int dr_comm_destroy(void);
 
 const char* dr_last_error(void);
 const char* dr_version(void);
+/* The layout version of this header's structs and the meaning of its entry points.  A host compares dr_abi_version() of the library it
+ * loaded with the DR_ABI_VERSION it was built against BEFORE it passes a struct: the structs carry no size field, so a host built against
+ * an older header would hand the library a shorter object than it reads (version 5 -> 6: DrRenderDesc grew by tail_offsets, 1344 -> 1352
+ * bytes; version 6 -> 7: DR_INTEGRATOR_DIRECT_ONE, dr_scene_workspace_bytes, the switch list of dr_set_option). */
+#define DR_ABI_VERSION 7
+int32_t dr_abi_version(void);
 
 /* Tuning / diagnostic switches.  Every switch is also an environment variable of the same name (DARTRAY_<NAME>); a
  * value set here takes precedence, is read at every use (nothing is latched at first use: the next render sees it) and

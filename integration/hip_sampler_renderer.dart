@@ -229,8 +229,19 @@ class _Blob {
 }
 
 class HipSamplerRenderer extends Renderer {
-  static final DynamicLibrary _lib = DynamicLibrary.open('libdartray_hip.so');
+  static final DynamicLibrary _lib = _open();
   static final _InitD _init = _lib.lookupFunction<_InitC, _InitD>('dr_init');
+  /// DR_ABI_VERSION of the include/dartray_hip.h these offsets were written against: the structs carry no size field, so a
+  /// library of another layout version is refused before any struct crosses the boundary.
+  static const int ABI_VERSION = 7;
+  static DynamicLibrary _open() {
+    DynamicLibrary l = DynamicLibrary.open('libdartray_hip.so');
+    _CommVoidD abi = l.lookupFunction<_CommVoidC, _CommVoidD>('dr_abi_version');
+    if (abi() != ABI_VERSION) {
+      LogSevere('libdartray_hip.so has ABI version ${abi()}, this binding was written against $ABI_VERSION');
+    }
+    return l;
+  }
   static final _SceneCreateD _sceneCreate = _lib.lookupFunction<_SceneCreateC, _SceneCreateD>('dr_scene_create');
   static final _RenderD _render = _lib.lookupFunction<_RenderC, _RenderD>('dr_render');
   static final _DestroyD _destroy = _lib.lookupFunction<_DestroyC, _DestroyD>('dr_scene_destroy');

@@ -60,6 +60,10 @@ int main(int argc, char** argv) {
   DrBvhNode nodes[7];
   uint64_t nnodes = 0;
   uint32_t order[4], depth = 0;
+  if (dr_abi_version() != DR_ABI_VERSION) {  /* a host checks the layout version before it passes a struct */
+    fprintf(stderr, "libdartray_hip.so has ABI version %d, this host was built against %d\n", (int)dr_abi_version(), DR_ABI_VERSION);
+    return 2;
+  }
   CHECK(dr_init(0));
   CHECK(dr_bvh_build(&verts[0][0], 8, &refined[0][0], 4, 4, nodes, &nnodes, order, &depth));
   uint32_t tri_idx[4][3], tri_material[4];

@@ -121,8 +121,10 @@ def test_dart_binding_offsets_equal_the_c_layout(tmp_path):
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(c), "-o", exe])
     res = subprocess.run([exe], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout
-    # every entry point the Dart file looks up exists in the header
+    # every entry point the Dart file looks up exists in the header, and the layout version it checks at load is the header's
     header = open(HEADER).read()
+    assert re.search(r"static const int ABI_VERSION = (\d+);", dart).group(1) == re.search(r"#define DR_ABI_VERSION (\d+)", header).group(1)
+    assert "lookupFunction<_CommVoidC, _CommVoidD>('dr_abi_version')" in dart
     for sym in re.findall(r"lookupFunction<\w+, \w+>\('(dr_\w+)'\)", dart):
         assert re.search(r"\b%s\s*\(" % sym, header), sym
 

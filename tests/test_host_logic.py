@@ -23,6 +23,10 @@ def test_library_exports_every_declared_symbol(hip):
     for name in declared:
         assert getattr(l, name) is not None
     assert b"gfx950" in l.dr_version()
+    # the ABI version a host checks at load: the header's define, the library's answer and the ctypes binding's constant agree
+    header = open(os.path.join(ROOT, "include", "dartray_hip.h")).read()
+    want = int(re.search(r"#define DR_ABI_VERSION (\d+)", header).group(1))
+    assert l.dr_abi_version() == want == hip.DR_ABI_VERSION
 
 
 def test_abi_struct_sizes_match_the_header(hip):
