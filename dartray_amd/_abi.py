@@ -13,6 +13,7 @@ DR_OK = 0
 DR_CAMERA_PERSPECTIVE, DR_CAMERA_ORTHOGRAPHIC, DR_CAMERA_ENVIRONMENT = 0, 1, 2
 DR_INTEGRATOR_DIRECT_ALL = 0
 DR_INTEGRATOR_PATH = 1
+DR_INTEGRATOR_DIRECT_ONE = 2
 DR_SAMPLER_HOST_BUFFER = 0
 DR_SAMPLER_COUNTER = 1
 DR_LIGHT_DIFFUSE_AREA = 0

@@ -1169,17 +1169,20 @@ class PathIntegrator:
 
 
 class DirectLightingIntegrator:
-    """surface_integrators/direct_lighting_integrator.dart:23-28 (strategy 'all')."""
+    """surface_integrators/direct_lighting_integrator.dart:23-28: strategy 'all' (UniformSampleAllLights, the default) or 'one'
+    (UniformSampleOneLight with the integrator's own lightNum slot, :51-55,82-87)."""
     SAMPLE_ALL_UNIFORM = 0
     SAMPLE_ONE_UNIFORM = 1
 
     def __init__(self, strategy=0, maxDepth=5):
-        if strategy != self.SAMPLE_ALL_UNIFORM:
-            raise NotImplementedError("only strategy 'all' (the default) is on the path")
+        if strategy not in (self.SAMPLE_ALL_UNIFORM, self.SAMPLE_ONE_UNIFORM):
+            raise ValueError("DirectLightingIntegrator strategy must be SAMPLE_ALL_UNIFORM (0) or SAMPLE_ONE_UNIFORM (1)")
         self.strategy = strategy
         self.maxDepth = int(maxDepth)
 
-    kind = _abi.DR_INTEGRATOR_DIRECT_ALL
+    @property
+    def kind(self):
+        return _abi.DR_INTEGRATOR_DIRECT_ONE if self.strategy == self.SAMPLE_ONE_UNIFORM else _abi.DR_INTEGRATOR_DIRECT_ALL
 
 
 class EmissionIntegrator:
@@ -1315,7 +1318,7 @@ def RegisterStandardPlugins():
     Plugin.register("accelerator", "bvh", BVHAccel.Create)
     Plugin.register("surfaceIntegrator", "path", lambda ps=None: PathIntegrator((ps or {}).get("maxdepth", 5)))
     Plugin.register("surfaceIntegrator", "directlighting",
-                    lambda ps=None: DirectLightingIntegrator(0, (ps or {}).get("maxdepth", 5)))
+                    lambda ps=None: DirectLightingIntegrator(1 if (ps or {}).get("strategy", "all") == "one" else 0, (ps or {}).get("maxdepth", 5)))
     Plugin.register("volumeIntegrator", "emission", lambda ps=None: EmissionIntegrator((ps or {}).get("stepsize", 1.0)))
     Plugin.register("renderer", "sampler", SamplerRenderer)
     Plugin.register("sampler", "lowdiscrepancy", LowDiscrepancySampler)

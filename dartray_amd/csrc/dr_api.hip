@@ -512,12 +512,14 @@ int dr_init(int device) {
 int32_t dr_sample_floats(int32_t integrator, uint32_t nlights) {
   // SURVEY.md Appendix B.  Path: 3 x (light 1D+2D, lightNum 1D, bsdf 1D+2D, path 1D+2D) + tau + scatter.
   if (integrator == DR_INTEGRATOR_PATH) return 5 + 14 + 18;
+  // strategy "one" (direct_lighting_integrator.dart:82-87): light component, lightNum, BSDF component + tau + scatter; light position, BSDF direction
+  if (integrator == DR_INTEGRATOR_DIRECT_ONE) return 5 + 5 + 4;
   return 5 + (2 * (int)nlights + 2) + 4 * (int)nlights;
 }
 
 int32_t dr_scene_sample_floats(const DrScene* scene, int32_t integrator) {
   if (!scene) return -1;
-  return integrator == DR_INTEGRATOR_DIRECT_ALL ? scene->dlNFloats : dr_sample_floats(integrator, scene->d.nlights);
+  return integrator == DR_INTEGRATOR_DIRECT_ALL ? scene->dlNFloats : dr_sample_floats(integrator, scene->d.nlights);  // ("all": the lights' nsamples decide)
 }
 
 int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
@@ -1163,8 +1165,11 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         p2 += 4 * ns[i];
       }
     }
+    // strategy "one": ONE EstimateDirect call; light < 0 = "the light floor(u * nLights) of the 1-D slot at float index pad1"; its slots
+    // are requested in the order light (1-D, 2-D), lightNum (1-D), BSDF (1-D, 2-D) (direct_lighting_integrator.dart:82-87), then tau / scatter
+    stages.push_back({-1, 1, 1, 5, 10, 12, 7, 6});
     sc->dlNBlocks = (int)blocks.size();
-    sc->dlNStages = (int)stages.size();
+    sc->dlNStages = (int)stages.size() - 1;
     sc->dlNFloats = o2;
     sc->dlN1D = n1D;
     TRY_SC(sc->dlBlocks.alloc(blocks.size()));
@@ -1333,9 +1338,11 @@ int planRender(RenderPlan& P) {
   const int spp = P.spp = rd->spp;
   if (spp <= 0 || (spp & (spp - 1)) != 0) return fail(DR_ERR_INVALID, "spp must be a power of two (low_discrepancy_sampler.dart:43-49)");
   if (spp > 4096) return fail(DR_ERR_UNSUPPORTED, "spp > 4096 (one pixel's shuffle table of a 16-pixel sampler group would not fit the LDS)");
-  if (rd->integrator != DR_INTEGRATOR_PATH && rd->integrator != DR_INTEGRATOR_DIRECT_ALL) return fail(DR_ERR_INVALID, "unknown integrator");
+  if (rd->integrator != DR_INTEGRATOR_PATH && rd->integrator != DR_INTEGRATOR_DIRECT_ALL && rd->integrator != DR_INTEGRATOR_DIRECT_ONE)
+    return fail(DR_ERR_INVALID, "unknown integrator");
   if (rd->max_depth < 0 || rd->max_depth > 64) return fail(DR_ERR_INVALID, "max_depth out of range");
-  P.direct = rd->integrator == DR_INTEGRATOR_DIRECT_ALL;
+  P.direct = rd->integrator != DR_INTEGRATOR_PATH;
+  const bool directOne = rd->integrator == DR_INTEGRATOR_DIRECT_ONE;  // strategy "one": the last entry of the scene's stage table, an arithmetic slot layout
   // DirectLighting over mirror / glass recurses through SpecularReflect / SpecularTransmit (integrator.dart:187-290):
   // an explicit per-slot stack and one round of the stage loop per vertex of the ray tree (k_shade_spec)
   P.dlSpec = P.direct && sc->hasSpecular;
@@ -1370,12 +1377,12 @@ int planRender(RenderPlan& P) {
   rp.sppShift = 0;
   while ((1 << rp.sppShift) < spp) ++rp.sppShift;
   rp.nLights = (int)sc->d.nlights;
-  rp.nFloats = P.direct ? sc->dlNFloats : dr_sample_floats(rd->integrator, sc->d.nlights);
-  rp.n1D = P.direct ? sc->dlN1D : 14;
-  rp.blocks = P.direct && sc->dlMulti ? sc->dlBlocks.p : nullptr;
+  rp.nFloats = P.direct && !directOne ? sc->dlNFloats : dr_sample_floats(rd->integrator, sc->d.nlights);
+  rp.n1D = directOne ? 5 : (P.direct ? sc->dlN1D : 14);
+  rp.blocks = P.direct && !directOne && sc->dlMulti ? sc->dlBlocks.p : nullptr;
   rp.nBlocks = sc->dlNBlocks;
-  rp.dstages = sc->dlStages.p;
-  rp.nDirectStages = P.direct ? sc->dlNStages : 0;
+  rp.dstages = directOne ? sc->dlStages.p + sc->dlNStages : sc->dlStages.p;
+  rp.nDirectStages = directOne ? (sc->d.nlights ? 1 : 0) : (P.direct ? sc->dlNStages : 0);
   rp.dlSpecular = P.dlSpec ? 1 : 0;
   rp.deferredNee = rd->integrator == DR_INTEGRATOR_PATH ? 1 : 0;
   rp.genMask = 0ull;
@@ -1424,7 +1431,7 @@ int planRender(RenderPlan& P) {
   for (const int2& p : P.pixels)
     if (p.x >= rp.left && p.x < rp.left + rp.width && p.y >= rp.top && p.y < rp.top + rp.height) P.filmSamples += spp;
   P.sgrid = g_numCU;  // the shade launchers size their grid per CU (DR_SHADE_GRID), grid-stride over the active list
-  P.nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : sc->dlNStages + 1;
+  P.nStages = rd->integrator == DR_INTEGRATOR_PATH ? rd->max_depth + 2 : rp.nDirectStages + 1;
   if (P.nStages > 248 || 8 * DR_WORK_STRIDE * (1 + 2 * P.nStages) > N_COUNTERS_TRACE - 1024) return fail(DR_ERR_UNSUPPORTED, "too many stages");
   return DR_OK;
 }

@@ -16,8 +16,10 @@ struct LdBlock {
 };
 // One EstimateDirect call of UniformSampleAllLights (integrator.dart:39-77): sample j of light `light`;
 // lc / lp / bd are the float indices of its light component, light position and BSDF direction samples.
+// light < 0: the one call of UniformSampleOneLight (integrator.dart:79-117; DirectLighting strategy "one"): the light is
+// floor(u * nLights) of the 1-D slot at float index `ln`, and the estimate is scaled by nLights instead of divided by n.
 struct DirectStage {
-  int32_t light, n, last, lc, lp, bd, bc, pad1;  // bc: float index of the BSDF sample's uComponent
+  int32_t light, n, last, lc, lp, bd, bc, ln;  // bc: float index of the BSDF sample's uComponent
 };
 
 // Per-render constants (by-value kernel argument).

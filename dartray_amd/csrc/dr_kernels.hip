@@ -1449,8 +1449,8 @@ __global__ void __launch_bounds__(DR_ENV_BLOCK) k_env(DScene sc, RenderParams rp
   stage_finish(s_push, pctx, q.closestQ, q.anyQ, q.activeOut, &q.ctr->shade_cont);
 }
 
-// DirectLightingIntegrator.Li with strategy "all" (direct_lighting_integrator.dart:30-68;
-// integrator.dart:39-77).  Stage s sets up EstimateDirect call s of UniformSampleAllLights (rp.dstages[s]:
+// DirectLightingIntegrator.Li with strategy "all" or "one" (direct_lighting_integrator.dart:30-68;
+// integrator.dart:39-117; "one": a single call whose light comes from the sample's lightNum slot).  Stage s sets up EstimateDirect call s of UniformSampleAllLights (rp.dstages[s]:
 // sample j of light i) at the camera hit and folds in the result of call s-1; the last stage finishes the
 // sum.  st.betaNee() carries the current light's Ld, st.beta() the running L of UniformSampleAllLights.
 template <bool QUAD, bool LLDS>
@@ -1515,8 +1515,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           else tri_dg(tr.p1, tr.p2, tr.p3, tr.reverse, F3{0, 0, 0}, d, 0.0, &dg);
           dg.p = ld3f<F_RO>(sr);
           Ld = ldcf<F_BETANEE>(sr);
-          Ld = cadd(Ld, resolve_nee<true, QUAD>(sc, lv, sr, flags, sr.i32<F_SHOCC>(), ldcf<F_LD1>(sr)));  // Ld += EstimateDirect
-          if (prev.last) {
+          const C3 Ed = resolve_nee<true, QUAD>(sc, lv, sr, flags, sr.i32<F_SHOCC>(), ldcf<F_LD1>(sr));
+          Ld = cadd(Ld, Ed);  // Ld += EstimateDirect
+          if (prev.light < 0) {
+            Lall = cmulD(Ed, (double)rp.nLights);  // UniformSampleOneLight: EstimateDirect(...) * nLights (integrator.dart:113-116)
+            Ld = C3{0.f, 0.f, 0.f};
+          } else if (prev.last) {
             Lall = cadd(Lall, cdivD(Ld, (double)prev.n));  // L += Ld / nSamples
             Ld = C3{0.f, 0.f, 0.f};
           }
@@ -1533,7 +1537,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK_OF(QUAD), SHADE_WAVES_OF(QUAD)) k_
           double lsc = sv_one(rp, st, slot, cur.lc);
           double ls0 = l0, ls1 = l1, bs0 = b0, bs1 = b1;
           double bsc = QUAD ? (double)sv_one(rp, st, slot, cur.bc) : 0.0;
-          pf |= setup_nee<true, QUAD, false, false>(sc, lv, sr, cur.light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
+          int light = cur.light;
+          if (light < 0) {  // strategy "one": lightNum = min(floor(sample.oneD[lightNumOffset][0] * nLights), nLights - 1) (integrator.dart:92-99)
+            light = (int)floor((double)sv_one(rp, st, slot, cur.ln) * (double)rp.nLights);
+            light = min(light, rp.nLights - 1);
+          }
+          pf |= setup_nee<true, QUAD, false, false>(sc, lv, sr, light, bsdf, bsdf.p, bsdf.nn, wo, ls0, ls1, lsc, bs0, bs1, bsc);
           again = true;
         } else {
           if (rp.nLights > 0) L = cadd(L, Lall);

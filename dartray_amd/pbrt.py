@@ -21,7 +21,7 @@ materials matte (Lambertian / Oren-Nayar), plastic, mirror, glass; area lights
 on any of those shapes, infinite lights (constant or .npy lat-long map), point,
 spot and distant lights; perspective / orthographic / environment cameras, image film, box / gaussian / mitchell / triangle / sinc filters,
 low-discrepancy sampler,
-bvh accelerator, path and directlighting (strategy "all") integrators.
+bvh accelerator, path and directlighting (strategies "all" and "one") integrators.
 
 A directive that needs a plugin outside that list (other quadrics, measured /
 metal / uber materials, textures, projection / goniometric lights, volumes,
@@ -899,10 +899,10 @@ class DartRay:
         if name == "path":
             return core.PathIntegrator(ps.findOneInt("maxdepth", 5))      # path_integrator.dart:133-136
         if name == "directlighting":                                       # direct_lighting_integrator.dart:98-111
+            maxdepth = ps.findOneInt("maxdepth", 5)
             st = ps.findOneString("strategy", "all")
-            if st == "one":
-                raise UnsupportedFeature("SurfaceIntegrator \"directlighting\" strategy 'one' is not on the path")
-            return core.DirectLightingIntegrator(0, ps.findOneInt("maxdepth", 5))
+            # (an unknown strategy is a LogWarning and 'all' in the reference, :102-108)
+            return core.DirectLightingIntegrator(1 if st == "one" else 0, maxdepth)
         raise UnsupportedFeature(f"SurfaceIntegrator \"{name}\": only 'path' and 'directlighting' are on the path")
 
     def makeRenderer(self, **renderer_kw):

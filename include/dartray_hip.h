@@ -215,6 +215,8 @@ typedef struct DrFilm {
 
 #define DR_INTEGRATOR_DIRECT_ALL 0 /* DirectLightingIntegrator, strategy "all" (direct_lighting_integrator.dart) */
 #define DR_INTEGRATOR_PATH 1       /* PathIntegrator (path_integrator.dart) */
+#define DR_INTEGRATOR_DIRECT_ONE 2 /* DirectLightingIntegrator, strategy "one" (direct_lighting_integrator.dart:51-55,82-87): ONE light per
+                                    * vertex, picked by its own 1-D sample slot (lightNumOffset), the estimate scaled by the light count */
 
 #define DR_SAMPLER_HOST_BUFFER 0 /* caller supplies sample vectors (+ the in-Li RNG draws) */
 #define DR_SAMPLER_COUNTER 1     /* on-device LD sampler, keyed per (pixel, block) / (pixel, sample) */

@@ -166,7 +166,7 @@ const int DR_SHADING_N = 1, DR_SHADING_S = 2, DR_SHADING_UV = 4;
 const int DR_COMM_ID_BYTES = 128;
 const int DR_PRIM_QUADRIC = 0xFFFFFFFF, DR_QUADRIC_SPHERE = 1, DR_QUADRIC_DISK = 2;
 const int DR_CAMERA_PERSPECTIVE = 0, DR_CAMERA_ORTHOGRAPHIC = 1, DR_CAMERA_ENVIRONMENT = 2;
-const int DR_INTEGRATOR_DIRECT_ALL = 0, DR_INTEGRATOR_PATH = 1;
+const int DR_INTEGRATOR_DIRECT_ALL = 0, DR_INTEGRATOR_PATH = 1, DR_INTEGRATOR_DIRECT_ONE = 2;
 const int DR_SAMPLER_COUNTER = 1;
 
 typedef _InitC = Int32 Function(Int32);
@@ -713,10 +713,8 @@ class HipSamplerRenderer extends Renderer {
         rd.i32(OFF_DrRenderDesc_max_depth, pi.maxDepth);
       } else if (surfaceIntegrator is DirectLightingIntegrator) {
         DirectLightingIntegrator di = surfaceIntegrator;
-        if (di.strategy != DirectLightingIntegrator.SAMPLE_ALL_UNIFORM) {
-          _unsupported('DirectLighting strategy "one"');
-        }
-        rd.i32(OFF_DrRenderDesc_integrator, DR_INTEGRATOR_DIRECT_ALL);
+        rd.i32(OFF_DrRenderDesc_integrator,
+               di.strategy == DirectLightingIntegrator.SAMPLE_ONE_UNIFORM ? DR_INTEGRATOR_DIRECT_ONE : DR_INTEGRATOR_DIRECT_ALL);
         rd.i32(OFF_DrRenderDesc_max_depth, di.maxDepth);
       } else {
         _unsupported('surface integrator ${surfaceIntegrator.runtimeType}');

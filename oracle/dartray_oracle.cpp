@@ -1812,7 +1812,7 @@ static S EstimateDirect(const Scene& sc, int lightIdx, const V& p, const V& n, c
 }
 
 struct IntegratorCfg {
-  int kind;      // 0 = DirectLighting(all), 1 = Path
+  int kind;      // 0 = DirectLighting(all), 1 = Path, 2 = DirectLighting(one)
   int maxDepth;
 };
 static const int SAMPLE_DEPTH = 3;  // path_integrator.dart:139
@@ -1830,7 +1830,11 @@ static void sample_layout(const Scene& sc, const IntegratorCfg& cfg, std::vector
       n1D->push_back(1); n2D->push_back(1);  // bsdfSampleOffsets
       n1D->push_back(1); n2D->push_back(1);  // pathSampleOffsets
     }
-  } else {  // direct_lighting_integrator.dart:70-87
+  } else if (cfg.kind == 2) {  // strategy "one" (direct_lighting_integrator.dart:82-87)
+    n1D->push_back(1); n2D->push_back(1);  // lightSampleOffsets[0] = LightSampleOffsets(1, sample)
+    n1D->push_back(1);                     // lightNumOffset = sample.add1D(1)
+    n1D->push_back(1); n2D->push_back(1);  // bsdfSampleOffsets[0] = BSDFSampleOffsets(1, sample)
+  } else {  // direct_lighting_integrator.dart:70-81
     for (size_t i = 0; i < sc.lights.size(); ++i) {
       int ns = sc.lights[i].nSamples;
       if (roundPow2) ns = rp2(ns);
@@ -1954,7 +1958,7 @@ static S SpecularBounce(const Scene& sc, const IntegratorCfg& cfg, const Ray& ra
   return L;
 }
 
-// DirectLightingIntegrator.Li, strategy "all" (direct_lighting_integrator.dart:30-68)
+// DirectLightingIntegrator.Li, strategies "all" and "one" (direct_lighting_integrator.dart:30-68)
 static S DirectLi(const Scene& sc, const IntegratorCfg& cfg, const Ray& ray, const Isect& isect, const SampleView& sv,
                   const std::vector<int>& n1D, const std::vector<int>& n2D, LiRng& rng) {
   S L{0, 0, 0};
@@ -1963,7 +1967,16 @@ static S DirectLi(const Scene& sc, const IntegratorCfg& cfg, const Ray& ray, con
   V p = bsdf.p;
   V n = bsdf.nn;
   L = sadd(L, isect_Le(sc, isect, wo));
-  if (!sc.lights.empty()) {
+  if (!sc.lights.empty() && cfg.kind == 2) {
+    // SAMPLE_ONE_UNIFORM (direct_lighting_integrator.dart:51-55): UniformSampleOneLight (integrator.dart:79-117) with the
+    // integrator's own slots -- oneD: [light component, lightNum, bsdf component], twoD: [light position, bsdf direction]
+    const int nLights = (int)sc.lights.size();
+    int lightNum = (int)std::floor(sv.oneD(1) * nLights);
+    lightNum = std::min(lightNum, nLights - 1);
+    L = sadd(L, smulD(EstimateDirect(sc, lightNum, p, n, wo, isect.rayEpsilon, bsdf, sv.twoD(0, 0), sv.twoD(0, 1), sv.oneD(0), sv.twoD(1, 0),
+                                     sv.twoD(1, 1), sv.oneD(2), BSDF_ALL & ~BSDF_SPECULAR),
+                      (D)nLights));
+  } else if (!sc.lights.empty()) {
     // UniformSampleAllLights (integrator.dart:39-77)
     S Lall{0, 0, 0};
     int off1 = 0, off2 = 0;  // running float offsets of the slots
