@@ -239,8 +239,9 @@ class DiffuseAreaLight:
 
 
 class InfiniteAreaLight:
-    """lights/infinite_area_light.dart:36-68.  `texels` is the radiance map's level-0 image [H, W, 3] f32
-    (MIPMap.pyramid[0]; power-of-two size) -- None gives the 1x1 white map of the no-'mapname' case;
+    """lights/infinite_area_light.dart:36-68.  `texels` is the radiance map's image [H, W, 3] f32 as MIPMap.texture receives it (a
+    size that is no power of two is resampled up to the next one, mipmap.dart:71-138: dr_scene_create does that) -- None gives the
+    1x1 white map of the no-'mapname' case;
     `L` the factor _radiance() multiplies in (:180-182).  NB when the reference loads a map from a file it
     ALSO pre-multiplies the texels by L (:44-49), i.e. L is applied twice; callers that want that pass
     pre-multiplied texels."""
@@ -255,9 +256,6 @@ class InfiniteAreaLight:
         if texels is None:
             texels = np.ones((1, 1, 3), dtype=np.float32)
         self.texels = np.ascontiguousarray(texels, dtype=np.float32)
-        h, w = self.texels.shape[:2]
-        if w & (w - 1) or h & (h - 1):
-            raise NotImplementedError("non power-of-two radiance maps are resampled by MIPMap (mipmap.dart:69-138): not on the path")
         self.shape = None
 
     def isDeltaLight(self):

@@ -289,6 +289,69 @@ void host_tri_normals(const float* a, const float* b, const float* c, bool rever
   for (int k = 0; k < 3; ++k) ns[k] = (float)(reverse ? n[k] * -1.0 : n[k]);
 }
 
+// MIPMap.texture's resampling of an RGB image to power-of-two resolution (mipmap.dart:71-138; wrap mode TEXTURE_REPEAT, the
+// InfiniteAreaLight's): a four-tap Lanczos zoom in s, then in t, every product and every partial sum a new Spectrum (f32 stores),
+// the t pass clamped to [0, inf) (_clamp, :358).  Weights: _resampleWeights (:360-384) in doubles.
+void resample_to_pow2(const float* img, int xres, int yres, std::vector<float>& out, int* wOut, int* hOut) {
+  auto roundUpPow2 = [](int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; };  // common.dart:105-113
+  struct Weight { int firstTexel; double w[4]; };
+  auto lanczos = [](double x) {  // texture.dart:27-39, tau = 2
+    x = std::fabs(x);
+    if (x < 1.0e-5) return 1.0;
+    if (x > 1.0) return 0.0;
+    x *= 3.141592653589793;
+    const double s = std::sin(x * 2.0) / (x * 2.0);
+    return s * (std::sin(x) / x);
+  };
+  auto weights = [&](int oldres, int newres) {
+    std::vector<Weight> wt(newres);
+    const double filterwidth = 2.0;
+    for (int i = 0; i < newres; ++i) {
+      const double center = (i + 0.5) * oldres / newres;
+      wt[i].firstTexel = (int)std::floor((center - filterwidth) + 0.5);
+      for (int j = 0; j < 4; ++j) wt[i].w[j] = lanczos(((wt[i].firstTexel + j + 0.5) - center) / filterwidth);
+      const double invSum = 1.0 / (wt[i].w[0] + wt[i].w[1] + wt[i].w[2] + wt[i].w[3]);
+      for (int j = 0; j < 4; ++j) wt[i].w[j] *= invSum;
+    }
+    return wt;
+  };
+  auto mod = [](int a, int n) { const int r = a % n; return r < 0 ? r + n : r; };  // Dart's % is never negative for a positive divisor
+  const int sPow2 = roundUpPow2(xres), tPow2 = roundUpPow2(yres);
+  out.assign(3 * (size_t)sPow2 * tPow2, 0.f);
+  const std::vector<Weight> sW = weights(xres, sPow2);
+  for (int t = 0; t < yres; ++t)
+    for (int s = 0; s < sPow2; ++s)
+      for (int j = 0; j < 4; ++j) {
+        const int origS = mod(sW[s].firstTexel + j, xres);
+        for (int c = 0; c < 3; ++c) {
+          float& dst = out[3 * ((size_t)t * sPow2 + s) + c];
+          const float px = (float)((double)img[3 * ((size_t)t * xres + origS) + c] * sW[s].w[j]);
+          dst = (float)((double)dst + (double)px);
+        }
+      }
+  const std::vector<Weight> tW = weights(yres, tPow2);
+  std::vector<float> work(3 * (size_t)tPow2);
+  for (int s = 0; s < sPow2; ++s) {
+    for (int t = 0; t < tPow2; ++t)
+      for (int c = 0; c < 3; ++c) {
+        float acc = 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const int off = mod(tW[t].firstTexel + j, yres);
+          const float px = (float)((double)out[3 * ((size_t)off * sPow2 + s) + c] * tW[t].w[j]);
+          acc = (float)((double)acc + (double)px);
+        }
+        work[3 * (size_t)t + c] = acc;
+      }
+    for (int t = 0; t < tPow2; ++t)
+      for (int c = 0; c < 3; ++c) {
+        const float v = work[3 * (size_t)t + c];
+        out[3 * ((size_t)t * sPow2 + s) + c] = (v < 0.f || v == 0.f) ? 0.f : v;  // num.clamp(0.0, INFINITY): NaN stays, -0.0 -> 0.0
+      }
+  }
+  *wOut = sPow2;
+  *hOut = tPow2;
+}
+
 int traceGrid() { return traceGridFor(DR_V2_WG_PER_CU); }  // the largest grid any variant launches (sizes the spill stacks)
 
 int ensureSpill(DrScene* sc, Workspace& w, int grid) {
@@ -990,9 +1053,17 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     if (envLight >= 0) {
       const DrAreaLight& a = desc->lights[envLight];
       const DrEnvMap& m = desc->env_maps[a.env_index];
-      const int w = m.width, h = m.height;
-      if (!m.texels || w <= 0 || h <= 0 || (w & (w - 1)) || (h & (h - 1)))
-        return bail(DR_ERR_UNSUPPORTED, "radiance map must have power-of-two width and height (mipmap.dart:69-138 resamples others)");
+      if (!m.texels || m.width <= 0 || m.height <= 0) return bail(DR_ERR_INVALID, "radiance map: null texels or empty size");
+      if (m.width > (1 << 14) || m.height > (1 << 14)) return bail(DR_ERR_UNSUPPORTED, "radiance map larger than 16384 texels a side");
+      // MIPMap.texture resamples an image whose width or height is no power of two up to the next one (mipmap.dart:71-138) before
+      // anything reads it; a host that hands over the decoded image (not a pyramid level) gets the same level 0 here
+      std::vector<float> resampled;
+      int w = m.width, h = m.height;
+      const float* texels = m.texels;
+      if ((w & (w - 1)) || (h & (h - 1))) {
+        resample_to_pow2(m.texels, w, h, resampled, &w, &h);
+        texels = resampled.data();
+      }
       // _setRadianceMap (infinite_area_light.dart:283-307): img = luminance(_radiance(u/w, v/h, filter)) * sin(theta),
       // filter = 1/max(w,h).  For a power-of-two map MIPMap.lookup's level = levels-1 + log2(filter) is 0 up to
       // rounding (mipmap.dart:211): either `triangle(0,s,t)` directly or triangle(0)*(1-d) + triangle(1)*d with
@@ -1001,7 +1072,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       auto texel = [&](int s, int t, int c) {
         s %= w; if (s < 0) s += w;
         t %= h; if (t < 0) t += h;
-        return (double)m.texels[3 * ((size_t)t * w + s) + c];
+        return (double)texels[3 * ((size_t)t * w + s) + c];
       };
       for (int v = 0; v < h; ++v) {
         const double sinTheta = std::sin(3.141592653589793 * (v + 0.5) / h);
@@ -1039,7 +1110,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       float mi = 0.f;
       dist1d(ci.data(), h, mf.data(), mc.data(), &mi);
       TRY_SC(sc->envTexels.alloc(3 * (size_t)w * h));
-      TRY_SC(hipMemcpy(sc->envTexels.p, m.texels, 3 * (size_t)w * h * sizeof(float), hipMemcpyHostToDevice));
+      TRY_SC(hipMemcpy(sc->envTexels.p, texels, 3 * (size_t)w * h * sizeof(float), hipMemcpyHostToDevice));
       TRY_SC(sc->envCondFunc.alloc(cf.size()));
       TRY_SC(hipMemcpy(sc->envCondFunc.p, cf.data(), cf.size() * sizeof(float), hipMemcpyHostToDevice));
       TRY_SC(sc->envCondCdf.alloc(cc.size()));

@@ -91,10 +91,12 @@ typedef struct DrAreaLight {
   double cone_width, cone_falloff_start;  /* DR_LIGHT_SPOT: total width and falloff start, degrees (spot_light.dart:42-48) */
 } DrAreaLight;
 
-/* InfiniteAreaLight.radianceMap level 0 (MIPMap.pyramid[0], lib/core/mipmap.dart:139,
- * f32 RGB texels, power-of-two size, TEXTURE_REPEAT) and Light.lightToWorld /
- * worldToLight (lib/core/light.dart:28-34).  The Distribution2D over
- * luminance x sin(theta) (infinite_area_light.dart:283-307) is rebuilt by the library. */
+/* InfiniteAreaLight's radiance map (f32 RGB texels, TEXTURE_REPEAT) and Light.lightToWorld / worldToLight
+ * (lib/core/light.dart:28-34).  texels: either level 0 of the light's MIPMap (MIPMap.pyramid[0], lib/core/mipmap.dart:139 -- always
+ * a power-of-two size) or the image as MIPMap.texture receives it (already multiplied by L, infinite_area_light.dart:44-49): a width
+ * or height that is no power of two is resampled up to the next one exactly as that constructor does (mipmap.dart:71-138: four-tap
+ * Lanczos, s then t, clamped at 0).  The Distribution2D over luminance x sin(theta) (infinite_area_light.dart:283-307) is rebuilt by
+ * the library.  At most 16384 texels a side. */
 typedef struct DrEnvMap {
   const float* texels; /* [height][width][3] */
   int32_t width, height;

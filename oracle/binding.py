@@ -86,6 +86,7 @@ def lib():
         l.orc_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         l.orc_intersect_brute.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         l.orc_sample_floats.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.orc_resample_pow2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         l.orc_render.argtypes = [C.c_void_p, C.POINTER(OrcRenderDesc), C.c_void_p, C.c_void_p, C.POINTER(OrcRecord)]
         l.orc_li_samples.argtypes = [C.c_void_p, C.POINTER(OrcRenderDesc), C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -129,6 +130,19 @@ def make_rays(o, d, tmin=0.0, tmax=np.inf):
     r["tmin"] = tmin
     r["tmax"] = tmax
     return r
+
+
+def resample_pow2(texels):
+    """MIPMap.texture's resampling of an [H, W, 3] f32 image to power-of-two size (mipmap.dart:71-138), as the oracle restates it."""
+    t = np.ascontiguousarray(texels, np.float32)
+    h, w = t.shape[:2]
+    p2 = lambda v: 1 << (int(v) - 1).bit_length()
+    out = np.zeros((p2(h), p2(w), 3), np.float32)
+    ow, oh = C.c_int(0), C.c_int(0)
+    if lib().orc_resample_pow2(t.ctypes.data, w, h, out.ctypes.data, C.byref(ow), C.byref(oh)) != 0:
+        raise RuntimeError("orc_resample_pow2 failed")
+    assert (oh.value, ow.value) == out.shape[:2]
+    return out
 
 
 class OracleScene:
@@ -209,7 +223,7 @@ class OracleScene:
             d.env_nsamples = env.nSamples
         self.h = l.orc_scene_create(C.byref(d))
         if not self.h:
-            raise RuntimeError("orc_scene_create failed (non power-of-two environment map, or a sphere used as an area light)")
+            raise RuntimeError("orc_scene_create failed (an empty environment map, or a sphere used as an area light)")
         info = (C.c_int64 * 6)()
         l.orc_scene_info(self.h, info)
         self.nnodes, self.nprims, self.depth, self.nlights, self.nverts, self.nlighttris = [int(v) for v in info]

@@ -434,9 +434,81 @@ struct EnvLight {
   }
   S radiance(D u, D v, D width = 0.0) const { return smul(lookup(u, v, width), L); }  // infinite_area_light.dart:180-182
 
-  // MIPMap.texture (mipmap.dart:61-170) for power-of-two maps + _setRadianceMap (infinite_area_light.dart:283-307)
-  bool init(const float* texels, int w, int h) {
-    if (w <= 0 || h <= 0 || (w & (w - 1)) || (h & (h - 1))) return false;  // non-pow2 maps are resampled first: not restated
+  // _resampleWeights (mipmap.dart:360-384): four Lanczos taps (texture.dart:27-39, tau = 2) per new texel, normalised
+  struct ResampleWeight { int firstTexel; D weight[4]; };
+  static D Lanczos(D x, D tau = 2.0) {
+    x = std::fabs(x);
+    if (x < 1.0e-5) return 1.0;
+    if (x > 1.0) return 0.0;
+    x *= kPi;
+    D s = std::sin(x * tau) / (x * tau);
+    D lanczos = std::sin(x) / x;
+    return s * lanczos;
+  }
+  static std::vector<ResampleWeight> resampleWeights(int oldres, int newres) {
+    std::vector<ResampleWeight> wt(newres);
+    D filterwidth = 2.0;
+    for (int i = 0; i < newres; ++i) {
+      D center = (i + 0.5) * oldres / newres;
+      wt[i].firstTexel = (int)std::floor((center - filterwidth) + 0.5);
+      for (int j = 0; j < 4; ++j) {
+        D pos = wt[i].firstTexel + j + 0.5;
+        wt[i].weight[j] = Lanczos((pos - center) / filterwidth);
+      }
+      D invSumWts = 1.0 / (wt[i].weight[0] + wt[i].weight[1] + wt[i].weight[2] + wt[i].weight[3]);
+      for (int j = 0; j < 4; ++j) wt[i].weight[j] *= invSumWts;
+    }
+    return wt;
+  }
+  // The resampling branch of MIPMap.texture (mipmap.dart:71-138), wrapMode TEXTURE_REPEAT: zoom in s into the first yres rows of the
+  // new image, then in t through workData, clamped to [0, inf).  Spectrum arithmetic: every `*` and `+` a Float32List store.
+  static std::vector<float> resampleToPow2(const float* img, int xres, int yres, int* sOut, int* tOut) {
+    auto RoundUpPow2 = [](int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; };
+    auto dartMod = [](int a, int n) { int r = a % n; return r < 0 ? r + n : r; };
+    int sPow2 = RoundUpPow2(xres), tPow2 = RoundUpPow2(yres);
+    std::vector<ResampleWeight> sWeights = resampleWeights(xres, sPow2);
+    std::vector<float> res(3 * (size_t)sPow2 * tPow2, 0.f);
+    auto at = [&](std::vector<float>& v, size_t i) { return S{v[3 * i], v[3 * i + 1], v[3 * i + 2]}; };
+    auto put = [&](std::vector<float>& v, size_t i, const S& x) { v[3 * i] = (float)x.r; v[3 * i + 1] = (float)x.g; v[3 * i + 2] = (float)x.b; };
+    for (int t = 0; t < yres; ++t)
+      for (int s = 0; s < sPow2; ++s) {
+        put(res, (size_t)t * sPow2 + s, S{0, 0, 0});
+        for (int j = 0; j < 4; ++j) {
+          int origS = dartMod(sWeights[s].firstTexel + j, xres);
+          if (origS >= 0 && origS < xres) {
+            size_t k = (size_t)t * xres + origS;
+            S px = smulD(S{img[3 * k], img[3 * k + 1], img[3 * k + 2]}, sWeights[s].weight[j]);
+            put(res, (size_t)t * sPow2 + s, sadd(at(res, (size_t)t * sPow2 + s), px));
+          }
+        }
+      }
+    std::vector<ResampleWeight> tWeights = resampleWeights(yres, tPow2);
+    std::vector<S> workData(tPow2);
+    for (int s = 0; s < sPow2; ++s) {
+      for (int t = 0; t < tPow2; ++t) {
+        workData[t] = S{0, 0, 0};
+        for (int j = 0; j < 4; ++j) {
+          int offset = dartMod(tWeights[t].firstTexel + j, yres);
+          if (offset >= 0 && offset < yres) workData[t] = sadd(workData[t], smulD(at(res, (size_t)offset * sPow2 + s), tWeights[t].weight[j]));
+        }
+      }
+      auto clamp0 = [](D v) { return (v < 0.0 || v == 0.0) ? 0.0 : v; };  // num.clamp(0.0, INFINITY): compareTo puts -0.0 below 0.0; NaN stays
+      for (int t = 0; t < tPow2; ++t) put(res, (size_t)t * sPow2 + s, S{clamp0(workData[t].r), clamp0(workData[t].g), clamp0(workData[t].b)});
+    }
+    *sOut = sPow2;
+    *tOut = tPow2;
+    return res;
+  }
+
+  // MIPMap.texture (mipmap.dart:61-170) + _setRadianceMap (infinite_area_light.dart:283-307)
+  bool init(const float* texelsIn, int w, int h) {
+    if (w <= 0 || h <= 0) return false;
+    std::vector<float> resampled;
+    const float* texels = texelsIn;
+    if ((w & (w - 1)) || (h & (h - 1))) {  // !IsPowerOf2(xres) || !IsPowerOf2(yres)
+      resampled = resampleToPow2(texelsIn, w, h, &w, &h);
+      texels = resampled.data();
+    }
     levels = 1 + (int)Log2((D)std::max(w, h));
     lw.assign(levels, 0); lh.assign(levels, 0);
     pyramid.resize(levels);
@@ -2603,6 +2675,17 @@ void orc_intersect_brute(void* h, const OrcRay* rays, int64_t n, OrcHit* out, in
       }
     }
   }
+}
+
+// MIPMap.texture's resampling branch alone (mipmap.dart:71-138): out must hold RoundUpPow2(w) * RoundUpPow2(h) * 3 floats
+int orc_resample_pow2(const float* texels, int w, int h, float* out, int* w_out, int* h_out) {
+  if (!texels || !out || w <= 0 || h <= 0) return -1;
+  int sw = 0, sh = 0;
+  std::vector<float> r = EnvLight::resampleToPow2(texels, w, h, &sw, &sh);
+  memcpy(out, r.data(), r.size() * sizeof(float));
+  *w_out = sw;
+  *h_out = sh;
+  return 0;
 }
 
 int orc_sample_floats(void* h, int integrator, int max_depth) {

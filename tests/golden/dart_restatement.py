@@ -858,7 +858,7 @@ class DiffuseAreaLight:
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# core/mipmap.dart (power-of-two RGB image, TEXTURE_REPEAT) and lights/infinite_area_light.dart
+# core/mipmap.dart (RGB image, TEXTURE_REPEAT; other sizes than powers of two are resampled first) and lights/infinite_area_light.dart
 # ---------------------------------------------------------------------------------------------------------------
 _invLog2 = 1.0 / math.log(2.0)                                     # common.dart:98
 
@@ -867,13 +867,90 @@ def Log2(x):                                                       # common.dart
     return math.log(x) * _invLog2
 
 
+def Lanczos(x, tau=2.0):                                           # texture.dart:27-39
+    x = abs(x)
+    if x < 1.0e-5:
+        return 1.0
+    if x > 1.0:
+        return 0.0
+    x *= math.pi
+    s_ = math.sin(x * tau) / (x * tau)
+    lanczos = math.sin(x) / x
+    return s_ * lanczos
+
+
+def RoundUpPow2(v):                                                # common.dart:105-113
+    v -= 1
+    for k in (1, 2, 4, 8, 16):
+        v |= v >> k
+    return v + 1
+
+
+def _resampleWeights(oldres, newres):                              # mipmap.dart:360-384 -> [(firstTexel, [w0, w1, w2, w3])]
+    wt = []
+    filterwidth = 2.0
+    for i in range(newres):
+        center = (i + 0.5) * oldres / newres
+        firstTexel = math.floor((center - filterwidth) + 0.5)
+        weight = [Lanczos(((firstTexel + j + 0.5) - center) / filterwidth) for j in range(4)]
+        invSumWts = 1.0 / (weight[0] + weight[1] + weight[2] + weight[3])
+        wt.append((firstTexel, [w * invSumWts for w in weight]))
+    return wt
+
+
+def dart_clamp(v, low, high):
+    """num.clamp (from memory of the SDK's double.dart): compareTo orders -0.0 below 0.0 and NaN above everything, NaN is returned as is."""
+    if v != v:
+        return v
+    if v < low or (v == 0.0 and low == 0.0 and math.copysign(1.0, v) < 0.0):
+        return low
+    if v > high:
+        return high
+    return v
+
+
+def resampleToPow2(img, xres, yres):
+    """The resampling branch of MIPMap.texture (mipmap.dart:71-138), wrapMode TEXTURE_REPEAT.  img: yres rows of xres RGB.
+    -> (resampledImage as a list of RGB, sPow2, tPow2)."""
+    sPow2, tPow2 = RoundUpPow2(xres), RoundUpPow2(yres)
+    sWeights = _resampleWeights(xres, sPow2)
+    res = [RGB(0.0)] * (sPow2 * tPow2)
+    for t in range(yres):                                          # apply sWeights to zoom in s direction
+        for s_ in range(sPow2):
+            acc = RGB(0.0)                                         # resampledImage[p] = zero
+            first, weight = sWeights[s_]
+            for j in range(4):
+                origS = (first + j) % xres                         # TEXTURE_REPEAT (Dart % is non-negative: so is Python's)
+                if 0 <= origS < xres:
+                    px = img[t * xres + origS] * weight[j]
+                    acc = acc + px                                 # resampledImage[t * sPow2 + s] += px
+            res[t * sPow2 + s_] = acc
+    tWeights = _resampleWeights(yres, tPow2)
+    for s_ in range(sPow2):                                        # resample image in t direction
+        workData = []
+        for t in range(tPow2):
+            w = RGB(0.0)
+            first, weight = tWeights[t]
+            for j in range(4):
+                offset = (first + j) % yres
+                if 0 <= offset < yres:
+                    w = w + res[offset * sPow2 + s_] * weight[j]
+            workData.append(w)
+        for t in range(tPow2):
+            w = workData[t]
+            res[t * sPow2 + s_] = RGB(dart_clamp(w.r, 0.0, INFINITY), dart_clamp(w.g, 0.0, INFINITY), dart_clamp(w.b, 0.0, INFINITY))   # _clamp(workData[t])
+    return res, sPow2, tPow2
+
+
 class MIPMap:
     def __init__(self, texels, width, height):
-        """MIPMap.texture (mipmap.dart:64-160) for a power-of-two image: `texels` = height rows of width (r, g, b)."""
-        assert width & (width - 1) == 0 and height & (height - 1) == 0
+        """MIPMap.texture (mipmap.dart:64-160): `texels` = height rows of width (r, g, b)."""
+        level0 = [RGB(*t) for t in texels]
+        if width & (width - 1) or height & (height - 1):           # !IsPowerOf2(xres) || !IsPowerOf2(yres)
+            level0, width, height = resampleToPow2(level0, width, height)
         self.width, self.height = width, height
         self.levels = 1 + int(Log2(max(width, height)))            # .toInt()
-        self.pyramid = [(width, height, [RGB(*t) for t in texels])]
+        self.pyramid = [(width, height, level0)]
         for i in range(1, self.levels):
             pw, ph, _ = self.pyramid[i - 1]
             sRes, tRes = max(1, pw // 2), max(1, ph // 2)
@@ -933,7 +1010,8 @@ class InfiniteAreaLight:
         self.lightToWorld, self.worldToLight = [float(x) for x in lightToWorld], [float(x) for x in worldToLight]
         self.L = RGB(*L)
         self.radianceMap = MIPMap(texels, width, height)
-        filt = 1.0 / max(width, height)                            # _setRadianceMap
+        width, height = self.radianceMap.width, self.radianceMap.height   # _setRadianceMap reads the map's own (resampled) size (:283-285)
+        filt = 1.0 / max(width, height)
         img = [0.0] * (width * height)
         for v in range(height):
             vp = v / height
@@ -1327,16 +1405,23 @@ def PathLi(scene, r, isect, sv, rng, maxDepth):
     return L
 
 
-def DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight):
-    """direct_lighting_integrator.dart:30-68 (strategy "all") with UniformSampleAllLights (integrator.dart:39-77).
-    Sample layout (requestSamples :70-87): per light a LightSampleOffsets then a BSDFSampleOffsets, each add1D(n) +
-    add2D(n); the volume integrator's two 1-D slots follow."""
+def DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight, strategy="all"):
+    """direct_lighting_integrator.dart:30-68 with UniformSampleAllLights (strategy "all", integrator.dart:39-77) or
+    UniformSampleOneLight (strategy "one", :79-117).
+    Sample layout (requestSamples :70-87).  "all": per light a LightSampleOffsets then a BSDFSampleOffsets, each add1D(n) +
+    add2D(n).  "one": LightSampleOffsets(1), lightNumOffset = add1D(1), BSDFSampleOffsets(1) -- oneD = [light component,
+    light number, bsdf component], twoD = [light position, bsdf direction].  The volume integrator's two 1-D slots follow."""
     bsdf = getBSDF(isect)
     wo = -ray.d
     p, n = bsdf.p, bsdf.nn
     L = RGB(0.0)
     L = L + isect_Le(isect, wo)
-    if scene.lights:
+    if scene.lights and strategy == "one":                          # SAMPLE_ONE_UNIFORM (:51-55)
+        n1D = 5
+        ls = (float(sv[5 + n1D]), float(sv[5 + n1D + 1]), float(sv[5]))
+        bs = (float(sv[5 + n1D + 2]), float(sv[5 + n1D + 3]), float(sv[5 + 2]))
+        L = L + UniformSampleOneLight(scene, p, n, wo, isect.rayEpsilon, bsdf, rng, float(sv[5 + 1]), ls, bs)
+    elif scene.lights:
         n1D = 2 + sum(2 * k for k in nSamplesPerLight)
         Lall = RGB(0.0)
         o1, o2 = 0, 0
@@ -1355,7 +1440,7 @@ def DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight):
         L = L + Lall
     if ray.depth + 1 < maxDepth:
         # trace rays for specular reflection and refraction (direct_lighting_integrator.dart:59-65)
-        li = lambda rd: RendererLi(scene, "direct", maxDepth, rd, sv, rng, nSamplesPerLight)
+        li = lambda rd: RendererLi(scene, "directone" if strategy == "one" else "direct", maxDepth, rd, sv, rng, nSamplesPerLight)
         L = L + SpecularBounce(ray, bsdf, rng, isect, li, BSDF_REFLECTION | BSDF_SPECULAR)
         L = L + SpecularBounce(ray, bsdf, rng, isect, li, BSDF_TRANSMISSION | BSDF_SPECULAR)
     return L
@@ -1385,7 +1470,7 @@ def RendererLi(scene, integrator, maxDepth, ray, sv, rng, nSamplesPerLight=None)
         if integrator == "path":
             Li = PathLi(scene, ray, isect, sv, rng, maxDepth)
         else:
-            Li = DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight)
+            Li = DirectLi(scene, ray, isect, sv, rng, maxDepth, nSamplesPerLight, "one" if integrator == "directone" else "all")
     else:
         Li = RGB(0.0)
         for light in scene.lights:

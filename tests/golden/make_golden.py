@@ -95,6 +95,20 @@ def main():
         np.savez_compressed(os.path.join(OUT, name), rgb=rec["rgb"], film=rec["film"],
                             pixel_xy=rec["pixel_xy"][::spp].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
                             tail_count=rec["tail_count"], Ls=rec["Ls"])
+    # (11) DirectLighting strategy "one": two lights, a matte and a mirror blob, serial mode
+    prims, mk = mrf.dlone_case()
+    r = mk()
+    rec = ob.OracleScene(prims).render(ob.render_desc(r, sampler_mode=0), record=17 * 17 * 4, max_tail=200)
+    np.savez_compressed(os.path.join(OUT, "cdlone_direct_serial.npz"), rgb=rec["rgb"], film=rec["film"],
+                        pixel_xy=rec["pixel_xy"][::4].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
+                        tail_count=rec["tail_count"], Ls=rec["Ls"])
+    # (12) the environment-map scene under a 24 x 10 map: MIPMap.texture's resampling to 32 x 16, serial mode
+    prims, mk = mrf.env_case(np2=True)
+    r = mk()
+    rec = ob.OracleScene(prims, env=r.env).render(ob.render_desc(r, sampler_mode=0), record=17 * 17 * 8, max_tail=40)
+    np.savez_compressed(os.path.join(OUT, "cenvnp2_path_serial.npz"), rgb=rec["rgb"], film=rec["film"],
+                        pixel_xy=rec["pixel_xy"][::8].copy(), sample_vec=rec["sample_vec"], tail=rec["tail"],
+                        tail_count=rec["tail_count"], Ls=rec["Ls"])
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

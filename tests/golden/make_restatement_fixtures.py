@@ -10,6 +10,8 @@ Dart text) on the recorded serial sample streams of the golden cases and commits
   restatement_cdl2.npz     DirectLighting over two area lights with 2 and 4 samples per light, 16 x 16, 4 spp
   restatement_cquad.npz    spheres and disks (matte / mirror / glass; a disk and a sphere emitter), PathIntegrator maxdepth 5, 16 x 16, 8 spp
   restatement_cquaddl.npz  the same scene under DirectLighting (maxdepth 5), 16 x 16, 4 spp
+  restatement_cdlone.npz   DirectLighting strategy "one" (maxdepth 5) over two area lights, a matte and a mirror blob, 16 x 16, 4 spp
+  restatement_cenvnp2.npz  the environment-map scene under a 24 x 10 map (no power of two: MIPMap.texture resamples it to 32 x 16), 16 x 16, 8 spp
 
 each with per-sample Li (`Ls`), the film (X, Y, Z, weightSum) and the written image (`rgb`), plus the number of RNG
 draws each sample consumed.  Inputs: the scene as the product's host code flattens it (BVH nodes from dr_bvh_build,
@@ -155,6 +157,10 @@ def cases():
     yield "restatement_cquad.npz", prims, mk(), "cquad_path_serial.npz", "path", None
     prims, mk = quad_case(direct=True)
     yield "restatement_cquaddl.npz", prims, mk(), "cquaddl_direct_serial.npz", "direct", [1, 1]
+    prims, mk = dlone_case()
+    yield "restatement_cdlone.npz", prims, mk(), "cdlone_direct_serial.npz", "directone", None
+    prims, mk = env_case(np2=True)
+    yield "restatement_cenvnp2.npz", prims, mk(), "cenvnp2_path_serial.npz", "path", None
 
 
 def quad_case(direct=False):
@@ -201,6 +207,26 @@ def dl2_case():
     return prims, mk
 
 
+def dlone_case():
+    """DirectLighting with strategy "one" (direct_lighting_integrator.dart:51-55,82-87): ONE light per vertex, picked by the
+    integrator's own lightNum slot, the estimate scaled by the light count; two area lights of different radiance (the
+    choice shows), a matte blob, and a mirror blob so that the SpecularReflect recursion re-reads the same slots at the
+    deeper vertices; maxdepth 5, 16 x 16, 4 spp."""
+    e2 = scenes._quad((-9.9, -2, -2), (-9.9, 2, -2), (-9.9, 2, 2), (-9.9, -2, 2), (0.5, 0.5, 0.5), core.DiffuseAreaLight((5.0, 9.0, 3.0), 1))
+    prims = scenes.cornell_walls() + [
+        scenes.emitter_quad(), e2,
+        core.GeometricPrimitive(scenes.blob_mesh(16, 8, radius=3.4, centre=(-3.8, -6.0, 1.5)), core.MatteMaterial((0.48, 0.48, 0.48))),
+        core.GeometricPrimitive(scenes.blob_mesh(16, 8, radius=3.0, centre=(4.2, -5.0, -1.0)), core.MirrorMaterial((0.9, 0.85, 0.8))),
+    ]
+    film = core.ImageFilm(16, 16, core.BoxFilter(0.5, 0.5))
+    cam = core.PerspectiveCamera.lookAt((0.0, 0.0, -35.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 35.0, film)
+
+    def mk():
+        return core.SamplerRenderer(core.LowDiscrepancySampler(cam, 4, 5489), cam,
+                                    core.DirectLightingIntegrator(core.DirectLightingIntegrator.SAMPLE_ONE_UNIFORM, 5), core.EmissionIntegrator())
+    return prims, mk
+
+
 def lens_case():
     """C2-small through a thin lens (lensradius 0.8, focaldistance 33): the depth-of-field branch of
     PerspectiveCamera.generateRayDifferential (perspective_camera.dart:104-119), PathIntegrator maxdepth 3, 16 x 16, 4 spp."""
@@ -225,14 +251,16 @@ def dlspec_case():
     return prims, mk
 
 
-def env_case():
-    """An open scene under an InfiniteAreaLight (32 x 16 procedural sky with a sun lobe) plus the quad emitter: floor, a
+def env_case(np2=False):
+    """(np2: the same scene under a 24 x 10 rendition of the sky -- neither side a power of two, so MIPMap.texture resamples it to
+    32 x 16 first, mipmap.dart:71-138: Lanczos taps with negative lobes around the sun, the clamp at 0, the REPEAT wrap at both seams.)
+    An open scene under an InfiniteAreaLight (32 x 16 procedural sky with a sun lobe) plus the quad emitter: floor, a
     matte blob and a mirror blob, PathIntegrator maxdepth 4, 16 x 16, 8 spp: Le of
     escaped camera and specular rays, Distribution2D sampling, Light.pdf for the BSDF-sampled direction, two lights in
     UniformSampleOneLight."""
     film = core.ImageFilm(16, 16, core.BoxFilter(0.5, 0.5))
     cam = core.PerspectiveCamera.lookAt((0.0, 2.0, -35.0), (0.0, -3.0, 0.0), (0.0, 1.0, 0.0), 40.0, film)
-    env = scenes.sky_env(32, 16)
+    env = scenes.sky_env(24, 10) if np2 else scenes.sky_env(32, 16)
     prims = [scenes.floor_quad(), scenes.emitter_quad(),
              core.GeometricPrimitive(scenes.blob_mesh(16, 8, radius=3.5, centre=(-3.5, -6.0, 1.0)), core.MatteMaterial((0.6, 0.5, 0.4))),
              core.GeometricPrimitive(scenes.blob_mesh(16, 8, radius=3.0, centre=(4.5, -6.5, -1.5)), core.MirrorMaterial((0.9, 0.9, 0.9)))]

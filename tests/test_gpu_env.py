@@ -23,7 +23,7 @@ def _parity(ob, prims, r, env, exact=True):
     return out
 
 
-@pytest.mark.parametrize("integ", [core.PathIntegrator(5), core.DirectLightingIntegrator(0, 5)])
+@pytest.mark.parametrize("integ", [core.PathIntegrator(5), core.DirectLightingIntegrator(0, 5), core.DirectLightingIntegrator(1, 5)])
 def test_sky_only(ob, gpu, integ):
     floor = scenes._quad((-50, 0, -50), (50, 0, -50), (50, 0, 50), (-50, 0, 50), (0.6, 0.6, 0.6))
     for env in (core.InfiniteAreaLight(scenes.SKY_TO_WORLD, (2.0, 2.0, 2.0), 1, None), scenes.sky_env(64, 32)):
@@ -37,7 +37,7 @@ def test_sky_only(ob, gpu, integ):
 def test_box_with_area_light_and_sky(ob, gpu):
     prims = scenes.cornell_prims(scenes.blob_prim(16, 8))
     env = scenes.sky_env(128, 64, L=(0.5, 0.5, 0.5))
-    for integ in (core.PathIntegrator(5), core.DirectLightingIntegrator(0, 5)):
+    for integ in (core.PathIntegrator(5), core.DirectLightingIntegrator(0, 5), core.DirectLightingIntegrator(1, 5)):
         film = core.ImageFilm(24, 24)
         cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
         r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 16), cam, integ, core.EmissionIntegrator())
@@ -74,3 +74,24 @@ def test_environment_map_taller_than_the_lds_copy(ob, gpu):
     cam = core.PerspectiveCamera.lookAt((0, 10, -30), (0, 0, 0), (0, 1, 0), 40.0, film)
     r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 16), cam, core.PathIntegrator(4), core.EmissionIntegrator())
     _parity(ob, [floor] + scenes.cornell_walls()[3:], r, sky)
+
+
+@pytest.mark.parametrize("size", [(96, 40), (24, 10), (33, 64), (128, 3)])
+def test_radiance_map_that_is_no_power_of_two(ob, gpu, size):
+    """A radiance map whose width or height is no power of two: dr_scene_create resamples it up to the next
+    one as MIPMap.texture does (mipmap.dart:71-138) before the Distribution2D is built.  Films and visit counters equal the oracle's
+    (which restates the resampling itself), and the light is the same one a host gets by handing over the resampled level 0."""
+    w, h = size
+    rng = np.random.default_rng(w * 1000 + h)
+    tex = (rng.random((h, w, 3)) ** 3 * 4).astype(np.float32)
+    tex[h // 5: h // 5 + max(1, h // 10), w // 4: w // 4 + max(1, w // 12)] += 30.0
+    prims = scenes.cornell_walls()[:1] + [scenes.emitter_quad(), scenes.blob_prim(16, 8)]
+    for integ in (core.PathIntegrator(4), core.DirectLightingIntegrator(1, 5)):
+        films = []
+        for texels in (tex, ob.resample_pow2(tex)):
+            env = core.InfiniteAreaLight(scenes.SKY_TO_WORLD, (1.0, 0.9, 0.8), 1, texels)
+            film = core.ImageFilm(24, 20)
+            cam = core.PerspectiveCamera.lookAt((0, 2, -35), (0, -3, 0), (0, 1, 0), 40.0, film)
+            r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 16), cam, integ, core.EmissionIntegrator())
+            films.append(_parity(ob, prims, r, env).film)
+        assert np.array_equal(films[0], films[1])

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("integ,rho", [(core.PathIntegrator(0), 0.5), (core.PathIntegrator(3), 0.5), (core.PathIntegrator(8), 0.8),
-                                       (core.DirectLightingIntegrator(0, 5), 0.6)], ids=["path0", "path3", "path8rr", "direct"])
+                                       (core.DirectLightingIntegrator(0, 5), 0.6), (core.DirectLightingIntegrator(1, 5), 0.6)],
+                         ids=["path0", "path3", "path8rr", "direct", "direct-one"])
 def test_white_furnace(gpu, integ, rho):
     Le = 1.25
     prims = _furnace_prims(rho, Le)

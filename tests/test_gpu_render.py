@@ -195,6 +195,44 @@ def test_two_emitters_direct_and_path(ob, gpu):
         assert out.rgb.mean() > 0
 
 
+@pytest.mark.parametrize("spp", [1, 8, 64])
+def test_direct_lighting_strategy_one(ob, gpu, spp):
+    """DirectLightingIntegrator with SAMPLE_ONE_UNIFORM (direct_lighting_integrator.dart:51-55): UniformSampleOneLight with the
+    integrator's own slots -- LightSampleOffsets(1), lightNumOffset = add1D(1), BSDFSampleOffsets(1) (:82-87: 5 + 5 + 4 = 14 floats) --
+    over three lights (two quads of different radiance and a constant sky, so that the choice shows) with a mirror blob whose
+    SpecularReflect recursion reads the same slots again at the deeper vertices.  Counter streams against the oracle (film and visit
+    counters), then the reference's one serial stream replayed through host buffers."""
+    e2 = scenes._quad((-9.9, -2, -2), (-9.9, 2, -2), (-9.9, 2, 2), (-9.9, -2, 2), (0.5, 0.5, 0.5), core.DiffuseAreaLight((5.0, 9.0, 3.0), 3))
+    prims = scenes.cornell_prims(scenes.blob_prim(16, 8)) + [e2, core.GeometricPrimitive(scenes.blob_mesh(12, 6, radius=2.5, centre=(5.5, -6.5, -3.0)),
+                                                                                     core.MirrorMaterial((0.9, 0.9, 0.9)))]
+    env = core.InfiniteAreaLight(scenes.SKY_TO_WORLD, (0.2, 0.3, 0.5), 2, None)
+    film = core.ImageFilm(20, 16)
+    cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
+    one = core.DirectLightingIntegrator(core.DirectLightingIntegrator.SAMPLE_ONE_UNIFORM, 5)
+    assert one.kind == _abi.DR_INTEGRATOR_DIRECT_ONE
+    r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, spp), cam, one, core.EmissionIntegrator())
+    scene = scenes.make_scene(prims, env)
+    out = r.render(scene)
+    osc = ob.OracleScene(prims, env=env)
+    osc.counters(reset=True)
+    ref = osc.render(ob.render_desc(r, sampler_mode=1))
+    _check(out, ref)
+    c, st = osc.counters(), r.last_stats
+    for k in ("closest_rays", "any_rays", "closest_nodes", "any_nodes", "closest_tris", "any_tris"):
+        assert st[k] == c[k], k
+    # ONE shadow ray (+ at most one MIS ray) per vertex, whatever the number of lights: strategy "all" traces three
+    assert st["any_rays"] <= st["closest_rays"]
+    assert _abi.lib().dr_scene_sample_floats(scene._device().handle, _abi.DR_INTEGRATOR_DIRECT_ONE) == 14
+    r_all = core.SamplerRenderer(core.LowDiscrepancySampler(cam, spp), cam, core.DirectLightingIntegrator(0, 5), core.EmissionIntegrator())
+    assert not np.array_equal(r_all.render(scene).film, out.film)
+    # serial reference stream -> host buffers
+    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=21 * 17 * spp, max_tail=200)
+    assert rec["sample_vec"].shape[1] == 14
+    r.sampler = core.HostBufferSampler(cam, spp, rec["pixel_xy"][::spp].copy(), rec["sample_vec"], rec["tail"])
+    out2 = r.render(scene)
+    assert np.array_equal(out2.film, rec["film"]) and np.array_equal(out2.rgb, rec["rgb"])
+
+
 @pytest.mark.parametrize("ns", [(2, 1), (3, 5), (16, 1)])
 def test_direct_lighting_with_several_samples_per_light(ob, gpu, ns):
     """UniformSampleAllLights with light.nSamples > 1 (integrator.dart:39-77): the LD sampler hands out

@@ -107,3 +107,46 @@ def test_position_of_the_infinite_light_in_scene_lights(ob):
     assert np.array_equal(last, same)
     assert not np.array_equal(last, first)
     assert np.isfinite(first).all() and first[..., :3].mean() > 0
+
+
+def _np2_map(w=96, h=40, seed=7):
+    rng = np.random.default_rng(seed)
+    tex = (rng.random((h, w, 3)) ** 3 * 4).astype(np.float32)
+    tex[5:9, 20:28] += 30.0          # a bright patch: the Lanczos taps around it have negative lobes (the clamp at 0 shows)
+    tex[:, 0] *= 0.1                 # the seam: REPEAT wrap takes column w - 1 next to column 0
+    return tex
+
+
+def test_radiance_map_that_is_no_power_of_two_is_resampled_like_mipmap_texture(ob):
+    """MIPMap.texture (mipmap.dart:71-138) on a 96 x 40 map: resampled to 128 x 64 (s then t, four Lanczos taps, REPEAT wrap,
+    clamped at 0).  The oracle's restatement against the independent Python one, bit for bit; properties of the result; and the
+    identity the C ABI documents -- handing over the image, or handing over the resampled level 0, is the same light."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import dart_restatement as dr
+    tex = _np2_map()
+    out = ob.resample_pow2(tex)
+    assert out.shape == (64, 128, 3) and out.min() >= 0.0 and np.isfinite(out).all()
+    res, sp, tp = dr.resampleToPow2([dr.RGB(*[float(c) for c in tex[y, x]]) for y in range(40) for x in range(96)], 96, 40)
+    assert (sp, tp) == (128, 64)
+    assert np.array_equal(np.array([r.tuple() for r in res], np.float32).reshape(64, 128, 3), out)
+    assert (out == 0.0).any()                                        # negative lobes next to the bright patch were clamped
+    assert out.mean() == pytest.approx(tex.mean(), rel=0.03)         # normalised weights: the zoom keeps the mean
+    flat = ob.resample_pow2(np.full((10, 24, 3), 0.75, np.float32))  # a constant map stays constant up to the f32 stores of the taps
+    assert flat.shape == (16, 32, 3) and np.allclose(flat, 0.75, rtol=1e-6)
+    # weights (mipmap.dart:360-384): four taps around the new texel's centre, summing to one
+    wts = dr._resampleWeights(96, 128)
+    assert all(abs(sum(w4) - 1.0) < 1e-12 and len(w4) == 4 for _, w4 in wts) and any(min(w4) < 0.0 for _, w4 in wts)
+    assert wts[0][0] == -2 and wts[127][0] == 94                     # the first / last taps reach across the seam (REPEAT)
+    env_img = core.InfiniteAreaLight(scenes.SKY_TO_WORLD, (1.0, 0.9, 0.8), 1, tex)
+    env_lvl0 = core.InfiniteAreaLight(scenes.SKY_TO_WORLD, (1.0, 0.9, 0.8), 1, out)
+    films = []
+    for env in (env_img, env_lvl0):
+        prims, r, osc = _floor_scene(ob, env, spp=16)
+        films.append(osc.render(ob.render_desc(r, sampler_mode=1))["film"])
+    assert np.array_equal(films[0], films[1]) and films[0][..., :3].max() > 0
+    # ... and it is not the light a naive nearest-neighbour enlargement would give
+    nn = tex[(np.arange(64) * 40) // 64][:, (np.arange(128) * 96) // 128]
+    prims, r, osc = _floor_scene(ob, core.InfiniteAreaLight(scenes.SKY_TO_WORLD, (1.0, 0.9, 0.8), 1, nn), spp=16)
+    assert not np.array_equal(osc.render(ob.render_desc(r, sampler_mode=1))["film"], films[0])

@@ -196,3 +196,29 @@ def test_white_furnace_pins_the_whole_path_integrator(ob, maxdepth, rho):
     assert rgb.mean() == pytest.approx(expect, rel=0.01), (rgb.mean(), expect)
     assert np.abs(rgb - expect).max() < 0.15 * expect      # per pixel: 256 spp
     assert np.allclose(rgb[..., 0], rgb[..., 1], rtol=1e-5)
+
+
+def test_direct_lighting_strategy_one_layout_and_estimator(ob):
+    """SAMPLE_ONE_UNIFORM (direct_lighting_integrator.dart:51-55,82-87): the sample vector is 5 camera floats + the 1-D slots
+    [light component, light number, bsdf component, tau, scatter] + the 2-D slots [light position, bsdf direction] = 14 floats;
+    it draws the same 6 RNG floats per hit as "all" (the two SpecularReflect / SpecularTransmit BSDFSample.random), and it is
+    an estimator of the same integral: over two lights its mean agrees with strategy "all" (which samples both lights at every
+    vertex) within the Monte-Carlo error, while the per-sample values differ."""
+    e2 = scenes._quad((-9.9, -2, -2), (-9.9, 2, -2), (-9.9, 2, 2), (-9.9, -2, 2), (0.5, 0.5, 0.5), core.DiffuseAreaLight((5.0, 9.0, 3.0), 1))
+    prims = scenes.cornell_prims(scenes.blob_prim(16, 8)) + [e2]
+    film = core.ImageFilm(12, 12)
+    cam = core.PerspectiveCamera.lookAt((0, 0, -35), (0, 0, 0), (0, 1, 0), 35.0, film)
+    osc = ob.OracleScene(prims)
+    means = {}
+    for strategy in (0, 1):
+        r = core.SamplerRenderer(core.LowDiscrepancySampler(cam, 256), cam, core.DirectLightingIntegrator(strategy, 5), core.EmissionIntegrator())
+        rd = ob.render_desc(r, sampler_mode=0)
+        rec = osc.render(rd, record=13 * 13 * 256, max_tail=8)
+        assert rec["sample_vec"].shape[1] == (14 if strategy else 5 + 2 * 2 + 2 + 4 * 2)
+        assert osc.sample_floats(rd.integrator, 5) == rec["sample_vec"].shape[1]
+        assert set(np.unique(rec["tail_count"])) <= {0, 6}
+        means[strategy] = rec["rgb"].mean(axis=(0, 1))
+    assert np.allclose(means[0], means[1], rtol=0.02), means
+    assert not np.array_equal(means[0], means[1])
+    with pytest.raises(ValueError):
+        core.DirectLightingIntegrator(2, 5)

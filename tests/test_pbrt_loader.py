@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from dartray_amd import core, pbrt, scenes
+from dartray_amd import _abi, core, pbrt, scenes
 
 HEADER = '''
 Film "image" "integer xresolution" [64] "integer yresolution" [48]
@@ -92,6 +92,18 @@ def test_defaults_are_the_reference_render_options():
     assert r.sampler.samplesPerPixel == 4
     assert np.array_equal(r.camera.cameraToWorld, np.eye(4, dtype=np.float32))
     assert np.allclose(api.scenePrimitives[0].material.Kd, 0.5)
+
+
+def test_directlighting_strategies():
+    """DirectLightingIntegrator.Create (direct_lighting_integrator.dart:98-111): 'all' (default), 'one', anything else -> 'all'."""
+    body = "\nWorldBegin\nShape \"trianglemesh\" " + QUAD + "\nWorldEnd"
+    for text, want in (('SurfaceIntegrator "directlighting"', 0), ('SurfaceIntegrator "directlighting" "string strategy" "all"', 0),
+                       ('SurfaceIntegrator "directlighting" "string strategy" "one" "integer maxdepth" 3', 1),
+                       ('SurfaceIntegrator "directlighting" "string strategy" "some"', 0)):
+        si = pbrt.loads(text + body).rendererObject.surfaceIntegrator
+        assert isinstance(si, core.DirectLightingIntegrator) and si.strategy == want
+        assert si.kind == (_abi.DR_INTEGRATOR_DIRECT_ONE if want else _abi.DR_INTEGRATOR_DIRECT_ALL)
+    assert si.maxDepth == 5 and pbrt.loads('SurfaceIntegrator "directlighting" "string strategy" "one" "integer maxdepth" 3' + body).rendererObject.surfaceIntegrator.maxDepth == 3
 
 
 def test_attribute_stack_restores_ctm_material_area_light_and_orientation():

@@ -36,7 +36,8 @@ def _cases():
                                              ("restatement_cspec.npz", 8, 17 * 17 * 8), ("restatement_cenv.npz", 8, 17 * 17 * 8),
                                              ("restatement_cdlspec.npz", 4, 17 * 17 * 4), ("restatement_clens.npz", 4, 17 * 17 * 4),
                                              ("restatement_cdl2.npz", 4, 17 * 17 * 4), ("restatement_cquad.npz", 8, 17 * 17 * 8),
-                                             ("restatement_cquaddl.npz", 4, 17 * 17 * 4)])
+                                             ("restatement_cquaddl.npz", 4, 17 * 17 * 4), ("restatement_cdlone.npz", 4, 17 * 17 * 4),
+                                             ("restatement_cenvnp2.npz", 8, 17 * 17 * 8)])
 def test_oracle_equals_the_independent_restatement(ob, name, spp, record):
     """The oracle, run live in the reference's serial mode, against what the Python restatement computed from the
     same sample vectors and RNG draws."""
@@ -45,7 +46,7 @@ def test_oracle_equals_the_independent_restatement(ob, name, spp, record):
     g = np.load(os.path.join(GOLDEN, golden))
     env = getattr(r, "env", None)
     osc = ob.OracleScene(prims, env=env) if env is not None else ob.OracleScene(prims)
-    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=record, max_tail=40 if integ == "path" else (200 if ("dlspec" in name or "quaddl" in name) else 8))
+    rec = osc.render(ob.render_desc(r, sampler_mode=0), record=record, max_tail=40 if integ == "path" else (200 if ("dlspec" in name or "quaddl" in name or "dlone" in name) else 8))
     assert np.array_equal(rec["sample_vec"], g["sample_vec"])          # same inputs as the fixtures were made from
     assert np.array_equal(rec["Ls"], fx["Ls"])                          # per-sample Li
     assert np.array_equal(rec["film"], fx["film"])                      # ImageFilm.addSample, in reference order
@@ -72,6 +73,8 @@ def test_live_restatement_regenerates_the_serial_streams():
         sv, pix, spp = g["sample_vec"], g["pixel_xy"], r.sampler.samplesPerPixel
         if integ == "path":
             n1D, n2D = [1] * 14, [1] * 9                       # requestSamples (path_integrator.dart:124-131) + the volume integrator's two slots
+        elif integ == "directone":
+            n1D, n2D = [1] * 5, [1] * 2                        # strategy "one" (direct_lighting_integrator.dart:82-87): light, lightNum, bsdf + tau, scatter
         else:
             n2D = [k for ns in nspl for k in (ns, ns)]          # per light: LightSampleOffsets, BSDFSampleOffsets (add1D(n) + add2D(n) each)
             n1D = n2D + [1, 1]
@@ -200,7 +203,8 @@ def test_restated_traversal_reproduces_the_golden_hit_records():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,spp", [("restatement_c1.npz", 4), ("restatement_c2small.npz", 8), ("restatement_cspec.npz", 8), ("restatement_cenv.npz", 8),
                                       ("restatement_cdlspec.npz", 4), ("restatement_clens.npz", 4), ("restatement_cdl2.npz", 4),
-                                      ("restatement_cquad.npz", 8), ("restatement_cquaddl.npz", 4)])
+                                      ("restatement_cquad.npz", 8), ("restatement_cquaddl.npz", 4), ("restatement_cdlone.npz", 4),
+                                      ("restatement_cenvnp2.npz", 8)])
 def test_gpu_replay_equals_the_independent_restatement(gpu, name, spp):
     _, prims, r, golden, integ, _ = _cases()[name]
     fx = np.load(os.path.join(GOLDEN, name))
