@@ -636,10 +636,21 @@ class Run:
         if getattr(args, "trace_kernels", None):
             self.dev.trace_kernels(tuple(int(x) for x in args.trace_kernels.split(",")))
 
-    def step(self):
+    def step(self, first=False):
+        import torch
         from dartray_amd import _abi, dist as drdist
         self.film.zero_()
-        self.renderer.render_device(self.scene, self.film.data_ptr(), self.stream)
+        if first and self.world > 1:
+            # the scene's first render carries the pilot: rank 0 renders first, its picks (kernel pair, state layout) go to the other
+            # ranks over the control plane, and they render without calibration batches of their own (dartray_amd/dist.py: share_pilot)
+            if self.rank == 0:
+                self.renderer.render_device(self.scene, self.film.data_ptr(), self.stream)
+                torch.cuda.synchronize()
+            self.picks = drdist.share_pilot(self.dev)
+            if self.rank != 0:
+                self.renderer.render_device(self.scene, self.film.data_ptr(), self.stream)
+        else:
+            self.renderer.render_device(self.scene, self.film.data_ptr(), self.stream)
         drdist.reduce_film(self.film, 0, self.stream)
         if self.rank == 0:
             _abi.check(self.lib.dr_film_resolve_device(self.film.data_ptr(), self.H * self.W, self.rgb.data_ptr(), self.stream))
@@ -653,9 +664,10 @@ class Run:
         # one-shot render pays on top of a steady-state step; timed on its own, not one of the W + K steps.
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        self.step()
+        self.step(first=True)
         torch.cuda.synchronize()
         first_ms = (time.perf_counter() - t0) * 1e3
+        picks_per_rank = drdist.gather_picks(self.dev)  # (closest, any_hit, layout) of every rank's scene after its first render
         if rank == 0:
             self.rgb.cpu()  # the image back on the host: what Renderer.render hands to its caller
         one_shot_render_ms = (time.perf_counter() - t0) * 1e3
@@ -799,6 +811,10 @@ class Run:
                                  (drdist.comm_error if drdist.rehearsal() else "FALLBACK torch.distributed RCCL group -- dr_comm_init failed: %s" % drdist.comm_error))
             if drdist.rehearsal():
                 out["rehearsal"] = "NOT a measurement: %d ranks on %d GPU(s)" % (world, torch.cuda.device_count())
+            # what every rank runs (rank 0's pilot, handed on): printed on the line only where the ranks differ
+            out["trace_kernels_all_ranks"] = [list(p) for p in picks_per_rank]
+            if len(set(picks_per_rank)) > 1:
+                out["trace_kernels_per_rank"] = [list(p) for p in picks_per_rank]
             out["per_rank_step_ms"] = {"min": round(own_min / steps * 1e3, 3), "max": round(own_max / steps * 1e3, 3),
                                        "note": "each rank's own clock before the closing barrier (rank 0's includes waiting for the reduce)"}
             out["reduce_ms"] = round(reduce_ms, 3)

@@ -179,6 +179,44 @@ def sample_set(renderer, rank):
     return renderer
 
 
+def share_pilot(dev, src=0):
+    """Make the ranks agree on what rank `src`'s pilot picked.  Call it after rank `src` has rendered the scene once and BEFORE the
+    other ranks render it: the (closest-hit, any-hit) traversal kernels and the path-state layout of `dev` on rank `src` travel over
+    the control plane (three integers, gloo) and the other ranks store them with dr_scene_set_trace_kernels /
+    dr_scene_set_state_layout -- their first render then runs no calibration batches of its own.  Every kernel and layout is
+    bit-exact, so this changes no film; it changes the job's time: a step is the max over ranks (the reference waits for its slowest
+    task too, lib/dartray_web/render_manager.dart:100-141), and a rank whose own pilot -- a few small launches, sharing the node with
+    seven other ranks' -- picks the slower kernel (12 % on C2-class scenes) sets the step for everyone.  Returns the picks
+    (closest, any_hit, layout); (0, 0, 0) = rank `src` ran no pilot (a small render): nothing is stored."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    t = torch.zeros(3, dtype=torch.int32)
+    if rank == src:
+        k = dev.trace_kernels()
+        t[0], t[1], t[2] = int(k[0]), int(k[1]), int(dev.state_layout()[0])
+    if world > 1:
+        dist.broadcast(t, src=src)
+    picks = (int(t[0]), int(t[1]), int(t[2]))
+    if rank != src:
+        if picks[0] and picks[1]:
+            dev.trace_kernels(picks[:2])
+        if picks[2]:
+            dev.state_layout(picks[2])
+    return picks
+
+
+def gather_picks(dev):
+    """What every rank's scene ended up with, as a list of (closest, any_hit, layout) per rank (control plane; diagnostics)."""
+    k = dev.trace_kernels()
+    mine = torch.tensor([int(k[0]), int(k[1]), int(dev.state_layout()[0])], dtype=torch.int32)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        return [tuple(int(v) for v in mine)]
+    out = [torch.zeros(3, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [tuple(int(v) for v in o) for o in out]
+
+
 def reduce_film(film, dst=0, stream=None):
     """Sum the per-rank (X, Y, Z, weight) films onto rank `dst` (one collective per render).  Device films go
     through dr_film_reduce (RCCL) on `stream` (default: torch's current stream)."""

@@ -159,3 +159,55 @@ def test_comm_init_or_fallback_is_symmetric_when_one_rank_fails(fail_rank, fail_
         assert "dr_comm_destroy" not in res[fail_rank]["calls"]
     else:  # nobody reached ncclCommInitRank
         assert all("dr_comm_init" not in r["calls"] for r in res)
+
+
+class _FakeDeviceScene:
+    """What dist.share_pilot touches of core._DeviceScene: the kernel pair and the state layout, with their setters."""
+
+    def __init__(self, kernels, layout):
+        self.kernels, self.layout, self.sets = tuple(kernels), layout, []
+
+    def trace_kernels(self, kernels=None):
+        if kernels is not None:
+            self.kernels = tuple(kernels)
+            self.sets.append(("kernels", tuple(kernels)))
+        return self.kernels
+
+    def state_layout(self, layout=None):
+        if layout is not None:
+            self.layout = layout
+            self.sets.append(("layout", layout))
+        return self.layout, 0.5
+
+
+def _pilot_worker(rank, world, init_file, out_dir, src_picks):
+    sys.path.insert(0, ROOT)
+    import json
+    import torch.distributed as dist
+    from dartray_amd import dist as drdist
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    # every rank's own pilot would have said something else; rank 0's is what counts
+    dev = _FakeDeviceScene(src_picks[:2], src_picks[2]) if rank == 0 else _FakeDeviceScene((0, 0), 0)
+    picks = drdist.share_pilot(dev)
+    allp = drdist.gather_picks(dev)
+    json.dump({"picks": picks, "kernels": dev.kernels, "layout": dev.layout, "sets": dev.sets, "all": allp}, open(os.path.join(out_dir, "r%d.json" % rank), "w"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("src_picks", [(5, 3, 4), (2, 2, 64), (0, 0, 0)])
+def test_ranks_take_rank_zeros_pilot_picks(src_picks):
+    """dist.share_pilot: rank 0's kernel pair and state layout reach every rank over the gloo control
+    plane and are stored there; (0, 0, 0) -- rank 0 ran no pilot -- stores nothing."""
+    import json
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_pilot_worker, args=(2, os.path.join(tmp, "init"), tmp, src_picks), nprocs=2, join=True)
+        r0, r1 = (json.load(open(os.path.join(tmp, "r%d.json" % k))) for k in (0, 1))
+    assert tuple(r0["picks"]) == tuple(r1["picks"]) == tuple(src_picks)
+    assert r0["sets"] == []                                            # the source rank keeps what it measured
+    if src_picks == (0, 0, 0):
+        assert r1["sets"] == [] and tuple(r1["kernels"]) == (0, 0)
+    else:
+        assert [tuple(x) if isinstance(x, list) else x for _, x in r1["sets"]] == [tuple(src_picks[:2]), src_picks[2]]
+        assert tuple(r1["kernels"]) == tuple(src_picks[:2]) and r1["layout"] == src_picks[2]
+    assert r0["all"] == r1["all"] and len(r0["all"]) == 2 and len({tuple(p) for p in r0["all"]}) == 1

@@ -66,10 +66,26 @@ rank, world, _ = drdist.init_process_group()
 prims, mk = scenes.config("C2", xres=160, yres=128, spp=16, blob=(60, 30))
 r = drdist.shard(mk(), rank, world)
 scene = scenes.make_scene(prims)
+dev = scene._device()
 H, W = r.camera.film.height, r.camera.film.width
 film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
-r.render_device(scene, film.data_ptr(), stream)
+# rank 0 renders first (DARTRAY_PILOT=force: its render runs the pilot), its picks travel to rank 1, which then runs no pilot
+if rank == 0:
+    r.render_device(scene, film.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert dev.last_render_info()["pilot_batches"] >= 3
+picks = drdist.share_pilot(dev)
+if rank != 0:
+    r.render_device(scene, film.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert dev.last_render_info()["pilot_batches"] == 0, dev.last_render_info()
+assert picks[0] in (2, 3, 5) and picks[1] in (2, 3) and picks[2] in (4, 64), picks
+assert dev.trace_kernels() == picks[:2] and dev.state_layout()[0] == picks[2]
+allp = drdist.gather_picks(dev)
+assert len(allp) == world and len(set(allp)) == 1, allp     # both ranks run the same kernels in the same layout
+info = dev.last_render_info()
+assert (info["closest_kernel"], info["any_hit_kernel"], info["state_layout"]) == picks, (info, picks)
 drdist.reduce_film(film, 0, stream)
 t = drdist.max_over_ranks(float(rank + 1))
 torch.cuda.synchronize()
@@ -100,7 +116,9 @@ def test_two_ranks_tile_shards_merged_by_dr_film_reduce(gpu, rehearsal):
         script = os.path.join(tmp, "worker.py")
         out = os.path.join(tmp, "film.npy")
         open(script, "w").write(_WORKER % {"root": ROOT})
-        env = dict(os.environ)
+        env = dict(os.environ, DARTRAY_PILOT="force")  # (a small scene: the pilot has to be asked for)
+        env.pop("DARTRAY_TRACE_IMPL", None)
+        env.pop("DARTRAY_STATE_LAYOUT", None)
         if rehearsal:
             env["DARTRAY_COMM_REHEARSAL"] = "1"
         res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
@@ -110,4 +128,4 @@ def test_two_ranks_tile_shards_merged_by_dr_film_reduce(gpu, rehearsal):
         merged = np.load(out)
     prims, mk = scenes.config("C2", xres=160, yres=128, spp=16, blob=(60, 30))
     single = mk().render(scenes.make_scene(prims)).film
-    assert np.array_equal(merged, single)
+    assert np.array_equal(merged, single)   # (and inside the worker: both ranks report the same kernel pair and state layout)
