@@ -141,121 +141,25 @@ def gen_alg_bytes_per_sample(nblocks, spp):
     return nblocks * idx + 8.0 * nblocks / spp + 2 * idx + 32.0
 
 
-def roofline_objects(st, dt_total, copy_gbps, closest_kernel="k_trace<0>", tag="C2", gen_bytes_per_sample=None, kernels_forced=False, pk=None):
-    # (round 5) the camera rays are traced by k_trace_pk (coherent waves); `pk` = its share of the closest-hit totals
-    # (dr_scene_get_coherent_stats): the dominant kernel's object below is the PER-LANE kernel alone, k_trace_pk gets its own
-    pk = pk or {"rays": 0, "nodes": 0, "tris": 0, "launches": 0, "ms": 0.0}
-    alg_all_closest = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
-    alg_pk = 32.0 * pk["nodes"] + 48.0 * pk["tris"]
-    alg = alg_all_closest - alg_pk
-    launches = max(1, st["closest_launches"] - pk["launches"])
-    lane_ms = st["closest_ms"] - pk["ms"]
-    achieved = alg / max(lane_ms * 1e-3, 1e-12) / 1e9
-    all_alg = alg_all_closest + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
-    # (the observed bounds were read off the committed profiles of the kernels the pilots pick: not claimed for forced kernels)
-    bo = {} if kernels_forced else BOUND_OBSERVED.get(tag, {})
-    roof = {"bound": bo.get("trace_bound", "hbm"), "bound_priced_against": "hbm",
-            "bound_source": "profiles/ (committed PMC passes of the pilots' kernels), not this run" if bo else "not profiled for these kernels",
-            "kernel": "%s (closest-hit BVH traversal)" % closest_kernel,
-            "achieved": round(achieved, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_GBPS, 4),
-            # an algorithmic-byte fraction at or above 1 has left the range where it discriminates (the bytes are served by caches):
-            # read frac_physical_of_copy / lane_utilisation / wait_share below instead
-            "saturated": bool(achieved / PEAK_GBPS > 1.0),
-            "traffic": None,  # HBM-side bytes come from separate rocprofv3 --pmc passes: see "traffic_profiled" / "physical_*"
-            "achieved_is": "algorithmic bytes per second (cache hits included), not HBM traffic",
-            "hbm_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
-            "alg_over_measured_copy": round(achieved / copy_gbps, 4) if copy_gbps else None,
-            "alg_bytes_per_launch": round(alg / launches, 1),
-            "avg_launch_ms": round(lane_ms / launches, 4), "launches": int(launches),
-            "camera_rays_by": ("k_trace_pk (coherent waves): %d launches, %.2f ms and %.1f GB of algorithmic bytes per launch -- not in this object: see roofline_camera"
-                               % (pk["launches"], pk["ms"] / max(1, pk["launches"]), alg_pk / max(1, pk["launches"]) / 1e9)) if pk["launches"] else None,
-            "avg_launch_ms_note": ("HIP events around each %s launch on its own stream; the stage's any-hit launch runs beside it on a second "
-                                   "stream (DARTRAY_OVERLAP_ANY=0 serialises them: profiles/r0*_kernel_stats_serial.csv, within 1 %% of this figure)"
-                                   % closest_kernel if os.environ.get("DARTRAY_OVERLAP_ANY", "1") != "0" else "%s, one kernel at a time" % closest_kernel),
-            "rank0_job_alg_GBps": round(all_alg / dt_total / 1e9, 2),
-            "rank0_trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt_total, 4)}
-    sb = shade_alg_bytes(st)
-    sa = sb / max(st["shade_ms"] * 1e-3, 1e-12) / 1e9
-    shade = {"bound": bo.get("shade_bound", "hbm"), "bound_priced_against": "hbm",
-             "kernel": "k_shade_path (vertex step of PathIntegrator.Li; + k_env on scenes with an environment map)",
-             "achieved": round(sa, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(sa / PEAK_GBPS, 4), "traffic": None,
-             "achieved_is": "algorithmic bytes per second, not HBM traffic",
-             "alg_over_measured_copy": round(sa / copy_gbps, 4) if copy_gbps else None,
-             "alg_bytes_per_item": round(sb / max(1, st["shade_items"]), 1),
-             "items": int(st["shade_items"]), "vertices": int(st["shade_vertices"]),
-             # rays the shading stages queued: continuation, MIS (BSDF-sampled direction towards the light) and shadow rays.  List entries
-             # without a vertex = items - vertices; of those, the ones known at push time (a path that ended with a MIS ray pending:
-             # Q_RESOLVE_BIT) = items - camera_samples - cont (every later entry either continues or is resolve-only)
-             "cont_rays": int(st["shade_cont"]), "mis_rays": int(st["shade_mis"]), "shadow_rays": int(st["shade_shadow"]),
-             "resolve_only_entries": int(st["shade_items"] - st["camera_samples"] - st["shade_cont"])}
-    gen = None
-    if gen_bytes_per_sample and st.get("gen_ms"):
-        gb = gen_bytes_per_sample * st["camera_samples"]
-        ga = gb / max(st["gen_ms"] * 1e-3, 1e-12) / 1e9
-        gen = {"bound": "lds-latency", "bound_priced_against": "hbm",
-               "kernel": "k_gen_samples_* + k_raygen (LDPixelSample: per (pixel, LD block) a seeded generator, burn-in draws and a Fisher-Yates shuffle in LDS; then the camera rays)",
-               "achieved": round(ga, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(ga / PEAK_GBPS, 4), "traffic": None,
-               "achieved_is": "algorithmic bytes per second: permuted-index bytes + scrambles written, camera rays written",
-               "alg_bytes_per_sample": round(gen_bytes_per_sample, 2),
-               "bound_observed": "the serial chain of a pixel's shuffle (generator step -> partner -> LDS swap, spp steps per block) at the "
-                                 "occupancy its LDS table allows (one 64-pixel group per CU at 1024 spp); bytes are not the limit"}
-    # the physical picture, from the committed PMC passes of the same command (never presented as this run's measurement)
-    prof = profiled_kernels(tag)
-    if prof:
-        for obj, prefix in ((roof, closest_kernel), (shade, "k_shade_path"), (gen, "k_gen_samples")):
-            if obj is None:
-                continue
-            k = next((v for n, v in prof["kernels"].items() if n.split("::")[-1].startswith(prefix)), None)
-            if not k or not k.get("hbm_side_GBps"):
-                continue
-            obj["physical_GBps"] = round(k["hbm_side_GBps"], 1)
-            obj["physical_frac_of_spec"] = round(k["hbm_side_GBps"] / PEAK_GBPS, 4)
-            obj["physical_frac_of_measured"] = round(k["hbm_side_GBps"] / copy_gbps, 4) if copy_gbps else None
-            # the figure to read next to `frac`: memory-side bytes per second against the copy rate this run measured
-            obj["frac_physical_of_copy"] = obj["physical_frac_of_measured"]
-            for src_key, dst_key in (("valu_lane_utilisation", "lane_utilisation"), ("wait_any_share_of_wave_cycles", "wait_share"),
-                                     ("l2_hit_rate", "l2_hit_rate")):
-                if k.get(src_key) is not None:
-                    obj[dst_key] = round(k[src_key], 4)
-            obj["physical_source"] = prof["source"] + " (rocprofv3 --pmc: TCC_EA0_RDREQ 32/64/128 B + WRITE_SIZE per launch / kernel-trace launch time; not this run)"
-        # memory-side bytes over algorithmic bytes, per kernel, both from the profiled run (1 = every byte fetched once;
-        # below: caches absorb re-reads; above: partial lines / re-reads -- the first thing to fix)
-        if prof.get("trace_ratio"):
-            roof["traffic_over_algorithmic"] = round(prof["trace_ratio"], 3)
-        if prof.get("shade_ratio"):
-            shade["traffic_over_algorithmic"] = round(prof["shade_ratio"], 3)
-        roof["bound_observed"] = bo.get("trace")
-        shade["bound_observed"] = bo.get("shade")
-    cam = None
-    if pk["launches"]:
-        ca = alg_pk / max(pk["ms"] * 1e-3, 1e-12) / 1e9
-        cam = {"bound": "scalar-load latency + VALU at full lane width", "bound_priced_against": "hbm",
-               "kernel": "k_trace_pk (closest-hit traversal of the camera rays by coherent waves: one stack per wave, node and triangles loaded once per wave)",
-               "achieved": round(ca, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(ca / PEAK_GBPS, 4), "saturated": bool(ca / PEAK_GBPS > 1.0),
-               "traffic": None, "achieved_is": "algorithmic bytes per second (32 B per ray and node visit: the reference's per-ray count), not HBM traffic -- "
-                                               "the wave loads a node ONCE for its 64 rays, so this figure exceeds any memory rate by construction",
-               "alg_bytes_per_launch": round(alg_pk / pk["launches"], 1), "avg_launch_ms": round(pk["ms"] / pk["launches"], 4), "launches": int(pk["launches"]),
-               "rays": int(pk["rays"]), "node_visits_per_ray": round(pk["nodes"] / max(1, pk["rays"]), 2)}
-    return roof, shade, gen, all_alg, cam
+# ---------------------------------------------------------------------------------------------------------------------
+# Figures derived from the committed rocprofv3 passes (profiles/r0N_<cfg>_traffic.json, built by tools/make_traffic.py).
+# They belong to the LIBRARY that was profiled: since round 6 a traffic file carries the sha256 of that library's kernel
+# sources, and nothing below is printed unless they equal the running library's -- otherwise the objects say
+# "stale_profile" and carry nulls (round 5 matched profiles to kernels by NAME only: change a kernel without retaking the
+# passes and the line printed last round's counters next to this round's time).
+# ---------------------------------------------------------------------------------------------------------------------
+KERNEL_SOURCES = ("dr_trace.hip", "dr_kernels.hip", "dr_device.h", "dr_kernels.h", "dr_wave.h", "dr_rng.h")
+CLOCK_HZ, SIMDS, CUS = 2.4e9, 1024, 256
 
 
-# What the PMC passes say bounds each kernel (MEASUREMENTS.md; profiles/r0*_traffic.json).  "bound" on the line is
-# the observed one; the fraction is priced against the HBM roofline either way ("bound_priced_against").
-BOUND_OBSERVED = {
-    "C2": {"trace_bound": "latency", "shade_bound": "valu-f64+latency",
-           "trace": "dependent-fetch latency at seven workgroups per CU on top of three half-loaded throughput ceilings of ~108 ms each per step -- VALU issue, "
-                    "the L1's divergent-load path, random lines beyond L2 (roofline.ceilings; MEASUREMENTS.md round 5: the occupancy-independent part is NOT "
-                    "Infinity-Cache bandwidth); the scene is cache resident (L2 / Infinity Cache serve ~half the algorithmic bytes)",
-           "shade": "f64 VALU issue (~0.7 busy) and state-access latency at 3 waves per SIMD; 1.6x the algorithmic bytes at the memory side"},
-    "C3": {"trace_bound": "latency", "shade_bound": "valu-f64+latency", "trace": "as C2 (same scene)", "shade": "as C2"},
-    "C4": {"trace_bound": "hbm", "shade_bound": "valu-f64+latency",
-           "trace": "HBM / Infinity Cache (tree beyond every cache: 640 MB nodes + 480 MB triangles): 0.7 of the measured copy rate at the memory "
-                    "side, the rest is the length of a ray's chain of dependent fetches", "shade": "as C2"},
-    "C5": {"trace_bound": "latency", "shade_bound": "latency (sparse state access)",
-           "trace": "dependent-fetch latency, upper tree cache resident",
-           "shade": "sparse state access: the stage lists thin out at the first bounce (four-slot line-grouped state layout picked for this render); "
-                    "3.2x the algorithmic bytes at the memory side (k_shade_path + k_env), half the list entries carry no vertex"},
-}
+def library_hashes():
+    """sha256 of the running library's kernel sources (dartray_amd/libdartray_hip.buildinfo.json, written by build(); _abi.lib()
+    has already checked that file against the sources and the .so)."""
+    try:
+        have = json.load(open(os.path.join(ROOT, "dartray_amd", "libdartray_hip.buildinfo.json"))).get("sources", {})
+    except (OSError, ValueError):
+        return {}
+    return {k: have[k] for k in KERNEL_SOURCES if k in have}
 
 
 def traffic_files(tag):
@@ -267,119 +171,232 @@ def traffic_files(tag):
         return []
 
 
-def kernel_profile(tag, names):
-    """What the committed PMC passes say about each named traversal kernel of this config (lane utilisation, wait share,
-    L2 hit rate, memory-side rate): the newest traffic file that has the kernel; {"profiled": False} when none has."""
-    out = {}
-    for role, kname in names.items():
-        hit = None
-        for fname in traffic_files(tag):
-            d = json.load(open(os.path.join(ROOT, "profiles", fname)))
-            k = next((v for n, v in d.get("kernels", {}).items() if n.split("::")[-1] == kname or n.split("::")[-1].startswith(kname + "(")), None)
-            if k:
-                hit = (fname, k)
-                break
-        if not hit:
-            out[role] = {"kernel": kname, "profiled": False}
+def load_profile(tag, hashes=None, directory=None):
+    """The newest committed traffic file of this config: (name, contents, fresh).  fresh = the file is stamped with the kernel-source
+    hashes of the library that is running; (None, None, False) when the config has no file."""
+    directory = directory or os.path.join(ROOT, "profiles")
+    hashes = library_hashes() if hashes is None else hashes
+    for name in traffic_files(tag) if directory == os.path.join(ROOT, "profiles") else sorted(os.listdir(directory), reverse=True):
+        try:
+            d = json.load(open(os.path.join(directory, name)))
+        except (OSError, ValueError):
             continue
-        fname, k = hit
-        out[role] = {"kernel": kname, "profiled": True, "source": "profiles/" + fname,
-                     "lane_utilisation": round(k["valu_lane_utilisation"], 4) if k.get("valu_lane_utilisation") is not None else None,
-                     "wait_share": round(k["wait_any_share_of_wave_cycles"], 4) if k.get("wait_any_share_of_wave_cycles") is not None else None,
-                     "l2_hit_rate": round(k["l2_hit_rate"], 4) if k.get("l2_hit_rate") is not None else None,
-                     "physical_GBps": round(k["hbm_side_GBps"], 1) if k.get("hbm_side_GBps") else None,
-                     "avg_launch_ms_serial": round(k["avg_launch_ms_kernel_trace"], 3) if k.get("avg_launch_ms_kernel_trace") else None}
-    return out
+        if "kernels" not in d:
+            continue
+        stamp = d.get("library_sources")
+        return name, d, bool(stamp) and bool(hashes) and stamp == hashes
+    return None, None, False
 
 
-def trace_ceilings(tag, kname, st, steps, pk=None):
-    """Throughput ceilings of the closest-hit traversal kernel, per step, from what the kernel asks of each shared resource:
-    the time each resource alone would need for this run's work at its MEASURED peak rate (tools/gather_rate.hip:
-    profiles/r05_gather_rates.json) -- VALU issue (2 cycles per wave64 instruction on a SIMD-32 with several waves resident), the
-    per-CU L1's divergent-address path (16-byte lane loads of different lines), L2 requests, and random 128-byte lines from beyond
-    L2 (Infinity Cache / HBM) -- with the per-byte demands (instructions, L2 requests, lines beyond L2 per algorithmic byte) taken
-    from the committed PMC passes of the same kernel on the same config.  The kernel is UNDER each of them; `binding` is the largest,
-    `frac_of_binding_ceiling` = that over the measured time: what a perfectly overlapped, latency-free version would reach."""
+def _valu_quad_cycles(v):
+    """SQ_ACTIVE_INST_VALU per launch of a traffic-file entry (files of rounds 3-5 kept it as a share of the launch time)."""
+    if v.get("valu_active_quad_cycles_per_launch") is not None:
+        return v["valu_active_quad_cycles_per_launch"]
+    if v.get("valu_issue_share_at_4_cycles_per_instruction") and v.get("avg_launch_ms_kernel_trace"):
+        return v["valu_issue_share_at_4_cycles_per_instruction"] * v["avg_launch_ms_kernel_trace"] * 1e-3 * CLOCK_HZ * SIMDS / 4.0
+    return None
+
+
+def _find_kernel(d, prefix, exact=False):
+    for n, v in d.get("kernels", {}).items():
+        base = n.split("::")[-1]
+        if base == prefix or (not exact and base.startswith(prefix)):
+            return v
+    return None
+
+
+def machine_rates():
+    """Measured peak rates of the shared resources (tools/gather_rate.hip on an MI355X: a property of the chip, not of the library)."""
     try:
-        rates = json.load(open(os.path.join(ROOT, "profiles", "r05_gather_rates.json")))
+        return json.load(open(os.path.join(ROOT, "profiles", "r05_gather_rates.json")))
     except (OSError, ValueError):
         return None
-    prof = None
-    for fname in traffic_files(tag):
-        d = json.load(open(os.path.join(ROOT, "profiles", fname)))
-        k = next((v for n, v in d.get("kernels", {}).items() if n.split("::")[-1] == kname), None)
-        if k and d.get("alg_bytes_per_launch") and d.get("kernel", "").split("::")[-1] == kname:
-            prof = (fname, d, k)
-            break
-    if not prof or not st["closest_ms"]:
-        return None
-    fname, d, k = prof
-    alg_prof = d["alg_bytes_per_launch"]
-    pk = pk or {"nodes": 0, "tris": 0, "ms": 0.0}
-    nodes, tris, ms = st["closest_nodes"] - pk["nodes"], st["closest_tris"] - pk["tris"], st["closest_ms"] - pk["ms"]  # the per-lane kernel's share
-    alg_run = (32.0 * nodes + 48.0 * tris) / steps
-    clk, simds, cus = 2.4e9, 1024, 256
-    out = {"kernel": kname, "per": "step", "measured_ms": round(ms / steps, 2),
-           "demand_source": "profiles/" + fname + " (per algorithmic byte)", "rate_source": "profiles/r05_gather_rates.json (tools/gather_rate.hip)"}
+
+
+def ceilings(k, scale, measured_ms, copy_gbps, kind, extra=None):
+    """Throughput ceilings of one kernel, in ms: the time each shared resource ALONE would need for the work, from what the profiled
+    launches asked of it (per-launch counters of traffic-file entry `k`, times `scale` = this run's work over the profiled work) at the
+    resource's measured peak rate.  The kernel is under each of them; `binding` is the largest, `frac_of_binding_ceiling` = that over
+    the measured time: what a perfectly overlapped, latency-free version would reach.
+      valu_issue       SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1024 SIMDs x clock): f64 / transcendental instructions occupy the pipe longer and
+                       are counted at what they occupy.  Traversal kernels (many waves interleaved: 2 cycles per wave64 f32 instruction): x 2.
+      lds_array        SQ_LDS_IDX_ACTIVE (all CUs) / (256 CUs x clock)
+      l2_requests      TCC_REQ / the measured L2 request rate
+      memory_lines     memory-side bytes / this run's measured copy rate (streaming kernels) or read requests / the measured random-line rate
+    """
+    rates = machine_rates()
     c = {}
-    if k.get("valu_issue_share_at_4_cycles_per_instruction") and k.get("avg_launch_ms_kernel_trace"):
-        instr = k["valu_issue_share_at_4_cycles_per_instruction"] * k["avg_launch_ms_kernel_trace"] * 1e-3 * clk / 4.0 * simds
-        c["valu_issue_ms"] = instr / alg_prof * alg_run * 2.0 / (simds * clk) * 1e3
-    c["l1_divergent_loads_ms"] = (2.0 * nodes + 3.0 * tris) / steps / (rates["l1_hit_lane_loads_per_cu_cycle"] * cus * clk) * 1e3
-    if k.get("l2_requests_per_launch"):
-        c["l2_requests_ms"] = k["l2_requests_per_launch"] / alg_prof * alg_run / rates["l2_hit_records_per_s"] * 1e3
-    if k.get("read_requests_per_launch"):
-        c["lines_beyond_l2_ms"] = k["read_requests_per_launch"] / alg_prof * alg_run / rates["infinity_cache_lines_per_s"] * 1e3
-    out["ceilings_ms"] = {n: round(v, 1) for n, v in c.items()}
+    q = _valu_quad_cycles(k)
+    if q is not None:
+        cyc = 2.0 if kind == "trace" else 4.0
+        c["valu_issue_ms"] = q * cyc / (SIMDS * CLOCK_HZ) * 1e3 * scale
+    if k.get("lds_array_cycles_per_launch"):
+        c["lds_array_ms"] = k["lds_array_cycles_per_launch"] / (CUS * CLOCK_HZ) * 1e3 * scale
+    if k.get("l2_requests_per_launch") and rates:
+        c["l2_requests_ms"] = k["l2_requests_per_launch"] / rates["l2_hit_records_per_s"] * 1e3 * scale
+    if kind == "trace":
+        if k.get("read_requests_per_launch") and rates:
+            c["lines_beyond_l2_ms"] = k["read_requests_per_launch"] / rates["infinity_cache_lines_per_s"] * 1e3 * scale
+    elif k.get("hbm_bytes_per_launch") and copy_gbps:
+        c["memory_lines_ms"] = k["hbm_bytes_per_launch"] / (copy_gbps * 1e9) * 1e3 * scale
+    for name, v in (extra or {}).items():
+        c[name] = v
+    if not c or not measured_ms:
+        return None
     binding = max(c, key=c.get)
-    out["binding"] = binding
-    out["frac_of_binding_ceiling"] = round(c[binding] / (ms / steps), 3)
-    out["reading"] = ("each shared resource alone would need this long for the step's closest-hit traversal; the kernel takes `measured_ms` because the "
-                      "resources overlap imperfectly behind dependent fetches at the occupancy its registers allow (7 workgroups per CU)")
+    return {"measured_ms": round(measured_ms, 3), "ceilings_ms": {n: round(v, 3) for n, v in c.items()}, "binding": binding,
+            "frac_of_binding_ceiling": round(c[binding] / measured_ms, 3)}
+
+
+def _attach_physical(obj, k, copy_gbps):
+    """The physical picture of one kernel from its (fresh) traffic-file entry."""
+    if not k or not k.get("hbm_side_GBps"):
+        return
+    obj["physical_GBps"] = round(k["hbm_side_GBps"], 1)
+    obj["frac_physical_of_spec"] = round(k["hbm_side_GBps"] / PEAK_GBPS, 4)
+    obj["frac_physical_of_copy"] = round(k["hbm_side_GBps"] / copy_gbps, 4) if copy_gbps else None
+    for src_key, dst_key in (("valu_lane_utilisation", "lane_utilisation"), ("wait_any_share_of_wave_cycles", "wait_share"), ("l2_hit_rate", "l2_hit_rate")):
+        if k.get(src_key) is not None:
+            obj[dst_key] = round(k[src_key], 4)
+
+
+def roofline_objects(st, dt_total, copy_gbps, steps, closest_kernel="k_trace<0>", tag="C2", gen_bytes_per_sample=None, kernels_forced=False, pk=None,
+                     profile=None):
+    """The roofline objects of a run: the dominant kernel (per-lane closest-hit traversal), the camera rays' coherent kernel, shading,
+    the sampler.  `achieved` = ALGORITHMIC bytes / the kernel's HIP-event time against the 8 TB/s spec (SURVEY section 8(d));
+    next to it, when the committed profile belongs to this library: memory-side traffic, lane utilisation, and the ceilings.
+    profile: load_profile(tag) (the tests hand in their own)."""
+    pk = pk or {"rays": 0, "nodes": 0, "tris": 0, "launches": 0, "ms": 0.0}
+    alg_all_closest = 32.0 * st["closest_nodes"] + 48.0 * st["closest_tris"]
+    alg_pk = 32.0 * pk["nodes"] + 48.0 * pk["tris"]
+    alg = alg_all_closest - alg_pk  # the per-lane kernel alone: the camera rays' k_trace_pk gets its own object
+    launches = max(1, st["closest_launches"] - pk["launches"])
+    lane_ms = st["closest_ms"] - pk["ms"]
+    achieved = alg / max(lane_ms * 1e-3, 1e-12) / 1e9
+    all_alg = alg_all_closest + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
+    pname, prof, fresh = profile if profile is not None else load_profile(tag)
+    usable = fresh and not kernels_forced_mismatch(prof, closest_kernel)
+    stale = None if (usable or not pname) else ("profiles/%s: %s" % (pname, "taken with another library (kernel sources differ)" if not fresh else "another traversal kernel was profiled"))
+    roof = {"bound": "hbm", "kernel": closest_kernel, "achieved": round(achieved, 2), "peak": PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / PEAK_GBPS, 4), "saturated": bool(achieved / PEAK_GBPS > 1.0), "traffic": None,
+            "hbm_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
+            "alg_bytes_per_launch": round(alg / launches, 1), "avg_launch_ms": round(lane_ms / launches, 4), "launches": int(launches),
+            "job_alg_GBps": round(all_alg / dt_total / 1e9, 2), "job_alg_GBps_without_camera_kernel": round((all_alg - alg_pk) / dt_total / 1e9, 2),
+            "trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt_total, 4), "stale_profile": stale}
+    sb = shade_alg_bytes(st)
+    sa = sb / max(st["shade_ms"] * 1e-3, 1e-12) / 1e9
+    shade = {"bound": "hbm", "kernel": "k_shade_path (+ k_env under an environment map)", "achieved": round(sa, 2), "peak": PEAK_GBPS, "unit": "GB/s",
+             "frac": round(sa / PEAK_GBPS, 4), "traffic": None, "alg_bytes_per_item": round(sb / max(1, st["shade_items"]), 1),
+             "items": int(st["shade_items"]), "vertices": int(st["shade_vertices"]), "cont_rays": int(st["shade_cont"]), "mis_rays": int(st["shade_mis"]),
+             "shadow_rays": int(st["shade_shadow"]), "resolve_only_entries": int(st["shade_items"] - st["camera_samples"] - st["shade_cont"]),
+             "stale_profile": stale}
+    gen = None
+    if gen_bytes_per_sample and st.get("gen_ms"):
+        gb = gen_bytes_per_sample * st["camera_samples"]
+        ga = gb / max(st["gen_ms"] * 1e-3, 1e-12) / 1e9
+        gen = {"bound": "hbm", "kernel": "k_gen_samples_* + k_raygen", "achieved": round(ga, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(ga / PEAK_GBPS, 4),
+               "traffic": None, "alg_bytes_per_sample": round(gen_bytes_per_sample, 2), "stale_profile": stale}
+    cam = None
+    if pk["launches"]:
+        ca = alg_pk / max(pk["ms"] * 1e-3, 1e-12) / 1e9
+        cam = {"bound": "hbm", "kernel": "k_trace_pk", "achieved": round(ca, 2), "peak": PEAK_GBPS, "unit": "GB/s", "frac": round(ca / PEAK_GBPS, 4),
+               "saturated": bool(ca / PEAK_GBPS > 1.0), "traffic": None, "alg_bytes_per_launch": round(alg_pk / pk["launches"], 1),
+               "avg_launch_ms": round(pk["ms"] / pk["launches"], 4), "launches": int(pk["launches"]), "rays": int(pk["rays"]),
+               "node_visits_per_ray": round(pk["nodes"] / max(1, pk["rays"]), 2), "stale_profile": stale}
+    if usable:
+        # the dominant kernel: memory-side bytes per launch, the observed bound, the ceilings
+        k = _find_kernel(prof, closest_kernel, exact=True)
+        if k:
+            _attach_physical(roof, k, copy_gbps)
+            roof["traffic"] = float(k["hbm_bytes_per_launch"]) if k.get("hbm_bytes_per_launch") else None
+            if prof.get("alg_bytes_per_launch") and roof["traffic"]:
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / prof["alg_bytes_per_launch"], 3)
+                scale = (alg / launches) / prof["alg_bytes_per_launch"]
+                extra = {}
+                rates = machine_rates()
+                if rates:  # the per-CU L1's divergent-address path: two 16-byte lane loads per node visit, three per triangle test
+                    nodes, tris = st["closest_nodes"] - pk["nodes"], st["closest_tris"] - pk["tris"]
+                    extra["l1_divergent_loads_ms"] = (2.0 * nodes + 3.0 * tris) / launches / (rates["l1_hit_lane_loads_per_cu_cycle"] * CUS * CLOCK_HZ) * 1e3
+                roof["ceilings"] = ceilings(k, scale, lane_ms / launches, copy_gbps, "trace", extra)
+                if roof["ceilings"]:
+                    roof["bound"] = "latency" if roof["ceilings"]["frac_of_binding_ceiling"] < 0.8 else roof["ceilings"]["binding"].replace("_ms", "")
+            roof["profile"] = "profiles/" + pname
+        # shading and the sampler: every launch of the profiled run's kernels of that kind, per render, against this run's time per step
+        # (same config, same workload; the shading demand is scaled by the algorithmic bytes)
+        renders = float(prof.get("pmc_renders", 2.0))
+        ks = _find_kernel(prof, "k_shade_path")
+        if ks:
+            _attach_physical(shade, ks, copy_gbps)
+            sh = prof.get("shade") or {}
+            if sh.get("traffic_over_algorithmic"):
+                shade["traffic_over_algorithmic"] = round(sh["traffic_over_algorithmic"], 3)
+            tot, n_shade = per_render_totals(prof, ("k_shade_path", "k_env"), renders, count=("k_shade_path",))
+            scale = (sb / steps) / (sh["alg_bytes_per_launch"] * n_shade) if sh.get("alg_bytes_per_launch") and n_shade else 1.0
+            shade["ceilings"] = ceilings(tot, scale, st["shade_ms"] / steps, copy_gbps, "shade")
+            if shade["ceilings"]:
+                shade["ceilings"]["per"] = "step (all shading launches)"
+                shade["bound"] = shade["ceilings"]["binding"].replace("_ms", "") if shade["ceilings"]["frac_of_binding_ceiling"] >= 0.5 else "latency"
+        kg = _find_kernel(prof, "k_gen_samples")
+        if gen and kg:
+            _attach_physical(gen, kg, copy_gbps)
+            tot, _ = per_render_totals(prof, ("k_gen_", "k_raygen", "k_mark_alive", "k_sum_alive"), renders)
+            gen["ceilings"] = ceilings(tot, 1.0, st["gen_ms"] / steps, copy_gbps, "gen")
+            if gen["ceilings"]:
+                gen["ceilings"]["per"] = "step (all sampler / raygen launches)"
+                gen["bound"] = gen["ceilings"]["binding"].replace("_ms", "") if gen["ceilings"]["frac_of_binding_ceiling"] >= 0.5 else "lds-latency (the shuffle's serial chain)"
+        if cam:
+            kc = _find_kernel(prof, "k_trace_pk")
+            if kc:
+                _attach_physical(cam, kc, copy_gbps)
+                cam["traffic"] = float(kc["hbm_bytes_per_launch"]) if kc.get("hbm_bytes_per_launch") else None
+                cam["ceilings"] = ceilings(kc, 1.0, pk["ms"] / pk["launches"], copy_gbps, "shade")  # (full lane width, scalar loads: VALU at what it occupies)
+                if cam["ceilings"]:
+                    cam["bound"] = cam["ceilings"]["binding"].replace("_ms", "") if cam["ceilings"]["frac_of_binding_ceiling"] >= 0.5 else "scalar-load latency"
+    return roof, shade, gen, all_alg, cam, alg_pk
+
+
+def per_render_totals(prof, prefixes, renders, count=None):
+    """Counters of every profiled kernel whose name starts with one of `prefixes`, summed over the pass's launches, per render.
+    -> (totals keyed like a traffic-file entry, launches per render of the `count` prefixes)."""
+    keys = ("valu_active_quad_cycles_per_launch", "l2_requests_per_launch", "hbm_bytes_per_launch", "lds_array_cycles_per_launch", "read_requests_per_launch")
+    tot, n = {}, 0.0
+    for name, v in prof.get("kernels", {}).items():
+        base = name.split("::")[-1]
+        if not base.startswith(tuple(prefixes)):
+            continue
+        for key in keys:
+            val = _valu_quad_cycles(v) if key == "valu_active_quad_cycles_per_launch" else v.get(key)
+            if val is not None:
+                tot[key] = tot.get(key, 0.0) + val * v["dispatches_in_pmc_pass"] / renders
+        if count is None or base.startswith(tuple(count)):
+            n += v["dispatches_in_pmc_pass"] / renders
+    return tot, n
+
+
+def kernels_forced_mismatch(prof, closest_kernel):
+    """The profile's dominant kernel is another one than this run's (forced kernels, another pilot pick)."""
+    return bool(prof) and bool(prof.get("kernel")) and prof["kernel"].split("::")[-1] != closest_kernel
+
+
+def kernel_profile(tag, names, profile=None):
+    """Per traversal kernel of the line: lane utilisation, wait share, L2 hit rate, memory-side rate -- from the committed PMC passes
+    when they belong to this library; {"profiled": False} / {"stale_profile": file} otherwise."""
+    pname, prof, fresh = profile if profile is not None else load_profile(tag)
+    out = {}
+    for role, kname in names.items():
+        k = _find_kernel(prof, kname, exact=True) if prof else None
+        if not k:
+            out[role] = {"kernel": kname, "profiled": False}
+        elif not fresh:
+            out[role] = {"kernel": kname, "profiled": True, "stale_profile": "profiles/" + pname}
+        else:
+            out[role] = {"kernel": kname, "profiled": True, "source": "profiles/" + pname,
+                         "lane_utilisation": round(k["valu_lane_utilisation"], 4) if k.get("valu_lane_utilisation") is not None else None,
+                         "wait_share": round(k["wait_any_share_of_wave_cycles"], 4) if k.get("wait_any_share_of_wave_cycles") is not None else None,
+                         "l2_hit_rate": round(k["l2_hit_rate"], 4) if k.get("l2_hit_rate") is not None else None,
+                         "physical_GBps": round(k["hbm_side_GBps"], 1) if k.get("hbm_side_GBps") else None,
+                         "avg_launch_ms_serial": round(k["avg_launch_ms_kernel_trace"], 3) if k.get("avg_launch_ms_kernel_trace") else None}
     return out
-
-
-def occupancy_model(tag, kname):
-    """The fitted occupancy model of C2's k_trace<0> (profiles/r05_c2_occupancy_model.json: closest-hit ms per step against
-    workgroups per CU, w = 3..7): the additive form the earlier rounds quoted, its residual, and the two forms that fit better."""
-    if tag not in ("C2", "C3") or kname != "k_trace<0>":
-        return None
-    try:
-        m = json.load(open(os.path.join(ROOT, "profiles", "r05_c2_occupancy_model.json")))["scenes"]["big"]["closest"]
-    except (OSError, ValueError, KeyError):
-        return None
-    a = m["additive"]
-    return {"form": "closest_ms_per_step = a + b / w  (w = workgroups per CU; a: not hidden by more resident waves, b / w: exposed latency)",
-            "a_ms": a["a_ms"], "b_ms": a["b_ms"], "rms_ms": a["rms_ms"], "w": 7, "predicted_ms": round(a["a_ms"] + a["b_ms"] / 7.0, 1),
-            "better_fits": {"soft_max sqrt(a^2 + (b/w)^2)": m["soft_max"], "closed_queue (MVA: one server C, delay M)": m["closed_queue"]},
-            "what_a_is": "NOT Infinity-Cache bandwidth: a tree that fits one XCD's L2 (0.19x the bytes beyond L2) keeps 0.93x the intercept, which follows the node "
-                         "visits (0.87x); numerically it coincides with three separate ceilings of ~105 ms each (roofline.ceilings) -- VALU issue, the L1's "
-                         "divergent-load path and random lines beyond L2 -- none of which binds alone (MEASUREMENTS.md, round 5)",
-            "source": "profiles/r05_c2_occupancy_model.json (tools/r05_c2_intercept.sh, tools/fit_occupancy.py)"}
-
-
-def profiled_kernels(tag):
-    """Per-kernel entries of the newest committed traffic file of this config."""
-    for name in traffic_files(tag):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            d = json.load(open(path))
-            if "kernels" in d:
-                return {"kernels": d["kernels"], "source": "profiles/" + name, "trace_ratio": d.get("traffic_over_algorithmic"),
-                        "shade_ratio": (d.get("shade") or {}).get("traffic_over_algorithmic")}
-    return None
-
-
-def profiled_traffic(tag):
-    """HBM-side bytes per launch from committed rocprofv3 --pmc passes of the same command, labelled with the file
-    they come from (never presented as this run's measurement)."""
-    for name in traffic_files(tag) + (["r01_k_traffic.json"] if tag == "C2" else []):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            d = json.load(open(path))
-            return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "kernel": d.get("kernel"), "source": "profiles/" + name,
-                    "note": "separate rocprofv3 --pmc passes (TCC_EA0_RDREQ 32/64/128 B + WRITE_SIZE), not this run"}
-    return None
 
 
 LINE_LIMIT = 8000  # bytes: the driver keeps a bounded window of stdout (round 5's 26 KB line was not parsed)
@@ -723,11 +740,12 @@ class Run:
         knames = {"closest": {2: "k_trace<0>", 3: "k_trace3<0>", 5: "k_trace3c"}.get(picked[0], str(picked[0])),
                   "any_hit": {2: "k_trace<1>", 3: "k_trace3a"}.get(picked[1], str(picked[1]))}
         pk = self.dev.coherent_stats()
-        roof, shade, gen, all_alg, cam = roofline_objects(st, dt, copy.value, knames["closest"], self.cfg, gbs, kernels_forced=forced, pk=pk)
+        profile = load_profile(self.cfg)
+        if os.environ.get("DARTRAY_BATCH_BITS") or os.environ.get("DARTRAY_TRACE_WG_PER_CU"):
+            profile = (profile[0], profile[1], False)  # (launches of another size / occupancy than the profiled ones)
+        roof, shade, gen, all_alg, cam, alg_pk = roofline_objects(st, dt, copy.value, steps, knames["closest"], self.cfg, gbs, kernels_forced=forced, pk=pk, profile=profile)
         if gen:
             gen["blocks_generated_of_named"] = round(gen_share, 4)
-        roof["ceilings"] = trace_ceilings(self.cfg, knames["closest"], st, steps, pk)
-        roof["model"] = occupancy_model(self.cfg, knames["closest"])
         pilot = self.dev.pilot()
         near = []  # picks the calibration batches decided by less than 2 %
         pc, pa = pilot["closest"], pilot["any_hit"]
@@ -782,14 +800,17 @@ class Run:
             "roofline_camera": cam,
             # per traversal kernel of this line, from the committed PMC passes of the same command (not this run): where the lanes and
             # the wave-cycles go -- the figures that move when a traversal kernel gets better or worse
-            "trace_kernels_profiled": kernel_profile(self.cfg, knames),
+            "trace_kernels_profiled": kernel_profile(self.cfg, knames, profile),
             "kernel_ms_per_step": dict({k: round(st[k] / steps, 2) for k in ("closest_ms", "any_ms", "shade_ms", "gen_ms", "film_ms", "total_ms")},
                                        note="a stage's any-hit launch runs beside its closest-hit launch (second stream): any_ms is its time "
                                             "after the closest-hit launch ended" if os.environ.get("DARTRAY_OVERLAP_ANY", "1") != "0" else "one kernel at a time"),
             "per_sample": {"rays": round((st["closest_rays"] + st["any_rays"]) / max(1, st["camera_samples"]), 3),
                            "nodes": round((st["closest_nodes"] + st["any_nodes"]) / max(1, st["camera_samples"]), 2),
                            "tris": round((st["closest_tris"] + st["any_tris"]) / max(1, st["camera_samples"]), 3),
-                           "alg_bytes": round(all_alg / max(1, st["camera_samples"]) + 148 + 32, 1)},
+                           # (148 B of sample vector + 32 B of film per sample on top of the traversal bytes)  the reference-count figure prices every
+                           # node visit of every ray at 32 B; k_trace_pk loads a node once per WAVE: the second figure leaves its never-requested bytes out
+                           "alg_bytes": round(all_alg / max(1, st["camera_samples"]) + 148 + 32, 1),
+                           "alg_bytes_without_camera_kernel": round((all_alg - alg_pk) / max(1, st["camera_samples"]) + 148 + 32, 1)},
             "first_render_ms": round(first_ms, 1),
             "second_render_ms": round(second_ms, 1),
             "pilot_ms": round(pilot_ms, 1),
@@ -820,14 +841,6 @@ class Run:
             out["reduce_ms"] = round(reduce_ms, 3)
             out["film_bytes_reduced_per_step"] = int(self.H * self.W * 16)
             out["one_gpu_same_workload"] = one_gpu_reference(self.mode, self.cfg)
-        tp = profiled_traffic(self.cfg)
-        if tp and world == 1 and not os.environ.get("DARTRAY_BATCH_BITS"):
-            out["traffic_profiled"] = tp
-            # roofline.traffic: the memory-side bytes per launch of the SAME kernel from the committed --pmc passes of this command (counters
-            # cannot be read inside a timed run: the guide's separate passes) -- null when the passes profiled another kernel than this run ran
-            if tp.get("kernel") and tp.get("hbm_bytes_per_launch") and out["roofline"].get("kernel", "").startswith(tp["kernel"].split("::")[-1] + " "):
-                out["roofline"]["traffic"] = float(tp["hbm_bytes_per_launch"])
-                out["roofline"]["traffic_source"] = "%s (%s)" % (tp["source"], tp["note"])
         return out
 
 

@@ -16,6 +16,21 @@ import os
 import re
 import sys
 
+# The sources whose text decides what a kernel does (bench.py compares their hashes with the running library's before it prints a
+# figure derived from a traffic file: profiles of another library are "stale_profile", not numbers).
+KERNEL_SOURCES = ("dr_trace.hip", "dr_kernels.hip", "dr_device.h", "dr_kernels.h", "dr_wave.h", "dr_rng.h")
+
+
+def library_sources(src, rnd):
+    """sha256 of the kernel sources of the library the passes profiled: OUTDIR/buildinfo.json (copied there by the profile script)
+    or profiles/<round>_buildinfo.json.  None for rounds that did not record it (r01-r05)."""
+    for name in ("buildinfo.json", "%s_buildinfo.json" % rnd):
+        p = os.path.join(src, name)
+        if os.path.exists(p):
+            have = json.load(open(p)).get("sources", {})
+            return {k: have[k] for k in KERNEL_SOURCES if k in have}
+    return None
+
 
 def parse_pmc(path):
     """{kernel: {"dispatches": n, counter: per-dispatch value}} of one pmc_summary.py text."""
@@ -55,19 +70,27 @@ def build(src, cfg, rnd):
         p = first("pmc_%s_%s.txt" % (cfg, kind), "%s_pmc_%s_%s.txt" % (rnd, cfg, kind))
         return (parse_pmc(p), p) if p else ({}, None)
 
-    (rd, rdp), (wr, wrp), (sq, sqp), (tcc, tccp) = pmc("rdreq"), pmc("wrreq"), pmc("sq"), pmc("tcc")
+    (rd, rdp), (wr, wrp), (sq, sqp), (tcc, tccp), (lds, ldsp) = pmc("rdreq"), pmc("wrreq"), pmc("sq"), pmc("tcc"), pmc("lds")
     if not rd or not wr:
         raise SystemExit("missing pmc_%s_rdreq / wrreq under %s" % (cfg, src))
     statsp = first("%s_kernel_stats_serial.csv" % cfg, "%s_%s_kernel_stats_serial.csv" % (rnd, cfg), "%s_kernel_stats.csv" % cfg,
                    "%s_%s_kernel_stats.csv" % (rnd, cfg))
     stats = {r["Name"]: r for r in csv.DictReader(open(statsp))}
     benchp = first("%s_bench.json" % cfg, "%s_%s_bench_under_rocprof.json" % (rnd, cfg))
-    bench = json.loads(open(benchp).read().strip().splitlines()[-1])
+    text = open(benchp).read().strip()
+    try:
+        bench = json.loads(text)  # round 6: the full result (sidecar), one JSON document
+    except ValueError:
+        bench = json.loads(text.splitlines()[-1])  # rounds 1-5: the last line of the log
     res = {"workload": bench["config"]["workload"], "bench_value_under_rocprof": bench["value"], "kernels": {}}
+    srcs = library_sources(src, rnd)
+    if srcs:
+        res["library_sources"] = srcs
+    res["pmc_renders"] = 3.0 if rnd >= "r06" else 2.0  # renders of a PMC pass (`--steps 1 --warmup 0`): the first, (r06: the second,) one step
     for name in rd:
         if not is_ours(name):
             continue
-        r, w, s, t = rd[name], wr.get(name, {}), sq.get(name, {}), tcc.get(name, {})
+        r, w, s, t, l = rd[name], wr.get(name, {}), sq.get(name, {}), tcc.get(name, {}), lds.get(name, {})
         reads = r.get("TCC_EA0_RDREQ_128B", 0) * 128 + r.get("TCC_EA0_RDREQ_64B", 0) * 64 + r.get("TCC_EA0_RDREQ_32B", 0) * 32
         writes = w.get("WRITE_SIZE", 0) * 1024
         # the stats file prints full signatures: match on the name in front of the argument list
@@ -85,6 +108,18 @@ def build(src, cfg, rnd):
             e["valu_issue_share_at_4_cycles_per_instruction"] = cycles / (avg_ms * 1e-3 * 2.4e9) if avg_ms else None
             e["valu_lane_utilisation"] = s["SQ_THREAD_CYCLES_VALU"] / (s["SQ_INSTS_VALU"] * 64)
             e["wait_any_share_of_wave_cycles"] = s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"] if s.get("SQ_WAVE_CYCLES") else None
+        if s and s.get("SQ_ACTIVE_INST_VALU") is not None:
+            e["valu_active_quad_cycles_per_launch"] = s["SQ_ACTIVE_INST_VALU"]  # x 4 cycles / (1024 SIMDs x clock) = the VALU's own time
+            e["valu_instructions_per_launch"] = s.get("SQ_INSTS_VALU")
+        if l and l.get("SQ_INSTS_LDS") is not None:
+            # LDS: instructions, issue quad-cycles, array cycles (all CUs summed), conflict cycles (MI355X_MICROARCH.md: SQ_LDS_IDX_ACTIVE = all
+            # LDS-array cycles, SQ_LDS_BANK_CONFLICT = the extra ones)
+            e["lds_instructions_per_launch"] = l["SQ_INSTS_LDS"]
+            e["lds_active_quad_cycles_per_launch"] = l.get("SQ_ACTIVE_INST_LDS")
+            e["lds_array_cycles_per_launch"] = l.get("SQ_LDS_IDX_ACTIVE")
+            e["lds_bank_conflict_cycles_per_launch"] = l.get("SQ_LDS_BANK_CONFLICT")
+            e["lds_issue_stall_quad_cycles_per_launch"] = l.get("SQ_WAIT_INST_LDS")
+            e["waves_per_launch"] = l.get("SQ_WAVES")
         if t and t.get("TCC_REQ_sum"):
             e["l2_requests_per_launch"] = t["TCC_REQ_sum"]
             e["l2_hit_rate"] = t["TCC_HIT_sum"] / max(1.0, t["TCC_HIT_sum"] + t["TCC_MISS_sum"])
@@ -100,7 +135,8 @@ def build(src, cfg, rnd):
     rs = bench.get("roofline_shade")
     if rs and rs.get("items"):
         launches = sum(v["dispatches_in_pmc_pass"] for k, v in res["kernels"].items() if base(k).startswith("k_shade_path"))
-        steps, pmc_renders = bench["steps"], 2.0  # the PMC pass: --steps 1 --warmup 0 = the first render + one step
+        # the PMC pass: --steps 1 --warmup 0 = the first render + one step (since round 6: + the second render bench.py times on its own)
+        steps, pmc_renders = bench["steps"], (3.0 if rnd >= "r06" else 2.0)
         per_render_launches = launches / pmc_renders
         alg = rs["items"] * rs["alg_bytes_per_item"] / steps / max(1.0, per_render_launches)
         phys = sum(v["hbm_bytes_per_launch"] * v["dispatches_in_pmc_pass"] for k, v in res["kernels"].items()
@@ -114,12 +150,12 @@ def build(src, cfg, rnd):
     if rnd >= "r05" and tk:
         res["trace_kernels"] = {"closest": tk["closest"], "any_hit": tk["any_hit"]}
         res["method"] = ("tools/profile_%s.sh: a dry run of the bench command reads what this config's pilot picks on the box (closest-hit %s, any-hit %s), "
-                         "then rocprofv3 --pmc passes (counters only, one group per pass) on `DARTRAY_PILOT=0 DARTRAY_STATE_LAYOUT=<picked> python3 bench.py %s"
-                         "--trace-kernels <picked> --steps 1 --warmup 0 --no-cpu-baseline --no-extra` (two full renders, every launch a full-size launch of "
+                         "then rocprofv3 --pmc passes (counters only, one group per pass) on `DARTRAY_PILOT=0 DARTRAY_STATE_LAYOUT=<picked> [r06: DARTRAY_BATCH_BITS=28] python3 bench.py %s"
+                         "--trace-kernels <picked> --steps 1 --warmup 0 --no-cpu-baseline --no-extra` (two -- r06: three -- full renders, every launch a full-size launch of "
                          "those kernels); launch times from the --kernel-trace --stats run of the same script (DARTRAY_OVERLAP_ANY=0).  Counters sit on the "
                          "L2's memory side, so Infinity-Cache hits are included: an upper bound on HBM bytes."
                          % (rnd, tk["closest"], tk["any_hit"], "" if cfg == "c2" else "--config %s " % cfg.upper()))
-    res["sources"] = ["profiles/%s_pmc_%s_%s.txt" % (rnd, cfg, k) for k, p in (("rdreq", rdp), ("wrreq", wrp), ("sq", sqp), ("tcc", tccp)) if p] + \
+    res["sources"] = ["profiles/%s_pmc_%s_%s.txt" % (rnd, cfg, k) for k, p in (("rdreq", rdp), ("wrreq", wrp), ("sq", sqp), ("tcc", tccp), ("lds", ldsp)) if p] + \
                      ["profiles/%s_%s" % (rnd, os.path.basename(statsp).replace(rnd + "_", ""))]
     return res
 

@@ -64,7 +64,8 @@ PY
   kern="${pick%% *}"; lay="${pick##* }"
   echo "$cfg: pilot picked kernels $kern, state layout $lay" | tee "$out/${cfg}_picked.txt"
   grep -h "traversal pilot\|state-layout pilot" "$out/${cfg}_dry.err" >> "$out/${cfg}_picked.txt"
-  e="DARTRAY_PILOT=0 DARTRAY_STATE_LAYOUT=$lay"
+  # (DARTRAY_BATCH_BITS=28: the scene's first render too goes in full-size batches, so that every launch of a pass is one)
+  e="DARTRAY_PILOT=0 DARTRAY_STATE_LAYOUT=$lay DARTRAY_BATCH_BITS=28"
   a="$a --trace-kernels $kern"
   if [ "$what" != pmc ]; then
     stats ${cfg} "$e" "$a $s $X"
