@@ -86,6 +86,7 @@ def lib():
         l.orc_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         l.orc_intersect_brute.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         l.orc_sample_floats.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.orc_order_study.argtypes = [C.c_int, C.c_void_p]
         l.orc_resample_pow2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         l.orc_render.argtypes = [C.c_void_p, C.POINTER(OrcRenderDesc), C.c_void_p, C.c_void_p, C.POINTER(OrcRecord)]
         l.orc_li_samples.argtypes = [C.c_void_p, C.POINTER(OrcRenderDesc), C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
@@ -130,6 +131,15 @@ def make_rays(o, d, tmin=0.0, tmax=np.inf):
     r["tmin"] = tmin
     r["tmax"] = tmax
     return r
+
+
+def order_study(enable=None):
+    """Measurement only (oracle: OrderStudy): enable True / False starts (and resets) / stops counting; returns the counts so far."""
+    out = (C.c_ulonglong * 11)()
+    lib().orc_order_study(-1 if enable is None else int(bool(enable)), out)
+    keys = ("rays", "occluded", "nodes_all", "tris_all", "nodes_occ_ref", "tris_occ_ref", "nodes_occ_far_first", "tris_occ_far_first",
+            "nodes_occ_larger_area_first", "tris_occ_larger_area_first", "ideal_nodes_occ")
+    return dict(zip(keys, (int(v) for v in out)))
 
 
 def resample_pow2(texels):

@@ -27,6 +27,7 @@
 // All citations are relative to /root/reference/lib/.
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -1277,7 +1278,111 @@ static bool bvh_intersect(const Scene& sc, Ray& ray, Isect* isect) {  // bvh_acc
   return hit;
 }
 
+// ---------------------------------------------------------------------------
+// Measurement only (orc_order_study; MEASUREMENTS.md round 6): BVHAccel.intersectP never modifies the ray (bvh_accel.dart:167-226), so a
+// leaf is reached iff its ancestors' slab tests pass, whatever order the children are taken in -- the BOOLEAN does not depend on the
+// order, only the work of a ray that finds an occluder does (it returns at the first one).  For every any-hit ray of a render this counts
+// the node visits / triangle tests of (0) the reference order (near child by the split axis' direction sign), (1) the far child first,
+// (2) the child with the larger surface area first, and a lower bound no order can beat: the shallowest occluding leaf's depth + 1.
+// It touches none of the counters the parity tests compare.
+// ---------------------------------------------------------------------------
+struct OrderStudy {
+  std::atomic<uint64_t> rays{0}, occluded{0}, nodesAll{0}, trisAll{0};
+  std::atomic<uint64_t> nodesOcc[3], trisOcc[3];
+  std::atomic<uint64_t> idealNodesOcc{0};
+  void reset() {
+    rays = occluded = nodesAll = trisAll = idealNodesOcc = 0;
+    for (int k = 0; k < 3; ++k) nodesOcc[k] = trisOcc[k] = 0;
+  }
+};
+static OrderStudy g_study;
+static std::atomic<int> g_studyOn{0};
+static inline bool slab(const LinearNode& n, const Ray& ray, const V& invDir, const int dirIsNeg[3]);
+static bool tri_intersectP(const V& p1, const V& p2, const V& p3, const Ray& ray);
+static bool study_leaf(const Scene& sc, const LinearNode& node, const Ray& ray, uint64_t* tris) {
+  for (int i = 0; i < node.nPrimitives; ++i) {
+    ++*tris;
+    const Prim& pr = sc.prims[node.offset + i];
+    if (pr.quadric >= 0) {
+      if (quadric_intersect(sc.quadrics[pr.quadric], ray, nullptr, nullptr, nullptr)) return true;
+    } else if (tri_intersectP(sc.vert(pr.v[0]), sc.vert(pr.v[1]), sc.vert(pr.v[2]), ray)) {
+      return true;
+    }
+  }
+  return false;
+}
+static bool study_walk(const Scene& sc, const Ray& ray, int mode, uint64_t* nodes, uint64_t* tris) {
+  V invDir = vec(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+  int dirIsNeg[3] = {invDir.x < 0 ? 1 : 0, invDir.y < 0 ? 1 : 0, invDir.z < 0 ? 1 : 0};
+  auto area = [](const LinearNode& n) {
+    D dx = n.bmax.x - n.bmin.x, dy = n.bmax.y - n.bmin.y, dz = n.bmax.z - n.bmin.z;
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+  };
+  std::vector<uint32_t> todo;
+  uint32_t nodeNum = 0;
+  for (;;) {
+    const LinearNode& node = sc.nodes[nodeNum];
+    ++*nodes;
+    bool pop = true;
+    if (slab(node, ray, invDir, dirIsNeg)) {
+      if (node.nPrimitives > 0) {
+        if (study_leaf(sc, node, ray, tris)) return true;
+      } else {
+        uint32_t first = nodeNum + 1, second = node.offset;  // the reference: second child first when the ray runs against the axis
+        bool swap = dirIsNeg[node.axis] != 0;
+        if (mode == 1) swap = !swap;
+        else if (mode == 2) swap = area(sc.nodes[second]) > area(sc.nodes[first]);
+        if (swap) std::swap(first, second);
+        todo.push_back(second);
+        nodeNum = first;
+        pop = false;
+      }
+    }
+    if (pop) {
+      if (todo.empty()) return false;
+      nodeNum = todo.back();
+      todo.pop_back();
+    }
+  }
+}
+static uint64_t study_ideal(const Scene& sc, const Ray& ray) {  // depth + 1 of the shallowest leaf that holds an occluder (0: none)
+  V invDir = vec(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+  int dirIsNeg[3] = {invDir.x < 0 ? 1 : 0, invDir.y < 0 ? 1 : 0, invDir.z < 0 ? 1 : 0};
+  std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 1u}};
+  uint64_t best = 0, dummy = 0;
+  while (!todo.empty()) {
+    auto [n, depth] = todo.back();
+    todo.pop_back();
+    if (best && depth >= best) continue;
+    const LinearNode& node = sc.nodes[n];
+    if (!slab(node, ray, invDir, dirIsNeg)) continue;
+    if (node.nPrimitives > 0) {
+      if (study_leaf(sc, node, ray, &dummy)) best = depth;
+    } else {
+      todo.push_back({n + 1, depth + 1});
+      todo.push_back({node.offset, depth + 1});
+    }
+  }
+  return best;
+}
+static void study_ray(const Scene& sc, const Ray& ray) {
+  uint64_t n[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+  const bool occ = study_walk(sc, ray, 0, &n[0], &t[0]);
+  g_study.rays++;
+  g_study.nodesAll += n[0];
+  g_study.trisAll += t[0];
+  if (!occ) return;  // a ray that finds nothing visits the same nodes in every order
+  g_study.occluded++;
+  for (int m = 1; m < 3; ++m) (void)study_walk(sc, ray, m, &n[m], &t[m]);
+  for (int m = 0; m < 3; ++m) {
+    g_study.nodesOcc[m] += n[m];
+    g_study.trisOcc[m] += t[m];
+  }
+  g_study.idealNodesOcc += study_ideal(sc, ray);
+}
+
 static bool bvh_intersectP(const Scene& sc, const Ray& ray) {  // bvh_accel.dart:167-226
+  if (g_studyOn.load(std::memory_order_relaxed) && !sc.nodes.empty()) study_ray(sc, ray);
   t_ctr.any_rays++;
   if (sc.nodes.empty()) return false;
   V invDir = vec(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
@@ -2675,6 +2780,22 @@ void orc_intersect_brute(void* h, const OrcRay* rays, int64_t n, OrcHit* out, in
       }
     }
   }
+}
+
+// Measurement only: see OrderStudy.  enable != 0 resets and starts counting; out (may be null): rays, occluded, nodes of all rays (reference
+// order), triangle tests of all rays, then for the occluded rays nodes / tris under orders 0 (reference), 1 (far first), 2 (larger area
+// first), and the lower bound (sum of depth + 1 of the shallowest occluding leaf).
+int orc_order_study(int enable, unsigned long long out[11]) {
+  if (out) {
+    out[0] = g_study.rays; out[1] = g_study.occluded; out[2] = g_study.nodesAll; out[3] = g_study.trisAll;
+    for (int m = 0; m < 3; ++m) { out[4 + 2 * m] = g_study.nodesOcc[m]; out[5 + 2 * m] = g_study.trisOcc[m]; }
+    out[10] = g_study.idealNodesOcc;
+  }
+  if (enable >= 0) {
+    if (enable) g_study.reset();
+    g_studyOn = enable ? 1 : 0;
+  }
+  return 0;
 }
 
 // MIPMap.texture's resampling branch alone (mipmap.dart:71-138): out must hold RoundUpPow2(w) * RoundUpPow2(h) * 3 floats
