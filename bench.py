@@ -439,7 +439,8 @@ def compact_line(d, detail_path=None):
     lay = c.get("state_layout", "")
     line["config"] = {"workload": c.get("workload"), "triangles": c.get("triangles"), "bvh_nodes": c.get("bvh_nodes"),
                       "samples_per_step": c.get("samples_per_step"), "parallelism": c.get("parallelism"),
-                      "kernels": {k: tk.get(k) for k in ("closest", "any_hit", "camera_rays")},
+                      "kernels": {k: tk.get(k) for k in ("closest", "any_hit", "camera_rays")}, "kernel_ids": tk.get("ids"),
+                      "any_hit_far_child_first": tk.get("any_hit_far_child_first"),
                       "kernels_forced": bool(str(tk.get("picked_by", "")).startswith("--trace-kernels")),
                       "state_layout": 4 if str(lay).startswith("four-slot") else 64,
                       "sampler": str(c.get("sampler_mode", "")).split(" ")[0] or None}
@@ -738,7 +739,8 @@ class Run:
         gbs = gen_alg_bytes_per_sample(gen_blocks(self.renderer, self.scene) * gen_share, self.spp)
         forced = bool(getattr(args, "trace_kernels", None)) or bool(os.environ.get("DARTRAY_TRACE_IMPL"))
         knames = {"closest": {2: "k_trace<0>", 3: "k_trace3<0>", 5: "k_trace3c"}.get(picked[0], str(picked[0])),
-                  "any_hit": {2: "k_trace<1>", 3: "k_trace3a"}.get(picked[1], str(picked[1]))}
+                  "any_hit": {2: "k_trace<1>", 3: "k_trace3a", 6: "k_trace<1>", 7: "k_trace3a"}.get(picked[1], str(picked[1]))}
+        far_first = picked[1] in (6, 7)  # the any-hit rays take the far child first (the boolean of intersectP does not depend on the order)
         pk = self.dev.coherent_stats()
         profile = load_profile(self.cfg)
         if os.environ.get("DARTRAY_BATCH_BITS") or os.environ.get("DARTRAY_TRACE_WG_PER_CU"):
@@ -782,7 +784,9 @@ class Run:
                           NAMES[self.cfg], self.renderer.surfaceIntegrator.maxDepth, self.res, self.res, self.spp),
                        "triangles": int(len(agg.tri_idx)), "bvh_nodes": int(len(agg.nodes)),
                        "bvh_builder": "%s (dr_bvh_build_%s), %.0f ms" % (agg.builder, "device" if agg.builder == "device" else "mixed", agg.build_ms),
-                       "trace_kernels": {"closest": knames["closest"], "any_hit": knames["any_hit"],
+                       "trace_kernels": {"closest": knames["closest"], "any_hit": knames["any_hit"], "any_hit_far_child_first": far_first,
+                                         "ids": [int(picked[0]), int(picked[1])],
+                                         "pilot_far_first_over_reference_order_per_ray": round(pilot.get("far_first", 0.0), 4),
                                          "camera_rays": "k_trace_pk" if pk["launches"] else knames["closest"],
                                          "picked_by": ("--trace-kernels / DARTRAY_TRACE_IMPL" if forced else
                                                        "the scene's pilot batches (closest-hit: best time per algorithmic byte, a pair kernel needs 5 %; any-hit: "

@@ -649,8 +649,8 @@ class _DeviceScene:
         return int(lay.value), float(dens.value)
 
     def trace_kernels(self, kernels=None):
-        """Get (closest, any-hit) traversal kernels of this scene (0 = not measured yet), or set them (2 / 3; (0, 0)
-        makes the next big render measure again)."""
+        """Get (closest, any-hit) traversal kernels of this scene (0 = not measured yet), or set them (2 / 3, closest-hit also 5,
+        any-hit also 6 / 7 = 2 / 3 with the far child first; (0, 0) makes the next big render measure again)."""
         arr = (C.c_uint32 * 2)(*(kernels or (0, 0)))
         if kernels is not None:
             _abi.check(_abi.lib().dr_scene_set_trace_kernels(self.handle, C.byref(arr)))
@@ -688,7 +688,8 @@ class _DeviceScene:
         (0.0 = that candidate was not timed)."""
         arr = (C.c_float * 6)()
         _abi.check(_abi.lib().dr_scene_get_pilot(self.handle, C.byref(arr)))
-        return {"closest": {2: float(arr[0]), 3: float(arr[1]), 5: float(arr[2])}, "any_hit": {2: float(arr[3]), 3: float(arr[4])}}
+        return {"closest": {2: float(arr[0]), 3: float(arr[1]), 5: float(arr[2])}, "any_hit": {2: float(arr[3]), 3: float(arr[4])},
+                "far_first": float(arr[5])}  # any-hit rays: far child first over the reference order, time per ray (0 = not measured)
 
 
 class Scene:

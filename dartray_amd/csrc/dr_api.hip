@@ -145,6 +145,7 @@ struct DrScene {
   int stateLayout = 0;          // path-state layout of this scene's path renders: 0 = not measured yet, 64 / 4 (LayoutOps)
   float layoutDensity = -1.f;   //   what decided it: the share of a pilot batch's slots still alive at the second bounce
   float calibMs[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // pilot of dr_render_device: [closest / any][v2 / v3 / v3c] ms
+  float calibFarFirst = 0.f;  // any-hit rays, far child first over the reference order: time per ray of k_trace<1> in the pilot's first two batches (0 = not measured)
   float calibPerGB[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  //   the same as ms per algorithmic GB (what the choice compares; 0 = not measured)
   // what the last dr_render_device call actually ran with (dr_scene_last_render_info): state layout, the traversal kernels of
   // its last batch, a reserved word (-1), calibration batches, workgroups per CU
@@ -1250,6 +1251,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       TRY_SC(hipMemcpy(sc->dlStages.p, stages.data(), stages.size() * sizeof(DirectStage), hipMemcpyHostToDevice));
   }
   sc->d.traceKernel[0] = sc->d.traceKernel[1] = 0;
+  sc->d.anyFarFirst = 0;
   *out = sc;
   return DR_OK;
 #undef TRY_SC
@@ -1275,7 +1277,7 @@ int dr_scene_get_pilot(const DrScene* sc, float out[6]) {
   for (int c = 0; c < 3; ++c) out[c] = sc->calibPerGB[0][c];
   out[3] = sc->calibPerGB[1][0];
   out[4] = sc->calibPerGB[1][1];
-  out[5] = 0.f;
+  out[5] = sc->calibFarFirst;
   return DR_OK;
 }
 
@@ -1287,9 +1289,9 @@ int dr_scene_set_trace_kernels(DrScene* sc, const uint32_t in[2]) {
     return DR_OK;
   }
   for (int k = 0; k < 2; ++k) {
-    if (in[k] != 2u && in[k] != 3u && !(k == 0 && in[k] == 5u))
-      return fail(DR_ERR_INVALID, "trace kernel must be 2 or 3 (closest-hit rays also 5; or 0, 0 to measure again)");
-    if (in[k] != 2u && (!sc->d.pairs || sc->d.nquads)) return fail(DR_ERR_UNSUPPORTED, "this scene cannot use the sibling-pair kernels");
+    if (in[k] != 2u && in[k] != 3u && !(k == 0 && in[k] == 5u) && !(k == 1 && (in[k] == 6u || in[k] == 7u)))
+      return fail(DR_ERR_INVALID, "trace kernel must be 2 or 3 (closest-hit rays also 5, any-hit rays also 6 / 7 = 2 / 3 far child first; or 0, 0 to measure again)");
+    if (in[k] != 2u && in[k] != 6u && (!sc->d.pairs || sc->d.nquads)) return fail(DR_ERR_UNSUPPORTED, "this scene cannot use the sibling-pair kernels");
   }
   sc->d.traceKernel[0] = in[0];
   sc->d.traceKernel[1] = in[1];
@@ -2007,6 +2009,8 @@ struct PilotResult {
   int setsRun = 0;
   double perByte[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};  // [closest / any][k_trace / k_trace3 / k_trace3c]: ms per algorithmic GB
   float ms[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  // any-hit rays of the first two batches, both through k_trace<1>: batch 0 far child first, batch 1 in the reference order
+  double anyMsPerRayFar = 0.0, anyMsPerRayRef = 0.0;
 };
 
 // The choice, from the calibration batches' times per algorithmic byte.
@@ -2036,6 +2040,16 @@ void pickTraceKernels(DrScene* sc, const PilotResult& R) {
   const double own = pairFamily ? perByte[1][1] : perByte[1][0], other = pairFamily ? perByte[1][0] : perByte[1][1];
   const bool cross = other > 0.0 && own > 0.0 && other < 0.85 * own;
   sc->d.traceKernel[1] = (pairFamily != cross) ? 3u : 2u;
+  // ... and their visit ORDER (round 6): intersectP's boolean does not depend on it (bvh_accel.dart:167-226 never touches the ray), the work
+  // of a ray that finds an occluder does.  The pilot's first batch -- the cache warm-up -- ran its any-hit rays far child first, the second
+  // in the reference order, both through k_trace<1>: where the far child first is cheaper per ray even in the cold batch (ratio below
+  // 0.97), the scene's any-hit rays take it -- in whichever kernel family they run (the order is a property of the rays and the tree).
+  // Measured at full size, kernels forced (profiles/r06_far_first_ab.txt): C5 (the courtyard under the sky: 42 % of the shadow rays are
+  // occluded and visit 35 % fewer nodes) any-hit 505.8 -> 398.9 ms, 1180 -> 1254 Msamples/s; C2 96.8 -> 93.1 ms and C4 101.0 -> 98.2 ms
+  // although their occluded rays visit 11 - 13 % MORE nodes that way -- they test 3 - 4 % fewer triangles, and an f64 triangle test costs
+  // several node visits.  Pilot ratios of the same boxes: C5 0.62, C2 0.90, C4 0.94.
+  sc->calibFarFirst = R.anyMsPerRayRef > 0.0 ? (float)(R.anyMsPerRayFar / R.anyMsPerRayRef) : 0.f;
+  if (R.anyMsPerRayRef > 0.0 && R.anyMsPerRayFar > 0.0 && R.anyMsPerRayFar < 0.97 * R.anyMsPerRayRef) sc->d.traceKernel[1] = sc->d.traceKernel[1] == 3u ? 7u : 6u;
   sc->traceCalibrated = true;
 }
 
@@ -2064,7 +2078,7 @@ int runPilot(RenderPlan& P, PilotResult& R) {
     const int col = set == 2 ? 1 : (set == 3 ? 2 : 0);
     if (P.calibrateTrace) {
       sc->d.traceKernel[0] = (uint32_t)impl;
-      sc->d.traceKernel[1] = impl == 5 ? 3u : (uint32_t)impl;
+      sc->d.traceKernel[1] = impl == 5 ? 3u : (set == 0 ? 6u : (uint32_t)impl);  // (the warm-up batch: k_trace<1> far child first, see pickTraceKernels)
     }
     TraceCounters c0, c1;
     int prc = readCtr(&c0);
@@ -2085,6 +2099,16 @@ int runPilot(RenderPlan& P, PilotResult& R) {
       if (dr_opt("DARTRAY_VERBOSE"))
         fprintf(stderr, "dartray_hip: state-layout pilot: %.3f of a batch's slots alive at the second bounce -> %s\n", sc->layoutDensity,
                 sc->stateLayout == 4 ? "four-slot line-grouped sub-tiles (sp4)" : "64-slot runs");
+    }
+    if (P.calibrateTrace && set <= 1) {  // any-hit time per ray, far child first (batch 0) against the reference order (batch 1)
+      float sum = 0.f;
+      for (auto& e : pt.ev[1]) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e.first, e.second);
+        sum += t;
+      }
+      const double rays = (double)(c1.any_rays - c0.any_rays);
+      (set == 0 ? R.anyMsPerRayFar : R.anyMsPerRayRef) = rays > 0.0 ? (double)sum / rays : 0.0;
     }
     if (set == 0 || !P.calibrateTrace) continue;
     // the per-lane kernels' own work: the batch's totals without what k_trace_pk traced of them (the camera rays)
@@ -2107,8 +2131,8 @@ int runPilot(RenderPlan& P, PilotResult& R) {
   sc->traceEvents.push_back({evP0, evP1, 5});  // DrRenderStats.pilot_ms: the time of the calibration batches
   if (P.calibrateTrace && dr_opt("DARTRAY_VERBOSE"))
     fprintf(stderr, "dartray_hip: traversal pilot (%d x %zu samples, rendered into the film), ms per algorithmic GB of the per-lane kernels: closest v2 %.4f / v3 %.4f / v3c %.4f -> v%u; "
-            "any hit v2 %.4f / v3 %.4f -> v%u\n", R.setsRun, P.calibPix * (size_t)P.spp, R.perByte[0][0], R.perByte[0][1], R.perByte[0][2], sc->d.traceKernel[0],
-            R.perByte[1][0], R.perByte[1][1], sc->d.traceKernel[1]);
+            "any hit v2 %.4f / v3 %.4f, far child first / reference order per ray %.3f -> v%u\n", R.setsRun, P.calibPix * (size_t)P.spp, R.perByte[0][0], R.perByte[0][1], R.perByte[0][2], sc->d.traceKernel[0],
+            R.perByte[1][0], R.perByte[1][1], sc->calibFarFirst, sc->d.traceKernel[1]);
   return DR_OK;
 }
 

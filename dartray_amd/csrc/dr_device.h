@@ -130,7 +130,11 @@ struct DScene {
   uint32_t npairs;
   uint32_t topPairs;    // pair order "top:T" (dr_scene_create): pairs [0, topPairs) are the top T levels of the tree, breadth-first;
                         // every sub-tree below them is one contiguous, depth-first run of records.  0: another order
-  uint32_t padTop;
+  // Any-hit rays only (set per launch by launch_trace / launch_intersect from the kernel id: 6 / 7): take the FAR child first.
+  // BVHAccel.intersectP never modifies the ray (bvh_accel.dart:167-226): a leaf is reached iff its ancestors' slab tests pass, in
+  // whatever order the children are taken, so the boolean is the reference's; only the work of a ray that finds an occluder depends
+  // on the order (MEASUREMENTS.md round 6: C5 any-hit -21 %, C2 / C4 -3 ... -4 %; the pilot decides per scene).
+  uint32_t anyFarFirst;
   const uint4* nodes;   // 2 x uint4 per node (DrBvhNode)
   const float4* tris;   // 3 x float4 per primitive
   // Shading record of a triangle, 32 B (2 x float4), for scenes of plain triangles with matte materials (the !QUAD

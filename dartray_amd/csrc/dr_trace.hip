@@ -538,7 +538,8 @@ DR_DEV void trace_persistent(const DScene& sc, const IO& io, uint32_t n, uint32_
           pop = false;
         } else {
           const uint32_t axis = (b.w >> 16) & 0xffu;
-          const bool neg = (axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz)) < 0.f;  // dirIsNeg[axis]
+          // dirIsNeg[axis]; any-hit rays of a far-child-first launch take the other child first (DScene.anyFarFirst: the boolean does not depend on it)
+          const bool neg = ((axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz)) < 0.f) != (ANY && sc.anyFarFirst != 0u);
           const uint32_t far = neg ? node + 1 : b.z;  // bvh_accel.dart:147-153
           node = neg ? b.z : node + 1;
           if (sp < STACK) lds[sp * DR_TRACE_BLOCK] = far;
@@ -1228,7 +1229,7 @@ DR_DEV void trace_pairs_any(const DScene& sc, const IO& io, uint32_t n, uint32_t
     if (mode == M_EXPAND) {
       const uint32_t axis = (cur >> 29) & 3u;
       const float iv = axis == 0 ? ray.ivx : (axis == 1 ? ray.ivy : ray.ivz);
-      const uint32_t nearHalf = iv < 0.f ? 2u : 0u;
+      const uint32_t nearHalf = ((iv < 0.f) != (sc.anyFarFirst != 0u)) ? 2u : 0u;  // (far child first: DScene.anyFarFirst)
       const uint4* pp = (const uint4*)((const char*)sc.pairs + ((size_t)(cur & 0x1fffffffu) << 6));
       n0 = pp[nearHalf], n1 = pp[nearHalf + 1u], f0 = pp[2u - nearHalf], f1 = pp[3u - nearHalf];
     }
@@ -1465,24 +1466,32 @@ __global__ void __launch_bounds__(DR_TRACE_BLOCK, DR_PK_WG_PER_CU) k_trace_pk(DS
 // launchers.  DARTRAY_TRACE_IMPL selects the kernel for A/B runs: 2 = k_trace, 3 = sibling pairs, 5 = 3 with k_trace3c.
 // ---------------------------------------------------------------------------
 // Kernel ids (DScene.traceKernel, DARTRAY_TRACE_IMPL, dr_scene_set_trace_kernels): 2 k_trace, 3 sibling pairs (k_trace3<0> /
-// k_trace3a), 5 sibling pairs with the closest-hit rays' cold state in LDS (k_trace3c; the any-hit rays: k_trace3a as with 3).  Returned
-// here: 2 / 3, with `*cold` set for id 5 on closest-hit rays.
-static int traceImpl(const DScene& sc, int anyHit, int force = 0, bool* cold = nullptr) {
-  const char e = dr_opt("DARTRAY_TRACE_IMPL").first();  // (read per launch: dr_set_option may change it between renders)
-  const int env = (e == '2' || e == '3' || e == '5') ? e - '0' : 0;
+// k_trace3a), 5 sibling pairs with the closest-hit rays' cold state in LDS (k_trace3c; the any-hit rays: k_trace3a as with 3); any-hit
+// rays only: 6 = 2 and 7 = 3 with the far child first (DScene.anyFarFirst; DARTRAY_TRACE_IMPL: a trailing 'f', e.g. 5f).  Returned
+// here: 2 / 3, with `*cold` set for id 5 on closest-hit rays and `*farFirst` for ids 6 / 7.
+static int traceImpl(const DScene& sc, int anyHit, int force = 0, bool* cold = nullptr, bool* farFirst = nullptr) {
+  const DrOpt eo = dr_opt("DARTRAY_TRACE_IMPL");  // (read per launch: dr_set_option may change it between renders)
+  const char e = eo.first();
+  int env = (e == '2' || e == '3' || e == '5') ? e - '0' : 0;
+  if (env && anyHit && eo.value.size() > 1 && eo.value[1] == 'f') env = env == 2 ? 6 : 7;
   // v2 is the fastest on cache-resident trees, v3 (sibling pairs) on big incoherent ones (MEASUREMENTS.md):
   // unless DARTRAY_TRACE_IMPL fixes it, the choice is the one measured for this scene (sc.traceKernel, set by the
   // pilot of dr_render_device)
   int impl = force ? force : (env ? env : (sc.traceKernel[anyHit ? 1 : 0] ? (int)sc.traceKernel[anyHit ? 1 : 0] : 2));
   if (cold) *cold = !anyHit && impl == 5;
-  if (impl == 5) impl = 3;
+  if (farFirst) *farFirst = anyHit && (impl == 6 || impl == 7);
+  if (impl == 5 || impl == 7) impl = 3;
+  if (impl == 6) impl = 2;
   if (sc.nquads) return 2;                     // only v2 tests quadric primitives
   return (impl == 3 && !sc.pairs) ? 2 : impl;  // scenes the pair layout cannot encode use v2
 }
-void launch_intersect(const DScene& sc, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
+void launch_intersect(const DScene& scIn, const DrRay* rays, int64_t n, DrHit* out, int anyHit, uint32_t* spill,
                       uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s, int forceImpl) {
   const dim3 g(grid), b(DR_TRACE_BLOCK);
-  const int impl = traceImpl(sc, anyHit, forceImpl);
+  bool farFirst = false;
+  const int impl = traceImpl(scIn, anyHit, forceImpl, nullptr, &farFirst);
+  DScene sc = scIn;
+  sc.anyFarFirst = farFirst ? 1u : 0u;
   if (impl == 3) {
     if (anyHit) hipLaunchKernelGGL(k_intersect3a, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
     else hipLaunchKernelGGL(k_intersect3<0>, g, b, 0, s, sc, rays, (uint32_t)n, out, spill, workCounter, ctr);
@@ -1501,14 +1510,17 @@ bool launch_trace_coherent(const DScene& sc, const BatchState& st, const uint32_
   return true;
 }
 int trace_kernel_id(const DScene& sc, int anyHit) {
-  bool cold = false;
-  const int impl = traceImpl(sc, anyHit, 0, &cold);
+  bool cold = false, farFirst = false;
+  const int impl = traceImpl(sc, anyHit, 0, &cold, &farFirst);
+  if (farFirst) return impl == 3 ? 7 : 6;
   return impl == 3 && cold ? 5 : impl;
 }
-void launch_trace(const DScene& sc, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
+void launch_trace(const DScene& scIn, const BatchState& st, const uint32_t* queue, const uint32_t* nQueue, int anyHit,
                   uint32_t* spill, uint32_t* workCounter, TraceCounters* ctr, int grid, hipStream_t s) {
-  bool cold = false;
-  const int impl = traceImpl(sc, anyHit, 0, &cold);
+  bool cold = false, farFirst = false;
+  const int impl = traceImpl(scIn, anyHit, 0, &cold, &farFirst);
+  DScene sc = scIn;
+  sc.anyFarFirst = farFirst ? 1u : 0u;
   if (impl == 3) grid = std::min(grid, traceGridFor(anyHit ? DR_TRACE3A_WAVES : (cold ? DR_TRACE3C_WAVES : DR_TRACE3_WAVES)));  // k_trace3: 30 KiB of LDS, 5 resident; k_trace3a: 22 KiB, 7; k_trace3c: 26 KiB, 6
   else if (!(impl == 2 && !sc.nquads)) grid = std::min(grid, traceGridFor(6));  // only k_trace fits 7 workgroups per CU
   const dim3 g(grid), b(DR_TRACE_BLOCK);

@@ -330,10 +330,10 @@ int dr_scene_set_trace_kernels(DrScene* scene, const uint32_t kernels[2]);
 int dr_scene_get_pilot(const DrScene* scene, float ms_per_gb_out[6]);
 /* Diagnostics: what the scene's LAST dr_render_device call actually ran with, switches (dr_set_option / environment)
  * included -- out[0] path-state layout (64 / 4), out[1] / out[2] the traversal kernel of its closest-hit / any-hit launches
- * (1, 2, 3, 5 as above; 4 = the treelet-parked traversal), out[3] the treelet parking rounds (-1 otherwise), out[4] the
+ * (2, 3, 5 as above), out[3] reserved (-1), out[4] the
  * calibration batches it ran (0: no pilot), out[5] its batches, out[6] workgroups per CU of a persistent traversal
  * launch, out[7] bit 0: a stage's any-hit launch ran beside its closest-hit launch, bit 1: the camera rays went through the
- * wave-coherent kernel (k_trace_pk), bit 2: so did the camera vertices' shadow rays, bit 3: the device sampler generated bounce b's blocks only for the pixel
+ * wave-coherent kernel (k_trace_pk), bit 3: the device sampler generated bounce b's blocks only for the pixel
  * groups alive at bounce b (DARTRAY_LAZY_GEN).  All 0 / -1 before the first render. */
 int dr_scene_last_render_info(const DrScene* scene, int32_t info_out[8]);
 /* Diagnostics: the part of DrRenderStats' closest-hit totals (closest_rays / _nodes / _tris / _launches / _ms, accumulated since the last
@@ -457,27 +457,25 @@ int32_t dr_abi_version(void);
  * needs no setenv in a long-lived foreign host.  name: with or without the DARTRAY_ prefix, any case; value NULL: back
  * to the environment's value; "": unset for this process.  Unknown names are DR_ERR_INVALID.  The film never depends on a
  * switch, with one stated exception: the switches pick between bit-exact variants of a kernel, a layout or a schedule, or
- * print diagnostics.  The exception is the sampler FORM: FLOAT_SAMPLES and the GEN_* switches choose how the device LD
- * sampler stores / draws the same keyed streams -- bit-exact by test (tests/test_gpu_render.py), but they are variants of
- * the sampler, not of a schedule.  The switches:
- *   TRACE_IMPL 1|2|3|5|4  traversal kernel for both ray kinds (default: the scene's measured choice; 5 = the pair kernels with the
- *                         closest-hit rays' cold state in LDS; 4 = treelet-parked); ANY8, CLOSEST_COLD: A/B variants of the pair kernels
- *   TRACE_WG_PER_CU n     workgroups of a persistent traversal launch per CU
- *   STATE_LAYOUT 64|4     path-state layout (default: picked per render from the pilot's stage-list densities)
- *   LAYOUT_PILOT 0        do not measure list densities; take the layout from the scene's lights as round 3 did
- *   BATCH_BITS b          at most 2^b camera samples per batch (16..28)
- *   PIPELINES 1|2, OVERLAP_ANY 0|1, PILOT 0|1, PILOT_FORCE, PILOT_BITS b   scheduling of a render's launches
- *   PAIR_ORDER ...        memory order of the sibling-pair records (read by dr_scene_create)
- *   TREELET_ROUNDS n, TREELET_SHARDS n, TREELET_MIN n   the treelet-parked traversal (TRACE_IMPL=4; MEASUREMENTS.md, round 4)
- *   SCENE_PREP host, GEN_PREPASS 0   dr_scene_create's checks on the host; no burn-in pre-pass above 256 spp
+ * print diagnostics.  The exception is the sampler: LAZY_GEN and the GEN_* switches choose when and how the device LD
+ * sampler draws the same keyed streams -- bit-exact by test (tests/test_gpu_render.py, test_gpu_options.py), but they are
+ * variants of the sampler, not of a schedule.  The fifteen switches (round 6; the A/B switches of measured negatives left the library with their
+ * code: experiments/r06_*.diff):
+ *   TRACE_IMPL 2|3|5      traversal kernels for both ray kinds: 2 = k_trace<0/1>, 3 = the sibling-pair kernels k_trace3<0> / k_trace3a,
+ *                         5 = 3 with the closest-hit rays' cold state in LDS (k_trace3c); default: the scene's measured choice
+ *   TRACE_WG_PER_CU n     workgroups of a persistent traversal launch per CU (occupancy sweeps)
+ *   STATE_LAYOUT 64|4     path-state layout (default: picked per scene from the pilot's stage-list densities)
+ *   BATCH_BITS b          at most 2^b camera samples per batch (16..28; default 27 for a scene's first big render, 28 afterwards)
+ *   OVERLAP_ANY 0         a stage's any-hit launch after its closest-hit launch instead of beside it
+ *   PILOT 0|force         no calibration batches / calibration batches also on renders too small to need them (tests)
  *   COHERENT_CAMERA 0     the camera rays through the per-lane traversal kernels like every other ray (default: the wave-coherent k_trace_pk)
- *   COHERENT_SHADOW 1     the camera vertices' shadow rays through k_trace_pk too (a measured negative, kept for A/B: default off)
- *   SPLIT_WG a,b          a stage's closest-hit / any-hit launches with a / b workgroups per CU from the start (a measured negative)
  *   LAZY_GEN 0            the device sampler shuffles every LD block for every pixel up front (default: bounce b's blocks only for the
  *                         64-pixel groups that still have a path alive at bounce b)
- *   GEN_SLOW_DRAWS, GEN_ALL_BLOCKS, GEN_LANES n, GEN_ONE_WAVE, FLOAT_SAMPLES, LDS_LIGHTS 0   A/B variants of the sampler / shade kernels
- *   BUILD_THREADS n, BUILD_DEBUG   the BVH builders;  RCCL_LIB path   librccl to bind;  STAGE_COUNTS 1|2 (per stage: list lengths and kernel times; 2: also
- *                         the node visits / triangle tests of each stage's traversals, waiting for the device after every stage), VERBOSE   diagnostics */
+ *   GEN_ALL_BLOCKS 1      ... and also the blocks no kernel reads;  GEN_SLOW_DRAWS 1   every generator step through Random.nextInt's retry loop
+ *   SCENE_PREP host       dr_scene_create's tree checks and pair records by the serial host loops (the reference the device code is tested against)
+ *   BUILD_THREADS n       threads of the host BVH builder;  RCCL_LIB path   the librccl to bind
+ *   STAGE_COUNTS 1|2      per stage: list lengths and kernel times (2: also the node visits / triangle tests of each stage's traversals,
+ *                         waiting for the device after every stage);  VERBOSE 1|2   what the library decided (2: + the BVH builders' timings) */
 int dr_set_option(const char* name, const char* value);
 
 

@@ -193,6 +193,10 @@ typedef _SetOptionD = int Function(Pointer<Utf8>, Pointer<Utf8>);
 typedef _SetLayoutC = Int32 Function(Pointer<Void>, Int32);
 typedef _SetLayoutD = int Function(Pointer<Void>, int);
 typedef _CommVoidD = int Function();
+typedef _KernelsC = Int32 Function(Pointer<Void>, Pointer<Uint32>);
+typedef _KernelsD = int Function(Pointer<Void>, Pointer<Uint32>);
+typedef _GetLayoutC = Int32 Function(Pointer<Void>, Pointer<Int32>, Pointer<Float>);
+typedef _GetLayoutD = int Function(Pointer<Void>, Pointer<Int32>, Pointer<Float>);
 typedef _DestroyC = Void Function(Pointer<Void>);
 typedef _DestroyD = void Function(Pointer<Void>);
 typedef _ErrC = Pointer<Utf8> Function();
@@ -255,6 +259,51 @@ class HipSamplerRenderer extends Renderer {
   static final _CommVoidD _commAvailable = _lib.lookupFunction<_CommVoidC, _CommVoidD>('dr_comm_available');
   static final _SetOptionD _setOption = _lib.lookupFunction<_SetOptionC, _SetOptionD>('dr_set_option');
   static final _SetLayoutD _setStateLayout = _lib.lookupFunction<_SetLayoutC, _SetLayoutD>('dr_scene_set_state_layout');
+  static final _GetLayoutD _getStateLayout = _lib.lookupFunction<_GetLayoutC, _GetLayoutD>('dr_scene_get_state_layout');
+  static final _KernelsD _getTraceKernels = _lib.lookupFunction<_KernelsC, _KernelsD>('dr_scene_get_trace_kernels');
+  static final _KernelsD _setTraceKernels = _lib.lookupFunction<_KernelsC, _KernelsD>('dr_scene_set_trace_kernels');
+
+  /// What the library's pilot picked for a scene: [closest-hit kernel, any-hit kernel, state layout] (include/dartray_hip.h:
+  /// dr_scene_get_trace_kernels / dr_scene_get_state_layout).  A render of a big scene measures them on its first batches; a host
+  /// that renders the same scene again (animation frames: this renderer builds a device scene per render, like the reference's
+  /// isolates load the scene per task) or a manager that knows rank 0's picks hands them in through [pilotPicks] and the render
+  /// runs no calibration batches -- and, on N GPUs, every rank runs the same kernels (a step is the slowest rank's: the Python
+  /// host's dartray_amd/dist.py share_pilot does the same over its control plane).  Every kernel and layout is bit-exact: the
+  /// image does not depend on them.  [lastPilotPicks] is what the last render of this renderer ended up with.
+  List<int> pilotPicks;
+  List<int> lastPilotPicks;
+
+  void _applyPilotPicks(Pointer<Void> scene) {
+    if (pilotPicks == null || pilotPicks.length != 3) {
+      return;
+    }
+    if (pilotPicks[0] != 0 && pilotPicks[1] != 0) {
+      Pointer<Uint32> k = calloc<Uint32>(2);
+      try {
+        k[0] = pilotPicks[0];
+        k[1] = pilotPicks[1];
+        _check(_setTraceKernels(scene, k));
+      } finally {
+        calloc.free(k);
+      }
+    }
+    if (pilotPicks[2] != 0) {
+      _check(_setStateLayout(scene, pilotPicks[2]));
+    }
+  }
+
+  void _readPilotPicks(Pointer<Void> scene) {
+    Pointer<Uint32> k = calloc<Uint32>(2);
+    Pointer<Int32> lay = calloc<Int32>(1);
+    try {
+      _check(_getTraceKernels(scene, k));
+      _check(_getStateLayout(scene, lay, nullptr));
+      lastPilotPicks = [k[0], k[1], lay[0]];
+    } finally {
+      calloc.free(k);
+      calloc.free(lay);
+    }
+  }
 
   /// Can this process join a multi-GPU render?  Binds librccl and checks its version WITHOUT talking to another rank, so
   /// that the workers can agree on it before anyone blocks in [commInit] (hip_render_manager.dart).
@@ -666,6 +715,7 @@ class HipSamplerRenderer extends Renderer {
         sd.u32(OFF_DrSceneDesc_nmesh_xforms, xformMeshes.length);
       }
       _check(_sceneCreate(sd.ptr, handle));
+      _applyPilotPicks(handle.value);
 
       // ---- DrRenderDesc: camera, film, integrator, sampler, task (sampler_renderer.dart:29-31,36-65) ----
       _Blob rd = new _Blob(SIZEOF_DrRenderDesc);
@@ -749,6 +799,7 @@ class HipSamplerRenderer extends Renderer {
       } else {
         _check(_render(handle.value, rd.ptr, lxyzw, rgb));
       }
+      _readPilotPicks(handle.value);
       OutputImage out = new OutputImage(film.left, film.top, film.width, film.height,
                                         film.xResolution, film.yResolution,
                                         new Float32List.fromList(rgb.asTypedList(3 * npix)));

@@ -140,7 +140,10 @@ def test_pilot_reports_what_it_measured_and_any_hit_follows_the_closest_hit_fami
         "assert info['pilot_batches'] == 4 or p['closest'][3] > 1.05 * p['closest'][2]\n"
         "own, other = (p['any_hit'][3], p['any_hit'][2]) if k[0] != 2 else (p['any_hit'][2], p['any_hit'][3])\n"
         "family = 3 if k[0] != 2 else 2\n"
-        "assert k[1] == (family if not other < 0.85 * own else 5 - family), (k, p)\n"
+        # the any-hit rays' visit order: far child first (ids 6 / 7 = 2 / 3) iff the pilot's first batch was cheaper per ray that way (ratio below 0.97)
+        "far = k[1] in (6, 7); base = k[1] - 4 if far else k[1]\n"
+        "assert base == (family if not other < 0.85 * own else 5 - family), (k, p)\n"
+        "assert p['far_first'] > 0 and far == (p['far_first'] < 0.97), (k, p)\n"
         "assert (info['closest_kernel'], info['any_hit_kernel']) == k\n"
         "b = r.render(scene).film; assert dev.last_render_info()['pilot_batches'] == 0 and np.array_equal(a, b)\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))

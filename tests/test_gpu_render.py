@@ -328,6 +328,47 @@ def test_alternative_traversal_kernels_are_bit_exact_too(impl):
     assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
 
 
+@pytest.mark.parametrize("kernels", [(2, 6), (3, 7), (5, 7), (2, 7)])
+def test_any_hit_rays_far_child_first(ob, gpu, kernels):
+    """BVHAccel.intersectP never modifies the ray (bvh_accel.dart:167-226): a leaf is reached iff its ancestors' slab tests pass, in
+    whatever order the children are taken -- the boolean is the reference's in every order, only the work of a ray that FINDS an
+    occluder changes.  Kernel ids 6 / 7 run the any-hit rays through k_trace<1> / k_trace3a with the far child first: the film must be
+    the oracle's bit for bit, the closest-hit counters and the ray counts too, and the any-hit node visits / triangle tests must equal
+    what the oracle counts for the SAME order (its order study walks every shadow ray of the render far child first as well)."""
+    prims, mk = scenes.config("C2", xres=40, yres=40, spp=16, blob=(60, 30))
+    r = mk()
+    scene = scenes.make_scene(prims)
+    dev = scene._device()
+    assert dev.trace_kernels(kernels) == kernels
+    out = r.render(scene)
+    info = dev.last_render_info()
+    assert (info["closest_kernel"], info["any_hit_kernel"]) == kernels, info
+    st = r.last_stats
+    osc = ob.OracleScene(prims)
+    osc.counters(reset=True)
+    ob.order_study(True)
+    ref = osc.render(ob.render_desc(r, sampler_mode=1))
+    study = ob.order_study(False)
+    c = osc.counters()
+    assert np.array_equal(out.film, ref["film"]) and np.array_equal(out.rgb, ref["rgb"])
+    for k in ("closest_rays", "any_rays", "closest_nodes", "closest_tris"):
+        assert st[k] == c[k], k
+    assert study["rays"] == c["any_rays"] and study["nodes_all"] == c["any_nodes"] and study["tris_all"] == c["any_tris"]  # the study's reference walk IS intersectP
+    assert st["any_nodes"] == study["nodes_all"] - study["nodes_occ_ref"] + study["nodes_occ_far_first"]
+    assert st["any_tris"] == study["tris_all"] - study["tris_occ_ref"] + study["tris_occ_far_first"]
+    assert st["any_nodes"] != c["any_nodes"] and 0 < study["occluded"] < study["rays"]
+    # Aggregate.intersectP on caller-supplied rays (dr_intersect): the same booleans in either order
+    rng = np.random.default_rng(5)
+    o = rng.uniform(-9, 9, (20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    far = dev.intersect(core.Ray(o, d, 1e-3, 25.0), any_hit=True)["prim"]
+    dev.trace_kernels((kernels[0], 2 if kernels[1] == 6 else 3))
+    assert np.array_equal(far, dev.intersect(core.Ray(o, d, 1e-3, 25.0), any_hit=True)["prim"]) and (far >= 0).any() and (far < 0).any()
+    with pytest.raises(_abi.DartRayHipError):
+        dev.trace_kernels((6, 2))   # the order is a property of any-hit rays only
+
+
 def test_traversal_pilot_leaves_results_and_counters_untouched():
     """The first big render of a big scene times both traversal kernels on a sample of its own rays
     (dr_render_device's pilot) before rendering; forced here on a small scene: film and visit counters must equal
@@ -345,7 +386,12 @@ def test_traversal_pilot_leaves_results_and_counters_untouched():
         "osc = ob.OracleScene(prims); osc.counters(reset=True)\n"
         "ref = osc.render(ob.render_desc(r, sampler_mode=1)); c = osc.counters(); st = r.last_stats\n"
         "assert np.array_equal(out.film, ref['film']) and np.array_equal(out2.film, ref['film'])\n"
-        "assert all(st[k] == c[k] for k in ('closest_nodes', 'any_nodes', 'closest_tris', 'any_tris', 'closest_rays', 'any_rays')), (st, c)\n"
+        # (the pilot's first batch runs its any-hit rays far child first, and the scene may keep that order: the any-hit visits of rays that
+        # find an occluder then differ from the reference order's, nothing else does)
+        "assert all(st[k] == c[k] for k in ('closest_nodes', 'closest_tris', 'closest_rays', 'any_rays')), (st, c)\n"
+        "far = scene._device().trace_kernels()[1] in (6, 7)\n"
+        "scene._device().trace_kernels((scene._device().trace_kernels()[0], 2)); out3 = r.render(scene); st3 = r.last_stats\n"
+        "assert np.array_equal(out3.film, ref['film']) and all(st3[k] == c[k] for k in ('closest_nodes', 'any_nodes', 'closest_tris', 'any_tris', 'closest_rays', 'any_rays')), (st3, c)\n"
         "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
     env = dict(os.environ, DARTRAY_PILOT="force", DARTRAY_VERBOSE="1")
     env.pop("DARTRAY_TRACE_IMPL", None)

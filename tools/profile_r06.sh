@@ -53,9 +53,7 @@ for cfg in $cfgs; do
   pick=$(python3 - "$out/${cfg}_dry.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-k = d["config"]["kernels"]
-c = {"k_trace<0>": 2, "k_trace3<0>": 3, "k_trace3c": 5}[k["closest"]]
-a = {"k_trace<1>": 2, "k_trace3a": 3}[k["any_hit"]]
+c, a = d["config"]["kernel_ids"]
 print("%d,%d %d" % (c, a, d["config"]["state_layout"]))
 PY
 )
