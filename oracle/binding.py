@@ -135,10 +135,12 @@ def make_rays(o, d, tmin=0.0, tmax=np.inf):
 
 def order_study(enable=None):
     """Measurement only (oracle: OrderStudy): enable True / False starts (and resets) / stops counting; returns the counts so far."""
-    out = (C.c_ulonglong * 11)()
+    out = (C.c_ulonglong * 17)()
     lib().orc_order_study(-1 if enable is None else int(bool(enable)), out)
     keys = ("rays", "occluded", "nodes_all", "tris_all", "nodes_occ_ref", "tris_occ_ref", "nodes_occ_far_first", "tris_occ_far_first",
-            "nodes_occ_larger_area_first", "tris_occ_larger_area_first", "ideal_nodes_occ")
+            "nodes_occ_larger_area_first", "tris_occ_larger_area_first", "ideal_nodes_occ", "nodes_occ_longer_interval_first",
+            "tris_occ_longer_interval_first", "nodes_occ_leaf_then_far_first", "tris_occ_leaf_then_far_first", "nodes_occ_smaller_area_first",
+            "tris_occ_smaller_area_first")
     return dict(zip(keys, (int(v) for v in out)))
 
 

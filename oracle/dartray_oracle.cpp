@@ -1288,11 +1288,11 @@ static bool bvh_intersect(const Scene& sc, Ray& ray, Isect* isect) {  // bvh_acc
 // ---------------------------------------------------------------------------
 struct OrderStudy {
   std::atomic<uint64_t> rays{0}, occluded{0}, nodesAll{0}, trisAll{0};
-  std::atomic<uint64_t> nodesOcc[3], trisOcc[3];
+  std::atomic<uint64_t> nodesOcc[6], trisOcc[6];
   std::atomic<uint64_t> idealNodesOcc{0};
   void reset() {
     rays = occluded = nodesAll = trisAll = idealNodesOcc = 0;
-    for (int k = 0; k < 3; ++k) nodesOcc[k] = trisOcc[k] = 0;
+    for (int k = 0; k < 6; ++k) nodesOcc[k] = trisOcc[k] = 0;
   }
 };
 static OrderStudy g_study;
@@ -1332,6 +1332,26 @@ static bool study_walk(const Scene& sc, const Ray& ray, int mode, uint64_t* node
         bool swap = dirIsNeg[node.axis] != 0;
         if (mode == 1) swap = !swap;
         else if (mode == 2) swap = area(sc.nodes[second]) > area(sc.nodes[first]);
+        else if (mode >= 3) {
+          // experiments: the child the ray spends the LONGER parameter interval in first (3); a leaf child first, else far first (4);
+          // the smaller-area child first (5)
+          auto span = [&](const LinearNode& c) {
+            D t0 = ray.mint, t1 = ray.maxt;
+            const D o[3] = {ray.o.x, ray.o.y, ray.o.z}, iv[3] = {invDir.x, invDir.y, invDir.z};
+            const D lo[3] = {c.bmin.x, c.bmin.y, c.bmin.z}, hi[3] = {c.bmax.x, c.bmax.y, c.bmax.z};
+            for (int a = 0; a < 3; ++a) {
+              D ta = (lo[a] - o[a]) * iv[a], tb = (hi[a] - o[a]) * iv[a];
+              if (ta > tb) std::swap(ta, tb);
+              if (ta > t0) t0 = ta;
+              if (tb < t1) t1 = tb;
+            }
+            return t1 - t0;  // negative: missed
+          };
+          const bool farSwap = !(dirIsNeg[node.axis] != 0);
+          if (mode == 3) { D a = span(sc.nodes[first]), b = span(sc.nodes[second]); swap = (a == b) ? farSwap : (b > a); }
+          else if (mode == 4) { bool l1 = sc.nodes[first].nPrimitives > 0, l2 = sc.nodes[second].nPrimitives > 0; swap = (l1 != l2) ? l2 : farSwap; }
+          else swap = area(sc.nodes[second]) < area(sc.nodes[first]);
+        }
         if (swap) std::swap(first, second);
         todo.push_back(second);
         nodeNum = first;
@@ -1366,15 +1386,15 @@ static uint64_t study_ideal(const Scene& sc, const Ray& ray) {  // depth + 1 of 
   return best;
 }
 static void study_ray(const Scene& sc, const Ray& ray) {
-  uint64_t n[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+  uint64_t n[6] = {0, 0, 0, 0, 0, 0}, t[6] = {0, 0, 0, 0, 0, 0};
   const bool occ = study_walk(sc, ray, 0, &n[0], &t[0]);
   g_study.rays++;
   g_study.nodesAll += n[0];
   g_study.trisAll += t[0];
   if (!occ) return;  // a ray that finds nothing visits the same nodes in every order
   g_study.occluded++;
-  for (int m = 1; m < 3; ++m) (void)study_walk(sc, ray, m, &n[m], &t[m]);
-  for (int m = 0; m < 3; ++m) {
+  for (int m = 1; m < 6; ++m) (void)study_walk(sc, ray, m, &n[m], &t[m]);
+  for (int m = 0; m < 6; ++m) {
     g_study.nodesOcc[m] += n[m];
     g_study.trisOcc[m] += t[m];
   }
@@ -2784,12 +2804,14 @@ void orc_intersect_brute(void* h, const OrcRay* rays, int64_t n, OrcHit* out, in
 
 // Measurement only: see OrderStudy.  enable != 0 resets and starts counting; out (may be null): rays, occluded, nodes of all rays (reference
 // order), triangle tests of all rays, then for the occluded rays nodes / tris under orders 0 (reference), 1 (far first), 2 (larger area
-// first), and the lower bound (sum of depth + 1 of the shallowest occluding leaf).
-int orc_order_study(int enable, unsigned long long out[11]) {
+// first), the lower bound (sum of depth + 1 of the shallowest occluding leaf), then orders 3 (longer ray interval first), 4 (leaf child
+// first, else far first), 5 (smaller area first).
+int orc_order_study(int enable, unsigned long long out[17]) {
   if (out) {
     out[0] = g_study.rays; out[1] = g_study.occluded; out[2] = g_study.nodesAll; out[3] = g_study.trisAll;
     for (int m = 0; m < 3; ++m) { out[4 + 2 * m] = g_study.nodesOcc[m]; out[5 + 2 * m] = g_study.trisOcc[m]; }
     out[10] = g_study.idealNodesOcc;
+    for (int m = 3; m < 6; ++m) { out[11 + 2 * (m - 3)] = g_study.nodesOcc[m]; out[12 + 2 * (m - 3)] = g_study.trisOcc[m]; }
   }
   if (enable >= 0) {
     if (enable) g_study.reset();

@@ -44,15 +44,23 @@ def main():
     s = ob.order_study(False)
     b = lambda n, t: 32.0 * n + 48.0 * t
     all_b = b(s["nodes_all"], s["tris_all"])
-    occ = {k: b(s["nodes_occ_" + k], s["tris_occ_" + k]) for k in ("ref", "far_first", "larger_area_first")}
+    orders = ("ref", "far_first", "larger_area_first", "longer_interval_first", "leaf_then_far_first", "smaller_area_first")
+    occ = {k: b(s["nodes_occ_" + k], s["tris_occ_" + k]) for k in orders}
+    # a cost in node visits: the f64 triangle test weighs ~16 node visits (fitted on the GPU's any-hit times of C2, far child first
+    # against the reference order: profiles/r06_far_first_ab.txt)
+    W = 16.0
+    cost_all = s["nodes_all"] + W * s["tris_all"]
+    cost = {k: s["nodes_occ_" + k] + W * s["tris_occ_" + k] for k in orders}
     out = {"config": cfg, "pixels": int(len(px)), "spp": spp, "oracle_build_s": round(t_build, 1), "render_s": round(dt, 1), **s,
            "occluded_share_of_rays": round(s["occluded"] / max(1, s["rays"]), 4),
            "occluded_share_of_any_hit_node_visits": round(s["nodes_occ_ref"] / max(1, s["nodes_all"]), 4),
            "occluded_share_of_any_hit_alg_bytes": round(occ["ref"] / max(1.0, all_b), 4),
-           "node_visits_per_occluded_ray": {k: round(s["nodes_occ_" + k] / max(1, s["occluded"]), 2) for k in ("ref", "far_first", "larger_area_first")},
+           "node_visits_per_occluded_ray": {k: round(s["nodes_occ_" + k] / max(1, s["occluded"]), 2) for k in orders},
+           "triangle_tests_per_occluded_ray": {k: round(s["tris_occ_" + k] / max(1, s["occluded"]), 3) for k in orders},
+           "saving_of_all_any_hit_cost_at_16_visits_per_triangle_test": {k: round((cost["ref"] - cost[k]) / max(1.0, cost_all), 4) for k in orders[1:]},
            "lower_bound_node_visits_per_occluded_ray": round(s["ideal_nodes_occ"] / max(1, s["occluded"]), 2),
            # what an order would save of ALL any-hit algorithmic bytes (rays that find nothing cost the same in every order)
-           "saving_of_all_any_hit_alg_bytes": {k: round((occ["ref"] - occ[k]) / max(1.0, all_b), 4) for k in ("far_first", "larger_area_first")},
+           "saving_of_all_any_hit_alg_bytes": {k: round((occ["ref"] - occ[k]) / max(1.0, all_b), 4) for k in orders[1:]},
            "saving_of_all_any_hit_node_visits_at_the_lower_bound": round((s["nodes_occ_ref"] - s["ideal_nodes_occ"]) / max(1, s["nodes_all"]), 4)}
     print(json.dumps(out))
 
