@@ -554,6 +554,19 @@ def test_full_size_c2_properties_and_sparse_parity(ob, gpu):
         err = rel_err_image(out.rgb[y, x][None], ref["rgb"][y, x][None]).max()
         assert err <= REL_TOL, (x, y, out.rgb[y, x], ref["rgb"][y, x])
         assert np.array_equal(out.film[y, x], ref["film"][y, x])
+    # The one-shot render above -- all a host of the reference ever does (Renderer.render once per task, dartray.dart:574) -- kept its
+    # batches at 2^27 slots: a workspace of about a third of the steady state's; rendering the scene AGAIN grows it to one batch per image
+    # (dr_scene_workspace_bytes; results do not depend on the batch size).
+    if not any(os.environ.get(k) for k in ("DARTRAY_BATCH_BITS", "DARTRAY_PILOT", "DARTRAY_TRACE_IMPL", "DARTRAY_STATE_LAYOUT")):
+        dev = scene._device()
+        info, first_ws = dev.last_render_info(), dev.workspace_bytes()
+        assert info["batches"] == 3 and info["pilot_batches"] in (3, 4) and st["batches"] >= 3
+        assert 15e9 < first_ws < 30e9, first_ws
+        out2 = r.render(scene)
+        assert np.array_equal(out2.film, out.film)
+        info2 = dev.last_render_info()
+        assert info2["batches"] == 1 and info2["pilot_batches"] == 0 and r.last_stats["batches"] == 1
+        assert 55e9 < dev.workspace_bytes() < 80e9 and dev.workspace_bytes() > 2.5 * first_ws
 
 
 def test_state_layout_is_chosen_from_the_pilot_batch_densities():
