@@ -22,8 +22,10 @@ workload: N = 1 -- configs[1] (C2): Cornell box + 1M-triangle displaced blob, Pa
           One "step" = one full pass of the hot path over the image.  Launch: `python bench.py --gpus N` starts
           the N ranks itself (torch.distributed.run, one process per GPU) unless it already runs under torchrun.
 Inputs (scene, BVH) are resident in HBM before the timed region; samples are generated on the device.  Synthetic
-procedural scene, no files.  The FIRST render of a scene allocates the path-state workspace and runs the library's
-traversal-kernel pilot: it is timed separately ("first_render_ms", "pilot_ms") and is not one of the W + K steps.
+procedural scene, no files.  The FIRST render of a scene allocates the path-state workspace (batches of 2^27 slots: what a one-shot
+host pays) and runs the library's traversal-kernel pilot: it is timed separately ("first_render_ms", "pilot_ms") and is not one of the
+W + K steps.  The SECOND render grows the workspace to one batch per image ("second_render_ms"): it is the first warm-up step.
+The printed line carries numbers only (< 8 000 bytes); the full result is written to the sidecar file the line names ("detail").
 
 Extra objects on the JSON line: "roofline" for the dominant kernel k_trace<0> (closest-hit BVH traversal):
 "achieved" = ALGORITHMIC bytes (32 B per node visit + 48 B per triangle test, counted on the device) / the kernel's
@@ -692,12 +694,14 @@ class Run:
         pilot_ms = self.dev.stats()["pilot_ms"]
         first_workspace = self.dev.workspace_bytes()
         # the SECOND render of a scene: the library kept the first one's batches at 2^27 slots (what a one-shot host pays for) and now grows the
-        # workspace to one batch per image -- the steady state of a frame loop; timed on its own, not one of the W + K steps either
+        # workspace to one batch per image -- the steady state of a frame loop; timed on its own.  It is the first of the W warm-up steps
+        # (an extra one when W = 0: the timed steps must run on the grown workspace), never one of the K timed steps.
         t0 = time.perf_counter()
         self.step()
         torch.cuda.synchronize()
         second_ms = (time.perf_counter() - t0) * 1e3
-        for _ in range(warmup):
+        warmup_left = max(0, warmup - 1)
+        for _ in range(warmup_left):
             self.step()
         torch.cuda.synchronize()
         self.dev.reset_stats()
