@@ -27,16 +27,15 @@ host pays) and runs the library's traversal-kernel pilot: it is timed separately
 W + K steps.  The SECOND render grows the workspace to one batch per image ("second_render_ms"): it is the first warm-up step.
 The printed line carries numbers only (< 8 000 bytes); the full result is written to the sidecar file the line names ("detail").
 
-Extra objects on the JSON line: "roofline" for the dominant kernel k_trace<0> (closest-hit BVH traversal):
-"achieved" = ALGORITHMIC bytes (32 B per node visit + 48 B per triangle test, counted on the device) / the kernel's
-summed HIP-event time, "frac" = that against the 8 TB/s spec.  Algorithmic bytes are mostly served by L1 / L2 / the
-Infinity Cache, so this figure can exceed what HBM could deliver ("alg_over_measured_copy" > 1 on the cache-resident
-scenes): the physical picture is next to it, from the committed rocprofv3 --pmc passes of the same command and
-labelled as such -- "physical_GBps" (L2-memory-side bytes per launch / launch time), "physical_frac_of_measured"
-(against this run's float4-copy rate) and "bound_observed"; "roofline_shade" likewise for k_shade_path; "cpu_baseline": the CPU oracle (a C++ port of
-the reference path) on one host core on a strided pixel subset; "cpu_baseline_threads": the same oracle, one OS thread
-per GetSubWindow task rectangle (the reference's isolate-per-task model); "extra_configs": short C4 and C5 runs
-(2 steps each, N = 1 only, after the headline's timed region) with their own roofline objects.
+Extra objects: "roofline" for the dominant kernel (the per-lane closest-hit BVH traversal): "achieved" = ALGORITHMIC bytes (32 B per
+node visit + 48 B per triangle test, counted on the device) / the kernel's summed HIP-event time, "frac" = that against the 8 TB/s
+spec.  Algorithmic bytes are mostly served by L1 / L2 / the Infinity Cache, so next to it, from the committed rocprofv3 --pmc passes
+of the same command AND ONLY when they were taken with the library that is running (kernel-source hashes; otherwise
+"stale_profile"): "traffic" (memory-side bytes per launch), "frac_physical_of_copy", "binding" / "frac_of_binding_ceiling" (the
+throughput ceilings); "roofline_others" likewise for the camera kernel, shading and the sampler; "cpu_baseline": the CPU oracle (a C++
+port of the reference path) on one host core on a strided pixel subset; "cpu_baseline_threads": the same oracle, one OS thread per
+GetSubWindow task rectangle (the reference's isolate-per-task model); "extra_configs": short C4 and C5 runs (2 steps each, N = 1
+only, after the headline's timed region).  Glossary of every key: profiles/README.md.
 """
 import argparse
 import json
