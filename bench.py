@@ -11,8 +11,8 @@ workload: N = 1 -- configs[1] (C2): Cornell box + 1M-triangle displaced blob, Pa
           the reference's task split, render_manager.dart:100-141), every rank accumulating a full-frame (X, Y, Z,
           weight) film and ONE RCCL reduce of the 268 MB film per step (dr_film_reduce of the C ABI: ncclReduce over
           xGMI) summing them on rank 0; total work is the same for every N ("scaling": "strong"), --steps / --warmup are
-          honoured as given.  Expected run time (one GPU renders C3 in 27.8 s per step, 617 Msamples/s: profiles/r05_c3_one_gpu.json): a step is
-          ~28.5 s / N -- N = 8: 3.6 s, N = 4: 7.1 s, N = 2: 14.3 s -- so the driver's `--steps 20 --warmup 5` (+ the first
+          honoured as given.  Expected run time (one GPU renders C3 in 27.6 s per step, 623 Msamples/s: profiles/r06_c3_one_gpu.json): a step is
+          ~28 s / N -- N = 8: 3.6 s, N = 4: 7.1 s, N = 2: 14.3 s -- so the driver's `--steps 20 --warmup 5` (+ the first
           render) is ~1.6 min at N = 8, ~3.1 min at N = 4 and ~6.2 min at N = 2, plus ~15 s of scene build per process.
           The same C2 scene per GPU as the N = 1 line is appended as "extra_configs"[0] ("scaling": "weak": the C2 view at
           256 spp on a square image with N x the pixels, side 1024 sqrt(N) in whole 32-pixel tiles, 2 timed steps of
