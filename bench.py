@@ -276,14 +276,18 @@ def roofline_objects(st, dt_total, copy_gbps, steps, closest_kernel="k_trace<0>"
     achieved = alg / max(lane_ms * 1e-3, 1e-12) / 1e9
     all_alg = alg_all_closest + 32.0 * st["any_nodes"] + 48.0 * st["any_tris"]
     pname, prof, fresh = profile if profile is not None else load_profile(tag)
-    usable = fresh and not kernels_forced_mismatch(prof, closest_kernel)
-    stale = None if (usable or not pname) else ("profiles/%s: %s" % (pname, "taken with another library (kernel sources differ)" if not fresh else "another traversal kernel was profiled"))
+    # (the passes profiled ONE closest-hit kernel: when this run's pilot picked the other of a near tie, the dominant kernel has no profile;
+    # shading, sampler and camera kernel are the same kernels either way)
+    usable = fresh
+    usable_dom = fresh and _find_kernel(prof, closest_kernel, exact=True) is not None
+    stale = None if (usable or not pname) else "profiles/%s: taken with another library (kernel sources differ)" % pname
+    stale_dom = stale if not usable else (None if usable_dom else "profiles/%s: another traversal kernel was profiled (%s)" % (pname, prof.get("kernel", "?").split("::")[-1]))
     roof = {"bound": "hbm", "kernel": closest_kernel, "achieved": round(achieved, 2), "peak": PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / PEAK_GBPS, 4), "saturated": bool(achieved / PEAK_GBPS > 1.0), "traffic": None,
             "hbm_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
             "alg_bytes_per_launch": round(alg / launches, 1), "avg_launch_ms": round(lane_ms / launches, 4), "launches": int(launches),
             "job_alg_GBps": round(all_alg / dt_total / 1e9, 2), "job_alg_GBps_without_camera_kernel": round((all_alg - alg_pk) / dt_total / 1e9, 2),
-            "trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt_total, 4), "stale_profile": stale}
+            "trace_share_of_time": round(st["trace_ms"] * 1e-3 / dt_total, 4), "stale_profile": stale_dom}
     sb = shade_alg_bytes(st)
     sa = sb / max(st["shade_ms"] * 1e-3, 1e-12) / 1e9
     shade = {"bound": "hbm", "kernel": "k_shade_path (+ k_env under an environment map)", "achieved": round(sa, 2), "peak": PEAK_GBPS, "unit": "GB/s",
@@ -306,11 +310,11 @@ def roofline_objects(st, dt_total, copy_gbps, steps, closest_kernel="k_trace<0>"
                "node_visits_per_ray": round(pk["nodes"] / max(1, pk["rays"]), 2), "stale_profile": stale}
     if usable:
         # the dominant kernel: memory-side bytes per launch, the observed bound, the ceilings
-        k = _find_kernel(prof, closest_kernel, exact=True)
+        k = _find_kernel(prof, closest_kernel, exact=True) if usable_dom else None
         if k:
             _attach_physical(roof, k, copy_gbps)
             roof["traffic"] = float(k["hbm_bytes_per_launch"]) if k.get("hbm_bytes_per_launch") else None
-            if prof.get("alg_bytes_per_launch") and roof["traffic"]:
+            if prof.get("alg_bytes_per_launch") and roof["traffic"] and not kernels_forced_mismatch(prof, closest_kernel):
                 roof["traffic_over_algorithmic"] = round(roof["traffic"] / prof["alg_bytes_per_launch"], 3)
                 scale = (alg / launches) / prof["alg_bytes_per_launch"]
                 extra = {}
