@@ -34,7 +34,7 @@ of the same command AND ONLY when they were taken with the library that is runni
 "stale_profile"): "traffic" (memory-side bytes per launch), "frac_physical_of_copy", "binding" / "frac_of_binding_ceiling" (the
 throughput ceilings); "roofline_others" likewise for the camera kernel, shading and the sampler; "cpu_baseline": the CPU oracle (a C++
 port of the reference path) on one host core on a strided pixel subset; "cpu_baseline_threads": the same oracle, one OS thread per
-GetSubWindow task rectangle (the reference's isolate-per-task model); "extra_configs": short C4 and C5 runs (2 steps each, N = 1
+GetSubWindow task rectangle (the reference's isolate-per-task model); "extra_configs": short C4 and C5 runs (3 steps each, N = 1
 only, after the headline's timed region).  Glossary of every key: profiles/README.md.
 """
 import argparse
@@ -89,7 +89,7 @@ def plan(world, scaling=None, config=None, res=0, spp=0, no_extra=False):
     extras = []
     default_shape = not (no_extra or config or res or spp)
     if world == 1 and default_shape:
-        extras = [("C4", 1024, 64, mode, 2, 1), ("C5", 2048, 512, mode, 2, 1)]
+        extras = [("C4", 1024, 64, mode, 3, 2), ("C5", 2048, 512, mode, 3, 2)]  # (three timed steps behind two warm-up steps: two were noisy, 252 - 268 on C4)
     elif world > 1 and default_shape and mode == "c3":
         extras = [("C2", weak_resolution(1024, world), 256, "weak", 2, 1)]
     return {"headline": (cfg, res_, spp_, mode), "extras": extras}
