@@ -586,29 +586,47 @@ int32_t dr_scene_sample_floats(const DrScene* scene, int32_t integrator) {
   return integrator == DR_INTEGRATOR_DIRECT_ALL ? scene->dlNFloats : dr_sample_floats(integrator, scene->d.nlights);  // ("all": the lights' nsamples decide)
 }
 
-int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
-  if (g_device < 0) return fail(DR_ERR_NO_DEVICE, "dr_init has not been called");
-  if (!desc || !out) return fail(DR_ERR_INVALID, "null argument");
-  if (desc->ntris > 0 && (!desc->nodes || !desc->verts || !desc->tri_idx || !desc->tri_material || !desc->tri_light ||
-                          !desc->tri_reverse || !desc->materials))
-    return fail(DR_ERR_INVALID, "scene arrays missing");
-  if (desc->ntris >= (1ull << 31) || desc->nnodes >= (1ull << 31)) return fail(DR_ERR_INVALID, "scene too large");
-  for (uint32_t i = 0; i < desc->nmaterials; ++i) {
-    if (desc->materials[i].type < DR_MATERIAL_MATTE || desc->materials[i].type > DR_MATERIAL_PLASTIC)
-      return fail(DR_ERR_INVALID, "unknown material type");
-  }
+// dr_scene_create in units (round 6): SceneBuilder carries what the steps share -- the host's description, the scene under construction, the
+// primitive tables on the device -- and every step returns DR_OK or the error it has already reported (dr_scene_create then deletes the scene).
+}  // extern "C"
+namespace {
+#define TRY_SC(expr)                                                             \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) return fail(DR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+struct SceneBuilder {
+  const DrSceneDesc* desc;
+  DrScene* sc;
+  bool hostPrep = false;           // DARTRAY_SCENE_PREP=host: the serial host loops (the reference the device code is tested against)
+  std::vector<uint8_t> level;      //   their per-node levels
+  uint32_t measuredDepth = 0;
+  DevBuf<float> dV;                // the primitive tables on the device (the device-side validation and the gather read them)
+  DevBuf<uint32_t> dI, dM;
+  DevBuf<int32_t> dL;
+  DevBuf<uint8_t> dR;
+
+  int validateOnHost();
+  int quadrics();
+  int uploadTables();
+  int pairsOnDevice();
+  int pairsOnHost();
+  int gatherPrimitives();
+  int shadingRecords();
+  int materials();
+  int lights();
+  int envLightTables(int envLight);
+  int finish();
+  int directLightingLayout();
+};
+
+int SceneBuilder::validateOnHost() {
   // Validation of the marshalled tree, independent of which kernels can use it: a foreign host's BVHAccel.nodes are
   // input, and a malformed node must come back as DR_ERR_INVALID, not as an out-of-bounds device read or an endless
   // traversal.  Children always have larger indices than their parent (first child i + 1, second child offset > i + 1:
   // the depth-first numbering of bvh_accel.dart:419-437), so every walk terminates, and one forward pass gives each
   // node's level: the height of the tree bounds the traversal stack (desc->bvh_depth == 0, "unknown", is measured here).
-  uint32_t measuredDepth = 0;
-  // k_trace addresses node i at byte offset i * 32 from a scalar base, in 32 bits (dr_trace.hip)
-  if (desc->nnodes > (1ull << 27)) return fail(DR_ERR_UNSUPPORTED, "more than 2^27 BVH nodes");
-  // Round 4: validation, height, pair records and the union check run on the device (dr_scene_prep.hip: C4 0.6 s -> 0.1 s).  The
-  // serial host loops below remain as the reference the device results are tested against (DARTRAY_SCENE_PREP=host).
-  const bool hostPrep = dr_opt("DARTRAY_SCENE_PREP").is("host");
-  std::vector<uint8_t> level(hostPrep ? desc->nnodes : 0, 0);
+  level.assign(hostPrep ? desc->nnodes : 0, 0);
   if (desc->nnodes && hostPrep) {
     const DrBvhNode* N = desc->nodes;
     for (uint64_t i = 0; i < desc->nnodes; ++i) {
@@ -633,20 +651,13 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     for (int k = 0; k < 3; ++k)
       if (desc->tri_idx[i + k] >= desc->nverts) return fail(DR_ERR_INVALID, "vertex index out of range");
   }
-  DrScene* sc = new DrScene();
-  memset(&sc->stats, 0, sizeof(sc->stats));
-  auto bail = [&](int code, const std::string& m) {
-    delete sc;
-    return fail(code, m);
-  };
-#define TRY_SC(expr)                                                             \
-  do {                                                                           \
-    hipError_t e_ = (expr);                                                      \
-    if (e_ != hipSuccess) return bail(DR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-  } while (0)
+  return DR_OK;
+}
+
+int SceneBuilder::quadrics() {
   // quadric shapes (sphere.dart:24-32, disk.dart:24-28): constructor-derived fields in f64
   for (uint32_t i = 0; i < desc->nquadrics; ++i) {
-    if (!desc->quadrics) return bail(DR_ERR_INVALID, "quadrics missing");
+    if (!desc->quadrics) return fail(DR_ERR_INVALID, "quadrics missing");
     const DrQuadric& a = desc->quadrics[i];
     DQuadric q;
     memset(&q, 0, sizeof(q));
@@ -657,7 +668,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       }
     for (int c = 0; c < 4; ++c)
       if (a.object_to_world[12 + c] != (c == 3 ? 1.0f : 0.0f) || a.world_to_object[12 + c] != (c == 3 ? 1.0f : 0.0f))
-        return bail(DR_ERR_UNSUPPORTED, "projective object transforms are not on the path");
+        return fail(DR_ERR_UNSUPPORTED, "projective object transforms are not on the path");
     auto clampd = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
     auto radians = [](double deg) { return (3.141592653589793 / 180.0) * deg; };  // common.dart:87-88
     q.kind = a.kind;
@@ -675,19 +686,19 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       q.innerRadius = a.params[2];
       q.phiMax = radians(clampd(a.params[3], 0.0, 360.0));
     } else {
-      return bail(DR_ERR_INVALID, "unknown quadric kind");
+      return fail(DR_ERR_INVALID, "unknown quadric kind");
     }
     sc->hostQuads.push_back(q);
   }
 
+  return DR_OK;
+}
+
+int SceneBuilder::uploadTables() {
   // nodes: the 32-byte marshalled node is consumed as two 16-byte loads
   TRY_SC(sc->nodes.alloc(2 * desc->nnodes));
   if (desc->nnodes) TRY_SC(hipMemcpy(sc->nodes.p, desc->nodes, desc->nnodes * sizeof(DrBvhNode), hipMemcpyHostToDevice));
   // the primitive tables (gathered into 48-byte records further down; the device-side validation reads them too)
-  DevBuf<float> dV;
-  DevBuf<uint32_t> dI, dM;
-  DevBuf<int32_t> dL;
-  DevBuf<uint8_t> dR;
   if (desc->ntris) {
     TRY_SC(dV.alloc(3 * std::max<uint64_t>(desc->nverts, 1)));
     TRY_SC(dI.alloc(3 * desc->ntris));
@@ -699,6 +710,10 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     TRY_SC(hipMemcpy(dM.p, desc->tri_material, desc->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
     TRY_SC(hipMemcpy(dL.p, desc->tri_light, desc->ntris * sizeof(int32_t), hipMemcpyHostToDevice));
   }
+  return DR_OK;
+}
+
+int SceneBuilder::pairsOnDevice() {
   // sibling-pair layout for the v3 traversal (see dr_device.h): children of the k-th interior node side by side
   sc->d.pairs = nullptr;
   sc->d.npairs = 0;
@@ -728,10 +743,10 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     }
     ScenePrepOut pout;
     const int prc = scene_prepare_device(pin, &pout);
-    if (prc != DR_OK) return bail(prc, pout.message);
+    if (prc != DR_OK) return fail(prc, pout.message);
     measuredDepth = pout.depth;
     if (desc->bvh_depth != 0 && desc->bvh_depth < measuredDepth)
-      return bail(DR_ERR_INVALID, "bvh_depth is smaller than the tree's height (pass 0 to have it measured)");
+      return fail(DR_ERR_INVALID, "bvh_depth is smaller than the tree's height (pass 0 to have it measured)");
     if (pout.pairsOk) {
       const DrBvhNode& r = desc->nodes[0];
       sc->d.pairs = sc->pairs.p;
@@ -748,6 +763,11 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
   }
   sc->bvhDepth = std::max(desc->bvh_depth, measuredDepth);  // (a caller may pass a bound larger than the height)
   if (desc->nnodes && sc->bvhDepth == 0) sc->bvhDepth = 1;  // a single leaf: "known, no stack needed"
+  return DR_OK;
+}
+
+// The serial reference of scene_prepare_device (DARTRAY_SCENE_PREP=host): pair records in the same memory order, the union check.
+int SceneBuilder::pairsOnHost() {
   if (desc->nnodes && hostPrep) {
     const DrBvhNode* N = desc->nodes;
     bool ok = desc->ntris < (1ull << 26) && desc->nquadrics == 0;  // only the v2 kernel tests quadrics
@@ -755,7 +775,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     uint32_t np = 0;
     for (uint64_t i = 0; i < desc->nnodes; ++i) {
       if (N[i].nprims == 0) {
-        if (i + 1 >= desc->nnodes || N[i].offset >= desc->nnodes || N[i].axis > 2) return bail(DR_ERR_INVALID, "malformed BVH node");
+        if (i + 1 >= desc->nnodes || N[i].offset >= desc->nnodes || N[i].axis > 2) return fail(DR_ERR_INVALID, "malformed BVH node");
         pairIndex[i] = np++;
       } else if (N[i].nprims > 31) {
         ok = false;  // packed references carry at most 31 primitives per leaf; fall back to the v2 kernel
@@ -794,7 +814,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
           hi[k] = std::max(a.bmax[k], b.bmax[k]);
         }
       } else {
-        if ((uint64_t)N[i].offset + N[i].nprims > desc->ntris) return bail(DR_ERR_INVALID, "leaf primitive range");
+        if ((uint64_t)N[i].offset + N[i].nprims > desc->ntris) return fail(DR_ERR_INVALID, "leaf primitive range");
         for (int k = 0; k < 3; ++k) {
           lo[k] = std::numeric_limits<float>::infinity();
           hi[k] = -lo[k];
@@ -802,7 +822,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         for (uint32_t t = 0; t < N[i].nprims; ++t)
           for (int v = 0; v < 3; ++v) {
             const uint32_t vi = desc->tri_idx[3 * ((uint64_t)N[i].offset + t) + v];
-            if (vi >= desc->nverts) return bail(DR_ERR_INVALID, "vertex index out of range");
+            if (vi >= desc->nverts) return fail(DR_ERR_INVALID, "vertex index out of range");
             for (int k = 0; k < 3; ++k) {
               lo[k] = std::min(lo[k], desc->verts[3 * (size_t)vi + k]);
               hi[k] = std::max(hi[k], desc->verts[3 * (size_t)vi + k]);
@@ -837,6 +857,10 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       }
     }
   }
+  return DR_OK;
+}
+
+int SceneBuilder::gatherPrimitives() {
   // primitives: gather vertices on the device
   TRY_SC(sc->tris.alloc(3 * desc->ntris));
   if (desc->ntris) {
@@ -847,22 +871,26 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     for (uint64_t i = 0; (desc->nquadrics || hostPrep) && i < desc->ntris; ++i) {
       if (desc->tri_idx[3 * i] == DR_PRIM_QUADRIC) {
         const uint32_t qi = desc->tri_idx[3 * i + 1];
-        if (qi >= desc->nquadrics) return bail(DR_ERR_INVALID, "quadric index out of range");
+        if (qi >= desc->nquadrics) return fail(DR_ERR_INVALID, "quadric index out of range");
         flags[i] |= (uint8_t)(sc->hostQuads[qi].kind << 1);
         sc->hostQuads[qi].reverse = desc->tri_reverse[i] ? 1 : 0;  // Shape.reverseOrientation of the primitive's shape
         continue;
       }
       for (int k = 0; k < 3; ++k)
-        if (desc->tri_idx[3 * i + k] >= desc->nverts) return bail(DR_ERR_INVALID, "vertex index out of range");
+        if (desc->tri_idx[3 * i + k] >= desc->nverts) return fail(DR_ERR_INVALID, "vertex index out of range");
     }
     for (uint64_t i = 0; hostPrep && i < desc->ntris; ++i) {
-      if (desc->tri_material[i] >= desc->nmaterials) return bail(DR_ERR_INVALID, "material index out of range");
-      if (desc->tri_light[i] >= (int32_t)desc->nlights) return bail(DR_ERR_INVALID, "light index out of range");
+      if (desc->tri_material[i] >= desc->nmaterials) return fail(DR_ERR_INVALID, "material index out of range");
+      if (desc->tri_light[i] >= (int32_t)desc->nlights) return fail(DR_ERR_INVALID, "light index out of range");
     }
     TRY_SC(hipMemcpy(dR.p, flags.data(), desc->ntris, hipMemcpyHostToDevice));
     launch_gather_tris(dV.p, dI.p, dM.p, dL.p, dR.p, sc->tris.p, desc->ntris, 0);
     TRY_SC(hipDeviceSynchronize());
   }
+  return DR_OK;
+}
+
+int SceneBuilder::shadingRecords() {
   // per-primitive shading records of meshes with N / S / uv (see ShadeRec in dr_device.h)
   sc->d.srec = nullptr;
   sc->d.xforms = nullptr;
@@ -875,14 +903,14 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       for (uint64_t i = 0; i < desc->ntris; ++i) {
         const uint32_t f = desc->tri_shading[i];
         if (!f || desc->tri_idx[3 * i] == DR_PRIM_QUADRIC) continue;
-        if (f > 7u) return bail(DR_ERR_INVALID, "unknown tri_shading bits");
+        if (f > 7u) return fail(DR_ERR_INVALID, "unknown tri_shading bits");
         if (((f & DR_SHADING_N) && !desc->vert_normals) || ((f & DR_SHADING_S) && !desc->vert_tangents) ||
             ((f & DR_SHADING_UV) && !desc->vert_uvs))
-          return bail(DR_ERR_INVALID, "tri_shading names an attribute whose vertex array is missing");
+          return fail(DR_ERR_INVALID, "tri_shading names an attribute whose vertex array is missing");
         uint32_t xf = 0;
         if (f & (DR_SHADING_N | DR_SHADING_S)) {
           if (!desc->tri_xform || !desc->mesh_xforms || desc->tri_xform[i] >= desc->nmesh_xforms)
-            return bail(DR_ERR_INVALID, "per-vertex normals / tangents need their mesh transform");
+            return fail(DR_ERR_INVALID, "per-vertex normals / tangents need their mesh transform");
           xf = desc->tri_xform[i];
         }
         float* r = &R[28 * (size_t)i];
@@ -914,6 +942,10 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
       sc->d.xforms = sc->xforms.p;
     }
   }
+  return DR_OK;
+}
+
+int SceneBuilder::materials() {
   // materials
   {
     // 4 x float4 per material: (Kd, -) (Kr, type) (Kt, -) (index, sigma: each double's low / high word)
@@ -932,6 +964,10 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     TRY_SC(sc->mats.alloc(m.size()));
     TRY_SC(hipMemcpy(sc->mats.p, m.data(), m.size() * sizeof(float4), hipMemcpyHostToDevice));
   }
+  return DR_OK;
+}
+
+int SceneBuilder::lights() {
   // lights: ShapeSet areas + Distribution1D (shape_set.dart:40-50; montecarlo.dart:25-52)
   {
     std::vector<DLight> L(std::max<uint32_t>(desc->nlights, 1));
@@ -941,8 +977,8 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     for (uint32_t i = 0; i < desc->nlights; ++i) {
       const DrAreaLight& a = desc->lights[i];
       if (a.kind == DR_LIGHT_INFINITE) {
-        if (a.env_index >= desc->nenv_maps || !desc->env_maps) return bail(DR_ERR_INVALID, "infinite light without a radiance map");
-        if (envLight >= 0) return bail(DR_ERR_UNSUPPORTED, "more than one infinite light");
+        if (a.env_index >= desc->nenv_maps || !desc->env_maps) return fail(DR_ERR_INVALID, "infinite light without a radiance map");
+        if (envLight >= 0) return fail(DR_ERR_UNSUPPORTED, "more than one infinite light");
         envLight = (int)i;
         DLight& d = L[i];
         d.L[0] = a.L[0]; d.L[1] = a.L[1]; d.L[2] = a.L[2];
@@ -973,8 +1009,8 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         sc->hasDeltaLight = true;
         continue;
       }
-      if (a.kind != DR_LIGHT_DIFFUSE_AREA) return bail(DR_ERR_INVALID, "unknown light kind");
-      if (a.ntris == 0 || (uint64_t)a.first_tri + a.ntris > desc->nlight_tris) return bail(DR_ERR_INVALID, "light triangle range");
+      if (a.kind != DR_LIGHT_DIFFUSE_AREA) return fail(DR_ERR_INVALID, "unknown light kind");
+      if (a.ntris == 0 || (uint64_t)a.first_tri + a.ntris > desc->nlight_tris) return fail(DR_ERR_INVALID, "light triangle range");
       DLight& d = L[i];
       d.L[0] = a.L[0]; d.L[1] = a.L[1]; d.L[2] = a.L[2];
       d.nsamples = std::max(1, a.nsamples);
@@ -988,7 +1024,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         const DrLightTri& lt = desc->light_tris[a.first_tri + t];
         DLightTri& o = LT[a.first_tri + t];
         if (lt.v[0] == DR_PRIM_QUADRIC) {
-          if (lt.v[1] >= desc->nquadrics) return bail(DR_ERR_INVALID, "light quadric index out of range");
+          if (lt.v[1] >= desc->nquadrics) return fail(DR_ERR_INVALID, "light quadric index out of range");
           const DQuadric& q = sc->hostQuads[lt.v[1]];
           memset(o.p, 0, sizeof(o.p));
           memcpy(&o.p[0], &lt.v[1], sizeof(uint32_t));
@@ -1014,7 +1050,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
           continue;
         }
         for (int k = 0; k < 3; ++k) {
-          if (lt.v[k] >= desc->nverts) return bail(DR_ERR_INVALID, "light vertex index out of range");
+          if (lt.v[k] >= desc->nverts) return fail(DR_ERR_INVALID, "light vertex index out of range");
           for (int c = 0; c < 3; ++c) o.p[3 * k + c] = desc->verts[3 * (size_t)lt.v[k] + c];
         }
         o.reverse = lt.reverse_orientation & 1u;
@@ -1022,7 +1058,7 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
         float luv[6];
         const bool hasUV = (lt.reverse_orientation & 2u) != 0;
         if (hasUV) {
-          if (!desc->vert_uvs) return bail(DR_ERR_INVALID, "light triangle with uvs but no vert_uvs");
+          if (!desc->vert_uvs) return fail(DR_ERR_INVALID, "light triangle with uvs but no vert_uvs");
           for (int k = 0; k < 3; ++k) {
             luv[2 * k] = desc->vert_uvs[2 * (size_t)lt.v[k]];
             luv[2 * k + 1] = desc->vert_uvs[2 * (size_t)lt.v[k] + 1];
@@ -1052,113 +1088,8 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     memset(&sc->d.env, 0, sizeof(sc->d.env));
     sc->d.hasEnv = 0;
     if (envLight >= 0) {
-      const DrAreaLight& a = desc->lights[envLight];
-      const DrEnvMap& m = desc->env_maps[a.env_index];
-      if (!m.texels || m.width <= 0 || m.height <= 0) return bail(DR_ERR_INVALID, "radiance map: null texels or empty size");
-      if (m.width > (1 << 14) || m.height > (1 << 14)) return bail(DR_ERR_UNSUPPORTED, "radiance map larger than 16384 texels a side");
-      // MIPMap.texture resamples an image whose width or height is no power of two up to the next one (mipmap.dart:71-138) before
-      // anything reads it; a host that hands over the decoded image (not a pyramid level) gets the same level 0 here
-      std::vector<float> resampled;
-      int w = m.width, h = m.height;
-      const float* texels = m.texels;
-      if ((w & (w - 1)) || (h & (h - 1))) {
-        resample_to_pow2(m.texels, w, h, resampled, &w, &h);
-        texels = resampled.data();
-      }
-      // _setRadianceMap (infinite_area_light.dart:283-307): img = luminance(_radiance(u/w, v/h, filter)) * sin(theta),
-      // filter = 1/max(w,h).  For a power-of-two map MIPMap.lookup's level = levels-1 + log2(filter) is 0 up to
-      // rounding (mipmap.dart:211): either `triangle(0,s,t)` directly or triangle(0)*(1-d) + triangle(1)*d with
-      // d ~ 1e-15, which rounds to the same f32 -- so the bilinear level-0 value is used.
-      std::vector<float> img((size_t)w * h);
-      auto texel = [&](int s, int t, int c) {
-        s %= w; if (s < 0) s += w;
-        t %= h; if (t < 0) t += h;
-        return (double)texels[3 * ((size_t)t * w + s) + c];
-      };
-      for (int v = 0; v < h; ++v) {
-        const double sinTheta = std::sin(3.141592653589793 * (v + 0.5) / h);
-        for (int u = 0; u < w; ++u) {
-          double s = ((double)u / w) * w - 0.5, t = ((double)v / h) * h - 0.5;
-          const int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
-          const double ds = s - s0, dt = t - t0;
-          double rgbv[3];
-          for (int c = 0; c < 3; ++c) {
-            double acc = r32(texel(s0, t0, c) * ((1.0 - ds) * (1.0 - dt)));
-            acc = r32(acc + r32(texel(s0, t0 + 1, c) * ((1.0 - ds) * dt)));
-            acc = r32(acc + r32(texel(s0 + 1, t0, c) * (ds * (1.0 - dt))));
-            acc = r32(acc + r32(texel(s0 + 1, t0 + 1, c) * (ds * dt)));
-            rgbv[c] = r32(acc * (double)a.L[c]);
-          }
-          float y = (float)(0.212671 * rgbv[0] + 0.715160 * rgbv[1] + 0.072169 * rgbv[2]);
-          img[u + (size_t)v * w] = (float)((double)y * sinTheta);
-        }
-      }
-      // Distribution2D (montecarlo.dart:223-237): one Distribution1D per row + the marginal over their integrals
-      auto dist1d = [](const float* f, int count, float* func, float* c, float* funcIntOut) {
-        for (int k = 0; k < count; ++k) func[k] = f[k];
-        c[0] = 0.0f;
-        for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)c[k - 1] + (double)func[k - 1] / (double)count);
-        const double funcInt = c[count];
-        if (funcInt == 0.0) {
-          for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)k / (double)count);
-        } else {
-          for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)c[k] / funcInt);
-        }
-        *funcIntOut = (float)funcInt;
-      };
-      std::vector<float> cf((size_t)w * h), cc((size_t)(w + 1) * h), ci(h), mf(h), mc(h + 1);
-      for (int v = 0; v < h; ++v) dist1d(&img[(size_t)v * w], w, &cf[(size_t)v * w], &cc[(size_t)v * (w + 1)], &ci[v]);
-      float mi = 0.f;
-      dist1d(ci.data(), h, mf.data(), mc.data(), &mi);
-      TRY_SC(sc->envTexels.alloc(3 * (size_t)w * h));
-      TRY_SC(hipMemcpy(sc->envTexels.p, texels, 3 * (size_t)w * h * sizeof(float), hipMemcpyHostToDevice));
-      TRY_SC(sc->envCondFunc.alloc(cf.size()));
-      TRY_SC(hipMemcpy(sc->envCondFunc.p, cf.data(), cf.size() * sizeof(float), hipMemcpyHostToDevice));
-      TRY_SC(sc->envCondCdf.alloc(cc.size()));
-      TRY_SC(hipMemcpy(sc->envCondCdf.p, cc.data(), cc.size() * sizeof(float), hipMemcpyHostToDevice));
-      TRY_SC(sc->envCondInt.alloc(ci.size()));
-      TRY_SC(hipMemcpy(sc->envCondInt.p, ci.data(), ci.size() * sizeof(float), hipMemcpyHostToDevice));
-      TRY_SC(sc->envMargFunc.alloc(mf.size()));
-      TRY_SC(hipMemcpy(sc->envMargFunc.p, mf.data(), mf.size() * sizeof(float), hipMemcpyHostToDevice));
-      TRY_SC(sc->envMargCdf.alloc(mc.size()));
-      TRY_SC(hipMemcpy(sc->envMargCdf.p, mc.data(), mc.size() * sizeof(float), hipMemcpyHostToDevice));
-      DEnv& e = sc->d.env;
-      // guide rows of the conditional CDFs (DEnv::condGuide): upper_bound at u = k / G, G = w / 4 (a power of two)
-      e.condGuide = nullptr;
-      e.guideN = 0;
-      if (w >= 16 && w + 1 <= 65535) {
-        const int G = w / 4;
-        std::vector<uint16_t> guide((size_t)h * (G + 1));
-        for (int v = 0; v < h; ++v) {
-          const float* c = &cc[(size_t)v * (w + 1)];
-          int i = 0;  // upper_bound is monotone in u: one sweep per row
-          for (int k = 0; k <= G; ++k) {
-            const double u = (double)k / (double)G;
-            while (i < w + 1 && !(u < (double)c[i])) ++i;
-            guide[(size_t)v * (G + 1) + k] = (uint16_t)i;
-          }
-        }
-        TRY_SC(sc->envCondGuide.alloc(guide.size()));
-        TRY_SC(hipMemcpy(sc->envCondGuide.p, guide.data(), guide.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        e.condGuide = sc->envCondGuide.p;
-        e.guideN = G;
-      }
-      e.texels = sc->envTexels.p;
-      e.condFunc = sc->envCondFunc.p;
-      e.condCdf = sc->envCondCdf.p;
-      e.condInt = sc->envCondInt.p;
-      e.margFunc = sc->envMargFunc.p;
-      e.margCdf = sc->envMargCdf.p;
-      e.margInt = mi;
-      e.w = w;
-      e.h = h;
-      for (int c = 0; c < 3; ++c) e.L[c] = a.L[c];
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) {
-          e.l2w[3 * r + c] = m.light_to_world[4 * r + c];
-          e.w2l[3 * r + c] = m.world_to_light[4 * r + c];
-        }
-      sc->d.hasEnv = 1;
+      const int erc = envLightTables(envLight);
+      if (erc) return erc;
     }
     TRY_SC(sc->lights.alloc(L.size()));
     TRY_SC(hipMemcpy(sc->lights.p, L.data(), L.size() * sizeof(DLight), hipMemcpyHostToDevice));
@@ -1167,6 +1098,123 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     TRY_SC(sc->lcdf.alloc(cdf.size()));
     TRY_SC(hipMemcpy(sc->lcdf.p, cdf.data(), cdf.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  return DR_OK;
+}
+
+// The InfiniteAreaLight's tables: the radiance map's level 0 (resampled like MIPMap.texture when its size is no power of two) and the
+// Distribution2D over luminance x sin(theta) (_setRadianceMap, infinite_area_light.dart:283-307).
+int SceneBuilder::envLightTables(int envLight) {
+    const DrAreaLight& a = desc->lights[envLight];
+    const DrEnvMap& m = desc->env_maps[a.env_index];
+    if (!m.texels || m.width <= 0 || m.height <= 0) return fail(DR_ERR_INVALID, "radiance map: null texels or empty size");
+    if (m.width > (1 << 14) || m.height > (1 << 14)) return fail(DR_ERR_UNSUPPORTED, "radiance map larger than 16384 texels a side");
+    // MIPMap.texture resamples an image whose width or height is no power of two up to the next one (mipmap.dart:71-138) before
+    // anything reads it; a host that hands over the decoded image (not a pyramid level) gets the same level 0 here
+    std::vector<float> resampled;
+    int w = m.width, h = m.height;
+    const float* texels = m.texels;
+    if ((w & (w - 1)) || (h & (h - 1))) {
+      resample_to_pow2(m.texels, w, h, resampled, &w, &h);
+      texels = resampled.data();
+    }
+    // _setRadianceMap (infinite_area_light.dart:283-307): img = luminance(_radiance(u/w, v/h, filter)) * sin(theta),
+    // filter = 1/max(w,h).  For a power-of-two map MIPMap.lookup's level = levels-1 + log2(filter) is 0 up to
+    // rounding (mipmap.dart:211): either `triangle(0,s,t)` directly or triangle(0)*(1-d) + triangle(1)*d with
+    // d ~ 1e-15, which rounds to the same f32 -- so the bilinear level-0 value is used.
+    std::vector<float> img((size_t)w * h);
+    auto texel = [&](int s, int t, int c) {
+      s %= w; if (s < 0) s += w;
+      t %= h; if (t < 0) t += h;
+      return (double)texels[3 * ((size_t)t * w + s) + c];
+    };
+    for (int v = 0; v < h; ++v) {
+      const double sinTheta = std::sin(3.141592653589793 * (v + 0.5) / h);
+      for (int u = 0; u < w; ++u) {
+        double s = ((double)u / w) * w - 0.5, t = ((double)v / h) * h - 0.5;
+        const int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
+        const double ds = s - s0, dt = t - t0;
+        double rgbv[3];
+        for (int c = 0; c < 3; ++c) {
+          double acc = r32(texel(s0, t0, c) * ((1.0 - ds) * (1.0 - dt)));
+          acc = r32(acc + r32(texel(s0, t0 + 1, c) * ((1.0 - ds) * dt)));
+          acc = r32(acc + r32(texel(s0 + 1, t0, c) * (ds * (1.0 - dt))));
+          acc = r32(acc + r32(texel(s0 + 1, t0 + 1, c) * (ds * dt)));
+          rgbv[c] = r32(acc * (double)a.L[c]);
+        }
+        float y = (float)(0.212671 * rgbv[0] + 0.715160 * rgbv[1] + 0.072169 * rgbv[2]);
+        img[u + (size_t)v * w] = (float)((double)y * sinTheta);
+      }
+    }
+    // Distribution2D (montecarlo.dart:223-237): one Distribution1D per row + the marginal over their integrals
+    auto dist1d = [](const float* f, int count, float* func, float* c, float* funcIntOut) {
+      for (int k = 0; k < count; ++k) func[k] = f[k];
+      c[0] = 0.0f;
+      for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)c[k - 1] + (double)func[k - 1] / (double)count);
+      const double funcInt = c[count];
+      if (funcInt == 0.0) {
+        for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)k / (double)count);
+      } else {
+        for (int k = 1; k < count + 1; ++k) c[k] = (float)((double)c[k] / funcInt);
+      }
+      *funcIntOut = (float)funcInt;
+    };
+    std::vector<float> cf((size_t)w * h), cc((size_t)(w + 1) * h), ci(h), mf(h), mc(h + 1);
+    for (int v = 0; v < h; ++v) dist1d(&img[(size_t)v * w], w, &cf[(size_t)v * w], &cc[(size_t)v * (w + 1)], &ci[v]);
+    float mi = 0.f;
+    dist1d(ci.data(), h, mf.data(), mc.data(), &mi);
+    TRY_SC(sc->envTexels.alloc(3 * (size_t)w * h));
+    TRY_SC(hipMemcpy(sc->envTexels.p, texels, 3 * (size_t)w * h * sizeof(float), hipMemcpyHostToDevice));
+    TRY_SC(sc->envCondFunc.alloc(cf.size()));
+    TRY_SC(hipMemcpy(sc->envCondFunc.p, cf.data(), cf.size() * sizeof(float), hipMemcpyHostToDevice));
+    TRY_SC(sc->envCondCdf.alloc(cc.size()));
+    TRY_SC(hipMemcpy(sc->envCondCdf.p, cc.data(), cc.size() * sizeof(float), hipMemcpyHostToDevice));
+    TRY_SC(sc->envCondInt.alloc(ci.size()));
+    TRY_SC(hipMemcpy(sc->envCondInt.p, ci.data(), ci.size() * sizeof(float), hipMemcpyHostToDevice));
+    TRY_SC(sc->envMargFunc.alloc(mf.size()));
+    TRY_SC(hipMemcpy(sc->envMargFunc.p, mf.data(), mf.size() * sizeof(float), hipMemcpyHostToDevice));
+    TRY_SC(sc->envMargCdf.alloc(mc.size()));
+    TRY_SC(hipMemcpy(sc->envMargCdf.p, mc.data(), mc.size() * sizeof(float), hipMemcpyHostToDevice));
+    DEnv& e = sc->d.env;
+    // guide rows of the conditional CDFs (DEnv::condGuide): upper_bound at u = k / G, G = w / 4 (a power of two)
+    e.condGuide = nullptr;
+    e.guideN = 0;
+    if (w >= 16 && w + 1 <= 65535) {
+      const int G = w / 4;
+      std::vector<uint16_t> guide((size_t)h * (G + 1));
+      for (int v = 0; v < h; ++v) {
+        const float* c = &cc[(size_t)v * (w + 1)];
+        int i = 0;  // upper_bound is monotone in u: one sweep per row
+        for (int k = 0; k <= G; ++k) {
+          const double u = (double)k / (double)G;
+          while (i < w + 1 && !(u < (double)c[i])) ++i;
+          guide[(size_t)v * (G + 1) + k] = (uint16_t)i;
+        }
+      }
+      TRY_SC(sc->envCondGuide.alloc(guide.size()));
+      TRY_SC(hipMemcpy(sc->envCondGuide.p, guide.data(), guide.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      e.condGuide = sc->envCondGuide.p;
+      e.guideN = G;
+    }
+    e.texels = sc->envTexels.p;
+    e.condFunc = sc->envCondFunc.p;
+    e.condCdf = sc->envCondCdf.p;
+    e.condInt = sc->envCondInt.p;
+    e.margFunc = sc->envMargFunc.p;
+    e.margCdf = sc->envMargCdf.p;
+    e.margInt = mi;
+    e.w = w;
+    e.h = h;
+    for (int c = 0; c < 3; ++c) e.L[c] = a.L[c];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        e.l2w[3 * r + c] = m.light_to_world[4 * r + c];
+        e.w2l[3 * r + c] = m.world_to_light[4 * r + c];
+      }
+    sc->d.hasEnv = 1;
+  return DR_OK;
+}
+
+int SceneBuilder::finish() {
   TRY_SC(sc->ctr.alloc(1));
   TRY_SC(hipMemset(sc->ctr.p, 0, sizeof(TraceCounters)));
   TRY_SC(sc->quads.alloc(std::max<size_t>(sc->hostQuads.size(), 1)));
@@ -1202,6 +1250,10 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     TRY_SC(hipDeviceSynchronize());
     sc->d.shtris = sc->shtris.p;
   }
+  return DR_OK;
+}
+
+int SceneBuilder::directLightingLayout() {
   {  // DirectLighting: one 1-D + one 2-D slot pair per light for the light sample and one for the BSDF sample, each
      // with roundSize(nSamples) entries (low_discrepancy_sampler.dart:43-49), then the two 1-D volume slots
     auto rp2 = [](int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; };
@@ -1250,11 +1302,46 @@ int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
     if (!stages.empty())
       TRY_SC(hipMemcpy(sc->dlStages.p, stages.data(), stages.size() * sizeof(DirectStage), hipMemcpyHostToDevice));
   }
-  sc->d.traceKernel[0] = sc->d.traceKernel[1] = 0;
-  sc->d.anyFarFirst = 0;
-  *out = sc;
   return DR_OK;
+}
 #undef TRY_SC
+}  // namespace
+extern "C" {
+
+int dr_scene_create(const DrSceneDesc* desc, DrScene** out) {
+  if (g_device < 0) return fail(DR_ERR_NO_DEVICE, "dr_init has not been called");
+  if (!desc || !out) return fail(DR_ERR_INVALID, "null argument");
+  if (desc->ntris > 0 && (!desc->nodes || !desc->verts || !desc->tri_idx || !desc->tri_material || !desc->tri_light ||
+                          !desc->tri_reverse || !desc->materials))
+    return fail(DR_ERR_INVALID, "scene arrays missing");
+  if (desc->ntris >= (1ull << 31) || desc->nnodes >= (1ull << 31)) return fail(DR_ERR_INVALID, "scene too large");
+  for (uint32_t i = 0; i < desc->nmaterials; ++i) {
+    if (desc->materials[i].type < DR_MATERIAL_MATTE || desc->materials[i].type > DR_MATERIAL_PLASTIC)
+      return fail(DR_ERR_INVALID, "unknown material type");
+  }
+  // k_trace addresses node i at byte offset i * 32 from a scalar base, in 32 bits (dr_trace.hip)
+  if (desc->nnodes > (1ull << 27)) return fail(DR_ERR_UNSUPPORTED, "more than 2^27 BVH nodes");
+  SceneBuilder B;
+  B.desc = desc;
+  B.sc = new DrScene();
+  memset(&B.sc->stats, 0, sizeof(B.sc->stats));
+  // Round 4: validation, height, pair records and the union check run on the device (dr_scene_prep.hip: C4 0.6 s -> 0.1 s).  The
+  // serial host loops remain as the reference the device results are tested against (DARTRAY_SCENE_PREP=host).
+  B.hostPrep = dr_opt("DARTRAY_SCENE_PREP").is("host");
+  int (SceneBuilder::*const steps[])() = {&SceneBuilder::validateOnHost, &SceneBuilder::quadrics, &SceneBuilder::uploadTables, &SceneBuilder::pairsOnDevice,
+                                          &SceneBuilder::pairsOnHost, &SceneBuilder::gatherPrimitives, &SceneBuilder::shadingRecords, &SceneBuilder::materials,
+                                          &SceneBuilder::lights, &SceneBuilder::finish, &SceneBuilder::directLightingLayout};
+  for (auto step : steps) {
+    const int rc = (B.*step)();
+    if (rc != DR_OK) {
+      delete B.sc;
+      return rc;
+    }
+  }
+  B.sc->d.traceKernel[0] = B.sc->d.traceKernel[1] = 0;
+  B.sc->d.anyFarFirst = 0;
+  *out = B.sc;
+  return DR_OK;
 }
 
 void dr_scene_destroy(DrScene* scene) { delete scene; }
