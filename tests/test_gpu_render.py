@@ -340,6 +340,14 @@ def test_any_hit_rays_far_child_first(ob, gpu, kernels):
     scene = scenes.make_scene(prims)
     dev = scene._device()
     assert dev.trace_kernels(kernels) == kernels
+    _abi.check(_abi.lib().dr_set_option(b"TRACE_IMPL", b""))  # ("" hides the environment's value: the suite is also run with DARTRAY_TRACE_IMPL=5)
+    try:
+        _far_child_first_checks(ob, prims, r, scene, dev, kernels)
+    finally:
+        _abi.check(_abi.lib().dr_set_option(b"TRACE_IMPL", None))
+
+
+def _far_child_first_checks(ob, prims, r, scene, dev, kernels):
     out = r.render(scene)
     info = dev.last_render_info()
     assert (info["closest_kernel"], info["any_hit_kernel"]) == kernels, info
